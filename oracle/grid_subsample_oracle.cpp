@@ -1,0 +1,100 @@
+// TEST INFRASTRUCTURE ONLY -- the product path never imports, links or calls this.
+//
+// CPU restatement of the reference's voxel-grid barycentre subsampling
+//   geotransformer/extensions/cpu/grid_subsampling/grid_subsampling_cpu.cpp:3-48  (one cloud)
+//   geotransformer/extensions/cpu/grid_subsampling/grid_subsampling_cpu.cpp:50-75 (stack-mode batch)
+//   geotransformer/extensions/cpu/grid_subsampling/grid_subsampling_cpu.h:7-21    (SampledData)
+//   geotransformer/extensions/extra/cloud/cloud.cpp:4-37                           (min/max corner)
+// following SURVEY.md App. A.1 step by step.  Written against flat float arrays
+// (no PointXYZ class); the only thing shared with the reference is the C++
+// standard library container whose ITERATION ORDER defines the output order
+// (grid_subsampling_cpu.cpp:44-47): std::unordered_map<size_t, ...>.
+//
+// Pinned against tests/golden/ext_*.npz (outputs of the reference itself).
+//
+// Build: g++ -O2 -ffp-contract=off -fPIC -shared (oracle/Makefile); no -march=native.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+struct Cell {
+  int count = 0;           // grid_subsampling_cpu.h:9
+  float sx = 0, sy = 0, sz = 0;  // grid_subsampling_cpu.h:10 (PointXYZ() == 0,0,0)
+};
+
+// One cloud; appends barycentres to `out` in hash-map iteration order.
+void subsample_one(const float* p, int64_t n, float v, std::vector<float>& out) {
+  if (n <= 0) return;  // (the reference would read points[0]; undefined there)
+  // cloud.cpp:4-37: component-wise min / max
+  float mnx = p[0], mny = p[1], mnz = p[2], mxx = p[0], mxy = p[1], mxz = p[2];
+  for (int64_t i = 0; i < n; ++i) {
+    const float x = p[3 * i], y = p[3 * i + 1], z = p[3 * i + 2];
+    if (x < mnx) mnx = x;
+    if (y < mny) mny = y;
+    if (z < mnz) mnz = z;
+    if (x > mxx) mxx = x;
+    if (y > mxy) mxy = y;
+    if (z > mxz) mxz = z;
+  }
+  // grid_subsampling_cpu.cpp:11 -- `minCorner * (1. / voxel_size)`: the double quotient
+  // is narrowed to float by operator*(PointXYZ, const float) (cloud.h:84-86); then
+  // floor (cloud.h:100-102) and a float multiply by voxel_size.
+  const float inv = static_cast<float>(1.0 / static_cast<double>(v));
+  const float ox = std::floor(mnx * inv) * v;
+  const float oy = std::floor(mny * inv) * v;
+  const float oz = std::floor(mnz * inv) * v;
+  // grid_subsampling_cpu.cpp:13-20 -- fp32 subtract and fp32 divide, floor, +1
+  const std::size_t NX = static_cast<std::size_t>(std::floor((mxx - ox) / v) + 1);
+  const std::size_t NY = static_cast<std::size_t>(std::floor((mxy - oy) / v) + 1);
+
+  std::unordered_map<std::size_t, Cell> cells;
+  for (int64_t i = 0; i < n; ++i) {
+    const float x = p[3 * i], y = p[3 * i + 1], z = p[3 * i + 2];
+    // grid_subsampling_cpu.cpp:32-35
+    const std::size_t iX = static_cast<std::size_t>(std::floor((x - ox) / v));
+    const std::size_t iY = static_cast<std::size_t>(std::floor((y - oy) / v));
+    const std::size_t iZ = static_cast<std::size_t>(std::floor((z - oz) / v));
+    const std::size_t key = iX + NX * iY + NX * NY * iZ;
+    Cell& c = cells[key];  // :37-41 (count/emplace/operator[] collapse to one lookup)
+    c.count += 1;          // grid_subsampling_cpu.h:17-20: sequential fp32 sums, input order
+    c.sx += x;
+    c.sy += y;
+    c.sz += z;
+  }
+  // grid_subsampling_cpu.cpp:44-47 -- point * (1.0 / count): double reciprocal narrowed
+  // to float, then three fp32 multiplies; emitted in the map's iteration order.
+  for (const auto& kv : cells) {
+    const float w = static_cast<float>(1.0 / static_cast<double>(kv.second.count));
+    out.push_back(kv.second.sx * w);
+    out.push_back(kv.second.sy * w);
+    out.push_back(kv.second.sz * w);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// out_points: capacity 3*n floats.  Returns total M; out_lengths[b] = m_b
+// (grid_subsampling_cpu.cpp:59-72).
+int64_t oracle_grid_subsampling(const float* pts, int64_t n, const int64_t* lengths, int64_t batch,
+                                float voxel, float* out_points, int64_t* out_lengths) {
+  std::vector<float> out;
+  out.reserve(static_cast<size_t>(n) * 3);
+  int64_t start = 0;
+  for (int64_t b = 0; b < batch; ++b) {
+    const size_t before = out.size() / 3;
+    subsample_one(pts + 3 * start, lengths[b], voxel, out);
+    out_lengths[b] = static_cast<int64_t>(out.size() / 3 - before);
+    start += lengths[b];
+  }
+  (void)n;
+  std::memcpy(out_points, out.data(), sizeof(float) * out.size());
+  return static_cast<int64_t>(out.size() / 3);
+}
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+"""Shared test helpers (CPU + GPU tests)."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name)))
+
+
+def c1_points():
+    """BASELINE config C1 inputs: torch.manual_seed(0); torch.rand(20000, 3)."""
+    import torch
+    g = torch.Generator().manual_seed(0)
+    return torch.rand(20000, 3, generator=g).numpy()
+
+
+def sqdist_f32(q, s):
+    """The reference metric (nanoflann.hpp:432-440) in numpy fp32: ((dx*dx + dy*dy) + dz*dz)."""
+    d = q.astype(np.float32) - s.astype(np.float32)
+    d2 = d * d
+    return (d2[..., 0] + d2[..., 1]) + d2[..., 2]
+
+
+def assert_neighbors_equal_up_to_ties(got, want, q, s, q_lengths, s_lengths):
+    """Rows must be identical except inside runs of EQUAL fp32 distance, where the reference's
+    order depends on its kd-tree traversal: those runs compare as sets."""
+    got = np.asarray(got).astype(np.int64)
+    want = np.asarray(want).astype(np.int64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    if np.array_equal(got, want):
+        return 0
+    pad = s.shape[0]
+    bad_rows = np.nonzero((got != want).any(axis=1))[0]
+    q_start = np.concatenate([[0], np.cumsum(q_lengths)])
+    n_tie_rows = 0
+    for r in bad_rows:
+        g, w = got[r], want[r]
+        assert ((g == pad) == (w == pad)).all(), f"row {r}: different neighbour count"
+        k = int((w != pad).sum())
+        dg = sqdist_f32(q[r][None, :], s[g[:k]])
+        dw = sqdist_f32(q[r][None, :], s[w[:k]])
+        assert np.array_equal(dg, dw), f"row {r}: distance sequences differ"
+        # group by distance run and compare as sets
+        i = 0
+        while i < k:
+            j = i
+            while j + 1 < k and dw[j + 1] == dw[i]:
+                j += 1
+            assert set(g[i:j + 1]) == set(w[i:j + 1]), f"row {r}: tie group differs"
+            i = j + 1
+        n_tie_rows += 1
+    return n_tie_rows
