@@ -1,0 +1,92 @@
+"""ctypes binding of libgaussreg_hip.so (include/gaussreg_hip.h).  Fails loudly."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgaussreg_hip.so")
+
+_lib = None
+
+c_void = ctypes.c_void_p
+c_i64 = ctypes.c_int64
+c_f32 = ctypes.c_float
+c_int = ctypes.c_int
+c_size = ctypes.c_size_t
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+
+# name -> (restype, argtypes); must list every symbol include/gaussreg_hip.h declares
+SIGNATURES = {
+    "gr_last_error": (ctypes.c_char_p, []),
+    "gr_version": (c_int, []),
+    "gr_radius_workspace_bytes": (c_size, [c_i64, c_i64, c_i64]),
+    "gr_radius_count": (c_int, [c_void, c_void, c_i64p, c_i64p, c_i64, c_i64, c_i64, c_f32, c_void, c_size,
+                                c_i64p, c_void]),
+    "gr_radius_fill": (c_int, [c_void, c_void, c_i64, c_i64, c_i64, c_f32, c_i64, c_i64p, c_void, c_void,
+                               c_size, c_void]),
+    "gr_grid_subsample_workspace_bytes": (c_size, [c_i64, c_i64]),
+    "gr_grid_subsample": (c_int, [c_void, c_i64p, c_i64, c_i64, c_f32, c_int, c_void, c_i64p, c_i64p, c_void,
+                                  c_size, c_void]),
+}
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library; raise (never fall back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                f"{LIB_PATH} is missing: build it with `python -m gaussreg_amd.build` "
+                "(there is no CPU fallback for the gaussreg_amd ops)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().gr_last_error()
+        raise RuntimeError("gaussreg_hip: " + (msg.decode() if msg else f"error {rc}"))
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise HipLibraryError("gaussreg_amd ops need an MI355X (torch.cuda.is_available() is False); "
+                              "there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+_ws_cache = {}
+
+
+def workspace(device, nbytes):
+    """Grow-only per-device scratch buffer (torch caching allocator owns the memory)."""
+    import torch
+    key = (device.type, device.index)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def stream_ptr(device):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def host_i64(values):
+    arr = (ctypes.c_int64 * max(len(values), 1))(*[int(v) for v in values])
+    return arr

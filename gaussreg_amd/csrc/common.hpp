@@ -1,0 +1,103 @@
+// Shared host/device helpers for libgaussreg_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/gaussreg_hip.h"
+
+namespace gr {
+
+constexpr int WAVE = 64;
+
+void set_error(const char* fmt, ...);
+
+#define GR_HIP(call)                                                                       \
+  do {                                                                                     \
+    hipError_t _e = (call);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      gr::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return GR_ERR_HIP;                                                                   \
+    }                                                                                      \
+  } while (0)
+
+#define GR_REQUIRE(cond, ...)       \
+  do {                              \
+    if (!(cond)) {                  \
+      gr::set_error(__VA_ARGS__);   \
+      return GR_ERR_INVALID;        \
+    }                               \
+  } while (0)
+
+#define GR_LAUNCH_CHECK() GR_HIP(hipGetLastError())
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Bump allocator over a caller-provided workspace (256-B aligned carves).
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+  template <typename T>
+  T* take(size_t count) {
+    off = align_up(off, 256);
+    T* r = reinterpret_cast<T*>(base ? base + off : nullptr);
+    off += sizeof(T) * count;
+    return r;
+  }
+  size_t used() const { return align_up(off, 256); }
+};
+
+// Order-preserving float <-> uint map (for atomicMin/Max on floats).
+__host__ __device__ inline uint32_t f2ord(float f) {
+  uint32_t u;
+#ifdef __HIP_DEVICE_COMPILE__
+  u = __float_as_uint(f);
+#else
+  memcpy(&u, &f, 4);
+#endif
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float ord2f(uint32_t o) {
+  uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  float f;
+#ifdef __HIP_DEVICE_COMPILE__
+  f = __uint_as_float(u);
+#else
+  memcpy(&f, &u, 4);
+#endif
+  return f;
+}
+
+// ---- exclusive scan of int32 arrays (rows of equal length), 3 small launches ----------------
+// scan_ws needs scan_ws_ints(n) int32 per row.
+size_t scan_ws_ints(int64_t n);
+// in/out may alias.  out[i] = sum_{j<i} in[j]; total[r] (optional, device) = row sum.
+int exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int rows, int64_t row_stride,
+                       int32_t* scan_ws, int32_t* total, hipStream_t stream);
+
+// Per-cloud bounding boxes of stacked points: bbox_dev[b*6 + {0,1,2}] = min xyz, +{3,4,5} = max xyz,
+// stored as order-preserving uints (decode with ord2f).  Empty clouds keep (0xffffffff, 0).
+int compute_bbox(const float* pts, int n, const int32_t* off_dev, int nb, uint32_t* bbox_dev,
+                 hipStream_t stream);
+
+// Stable LSD radix sort of (u64 key, i32 value) pairs on bits [begin_bit, end_bit) (rocPRIM).
+size_t sort_pairs_temp_bytes(int64_t n);
+int sort_pairs_u64_i32(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out,
+                       const int32_t* vals_in, int32_t* vals_out, int64_t n, int begin_bit,
+                       int end_bit, hipStream_t stream);
+
+// lower_bound over a small ascending int32 offsets table: largest b with off[b] <= i (b < nb)
+__device__ inline int find_batch(const int32_t* __restrict__ off, int nb, int32_t i) {
+  int lo = 0, hi = nb;  // off has nb+1 entries
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (off[mid] <= i) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+}  // namespace gr

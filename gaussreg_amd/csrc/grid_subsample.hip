@@ -1,0 +1,380 @@
+// Voxel-grid barycentre subsampling on MI355X, bit-identical to the reference.
+//
+// Replaces  geotransformer/extensions/cpu/grid_subsampling/grid_subsampling_cpu.cpp:3-75
+// (std::unordered_map voxel hashing, single thread) with:
+//   bbox      per-cloud min/max corner                      (cloud.cpp:4-37)
+//   [host]    origin / NX / NY per cloud, same fp32 expressions as :11-20 (B clouds -> trivial)
+//   keys      key = iX + NX*iY + NX*NY*iZ per point          (:32-35), composite (cloud, key)
+//   sort      stable radix sort of (key, point index)  -> points of one voxel are contiguous and
+//             in INPUT ORDER, which is what makes the fp32 sums reproducible
+//   cells     one thread per voxel run: sequential fp32 accumulate in input order
+//             (grid_subsampling_cpu.h:17-20), barycentre = sum * float(1.0 / count)  (:46)
+//   order     GR_ORDER_CELL: emit in (cloud, key) order.
+//             GR_ORDER_REFERENCE: rank voxels by first occurrence, replay those keys through a
+//             real std::unordered_map<size_t,int> on the host (the container whose iteration
+//             order IS the reference's output order, :44-47) and gather by that permutation.
+// Compiled with -ffp-contract=off.
+#include <cmath>
+#include <unordered_map>
+#include <vector>
+
+#include "common.hpp"
+
+namespace gr {
+namespace {
+
+struct CloudGrid {
+  float ox, oy, oz, v;
+  unsigned long long nx, nxny;
+};
+
+struct GridWs {
+  int32_t* off;         // [B+1]
+  uint32_t* bbox;       // [B*6]
+  CloudGrid* grids;     // [B]
+  uint64_t* keys_a;     // [N]
+  uint64_t* keys_b;     // [N]
+  int32_t* vals_a;      // [N]
+  int32_t* vals_b;      // [N]
+  int32_t* flags;       // [N]  head flags, then reused
+  int32_t* scan;        // [N]
+  int32_t* scan_ws;     // scan scratch
+  int32_t* totals;      // [2]
+  float* bary;          // [N*3] (cell order)
+  int32_t* first_idx;   // [N]
+  uint64_t* cell_key;   // [N]  raw voxel key per cell
+  int32_t* cell_batch;  // [N]
+  int32_t* m_b;         // [B]
+  int32_t* cell_of_rank;  // [N]
+  uint64_t* keys_fo;    // [N]  keys in first-occurrence order
+  int32_t* perm;        // [N]
+  void* sort_temp;
+  size_t sort_temp_bytes;
+  size_t bytes;
+};
+
+GridWs carve(void* ws, int64_t n, int64_t batch) {
+  GridWs w;
+  Carver c(ws);
+  w.off = c.take<int32_t>(batch + 1);
+  w.bbox = c.take<uint32_t>(batch * 6);
+  w.grids = c.take<CloudGrid>(batch);
+  w.keys_a = c.take<uint64_t>(n);
+  w.keys_b = c.take<uint64_t>(n);
+  w.vals_a = c.take<int32_t>(n);
+  w.vals_b = c.take<int32_t>(n);
+  w.flags = c.take<int32_t>(n);
+  w.scan = c.take<int32_t>(n);
+  w.scan_ws = c.take<int32_t>(scan_ws_ints(n));
+  w.totals = c.take<int32_t>(2);
+  w.bary = c.take<float>(3 * n);
+  w.first_idx = c.take<int32_t>(n);
+  w.cell_key = c.take<uint64_t>(n);
+  w.cell_batch = c.take<int32_t>(n);
+  w.m_b = c.take<int32_t>(batch);
+  w.cell_of_rank = c.take<int32_t>(n);
+  w.keys_fo = c.take<uint64_t>(n);
+  w.perm = c.take<int32_t>(n);
+  w.sort_temp_bytes = sort_pairs_temp_bytes(n);
+  w.sort_temp = c.take<char>(w.sort_temp_bytes);
+  w.bytes = c.used();
+  return w;
+}
+
+// (size_t)floor(x) as g++ emits it on x86-64 for in-range and slightly negative values:
+// signed truncation, then reinterpret (grid_subsampling_cpu.cpp:32-34 static_cast<size_t>)
+__host__ __device__ inline unsigned long long to_size_t(double f) {
+  return (unsigned long long)(long long)f;
+}
+
+__global__ __launch_bounds__(256) void keys_kernel(const float* __restrict__ pts, int n,
+                                                   const int32_t* __restrict__ off, int nb,
+                                                   const CloudGrid* __restrict__ grids,
+                                                   int key_bits, uint64_t* __restrict__ keys,
+                                                   int32_t* __restrict__ vals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = find_batch(off, nb, i);
+  const CloudGrid g = grids[b];
+  const float x = pts[3 * (int64_t)i], y = pts[3 * (int64_t)i + 1], z = pts[3 * (int64_t)i + 2];
+  // grid_subsampling_cpu.cpp:32-35: fp32 subtract, fp32 divide, floor
+  const unsigned long long ix = to_size_t(floor((double)((x - g.ox) / g.v)));
+  const unsigned long long iy = to_size_t(floor((double)((y - g.oy) / g.v)));
+  const unsigned long long iz = to_size_t(floor((double)((z - g.oz) / g.v)));
+  unsigned long long key = ix + g.nx * iy + g.nxny * iz;
+  if (key_bits < 64) key |= (unsigned long long)b << key_bits;  // composite (cloud, key)
+  keys[i] = key;
+  vals[i] = i;
+}
+
+// keys (without the cloud id) for points listed in `vals` order
+__global__ __launch_bounds__(256) void regather_keys_kernel(const float* __restrict__ pts,
+                                                            const int32_t* __restrict__ vals, int n,
+                                                            const int32_t* __restrict__ off, int nb,
+                                                            const CloudGrid* __restrict__ grids,
+                                                            uint64_t* __restrict__ keys) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int64_t i = vals[t];
+  const CloudGrid g = grids[find_batch(off, nb, (int)i)];
+  const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+  const unsigned long long ix = to_size_t(floor((double)((x - g.ox) / g.v)));
+  const unsigned long long iy = to_size_t(floor((double)((y - g.oy) / g.v)));
+  const unsigned long long iz = to_size_t(floor((double)((z - g.oz) / g.v)));
+  keys[t] = ix + g.nx * iy + g.nxny * iz;
+}
+
+__global__ __launch_bounds__(256) void batch_keys_kernel(const int32_t* __restrict__ vals, int n,
+                                                         const int32_t* __restrict__ off, int nb,
+                                                         uint64_t* __restrict__ bkeys) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) bkeys[t] = (uint64_t)find_batch(off, nb, vals[t]);
+}
+
+// head[t] = 1 where a new (cloud, voxel) run starts in sorted order
+__global__ __launch_bounds__(256) void heads_kernel(const uint64_t* __restrict__ keys,
+                                                    const int32_t* __restrict__ vals, int n,
+                                                    const int32_t* __restrict__ off, int nb,
+                                                    int composite, int32_t* __restrict__ head) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  int h = 1;
+  if (t > 0) {
+    h = keys[t] != keys[t - 1];
+    if (!h && !composite) h = find_batch(off, nb, vals[t]) != find_batch(off, nb, vals[t - 1]);
+  }
+  head[t] = h;
+}
+
+// one thread per run head: sequential fp32 sums in input order (stable sort => ascending index)
+__global__ __launch_bounds__(256) void cells_kernel(
+    const float* __restrict__ pts, const uint64_t* __restrict__ keys,
+    const int32_t* __restrict__ vals, const int32_t* __restrict__ head,
+    const int32_t* __restrict__ head_scan, int n, const int32_t* __restrict__ off, int nb,
+    int key_bits, float* __restrict__ bary, int32_t* __restrict__ first_idx,
+    uint64_t* __restrict__ cell_key, int32_t* __restrict__ cell_batch, int32_t* __restrict__ m_b,
+    int32_t* __restrict__ fo_flags) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n || !head[t]) return;
+  const int cell = head_scan[t];  // exclusive scan of head == index of this run
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  int count = 0;
+  int u = t;
+  do {
+    const int64_t i = vals[u];
+    sx += pts[3 * i];
+    sy += pts[3 * i + 1];
+    sz += pts[3 * i + 2];
+    ++count;
+    ++u;
+  } while (u < n && !head[u]);
+  // grid_subsampling_cpu.cpp:46: point * (1.0 / count) -- double reciprocal narrowed to float
+  const float wgt = (float)(1.0 / (double)count);
+  bary[3 * (int64_t)cell] = sx * wgt;
+  bary[3 * (int64_t)cell + 1] = sy * wgt;
+  bary[3 * (int64_t)cell + 2] = sz * wgt;
+  const int first = vals[t];
+  first_idx[cell] = first;
+  const int b = find_batch(off, nb, first);
+  cell_batch[cell] = b;
+  const unsigned long long k = keys[t];
+  cell_key[cell] = key_bits < 64 ? (k & ((1ull << key_bits) - 1ull)) : k;
+  atomicAdd(&m_b[b], 1);
+  fo_flags[first] = 1;
+}
+
+__global__ __launch_bounds__(256) void copy_cells_kernel(const float* __restrict__ bary, int m,
+                                                         float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 3 * m) out[i] = bary[i];
+}
+
+// rank cells by first occurrence: rank = (#cells whose first point index is smaller)
+__global__ __launch_bounds__(256) void fo_rank_kernel(const int32_t* __restrict__ first_idx,
+                                                      const uint64_t* __restrict__ cell_key,
+                                                      const int32_t* __restrict__ fo_scan, int m,
+                                                      int32_t* __restrict__ cell_of_rank,
+                                                      uint64_t* __restrict__ keys_fo) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= m) return;
+  const int r = fo_scan[first_idx[c]];
+  cell_of_rank[r] = c;
+  keys_fo[r] = cell_key[c];
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ bary,
+                                                     const int32_t* __restrict__ cell_of_rank,
+                                                     const int32_t* __restrict__ perm, int m,
+                                                     float* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const int c = cell_of_rank[perm[j]];
+  out[3 * (int64_t)j] = bary[3 * (int64_t)c];
+  out[3 * (int64_t)j + 1] = bary[3 * (int64_t)c + 1];
+  out[3 * (int64_t)j + 2] = bary[3 * (int64_t)c + 2];
+}
+
+inline int bits_for(unsigned long long v) {  // bits needed to represent values in [0, v)
+  int b = 0;
+  while (b < 64 && (1ull << b) < v) ++b;
+  return b;
+}
+
+}  // namespace
+}  // namespace gr
+
+using namespace gr;
+
+extern "C" size_t gr_grid_subsample_workspace_bytes(int64_t n, int64_t batch) {
+  if (n < 0 || batch < 0) return 0;
+  return carve(nullptr, n, batch).bytes;
+}
+
+extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, int64_t n,
+                                 int64_t batch, float voxel, int order_mode, float* out_points,
+                                 int64_t* h_out_lengths, int64_t* h_total_m, void* ws,
+                                 size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GR_REQUIRE(h_total_m && (batch == 0 || (h_lengths && h_out_lengths)), "null host pointer");
+  *h_total_m = 0;
+  GR_REQUIRE(n >= 0 && batch >= 0 && n < (1ll << 31) - 1 && batch < (1 << 20), "bad sizes");
+  GR_REQUIRE(order_mode == GR_ORDER_REFERENCE || order_mode == GR_ORDER_CELL, "bad order_mode %d", order_mode);
+  GR_REQUIRE(voxel > 0.0f && std::isfinite(voxel), "voxel_size must be positive and finite");
+  int64_t sum = 0;
+  for (int64_t b = 0; b < batch; ++b) {
+    GR_REQUIRE(h_lengths[b] >= 0, "negative length");
+    sum += h_lengths[b];
+    h_out_lengths[b] = 0;
+  }
+  GR_REQUIRE(sum == n, "lengths sum to %lld, expected %lld", (long long)sum, (long long)n);
+  if (n == 0) return GR_OK;
+  GridWs w = carve(ws, n, batch);
+  if (!ws || ws_bytes < w.bytes) {
+    set_error("grid_subsample workspace too small: need %zu bytes, got %zu", w.bytes, ws_bytes);
+    return GR_ERR_WORKSPACE;
+  }
+  const int nb = (int)batch;
+  std::vector<int32_t> off(batch + 1, 0);
+  for (int64_t b = 0; b < batch; ++b) off[b + 1] = off[b] + (int32_t)h_lengths[b];
+  GR_HIP(hipMemcpyAsync(w.off, off.data(), sizeof(int32_t) * (batch + 1), hipMemcpyHostToDevice, stream));
+  int rc = compute_bbox(points, (int)n, w.off, nb, w.bbox, stream);
+  if (rc != GR_OK) return rc;
+  std::vector<uint32_t> hb(batch * 6);
+  GR_HIP(hipMemcpyAsync(hb.data(), w.bbox, sizeof(uint32_t) * batch * 6, hipMemcpyDeviceToHost, stream));
+  GR_HIP(hipStreamSynchronize(stream));
+
+  // ---- per-cloud grid, exactly the reference's fp32 expressions (this TU: -ffp-contract=off)
+  std::vector<CloudGrid> hg(batch);
+  unsigned long long max_cells = 1;
+  bool wrap = false;
+  const float inv = static_cast<float>(1.0 / static_cast<double>(voxel));  // :11 `(1. / voxel_size)` -> float
+  for (int64_t b = 0; b < batch; ++b) {
+    CloudGrid g{0.f, 0.f, 0.f, voxel, 1ull, 1ull};
+    if (h_lengths[b] > 0) {
+      const float mnx = ord2f(hb[b * 6 + 0]), mny = ord2f(hb[b * 6 + 1]), mnz = ord2f(hb[b * 6 + 2]);
+      const float mxx = ord2f(hb[b * 6 + 3]), mxy = ord2f(hb[b * 6 + 4]), mxz = ord2f(hb[b * 6 + 5]);
+      g.ox = std::floor(mnx * inv) * voxel;
+      g.oy = std::floor(mny * inv) * voxel;
+      g.oz = std::floor(mnz * inv) * voxel;
+      const unsigned long long NX = to_size_t(std::floor((double)((mxx - g.ox) / voxel)) + 1);
+      const unsigned long long NY = to_size_t(std::floor((double)((mxy - g.oy) / voxel)) + 1);
+      const unsigned long long NZ = to_size_t(std::floor((double)((mxz - g.oz) / voxel)) + 1);
+      g.nx = NX;
+      g.nxny = NX * NY;
+      // can the smallest coordinate land in a negative cell (origin rounded above the min)?
+      if ((mnx - g.ox) / voxel < 0.f || (mny - g.oy) / voxel < 0.f || (mnz - g.oz) / voxel < 0.f) wrap = true;
+      const long double cells = (long double)NX * (long double)NY * (long double)NZ;
+      if (cells >= 18446744073709551615.0L || !std::isfinite((double)cells)) wrap = true;
+      else if ((unsigned long long)cells > max_cells) max_cells = (unsigned long long)cells;
+    }
+    hg[b] = g;
+  }
+  GR_HIP(hipMemcpyAsync(w.grids, hg.data(), sizeof(CloudGrid) * batch, hipMemcpyHostToDevice, stream));
+  int key_bits = wrap ? 64 : bits_for(max_cells);
+  const int b_bits = bits_for((unsigned long long)batch);
+  const bool composite = key_bits + b_bits <= 64 && key_bits < 64;
+  if (!composite) key_bits = 64;
+
+  GR_HIP(hipMemsetAsync(w.m_b, 0, sizeof(int32_t) * batch, stream));
+  GR_HIP(hipMemsetAsync(w.flags, 0, sizeof(int32_t) * n, stream));
+  const dim3 blk(256), grd((unsigned)((n + 255) / 256));
+  hipLaunchKernelGGL(keys_kernel, grd, blk, 0, stream, points, (int)n, w.off, nb, w.grids, key_bits, w.keys_a, w.vals_a);
+  GR_LAUNCH_CHECK();
+  uint64_t* keys_sorted = w.keys_b;
+  int32_t* vals_sorted = w.vals_b;
+  if (composite || batch == 1) {
+    rc = sort_pairs_u64_i32(w.sort_temp, w.sort_temp_bytes, w.keys_a, w.keys_b, w.vals_a, w.vals_b, n, 0,
+                            composite ? key_bits + b_bits : 64, stream);
+    if (rc != GR_OK) return rc;
+  } else {
+    // keys need all 64 bits: stable sort by key, then stable sort by cloud id
+    rc = sort_pairs_u64_i32(w.sort_temp, w.sort_temp_bytes, w.keys_a, w.keys_b, w.vals_a, w.vals_b, n, 0, 64, stream);
+    if (rc != GR_OK) return rc;
+    hipLaunchKernelGGL(batch_keys_kernel, grd, blk, 0, stream, w.vals_b, (int)n, w.off, nb, w.keys_a);
+    rc = sort_pairs_u64_i32(w.sort_temp, w.sort_temp_bytes, w.keys_a, w.keys_fo, w.vals_b, w.vals_a, n, 0,
+                            b_bits, stream);
+    if (rc != GR_OK) return rc;
+    // vals_a now holds point indices in (cloud, key, index) order; recompute their raw keys
+    vals_sorted = w.vals_a;
+    keys_sorted = w.keys_b;  // overwritten by regather_keys
+    hipLaunchKernelGGL(regather_keys_kernel, grd, blk, 0, stream, points, vals_sorted, (int)n, w.off, nb, w.grids, keys_sorted);
+  }
+  GR_LAUNCH_CHECK();
+
+  // ---- runs -> cells
+  int32_t* head = w.scan;        // head flags
+  int32_t* head_scan = w.perm;   // exclusive scan of head (perm is free until the very end)
+  hipLaunchKernelGGL(heads_kernel, grd, blk, 0, stream, keys_sorted, vals_sorted, (int)n, w.off, nb,
+                     composite ? 1 : 0, head);
+  rc = exclusive_scan_i32(head, head_scan, n, 1, n, w.scan_ws, w.totals, stream);
+  if (rc != GR_OK) return rc;
+  int32_t* fo_flags = w.flags;  // zeroed above
+  hipLaunchKernelGGL(cells_kernel, grd, blk, 0, stream, points, keys_sorted, vals_sorted, head, head_scan, (int)n,
+                     w.off, nb, composite ? key_bits : 64, w.bary, w.first_idx, w.cell_key, w.cell_batch, w.m_b,
+                     fo_flags);
+  GR_LAUNCH_CHECK();
+  std::vector<int32_t> h_mb(batch);
+  int32_t h_m = 0;
+  GR_HIP(hipMemcpyAsync(&h_m, w.totals, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  GR_HIP(hipMemcpyAsync(h_mb.data(), w.m_b, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, stream));
+
+  if (order_mode == GR_ORDER_CELL) {
+    GR_HIP(hipStreamSynchronize(stream));
+    hipLaunchKernelGGL(copy_cells_kernel, dim3((unsigned)((3 * (int64_t)h_m + 255) / 256)), blk, 0, stream, w.bary, h_m,
+                       out_points);
+    GR_LAUNCH_CHECK();
+  } else {
+    // first-occurrence rank of every cell, keys in that order -> host
+    int32_t* fo_scan = w.scan;  // head flags no longer needed
+    rc = exclusive_scan_i32(fo_flags, fo_scan, n, 1, n, w.scan_ws, w.totals + 1, stream);
+    if (rc != GR_OK) return rc;
+    GR_HIP(hipStreamSynchronize(stream));  // h_m valid
+    if (h_m > 0) {
+      hipLaunchKernelGGL(fo_rank_kernel, dim3((unsigned)((h_m + 255) / 256)), blk, 0, stream, w.first_idx, w.cell_key,
+                         fo_scan, h_m, w.cell_of_rank, w.keys_fo);
+      GR_LAUNCH_CHECK();
+      std::vector<uint64_t> hk(h_m);
+      GR_HIP(hipMemcpyAsync(hk.data(), w.keys_fo, sizeof(uint64_t) * h_m, hipMemcpyDeviceToHost, stream));
+      GR_HIP(hipStreamSynchronize(stream));
+      // Replay: the reference inserts keys in first-occurrence order into an unordered_map and
+      // emits in its iteration order (grid_subsampling_cpu.cpp:28-47).  Same container, same
+      // libstdc++, same order.  Ranks are global but clouds are contiguous in rank.
+      std::vector<int32_t> perm(h_m);
+      int64_t r0 = 0, j = 0;
+      for (int64_t b = 0; b < batch; ++b) {
+        std::unordered_map<std::size_t, int32_t> m;
+        for (int64_t r = r0; r < r0 + h_mb[b]; ++r) m.emplace((std::size_t)hk[r], (int32_t)r);
+        for (const auto& kv : m) perm[j++] = kv.second;
+        r0 += h_mb[b];
+      }
+      GR_HIP(hipMemcpyAsync(w.perm, perm.data(), sizeof(int32_t) * h_m, hipMemcpyHostToDevice, stream));
+      hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((h_m + 255) / 256)), blk, 0, stream, w.bary, w.cell_of_rank,
+                         w.perm, h_m, out_points);
+      GR_LAUNCH_CHECK();
+      GR_HIP(hipStreamSynchronize(stream));  // perm (host vector) must outlive the copy
+    }
+  }
+  for (int64_t b = 0; b < batch; ++b) h_out_lengths[b] = h_mb[b];
+  *h_total_m = h_m;
+  return GR_OK;
+}

@@ -1,0 +1,140 @@
+"""Mirror of the reference's native module ``geotransformer.ext`` (setup.py:10, pybind.cpp:6-18).
+
+Same two functions, same positional signatures, same error texts -- backed by the HIP kernels:
+
+    radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius) -> LongTensor (Nq, max_count)
+        reference: geotransformer/extensions/cpu/radius_neighbors/radius_neighbors.cpp:5-68
+    grid_subsampling(points, lengths, voxel_size) -> [s_points (M,3) f32, s_lengths (B,) i64]
+        reference: geotransformer/extensions/cpu/grid_subsampling/grid_subsampling.cpp:5-62
+
+Differences from the reference (documented in INTEGRATION.md): tensors may live on the GPU (the
+reference insists on CPU tensors); CPU tensors are accepted, computed on the GPU and returned on
+the CPU; outputs follow the input's device like the reference's `at::device(points.device())`.
+Nothing is ever computed on the CPU.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_ORDER = {"reference": 0, "cell": 1}
+
+
+def _check_float(x, name):
+    if x.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be a float tensor")  # torch_helper.h:31-35
+
+
+def _check_long(x, name):
+    if x.dtype != torch.int64:
+        raise RuntimeError(f"{name} must be an long tensor")  # torch_helper.h:25-29 (sic)
+
+
+def _check_contig(x, name):
+    if not x.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")  # torch_helper.h:12-13
+
+
+def _check_points(x, name):
+    if not isinstance(x, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if x.dim() != 2 or x.shape[1] != 3:
+        raise RuntimeError(f"{name} must have shape (N, 3)")
+
+
+def radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius):
+    dev = _lib.require_gpu()
+    L = _lib.lib()
+    for t, n in ((q_points, "q_points"), (s_points, "s_points")):
+        _check_points(t, n)
+        _check_float(t, n)
+    for t, n in ((q_lengths, "q_lengths"), (s_lengths, "s_lengths")):
+        _check_long(t, n)
+    for t, n in ((q_points, "q_points"), (s_points, "s_points"), (q_lengths, "q_lengths"), (s_lengths, "s_lengths")):
+        _check_contig(t, n)
+    if q_lengths.numel() != s_lengths.numel():
+        raise RuntimeError("q_lengths and s_lengths must have the same number of batch elements")
+    out_device = q_points.device
+    same = s_points is q_points or (s_points.data_ptr() == q_points.data_ptr() and s_points.shape == q_points.shape)
+    q = q_points if q_points.is_cuda else q_points.to(dev)
+    s = q if same else (s_points if s_points.is_cuda else s_points.to(dev))
+    dev = q.device
+    ql = q_lengths.tolist()
+    sl = s_lengths.tolist()
+    nq, ns, nb = q.shape[0], s.shape[0], len(ql)
+    hq, hs = _lib.host_i64(ql), _lib.host_i64(sl)
+    with torch.cuda.device(dev):
+        nbytes = L.gr_radius_workspace_bytes(nq, ns, nb)
+        ws = _lib.workspace(dev, nbytes)
+        info = (ctypes.c_int64 * 4)()
+        st = _lib.stream_ptr(dev)
+        _lib.check(L.gr_radius_count(_lib.ptr(q), _lib.ptr(s), hq, hs, nq, ns, nb, float(radius), _lib.ptr(ws),
+                                     ws.numel(), info, st))
+        width = int(info[0])
+        out = torch.empty((nq, width), dtype=torch.int64, device=dev)
+        if nq > 0 and width > 0:
+            _lib.check(L.gr_radius_fill(_lib.ptr(q), _lib.ptr(s), nq, ns, nb, float(radius), width, info,
+                                        _lib.ptr(out), _lib.ptr(ws), ws.numel(), st))
+    return out if out_device.type == "cuda" else out.to(out_device)
+
+
+def radius_neighbors_limited(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit):
+    """radius_neighbors + the column truncation of modules/ops/radius_search.py:25-26 done inside the
+    fill kernel: only min(max_count, neighbor_limit) columns are ever written (contiguous result)."""
+    dev = _lib.require_gpu()
+    L = _lib.lib()
+    out_device = q_points.device
+    same = s_points is q_points or (s_points.data_ptr() == q_points.data_ptr() and s_points.shape == q_points.shape)
+    q = q_points if q_points.is_cuda else q_points.to(dev)
+    s = q if same else (s_points if s_points.is_cuda else s_points.to(dev))
+    dev = q.device
+    ql, sl = q_lengths.tolist(), s_lengths.tolist()
+    nq, ns, nb = q.shape[0], s.shape[0], len(ql)
+    hq, hs = _lib.host_i64(ql), _lib.host_i64(sl)
+    with torch.cuda.device(dev):
+        ws = _lib.workspace(dev, L.gr_radius_workspace_bytes(nq, ns, nb))
+        info = (ctypes.c_int64 * 4)()
+        st = _lib.stream_ptr(dev)
+        _lib.check(L.gr_radius_count(_lib.ptr(q), _lib.ptr(s), hq, hs, nq, ns, nb, float(radius), _lib.ptr(ws),
+                                     ws.numel(), info, st))
+        width = int(info[0])
+        if neighbor_limit > 0:
+            width = min(width, int(neighbor_limit))
+        out = torch.empty((nq, width), dtype=torch.int64, device=dev)
+        if nq > 0 and width > 0:
+            _lib.check(L.gr_radius_fill(_lib.ptr(q), _lib.ptr(s), nq, ns, nb, float(radius), width, info,
+                                        _lib.ptr(out), _lib.ptr(ws), ws.numel(), st))
+    return out if out_device.type == "cuda" else out.to(out_device)
+
+
+def grid_subsampling(points, lengths, voxel_size, order="reference"):
+    """`order="reference"` (default) reproduces the reference's row order bit for bit;
+    `order="cell"` keeps everything on the device (rows sorted by voxel key)."""
+    dev = _lib.require_gpu()
+    L = _lib.lib()
+    _check_points(points, "points")
+    _check_float(points, "points")
+    _check_long(lengths, "lengths")
+    _check_contig(points, "points")
+    _check_contig(lengths, "lengths")
+    out_device = points.device
+    p = points if points.is_cuda else points.to(dev)
+    dev = p.device
+    lens = lengths.tolist()
+    n, nb = p.shape[0], len(lens)
+    hl = _lib.host_i64(lens)
+    out_l = (ctypes.c_int64 * max(nb, 1))()
+    total = ctypes.c_int64(0)
+    with torch.cuda.device(dev):
+        ws = _lib.workspace(dev, L.gr_grid_subsample_workspace_bytes(n, nb))
+        out = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        _lib.check(L.gr_grid_subsample(_lib.ptr(p), hl, n, nb, float(voxel_size), _ORDER[order], _lib.ptr(out),
+                                       out_l, ctypes.byref(total), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)))
+    s_points = out[: total.value]
+    if total.value != n:
+        s_points = s_points.clone()  # do not pin the (n,3) allocation behind a small view
+    s_lengths = torch.tensor([out_l[b] for b in range(nb)], dtype=torch.int64, device=lengths.device)
+    if out_device.type != "cuda":
+        s_points = s_points.to(out_device)
+    return [s_points, s_lengths]

@@ -1,0 +1,89 @@
+/* gaussreg_hip.h -- C ABI of libgaussreg_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for GaussReg's two data-parallel hot paths (BASELINE.json north_star):
+ *   (1) the GeoTransformer point-cloud op stack
+ *   (2) the 3D-Gaussian-splatting rasterizer forward
+ * Every entry point below names the reference interface it replaces (paths relative to the
+ * GaussReg tree).  Conventions:
+ *   - plain C types only; all pointers are DEVICE pointers unless the name starts with `h_`;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued on it.  Entry points that must
+ *     return a data-dependent size to the host (documented per function) synchronise that stream;
+ *   - the caller owns every buffer, including the workspace `ws` (size it with the matching
+ *     *_workspace_bytes function; contents are scratch unless stated otherwise);
+ *   - return value: 0 = ok, <0 = error (see gr_last_error()).  Nothing is ever computed on the CPU:
+ *     if no gfx950 device is usable the call fails, it does not fall back.
+ */
+#ifndef GAUSSREG_HIP_H_
+#define GAUSSREG_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GR_OK 0
+#define GR_ERR_INVALID -1   /* bad argument */
+#define GR_ERR_HIP -2       /* a HIP runtime call failed */
+#define GR_ERR_WORKSPACE -3 /* workspace too small */
+#define GR_ERR_UNSUPPORTED -4
+
+/* Thread-local description of the last error returned on this thread. */
+const char* gr_last_error(void);
+/* Library/ABI version (major*1000 + minor). */
+int gr_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * radius_neighbors  -- replaces
+ *   geotransformer/extensions/cpu/radius_neighbors/radius_neighbors.cpp:5-68     (entry, alloc)
+ *   geotransformer/extensions/cpu/radius_neighbors/radius_neighbors_cpu.cpp:3-91 (search)
+ * bound in Python as geotransformer.ext.radius_neighbors (geotransformer/extensions/pybind.cpp:8-12).
+ *
+ * Stack mode: q (nq,3) / s (ns,3) fp32 row-major hold `batch` clouds back to back; h_q_lengths /
+ * h_s_lengths (host, int64[batch]) give their sizes.  A support j is a neighbour of query i (same
+ * batch element) iff fp32 ((dx*dx + dy*dy) + dz*dz) < radius*radius; rows are sorted by ascending
+ * distance (ties: ascending index) and padded with `ns`.
+ *
+ * The row width is data dependent (radius_neighbors.cpp:54), so the op is two calls:
+ *   gr_radius_count : bins the supports into a uniform grid, counts, SYNCHRONISES `stream`, writes
+ *                     h_info[0] = max_count (the width the reference would return),
+ *                     h_info[1..3] = opaque plan values for the fill call.
+ *   gr_radius_fill  : writes out (nq, width) int64, width <= h_info[0] keeps the nearest `width`
+ *                     (== the truncation radius_search applies, modules/ops/radius_search.py:25-26).
+ * `ws` must be the same, untouched buffer in both calls.
+ */
+size_t gr_radius_workspace_bytes(int64_t nq, int64_t ns, int64_t batch);
+int gr_radius_count(const float* q, const float* s, const int64_t* h_q_lengths,
+                    const int64_t* h_s_lengths, int64_t nq, int64_t ns, int64_t batch, float radius,
+                    void* ws, size_t ws_bytes, int64_t* h_info /*[4]*/, void* stream);
+int gr_radius_fill(const float* q, const float* s, int64_t nq, int64_t ns, int64_t batch,
+                   float radius, int64_t width, const int64_t* h_info /*[4]*/, int64_t* out,
+                   void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * grid_subsampling -- replaces
+ *   geotransformer/extensions/cpu/grid_subsampling/grid_subsampling.cpp:5-62      (entry)
+ *   geotransformer/extensions/cpu/grid_subsampling/grid_subsampling_cpu.cpp:3-75  (voxel hashing)
+ * bound as geotransformer.ext.grid_subsampling (pybind.cpp:13-17).
+ *
+ * out_points has capacity (n,3); h_out_lengths (host, int64[batch]) receives m_b; *h_total_m the
+ * total.  Barycentres are bit-identical to the reference (sequential fp32 sums in input order,
+ * times float(1.0/count)).  order_mode selects the ROW ORDER inside each cloud:
+ *   GR_ORDER_REFERENCE  the reference's std::unordered_map iteration order (replayed on the host
+ *                       through the same libstdc++ container; one extra D2H/H2D hop), bit-for-bit
+ *                       the tensor the reference returns;
+ *   GR_ORDER_CELL       ascending voxel key -- fully on device, same multiset of rows.
+ * Synchronises `stream` (the output size is data dependent).
+ */
+#define GR_ORDER_REFERENCE 0
+#define GR_ORDER_CELL 1
+size_t gr_grid_subsample_workspace_bytes(int64_t n, int64_t batch);
+int gr_grid_subsample(const float* points, const int64_t* h_lengths, int64_t n, int64_t batch,
+                      float voxel_size, int order_mode, float* out_points, int64_t* h_out_lengths,
+                      int64_t* h_total_m, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAUSSREG_HIP_H_ */
