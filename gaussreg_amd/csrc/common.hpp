@@ -81,8 +81,10 @@ int exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int rows, int
 
 // Per-cloud bounding boxes of stacked points: bbox_dev[b*6 + {0,1,2}] = min xyz, +{3,4,5} = max xyz,
 // stored as order-preserving uints (decode with ord2f).  Empty clouds keep (0xffffffff, 0).
-int compute_bbox(const float* pts, int n, const int32_t* off_dev, int nb, uint32_t* bbox_dev,
-                 hipStream_t stream);
+// h_off: host copy of the nb+1 point offsets; h_blk: nb+1 ints of HOST scratch that must stay
+// alive until the stream is synchronised; blk_off_dev: nb+1 ints of device scratch.
+int compute_bbox(const float* pts, const int32_t* h_off, int32_t* h_blk, const int32_t* off_dev, int nb,
+                 uint32_t* bbox_dev, int32_t* blk_off_dev, hipStream_t stream);
 
 // Stable LSD radix sort of (u64 key, i32 value) pairs on bits [begin_bit, end_bit) (rocPRIM).
 size_t sort_pairs_temp_bytes(int64_t n);

@@ -31,6 +31,7 @@ struct CloudGrid {
 struct GridWs {
   int32_t* off;         // [B+1]
   uint32_t* bbox;       // [B*6]
+  int32_t* blk_off;     // [B+1]
   CloudGrid* grids;     // [B]
   uint64_t* keys_a;     // [N]
   uint64_t* keys_b;     // [N]
@@ -58,6 +59,7 @@ GridWs carve(void* ws, int64_t n, int64_t batch) {
   Carver c(ws);
   w.off = c.take<int32_t>(batch + 1);
   w.bbox = c.take<uint32_t>(batch * 6);
+  w.blk_off = c.take<int32_t>(batch + 1);
   w.grids = c.take<CloudGrid>(batch);
   w.keys_a = c.take<uint64_t>(n);
   w.keys_b = c.take<uint64_t>(n);
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256) void cells_kernel(
     const int32_t* __restrict__ vals, const int32_t* __restrict__ head,
     const int32_t* __restrict__ head_scan, int n, const int32_t* __restrict__ off, int nb,
     int key_bits, float* __restrict__ bary, int32_t* __restrict__ first_idx,
-    uint64_t* __restrict__ cell_key, int32_t* __restrict__ cell_batch, int32_t* __restrict__ m_b,
+    uint64_t* __restrict__ cell_key, int32_t* __restrict__ cell_batch,
     int32_t* __restrict__ fo_flags) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n || !head[t]) return;
@@ -179,8 +181,21 @@ __global__ __launch_bounds__(256) void cells_kernel(
   cell_batch[cell] = b;
   const unsigned long long k = keys[t];
   cell_key[cell] = key_bits < 64 ? (k & ((1ull << key_bits) - 1ull)) : k;
-  atomicAdd(&m_b[b], 1);
   fo_flags[first] = 1;
+}
+
+// m_b = number of voxel runs of cloud b: sorted positions [off[b], off[b+1]) belong to cloud b,
+// and head_scan (exclusive) numbers the runs, so m_b is a difference of two scan values.
+__global__ void cloud_counts_kernel(const int32_t* __restrict__ head_scan,
+                                    const int32_t* __restrict__ total, int n,
+                                    const int32_t* __restrict__ off, int nb,
+                                    int32_t* __restrict__ m_b) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  const int a = off[b], e = off[b + 1];
+  const int ca = a < n ? head_scan[a] : total[0];
+  const int ce = e < n ? head_scan[e] : total[0];
+  m_b[b] = ce - ca;
 }
 
 __global__ __launch_bounds__(256) void copy_cells_kernel(const float* __restrict__ bary, int m,
@@ -257,7 +272,8 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
   std::vector<int32_t> off(batch + 1, 0);
   for (int64_t b = 0; b < batch; ++b) off[b + 1] = off[b] + (int32_t)h_lengths[b];
   GR_HIP(hipMemcpyAsync(w.off, off.data(), sizeof(int32_t) * (batch + 1), hipMemcpyHostToDevice, stream));
-  int rc = compute_bbox(points, (int)n, w.off, nb, w.bbox, stream);
+  std::vector<int32_t> h_blk(batch + 1);
+  int rc = compute_bbox(points, off.data(), h_blk.data(), w.off, nb, w.bbox, w.blk_off, stream);
   if (rc != GR_OK) return rc;
   std::vector<uint32_t> hb(batch * 6);
   GR_HIP(hipMemcpyAsync(hb.data(), w.bbox, sizeof(uint32_t) * batch * 6, hipMemcpyDeviceToHost, stream));
@@ -295,7 +311,6 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
   const bool composite = key_bits + b_bits <= 64 && key_bits < 64;
   if (!composite) key_bits = 64;
 
-  GR_HIP(hipMemsetAsync(w.m_b, 0, sizeof(int32_t) * batch, stream));
   GR_HIP(hipMemsetAsync(w.flags, 0, sizeof(int32_t) * n, stream));
   const dim3 blk(256), grd((unsigned)((n + 255) / 256));
   hipLaunchKernelGGL(keys_kernel, grd, blk, 0, stream, points, (int)n, w.off, nb, w.grids, key_bits, w.keys_a, w.vals_a);
@@ -330,8 +345,9 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
   if (rc != GR_OK) return rc;
   int32_t* fo_flags = w.flags;  // zeroed above
   hipLaunchKernelGGL(cells_kernel, grd, blk, 0, stream, points, keys_sorted, vals_sorted, head, head_scan, (int)n,
-                     w.off, nb, composite ? key_bits : 64, w.bary, w.first_idx, w.cell_key, w.cell_batch, w.m_b,
-                     fo_flags);
+                     w.off, nb, composite ? key_bits : 64, w.bary, w.first_idx, w.cell_key, w.cell_batch, fo_flags);
+  hipLaunchKernelGGL(cloud_counts_kernel, dim3((nb + 255) / 256), blk, 0, stream, head_scan, w.totals, (int)n, w.off,
+                     nb, w.m_b);
   GR_LAUNCH_CHECK();
   std::vector<int32_t> h_mb(batch);
   int32_t h_m = 0;

@@ -39,13 +39,14 @@ struct RadiusHdr {
   int pad;
 };
 
-constexpr int RT = 256;  // threads per block in count/fill (block <-> 256 consecutive sorted queries)
+constexpr int RT = 128;  // queries per block in count/fill (3 threads per query)
 
 struct RadiusWs {
   RadiusHdr* hdr;
   int32_t* q_off;
   int32_t* s_off;
   uint32_t* bbox;
+  int32_t* blk_off;
   BatchGrid* grids;
   int32_t* s_cell;
   int32_t* q_cell;
@@ -54,7 +55,8 @@ struct RadiusWs {
   int32_t* scan_ws;
   float4* sorted_s;
   float4* sorted_q;
-  int32_t* q_count;
+  int32_t* q_count;    // [3][nq] hits per (z-slab, query)
+  int32_t* blk_stats;  // [blocks][2]
   int64_t ccap;
   size_t bytes;
 };
@@ -67,6 +69,7 @@ RadiusWs carve(void* ws, int64_t nq, int64_t ns, int64_t batch) {
   w.q_off = c.take<int32_t>(batch + 1);
   w.s_off = c.take<int32_t>(batch + 1);
   w.bbox = c.take<uint32_t>(batch * 6);
+  w.blk_off = c.take<int32_t>(batch + 1);
   w.grids = c.take<BatchGrid>(batch);
   w.s_cell = c.take<int32_t>(ns);
   w.q_cell = c.take<int32_t>(nq);
@@ -75,7 +78,8 @@ RadiusWs carve(void* ws, int64_t nq, int64_t ns, int64_t batch) {
   w.scan_ws = c.take<int32_t>(2 * scan_ws_ints(w.ccap + 1));
   w.sorted_s = c.take<float4>(ns);
   w.sorted_q = c.take<float4>(nq);
-  w.q_count = c.take<int32_t>(nq);
+  w.q_count = c.take<int32_t>(3 * nq);
+  w.blk_stats = c.take<int32_t>(2 * ((nq + RT - 1) / RT + 1));
   w.bytes = c.used();
   return w;
 }
@@ -198,160 +202,332 @@ __global__ __launch_bounds__(256) void scatter_kernel(
 }
 
 // ---------------------------------------------------------------- candidate traversal
-// Calls f(dist, support_orig_index) for every support of the query's 27-cell neighbourhood
-// with d < r2.
-template <typename F>
-__device__ inline void for_each_hit(const float4 qp, const BatchGrid& g,
-                                    const int32_t* __restrict__ start_s,
-                                    const float4* __restrict__ sorted_s, float r2, F&& f) {
-  int lo[3], hi[3];
-  const float p[3] = {qp.x, qp.y, qp.z};
-  bool empty = false;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const double u = cell_coord(p[k], g.org[k], g.inv_cell);
-    const double top = (double)(g.dim[k] - 1);
-    if (!(u + 1.0 >= 0.0) || !(u - 1.0 <= top)) empty = true;  // also catches NaN
-    lo[k] = (int)fmin(fmax(u - 1.0, 0.0), top);
-    hi[k] = (int)fmin(fmax(u + 1.0, 0.0), top);
-  }
-  if (empty) return;
-  for (int cz = lo[2]; cz <= hi[2]; ++cz)
-    for (int cy = lo[1]; cy <= hi[1]; ++cy) {
-      const int base = g.cell_base + g.dim[0] * (cy + g.dim[1] * cz);
-      const int p0 = start_s[base + lo[0]];
-      const int p1 = start_s[base + hi[0] + 1];
-      for (int t = p0; t < p1; ++t) {
-        const float4 sp = sorted_s[t];
-        // nanoflann.hpp:432-440: result += diff*diff for x, y, z starting from 0
-        const float dx = qp.x - sp.x;
-        const float dy = qp.y - sp.y;
-        const float dz = qp.z - sp.z;
-        const float d = (dx * dx + dy * dy) + dz * dz;
-        if (d < r2) f(d, __float_as_int(sp.w));
-      }
-    }
-}
+// A block owns RQ consecutive cell-ordered queries and runs 3*RQ threads: thread (j, slot) walks
+// the three (dy, dz = j-1) bands of query `slot`, so a wave holds 64 neighbouring queries looking
+// at the same z-slab.  Cells are numbered x-fastest, hence the union of the block's 27-cell
+// neighbourhoods is nine (dy,dz) "bands", each a CONTIGUOUS range of the cell-sorted support array.
+// The block stages those ranges in LDS with coalesced float4 loads (falls back to direct global
+// reads if they do not fit) and every thread then walks its own candidates out of LDS, four
+// independent ds_read_b128 in flight per step.
+//   COUNT pass: hits per (query, z-slab) -> q_cnt[3][nq]; per-block max / sum -> blk_stats
+//   FILL  pass: phase A appends (dist,index) keys unsorted into per-query LDS segments (the slab
+//               sub-counts give every thread a private sub-segment: no atomics);
+//               phase B gives each hit one thread, ranks it inside its segment (branch-free
+//               counting; segment reads are LDS broadcasts) and stores it straight to its final
+//               slot out[query][rank]; padding is written one row per wave.
+constexpr int NBAND = 9;
+constexpr int NSUB = 3;  // threads per query (one per z-slab)
 
-__global__ __launch_bounds__(RT) void count_kernel(const float4* __restrict__ sorted_q, int nq,
-                                                   const int32_t* __restrict__ q_off, int nb,
-                                                   const BatchGrid* __restrict__ grids,
-                                                   const int32_t* __restrict__ start_s,
-                                                   const float4* __restrict__ sorted_s, float r2,
-                                                   int32_t* __restrict__ q_count,
-                                                   RadiusHdr* __restrict__ hdr) {
-  __shared__ int wsum[RT / WAVE];
-  const int t = blockIdx.x * RT + threadIdx.x;
-  int n = 0;
-  if (t < nq) {
-    const float4 qp = sorted_q[t];
+template <int RQ>
+struct TravLds {
+  static constexpr int THREADS = NSUB * RQ;
+  static constexpr int STAGE_CAP = 12 * RQ;  // float4 slots
+  // ints: offs[RQ+1], orig[RQ], sub[3*RQ], band_lo[9], band_hi[9], band_base[10], wsum[THREADS/64]
+  static constexpr int N_INTS = (RQ + 1) + RQ + NSUB * RQ + 9 + 9 + 10 + THREADS / WAVE;
+  static constexpr size_t INTS_BYTES = (size_t)(N_INTS * 4 + 15) / 16 * 16;
+  static constexpr size_t STAGE_BYTES = (size_t)STAGE_CAP * 16;
+  static constexpr size_t FIXED = INTS_BYTES + STAGE_BYTES;
+  static size_t total(int64_t max_block_hits) {  // + keys (8 B) + row ids (1 B) per hit
+    return FIXED + (size_t)max_block_hits * 8 + ((size_t)max_block_hits + 15) / 16 * 16;
+  }
+};
+
+template <int RQ, bool FILL, bool HITS_IN_LDS>
+__global__ __launch_bounds__(NSUB* RQ) void traverse_kernel(
+    const float4* __restrict__ sorted_q, int nq, const int32_t* __restrict__ q_off, int nb,
+    const BatchGrid* __restrict__ grids, const int32_t* __restrict__ start_s,
+    const float4* __restrict__ sorted_s, float r2, int32_t* __restrict__ q_cnt,
+    int32_t* __restrict__ blk_stats, int width, int64_t pad_value, int64_t* __restrict__ out,
+    int max_block_hits, unsigned long long* __restrict__ g_hits, unsigned char* __restrict__ g_rows) {
+  using L = TravLds<RQ>;
+  static_assert(RQ % WAVE == 0 && RQ <= 256, "row ids are bytes; waves must not straddle slabs");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* offs = reinterpret_cast<int*>(smem);
+  int* orig = offs + (RQ + 1);
+  int* sub = orig + RQ;  // [NSUB][RQ]
+  int* band_lo = sub + NSUB * RQ;
+  int* band_hi = band_lo + NBAND;
+  int* band_base = band_hi + NBAND;
+  int* wsum = band_base + (NBAND + 1);
+  float4* stage = reinterpret_cast<float4*>(smem + L::INTS_BYTES);
+  unsigned long long* hits = HITS_IN_LDS ? reinterpret_cast<unsigned long long*>(smem + L::FIXED)
+                                         : g_hits + (int64_t)blockIdx.x * max_block_hits;
+  unsigned char* rows = HITS_IN_LDS
+                            ? reinterpret_cast<unsigned char*>(smem + L::FIXED + (size_t)max_block_hits * 8)
+                            : g_rows + (int64_t)blockIdx.x * max_block_hits;
+
+  const int tid = threadIdx.x;
+  const int slot = tid % RQ, j = tid / RQ;  // query slot in block, z-slab
+  const int t = blockIdx.x * RQ + slot;
+  const int lane = tid & (WAVE - 1);
+  const bool valid = t < nq;
+
+  if (tid < NBAND) {
+    band_lo[tid] = 0x7fffffff;
+    band_hi[tid] = 0;
+  }
+  int my_off = 0;
+  if (FILL) {
+    // every slab group redundantly scans the per-query totals (two waves each; no cross-group sync)
+    int c[NSUB] = {0, 0, 0};
+    if (valid) {
+#pragma unroll
+      for (int i = 0; i < NSUB; ++i) c[i] = q_cnt[(int64_t)i * nq + t];
+    }
+    const int tot = c[0] + c[1] + c[2];
+    int inc = tot;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+      int v = __shfl_up(inc, d, WAVE);
+      if (lane >= d) inc += v;
+    }
+    if (lane == WAVE - 1) wsum[tid / WAVE] = inc;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < RQ / WAVE; ++i)
+      if (i < slot / WAVE) base += wsum[j * (RQ / WAVE) + i];
+    const int q_start = base + inc - tot;
+    my_off = q_start + (j > 0 ? c[0] : 0) + (j > 1 ? c[1] : 0);
+    if (j == 0) {
+      offs[slot] = q_start;
+      if (slot == RQ - 1) offs[RQ] = q_start + tot;
+    }
+  } else {
+    __syncthreads();
+  }
+
+  // ---- per-thread candidate ranges (global positions in sorted_s) for bands (dy, dz = j-1)
+  float4 qp = make_float4(0.f, 0.f, 0.f, 0.f);
+  int p0[3] = {0, 0, 0}, p1[3] = {0, 0, 0};
+  if (valid) {
+    qp = sorted_q[t];
+    if (FILL && j == 0) orig[slot] = __float_as_int(qp.w);
     const int b = find_batch(q_off, nb, __float_as_int(qp.w));
     const BatchGrid g = grids[b];
-    for_each_hit(qp, g, start_s, sorted_s, r2, [&](float, int) { ++n; });
-    q_count[t] = n;
+    const double ux = cell_coord(qp.x, g.org[0], g.inv_cell);
+    const double uy = cell_coord(qp.y, g.org[1], g.inv_cell);
+    const double cz = cell_coord(qp.z, g.org[2], g.inv_cell) + (double)(j - 1);
+    const double tx = (double)(g.dim[0] - 1), ty = (double)(g.dim[1] - 1), tz = (double)(g.dim[2] - 1);
+    // the comparisons are written so that NaN coordinates give "no candidates"
+    if ((ux + 1.0 >= 0.0) && (ux - 1.0 <= tx) && cz >= 0.0 && cz <= tz) {
+      const int lx = (int)fmin(fmax(ux - 1.0, 0.0), tx);
+      const int hx = (int)fmin(fmax(ux + 1.0, 0.0), tx);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double cy = uy + (double)(i - 1);
+        if (cy >= 0.0 && cy <= ty) {
+          const int base = g.cell_base + g.dim[0] * ((int)cy + g.dim[1] * (int)cz);
+          p0[i] = start_s[base + lx];
+          p1[i] = start_s[base + hx + 1];
+        }
+      }
+    }
+  } else if (FILL && j == 0) {
+    orig[slot] = -1;
   }
-  int mx = n, sm = n;
+  // ---- block-wide extent of every band (waves are slab-uniform: band index = 3*j + i)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    int lo = p1[i] > p0[i] ? p0[i] : 0x7fffffff;
+    int hi = p1[i] > p0[i] ? p1[i] : 0;
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) {
+      lo = min(lo, __shfl_xor(lo, d, WAVE));
+      hi = max(hi, __shfl_xor(hi, d, WAVE));
+    }
+    if (lane == 0 && hi > 0) {
+      atomicMin(&band_lo[3 * j + i], lo);
+      atomicMax(&band_hi[3 * j + i], hi);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int k = 0; k < NBAND; ++k) {
+      band_base[k] = acc;
+      acc += band_hi[k] > band_lo[k] ? band_hi[k] - band_lo[k] : 0;
+    }
+    band_base[NBAND] = acc;
+  }
+  __syncthreads();
+  const bool staged = band_base[NBAND] <= L::STAGE_CAP;
+  if (staged) {
+#pragma unroll
+    for (int k = 0; k < NBAND; ++k) {
+      const int lo = band_lo[k], len = band_hi[k] - lo, bb = band_base[k];
+      for (int i = tid; i < len; i += L::THREADS) stage[bb + i] = sorted_s[lo + i];
+    }
+    __syncthreads();
+  }
+
+  // ---- walk the candidates (two instantiations so the staged loop uses ds_read, not flat loads)
+  int n = 0;
+  auto walk = [&](auto load) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int e = p1[i];
+      for (int p = p0[i]; p < e; p += 4) {
+        float4 sp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sp[u] = load(i, min(p + u, e - 1));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          // nanoflann.hpp:432-440: result += diff*diff for x, y, z starting from 0
+          const float dx = qp.x - sp[u].x;
+          const float dy = qp.y - sp[u].y;
+          const float dz = qp.z - sp[u].z;
+          const float d = (dx * dx + dy * dy) + dz * dz;
+          if (p + u < e && d < r2) {
+            if (FILL) {
+              // key orders by (distance, index); d >= 0 so its bit pattern is monotone
+              hits[my_off + n] = ((unsigned long long)__float_as_uint(d) << 32) |
+                                 (unsigned int)__float_as_int(sp[u].w);
+              rows[my_off + n] = (unsigned char)slot;
+            }
+            ++n;
+          }
+        }
+      }
+    }
+  };
+  if (valid) {
+    if (staged) {
+      int rel[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) rel[i] = band_base[3 * j + i] - band_lo[3 * j + i];
+      walk([&](int i, int p) { return stage[rel[i] + p]; });
+    } else {
+      walk([&](int, int p) { return sorted_s[p]; });
+    }
+  }
+
+  if (!FILL) {
+    if (valid) q_cnt[(int64_t)j * nq + t] = n;
+    sub[tid] = n;
+    __syncthreads();
+    if (tid < RQ) {
+      const int tot = sub[tid] + sub[RQ + tid] + sub[2 * RQ + tid];
+      int mx = tot, sm = tot;
+#pragma unroll
+      for (int d = WAVE / 2; d > 0; d >>= 1) {
+        mx = max(mx, __shfl_xor(mx, d, WAVE));
+        sm += __shfl_xor(sm, d, WAVE);
+      }
+      if (lane == 0) {
+        wsum[tid / WAVE] = mx;
+        wsum[RQ / WAVE + tid / WAVE] = sm;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int mx = 0, sm = 0;
+#pragma unroll
+      for (int i = 0; i < RQ / WAVE; ++i) {
+        mx = max(mx, wsum[i]);
+        sm += wsum[RQ / WAVE + i];
+      }
+      blk_stats[2 * blockIdx.x] = mx;      // reduced by reduce_stats_kernel: no same-address
+      blk_stats[2 * blockIdx.x + 1] = sm;  // global atomics (they cost ~11 ns EACH when contended)
+    }
+    return;
+  }
+
+  __syncthreads();
+  // ---- phase B: one thread per hit, rank inside its segment, store to the final slot
+  const int total_hits = offs[RQ];
+  for (int e = tid; e < total_hits; e += L::THREADS) {
+    const int r = rows[e];
+    const int a = offs[r], len = offs[r + 1] - a;
+    const unsigned long long key = hits[e];
+    int rank = 0;
+    for (int jj = 0; jj < len; ++jj) rank += hits[a + jj] < key ? 1 : 0;
+    if (rank < width) out[(int64_t)orig[r] * width + rank] = (int64_t)(unsigned int)(key & 0xffffffffull);
+  }
+  // ---- padding: one row per wave iteration, lanes along the row
+  const int rows_here = min(RQ, nq - blockIdx.x * RQ);
+  for (int r = tid / WAVE; r < rows_here; r += L::THREADS / WAVE) {
+    const int cnt = offs[r + 1] - offs[r];
+    int64_t* row = out + (int64_t)orig[r] * width;
+    for (int c = cnt + lane; c < width; c += WAVE) row[c] = pad_value;
+  }
+}
+
+// max / max over the per-block (max hits per query, hits per block) pairs -> hdr
+__global__ __launch_bounds__(1024) void reduce_stats_kernel(const int32_t* __restrict__ blk_stats,
+                                                            int blocks, RadiusHdr* __restrict__ hdr) {
+  __shared__ int sh[2][1024 / WAVE];
+  int mx = 0, ms = 0;
+  for (int i = threadIdx.x; i < blocks; i += 1024) {
+    mx = max(mx, blk_stats[2 * i]);
+    ms = max(ms, blk_stats[2 * i + 1]);
+  }
 #pragma unroll
   for (int d = WAVE / 2; d > 0; d >>= 1) {
     mx = max(mx, __shfl_xor(mx, d, WAVE));
-    sm += __shfl_xor(sm, d, WAVE);
+    ms = max(ms, __shfl_xor(ms, d, WAVE));
   }
-  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
-  if (lane == 0) {
-    wsum[w] = sm;
-    if (mx > 0) atomicMax(&hdr->max_count, (unsigned)mx);
+  if ((threadIdx.x & (WAVE - 1)) == 0) {
+    sh[0][threadIdx.x / WAVE] = mx;
+    sh[1][threadIdx.x / WAVE] = ms;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    int tot = 0;
-#pragma unroll
-    for (int i = 0; i < RT / WAVE; ++i) tot += wsum[i];
-    if (tot > 0) atomicMax(&hdr->max_block_hits, (unsigned)tot);
+    for (int i = 0; i < 1024 / WAVE; ++i) {
+      mx = max(mx, sh[0][i]);
+      ms = max(ms, sh[1][i]);
+    }
+    hdr->max_count = (unsigned)mx;
+    hdr->max_block_hits = (unsigned)ms;
   }
 }
-
-// LDS layout of the fill kernel (all dynamic, base 16-B aligned):
-//   [offs: RT+1 ints][orig: RT ints][wsum: RT/64 ints][pad to LDS_FIXED][segments: u64 ...]
-constexpr size_t LDS_FIXED = ((4 * (RT + 1) + 4 * RT + 4 * (RT / WAVE)) + 15) / 16 * 16;
 
 __global__ void pad_fill_kernel(int64_t* __restrict__ out, int64_t n, int64_t v) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = v;
 }
 
-template <bool SEG_IN_LDS>
-__global__ __launch_bounds__(RT) void fill_kernel(
-    const float4* __restrict__ sorted_q, int nq, const int32_t* __restrict__ q_off, int nb,
-    const BatchGrid* __restrict__ grids, const int32_t* __restrict__ start_s,
-    const float4* __restrict__ sorted_s, float r2, const int32_t* __restrict__ q_count, int width,
-    int64_t pad_value, int64_t* __restrict__ out, unsigned long long* __restrict__ gseg,
-    int64_t gseg_stride) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int* offs = reinterpret_cast<int*>(smem);
-  int* orig = offs + (RT + 1);
-  int* wsum = orig + RT;
-  unsigned long long* seg_lds = reinterpret_cast<unsigned long long*>(smem + LDS_FIXED);
+template <int RQ>
+int launch_count(const RadiusWs& w, const float4* sorted_q, int64_t nq, int nb, const int32_t* start_s, float r2,
+                 hipStream_t stream) {
+  using L = TravLds<RQ>;
+  const int blocks = (int)((nq + RQ - 1) / RQ);
+  hipLaunchKernelGGL((traverse_kernel<RQ, false, true>), dim3(blocks), dim3(L::THREADS), L::FIXED, stream, sorted_q,
+                     (int)nq, w.q_off, nb, w.grids, start_s, w.sorted_s, r2, w.q_count, w.blk_stats, 0, (int64_t)0,
+                     (int64_t*)nullptr, 0, (unsigned long long*)nullptr, (unsigned char*)nullptr);
+  hipLaunchKernelGGL(reduce_stats_kernel, dim3(1), dim3(1024), 0, stream, w.blk_stats, blocks, w.hdr);
+  GR_LAUNCH_CHECK();
+  return GR_OK;
+}
 
-  const int t = blockIdx.x * RT + threadIdx.x;
-  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
-  const bool valid = t < nq;
-  const int cnt = valid ? q_count[t] : 0;
-  // block exclusive scan of cnt
-  int inc = cnt;
-#pragma unroll
-  for (int d = 1; d < WAVE; d <<= 1) {
-    int v = __shfl_up(inc, d, WAVE);
-    if (lane >= d) inc += v;
+template <int RQ>
+int launch_fill(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns, int nb, float r2, int64_t width,
+                int64_t max_block_hits, int64_t* out, hipStream_t stream) {
+  using L = TravLds<RQ>;
+  const int blocks = (int)((nq + RQ - 1) / RQ);
+  const size_t lds = L::total(max_block_hits);
+  if (lds <= 160 * 1024) {
+    auto kern = traverse_kernel<RQ, true, true>;
+    if (lds > 64 * 1024)
+      GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 160 * 1024));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(L::THREADS), lds, stream, sorted_q, (int)nq, w.q_off, nb, w.grids,
+                       w.start, w.sorted_s, r2, w.q_count, w.blk_stats, (int)width, ns, out, (int)max_block_hits,
+                       (unsigned long long*)nullptr, (unsigned char*)nullptr);
+  } else {
+    // very dense neighbourhoods: hit lists live in a scratch allocation owned by this call
+    char* scratch = nullptr;
+    const size_t per_block = (size_t)max_block_hits;
+    GR_HIP(hipMallocAsync(reinterpret_cast<void**>(&scratch), (size_t)blocks * per_block * 9 + 256, stream));
+    unsigned long long* g_hits = reinterpret_cast<unsigned long long*>(scratch);
+    unsigned char* g_rows = reinterpret_cast<unsigned char*>(scratch + (size_t)blocks * per_block * 8);
+    hipLaunchKernelGGL((traverse_kernel<RQ, true, false>), dim3(blocks), dim3(L::THREADS), L::FIXED, stream,
+                       sorted_q, (int)nq, w.q_off, nb, w.grids, w.start, w.sorted_s, r2, w.q_count, w.blk_stats,
+                       (int)width, ns, out, (int)max_block_hits, g_hits, g_rows);
+    GR_HIP(hipFreeAsync(scratch, stream));
   }
-  if (lane == WAVE - 1) wsum[w] = inc;
-  __syncthreads();
-  int base = 0;
-#pragma unroll
-  for (int i = 0; i < RT / WAVE; ++i)
-    if (i < w) base += wsum[i];
-  const int my_off = base + inc - cnt;
-  offs[threadIdx.x] = my_off;
-  if (threadIdx.x == RT - 1) offs[RT] = my_off + cnt;
-
-  float4 qp = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (valid) qp = sorted_q[t];
-  orig[threadIdx.x] = valid ? __float_as_int(qp.w) : -1;
-
-  unsigned long long* seg =
-      SEG_IN_LDS ? (seg_lds + my_off) : (gseg + (int64_t)blockIdx.x * gseg_stride + my_off);
-  if (valid && cnt > 0) {
-    const int b = find_batch(q_off, nb, __float_as_int(qp.w));
-    const BatchGrid g = grids[b];
-    int n = 0;
-    for_each_hit(qp, g, start_s, sorted_s, r2, [&](float d, int idx) {
-      // key orders by (distance, index); d >= 0 so its bit pattern is monotone
-      const unsigned long long key =
-          ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)idx;
-      int j = n;
-      while (j > 0) {
-        const unsigned long long prev = seg[j - 1];
-        if (prev <= key) break;
-        seg[j] = prev;
-        --j;
-      }
-      seg[j] = key;
-      ++n;
-    });
-  }
-  __syncthreads();
-  // cooperative write-out: rows of this block, `width` int64 each, contiguous per row
-  const int rows = min(RT, nq - blockIdx.x * RT);
-  const unsigned long long* segb =
-      SEG_IN_LDS ? seg_lds : (gseg + (int64_t)blockIdx.x * gseg_stride);
-  const int total = rows * width;
-  for (int e = threadIdx.x; e < total; e += RT) {
-    const int r = e / width;
-    const int c = e - r * width;
-    const int o = offs[r];
-    const int n = offs[r + 1] - o;
-    const int64_t v = c < n ? (int64_t)(unsigned int)(segb[o + c] & 0xffffffffull) : pad_value;
-    out[(int64_t)orig[r] * width + c] = v;
-  }
+  GR_LAUNCH_CHECK();
+  return GR_OK;
 }
 
 }  // namespace
@@ -390,8 +566,8 @@ extern "C" int gr_radius_count(const float* q, const float* s, const int64_t* h_
   }
   const bool same = (q == s) && (nq == ns) && memcmp(h_q_lengths, h_s_lengths, sizeof(int64_t) * batch) == 0;
   // offsets (host -> device)
+  std::vector<int32_t> tmpv(3 * (batch + 1));  // q offsets | s offsets | bbox block offsets
   {
-    std::vector<int32_t> tmpv(2 * (batch + 1));
     int32_t* tmp = tmpv.data();
     tmp[0] = 0;
     tmp[batch + 1] = 0;
@@ -406,7 +582,7 @@ extern "C" int gr_radius_count(const float* q, const float* s, const int64_t* h_
   const int rows = same ? 1 : 2;
   GR_HIP(hipMemsetAsync(w.cnt, 0, sizeof(int32_t) * rows * (w.ccap + 1), stream));
   {
-    int rcb = compute_bbox(s, (int)ns, w.s_off, nb, w.bbox, stream);
+    int rcb = compute_bbox(s, tmpv.data() + batch + 1, tmpv.data() + 2 * (batch + 1), w.s_off, nb, w.bbox, w.blk_off, stream);
     if (rcb != GR_OK) return rcb;
   }
   hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(256), 0, stream, w.bbox, w.s_off, nb, radius, w.grids, w.hdr);
@@ -424,9 +600,8 @@ extern "C" int gr_radius_count(const float* q, const float* s, const int64_t* h_
                      w.s_cell, w.q_cell, start_s, start_q, cnt_s, cnt_q, w.sorted_s, w.sorted_q);
   const float4* sorted_q = same ? w.sorted_s : w.sorted_q;
   const float r2 = radius * radius;  // radius_neighbors_cpu.cpp:12 (fp32 product)
-  hipLaunchKernelGGL(count_kernel, dim3((nq + RT - 1) / RT), dim3(RT), 0, stream, sorted_q, (int)nq, w.q_off, nb,
-                     w.grids, start_s, w.sorted_s, r2, w.q_count, w.hdr);
-  GR_LAUNCH_CHECK();
+  rc = launch_count<RT>(w, sorted_q, nq, nb, start_s, r2, stream);
+  if (rc != GR_OK) return rc;
   RadiusHdr h;
   GR_HIP(hipMemcpyAsync(&h, w.hdr, sizeof(h), hipMemcpyDeviceToHost, stream));
   GR_HIP(hipStreamSynchronize(stream));
@@ -462,29 +637,5 @@ extern "C" int gr_radius_fill(const float* q, const float* s, int64_t nq, int64_
   const bool same = h_info[2] != 0;
   const float4* sorted_q = same ? w.sorted_s : w.sorted_q;
   const float r2 = radius * radius;
-  const int64_t max_block_hits = h_info[1];
-  const size_t lds_fixed = LDS_FIXED;
-  const size_t lds_seg = (size_t)max_block_hits * 8;
-  const int blocks = (int)((nq + RT - 1) / RT);
-  if (lds_fixed + lds_seg <= 64 * 1024) {
-    hipLaunchKernelGGL(fill_kernel<true>, dim3(blocks), dim3(RT), lds_fixed + lds_seg, stream, sorted_q, (int)nq,
-                       w.q_off, (int)batch, w.grids, w.start, w.sorted_s, r2, w.q_count, (int)width, ns, out,
-                       (unsigned long long*)nullptr, (int64_t)0);
-  } else if (lds_fixed + lds_seg <= 160 * 1024) {
-    GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fill_kernel<true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(fill_kernel<true>, dim3(blocks), dim3(RT), lds_fixed + lds_seg, stream, sorted_q, (int)nq,
-                       w.q_off, (int)batch, w.grids, w.start, w.sorted_s, r2, w.q_count, (int)width, ns, out,
-                       (unsigned long long*)nullptr, (int64_t)0);
-  } else {
-    // very dense neighbourhoods: segments live in a scratch allocation owned by this call
-    unsigned long long* gseg = nullptr;
-    GR_HIP(hipMallocAsync(reinterpret_cast<void**>(&gseg), (size_t)blocks * (size_t)max_block_hits * 8, stream));
-    hipLaunchKernelGGL(fill_kernel<false>, dim3(blocks), dim3(RT), lds_fixed, stream, sorted_q, (int)nq, w.q_off,
-                       (int)batch, w.grids, w.start, w.sorted_s, r2, w.q_count, (int)width, ns, out, gseg,
-                       max_block_hits);
-    GR_HIP(hipFreeAsync(gseg, stream));
-  }
-  GR_LAUNCH_CHECK();
-  return GR_OK;
+  return launch_fill<RT>(w, sorted_q, nq, ns, (int)batch, r2, width, h_info[1], out, stream);
 }
