@@ -29,6 +29,25 @@ SIGNATURES = {
 }
 
 
+class RasterView(ctypes.Structure):
+    """struct gr_raster_view (include/gaussreg_hip.h)."""
+    _fields_ = [("image_height", ctypes.c_int32), ("image_width", ctypes.c_int32),
+                ("tanfovx", c_f32), ("tanfovy", c_f32), ("bg", c_f32 * 3), ("scale_modifier", c_f32),
+                ("viewmatrix", c_f32 * 16), ("projmatrix", c_f32 * 16), ("campos", c_f32 * 3),
+                ("sh_degree", ctypes.c_int32), ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32)]
+
+
+SIGNATURES.update({
+    "gr_raster_geom_bytes": (c_size, [c_i64, c_int]),
+    "gr_raster_bin_bytes": (c_size, [c_i64, c_int, c_int, c_int]),
+    "gr_raster_preprocess": (c_int, [c_i64, c_int] + [c_void] * 7 + [ctypes.POINTER(RasterView), c_int, c_void,
+                                                                     c_void, c_size, c_i64p, c_void]),
+    "gr_raster_render": (c_int, [c_i64, ctypes.POINTER(RasterView), c_int, c_i64p, c_void, c_size, c_void, c_size,
+                                 c_void, c_void]),
+    "gr_raster_mark_visible": (c_int, [c_i64, c_void, ctypes.POINTER(c_f32), c_void, c_void]),
+})
+
+
 class HipLibraryError(RuntimeError):
     pass
 

@@ -1,0 +1,598 @@
+// 3D-Gaussian-splatting rasterizer forward for MI355X (gfx950), batched over views.
+//
+// Interface replaced: diff_gaussian_rasterization.GaussianRasterizer.forward (public upstream
+// graphdeco-inria/diff-gaussian-rasterization; NOT in the GaussReg tree).
+// Numerics contract: oracle/rasterizer_oracle.c -- every fp32 operation below is written in the
+// same order (fmaf where the oracle says fmaf, separate mul/add elsewhere; this TU is compiled
+// with -ffp-contract=off), so images and radii are compared bit-exact with the oracle.
+//
+// Pipeline per batch of V views over one set of P Gaussians:
+//   preprocess  1 thread / Gaussian, loops over the V cameras (inputs read once per batch;
+//               cov3D built once): cull, project, cov2D, conic, radius, tile rect, SH -> RGB
+//   scan        exclusive scan of tiles_touched per view (common.hip)      -> R_v on the host
+//   instances   key = ((view*tiles + tile) << 32) | depth_bits, value = Gaussian id
+//   sort        one stable radix sort for the whole batch (sort.hip)
+//   ranges      [start,end) of every (view, tile)
+//   blend       1 workgroup / tile (16x16 px, 4 waves): Gaussian parameters staged through LDS in
+//               batches of 256, front-to-back alpha blending, deterministic exp
+#include <vector>
+
+#include "common.hpp"
+
+namespace gr {
+namespace {
+
+constexpr int TILE = 16;
+constexpr int BLOCK = TILE * TILE;
+constexpr int MAX_VIEWS = 64;  // cameras per preprocess launch (constant-memory table)
+
+struct DevView {
+  float view[16];
+  float proj[16];
+  float campos[3];
+  float tanx, tany;
+  float fx, fy;
+  float scale_mod;
+  float bg[3];
+};
+
+__device__ __constant__ float SH_C0 = 0.28209479177387814f;
+__device__ __constant__ float SH_C1 = 0.4886025119029199f;
+__device__ __constant__ float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f,
+                                          0.31539156525252005f, -1.0925484305920792f,
+                                          0.5462742152960396f};
+__device__ __constant__ float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f,
+                                          -0.4570457994644658f, 0.3731763325901154f,
+                                          -0.4570457994644658f, 1.445305721320277f,
+                                          -0.5900435899266435f};
+
+// Deterministic expf (x <= 0): identical operation sequence to oracle_exp_det().
+__device__ __forceinline__ float exp_det(float x) {
+  x = fmaxf(x, -100.0f);
+  const float n = rintf(x * 1.44269504088896341f);
+  float r = fmaf(n, -0.693359375f, x);
+  r = fmaf(n, 2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = fmaf(p, r, 1.3981999507e-3f);
+  p = fmaf(p, r, 8.3334519073e-3f);
+  p = fmaf(p, r, 4.1665795894e-2f);
+  p = fmaf(p, r, 1.6666665459e-1f);
+  p = fmaf(p, r, 5.0000001201e-1f);
+  const float y = fmaf(p, r * r, r) + 1.0f;
+  return ldexpf(y, (int)n);
+}
+
+__device__ __forceinline__ void xform4x3(const float* M, const float* p, float* o) {
+  o[0] = fmaf(M[0], p[0], fmaf(M[4], p[1], fmaf(M[8], p[2], M[12])));
+  o[1] = fmaf(M[1], p[0], fmaf(M[5], p[1], fmaf(M[9], p[2], M[13])));
+  o[2] = fmaf(M[2], p[0], fmaf(M[6], p[1], fmaf(M[10], p[2], M[14])));
+}
+__device__ __forceinline__ void xform4x4(const float* M, const float* p, float* o) {
+  o[0] = fmaf(M[0], p[0], fmaf(M[4], p[1], fmaf(M[8], p[2], M[12])));
+  o[1] = fmaf(M[1], p[0], fmaf(M[5], p[1], fmaf(M[9], p[2], M[13])));
+  o[2] = fmaf(M[2], p[0], fmaf(M[6], p[1], fmaf(M[10], p[2], M[14])));
+  o[3] = fmaf(M[3], p[0], fmaf(M[7], p[1], fmaf(M[11], p[2], M[15])));
+}
+
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* sc, float mod, const float* q,
+                                                     float* c6) {
+  const float s0 = mod * sc[0], s1 = mod * sc[1], s2 = mod * sc[2];
+  const float r = q[0], x = q[1], y = q[2], z = q[3];
+  float R[3][3];
+  R[0][0] = 1.f - 2.f * (y * y + z * z);
+  R[0][1] = 2.f * (x * y - r * z);
+  R[0][2] = 2.f * (x * z + r * y);
+  R[1][0] = 2.f * (x * y + r * z);
+  R[1][1] = 1.f - 2.f * (x * x + z * z);
+  R[1][2] = 2.f * (y * z - r * x);
+  R[2][0] = 2.f * (x * z - r * y);
+  R[2][1] = 2.f * (y * z + r * x);
+  R[2][2] = 1.f - 2.f * (x * x + y * y);
+  float M[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    M[0][i] = s0 * R[i][0];
+    M[1][i] = s1 * R[i][1];
+    M[2][i] = s2 * R[i][2];
+  }
+#define GR_SIG(i, j) fmaf(M[0][i], M[0][j], fmaf(M[1][i], M[1][j], M[2][i] * M[2][j]))
+  c6[0] = GR_SIG(0, 0);
+  c6[1] = GR_SIG(0, 1);
+  c6[2] = GR_SIG(0, 2);
+  c6[3] = GR_SIG(1, 1);
+  c6[4] = GR_SIG(1, 2);
+  c6[5] = GR_SIG(2, 2);
+#undef GR_SIG
+}
+
+__device__ __forceinline__ void cov2d(const float* t_in, float fx, float fy, float tanx, float tany,
+                                      const float* c6, const float* V, float* out3) {
+  float t[3] = {t_in[0], t_in[1], t_in[2]};
+  const float limx = 1.3f * tanx, limy = 1.3f * tany;
+  const float txtz = t[0] / t[2], tytz = t[1] / t[2];
+  t[0] = fminf(limx, fmaxf(-limx, txtz)) * t[2];
+  t[1] = fminf(limy, fmaxf(-limy, tytz)) * t[2];
+  const float J00 = fx / t[2];
+  const float J02 = -(fx * t[0]) / (t[2] * t[2]);
+  const float J11 = fy / t[2];
+  const float J12 = -(fy * t[1]) / (t[2] * t[2]);
+  float A0[3], A1[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    A0[j] = fmaf(J00, V[j * 4 + 0], J02 * V[j * 4 + 2]);
+    A1[j] = fmaf(J11, V[j * 4 + 1], J12 * V[j * 4 + 2]);
+  }
+  const float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+  float B0[3], B1[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    B0[k] = fmaf(S[k][0], A0[0], fmaf(S[k][1], A0[1], S[k][2] * A0[2]));
+    B1[k] = fmaf(S[k][0], A1[0], fmaf(S[k][1], A1[1], S[k][2] * A1[2]));
+  }
+  out3[0] = fmaf(A0[0], B0[0], fmaf(A0[1], B0[1], A0[2] * B0[2])) + 0.3f;
+  out3[1] = fmaf(A1[0], B0[0], fmaf(A1[1], B0[1], A1[2] * B0[2]));
+  out3[2] = fmaf(A1[0], B1[0], fmaf(A1[1], B1[1], A1[2] * B1[2])) + 0.3f;
+}
+
+// sh: this Gaussian's coefficients, (M,3) row-major, already in registers/local memory
+template <typename ShLoad>
+__device__ __forceinline__ void sh_to_rgb(int deg, const float* pos, const float* campos,
+                                          ShLoad S, float* rgb) {
+  const float dx = pos[0] - campos[0], dy = pos[1] - campos[1], dz = pos[2] - campos[2];
+  const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float x = dx / len, y = dy / len, z = dz / len;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float res = SH_C0 * S(0, c);
+    if (deg > 0) {
+      res = res - SH_C1 * y * S(1, c) + SH_C1 * z * S(2, c) - SH_C1 * x * S(3, c);
+      if (deg > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        res = res + SH_C2[0] * xy * S(4, c) + SH_C2[1] * yz * S(5, c) +
+              SH_C2[2] * (2.0f * zz - xx - yy) * S(6, c) + SH_C2[3] * xz * S(7, c) +
+              SH_C2[4] * (xx - yy) * S(8, c);
+        if (deg > 2) {
+          res = res + SH_C3[0] * y * (3.0f * xx - yy) * S(9, c) + SH_C3[1] * xy * z * S(10, c) +
+                SH_C3[2] * y * (4.0f * zz - xx - yy) * S(11, c) +
+                SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * S(12, c) +
+                SH_C3[4] * x * (4.0f * zz - xx - yy) * S(13, c) +
+                SH_C3[5] * z * (xx - yy) * S(14, c) + SH_C3[6] * x * (xx - 3.0f * yy) * S(15, c);
+        }
+      }
+    }
+    res += 0.5f;
+    rgb[c] = fmaxf(res, 0.0f);
+  }
+}
+
+__device__ __forceinline__ void get_rect(float px, float py, int radius, int gx, int gy, int* rmin,
+                                         int* rmax) {
+  const float r = (float)radius;
+  rmin[0] = min(gx, max(0, (int)((px - r) / (float)TILE)));
+  rmin[1] = min(gy, max(0, (int)((py - r) / (float)TILE)));
+  rmax[0] = min(gx, max(0, (int)((px + r + (float)(TILE - 1)) / (float)TILE)));
+  rmax[1] = min(gy, max(0, (int)((py + r + (float)(TILE - 1)) / (float)TILE)));
+}
+
+// geometry state, one slab per view (SoA so the blend's gathers are aligned vector loads)
+struct Geom {
+  float* depth;          // [V][P]
+  float2* xy;            // [V][P]
+  float4* conic_opacity; // [V][P]
+  float4* rgb;           // [V][P] (w unused)
+  int32_t* tiles;        // [V][P] tiles touched, then exclusive offsets (in place)
+  int32_t* radius;       // [V][P] (copy of the caller's radii: render needs it)
+  int32_t* totals;       // [V]
+  DevView* views;        // [MAX_VIEWS] camera table (uniform loads)
+  int32_t* scan_ws;
+  size_t bytes;
+};
+
+Geom carve_geom(void* p, int64_t P, int V) {
+  Geom g;
+  Carver c(p);
+  g.depth = c.take<float>(P * V);
+  g.xy = c.take<float2>(P * V);
+  g.conic_opacity = c.take<float4>(P * V);
+  g.rgb = c.take<float4>(P * V);
+  g.tiles = c.take<int32_t>(P * V);
+  g.radius = c.take<int32_t>(P * V);
+  g.totals = c.take<int32_t>(V);
+  g.views = c.take<DevView>(MAX_VIEWS);
+  g.scan_ws = c.take<int32_t>(V * scan_ws_ints(P));
+  g.bytes = c.used();
+  return g;
+}
+
+struct Bin {
+  uint64_t* keys_a;
+  uint64_t* keys_b;
+  int32_t* vals_a;
+  int32_t* vals_b;
+  int2* ranges;  // [V * tiles]
+  void* sort_temp;
+  size_t sort_temp_bytes;
+  size_t bytes;
+};
+
+Bin carve_bin(void* p, int64_t R, int64_t vtiles) {
+  Bin b;
+  Carver c(p);
+  b.keys_a = c.take<uint64_t>(R);
+  b.keys_b = c.take<uint64_t>(R);
+  b.vals_a = c.take<int32_t>(R);
+  b.vals_b = c.take<int32_t>(R);
+  b.ranges = c.take<int2>(vtiles);
+  b.sort_temp_bytes = sort_pairs_temp_bytes(R);
+  b.sort_temp = c.take<char>(b.sort_temp_bytes);
+  b.bytes = c.used();
+  return b;
+}
+
+// ------------------------------------------------------------------------------------ preprocess
+template <bool HAS_SH, bool HAS_COV>
+__global__ __launch_bounds__(256) void preprocess_kernel(
+    int P, int D, int M, int V, const DevView* __restrict__ views, const float* __restrict__ means3D,
+    const float* __restrict__ shs, const float* __restrict__ colors_precomp,
+    const float* __restrict__ opacities, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, int W, int H,
+    int32_t* __restrict__ radii, int32_t* __restrict__ radius_g, float* __restrict__ depth,
+    float2* __restrict__ xy, float4* __restrict__ conic_opacity, float4* __restrict__ rgb_out,
+    int32_t* __restrict__ tiles) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const float p[3] = {means3D[3 * (int64_t)i], means3D[3 * (int64_t)i + 1], means3D[3 * (int64_t)i + 2]};
+  const float opacity = opacities[i];
+  float c6[6];
+  float sc[3], rot[4];
+  if (HAS_COV) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * (int64_t)i + k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sc[k] = scales[3 * (int64_t)i + k];
+    const float4 q = reinterpret_cast<const float4*>(rotations)[i];
+    rot[0] = q.x; rot[1] = q.y; rot[2] = q.z; rot[3] = q.w;
+  }
+  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  const float* sh = HAS_SH ? shs + (int64_t)i * M * 3 : nullptr;
+  float cpre[3] = {0.f, 0.f, 0.f};
+  if (!HAS_SH) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cpre[k] = colors_precomp[3 * (int64_t)i + k];
+  }
+  float mod_prev = 0.f;
+  bool have_cov = HAS_COV;
+  for (int v = 0; v < V; ++v) {
+    const DevView& cam = views[v];
+    const int64_t o = (int64_t)v * P + i;
+    int out_radius = 0, out_tiles = 0;
+    float out_depth = 0.f;
+    float2 out_xy = make_float2(0.f, 0.f);
+    float4 out_co = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 out_rgb = make_float4(0.f, 0.f, 0.f, 0.f);
+    float pv[3];
+    xform4x3(cam.view, p, pv);
+    if (pv[2] > 0.2f) {
+      float ph[4];
+      xform4x4(cam.proj, p, ph);
+      const float pw = 1.0f / (ph[3] + 0.0000001f);
+      const float pprojx = ph[0] * pw, pprojy = ph[1] * pw;
+      if (!HAS_COV && (!have_cov || cam.scale_mod != mod_prev)) {
+        cov3d_from_scale_rot(sc, cam.scale_mod, rot, c6);
+        have_cov = true;
+        mod_prev = cam.scale_mod;
+      }
+      float cv[3];
+      cov2d(pv, cam.fx, cam.fy, cam.tanx, cam.tany, c6, cam.view, cv);
+      const float det = cv[0] * cv[2] - cv[1] * cv[1];
+      if (det != 0.0f) {
+        const float det_inv = 1.f / det;
+        const float mid = 0.5f * (cv[0] + cv[2]);
+        const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float l1 = mid + sq, l2 = mid - sq;
+        const float my_radius = ceilf(3.f * sqrtf(fmaxf(l1, l2)));
+        const float px = ((pprojx + 1.0f) * (float)W - 1.0f) * 0.5f;
+        const float py = ((pprojy + 1.0f) * (float)H - 1.0f) * 0.5f;
+        int rmin[2], rmax[2];
+        get_rect(px, py, (int)my_radius, gx, gy, rmin, rmax);
+        const int ntile = (rmax[0] - rmin[0]) * (rmax[1] - rmin[1]);
+        if (ntile != 0) {
+          float rgb[3];
+          if (HAS_SH) {
+            sh_to_rgb(D, p, cam.campos, [&](int k, int c) { return sh[k * 3 + c]; }, rgb);
+          } else {
+            rgb[0] = cpre[0]; rgb[1] = cpre[1]; rgb[2] = cpre[2];
+          }
+          out_depth = pv[2];
+          out_radius = (int)my_radius;
+          out_xy = make_float2(px, py);
+          out_co = make_float4(cv[2] * det_inv, -cv[1] * det_inv, cv[0] * det_inv, opacity);
+          out_rgb = make_float4(rgb[0], rgb[1], rgb[2], 0.f);
+          out_tiles = ntile;
+        }
+      }
+    }
+    radii[o] = out_radius;
+    radius_g[o] = out_radius;
+    depth[o] = out_depth;
+    xy[o] = out_xy;
+    conic_opacity[o] = out_co;
+    rgb_out[o] = out_rgb;
+    tiles[o] = out_tiles;
+  }
+}
+
+// ------------------------------------------------------------------------------------ instances
+__global__ __launch_bounds__(256) void instances_kernel(
+    int P, int V, int W, int H, const int32_t* __restrict__ radii, const float* __restrict__ depth,
+    const float2* __restrict__ xy, const int32_t* __restrict__ offsets /* exclusive, per view */,
+    const int32_t* __restrict__ totals /* [V] */, uint64_t* __restrict__ keys,
+    int32_t* __restrict__ vals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int v = blockIdx.y;
+  if (i >= P) return;
+  const int64_t o = (int64_t)v * P + i;
+  const int r = radii[o];
+  if (r <= 0) return;
+  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  const float2 p = xy[o];
+  int rmin[2], rmax[2];
+  get_rect(p.x, p.y, r, gx, gy, rmin, rmax);
+  int64_t off = offsets[o];
+  for (int u = 0; u < v; ++u) off += totals[u];  // uniform: scalar loads
+  const uint64_t db = (uint64_t)__float_as_uint(depth[o]);
+  const uint64_t tile_base = (uint64_t)v * (uint64_t)(gx * gy);
+  for (int y = rmin[1]; y < rmax[1]; ++y)
+    for (int x = rmin[0]; x < rmax[0]; ++x) {
+      keys[off] = ((tile_base + (uint64_t)(y * gx + x)) << 32) | db;
+      vals[off] = i;
+      ++off;
+    }
+}
+
+__global__ __launch_bounds__(256) void ranges_kernel(int64_t R, const uint64_t* __restrict__ keys,
+                                                     int2* __restrict__ ranges) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= R) return;
+  const uint32_t t = (uint32_t)(keys[k] >> 32);
+  if (k == 0) {
+    ranges[t].x = 0;
+  } else {
+    const uint32_t tp = (uint32_t)(keys[k - 1] >> 32);
+    if (t != tp) {
+      ranges[tp].y = (int)k;
+      ranges[t].x = (int)k;
+    }
+  }
+  if (k == R - 1) ranges[t].y = (int)R;
+}
+
+// ------------------------------------------------------------------------------------ blend
+__global__ __launch_bounds__(BLOCK) void blend_kernel(
+    int P, int W, int H, const DevView* __restrict__ views, const int2* __restrict__ ranges,
+    const int32_t* __restrict__ point_list, const float2* __restrict__ xy, const float4* __restrict__ conic_opacity,
+    const float4* __restrict__ rgb, float* __restrict__ out_color) {
+  __shared__ float2 s_xy[BLOCK];
+  __shared__ float4 s_co[BLOCK];
+  __shared__ float4 s_rgb[BLOCK];
+  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  const int v = blockIdx.z;
+  const int tile = blockIdx.y * gx + blockIdx.x;
+  // 16x16 pixel tile; thread -> pixel so that one wave covers a 16x4 strip
+  const int lx = threadIdx.x % TILE, ly = threadIdx.x / TILE;
+  const int pxi = blockIdx.x * TILE + lx, pyi = blockIdx.y * TILE + ly;
+  const bool inside = pxi < W && pyi < H;
+  const float pfx = (float)pxi, pfy = (float)pyi;
+  const int2 range = ranges[(int64_t)v * gx * gy + tile];
+  const int64_t goff = (int64_t)v * P;
+  bool done = !inside;
+  float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+  for (int start = range.x; start < range.y; start += BLOCK) {
+    if (__syncthreads_and(done)) break;
+    const int k = start + threadIdx.x;
+    if (k < range.y) {
+      const int64_t id = goff + point_list[k];
+      s_xy[threadIdx.x] = xy[id];
+      s_co[threadIdx.x] = conic_opacity[id];
+      s_rgb[threadIdx.x] = rgb[id];
+    }
+    __syncthreads();
+    const int nb = min(BLOCK, range.y - start);
+    for (int j = 0; j < nb && !done; ++j) {
+      const float2 g = s_xy[j];
+      const float4 co = s_co[j];
+      const float dx = g.x - pfx, dy = g.y - pfy;
+      const float q = fmaf(co.x * dx, dx, (co.z * dy) * dy);
+      const float power = fmaf(-0.5f, q, -((co.y * dx) * dy));
+      if (power > 0.0f) continue;
+      // exact early-out: for opacity <= 1, power < -5.6 implies alpha < 1/255 (exp(-5.6) = 0.0037)
+      if (power < -5.6f && co.w <= 1.0f) continue;
+      const float alpha = fminf(0.99f, co.w * exp_det(power));
+      if (alpha < 1.0f / 255.0f) continue;
+      const float test_T = T * (1.0f - alpha);
+      if (test_T < 0.0001f) {
+        done = true;
+        continue;
+      }
+      const float4 col = s_rgb[j];
+      const float w = alpha * T;
+      C0 = fmaf(col.x, w, C0);
+      C1 = fmaf(col.y, w, C1);
+      C2 = fmaf(col.z, w, C2);
+      T = test_T;
+    }
+  }
+  if (inside) {
+    const DevView& cam = views[v];
+    float* o = out_color + (int64_t)v * 3 * H * W + (int64_t)pyi * W + pxi;
+    o[0] = fmaf(T, cam.bg[0], C0);
+    o[(int64_t)H * W] = fmaf(T, cam.bg[1], C1);
+    o[2 * (int64_t)H * W] = fmaf(T, cam.bg[2], C2);
+  }
+}
+
+__global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* __restrict__ means3D,
+                                                           float v2, float v6, float v10, float v14,
+                                                           uint8_t* __restrict__ present) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const float z = fmaf(v2, means3D[3 * (int64_t)i],
+                       fmaf(v6, means3D[3 * (int64_t)i + 1], fmaf(v10, means3D[3 * (int64_t)i + 2], v14)));
+  present[i] = z > 0.2f ? 1 : 0;
+}
+
+int check_views(const gr_raster_view* h_views, int num_views) {
+  GR_REQUIRE(h_views != nullptr && num_views >= 1, "need at least one view");
+  GR_REQUIRE(num_views <= MAX_VIEWS, "at most %d views per call (got %d)", MAX_VIEWS, num_views);
+  for (int v = 0; v < num_views; ++v) {
+    GR_REQUIRE(h_views[v].image_width == h_views[0].image_width &&
+                   h_views[v].image_height == h_views[0].image_height &&
+                   h_views[v].sh_degree == h_views[0].sh_degree,
+               "all views of one call must share image size and sh_degree");
+    GR_REQUIRE(h_views[v].image_width > 0 && h_views[v].image_height > 0, "bad image size");
+    GR_REQUIRE(h_views[v].sh_degree >= 0 && h_views[v].sh_degree <= 3, "sh_degree must be 0..3");
+  }
+  return GR_OK;
+}
+
+// dv must stay alive until `stream` is synchronised by the caller
+int upload_views(const gr_raster_view* h_views, int num_views, std::vector<DevView>& dv, DevView* d_views,
+                 hipStream_t stream) {
+  dv.resize(num_views);
+  for (int v = 0; v < num_views; ++v) {
+    const gr_raster_view& s = h_views[v];
+    DevView& d = dv[v];
+    memcpy(d.view, s.viewmatrix, sizeof(d.view));
+    memcpy(d.proj, s.projmatrix, sizeof(d.proj));
+    memcpy(d.campos, s.campos, sizeof(d.campos));
+    memcpy(d.bg, s.bg, sizeof(d.bg));
+    d.tanx = s.tanfovx;
+    d.tany = s.tanfovy;
+    d.fx = (float)s.image_width / (2.0f * s.tanfovx);
+    d.fy = (float)s.image_height / (2.0f * s.tanfovy);
+    d.scale_mod = s.scale_modifier;
+  }
+  GR_HIP(hipMemcpyAsync(d_views, dv.data(), sizeof(DevView) * num_views, hipMemcpyHostToDevice, stream));
+  return GR_OK;
+}
+
+}  // namespace
+}  // namespace gr
+
+using namespace gr;
+
+extern "C" size_t gr_raster_geom_bytes(int64_t P, int num_views) {
+  if (P < 0 || num_views < 1) return 0;
+  return carve_geom(nullptr, P, num_views).bytes;
+}
+
+extern "C" size_t gr_raster_bin_bytes(int64_t total_rendered, int width, int height, int num_views) {
+  if (total_rendered < 0 || width <= 0 || height <= 0 || num_views < 1) return 0;
+  const int64_t tiles = (int64_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+  return carve_bin(nullptr, total_rendered, tiles * num_views).bytes;
+}
+
+extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, const float* shs,
+                                    const float* colors_precomp, const float* opacities,
+                                    const float* scales, const float* rotations,
+                                    const float* cov3D_precomp, const gr_raster_view* h_views,
+                                    int num_views, int32_t* radii, void* geom, size_t geom_bytes,
+                                    int64_t* h_num_rendered, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  int rc = check_views(h_views, num_views);
+  if (rc != GR_OK) return rc;
+  GR_REQUIRE(h_num_rendered != nullptr, "h_num_rendered is null");
+  for (int v = 0; v < num_views; ++v) h_num_rendered[v] = 0;
+  GR_REQUIRE(P >= 0 && P < (1ll << 31) - 1, "P out of range");
+  if (P == 0) return GR_OK;
+  GR_REQUIRE(means3D && opacities && radii, "means3D / opacities / radii must be non-null");
+  GR_REQUIRE((shs != nullptr) != (colors_precomp != nullptr),
+             "Please provide excatly one of either SHs or precomputed colors!");
+  GR_REQUIRE(((scales != nullptr && rotations != nullptr) != (cov3D_precomp != nullptr)) &&
+                 ((scales != nullptr) == (rotations != nullptr)),
+             "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+  const int D = h_views[0].sh_degree;
+  if (shs) GR_REQUIRE(M >= (D + 1) * (D + 1), "shs has %d coefficients, sh_degree %d needs %d", M, D, (D + 1) * (D + 1));
+  Geom g = carve_geom(geom, P, num_views);
+  if (!geom || geom_bytes < g.bytes) {
+    set_error("raster geometry buffer too small: need %zu bytes, got %zu", g.bytes, geom_bytes);
+    return GR_ERR_WORKSPACE;
+  }
+  std::vector<DevView> dv;  // alive until the synchronise below
+  rc = upload_views(h_views, num_views, dv, g.views, stream);
+  if (rc != GR_OK) return rc;
+  const int W = h_views[0].image_width, H = h_views[0].image_height;
+  const dim3 blk(256), grd((unsigned)((P + 255) / 256));
+#define GR_PRE(SH, COV)                                                                           \
+  hipLaunchKernelGGL((preprocess_kernel<SH, COV>), grd, blk, 0, stream, (int)P, D, M, num_views,   \
+                     g.views, means3D, shs, colors_precomp, opacities, scales, rotations,          \
+                     cov3D_precomp, W, H, radii, g.radius, g.depth, g.xy, g.conic_opacity, g.rgb,  \
+                     g.tiles)
+  if (shs && cov3D_precomp) GR_PRE(true, true);
+  else if (shs) GR_PRE(true, false);
+  else if (cov3D_precomp) GR_PRE(false, true);
+  else GR_PRE(false, false);
+#undef GR_PRE
+  GR_LAUNCH_CHECK();
+  rc = exclusive_scan_i32(g.tiles, g.tiles, P, num_views, P, g.scan_ws, g.totals, stream);
+  if (rc != GR_OK) return rc;
+  std::vector<int32_t> tot(num_views);
+  GR_HIP(hipMemcpyAsync(tot.data(), g.totals, sizeof(int32_t) * num_views, hipMemcpyDeviceToHost, stream));
+  GR_HIP(hipStreamSynchronize(stream));
+  for (int v = 0; v < num_views; ++v) h_num_rendered[v] = tot[v];
+  return GR_OK;
+}
+
+extern "C" int gr_raster_render(int64_t P, const gr_raster_view* h_views, int num_views,
+                                const int64_t* h_num_rendered, const void* geom, size_t geom_bytes,
+                                void* bin, size_t bin_bytes, float* out_color, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  int rc = check_views(h_views, num_views);
+  if (rc != GR_OK) return rc;
+  GR_REQUIRE(out_color != nullptr && h_num_rendered != nullptr, "null argument");
+  const int W = h_views[0].image_width, H = h_views[0].image_height;
+  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  const int64_t vtiles = (int64_t)gx * gy * num_views;
+  GR_REQUIRE(vtiles < (1ll << 31), "too many tiles");
+  int64_t R = 0;
+  for (int v = 0; v < num_views; ++v) R += h_num_rendered[v];
+  GR_REQUIRE(R < (1ll << 31) - 1, "too many rendered instances (%lld)", (long long)R);
+  Geom g = carve_geom(const_cast<void*>(geom), P, num_views);
+  GR_REQUIRE(P == 0 || (geom && geom_bytes >= g.bytes), "geometry buffer missing or too small");
+  Bin b = carve_bin(bin, R, vtiles);
+  if (!bin || bin_bytes < b.bytes) {
+    set_error("raster binning buffer too small: need %zu bytes, got %zu", b.bytes, bin_bytes);
+    return GR_ERR_WORKSPACE;
+  }
+  GR_HIP(hipMemsetAsync(b.ranges, 0, sizeof(int2) * vtiles, stream));
+  const int32_t* point_list = b.vals_b;
+  if (R > 0) {
+    hipLaunchKernelGGL(instances_kernel, dim3((unsigned)((P + 255) / 256), num_views), dim3(256), 0, stream, (int)P,
+                       num_views, W, H, g.radius, g.depth, g.xy, g.tiles, g.totals, b.keys_a, b.vals_a);
+    GR_LAUNCH_CHECK();
+    int bits = 0;
+    while ((1ll << bits) < vtiles) ++bits;
+    rc = sort_pairs_u64_i32(b.sort_temp, b.sort_temp_bytes, b.keys_a, b.keys_b, b.vals_a, b.vals_b, R, 0, 32 + bits,
+                            stream);
+    if (rc != GR_OK) return rc;
+    hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, R, b.keys_b, b.ranges);
+    GR_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(blend_kernel, dim3(gx, gy, num_views), dim3(BLOCK), 0, stream, (int)P, W, H, g.views, b.ranges,
+                     point_list, g.xy, g.conic_opacity, g.rgb, out_color);
+  GR_LAUNCH_CHECK();
+  return GR_OK;
+}
+
+extern "C" int gr_raster_mark_visible(int64_t P, const float* means3D, const float* h_viewmatrix,
+                                      uint8_t* present, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GR_REQUIRE(P >= 0 && h_viewmatrix != nullptr, "bad argument");
+  if (P == 0) return GR_OK;
+  GR_REQUIRE(means3D && present, "null argument");
+  hipLaunchKernelGGL(mark_visible_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, (int)P, means3D,
+                     h_viewmatrix[2], h_viewmatrix[6], h_viewmatrix[10], h_viewmatrix[14], present);
+  GR_LAUNCH_CHECK();
+  return GR_OK;
+}

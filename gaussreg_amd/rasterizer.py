@@ -1,0 +1,149 @@
+"""Mirror of ``diff_gaussian_rasterization`` (forward only) on the HIP rasterizer.
+
+The package is NOT part of the GaussReg tree; the API below is the public
+upstream one (graphdeco-inria/diff-gaussian-rasterization, diff_gaussian_rasterization/__init__.py):
+
+    GaussianRasterizationSettings(image_height, image_width, tanfovx, tanfovy, bg, scale_modifier,
+                                  viewmatrix, projmatrix, sh_degree, campos, prefiltered, debug)
+    GaussianRasterizer(raster_settings).forward(means3D, means2D, opacities, shs=None,
+        colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None) -> (color, radii)
+    GaussianRasterizer.markVisible(positions) -> BoolTensor
+
+plus `rasterize_views(...)`: many cameras over one Gaussian set in one launch sequence (the
+throughput path: per-Gaussian inputs are read once per batch).  Forward only: outputs carry no
+autograd graph (fine registration in GaussReg only renders).
+"""
+import ctypes
+from typing import NamedTuple, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _view_struct(rs: GaussianRasterizationSettings) -> _lib.RasterView:
+    v = _lib.RasterView()
+    v.image_height, v.image_width = int(rs.image_height), int(rs.image_width)
+    v.tanfovx, v.tanfovy = float(rs.tanfovx), float(rs.tanfovy)
+    v.scale_modifier = float(rs.scale_modifier)
+    v.sh_degree = int(rs.sh_degree)
+    v.prefiltered, v.debug = int(bool(rs.prefiltered)), int(bool(rs.debug))
+    bg = rs.bg.detach().to("cpu", torch.float32).reshape(-1).tolist()
+    vm = rs.viewmatrix.detach().to("cpu", torch.float32).reshape(-1).tolist()
+    pm = rs.projmatrix.detach().to("cpu", torch.float32).reshape(-1).tolist()
+    cp = rs.campos.detach().to("cpu", torch.float32).reshape(-1).tolist()
+    if len(bg) != 3 or len(vm) != 16 or len(pm) != 16 or len(cp) != 3:
+        raise ValueError("bg/campos must have 3 elements, viewmatrix/projmatrix 16")
+    v.bg[:] = bg
+    v.viewmatrix[:] = vm
+    v.projmatrix[:] = pm
+    v.campos[:] = cp
+    return v
+
+
+def _dev_f32(t: Optional[torch.Tensor], dev, name):
+    if t is None or t.numel() == 0:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a tensor")
+    return t.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+
+def rasterize_views(settings: Sequence[GaussianRasterizationSettings], means3D, opacities, shs=None,
+                    colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+    """Render the same Gaussians from len(settings) cameras.
+
+    Returns (color (V,3,H,W) f32, radii (V,P) i32, num_rendered list[int])."""
+    dev = _lib.require_gpu()
+    L = _lib.lib()
+    if means3D.is_cuda:
+        dev = means3D.device
+    if (shs is None or shs.numel() == 0) == (colors_precomp is None or colors_precomp.numel() == 0):
+        raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+    has_sr = not (scales is None or scales.numel() == 0 or rotations is None or rotations.numel() == 0)
+    has_cov = not (cov3D_precomp is None or cov3D_precomp.numel() == 0)
+    if has_sr == has_cov or ((scales is None or scales.numel() == 0) != (rotations is None or rotations.numel() == 0)):
+        raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+    V = len(settings)
+    if V < 1:
+        raise ValueError("need at least one view")
+    views = (_lib.RasterView * V)(*[_view_struct(s) for s in settings])
+    H, W = int(settings[0].image_height), int(settings[0].image_width)
+    m = _dev_f32(means3D, dev, "means3D")
+    if m.dim() != 2 or m.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    P = m.shape[0]
+    op = _dev_f32(opacities, dev, "opacities")
+    sh = _dev_f32(shs, dev, "shs")
+    cp = _dev_f32(colors_precomp, dev, "colors_precomp")
+    sc = _dev_f32(scales, dev, "scales") if has_sr else None
+    rot = _dev_f32(rotations, dev, "rotations") if has_sr else None
+    cov = _dev_f32(cov3D_precomp, dev, "cov3D_precomp") if has_cov else None
+    M = 0 if sh is None else sh.reshape(P, -1, 3).shape[1]
+    color = torch.empty((V, 3, H, W), dtype=torch.float32, device=dev)
+    radii = torch.zeros((V, P), dtype=torch.int32, device=dev)
+    nr = (ctypes.c_int64 * V)()
+    with torch.cuda.device(dev):
+        st = _lib.stream_ptr(dev)
+        geom = torch.empty(L.gr_raster_geom_bytes(P, V) + 256, dtype=torch.uint8, device=dev)
+        _lib.check(L.gr_raster_preprocess(P, M, _lib.ptr(m), _lib.ptr(sh), _lib.ptr(cp), _lib.ptr(op), _lib.ptr(sc),
+                                          _lib.ptr(rot), _lib.ptr(cov), views, V, _lib.ptr(radii), _lib.ptr(geom),
+                                          geom.numel(), nr, st))
+        total = sum(int(nr[v]) for v in range(V))
+        binb = torch.empty(L.gr_raster_bin_bytes(total, W, H, V) + 256, dtype=torch.uint8, device=dev)
+        _lib.check(L.gr_raster_render(P, views, V, nr, _lib.ptr(geom), geom.numel(), _lib.ptr(binb), binb.numel(),
+                                      _lib.ptr(color), st))
+    return color, radii, [int(nr[v]) for v in range(V)]
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    color, radii, _ = rasterize_views([raster_settings], means3D, opacities, sh, colors_precomp, scales, rotations,
+                                      cov3Ds_precomp)
+    return color[0], radii[0]
+
+
+class GaussianRasterizer(torch.nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        with torch.no_grad():
+            dev = _lib.require_gpu()
+            L = _lib.lib()
+            p = positions.detach().to(device=positions.device if positions.is_cuda else dev,
+                                      dtype=torch.float32).contiguous()
+            present = torch.zeros((p.shape[0],), dtype=torch.uint8, device=p.device)
+            vm = (ctypes.c_float * 16)(*self.raster_settings.viewmatrix.detach().to("cpu", torch.float32)
+                                       .reshape(-1).tolist())
+            with torch.cuda.device(p.device):
+                _lib.check(L.gr_raster_mark_visible(p.shape[0], _lib.ptr(p), vm, _lib.ptr(present),
+                                                    _lib.stream_ptr(p.device)))
+            return present.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, rs)

@@ -83,6 +83,55 @@ int gr_grid_subsample(const float* points, const int64_t* h_lengths, int64_t n, 
                       float voxel_size, int order_mode, float* out_points, int64_t* h_out_lengths,
                       int64_t* h_total_m, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * 3D-Gaussian-splatting rasterizer, forward only -- the op GaussReg's fine-registration rendering
+ * needs (BASELINE.json north_star).  NOT PRESENT in the reference tree (the only
+ * trace is the acknowledgement at README.md:150); the interface replaced is the public
+ *   diff_gaussian_rasterization.GaussianRasterizer.forward / .markVisible
+ *   (graphdeco-inria/diff-gaussian-rasterization: rasterize_points.cu RasterizeGaussiansCUDA,
+ *    cuda_rasterizer/rasterizer_impl.cu CudaRasterizer::Rasterizer::forward / markVisible)
+ * with the same argument meaning.  Algorithm + numerics contract: oracle/rasterizer_oracle.c
+ * (the HIP image is bit-identical to that restatement).
+ *
+ * Batched over views: one Gaussian set, `num_views` cameras (HOST array of gr_raster_view), so
+ * per-Gaussian inputs are read once per batch.  Two calls because the number of (tile, Gaussian)
+ * instances R is data dependent (upstream syncs at the same place):
+ *   gr_raster_preprocess : cull / project / cov2D / SH->RGB / tile counts / prefix sums into
+ *                          `geom` (size gr_raster_geom_bytes), SYNCHRONISES `stream`,
+ *                          h_num_rendered[v] = R_v.  Also writes radii (num_views, P) int32.
+ *   gr_raster_render     : instance keys, radix sort by (view, tile, depth), tile ranges, per-tile
+ *                          front-to-back alpha blend -> out_color (num_views, 3, H, W) fp32.
+ *                          `bin` is scratch of size gr_raster_bin_bytes(sum R_v, ...).
+ * Exactly one of shs / colors_precomp and exactly one of (scales, rotations) / cov3D_precomp is
+ * non-null.  All views of one call share image size and SH degree (checked).
+ */
+typedef struct gr_raster_view {
+  int32_t image_height, image_width;
+  float tanfovx, tanfovy;
+  float bg[3];
+  float scale_modifier;
+  float viewmatrix[16]; /* as the Python API passes it: world->view transposed, read column-major */
+  float projmatrix[16]; /* full projection, same convention */
+  float campos[3];
+  int32_t sh_degree;
+  int32_t prefiltered;
+  int32_t debug;
+} gr_raster_view;
+
+size_t gr_raster_geom_bytes(int64_t P, int num_views);
+size_t gr_raster_bin_bytes(int64_t total_rendered, int width, int height, int num_views);
+int gr_raster_preprocess(int64_t P, int sh_coeffs, const float* means3D, const float* shs,
+                         const float* colors_precomp, const float* opacities, const float* scales,
+                         const float* rotations, const float* cov3D_precomp,
+                         const gr_raster_view* h_views, int num_views, int32_t* radii, void* geom,
+                         size_t geom_bytes, int64_t* h_num_rendered, void* stream);
+int gr_raster_render(int64_t P, const gr_raster_view* h_views, int num_views,
+                     const int64_t* h_num_rendered, const void* geom, size_t geom_bytes, void* bin,
+                     size_t bin_bytes, float* out_color, void* stream);
+/* present[i] = 1 iff Gaussian i passes the near-plane test of `viewmatrix` (markVisible). */
+int gr_raster_mark_visible(int64_t P, const float* means3D, const float* h_viewmatrix,
+                           uint8_t* present, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

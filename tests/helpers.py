@@ -53,3 +53,28 @@ def assert_neighbors_equal_up_to_ties(got, want, q, s, q_lengths, s_lengths):
             i = j + 1
         n_tie_rows += 1
     return n_tie_rows
+
+
+# ---------------------------------------------------------------- rasterizer scenes
+def raster_scene(P, W, H, seed=0, sh_degree=3, V=1):
+    from gaussreg_amd import synthetic
+    g = synthetic.gaussians_c2(P, seed, sh_degree=3)
+    cams = synthetic.camera_ring(V, W, H, seed)
+    return g, cams
+
+
+def oracle_render(g, cam, *, sh_degree=3, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, colors_precomp=None,
+                  cov3D_precomp=None):
+    from oracle import capi
+    kw = dict(viewmatrix=cam["viewmatrix"], projmatrix=cam["projmatrix"], campos=cam["campos"], bg=np.asarray(bg, np.float32),
+              W=cam["image_width"], H=cam["image_height"], tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],
+              sh_degree=sh_degree, scale_modifier=scale_modifier)
+    if colors_precomp is None:
+        kw["shs"] = g["shs"]
+    else:
+        kw["colors_precomp"] = colors_precomp
+    if cov3D_precomp is None:
+        kw["scales"], kw["rotations"] = g["scales"], g["rotations"]
+    else:
+        kw["cov3D_precomp"] = cov3D_precomp
+    return capi.rasterize_forward(g["means3D"], g["opacities"], **kw)
