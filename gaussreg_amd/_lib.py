@@ -18,6 +18,9 @@ c_i64p = ctypes.POINTER(ctypes.c_int64)
 SIGNATURES = {
     "gr_last_error": (ctypes.c_char_p, []),
     "gr_version": (c_int, []),
+    "gr_timing_enable": (None, [c_int]),
+    "gr_timing_reset": (None, []),
+    "gr_timing_read": (c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), c_i64p]),
     "gr_radius_workspace_bytes": (c_size, [c_i64, c_i64, c_i64]),
     "gr_radius_count": (c_int, [c_void, c_void, c_i64p, c_i64p, c_i64, c_i64, c_i64, c_f32, c_void, c_size,
                                 c_i64p, c_void]),

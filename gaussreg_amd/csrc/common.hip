@@ -1,4 +1,6 @@
 // Error plumbing + a small multi-row exclusive scan used by the binning kernels.
+#include <mutex>
+#include <string>
 #include <vector>
 
 #include "common.hpp"
@@ -12,6 +14,34 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// ------------------------------------------------------------------ kernel timing registry
+namespace {
+struct TimingRec {
+  std::string name;
+  hipEvent_t start, stop;
+};
+std::mutex g_tmutex;
+std::vector<TimingRec> g_trecs;
+bool g_timing_on = false;
+}  // namespace
+
+KernelTimer::KernelTimer(const char* name, hipStream_t stream) : slot_(-1), stream_(stream) {
+  if (!g_timing_on) return;
+  std::lock_guard<std::mutex> lk(g_tmutex);
+  TimingRec r;
+  r.name = name;
+  if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
+  (void)hipEventRecord(r.start, stream);
+  g_trecs.push_back(r);
+  slot_ = (int)g_trecs.size() - 1;
+}
+
+KernelTimer::~KernelTimer() {
+  if (slot_ < 0) return;
+  std::lock_guard<std::mutex> lk(g_tmutex);
+  (void)hipEventRecord(g_trecs[slot_].stop, stream_);
 }
 
 // ------------------------------------------------------------------ scan
@@ -200,3 +230,35 @@ int exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int rows, int
 
 extern "C" const char* gr_last_error(void) { return gr::g_err; }
 extern "C" int gr_version(void) { return 1000; }
+
+extern "C" void gr_timing_enable(int on) {
+  std::lock_guard<std::mutex> lk(gr::g_tmutex);
+  gr::g_timing_on = on != 0;
+}
+
+extern "C" void gr_timing_reset(void) {
+  std::lock_guard<std::mutex> lk(gr::g_tmutex);
+  for (auto& r : gr::g_trecs) {
+    (void)hipEventDestroy(r.start);
+    (void)hipEventDestroy(r.stop);
+  }
+  gr::g_trecs.clear();
+}
+
+extern "C" int gr_timing_read(const char* name, double* total_ms, int64_t* calls) {
+  std::lock_guard<std::mutex> lk(gr::g_tmutex);
+  double tot = 0.0;
+  int64_t n = 0;
+  for (auto& r : gr::g_trecs) {
+    if (r.name != name) continue;
+    if (hipEventSynchronize(r.stop) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+      tot += ms;
+      ++n;
+    }
+  }
+  if (total_ms) *total_ms = tot;
+  if (calls) *calls = n;
+  return GR_OK;
+}

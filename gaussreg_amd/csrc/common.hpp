@@ -92,6 +92,16 @@ int sort_pairs_u64_i32(void* temp, size_t temp_bytes, const uint64_t* keys_in, u
                        const int32_t* vals_in, int32_t* vals_out, int64_t n, int begin_bit,
                        int end_bit, hipStream_t stream);
 
+// Optional per-kernel HIP-event timing (off by default; bench.py turns it on to measure the
+// dominant kernel's average launch duration on the stream it is launched on).
+struct KernelTimer {
+  KernelTimer(const char* name, hipStream_t stream);
+  ~KernelTimer();
+  KernelTimer(const KernelTimer&) = delete;
+  int slot_;
+  hipStream_t stream_;
+};
+
 // lower_bound over a small ascending int32 offsets table: largest b with off[b] <= i (b < nb)
 __device__ inline int find_batch(const int32_t* __restrict__ off, int nb, int32_t i) {
   int lo = 0, hi = nb;  // off has nb+1 entries

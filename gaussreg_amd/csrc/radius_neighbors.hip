@@ -492,6 +492,7 @@ int launch_count(const RadiusWs& w, const float4* sorted_q, int64_t nq, int nb, 
                  hipStream_t stream) {
   using L = TravLds<RQ>;
   const int blocks = (int)((nq + RQ - 1) / RQ);
+  KernelTimer timer("radius_count", stream);
   hipLaunchKernelGGL((traverse_kernel<RQ, false, true>), dim3(blocks), dim3(L::THREADS), L::FIXED, stream, sorted_q,
                      (int)nq, w.q_off, nb, w.grids, start_s, w.sorted_s, r2, w.q_count, w.blk_stats, 0, (int64_t)0,
                      (int64_t*)nullptr, 0, (unsigned long long*)nullptr, (unsigned char*)nullptr);
@@ -506,6 +507,7 @@ int launch_fill(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t n
   using L = TravLds<RQ>;
   const int blocks = (int)((nq + RQ - 1) / RQ);
   const size_t lds = L::total(max_block_hits);
+  KernelTimer timer("radius_fill", stream);
   if (lds <= 160 * 1024) {
     auto kern = traverse_kernel<RQ, true, true>;
     if (lds > 64 * 1024)

@@ -529,10 +529,13 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
                      g.views, means3D, shs, colors_precomp, opacities, scales, rotations,          \
                      cov3D_precomp, W, H, radii, g.radius, g.depth, g.xy, g.conic_opacity, g.rgb,  \
                      g.tiles)
-  if (shs && cov3D_precomp) GR_PRE(true, true);
-  else if (shs) GR_PRE(true, false);
-  else if (cov3D_precomp) GR_PRE(false, true);
-  else GR_PRE(false, false);
+  {
+    KernelTimer timer("raster_preprocess", stream);
+    if (shs && cov3D_precomp) GR_PRE(true, true);
+    else if (shs) GR_PRE(true, false);
+    else if (cov3D_precomp) GR_PRE(false, true);
+    else GR_PRE(false, false);
+  }
 #undef GR_PRE
   GR_LAUNCH_CHECK();
   rc = exclusive_scan_i32(g.tiles, g.tiles, P, num_views, P, g.scan_ws, g.totals, stream);
@@ -573,12 +576,16 @@ extern "C" int gr_raster_render(int64_t P, const gr_raster_view* h_views, int nu
     GR_LAUNCH_CHECK();
     int bits = 0;
     while ((1ll << bits) < vtiles) ++bits;
-    rc = sort_pairs_u64_i32(b.sort_temp, b.sort_temp_bytes, b.keys_a, b.keys_b, b.vals_a, b.vals_b, R, 0, 32 + bits,
-                            stream);
+    {
+      KernelTimer timer("raster_sort", stream);
+      rc = sort_pairs_u64_i32(b.sort_temp, b.sort_temp_bytes, b.keys_a, b.keys_b, b.vals_a, b.vals_b, R, 0,
+                              32 + bits, stream);
+    }
     if (rc != GR_OK) return rc;
     hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, R, b.keys_b, b.ranges);
     GR_LAUNCH_CHECK();
   }
+  KernelTimer timer("raster_blend", stream);
   hipLaunchKernelGGL(blend_kernel, dim3(gx, gy, num_views), dim3(BLOCK), 0, stream, (int)P, W, H, g.views, b.ranges,
                      point_list, g.xy, g.conic_opacity, g.rgb, out_color);
   GR_LAUNCH_CHECK();

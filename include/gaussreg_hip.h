@@ -34,6 +34,13 @@ const char* gr_last_error(void);
 /* Library/ABI version (major*1000 + minor). */
 int gr_version(void);
 
+/* Optional per-kernel timing with HIP events recorded on the launch stream (measurement aid, off
+ * by default).  Timed kernels: "radius_fill", "radius_count", "raster_preprocess", "raster_sort",
+ * "raster_blend".  gr_timing_read waits for the recorded events and returns total ms / launches. */
+void gr_timing_enable(int on);
+void gr_timing_reset(void);
+int gr_timing_read(const char* name, double* total_ms, int64_t* calls);
+
 /* ------------------------------------------------------------------------------------------------
  * radius_neighbors  -- replaces
  *   geotransformer/extensions/cpu/radius_neighbors/radius_neighbors.cpp:5-68     (entry, alloc)
