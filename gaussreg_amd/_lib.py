@@ -59,6 +59,10 @@ def lib():
     """Load the HIP library; raise (never fall back) if it has not been built."""
     global _lib
     if _lib is None:
+        # torch first: libgaussreg_hip.so must bind to the SAME HIP runtime instance torch uses (the
+        # wheel bundles its own libamdhip64); loading ours first leaves two runtimes in the process
+        # and ours then reports "no ROCm-capable device".
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise HipLibraryError(
                 f"{LIB_PATH} is missing: build it with `python -m gaussreg_amd.build` "

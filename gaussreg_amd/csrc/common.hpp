@@ -102,6 +102,11 @@ struct KernelTimer {
   hipStream_t stream_;
 };
 
+size_t sort_pairs_u32_temp_bytes(int64_t n);
+int sort_pairs_u32_i32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
+                       const int32_t* vals_in, int32_t* vals_out, int64_t n, int begin_bit,
+                       int end_bit, hipStream_t stream);
+
 // lower_bound over a small ascending int32 offsets table: largest b with off[b] <= i (b < nb)
 __device__ inline int find_batch(const int32_t* __restrict__ off, int nb, int32_t i) {
   int lo = 0, hi = nb;  // off has nb+1 entries

@@ -9,9 +9,11 @@
 // Pipeline per batch of V views over one set of P Gaussians:
 //   preprocess  1 thread / Gaussian, loops over the V cameras (inputs read once per batch;
 //               cov3D built once): cull, project, cov2D, conic, radius, tile rect, SH -> RGB
-//   scan        exclusive scan of tiles_touched per view (common.hip)      -> R_v on the host
-//   instances   key = ((view*tiles + tile) << 32) | depth_bits, value = Gaussian id
-//   sort        one stable radix sort for the whole batch (sort.hip)
+//   depth sort  stable radix sort of (view, depth bits) -> per-view front-to-back Gaussian order
+//   scan        exclusive scan of tiles_touched IN THAT ORDER per view      -> R_v on the host
+//   instances   emitted in depth order: key = view*tiles + tile (32 bit), value = Gaussian id
+//   tile sort   stable radix sort on the tile bits only: each tile's run keeps the depth order
+//               (== upstream's single sort of (tile << 32 | depth) keys, at ~half the traffic)
 //   ranges      [start,end) of every (view, tile)
 //   blend       1 workgroup / tile (16x16 px, 4 waves): Gaussian parameters staged through LDS in
 //               batches of 256, front-to-back alpha blending, deterministic exp
@@ -174,14 +176,20 @@ __device__ __forceinline__ void get_rect(float px, float py, int radius, int gx,
   rmax[1] = min(gy, max(0, (int)((py + r + (float)(TILE - 1)) / (float)TILE)));
 }
 
-// geometry state, one slab per view (SoA so the blend's gathers are aligned vector loads)
+// geometry state: one 64-byte record per (view, Gaussian) so that the blend's per-instance gather
+// (ids arrive in depth order, i.e. random in memory) touches ONE 64-B sector instead of three lines:
+//   rec[0] = {px, py, depth, radius(int bits)}   rec[1] = {conic.x, conic.y, conic.z, opacity}
+//   rec[2] = {r, g, b, kc (cull factor)}          rec[3] = unused
 struct Geom {
-  float* depth;          // [V][P]
-  float2* xy;            // [V][P]
-  float4* conic_opacity; // [V][P]
-  float4* rgb;           // [V][P] (w unused)
-  int32_t* tiles;        // [V][P] tiles touched, then exclusive offsets (in place)
-  int32_t* radius;       // [V][P] (copy of the caller's radii: render needs it)
+  float4* rec;           // [V][P][4]
+  int32_t* tiles;        // [V][P] tiles touched (Gaussian order)
+  uint64_t* dkeys_a;     // [V*P] (view << 32 | depth bits)
+  uint64_t* dkeys_b;
+  int32_t* order_a;      // [V*P] Gaussian ids; order_b = per-view front-to-back order
+  int32_t* order_b;
+  int32_t* offs;         // [V*P] exclusive scan of tiles in depth order
+  void* sort_temp;
+  size_t sort_temp_bytes;
   int32_t* totals;       // [V]
   DevView* views;        // [MAX_VIEWS] camera table (uniform loads)
   int32_t* scan_ws;
@@ -191,12 +199,15 @@ struct Geom {
 Geom carve_geom(void* p, int64_t P, int V) {
   Geom g;
   Carver c(p);
-  g.depth = c.take<float>(P * V);
-  g.xy = c.take<float2>(P * V);
-  g.conic_opacity = c.take<float4>(P * V);
-  g.rgb = c.take<float4>(P * V);
+  g.rec = c.take<float4>(P * V * 4);
   g.tiles = c.take<int32_t>(P * V);
-  g.radius = c.take<int32_t>(P * V);
+  g.dkeys_a = c.take<uint64_t>(P * V);
+  g.dkeys_b = c.take<uint64_t>(P * V);
+  g.order_a = c.take<int32_t>(P * V);
+  g.order_b = c.take<int32_t>(P * V);
+  g.offs = c.take<int32_t>(P * V);
+  g.sort_temp_bytes = sort_pairs_temp_bytes(P * V);
+  g.sort_temp = c.take<char>(g.sort_temp_bytes);
   g.totals = c.take<int32_t>(V);
   g.views = c.take<DevView>(MAX_VIEWS);
   g.scan_ws = c.take<int32_t>(V * scan_ws_ints(P));
@@ -205,8 +216,8 @@ Geom carve_geom(void* p, int64_t P, int V) {
 }
 
 struct Bin {
-  uint64_t* keys_a;
-  uint64_t* keys_b;
+  uint32_t* keys_a;
+  uint32_t* keys_b;
   int32_t* vals_a;
   int32_t* vals_b;
   int2* ranges;  // [V * tiles]
@@ -218,12 +229,12 @@ struct Bin {
 Bin carve_bin(void* p, int64_t R, int64_t vtiles) {
   Bin b;
   Carver c(p);
-  b.keys_a = c.take<uint64_t>(R);
-  b.keys_b = c.take<uint64_t>(R);
+  b.keys_a = c.take<uint32_t>(R);
+  b.keys_b = c.take<uint32_t>(R);
   b.vals_a = c.take<int32_t>(R);
   b.vals_b = c.take<int32_t>(R);
   b.ranges = c.take<int2>(vtiles);
-  b.sort_temp_bytes = sort_pairs_temp_bytes(R);
+  b.sort_temp_bytes = sort_pairs_u32_temp_bytes(R);
   b.sort_temp = c.take<char>(b.sort_temp_bytes);
   b.bytes = c.used();
   return b;
@@ -236,9 +247,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const float* __restrict__ shs, const float* __restrict__ colors_precomp,
     const float* __restrict__ opacities, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, int W, int H,
-    int32_t* __restrict__ radii, int32_t* __restrict__ radius_g, float* __restrict__ depth,
-    float2* __restrict__ xy, float4* __restrict__ conic_opacity, float4* __restrict__ rgb_out,
-    int32_t* __restrict__ tiles) {
+    int32_t* __restrict__ radii, float4* __restrict__ rec, int32_t* __restrict__ tiles,
+    uint64_t* __restrict__ dkeys, int32_t* __restrict__ order) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
   const float p[3] = {means3D[3 * (int64_t)i], means3D[3 * (int64_t)i + 1], means3D[3 * (int64_t)i + 2]};
@@ -308,58 +318,77 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
           out_radius = (int)my_radius;
           out_xy = make_float2(px, py);
           out_co = make_float4(cv[2] * det_inv, -cv[1] * det_inv, cv[0] * det_inv, opacity);
-          out_rgb = make_float4(rgb[0], rgb[1], rgb[2], 0.f);
+          // rgb.w: k such that |d|^2 > |pc| * k  ==>  fp32 power < pc for any cutoff pc < 0 (blend
+          // strip culling).  power <= -|d|^2 (0.5/l1 - 2e-6): the 2e-6 covers the fp32 evaluation
+          // error of the quadratic form given lambda_min(cov) >= 0.3 (the +0.3 dilation).
+          const bool cullable = det > 0.0f && l2 >= 0.29f && l1 < 1.0e4f;
+          const float kc = cullable ? 1.001f / (0.5f / l1 - 2.0e-6f) : INFINITY;
+          out_rgb = make_float4(rgb[0], rgb[1], rgb[2], kc);
           out_tiles = ntile;
         }
       }
     }
     radii[o] = out_radius;
-    radius_g[o] = out_radius;
-    depth[o] = out_depth;
-    xy[o] = out_xy;
-    conic_opacity[o] = out_co;
-    rgb_out[o] = out_rgb;
     tiles[o] = out_tiles;
+    dkeys[o] = ((uint64_t)v << 32) | (uint64_t)__float_as_uint(out_depth);  // culled: depth 0, no tiles
+    order[o] = i;
+    float4* r = rec + 4 * o;
+    r[0] = make_float4(out_xy.x, out_xy.y, out_depth, __int_as_float(out_radius));
+    if (out_radius > 0) {  // culled Gaussians are never gathered
+      r[1] = out_co;
+      r[2] = out_rgb;
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------ instances
+// tiles touched, gathered into per-view depth order (input of the offsets scan)
+__global__ __launch_bounds__(256) void gather_tiles_kernel(int64_t n, int P,
+                                                           const int32_t* __restrict__ order,
+                                                           const int32_t* __restrict__ tiles,
+                                                           int32_t* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int64_t v = t / P;
+  out[t] = tiles[v * P + order[t]];
+}
+
+// one thread per depth-ordered Gaussian: emits its (view*tiles + tile, id) instances contiguously
 __global__ __launch_bounds__(256) void instances_kernel(
-    int P, int V, int W, int H, const int32_t* __restrict__ radii, const float* __restrict__ depth,
-    const float2* __restrict__ xy, const int32_t* __restrict__ offsets /* exclusive, per view */,
-    const int32_t* __restrict__ totals /* [V] */, uint64_t* __restrict__ keys,
+    int P, int V, int W, int H, const float4* __restrict__ rec, const int32_t* __restrict__ order,
+    const int32_t* __restrict__ offsets /* exclusive, per view, depth order */,
+    const int32_t* __restrict__ totals /* [V] */, uint32_t* __restrict__ keys,
     int32_t* __restrict__ vals) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int v = blockIdx.y;
-  if (i >= P) return;
-  const int64_t o = (int64_t)v * P + i;
-  const int r = radii[o];
+  if (t >= P) return;
+  const int i = order[(int64_t)v * P + t];
+  const float4 r0 = rec[4 * ((int64_t)v * P + i)];
+  const int r = __float_as_int(r0.w);
   if (r <= 0) return;
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-  const float2 p = xy[o];
   int rmin[2], rmax[2];
-  get_rect(p.x, p.y, r, gx, gy, rmin, rmax);
-  int64_t off = offsets[o];
+  get_rect(r0.x, r0.y, r, gx, gy, rmin, rmax);
+  int64_t off = offsets[(int64_t)v * P + t];
   for (int u = 0; u < v; ++u) off += totals[u];  // uniform: scalar loads
-  const uint64_t db = (uint64_t)__float_as_uint(depth[o]);
-  const uint64_t tile_base = (uint64_t)v * (uint64_t)(gx * gy);
+  const uint32_t tile_base = (uint32_t)v * (uint32_t)(gx * gy);
   for (int y = rmin[1]; y < rmax[1]; ++y)
     for (int x = rmin[0]; x < rmax[0]; ++x) {
-      keys[off] = ((tile_base + (uint64_t)(y * gx + x)) << 32) | db;
+      keys[off] = tile_base + (uint32_t)(y * gx + x);
       vals[off] = i;
       ++off;
     }
 }
 
-__global__ __launch_bounds__(256) void ranges_kernel(int64_t R, const uint64_t* __restrict__ keys,
+__global__ __launch_bounds__(256) void ranges_kernel(int64_t R, const uint32_t* __restrict__ keys,
                                                      int2* __restrict__ ranges) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= R) return;
-  const uint32_t t = (uint32_t)(keys[k] >> 32);
+  const uint32_t t = keys[k];
   if (k == 0) {
     ranges[t].x = 0;
   } else {
-    const uint32_t tp = (uint32_t)(keys[k - 1] >> 32);
+    const uint32_t tp = keys[k - 1];
     if (t != tp) {
       ranges[tp].y = (int)k;
       ranges[t].x = (int)k;
@@ -371,11 +400,11 @@ __global__ __launch_bounds__(256) void ranges_kernel(int64_t R, const uint64_t* 
 // ------------------------------------------------------------------------------------ blend
 __global__ __launch_bounds__(BLOCK) void blend_kernel(
     int P, int W, int H, const DevView* __restrict__ views, const int2* __restrict__ ranges,
-    const int32_t* __restrict__ point_list, const float2* __restrict__ xy, const float4* __restrict__ conic_opacity,
-    const float4* __restrict__ rgb, float* __restrict__ out_color) {
+    const int32_t* __restrict__ point_list, const float4* __restrict__ rec, float* __restrict__ out_color) {
   __shared__ float2 s_xy[BLOCK];
   __shared__ float4 s_co[BLOCK];
   __shared__ float4 s_rgb[BLOCK];
+  __shared__ float2 s_aux[BLOCK];  // {power cutoff pc, squared cull radius}
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   const int v = blockIdx.z;
   const int tile = blockIdx.y * gx + blockIdx.x;
@@ -384,6 +413,10 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
   const int pxi = blockIdx.x * TILE + lx, pyi = blockIdx.y * TILE + ly;
   const bool inside = pxi < W && pyi < H;
   const float pfx = (float)pxi, pfy = (float)pyi;
+  // this wave's pixel strip (for the wave-uniform cull test)
+  const float sx_lo = (float)(blockIdx.x * TILE), sx_hi = sx_lo + (float)(TILE - 1);
+  const float sy_lo = (float)(blockIdx.y * TILE + (threadIdx.x / WAVE) * (WAVE / TILE));
+  const float sy_hi = sy_lo + (float)(WAVE / TILE - 1);
   const int2 range = ranges[(int64_t)v * gx * gy + tile];
   const int64_t goff = (int64_t)v * P;
   bool done = !inside;
@@ -392,22 +425,35 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
     if (__syncthreads_and(done)) break;
     const int k = start + threadIdx.x;
     if (k < range.y) {
-      const int64_t id = goff + point_list[k];
-      s_xy[threadIdx.x] = xy[id];
-      s_co[threadIdx.x] = conic_opacity[id];
-      s_rgb[threadIdx.x] = rgb[id];
+      const float4* r = rec + 4 * (goff + point_list[k]);
+      const float4 r0 = r[0];
+      const float4 co = r[1];
+      const float4 col = r[2];
+      s_xy[threadIdx.x] = make_float2(r0.x, r0.y);
+      s_co[threadIdx.x] = co;
+      s_rgb[threadIdx.x] = col;
+      // Exact skip rules (they only ever skip what the reference test `alpha < 1/255` skips):
+      //   power < pc = -ln(255 op) - 1e-3   ==>   op * exp(power) < 1/255
+      //   |d|^2 > |pc| * col.w              ==>   power < pc            (see preprocess)
+      // NaN / non-positive opacity make both comparisons false: nothing is skipped early.
+      const float pc = -__logf(255.0f * co.w) - 1.0e-3f;
+      s_aux[threadIdx.x] = make_float2(pc, -pc * col.w);
     }
     __syncthreads();
     const int nb = min(BLOCK, range.y - start);
     for (int j = 0; j < nb && !done; ++j) {
       const float2 g = s_xy[j];
+      const float2 aux = s_aux[j];
+      // wave-uniform: is the whole 16x4 strip outside the Gaussian's cutoff radius?
+      const float ex = fmaxf(fmaxf(sx_lo - g.x, g.x - sx_hi), 0.0f);
+      const float ey = fmaxf(fmaxf(sy_lo - g.y, g.y - sy_hi), 0.0f);
+      if (ex * ex + ey * ey > aux.y) continue;
       const float4 co = s_co[j];
       const float dx = g.x - pfx, dy = g.y - pfy;
       const float q = fmaf(co.x * dx, dx, (co.z * dy) * dy);
       const float power = fmaf(-0.5f, q, -((co.y * dx) * dy));
       if (power > 0.0f) continue;
-      // exact early-out: for opacity <= 1, power < -5.6 implies alpha < 1/255 (exp(-5.6) = 0.0037)
-      if (power < -5.6f && co.w <= 1.0f) continue;
+      if (power < aux.x) continue;
       const float alpha = fminf(0.99f, co.w * exp_det(power));
       if (alpha < 1.0f / 255.0f) continue;
       const float test_T = T * (1.0f - alpha);
@@ -527,8 +573,7 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
 #define GR_PRE(SH, COV)                                                                           \
   hipLaunchKernelGGL((preprocess_kernel<SH, COV>), grd, blk, 0, stream, (int)P, D, M, num_views,   \
                      g.views, means3D, shs, colors_precomp, opacities, scales, rotations,          \
-                     cov3D_precomp, W, H, radii, g.radius, g.depth, g.xy, g.conic_opacity, g.rgb,  \
-                     g.tiles)
+                     cov3D_precomp, W, H, radii, g.rec, g.tiles, g.dkeys_a, g.order_a)
   {
     KernelTimer timer("raster_preprocess", stream);
     if (shs && cov3D_precomp) GR_PRE(true, true);
@@ -538,7 +583,18 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
   }
 #undef GR_PRE
   GR_LAUNCH_CHECK();
-  rc = exclusive_scan_i32(g.tiles, g.tiles, P, num_views, P, g.scan_ws, g.totals, stream);
+  {
+    KernelTimer timer("raster_sort", stream);
+    int vbits = 0;
+    while ((1 << vbits) < num_views) ++vbits;
+    rc = sort_pairs_u64_i32(g.sort_temp, g.sort_temp_bytes, g.dkeys_a, g.dkeys_b, g.order_a, g.order_b,
+                            P * num_views, 0, 32 + vbits, stream);
+    if (rc != GR_OK) return rc;
+  }
+  hipLaunchKernelGGL(gather_tiles_kernel, dim3((unsigned)((P * num_views + 255) / 256)), blk, 0, stream,
+                     P * num_views, (int)P, g.order_b, g.tiles, g.offs);
+  GR_LAUNCH_CHECK();
+  rc = exclusive_scan_i32(g.offs, g.offs, P, num_views, P, g.scan_ws, g.totals, stream);
   if (rc != GR_OK) return rc;
   std::vector<int32_t> tot(num_views);
   GR_HIP(hipMemcpyAsync(tot.data(), g.totals, sizeof(int32_t) * num_views, hipMemcpyDeviceToHost, stream));
@@ -572,14 +628,14 @@ extern "C" int gr_raster_render(int64_t P, const gr_raster_view* h_views, int nu
   const int32_t* point_list = b.vals_b;
   if (R > 0) {
     hipLaunchKernelGGL(instances_kernel, dim3((unsigned)((P + 255) / 256), num_views), dim3(256), 0, stream, (int)P,
-                       num_views, W, H, g.radius, g.depth, g.xy, g.tiles, g.totals, b.keys_a, b.vals_a);
+                       num_views, W, H, g.rec, g.order_b, g.offs, g.totals, b.keys_a, b.vals_a);
     GR_LAUNCH_CHECK();
     int bits = 0;
     while ((1ll << bits) < vtiles) ++bits;
     {
       KernelTimer timer("raster_sort", stream);
-      rc = sort_pairs_u64_i32(b.sort_temp, b.sort_temp_bytes, b.keys_a, b.keys_b, b.vals_a, b.vals_b, R, 0,
-                              32 + bits, stream);
+      rc = sort_pairs_u32_i32(b.sort_temp, b.sort_temp_bytes, b.keys_a, b.keys_b, b.vals_a, b.vals_b, R, 0, bits,
+                              stream);
     }
     if (rc != GR_OK) return rc;
     hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, R, b.keys_b, b.ranges);
@@ -587,7 +643,7 @@ extern "C" int gr_raster_render(int64_t P, const gr_raster_view* h_views, int nu
   }
   KernelTimer timer("raster_blend", stream);
   hipLaunchKernelGGL(blend_kernel, dim3(gx, gy, num_views), dim3(BLOCK), 0, stream, (int)P, W, H, g.views, b.ranges,
-                     point_list, g.xy, g.conic_opacity, g.rgb, out_color);
+                     point_list, g.rec, out_color);
   GR_LAUNCH_CHECK();
   return GR_OK;
 }

@@ -33,4 +33,28 @@ int sort_pairs_u64_i32(void* temp, size_t temp_bytes, const uint64_t* keys_in, u
   return GR_OK;
 }
 
+size_t sort_pairs_u32_temp_bytes(int64_t n) {
+  size_t bytes = 0;
+  if (n <= 0) return 256;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                  (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)n, 0u, 32u,
+                                  (hipStream_t)0);
+  return align_up(bytes + 256, 256);
+}
+
+int sort_pairs_u32_i32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
+                       const int32_t* vals_in, int32_t* vals_out, int64_t n, int begin_bit,
+                       int end_bit, hipStream_t stream) {
+  if (n <= 0) return GR_OK;
+  if (end_bit <= begin_bit) {
+    GR_HIP(hipMemcpyAsync(keys_out, keys_in, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, stream));
+    GR_HIP(hipMemcpyAsync(vals_out, vals_in, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, stream));
+    return GR_OK;
+  }
+  size_t bytes = temp_bytes;
+  GR_HIP(rocprim::radix_sort_pairs(temp, bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n,
+                                   (unsigned)begin_bit, (unsigned)end_bit, stream));
+  return GR_OK;
+}
+
 }  // namespace gr
