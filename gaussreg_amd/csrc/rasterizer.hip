@@ -182,7 +182,6 @@ __device__ __forceinline__ void get_rect(float px, float py, int radius, int gx,
 //   rec[2] = {r, g, b, kc (cull factor)}          rec[3] = unused
 struct Geom {
   float4* rec;           // [V][P][4]
-  int32_t* tiles;        // [V][P] tiles touched (Gaussian order)
   uint64_t* dkeys_a;     // [V*P] (view << 32 | depth bits)
   uint64_t* dkeys_b;
   int32_t* order_a;      // [V*P] Gaussian ids; order_b = per-view front-to-back order
@@ -200,7 +199,6 @@ Geom carve_geom(void* p, int64_t P, int V) {
   Geom g;
   Carver c(p);
   g.rec = c.take<float4>(P * V * 4);
-  g.tiles = c.take<int32_t>(P * V);
   g.dkeys_a = c.take<uint64_t>(P * V);
   g.dkeys_b = c.take<uint64_t>(P * V);
   g.order_a = c.take<int32_t>(P * V);
@@ -241,15 +239,54 @@ Bin carve_bin(void* p, int64_t R, int64_t vtiles) {
 }
 
 // ------------------------------------------------------------------------------------ preprocess
-template <bool HAS_SH, bool HAS_COV>
+// The depth-sort key carries the tile rectangle in the bits the sort ignores, so the instance
+// emission (which runs in depth order) never has to gather the geometry records:
+//   bits  0..31 depth bits | 32..37 view | 38..44 rect.x | 45..51 rect.y | 52..57 w | 58..63 h
+// Rectangles that do not fit (w or h > 63, x or y > 126) store the marker below and are gathered.
+constexpr int KEY_VIEW_BITS = 6;
+constexpr uint64_t RECT_MARKER = (127ull << 38) | (127ull << 45);  // w = h = 0
+
+__device__ __forceinline__ uint64_t pack_rect(const int* rmin, const int* rmax) {
+  const int w = rmax[0] - rmin[0], h = rmax[1] - rmin[1];
+  if (w > 63 || h > 63 || rmin[0] > 126 || rmin[1] > 126) return RECT_MARKER;
+  return ((uint64_t)rmin[0] << 38) | ((uint64_t)rmin[1] << 45) | ((uint64_t)w << 52) | ((uint64_t)h << 58);
+}
+
+constexpr int SH_ROW = 13;  // float4 per staged Gaussian: 12 used + 1 pad -> conflict-free ds_read_b128
+
+template <bool HAS_SH, bool HAS_COV, bool SH16>
 __global__ __launch_bounds__(256) void preprocess_kernel(
     int P, int D, int M, int V, const DevView* __restrict__ views, const float* __restrict__ means3D,
     const float* __restrict__ shs, const float* __restrict__ colors_precomp,
     const float* __restrict__ opacities, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, int W, int H,
-    int32_t* __restrict__ radii, float4* __restrict__ rec, int32_t* __restrict__ tiles,
-    uint64_t* __restrict__ dkeys, int32_t* __restrict__ order) {
+    int32_t* __restrict__ radii, float4* __restrict__ rec, uint64_t* __restrict__ dkeys,
+    int32_t* __restrict__ order) {
+  __shared__ float4 s_sh[SH16 ? 256 * SH_ROW : 1];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float shr[SH16 ? 48 : 1];
+  if (SH16) {
+    // degree-3 SH = 192 B per Gaussian: read the block's 48 KB as one coalesced float4 stream,
+    // transpose through LDS (row stride 13 float4 keeps the per-thread ds_read_b128 conflict-free)
+    const int g0 = blockIdx.x * 256;
+    const int n_here = min(256, P - g0);
+    const float4* src = reinterpret_cast<const float4*>(shs + (int64_t)g0 * 48);
+    for (int f = threadIdx.x; f < n_here * 12; f += 256) {
+      const int g = f / 12, j = f - g * 12;
+      s_sh[g * SH_ROW + j] = src[f];
+    }
+    __syncthreads();
+    if (i < P) {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        const float4 t = s_sh[threadIdx.x * SH_ROW + j];
+        shr[4 * j] = t.x;
+        shr[4 * j + 1] = t.y;
+        shr[4 * j + 2] = t.z;
+        shr[4 * j + 3] = t.w;
+      }
+    }
+  }
   if (i >= P) return;
   const float p[3] = {means3D[3 * (int64_t)i], means3D[3 * (int64_t)i + 1], means3D[3 * (int64_t)i + 2]};
   const float opacity = opacities[i];
@@ -261,8 +298,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
   } else {
 #pragma unroll
     for (int k = 0; k < 3; ++k) sc[k] = scales[3 * (int64_t)i + k];
-    const float4 q = reinterpret_cast<const float4*>(rotations)[i];
-    rot[0] = q.x; rot[1] = q.y; rot[2] = q.z; rot[3] = q.w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rot[k] = rotations[4 * (int64_t)i + k];
   }
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   const float* sh = HAS_SH ? shs + (int64_t)i * M * 3 : nullptr;
@@ -276,7 +313,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
   for (int v = 0; v < V; ++v) {
     const DevView& cam = views[v];
     const int64_t o = (int64_t)v * P + i;
-    int out_radius = 0, out_tiles = 0;
+    int out_radius = 0;
+    uint64_t out_key = (uint64_t)v << 32;  // culled: depth 0, empty rectangle
     float out_depth = 0.f;
     float2 out_xy = make_float2(0.f, 0.f);
     float4 out_co = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -310,7 +348,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         if (ntile != 0) {
           float rgb[3];
           if (HAS_SH) {
-            sh_to_rgb(D, p, cam.campos, [&](int k, int c) { return sh[k * 3 + c]; }, rgb);
+            if (SH16) sh_to_rgb(D, p, cam.campos, [&](int k, int c) { return shr[k * 3 + c]; }, rgb);
+            else sh_to_rgb(D, p, cam.campos, [&](int k, int c) { return sh[k * 3 + c]; }, rgb);
           } else {
             rgb[0] = cpre[0]; rgb[1] = cpre[1]; rgb[2] = cpre[2];
           }
@@ -319,18 +358,17 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
           out_xy = make_float2(px, py);
           out_co = make_float4(cv[2] * det_inv, -cv[1] * det_inv, cv[0] * det_inv, opacity);
           // rgb.w: k such that |d|^2 > |pc| * k  ==>  fp32 power < pc for any cutoff pc < 0 (blend
-          // strip culling).  power <= -|d|^2 (0.5/l1 - 2e-6): the 2e-6 covers the fp32 evaluation
+          // cell culling).  power <= -|d|^2 (0.5/l1 - 2e-6): the 2e-6 covers the fp32 evaluation
           // error of the quadratic form given lambda_min(cov) >= 0.3 (the +0.3 dilation).
           const bool cullable = det > 0.0f && l2 >= 0.29f && l1 < 1.0e4f;
           const float kc = cullable ? 1.001f / (0.5f / l1 - 2.0e-6f) : INFINITY;
           out_rgb = make_float4(rgb[0], rgb[1], rgb[2], kc);
-          out_tiles = ntile;
+          out_key |= (uint64_t)__float_as_uint(out_depth) | pack_rect(rmin, rmax);
         }
       }
     }
     radii[o] = out_radius;
-    tiles[o] = out_tiles;
-    dkeys[o] = ((uint64_t)v << 32) | (uint64_t)__float_as_uint(out_depth);  // culled: depth 0, no tiles
+    dkeys[o] = out_key;
     order[o] = i;
     float4* r = rec + 4 * o;
     r[0] = make_float4(out_xy.x, out_xy.y, out_depth, __int_as_float(out_radius));
@@ -342,34 +380,50 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
 }
 
 // ------------------------------------------------------------------------------------ instances
-// tiles touched, gathered into per-view depth order (input of the offsets scan)
-__global__ __launch_bounds__(256) void gather_tiles_kernel(int64_t n, int P,
-                                                           const int32_t* __restrict__ order,
-                                                           const int32_t* __restrict__ tiles,
-                                                           int32_t* __restrict__ out) {
+__device__ __forceinline__ bool rect_of(uint64_t key, int id, int64_t vbase, const float4* __restrict__ rec,
+                                         int gx, int gy, int* rmin, int* rmax) {
+  const int w = (int)((key >> 52) & 63), h = (int)((key >> 58) & 63);
+  rmin[0] = (int)((key >> 38) & 127);
+  rmin[1] = (int)((key >> 45) & 127);
+  if (w == 0 && h == 0 && rmin[0] == 127 && rmin[1] == 127) {  // marker: did not fit, gather the record
+    const float4 r0 = rec[4 * (vbase + id)];
+    get_rect(r0.x, r0.y, __float_as_int(r0.w), gx, gy, rmin, rmax);
+    return true;
+  }
+  rmax[0] = rmin[0] + w;
+  rmax[1] = rmin[1] + h;
+  return w * h != 0;
+}
+
+// tiles touched per depth-ordered Gaussian (input of the offsets scan), decoded from the sorted keys
+__global__ __launch_bounds__(256) void tiles_from_keys_kernel(int64_t n, int P, int W, int H,
+                                                              const uint64_t* __restrict__ keys,
+                                                              const int32_t* __restrict__ order,
+                                                              const float4* __restrict__ rec,
+                                                              int32_t* __restrict__ out) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
-  const int64_t v = t / P;
-  out[t] = tiles[v * P + order[t]];
+  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  int rmin[2], rmax[2];
+  const bool any = rect_of(keys[t], order[t], (t / P) * P, rec, gx, gy, rmin, rmax);
+  out[t] = any ? (rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) : 0;
 }
 
 // one thread per depth-ordered Gaussian: emits its (view*tiles + tile, id) instances contiguously
 __global__ __launch_bounds__(256) void instances_kernel(
-    int P, int V, int W, int H, const float4* __restrict__ rec, const int32_t* __restrict__ order,
-    const int32_t* __restrict__ offsets /* exclusive, per view, depth order */,
+    int P, int V, int W, int H, const float4* __restrict__ rec, const uint64_t* __restrict__ dkeys,
+    const int32_t* __restrict__ order, const int32_t* __restrict__ offsets /* exclusive, per view, depth order */,
     const int32_t* __restrict__ totals /* [V] */, uint32_t* __restrict__ keys,
     int32_t* __restrict__ vals) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int v = blockIdx.y;
   if (t >= P) return;
-  const int i = order[(int64_t)v * P + t];
-  const float4 r0 = rec[4 * ((int64_t)v * P + i)];
-  const int r = __float_as_int(r0.w);
-  if (r <= 0) return;
+  const int64_t vbase = (int64_t)v * P;
+  const int i = order[vbase + t];
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   int rmin[2], rmax[2];
-  get_rect(r0.x, r0.y, r, gx, gy, rmin, rmax);
-  int64_t off = offsets[(int64_t)v * P + t];
+  if (!rect_of(dkeys[vbase + t], i, vbase, rec, gx, gy, rmin, rmax)) return;
+  int64_t off = offsets[vbase + t];
   for (int u = 0; u < v; ++u) off += totals[u];  // uniform: scalar loads
   const uint32_t tile_base = (uint32_t)v * (uint32_t)(gx * gy);
   for (int y = rmin[1]; y < rmax[1]; ++y)
@@ -398,70 +452,122 @@ __global__ __launch_bounds__(256) void ranges_kernel(int64_t R, const uint32_t* 
 }
 
 // ------------------------------------------------------------------------------------ blend
+// Per-tile front-to-back blend.  A 16x16 tile is 16 cells of 4x4 pixels; 16 consecutive lanes own
+// one cell, a wave owns a row of four cells.  Per batch of 256 depth-ordered Gaussians:
+//   load   thread k gathers Gaussian k's 48-byte record into LDS, computes its exact cutoffs
+//          (pc: power below which alpha < 1/255; rc2: squared radius beyond which power < pc) and a
+//          16-bit mask of the cells its cutoff circle touches;
+//   lists  wave ballots turn the masks into 16 ORDER-PRESERVING index lists (one per cell);
+//   blend  every 16-lane group walks ITS OWN list -- lanes of one wave work on different
+//          Gaussians in the same instruction (per-lane LDS gathers), so a wave's trip count is
+//          the longest of its four cell lists (~1/4 of the batch) instead of the whole batch.
+// The cutoffs only skip (pixel, Gaussian) pairs that the reference test `alpha < 1/255` skips,
+// and per-pixel order is untouched, so the image stays bit-identical to the oracle.
+constexpr int CELL = 4;
+constexpr int NCELL = (TILE / CELL) * (TILE / CELL);  // 16
+
 __global__ __launch_bounds__(BLOCK) void blend_kernel(
     int P, int W, int H, const DevView* __restrict__ views, const int2* __restrict__ ranges,
     const int32_t* __restrict__ point_list, const float4* __restrict__ rec, float* __restrict__ out_color) {
-  __shared__ float2 s_xy[BLOCK];
-  __shared__ float4 s_co[BLOCK];
-  __shared__ float4 s_rgb[BLOCK];
-  __shared__ float2 s_aux[BLOCK];  // {power cutoff pc, squared cull radius}
+  __shared__ float4 s_a[BLOCK];  // {px, py, pc, rc2}
+  __shared__ float4 s_b[BLOCK];  // {conic.x, conic.y, conic.z, opacity}
+  __shared__ float4 s_c[BLOCK];  // {r, g, b, -}
+  __shared__ unsigned char s_list[NCELL][BLOCK];
+  __shared__ int s_cnt[NCELL][BLOCK / WAVE + 1];  // per (cell, loading wave) counts -> bases; [.][4] = total
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   const int v = blockIdx.z;
   const int tile = blockIdx.y * gx + blockIdx.x;
-  // 16x16 pixel tile; thread -> pixel so that one wave covers a 16x4 strip
-  const int lx = threadIdx.x % TILE, ly = threadIdx.x / TILE;
+  const int tid = threadIdx.x;
+  const int lane = tid & (WAVE - 1), lw = tid / WAVE;
+  const int cell = tid / (CELL * CELL), pin = tid % (CELL * CELL);
+  const int lx = (cell % (TILE / CELL)) * CELL + pin % CELL;
+  const int ly = (cell / (TILE / CELL)) * CELL + pin / CELL;
   const int pxi = blockIdx.x * TILE + lx, pyi = blockIdx.y * TILE + ly;
   const bool inside = pxi < W && pyi < H;
   const float pfx = (float)pxi, pfy = (float)pyi;
-  // this wave's pixel strip (for the wave-uniform cull test)
-  const float sx_lo = (float)(blockIdx.x * TILE), sx_hi = sx_lo + (float)(TILE - 1);
-  const float sy_lo = (float)(blockIdx.y * TILE + (threadIdx.x / WAVE) * (WAVE / TILE));
-  const float sy_hi = sy_lo + (float)(WAVE / TILE - 1);
+  const float tx0 = (float)(blockIdx.x * TILE), ty0 = (float)(blockIdx.y * TILE);
   const int2 range = ranges[(int64_t)v * gx * gy + tile];
   const int64_t goff = (int64_t)v * P;
   bool done = !inside;
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
   for (int start = range.x; start < range.y; start += BLOCK) {
     if (__syncthreads_and(done)) break;
-    const int k = start + threadIdx.x;
+    // ---- load + cutoffs + cell mask
+    const int k = start + tid;
+    unsigned mask = 0;
     if (k < range.y) {
       const float4* r = rec + 4 * (goff + point_list[k]);
       const float4 r0 = r[0];
       const float4 co = r[1];
       const float4 col = r[2];
-      s_xy[threadIdx.x] = make_float2(r0.x, r0.y);
-      s_co[threadIdx.x] = co;
-      s_rgb[threadIdx.x] = col;
       // Exact skip rules (they only ever skip what the reference test `alpha < 1/255` skips):
       //   power < pc = -ln(255 op) - 1e-3   ==>   op * exp(power) < 1/255
       //   |d|^2 > |pc| * col.w              ==>   power < pc            (see preprocess)
-      // NaN / non-positive opacity make both comparisons false: nothing is skipped early.
+      // NaN / non-positive opacity make every comparison false: nothing is skipped early.
       const float pc = -__logf(255.0f * co.w) - 1.0e-3f;
-      s_aux[threadIdx.x] = make_float2(pc, -pc * col.w);
+      const float rc2 = -pc * col.w;
+      s_a[tid] = make_float4(r0.x, r0.y, pc, rc2);
+      s_b[tid] = co;
+      s_c[tid] = col;
+      float ex2[TILE / CELL], ey2[TILE / CELL];
+#pragma unroll
+      for (int c = 0; c < TILE / CELL; ++c) {
+        const float xlo = tx0 + (float)(c * CELL), ylo = ty0 + (float)(c * CELL);
+        const float ex = fmaxf(fmaxf(xlo - r0.x, r0.x - (xlo + (float)(CELL - 1))), 0.0f);
+        const float ey = fmaxf(fmaxf(ylo - r0.y, r0.y - (ylo + (float)(CELL - 1))), 0.0f);
+        ex2[c] = ex * ex;
+        ey2[c] = ey * ey;
+      }
+#pragma unroll
+      for (int c = 0; c < NCELL; ++c)
+        if (!(ex2[c % (TILE / CELL)] + ey2[c / (TILE / CELL)] > rc2)) mask |= 1u << c;
+    }
+    // ---- order-preserving per-cell lists
+    unsigned rank_lo = 0, rank_hi = 0;  // 16 x 8-bit... ranks need up to 6 bits each: pack 8 per 64? keep simple
+    unsigned char myrank[NCELL];
+#pragma unroll
+    for (int c = 0; c < NCELL; ++c) {
+      const unsigned long long bal = __ballot((mask >> c) & 1u);
+      myrank[c] = (unsigned char)__popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) s_cnt[c][lw] = __popcll(bal);
+    }
+    (void)rank_lo;
+    (void)rank_hi;
+    __syncthreads();
+    if (tid < NCELL) {
+      int acc = 0;
+#pragma unroll
+      for (int w = 0; w < BLOCK / WAVE; ++w) {
+        const int n = s_cnt[tid][w];
+        s_cnt[tid][w] = acc;
+        acc += n;
+      }
+      s_cnt[tid][BLOCK / WAVE] = acc;
     }
     __syncthreads();
-    const int nb = min(BLOCK, range.y - start);
-    for (int j = 0; j < nb && !done; ++j) {
-      const float2 g = s_xy[j];
-      const float2 aux = s_aux[j];
-      // wave-uniform: is the whole 16x4 strip outside the Gaussian's cutoff radius?
-      const float ex = fmaxf(fmaxf(sx_lo - g.x, g.x - sx_hi), 0.0f);
-      const float ey = fmaxf(fmaxf(sy_lo - g.y, g.y - sy_hi), 0.0f);
-      if (ex * ex + ey * ey > aux.y) continue;
-      const float4 co = s_co[j];
-      const float dx = g.x - pfx, dy = g.y - pfy;
+#pragma unroll
+    for (int c = 0; c < NCELL; ++c)
+      if ((mask >> c) & 1u) s_list[c][s_cnt[c][lw] + myrank[c]] = (unsigned char)tid;
+    __syncthreads();
+    // ---- blend: each 16-lane group walks its own list
+    const int n_cell = done ? 0 : s_cnt[cell][BLOCK / WAVE];
+    for (int i = 0; i < n_cell; ++i) {
+      const int j = s_list[cell][i];
+      const float4 a = s_a[j];
+      const float4 co = s_b[j];
+      const float dx = a.x - pfx, dy = a.y - pfy;
       const float q = fmaf(co.x * dx, dx, (co.z * dy) * dy);
       const float power = fmaf(-0.5f, q, -((co.y * dx) * dy));
       if (power > 0.0f) continue;
-      if (power < aux.x) continue;
+      if (power < a.z) continue;
       const float alpha = fminf(0.99f, co.w * exp_det(power));
       if (alpha < 1.0f / 255.0f) continue;
       const float test_T = T * (1.0f - alpha);
       if (test_T < 0.0001f) {
         done = true;
-        continue;
+        break;
       }
-      const float4 col = s_rgb[j];
+      const float4 col = s_c[j];
       const float w = alpha * T;
       C0 = fmaf(col.x, w, C0);
       C1 = fmaf(col.y, w, C1);
@@ -570,16 +676,17 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
   if (rc != GR_OK) return rc;
   const int W = h_views[0].image_width, H = h_views[0].image_height;
   const dim3 blk(256), grd((unsigned)((P + 255) / 256));
-#define GR_PRE(SH, COV)                                                                           \
-  hipLaunchKernelGGL((preprocess_kernel<SH, COV>), grd, blk, 0, stream, (int)P, D, M, num_views,   \
+  const bool sh16 = shs != nullptr && M == 16 && (reinterpret_cast<uintptr_t>(shs) % 16 == 0);
+#define GR_PRE(SH, COV, S16)                                                                       \
+  hipLaunchKernelGGL((preprocess_kernel<SH, COV, S16>), grd, blk, 0, stream, (int)P, D, M, num_views, \
                      g.views, means3D, shs, colors_precomp, opacities, scales, rotations,          \
-                     cov3D_precomp, W, H, radii, g.rec, g.tiles, g.dkeys_a, g.order_a)
+                     cov3D_precomp, W, H, radii, g.rec, g.dkeys_a, g.order_a)
   {
     KernelTimer timer("raster_preprocess", stream);
-    if (shs && cov3D_precomp) GR_PRE(true, true);
-    else if (shs) GR_PRE(true, false);
-    else if (cov3D_precomp) GR_PRE(false, true);
-    else GR_PRE(false, false);
+    if (shs && cov3D_precomp) { if (sh16) GR_PRE(true, true, true); else GR_PRE(true, true, false); }
+    else if (shs) { if (sh16) GR_PRE(true, false, true); else GR_PRE(true, false, false); }
+    else if (cov3D_precomp) GR_PRE(false, true, false);
+    else GR_PRE(false, false, false);
   }
 #undef GR_PRE
   GR_LAUNCH_CHECK();
@@ -587,12 +694,13 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
     KernelTimer timer("raster_sort", stream);
     int vbits = 0;
     while ((1 << vbits) < num_views) ++vbits;
+    static_assert((1 << KEY_VIEW_BITS) >= MAX_VIEWS, "view id must fit its key field");
     rc = sort_pairs_u64_i32(g.sort_temp, g.sort_temp_bytes, g.dkeys_a, g.dkeys_b, g.order_a, g.order_b,
                             P * num_views, 0, 32 + vbits, stream);
     if (rc != GR_OK) return rc;
   }
-  hipLaunchKernelGGL(gather_tiles_kernel, dim3((unsigned)((P * num_views + 255) / 256)), blk, 0, stream,
-                     P * num_views, (int)P, g.order_b, g.tiles, g.offs);
+  hipLaunchKernelGGL(tiles_from_keys_kernel, dim3((unsigned)((P * num_views + 255) / 256)), blk, 0, stream,
+                     P * num_views, (int)P, W, H, g.dkeys_b, g.order_b, g.rec, g.offs);
   GR_LAUNCH_CHECK();
   rc = exclusive_scan_i32(g.offs, g.offs, P, num_views, P, g.scan_ws, g.totals, stream);
   if (rc != GR_OK) return rc;
@@ -628,7 +736,7 @@ extern "C" int gr_raster_render(int64_t P, const gr_raster_view* h_views, int nu
   const int32_t* point_list = b.vals_b;
   if (R > 0) {
     hipLaunchKernelGGL(instances_kernel, dim3((unsigned)((P + 255) / 256), num_views), dim3(256), 0, stream, (int)P,
-                       num_views, W, H, g.rec, g.order_b, g.offs, g.totals, b.keys_a, b.vals_a);
+                       num_views, W, H, g.rec, g.dkeys_b, g.order_b, g.offs, g.totals, b.keys_a, b.vals_a);
     GR_LAUNCH_CHECK();
     int bits = 0;
     while ((1ll << bits) < vtiles) ++bits;
