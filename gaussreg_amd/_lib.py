@@ -51,6 +51,23 @@ SIGNATURES.update({
 })
 
 
+SIGNATURES.update({
+    "gr_pairwise_distance_workspace_bytes": (c_size, [c_i64, c_i64]),
+    "gr_pairwise_distance": (c_int, [c_void, c_void, c_i64, c_i64, c_i64, c_int, c_void, c_void, c_size, c_void]),
+    "gr_superpoint_matching_workspace_bytes": (c_size, [c_i64, c_i64]),
+    "gr_superpoint_matching": (c_int, [c_void, c_void, c_i64, c_i64, c_i64, c_void, c_void, c_int, c_int, c_void,
+                                       c_void, c_void, c_i64p, c_void, c_size, c_void]),
+    "gr_point_matching_workspace_bytes": (c_size, [c_i64]),
+    "gr_corr_matrix": (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_void, c_int, c_int, c_f32, c_void, c_i64p,
+                               c_void, c_size, c_void]),
+    "gr_corr_gather": (c_int, [c_void, c_i64, c_i64, c_i64] + [c_void] * 6 + [c_int] + [c_void] * 5 +
+                       [c_void, c_size, c_void]),
+    "gr_point_to_node_workspace_bytes": (c_size, [c_i64, c_i64]),
+    "gr_point_to_node_partition": (c_int, [c_void, c_i64, c_void, c_i64, c_int, c_void, c_void, c_void, c_void,
+                                           c_void, c_size, c_void]),
+})
+
+
 class HipLibraryError(RuntimeError):
     pass
 

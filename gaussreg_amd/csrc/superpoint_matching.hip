@@ -1,0 +1,416 @@
+// pairwise_distance (the one dense contraction on the path, fp32 MFMA) and SuperPointMatching.
+//
+// Replaces the ATen call chains of
+//   geotransformer/modules/ops/pairwise_distance.py:4-31                       (a8)
+//   geotransformer/modules/geotransformer/superpoint_matching.py:32-48          (a9)
+// pairwise: d = clamp((x2 - 2*xy) + y2, 0)  or  clamp(2 - 2*xy, 0) with xy on v_mfma_f32_32x32x2_f32
+// (exact fp32, == an fmaf chain over k -- cdna_hip_programming.md section 3).
+// SuperPointMatching: mask compaction -> S = exp(-d) -> row / column sums (fixed summation order,
+// no float atomics: results are reproducible run to run) -> score = (S/rowsum)*(S/colsum) ->
+// exact global top-k by a 3-pass radix select on the score bits (ties: lowest flat index first)
+// -> sorted (score desc) -> indices mapped back through the compaction tables.
+#include "common.hpp"
+
+namespace gr {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int PD_T = 64;   // output tile 64 x 64 per 256-thread block, 32 x 32 per wave
+constexpr int PD_K = 32;   // k-slab staged in LDS
+constexpr int PD_LD = PD_K + 1;
+
+enum { EPI_DIST = 0, EPI_EXPNEG = 1 };
+
+// out[i][j] = epilogue(dist(x[xi[i]], y[yi[j]]));  xi / yi optional gather tables (nullptr = identity).
+// n_dev / m_dev (optional) hold the row / column counts on the device (after a compaction).
+template <int EPI>
+__global__ __launch_bounds__(256) void pairwise_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, const int32_t* __restrict__ xi,
+    const int32_t* __restrict__ yi, int n, int m, const int32_t* __restrict__ nm_dev, int C,
+    int normalized, const float* __restrict__ x2, const float* __restrict__ y2,
+    float* __restrict__ out, int ld_out) {
+  __shared__ float sx[PD_T][PD_LD];
+  __shared__ float sy[PD_T][PD_LD];
+  if (nm_dev) {
+    n = nm_dev[0];
+    m = nm_dev[1];
+  }
+  const int i0 = blockIdx.y * PD_T, j0 = blockIdx.x * PD_T;
+  if (i0 >= n || j0 >= m) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wi = (w >> 1) * 32, wj = (w & 1) * 32;  // wave's 32x32 sub-tile
+  f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < C; k0 += PD_K) {
+    // stage 64 x 32 slabs of x and y (coalesced along k); out-of-range -> 0
+    for (int e = tid; e < PD_T * PD_K; e += 256) {
+      const int r = e / PD_K, k = e % PD_K;
+      const int gi = i0 + r, gj = j0 + r, gk = k0 + k;
+      float vx = 0.f, vy = 0.f;
+      if (gk < C) {
+        if (gi < n) vx = x[(int64_t)(xi ? xi[gi] : gi) * C + gk];
+        if (gj < m) vy = y[(int64_t)(yi ? yi[gj] : gj) * C + gk];
+      }
+      sx[r][k] = vx;
+      sy[r][k] = vy;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PD_K; k += 2) {
+      // A[i = lane & 31][k = lane >> 5],  B[k = lane >> 5][j = lane & 31]
+      const float a = sx[wi + (lane & 31)][k + (lane >> 5)];
+      const float b = sy[wj + (lane & 31)][k + (lane >> 5)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int gi = i0 + wi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int gj = j0 + wj + (lane & 31);
+    if (gi < n && gj < m) {
+      const float xy = acc[r];
+      float d;
+      if (normalized) d = 2.0f - 2.0f * xy;                    // pairwise_distance.py:26
+      else d = (x2[gi] - 2.0f * xy) + y2[gj];                   // pairwise_distance.py:30
+      d = fmaxf(d, 0.0f);                                       // :31 clamp(min=0)
+      if (EPI == EPI_EXPNEG) d = expf(-d);                      // superpoint_matching.py:37
+      out[(int64_t)gi * ld_out + gj] = d;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x, int n, int C,
+                                                     float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < C; ++k) {
+    const float v = x[(int64_t)i * C + k];
+    s += v * v;
+  }
+  out[i] = s;
+}
+
+// ---------------------------------------------------------------- SuperPointMatching pieces
+struct SpmHdr {
+  int32_t nr, ns;       // compacted sizes
+  uint32_t prefix;      // selected high bits so far
+  int32_t k_rem;        // how many still to take inside the selected bin
+  int32_t k;            // min(num_correspondences, nr * ns)
+  int32_t n_cand;       // candidates gathered (score >= threshold)
+  int32_t pad[2];
+};
+
+// single block: order-preserving compaction of the true mask entries (torch.nonzero order)
+__global__ __launch_bounds__(1024) void compact_masks_kernel(const uint8_t* __restrict__ rm, int nr_all,
+                                                             const uint8_t* __restrict__ sm, int ns_all,
+                                                             int num_corr, int32_t* __restrict__ ridx,
+                                                             int32_t* __restrict__ sidx,
+                                                             SpmHdr* __restrict__ hdr) {
+  __shared__ int wsum[1024 / WAVE];
+  __shared__ int carry;
+  for (int which = 0; which < 2; ++which) {
+    const uint8_t* mask = which ? sm : rm;
+    const int n = which ? ns_all : nr_all;
+    int32_t* dst = which ? sidx : ridx;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+      const int i = base + threadIdx.x;
+      const int f = (i < n) && (mask == nullptr || mask[i] != 0);
+      const unsigned long long bal = __ballot(f);
+      const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+      if (lane == 0) wsum[w] = __popcll(bal);
+      __syncthreads();
+      int off = carry;
+      for (int u = 0; u < w; ++u) off += wsum[u];
+      if (f) dst[off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int t = 0;
+        for (int u = 0; u < 1024 / WAVE; ++u) t += wsum[u];
+        carry += t;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      if (which) hdr->ns = carry; else hdr->nr = carry;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const long long tot = (long long)hdr->nr * hdr->ns;
+    hdr->k = (int)(tot < num_corr ? tot : num_corr);
+    hdr->prefix = 0;
+    hdr->k_rem = hdr->k;
+    hdr->n_cand = 0;
+  }
+}
+
+// row sums: one wave per row, lanes stride the columns, fixed-shape tree reduce
+__global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ S, int ld,
+                                                     const SpmHdr* __restrict__ hdr,
+                                                     float* __restrict__ rs) {
+  const int nr = hdr->nr, ns = hdr->ns;
+  const int r = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
+  const int lane = threadIdx.x & (WAVE - 1);
+  if (r >= nr) return;
+  float s = 0.f;
+  for (int c = lane; c < ns; c += WAVE) s += S[(int64_t)r * ld + c];
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) s += __shfl_xor(s, d, WAVE);
+  if (lane == 0) rs[r] = s;
+}
+
+// column sums: one thread per column, rows in order (coalesced across threads)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ S, int ld,
+                                                     const SpmHdr* __restrict__ hdr,
+                                                     float* __restrict__ cs) {
+  const int nr = hdr->nr, ns = hdr->ns;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ns) return;
+  float s = 0.f;
+  for (int r = 0; r < nr; ++r) s += S[(int64_t)r * ld + c];
+  cs[c] = s;
+}
+
+__device__ __forceinline__ float spm_score(const float* __restrict__ S, int ld, const float* rs,
+                                           const float* cs, int dual, int r, int c) {
+  const float s = S[(int64_t)r * ld + c];
+  // superpoint_matching.py:38-41: (S / rowsum) * (S / colsum)
+  return dual ? (s / rs[r]) * (s / cs[c]) : s;
+}
+
+constexpr int SEL_BITS[3] = {11, 11, 10};
+constexpr int SEL_SHIFT[3] = {21, 10, 0};
+
+// histogram of digit `pass` over the elements whose higher digits equal hdr->prefix
+__global__ __launch_bounds__(256) void select_hist_kernel(const float* __restrict__ S, int ld,
+                                                          const float* __restrict__ rs,
+                                                          const float* __restrict__ cs, int dual,
+                                                          const SpmHdr* __restrict__ hdr, int pass,
+                                                          uint32_t* __restrict__ hist /* [2048] */) {
+  __shared__ uint32_t sh[2048];
+  for (int i = threadIdx.x; i < 2048; i += 256) sh[i] = 0;
+  __syncthreads();
+  const int ns = hdr->ns;
+  const int64_t total = (int64_t)hdr->nr * ns;
+  const uint32_t prefix = hdr->prefix;
+  const int shift = SEL_SHIFT[pass], bits = SEL_BITS[pass];
+  const int hi_shift = shift + bits;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e / ns), c = (int)(e % ns);
+    const uint32_t u = __float_as_uint(spm_score(S, ld, rs, cs, dual, r, c));
+    if (hi_shift >= 32 || (u >> hi_shift) == (prefix >> hi_shift)) atomicAdd(&sh[(u >> shift) & ((1u << bits) - 1u)], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2048; i += 256)
+    if (sh[i]) atomicAdd(&hist[i], sh[i]);
+}
+
+// single block: pick the bin holding the k_rem-th largest, update prefix / k_rem, clear the histogram
+__global__ __launch_bounds__(256) void select_pick_kernel(SpmHdr* __restrict__ hdr, int pass,
+                                                          uint32_t* __restrict__ hist) {
+  __shared__ uint32_t sh[2048];
+  const int nb = 1 << SEL_BITS[pass];
+  for (int i = threadIdx.x; i < 2048; i += 256) {
+    sh[i] = i < nb ? hist[i] : 0;
+    hist[i] = 0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int k = hdr->k_rem;
+    int b = nb - 1;
+    if (k > 0) {
+      for (; b > 0; --b) {
+        if ((int)sh[b] >= k) break;
+        k -= (int)sh[b];
+      }
+    }
+    hdr->prefix |= (uint32_t)b << SEL_SHIFT[pass];
+    hdr->k_rem = k;  // how many of the selected bin are needed
+  }
+}
+
+constexpr int CAND_CAP = 4096;
+
+// gather every element with score >= threshold (bit pattern in hdr->prefix) as a sortable key
+__global__ __launch_bounds__(256) void select_gather_kernel(const float* __restrict__ S, int ld,
+                                                            const float* __restrict__ rs,
+                                                            const float* __restrict__ cs, int dual,
+                                                            SpmHdr* __restrict__ hdr,
+                                                            unsigned long long* __restrict__ cand) {
+  const int ns = hdr->ns;
+  const int64_t total = (int64_t)hdr->nr * ns;
+  const uint32_t thr = hdr->prefix;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e / ns), c = (int)(e % ns);
+    const uint32_t u = __float_as_uint(spm_score(S, ld, rs, cs, dual, r, c));
+    if (u >= thr) {
+      const int slot = atomicAdd(&hdr->n_cand, 1);
+      // larger key = higher score, then LOWER flat index
+      if (slot < CAND_CAP) cand[slot] = ((unsigned long long)u << 32) | (uint32_t)(~(uint32_t)e);
+    }
+  }
+}
+
+// single block: sort the candidates (descending), emit the first k
+__global__ __launch_bounds__(1024) void select_emit_kernel(const SpmHdr* __restrict__ hdr,
+                                                           const unsigned long long* __restrict__ cand,
+                                                           const int32_t* __restrict__ ridx,
+                                                           const int32_t* __restrict__ sidx,
+                                                           int64_t* __restrict__ out_ref,
+                                                           int64_t* __restrict__ out_src,
+                                                           float* __restrict__ out_score) {
+  __shared__ unsigned long long sk[CAND_CAP];
+  const int n = min(hdr->n_cand, CAND_CAP);
+  for (int i = threadIdx.x; i < CAND_CAP; i += 1024) sk[i] = i < n ? cand[i] : 0ull;
+  __syncthreads();
+  // bitonic sort, descending
+  for (int size = 2; size <= CAND_CAP; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < CAND_CAP / 2; t += 1024) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool desc = (lo & size) == 0;
+        const unsigned long long a = sk[lo], b = sk[hi];
+        if ((a < b) == desc) {
+          sk[lo] = b;
+          sk[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const int k = hdr->k, ns = hdr->ns;
+  for (int i = threadIdx.x; i < k; i += 1024) {
+    const unsigned long long key = sk[i];
+    const uint32_t e = ~(uint32_t)(key & 0xffffffffull);
+    out_ref[i] = ridx[e / (uint32_t)ns];   // superpoint_matching.py:44,47
+    out_src[i] = sidx[e % (uint32_t)ns];   // :45,48
+    out_score[i] = __uint_as_float((uint32_t)(key >> 32));
+  }
+}
+
+struct SpmWs {
+  SpmHdr* hdr;
+  int32_t* ridx;
+  int32_t* sidx;
+  float* S;
+  float* rs;
+  float* cs;
+  uint32_t* hist;
+  unsigned long long* cand;
+  size_t bytes;
+};
+
+SpmWs carve_spm(void* p, int64_t nr, int64_t ns) {
+  SpmWs w;
+  Carver c(p);
+  w.hdr = c.take<SpmHdr>(1);
+  w.ridx = c.take<int32_t>(nr);
+  w.sidx = c.take<int32_t>(ns);
+  w.S = c.take<float>(nr * ns);
+  w.rs = c.take<float>(nr);
+  w.cs = c.take<float>(ns);
+  w.hist = c.take<uint32_t>(2048);
+  w.cand = c.take<unsigned long long>(CAND_CAP);
+  w.bytes = c.used();
+  return w;
+}
+
+}  // namespace
+}  // namespace gr
+
+using namespace gr;
+
+extern "C" size_t gr_pairwise_distance_workspace_bytes(int64_t n, int64_t m) {
+  if (n < 0 || m < 0) return 0;
+  return align_up((size_t)(n + m) * sizeof(float) + 512, 256);
+}
+
+extern "C" int gr_pairwise_distance(const float* x, const float* y, int64_t n, int64_t m, int64_t c,
+                                    int normalized, float* out, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GR_REQUIRE(n >= 0 && m >= 0 && c >= 0 && n < (1ll << 31) && m < (1ll << 31) && c < (1ll << 31), "bad sizes");
+  if (n == 0 || m == 0) return GR_OK;
+  GR_REQUIRE(x && y && out, "null argument");
+  float* x2 = nullptr;
+  float* y2 = nullptr;
+  if (!normalized) {
+    if (!ws || ws_bytes < gr_pairwise_distance_workspace_bytes(n, m)) {
+      set_error("pairwise_distance workspace too small");
+      return GR_ERR_WORKSPACE;
+    }
+    x2 = static_cast<float*>(ws);
+    y2 = x2 + align_up((size_t)n, 64);
+    hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, (int)n, (int)c, x2);
+    hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, y, (int)m, (int)c, y2);
+  }
+  const dim3 grid((unsigned)((m + PD_T - 1) / PD_T), (unsigned)((n + PD_T - 1) / PD_T));
+  hipLaunchKernelGGL((pairwise_kernel<EPI_DIST>), grid, dim3(256), 0, stream, x, y, (const int32_t*)nullptr,
+                     (const int32_t*)nullptr, (int)n, (int)m, (const int32_t*)nullptr, (int)c, normalized, x2, y2, out,
+                     (int)m);
+  GR_LAUNCH_CHECK();
+  return GR_OK;
+}
+
+extern "C" size_t gr_superpoint_matching_workspace_bytes(int64_t nr, int64_t ns) {
+  if (nr < 0 || ns < 0) return 0;
+  return carve_spm(nullptr, nr, ns).bytes;
+}
+
+extern "C" int gr_superpoint_matching(const float* ref_feats, const float* src_feats, int64_t nr, int64_t ns,
+                                      int64_t c, const uint8_t* ref_masks, const uint8_t* src_masks,
+                                      int num_correspondences, int dual_normalization, int64_t* out_ref_idx,
+                                      int64_t* out_src_idx, float* out_scores, int64_t* h_num_out, void* ws,
+                                      size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GR_REQUIRE(h_num_out != nullptr, "h_num_out is null");
+  *h_num_out = 0;
+  GR_REQUIRE(nr >= 0 && ns >= 0 && c >= 0 && num_correspondences >= 0, "bad sizes");
+  GR_REQUIRE(nr * ns < (1ll << 32), "score matrix too large (%lld x %lld)", (long long)nr, (long long)ns);
+  GR_REQUIRE(num_correspondences <= CAND_CAP / 2, "num_correspondences must be <= %d", CAND_CAP / 2);
+  if (nr == 0 || ns == 0 || num_correspondences == 0) return GR_OK;
+  GR_REQUIRE(ref_feats && src_feats && out_ref_idx && out_src_idx && out_scores, "null argument");
+  SpmWs w = carve_spm(ws, nr, ns);
+  if (!ws || ws_bytes < w.bytes) {
+    set_error("superpoint_matching workspace too small: need %zu bytes, got %zu", w.bytes, ws_bytes);
+    return GR_ERR_WORKSPACE;
+  }
+  GR_HIP(hipMemsetAsync(w.hist, 0, 2048 * sizeof(uint32_t), stream));
+  hipLaunchKernelGGL(compact_masks_kernel, dim3(1), dim3(1024), 0, stream, ref_masks, (int)nr, src_masks, (int)ns,
+                     num_correspondences, w.ridx, w.sidx, w.hdr);
+  const dim3 grid((unsigned)((ns + PD_T - 1) / PD_T), (unsigned)((nr + PD_T - 1) / PD_T));
+  // features are L2-normalised by the caller (model.py:143-144): d = 2 - 2 xy  (superpoint_matching.py:37)
+  hipLaunchKernelGGL((pairwise_kernel<EPI_EXPNEG>), grid, dim3(256), 0, stream, ref_feats, src_feats, w.ridx, w.sidx,
+                     (int)nr, (int)ns, reinterpret_cast<const int32_t*>(w.hdr), (int)c, 1, (const float*)nullptr,
+                     (const float*)nullptr, w.S, (int)ns);
+  if (dual_normalization) {
+    hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, stream, w.S, (int)ns, w.hdr, w.rs);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, w.S, (int)ns, w.hdr, w.cs);
+  }
+  const int sel_blocks = (int)std::min<int64_t>(1024, (nr * ns + 255) / 256);
+  for (int pass = 0; pass < 3; ++pass) {
+    hipLaunchKernelGGL(select_hist_kernel, dim3(sel_blocks), dim3(256), 0, stream, w.S, (int)ns, w.rs, w.cs,
+                       dual_normalization, w.hdr, pass, w.hist);
+    hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(256), 0, stream, w.hdr, pass, w.hist);
+  }
+  hipLaunchKernelGGL(select_gather_kernel, dim3(sel_blocks), dim3(256), 0, stream, w.S, (int)ns, w.rs, w.cs,
+                     dual_normalization, w.hdr, w.cand);
+  hipLaunchKernelGGL(select_emit_kernel, dim3(1), dim3(1024), 0, stream, w.hdr, w.cand, w.ridx, w.sidx, out_ref_idx,
+                     out_src_idx, out_scores);
+  GR_LAUNCH_CHECK();
+  SpmHdr h;
+  GR_HIP(hipMemcpyAsync(&h, w.hdr, sizeof(h), hipMemcpyDeviceToHost, stream));
+  GR_HIP(hipStreamSynchronize(stream));
+  if (h.n_cand > CAND_CAP) {
+    set_error("superpoint_matching: %d scores tie at the selection threshold (more than %d); degenerate input",
+              h.n_cand, CAND_CAP);
+    return GR_ERR_UNSUPPORTED;
+  }
+  *h_num_out = h.k;
+  return GR_OK;
+}

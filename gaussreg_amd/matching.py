@@ -1,0 +1,134 @@
+"""Mirror of the reference's matching nn.Modules, bodies replaced by fused HIP kernels.
+
+    SuperPointMatching   geotransformer/modules/geotransformer/superpoint_matching.py:7-50
+    PointMatching        geotransformer/modules/geotransformer/point_matching.py:5-115
+                         (compute_correspondence_matrix is also what LocalGlobalRegistration uses,
+                          local_global_registration.py:49-83)
+
+Same constructor arguments, same forward signatures and return tuples; no parameters or buffers
+(no state-dict keys), like the reference.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def _f32c(t, dev):
+    if t.dtype != torch.float32:
+        raise RuntimeError("expected a float tensor")
+    return (t if t.is_cuda else t.to(dev)).contiguous()
+
+
+def _boolc(t, dev):
+    if t.dtype != torch.bool:
+        t = t != 0
+    return (t if t.is_cuda else t.to(dev)).contiguous()
+
+
+class SuperPointMatching(nn.Module):
+    def __init__(self, num_correspondences, dual_normalization=True):
+        super().__init__()
+        self.num_correspondences = num_correspondences
+        self.dual_normalization = dual_normalization
+
+    @torch.no_grad()
+    def forward(self, ref_feats, src_feats, ref_masks=None, src_masks=None):
+        """-> (ref_corr_indices (k,) i64, src_corr_indices (k,) i64, corr_scores (k,) f32 descending)."""
+        dev = _lib.require_gpu()
+        L = _lib.lib()
+        out_device = ref_feats.device
+        rf = _f32c(ref_feats, dev)
+        dev = rf.device
+        sf = _f32c(src_feats, dev)
+        rm = None if ref_masks is None else _boolc(ref_masks, dev)
+        sm = None if src_masks is None else _boolc(src_masks, dev)
+        nr, c = rf.shape
+        ns = sf.shape[0]
+        k = int(self.num_correspondences)
+        ri = torch.empty((k,), dtype=torch.int64, device=dev)
+        si = torch.empty((k,), dtype=torch.int64, device=dev)
+        sc = torch.empty((k,), dtype=torch.float32, device=dev)
+        n_out = ctypes.c_int64(0)
+        with torch.cuda.device(dev):
+            ws = _lib.workspace(dev, L.gr_superpoint_matching_workspace_bytes(nr, ns))
+            _lib.check(L.gr_superpoint_matching(_lib.ptr(rf), _lib.ptr(sf), nr, ns, c, _lib.ptr(rm), _lib.ptr(sm), k,
+                                                int(bool(self.dual_normalization)), _lib.ptr(ri), _lib.ptr(si),
+                                                _lib.ptr(sc), ctypes.byref(n_out), _lib.ptr(ws), ws.numel(),
+                                                _lib.stream_ptr(dev)))
+        n = n_out.value
+        ri, si, sc = ri[:n], si[:n], sc[:n]
+        if out_device.type != "cuda":
+            ri, si, sc = ri.to(out_device), si.to(out_device), sc.to(out_device)
+        return ri, si, sc
+
+
+class PointMatching(nn.Module):
+    def __init__(self, k: int, mutual: bool = True, confidence_threshold: float = 0.05, use_dustbin: bool = False,
+                 use_global_score: bool = False, remove_duplicate: bool = False):
+        super().__init__()
+        self.k = k
+        self.mutual = mutual
+        self.confidence_threshold = confidence_threshold
+        self.use_dustbin = use_dustbin
+        self.use_global_score = use_global_score
+        self.remove_duplicate = remove_duplicate
+        if use_dustbin:
+            # the reference's dustbin branch slices corr_mat[:, -1:, -1] (point_matching.py:61-62), which
+            # yields a (B, 1) tensor and cannot be combined with the (B, K, K) mask on the next line;
+            # GaussReg never enables it (model.py:51-65 uses LocalGlobalRegistration with use_dustbin False)
+            raise NotImplementedError("use_dustbin=True is not supported (unusable in the reference as well)")
+
+    def _corr(self, score_mat, ref_knn_masks, src_knn_masks, want_count):
+        dev = _lib.require_gpu()
+        L = _lib.lib()
+        s = _f32c(score_mat, dev)
+        dev = s.device
+        rm, sm = _boolc(ref_knn_masks, dev), _boolc(src_knn_masks, dev)
+        B, K1, K2 = s.shape
+        corr = torch.empty((B, K1, K2), dtype=torch.bool, device=dev)
+        n = ctypes.c_int64(0)
+        with torch.cuda.device(dev):
+            ws = _lib.workspace(dev, L.gr_point_matching_workspace_bytes(B))
+            _lib.check(L.gr_corr_matrix(_lib.ptr(s), B, K1, K2, _lib.ptr(rm), _lib.ptr(sm), int(self.k),
+                                        int(bool(self.mutual)), float(self.confidence_threshold), _lib.ptr(corr),
+                                        ctypes.byref(n) if want_count else None, _lib.ptr(ws), ws.numel(),
+                                        _lib.stream_ptr(dev)))
+        return s, corr, n.value, ws
+
+    @torch.no_grad()
+    def compute_correspondence_matrix(self, score_mat, ref_knn_masks, src_knn_masks):
+        """`score_mat` here is exp(log-scores), as in the reference call sites (point_matching.py:98,
+        local_global_registration.py:211); the kernel exponentiates, so pass it the logs."""
+        s, corr, _, _ = self._corr(torch.log(score_mat), ref_knn_masks, src_knn_masks, False)
+        return corr if score_mat.is_cuda else corr.to(score_mat.device)
+
+    @torch.no_grad()
+    def forward(self, ref_knn_points, src_knn_points, ref_knn_masks, src_knn_masks, ref_knn_indices, src_knn_indices,
+                score_mat, global_scores):
+        out_device = score_mat.device
+        s, corr, n, ws = self._corr(score_mat, ref_knn_masks, src_knn_masks, True)
+        dev = s.device
+        L = _lib.lib()
+        B, K1, K2 = s.shape
+        rp, sp = _f32c(ref_knn_points, dev), _f32c(src_knn_points, dev)
+        ri = ref_knn_indices.to(dev).contiguous()
+        si = src_knn_indices.to(dev).contiguous()
+        gs = _f32c(global_scores, dev) if (self.use_global_score and global_scores is not None) else None
+        o_rp = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        o_sp = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        o_ri = torch.empty((n,), dtype=torch.int64, device=dev)
+        o_si = torch.empty((n,), dtype=torch.int64, device=dev)
+        o_sc = torch.empty((n,), dtype=torch.float32, device=dev)
+        if n > 0:
+            with torch.cuda.device(dev):
+                _lib.check(L.gr_corr_gather(_lib.ptr(s), B, K1, K2, _lib.ptr(corr), _lib.ptr(rp), _lib.ptr(sp),
+                                            _lib.ptr(ri), _lib.ptr(si), _lib.ptr(gs), int(gs is not None),
+                                            _lib.ptr(o_rp), _lib.ptr(o_sp), _lib.ptr(o_ri), _lib.ptr(o_si),
+                                            _lib.ptr(o_sc), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)))
+        outs = (o_rp, o_sp, o_ri, o_si, o_sc)
+        if out_device.type != "cuda":
+            outs = tuple(o.to(out_device) for o in outs)
+        return outs

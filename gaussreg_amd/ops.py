@@ -26,3 +26,70 @@ def radius_search(q_points, s_points, q_lengths, s_lengths, radius, neighbor_lim
         ext._check_long(t, n)
         ext._check_contig(t, n)
     return ext.radius_neighbors_limited(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit)
+
+
+# ---------------------------------------------------------------------------------------------
+# dense / partition operators (reference: modules/ops/pairwise_distance.py, pointcloud_partition.py)
+import ctypes  # noqa: E402
+
+import torch  # noqa: E402
+
+from . import _lib  # noqa: E402
+
+
+def _cuda_f32(t, name):
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be a float tensor")
+    dev = _lib.require_gpu()
+    return (t if t.is_cuda else t.to(dev)).contiguous()
+
+
+def pairwise_distance(x, y, normalized=False, channel_first=False):
+    """pairwise_distance.py:4-31.  (*, N, C) x (*, M, C) -> (*, N, M); leading dims are looped."""
+    if channel_first:
+        x, y = x.transpose(-1, -2), y.transpose(-1, -2)
+    out_device = x.device
+    lead = x.shape[:-2]
+    if y.shape[:-2] != lead:
+        raise RuntimeError("pairwise_distance: x and y must have the same leading (batch) dimensions")
+    xs = _cuda_f32(x, "x").reshape(-1, x.shape[-2], x.shape[-1])
+    ys = _cuda_f32(y, "y").reshape(-1, y.shape[-2], y.shape[-1])
+    L = _lib.lib()
+    B, N, C = xs.shape
+    M = ys.shape[1]
+    out = torch.empty((B, N, M), dtype=torch.float32, device=xs.device)
+    with torch.cuda.device(xs.device):
+        ws = _lib.workspace(xs.device, L.gr_pairwise_distance_workspace_bytes(N, M))
+        st = _lib.stream_ptr(xs.device)
+        for b in range(B):
+            _lib.check(L.gr_pairwise_distance(_lib.ptr(xs[b]), _lib.ptr(ys[b]), N, M, C, int(bool(normalized)),
+                                              _lib.ptr(out[b]), _lib.ptr(ws), ws.numel(), st))
+    out = out.reshape(*lead, N, M)
+    return out if out_device.type == "cuda" else out.to(out_device)
+
+
+@torch.no_grad()
+def point_to_node_partition(points, nodes, point_limit, return_count=False):
+    """pointcloud_partition.py:61-111 without the (M, N) matrix.  Returns
+    (point_to_node (N,), [node_sizes (M,)], node_masks (M,), node_knn_indices (M,K), node_knn_masks (M,K))."""
+    out_device = points.device
+    p = _cuda_f32(points, "points")
+    nd = _cuda_f32(nodes, "nodes")
+    L = _lib.lib()
+    N, M, K = p.shape[0], nd.shape[0], int(point_limit)
+    dev = p.device
+    p2n = torch.empty((N,), dtype=torch.int64, device=dev)
+    masks = torch.empty((M,), dtype=torch.bool, device=dev)
+    knn_idx = torch.empty((M, K), dtype=torch.int64, device=dev)
+    knn_masks = torch.empty((M, K), dtype=torch.bool, device=dev)
+    with torch.cuda.device(dev):
+        ws = _lib.workspace(dev, L.gr_point_to_node_workspace_bytes(N, M))
+        _lib.check(L.gr_point_to_node_partition(_lib.ptr(p), N, _lib.ptr(nd), M, K, _lib.ptr(p2n), _lib.ptr(masks),
+                                                _lib.ptr(knn_idx), _lib.ptr(knn_masks), _lib.ptr(ws), ws.numel(),
+                                                _lib.stream_ptr(dev)))
+    res = [p2n, masks, knn_idx, knn_masks]
+    if return_count:
+        res.insert(1, torch.bincount(p2n, minlength=M))
+    if out_device.type != "cuda":
+        res = [r.to(out_device) for r in res]
+    return tuple(res)

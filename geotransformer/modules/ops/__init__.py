@@ -1,1 +1,6 @@
-from gaussreg_amd.ops import grid_subsample, radius_search  # noqa: F401
+from gaussreg_amd.ops import (  # noqa: F401
+    grid_subsample,
+    pairwise_distance,
+    point_to_node_partition,
+    radius_search,
+)

@@ -139,6 +139,50 @@ int gr_raster_render(int64_t P, const gr_raster_view* h_views, int num_views,
 int gr_raster_mark_visible(int64_t P, const float* means3D, const float* h_viewmatrix,
                            uint8_t* present, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Matching operators -- in the reference these are chains of stock ATen calls inside nn.Modules
+ * (no native code: SURVEY.md section 0 F2); the entry points replace the bodies of:
+ *
+ * gr_pairwise_distance       geotransformer/modules/ops/pairwise_distance.py:4-31 (channel-last, 2-D):
+ *                            out (n,m) = clamp((|x|^2 - 2 x y^T) + |y|^2, 0), or clamp(2 - 2 x y^T, 0) if
+ *                            `normalized`; x y^T on fp32 MFMA.
+ * gr_superpoint_matching     geotransformer/modules/geotransformer/superpoint_matching.py:13-50 (forward):
+ *                            masks (uint8, may be null = all true), L2-normalised features (nr,c)/(ns,c);
+ *                            out_* have room for num_correspondences entries; *h_num_out =
+ *                            min(num_correspondences, #valid_ref * #valid_src).  Synchronises `stream`.
+ * gr_corr_matrix             .../point_matching.py:32-66 == local_global_registration.py:49-83
+ *                            (compute_correspondence_matrix on exp(score_mat), use_dustbin=False):
+ *                            corr_mat (batch,k1,k2) uint8; *h_num_corr (optional) = number of true
+ *                            entries (synchronises when non-null).
+ * gr_corr_gather             .../point_matching.py:107-113: torch.nonzero order gathers; outputs sized by
+ *                            the count gr_corr_matrix returned; `ws` must be the buffer used there.
+ * gr_point_to_node_partition geotransformer/modules/ops/pointcloud_partition.py:61-111 (return_count=False):
+ *                            point_to_node (n) i64, node_masks (m) u8, node_knn_indices (m,point_limit) i64
+ *                            padded with n, node_knn_masks (m,point_limit) u8.
+ */
+size_t gr_pairwise_distance_workspace_bytes(int64_t n, int64_t m);
+int gr_pairwise_distance(const float* x, const float* y, int64_t n, int64_t m, int64_t c, int normalized,
+                         float* out, void* ws, size_t ws_bytes, void* stream);
+size_t gr_superpoint_matching_workspace_bytes(int64_t nr, int64_t ns);
+int gr_superpoint_matching(const float* ref_feats, const float* src_feats, int64_t nr, int64_t ns, int64_t c,
+                           const uint8_t* ref_masks, const uint8_t* src_masks, int num_correspondences,
+                           int dual_normalization, int64_t* out_ref_idx, int64_t* out_src_idx,
+                           float* out_scores, int64_t* h_num_out, void* ws, size_t ws_bytes, void* stream);
+size_t gr_point_matching_workspace_bytes(int64_t batch);
+int gr_corr_matrix(const float* score_mat, int64_t batch, int64_t k1, int64_t k2,
+                   const uint8_t* ref_knn_masks, const uint8_t* src_knn_masks, int k, int mutual,
+                   float confidence_threshold, uint8_t* corr_mat, int64_t* h_num_corr, void* ws,
+                   size_t ws_bytes, void* stream);
+int gr_corr_gather(const float* score_mat, int64_t batch, int64_t k1, int64_t k2, const uint8_t* corr_mat,
+                   const float* ref_knn_points, const float* src_knn_points, const int64_t* ref_knn_indices,
+                   const int64_t* src_knn_indices, const float* global_scores, int use_global_score,
+                   float* out_ref_points, float* out_src_points, int64_t* out_ref_indices,
+                   int64_t* out_src_indices, float* out_scores, void* ws, size_t ws_bytes, void* stream);
+size_t gr_point_to_node_workspace_bytes(int64_t n, int64_t m);
+int gr_point_to_node_partition(const float* points, int64_t n, const float* nodes, int64_t m, int point_limit,
+                               int64_t* point_to_node, uint8_t* node_masks, int64_t* node_knn_indices,
+                               uint8_t* node_knn_masks, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

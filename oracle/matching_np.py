@@ -1,0 +1,104 @@
+"""TEST INFRASTRUCTURE ONLY.  NumPy fp32 restatement of the reference's pure-PyTorch matching ops.
+
+Pinned against tests/golden/matching.npz, which was produced by importing the reference's own
+modules (tests/golden/gen_golden_matching.py).  Float paths: the reference runs ATen CPU/GPU
+kernels whose summation order is not specified, so parity is asserted to 1e-5 relative on values
+and exactly on indices wherever score gaps exceed the fp noise.
+
+  pairwise_distance           geotransformer/modules/ops/pairwise_distance.py:4-31
+  superpoint_matching         geotransformer/modules/geotransformer/superpoint_matching.py:13-50
+  correspondence_matrix       geotransformer/modules/geotransformer/point_matching.py:32-66
+                              (== local_global_registration.py:49-83)
+  point_matching              geotransformer/modules/geotransformer/point_matching.py:68-115
+  point_to_node_partition     geotransformer/modules/ops/pointcloud_partition.py:61-111
+"""
+import numpy as np
+
+f32 = np.float32
+
+
+def pairwise_distance(x, y, normalized=False):
+    """pairwise_distance.py:19-31 (channel-last): clamp(x2 - 2 xy + y2, 0) or clamp(2 - 2 xy, 0)."""
+    x, y = np.asarray(x, f32), np.asarray(y, f32)
+    xy = x @ y.T
+    if normalized:
+        d = f32(2.0) - f32(2.0) * xy
+    else:
+        x2 = (x * x).sum(-1, dtype=f32)[:, None]
+        y2 = (y * y).sum(-1, dtype=f32)[None, :]
+        d = x2 - f32(2.0) * xy + y2
+    return np.maximum(d, f32(0.0)).astype(f32)
+
+
+def superpoint_matching(ref_feats, src_feats, ref_masks=None, src_masks=None, num_correspondences=256,
+                        dual_normalization=True):
+    """superpoint_matching.py:32-48.  Ties in the global top-k are broken by ascending flat index."""
+    ref_feats, src_feats = np.asarray(ref_feats, f32), np.asarray(src_feats, f32)
+    if ref_masks is None:
+        ref_masks = np.ones(ref_feats.shape[0], bool)
+    if src_masks is None:
+        src_masks = np.ones(src_feats.shape[0], bool)
+    ref_indices = np.nonzero(ref_masks)[0]
+    src_indices = np.nonzero(src_masks)[0]
+    rf, sf = ref_feats[ref_indices], src_feats[src_indices]
+    s = np.exp(-pairwise_distance(rf, sf, normalized=True)).astype(f32)
+    if dual_normalization:
+        rs = s / s.sum(1, keepdims=True, dtype=f32)
+        cs = s / s.sum(0, keepdims=True, dtype=f32)
+        s = (rs * cs).astype(f32)
+    k = min(num_correspondences, s.size)
+    flat = s.reshape(-1)
+    order = np.lexsort((np.arange(flat.size), -flat))[:k]  # descending score, ascending index
+    scores = flat[order]
+    return ref_indices[order // s.shape[1]], src_indices[order % s.shape[1]], scores, s
+
+
+def _topk_mask(a, k, axis):
+    """True at the k largest entries along `axis` (ties: lowest index first)."""
+    n = a.shape[axis]
+    idx = np.argsort(-a, axis=axis, kind="stable")
+    take = np.take(idx, np.arange(min(k, n)), axis=axis)
+    m = np.zeros(a.shape, bool)
+    np.put_along_axis(m, take, True, axis=axis)
+    return m
+
+
+def correspondence_matrix(score_mat_exp, ref_knn_masks, src_knn_masks, k=3, mutual=True, confidence_threshold=0.05):
+    """point_matching.py:32-66: (row top-k & > thr) AND/OR (col top-k & > thr), AND validity mask."""
+    s = np.asarray(score_mat_exp, f32)
+    mask = ref_knn_masks[:, :, None] & src_knn_masks[:, None, :]
+    ref_corr = _topk_mask(s, k, 2) & (s > f32(confidence_threshold))
+    src_corr = _topk_mask(s, k, 1) & (s > f32(confidence_threshold))
+    corr = (ref_corr & src_corr) if mutual else (ref_corr | src_corr)
+    return corr & mask
+
+
+def point_matching(ref_knn_points, src_knn_points, ref_knn_masks, src_knn_masks, ref_knn_indices, src_knn_indices,
+                   score_mat, global_scores, k=3, mutual=True, confidence_threshold=0.05, use_global_score=False):
+    """point_matching.py:96-115 (use_dustbin=False)."""
+    s = np.exp(np.asarray(score_mat, f32)).astype(f32)
+    corr = correspondence_matrix(s, ref_knn_masks, src_knn_masks, k, mutual, confidence_threshold)
+    if use_global_score:
+        s = (s * np.asarray(global_scores, f32)[:, None, None]).astype(f32)
+    b, i, j = np.nonzero(corr)
+    return (ref_knn_points[b, i], src_knn_points[b, j], ref_knn_indices[b, i], src_knn_indices[b, j], s[b, i, j], corr)
+
+
+def point_to_node_partition(points, nodes, point_limit):
+    """pointcloud_partition.py:84-102.  Returns point_to_node (N,), node_masks (M,),
+    node_knn_indices (M,K) padded with N, node_knn_masks (M,K)."""
+    points, nodes = np.asarray(points, f32), np.asarray(nodes, f32)
+    N, M = points.shape[0], nodes.shape[0]
+    d = pairwise_distance(nodes, points)  # (M, N)
+    p2n = d.argmin(0)
+    node_masks = np.zeros(M, bool)
+    node_masks[p2n] = True
+    d = d.copy()
+    own = np.zeros_like(d, bool)
+    own[p2n, np.arange(N)] = True
+    d[~own] = f32(1e12)
+    K = point_limit
+    order = np.argsort(d, axis=1, kind="stable")[:, :K]
+    knn_masks = p2n[order] == np.arange(M)[:, None]
+    knn_idx = np.where(knn_masks, order, N)
+    return p2n, node_masks, knn_idx, knn_masks, d

@@ -1,0 +1,148 @@
+"""GPU parity: HIP matching operators (through the C ABI) vs golden vectors produced by the
+reference's own Python modules, and vs oracle/matching_np.py on seeded inputs.
+Tolerance: values 1e-5 relative (GPU/CPU summation order differs), indices exact (the fixtures have
+no score ties within fp noise)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _c(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_pairwise_distance_vs_reference_golden():
+    from gaussreg_amd.ops import pairwise_distance
+    g = load_golden("matching.npz")
+    d = pairwise_distance(_c(g["pd_x"]), _c(g["pd_y"])).cpu().numpy()
+    np.testing.assert_allclose(d, g["pd_plain"], rtol=1e-5, atol=2e-5)
+    dn = pairwise_distance(_c(g["pd_xn"]), _c(g["pd_yn"]), normalized=True).cpu().numpy()
+    np.testing.assert_allclose(dn, g["pd_normalized"], rtol=1e-5, atol=2e-6)
+    # batched + channel_first
+    x = torch.randn(3, 17, 50, device="cuda")
+    y = torch.randn(3, 17, 70, device="cuda")
+    d3 = pairwise_distance(x, y, channel_first=True)
+    ref = ((x.transpose(1, 2)[:, :, None, :] - y.transpose(1, 2)[:, None, :, :]) ** 2).sum(-1)
+    torch.testing.assert_close(d3, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_superpoint_matching_vs_reference_golden():
+    from gaussreg_amd.matching import SuperPointMatching
+    g = load_golden("matching.npz")
+    ri, si, sc = SuperPointMatching(256, True)(_c(g["spm_ref"]), _c(g["spm_src"]), _c(g["spm_ref_masks"]),
+                                               _c(g["spm_src_masks"]))
+    assert ri.dtype == torch.int64 and sc.dtype == torch.float32 and ri.shape == (256,)
+    np.testing.assert_allclose(sc.cpu().numpy(), g["spm_scores"], rtol=1e-5)
+    assert np.array_equal(ri.cpu().numpy(), g["spm_ref_idx"])
+    assert np.array_equal(si.cpu().numpy(), g["spm_src_idx"])
+    ri, si, sc = SuperPointMatching(64, False)(_c(g["spm_ref"]), _c(g["spm_src"]))
+    np.testing.assert_allclose(sc.cpu().numpy(), g["spm_nodual_scores"], rtol=1e-5)
+    assert np.array_equal(ri.cpu().numpy(), g["spm_nodual_ref_idx"])
+    assert np.array_equal(si.cpu().numpy(), g["spm_nodual_src_idx"])
+
+
+@pytest.mark.parametrize("nr,ns,k", [(767, 801, 256), (40, 3, 256), (1500, 1200, 256)])
+def test_superpoint_matching_vs_oracle(nr, ns, k):
+    from gaussreg_amd.matching import SuperPointMatching
+    from oracle import matching_np as M
+    rng = np.random.default_rng(nr)
+    base = rng.normal(size=(max(nr, ns), 256)).astype(np.float32)
+    ref = base[:nr] + 0.4 * rng.normal(size=(nr, 256)).astype(np.float32)
+    src = base[rng.permutation(max(nr, ns))[:ns]] + 0.4 * rng.normal(size=(ns, 256)).astype(np.float32)
+    ref /= np.linalg.norm(ref, axis=1, keepdims=True)
+    src /= np.linalg.norm(src, axis=1, keepdims=True)
+    rm, sm = rng.random(nr) > 0.1, rng.random(ns) > 0.1
+    wri, wsi, wsc, _ = M.superpoint_matching(ref, src, rm, sm, k, True)
+    ri, si, sc = SuperPointMatching(k, True)(_c(ref), _c(src), _c(rm), _c(sm))
+    assert sc.shape[0] == wsc.shape[0] == min(k, int(rm.sum()) * int(sm.sum()))
+    np.testing.assert_allclose(sc.cpu().numpy(), wsc, rtol=2e-5)
+    # indices: exact wherever neighbouring scores differ by more than the fp noise
+    gap = np.abs(np.diff(wsc)) / wsc[:-1]
+    safe = np.concatenate([[True], gap > 2e-5]) & np.concatenate([gap > 2e-5, [True]])
+    assert np.array_equal(ri.cpu().numpy()[safe], wri[safe]) and np.array_equal(si.cpu().numpy()[safe], wsi[safe])
+    assert safe.mean() > 0.5
+    # as multisets of (ref, src) pairs the two results agree except possibly at the k-th boundary
+    got = set(zip(ri.cpu().numpy().tolist(), si.cpu().numpy().tolist()))
+    want = set(zip(wri.tolist(), wsi.tolist()))
+    assert len(got ^ want) <= 4
+
+
+def test_point_matching_vs_reference_golden():
+    from gaussreg_amd.matching import PointMatching
+    g = load_golden("matching.npz")
+    args = [_c(g[k]) for k in ("pm_ref_points", "pm_src_points", "pm_ref_masks", "pm_src_masks", "pm_ref_idx",
+                               "pm_src_idx", "pm_score", "pm_global")]
+    pm = PointMatching(k=3, mutual=True, confidence_threshold=0.05)
+    corr = pm.compute_correspondence_matrix(torch.exp(args[6]), args[2], args[3])
+    assert corr.dtype == torch.bool and np.array_equal(corr.cpu().numpy(), g["pm_corr_mat"])
+    rp, sp, ri, si, sc = pm(*args)
+    assert np.array_equal(ri.cpu().numpy(), g["pm_out_ref_idx"]) and np.array_equal(si.cpu().numpy(), g["pm_out_src_idx"])
+    assert np.array_equal(rp.cpu().numpy(), g["pm_out_ref_points"]) and np.array_equal(sp.cpu().numpy(), g["pm_out_src_points"])
+    np.testing.assert_allclose(sc.cpu().numpy(), g["pm_out_scores"], rtol=1e-5)
+    pm2 = PointMatching(k=2, mutual=False, confidence_threshold=0.1, use_global_score=True)
+    rp, sp, ri, si, sc = pm2(*args)
+    assert np.array_equal(ri.cpu().numpy(), g["pm2_out_ref_idx"]) and np.array_equal(si.cpu().numpy(), g["pm2_out_src_idx"])
+    np.testing.assert_allclose(sc.cpu().numpy(), g["pm2_out_scores"], rtol=1e-5)
+    with pytest.raises(NotImplementedError):
+        PointMatching(3, use_dustbin=True)
+
+
+def test_point_matching_demo_shape_vs_oracle():
+    """P=256 patches of 128x128 (config.py:110-125 shapes)."""
+    from gaussreg_amd.matching import PointMatching
+    from oracle import matching_np as M
+    rng = np.random.default_rng(2)
+    P, K = 256, 128
+    logits = rng.normal(size=(P, K, K)).astype(np.float32) * 4
+    score = (logits - np.log(np.exp(logits).sum(2, keepdims=True)) + logits - np.log(np.exp(logits).sum(1, keepdims=True))) * 0.5
+    score = score.astype(np.float32)
+    rm, sm = rng.random((P, K)) > 0.3, rng.random((P, K)) > 0.3
+    rp, sp = rng.normal(size=(P, K, 3)).astype(np.float32), rng.normal(size=(P, K, 3)).astype(np.float32)
+    ri, si = rng.integers(0, 30000, (P, K)), rng.integers(0, 30000, (P, K))
+    gs = rng.random(P).astype(np.float32)
+    want = M.point_matching(rp, sp, rm, sm, ri, si, score, gs)
+    got = PointMatching(3)( _c(rp), _c(sp), _c(rm), _c(sm), _c(ri), _c(si), _c(score), _c(gs))
+    assert got[2].shape[0] == want[2].shape[0] > 100
+    assert np.array_equal(got[2].cpu().numpy(), want[2]) and np.array_equal(got[3].cpu().numpy(), want[3])
+    assert np.array_equal(got[0].cpu().numpy(), want[0]) and np.array_equal(got[1].cpu().numpy(), want[1])
+    np.testing.assert_allclose(got[4].cpu().numpy(), want[4], rtol=1e-5)
+
+
+def test_point_to_node_vs_reference_golden():
+    from gaussreg_amd.ops import point_to_node_partition
+    g = load_golden("matching.npz")
+    p2n, nm, idx, km = point_to_node_partition(_c(g["p2n_points"]), _c(g["p2n_nodes"]), 64)
+    assert p2n.dtype == torch.int64 and nm.dtype == torch.bool and idx.dtype == torch.int64 and km.dtype == torch.bool
+    assert np.array_equal(p2n.cpu().numpy(), g["p2n_point_to_node"])
+    assert np.array_equal(nm.cpu().numpy(), g["p2n_node_masks"])
+    assert np.array_equal(km.cpu().numpy(), g["p2n_knn_masks"])
+    assert np.array_equal(idx.cpu().numpy(), g["p2n_knn_idx"])
+    out = point_to_node_partition(_c(g["p2n_points"]), _c(g["p2n_nodes"]), 64, return_count=True)
+    assert np.array_equal(out[1].cpu().numpy(), np.bincount(g["p2n_point_to_node"], minlength=g["p2n_nodes"].shape[0]))
+
+
+def test_point_to_node_demo_shape_vs_oracle():
+    """N ~ 25 k fine points, M ~ 767 nodes, K = 128."""
+    from gaussreg_amd.ops import point_to_node_partition
+    from oracle import matching_np as M
+    rng = np.random.default_rng(4)
+    N, Mn = 24745, 767
+    pts = (rng.random((N, 3)) * [4.0, 3.0, 2.5]).astype(np.float32)
+    nodes = pts[rng.permutation(N)[:Mn]] + rng.normal(0, 0.02, (Mn, 3)).astype(np.float32)
+    wp, wm, widx, wkm, dmat = M.point_to_node_partition(pts, nodes, 128)
+    p2n, nm, idx, km = [t.cpu().numpy() for t in point_to_node_partition(_c(pts), _c(nodes), 128)]
+    # argmin may legitimately differ where the two best node distances are within fp noise
+    full = M.pairwise_distance(nodes, pts)
+    part = np.partition(full, 1, axis=0)
+    clear = (part[1] - part[0]) > 1e-5
+    assert clear.mean() > 0.99 and np.array_equal(p2n[clear], wp[clear])
+    if np.array_equal(p2n, wp):
+        assert np.array_equal(nm, wm) and np.array_equal(km, wkm)
+        same_rows = (idx == widx).all(1)
+        assert same_rows.mean() > 0.98  # rows differ only where two member distances tie within fp noise
+        for r in np.nonzero(~same_rows)[0]:
+            assert set(idx[r]) == set(widx[r])
