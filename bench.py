@@ -47,6 +47,19 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(key, ok):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary (separate FETCH_SIZE / WRITE_SIZE
+    passes, FETCH doubled per MI355X_MICROARCH.md); only valid for the configuration it was taken on."""
+    if not ok:
+        return None
+    try:
+        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_hbm.json"))
+        with open(os.path.join(ROOT, "profiles", cands[-1])) as fh:
+            return json.load(fh)["traffic_bytes_per_launch"].get(key)
+    except Exception:
+        return None
+
+
 def timing_read(L, name):
     tot = ctypes.c_double(0)
     n = ctypes.c_int64(0)
@@ -143,7 +156,8 @@ def main():
                 "achieved": round(blend_bytes / blend_avg_s / 1e9, 2) if blend_avg_s > 0 else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(blend_bytes / blend_avg_s / 1e9 / HBM_PEAK_GBS, 4) if blend_avg_s > 0 else None,
-                "traffic": None, "bytes_per_launch": blend_bytes, "avg_launch_ms": round(blend_avg_s * 1e3, 4),
+                "traffic": pmc_traffic("raster_blend", (P, W, H, V) == (1_000_000, 640, 480, 8)),
+                "bytes_per_launch": blend_bytes, "avg_launch_ms": round(blend_avg_s * 1e3, 4),
                 "other_kernels_ms": {"raster_preprocess": round(pre_ms / max(pre_n, 1), 4),
                                      "raster_sort": round(sort_ms / max(sort_n, 1), 4)}}
 
@@ -184,7 +198,7 @@ def main():
                                "achieved": round(fill_bytes / fill_avg_s / 1e9, 2) if fill_avg_s > 0 else None,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(fill_bytes / fill_avg_s / 1e9 / HBM_PEAK_GBS, 4) if fill_avg_s > 0 else None,
-                               "traffic": None, "bytes_per_launch": fill_bytes,
+                               "traffic": pmc_traffic("radius_fill", B == 8), "bytes_per_launch": fill_bytes,
                                "avg_launch_ms": round(fill_avg_s * 1e3, 4),
                                "other_kernels_ms": {"radius_count": round(cnt_ms / max(cnt_n, 1), 4)}}}
 
