@@ -56,6 +56,8 @@ struct RadiusWs {
   float4* sorted_s;
   float4* sorted_q;
   int32_t* q_count;    // [3][nq] hits per (z-slab, query)
+  int2* q_rng;         // [3 dy][3 slab][nq] candidate range (p0, p1) per band
+  unsigned long long* q_mask;  // [3 slab][nq] hit bits in candidate enumeration order
   int32_t* blk_stats;  // [blocks][2]
   int64_t ccap;
   size_t bytes;
@@ -79,6 +81,8 @@ RadiusWs carve(void* ws, int64_t nq, int64_t ns, int64_t batch) {
   w.sorted_s = c.take<float4>(ns);
   w.sorted_q = c.take<float4>(nq);
   w.q_count = c.take<int32_t>(3 * nq);
+  w.q_rng = c.take<int2>(9 * nq);
+  w.q_mask = c.take<unsigned long long>(3 * nq);
   w.blk_stats = c.take<int32_t>(2 * ((nq + RT - 1) / RT + 1));
   w.bytes = c.used();
   return w;
@@ -223,12 +227,14 @@ struct TravLds {
   static constexpr int THREADS = NSUB * RQ;
   static constexpr int STAGE_CAP = 12 * RQ;  // float4 slots
   // ints: offs[RQ+1], orig[RQ], sub[3*RQ], band_lo[9], band_hi[9], band_base[10], wsum[THREADS/64]
-  static constexpr int N_INTS = (RQ + 1) + RQ + NSUB * RQ + 9 + 9 + 10 + THREADS / WAVE;
-  static constexpr size_t INTS_BYTES = (size_t)(N_INTS * 4 + 15) / 16 * 16;
+  static constexpr int TABLE_MAX = 64;  // clouds whose offsets / grids are cached in LDS
+  static constexpr int N_INTS = (RQ + 1) + RQ + NSUB * RQ + 9 + 9 + 10 + THREADS / WAVE + (TABLE_MAX + 1);
+  static constexpr size_t TABLE_OFF = (size_t)(N_INTS * 4 + 15) / 16 * 16;
+  static constexpr size_t INTS_BYTES = TABLE_OFF + (size_t)TABLE_MAX * 48;
   static constexpr size_t STAGE_BYTES = (size_t)STAGE_CAP * 16;
   static constexpr size_t FIXED = INTS_BYTES + STAGE_BYTES;
-  static size_t total(int64_t max_block_hits) {  // + keys (8 B) + row ids (1 B) per hit
-    return FIXED + (size_t)max_block_hits * 8 + ((size_t)max_block_hits + 15) / 16 * 16;
+  static size_t total(int64_t max_block_hits) {  // FILL: int tables + keys (8 B) + row ids (1 B) per hit
+    return TABLE_OFF + (size_t)max_block_hits * 8 + ((size_t)max_block_hits + 15) / 16 * 16;
   }
 };
 
@@ -236,8 +242,8 @@ template <int RQ, bool FILL, bool HITS_IN_LDS>
 __global__ __launch_bounds__(NSUB* RQ) void traverse_kernel(
     const float4* __restrict__ sorted_q, int nq, const int32_t* __restrict__ q_off, int nb,
     const BatchGrid* __restrict__ grids, const int32_t* __restrict__ start_s,
-    const float4* __restrict__ sorted_s, float r2, int32_t* __restrict__ q_cnt,
-    int32_t* __restrict__ blk_stats, int width, int64_t pad_value, int64_t* __restrict__ out,
+    const float4* __restrict__ sorted_s, float r2, int32_t* __restrict__ q_cnt, int2* __restrict__ q_rng,
+    unsigned long long* __restrict__ q_mask, int32_t* __restrict__ blk_stats, int width, int64_t pad_value, int64_t* __restrict__ out,
     int max_block_hits, unsigned long long* __restrict__ g_hits, unsigned char* __restrict__ g_rows) {
   using L = TravLds<RQ>;
   static_assert(RQ % WAVE == 0 && RQ <= 256, "row ids are bytes; waves must not straddle slabs");
@@ -249,22 +255,42 @@ __global__ __launch_bounds__(NSUB* RQ) void traverse_kernel(
   int* band_hi = band_lo + NBAND;
   int* band_base = band_hi + NBAND;
   int* wsum = band_base + (NBAND + 1);
+  // COUNT pass only: per-cloud tables cached in LDS so the per-query setup is not a chain of
+  // dependent global round trips (query -> cloud id -> grid -> cell starts)
+  int* s_qoff = wsum + L::THREADS / WAVE;
+  BatchGrid* s_grids = reinterpret_cast<BatchGrid*>(smem + L::TABLE_OFF);
   float4* stage = reinterpret_cast<float4*>(smem + L::INTS_BYTES);
-  unsigned long long* hits = HITS_IN_LDS ? reinterpret_cast<unsigned long long*>(smem + L::FIXED)
+  // FILL keeps no candidate stage: its hit segments start right after the int tables
+  unsigned long long* hits = HITS_IN_LDS ? reinterpret_cast<unsigned long long*>(smem + L::TABLE_OFF)
                                          : g_hits + (int64_t)blockIdx.x * max_block_hits;
   unsigned char* rows = HITS_IN_LDS
-                            ? reinterpret_cast<unsigned char*>(smem + L::FIXED + (size_t)max_block_hits * 8)
+                            ? reinterpret_cast<unsigned char*>(smem + L::TABLE_OFF + (size_t)max_block_hits * 8)
                             : g_rows + (int64_t)blockIdx.x * max_block_hits;
 
   const int tid = threadIdx.x;
   const int slot = tid % RQ, j = tid / RQ;  // query slot in block, z-slab
-  const int t = blockIdx.x * RQ + slot;
+  // XCD-aware block order: the dispatcher places block b on XCD b % 8 (speed only, never
+  // correctness).  Give each XCD one CONTIGUOUS eighth of the cell-ordered queries so the candidate
+  // bands of neighbouring blocks (which overlap ~9x) are served by that XCD's own 4 MiB L2 instead
+  // of being re-fetched from Infinity Cache by all eight.
+  const int nblk = (nq + RQ - 1) / RQ;
+  const int per_xcd = gridDim.x / 8;  // the grid is padded to a multiple of 8 blocks
+  const int blk = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (blk >= nblk) return;
+  const int t = blk * RQ + slot;
   const int lane = tid & (WAVE - 1);
   const bool valid = t < nq;
 
   if (tid < NBAND) {
     band_lo[tid] = 0x7fffffff;
     band_hi[tid] = 0;
+  }
+  const bool tables_in_lds = !FILL && nb <= L::TABLE_MAX;
+  if (tables_in_lds) {
+    for (int i = tid; i <= nb; i += L::THREADS) s_qoff[i] = q_off[i];
+    const int4* gsrc = reinterpret_cast<const int4*>(grids);
+    int4* gdst = reinterpret_cast<int4*>(s_grids);
+    for (int i = tid; i < nb * 3; i += L::THREADS) gdst[i] = gsrc[i];
   }
   int my_off = 0;
   if (FILL) {
@@ -297,108 +323,170 @@ __global__ __launch_bounds__(NSUB* RQ) void traverse_kernel(
     __syncthreads();
   }
 
-  // ---- per-thread candidate ranges (global positions in sorted_s) for bands (dy, dz = j-1)
+  // ---- per-thread candidate ranges (global positions in sorted_s) for bands (dy, dz = j-1):
+  //      computed by the COUNT pass and stored; the FILL pass just reloads them (one coalesced trip)
   float4 qp = make_float4(0.f, 0.f, 0.f, 0.f);
   int p0[3] = {0, 0, 0}, p1[3] = {0, 0, 0};
   if (valid) {
     qp = sorted_q[t];
-    if (FILL && j == 0) orig[slot] = __float_as_int(qp.w);
-    const int b = find_batch(q_off, nb, __float_as_int(qp.w));
-    const BatchGrid g = grids[b];
-    const double ux = cell_coord(qp.x, g.org[0], g.inv_cell);
-    const double uy = cell_coord(qp.y, g.org[1], g.inv_cell);
-    const double cz = cell_coord(qp.z, g.org[2], g.inv_cell) + (double)(j - 1);
-    const double tx = (double)(g.dim[0] - 1), ty = (double)(g.dim[1] - 1), tz = (double)(g.dim[2] - 1);
-    // the comparisons are written so that NaN coordinates give "no candidates"
-    if ((ux + 1.0 >= 0.0) && (ux - 1.0 <= tx) && cz >= 0.0 && cz <= tz) {
-      const int lx = (int)fmin(fmax(ux - 1.0, 0.0), tx);
-      const int hx = (int)fmin(fmax(ux + 1.0, 0.0), tx);
+    if (FILL) {
+      if (j == 0) orig[slot] = __float_as_int(qp.w);
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        const double cy = uy + (double)(i - 1);
-        if (cy >= 0.0 && cy <= ty) {
-          const int base = g.cell_base + g.dim[0] * ((int)cy + g.dim[1] * (int)cz);
-          p0[i] = start_s[base + lx];
-          p1[i] = start_s[base + hx + 1];
+        const int2 r = q_rng[(int64_t)(i * NSUB + j) * nq + t];
+        p0[i] = r.x;
+        p1[i] = r.y;
+      }
+    } else {
+      int b;
+      BatchGrid g;
+      if (tables_in_lds) {
+        b = find_batch(s_qoff, nb, __float_as_int(qp.w));
+        g = s_grids[b];
+      } else {
+        b = find_batch(q_off, nb, __float_as_int(qp.w));
+        g = grids[b];
+      }
+      const double ux = cell_coord(qp.x, g.org[0], g.inv_cell);
+      const double uy = cell_coord(qp.y, g.org[1], g.inv_cell);
+      const double cz = cell_coord(qp.z, g.org[2], g.inv_cell) + (double)(j - 1);
+      const double tx = (double)(g.dim[0] - 1), ty = (double)(g.dim[1] - 1), tz = (double)(g.dim[2] - 1);
+      // the comparisons are written so that NaN coordinates give "no candidates"
+      if ((ux + 1.0 >= 0.0) && (ux - 1.0 <= tx) && cz >= 0.0 && cz <= tz) {
+        const int lx = (int)fmin(fmax(ux - 1.0, 0.0), tx);
+        const int hx = (int)fmin(fmax(ux + 1.0, 0.0), tx);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const double cy = uy + (double)(i - 1);
+          if (cy >= 0.0 && cy <= ty) {
+            const int base = g.cell_base + g.dim[0] * ((int)cy + g.dim[1] * (int)cz);
+            p0[i] = start_s[base + lx];
+            p1[i] = start_s[base + hx + 1];
+          }
         }
       }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) q_rng[(int64_t)(i * NSUB + j) * nq + t] = make_int2(p0[i], p1[i]);
     }
   } else if (FILL && j == 0) {
     orig[slot] = -1;
   }
-  // ---- block-wide extent of every band (waves are slab-uniform: band index = 3*j + i)
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    int lo = p1[i] > p0[i] ? p0[i] : 0x7fffffff;
-    int hi = p1[i] > p0[i] ? p1[i] : 0;
-#pragma unroll
-    for (int d = WAVE / 2; d > 0; d >>= 1) {
-      lo = min(lo, __shfl_xor(lo, d, WAVE));
-      hi = max(hi, __shfl_xor(hi, d, WAVE));
-    }
-    if (lane == 0 && hi > 0) {
-      atomicMin(&band_lo[3 * j + i], lo);
-      atomicMax(&band_hi[3 * j + i], hi);
-    }
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int k = 0; k < NBAND; ++k) {
-      band_base[k] = acc;
-      acc += band_hi[k] > band_lo[k] ? band_hi[k] - band_lo[k] : 0;
-    }
-    band_base[NBAND] = acc;
-  }
-  __syncthreads();
-  const bool staged = band_base[NBAND] <= L::STAGE_CAP;
-  if (staged) {
-#pragma unroll
-    for (int k = 0; k < NBAND; ++k) {
-      const int lo = band_lo[k], len = band_hi[k] - lo, bb = band_base[k];
-      for (int i = tid; i < len; i += L::THREADS) stage[bb + i] = sorted_s[lo + i];
-    }
-    __syncthreads();
-  }
-
-  // ---- walk the candidates (two instantiations so the staged loop uses ds_read, not flat loads)
   int n = 0;
-  auto walk = [&](auto load) {
+  if (!FILL) {
+    // ---- block-wide extent of every band (waves are slab-uniform: band index = 3*j + i)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const int e = p1[i];
-      for (int p = p0[i]; p < e; p += 4) {
-        float4 sp[4];
+      int lo = p1[i] > p0[i] ? p0[i] : 0x7fffffff;
+      int hi = p1[i] > p0[i] ? p1[i] : 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) sp[u] = load(i, min(p + u, e - 1));
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          // nanoflann.hpp:432-440: result += diff*diff for x, y, z starting from 0
-          const float dx = qp.x - sp[u].x;
-          const float dy = qp.y - sp[u].y;
-          const float dz = qp.z - sp[u].z;
-          const float d = (dx * dx + dy * dy) + dz * dz;
-          if (p + u < e && d < r2) {
-            if (FILL) {
-              // key orders by (distance, index); d >= 0 so its bit pattern is monotone
-              hits[my_off + n] = ((unsigned long long)__float_as_uint(d) << 32) |
-                                 (unsigned int)__float_as_int(sp[u].w);
-              rows[my_off + n] = (unsigned char)slot;
-            }
-            ++n;
-          }
-        }
+      for (int d = WAVE / 2; d > 0; d >>= 1) {
+        lo = min(lo, __shfl_xor(lo, d, WAVE));
+        hi = max(hi, __shfl_xor(hi, d, WAVE));
+      }
+      if (lane == 0 && hi > 0) {
+        atomicMin(&band_lo[3 * j + i], lo);
+        atomicMax(&band_hi[3 * j + i], hi);
       }
     }
-  };
-  if (valid) {
+    __syncthreads();
+    if (tid == 0) {
+      int acc = 0;
+      for (int k = 0; k < NBAND; ++k) {
+        band_base[k] = acc;
+        acc += band_hi[k] > band_lo[k] ? band_hi[k] - band_lo[k] : 0;
+      }
+      band_base[NBAND] = acc;
+    }
+    __syncthreads();
+    const bool staged = band_base[NBAND] <= L::STAGE_CAP;
     if (staged) {
-      int rel[3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) rel[i] = band_base[3 * j + i] - band_lo[3 * j + i];
-      walk([&](int i, int p) { return stage[rel[i] + p]; });
+      for (int k = 0; k < NBAND; ++k) {
+        const int lo = band_lo[k], len = band_hi[k] - lo, bb = band_base[k];
+        for (int i = tid; i < len; i += L::THREADS) stage[bb + i] = sorted_s[lo + i];
+      }
+      __syncthreads();
+    }
+    // ---- walk every candidate; remember the hits as a bit mask (bit = position in this thread's
+    //      enumeration order) so the FILL pass only ever touches the ~16 % that matter
+    unsigned long long mask = 0ull;
+    int bitpos = 0;
+    auto walk = [&](auto load) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int e = p1[i];
+        for (int p = p0[i]; p < e; p += 4) {
+          float4 sp[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) sp[u] = load(i, min(p + u, e - 1));
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            // nanoflann.hpp:432-440: result += diff*diff for x, y, z starting from 0
+            const float dx = qp.x - sp[u].x;
+            const float dy = qp.y - sp[u].y;
+            const float dz = qp.z - sp[u].z;
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            const bool hit = p + u < e && d < r2;
+            if (hit && bitpos + u < 64) mask |= 1ull << (bitpos + u);
+            n += hit ? 1 : 0;
+          }
+          bitpos += min(4, e - p);
+        }
+      }
+    };
+    if (valid) {
+      if (staged) {
+        int rel[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rel[i] = band_base[3 * j + i] - band_lo[3 * j + i];
+        walk([&](int i, int p) { return stage[rel[i] + p]; });
+      } else {
+        walk([&](int, int p) { return sorted_s[p]; });
+      }
+      q_mask[(int64_t)j * nq + t] = mask;
+    }
+  } else if (valid) {
+    // ---- FILL: gather only the hits (bit mask from the COUNT pass), eight loads in flight;
+    //      threads with more than 64 candidates re-walk everything
+    const int len0 = p1[0] - p0[0], len1 = p1[1] - p0[1], len2 = p1[2] - p0[2];
+    auto emit = [&](const float4 sp) {
+      const float dx = qp.x - sp.x;
+      const float dy = qp.y - sp.y;
+      const float dz = qp.z - sp.z;
+      const float d = (dx * dx + dy * dy) + dz * dz;
+      if (d < r2) {
+        // key orders by (distance, index); d >= 0 so its bit pattern is monotone
+        hits[my_off + n] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)__float_as_int(sp.w);
+        rows[my_off + n] = (unsigned char)slot;
+        ++n;
+      }
+    };
+    if (len0 + len1 + len2 <= 64) {
+      unsigned long long bits = q_mask[(int64_t)j * nq + t];
+      while (bits) {
+        int pos[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          pos[u] = -1;
+          if (bits) {
+            const int bpos = __ffsll((long long)bits) - 1;
+            bits &= bits - 1;
+            // enumeration order: band 0, then band 1, then band 2
+            pos[u] = bpos < len0 ? p0[0] + bpos : (bpos < len0 + len1 ? p0[1] + (bpos - len0) : p0[2] + (bpos - len0 - len1));
+          }
+        }
+        float4 sp[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (pos[u] >= 0) sp[u] = sorted_s[pos[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (pos[u] >= 0) emit(sp[u]);
+      }
     } else {
-      walk([&](int, int p) { return sorted_s[p]; });
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        for (int p = p0[i]; p < p1[i]; ++p) emit(sorted_s[p]);
     }
   }
 
@@ -427,8 +515,8 @@ __global__ __launch_bounds__(NSUB* RQ) void traverse_kernel(
         mx = max(mx, wsum[i]);
         sm += wsum[RQ / WAVE + i];
       }
-      blk_stats[2 * blockIdx.x] = mx;      // reduced by reduce_stats_kernel: no same-address
-      blk_stats[2 * blockIdx.x + 1] = sm;  // global atomics (they cost ~11 ns EACH when contended)
+      blk_stats[2 * blk] = mx;      // reduced by reduce_stats_kernel: no same-address
+      blk_stats[2 * blk + 1] = sm;  // global atomics (they cost ~11 ns EACH when contended)
     }
     return;
   }
@@ -441,15 +529,20 @@ __global__ __launch_bounds__(NSUB* RQ) void traverse_kernel(
     const int a = offs[r], len = offs[r + 1] - a;
     const unsigned long long key = hits[e];
     int rank = 0;
-    for (int jj = 0; jj < len; ++jj) rank += hits[a + jj] < key ? 1 : 0;
+    int jj = 0;
+    for (; jj + 4 <= len; jj += 4) {  // four independent LDS reads in flight
+      const unsigned long long h0 = hits[a + jj], h1 = hits[a + jj + 1], h2 = hits[a + jj + 2], h3 = hits[a + jj + 3];
+      rank += (h0 < key ? 1 : 0) + (h1 < key ? 1 : 0) + (h2 < key ? 1 : 0) + (h3 < key ? 1 : 0);
+    }
+    for (; jj < len; ++jj) rank += hits[a + jj] < key ? 1 : 0;
     if (rank < width) out[(int64_t)orig[r] * width + rank] = (int64_t)(unsigned int)(key & 0xffffffffull);
   }
   // ---- padding: one row per wave iteration, lanes along the row
-  const int rows_here = min(RQ, nq - blockIdx.x * RQ);
-  for (int r = tid / WAVE; r < rows_here; r += L::THREADS / WAVE) {
+  const int rows_here = min(RQ, nq - blk * RQ);
+  for (int r = tid / 32; r < rows_here; r += L::THREADS / 32) {  // half a wave per row
     const int cnt = offs[r + 1] - offs[r];
     int64_t* row = out + (int64_t)orig[r] * width;
-    for (int c = cnt + lane; c < width; c += WAVE) row[c] = pad_value;
+    for (int c = cnt + (lane & 31); c < width; c += 32) row[c] = pad_value;
   }
 }
 
@@ -492,10 +585,11 @@ int launch_count(const RadiusWs& w, const float4* sorted_q, int64_t nq, int nb, 
                  hipStream_t stream) {
   using L = TravLds<RQ>;
   const int blocks = (int)((nq + RQ - 1) / RQ);
+  const int grid = (blocks + 7) / 8 * 8;
   KernelTimer timer("radius_count", stream);
-  hipLaunchKernelGGL((traverse_kernel<RQ, false, true>), dim3(blocks), dim3(L::THREADS), L::FIXED, stream, sorted_q,
-                     (int)nq, w.q_off, nb, w.grids, start_s, w.sorted_s, r2, w.q_count, w.blk_stats, 0, (int64_t)0,
-                     (int64_t*)nullptr, 0, (unsigned long long*)nullptr, (unsigned char*)nullptr);
+  hipLaunchKernelGGL((traverse_kernel<RQ, false, true>), dim3(grid), dim3(L::THREADS), L::FIXED, stream, sorted_q,
+                     (int)nq, w.q_off, nb, w.grids, start_s, w.sorted_s, r2, w.q_count, w.q_rng, w.q_mask, w.blk_stats,
+                     0, (int64_t)0, (int64_t*)nullptr, 0, (unsigned long long*)nullptr, (unsigned char*)nullptr);
   hipLaunchKernelGGL(reduce_stats_kernel, dim3(1), dim3(1024), 0, stream, w.blk_stats, blocks, w.hdr);
   GR_LAUNCH_CHECK();
   return GR_OK;
@@ -506,6 +600,7 @@ int launch_fill(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t n
                 int64_t max_block_hits, int64_t* out, hipStream_t stream) {
   using L = TravLds<RQ>;
   const int blocks = (int)((nq + RQ - 1) / RQ);
+  const int grid = (blocks + 7) / 8 * 8;
   const size_t lds = L::total(max_block_hits);
   KernelTimer timer("radius_fill", stream);
   if (lds <= 160 * 1024) {
@@ -513,19 +608,19 @@ int launch_fill(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t n
     if (lds > 64 * 1024)
       GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  160 * 1024));
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(L::THREADS), lds, stream, sorted_q, (int)nq, w.q_off, nb, w.grids,
-                       w.start, w.sorted_s, r2, w.q_count, w.blk_stats, (int)width, ns, out, (int)max_block_hits,
-                       (unsigned long long*)nullptr, (unsigned char*)nullptr);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(L::THREADS), lds, stream, sorted_q, (int)nq, w.q_off, nb, w.grids,
+                       w.start, w.sorted_s, r2, w.q_count, w.q_rng, w.q_mask, w.blk_stats, (int)width, ns, out,
+                       (int)max_block_hits, (unsigned long long*)nullptr, (unsigned char*)nullptr);
   } else {
     // very dense neighbourhoods: hit lists live in a scratch allocation owned by this call
     char* scratch = nullptr;
     const size_t per_block = (size_t)max_block_hits;
-    GR_HIP(hipMallocAsync(reinterpret_cast<void**>(&scratch), (size_t)blocks * per_block * 9 + 256, stream));
+    GR_HIP(hipMallocAsync(reinterpret_cast<void**>(&scratch), (size_t)grid * per_block * 9 + 256, stream));
     unsigned long long* g_hits = reinterpret_cast<unsigned long long*>(scratch);
-    unsigned char* g_rows = reinterpret_cast<unsigned char*>(scratch + (size_t)blocks * per_block * 8);
-    hipLaunchKernelGGL((traverse_kernel<RQ, true, false>), dim3(blocks), dim3(L::THREADS), L::FIXED, stream,
-                       sorted_q, (int)nq, w.q_off, nb, w.grids, w.start, w.sorted_s, r2, w.q_count, w.blk_stats,
-                       (int)width, ns, out, (int)max_block_hits, g_hits, g_rows);
+    unsigned char* g_rows = reinterpret_cast<unsigned char*>(scratch + (size_t)grid * per_block * 8);
+    hipLaunchKernelGGL((traverse_kernel<RQ, true, false>), dim3(grid), dim3(L::THREADS), L::TABLE_OFF, stream,
+                       sorted_q, (int)nq, w.q_off, nb, w.grids, w.start, w.sorted_s, r2, w.q_count, w.q_rng,
+                       w.q_mask, w.blk_stats, (int)width, ns, out, (int)max_block_hits, g_hits, g_rows);
     GR_HIP(hipFreeAsync(scratch, stream));
   }
   GR_LAUNCH_CHECK();
