@@ -102,6 +102,10 @@ struct KernelTimer {
   hipStream_t stream_;
 };
 
+// Host: iteration order of std::unordered_map<size_t,...> after inserting `keys` (distinct) in order;
+// perm_out[j] = base + index of the j-th iterated key (hash_order.hip).
+void unordered_map_order(const uint64_t* keys, int64_t n, int32_t base, int32_t* perm_out);
+
 size_t sort_pairs_u32_temp_bytes(int64_t n);
 int sort_pairs_u32_i32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
                        const int32_t* vals_in, int32_t* vals_out, int64_t n, int begin_bit,

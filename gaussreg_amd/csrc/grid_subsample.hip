@@ -15,7 +15,6 @@
 //             order IS the reference's output order, :44-47) and gather by that permutation.
 // Compiled with -ffp-contract=off.
 #include <cmath>
-#include <unordered_map>
 #include <vector>
 
 #include "common.hpp"
@@ -373,14 +372,13 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
       GR_HIP(hipMemcpyAsync(hk.data(), w.keys_fo, sizeof(uint64_t) * h_m, hipMemcpyDeviceToHost, stream));
       GR_HIP(hipStreamSynchronize(stream));
       // Replay: the reference inserts keys in first-occurrence order into an unordered_map and
-      // emits in its iteration order (grid_subsampling_cpu.cpp:28-47).  Same container, same
-      // libstdc++, same order.  Ranks are global but clouds are contiguous in rank.
+      // emits in its iteration order (grid_subsampling_cpu.cpp:28-47).  hash_order.hip replays the
+      // container's own linking rules with the real libstdc++ rehash policy on flat arrays (no node
+      // allocations).  Ranks are global but clouds are contiguous in rank.
       std::vector<int32_t> perm(h_m);
-      int64_t r0 = 0, j = 0;
+      int64_t r0 = 0;
       for (int64_t b = 0; b < batch; ++b) {
-        std::unordered_map<std::size_t, int32_t> m;
-        for (int64_t r = r0; r < r0 + h_mb[b]; ++r) m.emplace((std::size_t)hk[r], (int32_t)r);
-        for (const auto& kv : m) perm[j++] = kv.second;
+        unordered_map_order(hk.data() + r0, h_mb[b], (int32_t)r0, perm.data() + r0);  // hash_order.hip
         r0 += h_mb[b];
       }
       GR_HIP(hipMemcpyAsync(w.perm, perm.data(), sizeof(int32_t) * h_m, hipMemcpyHostToDevice, stream));

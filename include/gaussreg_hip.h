@@ -83,6 +83,10 @@ int gr_radius_fill(const float* q, const float* s, int64_t nq, int64_t ns, int64
  *   GR_ORDER_CELL       ascending voxel key -- fully on device, same multiset of rows.
  * Synchronises `stream` (the output size is data dependent).
  */
+/* Host-only helper behind GR_ORDER_REFERENCE (exported so it can be tested without a GPU):
+ * h_perm[j] = index of the j-th key std::unordered_map<size_t,...> iterates after inserting the
+ * n distinct h_keys in order. */
+int gr_host_unordered_map_order(const uint64_t* h_keys, int64_t n, int32_t* h_perm);
 #define GR_ORDER_REFERENCE 0
 #define GR_ORDER_CELL 1
 size_t gr_grid_subsample_workspace_bytes(int64_t n, int64_t batch);

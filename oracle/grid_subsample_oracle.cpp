@@ -98,3 +98,12 @@ int64_t oracle_grid_subsampling(const float* pts, int64_t n, const int64_t* leng
 }
 
 }  // extern "C"
+
+// Iteration order of a REAL std::unordered_map<size_t,int> after inserting `keys` in order
+// (checker for the product's array replay, gaussreg_amd/csrc/hash_order.hip).
+extern "C" void oracle_unordered_map_order(const uint64_t* keys, int64_t n, int32_t* perm) {
+  std::unordered_map<std::size_t, int32_t> m;
+  for (int64_t i = 0; i < n; ++i) m.emplace(static_cast<std::size_t>(keys[i]), static_cast<int32_t>(i));
+  int64_t j = 0;
+  for (const auto& kv : m) perm[j++] = kv.second;
+}
