@@ -2,6 +2,7 @@
 from gaussreg_amd.rasterizer import (  # noqa: F401
     GaussianRasterizationSettings,
     GaussianRasterizer,
+    ViewBatch,
     rasterize_gaussians,
     rasterize_views,
 )

@@ -1,0 +1,221 @@
+// KPConv forward ("next" row) without the (M,H,C) / (M,H,K) / (K,M,C) temporaries.
+//
+// Replaces  geotransformer/modules/kpconv/kpconv.py:90-120  (and functional.py:6-22, 54-67 for the two
+// pooling helpers).  The reference gathers neighbor_feats (M,H,C) -- 1.2 GB at stage 2 of the demo
+// pyramid -- and runs two batched matmuls over it.  Here:
+//   rowflag   flag[n] = (sum_c feats[n,c] > 0)                       (kpconv.py:112-113, once per call)
+//   gather    one workgroup per query: kernel-point influences w[h,k] = max(1 - |y_h - kp_k| / sigma, 0)
+//             computed once into LDS, then every thread owns a channel and accumulates the K weighted sums
+//             over the neighbours with coalesced feature-row reads            -> WF (M, K*Cin)
+//   gemm      out = WF (M x K*Cin) . W (K*Cin x Cout) on fp32 MFMA 32x32x2, epilogue / neighbor_num + bias
+#include "common.hpp"
+
+namespace gr {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int KP_MAX = 16;   // kernel points (config.py:84 kernel_size = 15)
+constexpr int KP_HMAX = 256; // neighbours per query staged at once
+
+__global__ __launch_bounds__(256) void rowflag_kernel(const float* __restrict__ f, int n, int C,
+                                                      uint8_t* __restrict__ flag) {
+  const int row = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
+  const int lane = threadIdx.x & (WAVE - 1);
+  if (row >= n) return;
+  float s = 0.f;
+  for (int c = lane; c < C; c += WAVE) s += f[(int64_t)row * C + c];
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) s += __shfl_xor(s, d, WAVE);
+  if (lane == 0) flag[row] = s > 0.0f ? 1 : 0;
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void kp_gather_kernel(
+    const float* __restrict__ s_feats, const float* __restrict__ q_points, const float* __restrict__ s_points,
+    const int64_t* __restrict__ nbr, int N, int H, int Cin, int K, const float* __restrict__ kpts, float sigma,
+    float inf, const uint8_t* __restrict__ flag, float* __restrict__ WF, float* __restrict__ inv_num) {
+  __shared__ float s_w[KP_HMAX][KP_MAX + 1];
+  __shared__ int s_idx[KP_HMAX];
+  __shared__ int s_cnt;
+  const int m = blockIdx.x;
+  const float qx = q_points[3 * (int64_t)m], qy = q_points[3 * (int64_t)m + 1], qz = q_points[3 * (int64_t)m + 2];
+  float acc[KP_MAX];
+#pragma unroll
+  for (int k = 0; k < KP_MAX; ++k) acc[k] = 0.f;
+  if (threadIdx.x == 0) s_cnt = 0;
+  for (int h0 = 0; h0 < H; h0 += KP_HMAX) {
+    const int hn = min(KP_HMAX, H - h0);
+    __syncthreads();
+    int local = 0;
+    for (int h = threadIdx.x; h < hn; h += T) {
+      const int64_t idx = nbr[(int64_t)m * H + h0 + h];
+      const bool pad = idx >= N || idx < 0;
+      s_idx[h] = pad ? -1 : (int)idx;
+      // kpconv.py:90-92: shadow support at +inf, neighbours centred on the query
+      const float nx = (pad ? inf : s_points[3 * idx]) - qx;
+      const float ny = (pad ? inf : s_points[3 * idx + 1]) - qy;
+      const float nz = (pad ? inf : s_points[3 * idx + 2]) - qz;
+      for (int k = 0; k < K; ++k) {
+        const float dx = nx - kpts[3 * k], dy = ny - kpts[3 * k + 1], dz = nz - kpts[3 * k + 2];
+        const float sq = (dx * dx + dy * dy) + dz * dz;                   // :97
+        s_w[h][k] = fmaxf(1.0f - sqrtf(sq) / sigma, 0.0f);                // :98
+      }
+      local += (!pad && flag[idx]) ? 1 : 0;                               // :112-113
+    }
+    if (local) atomicAdd(&s_cnt, local);
+    __syncthreads();
+    for (int c = threadIdx.x; c < Cin; c += T) {
+      // a thread owns channel c only when Cin <= T; otherwise it flushes per c below
+      float a[KP_MAX];
+#pragma unroll
+      for (int k = 0; k < KP_MAX; ++k) a[k] = 0.f;
+      for (int h = 0; h < hn; ++h) {
+        const int idx = s_idx[h];
+        if (idx < 0) continue;                                            // zero shadow feature (:103)
+        const float fv = s_feats[(int64_t)idx * Cin + c];
+#pragma unroll
+        for (int k = 0; k < KP_MAX; ++k) a[k] = fmaf(s_w[h][k], fv, a[k]);  // :105 (M,K,H) x (M,H,C)
+      }
+      if (Cin <= T) {
+#pragma unroll
+        for (int k = 0; k < KP_MAX; ++k) acc[k] += a[k];
+      } else {
+        float* dst = WF + (int64_t)m * K * Cin + c;
+        for (int k = 0; k < K; ++k) dst[(int64_t)k * Cin] = (h0 == 0 ? 0.f : dst[(int64_t)k * Cin]) + a[k];
+      }
+    }
+  }
+  if (Cin <= T && threadIdx.x < Cin) {
+    float* dst = WF + (int64_t)m * K * Cin + threadIdx.x;
+    for (int k = 0; k < K; ++k) dst[(int64_t)k * Cin] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) inv_num[m] = (float)max(s_cnt, 1);                // :114 max(neighbor_num, 1)
+}
+
+constexpr int GT = 64, GK = 32, GLD = GK + 1;
+
+// C (M x N) = A (M x Kd, row-major) . B (Kd x N, row-major);  out = C / den[m] + bias[n]
+__global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ A, const float* __restrict__ B, int M,
+                                                      int N, int Kd, const float* __restrict__ den,
+                                                      const float* __restrict__ bias, float* __restrict__ out) {
+  __shared__ float sa[GT][GLD];
+  __shared__ float sb[GT][GLD];
+  const int i0 = blockIdx.y * GT, j0 = blockIdx.x * GT;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wi = (w >> 1) * 32, wj = (w & 1) * 32;
+  f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < Kd; k0 += GK) {
+    for (int e = tid; e < GT * GK; e += 256) {
+      const int r = e / GK, k = e % GK;   // A tile: coalesced along k
+      const int gi = i0 + r, gk = k0 + k;
+      sa[r][k] = (gi < M && gk < Kd) ? A[(int64_t)gi * Kd + gk] : 0.f;
+      const int kk = e / GT, j = e % GT;  // B tile: coalesced along j, stored transposed
+      const int gj = j0 + j, gkb = k0 + kk;
+      sb[j][kk] = (gj < N && gkb < Kd) ? B[(int64_t)gkb * N + gj] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < GK; k += 2) {
+      const float a = sa[wi + (lane & 31)][k + (lane >> 5)];
+      const float b = sb[wj + (lane & 31)][k + (lane >> 5)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int gi = i0 + wi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int gj = j0 + wj + (lane & 31);
+    if (gi < M && gj < N) {
+      float v = acc[r];
+      if (den) v = v / den[gi];          // kpconv.py:115
+      if (bias) v = v + bias[gj];        // :118-119
+      out[(int64_t)gi * N + gj] = v;
+    }
+  }
+}
+
+// functional.py:54-67 maxpool (zero shadow row) / :6-22 nearest_upsample
+__global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ x, int N, int C,
+                                                   const int64_t* __restrict__ nbr, int M, int H, int mode,
+                                                   float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)M * C) return;
+  const int m = (int)(e / C), c = (int)(e % C);
+  if (mode == 1) {  // nearest upsample: first neighbour only
+    const int64_t idx = nbr[(int64_t)m * H];
+    out[e] = (idx >= N || idx < 0) ? 0.f : x[idx * C + c];
+    return;
+  }
+  float best = -INFINITY;
+  for (int h = 0; h < H; ++h) {
+    const int64_t idx = nbr[(int64_t)m * H + h];
+    const float v = (idx >= N || idx < 0) ? 0.f : x[idx * C + c];
+    best = fmaxf(best, v);
+  }
+  out[e] = best;
+}
+
+}  // namespace
+}  // namespace gr
+
+using namespace gr;
+
+extern "C" size_t gr_kpconv_workspace_bytes(int64_t n, int64_t m, int64_t k, int64_t cin) {
+  if (n < 0 || m < 0 || k < 0 || cin < 0) return 0;
+  return align_up((size_t)m * k * cin * sizeof(float), 256) + align_up((size_t)m * sizeof(float), 256) +
+         align_up((size_t)n + 1, 256) + 1024;
+}
+
+extern "C" int gr_kpconv_forward(const float* s_feats, const float* q_points, const float* s_points,
+                                 const int64_t* neighbor_indices, int64_t n, int64_t m, int64_t h, int64_t cin,
+                                 int64_t cout, const float* kernel_points, int64_t k, const float* weights,
+                                 const float* bias, float sigma, float inf, float* out, void* ws, size_t ws_bytes,
+                                 void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GR_REQUIRE(n >= 0 && m >= 0 && h >= 0 && cin >= 1 && cout >= 1 && k >= 1, "bad sizes");
+  GR_REQUIRE(k <= KP_MAX, "kernel_size must be <= %d", KP_MAX);
+  GR_REQUIRE(m * k * cin < (1ll << 40) && n < (1ll << 31) && m < (1ll << 31), "sizes too large");
+  if (m == 0) return GR_OK;
+  GR_REQUIRE(s_feats && q_points && s_points && neighbor_indices && kernel_points && weights && out, "null argument");
+  if (!ws || ws_bytes < gr_kpconv_workspace_bytes(n, m, k, cin)) {
+    set_error("kpconv workspace too small");
+    return GR_ERR_WORKSPACE;
+  }
+  char* p = static_cast<char*>(ws);
+  float* WF = reinterpret_cast<float*>(p);
+  p += align_up((size_t)m * k * cin * sizeof(float), 256);
+  float* num = reinterpret_cast<float*>(p);
+  p += align_up((size_t)m * sizeof(float), 256);
+  uint8_t* flag = reinterpret_cast<uint8_t*>(p);
+  KernelTimer timer("kpconv", stream);
+  if (n > 0)
+    hipLaunchKernelGGL(rowflag_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, s_feats, (int)n, (int)cin, flag);
+  if (cin <= 64)
+    hipLaunchKernelGGL((kp_gather_kernel<64>), dim3((unsigned)m), dim3(64), 0, stream, s_feats, q_points, s_points,
+                       neighbor_indices, (int)n, (int)h, (int)cin, (int)k, kernel_points, sigma, inf, flag, WF, num);
+  else if (cin <= 128)
+    hipLaunchKernelGGL((kp_gather_kernel<128>), dim3((unsigned)m), dim3(128), 0, stream, s_feats, q_points, s_points,
+                       neighbor_indices, (int)n, (int)h, (int)cin, (int)k, kernel_points, sigma, inf, flag, WF, num);
+  else
+    hipLaunchKernelGGL((kp_gather_kernel<256>), dim3((unsigned)m), dim3(256), 0, stream, s_feats, q_points, s_points,
+                       neighbor_indices, (int)n, (int)h, (int)cin, (int)k, kernel_points, sigma, inf, flag, WF, num);
+  const dim3 grid((unsigned)((cout + GT - 1) / GT), (unsigned)((m + GT - 1) / GT));
+  hipLaunchKernelGGL(gemm_nn_kernel, grid, dim3(256), 0, stream, WF, weights, (int)m, (int)cout, (int)(k * cin), num, bias,
+                     out);
+  GR_LAUNCH_CHECK();
+  return GR_OK;
+}
+
+extern "C" int gr_neighbor_pool(const float* x, int64_t n, int64_t c, const int64_t* neighbor_indices, int64_t m,
+                                int64_t h, int mode, float* out, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GR_REQUIRE(n >= 0 && c >= 1 && m >= 0 && h >= 1 && (mode == 0 || mode == 1), "bad arguments");
+  if (m == 0) return GR_OK;
+  GR_REQUIRE(x && neighbor_indices && out, "null argument");
+  hipLaunchKernelGGL(pool_kernel, dim3((unsigned)((m * c + 255) / 256)), dim3(256), 0, stream, x, (int)n, (int)c,
+                     neighbor_indices, (int)m, (int)h, mode, out);
+  GR_LAUNCH_CHECK();
+  return GR_OK;
+}

@@ -164,6 +164,23 @@ int gr_raster_mark_visible(int64_t P, const float* means3D, const float* h_viewm
  *                            point_to_node (n) i64, node_masks (m) u8, node_knn_indices (m,point_limit) i64
  *                            padded with n, node_knn_masks (m,point_limit) u8.
  */
+/* gr_sinkhorn ("next" row): geotransformer/modules/sinkhorn/learnable_sinkhorn.py:20-66
+ * LearnableLogOptimalTransport.forward: scores (batch,m,n), masks uint8 (null = all valid), alpha read
+ * from DEVICE memory (the module's learnable parameter), out (batch, m+1, n+1). */
+int gr_sinkhorn(const float* scores, int64_t batch, int64_t m, int64_t n, const uint8_t* row_masks,
+                const uint8_t* col_masks, const float* alpha_dev, int num_iterations, float inf, float* out,
+                void* stream);
+/* gr_kpconv_forward ("next" row): geotransformer/modules/kpconv/kpconv.py:79-122 KPConv.forward
+ * (rigid kernel points): s_feats (n,cin), q_points (m,3), s_points (n,3), neighbor_indices (m,h) int64 padded
+ * with n, kernel_points (k,3), weights (k,cin,cout), bias (cout) or null -> out (m,cout).
+ * gr_neighbor_pool: kpconv/functional.py maxpool (mode 0, :54-67) / nearest_upsample (mode 1, :6-22). */
+size_t gr_kpconv_workspace_bytes(int64_t n, int64_t m, int64_t k, int64_t cin);
+int gr_kpconv_forward(const float* s_feats, const float* q_points, const float* s_points,
+                      const int64_t* neighbor_indices, int64_t n, int64_t m, int64_t h, int64_t cin, int64_t cout,
+                      const float* kernel_points, int64_t k, const float* weights, const float* bias, float sigma,
+                      float inf, float* out, void* ws, size_t ws_bytes, void* stream);
+int gr_neighbor_pool(const float* x, int64_t n, int64_t c, const int64_t* neighbor_indices, int64_t m, int64_t h,
+                     int mode, float* out, void* stream);
 size_t gr_pairwise_distance_workspace_bytes(int64_t n, int64_t m);
 int gr_pairwise_distance(const float* x, const float* y, int64_t n, int64_t m, int64_t c, int normalized,
                          float* out, void* ws, size_t ws_bytes, void* stream);

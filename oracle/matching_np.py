@@ -102,3 +102,69 @@ def point_to_node_partition(points, nodes, point_limit):
     knn_masks = p2n[order] == np.arange(M)[:, None]
     knn_idx = np.where(knn_masks, order, N)
     return p2n, node_masks, knn_idx, knn_masks, d
+
+
+# ------------------------------------------------------------------------------------------------
+# "next" rows
+def _logsumexp(a, axis):
+    m = a.max(axis=axis, keepdims=True)
+    return (np.log(np.exp(a - m).sum(axis=axis, dtype=f32, keepdims=True)) + m).squeeze(axis).astype(f32)
+
+
+def sinkhorn(scores, row_masks=None, col_masks=None, alpha=1.0, num_iterations=100, inf=1e12):
+    """geotransformer/modules/sinkhorn/learnable_sinkhorn.py:20-66 (forward) in fp32 NumPy."""
+    s = np.asarray(scores, f32)
+    B, M, N = s.shape
+    rm = np.ones((B, M), bool) if row_masks is None else np.asarray(row_masks, bool)
+    cm = np.ones((B, N), bool) if col_masks is None else np.asarray(col_masks, bool)
+    prm = np.zeros((B, M + 1), bool)
+    prm[:, :M] = ~rm
+    pcm = np.zeros((B, N + 1), bool)
+    pcm[:, :N] = ~cm
+    P = np.full((B, M + 1, N + 1), f32(alpha), f32)
+    P[:, :M, :N] = s
+    P[prm[:, :, None] | pcm[:, None, :]] = f32(-inf)
+    nvr, nvc = rm.sum(1).astype(f32), cm.sum(1).astype(f32)
+    norm = -np.log(nvr + nvc).astype(f32)
+    log_mu = np.empty((B, M + 1), f32)
+    log_mu[:, :M] = norm[:, None]
+    log_mu[:, M] = np.log(nvc) + norm
+    log_mu[prm] = f32(-inf)
+    log_nu = np.empty((B, N + 1), f32)
+    log_nu[:, :N] = norm[:, None]
+    log_nu[:, N] = np.log(nvr) + norm
+    log_nu[pcm] = f32(-inf)
+    u, v = np.zeros_like(log_mu), np.zeros_like(log_nu)
+    for _ in range(num_iterations):
+        u = log_mu - _logsumexp(P + v[:, None, :], 2)
+        v = log_nu - _logsumexp(P + u[:, :, None], 1)
+    return (P + u[:, :, None] + v[:, None, :] - norm[:, None, None]).astype(f32)
+
+
+def kpconv(s_feats, q_points, s_points, neighbor_indices, kernel_points, weights, sigma, bias=None, inf=1e6):
+    """geotransformer/modules/kpconv/kpconv.py:90-120 in fp32 NumPy."""
+    s_feats, q_points, s_points = np.asarray(s_feats, f32), np.asarray(q_points, f32), np.asarray(s_points, f32)
+    sp = np.concatenate([s_points, np.full((1, 3), inf, f32)], 0)
+    nb = sp[neighbor_indices] - q_points[:, None, :]                      # (M, H, 3)
+    diff = nb[:, :, None, :] - np.asarray(kernel_points, f32)[None, None]  # (M, H, K, 3)
+    sq = (diff * diff).sum(-1, dtype=f32)
+    w = np.maximum(f32(1.0) - np.sqrt(sq) / f32(sigma), f32(0.0)).astype(f32)  # (M, H, K)
+    sf = np.concatenate([s_feats, np.zeros((1, s_feats.shape[1]), f32)], 0)
+    nf = sf[neighbor_indices]                                              # (M, H, C)
+    wf = np.einsum("mhk,mhc->mkc", w, nf).astype(f32)
+    o = np.einsum("mkc,kco->mo", wf, np.asarray(weights, f32)).astype(f32)
+    num = np.maximum((nf.sum(-1, dtype=f32) > 0).sum(-1), 1)
+    o = o / num[:, None].astype(f32)
+    if bias is not None:
+        o = o + np.asarray(bias, f32)
+    return o.astype(f32)
+
+
+def maxpool(x, neighbor_indices):
+    x = np.concatenate([np.asarray(x, f32), np.zeros((1, x.shape[1]), f32)], 0)
+    return x[neighbor_indices].max(1)
+
+
+def nearest_upsample(x, upsample_indices):
+    x = np.concatenate([np.asarray(x, f32), np.zeros((1, x.shape[1]), f32)], 0)
+    return x[upsample_indices[:, 0]]

@@ -1,0 +1,76 @@
+"""GPU parity for the "next" rows: fused Sinkhorn and KPConv forward vs golden vectors
+from the reference's own modules, and vs the NumPy oracle at demo shapes."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _c(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_sinkhorn_vs_reference_golden():
+    from geotransformer.modules.sinkhorn import LearnableLogOptimalTransport
+    g = load_golden("next_rows.npz")
+    ot = LearnableLogOptimalTransport(100).cuda()
+    assert list(ot.state_dict().keys()) == ["alpha"]
+    o = ot(_c(g["sk_scores"]), _c(g["sk_row_masks"]), _c(g["sk_col_masks"]))
+    np.testing.assert_allclose(o.cpu().numpy(), g["sk_out_alpha1"], rtol=2e-5, atol=3e-4)
+    with torch.no_grad():
+        ot.alpha.fill_(0.37)
+    o = ot(_c(g["sk_scores"]), _c(g["sk_row_masks"]), _c(g["sk_col_masks"]))
+    np.testing.assert_allclose(o.cpu().numpy(), g["sk_out_alpha037"], rtol=2e-5, atol=3e-4)
+    o = ot(_c(g["sk_scores"]))
+    np.testing.assert_allclose(o.cpu().numpy(), g["sk_out_nomask_alpha037"], rtol=2e-5, atol=3e-4)
+
+
+def test_sinkhorn_demo_shape_vs_oracle():
+    from gaussreg_amd.sinkhorn import LearnableLogOptimalTransport
+    from oracle import matching_np as M
+    rng = np.random.default_rng(0)
+    B, K = 16, 128
+    s = (rng.normal(size=(B, K, K)) * 1.5).astype(np.float32)
+    rm, cm = rng.random((B, K)) > 0.3, rng.random((B, K)) > 0.3
+    want = M.sinkhorn(s, rm, cm, alpha=1.0, num_iterations=100)
+    got = LearnableLogOptimalTransport(100)(_c(s), _c(rm), _c(cm)).cpu().numpy()
+    assert got.shape == (B, K + 1, K + 1)
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=5e-4)
+
+
+def test_kpconv_vs_reference_golden():
+    from geotransformer.modules.kpconv import KPConv, maxpool, nearest_upsample
+    g = load_golden("next_rows.npz")
+    K, Cin, Cout = g["kp_weights"].shape
+    conv = KPConv(Cin, Cout, K, radius=0.0625, sigma=float(g["kp_sigma"]), bias=True)
+    assert set(conv.state_dict().keys()) == {"weights", "bias", "kernel_points"}
+    conv.load_state_dict({"weights": torch.from_numpy(g["kp_weights"]), "bias": torch.from_numpy(g["kp_bias"]),
+                          "kernel_points": torch.from_numpy(g["kp_kernel_points"])})
+    conv = conv.cuda()
+    y = conv(_c(g["kp_s_feats"]), _c(g["kp_q_points"]), _c(g["kp_s_points"]), _c(g["kp_neighbors"]))
+    np.testing.assert_allclose(y.cpu().numpy(), g["kp_out"], rtol=1e-4, atol=2e-5)
+    assert np.array_equal(maxpool(_c(g["kp_s_feats"]), _c(g["kp_neighbors"])).cpu().numpy(), g["kp_maxpool"])
+    assert np.array_equal(nearest_upsample(_c(g["kp_s_feats"]), _c(g["kp_neighbors"])).cpu().numpy(), g["kp_upsample"])
+
+
+@pytest.mark.parametrize("Cin,Cout,H", [(4, 64, 40), (128, 256, 35), (300, 96, 20)])
+def test_kpconv_shapes_vs_oracle(Cin, Cout, H):
+    from gaussreg_amd.kpconv import KPConv
+    from oracle import matching_np as M
+    rng = np.random.default_rng(Cin)
+    N, Mq, K = 3000, 2500, 15
+    sp = rng.random((N, 3)).astype(np.float32) * 0.6
+    qp = sp[rng.permutation(N)[:Mq]] + rng.normal(0, 0.004, (Mq, 3)).astype(np.float32)
+    d = ((qp[:, None, :] - sp[None]) ** 2).sum(-1)
+    idx = np.argsort(d, axis=1)[:, :H]
+    idx = np.where(np.take_along_axis(d, idx, 1) > 0.07 ** 2, N, idx).astype(np.int64)
+    f = np.maximum(rng.normal(size=(N, Cin)), 0).astype(np.float32)  # ReLU-like features
+    f[::11] = 0
+    kp = (rng.normal(size=(K, 3)) * 0.035).astype(np.float32)
+    conv = KPConv(Cin, Cout, K, 0.0625, 0.045, bias=False, kernel_points=kp).cuda()
+    y = conv(_c(f), _c(qp), _c(sp), _c(idx)).cpu().numpy()
+    want = M.kpconv(f, qp, sp, idx, kp, conv.weights.detach().cpu().numpy(), 0.045)
+    np.testing.assert_allclose(y, want, rtol=2e-4, atol=2e-5)
