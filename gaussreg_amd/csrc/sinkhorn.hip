@@ -5,15 +5,21 @@
 // 2 x num_iterations logsumexp kernels over (B, M+1, N+1) plus ~20 small ATen ops; at the demo
 // shapes (B=256, M=N=128, 100 iterations -- config.py:118-125) that is >200 launches re-reading a
 // 17 MB tensor each, here one launch that reads the scores once.
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace gr {
 namespace {
 
-constexpr int SK_T = 256;
+constexpr int SK_PARTS = 4;   // threads per row / column
+constexpr int SK_T = 576;     // >= SK_PARTS * (max(M,N)+1) for the demo shape (4 * 129 = 516), 9 waves
 
 __device__ __forceinline__ float lse_finish(float mx, float s) { return logf(s) + mx; }
 
+// Thread (part p, index i) reduces a contiguous quarter of row / column i to a (max, sum-exp) partial;
+// part 0 merges the four partials in fixed order.  Row stride is odd, so lanes that differ in i hit
+// different banks in both passes.
 __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict__ scores, int M, int N,
                                                         const uint8_t* __restrict__ row_masks,
                                                         const uint8_t* __restrict__ col_masks,
@@ -21,13 +27,16 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
                                                         float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int R = M + 1, C = N + 1;
-  const int ld = C | 1;  // odd row stride: a thread per row walking columns stays conflict-free
+  const int ld = C | 1;
+  const int mxd = max(R, C);
   float* S = reinterpret_cast<float*>(smem);
   float* u = S + (size_t)R * ld;
   float* v = u + R;
   float* log_mu = v + C;
   float* log_nu = log_mu + R;
-  int* cnt = reinterpret_cast<int*>(log_nu + C);
+  float* pm = log_nu + C;                 // [SK_PARTS][mxd] partial max
+  float* ps = pm + SK_PARTS * mxd;        // [SK_PARTS][mxd] partial sum
+  int* cnt = reinterpret_cast<int*>(ps + SK_PARTS * mxd);
   const int b = blockIdx.x;
   const float alpha = alpha_p[0];
   const uint8_t* rm = row_masks ? row_masks + (int64_t)b * M : nullptr;
@@ -38,8 +47,8 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
   int nr = 0, nc = 0;
   for (int i = threadIdx.x; i < M; i += SK_T) nr += (!rm || rm[i]) ? 1 : 0;
   for (int j = threadIdx.x; j < N; j += SK_T) nc += (!cm || cm[j]) ? 1 : 0;
-  atomicAdd(&cnt[0], nr);
-  atomicAdd(&cnt[1], nc);
+  if (nr) atomicAdd(&cnt[0], nr);
+  if (nc) atomicAdd(&cnt[1], nc);
   // padded scores: [scores | alpha ; alpha ... alpha], masked rows / columns -> -inf (:44-48)
   for (int e = threadIdx.x; e < R * C; e += SK_T) {
     const int i = e / C, j = e % C;
@@ -64,22 +73,55 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
   }
   __syncthreads();
   // log_sinkhorn_normalization (:13-18); logsumexp = max + log(sum exp(x - max))
+  const int part = threadIdx.x / mxd, idx = threadIdx.x % mxd;  // part >= SK_PARTS: idle thread
+  const bool active = part < SK_PARTS;
+  const int cper = (C + SK_PARTS - 1) / SK_PARTS, rper = (R + SK_PARTS - 1) / SK_PARTS;
   for (int it = 0; it < iters; ++it) {
-    for (int i = threadIdx.x; i < R; i += SK_T) {
-      const float* row = S + i * ld;
+    if (active && idx < R) {
+      const float* row = S + idx * ld;
+      const int j0 = part * cper, j1 = min(C, j0 + cper);
       float mx = -INFINITY;
-      for (int j = 0; j < C; ++j) mx = fmaxf(mx, row[j] + v[j]);
+      for (int j = j0; j < j1; ++j) mx = fmaxf(mx, row[j] + v[j]);
       float s = 0.f;
-      for (int j = 0; j < C; ++j) s += expf((row[j] + v[j]) - mx);
-      u[i] = log_mu[i] - lse_finish(mx, s);
+      for (int j = j0; j < j1; ++j) s += expf((row[j] + v[j]) - mx);
+      pm[part * mxd + idx] = mx;
+      ps[part * mxd + idx] = s;
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < C; j += SK_T) {
-      float mx = -INFINITY;
-      for (int i = 0; i < R; ++i) mx = fmaxf(mx, S[i * ld + j] + u[i]);
+    if (part == 0 && idx < R) {
+      float mx = pm[idx];
+#pragma unroll
+      for (int p = 1; p < SK_PARTS; ++p) mx = fmaxf(mx, pm[p * mxd + idx]);
       float s = 0.f;
-      for (int i = 0; i < R; ++i) s += expf((S[i * ld + j] + u[i]) - mx);
-      v[j] = log_nu[j] - lse_finish(mx, s);
+#pragma unroll
+      for (int p = 0; p < SK_PARTS; ++p) {
+        const float m_p = pm[p * mxd + idx];
+        if (m_p > -INFINITY) s += ps[p * mxd + idx] * expf(m_p - mx);  // empty part: (-inf, 0)
+      }
+      u[idx] = log_mu[idx] - lse_finish(mx, s);
+    }
+    __syncthreads();
+    if (active && idx < C) {
+      const int i0 = part * rper, i1 = min(R, i0 + rper);
+      float mx = -INFINITY;
+      for (int i = i0; i < i1; ++i) mx = fmaxf(mx, S[i * ld + idx] + u[i]);
+      float s = 0.f;
+      for (int i = i0; i < i1; ++i) s += expf((S[i * ld + idx] + u[i]) - mx);
+      pm[part * mxd + idx] = mx;
+      ps[part * mxd + idx] = s;
+    }
+    __syncthreads();
+    if (part == 0 && idx < C) {
+      float mx = pm[idx];
+#pragma unroll
+      for (int p = 1; p < SK_PARTS; ++p) mx = fmaxf(mx, pm[p * mxd + idx]);
+      float s = 0.f;
+#pragma unroll
+      for (int p = 0; p < SK_PARTS; ++p) {
+        const float m_p = pm[p * mxd + idx];
+        if (m_p > -INFINITY) s += ps[p * mxd + idx] * expf(m_p - mx);
+      }
+      v[idx] = log_nu[idx] - lse_finish(mx, s);
     }
     __syncthreads();
   }
@@ -91,8 +133,8 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
 }
 
 size_t sinkhorn_lds(int M, int N) {
-  const int R = M + 1, C = N + 1, ld = C | 1;
-  return sizeof(float) * ((size_t)R * ld + 2 * R + 2 * C) + 64;
+  const int R = M + 1, C = N + 1, ld = C | 1, mxd = R > C ? R : C;
+  return sizeof(float) * ((size_t)R * ld + 2 * R + 2 * C + 2 * SK_PARTS * mxd) + 64;
 }
 
 }  // namespace
@@ -107,6 +149,8 @@ extern "C" int gr_sinkhorn(const float* scores, int64_t batch, int64_t m, int64_
   GR_REQUIRE(batch >= 0 && m >= 1 && n >= 1 && num_iterations >= 0, "bad sizes");
   if (batch == 0) return GR_OK;
   GR_REQUIRE(scores && alpha_dev && out, "null argument");
+  GR_REQUIRE(SK_PARTS * (std::max(m, n) + 1) <= SK_T, "sinkhorn: matrices larger than %d are not supported",
+             SK_T / SK_PARTS - 1);
   const size_t lds = sinkhorn_lds((int)m, (int)n);
   if (lds > 160 * 1024) {
     set_error("sinkhorn: a (%lld+1) x (%lld+1) matrix does not fit in LDS (%zu bytes)", (long long)m, (long long)n, lds);

@@ -164,90 +164,176 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ S
   if (lane == 0) rs[r] = s;
 }
 
-// column sums: one thread per column, rows in order (coalesced across threads)
+// column sums: a block owns 64 columns; its four waves each sum a contiguous quarter of the rows
+// (coalesced across lanes), partials combined in fixed order -> reproducible
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ S, int ld,
                                                      const SpmHdr* __restrict__ hdr,
                                                      float* __restrict__ cs) {
+  __shared__ float part[4][WAVE];
   const int nr = hdr->nr, ns = hdr->ns;
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= ns) return;
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  const int c = blockIdx.x * WAVE + lane;
+  const int per = (nr + 3) / 4;
+  const int r0 = w * per, r1 = min(nr, r0 + per);
   float s = 0.f;
-  for (int r = 0; r < nr; ++r) s += S[(int64_t)r * ld + c];
-  cs[c] = s;
+  if (c < ns) {
+    int r = r0;
+    for (; r + 8 <= r1; r += 8) {  // eight independent loads in flight, summed in row order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = S[(int64_t)(r + u) * ld + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; r < r1; ++r) s += S[(int64_t)r * ld + c];
+  }
+  part[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c < ns) cs[c] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
 
-__device__ __forceinline__ float spm_score(const float* __restrict__ S, int ld, const float* rs,
-                                           const float* cs, int dual, int r, int c) {
+// scores, dense (nr x ns) row-major: superpoint_matching.py:38-41  (S / rowsum) * (S / colsum)
+__global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ S, int ld,
+                                                        const float* __restrict__ rs,
+                                                        const float* __restrict__ cs, int dual,
+                                                        const SpmHdr* __restrict__ hdr,
+                                                        float* __restrict__ score) {
+  const int nr = hdr->nr, ns = hdr->ns;
+  const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+  if (r >= nr || c >= ns) return;
   const float s = S[(int64_t)r * ld + c];
-  // superpoint_matching.py:38-41: (S / rowsum) * (S / colsum)
-  return dual ? (s / rs[r]) * (s / cs[c]) : s;
+  score[(int64_t)r * ns + c] = dual ? (s / rs[r]) * (s / cs[c]) : s;
+}
+
+// LDS histogram increment that stays fast when most lanes hit the same bin (the scores of one
+// matrix share their exponent): lanes with equal bins are merged with ballots, one lane adds the count.
+__device__ __forceinline__ void hist_add(uint32_t* sh, uint32_t bin, bool active) {
+  unsigned long long todo = __ballot(active);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t lb = (uint32_t)__shfl((int)bin, leader, WAVE);
+    const unsigned long long same = __ballot(active && bin == lb) & todo;
+    if ((int)(threadIdx.x & (WAVE - 1)) == leader) atomicAdd(&sh[lb], (uint32_t)__popcll(same));
+    todo &= ~same;
+  }
 }
 
 constexpr int SEL_BITS[3] = {11, 11, 10};
 constexpr int SEL_SHIFT[3] = {21, 10, 0};
 
-// histogram of digit `pass` over the elements whose higher digits equal hdr->prefix
-__global__ __launch_bounds__(256) void select_hist_kernel(const float* __restrict__ S, int ld,
-                                                          const float* __restrict__ rs,
-                                                          const float* __restrict__ cs, int dual,
-                                                          const SpmHdr* __restrict__ hdr, int pass,
-                                                          uint32_t* __restrict__ hist /* [2048] */) {
+// The k-th largest score is found by a 3-digit radix select (11 / 11 / 10 bits of the fp32 pattern).
+// Every selection kernel first re-derives, from the previous digit's histogram, which bin holds the
+// k-th largest (`pick`: a 2048-entry scan every block repeats for itself -- cheaper than a launch).
+struct Pick {
+  uint32_t prefix;
+  int k_rem;
+};
+
+__device__ inline Pick pick_from_hist(const uint32_t* __restrict__ hist_prev, int prev_pass, uint32_t prefix,
+                                      int k_rem, uint32_t* sh /* [2048] */) {
+  // block-parallel (256 threads): thread t owns bins [8t, 8t+8); a suffix scan over the per-thread
+  // totals finds the thread whose bins contain the k-th largest, which then walks its 8 bins.
+  // (A single thread walking 2048 LDS bins costs ~100 us of dependent-load latency.)
+  __shared__ Pick res;
+  __shared__ uint32_t tsum[256];
+  const int nb = 1 << SEL_BITS[prev_pass];
+  const int t = threadIdx.x;
+  uint32_t mine = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int bin = 8 * t + i;
+    const uint32_t v = bin < nb ? hist_prev[bin] : 0;
+    sh[bin] = v;
+    mine += v;
+  }
+  tsum[t] = mine;
+  __syncthreads();
+  // inclusive suffix scan of tsum (Hillis-Steele, 8 steps)
+  for (int d = 1; d < 256; d <<= 1) {
+    const uint32_t add = (t + d < 256) ? tsum[t + d] : 0;
+    __syncthreads();
+    tsum[t] += add;
+    __syncthreads();
+  }
+  if (t == 0) {  // default when k_rem == 0 or fewer than k_rem elements exist: lowest bin
+    res.prefix = prefix;
+    res.k_rem = k_rem;
+  }
+  __syncthreads();
+  const uint32_t above = tsum[t] - mine;  // elements in bins of higher threads
+  if (k_rem > 0 && above < (uint32_t)k_rem && (uint32_t)k_rem <= tsum[t]) {
+    int k = k_rem - (int)above;
+    int bsel = 8 * t;
+#pragma unroll
+    for (int i = 7; i >= 0; --i) {
+      const int c = (int)sh[8 * t + i];
+      if (c >= k) {
+        bsel = 8 * t + i;
+        break;
+      }
+      k -= c;
+    }
+    res.prefix = prefix | ((uint32_t)bsel << SEL_SHIFT[prev_pass]);
+    res.k_rem = k;
+  } else if (k_rem == 0 && t == 0) {
+    res.prefix = prefix | ((uint32_t)(nb - 1) << SEL_SHIFT[prev_pass]);
+  }
+  __syncthreads();
+  return res;
+}
+
+// pass 0: plain histogram of the top digit.  pass 1/2: pick digit pass-1 first (from hist[pass-1]).
+__global__ __launch_bounds__(256) void select_hist_kernel(const float* __restrict__ score,
+                                                          SpmHdr* __restrict__ hdr, int pass,
+                                                          uint32_t* __restrict__ hist /* [3][2048] */) {
   __shared__ uint32_t sh[2048];
+  uint32_t prefix = 0;
+  int k_rem = hdr->k;
+  for (int pp = 0; pp < pass; ++pp) {  // replay the picks of the earlier digits (deterministic)
+    const Pick pk = pick_from_hist(hist + pp * 2048, pp, prefix, k_rem, sh);
+    prefix = pk.prefix;
+    k_rem = pk.k_rem;
+    __syncthreads();
+  }
   for (int i = threadIdx.x; i < 2048; i += 256) sh[i] = 0;
   __syncthreads();
   const int ns = hdr->ns;
   const int64_t total = (int64_t)hdr->nr * ns;
-  const uint32_t prefix = hdr->prefix;
   const int shift = SEL_SHIFT[pass], bits = SEL_BITS[pass];
   const int hi_shift = shift + bits;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int r = (int)(e / ns), c = (int)(e % ns);
-    const uint32_t u = __float_as_uint(spm_score(S, ld, rs, cs, dual, r, c));
-    if (hi_shift >= 32 || (u >> hi_shift) == (prefix >> hi_shift)) atomicAdd(&sh[(u >> shift) & ((1u << bits) - 1u)], 1u);
+  const int64_t total_up = (total + 255) / 256 * 256;  // whole waves enter hist_add together
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total_up; e += (int64_t)gridDim.x * 256) {
+    const uint32_t u = e < total ? __float_as_uint(score[e]) : 0u;
+    const bool in = e < total && (hi_shift >= 32 || (u >> hi_shift) == (prefix >> hi_shift));
+    hist_add(sh, (u >> shift) & ((1u << bits) - 1u), in);
   }
   __syncthreads();
+  uint32_t* dst = hist + pass * 2048;
   for (int i = threadIdx.x; i < 2048; i += 256)
-    if (sh[i]) atomicAdd(&hist[i], sh[i]);
-}
-
-// single block: pick the bin holding the k_rem-th largest, update prefix / k_rem, clear the histogram
-__global__ __launch_bounds__(256) void select_pick_kernel(SpmHdr* __restrict__ hdr, int pass,
-                                                          uint32_t* __restrict__ hist) {
-  __shared__ uint32_t sh[2048];
-  const int nb = 1 << SEL_BITS[pass];
-  for (int i = threadIdx.x; i < 2048; i += 256) {
-    sh[i] = i < nb ? hist[i] : 0;
-    hist[i] = 0;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int k = hdr->k_rem;
-    int b = nb - 1;
-    if (k > 0) {
-      for (; b > 0; --b) {
-        if ((int)sh[b] >= k) break;
-        k -= (int)sh[b];
-      }
-    }
-    hdr->prefix |= (uint32_t)b << SEL_SHIFT[pass];
-    hdr->k_rem = k;  // how many of the selected bin are needed
-  }
+    if (sh[i]) atomicAdd(&dst[i], sh[i]);
 }
 
 constexpr int CAND_CAP = 4096;
 
 // gather every element with score >= threshold (bit pattern in hdr->prefix) as a sortable key
-__global__ __launch_bounds__(256) void select_gather_kernel(const float* __restrict__ S, int ld,
-                                                            const float* __restrict__ rs,
-                                                            const float* __restrict__ cs, int dual,
+__global__ __launch_bounds__(256) void select_gather_kernel(const float* __restrict__ score,
                                                             SpmHdr* __restrict__ hdr,
+                                                            const uint32_t* __restrict__ hist,
                                                             unsigned long long* __restrict__ cand) {
+  __shared__ uint32_t sh[2048];
+  uint32_t prefix = 0;
+  int k_rem = hdr->k;
+  for (int pp = 0; pp < 3; ++pp) {
+    const Pick pk = pick_from_hist(hist + pp * 2048, pp, prefix, k_rem, sh);
+    prefix = pk.prefix;
+    k_rem = pk.k_rem;
+    __syncthreads();
+  }
   const int ns = hdr->ns;
   const int64_t total = (int64_t)hdr->nr * ns;
-  const uint32_t thr = hdr->prefix;
+  const uint32_t thr = hdr->k > 0 ? prefix : 0xffffffffu;  // exact bit pattern of the k-th largest score
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int r = (int)(e / ns), c = (int)(e % ns);
-    const uint32_t u = __float_as_uint(spm_score(S, ld, rs, cs, dual, r, c));
+    const uint32_t u = __float_as_uint(score[e]);
     if (u >= thr) {
       const int slot = atomicAdd(&hdr->n_cand, 1);
       // larger key = higher score, then LOWER flat index
@@ -266,12 +352,14 @@ __global__ __launch_bounds__(1024) void select_emit_kernel(const SpmHdr* __restr
                                                            float* __restrict__ out_score) {
   __shared__ unsigned long long sk[CAND_CAP];
   const int n = min(hdr->n_cand, CAND_CAP);
-  for (int i = threadIdx.x; i < CAND_CAP; i += 1024) sk[i] = i < n ? cand[i] : 0ull;
+  int np2 = 2;
+  while (np2 < n) np2 <<= 1;
+  for (int i = threadIdx.x; i < np2; i += 1024) sk[i] = i < n ? cand[i] : 0ull;
   __syncthreads();
-  // bitonic sort, descending
-  for (int size = 2; size <= CAND_CAP; size <<= 1) {
+  // bitonic sort, descending, over the smallest power of two that holds the candidates
+  for (int size = 2; size <= np2; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = threadIdx.x; t < CAND_CAP / 2; t += 1024) {
+      for (int t = threadIdx.x; t < np2 / 2; t += 1024) {
         const int lo = 2 * t - (t & (stride - 1));
         const int hi = lo + stride;
         const bool desc = (lo & size) == 0;
@@ -299,6 +387,7 @@ struct SpmWs {
   int32_t* ridx;
   int32_t* sidx;
   float* S;
+  float* score;
   float* rs;
   float* cs;
   uint32_t* hist;
@@ -313,9 +402,10 @@ SpmWs carve_spm(void* p, int64_t nr, int64_t ns) {
   w.ridx = c.take<int32_t>(nr);
   w.sidx = c.take<int32_t>(ns);
   w.S = c.take<float>(nr * ns);
+  w.score = c.take<float>(nr * ns);
   w.rs = c.take<float>(nr);
   w.cs = c.take<float>(ns);
-  w.hist = c.take<uint32_t>(2048);
+  w.hist = c.take<uint32_t>(3 * 2048);
   w.cand = c.take<unsigned long long>(CAND_CAP);
   w.bytes = c.used();
   return w;
@@ -380,7 +470,7 @@ extern "C" int gr_superpoint_matching(const float* ref_feats, const float* src_f
     set_error("superpoint_matching workspace too small: need %zu bytes, got %zu", w.bytes, ws_bytes);
     return GR_ERR_WORKSPACE;
   }
-  GR_HIP(hipMemsetAsync(w.hist, 0, 2048 * sizeof(uint32_t), stream));
+  GR_HIP(hipMemsetAsync(w.hist, 0, 3 * 2048 * sizeof(uint32_t), stream));
   hipLaunchKernelGGL(compact_masks_kernel, dim3(1), dim3(1024), 0, stream, ref_masks, (int)nr, src_masks, (int)ns,
                      num_correspondences, w.ridx, w.sidx, w.hdr);
   const dim3 grid((unsigned)((ns + PD_T - 1) / PD_T), (unsigned)((nr + PD_T - 1) / PD_T));
@@ -390,16 +480,15 @@ extern "C" int gr_superpoint_matching(const float* ref_feats, const float* src_f
                      (const float*)nullptr, w.S, (int)ns);
   if (dual_normalization) {
     hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, stream, w.S, (int)ns, w.hdr, w.rs);
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, w.S, (int)ns, w.hdr, w.cs);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((ns + WAVE - 1) / WAVE)), dim3(256), 0, stream, w.S, (int)ns, w.hdr,
+                       w.cs);
   }
-  const int sel_blocks = (int)std::min<int64_t>(1024, (nr * ns + 255) / 256);
-  for (int pass = 0; pass < 3; ++pass) {
-    hipLaunchKernelGGL(select_hist_kernel, dim3(sel_blocks), dim3(256), 0, stream, w.S, (int)ns, w.rs, w.cs,
-                       dual_normalization, w.hdr, pass, w.hist);
-    hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(256), 0, stream, w.hdr, pass, w.hist);
-  }
-  hipLaunchKernelGGL(select_gather_kernel, dim3(sel_blocks), dim3(256), 0, stream, w.S, (int)ns, w.rs, w.cs,
-                     dual_normalization, w.hdr, w.cand);
+  hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((ns + 255) / 256), (unsigned)nr), dim3(256), 0, stream, w.S,
+                     (int)ns, w.rs, w.cs, dual_normalization, w.hdr, w.score);
+  const int sel_blocks = (int)std::min<int64_t>(512, (nr * ns + 1023) / 1024);
+  for (int pass = 0; pass < 3; ++pass)
+    hipLaunchKernelGGL(select_hist_kernel, dim3(sel_blocks), dim3(256), 0, stream, w.score, w.hdr, pass, w.hist);
+  hipLaunchKernelGGL(select_gather_kernel, dim3(sel_blocks), dim3(256), 0, stream, w.score, w.hdr, w.hist, w.cand);
   hipLaunchKernelGGL(select_emit_kernel, dim3(1), dim3(1024), 0, stream, w.hdr, w.cand, w.ridx, w.sidx, out_ref_idx,
                      out_src_idx, out_scores);
   GR_LAUNCH_CHECK();
