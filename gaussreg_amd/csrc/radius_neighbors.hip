@@ -530,7 +530,14 @@ __global__ __launch_bounds__(NSUB* RQ) void traverse_kernel(
     const unsigned long long key = hits[e];
     int rank = 0;
     int jj = 0;
-    for (; jj + 4 <= len; jj += 4) {  // four independent LDS reads in flight
+    for (; jj + 8 <= len; jj += 8) {  // eight independent LDS reads in flight
+      unsigned long long hk[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) hk[u] = hits[a + jj + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) rank += hk[u] < key ? 1 : 0;
+    }
+    for (; jj + 4 <= len; jj += 4) {
       const unsigned long long h0 = hits[a + jj], h1 = hits[a + jj + 1], h2 = hits[a + jj + 2], h3 = hits[a + jj + 3];
       rank += (h0 < key ? 1 : 0) + (h1 < key ? 1 : 0) + (h2 < key ? 1 : 0) + (h3 < key ? 1 : 0);
     }
