@@ -114,3 +114,19 @@ def test_empty_scene_renders_background():
     assert int(radii.abs().sum()) == 0
     assert torch.equal(img[:, 0, 0].cpu(), torch.tensor([0.25, 0.5, 0.75]))
     assert bool((img == img[:, :1, :1]).all())
+
+
+@pytest.mark.parametrize("P,W,H,V", [(1_000_000, 640, 480, 2), (3_000_000, 1920, 1080, 1)])
+def test_full_size_configs_bit_exact(P, W, H, V):
+    """BASELINE configs[1] (1 M Gaussians, 640x480) and configs[3] (3 M Gaussians, 1920x1080) at FULL size:
+    image and radii bit-identical to the oracle (the oracle needs a few seconds per view on one core)."""
+    from gaussreg_amd.rasterizer import rasterize_views
+    g, cams = raster_scene(P, W, H, seed=0, V=V)
+    d = _cu(g)
+    imgs, radii, nr = rasterize_views([_settings(c) for c in cams], d["means3D"], d["opacities"], shs=d["shs"],
+                                      scales=d["scales"], rotations=d["rotations"])
+    for v in range(V):
+        want, wr, wR = oracle_render(g, cams[v])
+        assert nr[v] == wR
+        assert np.array_equal(radii[v].cpu().numpy(), wr)
+        _assert_bit_equal(imgs[v].cpu().numpy(), want, f"{P} Gaussians {W}x{H} view {v}")
