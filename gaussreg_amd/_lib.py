@@ -58,6 +58,10 @@ SIGNATURES.update({
     "gr_kpconv_forward": (c_int, [c_void] * 4 + [c_i64] * 5 + [c_void, c_i64, c_void, c_void, c_f32, c_f32, c_void,
                                                             c_void, c_size, c_void]),
     "gr_neighbor_pool": (c_int, [c_void, c_i64, c_i64, c_void, c_i64, c_i64, c_int, c_void, c_void]),
+    "gr_gs_fuse_workspace_bytes": (c_size, [c_i64, c_i64]),
+    "gr_gs_fuse": (c_int, [c_void, c_i64, c_void, c_i64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                           ctypes.c_double, ctypes.POINTER(c_f32), ctypes.POINTER(c_f32), ctypes.POINTER(c_f32), c_void,
+                           c_i64p, c_void, c_size, c_void]),
     "gr_pairwise_distance_workspace_bytes": (c_size, [c_i64, c_i64]),
     "gr_pairwise_distance": (c_int, [c_void, c_void, c_i64, c_i64, c_i64, c_int, c_void, c_void, c_size, c_void]),
     "gr_superpoint_matching_workspace_bytes": (c_size, [c_i64, c_i64]),

@@ -181,6 +181,15 @@ int gr_kpconv_forward(const float* s_feats, const float* q_points, const float* 
                       float inf, float* out, void* ws, size_t ws_bytes, void* stream);
 int gr_neighbor_pool(const float* x, int64_t n, int64_t c, const int64_t* neighbor_indices, int64_t m, int64_t h,
                      int mode, float* out, void* stream);
+/* gr_gs_fuse ("next" row): gs_fusion.py:231-262 gaussian_fuse on the GS .ply wire format.
+ * rec1 / rec2: device arrays of 62-float vertex records (gs_fusion.py:172-184 property order).  The host
+ * passes the similarity transform split as the reference does (:237-240): h_rotation (3x3 row-major, scale
+ * divided out), h_translation (3), h_scale, and the three SH band transforms (3x3, 5x5, 7x7 row-major,
+ * new = old @ T).  out_rec has room for n1 + n2 records; *h_num_out = kept vertices.  Synchronises. */
+size_t gr_gs_fuse_workspace_bytes(int64_t n1, int64_t n2);
+int gr_gs_fuse(const float* rec1, int64_t n1, const float* rec2, int64_t n2, const double* h_rotation,
+               const double* h_translation, double h_scale, const float* h_sh_t1, const float* h_sh_t2,
+               const float* h_sh_t3, float* out_rec, int64_t* h_num_out, void* ws, size_t ws_bytes, void* stream);
 size_t gr_pairwise_distance_workspace_bytes(int64_t n, int64_t m);
 int gr_pairwise_distance(const float* x, const float* y, int64_t n, int64_t m, int64_t c, int normalized,
                          float* out, void* ws, size_t ws_bytes, void* stream);

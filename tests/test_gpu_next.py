@@ -74,3 +74,19 @@ def test_kpconv_shapes_vs_oracle(Cin, Cout, H):
     y = conv(_c(f), _c(qp), _c(sp), _c(idx)).cpu().numpy()
     want = M.kpconv(f, qp, sp, idx, kp, conv.weights.detach().cpu().numpy(), 0.045)
     np.testing.assert_allclose(y, want, rtol=2e-4, atol=2e-5)
+
+
+def test_gs_fusion_vs_reference_golden(tmp_path):
+    from gaussreg_amd.gs_io import gaussian_fuse, gaussian_fuse_records, read_gs_ply, write_gs_ply
+    g = load_golden("gs_fusion.npz")
+    fused = gaussian_fuse_records(g["rec1"], g["rec2"], g["transform"]).cpu().numpy()
+    assert fused.shape == g["fused"].shape
+    np.testing.assert_allclose(fused, g["fused"], rtol=2e-5, atol=2e-6)
+    # xyz / log-scales of the transformed cloud are computed in fp64 like the reference: bit-exact
+    assert np.array_equal(fused[:, 0:3].view(np.uint32), g["fused"][:, 0:3].view(np.uint32))
+    assert np.array_equal(fused[:, 55:58].view(np.uint32), g["fused"][:, 55:58].view(np.uint32))
+    # file-level entry point with the reference's signature
+    p1, p2, pt, po = [str(tmp_path / f) for f in ("a.ply", "b.ply", "t.npz", "out/o.ply")]
+    write_gs_ply(p1, g["rec1"]); write_gs_ply(p2, g["rec2"]); np.savez(pt, estimated_transform=g["transform"])
+    gaussian_fuse(p1, p2, pt, po)
+    assert np.array_equal(read_gs_ply(po), fused)
