@@ -551,10 +551,15 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
     __syncthreads();
     // ---- blend: each 16-lane group walks its own list
     const int n_cell = done ? 0 : s_cnt[cell][BLOCK / WAVE];
+    // the next Gaussian's parameters are fetched while the current one is evaluated
+    int jn = s_list[cell][0];
+    float4 a_n = s_a[jn], b_n = s_b[jn];
     for (int i = 0; i < n_cell; ++i) {
-      const int j = s_list[cell][i];
-      const float4 a = s_a[j];
-      const float4 co = s_b[j];
+      const int j = jn;
+      const float4 a = a_n, co = b_n;
+      jn = s_list[cell][min(i + 1, BLOCK - 1)];
+      a_n = s_a[jn];
+      b_n = s_b[jn];
       const float dx = a.x - pfx, dy = a.y - pfy;
       const float q = fmaf(co.x * dx, dx, (co.z * dy) * dy);
       const float power = fmaf(-0.5f, q, -((co.y * dx) * dy));
