@@ -72,6 +72,9 @@ SIGNATURES.update({
                                c_void, c_size, c_void]),
     "gr_corr_gather": (c_int, [c_void, c_i64, c_i64, c_i64] + [c_void] * 6 + [c_int] + [c_void] * 5 +
                        [c_void, c_size, c_void]),
+    "gr_lgr_workspace_bytes": (c_size, [c_i64]),
+    "gr_lgr_register": (c_int, [c_void, c_void, c_void, c_i64, c_i64, c_void, c_f32, c_int, c_int, c_void, c_void,
+                                c_size, c_void]),
     "gr_point_to_node_workspace_bytes": (c_size, [c_i64, c_i64]),
     "gr_point_to_node_partition": (c_int, [c_void, c_i64, c_void, c_i64, c_int, c_void, c_void, c_void, c_void,
                                            c_void, c_size, c_void]),

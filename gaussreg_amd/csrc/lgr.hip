@@ -1,0 +1,274 @@
+// LocalGlobalRegistration.local_to_global_registration on the GPU, no host round trips.
+//
+// Replaces  geotransformer/modules/geotransformer/local_global_registration.py:135-193  and the
+// weighted Kabsch it calls, geotransformer/modules/registration/procrustes.py:6-82, which ships every 3x3
+// covariance to the CPU for torch.svd (procrustes.py:59) -- 1 + num_refinement_steps GPU->CPU->GPU syncs
+// per forward in the reference.  Input: the dense correspondences already gathered in torch.nonzero order
+// (gr_corr_gather) plus the per-patch offsets / counts gr_corr_matrix left in the workspace.
+//   local     one workgroup per patch correspondence with >= correspondence_threshold matches:
+//             weighted centroids + 3x3 covariance by block reduction, optimal rotation in fp64
+//   verify    one workgroup per hypothesis: inliers (residual < acceptance_radius) over ALL correspondences
+//   refine    one workgroup: best hypothesis -> mask -> weighted Kabsch, num_refinement_steps times
+// Rotation: the proper rotation maximising tr(R H) -- Horn's unit-quaternion form (largest eigenvector of a
+// symmetric 4x4 built from H, cyclic Jacobi in fp64); identical to V diag(1,1,det(VU^T)) U^T of
+// procrustes.py:59-64 whenever that is unique.
+#include "common.hpp"
+
+namespace gr {
+namespace {
+
+constexpr int LG_T = 256;
+
+// largest-eigenvalue eigenvector of symmetric 4x4 A (row-major), cyclic Jacobi
+__device__ void horn_rotation(const double* H /*3x3: H[a][b] = sum w src_a ref_b*/, double* R /*3x3*/) {
+  const double Sxx = H[0], Sxy = H[1], Sxz = H[2], Syx = H[3], Syy = H[4], Syz = H[5], Szx = H[6], Szy = H[7], Szz = H[8];
+  double A[4][4] = {{Sxx + Syy + Szz, Syz - Szy, Szx - Sxz, Sxy - Syx},
+                    {Syz - Szy, Sxx - Syy - Szz, Sxy + Syx, Szx + Sxz},
+                    {Szx - Sxz, Sxy + Syx, -Sxx + Syy - Szz, Syz + Szy},
+                    {Sxy - Syx, Szx + Sxz, Syz + Szy, -Sxx - Syy + Szz}};
+  double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+  for (int sweep = 0; sweep < 16; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < 4; ++p)
+      for (int q = p + 1; q < 4; ++q) off += A[p][q] * A[p][q];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 3; ++p)
+      for (int q = p + 1; q < 4; ++q) {
+        if (fabs(A[p][q]) < 1e-300) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 4; ++k) {
+          const double akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - s * akq;
+          A[k][q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 4; ++k) {
+          const double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - s * aqk;
+          A[q][k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < 4; ++k) {
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - s * vkq;
+          V[k][q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  int best = 0;
+  for (int k = 1; k < 4; ++k)
+    if (A[k][k] > A[best][best]) best = k;
+  double w = V[0][best], x = V[1][best], y = V[2][best], z = V[3][best];
+  const double nrm = sqrt(w * w + x * x + y * y + z * z);
+  w /= nrm; x /= nrm; y /= nrm; z /= nrm;
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z);     R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y);     R[7] = 2 * (y * z + w * x);     R[8] = 1 - 2 * (x * x + y * y);
+}
+
+// block-wide sum of NV doubles per thread -> result in sh[0..NV) (valid for all threads after return)
+template <int NV>
+__device__ void block_sum(double* v, double* sh /* [NV][LG_T/64] + NV */) {
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double x = v[k];
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) x += __shfl_xor(x, d, WAVE);
+    v[k] = x;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  if (lane == 0)
+    for (int k = 0; k < NV; ++k) sh[k * (LG_T / WAVE) + w] = v[k];
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double s = 0;
+    for (int i = 0; i < LG_T / WAVE; ++i) s += sh[threadIdx.x * (LG_T / WAVE) + i];
+    sh[NV * (LG_T / WAVE) + threadIdx.x] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = sh[NV * (LG_T / WAVE) + k];
+}
+
+// weighted Kabsch over correspondences [a, b) with weight(i); thread 0 ends up with (R, t) in T[12]
+// procrustes.py:41-66: w = w / (sum w + eps); centroids; H = sum w (src - cs)(ref - cr)^T
+template <typename WF>
+__device__ void block_procrustes(const float* __restrict__ src, const float* __restrict__ ref, int a, int b, WF weight,
+                                 float eps, double* sh, float* T /* shared [12] */) {
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};  // sum w, sum w*src (3), sum w*ref (3)
+  for (int i = a + threadIdx.x; i < b; i += LG_T) {
+    const double w = weight(i);
+    acc[0] += w;
+    for (int k = 0; k < 3; ++k) {
+      acc[1 + k] += w * src[3 * (int64_t)i + k];
+      acc[4 + k] += w * ref[3 * (int64_t)i + k];
+    }
+  }
+  block_sum<7>(acc, sh);
+  const double wn = 1.0 / (acc[0] + (double)eps);
+  const double cs[3] = {acc[1] * wn, acc[2] * wn, acc[3] * wn}, cr[3] = {acc[4] * wn, acc[5] * wn, acc[6] * wn};
+  double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = a + threadIdx.x; i < b; i += LG_T) {
+    const double w = weight(i) * wn;
+    double s[3], r[3];
+    for (int k = 0; k < 3; ++k) {
+      s[k] = (double)src[3 * (int64_t)i + k] - cs[k];
+      r[k] = (double)ref[3 * (int64_t)i + k] - cr[k];
+    }
+    for (int p = 0; p < 3; ++p)
+      for (int q = 0; q < 3; ++q) h[p * 3 + q] += s[p] * w * r[q];
+  }
+  block_sum<9>(h, sh);
+  if (threadIdx.x == 0) {
+    double R[9];
+    horn_rotation(h, R);
+    for (int k = 0; k < 9; ++k) T[k] = (float)R[k];
+    for (int r = 0; r < 3; ++r) T[9 + r] = (float)(cr[r] - (R[r * 3] * cs[0] + R[r * 3 + 1] * cs[1] + R[r * 3 + 2] * cs[2]));
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ bool inlier(const float* T, const float* src, const float* ref, int64_t i, float radius) {
+  const float sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
+  // apply_transform: p R^T + t  (ops/transformation.py:38), then torch.linalg.norm
+  const float ax = (sx * T[0] + sy * T[1] + sz * T[2]) + T[9];
+  const float ay = (sx * T[3] + sy * T[4] + sz * T[5]) + T[10];
+  const float az = (sx * T[6] + sy * T[7] + sz * T[8]) + T[11];
+  const float dx = ref[3 * i] - ax, dy = ref[3 * i + 1] - ay, dz = ref[3 * i + 2] - az;
+  return sqrtf((dx * dx + dy * dy) + dz * dz) < radius;
+}
+
+// per patch: local transform (or valid = 0)
+__global__ __launch_bounds__(LG_T) void lgr_local_kernel(const float* __restrict__ src, const float* __restrict__ ref,
+                                                         const float* __restrict__ scores,
+                                                         const int32_t* __restrict__ counts,
+                                                         const int32_t* __restrict__ offsets, int min_corr,
+                                                         float* __restrict__ transforms /* [B][12] */,
+                                                         int32_t* __restrict__ valid) {
+  __shared__ double sh[9 * (LG_T / WAVE) + 16];
+  __shared__ float T[12];
+  const int p = blockIdx.x;
+  const int n = counts[p];
+  if (n < min_corr) {
+    if (threadIdx.x == 0) valid[p] = 0;
+    return;
+  }
+  const int a = offsets[p];
+  block_procrustes(src, ref, a, a + n, [&](int i) { return (double)fmaxf(scores[i], 0.0f); }, 1e-5f, sh, T);
+  if (threadIdx.x < 12) transforms[p * 12 + threadIdx.x] = T[threadIdx.x];
+  if (threadIdx.x == 0) valid[p] = 1;
+}
+
+// per hypothesis: number of inliers over all C correspondences
+__global__ __launch_bounds__(LG_T) void lgr_verify_kernel(const float* __restrict__ src, const float* __restrict__ ref, int C,
+                                                          const float* __restrict__ transforms,
+                                                          const int32_t* __restrict__ valid, float radius,
+                                                          int32_t* __restrict__ inliers) {
+  __shared__ int wsum[LG_T / WAVE];
+  __shared__ float T[12];
+  const int p = blockIdx.x;
+  if (!valid[p]) {
+    if (threadIdx.x == 0) inliers[p] = -1;
+    return;
+  }
+  if (threadIdx.x < 12) T[threadIdx.x] = transforms[p * 12 + threadIdx.x];
+  __syncthreads();
+  int n = 0;
+  for (int i = threadIdx.x; i < C; i += LG_T) n += inlier(T, src, ref, i, radius) ? 1 : 0;
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) n += __shfl_xor(n, d, WAVE);
+  if ((threadIdx.x & (WAVE - 1)) == 0) wsum[threadIdx.x / WAVE] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int i = 0; i < LG_T / WAVE; ++i) t += wsum[i];
+    inliers[p] = t;
+  }
+}
+
+// best hypothesis + global refinement (local_global_registration.py:171-192)
+__global__ __launch_bounds__(LG_T) void lgr_refine_kernel(const float* __restrict__ src, const float* __restrict__ ref,
+                                                          const float* __restrict__ scores, int C, int B,
+                                                          const float* __restrict__ transforms,
+                                                          const int32_t* __restrict__ inliers, float radius, int steps,
+                                                          float* __restrict__ out_transform /* 4x4 row-major */) {
+  __shared__ double sh[9 * (LG_T / WAVE) + 16];
+  __shared__ float T[12];
+  __shared__ int best_sh;
+  if (threadIdx.x == 0) {
+    int best = -1, bn = -1;
+    for (int p = 0; p < B; ++p)
+      if (inliers[p] > bn) {  // first maximum, like argmax
+        bn = inliers[p];
+        best = p;
+      }
+    best_sh = best;
+  }
+  __syncthreads();
+  const int best = best_sh;
+  if (best >= 0) {
+    if (threadIdx.x < 12) T[threadIdx.x] = transforms[best * 12 + threadIdx.x];
+    __syncthreads();
+  } else {
+    // degenerate: no patch qualifies -> all correspondences, plain scores (:176-180)
+    block_procrustes(src, ref, 0, C, [&](int i) { return (double)fmaxf(scores[i], 0.0f); }, 1e-5f, sh, T);
+  }
+  for (int s = 0; s < steps; ++s) {
+    // scores * inlier mask of the current transform, then weighted Kabsch (:183-190)
+    float Tc[12];
+    for (int k = 0; k < 12; ++k) Tc[k] = T[k];
+    __syncthreads();
+    block_procrustes(src, ref, 0, C,
+                     [&](int i) { return inlier(Tc, src, ref, i, radius) ? (double)fmaxf(scores[i], 0.0f) : 0.0; },
+                     1e-5f, sh, T);
+  }
+  if (threadIdx.x < 16) {
+    const int r = threadIdx.x / 4, c = threadIdx.x % 4;
+    out_transform[threadIdx.x] = r < 3 ? (c < 3 ? T[r * 3 + c] : T[9 + r]) : (c == 3 ? 1.0f : 0.0f);
+  }
+}
+
+}  // namespace
+}  // namespace gr
+
+using namespace gr;
+
+extern "C" size_t gr_lgr_workspace_bytes(int64_t batch) {
+  if (batch < 0) return 0;
+  return align_up((size_t)batch * 12 * 4, 256) + 2 * align_up((size_t)batch * 4, 256) + 256;
+}
+
+extern "C" int gr_lgr_register(const float* ref_corr_points, const float* src_corr_points, const float* corr_scores,
+                               int64_t num_corr, int64_t batch, const void* pm_ws, float acceptance_radius,
+                               int correspondence_threshold, int num_refinement_steps, float* out_transform, void* ws,
+                               size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GR_REQUIRE(num_corr >= 0 && batch >= 0 && num_refinement_steps >= 1 && num_corr < (1ll << 31), "bad arguments");
+  GR_REQUIRE(out_transform != nullptr, "out_transform is null");
+  GR_REQUIRE(num_corr > 0, "no correspondences: the reference's procrustes would divide by eps here");
+  GR_REQUIRE(ref_corr_points && src_corr_points && corr_scores && pm_ws, "null argument");
+  if (!ws || ws_bytes < gr_lgr_workspace_bytes(batch)) {
+    set_error("lgr workspace too small");
+    return GR_ERR_WORKSPACE;
+  }
+  Carver c(ws);
+  float* transforms = c.take<float>(batch * 12);
+  int32_t* valid = c.take<int32_t>(batch);
+  int32_t* inl = c.take<int32_t>(batch);
+  const int32_t* counts = static_cast<const int32_t*>(pm_ws);  // layout of gr_corr_matrix's workspace
+  const int32_t* offsets = counts + batch;
+  KernelTimer timer("lgr", stream);
+  if (batch > 0) {
+    hipLaunchKernelGGL(lgr_local_kernel, dim3((unsigned)batch), dim3(LG_T), 0, stream, src_corr_points, ref_corr_points,
+                       corr_scores, counts, offsets, correspondence_threshold, transforms, valid);
+    hipLaunchKernelGGL(lgr_verify_kernel, dim3((unsigned)batch), dim3(LG_T), 0, stream, src_corr_points, ref_corr_points,
+                       (int)num_corr, transforms, valid, acceptance_radius, inl);
+  }
+  // the first refinement step of the reference is "procrustes with the best hypothesis' mask" (:183), the
+  // remaining num_refinement_steps - 1 recompute the mask from the running estimate (:184-190)
+  hipLaunchKernelGGL(lgr_refine_kernel, dim3(1), dim3(LG_T), 0, stream, src_corr_points, ref_corr_points, corr_scores,
+                     (int)num_corr, (int)batch, transforms, inl, acceptance_radius, num_refinement_steps, out_transform);
+  GR_LAUNCH_CHECK();
+  return GR_OK;
+}

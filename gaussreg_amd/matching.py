@@ -132,3 +132,66 @@ class PointMatching(nn.Module):
         if out_device.type != "cuda":
             outs = tuple(o.to(out_device) for o in outs)
         return outs
+
+
+class LocalGlobalRegistration(nn.Module):
+    """Mirror of geotransformer/modules/geotransformer/local_global_registration.py:11-235 (forward,
+    inference).  Correspondence extraction = the PointMatching kernels; hypothesis generation, verification
+    and refinement run in three more launches with no GPU->CPU SVD round trips (the reference does
+    1 + num_refinement_steps of them, registration/procrustes.py:59)."""
+
+    def __init__(self, k: int, acceptance_radius: float, mutual: bool = True, confidence_threshold: float = 0.05,
+                 use_dustbin: bool = False, use_global_score: bool = False, correspondence_threshold: int = 3,
+                 correspondence_limit=None, num_refinement_steps: int = 5):
+        super().__init__()
+        self.k = k
+        self.acceptance_radius = acceptance_radius
+        self.mutual = mutual
+        self.confidence_threshold = confidence_threshold
+        self.use_dustbin = use_dustbin
+        self.use_global_score = use_global_score
+        self.correspondence_threshold = correspondence_threshold
+        self.correspondence_limit = correspondence_limit
+        self.num_refinement_steps = num_refinement_steps
+        if use_dustbin:
+            raise NotImplementedError("use_dustbin=True is not supported (GaussReg sets it False, config.py:121)")
+        if correspondence_limit is not None:
+            raise NotImplementedError("correspondence_limit is not supported (GaussReg sets it None, config.py:124)")
+        self._pm = PointMatching(k, mutual, confidence_threshold, False, use_global_score)
+
+    @torch.no_grad()
+    def compute_correspondence_matrix(self, score_mat, ref_knn_masks, src_knn_masks):
+        return self._pm.compute_correspondence_matrix(score_mat, ref_knn_masks, src_knn_masks)
+
+    @torch.no_grad()
+    def forward(self, ref_knn_points, src_knn_points, ref_knn_masks, src_knn_masks, score_mat, global_scores):
+        """-> (ref_corr_points (C,3), src_corr_points (C,3), corr_scores (C,), estimated_transform (4,4))."""
+        out_device = score_mat.device
+        s, corr, n, pm_ws = self._pm._corr(score_mat, ref_knn_masks, src_knn_masks, True)
+        dev = s.device
+        L = _lib.lib()
+        B, K1, K2 = s.shape
+        rp, sp = _f32c(ref_knn_points, dev), _f32c(src_knn_points, dev)
+        gs = _f32c(global_scores, dev) if (self.use_global_score and global_scores is not None) else None
+        o_rp = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        o_sp = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        o_sc = torch.empty((n,), dtype=torch.float32, device=dev)
+        idx_dummy = torch.zeros((B, max(K1, K2)), dtype=torch.int64, device=dev)
+        o_i = torch.empty((2, max(n, 1)), dtype=torch.int64, device=dev)
+        transform = torch.eye(4, dtype=torch.float32, device=dev)
+        if n > 0:
+            with torch.cuda.device(dev):
+                st = _lib.stream_ptr(dev)
+                _lib.check(L.gr_corr_gather(_lib.ptr(s), B, K1, K2, _lib.ptr(corr), _lib.ptr(rp), _lib.ptr(sp),
+                                            _lib.ptr(idx_dummy), _lib.ptr(idx_dummy), _lib.ptr(gs), int(gs is not None),
+                                            _lib.ptr(o_rp), _lib.ptr(o_sp), _lib.ptr(o_i[0]), _lib.ptr(o_i[1]),
+                                            _lib.ptr(o_sc), _lib.ptr(pm_ws), pm_ws.numel(), st))
+                ws2 = torch.empty(L.gr_lgr_workspace_bytes(B) + 256, dtype=torch.uint8, device=dev)
+                _lib.check(L.gr_lgr_register(_lib.ptr(o_rp), _lib.ptr(o_sp), _lib.ptr(o_sc), n, B, _lib.ptr(pm_ws),
+                                             float(self.acceptance_radius), int(self.correspondence_threshold),
+                                             int(self.num_refinement_steps), _lib.ptr(transform), _lib.ptr(ws2),
+                                             ws2.numel(), st))
+        outs = (o_rp, o_sp, o_sc, transform)
+        if out_device.type != "cuda":
+            outs = tuple(o.to(out_device) for o in outs)
+        return outs

@@ -1,1 +1,1 @@
-from gaussreg_amd.matching import PointMatching, SuperPointMatching  # noqa: F401
+from gaussreg_amd.matching import LocalGlobalRegistration, PointMatching, SuperPointMatching  # noqa: F401

@@ -208,6 +208,16 @@ int gr_corr_gather(const float* score_mat, int64_t batch, int64_t k1, int64_t k2
                    const int64_t* src_knn_indices, const float* global_scores, int use_global_score,
                    float* out_ref_points, float* out_src_points, int64_t* out_ref_indices,
                    int64_t* out_src_indices, float* out_scores, void* ws, size_t ws_bytes, void* stream);
+/* gr_lgr_register: geotransformer/modules/geotransformer/local_global_registration.py:135-193
+ * (local_to_global_registration, correspondence_limit = None) + registration/procrustes.py:6-82, with no
+ * host round trip.  Inputs are the outputs of gr_corr_gather (num_corr rows, torch.nonzero order) and `pm_ws`,
+ * the workspace gr_corr_matrix / gr_corr_gather used (it holds the per-patch counts / offsets).
+ * out_transform: 16 floats, row-major 4x4, on the device. */
+size_t gr_lgr_workspace_bytes(int64_t batch);
+int gr_lgr_register(const float* ref_corr_points, const float* src_corr_points, const float* corr_scores,
+                    int64_t num_corr, int64_t batch, const void* pm_ws, float acceptance_radius,
+                    int correspondence_threshold, int num_refinement_steps, float* out_transform, void* ws,
+                    size_t ws_bytes, void* stream);
 size_t gr_point_to_node_workspace_bytes(int64_t n, int64_t m);
 int gr_point_to_node_partition(const float* points, int64_t n, const float* nodes, int64_t m, int point_limit,
                                int64_t* point_to_node, uint8_t* node_masks, int64_t* node_knn_indices,

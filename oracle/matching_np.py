@@ -168,3 +168,47 @@ def maxpool(x, neighbor_indices):
 def nearest_upsample(x, upsample_indices):
     x = np.concatenate([np.asarray(x, f32), np.zeros((1, x.shape[1]), f32)], 0)
     return x[upsample_indices[:, 0]]
+
+
+# ------------------------------------------------------------------------------------------------
+def weighted_procrustes(src, ref, w, eps=1e-5):
+    """geotransformer/modules/registration/procrustes.py:41-66 (single problem) -> 4x4 float64."""
+    w = np.where(w < 0, 0, w).astype(np.float64)
+    w = w / (w.sum() + eps)
+    cs, cr = (src * w[:, None]).sum(0), (ref * w[:, None]).sum(0)
+    H = (src - cs).T @ (w[:, None] * (ref - cr))
+    U, _, Vt = np.linalg.svd(H)
+    V = Vt.T
+    D = np.eye(3)
+    D[2, 2] = np.sign(np.linalg.det(V @ U.T))
+    R = V @ D @ U.T
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = cr - R @ cs
+    return T
+
+
+def local_global_registration(ref_knn_points, src_knn_points, ref_knn_masks, src_knn_masks, score_mat, k=3,
+                              acceptance_radius=0.1, mutual=True, confidence_threshold=0.05,
+                              correspondence_threshold=3, num_refinement_steps=5):
+    """local_global_registration.py:135-235 (use_dustbin=False, use_global_score=False, no limit)."""
+    s = np.exp(np.asarray(score_mat, f32)).astype(f32)
+    corr = correspondence_matrix(s, ref_knn_masks, src_knn_masks, k, mutual, confidence_threshold)
+    b, i, j = np.nonzero(corr)
+    ref, src, sc = ref_knn_points[b, i].astype(np.float64), src_knn_points[b, j].astype(np.float64), s[b, i, j]
+
+    def inl(T):
+        return np.linalg.norm(ref - (src @ T[:3, :3].T + T[:3, 3]), axis=1) < acceptance_radius
+
+    starts = np.concatenate([[0], np.nonzero(b[1:] != b[:-1])[0] + 1, [len(b)]])
+    chunks = [(x, y) for x, y in zip(starts[:-1], starts[1:]) if y - x >= correspondence_threshold]
+    if chunks:
+        Ts = [weighted_procrustes(src[x:y], ref[x:y], sc[x:y]) for x, y in chunks]
+        counts = [int(inl(T).sum()) for T in Ts]
+        cur = sc * inl(Ts[int(np.argmax(counts))])
+    else:
+        cur = sc * inl(weighted_procrustes(src, ref, sc))
+    T = weighted_procrustes(src, ref, cur)
+    for _ in range(num_refinement_steps - 1):
+        T = weighted_procrustes(src, ref, sc * inl(T))
+    return ref.astype(f32), src.astype(f32), sc, T.astype(f32)

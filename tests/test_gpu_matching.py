@@ -146,3 +146,43 @@ def test_point_to_node_demo_shape_vs_oracle():
         assert same_rows.mean() > 0.98  # rows differ only where two member distances tie within fp noise
         for r in np.nonzero(~same_rows)[0]:
             assert set(idx[r]) == set(widx[r])
+
+
+def test_local_global_registration_vs_reference_golden():
+    from geotransformer.modules.geotransformer import LocalGlobalRegistration
+    g = load_golden("matching.npz")
+    lgr = LocalGlobalRegistration(3, 0.1, mutual=True, confidence_threshold=0.05, correspondence_threshold=3,
+                                  num_refinement_steps=5)
+    r, s, sc, T = lgr(_c(g["lgr_ref_points"]), _c(g["lgr_src_points"]), _c(g["lgr_ref_masks"]), _c(g["lgr_src_masks"]),
+                      _c(g["lgr_score"]), _c(g["lgr_global"]))
+    assert np.array_equal(r.cpu().numpy(), g["lgr_out_ref"]) and np.array_equal(s.cpu().numpy(), g["lgr_out_src"])
+    np.testing.assert_allclose(sc.cpu().numpy(), g["lgr_out_scores"], rtol=1e-5)
+    assert T.shape == (4, 4)
+    np.testing.assert_allclose(T.cpu().numpy(), g["lgr_out_transform"], atol=5e-5)
+
+
+def test_local_global_registration_degenerate_and_demo_shape():
+    from gaussreg_amd.matching import LocalGlobalRegistration
+    from oracle import matching_np as M
+    rng = np.random.default_rng(9)
+    P, K = 256, 128
+    ang = 0.4
+    Rm = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    src = rng.random((P, K, 3)) * 3
+    ref = src @ Rm.T + [0.1, 0.2, -0.3] + rng.normal(0, 0.01, (P, K, 3))
+    logits = rng.normal(size=(P, K, K)) - 8.0
+    logits[:, np.arange(K), np.arange(K)] = 4.0 + rng.normal(size=(P, K))
+    ls = logits - np.log(np.exp(logits).sum(2, keepdims=True))
+    ls = ((ls + logits - np.log(np.exp(logits).sum(1, keepdims=True))) * 0.5).astype(np.float32)
+    rm, sm = rng.random((P, K)) > 0.2, rng.random((P, K)) > 0.2
+    src, ref = src.astype(np.float32), ref.astype(np.float32)
+    want = M.local_global_registration(ref, src, rm, sm, ls)
+    lgr = LocalGlobalRegistration(3, 0.1)
+    got = lgr(_c(ref), _c(src), _c(rm), _c(sm), _c(ls), None)
+    assert got[0].shape[0] == want[0].shape[0] > 1000
+    np.testing.assert_allclose(got[3].cpu().numpy(), want[3], atol=5e-5)
+    # degenerate: threshold so high that no patch qualifies -> global initialisation branch
+    lgr2 = LocalGlobalRegistration(3, 0.1, correspondence_threshold=10 ** 6)
+    T2 = lgr2(_c(ref), _c(src), _c(rm), _c(sm), _c(ls), None)[3].cpu().numpy()
+    want2 = M.local_global_registration(ref, src, rm, sm, ls, correspondence_threshold=10 ** 6)[3]
+    np.testing.assert_allclose(T2, want2, atol=5e-5)

@@ -43,3 +43,13 @@ def test_point_to_node_partition():
     assert np.array_equal(nm, g["p2n_node_masks"]) and not nm[-1]
     assert np.array_equal(km, g["p2n_knn_masks"])
     assert np.array_equal(idx, g["p2n_knn_idx"])
+
+
+def test_local_global_registration():
+    g = load_golden("matching.npz")
+    r, s_, sc, T = M.local_global_registration(g["lgr_ref_points"], g["lgr_src_points"], g["lgr_ref_masks"],
+                                               g["lgr_src_masks"], g["lgr_score"])
+    assert np.array_equal(r, g["lgr_out_ref"]) and np.array_equal(s_, g["lgr_out_src"])
+    np.testing.assert_allclose(sc, g["lgr_out_scores"], rtol=1e-6)
+    np.testing.assert_allclose(T, g["lgr_out_transform"], atol=2e-5)
+    np.testing.assert_allclose(T, g["lgr_true_transform"], atol=5e-3)  # and it found the planted motion
