@@ -662,7 +662,18 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
   GR_REQUIRE(h_num_rendered != nullptr, "h_num_rendered is null");
   for (int v = 0; v < num_views; ++v) h_num_rendered[v] = 0;
   GR_REQUIRE(P >= 0 && P < (1ll << 31) - 1, "P out of range");
-  if (P == 0) return GR_OK;
+  if (P == 0) {  // nothing to project, but the render call still needs the camera table (background)
+    Geom g0 = carve_geom(geom, 0, num_views);
+    if (!geom || geom_bytes < g0.bytes) {
+      set_error("raster geometry buffer too small: need %zu bytes, got %zu", g0.bytes, geom_bytes);
+      return GR_ERR_WORKSPACE;
+    }
+    std::vector<DevView> dv0;
+    rc = upload_views(h_views, num_views, dv0, g0.views, stream);
+    if (rc != GR_OK) return rc;
+    GR_HIP(hipStreamSynchronize(stream));
+    return GR_OK;
+  }
   GR_REQUIRE(means3D && opacities && radii, "means3D / opacities / radii must be non-null");
   GR_REQUIRE((shs != nullptr) != (colors_precomp != nullptr),
              "Please provide excatly one of either SHs or precomputed colors!");

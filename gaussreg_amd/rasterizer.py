@@ -69,7 +69,7 @@ class ViewBatch:
 
 
 def _dev_f32(t: Optional[torch.Tensor], dev, name):
-    if t is None or t.numel() == 0:
+    if t is None:
         return None
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a tensor")
@@ -86,11 +86,16 @@ def rasterize_views(settings, means3D, opacities, shs=None,
     L = _lib.lib()
     if means3D.is_cuda:
         dev = means3D.device
-    if (shs is None or shs.numel() == 0) == (colors_precomp is None or colors_precomp.numel() == 0):
+    n_pts = int(means3D.shape[0])
+
+    def given(t):  # upstream passes empty tensors for "not provided"; with zero Gaussians everything is empty
+        return t is not None and (t.numel() > 0 or n_pts == 0)
+
+    if given(shs) == given(colors_precomp):
         raise Exception('Please provide excatly one of either SHs or precomputed colors!')
-    has_sr = not (scales is None or scales.numel() == 0 or rotations is None or rotations.numel() == 0)
-    has_cov = not (cov3D_precomp is None or cov3D_precomp.numel() == 0)
-    if has_sr == has_cov or ((scales is None or scales.numel() == 0) != (rotations is None or rotations.numel() == 0)):
+    has_sr = given(scales) and given(rotations)
+    has_cov = given(cov3D_precomp)
+    if has_sr == has_cov or (given(scales) != given(rotations)):
         raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
     vb = settings if isinstance(settings, ViewBatch) else ViewBatch(settings)
     V, views, H, W = vb.count, vb.array, vb.height, vb.width
@@ -99,12 +104,12 @@ def rasterize_views(settings, means3D, opacities, shs=None,
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     P = m.shape[0]
     op = _dev_f32(opacities, dev, "opacities")
-    sh = _dev_f32(shs, dev, "shs")
-    cp = _dev_f32(colors_precomp, dev, "colors_precomp")
+    sh = _dev_f32(shs, dev, "shs") if given(shs) else None
+    cp = _dev_f32(colors_precomp, dev, "colors_precomp") if given(colors_precomp) else None
     sc = _dev_f32(scales, dev, "scales") if has_sr else None
     rot = _dev_f32(rotations, dev, "rotations") if has_sr else None
     cov = _dev_f32(cov3D_precomp, dev, "cov3D_precomp") if has_cov else None
-    M = 0 if sh is None else sh.reshape(P, -1, 3).shape[1]
+    M = 0 if sh is None else (sh.shape[1] if sh.dim() == 3 else sh.reshape(max(P, 1), -1, 3).shape[1])
     color = torch.empty((V, 3, H, W), dtype=torch.float32, device=dev)
     radii = torch.empty((V, P), dtype=torch.int32, device=dev)  # every entry is written by preprocess
     nr = (ctypes.c_int64 * V)()

@@ -130,3 +130,35 @@ def test_full_size_configs_bit_exact(P, W, H, V):
         assert nr[v] == wR
         assert np.array_equal(radii[v].cpu().numpy(), wr)
         _assert_bit_equal(imgs[v].cpu().numpy(), want, f"{P} Gaussians {W}x{H} view {v}")
+
+
+def test_huge_gaussians_take_the_rect_marker_path():
+    """A rectangle wider than 63 tiles does not fit the bits packed into the depth-sort key: those Gaussians
+    go through the gather fallback.  1232 x 48 image, a few screen-filling Gaussians among small ones."""
+    from gaussreg_amd.rasterizer import GaussianRasterizer
+    W, H, P = 1232, 48, 400
+    g, cams = raster_scene(P, W, H, seed=21)
+    g["scales"][:6] = np.float32([2.0, 0.05, 0.05])      # metres: hundreds of pixels wide
+    g["means3D"][:6, :2] *= 0.2
+    want, wr, wR = oracle_render(g, cams[0])
+    assert wr[:6].max() > 64 * 16 // 2
+    d = _cu(g)
+    img, radii = GaussianRasterizer(_settings(cams[0]))(d["means3D"], None, d["opacities"], shs=d["shs"],
+                                                        scales=d["scales"], rotations=d["rotations"])
+    assert np.array_equal(radii.cpu().numpy(), wr)
+    _assert_bit_equal(img.cpu().numpy(), want, "wide image with screen-filling Gaussians")
+
+
+def test_zero_gaussians_and_odd_sizes():
+    from gaussreg_amd.rasterizer import GaussianRasterizer, rasterize_views
+    g, cams = raster_scene(50, 37, 23, seed=2)
+    d = _cu(g)
+    img, radii, nr = rasterize_views([_settings(cams[0], bg=(0.2, 0.4, 0.6))], d["means3D"][:0], d["opacities"][:0],
+                                     shs=d["shs"][:0], scales=d["scales"][:0], rotations=d["rotations"][:0])
+    assert img.shape == (1, 3, 23, 37) and radii.shape == (1, 0) and nr == [0]
+    assert torch.equal(img[0, :, 5, 7].cpu(), torch.tensor([0.2, 0.4, 0.6]))
+    want, wr, _ = oracle_render(g, cams[0])
+    img, radii = GaussianRasterizer(_settings(cams[0]))(d["means3D"], None, d["opacities"], shs=d["shs"],
+                                                        scales=d["scales"], rotations=d["rotations"])
+    assert np.array_equal(radii.cpu().numpy(), wr)
+    _assert_bit_equal(img.cpu().numpy(), want, "37x23 image")
