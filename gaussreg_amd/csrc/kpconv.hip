@@ -136,6 +136,88 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
   }
 }
 
+// Larger tile for the layers that dominate the backbone (M >= 128, N >= 128): 128 x 128 x 16 block tile,
+// 64 x 64 per wave = 2 x 2 MFMA 32x32x2 accumulators (A and B fragments are each reused twice), LDS
+// double-buffered so the global loads of slab k+1 overlap the 32 MFMAs of slab k.
+constexpr int BT = 128, BK = 16, BLD = BK + 1;
+
+__global__ __launch_bounds__(256) void gemm_nn_big_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                          int M, int N, int Kd, const float* __restrict__ den,
+                                                          const float* __restrict__ bias, float* __restrict__ out) {
+  __shared__ float sa[2][BT][BLD];
+  __shared__ float sb[2][BT][BLD];
+  const int i0 = blockIdx.y * BT, j0 = blockIdx.x * BT;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wi = (w >> 1) * 64, wj = (w & 1) * 64;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  // staging: A tile 128 rows x 16 k (coalesced along k: 16 threads per row), B tile 16 k x 128 cols
+  float ra[8], rb[8];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = tid + u * 256;
+      const int r = e / BK, k = e % BK;
+      const int gi = i0 + r, gk = k0 + k;
+      ra[u] = (gi < M && gk < Kd) ? A[(int64_t)gi * Kd + gk] : 0.f;
+      const int kk = e / BT, j = e % BT;
+      const int gj = j0 + j, gkb = k0 + kk;
+      rb[u] = (gj < N && gkb < Kd) ? B[(int64_t)gkb * N + gj] : 0.f;
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = tid + u * 256;
+      sa[buf][e / BK][e % BK] = ra[u];
+      sb[buf][e % BT][e / BT] = rb[u];
+    }
+  };
+  load(0);
+  store(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < Kd; k0 += BK) {
+    const bool more = k0 + BK < Kd;
+    if (more) load(k0 + BK);  // in flight during the MFMAs below
+#pragma unroll
+    for (int k = 0; k < BK; k += 2) {
+      const int kk = k + (lane >> 5);
+      const float a0 = sa[buf][wi + (lane & 31)][kk], a1 = sa[buf][wi + 32 + (lane & 31)][kk];
+      const float b0 = sb[buf][wj + (lane & 31)][kk], b1 = sb[buf][wj + 32 + (lane & 31)][kk];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) {
+      store(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gi = i0 + wi + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int gj = j0 + wj + b * 32 + (lane & 31);
+        if (gi < M && gj < N) {
+          float v = acc[a][b][r];
+          if (den) v = v / den[gi];
+          if (bias) v = v + bias[gj];
+          out[(int64_t)gi * N + gj] = v;
+        }
+      }
+}
+
 // functional.py:54-67 maxpool (zero shadow row) / :6-22 nearest_upsample
 __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ x, int N, int C,
                                                    const int64_t* __restrict__ nbr, int M, int H, int mode,
@@ -201,9 +283,15 @@ extern "C" int gr_kpconv_forward(const float* s_feats, const float* q_points, co
   else
     hipLaunchKernelGGL((kp_gather_kernel<256>), dim3((unsigned)m), dim3(256), 0, stream, s_feats, q_points, s_points,
                        neighbor_indices, (int)n, (int)h, (int)cin, (int)k, kernel_points, sigma, inf, flag, WF, num);
-  const dim3 grid((unsigned)((cout + GT - 1) / GT), (unsigned)((m + GT - 1) / GT));
-  hipLaunchKernelGGL(gemm_nn_kernel, grid, dim3(256), 0, stream, WF, weights, (int)m, (int)cout, (int)(k * cin), num, bias,
-                     out);
+  if (m >= BT && cout >= BT) {
+    const dim3 grid((unsigned)((cout + BT - 1) / BT), (unsigned)((m + BT - 1) / BT));
+    hipLaunchKernelGGL(gemm_nn_big_kernel, grid, dim3(256), 0, stream, WF, weights, (int)m, (int)cout, (int)(k * cin), num,
+                       bias, out);
+  } else {
+    const dim3 grid((unsigned)((cout + GT - 1) / GT), (unsigned)((m + GT - 1) / GT));
+    hipLaunchKernelGGL(gemm_nn_kernel, grid, dim3(256), 0, stream, WF, weights, (int)m, (int)cout, (int)(k * cin), num,
+                       bias, out);
+  }
   GR_LAUNCH_CHECK();
   return GR_OK;
 }
