@@ -75,6 +75,10 @@ SIGNATURES.update({
     "gr_lgr_workspace_bytes": (c_size, [c_i64]),
     "gr_lgr_register": (c_int, [c_void, c_void, c_void, c_i64, c_i64, c_void, c_f32, c_int, c_int, c_void, c_void,
                                 c_size, c_void]),
+    "gr_ransac_sample_hash": (ctypes.c_uint32, [ctypes.c_uint32] * 4),
+    "gr_ransac_workspace_bytes": (c_size, [c_i64]),
+    "gr_ransac_similarity": (c_int, [c_void, c_void, c_i64, c_int, c_i64, ctypes.c_uint32, c_f32, c_int, c_int, c_void,
+                                     c_void, c_void, c_size, c_void]),
     "gr_point_to_node_workspace_bytes": (c_size, [c_i64, c_i64]),
     "gr_point_to_node_partition": (c_int, [c_void, c_i64, c_void, c_i64, c_int, c_void, c_void, c_void, c_void,
                                            c_void, c_size, c_void]),

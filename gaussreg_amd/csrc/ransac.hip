@@ -1,0 +1,280 @@
+// RANSAC over putative correspondences with a similarity (rotation + uniform scale + translation) model
+// ("next" row).  Stands in for the Open3D call GaussReg ends its coarse registration
+// with -- geotransformer/utils/open3d.py:169-198 registration_ransac_based_on_correspondence(...,
+// TransformationEstimationPointToPoint(True), ransac_n=5, RANSACConvergenceCriteria(10000, 10000)), called
+// from experiments/geotransformer.gaussian_splatting.indoor/model.py:209-215.  PARITY UNPINNED: Open3D
+// (0.11.2, environment.yaml:111) is neither in the reference tree nor installed, and its sampler is unseeded;
+// what is restated is the published algorithm: sample n correspondences, Umeyama similarity, score by the
+// number of correspondences within the distance threshold (ties: lower inlier RMSE), keep the best.
+//   hypotheses  one thread per hypothesis: counter-hash sampling of n distinct correspondences, Umeyama in
+//               fp64 (Horn quaternion rotation, scale = sum(ref_c . R src_c) / sum |src_c|^2), then every
+//               correspondence (staged through LDS, broadcast reads) is tested        -> (inliers, rmse)
+//   best        block reduction over hypotheses; optional refit on the best hypothesis' inliers
+#include "common.hpp"
+
+namespace gr {
+namespace {
+
+constexpr int RS_T = 256;
+constexpr int RS_MAXN = 8;
+
+__host__ __device__ inline uint32_t rs_hash(uint32_t seed, uint32_t h, uint32_t k, uint32_t attempt) {
+  uint32_t x = seed ^ (h * 0x9E3779B9u) ^ (k * 0x85EBCA6Bu) ^ (attempt * 0xC2B2AE35u);
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+
+__device__ void jacobi_maxvec4(double A[4][4], double* q) {
+  double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+  for (int sweep = 0; sweep < 16; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < 4; ++p)
+      for (int r = p + 1; r < 4; ++r) off += A[p][r] * A[p][r];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 3; ++p)
+      for (int r = p + 1; r < 4; ++r) {
+        if (fabs(A[p][r]) < 1e-300) continue;
+        const double theta = (A[r][r] - A[p][p]) / (2.0 * A[p][r]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 4; ++k) { const double a = A[k][p], b = A[k][r]; A[k][p] = c * a - s * b; A[k][r] = s * a + c * b; }
+        for (int k = 0; k < 4; ++k) { const double a = A[p][k], b = A[r][k]; A[p][k] = c * a - s * b; A[r][k] = s * a + c * b; }
+        for (int k = 0; k < 4; ++k) { const double a = V[k][p], b = V[k][r]; V[k][p] = c * a - s * b; V[k][r] = s * a + c * b; }
+      }
+  }
+  int best = 0;
+  for (int k = 1; k < 4; ++k)
+    if (A[k][k] > A[best][best]) best = k;
+  double n = 0;
+  for (int k = 0; k < 4; ++k) { q[k] = V[k][best]; n += q[k] * q[k]; }
+  n = sqrt(n);
+  for (int k = 0; k < 4; ++k) q[k] /= n;
+}
+
+// Umeyama similarity from sums: n, sum src, sum ref, sum src_a*ref_b (9), sum |src|^2  ->  T (3x4: sR | t)
+__device__ bool umeyama_from_sums(double n, const double* ss, const double* sr, const double* sxy, double s2, int with_scale,
+                                  float* T) {
+  if (n < 1.0) return false;
+  double cs[3], cr[3], H[9];
+  for (int k = 0; k < 3; ++k) { cs[k] = ss[k] / n; cr[k] = sr[k] / n; }
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) H[a * 3 + b] = sxy[a * 3 + b] - n * cs[a] * cr[b];  // sum (src-cs)_a (ref-cr)_b
+  const double var = s2 - n * (cs[0] * cs[0] + cs[1] * cs[1] + cs[2] * cs[2]);
+  double A[4][4] = {{H[0] + H[4] + H[8], H[5] - H[7], H[6] - H[2], H[1] - H[3]},
+                    {H[5] - H[7], H[0] - H[4] - H[8], H[1] + H[3], H[6] + H[2]},
+                    {H[6] - H[2], H[1] + H[3], -H[0] + H[4] - H[8], H[5] + H[7]},
+                    {H[1] - H[3], H[6] + H[2], H[5] + H[7], -H[0] - H[4] + H[8]}};
+  double q[4];
+  jacobi_maxvec4(A, q);
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                       2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                       2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
+  double scale = 1.0;
+  if (with_scale) {
+    double tr = 0;  // sum_i ref_c . (R src_c) = sum_ab R[b][a] H[a][b]
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) tr += R[b * 3 + a] * H[a * 3 + b];
+    if (!(var > 1e-300)) return false;
+    scale = tr / var;
+    if (!(scale > 0.0) || !isfinite(scale)) return false;
+  }
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) T[r * 4 + c] = (float)(scale * R[r * 3 + c]);
+    T[r * 4 + 3] = (float)(cr[r] - scale * (R[r * 3] * cs[0] + R[r * 3 + 1] * cs[1] + R[r * 3 + 2] * cs[2]));
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(RS_T) void ransac_hypotheses_kernel(const float* __restrict__ src, const float* __restrict__ ref,
+                                                                 int C, int n_sample, int num_hyp, uint32_t seed,
+                                                                 float thr, int with_scale, float* __restrict__ transforms,
+                                                                 int32_t* __restrict__ inliers, float* __restrict__ sqerr) {
+  __shared__ float s_src[RS_T * 3];
+  __shared__ float s_ref[RS_T * 3];
+  const int h = blockIdx.x * RS_T + threadIdx.x;
+  float T[12];
+  bool ok = false;
+  if (h < num_hyp) {
+    int idx[RS_MAXN];
+    for (int k = 0; k < n_sample; ++k) {
+      uint32_t attempt = 0;
+      for (;;) {
+        idx[k] = (int)(rs_hash(seed, (uint32_t)h, (uint32_t)k, attempt) % (uint32_t)C);
+        bool dup = false;
+        for (int j = 0; j < k; ++j) dup = dup || idx[j] == idx[k];
+        if (!dup || attempt > 64) break;
+        ++attempt;
+      }
+    }
+    double ss[3] = {0, 0, 0}, sr[3] = {0, 0, 0}, sxy[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, s2 = 0;
+    for (int k = 0; k < n_sample; ++k) {
+      const double a[3] = {src[3 * idx[k]], src[3 * idx[k] + 1], src[3 * idx[k] + 2]};
+      const double b[3] = {ref[3 * idx[k]], ref[3 * idx[k] + 1], ref[3 * idx[k] + 2]};
+      for (int p = 0; p < 3; ++p) {
+        ss[p] += a[p];
+        sr[p] += b[p];
+        s2 += a[p] * a[p];
+        for (int r = 0; r < 3; ++r) sxy[p * 3 + r] += a[p] * b[r];
+      }
+    }
+    ok = umeyama_from_sums((double)n_sample, ss, sr, sxy, s2, with_scale, T);
+  }
+  int cnt = 0;
+  float err = 0.f;
+  const float thr2 = thr * thr;
+  for (int c0 = 0; c0 < C; c0 += RS_T) {
+    const int nn = min(RS_T, C - c0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < nn * 3; e += RS_T) {
+      s_src[e] = src[3 * (int64_t)c0 + e];
+      s_ref[e] = ref[3 * (int64_t)c0 + e];
+    }
+    __syncthreads();
+    if (ok) {
+      for (int i = 0; i < nn; ++i) {
+        const float x = s_src[3 * i], y = s_src[3 * i + 1], z = s_src[3 * i + 2];
+        const float dx = s_ref[3 * i] - (fmaf(T[0], x, fmaf(T[1], y, fmaf(T[2], z, T[3]))));
+        const float dy = s_ref[3 * i + 1] - (fmaf(T[4], x, fmaf(T[5], y, fmaf(T[6], z, T[7]))));
+        const float dz = s_ref[3 * i + 2] - (fmaf(T[8], x, fmaf(T[9], y, fmaf(T[10], z, T[11]))));
+        const float d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+        if (d2 < thr2) {
+          ++cnt;
+          err += d2;
+        }
+      }
+    }
+  }
+  if (h < num_hyp) {
+    inliers[h] = ok ? cnt : -1;
+    sqerr[h] = err;
+    for (int k = 0; k < 12; ++k) transforms[h * 12 + k] = ok ? T[k] : 0.f;
+  }
+}
+
+// best hypothesis (most inliers, then lowest squared error, then lowest index) + optional refit on its inliers
+__global__ __launch_bounds__(1024) void ransac_best_kernel(const float* __restrict__ src, const float* __restrict__ ref, int C,
+                                                           int num_hyp, const float* __restrict__ transforms,
+                                                           const int32_t* __restrict__ inliers,
+                                                           const float* __restrict__ sqerr, float thr, int with_scale,
+                                                           int refine, float* __restrict__ out /* 4x4 */,
+                                                           int32_t* __restrict__ out_stats /* [2]: inliers, best id */) {
+  __shared__ int s_cnt[1024];
+  __shared__ float s_err[1024];
+  __shared__ int s_id[1024];
+  __shared__ double s_acc[1][1024 / WAVE];
+  __shared__ float T[12];
+  int bc = -2, bi = -1;
+  float be = INFINITY;
+  for (int h = threadIdx.x; h < num_hyp; h += 1024) {
+    const int c = inliers[h];
+    const float e = sqerr[h];
+    if (c > bc || (c == bc && e < be)) { bc = c; be = e; bi = h; }
+  }
+  s_cnt[threadIdx.x] = bc; s_err[threadIdx.x] = be; s_id[threadIdx.x] = bi;
+  __syncthreads();
+  for (int d = 512; d > 0; d >>= 1) {
+    if (threadIdx.x < d) {
+      const int o = threadIdx.x + d;
+      const bool better = s_cnt[o] > s_cnt[threadIdx.x] ||
+                          (s_cnt[o] == s_cnt[threadIdx.x] && (s_err[o] < s_err[threadIdx.x] ||
+                                                               (s_err[o] == s_err[threadIdx.x] && s_id[o] >= 0 &&
+                                                                (s_id[threadIdx.x] < 0 || s_id[o] < s_id[threadIdx.x]))));
+      if (better) { s_cnt[threadIdx.x] = s_cnt[o]; s_err[threadIdx.x] = s_err[o]; s_id[threadIdx.x] = s_id[o]; }
+    }
+    __syncthreads();
+  }
+  const int best = s_id[0];
+  if (threadIdx.x < 12) T[threadIdx.x] = best >= 0 && s_cnt[0] >= 0 ? transforms[best * 12 + threadIdx.x] : (threadIdx.x % 5 == 0 ? 1.f : 0.f);
+  __syncthreads();
+  if (refine && best >= 0 && s_cnt[0] >= 3) {
+    // Umeyama on every inlier of the best hypothesis: 17 fp64 sums {n, sum src, sum ref, sum src_a ref_b, sum |src|^2}
+    double acc[17];
+    for (int k = 0; k < 17; ++k) acc[k] = 0;
+    const float thr2 = thr * thr;
+    for (int i = threadIdx.x; i < C; i += 1024) {
+      const float x = src[3 * (int64_t)i], y = src[3 * (int64_t)i + 1], z = src[3 * (int64_t)i + 2];
+      const float rx = ref[3 * (int64_t)i], ry = ref[3 * (int64_t)i + 1], rz = ref[3 * (int64_t)i + 2];
+      const float dx = rx - fmaf(T[0], x, fmaf(T[1], y, fmaf(T[2], z, T[3])));
+      const float dy = ry - fmaf(T[4], x, fmaf(T[5], y, fmaf(T[6], z, T[7])));
+      const float dz = rz - fmaf(T[8], x, fmaf(T[9], y, fmaf(T[10], z, T[11])));
+      if (fmaf(dx, dx, fmaf(dy, dy, dz * dz)) < thr2) {
+        const double a3[3] = {x, y, z}, b3[3] = {rx, ry, rz};
+        acc[0] += 1.0;
+        for (int p = 0; p < 3; ++p) {
+          acc[1 + p] += a3[p];
+          acc[4 + p] += b3[p];
+          acc[16] += a3[p] * a3[p];
+          for (int r = 0; r < 3; ++r) acc[7 + p * 3 + r] += a3[p] * b3[r];
+        }
+      }
+    }
+    double red[17];
+    for (int k = 0; k < 17; ++k) {
+      double v = acc[k];
+      for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, WAVE);
+      __syncthreads();
+      if ((threadIdx.x & (WAVE - 1)) == 0) s_acc[0][threadIdx.x / WAVE] = v;
+      __syncthreads();
+      double t = 0;
+      for (int w = 0; w < 1024 / WAVE; ++w) t += s_acc[0][w];
+      red[k] = t;
+    }
+    if (threadIdx.x == 0) {
+      float Tn[12];
+      if (umeyama_from_sums(red[0], red + 1, red + 4, red + 7, red[16], with_scale, Tn))
+        for (int k = 0; k < 12; ++k) T[k] = Tn[k];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 16) {
+    const int r = threadIdx.x / 4, c = threadIdx.x % 4;
+    out[threadIdx.x] = r < 3 ? T[r * 4 + c] : (c == 3 ? 1.f : 0.f);
+  }
+  if (threadIdx.x == 0 && out_stats) {
+    out_stats[0] = s_cnt[0];
+    out_stats[1] = best;
+  }
+}
+
+}  // namespace
+}  // namespace gr
+
+using namespace gr;
+
+extern "C" uint32_t gr_ransac_sample_hash(uint32_t seed, uint32_t hypothesis, uint32_t k, uint32_t attempt) {
+  return rs_hash(seed, hypothesis, k, attempt);
+}
+
+extern "C" size_t gr_ransac_workspace_bytes(int64_t num_hypotheses) {
+  if (num_hypotheses < 0) return 0;
+  return align_up((size_t)num_hypotheses * 12 * 4, 256) + 2 * align_up((size_t)num_hypotheses * 4, 256) + 256;
+}
+
+extern "C" int gr_ransac_similarity(const float* src_points, const float* ref_points, int64_t num_corr, int ransac_n,
+                                    int64_t num_hypotheses, uint32_t seed, float distance_threshold, int with_scaling,
+                                    int refine, float* out_transform, int32_t* out_stats, void* ws, size_t ws_bytes,
+                                    void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GR_REQUIRE(num_corr >= 0 && num_hypotheses >= 1 && num_hypotheses < (1 << 24), "bad sizes");
+  GR_REQUIRE(ransac_n >= 3 && ransac_n <= RS_MAXN, "ransac_n must be in [3, %d]", RS_MAXN);
+  GR_REQUIRE(num_corr >= ransac_n, "need at least ransac_n correspondences");
+  GR_REQUIRE(src_points && ref_points && out_transform, "null argument");
+  if (!ws || ws_bytes < gr_ransac_workspace_bytes(num_hypotheses)) {
+    set_error("ransac workspace too small");
+    return GR_ERR_WORKSPACE;
+  }
+  Carver c(ws);
+  float* transforms = c.take<float>(num_hypotheses * 12);
+  int32_t* inl = c.take<int32_t>(num_hypotheses);
+  float* err = c.take<float>(num_hypotheses);
+  KernelTimer timer("ransac", stream);
+  hipLaunchKernelGGL(ransac_hypotheses_kernel, dim3((unsigned)((num_hypotheses + RS_T - 1) / RS_T)), dim3(RS_T), 0, stream,
+                     src_points, ref_points, (int)num_corr, ransac_n, (int)num_hypotheses, seed, distance_threshold,
+                     with_scaling, transforms, inl, err);
+  hipLaunchKernelGGL(ransac_best_kernel, dim3(1), dim3(1024), 0, stream, src_points, ref_points, (int)num_corr,
+                     (int)num_hypotheses, transforms, inl, err, distance_threshold, with_scaling, refine, out_transform,
+                     out_stats);
+  GR_LAUNCH_CHECK();
+  return GR_OK;
+}

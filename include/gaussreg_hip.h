@@ -218,6 +218,19 @@ int gr_lgr_register(const float* ref_corr_points, const float* src_corr_points, 
                     int64_t num_corr, int64_t batch, const void* pm_ws, float acceptance_radius,
                     int correspondence_threshold, int num_refinement_steps, float* out_transform, void* ws,
                     size_t ws_bytes, void* stream);
+/* gr_ransac_similarity ("next" row; PARITY UNPINNED -- Open3D is not in the reference tree):
+ * stands in for geotransformer/utils/open3d.py:169-198 (registration_ransac_based_on_correspondence with
+ * TransformationEstimationPointToPoint(with_scaling)), called from model.py:209-215.  Row i of src_points
+ * corresponds to row i of ref_points.  out_transform: 16 floats (4x4 row-major, scale folded into the 3x3
+ * block) on the device; out_stats (optional, device int32[2]) = {inliers of the best hypothesis, its id}.
+ * gr_ransac_sample_hash exposes the counter hash the sampler uses (index = hash % num_corr, retried with
+ * attempt+1 on duplicates) so a checker can replay the same hypotheses. */
+uint32_t gr_ransac_sample_hash(uint32_t seed, uint32_t hypothesis, uint32_t k, uint32_t attempt);
+size_t gr_ransac_workspace_bytes(int64_t num_hypotheses);
+int gr_ransac_similarity(const float* src_points, const float* ref_points, int64_t num_corr, int ransac_n,
+                         int64_t num_hypotheses, uint32_t seed, float distance_threshold, int with_scaling,
+                         int refine, float* out_transform, int32_t* out_stats, void* ws, size_t ws_bytes,
+                         void* stream);
 size_t gr_point_to_node_workspace_bytes(int64_t n, int64_t m);
 int gr_point_to_node_partition(const float* points, int64_t n, const float* nodes, int64_t m, int point_limit,
                                int64_t* point_to_node, uint8_t* node_masks, int64_t* node_knn_indices,

@@ -90,3 +90,69 @@ def test_gs_fusion_vs_reference_golden(tmp_path):
     write_gs_ply(p1, g["rec1"]); write_gs_ply(p2, g["rec2"]); np.savez(pt, estimated_transform=g["transform"])
     gaussian_fuse(p1, p2, pt, po)
     assert np.array_equal(read_gs_ply(po), fused)
+
+
+def _planted_similarity(n, outlier_frac, seed):
+    rng = np.random.default_rng(seed)
+    ax = rng.normal(size=3); ax /= np.linalg.norm(ax); ang = 1.1
+    Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+    sc, t = 1.8, np.array([0.4, -1.0, 2.0])
+    src = rng.random((n, 3)) * 4
+    ref = sc * src @ R.T + t + rng.normal(0, 0.005, (n, 3))
+    bad = rng.random(n) < outlier_frac
+    ref[bad] = rng.random((int(bad.sum()), 3)) * 8
+    T = np.eye(4); T[:3, :3] = sc * R; T[:3, 3] = t
+    return src.astype(np.float32), ref.astype(np.float32), T, ~bad
+
+
+@pytest.mark.parametrize("outliers", [0.0, 0.5, 0.8])
+def test_ransac_similarity_recovers_planted_transform(outliers):
+    """Parity unpinned (Open3D absent): judged on registration error, as SURVEY 8c prescribes."""
+    from gaussreg_amd.registration import registration_with_ransac_from_correspondences as ransac
+    src, ref, T, good = _planted_similarity(2500, outliers, 3)
+    est, stats = ransac(_c(src), _c(ref), distance_threshold=0.05, ransac_n=5, num_iterations=10000, return_stats=True)
+    est = est.cpu().numpy()
+    assert int(stats[0]) >= 0.9 * good.sum()
+    np.testing.assert_allclose(est[:3, :3], T[:3, :3], atol=5e-3)
+    np.testing.assert_allclose(est[:3, 3], T[:3, 3], atol=2e-2)
+    assert est[3].tolist() == [0, 0, 0, 1]
+    # rigid variant ignores the scale
+    src2 = src; ref2 = (src @ (T[:3, :3] / 1.8).T + T[:3, 3]).astype(np.float32)
+    est2 = ransac(_c(src2), _c(ref2), distance_threshold=0.05, ransac_n=3, num_iterations=2000, with_scaling=False).cpu().numpy()
+    np.testing.assert_allclose(est2[:3, :3], T[:3, :3] / 1.8, atol=2e-3)
+
+
+def test_ransac_hypotheses_match_host_replay():
+    """Replay the sampler's hash on the host and check the winning hypothesis really is the best one."""
+    import ctypes
+    from gaussreg_amd import _lib
+    from gaussreg_amd.registration import registration_with_ransac_from_correspondences as ransac
+    src, ref, T, good = _planted_similarity(300, 0.6, 5)
+    H = 500
+    est, stats = ransac(_c(src), _c(ref), distance_threshold=0.05, ransac_n=5, num_iterations=H, refine=False, seed=7,
+                        return_stats=True)
+    L = _lib.lib()
+    best = (-1, None)
+    for h in range(H):
+        idx = []
+        for k in range(5):
+            a = 0
+            while True:
+                i = L.gr_ransac_sample_hash(7, h, k, a) % 300
+                if i not in idx or a > 64:
+                    break
+                a += 1
+            idx.append(i)
+        s, r = src[idx].astype(np.float64), ref[idx].astype(np.float64)
+        cs, cr = s.mean(0), r.mean(0)
+        Hm = (s - cs).T @ (r - cr)
+        U, S, Vt = np.linalg.svd(Hm)
+        D = np.eye(3); D[2, 2] = np.sign(np.linalg.det(Vt.T @ U.T))
+        Rm = Vt.T @ D @ U.T
+        c = np.trace(np.diag(S) @ D) / ((s - cs) ** 2).sum()
+        res = np.linalg.norm(ref - (c * src @ Rm.T + (cr - c * Rm @ cs)), axis=1)
+        n_in = int((res < 0.05).sum())
+        if n_in > best[0]:
+            best = (n_in, h)
+    assert int(stats[0]) == best[0]
