@@ -1,0 +1,260 @@
+// Farthest point sampling in stack mode ("next" row).
+// Stands in for fpsample.bucket_fps_kdline_sampling(points, n, h=9) that GaussReg calls before collation
+// (experiments/.../demo.py:46, test.py:46, datasets/.../dataset.py:127; pin environment.yaml:66).
+// PARITY UNPINNED: fpsample (Rust) is not in the reference tree; it computes exact FPS with a kd-bucket
+// acceleration, so from the same start index the sample SET is the one below up to ties; the start index
+// is the caller's (the package draws it at random).  Contract here: sample 0 = start_idx; sample k+1 =
+// arg max_i min_{j<=k} |p_i - p_sample_j|^2 in fp32 ((dx*dx + dy*dy) + dz*dz), lowest index on ties.
+//
+// FPS is sequential in k, so one iteration has to be as short as the hardware allows:
+//   * a cloud is split over G workgroups (G*batch <= 256, so all of them are co-resident), each keeping its
+//     points AND their running min-distance in registers (PPT <= 20 per thread); beyond that the slab streams
+//     from L2 with 4 loads in flight;
+//   * per iteration a workgroup publishes its best candidate {d, idx, x, y, z} in a double-buffered slot, every
+//     word tagged with the iteration number; lane g of wave 0 in every workgroup polls slot g until all five
+//     tags are current, then the wave reduces the G candidates and everybody continues with the winner's
+//     coordinates -- one store + one load round trip per iteration, no fences, no counters.
+//   * the spin is bounded: a lane that waits > 2^22 polls raises an error flag and all leave (no GPU hang).
+#include <vector>
+
+#include "common.hpp"
+
+namespace gr {
+namespace {
+
+constexpr int FPS_T = 1024;
+constexpr int FPS_GMAX = 64;
+
+struct FpsCand {  // 64 B: five (iteration tag << 32 | payload) words {d, idx, x, y, z}, agent-scope accesses
+  unsigned long long w[8];
+};
+
+__device__ __forceinline__ unsigned long long fps_key(float d, int idx) {
+  return ((unsigned long long)__float_as_uint(d) << 32) | (0xffffffffu - (unsigned)idx);  // d >= 0: bits are ordered
+}
+
+template <int PPT>
+__global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ pts, const int32_t* __restrict__ off,
+                                                    const int32_t* __restrict__ samp_off,
+                                                    const int32_t* __restrict__ start_idx, float* __restrict__ mind,
+                                                    FpsCand* __restrict__ cand,
+                                                    int* __restrict__ err, int G, int64_t* __restrict__ out) {
+  __shared__ unsigned long long s_key[FPS_T / WAVE];
+  __shared__ float s_c[4];
+  __shared__ int s_abort;
+  const int b = blockIdx.x / G, part = blockIdx.x % G;
+  const int p0 = off[b], n = off[b + 1] - p0;
+  const int o0 = samp_off[b], k = samp_off[b + 1] - o0;
+  if (n <= 0 || k <= 0) return;
+  const float* P = pts + 3 * (int64_t)p0;
+  float* D = mind + p0;
+  // this workgroup's slab [lo, hi): whole multiples of FPS_T except the last
+  const int per = ((n + G - 1) / G + FPS_T - 1) / FPS_T * FPS_T;
+  const int lo = min(part * per, n), hi = min(lo + per, n);
+  float px[PPT > 0 ? PPT : 1], py[PPT > 0 ? PPT : 1], pz[PPT > 0 ? PPT : 1], pd[PPT > 0 ? PPT : 1];
+  if (PPT > 0) {
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int i = lo + j * FPS_T + threadIdx.x;
+      const bool v = i < hi;
+      px[j] = v ? P[3 * i] : 0.f;
+      py[j] = v ? P[3 * i + 1] : 0.f;
+      pz[j] = v ? P[3 * i + 2] : 0.f;
+      pd[j] = v ? INFINITY : -1.0f;  // -1: never beats a real candidate (all real d >= 0)
+    }
+  } else {
+    for (int i = lo + threadIdx.x; i < hi; i += FPS_T) D[i] = INFINITY;
+  }
+  int cur = start_idx ? min(max(start_idx[b], 0), n - 1) : 0;
+  float cx = P[3 * cur], cy = P[3 * cur + 1], cz = P[3 * cur + 2];
+  if (part == 0 && threadIdx.x == 0) out[o0] = cur;
+  if (threadIdx.x == 0) s_abort = 0;
+  FpsCand* slots = cand + (size_t)b * 2 * FPS_GMAX;
+
+  for (int s = 1; s < k; ++s) {
+    float best = -1.0f;
+    int bi = 0;
+    if (PPT > 0) {
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) {
+        const float dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;
+        const float d = fminf(pd[j], (dx * dx + dy * dy) + dz * dz);
+        pd[j] = d;
+        if (d > best) {  // ascending index within the thread: the first maximum is kept
+          best = d;
+          bi = lo + j * FPS_T + threadIdx.x;
+        }
+      }
+    } else {
+      int i = lo + threadIdx.x;
+      for (; i + 3 * FPS_T < hi; i += 4 * FPS_T) {
+        float x[4], y[4], z[4], dd[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int q = i + u * FPS_T;
+          x[u] = P[3 * q], y[u] = P[3 * q + 1], z[u] = P[3 * q + 2], dd[u] = D[q];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float dx = x[u] - cx, dy = y[u] - cy, dz = z[u] - cz;
+          const float d = fminf(dd[u], (dx * dx + dy * dy) + dz * dz);
+          D[i + u * FPS_T] = d;
+          if (d > best) best = d, bi = i + u * FPS_T;
+        }
+      }
+      for (; i < hi; i += FPS_T) {
+        const float dx = P[3 * i] - cx, dy = P[3 * i + 1] - cy, dz = P[3 * i + 2] - cz;
+        const float d = fminf(D[i], (dx * dx + dy * dy) + dz * dz);
+        D[i] = d;
+        if (d > best) best = d, bi = i;
+      }
+    }
+    unsigned long long key = best >= 0.f ? fps_key(best, bi) : 0ull;
+#pragma unroll
+    for (int dd = WAVE / 2; dd > 0; dd >>= 1) {
+      const unsigned long long o = __shfl_xor(key, dd, WAVE);
+      key = o > key ? o : key;
+    }
+    if ((threadIdx.x & (WAVE - 1)) == 0) s_key[threadIdx.x / WAVE] = key;
+    __syncthreads();
+    if (threadIdx.x < WAVE) {
+      unsigned long long v = threadIdx.x < FPS_T / WAVE ? s_key[threadIdx.x] : 0ull;
+#pragma unroll
+      for (int dd = WAVE / 2; dd > 0; dd >>= 1) {
+        const unsigned long long o = __shfl_xor(v, dd, WAVE);
+        v = o > v ? o : v;
+      }
+      // v = this workgroup's best; fetch its coordinates (a uniform, cached load)
+      int wi = v ? (int)(0xffffffffu - (unsigned)(v & 0xffffffffu)) : 0;
+      float wx = P[3 * wi], wy = P[3 * wi + 1], wz = P[3 * wi + 2];
+      if (G > 1) {
+        // tagged exchange: every 64-bit word carries the iteration number in its high half, so a reader knows a
+        // word is current without any fence or counter (relaxed agent-scope accesses go past the per-XCD L2s)
+        FpsCand* slot = slots + (size_t)(s & 1) * FPS_GMAX;
+        const unsigned long long tag = (unsigned long long)(unsigned)s << 32;
+        if (threadIdx.x == 0) {
+          unsigned long long* w = reinterpret_cast<unsigned long long*>(&slot[part]);
+          __hip_atomic_store(w + 0, tag | (unsigned)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(w + 1, tag | (unsigned)wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(w + 2, tag | __float_as_uint(wx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(w + 3, tag | __float_as_uint(wy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(w + 4, tag | __float_as_uint(wz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned long long ck = 0ull;
+        unsigned ux = 0, uy = 0, uz = 0;
+        bool bad = false;
+        if ((int)threadIdx.x < G) {
+          const unsigned long long* w = reinterpret_cast<const unsigned long long*>(&slot[threadIdx.x]);
+          int spins = 0;
+          for (;;) {
+            unsigned long long r[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) r[u] = __hip_atomic_load(w + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool ok = true;
+#pragma unroll
+            for (int u = 0; u < 5; ++u) ok = ok && (r[u] >> 32) == (unsigned)s;
+            if (ok) {
+              ck = ((r[0] & 0xffffffffull) << 32) | (0xffffffffu - (unsigned)r[1]);
+              ux = (unsigned)r[2], uy = (unsigned)r[3], uz = (unsigned)r[4];
+              break;
+            }
+            if (++spins > (1 << 22) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+              __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              bad = true;
+              break;
+            }
+          }
+        }
+        if (__any(bad)) {
+          if (threadIdx.x == 0) s_abort = 1;
+        }
+#pragma unroll
+        for (int dd = WAVE / 2; dd > 0; dd >>= 1) {
+          const unsigned long long ok = __shfl_xor(ck, dd, WAVE);
+          const unsigned ox = __shfl_xor(ux, dd, WAVE), oy = __shfl_xor(uy, dd, WAVE), oz = __shfl_xor(uz, dd, WAVE);
+          if (ok > ck) ck = ok, ux = ox, uy = oy, uz = oz;
+        }
+        wi = (int)(0xffffffffu - (unsigned)(ck & 0xffffffffu));
+        wx = __uint_as_float(ux), wy = __uint_as_float(uy), wz = __uint_as_float(uz);
+      }
+      if (threadIdx.x == 0) {
+        s_c[0] = wx, s_c[1] = wy, s_c[2] = wz, s_c[3] = __int_as_float(wi);
+        if (part == 0) out[o0 + s] = wi;
+      }
+    }
+    __syncthreads();
+    cx = s_c[0], cy = s_c[1], cz = s_c[2];
+    cur = __float_as_int(s_c[3]);
+    if (G > 1 && s_abort) return;  // barrier timed out: the whole workgroup leaves (uniform: read after the sync)
+  }
+}
+
+}  // namespace
+}  // namespace gr
+
+using namespace gr;
+
+extern "C" size_t gr_fps_workspace_bytes(int64_t n, int64_t batch) {
+  if (n < 0 || batch < 0) return 0;
+  return align_up((size_t)n * 4, 256) + 3 * align_up((size_t)(batch + 1) * 4, 256) +
+         align_up((size_t)batch * 2 * FPS_GMAX * sizeof(FpsCand), 256) + align_up((size_t)(batch + 1) * 4, 256) + 512;
+}
+
+extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64_t* h_num_samples,
+                      const int64_t* h_start_indices, int64_t n, int64_t batch, int64_t* out_indices, void* ws,
+                      size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GR_REQUIRE(n >= 0 && batch >= 0 && n < (1ll << 31) - 1 && batch < (1 << 20), "bad sizes");
+  if (batch == 0 || n == 0) return GR_OK;
+  GR_REQUIRE(points && h_lengths && h_num_samples && out_indices, "null argument");
+  if (!ws || ws_bytes < gr_fps_workspace_bytes(n, batch)) {
+    set_error("fps workspace too small");
+    return GR_ERR_WORKSPACE;
+  }
+  std::vector<int32_t> off(batch + 1, 0), soff(batch + 1, 0), st(batch, 0);
+  int64_t nmax = 0;
+  for (int64_t b = 0; b < batch; ++b) {
+    GR_REQUIRE(h_lengths[b] >= 0 && h_num_samples[b] >= 0 && h_num_samples[b] <= h_lengths[b],
+               "cloud %lld: cannot draw %lld samples from %lld points", (long long)b, (long long)h_num_samples[b],
+               (long long)h_lengths[b]);
+    off[b + 1] = off[b] + (int32_t)h_lengths[b];
+    soff[b + 1] = soff[b] + (int32_t)h_num_samples[b];
+    st[b] = h_start_indices ? (int32_t)h_start_indices[b] : 0;
+    nmax = std::max(nmax, h_lengths[b]);
+  }
+  GR_REQUIRE(off[batch] == n, "lengths do not sum to n");
+  // G workgroups per cloud, all co-resident: G*batch <= 256 (one 1024-thread workgroup per CU)
+  int G = (int)std::min<int64_t>({(int64_t)FPS_GMAX, (nmax + 2047) / 2048, std::max<int64_t>(1, 256 / batch)});
+  G = std::max(G, 1);
+  const int64_t per = ((nmax + G - 1) / G + FPS_T - 1) / FPS_T;  // points per thread
+  Carver c(ws);
+  float* mind = c.take<float>(n);
+  int32_t* d_off = c.take<int32_t>(batch + 1);
+  int32_t* d_soff = c.take<int32_t>(batch + 1);
+  int32_t* d_st = c.take<int32_t>(batch + 1);
+  FpsCand* cand = c.take<FpsCand>((size_t)batch * 2 * FPS_GMAX);
+  unsigned* arrive = c.take<unsigned>(batch + 1);  // [batch] = error flag
+  GR_HIP(hipMemcpyAsync(d_off, off.data(), sizeof(int32_t) * (batch + 1), hipMemcpyHostToDevice, stream));
+  GR_HIP(hipMemcpyAsync(d_soff, soff.data(), sizeof(int32_t) * (batch + 1), hipMemcpyHostToDevice, stream));
+  GR_HIP(hipMemcpyAsync(d_st, st.data(), sizeof(int32_t) * batch, hipMemcpyHostToDevice, stream));
+  GR_HIP(hipMemsetAsync(arrive, 0, sizeof(unsigned) * (batch + 1), stream));
+  GR_HIP(hipMemsetAsync(cand, 0, sizeof(FpsCand) * (size_t)batch * 2 * FPS_GMAX, stream));
+  int* err = reinterpret_cast<int*>(arrive + batch);
+  {
+    KernelTimer timer("fps", stream);
+    const dim3 grid((unsigned)(batch * G)), block(FPS_T);
+#define GR_FPS_LAUNCH(PPT) \
+  hipLaunchKernelGGL(fps_kernel<PPT>, grid, block, 0, stream, points, d_off, d_soff, d_st, mind, cand, err, G, out_indices)
+    if (per <= 4) GR_FPS_LAUNCH(4);
+    else if (per <= 16) GR_FPS_LAUNCH(16);
+    else if (per <= 20) GR_FPS_LAUNCH(20);
+    else GR_FPS_LAUNCH(0);
+#undef GR_FPS_LAUNCH
+    GR_LAUNCH_CHECK();
+  }
+  int h_err = 0;
+  GR_HIP(hipMemcpyAsync(&h_err, err, sizeof(int), hipMemcpyDeviceToHost, stream));
+  GR_HIP(hipStreamSynchronize(stream));  // also keeps the host staging vectors alive past the copies
+  GR_REQUIRE(h_err == 0, "fps: inter-workgroup barrier timed out (GPU shared with another job?)");
+  return GR_OK;
+}

@@ -32,3 +32,24 @@ def registration_with_ransac_from_correspondences(src_points, ref_points, corres
                                           _lib.ptr(out), _lib.ptr(stats), _lib.ptr(ws), ws.numel(),
                                           _lib.stream_ptr(dev)))
     return (out, stats) if return_stats else out
+
+
+@torch.no_grad()
+def farthest_point_sampling(points, lengths, num_samples, start_indices=None):
+    """Exact FPS in stack mode (stand-in for fpsample.bucket_fps_kdline_sampling, demo.py:46; parity unpinned).
+    points (N,3); lengths / num_samples: per-cloud sizes (lists or 1-D tensors).  Returns a list of int64
+    CUDA tensors with LOCAL indices, one per cloud, in sampling order (first = start index, default 0)."""
+    dev = _lib.require_gpu()
+    L = _lib.lib()
+    p = torch.as_tensor(points, dtype=torch.float32)
+    p = (p if p.is_cuda else p.to(dev)).contiguous()
+    dev = p.device
+    lens = [int(x) for x in (lengths.tolist() if hasattr(lengths, "tolist") else lengths)]
+    ks = [int(x) for x in (num_samples.tolist() if hasattr(num_samples, "tolist") else num_samples)]
+    st = None if start_indices is None else _lib.host_i64([int(x) for x in start_indices])
+    out = torch.empty((sum(ks),), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        ws = _lib.workspace(dev, L.gr_fps_workspace_bytes(p.shape[0], len(lens)))
+        _lib.check(L.gr_fps(_lib.ptr(p), _lib.host_i64(lens), _lib.host_i64(ks), st, p.shape[0], len(lens), _lib.ptr(out),
+                            _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)))
+    return list(torch.split(out, ks))

@@ -231,6 +231,14 @@ int gr_ransac_similarity(const float* src_points, const float* ref_points, int64
                          int64_t num_hypotheses, uint32_t seed, float distance_threshold, int with_scaling,
                          int refine, float* out_transform, int32_t* out_stats, void* ws, size_t ws_bytes,
                          void* stream);
+/* gr_fps ("next" row; PARITY UNPINNED -- fpsample is not in the reference tree): exact farthest
+ * point sampling in stack mode, stands in for fpsample.bucket_fps_kdline_sampling (demo.py:46, test.py:46,
+ * dataset.py:127).  points (n,3) hold `batch` clouds (h_lengths); cloud b yields h_num_samples[b] LOCAL indices
+ * starting with h_start_indices[b] (null = 0), concatenated in out_indices (int64).  Synchronises. */
+size_t gr_fps_workspace_bytes(int64_t n, int64_t batch);
+int gr_fps(const float* points, const int64_t* h_lengths, const int64_t* h_num_samples,
+           const int64_t* h_start_indices, int64_t n, int64_t batch, int64_t* out_indices, void* ws,
+           size_t ws_bytes, void* stream);
 size_t gr_point_to_node_workspace_bytes(int64_t n, int64_t m);
 int gr_point_to_node_partition(const float* points, int64_t n, const float* nodes, int64_t m, int point_limit,
                                int64_t* point_to_node, uint8_t* node_masks, int64_t* node_knn_indices,

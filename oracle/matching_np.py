@@ -212,3 +212,16 @@ def local_global_registration(ref_knn_points, src_knn_points, ref_knn_masks, src
     for _ in range(num_refinement_steps - 1):
         T = weighted_procrustes(src, ref, sc * inl(T))
     return ref.astype(f32), src.astype(f32), sc, T.astype(f32)
+
+
+def farthest_point_sampling(points, k, start=0):
+    """Exact FPS, fp32 ((dx*dx + dy*dy) + dz*dz), first maximum on ties (contract of gr_fps; fpsample unpinned)."""
+    p = np.asarray(points, f32)
+    d = np.full(p.shape[0], np.inf, f32)
+    out = [int(start)]
+    for _ in range(1, k):
+        diff = p - p[out[-1]]
+        dd = (diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]) + diff[:, 2] * diff[:, 2]
+        d = np.minimum(d, dd)
+        out.append(int(np.argmax(d)))
+    return np.array(out, np.int64)

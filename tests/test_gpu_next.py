@@ -156,3 +156,31 @@ def test_ransac_hypotheses_match_host_replay():
         if n_in > best[0]:
             best = (n_in, h)
     assert int(stats[0]) == best[0]
+
+
+def test_fps_matches_oracle_and_batches():
+    from gaussreg_amd.registration import farthest_point_sampling
+    from oracle import matching_np as M
+    rng = np.random.default_rng(1)
+    a, b = rng.random((5000, 3)).astype(np.float32), (rng.random((3000, 3)) * [4, 3, 2.5]).astype(np.float32)
+    pts = np.concatenate([a, b])
+    got = farthest_point_sampling(_c(pts), [5000, 3000], [700, 300], start_indices=[0, 17])
+    assert np.array_equal(got[0].cpu().numpy(), M.farthest_point_sampling(a, 700, 0))
+    assert np.array_equal(got[1].cpu().numpy(), M.farthest_point_sampling(b, 300, 17))
+    assert len(set(got[0].cpu().numpy().tolist())) == 700   # distinct points
+
+
+@pytest.mark.parametrize("n,k,batch", [(200000, 1500, 1), (60000, 800, 3), (150000, 300, 40)])
+def test_fps_multi_workgroup_paths(n, k, batch):
+    """Register-resident split (PPT 4 / 16) and the streaming path, with and without the inter-workgroup barrier."""
+    from gaussreg_amd.registration import farthest_point_sampling
+    from oracle import matching_np as M
+    rng = np.random.default_rng(n)
+    lens = [n - 1000 * b for b in range(batch)] if batch <= 3 else [n // batch] * batch
+    pts = (rng.random((sum(lens), 3)) * [6, 5, 3]).astype(np.float32)
+    got = farthest_point_sampling(_c(pts), lens, [k] * len(lens), start_indices=[b for b in range(len(lens))])
+    o = 0
+    for b, L in enumerate(lens):
+        if b in (0, len(lens) - 1):
+            assert np.array_equal(got[b].cpu().numpy(), M.farthest_point_sampling(pts[o:o + L], k, b))
+        o += L
