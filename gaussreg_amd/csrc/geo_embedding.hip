@@ -1,0 +1,350 @@
+// GeometricStructureEmbedding forward ("next" row):
+//   geotransformer/modules/geotransformer/geotransformer.py:26-73   (indices + the two projections)
+//   geotransformer/modules/transformer/positional_embedding.py:8-34 (sinusoidal embedding)
+// The reference materialises, per cloud of N superpoints, d_indices (N,N), a_indices (N,N,k), two sinusoidal
+// embeddings (N,N,C) and (N,N,k,C), and runs 1+k Linear(C,C) layers over them: 2*(1+k)*N^2*C^2 flop
+// (308 GFLOP at N=767, C=256, k=3) and ~1.8 GB of temporaries.  Here one kernel per cloud produces the final
+// (N,N,C) tensor directly:
+//   * a workgroup owns 128 consecutive (n,m) pairs x 256 output channels;
+//   * per pair it computes the distance index and the k angular indices once (LDS),
+//   * the sinusoidal rows are generated on the fly, 16 K-values at a time, straight into the A tile of an
+//     fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32) whose B tile streams W_a / W_d out of L2, double-buffered;
+//   * the k angular GEMMs are reduced (max / mean) in registers, the distance GEMM is added, biases applied,
+//     and only the result is written: the output (N*N*C*4 B) is the only HBM traffic that scales with N^2.
+// Float op order differs from ATen (GEMM summation order), so parity is a tolerance (tests/test_gpu_next.py).
+#include "common.hpp"
+
+namespace gr {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GE_ROWS = 128;  // (n,m) pairs per workgroup
+constexpr int GE_COLS = 256;  // output channels per workgroup
+constexpr int GE_K = 16;      // K slab
+constexpr int GE_LD = GE_K + 1;
+constexpr int GE_T = 512;
+constexpr int GE_KMAX = 8;    // angle_k <= 8
+
+__device__ __forceinline__ float sq_dist_ref(const float3 a, float a2, const float3 b, float b2) {
+  // pairwise_distance.py:21-31: xy by matmul, then (x2 - 2 xy) + y2, clamped at 0
+  const float xy = fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x));
+  return fmaxf((a2 - 2.0f * xy) + b2, 0.0f);
+}
+__device__ __forceinline__ float3 ld3(const float* p, int i) { return make_float3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+__device__ __forceinline__ float norm2(const float3 a) { return (a.x * a.x + a.y * a.y) + a.z * a.z; }
+
+// k nearest other points per point: geotransformer.py:42 topk(k+1, largest=False)[1][:, :, 1:]
+// (ascending distance, the first -- the point itself -- dropped; ties: lowest index first).  One wave per point.
+__global__ __launch_bounds__(256) void geo_knn_kernel(const float* __restrict__ pts, int n, int k,
+                                                      int32_t* __restrict__ knn) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const float3 p = ld3(pts, row);
+  const float p2 = norm2(p);
+  unsigned long long best[GE_KMAX + 1];
+#pragma unroll
+  for (int i = 0; i <= GE_KMAX; ++i) best[i] = ~0ull;
+  for (int m = lane; m < n; m += 64) {
+    const float3 q = ld3(pts, m);
+    const float d = sqrtf(sq_dist_ref(p, p2, q, norm2(q)));
+    unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)m;
+#pragma unroll
+    for (int i = 0; i <= GE_KMAX; ++i) {  // sorted insertion (register-resident)
+      const unsigned long long lo = key < best[i] ? key : best[i];
+      key = key < best[i] ? best[i] : key;
+      best[i] = lo;
+    }
+  }
+  for (int s = 0; s <= k; ++s) {
+    unsigned long long v = best[0];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      const unsigned long long o = __shfl_xor(v, d, 64);
+      v = o < v ? o : v;
+    }
+    if (best[0] == v) {  // the owner pops (keys are unique: they carry the index)
+#pragma unroll
+      for (int i = 0; i < GE_KMAX; ++i) best[i] = best[i + 1];
+      best[GE_KMAX] = ~0ull;
+    }
+    if (s > 0 && lane == 0) knn[row * k + (s - 1)] = v == ~0ull ? row : (int)(unsigned)(v & 0xffffffffull);
+  }
+}
+
+__global__ __launch_bounds__(GE_T) void geo_embedding_kernel(
+    const float* __restrict__ pts, int n, const int32_t* __restrict__ knn, int k, const float* __restrict__ w_d,
+    const float* __restrict__ b_d, const float* __restrict__ w_a, const float* __restrict__ b_a,
+    const float* __restrict__ div_term, int C, float sigma_d, float factor_a, int mean, float* __restrict__ out) {
+  __shared__ float sa[2][GE_ROWS][GE_LD];
+  __shared__ float sb[2][GE_COLS][GE_LD];
+  __shared__ float xs[GE_KMAX + 1][GE_ROWS];  // [0..k-1] angular indices, [k] distance index
+  const int64_t total = (int64_t)n * n;
+  const int64_t r0 = (int64_t)blockIdx.x * GE_ROWS;
+  const int j0 = blockIdx.y * GE_COLS;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wi = (w >> 2) * 64, wj = (w & 3) * 64;
+
+  // ---- per-pair indices (geotransformer.py:38-55)
+  if (tid < GE_ROWS) {
+    const int64_t r = r0 + tid;
+    float xd = 0.f, xa[GE_KMAX];
+#pragma unroll
+    for (int i = 0; i < GE_KMAX; ++i) xa[i] = 0.f;
+    if (r < total) {
+      const int a = (int)(r / n), b = (int)(r - (int64_t)a * n);
+      const float3 pa = ld3(pts, a), pb = ld3(pts, b);
+      xd = sqrtf(sq_dist_ref(pa, norm2(pa), pb, norm2(pb))) / sigma_d;
+      const float3 anc = make_float3(pb.x - pa.x, pb.y - pa.y, pb.z - pa.z);
+#pragma unroll
+      for (int i = 0; i < GE_KMAX; ++i)
+        if (i < k) {
+          const float3 pk = ld3(pts, knn[a * k + i]);
+          const float3 ref = make_float3(pk.x - pa.x, pk.y - pa.y, pk.z - pa.z);
+          const float3 cr = make_float3(ref.y * anc.z - ref.z * anc.y, ref.z * anc.x - ref.x * anc.z,
+                                        ref.x * anc.y - ref.y * anc.x);
+          const float sn = sqrtf(norm2(cr));
+          // torch.sum accumulates from +0: an all-(-0) product row (a == b, anc = +0) must give +0, not -0 (atan2 -> pi)
+          const float cs = ((0.0f + ref.x * anc.x) + ref.y * anc.y) + ref.z * anc.z;
+          xa[i] = atan2f(sn, cs) * factor_a;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < GE_KMAX; ++i)
+      if (i < k) xs[i][tid] = xa[i];
+    xs[k][tid] = xd;
+  }
+  __syncthreads();
+
+  f32x16 acc[2][2], red[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f, red[a][b][r] = 0.f;
+
+  // staging registers: A = 128 rows x 8 frequencies (sin, cos) -> 2 per thread; B = 256 cols x 16 k -> 8 per thread
+  float ra_s[2], ra_c[2], rb[8];
+  const int slabs = C / GE_K;  // C % 16 == 0 (checked by the host)
+  auto gen = [&](int phase, int k0) {
+    const float* W = phase < k ? w_a : w_d;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + u * GE_T;
+      const int r = e >> 3, f = e & 7;
+      const float omega = xs[phase][r] * div_term[(k0 >> 1) + f];  // positional_embedding.py:27
+      sincosf(omega, &ra_s[u], &ra_c[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = tid + u * GE_T;
+      const int j = e >> 4, kk = e & 15;
+      const int gj = j0 + j;
+      rb[u] = gj < C ? W[(int64_t)gj * C + k0 + kk] : 0.f;  // nn.Linear: y = x W^T
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + u * GE_T;
+      const int r = e >> 3, f = e & 7;
+      sa[buf][r][2 * f] = ra_s[u];  // positional_embedding.py:30-31: (sin, cos) interleaved
+      sa[buf][r][2 * f + 1] = ra_c[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = tid + u * GE_T;
+      sb[buf][e >> 4][e & 15] = rb[u];
+    }
+  };
+
+  const int steps = (k + 1) * slabs;
+  gen(0, 0);
+  store(0);
+  __syncthreads();
+  int buf = 0;
+  for (int s = 0; s < steps; ++s) {
+    const int phase = s / slabs;
+    const bool more = s + 1 < steps;
+    if (more) gen((s + 1) / slabs, ((s + 1) % slabs) * GE_K);  // overlaps the MFMAs below
+#pragma unroll
+    for (int kk2 = 0; kk2 < GE_K; kk2 += 2) {
+      const int kk = kk2 + (lane >> 5);
+      const float a0 = sa[buf][wi + (lane & 31)][kk], a1 = sa[buf][wi + 32 + (lane & 31)][kk];
+      const float b0 = sb[buf][wj + (lane & 31)][kk], b1 = sb[buf][wj + 32 + (lane & 31)][kk];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if ((s + 1) % slabs == 0 && phase < k) {
+      // one angular projection finished: fold it into the reduction over the k neighbours (geotransformer.py:65-68)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[a][b][r];
+            red[a][b][r] = phase == 0 ? v : (mean ? red[a][b][r] + v : fmaxf(red[a][b][r], v));
+            acc[a][b][r] = 0.f;
+          }
+    }
+    if (more) {
+      store(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+  // ---- epilogue: (proj_d + b_d) + reduce_k(proj_a + b_a)
+  const float inv_k = k > 0 ? 1.0f / (float)k : 0.f;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int gj = j0 + wj + b * 32 + (lane & 31);
+      if (gj >= C) continue;
+      const float bd = b_d[gj], ba = k > 0 ? b_a[gj] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t gi = r0 + wi + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (gi < total) {
+          const float av = k > 0 ? (mean ? (red[a][b][r] + (float)k * ba) * inv_k : red[a][b][r] + ba) : 0.f;
+          out[gi * C + gj] = (acc[a][b][r] + bd) + av;
+        }
+      }
+    }
+}
+
+}  // namespace
+}  // namespace gr
+
+using namespace gr;
+
+extern "C" size_t gr_geo_embedding_workspace_bytes(int64_t n, int64_t angle_k) {
+  if (n < 0 || angle_k < 0) return 0;
+  return align_up((size_t)n * (size_t)std::max<int64_t>(angle_k, 1) * 4, 256) + 256;
+}
+
+extern "C" int gr_geo_embedding(const float* points, int64_t n, const float* w_d, const float* b_d, const float* w_a,
+                                const float* b_a, const float* div_term, int64_t c, float sigma_d, float factor_a,
+                                int64_t angle_k, int reduction_mean, float* out, void* ws, size_t ws_bytes,
+                                void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GR_REQUIRE(n >= 0 && n < 46341, "geo_embedding: n*n must fit int32 pair ids per row (n=%lld)", (long long)n);
+  GR_REQUIRE(c > 0 && c % GE_K == 0, "geo_embedding: hidden_dim must be a positive multiple of 16 (got %lld)", (long long)c);
+  GR_REQUIRE(angle_k >= 0 && angle_k <= GE_KMAX, "geo_embedding: angle_k must be in [0, %d]", GE_KMAX);
+  GR_REQUIRE(angle_k < n || n == 0, "geo_embedding: angle_k (%lld) needs more than %lld points", (long long)angle_k, (long long)n);
+  if (n == 0) return GR_OK;
+  GR_REQUIRE(points && w_d && b_d && div_term && out && (angle_k == 0 || (w_a && b_a)), "null argument");
+  if (!ws || ws_bytes < gr_geo_embedding_workspace_bytes(n, angle_k)) {
+    set_error("geo_embedding workspace too small");
+    return GR_ERR_WORKSPACE;
+  }
+  Carver cv(ws);
+  int32_t* knn = cv.take<int32_t>((size_t)n * std::max<int64_t>(angle_k, 1));
+  if (angle_k > 0)
+    hipLaunchKernelGGL(geo_knn_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, points, (int)n, (int)angle_k, knn);
+  {
+    KernelTimer timer("geo_embedding", stream);
+    const dim3 grid((unsigned)((n * n + GE_ROWS - 1) / GE_ROWS), (unsigned)((c + GE_COLS - 1) / GE_COLS));
+    hipLaunchKernelGGL(geo_embedding_kernel, grid, dim3(GE_T), 0, stream, points, (int)n, knn, (int)angle_k, w_d, b_d,
+                       w_a, b_a, div_term, (int)c, sigma_d, factor_a, reduction_mean, out);
+  }
+  GR_LAUNCH_CHECK();
+  return GR_OK;
+}
+
+// ---------------------------------------------------------------- RPE attention: positional score term
+// rpe_transformer.py:55-57 projects the whole (N,M,C) embedding through proj_p in EVERY attention layer
+// (2*N*M*C^2 flop = 77 GFLOP at N=M=767, C=256, plus a 602 MB temporary) and then contracts it with q:
+//     s_p[h,n,m] = sum_c q[h,n,c] * (W_p emb[n,m] + b_p)[h*ch + c]
+// The sum is linear in emb, so it is re-associated as   s_p[h,n,m] = emb[n,m,:] . u[n,h,:] + q[h,n,:].b_p[h]
+// with u[n,h,:] = W_p[h-block]^T q[h,n,:] (a tiny GEMM done by the caller): one pass over the embedding, memory-bound.
+// Workgroup = one query row n, 4 waves; 16 lanes share one (n,m) row (float4 loads, 256 B per 16 lanes).
+namespace gr {
+namespace {
+
+template <int H, int CV>  // CV = C / 64 (float4 chunks per lane)
+__global__ __launch_bounds__(256) void rpe_scores_kernel(const float* __restrict__ emb, const float* __restrict__ u,
+                                                         const float* __restrict__ add, int n_rows, int m_cols,
+                                                         float* __restrict__ out) {
+  constexpr int C = CV * 64;
+  const int n = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, sub = lane & 15, grp = lane >> 4;
+  float4 ur[H][CV];
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int i = 0; i < CV; ++i)
+      ur[h][i] = *reinterpret_cast<const float4*>(u + ((int64_t)n * H + h) * C + i * 64 + sub * 4);
+  float bias[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) bias[h] = add ? add[n * H + h] : 0.f;
+  const int m_lo = blockIdx.y * 256;
+  const int m_hi = min(m_lo + 256, m_cols);
+  for (int m = m_lo + w * 4 + grp; m < m_hi; m += 16) {  // the 16 lanes of a row enter and leave together
+    const bool live = true;
+    const float* row = emb + ((int64_t)n * m_cols + m) * C + sub * 4;
+    float4 e[CV];
+#pragma unroll
+    for (int i = 0; i < CV; ++i) e[i] = *reinterpret_cast<const float4*>(row + i * 64);
+    float acc[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < CV; ++i) {
+        a = fmaf(e[i].x, ur[h][i].x, a);
+        a = fmaf(e[i].y, ur[h][i].y, a);
+        a = fmaf(e[i].z, ur[h][i].z, a);
+        a = fmaf(e[i].w, ur[h][i].w, a);
+      }
+      acc[h] = a;
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+#pragma unroll
+      for (int d = 8; d > 0; d >>= 1) acc[h] += __shfl_xor(acc[h], d, 64);
+    }
+    if (live && sub < H) {
+      float v = acc[0];
+#pragma unroll
+      for (int h = 1; h < H; ++h) v = sub == h ? acc[h] : v;
+      float bv = bias[0];
+#pragma unroll
+      for (int h = 1; h < H; ++h) bv = sub == h ? bias[h] : bv;
+      out[((int64_t)sub * n_rows + n) * m_cols + m] = v + bv;
+    }
+  }
+}
+
+}  // namespace
+}  // namespace gr
+
+extern "C" int gr_rpe_scores(const float* embed, const float* u, const float* add, int64_t n, int64_t m, int64_t c,
+                             int64_t heads, float* out, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GR_REQUIRE(n >= 0 && m >= 0 && n < (1 << 24) && m < (1 << 24), "rpe_scores: bad sizes");
+  GR_REQUIRE((c == 64 || c == 128 || c == 256) && (heads == 1 || heads == 2 || heads == 4 || heads == 8),
+             "rpe_scores: d_model must be 64/128/256 and num_heads 1/2/4/8 (got %lld, %lld)", (long long)c, (long long)heads);
+  if (n == 0 || m == 0) return GR_OK;
+  GR_REQUIRE(embed && u && out, "null argument");
+  const dim3 grid((unsigned)n, (unsigned)((m + 255) / 256));
+  KernelTimer timer("rpe_scores", stream);
+#define GR_RPE(H, CV)                                                                                          \
+  hipLaunchKernelGGL((rpe_scores_kernel<H, CV>), grid, dim3(256), 0, stream, embed, u, add, (int)n, (int)m, out)
+#define GR_RPE_H(CV)          \
+  switch (heads) {            \
+    case 1: GR_RPE(1, CV); break; \
+    case 2: GR_RPE(2, CV); break; \
+    case 4: GR_RPE(4, CV); break; \
+    default: GR_RPE(8, CV); break; \
+  }
+  if (c == 64) { GR_RPE_H(1) } else if (c == 128) { GR_RPE_H(2) } else { GR_RPE_H(4) }
+#undef GR_RPE_H
+#undef GR_RPE
+  GR_LAUNCH_CHECK();
+  return GR_OK;
+}

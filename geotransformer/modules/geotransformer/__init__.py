@@ -1,1 +1,2 @@
+from gaussreg_amd.embedding import GeometricStructureEmbedding  # noqa: F401
 from gaussreg_amd.matching import LocalGlobalRegistration, PointMatching, SuperPointMatching  # noqa: F401

@@ -1,0 +1,2 @@
+from gaussreg_amd.embedding import SinusoidalPositionalEmbedding  # noqa: F401
+from gaussreg_amd.rpe_attention import RPEMultiHeadAttention  # noqa: F401

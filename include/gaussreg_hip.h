@@ -235,6 +235,21 @@ int gr_ransac_similarity(const float* src_points, const float* ref_points, int64
  * point sampling in stack mode, stands in for fpsample.bucket_fps_kdline_sampling (demo.py:46, test.py:46,
  * dataset.py:127).  points (n,3) hold `batch` clouds (h_lengths); cloud b yields h_num_samples[b] LOCAL indices
  * starting with h_start_indices[b] (null = 0), concatenated in out_indices (int64).  Synchronises. */
+/* gr_geo_embedding ("next" row): GeometricStructureEmbedding.forward for one cloud
+ * (geotransformer/modules/geotransformer/geotransformer.py:26-73 + transformer/positional_embedding.py:8-34):
+ * out (n,n,c) = proj_d(sinemb(|p_a-p_b| / sigma_d)) + reduce_k proj_a(sinemb(angle(p_knn(a,k)-p_a, p_b-p_a) * factor_a)).
+ * w_d, w_a: (c,c) nn.Linear weights (row = output channel); b_d, b_a: (c); div_term: (c/2) buffer of the sinusoidal
+ * embedding; reduction_mean: 0 = 'max', 1 = 'mean'; angle_k <= 8; c % 16 == 0.  Asynchronous on `stream`. */
+size_t gr_geo_embedding_workspace_bytes(int64_t n, int64_t angle_k);
+int gr_geo_embedding(const float* points, int64_t n, const float* w_d, const float* b_d, const float* w_a,
+                     const float* b_a, const float* div_term, int64_t c, float sigma_d, float factor_a,
+                     int64_t angle_k, int reduction_mean, float* out, void* ws, size_t ws_bytes, void* stream);
+/* gr_rpe_scores: positional score term of RPEMultiHeadAttention (geotransformer/modules/transformer/
+ * rpe_transformer.py:55-57) re-associated so the (N,M,C) embedding is read once and never projected:
+ * out[h][n][m] = sum_j embed[n][m][j] * u[n][h][j] + add[n][h], with u = q W_p (per head) and add = q . b_p computed
+ * by the caller.  embed (n,m,c), u (n,heads,c), add (n,heads) or null, out (heads,n,m).  c in {64,128,256}. */
+int gr_rpe_scores(const float* embed, const float* u, const float* add, int64_t n, int64_t m, int64_t c,
+                  int64_t heads, float* out, void* stream);
 size_t gr_fps_workspace_bytes(int64_t n, int64_t batch);
 int gr_fps(const float* points, const int64_t* h_lengths, const int64_t* h_num_samples,
            const int64_t* h_start_indices, int64_t n, int64_t batch, int64_t* out_indices, void* ws,

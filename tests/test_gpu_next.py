@@ -184,3 +184,58 @@ def test_fps_multi_workgroup_paths(n, k, batch):
         if b in (0, len(lens) - 1):
             assert np.array_equal(got[b].cpu().numpy(), M.farthest_point_sampling(pts[o:o + L], k, b))
         o += L
+
+
+# ---------------------------------------------------------------- RPE rows (geo embedding, attention score term)
+def _gse(g, tag):
+    from gaussreg_amd.embedding import GeometricStructureEmbedding
+    c, k, mean = (int(x) for x in g[f"gse_{tag}_cfg"])
+    m = GeometricStructureEmbedding(c, 0.2, 15, k, reduction_a="mean" if mean else "max")
+    m.load_state_dict({"embedding.div_term": torch.from_numpy(g[f"gse_{tag}_div"]),
+                       "proj_d.weight": torch.from_numpy(g[f"gse_{tag}_w_d"]), "proj_d.bias": torch.from_numpy(g[f"gse_{tag}_b_d"]),
+                       "proj_a.weight": torch.from_numpy(g[f"gse_{tag}_w_a"]), "proj_a.bias": torch.from_numpy(g[f"gse_{tag}_b_a"])})
+    return m.cuda()
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_geo_embedding_matches_reference_golden(tag):
+    g = load_golden("rpe.npz")
+    out = _gse(g, tag)(_c(g[f"gse_{tag}_points"])).cpu().numpy()
+    ref = g[f"gse_{tag}_out"]
+    n = ref.shape[1]
+    off = ~np.eye(n, dtype=bool)
+    # float tolerance (GEMM summation order, sincos): 2e-5 abs on values of magnitude ~2.  The diagonal (a == b) is
+    # rounding noise of x2 - 2xy + y2 in the reference itself (d index ~1e-3 instead of 0): looser there.
+    np.testing.assert_allclose(out[0][off], ref[0][off], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(out[0][~off], ref[0][~off], rtol=0, atol=2e-2)
+
+
+def test_geo_embedding_demo_shape_vs_oracle():
+    from gaussreg_amd.embedding import GeometricStructureEmbedding
+    from oracle import rpe_np as R
+    torch.manual_seed(3)
+    n = 300                                     # (N, N, 256) rows cross several workgroup / n boundaries
+    m = GeometricStructureEmbedding(256, 0.2, 15, 3).cuda()
+    pts = torch.rand(1, n, 3) * torch.tensor([6.0, 5.0, 3.0])
+    out = m(pts.cuda())[0].cpu().numpy()
+    ref = R.geometric_structure_embedding(pts[0].numpy(), m.proj_d.weight.detach().cpu().numpy(), m.proj_d.bias.detach().cpu().numpy(),
+                                          m.proj_a.weight.detach().cpu().numpy(), m.proj_a.bias.detach().cpu().numpy(),
+                                          m.embedding.div_term.cpu().numpy(), 0.2, 15, 3)
+    off = ~np.eye(n, dtype=bool)
+    np.testing.assert_allclose(out[off], ref[off], rtol=5e-5, atol=5e-5)
+
+
+def test_rpe_attention_matches_reference_golden():
+    from gaussreg_amd.rpe_attention import RPEMultiHeadAttention
+    g = load_golden("rpe.npz")
+    c, h = (int(x) for x in g["rpe_cfg"])
+    att = RPEMultiHeadAttention(c, h)
+    att.load_state_dict({k[len("rpe_sd_"):].replace("__", "."): torch.from_numpy(v) for k, v in g.items() if k.startswith("rpe_sd_")})
+    att = att.cuda()
+    q, k, e = _c(g["rpe_q"]), _c(g["rpe_k"]), _c(g["rpe_emb"])
+    hid, sc = att(q, k, k, e)
+    np.testing.assert_allclose(hid.cpu().numpy(), g["rpe_h0"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(sc.cpu().numpy(), g["rpe_s0"], rtol=1e-4, atol=2e-6)
+    hid, sc = att(q, k, k, e, key_weights=_c(g["rpe_weights"]), key_masks=_c(g["rpe_masks"]), attention_factors=_c(g["rpe_factors"]))
+    np.testing.assert_allclose(hid.cpu().numpy(), g["rpe_h1"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(sc.cpu().numpy(), g["rpe_s1"], rtol=1e-4, atol=2e-6)

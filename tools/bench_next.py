@@ -72,3 +72,25 @@ def kp_torch():
     o = (torch.matmul(w, nf).permute(1, 0, 2) @ conv.weights).sum(0)
     num = (nf.sum(-1) > 0).sum(-1).clamp(min=1); return o / num[:, None]
 print(f"KPConv 28020 pts, H=43, 256->256: HIP {timeit(lambda: conv(f, spt, spt, nb), 10):.3f} ms  torch {timeit(kp_torch, 5):.3f} ms")
+# ---- GeometricStructureEmbedding N = 767, C = 256, k = 3 (demo superpoint count)
+from gaussreg_amd.embedding import GeometricStructureEmbedding
+from gaussreg_amd.rpe_attention import RPEMultiHeadAttention
+N, C = 767, 256
+gse = GeometricStructureEmbedding(C, 0.2, 15, 3).cuda(); pc = torch.rand(1, N, 3, device="cuda", generator=g) * 5
+def gse_torch():  # geotransformer.py:26-73 with stock ops
+    p = pc; xy = p @ p.transpose(1, 2); x2 = (p ** 2).sum(-1)
+    dist = (x2[:, :, None] - 2 * xy + x2[:, None, :]).clamp(min=0).sqrt(); d_idx = dist / 0.2
+    knn = dist.topk(4, dim=2, largest=False)[1][:, :, 1:]
+    kp_ = p[0][knn[0]][None]; ref = kp_ - p[:, :, None]; anc = p[:, None] - p[:, :, None]
+    ref = ref[:, :, None].expand(1, N, N, 3, 3); anc = anc[:, :, :, None].expand(1, N, N, 3, 3)
+    a_idx = torch.atan2(torch.linalg.norm(torch.cross(ref, anc, dim=-1), dim=-1), (ref * anc).sum(-1)) * gse.factor_a
+    return gse.proj_d(gse.embedding(d_idx)) + gse.proj_a(gse.embedding(a_idx)).max(dim=3)[0]
+with torch.no_grad():
+    print(f"GeometricStructureEmbedding N=767 C=256 k=3: HIP {timeit(lambda: gse(pc), 5):.3f} ms  torch {timeit(gse_torch, 3):.3f} ms")
+    emb = gse(pc); att = RPEMultiHeadAttention(C, 4).cuda(); x = R(1, N, C)
+    def att_torch():  # rpe_transformer.py:51-72 as written
+        q = att.proj_q(x).view(1, N, 4, 64).permute(0, 2, 1, 3); k = att.proj_k(x).view(1, N, 4, 64).permute(0, 2, 1, 3)
+        v = att.proj_v(x).view(1, N, 4, 64).permute(0, 2, 1, 3); p = att.proj_p(emb).view(1, N, N, 4, 64).permute(0, 3, 1, 2, 4)
+        s = (torch.einsum('bhnc,bhnmc->bhnm', q, p) + torch.einsum('bhnc,bhmc->bhnm', q, k)) / 8.0
+        s = torch.softmax(s, -1); return torch.matmul(s, v)
+    print(f"RPEMultiHeadAttention N=767 C=256 H=4: HIP+torch {timeit(lambda: att(x, x, x, emb), 5):.3f} ms  torch {timeit(att_torch, 3):.3f} ms")
