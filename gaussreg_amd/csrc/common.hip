@@ -82,9 +82,16 @@ __global__ __launch_bounds__(SCAN_T) void scan_tiles_kernel(const int32_t* __res
                                                             int32_t* __restrict__ out, int64_t n,
                                                             int64_t row_stride,
                                                             int32_t* __restrict__ partial,
-                                                            int tiles) {
+                                                            int tiles, const int32_t* __restrict__ last_dev) {
   const int row = blockIdx.y;
   const int64_t tile0 = (int64_t)blockIdx.x * SCAN_TILE;
+  if (last_dev) {  // only entries 0..*last_dev are wanted (the array is sized for a worst case)
+    n = min(n, (int64_t)*last_dev + 1);
+    if (tile0 >= n) {
+      if (threadIdx.x == 0) partial[(int64_t)row * tiles + blockIdx.x] = 0;
+      return;
+    }
+  }
   const int32_t* src = in + row * row_stride;
   int32_t* dst = out + row * row_stride;
   int v[SCAN_ITEMS];
@@ -126,8 +133,12 @@ __global__ __launch_bounds__(SCAN_T) void scan_partials_kernel(int32_t* __restri
 __global__ __launch_bounds__(SCAN_T) void scan_add_kernel(int32_t* __restrict__ out, int64_t n,
                                                           int64_t row_stride,
                                                           const int32_t* __restrict__ partial,
-                                                          int tiles) {
+                                                          int tiles, const int32_t* __restrict__ last_dev) {
   const int row = blockIdx.y;
+  if (last_dev) {
+    n = min(n, (int64_t)*last_dev + 1);
+    if ((int64_t)blockIdx.x * SCAN_TILE >= n) return;
+  }
   const int add = partial[(int64_t)row * tiles + blockIdx.x];
   if (add == 0) return;
   int32_t* dst = out + row * row_stride;
@@ -212,16 +223,16 @@ int compute_bbox(const float* pts, const int32_t* h_off, int32_t* blk, const int
 size_t scan_ws_ints(int64_t n) { return (size_t)((n + SCAN_TILE - 1) / SCAN_TILE) + 1; }
 
 int exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int rows, int64_t row_stride,
-                       int32_t* scan_ws, int32_t* total, hipStream_t stream) {
+                       int32_t* scan_ws, int32_t* total, hipStream_t stream, const int32_t* last_dev) {
   if (n <= 0 || rows <= 0) return GR_OK;
   const int tiles = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
   hipLaunchKernelGGL(scan_tiles_kernel, dim3(tiles, rows), dim3(SCAN_T), 0, stream, in, out, n,
-                     row_stride, scan_ws, tiles);
+                     row_stride, scan_ws, tiles, last_dev);
   hipLaunchKernelGGL(scan_partials_kernel, dim3(rows), dim3(SCAN_T), 0, stream, scan_ws, tiles,
                      total);
   if (tiles > 1)
     hipLaunchKernelGGL(scan_add_kernel, dim3(tiles, rows), dim3(SCAN_T), 0, stream, out, n,
-                       row_stride, scan_ws, tiles);
+                       row_stride, scan_ws, tiles, last_dev);
   GR_LAUNCH_CHECK();
   return GR_OK;
 }

@@ -76,8 +76,10 @@ __host__ __device__ inline float ord2f(uint32_t o) {
 // scan_ws needs scan_ws_ints(n) int32 per row.
 size_t scan_ws_ints(int64_t n);
 // in/out may alias.  out[i] = sum_{j<i} in[j]; total[r] (optional, device) = row sum.
+// last_dev (optional, device): only out[0..*last_dev] is needed -- tiles past it are skipped (arrays sized for a
+// worst case whose real extent is only known on the device).
 int exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int rows, int64_t row_stride,
-                       int32_t* scan_ws, int32_t* total, hipStream_t stream);
+                       int32_t* scan_ws, int32_t* total, hipStream_t stream, const int32_t* last_dev = nullptr);
 
 // Per-cloud bounding boxes of stacked points: bbox_dev[b*6 + {0,1,2}] = min xyz, +{3,4,5} = max xyz,
 // stored as order-preserving uints (decode with ord2f).  Empty clouds keep (0xffffffff, 0).

@@ -50,6 +50,8 @@ struct RadiusWs {
   BatchGrid* grids;
   int32_t* s_cell;
   int32_t* q_cell;
+  int32_t* s_rank;  // arrival order of a point inside its cell (from the histogram atomics)
+  int32_t* q_rank;
   int32_t* cnt;    // [2][ccap+1]
   int32_t* start;  // [2][ccap+1]
   int32_t* scan_ws;
@@ -75,6 +77,8 @@ RadiusWs carve(void* ws, int64_t nq, int64_t ns, int64_t batch) {
   w.grids = c.take<BatchGrid>(batch);
   w.s_cell = c.take<int32_t>(ns);
   w.q_cell = c.take<int32_t>(nq);
+  w.s_rank = c.take<int32_t>(ns);
+  w.q_rank = c.take<int32_t>(nq);
   w.cnt = c.take<int32_t>(2 * (w.ccap + 1));
   w.start = c.take<int32_t>(2 * (w.ccap + 1));
   w.scan_ws = c.take<int32_t>(2 * scan_ws_ints(w.ccap + 1));
@@ -168,19 +172,20 @@ __global__ __launch_bounds__(256) void bin_count_kernel(
     const float* __restrict__ s, int ns, const float* __restrict__ q, int nq,
     const int32_t* __restrict__ s_off, const int32_t* __restrict__ q_off, int nb,
     const BatchGrid* __restrict__ grids, int32_t* __restrict__ s_cell, int32_t* __restrict__ q_cell,
-    int32_t* __restrict__ cnt_s, int32_t* __restrict__ cnt_q) {
+    int32_t* __restrict__ s_rank, int32_t* __restrict__ q_rank, int32_t* __restrict__ cnt_s,
+    int32_t* __restrict__ cnt_q) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < ns) {
     const int b = find_batch(s_off, nb, i);
     const int c = clamped_cell(grids[b], s[3 * (int64_t)i], s[3 * (int64_t)i + 1], s[3 * (int64_t)i + 2]);
     s_cell[i] = c;
-    atomicAdd(&cnt_s[c], 1);
+    s_rank[i] = atomicAdd(&cnt_s[c], 1);  // the returned count doubles as the slot inside the cell
   } else if (i < ns + nq) {
     const int j = i - ns;
     const int b = find_batch(q_off, nb, j);
     const int c = clamped_cell(grids[b], q[3 * (int64_t)j], q[3 * (int64_t)j + 1], q[3 * (int64_t)j + 2]);
     q_cell[j] = c;
-    atomicAdd(&cnt_q[c], 1);
+    q_rank[j] = atomicAdd(&cnt_q[c], 1);
   }
 }
 
@@ -188,18 +193,18 @@ __global__ __launch_bounds__(256) void scatter_kernel(
     const float* __restrict__ s, int ns, const float* __restrict__ q, int nq,
     const int32_t* __restrict__ s_cell, const int32_t* __restrict__ q_cell,
     const int32_t* __restrict__ start_s, const int32_t* __restrict__ start_q,
-    int32_t* __restrict__ cnt_s, int32_t* __restrict__ cnt_q, float4* __restrict__ sorted_s,
+    const int32_t* __restrict__ s_rank, const int32_t* __restrict__ q_rank, float4* __restrict__ sorted_s,
     float4* __restrict__ sorted_q) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < ns) {
     const int c = s_cell[i];
-    const int slot = start_s[c] + atomicSub(&cnt_s[c], 1) - 1;
+    const int slot = start_s[c] + s_rank[i];
     sorted_s[slot] = make_float4(s[3 * (int64_t)i], s[3 * (int64_t)i + 1], s[3 * (int64_t)i + 2],
                                  __int_as_float(i));
   } else if (i < ns + nq) {
     const int j = i - ns;
     const int c = q_cell[j];
-    const int slot = start_q[c] + atomicSub(&cnt_q[c], 1) - 1;
+    const int slot = start_q[c] + q_rank[j];
     sorted_q[slot] = make_float4(q[3 * (int64_t)j], q[3 * (int64_t)j + 1], q[3 * (int64_t)j + 2],
                                  __int_as_float(j));
   }
@@ -221,6 +226,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(
 //               slot out[query][rank]; padding is written one row per wave.
 constexpr int NBAND = 9;
 constexpr int NSUB = 3;  // threads per query (one per z-slab)
+constexpr int GB = 4;    // hit loads in flight per thread in the FILL gather
 
 template <int RQ>
 struct TravLds {
@@ -239,7 +245,7 @@ struct TravLds {
 };
 
 template <int RQ, bool FILL, bool HITS_IN_LDS>
-__global__ __launch_bounds__(NSUB* RQ) void traverse_kernel(
+__global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))) void traverse_kernel(
     const float4* __restrict__ sorted_q, int nq, const int32_t* __restrict__ q_off, int nb,
     const BatchGrid* __restrict__ grids, const int32_t* __restrict__ start_s,
     const float4* __restrict__ sorted_s, float r2, int32_t* __restrict__ q_cnt, int2* __restrict__ q_rng,
@@ -464,9 +470,9 @@ __global__ __launch_bounds__(NSUB* RQ) void traverse_kernel(
     if (len0 + len1 + len2 <= 64) {
       unsigned long long bits = q_mask[(int64_t)j * nq + t];
       while (bits) {
-        int pos[8];
+        int pos[GB];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < GB; ++u) {
           pos[u] = -1;
           if (bits) {
             const int bpos = __ffsll((long long)bits) - 1;
@@ -475,12 +481,12 @@ __global__ __launch_bounds__(NSUB* RQ) void traverse_kernel(
             pos[u] = bpos < len0 ? p0[0] + bpos : (bpos < len0 + len1 ? p0[1] + (bpos - len0) : p0[2] + (bpos - len0 - len1));
           }
         }
-        float4 sp[8];
+        float4 sp[GB];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < GB; ++u)
           if (pos[u] >= 0) sp[u] = sorted_s[pos[u]];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < GB; ++u)
           if (pos[u] >= 0) emit(sp[u]);
       }
     } else {
@@ -696,12 +702,13 @@ extern "C" int gr_radius_count(const float* q, const float* s, const int64_t* h_
   int32_t* start_q = same ? w.start : w.start + (w.ccap + 1);
   const int nq_bin = same ? 0 : (int)nq;
   hipLaunchKernelGGL(bin_count_kernel, dim3((ns + nq_bin + 255) / 256), dim3(256), 0, stream, s, (int)ns, q, nq_bin,
-                     w.s_off, w.q_off, nb, w.grids, w.s_cell, w.q_cell, cnt_s, cnt_q);
+                     w.s_off, w.q_off, nb, w.grids, w.s_cell, w.q_cell, w.s_rank, w.q_rank, cnt_s, cnt_q);
   GR_LAUNCH_CHECK();
-  int rc = exclusive_scan_i32(w.cnt, w.start, w.ccap + 1, rows, w.ccap + 1, w.scan_ws, nullptr, stream);
+  int rc = exclusive_scan_i32(w.cnt, w.start, w.ccap + 1, rows, w.ccap + 1, w.scan_ws, nullptr, stream,
+                              &w.hdr->total_cells);
   if (rc != GR_OK) return rc;
   hipLaunchKernelGGL(scatter_kernel, dim3((ns + nq_bin + 255) / 256), dim3(256), 0, stream, s, (int)ns, q, nq_bin,
-                     w.s_cell, w.q_cell, start_s, start_q, cnt_s, cnt_q, w.sorted_s, w.sorted_q);
+                     w.s_cell, w.q_cell, start_s, start_q, w.s_rank, w.q_rank, w.sorted_s, w.sorted_q);
   const float4* sorted_q = same ? w.sorted_s : w.sorted_q;
   const float r2 = radius * radius;  // radius_neighbors_cpu.cpp:12 (fp32 product)
   rc = launch_count<RT>(w, sorted_q, nq, nb, start_s, r2, stream);
