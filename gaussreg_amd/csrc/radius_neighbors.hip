@@ -224,6 +224,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(
 //               phase B gives each hit one thread, ranks it inside its segment (branch-free
 //               counting; segment reads are LDS broadcasts) and stores it straight to its final
 //               slot out[query][rank]; padding is written one row per wave.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int NBAND = 9;
 constexpr int NSUB = 3;  // threads per query (one per z-slab)
 constexpr int GB = 4;    // hit loads in flight per thread in the FILL gather
@@ -231,13 +232,13 @@ constexpr int GB = 4;    // hit loads in flight per thread in the FILL gather
 template <int RQ>
 struct TravLds {
   static constexpr int THREADS = NSUB * RQ;
-  static constexpr int STAGE_CAP = 12 * RQ;  // float4 slots
+  static constexpr int STAGE_CAP = 12 * RQ;  // candidates the block can stage
   // ints: offs[RQ+1], orig[RQ], sub[3*RQ], band_lo[9], band_hi[9], band_base[10], wsum[THREADS/64]
   static constexpr int TABLE_MAX = 64;  // clouds whose offsets / grids are cached in LDS
   static constexpr int N_INTS = (RQ + 1) + RQ + NSUB * RQ + 9 + 9 + 10 + THREADS / WAVE + (TABLE_MAX + 1);
   static constexpr size_t TABLE_OFF = (size_t)(N_INTS * 4 + 15) / 16 * 16;
   static constexpr size_t INTS_BYTES = TABLE_OFF + (size_t)TABLE_MAX * 48;
-  static constexpr size_t STAGE_BYTES = (size_t)STAGE_CAP * 16;
+  static constexpr size_t STAGE_BYTES = (size_t)STAGE_CAP * 12;  // three coordinate planes
   static constexpr size_t FIXED = INTS_BYTES + STAGE_BYTES;
   static size_t total(int64_t max_block_hits) {  // FILL: int tables + keys (8 B) + row ids (1 B) per hit
     return TABLE_OFF + (size_t)max_block_hits * 8 + ((size_t)max_block_hits + 15) / 16 * 16;
@@ -405,11 +406,41 @@ __global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))
     }
     __syncthreads();
     const bool staged = band_base[NBAND] <= L::STAGE_CAP;
+    // candidates are staged as three coordinate planes (the index is not needed to COUNT), so a thread can
+    // pull two neighbours per plane into one 64-bit register pair and test them with packed fp32 math
+    float* sx = reinterpret_cast<float*>(stage);
+    float* sy = sx + L::STAGE_CAP;
+    float* sz = sy + L::STAGE_CAP;
     if (staged) {
+      // one flat pass over the union of the nine bands: every thread issues ALL its loads (<= 4) before the
+      // first LDS write, so the block pays one global round trip here instead of one per band
+      const int total = band_base[NBAND];
+      int bl[NBAND], bs[NBAND];
 #pragma unroll
       for (int k = 0; k < NBAND; ++k) {
-        const int lo = band_lo[k], len = band_hi[k] - lo, bb = band_base[k];
-        for (int i = tid; i < len; i += L::THREADS) stage[bb + i] = sorted_s[lo + i];
+        bl[k] = band_lo[k];
+        bs[k] = band_base[k];
+      }
+      constexpr int PER = L::STAGE_CAP / L::THREADS;
+      float4 v[PER];
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int f = tid + u * L::THREADS;
+        if (f < total) {
+          int src = bl[0] + f;
+#pragma unroll
+          for (int k = 1; k < NBAND; ++k) src = f >= bs[k] ? bl[k] + (f - bs[k]) : src;
+          v[u] = sorted_s[src];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int f = tid + u * L::THREADS;
+        if (f < total) {
+          sx[f] = v[u].x;
+          sy[f] = v[u].y;
+          sz[f] = v[u].z;
+        }
       }
       __syncthreads();
     }
@@ -417,40 +448,50 @@ __global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))
     //      enumeration order) so the FILL pass only ever touches the ~16 % that matter
     unsigned long long mask = 0ull;
     int bitpos = 0;
-    auto walk = [&](auto load) {
+    if (valid && staged) {
+      const f32x2 qx = {qp.x, qp.x}, qy = {qp.y, qp.y}, qz = {qp.z, qp.z};
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        const int e = p1[i];
-        for (int p = p0[i]; p < e; p += 4) {
-          float4 sp[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) sp[u] = load(i, min(p + u, e - 1));
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            // nanoflann.hpp:432-440: result += diff*diff for x, y, z starting from 0
-            const float dx = qp.x - sp[u].x;
-            const float dy = qp.y - sp[u].y;
-            const float dz = qp.z - sp[u].z;
-            const float d = (dx * dx + dy * dy) + dz * dz;
-            const bool hit = p + u < e && d < r2;
-            if (hit && bitpos + u < 64) mask |= 1ull << (bitpos + u);
-            n += hit ? 1 : 0;
-          }
-          bitpos += min(4, e - p);
+        const int rel = band_base[3 * j + i] - band_lo[3 * j + i];
+        int p = p0[i] + rel;
+        const int e = p1[i] + rel;
+        for (; p + 4 <= e; p += 4) {
+          const f32x2 xa = {sx[p], sx[p + 1]}, xb = {sx[p + 2], sx[p + 3]};
+          const f32x2 ya = {sy[p], sy[p + 1]}, yb = {sy[p + 2], sy[p + 3]};
+          const f32x2 za = {sz[p], sz[p + 1]}, zb = {sz[p + 2], sz[p + 3]};
+          // nanoflann.hpp:432-440: result += diff*diff for x, y, z starting from 0 (two lanes per op)
+          const f32x2 dxa = qx - xa, dya = qy - ya, dza = qz - za;
+          const f32x2 dxb = qx - xb, dyb = qy - yb, dzb = qz - zb;
+          const f32x2 da = (dxa * dxa + dya * dya) + dza * dza;
+          const f32x2 db = (dxb * dxb + dyb * dyb) + dzb * dzb;
+          const unsigned hb = (da.x < r2 ? 1u : 0u) | (da.y < r2 ? 2u : 0u) | (db.x < r2 ? 4u : 0u) | (db.y < r2 ? 8u : 0u);
+          if (bitpos < 64) mask |= (unsigned long long)hb << bitpos;
+          n += __popc(hb);
+          bitpos += 4;
+        }
+        for (; p < e; ++p) {
+          const float dx = qp.x - sx[p], dy = qp.y - sy[p], dz = qp.z - sz[p];
+          const float d = (dx * dx + dy * dy) + dz * dz;
+          const bool hit = d < r2;
+          if (hit && bitpos < 64) mask |= 1ull << bitpos;
+          n += hit ? 1 : 0;
+          ++bitpos;
         }
       }
-    };
-    if (valid) {
-      if (staged) {
-        int rel[3];
+    } else if (valid) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) rel[i] = band_base[3 * j + i] - band_lo[3 * j + i];
-        walk([&](int i, int p) { return stage[rel[i] + p]; });
-      } else {
-        walk([&](int, int p) { return sorted_s[p]; });
-      }
-      q_mask[(int64_t)j * nq + t] = mask;
+      for (int i = 0; i < 3; ++i)
+        for (int p = p0[i]; p < p1[i]; ++p) {
+          const float4 sp = sorted_s[p];
+          const float dx = qp.x - sp.x, dy = qp.y - sp.y, dz = qp.z - sp.z;
+          const float d = (dx * dx + dy * dy) + dz * dz;
+          const bool hit = d < r2;
+          if (hit && bitpos < 64) mask |= 1ull << bitpos;
+          n += hit ? 1 : 0;
+          ++bitpos;
+        }
     }
+    if (valid) q_mask[(int64_t)j * nq + t] = mask;
   } else if (valid) {
     // ---- FILL: gather only the hits (bit mask from the COUNT pass), eight loads in flight;
     //      threads with more than 64 candidates re-walk everything
