@@ -237,12 +237,14 @@ struct TravLds {
   static constexpr int TABLE_MAX = 64;  // clouds whose offsets / grids are cached in LDS
   static constexpr int N_INTS = (RQ + 1) + RQ + NSUB * RQ + 9 + 9 + 10 + THREADS / WAVE + (TABLE_MAX + 1);
   static constexpr size_t TABLE_OFF = (size_t)(N_INTS * 4 + 15) / 16 * 16;
+  // the FILL pass only needs offs, orig and wsum (laid out first): its hit segments start right after them
+  static constexpr size_t FILL_OFF = (size_t)(((RQ + 1) + RQ + THREADS / WAVE) * 4 + 15) / 16 * 16;
   static constexpr size_t INTS_BYTES = TABLE_OFF + (size_t)TABLE_MAX * 48;
   static constexpr size_t STAGE_BYTES = (size_t)STAGE_CAP * 12;  // three coordinate planes
   static constexpr size_t FIXED = INTS_BYTES + STAGE_BYTES;
-  static size_t total(int64_t max_block_hits) {  // FILL: int tables + keys (8 B) + row ids (1 B) per hit
-    return TABLE_OFF + (size_t)max_block_hits * 8 + ((size_t)max_block_hits + 15) / 16 * 16;
-  }
+  // FILL: slots = hits + at most one pad slot per query, rounded to 16 so every block's key array stays 16-B aligned
+  static int64_t slots(int64_t max_block_hits) { return (max_block_hits + RQ + 15) / 16 * 16; }
+  static size_t total(int64_t slots) { return FILL_OFF + (size_t)slots * 9; }  // int tables + keys (8 B) + row ids (1 B)
 };
 
 template <int RQ, bool FILL, bool HITS_IN_LDS>
@@ -257,21 +259,21 @@ __global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* offs = reinterpret_cast<int*>(smem);
   int* orig = offs + (RQ + 1);
-  int* sub = orig + RQ;  // [NSUB][RQ]
+  int* wsum = orig + RQ;
+  int* sub = wsum + L::THREADS / WAVE;  // [NSUB][RQ]
   int* band_lo = sub + NSUB * RQ;
   int* band_hi = band_lo + NBAND;
   int* band_base = band_hi + NBAND;
-  int* wsum = band_base + (NBAND + 1);
   // COUNT pass only: per-cloud tables cached in LDS so the per-query setup is not a chain of
   // dependent global round trips (query -> cloud id -> grid -> cell starts)
-  int* s_qoff = wsum + L::THREADS / WAVE;
+  int* s_qoff = band_base + (NBAND + 1);
   BatchGrid* s_grids = reinterpret_cast<BatchGrid*>(smem + L::TABLE_OFF);
   float4* stage = reinterpret_cast<float4*>(smem + L::INTS_BYTES);
   // FILL keeps no candidate stage: its hit segments start right after the int tables
-  unsigned long long* hits = HITS_IN_LDS ? reinterpret_cast<unsigned long long*>(smem + L::TABLE_OFF)
+  unsigned long long* hits = HITS_IN_LDS ? reinterpret_cast<unsigned long long*>(smem + L::FILL_OFF)
                                          : g_hits + (int64_t)blockIdx.x * max_block_hits;
   unsigned char* rows = HITS_IN_LDS
-                            ? reinterpret_cast<unsigned char*>(smem + L::TABLE_OFF + (size_t)max_block_hits * 8)
+                            ? reinterpret_cast<unsigned char*>(smem + L::FILL_OFF + (size_t)max_block_hits * 8)
                             : g_rows + (int64_t)blockIdx.x * max_block_hits;
 
   const int tid = threadIdx.x;
@@ -308,7 +310,8 @@ __global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))
       for (int i = 0; i < NSUB; ++i) c[i] = q_cnt[(int64_t)i * nq + t];
     }
     const int tot = c[0] + c[1] + c[2];
-    int inc = tot;
+    const int tot2 = (tot + 1) & ~1;  // segments start on even slots: the rank loop reads two keys per ds_read_b128
+    int inc = tot2;
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) {
       int v = __shfl_up(inc, d, WAVE);
@@ -320,11 +323,15 @@ __global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))
 #pragma unroll
     for (int i = 0; i < RQ / WAVE; ++i)
       if (i < slot / WAVE) base += wsum[j * (RQ / WAVE) + i];
-    const int q_start = base + inc - tot;
+    const int q_start = base + inc - tot2;
     my_off = q_start + (j > 0 ? c[0] : 0) + (j > 1 ? c[1] : 0);
     if (j == 0) {
       offs[slot] = q_start;
-      if (slot == RQ - 1) offs[RQ] = q_start + tot;
+      if (slot == RQ - 1) offs[RQ] = q_start + tot2;
+      if (tot2 != tot) {  // pad slot: larger than every real key, skipped by the rank phase
+        hits[q_start + tot] = ~0ull;
+        rows[q_start + tot] = 0xff;
+      }
     }
   } else {
     __syncthreads();
@@ -573,28 +580,30 @@ __global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))
   const int total_hits = offs[RQ];
   for (int e = tid; e < total_hits; e += L::THREADS) {
     const int r = rows[e];
-    const int a = offs[r], len = offs[r + 1] - a;
+    if (r == 0xff) continue;  // pad slot
+    const int a = offs[r], len = offs[r + 1] - a;  // both even
     const unsigned long long key = hits[e];
+    const ulonglong2* seg = reinterpret_cast<const ulonglong2*>(hits + a);
     int rank = 0;
     int jj = 0;
-    for (; jj + 8 <= len; jj += 8) {  // eight independent LDS reads in flight
-      unsigned long long hk[8];
+    for (; jj + 4 <= len / 2; jj += 4) {  // eight keys per step, four independent ds_read_b128 in flight
+      ulonglong2 hk[4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) hk[u] = hits[a + jj + u];
+      for (int u = 0; u < 4; ++u) hk[u] = seg[jj + u];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) rank += hk[u] < key ? 1 : 0;
+      for (int u = 0; u < 4; ++u) rank += (hk[u].x < key ? 1 : 0) + (hk[u].y < key ? 1 : 0);
     }
-    for (; jj + 4 <= len; jj += 4) {
-      const unsigned long long h0 = hits[a + jj], h1 = hits[a + jj + 1], h2 = hits[a + jj + 2], h3 = hits[a + jj + 3];
-      rank += (h0 < key ? 1 : 0) + (h1 < key ? 1 : 0) + (h2 < key ? 1 : 0) + (h3 < key ? 1 : 0);
+    for (; jj < len / 2; ++jj) {
+      const ulonglong2 h = seg[jj];
+      rank += (h.x < key ? 1 : 0) + (h.y < key ? 1 : 0);
     }
-    for (; jj < len; ++jj) rank += hits[a + jj] < key ? 1 : 0;
     if (rank < width) out[(int64_t)orig[r] * width + rank] = (int64_t)(unsigned int)(key & 0xffffffffull);
   }
   // ---- padding: one row per wave iteration, lanes along the row
   const int rows_here = min(RQ, nq - blk * RQ);
   for (int r = tid / 32; r < rows_here; r += L::THREADS / 32) {  // half a wave per row
-    const int cnt = offs[r + 1] - offs[r];
+    int cnt = offs[r + 1] - offs[r];
+    if (cnt > 0 && rows[offs[r + 1] - 1] == 0xff) --cnt;  // the segment ends in a pad slot
     int64_t* row = out + (int64_t)orig[r] * width;
     for (int c = cnt + (lane & 31); c < width; c += 32) row[c] = pad_value;
   }
@@ -655,7 +664,8 @@ int launch_fill(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t n
   using L = TravLds<RQ>;
   const int blocks = (int)((nq + RQ - 1) / RQ);
   const int grid = (blocks + 7) / 8 * 8;
-  const size_t lds = L::total(max_block_hits);
+  const int64_t cap = L::slots(max_block_hits);
+  const size_t lds = L::total(cap);
   KernelTimer timer("radius_fill", stream);
   if (lds <= 160 * 1024) {
     auto kern = traverse_kernel<RQ, true, true>;
@@ -664,17 +674,17 @@ int launch_fill(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t n
                                  160 * 1024));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(L::THREADS), lds, stream, sorted_q, (int)nq, w.q_off, nb, w.grids,
                        w.start, w.sorted_s, r2, w.q_count, w.q_rng, w.q_mask, w.blk_stats, (int)width, ns, out,
-                       (int)max_block_hits, (unsigned long long*)nullptr, (unsigned char*)nullptr);
+                       (int)cap, (unsigned long long*)nullptr, (unsigned char*)nullptr);
   } else {
     // very dense neighbourhoods: hit lists live in a scratch allocation owned by this call
     char* scratch = nullptr;
-    const size_t per_block = (size_t)max_block_hits;
+    const size_t per_block = (size_t)cap;
     GR_HIP(hipMallocAsync(reinterpret_cast<void**>(&scratch), (size_t)grid * per_block * 9 + 256, stream));
     unsigned long long* g_hits = reinterpret_cast<unsigned long long*>(scratch);
     unsigned char* g_rows = reinterpret_cast<unsigned char*>(scratch + (size_t)grid * per_block * 8);
-    hipLaunchKernelGGL((traverse_kernel<RQ, true, false>), dim3(grid), dim3(L::THREADS), L::TABLE_OFF, stream,
+    hipLaunchKernelGGL((traverse_kernel<RQ, true, false>), dim3(grid), dim3(L::THREADS), L::FILL_OFF, stream,
                        sorted_q, (int)nq, w.q_off, nb, w.grids, w.start, w.sorted_s, r2, w.q_count, w.q_rng,
-                       w.q_mask, w.blk_stats, (int)width, ns, out, (int)max_block_hits, g_hits, g_rows);
+                       w.q_mask, w.blk_stats, (int)width, ns, out, (int)cap, g_hits, g_rows);
     GR_HIP(hipFreeAsync(scratch, stream));
   }
   GR_LAUNCH_CHECK();
