@@ -302,12 +302,25 @@ __global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))
     for (int i = tid; i < nb * 3; i += L::THREADS) gdst[i] = gsrc[i];
   }
   int my_off = 0;
+  float4 qp = make_float4(0.f, 0.f, 0.f, 0.f);
+  int p0[3] = {0, 0, 0}, p1[3] = {0, 0, 0};
+  unsigned long long fill_bits = 0ull;
   if (FILL) {
     // every slab group redundantly scans the per-query totals (two waves each; no cross-group sync)
     int c[NSUB] = {0, 0, 0};
     if (valid) {
 #pragma unroll
       for (int i = 0; i < NSUB; ++i) c[i] = q_cnt[(int64_t)i * nq + t];
+      // everything else this thread needs from the COUNT pass is requested NOW, so the block pays one global
+      // round trip for (counts, query, ranges, hit mask) instead of two separated by the barrier below
+      qp = sorted_q[t];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int2 r = q_rng[(int64_t)(i * NSUB + j) * nq + t];
+        p0[i] = r.x;
+        p1[i] = r.y;
+      }
+      fill_bits = q_mask[(int64_t)j * nq + t];
     }
     const int tot = c[0] + c[1] + c[2];
     const int tot2 = (tot + 1) & ~1;  // segments start on even slots: the rank loop reads two keys per ds_read_b128
@@ -339,19 +352,11 @@ __global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))
 
   // ---- per-thread candidate ranges (global positions in sorted_s) for bands (dy, dz = j-1):
   //      computed by the COUNT pass and stored; the FILL pass just reloads them (one coalesced trip)
-  float4 qp = make_float4(0.f, 0.f, 0.f, 0.f);
-  int p0[3] = {0, 0, 0}, p1[3] = {0, 0, 0};
   if (valid) {
-    qp = sorted_q[t];
     if (FILL) {
       if (j == 0) orig[slot] = __float_as_int(qp.w);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int2 r = q_rng[(int64_t)(i * NSUB + j) * nq + t];
-        p0[i] = r.x;
-        p1[i] = r.y;
-      }
     } else {
+      qp = sorted_q[t];
       int b;
       BatchGrid g;
       if (tables_in_lds) {
@@ -516,7 +521,7 @@ __global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))
       }
     };
     if (len0 + len1 + len2 <= 64) {
-      unsigned long long bits = q_mask[(int64_t)j * nq + t];
+      unsigned long long bits = fill_bits;
       while (bits) {
         int pos[GB];
 #pragma unroll
