@@ -253,7 +253,7 @@ __global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))
     const BatchGrid* __restrict__ grids, const int32_t* __restrict__ start_s,
     const float4* __restrict__ sorted_s, float r2, int32_t* __restrict__ q_cnt, int2* __restrict__ q_rng,
     unsigned long long* __restrict__ q_mask, int32_t* __restrict__ blk_stats, int width, int64_t pad_value, int64_t* __restrict__ out,
-    int max_block_hits, unsigned long long* __restrict__ g_hits, unsigned char* __restrict__ g_rows) {
+    int max_block_hits, unsigned long long* __restrict__ g_hits, unsigned char* __restrict__ g_rows, int mono) {
   using L = TravLds<RQ>;
   static_assert(RQ % WAVE == 0 && RQ <= 256, "row ids are bytes; waves must not straddle slabs");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -395,12 +395,26 @@ __global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))
     // ---- block-wide extent of every band (waves are slab-uniform: band index = 3*j + i)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      int lo = p1[i] > p0[i] ? p0[i] : 0x7fffffff;
-      int hi = p1[i] > p0[i] ? p1[i] : 0;
+      const bool has = p1[i] > p0[i];
+      int lo, hi;
+      if (mono) {
+        // self-search: queries are in cell order and every range comes from the query's own cell, so p0 and p1 are
+        // non-decreasing along the wave -- the extent is (first valid lane's p0, last valid lane's p1)
+        const unsigned long long m = __ballot(has);
+        lo = 0x7fffffff;
+        hi = 0;
+        if (m) {
+          lo = __builtin_amdgcn_readlane(p0[i], __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1));
+          hi = __builtin_amdgcn_readlane(p1[i], __builtin_amdgcn_readfirstlane(63 - __clzll((long long)m)));
+        }
+      } else {
+        lo = has ? p0[i] : 0x7fffffff;
+        hi = has ? p1[i] : 0;
 #pragma unroll
-      for (int d = WAVE / 2; d > 0; d >>= 1) {
-        lo = min(lo, __shfl_xor(lo, d, WAVE));
-        hi = max(hi, __shfl_xor(hi, d, WAVE));
+        for (int d = WAVE / 2; d > 0; d >>= 1) {
+          lo = min(lo, __shfl_xor(lo, d, WAVE));
+          hi = max(hi, __shfl_xor(hi, d, WAVE));
+        }
       }
       if (lane == 0 && hi > 0) {
         atomicMin(&band_lo[3 * j + i], lo);
@@ -650,14 +664,14 @@ __global__ void pad_fill_kernel(int64_t* __restrict__ out, int64_t n, int64_t v)
 
 template <int RQ>
 int launch_count(const RadiusWs& w, const float4* sorted_q, int64_t nq, int nb, const int32_t* start_s, float r2,
-                 hipStream_t stream) {
+                 bool mono, hipStream_t stream) {
   using L = TravLds<RQ>;
   const int blocks = (int)((nq + RQ - 1) / RQ);
   const int grid = (blocks + 7) / 8 * 8;
   KernelTimer timer("radius_count", stream);
   hipLaunchKernelGGL((traverse_kernel<RQ, false, true>), dim3(grid), dim3(L::THREADS), L::FIXED, stream, sorted_q,
                      (int)nq, w.q_off, nb, w.grids, start_s, w.sorted_s, r2, w.q_count, w.q_rng, w.q_mask, w.blk_stats,
-                     0, (int64_t)0, (int64_t*)nullptr, 0, (unsigned long long*)nullptr, (unsigned char*)nullptr);
+                     0, (int64_t)0, (int64_t*)nullptr, 0, (unsigned long long*)nullptr, (unsigned char*)nullptr, mono ? 1 : 0);
   hipLaunchKernelGGL(reduce_stats_kernel, dim3(1), dim3(1024), 0, stream, w.blk_stats, blocks, w.hdr);
   GR_LAUNCH_CHECK();
   return GR_OK;
@@ -679,7 +693,7 @@ int launch_fill(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t n
                                  160 * 1024));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(L::THREADS), lds, stream, sorted_q, (int)nq, w.q_off, nb, w.grids,
                        w.start, w.sorted_s, r2, w.q_count, w.q_rng, w.q_mask, w.blk_stats, (int)width, ns, out,
-                       (int)cap, (unsigned long long*)nullptr, (unsigned char*)nullptr);
+                       (int)cap, (unsigned long long*)nullptr, (unsigned char*)nullptr, 0);
   } else {
     // very dense neighbourhoods: hit lists live in a scratch allocation owned by this call
     char* scratch = nullptr;
@@ -689,7 +703,7 @@ int launch_fill(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t n
     unsigned char* g_rows = reinterpret_cast<unsigned char*>(scratch + (size_t)grid * per_block * 8);
     hipLaunchKernelGGL((traverse_kernel<RQ, true, false>), dim3(grid), dim3(L::THREADS), L::FILL_OFF, stream,
                        sorted_q, (int)nq, w.q_off, nb, w.grids, w.start, w.sorted_s, r2, w.q_count, w.q_rng,
-                       w.q_mask, w.blk_stats, (int)width, ns, out, (int)cap, g_hits, g_rows);
+                       w.q_mask, w.blk_stats, (int)width, ns, out, (int)cap, g_hits, g_rows, 0);
     GR_HIP(hipFreeAsync(scratch, stream));
   }
   GR_LAUNCH_CHECK();
@@ -767,7 +781,7 @@ extern "C" int gr_radius_count(const float* q, const float* s, const int64_t* h_
                      w.s_cell, w.q_cell, start_s, start_q, w.s_rank, w.q_rank, w.sorted_s, w.sorted_q);
   const float4* sorted_q = same ? w.sorted_s : w.sorted_q;
   const float r2 = radius * radius;  // radius_neighbors_cpu.cpp:12 (fp32 product)
-  rc = launch_count<RT>(w, sorted_q, nq, nb, start_s, r2, stream);
+  rc = launch_count<RT>(w, sorted_q, nq, nb, start_s, r2, same, stream);
   if (rc != GR_OK) return rc;
   RadiusHdr h;
   GR_HIP(hipMemcpyAsync(&h, w.hdr, sizeof(h), hipMemcpyDeviceToHost, stream));
