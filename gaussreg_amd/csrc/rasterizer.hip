@@ -463,6 +463,7 @@ __global__ __launch_bounds__(256) void ranges_kernel(int64_t R, const uint32_t* 
 //          the longest of its four cell lists (~1/4 of the batch) instead of the whole batch.
 // The cutoffs only skip (pixel, Gaussian) pairs that the reference test `alpha < 1/255` skips,
 // and per-pixel order is untouched, so the image stays bit-identical to the oracle.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int CELL = 4;
 constexpr int NCELL = (TILE / CELL) * (TILE / CELL);  // 16
 
@@ -551,33 +552,60 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
     __syncthreads();
     // ---- blend: each 16-lane group walks its own list
     const int n_cell = done ? 0 : s_cnt[cell][BLOCK / WAVE];
-    // the next Gaussian's parameters are fetched while the current one is evaluated
-    int jn = s_list[cell][0];
-    float4 a_n = s_a[jn], b_n = s_b[jn];
-    for (int i = 0; i < n_cell; ++i) {
-      const int j = jn;
-      const float4 a = a_n, co = b_n;
-      jn = s_list[cell][min(i + 1, BLOCK - 1)];
-      a_n = s_a[jn];
-      b_n = s_b[jn];
-      const float dx = a.x - pfx, dy = a.y - pfy;
-      const float q = fmaf(co.x * dx, dx, (co.z * dy) * dy);
-      const float power = fmaf(-0.5f, q, -((co.y * dx) * dy));
-      if (power > 0.0f) continue;
-      if (power < a.z) continue;
-      const float alpha = fminf(0.99f, co.w * exp_det(power));
-      if (alpha < 1.0f / 255.0f) continue;
-      const float test_T = T * (1.0f - alpha);
-      if (test_T < 0.0001f) {
-        done = true;
-        break;
+    // Two list entries per step: everything up to alpha is evaluated for both at once with packed fp32 math
+    // (v_pk_fma/mul/add_f32 -- the same IEEE operations as the scalar sequence of the oracle, two per lane-slot);
+    // only the order-dependent tail (transmittance test, colour accumulation) runs entry by entry.
+    for (int i = 0; i < n_cell; i += 2) {
+      const bool have1 = i + 1 < n_cell;
+      const int j0 = s_list[cell][i], j1 = s_list[cell][min(i + 1, BLOCK - 1)];
+      const float4 a0 = s_a[j0], b0 = s_b[j0], a1 = s_a[j1], b1 = s_b[j1];
+      const f32x2 dx = f32x2{a0.x, a1.x} - pfx, dy = f32x2{a0.y, a1.y} - pfy;
+      const f32x2 cx = {b0.x, b1.x}, cy = {b0.y, b1.y}, cz = {b0.z, b1.z}, cw = {b0.w, b1.w};
+      const f32x2 q = __builtin_elementwise_fma(cx * dx, dx, (cz * dy) * dy);
+      const f32x2 power = __builtin_elementwise_fma(f32x2{-0.5f, -0.5f}, q, -((cy * dx) * dy));
+      // exp_det(), two at a time
+      const f32x2 x = {fmaxf(power.x, -100.0f), fmaxf(power.y, -100.0f)};
+      const f32x2 t = x * 1.44269504088896341f;
+      const f32x2 n = {rintf(t.x), rintf(t.y)};
+      f32x2 r = __builtin_elementwise_fma(n, f32x2{-0.693359375f, -0.693359375f}, x);
+      r = __builtin_elementwise_fma(n, f32x2{2.12194440e-4f, 2.12194440e-4f}, r);
+      f32x2 pl = {1.9875691500e-4f, 1.9875691500e-4f};
+      pl = __builtin_elementwise_fma(pl, r, f32x2{1.3981999507e-3f, 1.3981999507e-3f});
+      pl = __builtin_elementwise_fma(pl, r, f32x2{8.3334519073e-3f, 8.3334519073e-3f});
+      pl = __builtin_elementwise_fma(pl, r, f32x2{4.1665795894e-2f, 4.1665795894e-2f});
+      pl = __builtin_elementwise_fma(pl, r, f32x2{1.6666665459e-1f, 1.6666665459e-1f});
+      pl = __builtin_elementwise_fma(pl, r, f32x2{5.0000001201e-1f, 5.0000001201e-1f});
+      const f32x2 y = __builtin_elementwise_fma(pl, r * r, r) + 1.0f;
+      const f32x2 al = cw * f32x2{ldexpf(y.x, (int)n.x), ldexpf(y.y, (int)n.y)};
+      const float alpha0 = fminf(0.99f, al.x), alpha1 = fminf(0.99f, al.y);
+      const bool ok0 = !(power.x > 0.0f) && !(power.x < a0.z) && !(alpha0 < 1.0f / 255.0f);
+      const bool ok1 = have1 && !(power.y > 0.0f) && !(power.y < a1.z) && !(alpha1 < 1.0f / 255.0f);
+      if (ok0) {
+        const float test_T = T * (1.0f - alpha0);
+        if (test_T < 0.0001f) {
+          done = true;
+          break;
+        }
+        const float4 col = s_c[j0];
+        const float w = alpha0 * T;
+        C0 = fmaf(col.x, w, C0);
+        C1 = fmaf(col.y, w, C1);
+        C2 = fmaf(col.z, w, C2);
+        T = test_T;
       }
-      const float4 col = s_c[j];
-      const float w = alpha * T;
-      C0 = fmaf(col.x, w, C0);
-      C1 = fmaf(col.y, w, C1);
-      C2 = fmaf(col.z, w, C2);
-      T = test_T;
+      if (ok1) {
+        const float test_T = T * (1.0f - alpha1);
+        if (test_T < 0.0001f) {
+          done = true;
+          break;
+        }
+        const float4 col = s_c[j1];
+        const float w = alpha1 * T;
+        C0 = fmaf(col.x, w, C0);
+        C1 = fmaf(col.y, w, C1);
+        C2 = fmaf(col.z, w, C2);
+        T = test_T;
+      }
     }
   }
   if (inside) {
