@@ -363,6 +363,29 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
           const bool cullable = det > 0.0f && l2 >= 0.29f && l1 < 1.0e4f;
           const float kc = cullable ? 1.001f / (0.5f / l1 - 2.0e-6f) : INFINITY;
           out_rgb = make_float4(rgb[0], rgb[1], rgb[2], kc);
+          // Tile rectangle actually emitted: the reference square (radius = ceil(3 sigma_max)) intersected with the
+          // bounding box of the region where alpha can reach 1/255.  A pixel contributes only if fp32 power >= pc
+          // (pc as in the blend, with margin); inside the cutoff circle rc2 the fp32 quadratic form is within
+          // 2e-6 rc2 of the exact one, whose level set {0.5 d^T A d <= c'} has half-extents sqrt(2 c' Sigma_xx / yy).
+          // Only (tile, Gaussian) pairs that blend nothing are dropped, so the image is unchanged; `radii` is not.
+          if (cullable) {
+            const float pcm = __logf(255.0f * opacity) + 2.0e-3f;
+            if (pcm > 0.0f) {
+              const float cp = pcm + 2.0e-6f * (pcm * kc);
+              const float hx = sqrtf(2.0f * cp * cv[0]) * 1.001f + 1.0e-2f;
+              const float hy = sqrtf(2.0f * cp * cv[2]) * 1.001f + 1.0e-2f;
+              // pixels x with |x - px| <= hx: [ceil(px - hx), floor(px + hx)] -> tiles
+              const float xlo = ceilf(px - hx), xhi = floorf(px + hx), ylo = ceilf(py - hy), yhi = floorf(py + hy);
+              if (xlo > -1.0e6f && xhi < 1.0e6f && ylo > -1.0e6f && yhi < 1.0e6f) {
+                rmin[0] = max(rmin[0], (int)floorf(xlo / (float)TILE));
+                rmin[1] = max(rmin[1], (int)floorf(ylo / (float)TILE));
+                rmax[0] = min(rmax[0], (int)floorf(xhi / (float)TILE) + 1);
+                rmax[1] = min(rmax[1], (int)floorf(yhi / (float)TILE) + 1);
+                if (rmax[0] < rmin[0]) rmax[0] = rmin[0];
+                if (rmax[1] < rmin[1]) rmax[1] = rmin[1];
+              }
+            }
+          }
           out_key |= (uint64_t)__float_as_uint(out_depth) | pack_rect(rmin, rmax);
         }
       }

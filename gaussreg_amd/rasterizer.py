@@ -81,7 +81,9 @@ def rasterize_views(settings, means3D, opacities, shs=None,
     """Render the same Gaussians from len(settings) cameras (`settings`: a sequence of
     GaussianRasterizationSettings, or a prebuilt ViewBatch).
 
-    Returns (color (V,3,H,W) f32, radii (V,P) i32, num_rendered list[int])."""
+    Returns (color (V,3,H,W) f32, radii (V,P) i32, num_rendered list[int]).  num_rendered = (tile, Gaussian)
+    instances actually binned per view: at most the reference's count (pairs that cannot reach alpha = 1/255
+    anywhere in the tile are dropped before the sort; the image is unaffected)."""
     dev = _lib.require_gpu()
     L = _lib.lib()
     if means3D.is_cuda:

@@ -109,7 +109,9 @@ int gr_grid_subsample(const float* points, const int64_t* h_lengths, int64_t n, 
  * instances R is data dependent (upstream syncs at the same place):
  *   gr_raster_preprocess : cull / project / cov2D / SH->RGB / tile counts / prefix sums into
  *                          `geom` (size gr_raster_geom_bytes), SYNCHRONISES `stream`,
- *                          h_num_rendered[v] = R_v.  Also writes radii (num_views, P) int32.
+ *                          h_num_rendered[v] = R_v = instances binned (<= upstream's count: pairs that
+ *                          cannot reach alpha = 1/255 inside the tile are dropped, the image is unaffected).
+ *                          Also writes radii (num_views, P) int32, exactly upstream's values.
  *   gr_raster_render     : instance keys, radix sort by (view, tile, depth), tile ranges, per-tile
  *                          front-to-back alpha blend -> out_color (num_views, 3, H, W) fp32.
  *                          `bin` is scratch of size gr_raster_bin_bytes(sum R_v, ...).

@@ -84,7 +84,7 @@ def test_multi_view_batch_equals_single_views():
     assert imgs.shape == (V, 3, H, W) and radii.shape == (V, P)
     for v in range(V):
         want, wr, wR = oracle_render(g, cams[v])
-        assert nr[v] == wR
+        assert 0 < nr[v] <= wR   # instances emitted: the reference count minus (tile, Gaussian) pairs that blend nothing
         assert np.array_equal(radii[v].cpu().numpy(), wr)
         _assert_bit_equal(imgs[v].cpu().numpy(), want, f"view {v}")
 
@@ -127,7 +127,7 @@ def test_full_size_configs_bit_exact(P, W, H, V):
                                       scales=d["scales"], rotations=d["rotations"])
     for v in range(V):
         want, wr, wR = oracle_render(g, cams[v])
-        assert nr[v] == wR
+        assert 0 < nr[v] <= wR   # instances emitted: the reference count minus (tile, Gaussian) pairs that blend nothing
         assert np.array_equal(radii[v].cpu().numpy(), wr)
         _assert_bit_equal(imgs[v].cpu().numpy(), want, f"{P} Gaussians {W}x{H} view {v}")
 
