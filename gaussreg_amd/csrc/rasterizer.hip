@@ -178,7 +178,7 @@ __device__ __forceinline__ void get_rect(float px, float py, int radius, int gx,
 
 // geometry state: one 64-byte record per (view, Gaussian) so that the blend's per-instance gather
 // (ids arrive in depth order, i.e. random in memory) touches ONE 64-B sector instead of three lines:
-//   rec[0] = {px, py, depth, radius(int bits)}   rec[1] = {conic.x, conic.y, conic.z, opacity}
+//   rec[0] = {px, py, sxx, syy (axis cull factors)}   rec[3] = {radius(int bits), depth, -, -}   rec[1] = {conic.x, conic.y, conic.z, opacity}
 //   rec[2] = {r, g, b, kc (cull factor)}          rec[3] = unused
 struct Geom {
   float4* rec;           // [V][P][4]
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const int64_t o = (int64_t)v * P + i;
     int out_radius = 0;
     uint64_t out_key = (uint64_t)v << 32;  // culled: depth 0, empty rectangle
-    float out_depth = 0.f;
+    float out_depth = 0.f, out_sxx = INFINITY, out_syy = INFINITY;
     float2 out_xy = make_float2(0.f, 0.f);
     float4 out_co = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 out_rgb = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -369,6 +369,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
           // 2e-6 rc2 of the exact one, whose level set {0.5 d^T A d <= c'} has half-extents sqrt(2 c' Sigma_xx / yy).
           // Only (tile, Gaussian) pairs that blend nothing are dropped, so the image is unchanged; `radii` is not.
           if (cullable) {
+            // blend cell culling along the axes: |dx|^2 > c' * sxx (or |dy|^2 > c' * syy) ==> no contribution
+            out_sxx = 2.0f * cv[0] * 1.004f;
+            out_syy = 2.0f * cv[2] * 1.004f;
             const float pcm = __logf(255.0f * opacity) + 2.0e-3f;
             if (pcm > 0.0f) {
               const float cp = pcm + 2.0e-6f * (pcm * kc);
@@ -394,10 +397,11 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     dkeys[o] = out_key;
     order[o] = i;
     float4* r = rec + 4 * o;
-    r[0] = make_float4(out_xy.x, out_xy.y, out_depth, __int_as_float(out_radius));
+    r[0] = make_float4(out_xy.x, out_xy.y, out_sxx, out_syy);
     if (out_radius > 0) {  // culled Gaussians are never gathered
       r[1] = out_co;
       r[2] = out_rgb;
+      r[3] = make_float4(__int_as_float(out_radius), out_depth, 0.f, 0.f);  // read by the wide-rectangle fallback only
     }
   }
 }
@@ -410,7 +414,7 @@ __device__ __forceinline__ bool rect_of(uint64_t key, int id, int64_t vbase, con
   rmin[1] = (int)((key >> 45) & 127);
   if (w == 0 && h == 0 && rmin[0] == 127 && rmin[1] == 127) {  // marker: did not fit, gather the record
     const float4 r0 = rec[4 * (vbase + id)];
-    get_rect(r0.x, r0.y, __float_as_int(r0.w), gx, gy, rmin, rmax);
+    get_rect(r0.x, r0.y, __float_as_int(rec[4 * (vbase + id) + 3].x), gx, gy, rmin, rmax);
     return true;
   }
   rmax[0] = rmin[0] + w;
@@ -530,6 +534,9 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
       // NaN / non-positive opacity make every comparison false: nothing is skipped early.
       const float pc = -__logf(255.0f * co.w) - 1.0e-3f;
       const float rc2 = -pc * col.w;
+      // exact level set of the quadratic form, per axis (see preprocess): c' = |pc| + 2e-6 rc2 covers the fp32 error
+      const float cpr = -pc + 1.0e-3f + 2.0e-6f * rc2;
+      const float hx2 = cpr * r0.z, hy2 = cpr * r0.w;
       s_a[tid] = make_float4(r0.x, r0.y, pc, rc2);
       s_b[tid] = co;
       s_c[tid] = col;
@@ -544,7 +551,9 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
       }
 #pragma unroll
       for (int c = 0; c < NCELL; ++c)
-        if (!(ex2[c % (TILE / CELL)] + ey2[c / (TILE / CELL)] > rc2)) mask |= 1u << c;
+        if (!(ex2[c % (TILE / CELL)] + ey2[c / (TILE / CELL)] > rc2) && !(ex2[c % (TILE / CELL)] > hx2) &&
+            !(ey2[c / (TILE / CELL)] > hy2))
+          mask |= 1u << c;
     }
     // ---- order-preserving per-cell lists
     unsigned rank_lo = 0, rank_hi = 0;  // 16 x 8-bit... ranks need up to 6 bits each: pack 8 per 64? keep simple
