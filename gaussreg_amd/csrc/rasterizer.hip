@@ -182,14 +182,14 @@ __device__ __forceinline__ void get_rect(float px, float py, int radius, int gx,
 //   rec[2] = {r, g, b, kc (cull factor)}          rec[3] = unused
 struct Geom {
   float4* rec;           // [V][P][4]
-  uint64_t* dkeys_a;     // [V*P] (view << 32 | depth bits)
+  uint64_t* dkeys_a;     // [V*P] rect bits | view << 27 | rebased depth bits (see KEY_DEPTH_BITS)
   uint64_t* dkeys_b;
   int32_t* order_a;      // [V*P] Gaussian ids; order_b = per-view front-to-back order
   int32_t* order_b;
   int32_t* offs;         // [V*P] exclusive scan of tiles in depth order
   void* sort_temp;
   size_t sort_temp_bytes;
-  int32_t* totals;       // [V]
+  int32_t* totals;       // [V] then [V] = depth-overflow flag
   DevView* views;        // [MAX_VIEWS] camera table (uniform loads)
   int32_t* scan_ws;
   size_t bytes;
@@ -206,7 +206,7 @@ Geom carve_geom(void* p, int64_t P, int V) {
   g.offs = c.take<int32_t>(P * V);
   g.sort_temp_bytes = sort_pairs_temp_bytes(P * V);
   g.sort_temp = c.take<char>(g.sort_temp_bytes);
-  g.totals = c.take<int32_t>(V);
+  g.totals = c.take<int32_t>(V + 1);
   g.views = c.take<DevView>(MAX_VIEWS);
   g.scan_ws = c.take<int32_t>(V * scan_ws_ints(P));
   g.bytes = c.used();
@@ -244,6 +244,12 @@ Bin carve_bin(void* p, int64_t R, int64_t vtiles) {
 //   bits  0..31 depth bits | 32..37 view | 38..44 rect.x | 45..51 rect.y | 52..57 w | 58..63 h
 // Rectangles that do not fit (w or h > 63, x or y > 126) store the marker below and are gathered.
 constexpr int KEY_VIEW_BITS = 6;
+// Depth-sort key: [0,27) = float bits of depth minus those of 0.125 (visible depths are > 0.2, so this is >= 0 and
+// order-preserving; < 2^27 while depth < 8192), [27, 27+view bits) = view.  27 + 4 view bits sort in four 8-bit radix
+// passes instead of the five that (view << 32 | depth bits) needs.  A depth >= 8192 raises a flag and the call
+// re-sorts with full keys (slow path, never taken by sane scenes).
+constexpr int KEY_DEPTH_BITS = 27;
+constexpr uint32_t KEY_DEPTH_BASE = 0x3E000000u;  // bits of 0.125f
 constexpr uint64_t RECT_MARKER = (127ull << 38) | (127ull << 45);  // w = h = 0
 
 __device__ __forceinline__ uint64_t pack_rect(const int* rmin, const int* rmax) {
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const float* __restrict__ opacities, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, int W, int H,
     int32_t* __restrict__ radii, float4* __restrict__ rec, uint64_t* __restrict__ dkeys,
-    int32_t* __restrict__ order) {
+    int32_t* __restrict__ order, int32_t* __restrict__ far_flag) {
   __shared__ float4 s_sh[SH16 ? 256 * SH_ROW : 1];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float shr[SH16 ? 48 : 1];
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const DevView& cam = views[v];
     const int64_t o = (int64_t)v * P + i;
     int out_radius = 0;
-    uint64_t out_key = (uint64_t)v << 32;  // culled: depth 0, empty rectangle
+    uint64_t out_key = (uint64_t)v << KEY_DEPTH_BITS;  // culled: depth key 0, empty rectangle
     float out_depth = 0.f, out_sxx = INFINITY, out_syy = INFINITY;
     float2 out_xy = make_float2(0.f, 0.f);
     float4 out_co = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -389,7 +395,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
               }
             }
           }
-          out_key |= (uint64_t)__float_as_uint(out_depth) | pack_rect(rmin, rmax);
+          uint32_t dk = __float_as_uint(out_depth) - KEY_DEPTH_BASE;  // out_depth > 0.2 > 0.125
+          if (dk >= (1u << KEY_DEPTH_BITS)) {
+            dk = (1u << KEY_DEPTH_BITS) - 1;
+            atomicOr(far_flag, 1);
+          }
+          out_key |= (uint64_t)dk | pack_rect(rmin, rmax);
         }
       }
     }
@@ -404,6 +415,17 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
       r[3] = make_float4(__int_as_float(out_radius), out_depth, 0.f, 0.f);  // read by the wide-rectangle fallback only
     }
   }
+}
+
+// slow path of the depth sort: keys with the full 32 depth bits (view << 32 | depth bits), rectangle bits kept
+__global__ __launch_bounds__(256) void full_keys_kernel(int64_t n, int P, const float4* __restrict__ rec,
+                                                        const int32_t* __restrict__ radii, uint64_t* __restrict__ keys) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n) return;
+  const uint64_t v = (uint64_t)(o / P);
+  const uint64_t rect = keys[o] & ~((1ull << 38) - 1ull);
+  const uint32_t dbits = radii[o] > 0 ? __float_as_uint(rec[4 * o + 3].y) : 0u;
+  keys[o] = rect | (v << 32) | dbits;
 }
 
 // ------------------------------------------------------------------------------------ instances
@@ -756,7 +778,8 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
 #define GR_PRE(SH, COV, S16)                                                                       \
   hipLaunchKernelGGL((preprocess_kernel<SH, COV, S16>), grd, blk, 0, stream, (int)P, D, M, num_views, \
                      g.views, means3D, shs, colors_precomp, opacities, scales, rotations,          \
-                     cov3D_precomp, W, H, radii, g.rec, g.dkeys_a, g.order_a)
+                     cov3D_precomp, W, H, radii, g.rec, g.dkeys_a, g.order_a, g.totals + num_views)
+  GR_HIP(hipMemsetAsync(g.totals + num_views, 0, sizeof(int32_t), stream));  // depth-overflow flag
   {
     KernelTimer timer("raster_preprocess", stream);
     if (shs && cov3D_precomp) { if (sh16) GR_PRE(true, true, true); else GR_PRE(true, true, false); }
@@ -766,23 +789,35 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
   }
 #undef GR_PRE
   GR_LAUNCH_CHECK();
-  {
-    KernelTimer timer("raster_sort", stream);
-    int vbits = 0;
-    while ((1 << vbits) < num_views) ++vbits;
-    static_assert((1 << KEY_VIEW_BITS) >= MAX_VIEWS, "view id must fit its key field");
-    rc = sort_pairs_u64_i32(g.sort_temp, g.sort_temp_bytes, g.dkeys_a, g.dkeys_b, g.order_a, g.order_b,
-                            P * num_views, 0, 32 + vbits, stream);
+  int vbits = 0;
+  while ((1 << vbits) < num_views) ++vbits;
+  static_assert((1 << KEY_VIEW_BITS) >= MAX_VIEWS && KEY_DEPTH_BITS + KEY_VIEW_BITS <= 38, "view id must fit its key field");
+  std::vector<int32_t> tot(num_views + 1);
+  auto sort_and_count = [&](int end_bit) -> int {
+    {
+      KernelTimer timer("raster_sort", stream);
+      int rcs = sort_pairs_u64_i32(g.sort_temp, g.sort_temp_bytes, g.dkeys_a, g.dkeys_b, g.order_a, g.order_b,
+                                   P * num_views, 0, end_bit, stream);
+      if (rcs != GR_OK) return rcs;
+    }
+    hipLaunchKernelGGL(tiles_from_keys_kernel, dim3((unsigned)((P * num_views + 255) / 256)), blk, 0, stream,
+                       P * num_views, (int)P, W, H, g.dkeys_b, g.order_b, g.rec, g.offs);
+    GR_LAUNCH_CHECK();
+    int rcs = exclusive_scan_i32(g.offs, g.offs, P, num_views, P, g.scan_ws, g.totals, stream);
+    if (rcs != GR_OK) return rcs;
+    GR_HIP(hipMemcpyAsync(tot.data(), g.totals, sizeof(int32_t) * (num_views + 1), hipMemcpyDeviceToHost, stream));
+    GR_HIP(hipStreamSynchronize(stream));
+    return GR_OK;
+  };
+  rc = sort_and_count(KEY_DEPTH_BITS + vbits);
+  if (rc != GR_OK) return rc;
+  if (tot[num_views] != 0) {  // some depth >= 8192: redo the ordering with full-width keys
+    hipLaunchKernelGGL(full_keys_kernel, dim3((unsigned)((P * num_views + 255) / 256)), blk, 0, stream, P * num_views,
+                       (int)P, g.rec, radii, g.dkeys_a);
+    GR_LAUNCH_CHECK();
+    rc = sort_and_count(32 + vbits);
     if (rc != GR_OK) return rc;
   }
-  hipLaunchKernelGGL(tiles_from_keys_kernel, dim3((unsigned)((P * num_views + 255) / 256)), blk, 0, stream,
-                     P * num_views, (int)P, W, H, g.dkeys_b, g.order_b, g.rec, g.offs);
-  GR_LAUNCH_CHECK();
-  rc = exclusive_scan_i32(g.offs, g.offs, P, num_views, P, g.scan_ws, g.totals, stream);
-  if (rc != GR_OK) return rc;
-  std::vector<int32_t> tot(num_views);
-  GR_HIP(hipMemcpyAsync(tot.data(), g.totals, sizeof(int32_t) * num_views, hipMemcpyDeviceToHost, stream));
-  GR_HIP(hipStreamSynchronize(stream));
   for (int v = 0; v < num_views; ++v) h_num_rendered[v] = tot[v];
   return GR_OK;
 }

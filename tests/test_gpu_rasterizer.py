@@ -162,3 +162,30 @@ def test_zero_gaussians_and_odd_sizes():
                                                         scales=d["scales"], rotations=d["rotations"])
     assert np.array_equal(radii.cpu().numpy(), wr)
     _assert_bit_equal(img.cpu().numpy(), want, "37x23 image")
+
+
+def test_far_depth_takes_full_key_sort():
+    """Depths >= 8192 do not fit the 27-bit rebased depth key: the call re-sorts with full-width keys.  The whole
+    scene (positions, sizes, camera offsets) is scaled by 4000 -- same picture, depths of ~12 km."""
+    from gaussreg_amd.rasterizer import rasterize_views
+    P, W, H, V = 6000, 128, 96, 3
+    g, cams = raster_scene(P, W, H, seed=5, V=V)
+    k = np.float32(4000.0)
+    g["means3D"] = (g["means3D"] * k).astype(np.float32)
+    g["scales"] = (g["scales"] * k).astype(np.float32)
+    cams = [dict(c) for c in cams]
+    for c in cams:   # translate the camera centre with the scene: view = [R^T | -R^T C]
+        vm = c["viewmatrix"].copy()          # stored transposed: last ROW holds the translation
+        vm[3, :3] *= k
+        proj = c["projmatrix"].T.astype(np.float64) @ np.linalg.inv(c["viewmatrix"].T.astype(np.float64))
+        c["viewmatrix"] = vm
+        c["projmatrix"] = (proj @ vm.T.astype(np.float64)).T.astype(np.float32)
+        c["campos"] = (c["campos"] * k).astype(np.float32)
+    d = _cu(g)
+    imgs, radii, nr = rasterize_views([_settings(c) for c in cams], d["means3D"], d["opacities"], shs=d["shs"],
+                                      scales=d["scales"], rotations=d["rotations"])
+    for v in range(V):
+        want, wr, wR = oracle_render(g, cams[v])
+        assert wr.max() > 0 and want.std() > 0
+        assert np.array_equal(radii[v].cpu().numpy(), wr)
+        _assert_bit_equal(imgs[v].cpu().numpy(), want, f"far view {v}")
