@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--views", type=int, default=16, help="cameras per step (per GPU)")
+    ap.add_argument("--views", type=int, default=32, help="cameras per step (per GPU)")
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
@@ -47,15 +47,19 @@ def parse():
     return ap.parse_args()
 
 
-def pmc_traffic(key, ok):
+def pmc_traffic(key, ok, units=None):
     """HBM bytes per launch from the committed rocprofv3 --pmc summary (separate FETCH_SIZE / WRITE_SIZE
-    passes, FETCH doubled per MI355X_MICROARCH.md); only valid for the configuration it was taken on."""
+    passes, FETCH doubled per MI355X_MICROARCH.md); only valid for the configuration it was taken on
+    (`units` = views or clouds per launch must match what the summary records)."""
     if not ok:
         return None
     try:
         cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_hbm.json"))
         with open(os.path.join(ROOT, "profiles", cands[-1])) as fh:
-            return json.load(fh)["traffic_bytes_per_launch"].get(key)
+            doc = json.load(fh)
+        if units is not None and doc.get("units_per_launch", {}).get(key) != units:
+            return None
+        return doc["traffic_bytes_per_launch"].get(key)
     except Exception:
         return None
 
@@ -157,7 +161,7 @@ def main():
                 "achieved": round(blend_bytes / blend_avg_s / 1e9, 2) if blend_avg_s > 0 else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(blend_bytes / blend_avg_s / 1e9 / HBM_PEAK_GBS, 4) if blend_avg_s > 0 else None,
-                "traffic": pmc_traffic("raster_blend", (P, W, H, V) == (1_000_000, 640, 480, 16)),
+                "traffic": pmc_traffic("raster_blend", (P, W, H) == (1_000_000, 640, 480), V),
                 "bytes_per_launch": blend_bytes, "avg_launch_ms": round(blend_avg_s * 1e3, 4),
                 "other_kernels_ms": {"raster_preprocess": round(pre_ms / max(pre_n, 1), 4),
                                      "raster_sort": round(sort_ms / max(sort_n, 1), 4)}}
@@ -199,7 +203,7 @@ def main():
                                "achieved": round(fill_bytes / fill_avg_s / 1e9, 2) if fill_avg_s > 0 else None,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(fill_bytes / fill_avg_s / 1e9 / HBM_PEAK_GBS, 4) if fill_avg_s > 0 else None,
-                               "traffic": pmc_traffic("radius_fill", B == 8), "bytes_per_launch": fill_bytes,
+                               "traffic": pmc_traffic("radius_fill", True, B), "bytes_per_launch": fill_bytes,
                                "avg_launch_ms": round(fill_avg_s * 1e3, 4),
                                "other_kernels_ms": {"radius_count": round(cnt_ms / max(cnt_n, 1), 4)}}}
 

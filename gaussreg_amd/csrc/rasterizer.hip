@@ -408,8 +408,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     dkeys[o] = out_key;
     order[o] = i;
     float4* r = rec + 4 * o;
-    r[0] = make_float4(out_xy.x, out_xy.y, out_sxx, out_syy);
-    if (out_radius > 0) {  // culled Gaussians are never gathered
+    if (out_radius > 0) {  // culled Gaussians are never gathered: their 64-B line is not touched at all
+      r[0] = make_float4(out_xy.x, out_xy.y, out_sxx, out_syy);
       r[1] = out_co;
       r[2] = out_rgb;
       r[3] = make_float4(__int_as_float(out_radius), out_depth, 0.f, 0.f);  // read by the wide-rectangle fallback only

@@ -1,6 +1,6 @@
 """Summarise two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; tools/pmc.sh) into profiles/<round>_pmc_hbm.json.
 usage: python tools/pmc_summary.py gpurun_out/pmc_fetch/fetch_counter_collection.csv \
-                                   gpurun_out/pmc_write/write_counter_collection.csv profiles/r01_pmc_hbm.json"""
+                                   gpurun_out/pmc_write/write_counter_collection.csv profiles/r01_pmc_hbm.json [views clouds]"""
 import collections
 import csv
 import json
@@ -33,6 +33,8 @@ def collect(path, counter):
 
 def main():
     fetch, write, out = sys.argv[1:4]
+    views = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+    clouds = int(sys.argv[5]) if len(sys.argv) > 5 else 8
     f = collect(fetch, "FETCH_SIZE")
     w = collect(write, "WRITE_SIZE")
     kernels = []
@@ -42,7 +44,8 @@ def main():
     doc = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes (tools/pmc.sh), command: python bench.py "
                    "--steps 3 --warmup 1 --no-cpu-baseline; values in KB per launch as reported. Per MI355X_MICROARCH.md (HBM "
                    "section) FETCH_SIZE on gfx950 counts wide coalesced reads at 1/2 -> hbm_bytes ~= (2*FETCH_SIZE + WRITE_SIZE)*1024.",
-           "config": {"raster": "1M Gaussians, 640x480, 16 views/launch", "radius": "8 x 200k-pt clouds/launch, r=0.0625"},
+           "config": {"raster": f"1M Gaussians, 640x480, {views} views/launch", "radius": f"{clouds} x 200k-pt clouds/launch, r=0.0625"},
+           "units_per_launch": {"raster_blend": views, "radius_fill": clouds},
            "kernels": kernels, "traffic_bytes_per_launch": {}}
     for k in kernels:  # the two kernels bench.py prices against the HBM roofline
         hbm = int((2 * k["fetch_size_kb_avg"] + k["write_size_kb_avg"]) * 1024)
