@@ -93,6 +93,9 @@ size_t sort_pairs_temp_bytes(int64_t n);
 int sort_pairs_u64_i32(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out,
                        const int32_t* vals_in, int32_t* vals_out, int64_t n, int begin_bit,
                        int end_bit, hipStream_t stream);
+// value stream generated on the fly: value(i) = i mod period
+int sort_pairs_u64_iota(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, int64_t period,
+                        int32_t* vals_out, int64_t n, int begin_bit, int end_bit, hipStream_t stream);
 
 // Optional per-kernel HIP-event timing (off by default; bench.py turns it on to measure the
 // dominant kernel's average launch duration on the stream it is launched on).

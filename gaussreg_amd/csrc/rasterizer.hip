@@ -184,7 +184,7 @@ struct Geom {
   float4* rec;           // [V][P][4]
   uint64_t* dkeys_a;     // [V*P] rect bits | view << 27 | rebased depth bits (see KEY_DEPTH_BITS)
   uint64_t* dkeys_b;
-  int32_t* order_a;      // [V*P] Gaussian ids; order_b = per-view front-to-back order
+  int32_t* order_a;      // (unused: the sort generates ids on the fly); order_b = per-view front-to-back order
   int32_t* order_b;
   int32_t* offs;         // [V*P] exclusive scan of tiles in depth order
   void* sort_temp;
@@ -201,7 +201,7 @@ Geom carve_geom(void* p, int64_t P, int V) {
   g.rec = c.take<float4>(P * V * 4);
   g.dkeys_a = c.take<uint64_t>(P * V);
   g.dkeys_b = c.take<uint64_t>(P * V);
-  g.order_a = c.take<int32_t>(P * V);
+  g.order_a = nullptr;
   g.order_b = c.take<int32_t>(P * V);
   g.offs = c.take<int32_t>(P * V);
   g.sort_temp_bytes = sort_pairs_temp_bytes(P * V);
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const float* __restrict__ opacities, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, int W, int H,
     int32_t* __restrict__ radii, float4* __restrict__ rec, uint64_t* __restrict__ dkeys,
-    int32_t* __restrict__ order, int32_t* __restrict__ far_flag) {
+    int32_t* __restrict__ far_flag) {
   __shared__ float4 s_sh[SH16 ? 256 * SH_ROW : 1];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float shr[SH16 ? 48 : 1];
@@ -406,7 +406,6 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     }
     radii[o] = out_radius;
     dkeys[o] = out_key;
-    order[o] = i;
     float4* r = rec + 4 * o;
     if (out_radius > 0) {  // culled Gaussians are never gathered: their 64-B line is not touched at all
       r[0] = make_float4(out_xy.x, out_xy.y, out_sxx, out_syy);
@@ -778,7 +777,7 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
 #define GR_PRE(SH, COV, S16)                                                                       \
   hipLaunchKernelGGL((preprocess_kernel<SH, COV, S16>), grd, blk, 0, stream, (int)P, D, M, num_views, \
                      g.views, means3D, shs, colors_precomp, opacities, scales, rotations,          \
-                     cov3D_precomp, W, H, radii, g.rec, g.dkeys_a, g.order_a, g.totals + num_views)
+                     cov3D_precomp, W, H, radii, g.rec, g.dkeys_a, g.totals + num_views)
   GR_HIP(hipMemsetAsync(g.totals + num_views, 0, sizeof(int32_t), stream));  // depth-overflow flag
   {
     KernelTimer timer("raster_preprocess", stream);
@@ -796,8 +795,8 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
   auto sort_and_count = [&](int end_bit) -> int {
     {
       KernelTimer timer("raster_sort", stream);
-      int rcs = sort_pairs_u64_i32(g.sort_temp, g.sort_temp_bytes, g.dkeys_a, g.dkeys_b, g.order_a, g.order_b,
-                                   P * num_views, 0, end_bit, stream);
+      int rcs = sort_pairs_u64_iota(g.sort_temp, g.sort_temp_bytes, g.dkeys_a, g.dkeys_b, P, g.order_b,
+                                    P * num_views, 0, end_bit, stream);
       if (rcs != GR_OK) return rcs;
     }
     hipLaunchKernelGGL(tiles_from_keys_kernel, dim3((unsigned)((P * num_views + 255) / 256)), blk, 0, stream,
