@@ -75,14 +75,16 @@ RadiusWs carve(void* ws, int64_t nq, int64_t ns, int64_t batch) {
   w.bbox = c.take<uint32_t>(batch * 6);
   w.blk_off = c.take<int32_t>(batch + 1);
   w.grids = c.take<BatchGrid>(batch);
+  // support side first (sizes depend on ns and batch only): a later call with other queries finds it in place
   w.s_cell = c.take<int32_t>(ns);
-  w.q_cell = c.take<int32_t>(nq);
   w.s_rank = c.take<int32_t>(ns);
-  w.q_rank = c.take<int32_t>(nq);
   w.cnt = c.take<int32_t>(2 * (w.ccap + 1));
   w.start = c.take<int32_t>(2 * (w.ccap + 1));
   w.scan_ws = c.take<int32_t>(2 * scan_ws_ints(w.ccap + 1));
   w.sorted_s = c.take<float4>(ns);
+  // query side
+  w.q_cell = c.take<int32_t>(nq);
+  w.q_rank = c.take<int32_t>(nq);
   w.sorted_q = c.take<float4>(nq);
   w.q_count = c.take<int32_t>(3 * nq);
   w.q_rng = c.take<int2>(9 * nq);
@@ -138,14 +140,32 @@ __global__ void grid_setup_kernel(const uint32_t* __restrict__ bbox,
     g.cell_base = 0;
     grids[b] = g;
   }
+  // exclusive prefix of the per-cloud cell counts: chunks of blockDim clouds, running carry in LDS
+  // (a serial loop over global memory cost ~0.2 us per cloud)
+  __shared__ int s_cnt[256];
+  __shared__ int s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int base = 0;
-    for (int b = 0; b < nb; ++b) {
-      grids[b].cell_base = base;
-      base += grids[b].dim[0] * grids[b].dim[1] * grids[b].dim[2];
+  for (int b0 = 0; b0 < nb; b0 += blockDim.x) {
+    const int b = b0 + threadIdx.x;
+    const int cells = b < nb ? grids[b].dim[0] * grids[b].dim[1] * grids[b].dim[2] : 0;
+    s_cnt[threadIdx.x] = cells;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int acc = s_carry;
+      for (int k = 0; k < (int)blockDim.x; ++k) {
+        const int c = s_cnt[k];
+        s_cnt[k] = acc;
+        acc += c;
+      }
+      s_carry = acc;
     }
-    hdr->total_cells = base;
+    __syncthreads();
+    if (b < nb) grids[b].cell_base = s_cnt[threadIdx.x];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    hdr->total_cells = s_carry;
     hdr->max_count = 0;
     hdr->max_block_hits = 0;
   }
@@ -724,6 +744,14 @@ extern "C" int gr_radius_count(const float* q, const float* s, const int64_t* h_
                                const int64_t* h_s_lengths, int64_t nq, int64_t ns, int64_t batch,
                                float radius, void* ws, size_t ws_bytes, int64_t* h_info,
                                void* stream_) {
+  return gr_radius_count_cached(q, s, h_q_lengths, h_s_lengths, nq, ns, batch, radius, ws, ws_bytes, h_info, nullptr, 0,
+                                stream_);
+}
+
+extern "C" int gr_radius_count_cached(const float* q, const float* s, const int64_t* h_q_lengths,
+                                      const int64_t* h_s_lengths, int64_t nq, int64_t ns, int64_t batch,
+                                      float radius, void* ws, size_t ws_bytes, int64_t* h_info,
+                                      int64_t* h_support_sig, int reuse_support, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   GR_REQUIRE(h_info != nullptr, "h_info is null");
   h_info[0] = h_info[1] = h_info[2] = h_info[3] = 0;
@@ -745,6 +773,23 @@ extern "C" int gr_radius_count(const float* q, const float* s, const int64_t* h_
     return GR_ERR_WORKSPACE;
   }
   const bool same = (q == s) && (nq == ns) && memcmp(h_q_lengths, h_s_lengths, sizeof(int64_t) * batch) == 0;
+  // signature of the support side (cloud pointer, sizes, radius, lengths): lets a caller that searches the same
+  // supports again (other queries, same radius -- the three searches per level of the data pyramid) skip the binning
+  int64_t sig[4] = {ns, batch, 0, (int64_t)reinterpret_cast<uintptr_t>(s)};
+  {
+    uint32_t rb;
+    memcpy(&rb, &radius, 4);
+    uint64_t hsh = 1469598103934665603ull ^ rb;
+    for (int64_t b = 0; b < batch; ++b) hsh = (hsh ^ (uint64_t)h_s_lengths[b]) * 1099511628211ull;
+    sig[2] = (int64_t)hsh;
+  }
+  const bool reuse = reuse_support != 0;
+  if (reuse) {
+    GR_REQUIRE(h_support_sig != nullptr, "reuse_support needs the signature written by the preparing call");
+    GR_REQUIRE(memcmp(sig, h_support_sig, sizeof(sig)) == 0,
+               "reuse_support: supports / lengths / radius differ from the call that prepared this workspace");
+  }
+  if (h_support_sig) memcpy(h_support_sig, sig, sizeof(sig));
   // offsets (host -> device)
   std::vector<int32_t> tmpv(3 * (batch + 1));  // q offsets | s offsets | bbox block offsets
   {
@@ -756,29 +801,44 @@ extern "C" int gr_radius_count(const float* q, const float* s, const int64_t* h_
       tmp[batch + 1 + b + 1] = tmp[batch + 1 + b] + (int32_t)h_s_lengths[b];
     }
     GR_HIP(hipMemcpyAsync(w.q_off, tmp, sizeof(int32_t) * (batch + 1), hipMemcpyHostToDevice, stream));
-    GR_HIP(hipMemcpyAsync(w.s_off, tmp + batch + 1, sizeof(int32_t) * (batch + 1), hipMemcpyHostToDevice, stream));
+    if (!reuse)
+      GR_HIP(hipMemcpyAsync(w.s_off, tmp + batch + 1, sizeof(int32_t) * (batch + 1), hipMemcpyHostToDevice, stream));
   }
   const int nb = (int)batch;
-  const int rows = same ? 1 : 2;
-  GR_HIP(hipMemsetAsync(w.cnt, 0, sizeof(int32_t) * rows * (w.ccap + 1), stream));
-  {
-    int rcb = compute_bbox(s, tmpv.data() + batch + 1, tmpv.data() + 2 * (batch + 1), w.s_off, nb, w.bbox, w.blk_off, stream);
-    if (rcb != GR_OK) return rcb;
-  }
-  hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(256), 0, stream, w.bbox, w.s_off, nb, radius, w.grids, w.hdr);
   int32_t* cnt_s = w.cnt;
   int32_t* cnt_q = same ? w.cnt : w.cnt + (w.ccap + 1);
   int32_t* start_s = w.start;
   int32_t* start_q = same ? w.start : w.start + (w.ccap + 1);
-  const int nq_bin = same ? 0 : (int)nq;
-  hipLaunchKernelGGL(bin_count_kernel, dim3((ns + nq_bin + 255) / 256), dim3(256), 0, stream, s, (int)ns, q, nq_bin,
-                     w.s_off, w.q_off, nb, w.grids, w.s_cell, w.q_cell, w.s_rank, w.q_rank, cnt_s, cnt_q);
-  GR_LAUNCH_CHECK();
-  int rc = exclusive_scan_i32(w.cnt, w.start, w.ccap + 1, rows, w.ccap + 1, w.scan_ws, nullptr, stream,
-                              &w.hdr->total_cells);
-  if (rc != GR_OK) return rc;
-  hipLaunchKernelGGL(scatter_kernel, dim3((ns + nq_bin + 255) / 256), dim3(256), 0, stream, s, (int)ns, q, nq_bin,
-                     w.s_cell, w.q_cell, start_s, start_q, w.s_rank, w.q_rank, w.sorted_s, w.sorted_q);
+  int rc = GR_OK;
+  if (!reuse) {
+    // ---- supports (and, in the same launches, the queries): bbox, grid, histogram, scan, scatter
+    const int rows = same ? 1 : 2;
+    GR_HIP(hipMemsetAsync(w.cnt, 0, sizeof(int32_t) * rows * (w.ccap + 1), stream));
+    {
+      int rcb = compute_bbox(s, tmpv.data() + batch + 1, tmpv.data() + 2 * (batch + 1), w.s_off, nb, w.bbox, w.blk_off, stream);
+      if (rcb != GR_OK) return rcb;
+    }
+    hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(256), 0, stream, w.bbox, w.s_off, nb, radius, w.grids, w.hdr);
+    const int nq_bin = same ? 0 : (int)nq;
+    hipLaunchKernelGGL(bin_count_kernel, dim3((ns + nq_bin + 255) / 256), dim3(256), 0, stream, s, (int)ns, q, nq_bin,
+                       w.s_off, w.q_off, nb, w.grids, w.s_cell, w.q_cell, w.s_rank, w.q_rank, cnt_s, cnt_q);
+    GR_LAUNCH_CHECK();
+    rc = exclusive_scan_i32(w.cnt, w.start, w.ccap + 1, rows, w.ccap + 1, w.scan_ws, nullptr, stream,
+                            &w.hdr->total_cells);
+    if (rc != GR_OK) return rc;
+    hipLaunchKernelGGL(scatter_kernel, dim3((ns + nq_bin + 255) / 256), dim3(256), 0, stream, s, (int)ns, q, nq_bin,
+                       w.s_cell, w.q_cell, start_s, start_q, w.s_rank, w.q_rank, w.sorted_s, w.sorted_q);
+  } else if (!same) {
+    // ---- the support grid is in place: only the queries are binned into it
+    GR_HIP(hipMemsetAsync(cnt_q, 0, sizeof(int32_t) * (w.ccap + 1), stream));
+    hipLaunchKernelGGL(bin_count_kernel, dim3((nq + 255) / 256), dim3(256), 0, stream, s, 0, q, (int)nq, w.s_off,
+                       w.q_off, nb, w.grids, w.s_cell, w.q_cell, w.s_rank, w.q_rank, cnt_s, cnt_q);
+    GR_LAUNCH_CHECK();
+    rc = exclusive_scan_i32(cnt_q, start_q, w.ccap + 1, 1, w.ccap + 1, w.scan_ws, nullptr, stream, &w.hdr->total_cells);
+    if (rc != GR_OK) return rc;
+    hipLaunchKernelGGL(scatter_kernel, dim3((nq + 255) / 256), dim3(256), 0, stream, s, 0, q, (int)nq, w.s_cell,
+                       w.q_cell, start_s, start_q, w.s_rank, w.q_rank, w.sorted_s, w.sorted_q);
+  }
   const float4* sorted_q = same ? w.sorted_s : w.sorted_q;
   const float r2 = radius * radius;  // radius_neighbors_cpu.cpp:12 (fp32 product)
   rc = launch_count<RT>(w, sorted_q, nq, nb, start_s, r2, same, stream);

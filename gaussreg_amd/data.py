@@ -5,6 +5,7 @@ order with the same parameters; tensors stay on the GPU between calls (the refer
 the CPU inside the DataLoader collate_fn and copies everything to the GPU afterwards)."""
 import torch
 
+from . import ext
 from .ops import grid_subsample, radius_search
 
 
@@ -19,17 +20,20 @@ def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, 
         points_list.append(points)
         lengths_list.append(lengths)
         voxel_size *= 2
-    # radius search (data.py:31-69)
+    # radius search (data.py:31-69).  Level i's supports with radius r_i serve three searches (up-sampling of level
+    # i-1, self, sub-sampling of level i+1): one SupportGrid per level bins them once.
+    on_gpu = points_list[0].is_cuda
+    grids = [ext.SupportGrid(points_list[max(i - 1, 0)].shape[0]) if on_gpu else None for i in range(num_stages)]
     for i in range(num_stages):
         cur_points, cur_lengths = points_list[i], lengths_list[i]
         neighbors_list.append(radius_search(cur_points, cur_points, cur_lengths, cur_lengths, radius,
-                                            neighbor_limits[i]))
+                                            neighbor_limits[i], grid=grids[i]))
         if i < num_stages - 1:
             sub_points, sub_lengths = points_list[i + 1], lengths_list[i + 1]
             subsampling_list.append(radius_search(sub_points, cur_points, sub_lengths, cur_lengths, radius,
-                                                  neighbor_limits[i]))
+                                                  neighbor_limits[i], grid=grids[i]))
             upsampling_list.append(radius_search(cur_points, sub_points, cur_lengths, sub_lengths, radius * 2,
-                                                 neighbor_limits[i + 1]))
+                                                 neighbor_limits[i + 1], grid=grids[i + 1]))
         radius *= 2
     return {'points': points_list, 'lengths': lengths_list, 'neighbors': neighbors_list,
             'subsampling': subsampling_list, 'upsampling': upsampling_list}

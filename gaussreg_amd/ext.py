@@ -43,47 +43,40 @@ def _check_points(x, name):
         raise RuntimeError(f"{name} must have shape (N, 3)")
 
 
-def radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius):
-    dev = _lib.require_gpu()
-    L = _lib.lib()
-    for t, n in ((q_points, "q_points"), (s_points, "s_points")):
-        _check_points(t, n)
-        _check_float(t, n)
-    for t, n in ((q_lengths, "q_lengths"), (s_lengths, "s_lengths")):
-        _check_long(t, n)
-    for t, n in ((q_points, "q_points"), (s_points, "s_points"), (q_lengths, "q_lengths"), (s_lengths, "s_lengths")):
-        _check_contig(t, n)
-    if q_lengths.numel() != s_lengths.numel():
-        raise RuntimeError("q_lengths and s_lengths must have the same number of batch elements")
-    out_device = q_points.device
-    same = s_points is q_points or (s_points.data_ptr() == q_points.data_ptr() and s_points.shape == q_points.shape)
-    q = q_points if q_points.is_cuda else q_points.to(dev)
-    s = q if same else (s_points if s_points.is_cuda else s_points.to(dev))
-    dev = q.device
-    ql = q_lengths.tolist()
-    sl = s_lengths.tolist()
-    nq, ns, nb = q.shape[0], s.shape[0], len(ql)
-    hq, hs = _lib.host_i64(ql), _lib.host_i64(sl)
-    with torch.cuda.device(dev):
-        nbytes = L.gr_radius_workspace_bytes(nq, ns, nb)
-        ws = _lib.workspace(dev, nbytes)
-        info = (ctypes.c_int64 * 4)()
-        st = _lib.stream_ptr(dev)
-        _lib.check(L.gr_radius_count(_lib.ptr(q), _lib.ptr(s), hq, hs, nq, ns, nb, float(radius), _lib.ptr(ws),
-                                     ws.numel(), info, st))
-        width = int(info[0])
-        out = torch.empty((nq, width), dtype=torch.int64, device=dev)
-        if nq > 0 and width > 0:
-            _lib.check(L.gr_radius_fill(_lib.ptr(q), _lib.ptr(s), nq, ns, nb, float(radius), width, info,
-                                        _lib.ptr(out), _lib.ptr(ws), ws.numel(), st))
-    return out if out_device.type == "cuda" else out.to(out_device)
+class SupportGrid:
+    """Cell grid of one support cloud, kept between searches that use the SAME supports, lengths and radius with
+    different queries (the data pyramid does three per level, geotransformer/utils/data.py:44-75): the first search
+    bins the supports, the following ones only bin their queries (gr_radius_count_cached).  Owns its workspace, sized
+    for the largest query set announced in `max_queries`.  The support tensor must not be modified in between."""
+
+    def __init__(self, max_queries):
+        self.max_queries = int(max_queries)
+        self.ws = None
+        self.sig = (ctypes.c_int64 * 4)()
+        self.key = None          # (data_ptr, ns, nb, radius): what the grid was built for
+        self._keep = None        # keeps the support tensor alive
+
+    def workspace(self, L, dev, nq, ns, nb):
+        need = L.gr_radius_workspace_bytes(max(nq, self.max_queries), ns, nb)
+        if self.ws is None or self.ws.numel() < need or self.ws.device != dev:
+            self.ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+            self.key = None      # a new buffer holds no grid
+        return self.ws
 
 
-def radius_neighbors_limited(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit):
-    """radius_neighbors + the column truncation of modules/ops/radius_search.py:25-26 done inside the
-    fill kernel: only min(max_count, neighbor_limit) columns are ever written (contiguous result)."""
+def _radius(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, grid, checks):
     dev = _lib.require_gpu()
     L = _lib.lib()
+    if checks:
+        for t, n in ((q_points, "q_points"), (s_points, "s_points")):
+            _check_points(t, n)
+            _check_float(t, n)
+        for t, n in ((q_lengths, "q_lengths"), (s_lengths, "s_lengths")):
+            _check_long(t, n)
+        for t, n in ((q_points, "q_points"), (s_points, "s_points"), (q_lengths, "q_lengths"), (s_lengths, "s_lengths")):
+            _check_contig(t, n)
+        if q_lengths.numel() != s_lengths.numel():
+            raise RuntimeError("q_lengths and s_lengths must have the same number of batch elements")
     out_device = q_points.device
     same = s_points is q_points or (s_points.data_ptr() == q_points.data_ptr() and s_points.shape == q_points.shape)
     q = q_points if q_points.is_cuda else q_points.to(dev)
@@ -93,19 +86,39 @@ def radius_neighbors_limited(q_points, s_points, q_lengths, s_lengths, radius, n
     nq, ns, nb = q.shape[0], s.shape[0], len(ql)
     hq, hs = _lib.host_i64(ql), _lib.host_i64(sl)
     with torch.cuda.device(dev):
-        ws = _lib.workspace(dev, L.gr_radius_workspace_bytes(nq, ns, nb))
         info = (ctypes.c_int64 * 4)()
         st = _lib.stream_ptr(dev)
-        _lib.check(L.gr_radius_count(_lib.ptr(q), _lib.ptr(s), hq, hs, nq, ns, nb, float(radius), _lib.ptr(ws),
-                                     ws.numel(), info, st))
+        if grid is None:
+            ws = _lib.workspace(dev, L.gr_radius_workspace_bytes(nq, ns, nb))
+            _lib.check(L.gr_radius_count(_lib.ptr(q), _lib.ptr(s), hq, hs, nq, ns, nb, float(radius), _lib.ptr(ws),
+                                         ws.numel(), info, st))
+        else:
+            ws = grid.workspace(L, dev, nq, ns, nb)
+            key = (s.data_ptr(), ns, nb, float(radius), tuple(sl))
+            reuse = 1 if (grid.key == key and ns > 0 and nq > 0) else 0
+            _lib.check(L.gr_radius_count_cached(_lib.ptr(q), _lib.ptr(s), hq, hs, nq, ns, nb, float(radius), _lib.ptr(ws),
+                                                ws.numel(), info, grid.sig, reuse, st))
+            grid.key = key if (ns > 0 and nq > 0 and nb > 0) else None
+            grid._keep = s
         width = int(info[0])
-        if neighbor_limit > 0:
+        if neighbor_limit is not None and neighbor_limit > 0:
             width = min(width, int(neighbor_limit))
         out = torch.empty((nq, width), dtype=torch.int64, device=dev)
         if nq > 0 and width > 0:
             _lib.check(L.gr_radius_fill(_lib.ptr(q), _lib.ptr(s), nq, ns, nb, float(radius), width, info,
                                         _lib.ptr(out), _lib.ptr(ws), ws.numel(), st))
     return out if out_device.type == "cuda" else out.to(out_device)
+
+
+def radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius, grid=None):
+    """`grid`: optional SupportGrid shared by consecutive searches over the same supports and radius."""
+    return _radius(q_points, s_points, q_lengths, s_lengths, radius, None, grid, True)
+
+
+def radius_neighbors_limited(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, grid=None):
+    """radius_neighbors + the column truncation of modules/ops/radius_search.py:25-26 done inside the
+    fill kernel: only min(max_count, neighbor_limit) columns are ever written (contiguous result)."""
+    return _radius(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, grid, False)
 
 
 def grid_subsampling(points, lengths, voxel_size, order="reference"):

@@ -64,6 +64,15 @@ size_t gr_radius_workspace_bytes(int64_t nq, int64_t ns, int64_t batch);
 int gr_radius_count(const float* q, const float* s, const int64_t* h_q_lengths,
                     const int64_t* h_s_lengths, int64_t nq, int64_t ns, int64_t batch, float radius,
                     void* ws, size_t ws_bytes, int64_t* h_info /*[4]*/, void* stream);
+/* Same as gr_radius_count, for callers that search the SAME supports (pointer, lengths, radius) several times with
+ * different queries -- the data pyramid does so three times per level (geotransformer/utils/data.py:44-75).  The
+ * call with reuse_support = 0 bins the supports and writes a signature to h_support_sig[4]; later calls with
+ * reuse_support = 1, the same `ws` (sized for the largest nq used) and that signature skip the support binning
+ * (checked: a different cloud pointer / lengths / radius is an error).  The support data must not change between. */
+int gr_radius_count_cached(const float* q, const float* s, const int64_t* h_q_lengths,
+                           const int64_t* h_s_lengths, int64_t nq, int64_t ns, int64_t batch, float radius,
+                           void* ws, size_t ws_bytes, int64_t* h_info /*[4]*/, int64_t* h_support_sig /*[4]*/,
+                           int reuse_support, void* stream);
 int gr_radius_fill(const float* q, const float* s, int64_t nq, int64_t ns, int64_t batch,
                    float radius, int64_t width, const int64_t* h_info /*[4]*/, int64_t* out,
                    void* ws, size_t ws_bytes, void* stream);

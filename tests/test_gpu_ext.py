@@ -179,3 +179,26 @@ def test_200k_properties():
     # grid subsample: count as on the reference, rows of every voxel average back into the voxel
     sp, sl = _ext().grid_subsampling(d, lens, 0.05)
     assert sl.tolist() == [74011]
+
+
+def test_support_grid_reuse_gives_identical_results():
+    """Searches that share a SupportGrid (same supports + radius, other queries) must equal independent searches,
+    and a changed support / radius must not be served from the cache."""
+    ext = _ext()
+    rng = np.random.default_rng(9)
+    s = _t((rng.random((9000, 3)) * [2.0, 1.5, 1.0]).astype(np.float32))
+    q1 = _t((rng.random((4000, 3)) * [2.2, 1.5, 1.0] - [0.1, 0, 0]).astype(np.float32))
+    q2 = _t((rng.random((12000, 3)) * [2.0, 1.5, 1.0]).astype(np.float32))
+    sl = torch.tensor([5000, 4000])
+    grid = ext.SupportGrid(max_queries=12000)
+    pairs = [(q2, torch.tensor([7000, 5000])), (s, sl), (q1, torch.tensor([1500, 2500])), (s, sl)]
+    for q, ql in pairs:   # first call builds (q != s), then self-search and another query set reuse it
+        got = ext.radius_neighbors(q, s, ql, sl, 0.11, grid=grid)
+        want = ext.radius_neighbors(q, s, ql, sl, 0.11)
+        assert torch.equal(got, want)
+        lim = ext.radius_neighbors_limited(q, s, ql, sl, 0.11, 7, grid=grid)
+        assert torch.equal(lim, want[:, :7])
+    # other radius / other supports with the same grid object: rebuilt, not reused
+    assert torch.equal(ext.radius_neighbors(q1, s, pairs[2][1], sl, 0.2, grid=grid), ext.radius_neighbors(q1, s, pairs[2][1], sl, 0.2))
+    s2 = s.clone() * 0.5
+    assert torch.equal(ext.radius_neighbors(q1, s2, pairs[2][1], sl, 0.2, grid=grid), ext.radius_neighbors(q1, s2, pairs[2][1], sl, 0.2))
