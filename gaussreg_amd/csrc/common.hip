@@ -50,12 +50,8 @@ constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = SCAN_T * SCAN_ITEMS;  // 2048 elements per block
 
 __device__ inline int wave_incl_scan(int v, int lane) {
-#pragma unroll
-  for (int d = 1; d < WAVE; d <<= 1) {
-    int t = __shfl_up(v, d, WAVE);
-    if (lane >= d) v += t;
-  }
-  return v;
+  (void)lane;
+  return wave_incl_scan_add_dpp(v);
 }
 
 // block-wide exclusive scan of one int per thread (256 threads); returns exclusive prefix, *total

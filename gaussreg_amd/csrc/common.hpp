@@ -117,6 +117,18 @@ int sort_pairs_u32_i32(void* temp, size_t temp_bytes, const uint32_t* keys_in, u
                        int end_bit, hipStream_t stream);
 
 // lower_bound over a small ascending int32 offsets table: largest b with off[b] <= i (b < nb)
+// ---- wave64 scan / reduction on the DPP shift network (row_shr 1/2/4/8 inside 16-lane rows, row_bcast 15/31 across
+// rows): six dependent VALU ops instead of six ds_bpermute round trips.  `old` = identity for lanes without a source.
+__device__ __forceinline__ int wave_incl_scan_add_dpp(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
 __device__ inline int find_batch(const int32_t* __restrict__ off, int nb, int32_t i) {
   int lo = 0, hi = nb;  // off has nb+1 entries
   while (hi - lo > 1) {

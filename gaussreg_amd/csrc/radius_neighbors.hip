@@ -344,12 +344,7 @@ __global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))
     }
     const int tot = c[0] + c[1] + c[2];
     const int tot2 = (tot + 1) & ~1;  // segments start on even slots: the rank loop reads two keys per ds_read_b128
-    int inc = tot2;
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-      int v = __shfl_up(inc, d, WAVE);
-      if (lane >= d) inc += v;
-    }
+    const int inc = wave_incl_scan_add_dpp(tot2);
     if (lane == WAVE - 1) wsum[tid / WAVE] = inc;
     __syncthreads();
     int base = 0;
