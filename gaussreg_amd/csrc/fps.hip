@@ -199,6 +199,7 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ pt
 // because accepting samples only lowers other points' distances.  So every round accepts the longest such prefix
 // (always >= 1: c_1 is the arg-max) -- at 30 000 of 200 000 points about 7 of 8 candidates, i.e. 7x fewer rounds.
 // Threads contribute their best point; their second best is folded into B, which keeps the rule exact.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int FPS_M = 8;                       // candidates per round (M * M <= 64: pair checks by one wave)
 constexpr int FPS_MW = 4;                      // candidates a single wave passes up (the global top 8 almost never
                                                // holds more than a few points of one wave; the rest raises the bound B)
@@ -267,18 +268,29 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
   for (unsigned round = 1; count < k; ++round) {
     // ---- 1. fold the samples accepted last round into the running distances; per-thread best and runner-up
     const int na = s_na;
+    // sample-major: one LDS read of the sample, then all of this thread's points two at a time (packed fp32 --
+    // the same sub / mul / add sequence as the scalar form, so distances stay bit-identical)
+    for (int a = 0; a < na; ++a) {
+      const float ax = s_acc[a][0], ay = s_acc[a][1], az = s_acc[a][2];
+      const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
+#pragma unroll
+      for (int j = 0; j + 1 < PPT; j += 2) {
+        const f32x2 dx = f32x2{px[j], px[j + 1]} - ax2, dy = f32x2{py[j], py[j + 1]} - ay2, dz = f32x2{pz[j], pz[j + 1]} - az2;
+        const f32x2 dd = (dx * dx + dy * dy) + dz * dz;
+        pd[j] = fminf(pd[j], dd.x);
+        pd[j + 1] = fminf(pd[j + 1], dd.y);
+      }
+      if (PPT & 1) {
+        const float dx = px[PPT - 1] - ax, dy = py[PPT - 1] - ay, dz = pz[PPT - 1] - az;
+        pd[PPT - 1] = fminf(pd[PPT - 1], (dx * dx + dy * dy) + dz * dz);
+      }
+    }
     unsigned long long best = 0ull, second = 0ull;
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
       const int i = lo + j * FPS_T + threadIdx.x;
       if (i < hi) {
-        float d = pd[j];
-        for (int a = 0; a < na; ++a) {
-          const float dx = px[j] - s_acc[a][0], dy = py[j] - s_acc[a][1], dz = pz[j] - s_acc[a][2];
-          d = fminf(d, (dx * dx + dy * dy) + dz * dz);
-        }
-        pd[j] = d;
-        const unsigned long long kk = fps_key(d, i);
+        const unsigned long long kk = fps_key(pd[j], i);
         if (kk > best) {
           second = best;
           best = kk;
