@@ -21,7 +21,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int GE_ROWS = 128;  // (n,m) pairs per workgroup
 constexpr int GE_COLS = 256;  // output channels per workgroup
-constexpr int GE_K = 16;      // K slab
+constexpr int GE_K = 32;      // K slab
 constexpr int GE_LD = GE_K + 1;
 constexpr int GE_T = 512;
 constexpr int GE_KMAX = 8;    // angle_k <= 8
@@ -33,6 +33,7 @@ __device__ __forceinline__ float sq_dist_ref(const float3 a, float a2, const flo
 }
 __device__ __forceinline__ float3 ld3(const float* p, int i) { return make_float3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
 __device__ __forceinline__ float norm2(const float3 a) { return (a.x * a.x + a.y * a.y) + a.z * a.z; }
+
 
 // k nearest other points per point: geotransformer.py:42 topk(k+1, largest=False)[1][:, :, 1:]
 // (ascending distance, the first -- the point itself -- dropped; ties: lowest index first).  One wave per point.
@@ -125,37 +126,38 @@ __global__ __launch_bounds__(GE_T) void geo_embedding_kernel(
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f, red[a][b][r] = 0.f;
 
   // staging registers: A = 128 rows x 8 frequencies (sin, cos) -> 2 per thread; B = 256 cols x 16 k -> 8 per thread
-  float ra_s[2], ra_c[2], rb[8];
+  constexpr int NA = GE_ROWS * (GE_K / 2) / GE_T, NB = GE_COLS * GE_K / GE_T, NF = GE_K / 2;
+  float ra_s[NA], ra_c[NA], rb[NB];
   const int slabs = C / GE_K;  // C % 16 == 0 (checked by the host)
   auto gen = [&](int phase, int k0) {
     const float* W = phase < k ? w_a : w_d;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NA; ++u) {
       const int e = tid + u * GE_T;
-      const int r = e >> 3, f = e & 7;
+      const int r = e / NF, f = e % NF;
       const float omega = xs[phase][r] * div_term[(k0 >> 1) + f];  // positional_embedding.py:27
       sincosf(omega, &ra_s[u], &ra_c[u]);
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < NB; ++u) {
       const int e = tid + u * GE_T;
-      const int j = e >> 4, kk = e & 15;
+      const int j = e / GE_K, kk = e % GE_K;
       const int gj = j0 + j;
       rb[u] = gj < C ? W[(int64_t)gj * C + k0 + kk] : 0.f;  // nn.Linear: y = x W^T
     }
   };
   auto store = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NA; ++u) {
       const int e = tid + u * GE_T;
-      const int r = e >> 3, f = e & 7;
+      const int r = e / NF, f = e % NF;
       sa[buf][r][2 * f] = ra_s[u];  // positional_embedding.py:30-31: (sin, cos) interleaved
       sa[buf][r][2 * f + 1] = ra_c[u];
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < NB; ++u) {
       const int e = tid + u * GE_T;
-      sb[buf][e >> 4][e & 15] = rb[u];
+      sb[buf][e / GE_K][e % GE_K] = rb[u];
     }
   };
 
@@ -233,7 +235,7 @@ extern "C" int gr_geo_embedding(const float* points, int64_t n, const float* w_d
                                 void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   GR_REQUIRE(n >= 0 && n < 46341, "geo_embedding: n*n must fit int32 pair ids per row (n=%lld)", (long long)n);
-  GR_REQUIRE(c > 0 && c % GE_K == 0, "geo_embedding: hidden_dim must be a positive multiple of 16 (got %lld)", (long long)c);
+  GR_REQUIRE(c > 0 && c % GE_K == 0, "geo_embedding: hidden_dim must be a positive multiple of 32 (got %lld)", (long long)c);
   GR_REQUIRE(angle_k >= 0 && angle_k <= GE_KMAX, "geo_embedding: angle_k must be in [0, %d]", GE_KMAX);
   GR_REQUIRE(angle_k < n || n == 0, "geo_embedding: angle_k (%lld) needs more than %lld points", (long long)angle_k, (long long)n);
   if (n == 0) return GR_OK;
