@@ -129,6 +129,25 @@ __device__ __forceinline__ int wave_incl_scan_add_dpp(int v) {
   return v;
 }
 
+// wave-wide min / max / sum of an int on the same network; the result is valid in every lane (read back from lane 63)
+#define GR_DPP_REDUCE(NAME, OP, IDENT)                                                         \
+  __device__ __forceinline__ int NAME(int v) {                                                 \
+    v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x111, 0xf, 0xf, false));                  \
+    v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x112, 0xf, 0xf, false));                  \
+    v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x114, 0xf, 0xf, false));                  \
+    v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x118, 0xf, 0xf, false));                  \
+    v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x142, 0xa, 0xf, false));                  \
+    v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x143, 0xc, 0xf, false));                  \
+    return __builtin_amdgcn_readlane(v, 63);                                                   \
+  }
+#define GR_OP_MIN(a, b) min(a, b)
+#define GR_OP_MAX(a, b) max(a, b)
+#define GR_OP_ADD(a, b) ((a) + (b))
+GR_DPP_REDUCE(wave_min_i32_dpp, GR_OP_MIN, 0x7fffffff)
+GR_DPP_REDUCE(wave_max_i32_dpp, GR_OP_MAX, (int)0x80000000)
+GR_DPP_REDUCE(wave_sum_i32_dpp, GR_OP_ADD, 0)
+#undef GR_DPP_REDUCE
+
 __device__ inline int find_batch(const int32_t* __restrict__ off, int nb, int32_t i) {
   int lo = 0, hi = nb;  // off has nb+1 entries
   while (hi - lo > 1) {

@@ -423,13 +423,8 @@ __global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))
           hi = __builtin_amdgcn_readlane(p1[i], __builtin_amdgcn_readfirstlane(63 - __clzll((long long)m)));
         }
       } else {
-        lo = has ? p0[i] : 0x7fffffff;
-        hi = has ? p1[i] : 0;
-#pragma unroll
-        for (int d = WAVE / 2; d > 0; d >>= 1) {
-          lo = min(lo, __shfl_xor(lo, d, WAVE));
-          hi = max(hi, __shfl_xor(hi, d, WAVE));
-        }
+        lo = wave_min_i32_dpp(has ? p0[i] : 0x7fffffff);
+        hi = wave_max_i32_dpp(has ? p1[i] : 0);
       }
       if (lane == 0 && hi > 0) {
         atomicMin(&band_lo[3 * j + i], lo);
@@ -584,12 +579,7 @@ __global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))
     __syncthreads();
     if (tid < RQ) {
       const int tot = sub[tid] + sub[RQ + tid] + sub[2 * RQ + tid];
-      int mx = tot, sm = tot;
-#pragma unroll
-      for (int d = WAVE / 2; d > 0; d >>= 1) {
-        mx = max(mx, __shfl_xor(mx, d, WAVE));
-        sm += __shfl_xor(sm, d, WAVE);
-      }
+      const int mx = wave_max_i32_dpp(tot), sm = wave_sum_i32_dpp(tot);
       if (lane == 0) {
         wsum[tid / WAVE] = mx;
         wsum[RQ / WAVE + tid / WAVE] = sm;
