@@ -17,6 +17,10 @@
 #include <cmath>
 #include <vector>
 
+#include <algorithm>
+#include <atomic>
+#include <thread>
+
 #include "common.hpp"
 
 namespace gr {
@@ -376,10 +380,22 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
       // container's own linking rules with the real libstdc++ rehash policy on flat arrays (no node
       // allocations).  Ranks are global but clouds are contiguous in rank.
       std::vector<int32_t> perm(h_m);
-      int64_t r0 = 0;
-      for (int64_t b = 0; b < batch; ++b) {
-        unordered_map_order(hk.data() + r0, h_mb[b], (int32_t)r0, perm.data() + r0);  // hash_order.hip
-        r0 += h_mb[b];
+      {
+        // clouds are independent: replay them on several host threads when there is enough work
+        // (128 clouds x 50 k voxels took 110 ms on one core -- 8x the whole device-side pyramid)
+        std::vector<int64_t> r0(batch + 1, 0);
+        for (int64_t b = 0; b < batch; ++b) r0[b + 1] = r0[b] + h_mb[b];
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const int64_t want = std::min<int64_t>({(int64_t)batch, (int64_t)hw, (int64_t)64, h_m / 40000 + 1});
+        std::atomic<int64_t> next_cloud{0};
+        auto worker = [&]() {
+          for (int64_t b = next_cloud.fetch_add(1); b < batch; b = next_cloud.fetch_add(1))
+            unordered_map_order(hk.data() + r0[b], h_mb[b], (int32_t)r0[b], perm.data() + r0[b]);  // hash_order.hip
+        };
+        std::vector<std::thread> pool;
+        for (int64_t t = 1; t < want; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto& th : pool) th.join();
       }
       GR_HIP(hipMemcpyAsync(w.perm, perm.data(), sizeof(int32_t) * h_m, hipMemcpyHostToDevice, stream));
       hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((h_m + 255) / 256)), blk, 0, stream, w.bary, w.cell_of_rank,

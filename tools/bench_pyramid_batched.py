@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests", "golde
 from gen_golden_ext import room_pair
 from gaussreg_amd.data import precompute_data_stack_mode
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+ORDER = sys.argv[2] if len(sys.argv) > 2 else "cell"
 limits = [89, 30, 43, 49, 49]
 clouds = []
 for b in range(B):
@@ -13,8 +14,8 @@ for b in range(B):
     clouds += [r_, s_]
 bp = torch.from_numpy(np.concatenate(clouds)).cuda()
 bl = torch.tensor([30000] * (2 * B))
-out = precompute_data_stack_mode(bp, bl, 5, 0.025, 0.0625, limits, order="cell")
+out = precompute_data_stack_mode(bp, bl, 5, 0.025, 0.0625, limits, order=ORDER)
 torch.cuda.synchronize(); t = time.perf_counter()
-for _ in range(5): out = precompute_data_stack_mode(bp, bl, 5, 0.025, 0.0625, limits, order="cell")
+for _ in range(5): out = precompute_data_stack_mode(bp, bl, 5, 0.025, 0.0625, limits, order=ORDER)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 5
-print(f"HIP pyramid, {B} pairs per call: {dt*1e3:.1f} ms -> {B/dt:.0f} pairs/s; level sizes {[p.shape[0] for p in out['points']]}")
+print(f"HIP pyramid ({ORDER} order), {B} pairs per call: {dt*1e3:.1f} ms -> {B/dt:.0f} pairs/s; level sizes {[p.shape[0] for p in out['points']]}")
