@@ -27,7 +27,9 @@ void unordered_map_order(const uint64_t* keys, int64_t n, int32_t base, int32_t*
   std::vector<int32_t> bucket(1, EMPTY);  // "before" node of each bucket (HEAD = the list head slot)
   std::vector<int32_t> next(static_cast<size_t>(n > 0 ? n : 1));
   int32_t head = NIL;
+  constexpr int64_t AHEAD = 12;  // the bucket array is hit at random: ask for the line a few inserts early
   for (int64_t i = 0; i < n; ++i) {
+    if (i + AHEAD < n) __builtin_prefetch(&bucket[static_cast<std::size_t>(keys[i + AHEAD]) % bkt_count], 1, 1);
     const auto need = policy._M_need_rehash(bkt_count, static_cast<std::size_t>(i), 1);
     if (need.first) {
       const std::size_t nb = need.second;
