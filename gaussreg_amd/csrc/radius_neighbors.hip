@@ -253,15 +253,16 @@ template <int RQ>
 struct TravLds {
   static constexpr int THREADS = NSUB * RQ;
   static constexpr int STAGE_CAP = 12 * RQ;  // candidates the block can stage
-  // ints: offs[RQ+1], orig[RQ], sub[3*RQ], band_lo[9], band_hi[9], band_base[10], wsum[THREADS/64]
-  static constexpr int TABLE_MAX = 64;  // clouds whose offsets / grids are cached in LDS
-  static constexpr int N_INTS = (RQ + 1) + RQ + NSUB * RQ + 9 + 9 + 10 + THREADS / WAVE + (TABLE_MAX + 1);
+  // ints: offs[RQ+1], orig[RQ], wsum[THREADS/64], sub[3*RQ], band_lo[9], band_hi[9], band_base[10]
+  static constexpr int TABLE_MAX = 256;  // clouds whose offsets / grids are cached in LDS (sized per launch)
+  static constexpr int N_INTS = (RQ + 1) + RQ + NSUB * RQ + 9 + 9 + 10 + THREADS / WAVE;
   static constexpr size_t TABLE_OFF = (size_t)(N_INTS * 4 + 15) / 16 * 16;
   // the FILL pass only needs offs, orig and wsum (laid out first): its hit segments start right after them
   static constexpr size_t FILL_OFF = (size_t)(((RQ + 1) + RQ + THREADS / WAVE) * 4 + 15) / 16 * 16;
-  static constexpr size_t INTS_BYTES = TABLE_OFF + (size_t)TABLE_MAX * 48;
+  // COUNT pass: [int tables | q offsets of `tcap` clouds | their grids | candidate planes]
+  static __host__ __device__ size_t tables_bytes(int tcap) { return tcap > 0 ? ((size_t)(tcap + 1) * 4 + 15) / 16 * 16 + (size_t)tcap * 48 : 0; }
   static constexpr size_t STAGE_BYTES = (size_t)STAGE_CAP * 12;  // three coordinate planes
-  static constexpr size_t FIXED = INTS_BYTES + STAGE_BYTES;
+  static size_t count_bytes(int tcap) { return TABLE_OFF + tables_bytes(tcap) + STAGE_BYTES; }
   // FILL: slots = hits + at most one pad slot per query, rounded to 16 so every block's key array stays 16-B aligned
   static int64_t slots(int64_t max_block_hits) { return (max_block_hits + RQ + 15) / 16 * 16; }
   static size_t total(int64_t slots) { return FILL_OFF + (size_t)slots * 9; }  // int tables + keys (8 B) + row ids (1 B)
@@ -286,9 +287,10 @@ __global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))
   int* band_base = band_hi + NBAND;
   // COUNT pass only: per-cloud tables cached in LDS so the per-query setup is not a chain of
   // dependent global round trips (query -> cloud id -> grid -> cell starts)
-  int* s_qoff = band_base + (NBAND + 1);
-  BatchGrid* s_grids = reinterpret_cast<BatchGrid*>(smem + L::TABLE_OFF);
-  float4* stage = reinterpret_cast<float4*>(smem + L::INTS_BYTES);
+  const int tcap = FILL ? 0 : (nb <= L::TABLE_MAX ? nb : 0);
+  int* s_qoff = reinterpret_cast<int*>(smem + L::TABLE_OFF);
+  BatchGrid* s_grids = reinterpret_cast<BatchGrid*>(smem + L::TABLE_OFF + ((size_t)(tcap + 1) * 4 + 15) / 16 * 16);
+  float4* stage = reinterpret_cast<float4*>(smem + L::TABLE_OFF + L::tables_bytes(tcap));
   // FILL keeps no candidate stage: its hit segments start right after the int tables
   unsigned long long* hits = HITS_IN_LDS ? reinterpret_cast<unsigned long long*>(smem + L::FILL_OFF)
                                          : g_hits + (int64_t)blockIdx.x * max_block_hits;
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))
     band_lo[tid] = 0x7fffffff;
     band_hi[tid] = 0;
   }
-  const bool tables_in_lds = !FILL && nb <= L::TABLE_MAX;
+  const bool tables_in_lds = tcap > 0;
   if (tables_in_lds) {
     for (int i = tid; i <= nb; i += L::THREADS) s_qoff[i] = q_off[i];
     const int4* gsrc = reinterpret_cast<const int4*>(grids);
@@ -674,7 +676,7 @@ int launch_count(const RadiusWs& w, const float4* sorted_q, int64_t nq, int nb, 
   const int blocks = (int)((nq + RQ - 1) / RQ);
   const int grid = (blocks + 7) / 8 * 8;
   KernelTimer timer("radius_count", stream);
-  hipLaunchKernelGGL((traverse_kernel<RQ, false, true>), dim3(grid), dim3(L::THREADS), L::FIXED, stream, sorted_q,
+  hipLaunchKernelGGL((traverse_kernel<RQ, false, true>), dim3(grid), dim3(L::THREADS), L::count_bytes(nb <= L::TABLE_MAX ? nb : 0), stream, sorted_q,
                      (int)nq, w.q_off, nb, w.grids, start_s, w.sorted_s, r2, w.q_count, w.q_rng, w.q_mask, w.blk_stats,
                      0, (int64_t)0, (int64_t*)nullptr, 0, (unsigned long long*)nullptr, (unsigned char*)nullptr, mono ? 1 : 0);
   hipLaunchKernelGGL(reduce_stats_kernel, dim3(1), dim3(1024), 0, stream, w.blk_stats, blocks, w.hdr);
