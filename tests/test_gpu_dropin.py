@@ -1,0 +1,97 @@
+"""The names GaussReg's scripts import (demo.py:10-21, test.py:12-18, model.py:7-14, gs_fusion.py) resolve to this
+repo's alias packages and work together on one synthetic pair: FPS -> collate/pyramid -> backbone-style KPConv +
+pooling -> superpoint embedding / attention / matching -> patch partition -> Sinkhorn -> local-global registration ->
+RANSAC, plus one rendered view.  Shapes, dtypes, devices and cross-operator consistency are checked (parity of every
+operator has its own test file)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_demo_flow_through_the_alias_packages():
+    import fpsample
+    from geotransformer.utils.data import registration_collate_fn_stack_mode
+    from geotransformer.modules.ops import point_to_node_partition, pairwise_distance
+    from geotransformer.modules.kpconv import KPConv, maxpool, nearest_upsample
+    from geotransformer.modules.geotransformer import (GeometricStructureEmbedding, SuperPointMatching, PointMatching,
+                                                       LocalGlobalRegistration)
+    from geotransformer.modules.transformer import RPEMultiHeadAttention
+    from geotransformer.modules.sinkhorn import LearnableLogOptimalTransport
+    from gaussreg_amd.registration import registration_with_ransac_from_correspondences
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from gen_golden_ext import room_pair
+
+    ref, src = room_pair(20000, 3)
+    ri = fpsample.bucket_fps_kdline_sampling(ref, 6000, h=9)
+    si = fpsample.bucket_fps_kdline_sampling(src, 6000, h=9)
+    assert ri.shape == (6000,) and len(set(ri.tolist())) == 6000
+    ref, src = ref[ri.astype(np.int64)], src[si.astype(np.int64)]
+    d = registration_collate_fn_stack_mode([{"ref_points": ref, "src_points": src, "ref_feats": np.ones((6000, 1), np.float32),
+                                             "src_feats": np.ones((6000, 1), np.float32)}], 4, 0.025, 0.0625,
+                                           [38, 36, 36, 38], device="cuda")
+    pts, nbr, sub, up = d["points"], d["neighbors"], d["subsampling"], d["upsampling"]
+    assert all(p.is_cuda for p in pts) and len(nbr) == 4 and len(sub) == 3 and len(up) == 3
+    for i in range(4):
+        assert nbr[i].shape[0] == pts[i].shape[0] and nbr[i].dtype == torch.int64 and nbr[i].shape[1] <= [38, 36, 36, 38][i]
+        assert int(nbr[i].max()) <= pts[i].shape[0]           # padding value = number of supports
+    # a backbone-style stage: conv at level 0, strided conv to level 1, pooling helpers
+    kp = torch.randn(15, 3) * 0.03
+    f0 = KPConv(1, 32, 15, 0.0625, 0.05, kernel_points=kp).cuda()(d["features"], pts[0], pts[0], nbr[0])
+    f1 = KPConv(32, 64, 15, 0.0625, 0.05, kernel_points=kp).cuda()(torch.relu(f0), pts[1], pts[0], sub[0])
+    assert f0.shape == (pts[0].shape[0], 32) and f1.shape == (pts[1].shape[0], 64) and torch.isfinite(f1).all()
+    assert maxpool(f0, sub[0]).shape == (pts[1].shape[0], 32) and nearest_upsample(f1, up[0]).shape == (pts[0].shape[0], 64)
+    # superpoint level
+    nc = d["lengths"][-1].tolist()
+    ref_c, src_c = pts[-1][:nc[0]], pts[-1][nc[0]:]
+    gse = GeometricStructureEmbedding(64, 0.2, 15, 3).cuda()
+    emb = gse(ref_c[None])
+    assert emb.shape == (1, nc[0], nc[0], 64) and torch.isfinite(emb).all()
+    x = torch.randn(1, nc[0], 64, device="cuda")
+    hid, sc = RPEMultiHeadAttention(64, 4).cuda()(x, x, x, emb)
+    assert hid.shape == (1, nc[0], 64) and torch.allclose(sc.sum(-1), torch.ones_like(sc.sum(-1)), atol=1e-4)
+    fr = torch.nn.functional.normalize(torch.randn(nc[0], 64, device="cuda"), dim=1)
+    fs = torch.nn.functional.normalize(torch.randn(nc[1], 64, device="cuda"), dim=1)
+    ci, cj, cs = SuperPointMatching(32)(fr, fs)
+    assert ci.shape == cj.shape == cs.shape == (32,) and bool((cs[:-1] >= cs[1:]).all())
+    assert torch.allclose(pairwise_distance(fr, fs, normalized=True)[ci, cj], (2 - 2 * (fr[ci] * fs[cj]).sum(1)).clamp(min=0), atol=1e-5)
+    # patches around the matched superpoints, optimal transport, registration
+    nf = d["lengths"][1].tolist()
+    _, r_masks, r_knn, r_kmask = point_to_node_partition(pts[1][:nf[0]], ref_c, 32)
+    _, s_masks, s_knn, s_kmask = point_to_node_partition(pts[1][nf[0]:], src_c, 32)
+    pad_r = torch.cat([pts[1][:nf[0]], torch.zeros(1, 3, device="cuda")]); pad_s = torch.cat([pts[1][nf[0]:], torch.zeros(1, 3, device="cuda")])
+    rk, sk = r_knn[ci], s_knn[cj]
+    rkp, skp = pad_r[rk], pad_s[sk]
+    scores = torch.randn(32, 32, 32, device="cuda")
+    ot = LearnableLogOptimalTransport(20).cuda()(scores, r_kmask[ci], s_kmask[cj])
+    assert ot.shape == (32, 33, 33)
+    pm = PointMatching(3, True, 0.05, False)
+    out = pm(rkp, skp, r_kmask[ci], s_kmask[cj], rk, sk, ot[:, :-1, :-1], cs)
+    assert len(out) == 5 and out[0].shape[1] == 3
+    lgr = LocalGlobalRegistration(3, 0.1, True, 0.05, False, False, 3, None, 5)
+    rc, scp, csc, T = lgr(rkp, skp, r_kmask[ci], s_kmask[cj], ot[:, :-1, :-1], cs)
+    assert T.shape == (4, 4) and torch.isfinite(T).all()
+    a = torch.rand(800, 3, device="cuda") * 3
+    R = torch.linalg.qr(torch.randn(3, 3, device="cuda"))[0]
+    R = R * torch.sign(torch.linalg.det(R))
+    b = 1.2 * a @ R.T + torch.tensor([0.3, -0.2, 0.5], device="cuda")
+    Tr = registration_with_ransac_from_correspondences(a, b, None, 0.05, 3, 2000)
+    assert torch.allclose(Tr[:3, :3], 1.2 * R, atol=2e-3) and torch.allclose(Tr[:3, 3], torch.tensor([0.3, -0.2, 0.5], device="cuda"), atol=5e-3)
+
+
+def test_one_rendered_view_through_diff_gaussian_rasterization():
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from helpers import raster_scene
+    g, cams = raster_scene(3000, 96, 64, seed=4)
+    c = cams[0]
+    st = GaussianRasterizationSettings(image_height=64, image_width=96, tanfovx=c["tanfovx"], tanfovy=c["tanfovy"],
+                                       bg=torch.tensor([0.1, 0.2, 0.3]), scale_modifier=1.0,
+                                       viewmatrix=torch.from_numpy(c["viewmatrix"]), projmatrix=torch.from_numpy(c["projmatrix"]),
+                                       sh_degree=3, campos=torch.from_numpy(c["campos"]), prefiltered=False, debug=False)
+    t = {k: torch.from_numpy(v).cuda() for k, v in g.items()}
+    img, radii = GaussianRasterizer(st)(means3D=t["means3D"], means2D=None, opacities=t["opacities"], shs=t["shs"],
+                                        scales=t["scales"], rotations=t["rotations"])
+    assert img.shape == (3, 64, 96) and radii.shape == (3000,) and img.is_cuda and torch.isfinite(img).all()
+    assert int((radii > 0).sum()) > 100 and float(img.std()) > 0
