@@ -203,7 +203,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int FPS_M = 8;                       // candidates per round (M * M <= 64: pair checks by one wave)
 constexpr int FPS_MW = 4;                      // candidates a single wave passes up (the global top 8 almost never
                                                // holds more than a few points of one wave; the rest raises the bound B)
-constexpr int FPS_SLOT_W = 2 * FPS_M + 2;      // tagged words per workgroup slot: M x (d, idx) + bound (hi, lo)
+constexpr int FPS_SLOT_W = FPS_M + 1;          // words per workgroup slot: M keys + bound, each with a 1-bit tag in bit 63
+                                               // (keys use 63 bits: d >= 0 has a clear sign bit)
 
 // Wave-wide maximum through the DPP lanes-shift network (row_shr 1/2/4/8, row_bcast 15/31): six dependent VALU ops
 // instead of six ds_bpermute round trips (~0.4 us each way for a 64-bit butterfly) -- the rounds below call it 27 times.
@@ -265,7 +266,9 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
   __syncthreads();
   unsigned long long* slots = slots_all + (size_t)b * 2 * FPS_GMAX * FPS_SLOT_W;
   int count = 1;
-  for (unsigned round = 1; count < k; ++round) {
+  // rounds start at 2: buffer (round & 1) is reused every second round and its words carry the tag bit
+  // (round >> 1) & 1, which flips between consecutive uses; zero-initialised slots read as tag 0, first uses expect 1
+  for (unsigned round = 2; count < k; ++round) {
     // ---- 1. fold the samples accepted last round into the running distances; per-thread best and runner-up
     const int na = s_na;
     // sample-major: one LDS read of the sample, then all of this thread's points two at a time (packed fp32 --
@@ -333,19 +336,12 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
       bool bad = false;
       if (G > 1) {
         unsigned long long* buf = slots + (size_t)(round & 1u) * FPS_GMAX * FPS_SLOT_W;
-        const unsigned long long tag = (unsigned long long)round << 32;
-        if (lane < M) {
-          __hip_atomic_store(buf + part * FPS_SLOT_W + 2 * lane, tag | (unsigned)(mykey >> 32), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(buf + part * FPS_SLOT_W + 2 * lane + 1, tag | (unsigned)mykey, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-        } else if (lane == M) {
-          __hip_atomic_store(buf + part * FPS_SLOT_W + 2 * M, tag | (unsigned)(bnd >> 32), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(buf + part * FPS_SLOT_W + 2 * M + 1, tag | (unsigned)bnd, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // lane g polls workgroup g's slot until all its words carry this round's tag
+        const unsigned long long tag = (unsigned long long)((round >> 1) & 1u) << 63;
+        if (lane < M)
+          __hip_atomic_store(buf + part * FPS_SLOT_W + lane, tag | mykey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (lane == M)
+          __hip_atomic_store(buf + part * FPS_SLOT_W + M, tag | bnd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // lane g polls workgroup g's slot until all its words carry this round's tag bit
         unsigned long long kk[M];
         unsigned long long sb = 0ull;
 #pragma unroll
@@ -359,11 +355,11 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
             for (int u = 0; u < FPS_SLOT_W; ++u) rd[u] = __hip_atomic_load(w + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             bool ok = true;
 #pragma unroll
-            for (int u = 0; u < FPS_SLOT_W; ++u) ok = ok && (unsigned)(rd[u] >> 32) == round;
+            for (int u = 0; u < FPS_SLOT_W; ++u) ok = ok && ((rd[u] ^ tag) >> 63) == 0ull;
             if (ok) {
 #pragma unroll
-              for (int r = 0; r < M; ++r) kk[r] = (rd[2 * r] << 32) | (rd[2 * r + 1] & 0xffffffffull);
-              sb = (rd[2 * M] << 32) | (rd[2 * M + 1] & 0xffffffffull);
+              for (int r = 0; r < M; ++r) kk[r] = rd[r] & ~(1ull << 63);
+              sb = rd[M] & ~(1ull << 63);
               break;
             }
             if (++spins > (1 << 22) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
