@@ -201,6 +201,8 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ pt
 // Threads contribute their best point; their second best is folded into B, which keeps the rule exact.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int FPS_M = 8;                       // candidates per round (M * M <= 64: pair checks by one wave)
+constexpr int FPS_MG = 16;                     // candidates of the global acceptance chain (a workgroup passes up M = 8:
+                                               // 64 workgroups x 8 keys feed a global top 16)
 constexpr int FPS_MW = 4;                      // candidates a single wave passes up (the global top 8 almost never
                                                // holds more than a few points of one wave; the rest raises the bound B)
 constexpr int FPS_SLOT_W = FPS_M + 1;          // words per workgroup slot: M keys + bound, each with a 1-bit tag in bit 63
@@ -231,10 +233,11 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
                                                           const int32_t* __restrict__ start_idx,
                                                           unsigned long long* __restrict__ slots_all,
                                                           int* __restrict__ err, int G, int64_t* __restrict__ out) {
-  constexpr int M = FPS_M, MW = FPS_MW, NW = FPS_T / WAVE;
+  constexpr int M = FPS_M, MG = FPS_MG, MW = FPS_MW, NW = FPS_T / WAVE;
   __shared__ unsigned long long s_wtop[NW * MW];
   __shared__ unsigned long long s_wbound[NW];
-  __shared__ float s_acc[M][4];
+  __shared__ float s_acc[MG][4];
+  __shared__ float s_cand[MG][4];
   __shared__ int s_na, s_abort;
   const int b = blockIdx.x / G, part = blockIdx.x % G;
   const int p0 = off[b], n = off[b + 1] - p0;
@@ -369,9 +372,9 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
             }
           }
         }
-        // global top-M over G x M keys (M per lane)
+        // global top-MG over G x M keys (M per lane)
 #pragma unroll
-        for (int r = 0; r < M; ++r) {
+        for (int r = 0; r < MG; ++r) {
           unsigned long long loc = kk[0];
 #pragma unroll
           for (int u = 1; u < M; ++u) loc = kk[u] > loc ? kk[u] : loc;
@@ -386,9 +389,10 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
         for (int u = 0; u < M; ++u) rest = kk[u] > rest ? kk[u] : rest;
         bnd = wave_max_u64(rest);
       }
-      // ---- acceptance: lane r < M owns candidate r (mykey), fetches its coordinates (the cloud is read-only)
+      // ---- acceptance: lane r < NC owns candidate r (mykey), fetches its coordinates (the cloud is read-only)
+      const int NC = G > 1 ? MG : M;  // a single workgroup only has its own M candidates
       const int ci = (int)(0xffffffffu - (unsigned)(mykey & 0xffffffffull));
-      const bool live = lane < M && mykey != 0ull;
+      const bool live = lane < NC && mykey != 0ull;
       float cx = 0.f, cy = 0.f, cz = 0.f;
       if (live) {
         cx = P[3 * ci];
@@ -396,18 +400,29 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
         cz = P[3 * ci + 2];
       }
       const float cd = __uint_as_float((unsigned)(mykey >> 32));
-      // pair (i, j), j < i, checked by lane i * M + j: does accepting c_j lower d(c_i)?
-      const int pi = lane / M, pj = lane % M;
-      const float ix = __shfl(cx, pi, WAVE), iy = __shfl(cy, pi, WAVE), iz = __shfl(cz, pi, WAVE);
-      const float jx = __shfl(cx, pj, WAVE), jy = __shfl(cy, pj, WAVE), jz = __shfl(cz, pj, WAVE);
-      const float di = __shfl(cd, pi, WAVE);
-      const float ddx = ix - jx, ddy = iy - jy, ddz = iz - jz;
-      const bool hurts = pj < pi && ((ddx * ddx + ddy * ddy) + ddz * ddz) < di;
-      const unsigned long long hurt_mask = __ballot(hurts);
-      const unsigned long long ok_mask = __ballot(live && mykey > bnd);  // bit r: candidate r beats everything uncollected
+      if (lane < MG) {
+        s_cand[lane][0] = cx;
+        s_cand[lane][1] = cy;
+        s_cand[lane][2] = cz;
+        s_cand[lane][3] = cd;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // candidate i = lane / 4 is checked against the earlier candidates j = (lane % 4) * 4 + u: does accepting c_j
+      // lower d(c_i)?  (a prefix is accepted, so every j < i counts)
+      const int pi = lane >> 2;
+      bool hurts = false;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pj = (lane & 3) * 4 + u;
+        const float ddx = s_cand[pi][0] - s_cand[pj][0], ddy = s_cand[pi][1] - s_cand[pj][1],
+                    ddz = s_cand[pi][2] - s_cand[pj][2];
+        hurts = hurts || (pj < pi && ((ddx * ddx + ddy * ddy) + ddz * ddz) < s_cand[pi][3]);
+      }
+      const unsigned long long hurt_mask = __ballot(hurts);                  // bits 4i .. 4i+3: candidate i is hurt
+      const unsigned long long ok_mask = __ballot(live && mykey > bnd);      // bit r: candidate r beats everything uncollected
       int acc = 0;
-      while (acc < M && count + acc < k && ((ok_mask >> acc) & 1ull) &&
-             ((hurt_mask >> (acc * M)) & ((1ull << acc) - 1ull)) == 0ull)
+      while (acc < NC && count + acc < k && ((ok_mask >> acc) & 1ull) && ((hurt_mask >> (4 * acc)) & 0xfull) == 0ull)
         ++acc;
       if (__any(bad)) {
         if (lane == 0) s_abort = 1;
