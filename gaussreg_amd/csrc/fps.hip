@@ -372,22 +372,19 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
             }
           }
         }
-        // global top-MG over G x M keys (M per lane)
+        // global top-MG over G x M keys: every lane's M keys arrive sorted (largest first), so this is a 64-way merge
+        // of sorted lists -- the wave maximum of the heads, then the owning lane shifts its list up
 #pragma unroll
         for (int r = 0; r < MG; ++r) {
-          unsigned long long loc = kk[0];
-#pragma unroll
-          for (int u = 1; u < M; ++u) loc = kk[u] > loc ? kk[u] : loc;
-          const unsigned long long w = wave_max_u64(loc);
+          const unsigned long long w = wave_max_u64(kk[0]);
           if (lane == r) mykey = w;
+          if (kk[0] == w && w != 0ull) {
 #pragma unroll
-          for (int u = 0; u < M; ++u)
-            if (kk[u] == w) kk[u] = 0ull;
+            for (int u = 0; u + 1 < M; ++u) kk[u] = kk[u + 1];
+            kk[M - 1] = 0ull;
+          }
         }
-        unsigned long long rest = sb;
-#pragma unroll
-        for (int u = 0; u < M; ++u) rest = kk[u] > rest ? kk[u] : rest;
-        bnd = wave_max_u64(rest);
+        bnd = wave_max_u64(kk[0] > sb ? kk[0] : sb);  // the largest key left anywhere, or a workgroup's own bound
       }
       // ---- acceptance: lane r < NC owns candidate r (mykey), fetches its coordinates (the cloud is read-only)
       const int NC = G > 1 ? MG : M;  // a single workgroup only has its own M candidates
