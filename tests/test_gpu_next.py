@@ -239,3 +239,16 @@ def test_rpe_attention_matches_reference_golden():
     hid, sc = att(q, k, k, e, key_weights=_c(g["rpe_weights"]), key_masks=_c(g["rpe_masks"]), attention_factors=_c(g["rpe_factors"]))
     np.testing.assert_allclose(hid.cpu().numpy(), g["rpe_h1"], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(sc.cpu().numpy(), g["rpe_s1"], rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("n,batch,k", [(50000, 64, 64), (60000, 100, 40), (9000, 30, 200)])
+def test_fps_register_and_streaming_slabs(n, batch, k):
+    """Slab sizes per thread: 13 (20-register path), 30 (distances streamed from L2, one sample per round), and a
+    batch whose clouds get several workgroups each (12-register path)."""
+    from gaussreg_amd.registration import farthest_point_sampling
+    from oracle import matching_np as M
+    rng = np.random.default_rng(n + batch)
+    pts = (rng.random((n * batch, 3)) * [5, 4, 3]).astype(np.float32)
+    got = farthest_point_sampling(_c(pts), [n] * batch, [k] * batch, start_indices=[b % 7 for b in range(batch)])
+    for b in (0, batch // 2, batch - 1):
+        assert np.array_equal(got[b].cpu().numpy(), M.farthest_point_sampling(pts[b * n:(b + 1) * n], k, b % 7))
