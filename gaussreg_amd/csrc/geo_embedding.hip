@@ -12,6 +12,8 @@
 //   * the k angular GEMMs are reduced (max / mean) in registers, the distance GEMM is added, biases applied,
 //     and only the result is written: the output (N*N*C*4 B) is the only HBM traffic that scales with N^2.
 // Float op order differs from ATen (GEMM summation order), so parity is a tolerance (tests/test_gpu_next.py).
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace gr {
@@ -25,6 +27,7 @@ constexpr int GE_K = 32;      // K slab
 constexpr int GE_LD = GE_K + 1;
 constexpr int GE_T = 512;
 constexpr int GE_KMAX = 8;    // angle_k <= 8
+constexpr int GE_SPLIT_CMAX = 512;  // hidden_dim up to which the split-bf16 kernel's weight planes fit the workspace
 
 __device__ __forceinline__ float sq_dist_ref(const float3 a, float a2, const float3 b, float b2) {
   // pairwise_distance.py:21-31: xy by matmul, then (x2 - 2 xy) + y2, clamped at 0
@@ -73,20 +76,11 @@ __global__ __launch_bounds__(256) void geo_knn_kernel(const float* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(GE_T) void geo_embedding_kernel(
-    const float* __restrict__ pts, int n, const int32_t* __restrict__ knn, int k, const float* __restrict__ w_d,
-    const float* __restrict__ b_d, const float* __restrict__ w_a, const float* __restrict__ b_a,
-    const float* __restrict__ div_term, int C, float sigma_d, float factor_a, int mean, float* __restrict__ out) {
-  __shared__ float sa[2][GE_ROWS][GE_LD];
-  __shared__ float sb[2][GE_COLS][GE_LD];
-  __shared__ float xs[GE_KMAX + 1][GE_ROWS];  // [0..k-1] angular indices, [k] distance index
-  const int64_t total = (int64_t)n * n;
-  const int64_t r0 = (int64_t)blockIdx.x * GE_ROWS;
-  const int j0 = blockIdx.y * GE_COLS;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int wi = (w >> 2) * 64, wj = (w & 3) * 64;
-
-  // ---- per-pair indices (geotransformer.py:38-55)
+// per-pair embedding indices (geotransformer.py:38-55) for the GE_ROWS consecutive (a, b) pairs of a workgroup:
+// xs[0..k-1][row] = angular indices, xs[k][row] = distance index
+__device__ __forceinline__ void ge_pair_indices(const float* __restrict__ pts, int n, const int32_t* __restrict__ knn,
+                                                int k, float sigma_d, float factor_a, int64_t r0, int64_t total, int tid,
+                                                float (*xs)[GE_ROWS]) {
   if (tid < GE_ROWS) {
     const int64_t r = r0 + tid;
     float xd = 0.f, xa[GE_KMAX];
@@ -115,6 +109,22 @@ __global__ __launch_bounds__(GE_T) void geo_embedding_kernel(
       if (i < k) xs[i][tid] = xa[i];
     xs[k][tid] = xd;
   }
+}
+
+__global__ __launch_bounds__(GE_T) void geo_embedding_kernel(
+    const float* __restrict__ pts, int n, const int32_t* __restrict__ knn, int k, const float* __restrict__ w_d,
+    const float* __restrict__ b_d, const float* __restrict__ w_a, const float* __restrict__ b_a,
+    const float* __restrict__ div_term, int C, float sigma_d, float factor_a, int mean, float* __restrict__ out) {
+  __shared__ float sa[2][GE_ROWS][GE_LD];
+  __shared__ float sb[2][GE_COLS][GE_LD];
+  __shared__ float xs[GE_KMAX + 1][GE_ROWS];  // [0..k-1] angular indices, [k] distance index
+  const int64_t total = (int64_t)n * n;
+  const int64_t r0 = (int64_t)blockIdx.x * GE_ROWS;
+  const int j0 = blockIdx.y * GE_COLS;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wi = (w >> 2) * 64, wj = (w & 3) * 64;
+
+  ge_pair_indices(pts, n, knn, k, sigma_d, factor_a, r0, total, tid, xs);
   __syncthreads();
 
   f32x16 acc[2][2], red[2][2];
@@ -219,6 +229,227 @@ __global__ __launch_bounds__(GE_T) void geo_embedding_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------- split-bf16 variant of the same GEMMs
+// The bf16 matrix pipe of gfx950 is 16x the fp32 one.  Every fp32 operand is split exactly into three bf16 parts,
+// x = hi + mid + lo (8 mantissa bits each), and a product a*b is evaluated as the six part products of weight
+// >= 2^-18 relative: hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi, accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16.  What is dropped (mid*lo, lo*mid, lo*lo) is below 2^-26 of the product -- smaller than
+// one fp32 rounding -- so the result differs from the fp32-MFMA kernel only by summation order, at 6/16 of its
+// matrix-pipe time.  Fragment layout (probed on the hardware): A lane l = row l & 31, k = 8 * (l >> 5) + 0..7.
+
+// sin and cos for moderate arguments (|x| < 2^11; the embedding's index * div_term is a few tens): three-constant
+// Cody-Waite reduction by pi/2 and the Cephes single-precision polynomials on [-pi/4, pi/4] (~1 ulp).  Used by the
+// split-bf16 kernel, where the operand generation competes with a 2.7x faster matrix pipe; workgroups that see a larger
+// index (or a non-finite one) use the library sincosf().
+__device__ __forceinline__ void sincos_moderate(float x, float* sn, float* cs) {
+  const float kf = rintf(x * 0.636619772367581343f);  // 2/pi
+  float r = fmaf(kf, -1.5703125f, x);                   // pi/2 = 1.5703125 + 4.837512969970703125e-4 + 7.54978995489188e-8
+  r = fmaf(kf, -4.837512969970703125e-4f, r);
+  r = fmaf(kf, -7.54978995489188e-8f, r);
+  const float r2 = r * r;
+  float ps = -1.9515295891e-4f;
+  ps = fmaf(ps, r2, 8.3321608736e-3f);
+  ps = fmaf(ps, r2, -1.6666654611e-1f);
+  const float s = fmaf(ps * r2, r, r);
+  float pc = 2.443315711809948e-5f;
+  pc = fmaf(pc, r2, -1.388731625493765e-3f);
+  pc = fmaf(pc, r2, 4.166664568298827e-2f);
+  const float c = fmaf(pc * r2, r2, fmaf(-0.5f, r2, 1.0f));
+  const int q = (int)kf;
+  const float s1 = (q & 1) ? c : s, c1 = (q & 1) ? s : c;
+  *sn = (q & 2) ? -s1 : s1;
+  *cs = ((q + 1) & 2) ? -c1 : c1;
+}
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+constexpr int GS_K = 16;            // K slab = one MFMA k-step
+constexpr int GS_LD = GS_K + 8;     // bf16 per LDS row (48 B: ds_read_b128 of 16 rows hits 16 disjoint bank quads)
+
+// x = hi + mid + lo with three bf16 parts taken by truncation: every subtraction is exact and the three parts carry
+// the 24 significant bits of x (what is left is below one ulp of x).  Returned in the HIGH halves of the words.
+__device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(hi);
+  mid = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(mid);
+  lo = __float_as_uint(r2) & 0xffff0000u;
+}
+
+// W (c x c fp32, row = output channel) -> three bf16 planes of the same shape
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, int64_t n,
+                                                            unsigned short* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  unsigned h, m, l;
+  split3(w[i], h, m, l);
+  out[i] = (unsigned short)(h >> 16);
+  out[n + i] = (unsigned short)(m >> 16);
+  out[2 * n + i] = (unsigned short)(l >> 16);
+}
+
+__global__ __launch_bounds__(GE_T) void geo_embedding_split_kernel(
+    const float* __restrict__ pts, int n, const int32_t* __restrict__ knn, int k,
+    const unsigned short* __restrict__ wd3, const float* __restrict__ b_d, const unsigned short* __restrict__ wa3,
+    const float* __restrict__ b_a, const float* __restrict__ div_term, int C, float sigma_d, float factor_a, int mean,
+    float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) unsigned short sa[2][3][GE_ROWS][GS_LD];
+  __shared__ __attribute__((aligned(16))) unsigned short sb[2][3][GE_COLS][GS_LD];
+  __shared__ float xs[GE_KMAX + 1][GE_ROWS];
+  const int64_t total = (int64_t)n * n;
+  const int64_t r0 = (int64_t)blockIdx.x * GE_ROWS;
+  const int j0 = blockIdx.y * GE_COLS;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wi = (w >> 2) * 64, wj = (w & 3) * 64;
+  __shared__ int s_big;
+  if (tid == 0) s_big = 0;
+  __syncthreads();
+  ge_pair_indices(pts, n, knn, k, sigma_d, factor_a, r0, total, tid, xs);
+  if (tid < GE_ROWS) {
+    float mx = 0.f;
+    for (int i = 0; i <= k; ++i) mx = fmaxf(mx, fabsf(xs[i][tid]));
+    if (!(mx < 2048.0f) || isnan(mx)) s_big = 1;
+    for (int i = 0; i <= k; ++i)
+      if (isnan(xs[i][tid])) s_big = 1;
+  }
+  __syncthreads();
+  const bool big = s_big != 0;
+
+  f32x16 acc[2][2], red[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f, red[a][b][r] = 0.f;
+
+  // staging: A = 128 rows x 8 frequencies -> 2 (row, f) per thread, each (sin, cos) x 3 parts packed in three words;
+  //          B = 3 planes x 256 cols x 16 k bf16 = 1536 16-byte chunks -> 3 per thread
+  constexpr int NA = GE_ROWS * (GS_K / 2) / GE_T, NF = GS_K / 2, NBC = 3 * GE_COLS * 2 / GE_T;
+  unsigned ra[NA][3];
+  uint4 rbv[1][NBC];
+  const int slabs = C / GS_K;
+  const int64_t plane = (int64_t)C * C;
+  auto gen_a = [&](int phase, int k0) {
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int e = tid + u * GE_T;
+      const int r = e / NF, f = e % NF;
+      const float omega = xs[phase][r] * div_term[(k0 >> 1) + f];  // positional_embedding.py:27
+      float sn, cs;
+      if (big) sincosf(omega, &sn, &cs);
+      else sincos_moderate(omega, &sn, &cs);
+      unsigned sh, sm, sl, ch, cm, cl;
+      split3(sn, sh, sm, sl);
+      split3(cs, ch, cm, cl);
+      ra[u][0] = (sh >> 16) | ch;  // positional_embedding.py:30-31: (sin, cos) interleaved along k
+      ra[u][1] = (sm >> 16) | cm;
+      ra[u][2] = (sl >> 16) | cl;
+    }
+  };
+  auto load_b = [&](auto slot, int phase, int k0) {
+    constexpr int R = decltype(slot)::value;
+    const unsigned short* W3 = phase < k ? wa3 : wd3;
+#pragma unroll
+    for (int u = 0; u < NBC; ++u) {
+      const int e = tid + u * GE_T;
+      const int p = e / (GE_COLS * 2), rem = e % (GE_COLS * 2);
+      const int col = rem >> 1, half = rem & 1;
+      const int gj = min(j0 + col, C - 1);
+      rbv[R][u] = *reinterpret_cast<const uint4*>(W3 + p * plane + (int64_t)gj * C + k0 + half * 8);
+    }
+  };
+  auto store = [&](auto slot, int buf) {
+    constexpr int R = decltype(slot)::value;
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int e = tid + u * GE_T;
+      const int r = e / NF, f = e % NF;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(&sa[buf][p][r][2 * f]) = ra[u][p];
+    }
+#pragma unroll
+    for (int u = 0; u < NBC; ++u) {
+      const int e = tid + u * GE_T;
+      const int p = e / (GE_COLS * 2), rem = e % (GE_COLS * 2);
+      *reinterpret_cast<uint4*>(&sb[buf][p][rem >> 1][(rem & 1) * 8]) = rbv[R][u];
+    }
+  };
+
+  const int steps = (k + 1) * slabs;
+  using Slot0 = std::integral_constant<int, 0>;
+  load_b(Slot0{}, 0, 0);
+  gen_a(0, 0);
+  store(Slot0{}, 0);
+  __syncthreads();
+  for (int s = 0; s < steps; ++s) {
+    const int buf = s & 1;
+    const int phase = s / slabs;
+    const bool more = s + 1 < steps;
+    if (more) {  // next slab: weights requested, operands generated while this slab's MFMAs run
+      load_b(Slot0{}, (s + 1) / slabs, ((s + 1) % slabs) * GS_K);
+      gen_a((s + 1) / slabs, ((s + 1) % slabs) * GS_K);
+    }
+    {
+      const int ra_ = wi + (lane & 31), rb_ = wj + (lane & 31), kh = (lane >> 5) * 8;
+      bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        fa[0][p] = *reinterpret_cast<const bf16x8*>(&sa[buf][p][ra_][kh]);
+        fa[1][p] = *reinterpret_cast<const bf16x8*>(&sa[buf][p][ra_ + 32][kh]);
+        fb[0][p] = *reinterpret_cast<const bf16x8*>(&sb[buf][p][rb_][kh]);
+        fb[1][p] = *reinterpret_cast<const bf16x8*>(&sb[buf][p][rb_ + 32][kh]);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          f32x16 c = acc[a][b];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][0], c, 0, 0, 0);  // lo  * hi
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][2], c, 0, 0, 0);  // hi  * lo
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][1], c, 0, 0, 0);  // mid * mid
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][0], c, 0, 0, 0);  // mid * hi
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][1], c, 0, 0, 0);  // hi  * mid
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][0], c, 0, 0, 0);  // hi  * hi
+          acc[a][b] = c;
+        }
+    }
+    if ((s + 1) % slabs == 0 && phase < k) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[a][b][r];
+            red[a][b][r] = phase == 0 ? v : (mean ? red[a][b][r] + v : fmaxf(red[a][b][r], v));
+            acc[a][b][r] = 0.f;
+          }
+    }
+    if (more) {
+      store(Slot0{}, buf ^ 1);
+      __syncthreads();
+    }
+  }
+  const float inv_k = k > 0 ? 1.0f / (float)k : 0.f;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int gj = j0 + wj + b * 32 + (lane & 31);
+      if (gj >= C) continue;
+      const float bd = b_d[gj], ba = k > 0 ? b_a[gj] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t gi = r0 + wi + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (gi < total) {
+          const float av = k > 0 ? (mean ? (red[a][b][r] + (float)k * ba) * inv_k : red[a][b][r] + ba) : 0.f;
+          out[gi * C + gj] = (acc[a][b][r] + bd) + av;
+        }
+      }
+    }
+}
+
 }  // namespace
 }  // namespace gr
 
@@ -226,7 +457,8 @@ using namespace gr;
 
 extern "C" size_t gr_geo_embedding_workspace_bytes(int64_t n, int64_t angle_k) {
   if (n < 0 || angle_k < 0) return 0;
-  return align_up((size_t)n * (size_t)std::max<int64_t>(angle_k, 1) * 4, 256) + 256;
+  return align_up((size_t)n * (size_t)std::max<int64_t>(angle_k, 1) * 4, 256) + 256 +
+         2 * align_up((size_t)3 * GE_SPLIT_CMAX * GE_SPLIT_CMAX * 2, 256);  // split weights (bf16 x 3) of proj_d, proj_a
 }
 
 extern "C" int gr_geo_embedding(const float* points, int64_t n, const float* w_d, const float* b_d, const float* w_a,
@@ -235,7 +467,7 @@ extern "C" int gr_geo_embedding(const float* points, int64_t n, const float* w_d
                                 void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   GR_REQUIRE(n >= 0 && n < 46341, "geo_embedding: n*n must fit int32 pair ids per row (n=%lld)", (long long)n);
-  GR_REQUIRE(c > 0 && c % GE_K == 0, "geo_embedding: hidden_dim must be a positive multiple of 32 (got %lld)", (long long)c);
+  GR_REQUIRE(c > 0 && c % 16 == 0, "geo_embedding: hidden_dim must be a positive multiple of 16 (got %lld)", (long long)c);
   GR_REQUIRE(angle_k >= 0 && angle_k <= GE_KMAX, "geo_embedding: angle_k must be in [0, %d]", GE_KMAX);
   GR_REQUIRE(angle_k < n || n == 0, "geo_embedding: angle_k (%lld) needs more than %lld points", (long long)angle_k, (long long)n);
   if (n == 0) return GR_OK;
@@ -248,11 +480,24 @@ extern "C" int gr_geo_embedding(const float* points, int64_t n, const float* w_d
   int32_t* knn = cv.take<int32_t>((size_t)n * std::max<int64_t>(angle_k, 1));
   if (angle_k > 0)
     hipLaunchKernelGGL(geo_knn_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, points, (int)n, (int)angle_k, knn);
-  {
+  const bool fp32_mfma = (reduction_mean & 2) != 0 || c > GE_SPLIT_CMAX || c % 16 != 0;
+  const int mean = reduction_mean & 1;
+  const dim3 grid((unsigned)((n * n + GE_ROWS - 1) / GE_ROWS), (unsigned)((c + GE_COLS - 1) / GE_COLS));
+  if (fp32_mfma) {
+    GR_REQUIRE(c % GE_K == 0, "geo_embedding: the fp32-MFMA kernel needs hidden_dim %% 32 == 0 (got %lld)", (long long)c);
     KernelTimer timer("geo_embedding", stream);
-    const dim3 grid((unsigned)((n * n + GE_ROWS - 1) / GE_ROWS), (unsigned)((c + GE_COLS - 1) / GE_COLS));
     hipLaunchKernelGGL(geo_embedding_kernel, grid, dim3(GE_T), 0, stream, points, (int)n, knn, (int)angle_k, w_d, b_d,
-                       w_a, b_a, div_term, (int)c, sigma_d, factor_a, reduction_mean, out);
+                       w_a, b_a, div_term, (int)c, sigma_d, factor_a, mean, out);
+  } else {
+    unsigned short* wd3 = cv.take<unsigned short>((size_t)3 * GE_SPLIT_CMAX * GE_SPLIT_CMAX);
+    unsigned short* wa3 = cv.take<unsigned short>((size_t)3 * GE_SPLIT_CMAX * GE_SPLIT_CMAX);
+    const int64_t nw = c * c;
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, w_d, nw, wd3);
+    if (angle_k > 0)
+      hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, w_a, nw, wa3);
+    KernelTimer timer("geo_embedding", stream);
+    hipLaunchKernelGGL(geo_embedding_split_kernel, grid, dim3(GE_T), 0, stream, points, (int)n, knn, (int)angle_k, wd3,
+                       b_d, wa3, b_a, div_term, (int)c, sigma_d, factor_a, mean, out);
   }
   GR_LAUNCH_CHECK();
   return GR_OK;

@@ -28,8 +28,12 @@ class SinusoidalPositionalEmbedding(nn.Module):
 
 
 class GeometricStructureEmbedding(nn.Module):
-    def __init__(self, hidden_dim, sigma_d, sigma_a, angle_k, reduction_a='max'):
+    def __init__(self, hidden_dim, sigma_d, sigma_a, angle_k, reduction_a='max', fp32_mfma=False):
+        """`fp32_mfma=True` runs the projections on fp32 MFMAs (v_mfma_f32_32x32x2_f32) instead of the default
+        split-bf16 scheme (every operand = three bf16 parts, six bf16 MFMAs per product, fp32 accumulation: the same
+        accuracy within summation order at about 0.8x the time)."""
         super().__init__()
+        self.fp32_mfma = bool(fp32_mfma)
         self.sigma_d = sigma_d
         self.sigma_a = sigma_a
         self.factor_a = 180.0 / (self.sigma_a * np.pi)
@@ -62,6 +66,6 @@ class GeometricStructureEmbedding(nn.Module):
             for b in range(B):
                 _lib.check(L.gr_geo_embedding(_lib.ptr(p[b]), N, _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(wa), _lib.ptr(ba),
                                               _lib.ptr(div), C, float(self.sigma_d), float(self.factor_a),
-                                              int(self.angle_k), 1 if self.reduction_a == 'mean' else 0,
+                                              int(self.angle_k), (1 if self.reduction_a == 'mean' else 0) | (2 if self.fp32_mfma else 0),
                                               _lib.ptr(out[b]), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)))
         return out if out_device.type == "cuda" else out.to(out_device)

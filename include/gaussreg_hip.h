@@ -250,7 +250,9 @@ int gr_ransac_similarity(const float* src_points, const float* ref_points, int64
  * (geotransformer/modules/geotransformer/geotransformer.py:26-73 + transformer/positional_embedding.py:8-34):
  * out (n,n,c) = proj_d(sinemb(|p_a-p_b| / sigma_d)) + reduce_k proj_a(sinemb(angle(p_knn(a,k)-p_a, p_b-p_a) * factor_a)).
  * w_d, w_a: (c,c) nn.Linear weights (row = output channel); b_d, b_a: (c); div_term: (c/2) buffer of the sinusoidal
- * embedding; reduction_mean: 0 = 'max', 1 = 'mean'; angle_k <= 8; c % 32 == 0.  Asynchronous on `stream`. */
+ * embedding; reduction_mean: bit 0 = 'mean' instead of 'max', bit 1 = run the projections on fp32 MFMAs (c % 32 == 0)
+ * instead of the default split-bf16 scheme (three bf16 parts per operand, six bf16 MFMAs per product, fp32 accumulate:
+ * fp32 accuracy up to summation order; c % 16 == 0, c <= 512); angle_k <= 8.  Asynchronous on `stream`. */
 size_t gr_geo_embedding_workspace_bytes(int64_t n, int64_t angle_k);
 int gr_geo_embedding(const float* points, int64_t n, const float* w_d, const float* b_d, const float* w_a,
                      const float* b_a, const float* div_term, int64_t c, float sigma_d, float factor_a,

@@ -187,20 +187,22 @@ def test_fps_multi_workgroup_paths(n, k, batch):
 
 
 # ---------------------------------------------------------------- RPE rows (geo embedding, attention score term)
-def _gse(g, tag):
+def _gse(g, tag, fp32_mfma=False):
     from gaussreg_amd.embedding import GeometricStructureEmbedding
     c, k, mean = (int(x) for x in g[f"gse_{tag}_cfg"])
-    m = GeometricStructureEmbedding(c, 0.2, 15, k, reduction_a="mean" if mean else "max")
+    m = GeometricStructureEmbedding(c, 0.2, 15, k, reduction_a="mean" if mean else "max", fp32_mfma=fp32_mfma)
     m.load_state_dict({"embedding.div_term": torch.from_numpy(g[f"gse_{tag}_div"]),
                        "proj_d.weight": torch.from_numpy(g[f"gse_{tag}_w_d"]), "proj_d.bias": torch.from_numpy(g[f"gse_{tag}_b_d"]),
                        "proj_a.weight": torch.from_numpy(g[f"gse_{tag}_w_a"]), "proj_a.bias": torch.from_numpy(g[f"gse_{tag}_b_a"])})
     return m.cuda()
 
 
+@pytest.mark.parametrize("fp32_mfma", [False, True])
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
-def test_geo_embedding_matches_reference_golden(tag):
+def test_geo_embedding_matches_reference_golden(tag, fp32_mfma):
+    """Both projection kernels: split-bf16 (default) and fp32 MFMA."""
     g = load_golden("rpe.npz")
-    out = _gse(g, tag)(_c(g[f"gse_{tag}_points"])).cpu().numpy()
+    out = _gse(g, tag, fp32_mfma)(_c(g[f"gse_{tag}_points"])).cpu().numpy()
     ref = g[f"gse_{tag}_out"]
     n = ref.shape[1]
     off = ~np.eye(n, dtype=bool)
@@ -223,6 +225,9 @@ def test_geo_embedding_demo_shape_vs_oracle():
                                           m.embedding.div_term.cpu().numpy(), 0.2, 15, 3)
     off = ~np.eye(n, dtype=bool)
     np.testing.assert_allclose(out[off], ref[off], rtol=5e-5, atol=5e-5)
+    m.fp32_mfma = True                          # the two kernels agree far inside the tolerance
+    out32 = m(pts.cuda())[0].cpu().numpy()
+    assert np.abs(out32 - out)[off].max() < 5e-6
 
 
 def test_rpe_attention_matches_reference_golden():

@@ -28,10 +28,11 @@ for n, c in ((767, 256), (8192, 256)):
     y = torch.randn(n, c, device="cuda", generator=g)
     t = timeit(lambda: ops.pairwise_distance(x, y))
     rows.append((f"pairwise_distance {n}x{n}x{c}", 2.0 * n * n * c, t))
-gse = GeometricStructureEmbedding(256, 0.2, 15, 3).cuda()
 pc = torch.rand(1, 767, 3, device="cuda", generator=g) * 5
-t = timeit(lambda: gse(pc), 5)
-rows.append(("geo_embedding N=767 C=256 k=3", 2.0 * 767 * 767 * 256 * 256 * 4, t))
+for fp32 in (True, False):
+    gse = GeometricStructureEmbedding(256, 0.2, 15, 3, fp32_mfma=fp32).cuda()
+    t = timeit(lambda: gse(pc), 5)
+    rows.append((f"geo_embedding N=767 C=256 k=3 ({'fp32 MFMA' if fp32 else 'split-bf16 x6 MFMA, fp32-equivalent flops'})", 2.0 * 767 * 767 * 256 * 256 * 4, t))
 N, H, C = 28020, 43, 256
 spt = torch.rand(N, 3, device="cuda", generator=g)
 nb = torch.randint(0, N + 1, (N, H), device="cuda")
