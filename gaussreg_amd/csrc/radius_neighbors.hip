@@ -10,14 +10,18 @@
 // compiled with -ffp-contract=off so (1) stays three multiplies and two adds.
 //
 // Pipeline (all on `stream`):
-//   bbox        per-cloud bounding box of the supports (wave-reduced ordered-uint atomics)
+//   bbox        per-cloud bounding box of the supports (block reductions, six atomics per block)
 //   grid_setup  per-cloud cell edge (>= radius, coarsened so cells <= max(4096, 4 n_b)), dims, bases
-//   bin_count   cell id per support / per query + per-cell histogram
-//   scan        exclusive scan of the histograms (common.hip)
-//   scatter     counting-sort supports and queries into cell order as float4 {x,y,z,orig index}
-//   count       one thread per (cell-ordered) query: hits per query, max over queries  -> host
-//   fill        same traversal; hits insertion-sorted by (d, index) in LDS segments sized by the
-//               count pass; rows staged in LDS and written as contiguous int64 runs
+//   bin_count   cell id per support / per query; the histogram atomic returns the point's slot inside its cell
+//   scan        exclusive scan of the histograms, stopped at the real cell count (common.hip)
+//   scatter     counting-sort supports and queries into cell order as float4 {x,y,z,orig index} (no atomics)
+//   count       thread per (cell-ordered query, z-slab): candidates staged in LDS as coordinate planes, tested two at
+//               a time with packed fp32 math; per thread a hit count, the nine candidate ranges and a hit bit mask;
+//               max over queries -> host (the row width the reference returns)
+//   fill        gathers only the hits named by the masks into per-query LDS segments, ranks every hit inside its
+//               segment by counting (one thread per hit) and stores it at out[query][rank]; pads the rows
+// gr_radius_count_cached lets consecutive searches over the same supports and radius skip bbox .. scatter for the
+// support side (the data pyramid searches every level's supports three times).
 #include <vector>
 
 #include "common.hpp"
