@@ -202,3 +202,37 @@ def test_support_grid_reuse_gives_identical_results():
     assert torch.equal(ext.radius_neighbors(q1, s, pairs[2][1], sl, 0.2, grid=grid), ext.radius_neighbors(q1, s, pairs[2][1], sl, 0.2))
     s2 = s.clone() * 0.5
     assert torch.equal(ext.radius_neighbors(q1, s2, pairs[2][1], sl, 0.2, grid=grid), ext.radius_neighbors(q1, s2, pairs[2][1], sl, 0.2))
+
+
+def test_small_shape_fuzz_vs_oracle():
+    """Many tiny, ragged configurations (empty clouds, single points, duplicates, radius from tiny to covering
+    everything, self-search and q != s, with and without a shared SupportGrid) against the CPU oracle."""
+    from oracle import capi
+    ext = _ext()
+    rng = np.random.default_rng(2024)
+    for it in range(60):
+        batch = int(rng.integers(1, 5))
+        sl = rng.integers(0, 40, batch).astype(np.int64)
+        ql = rng.integers(0, 40, batch).astype(np.int64)
+        if it % 5 == 0:
+            sl[rng.integers(0, batch)] = 0
+        s = rng.random((int(sl.sum()), 3)).astype(np.float32)
+        q = rng.random((int(ql.sum()), 3)).astype(np.float32)
+        if it % 3 == 0 and len(s) > 4:
+            s[1] = s[0]; s[3] = s[2]                      # duplicates -> equal distances
+        radius = float(rng.choice([1e-4, 0.05, 0.2, 0.7, 3.0]))
+        ts, tq = _t(s), _t(q)
+        grid = ext.SupportGrid(max(len(q), len(s), 1))
+        for (qq, qqt, qql) in ((s, ts, sl), (q, tq, ql), (s, ts, sl)):
+            want = capi.radius_neighbors(qq, s, qql, sl, radius)
+            got = ext.radius_neighbors(qqt, ts, torch.from_numpy(qql), torch.from_numpy(sl), radius).cpu().numpy()
+            got_c = ext.radius_neighbors(qqt, ts, torch.from_numpy(qql), torch.from_numpy(sl), radius, grid=grid).cpu().numpy()
+            assert got.shape == want.shape and got_c.shape == want.shape, (it, got.shape, want.shape)
+            if it % 3 == 0:   # duplicates: rows equal as sets of (distance-sorted) neighbours up to tie order
+                assert np.array_equal(np.sort(got, 1), np.sort(want, 1)) and np.array_equal(np.sort(got_c, 1), np.sort(want, 1))
+            else:
+                assert np.array_equal(got, want) and np.array_equal(got_c, want), it
+        if len(s):
+            wp, wl = capi.grid_subsampling(s, sl, max(radius / 2, 0.01))
+            gp, gl = ext.grid_subsampling(ts, torch.from_numpy(sl), max(radius / 2, 0.01))
+            assert np.array_equal(gl.numpy(), wl) and np.array_equal(gp.cpu().numpy().view(np.uint32), wp.view(np.uint32))
