@@ -189,3 +189,29 @@ def test_far_depth_takes_full_key_sort():
         assert wr.max() > 0 and want.std() > 0
         assert np.array_equal(radii[v].cpu().numpy(), wr)
         _assert_bit_equal(imgs[v].cpu().numpy(), want, f"far view {v}")
+
+
+def test_fuzz_extreme_gaussians_bit_exact():
+    """Random small scenes seeded with the extremes the cull rules have to survive: opacity 0 / 1 / barely above
+    1/255, needle-thin and huge Gaussians, points behind / on the near plane, image sizes that are not tile
+    multiples, 1-5 views -- images and radii must stay bit-identical to the oracle."""
+    from gaussreg_amd.rasterizer import rasterize_views
+    rng = np.random.default_rng(77)
+    for it in range(12):
+        P = int(rng.integers(200, 3000))
+        W, H, V = int(rng.integers(17, 140)), int(rng.integers(17, 110)), int(rng.integers(1, 6))
+        g, cams = raster_scene(P, W, H, seed=100 + it, V=V)
+        k = P // 10
+        g["opacities"][:k] = rng.choice(np.float32([0.0, 1.0, 1.0 / 255.0, 0.00393, 0.004, 0.0045, 0.5]), (k, 1))
+        g["scales"][k:2 * k] = np.exp(rng.normal(np.log(0.05), 1.5, (k, 3))).astype(np.float32)       # from dust to walls
+        g["scales"][2 * k:3 * k, 0] *= np.float32(40.0)                                               # needles
+        g["means3D"][3 * k:4 * k, 2] = rng.choice(np.float32([-1.0, 0.0, 0.19, 0.2, 0.2001, 0.25]), k)  # near plane
+        d = _cu(g)
+        bg = tuple(float(x) for x in rng.random(3).astype(np.float32))
+        imgs, radii, nr = rasterize_views([_settings(c, bg=bg) for c in cams], d["means3D"], d["opacities"], shs=d["shs"],
+                                          scales=d["scales"], rotations=d["rotations"])
+        for v in range(V):
+            want, wr, wR = oracle_render(g, cams[v], bg=bg)
+            assert np.array_equal(radii[v].cpu().numpy(), wr), (it, v)
+            assert nr[v] <= wR
+            _assert_bit_equal(imgs[v].cpu().numpy(), want, f"fuzz scene {it} view {v} ({P} Gaussians, {W}x{H})")
