@@ -69,12 +69,29 @@ __global__ __launch_bounds__(T) void kp_gather_kernel(
       float a[KP_MAX];
 #pragma unroll
       for (int k = 0; k < KP_MAX; ++k) a[k] = 0.f;
-      for (int h = 0; h < hn; ++h) {
+      // four neighbour rows requested before the first one is consumed (the loop is a chain of gathers otherwise);
+      // a shadow neighbour contributes an exact zero either way (:103), so it is loaded as 0 instead of skipped
+      int h = 0;
+      for (; h + 4 <= hn; h += 4) {
+        float fv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = s_idx[h + u];
+          fv[u] = idx < 0 ? 0.f : s_feats[(int64_t)idx * Cin + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (s_idx[h + u] >= 0) {
+#pragma unroll
+            for (int k = 0; k < KP_MAX; ++k) a[k] = fmaf(s_w[h + u][k], fv[u], a[k]);  // :105 (M,K,H) x (M,H,C)
+          }
+      }
+      for (; h < hn; ++h) {
         const int idx = s_idx[h];
         if (idx < 0) continue;                                            // zero shadow feature (:103)
         const float fv = s_feats[(int64_t)idx * Cin + c];
 #pragma unroll
-        for (int k = 0; k < KP_MAX; ++k) a[k] = fmaf(s_w[h][k], fv, a[k]);  // :105 (M,K,H) x (M,H,C)
+        for (int k = 0; k < KP_MAX; ++k) a[k] = fmaf(s_w[h][k], fv, a[k]);
       }
       if (Cin <= T) {
 #pragma unroll
