@@ -577,7 +577,6 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
           mask |= 1u << c;
     }
     // ---- order-preserving per-cell lists
-    unsigned rank_lo = 0, rank_hi = 0;  // 16 x 8-bit... ranks need up to 6 bits each: pack 8 per 64? keep simple
     unsigned char myrank[NCELL];
 #pragma unroll
     for (int c = 0; c < NCELL; ++c) {
@@ -585,8 +584,6 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
       myrank[c] = (unsigned char)__popcll(bal & ((1ull << lane) - 1ull));
       if (lane == 0) s_cnt[c][lw] = __popcll(bal);
     }
-    (void)rank_lo;
-    (void)rank_hi;
     __syncthreads();
     if (tid < NCELL) {
       int acc = 0;
