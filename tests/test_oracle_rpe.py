@@ -32,3 +32,26 @@ def test_rpe_attention_oracle_matches_reference():
                                          g["rpe_weights"][0], g["rpe_masks"][0], g["rpe_factors"][0])
     np.testing.assert_allclose(hid, g["rpe_h1"][0], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(sc, g["rpe_s1"][0], rtol=1e-4, atol=1e-6)
+
+
+def test_host_mirrors_keep_reference_state_dict_keys_and_embedding_matches():
+    """CPU-only: the nn.Module mirrors expose the reference's parameter / buffer names (checkpoints load unchanged) and
+    the plain-torch sinusoidal embedding equals the NumPy restatement."""
+    import torch
+    from gaussreg_amd.embedding import GeometricStructureEmbedding, SinusoidalPositionalEmbedding
+    from gaussreg_amd.rpe_attention import RPEMultiHeadAttention
+    m = GeometricStructureEmbedding(64, 0.2, 15, 3)
+    assert sorted(m.state_dict().keys()) == ["embedding.div_term", "proj_a.bias", "proj_a.weight", "proj_d.bias", "proj_d.weight"]
+    a = RPEMultiHeadAttention(64, 4)
+    assert sorted(a.state_dict().keys()) == sorted(f"proj_{n}.{p}" for n in "qkvp" for p in ("weight", "bias"))
+    with pytest.raises(ValueError):
+        RPEMultiHeadAttention(65, 4)
+    with pytest.raises(ValueError):
+        SinusoidalPositionalEmbedding(63)
+    with pytest.raises(ValueError):
+        GeometricStructureEmbedding(64, 0.2, 15, 3, reduction_a="sum")
+    emb = SinusoidalPositionalEmbedding(32)
+    idx = torch.rand(5, 7) * 20
+    np.testing.assert_allclose(emb(idx).numpy(), R.sinusoidal_embedding(idx.numpy(), emb.div_term.numpy()), rtol=1e-5, atol=1e-6)
+    g = load_golden("rpe.npz")
+    np.testing.assert_allclose(emb.div_term.numpy(), g["gse_c_div"], rtol=1e-6)   # same buffer as the reference builds
