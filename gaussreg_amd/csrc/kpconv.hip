@@ -8,6 +8,8 @@
 //             computed once into LDS, then every thread owns a channel and accumulates the K weighted sums
 //             over the neighbours with coalesced feature-row reads            -> WF (M, K*Cin)
 //   gemm      out = WF (M x K*Cin) . W (K*Cin x Cout) on fp32 MFMA 32x32x2, epilogue / neighbor_num + bias
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace gr {
@@ -34,8 +36,12 @@ __global__ __launch_bounds__(T) void kp_gather_kernel(
     const float* __restrict__ s_feats, const float* __restrict__ q_points, const float* __restrict__ s_points,
     const int64_t* __restrict__ nbr, int N, int H, int Cin, int K, const float* __restrict__ kpts, float sigma,
     float inf, const uint8_t* __restrict__ flag, float* __restrict__ WF, float* __restrict__ inv_num) {
-  __shared__ float s_w[KP_HMAX][KP_MAX + 1];
-  __shared__ int s_idx[KP_HMAX];
+  // sized per launch for min(H, KP_HMAX) neighbours: a fixed 256-row table (17 KB) capped the kernel at 9 one-wave
+  // workgroups per CU, and every workgroup is a chain of three dependent gathers
+  extern __shared__ __attribute__((aligned(16))) float kp_smem[];
+  const int hcap = min(H, KP_HMAX);
+  float (*s_w)[KP_MAX + 1] = reinterpret_cast<float (*)[KP_MAX + 1]>(kp_smem);
+  int* s_idx = reinterpret_cast<int*>(kp_smem + (size_t)hcap * (KP_MAX + 1));
   __shared__ int s_cnt;
   const int m = blockIdx.x;
   const float qx = q_points[3 * (int64_t)m], qy = q_points[3 * (int64_t)m + 1], qz = q_points[3 * (int64_t)m + 2];
@@ -309,14 +315,15 @@ extern "C" int gr_kpconv_forward(const float* s_feats, const float* q_points, co
   KernelTimer timer("kpconv", stream);
   if (n > 0)
     hipLaunchKernelGGL(rowflag_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, s_feats, (int)n, (int)cin, flag);
+  const size_t kp_lds = (size_t)std::min<int64_t>(h, KP_HMAX) * (KP_MAX + 2) * sizeof(float);
   if (cin <= 64)
-    hipLaunchKernelGGL((kp_gather_kernel<64>), dim3((unsigned)m), dim3(64), 0, stream, s_feats, q_points, s_points,
+    hipLaunchKernelGGL((kp_gather_kernel<64>), dim3((unsigned)m), dim3(64), kp_lds, stream, s_feats, q_points, s_points,
                        neighbor_indices, (int)n, (int)h, (int)cin, (int)k, kernel_points, sigma, inf, flag, WF, num);
   else if (cin <= 128)
-    hipLaunchKernelGGL((kp_gather_kernel<128>), dim3((unsigned)m), dim3(128), 0, stream, s_feats, q_points, s_points,
+    hipLaunchKernelGGL((kp_gather_kernel<128>), dim3((unsigned)m), dim3(128), kp_lds, stream, s_feats, q_points, s_points,
                        neighbor_indices, (int)n, (int)h, (int)cin, (int)k, kernel_points, sigma, inf, flag, WF, num);
   else
-    hipLaunchKernelGGL((kp_gather_kernel<256>), dim3((unsigned)m), dim3(256), 0, stream, s_feats, q_points, s_points,
+    hipLaunchKernelGGL((kp_gather_kernel<256>), dim3((unsigned)m), dim3(256), kp_lds, stream, s_feats, q_points, s_points,
                        neighbor_indices, (int)n, (int)h, (int)cin, (int)k, kernel_points, sigma, inf, flag, WF, num);
   if (m >= BT && cout >= BT) {
     const int64_t blocks128 = ((cout + BT - 1) / BT) * ((m + BT - 1) / BT);
