@@ -167,26 +167,26 @@ constexpr int BT = 128, BK = 16, BLD = BK + 1;
 // BM = rows per workgroup: 128 (2 x 2 waves of 64 x 64) or 64 (2 x 2 waves of 32 x 64) -- the smaller tile doubles the
 // number of workgroups when M is only ~10^4 rows and the K loop (15 * Cin long, serial inside a workgroup) would
 // otherwise leave the matrix pipes of half the chip waiting on one wave per SIMD.
-template <int BM>
+template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_nn_big_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                           int M, int N, int Kd, const float* __restrict__ den,
                                                           const float* __restrict__ bias, float* __restrict__ out) {
-  constexpr int WM = BM / 2;       // rows per wave
-  constexpr int TA = WM / 32;      // 32-row MFMA tiles per wave
+  constexpr int WM = BM / 2, WN = BN / 2;    // rows / columns per wave (2 x 2 waves)
+  constexpr int TA = WM / 32, TB = WN / 32;  // 32 x 32 MFMA tiles per wave
   __shared__ float sa[2][BM][BLD];
-  __shared__ float sb[2][BT][BLD];
-  const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BT;
+  __shared__ float sb[2][BN][BLD];
+  const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int wi = (w >> 1) * WM, wj = (w & 1) * 64;
-  f32x16 acc[TA][2];
+  const int wi = (w >> 1) * WM, wj = (w & 1) * WN;
+  f32x16 acc[TA][TB];
 #pragma unroll
   for (int a = 0; a < TA; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < TB; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  // staging: A tile BM rows x 16 k (coalesced along k: 16 threads per row), B tile 16 k x 128 cols
-  constexpr int NA = BM * BK / 256, NBv = BT * BK / 256;
+  // staging: A tile BM rows x 16 k (coalesced along k: 16 threads per row), B tile 16 k x BN cols
+  constexpr int NA = BM * BK / 256, NBv = BN * BK / 256;
   float ra[NA], rb[NBv];
   auto load = [&](int k0) {
 #pragma unroll
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void gemm_nn_big_kernel(const float* __restric
 #pragma unroll
     for (int u = 0; u < NBv; ++u) {
       const int e = tid + u * 256;
-      const int kk = e / BT, j = e % BT;
+      const int kk = e / BN, j = e % BN;
       const int gj = j0 + j, gkb = k0 + kk;
       rb[u] = (gj < N && gkb < Kd) ? B[(int64_t)gkb * N + gj] : 0.f;
     }
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void gemm_nn_big_kernel(const float* __restric
 #pragma unroll
     for (int u = 0; u < NBv; ++u) {
       const int e = tid + u * 256;
-      sb[buf][e % BT][e / BT] = rb[u];
+      sb[buf][e % BN][e / BN] = rb[u];
     }
   };
   load(0);
@@ -226,15 +226,15 @@ __global__ __launch_bounds__(256) void gemm_nn_big_kernel(const float* __restric
 #pragma unroll
     for (int k = 0; k < BK; k += 2) {
       const int kk = k + (lane >> 5);
-      float av[TA];
+      float av[TA], bv[TB];
 #pragma unroll
       for (int a = 0; a < TA; ++a) av[a] = sa[buf][wi + a * 32 + (lane & 31)][kk];
-      const float b0 = sb[buf][wj + (lane & 31)][kk], b1 = sb[buf][wj + 32 + (lane & 31)][kk];
 #pragma unroll
-      for (int a = 0; a < TA; ++a) {
-        acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], b0, acc[a][0], 0, 0, 0);
-        acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], b1, acc[a][1], 0, 0, 0);
-      }
+      for (int b = 0; b < TB; ++b) bv[b] = sb[buf][wj + b * 32 + (lane & 31)][kk];
+#pragma unroll
+      for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < TB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
     }
     if (more) {
       store(buf ^ 1);
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void gemm_nn_big_kernel(const float* __restric
 #pragma unroll
   for (int a = 0; a < TA; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < TB; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int gi = i0 + wi + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -325,21 +325,26 @@ extern "C" int gr_kpconv_forward(const float* s_feats, const float* q_points, co
   else
     hipLaunchKernelGGL((kp_gather_kernel<256>), dim3((unsigned)m), dim3(256), kp_lds, stream, s_feats, q_points, s_points,
                        neighbor_indices, (int)n, (int)h, (int)cin, (int)k, kernel_points, sigma, inf, flag, WF, num);
-  if (m >= BT && cout >= BT) {
+  const int kd = (int)(k * cin);
+  if (m >= BT && cout > 64) {
     const int64_t blocks128 = ((cout + BT - 1) / BT) * ((m + BT - 1) / BT);
     if (blocks128 >= 768) {  // three or more 128-row workgroups per CU: the big tile's operand reuse wins
       const dim3 grid((unsigned)((cout + BT - 1) / BT), (unsigned)((m + BT - 1) / BT));
-      hipLaunchKernelGGL(gemm_nn_big_kernel<128>, grid, dim3(256), 0, stream, WF, weights, (int)m, (int)cout,
-                         (int)(k * cin), num, bias, out);
+      hipLaunchKernelGGL((gemm_nn_big_kernel<128, 128>), grid, dim3(256), 0, stream, WF, weights, (int)m, (int)cout, kd, num,
+                         bias, out);
     } else {
       const dim3 grid((unsigned)((cout + BT - 1) / BT), (unsigned)((m + 63) / 64));
-      hipLaunchKernelGGL(gemm_nn_big_kernel<64>, grid, dim3(256), 0, stream, WF, weights, (int)m, (int)cout,
-                         (int)(k * cin), num, bias, out);
+      hipLaunchKernelGGL((gemm_nn_big_kernel<64, 128>), grid, dim3(256), 0, stream, WF, weights, (int)m, (int)cout, kd, num,
+                         bias, out);
     }
+  } else if (m >= BT && cout > 16) {
+    // narrow outputs (the 32- and 64-channel stages): 128 x 64 tiles, same double-buffered pipeline
+    const dim3 grid((unsigned)((cout + 63) / 64), (unsigned)((m + BT - 1) / BT));
+    hipLaunchKernelGGL((gemm_nn_big_kernel<128, 64>), grid, dim3(256), 0, stream, WF, weights, (int)m, (int)cout, kd, num, bias,
+                       out);
   } else {
     const dim3 grid((unsigned)((cout + GT - 1) / GT), (unsigned)((m + GT - 1) / GT));
-    hipLaunchKernelGGL(gemm_nn_kernel, grid, dim3(256), 0, stream, WF, weights, (int)m, (int)cout, (int)(k * cin), num,
-                       bias, out);
+    hipLaunchKernelGGL(gemm_nn_kernel, grid, dim3(256), 0, stream, WF, weights, (int)m, (int)cout, kd, num, bias, out);
   }
   GR_LAUNCH_CHECK();
   return GR_OK;
