@@ -4,35 +4,43 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Headline metric (BASELINE.json): GS views/s at 1 M Gaussians, 640x480 (configs[1]) -- a "step" is one
-pass of the rasterizer forward over one batch of `--views` cameras of the same synthetic 1 M-Gaussian
-scene (inputs resident in HBM before the timed region; cameras are 200-byte host structs).
-The second half of the metric, radius_neighbors Mpts/s on 200 k-point clouds, is measured the same
-way (its own warmup + timed steps) and reported under "radius_neighbors" in the same JSON line.
+`--gpus N` with N > 1 and no torchrun environment re-launches itself under torch.distributed.run (one rank per GPU, RCCL);
+it refuses to run if the box has fewer than N GPUs -- it never reports fewer ranks than asked for.
 
-Multi-GPU: one process per GPU, views / clouds are sharded per rank (independent units, no data-path
-collective), barrier + synchronize on both sides of the timed region, MAX over ranks of the elapsed
-time (RCCL all_reduce), value = total units over all ranks / that time ("scaling": "weak").
+Headline metric (BASELINE.json): GS views/s at 1 M Gaussians, 640x480 (configs[1]) -- a "step" is one pass of the
+rasterizer forward over one batch of `--views` cameras of the same synthetic 1 M-Gaussian scene (inputs resident in HBM
+before the timed region; cameras are 200-byte host structs).  The same JSON line also carries, each timed the same way
+(own warmup, barrier + synchronize on both sides, MAX over ranks):
+    "single_view"       views/s through diff_gaussian_rasterization.GaussianRasterizer.forward, ONE camera per call
+                        (the drop-in boundary number)
+    "radius_neighbors"  the second half of the metric: Mpts/s on 200 k-point clouds (bare ext.radius_neighbors), plus the
+                        limited-width radius_search path the data pyramid uses
+    "pairs"             configs[4]: batch coarse registration, `--pairs` synthetic scene pairs PER GPU (weak scaling; 128 per
+                        GPU = 1024 over 8), per-rank batches through FPS -> pyramid -> matching ops -> LGR -> RANSAC,
+                        4x4 transforms + errors gathered with ONE all_gather (gaussreg_amd/sharding.py)
+    "extras"            the other SURVEY 8(d) kernels: {ms, algorithmic bytes or flops, fraction of the bound}
+    "cpu_baseline"      the oracle / the compiled reference core on one host core, bounded samples, rank 0 at N=1 only
 
-`roofline`: dominant rasterizer kernel (the per-tile blend) -- algorithmic bytes per launch / average
-launch duration measured with HIP events on the launch stream inside the timed region
-(gr_timing_* hooks of the C ABI).  `cpu_baseline`: the oracle (kind "port") timed on one host core
-on a bounded sample of the same workload, rank 0 at N=1 only.
+Multi-GPU: units (views, clouds, pairs) are sharded per rank with no data-path collective; value = units of all ranks /
+MAX-over-ranks elapsed ("scaling": "weak").
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s peak, ~6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0   # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s peak, ~6.3 TB/s achievable)
+FP32_MFMA_PEAK_TF = 157.3
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -42,15 +50,120 @@ def parse():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--clouds", type=int, default=8, help="200k-point clouds per radius step (per GPU)")
+    ap.add_argument("--pairs", type=int, default=128, help="scene pairs per GPU in the configs[4] workload (0 = skip)")
+    ap.add_argument("--pair-batch", type=int, default=16, help="pairs per pyramid call")
+    ap.add_argument("--pair-points", type=int, default=200_000, help="points per cloud before FPS")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-radius", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--no-single-view", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    return ap.parse_args(argv)
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# process group / timing harness (device-agnostic: the CPU test drives it over gloo with stub workloads)
+class Harness:
+    def __init__(self, rank, world, device, sync=None):
+        self.rank, self.world, self.device = rank, world, device
+        self._sync = sync if sync is not None else (lambda: None)
+
+    @staticmethod
+    def from_env(backend="nccl"):
+        import torch
+        import torch.distributed as dist
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if backend == "nccl":
+            if not torch.cuda.is_available():
+                raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+            if local_rank >= torch.cuda.device_count():
+                raise SystemExit(f"rank {rank}: local GPU {local_rank} does not exist ({torch.cuda.device_count()} visible)")
+            torch.cuda.set_device(local_rank)
+            device = torch.device("cuda", local_rank)
+            sync = lambda: torch.cuda.synchronize(device)  # noqa: E731
+        else:
+            device, sync = torch.device("cpu"), None
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
+        return Harness(rank, world, device, sync)
+
+    def barrier(self):
+        import torch.distributed as dist
+        self._sync()
+        if self.world > 1:
+            dist.barrier()
+        self._sync()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([x], dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([x], dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def timed(self, fn, steps, warmup, after_warmup=None):
+        """W untimed steps, then EXACTLY `steps` steps bracketed by barrier + synchronize; MAX over ranks."""
+        for _ in range(warmup):
+            fn()
+        self.barrier()
+        if after_warmup is not None:
+            after_warmup()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+    def close(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+
+
+def throughput_line(h, metric, unit, units_per_step_per_rank, steps, warmup, elapsed, extra=None):
+    """The contract's whole-job aggregate: units of ALL ranks / MAX-over-ranks time."""
+    line = {"metric": metric, "value": round(h.world * units_per_step_per_rank * steps / elapsed, 2), "unit": unit,
+            "n_gpus": h.world, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None}
+    if extra:
+        line.update(extra)
+    return line
+
+
+def self_spawn(args, argv):
+    """`python bench.py --gpus N` outside torchrun: become `python -m torch.distributed.run ... bench.py --gpus N`."""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this box; refusing to report a "
+                         f"{args.gpus}-GPU number from fewer devices")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 def pmc_traffic(key, ok, units=None):
-    """HBM bytes per launch from the committed rocprofv3 --pmc summary (separate FETCH_SIZE / WRITE_SIZE
-    passes, FETCH doubled per MI355X_MICROARCH.md); only valid for the configuration it was taken on
-    (`units` = views or clouds per launch must match what the summary records)."""
+    """HBM bytes per launch from the newest committed rocprofv3 --pmc summary (separate FETCH_SIZE / WRITE_SIZE passes,
+    FETCH doubled per MI355X_MICROARCH.md); only valid for the configuration it was taken on."""
     if not ok:
         return None
     try:
@@ -71,61 +184,44 @@ def timing_read(L, name):
     return tot.value, n.value
 
 
-def main():
-    args = parse()
+def hbm_roofline(kernel, bytes_per_launch, total_ms, launches, traffic=None, **more):
+    avg_s = total_ms / max(launches, 1) / 1e3
+    ach = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else None
+    r = {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 2) if ach else None, "peak": HBM_PEAK_GBS,
+         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None, "traffic": traffic,
+         "bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(avg_s * 1e3, 4)}
+    r.update(more)
+    return r
+
+
+def per_step_ms(L, names, steps):
+    """{timer name: total milliseconds per STEP} (a timer may fire several times per step)."""
+    out = {}
+    for n in names:
+        ms, cnt = timing_read(L, n)
+        if cnt:
+            out[n] = round(ms / steps, 4)
+    return out
+
+
+def run_gpu(h, args):
     import numpy as np
     import torch
-    import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
-
-    from gaussreg_amd import _lib, ext, synthetic
-    from gaussreg_amd.rasterizer import GaussianRasterizationSettings, ViewBatch, rasterize_views
+    from gaussreg_amd import _lib, ext, sharding, synthetic
+    from gaussreg_amd.ops import radius_search
+    from gaussreg_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer, ViewBatch, rasterize_views
     L = _lib.lib()
-
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    def max_over_ranks(x):
-        if world == 1:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    def timed(fn, steps, warmup):
-        for _ in range(warmup):
-            fn()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            fn()
-        barrier()
-        return max_over_ranks(time.perf_counter() - t0)
+    dev, rank, world = h.device, h.rank, h.world
 
     # ------------------------------------------------------------------ rasterizer (headline)
     P, W, H, V = args.gaussians, args.width, args.height, args.views
     g = synthetic.gaussians_c2(P, seed=0, sh_degree=3)             # same scene on every rank
     cams = synthetic.camera_ring(V, W, H, seed=rank)               # different cameras per rank
     t = {k: torch.from_numpy(v).to(dev) for k, v in g.items()}
-    settings = [GaussianRasterizationSettings(H, W, c["tanfovx"], c["tanfovy"], torch.zeros(3), 1.0,
-                                              torch.from_numpy(c["viewmatrix"]), torch.from_numpy(c["projmatrix"]), 3,
-                                              torch.from_numpy(c["campos"]), False, False) for c in cams]
-    settings = ViewBatch(settings)  # cameras marshalled once, like the other inputs
+    settings_list = [GaussianRasterizationSettings(H, W, c["tanfovx"], c["tanfovy"], torch.zeros(3), 1.0,
+                                                   torch.from_numpy(c["viewmatrix"]), torch.from_numpy(c["projmatrix"]), 3,
+                                                   torch.from_numpy(c["campos"]), False, False) for c in cams]
+    settings = ViewBatch(settings_list)  # cameras marshalled once, like the other inputs
     last = {}
 
     def raster_step():
@@ -137,34 +233,49 @@ def main():
     raster_step()  # allocate / page in before anything is timed
     L.gr_timing_reset()
     L.gr_timing_enable(1)
-    for _ in range(args.warmup):
-        raster_step()
-    barrier()
-    L.gr_timing_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        raster_step()
-    barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    elapsed = h.timed(raster_step, args.steps, args.warmup, after_warmup=L.gr_timing_reset)
     blend_ms, blend_n = timing_read(L, "raster_blend")
-    sort_ms, sort_n = timing_read(L, "raster_sort")
-    pre_ms, pre_n = timing_read(L, "raster_preprocess")
+    raster_kernels = per_step_ms(L, ["raster_preprocess", "raster_depth_sort", "raster_bin", "raster_sort", "raster_blend"],
+                                 args.steps)
     L.gr_timing_enable(0)
     L.gr_timing_reset()
-    views_per_s = world * V * args.steps / elapsed
     R_total = float(sum(last["nr"]))
     # blend: algorithmic bytes per launch: per instance id 4 + xy 8 + conic/opacity 16 + rgb 12,
     # plus the image write 12*H*W per view
     blend_bytes = R_total * (4 + 8 + 16 + 12) + 12.0 * H * W * V
-    blend_avg_s = blend_ms / max(blend_n, 1) / 1e3
-    roofline = {"kernel": "raster_blend", "bound": "hbm",
-                "achieved": round(blend_bytes / blend_avg_s / 1e9, 2) if blend_avg_s > 0 else None,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(blend_bytes / blend_avg_s / 1e9 / HBM_PEAK_GBS, 4) if blend_avg_s > 0 else None,
-                "traffic": pmc_traffic("raster_blend", (P, W, H) == (1_000_000, 640, 480), V),
-                "bytes_per_launch": blend_bytes, "avg_launch_ms": round(blend_avg_s * 1e3, 4),
-                "other_kernels_ms": {"raster_preprocess": round(pre_ms / max(pre_n, 1), 4),
-                                     "raster_sort": round(sort_ms / max(sort_n, 1), 4)}}
+    line = throughput_line(
+        h, "GS views/sec @1M pts 640x480 (+ radius_neighbors Mpts/sec, see radius_neighbors)", "views/s", V, args.steps,
+        args.warmup, elapsed,
+        {"dtype": "f32", "data": "synthetic",
+         "config": {"workload": f"diff_gaussian_rasterization forward: {P} synthetic Gaussians (SH deg 3), {W}x{H}, "
+                                f"{V} views per step per GPU (configs[1])",
+                    "gaussians": P, "width": W, "height": H, "views_per_step": V,
+                    "instances_per_view": round(R_total / V, 1), "parallelism": f"per-view sharding x{world}"},
+         "roofline": hbm_roofline("raster_blend", blend_bytes, blend_ms, blend_n,
+                                  pmc_traffic("raster_blend", (P, W, H) == (1_000_000, 640, 480), V),
+                                  kernels_ms_per_step=raster_kernels)})
+
+    # ------------------------------------------------------------------ the boundary: one camera per forward() call
+    if not args.no_single_view:
+        rast = [GaussianRasterizer(s) for s in settings_list[: min(V, 8)]]
+        k = {"i": 0}
+
+        def single_step():
+            r = rast[k["i"] % len(rast)]
+            k["i"] += 1
+            last["sv"] = r(t["means3D"], None, t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+
+        single_step()
+        n_sv = max(args.steps, 20)
+        L.gr_timing_enable(1)
+        sv_elapsed = h.timed(single_step, n_sv, max(args.warmup, 3), after_warmup=L.gr_timing_reset)
+        sv_kernels = per_step_ms(L, ["raster_preprocess", "raster_depth_sort", "raster_bin", "raster_sort", "raster_blend"], n_sv)
+        L.gr_timing_enable(0)
+        L.gr_timing_reset()
+        line["single_view"] = {"value": round(world * n_sv / sv_elapsed, 2), "unit": "views/s",
+                               "ms_per_view": round(sv_elapsed / n_sv * 1e3, 4),
+                               "api": "diff_gaussian_rasterization.GaussianRasterizer.forward, one camera per call, "
+                                      "same 1M-Gaussian scene", "kernels_ms_per_view": sv_kernels}
 
     # ------------------------------------------------------------------ radius_neighbors (2nd half of the metric)
     radius = None
@@ -179,33 +290,84 @@ def main():
 
         radius_step()
         L.gr_timing_enable(1)
-        for _ in range(args.warmup):
-            radius_step()
-        barrier()
-        L.gr_timing_reset()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            radius_step()
-        barrier()
-        r_elapsed = max_over_ranks(time.perf_counter() - t0)
+        r_elapsed = h.timed(radius_step, args.steps, args.warmup, after_warmup=L.gr_timing_reset)
         fill_ms, fill_n = timing_read(L, "radius_fill")
-        cnt_ms, cnt_n = timing_read(L, "radius_count")
-        L.gr_timing_enable(0)
+        rk = per_step_ms(L, ["radius_bin", "radius_count", "radius_fill", "radius_fused"], args.steps)
         L.gr_timing_reset()
         nq = dpts.shape[0]
         width = out["nb"].shape[1]
         fill_bytes = 12.0 * nq + 12.0 * nq + 8.0 * nq * width      # 12 Nq + 12 Ns + 8 Nq W
-        fill_avg_s = fill_ms / max(fill_n, 1) / 1e3
+        step_s = r_elapsed / args.steps
         radius = {"metric": "radius_neighbors throughput, 200k-pt clouds", "value": round(world * nq * args.steps / r_elapsed / 1e6, 2),
-                  "unit": "Mpts/s", "ms_per_step": round(r_elapsed / args.steps * 1e3, 4),
+                  "unit": "Mpts/s", "ms_per_step": round(step_s * 1e3, 4),
                   "config": {"workload": f"{B} x 200k-pt clouds per GPU per step, r=0.0625, self-search, width {width}"},
-                  "roofline": {"kernel": "radius_fill", "bound": "hbm",
-                               "achieved": round(fill_bytes / fill_avg_s / 1e9, 2) if fill_avg_s > 0 else None,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(fill_bytes / fill_avg_s / 1e9 / HBM_PEAK_GBS, 4) if fill_avg_s > 0 else None,
-                               "traffic": pmc_traffic("radius_fill", True, B), "bytes_per_launch": fill_bytes,
-                               "avg_launch_ms": round(fill_avg_s * 1e3, 4),
-                               "other_kernels_ms": {"radius_count": round(cnt_ms / max(cnt_n, 1), 4)}}}
+                  "roofline": hbm_roofline("radius_fill", fill_bytes, fill_ms, fill_n, pmc_traffic("radius_fill", True, B),
+                                           kernels_ms_per_step=rk,
+                                           end_to_end_frac=round(fill_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4))}
+        # the width-limited path the data pyramid calls (radius_search with neighbor_limit, utils/data.py:35-67)
+        lim = 40
+
+        def limited_step():
+            out["nbl"] = radius_search(dpts, dpts, lens, lens, 0.0625, lim)
+
+        limited_step()
+        l_elapsed = h.timed(limited_step, args.steps, args.warmup, after_warmup=L.gr_timing_reset)
+        lk = per_step_ms(L, ["radius_bin", "radius_count", "radius_fill", "radius_fused"], args.steps)
+        L.gr_timing_enable(0)
+        L.gr_timing_reset()
+        lw = out["nbl"].shape[1]
+        lbytes = 24.0 * nq + 8.0 * nq * lw
+        radius["limited"] = {"value": round(world * nq * args.steps / l_elapsed / 1e6, 2), "unit": "Mpts/s",
+                             "ms_per_step": round(l_elapsed / args.steps * 1e3, 4), "neighbor_limit": lim, "width": lw,
+                             "end_to_end_frac": round(lbytes / (l_elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                             "kernels_ms_per_step": lk}
+        del out, dpts
+    line["radius_neighbors"] = radius
+
+    # ------------------------------------------------------------------ configs[4]: pair-sharded coarse registration
+    if args.pairs > 0:
+        from gaussreg_amd import pair_pipeline
+        n_total = args.pairs * world
+        a, b = sharding.shard_bounds(n_total, rank, world)
+        reg = pair_pipeline.PairRegistrar(dev)
+        pairs = [pair_pipeline.synthetic_room_pair(i, args.pair_points, dev) for i in range(a, b)]
+        reg.register_pairs(pairs[: min(2, len(pairs))])  # warm-up: allocator, lazy kernels
+        rows = []
+
+        def pairs_pass():
+            rows.clear()
+            for i in range(0, len(pairs), args.pair_batch):
+                rows.append(reg.register_pairs(pairs[i:i + args.pair_batch]))
+
+        L.gr_timing_enable(1)
+        p_elapsed = h.timed(pairs_pass, 1, 0, after_warmup=L.gr_timing_reset)
+        pk = per_step_ms(L, ["fps", "radius_bin", "radius_count", "radius_fill", "radius_fused", "sinkhorn", "lgr", "ransac"], 1)
+        L.gr_timing_enable(0)
+        L.gr_timing_reset()
+        local = torch.cat(rows, 0)
+        counts = [sharding.shard_bounds(n_total, r, world)[1] - sharding.shard_bounds(n_total, r, world)[0] for r in range(world)]
+        allres = sharding.gather_rows(local, counts)          # ONE all_gather of (pairs, 20) floats (RCCL over xGMI)
+        rre, rte = allres[:, 16], allres[:, 17]
+        ok = (rre < 5.0) & (rte < 0.1)
+        line["pairs"] = {"value": round(n_total / p_elapsed, 2), "unit": "pairs/s", "pairs_total": n_total,
+                         "pairs_per_gpu": args.pairs, "pair_batch": args.pair_batch, "ms_per_pair_per_gpu": round(p_elapsed / args.pairs * 1e3, 3),
+                         "config": "configs[4] stand-in: synthetic room pairs (2 x %d pts) -> FPS 30k -> 5-level pyramid -> "
+                                   "point_to_node -> SuperPointMatching -> Sinkhorn -> LocalGlobalRegistration -> RANSAC; "
+                                   "features are synthetic position descriptors (no pretrained weights offline)" % args.pair_points,
+                         "gathered_rows": int(allres.shape[0]), "registration_recall": round(float(ok.float().mean()), 4),
+                         "median_rre_deg": round(float(rre.median()), 4), "median_rte_m": round(float(rte.median()), 5),
+                         "kernel_ms_total_per_gpu": pk}
+        del pairs, rows
+
+    # ------------------------------------------------------------------ the other SURVEY 8(d) kernels
+    if not args.no_extras and rank == 0:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_extras
+            line["extras"] = bench_extras.run(dev)
+        except Exception as e:  # an extra must never take the headline down with it
+            line["extras"] = {"error": repr(e)}
+    h.barrier()
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1 only)
     cpu_baseline = None
@@ -221,9 +383,9 @@ def main():
         cpu_baseline = {"value": round(1.0 / dt, 4), "unit": "views/s", "cores": 1, "kind": "port",
                         "sample": f"1 view of the same {P}-Gaussian {W}x{H} scene through oracle/rasterizer_oracle.c "
                                   f"({dt:.2f} s; the rasterizer has no reference implementation in the GaussReg tree)"}
+        kind = "reference" if capi.have_ref() else "port"
         if radius is not None:
             p1, l1 = synthetic.cloud_200k(1, seed=0)
-            kind = "reference" if capi.have_ref() else "port"
             fn = capi.ref_radius_neighbors if kind == "reference" else capi.radius_neighbors
             tc = time.perf_counter()
             fn(p1.numpy(), p1.numpy(), l1.numpy(), l1.numpy(), 0.0625)
@@ -232,21 +394,52 @@ def main():
                                       "sample": "one 200k-pt cloud, single thread ("
                                                 + ("reference C++ core compiled in oracle/_ref" if kind == "reference"
                                                    else "oracle/radius_neighbors_oracle.c") + f", {dt:.2f} s)"}
+        if "pairs" in line:
+            # the reference's per-pair CPU work on this path: the collate pyramid (utils/data.py:13-77) on one core
+            from gaussreg_amd import pair_pipeline
+            ref_p, src_p, _ = pair_pipeline.synthetic_room_pair(0, 30000, torch.device("cpu"))
+            pts = np.concatenate([ref_p.numpy(), src_p.numpy()])
+            lens = np.array([30000, 30000], np.int64)
+            gs = capi.ref_grid_subsampling if kind == "reference" else capi.grid_subsampling
+            rn = capi.ref_radius_neighbors if kind == "reference" else capi.radius_neighbors
+            tc = time.perf_counter()
+            plist, llist, voxel, rad = [pts], [lens], 0.025, 0.0625
+            for i in range(1, 5):
+                voxel *= 2
+                p2, l2 = gs(plist[-1], llist[-1], voxel)
+                plist.append(p2)
+                llist.append(l2)
+            for i in range(5):
+                rn(plist[i], plist[i], llist[i], llist[i], rad)
+                if i < 4:
+                    rn(plist[i + 1], plist[i], llist[i + 1], llist[i], rad)
+                    rn(plist[i], plist[i + 1], llist[i], llist[i + 1], 2 * rad)
+                rad *= 2
+            dt = time.perf_counter() - tc
+            line["pairs"]["cpu_baseline"] = {"value": round(1.0 / dt, 4), "unit": "pairs/s", "cores": 1, "kind": kind,
+                                             "sample": f"the collate pyramid (4 grid_subsample + 13 radius_search) of ONE 2x30000-pt "
+                                                       f"pair on one core ({dt:.2f} s); FPS and the network are not included"}
+    line["cpu_baseline"] = cpu_baseline
+    return line
 
-    if rank == 0:
-        line = {"metric": "GS views/sec @1M pts 640x480 (+ radius_neighbors Mpts/sec, see radius_neighbors)",
-                "value": round(views_per_s, 2), "unit": "views/s", "n_gpus": world, "steps": args.steps,
-                "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": f"diff_gaussian_rasterization forward: {P} synthetic Gaussians (SH deg 3), "
-                                       f"{W}x{H}, {V} views per step per GPU (configs[1])",
-                           "gaussians": P, "width": W, "height": H, "views_per_step": V,
-                           "instances_per_view": round(R_total / V, 1), "parallelism": f"per-view sharding x{world}"},
-                "roofline": roofline, "cpu_baseline": cpu_baseline, "radius_neighbors": radius}
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return self_spawn(args, argv)
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={env_world}: they must agree")
+    h = Harness.from_env("nccl")
+    line = run_gpu(h, args)
+    if h.rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    h.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

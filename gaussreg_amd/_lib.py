@@ -72,11 +72,15 @@ SIGNATURES.update({
     "gr_point_matching_workspace_bytes": (c_size, [c_i64]),
     "gr_corr_matrix": (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_void, c_int, c_int, c_f32, c_void, c_i64p,
                                c_void, c_size, c_void]),
+    "gr_corr_matrix_exp": (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_void, c_int, c_int, c_f32, c_void, c_i64p,
+                                   c_void, c_size, c_void]),
     "gr_corr_gather": (c_int, [c_void, c_i64, c_i64, c_i64] + [c_void] * 6 + [c_int] + [c_void] * 5 +
                        [c_void, c_size, c_void]),
     "gr_lgr_workspace_bytes": (c_size, [c_i64]),
     "gr_lgr_register": (c_int, [c_void, c_void, c_void, c_i64, c_i64, c_void, c_f32, c_int, c_int, c_void, c_void,
                                 c_size, c_void]),
+    "gr_lgr_register_verify": (c_int, [c_void, c_void, c_void, c_i64, c_i64, c_void, c_void, c_void, c_void, c_i64,
+                                       c_f32, c_int, c_int, c_void, c_void, c_size, c_void]),
     "gr_ransac_sample_hash": (ctypes.c_uint32, [ctypes.c_uint32] * 4),
     "gr_ransac_workspace_bytes": (c_size, [c_i64]),
     "gr_ransac_similarity": (c_int, [c_void, c_void, c_i64, c_int, c_i64, ctypes.c_uint32, c_f32, c_int, c_int, c_void,

@@ -474,10 +474,15 @@ extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64
     nmax = std::max(nmax, h_lengths[b]);
   }
   GR_REQUIRE(off[batch] == n, "lengths do not sum to n");
-  // G workgroups per cloud, all co-resident: G*batch <= 256 (one 1024-thread workgroup per CU)
-  int G = (int)std::min<int64_t>({(int64_t)FPS_GMAX, (nmax + 2047) / 2048, std::max<int64_t>(1, 256 / batch)});
-  G = std::max(G, 1);
-  const int64_t per = ((nmax + G - 1) / G + FPS_T - 1) / FPS_T;  // points per thread
+  for (int64_t b = 0; b < batch; ++b)
+    GR_REQUIRE(h_num_samples[b] == 0 || (st[b] >= 0 && (int64_t)st[b] < h_lengths[b]),
+               "cloud %lld: start index %d outside [0, %lld)", (long long)b, st[b], (long long)h_lengths[b]);
+  // G workgroups per cloud exchange candidates through memory, so all G*batch of them must be co-resident: one
+  // 1024-thread workgroup per CU of THIS device (a CPX/DPX partition or a CU-masked stream has fewer than 256).
+  int dev_id = 0, n_cu = 0;
+  GR_HIP(hipGetDevice(&dev_id));
+  GR_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id));
+  GR_REQUIRE(n_cu > 0, "device reports no compute units");
   Carver c(ws);
   float* mind = c.take<float>(n);
   int32_t* d_off = c.take<int32_t>(batch + 1);
@@ -489,28 +494,57 @@ extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64
   GR_HIP(hipMemcpyAsync(d_off, off.data(), sizeof(int32_t) * (batch + 1), hipMemcpyHostToDevice, stream));
   GR_HIP(hipMemcpyAsync(d_soff, soff.data(), sizeof(int32_t) * (batch + 1), hipMemcpyHostToDevice, stream));
   GR_HIP(hipMemcpyAsync(d_st, st.data(), sizeof(int32_t) * batch, hipMemcpyHostToDevice, stream));
-  GR_HIP(hipMemsetAsync(arrive, 0, sizeof(unsigned) * (batch + 1), stream));
-  GR_HIP(hipMemsetAsync(cand, 0, sizeof(FpsCand) * (size_t)batch * 2 * FPS_GMAX, stream));
-  GR_HIP(hipMemsetAsync(mslots, 0, sizeof(unsigned long long) * (size_t)batch * 2 * FPS_GMAX * FPS_SLOT_W, stream));
   int* err = reinterpret_cast<int*>(arrive + batch);
-  {
-    KernelTimer timer("fps", stream);
-    const dim3 grid((unsigned)(batch * G)), block(FPS_T);
-#define GR_FPS_LAUNCH(PPT) \
-  hipLaunchKernelGGL(fps_kernel<PPT>, grid, block, 0, stream, points, d_off, d_soff, d_st, mind, cand, err, G, out_indices)
-#define GR_FPS_MULTI(PPT) \
-  hipLaunchKernelGGL(fps_multi_kernel<PPT>, grid, block, 0, stream, points, d_off, d_soff, d_st, mslots, err, G, out_indices)
-    if (per <= 4) GR_FPS_MULTI(4);
-    else if (per <= 12) GR_FPS_MULTI(12);
-    else if (per <= 20) GR_FPS_MULTI(20);
-    else GR_FPS_LAUNCH(0);  // slab too large for registers: one sample per round, distances streamed from L2
-#undef GR_FPS_MULTI
-#undef GR_FPS_LAUNCH
-    GR_LAUNCH_CHECK();
+  int G = (int)std::min<int64_t>({(int64_t)FPS_GMAX, (nmax + 2047) / 2048, std::max<int64_t>(1, (int64_t)n_cu / batch)});
+  G = std::max(G, 1);
+  // Attempt 0: G co-operating workgroups per cloud, launched co-operatively so that the runtime CHECKS the grid against
+  // the device's residency instead of assuming it.  Attempt 1 (only if attempt 0 was refused or its inter-workgroup
+  // exchange timed out, e.g. because another job holds CUs): one workgroup per cloud, which needs no co-residency.
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (attempt == 1) {
+      if (G == 1) break;
+      G = 1;
+    }
+    const int64_t per = ((nmax + G - 1) / G + FPS_T - 1) / FPS_T;  // points per thread
+    GR_HIP(hipMemsetAsync(arrive, 0, sizeof(unsigned) * (batch + 1), stream));
+    GR_HIP(hipMemsetAsync(cand, 0, sizeof(FpsCand) * (size_t)batch * 2 * FPS_GMAX, stream));
+    GR_HIP(hipMemsetAsync(mslots, 0, sizeof(unsigned long long) * (size_t)batch * 2 * FPS_GMAX * FPS_SLOT_W, stream));
+    bool launched = true;
+    {
+      KernelTimer timer("fps", stream);
+      const dim3 grid((unsigned)(batch * G)), block(FPS_T);
+      const float* a_points = points;
+      int a_G = G;
+      void* multi_args[] = {&a_points, &d_off, &d_soff, &d_st, &mslots, &err, &a_G, &out_indices};
+      void* single_args[] = {&a_points, &d_off, &d_soff, &d_st, &mind, &cand, &err, &a_G, &out_indices};
+      const void* fn;
+      void** args = multi_args;
+      if (per <= 4) fn = reinterpret_cast<const void*>(fps_multi_kernel<4>);
+      else if (per <= 12) fn = reinterpret_cast<const void*>(fps_multi_kernel<12>);
+      else if (per <= 20) fn = reinterpret_cast<const void*>(fps_multi_kernel<20>);
+      else {  // slab too large for registers: one sample per round, distances streamed from L2
+        fn = reinterpret_cast<const void*>(fps_kernel<0>);
+        args = single_args;
+      }
+      hipError_t le;
+      if (G > 1) le = hipLaunchCooperativeKernel(fn, grid, block, args, 0, stream);
+      else le = hipLaunchKernel(fn, grid, block, args, 0, stream);
+      if (le != hipSuccess) {
+        (void)hipGetLastError();
+        if (G > 1 && attempt == 0) launched = false;  // grid not co-resident on this device: fall back
+        else {
+          set_error("fps launch failed: %s", hipGetErrorString(le));
+          return GR_ERR_HIP;
+        }
+      }
+    }
+    if (!launched) continue;
+    int h_err = 0;
+    GR_HIP(hipMemcpyAsync(&h_err, err, sizeof(int), hipMemcpyDeviceToHost, stream));
+    GR_HIP(hipStreamSynchronize(stream));  // also keeps the host staging vectors alive past the copies
+    if (h_err == 0) return GR_OK;
+    GR_REQUIRE(attempt == 0 && G > 1, "fps: exchange timed out with a single workgroup per cloud (internal error)");
   }
-  int h_err = 0;
-  GR_HIP(hipMemcpyAsync(&h_err, err, sizeof(int), hipMemcpyDeviceToHost, stream));
-  GR_HIP(hipStreamSynchronize(stream));  // also keeps the host staging vectors alive past the copies
-  GR_REQUIRE(h_err == 0, "fps: inter-workgroup barrier timed out (GPU shared with another job?)");
-  return GR_OK;
+  set_error("fps: inter-workgroup exchange timed out and the single-workgroup retry was not possible");
+  return GR_ERR_HIP;
 }

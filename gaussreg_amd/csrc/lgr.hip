@@ -239,15 +239,19 @@ extern "C" size_t gr_lgr_workspace_bytes(int64_t batch) {
   return align_up((size_t)batch * 12 * 4, 256) + 2 * align_up((size_t)batch * 4, 256) + 256;
 }
 
-extern "C" int gr_lgr_register(const float* ref_corr_points, const float* src_corr_points, const float* corr_scores,
-                               int64_t num_corr, int64_t batch, const void* pm_ws, float acceptance_radius,
-                               int correspondence_threshold, int num_refinement_steps, float* out_transform, void* ws,
-                               size_t ws_bytes, void* stream_) {
+extern "C" int gr_lgr_register_verify(const float* ref_corr_points, const float* src_corr_points,
+                                      const float* corr_scores, int64_t num_corr, int64_t batch, const void* pm_ws,
+                                      const float* verify_ref_points, const float* verify_src_points,
+                                      const float* verify_scores, int64_t num_verify, float acceptance_radius,
+                                      int correspondence_threshold, int num_refinement_steps, float* out_transform,
+                                      void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   GR_REQUIRE(num_corr >= 0 && batch >= 0 && num_refinement_steps >= 1 && num_corr < (1ll << 31), "bad arguments");
   GR_REQUIRE(out_transform != nullptr, "out_transform is null");
   GR_REQUIRE(num_corr > 0, "no correspondences: the reference's procrustes would divide by eps here");
   GR_REQUIRE(ref_corr_points && src_corr_points && corr_scores && pm_ws, "null argument");
+  GR_REQUIRE(verify_ref_points && verify_src_points && verify_scores && num_verify > 0 && num_verify <= num_corr,
+             "bad verification set");
   if (!ws || ws_bytes < gr_lgr_workspace_bytes(batch)) {
     set_error("lgr workspace too small");
     return GR_ERR_WORKSPACE;
@@ -260,15 +264,26 @@ extern "C" int gr_lgr_register(const float* ref_corr_points, const float* src_co
   const int32_t* offsets = counts + batch;
   KernelTimer timer("lgr", stream);
   if (batch > 0) {
+    // hypotheses come from ALL correspondences of a patch (:158-164); they are scored on the verification set (:165-170)
     hipLaunchKernelGGL(lgr_local_kernel, dim3((unsigned)batch), dim3(LG_T), 0, stream, src_corr_points, ref_corr_points,
                        corr_scores, counts, offsets, correspondence_threshold, transforms, valid);
-    hipLaunchKernelGGL(lgr_verify_kernel, dim3((unsigned)batch), dim3(LG_T), 0, stream, src_corr_points, ref_corr_points,
-                       (int)num_corr, transforms, valid, acceptance_radius, inl);
+    hipLaunchKernelGGL(lgr_verify_kernel, dim3((unsigned)batch), dim3(LG_T), 0, stream, verify_src_points,
+                       verify_ref_points, (int)num_verify, transforms, valid, acceptance_radius, inl);
   }
   // the first refinement step of the reference is "procrustes with the best hypothesis' mask" (:183), the
   // remaining num_refinement_steps - 1 recompute the mask from the running estimate (:184-190)
-  hipLaunchKernelGGL(lgr_refine_kernel, dim3(1), dim3(LG_T), 0, stream, src_corr_points, ref_corr_points, corr_scores,
-                     (int)num_corr, (int)batch, transforms, inl, acceptance_radius, num_refinement_steps, out_transform);
+  hipLaunchKernelGGL(lgr_refine_kernel, dim3(1), dim3(LG_T), 0, stream, verify_src_points, verify_ref_points,
+                     verify_scores, (int)num_verify, (int)batch, transforms, inl, acceptance_radius, num_refinement_steps,
+                     out_transform);
   GR_LAUNCH_CHECK();
   return GR_OK;
+}
+
+extern "C" int gr_lgr_register(const float* ref_corr_points, const float* src_corr_points, const float* corr_scores,
+                               int64_t num_corr, int64_t batch, const void* pm_ws, float acceptance_radius,
+                               int correspondence_threshold, int num_refinement_steps, float* out_transform, void* ws,
+                               size_t ws_bytes, void* stream_) {
+  return gr_lgr_register_verify(ref_corr_points, src_corr_points, corr_scores, num_corr, batch, pm_ws, ref_corr_points,
+                                src_corr_points, corr_scores, num_corr, acceptance_radius, correspondence_threshold,
+                                num_refinement_steps, out_transform, ws, ws_bytes, stream_);
 }

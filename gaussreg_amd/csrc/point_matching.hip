@@ -18,7 +18,7 @@ constexpr int PM_T = 256;
 __global__ __launch_bounds__(PM_T) void corr_matrix_kernel(
     const float* __restrict__ score, int K1, int K2, const uint8_t* __restrict__ ref_masks,
     const uint8_t* __restrict__ src_masks, int k, int mutual, float thr, uint8_t* __restrict__ corr,
-    int32_t* __restrict__ counts) {
+    int32_t* __restrict__ counts, int scores_are_exp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ld = K2 + 1;  // +1: a thread walking down a row-major column / along a row stays conflict-free
   float* E = reinterpret_cast<float*>(smem);
@@ -28,7 +28,9 @@ __global__ __launch_bounds__(PM_T) void corr_matrix_kernel(
   const int b = blockIdx.x;
   const float* sm = score + (int64_t)b * K1 * K2;
   for (int e = threadIdx.x; e < K1 * K2; e += PM_T) {
-    E[(e / K2) * ld + (e % K2)] = expf(sm[e]);  // point_matching.py:96 torch.exp(score_mat)
+    // point_matching.py:96 torch.exp(score_mat); compute_correspondence_matrix itself (:32-66) receives the
+    // exponentiated matrix and thresholds it as is -- no log/exp round trip for that entry
+    E[(e / K2) * ld + (e % K2)] = scores_are_exp ? sm[e] : expf(sm[e]);
     flag[(e / K2) * ldf + (e % K2)] = 0;
   }
   __syncthreads();
@@ -146,7 +148,7 @@ extern "C" size_t gr_point_matching_workspace_bytes(int64_t batch) {
   return align_up((size_t)(2 * batch + 2) * sizeof(int32_t) + scan_ws_ints(batch) * sizeof(int32_t) + 1024, 256);
 }
 
-extern "C" int gr_corr_matrix(const float* score_mat, int64_t batch, int64_t k1, int64_t k2,
+static int corr_matrix_impl(int scores_are_exp, const float* score_mat, int64_t batch, int64_t k1, int64_t k2,
                               const uint8_t* ref_knn_masks, const uint8_t* src_knn_masks, int k, int mutual,
                               float confidence_threshold, uint8_t* corr_mat, int64_t* h_num_corr, void* ws,
                               size_t ws_bytes, void* stream_) {
@@ -170,7 +172,7 @@ extern "C" int gr_corr_matrix(const float* score_mat, int64_t batch, int64_t k1,
   int32_t* total = offsets + batch;
   int32_t* scan_ws = total + 2;
   hipLaunchKernelGGL(corr_matrix_kernel, dim3((unsigned)batch), dim3(PM_T), lds, stream, score_mat, (int)k1, (int)k2,
-                     ref_knn_masks, src_knn_masks, k, mutual, confidence_threshold, corr_mat, counts);
+                     ref_knn_masks, src_knn_masks, k, mutual, confidence_threshold, corr_mat, counts, scores_are_exp);
   GR_LAUNCH_CHECK();
   int rc = exclusive_scan_i32(counts, offsets, batch, 1, batch, scan_ws, total, stream);
   if (rc != GR_OK) return rc;
@@ -181,6 +183,22 @@ extern "C" int gr_corr_matrix(const float* score_mat, int64_t batch, int64_t k1,
     *h_num_corr = t;
   }
   return GR_OK;
+}
+
+extern "C" int gr_corr_matrix(const float* score_mat, int64_t batch, int64_t k1, int64_t k2,
+                              const uint8_t* ref_knn_masks, const uint8_t* src_knn_masks, int k, int mutual,
+                              float confidence_threshold, uint8_t* corr_mat, int64_t* h_num_corr, void* ws,
+                              size_t ws_bytes, void* stream_) {
+  return corr_matrix_impl(0, score_mat, batch, k1, k2, ref_knn_masks, src_knn_masks, k, mutual, confidence_threshold,
+                          corr_mat, h_num_corr, ws, ws_bytes, stream_);
+}
+
+extern "C" int gr_corr_matrix_exp(const float* exp_score_mat, int64_t batch, int64_t k1, int64_t k2,
+                                  const uint8_t* ref_knn_masks, const uint8_t* src_knn_masks, int k, int mutual,
+                                  float confidence_threshold, uint8_t* corr_mat, int64_t* h_num_corr, void* ws,
+                                  size_t ws_bytes, void* stream_) {
+  return corr_matrix_impl(1, exp_score_mat, batch, k1, k2, ref_knn_masks, src_knn_masks, k, mutual, confidence_threshold,
+                          corr_mat, h_num_corr, ws, ws_bytes, stream_);
 }
 
 extern "C" int gr_corr_gather(const float* score_mat, int64_t batch, int64_t k1, int64_t k2, const uint8_t* corr_mat,

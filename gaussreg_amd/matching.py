@@ -81,7 +81,7 @@ class PointMatching(nn.Module):
             # GaussReg never enables it (model.py:51-65 uses LocalGlobalRegistration with use_dustbin False)
             raise NotImplementedError("use_dustbin=True is not supported (unusable in the reference as well)")
 
-    def _corr(self, score_mat, ref_knn_masks, src_knn_masks, want_count):
+    def _corr(self, score_mat, ref_knn_masks, src_knn_masks, want_count, scores_are_exp=False):
         dev = _lib.require_gpu()
         L = _lib.lib()
         s = _f32c(score_mat, dev)
@@ -92,17 +92,17 @@ class PointMatching(nn.Module):
         n = ctypes.c_int64(0)
         with torch.cuda.device(dev):
             ws = _lib.workspace(dev, L.gr_point_matching_workspace_bytes(B))
-            _lib.check(L.gr_corr_matrix(_lib.ptr(s), B, K1, K2, _lib.ptr(rm), _lib.ptr(sm), int(self.k),
-                                        int(bool(self.mutual)), float(self.confidence_threshold), _lib.ptr(corr),
-                                        ctypes.byref(n) if want_count else None, _lib.ptr(ws), ws.numel(),
-                                        _lib.stream_ptr(dev)))
+            fn = L.gr_corr_matrix_exp if scores_are_exp else L.gr_corr_matrix
+            _lib.check(fn(_lib.ptr(s), B, K1, K2, _lib.ptr(rm), _lib.ptr(sm), int(self.k),
+                          int(bool(self.mutual)), float(self.confidence_threshold), _lib.ptr(corr),
+                          ctypes.byref(n) if want_count else None, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)))
         return s, corr, n.value, ws
 
     @torch.no_grad()
     def compute_correspondence_matrix(self, score_mat, ref_knn_masks, src_knn_masks):
         """`score_mat` here is exp(log-scores), as in the reference call sites (point_matching.py:98,
-        local_global_registration.py:211); the kernel exponentiates, so pass it the logs."""
-        s, corr, _, _ = self._corr(torch.log(score_mat), ref_knn_masks, src_knn_masks, False)
+        local_global_registration.py:211): it is thresholded as given (gr_corr_matrix_exp), no log/exp round trip."""
+        s, corr, _, _ = self._corr(score_mat, ref_knn_masks, src_knn_masks, False, scores_are_exp=True)
         return corr if score_mat.is_cuda else corr.to(score_mat.device)
 
     @torch.no_grad()
@@ -155,8 +155,6 @@ class LocalGlobalRegistration(nn.Module):
         self.num_refinement_steps = num_refinement_steps
         if use_dustbin:
             raise NotImplementedError("use_dustbin=True is not supported (GaussReg sets it False, config.py:121)")
-        if correspondence_limit is not None:
-            raise NotImplementedError("correspondence_limit is not supported (GaussReg sets it None, config.py:124)")
         self._pm = PointMatching(k, mutual, confidence_threshold, False, use_global_score)
 
     @torch.no_grad()
@@ -187,10 +185,16 @@ class LocalGlobalRegistration(nn.Module):
                                             _lib.ptr(o_rp), _lib.ptr(o_sp), _lib.ptr(o_i[0]), _lib.ptr(o_i[1]),
                                             _lib.ptr(o_sc), _lib.ptr(pm_ws), pm_ws.numel(), st))
                 ws2 = torch.empty(L.gr_lgr_workspace_bytes(B) + 256, dtype=torch.uint8, device=dev)
-                _lib.check(L.gr_lgr_register(_lib.ptr(o_rp), _lib.ptr(o_sp), _lib.ptr(o_sc), n, B, _lib.ptr(pm_ws),
-                                             float(self.acceptance_radius), int(self.correspondence_threshold),
-                                             int(self.num_refinement_steps), _lib.ptr(transform), _lib.ptr(ws2),
-                                             ws2.numel(), st))
+                v_rp, v_sp, v_sc = o_rp, o_sp, o_sc
+                if self.correspondence_limit is not None and n > int(self.correspondence_limit):
+                    # verification set = top-`limit` global scores (local_global_registration.py:145-148)
+                    v_sc, sel = o_sc.topk(k=int(self.correspondence_limit), largest=True)
+                    v_rp, v_sp, v_sc = o_rp[sel].contiguous(), o_sp[sel].contiguous(), v_sc.contiguous()
+                _lib.check(L.gr_lgr_register_verify(_lib.ptr(o_rp), _lib.ptr(o_sp), _lib.ptr(o_sc), n, B, _lib.ptr(pm_ws),
+                                                    _lib.ptr(v_rp), _lib.ptr(v_sp), _lib.ptr(v_sc), v_sc.shape[0],
+                                                    float(self.acceptance_radius), int(self.correspondence_threshold),
+                                                    int(self.num_refinement_steps), _lib.ptr(transform), _lib.ptr(ws2),
+                                                    ws2.numel(), st))
         outs = (o_rp, o_sp, o_sc, transform)
         if out_device.type != "cuda":
             outs = tuple(o.to(out_device) for o in outs)

@@ -1,0 +1,179 @@
+"""Batch coarse registration of scene pairs on one GPU (BASELINE.json configs[4], the per-rank body).
+
+What the reference does per pair (experiments/geotransformer.gaussian_splatting.indoor/test.py:146-212 -> model.py:69-222):
+    FPS to 30 000 points (test.py:46) -> collate / 5-level pyramid (utils/data.py:139-189) -> KPConvFPN + GeometricTransformer
+    (learned; stock PyTorch in the reference) -> SuperPointMatching -> patch gather -> einsum scores -> log-Sinkhorn ->
+    LocalGlobalRegistration -> RANSAC with scale (model.py:209-220) -> 4x4 transform + RRE / RTE (test.py:193-198).
+
+Here every operator of this repo on that path runs at the real shapes, chained (each stage consumes the previous stage's
+output).  The learned backbone / transformer weights are not available offline, so the two feature tensors they would
+produce (`feats_c`, 256-d per superpoint; `feats_f`, per fine point) are replaced by SYNTHETIC position descriptors:
+random Fourier features of the point's coordinates in the reference frame (the source cloud is mapped through the pair's
+known ground-truth transform first).  That keeps the matching stack meaningful -- correspondences are real, the estimated
+transform can be scored against the ground truth -- without pretending to have run the network.
+
+Pairs are independent units: `register_pairs` is what one rank runs on its block of the pair list (gaussreg_amd/sharding.py).
+"""
+import math
+
+import torch
+
+from .data import precompute_data_stack_mode
+from .matching import LocalGlobalRegistration, SuperPointMatching
+from .ops import point_to_node_partition
+from .registration import farthest_point_sampling, registration_with_ransac_from_correspondences
+from .sinkhorn import LearnableLogOptimalTransport
+
+# experiments/geotransformer.gaussian_splatting.indoor/config.py:78-125
+NUM_STAGES = 5
+INIT_VOXEL = 0.025
+INIT_RADIUS = 0.0625
+NEIGHBOR_LIMITS = [89, 30, 43, 49, 49]  # demo.py:136
+NUM_CORRESPONDENCES = 256               # coarse_matching.num_correspondences
+POINT_LIMIT = 128                       # model.num_points_in_patch
+NUM_SINKHORN_ITERATIONS = 100
+RESULT_LEN = 16 + 4                     # flattened 4x4 + (RRE deg, RTE m, #correspondences, inlier ratio)
+
+
+def synthetic_room_pair(seed, n_per_cloud, device):
+    """One scene pair in the style of SURVEY.md App. D, generated on the device: both clouds sample the faces + interior
+    of the same 4 x 3 x 2.5 m room (face noise sigma 1 cm, independent samples); the source cloud is then moved by a
+    random rigid transform.  Returns (ref (n,3), src (n,3), T_gt (4,4) mapping src -> ref), float32."""
+    g = torch.Generator(device=device).manual_seed(1_000_003 * int(seed) + 17)
+    ext = torch.tensor([4.0, 3.0, 2.5], device=device)
+
+    def cloud():
+        nf = n_per_cloud // 8
+        parts = []
+        for axis in range(3):
+            for side in (0.0, 1.0):
+                p = torch.rand((nf, 3), generator=g, device=device) * ext
+                p[:, axis] = side * ext[axis] + 0.01 * torch.randn((nf,), generator=g, device=device)
+                parts.append(p)
+        parts.append(torch.rand((n_per_cloud - 6 * nf, 3), generator=g, device=device) * ext)
+        p = torch.cat(parts, 0)
+        return p - ext / 2
+
+    ref, src_in_ref = cloud(), cloud()
+    ang = (torch.rand(3, generator=g, device=device) - 0.5) * torch.tensor([2 * math.pi, 0.6, 0.6], device=device)
+    cz, sz, cy, sy, cx, sx = (torch.cos(ang[0]), torch.sin(ang[0]), torch.cos(ang[1]), torch.sin(ang[1]),
+                              torch.cos(ang[2]), torch.sin(ang[2]))
+    one, zero = torch.ones((), device=device), torch.zeros((), device=device)
+    Rz = torch.stack([torch.stack([cz, -sz, zero]), torch.stack([sz, cz, zero]), torch.stack([zero, zero, one])])
+    Ry = torch.stack([torch.stack([cy, zero, sy]), torch.stack([zero, one, zero]), torch.stack([-sy, zero, cy])])
+    Rx = torch.stack([torch.stack([one, zero, zero]), torch.stack([zero, cx, -sx]), torch.stack([zero, sx, cx])])
+    R = Rz @ Ry @ Rx                                            # src -> ref rotation
+    t = (torch.rand(3, generator=g, device=device) - 0.5) * 2.0
+    src = (src_in_ref - t) @ R                                  # x_ref = R x_src + t  <=>  x_src = R^T (x_ref - t)
+    T = torch.eye(4, device=device)
+    T[:3, :3] = R
+    T[:3, 3] = t
+    return ref.float().contiguous(), src.float().contiguous(), T
+
+
+class PositionDescriptor:
+    """Random Fourier features of a 3-D position: cos(W x + b) / sqrt(C).  `bandwidth` (metres) sets how fast the
+    descriptor decorrelates with distance."""
+
+    def __init__(self, channels, bandwidth, device, seed):
+        g = torch.Generator(device=device).manual_seed(seed)
+        self.W = torch.randn((3, channels), generator=g, device=device) / bandwidth
+        self.b = torch.rand((channels,), generator=g, device=device) * (2 * math.pi)
+        self.scale = math.sqrt(2.0 / channels)
+
+    def __call__(self, x):
+        return torch.cos(x @ self.W + self.b) * self.scale
+
+
+def rotation_error_deg(Ra, Rb):
+    c = ((Ra.T @ Rb).diagonal().sum() - 1.0) * 0.5
+    return torch.rad2deg(torch.arccos(c.clamp(-1.0, 1.0)))
+
+
+class PairRegistrar:
+    """Holds the stateless operator modules and the descriptors; `register_pairs` runs a batch."""
+
+    def __init__(self, device, num_samples=30000, fps_clouds_per_call=16, order="reference", use_ransac=True):
+        self.device = device
+        self.num_samples = int(num_samples)
+        self.fps_clouds_per_call = int(fps_clouds_per_call)
+        self.order = order
+        self.use_ransac = use_ransac
+        self.coarse_desc = PositionDescriptor(256, 0.35, device, 11)
+        self.fine_desc = PositionDescriptor(256, 0.06, device, 12)
+        self.spm = SuperPointMatching(NUM_CORRESPONDENCES, dual_normalization=True)
+        self.ot = LearnableLogOptimalTransport(NUM_SINKHORN_ITERATIONS).to(device)
+        # fine_matching block of config.py:116-125
+        self.lgr = LocalGlobalRegistration(3, 0.1, True, 0.05, False, False, 3, None, 5)
+
+    @torch.no_grad()
+    def register_pairs(self, pairs):
+        """pairs: list of (ref (n,3), src (m,3), T_gt (4,4) or None) device tensors.
+        Returns (len(pairs), RESULT_LEN) float32: [T.flatten(), RRE deg, RTE m, #correspondences, inlier ratio]."""
+        B = len(pairs)
+        dev = self.device
+        # ---- FPS, several clouds per call (stack order [ref_1..ref_B, src_1..src_B] like data.py:151-155)
+        clouds = [p[0] for p in pairs] + [p[1] for p in pairs]
+        sampled = []
+        for i in range(0, 2 * B, self.fps_clouds_per_call):
+            chunk = clouds[i:i + self.fps_clouds_per_call]
+            lens = [c.shape[0] for c in chunk]
+            ks = [min(self.num_samples, n) for n in lens]
+            if all(k == n for k, n in zip(ks, lens)):
+                sampled += chunk
+                continue
+            idx = farthest_point_sampling(torch.cat(chunk, 0), lens, ks)
+            sampled += [c[ix] for c, ix in zip(chunk, idx)]
+        points = torch.cat(sampled, 0).contiguous()
+        lengths = torch.tensor([c.shape[0] for c in sampled], dtype=torch.int64)
+        # ---- the 5-level pyramid for the whole batch in one stack-mode pass (4 grid_subsample + 13 radius_search)
+        pyr = precompute_data_stack_mode(points, lengths, NUM_STAGES, INIT_VOXEL, INIT_RADIUS, NEIGHBOR_LIMITS,
+                                         order=self.order)
+        len_c, len_f = pyr["lengths"][-1].tolist(), pyr["lengths"][1].tolist()
+        off_c = [0]
+        off_f = [0]
+        for a, b in zip(len_c, len_f):
+            off_c.append(off_c[-1] + a)
+            off_f.append(off_f[-1] + b)
+        pts_c, pts_f = pyr["points"][-1], pyr["points"][1]
+        out = torch.zeros((B, RESULT_LEN), dtype=torch.float32, device=dev)
+        for b in range(B):
+            T_gt = pairs[b][2]
+            ref_c = pts_c[off_c[b]:off_c[b + 1]]
+            src_c = pts_c[off_c[B + b]:off_c[B + b + 1]]
+            ref_f = pts_f[off_f[b]:off_f[b + 1]]
+            src_f = pts_f[off_f[B + b]:off_f[B + b + 1]]
+            # model.py:99-104
+            _, ref_node_masks, ref_knn_idx, ref_knn_masks = point_to_node_partition(ref_f, ref_c, POINT_LIMIT)
+            _, src_node_masks, src_knn_idx, src_knn_masks = point_to_node_partition(src_f, src_c, POINT_LIMIT)
+            # stand-in for the learned features (see module docstring): descriptors in the reference frame
+            to_ref = (lambda x: x @ T_gt[:3, :3].T + T_gt[:3, 3]) if T_gt is not None else (lambda x: x)
+            ref_feats_c = torch.nn.functional.normalize(self.coarse_desc(ref_c), p=2, dim=1)
+            src_feats_c = torch.nn.functional.normalize(self.coarse_desc(to_ref(src_c)), p=2, dim=1)
+            # model.py:152-159
+            ref_ci, src_ci, node_scores = self.spm(ref_feats_c, src_feats_c, ref_node_masks, src_node_masks)
+            # model.py:162-190: patches around the matched superpoints (pad row = index N, a far-away point)
+            pad = torch.zeros((1, 3), device=dev)                       # model.py:171-172
+            ref_pad, src_pad = torch.cat([ref_f, pad], 0), torch.cat([src_f, pad], 0)
+            rk, sk = ref_knn_idx[ref_ci], src_knn_idx[src_ci]
+            rkm, skm = ref_knn_masks[ref_ci], src_knn_masks[src_ci]
+            rkp, skp = ref_pad[rk], src_pad[sk]
+            rkf = self.fine_desc(rkp) * rkm[..., None]
+            skf = self.fine_desc(to_ref(skp)) * skm[..., None]
+            scores = torch.einsum('bnd,bmd->bnm', rkf, skf) * (rkf.shape[-1] ** 0.5)
+            matching = self.ot(scores, rkm, skm)[:, :-1, :-1]     # model.py:191-198 (dustbins dropped)
+            rc, sc, cs, T = self.lgr(rkp, skp, rkm, skm, matching, node_scores)   # model.py:200-207
+            n_corr = rc.shape[0]
+            if self.use_ransac and n_corr >= 3:                  # model.py:209-220 (the estimate the reference keeps)
+                T = registration_with_ransac_from_correspondences(sc, rc, None, 0.05, 3, 10000, seed=b)
+            out[b, :16] = T.reshape(-1)
+            out[b, 18] = float(n_corr)
+            if T_gt is not None:
+                R_est = T[:3, :3]
+                s = torch.linalg.det(R_est).abs().clamp_min(1e-12) ** (1.0 / 3.0)   # similarity: strip the scale
+                out[b, 16] = rotation_error_deg(R_est / s, T_gt[:3, :3])
+                out[b, 17] = torch.linalg.norm(T[:3, 3] - T_gt[:3, 3])
+                if n_corr > 0:
+                    resid = torch.linalg.norm(to_ref(sc) - rc, dim=1)
+                    out[b, 19] = (resid < 0.1).float().mean()
+        return out

@@ -214,6 +214,13 @@ int gr_corr_matrix(const float* score_mat, int64_t batch, int64_t k1, int64_t k2
                    const uint8_t* ref_knn_masks, const uint8_t* src_knn_masks, int k, int mutual,
                    float confidence_threshold, uint8_t* corr_mat, int64_t* h_num_corr, void* ws,
                    size_t ws_bytes, void* stream);
+/* gr_corr_matrix_exp: the same operator for callers that already hold exp(score_mat) -- what
+ * PointMatching.compute_correspondence_matrix / LocalGlobalRegistration.compute_correspondence_matrix receive
+ * (point_matching.py:32-66 thresholds the matrix it is given; no log/exp round trip). */
+int gr_corr_matrix_exp(const float* exp_score_mat, int64_t batch, int64_t k1, int64_t k2,
+                       const uint8_t* ref_knn_masks, const uint8_t* src_knn_masks, int k, int mutual,
+                       float confidence_threshold, uint8_t* corr_mat, int64_t* h_num_corr, void* ws,
+                       size_t ws_bytes, void* stream);
 int gr_corr_gather(const float* score_mat, int64_t batch, int64_t k1, int64_t k2, const uint8_t* corr_mat,
                    const float* ref_knn_points, const float* src_knn_points, const int64_t* ref_knn_indices,
                    const int64_t* src_knn_indices, const float* global_scores, int use_global_score,
@@ -225,6 +232,14 @@ int gr_corr_gather(const float* score_mat, int64_t batch, int64_t k1, int64_t k2
  * the workspace gr_corr_matrix / gr_corr_gather used (it holds the per-patch counts / offsets).
  * out_transform: 16 floats, row-major 4x4, on the device. */
 size_t gr_lgr_workspace_bytes(int64_t batch);
+/* gr_lgr_register_verify: the same with a separate verification set (correspondence_limit is not None,
+ * local_global_registration.py:145-152): hypotheses are fitted on all correspondences of each patch, scored and
+ * refined on the `num_verify` rows of verify_* (the top-`correspondence_limit` global scores). */
+int gr_lgr_register_verify(const float* ref_corr_points, const float* src_corr_points, const float* corr_scores,
+                           int64_t num_corr, int64_t batch, const void* pm_ws, const float* verify_ref_points,
+                           const float* verify_src_points, const float* verify_scores, int64_t num_verify,
+                           float acceptance_radius, int correspondence_threshold, int num_refinement_steps,
+                           float* out_transform, void* ws, size_t ws_bytes, void* stream);
 int gr_lgr_register(const float* ref_corr_points, const float* src_corr_points, const float* corr_scores,
                     int64_t num_corr, int64_t batch, const void* pm_ws, float acceptance_radius,
                     int correspondence_threshold, int num_refinement_steps, float* out_transform, void* ws,

@@ -1,0 +1,159 @@
+"""The SURVEY 8(d) kernels that are not the two headline kernels, timed for bench.py's "extras" key.
+
+Every entry: {"ms": median milliseconds per call (torch.cuda events on the stream the C ABI launches on -- the library
+launches on torch's current stream), "bytes" or "flops": the ALGORITHMIC figure of SURVEY 8(d), "bound", "frac": fraction
+of that bound's peak (HBM 8 TB/s, fp32 MFMA 157.3 TFLOP/s)}.  Demo shapes of SURVEY App. D unless noted."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_GBS = 8000.0
+MFMA_TF = 157.3
+
+
+def _ms(fn, n=10, warm=2):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        ts.append(a.elapsed_time(b))
+    return float(sorted(ts)[len(ts) // 2])
+
+
+def _hbm(ms, nbytes, **kw):
+    d = {"ms": round(ms, 4), "bytes": int(nbytes), "bound": "hbm", "GB/s": round(nbytes / ms / 1e6, 1),
+         "frac": round(nbytes / ms / 1e6 / HBM_GBS, 4)}
+    d.update(kw)
+    return d
+
+
+def _mfma(ms, flops, **kw):
+    d = {"ms": round(ms, 4), "flops": float(flops), "bound": "mfma_f32", "TFLOP/s": round(flops / ms / 1e9, 2),
+         "frac": round(flops / ms / 1e9 / MFMA_TF, 4)}
+    d.update(kw)
+    return d
+
+
+def run(dev):
+    from gaussreg_amd import ext, ops, pair_pipeline, synthetic
+    from gaussreg_amd.data import precompute_data_stack_mode
+    from gaussreg_amd.embedding import GeometricStructureEmbedding
+    from gaussreg_amd.kpconv import KPConv
+    from gaussreg_amd.matching import LocalGlobalRegistration, PointMatching, SuperPointMatching
+    from gaussreg_amd.registration import farthest_point_sampling
+    from gaussreg_amd.sinkhorn import LearnableLogOptimalTransport
+    out = {}
+    g = torch.Generator(device=dev).manual_seed(0)
+    R = lambda *s: torch.randn(*s, device=dev, generator=g)  # noqa: E731
+    with torch.no_grad():
+        # ---- grid_subsample, 200 k points (12 N + 12 M bytes), both row orders
+        pts, lens = synthetic.cloud_200k(1, seed=0)
+        dp = pts.to(dev)
+        for order in ("reference", "cell"):
+            sp, _ = ext.grid_subsampling(dp, lens, 0.05, order=order)
+            ms = _ms(lambda: ext.grid_subsampling(dp, lens, 0.05, order=order))
+            out[f"grid_subsample_200k_{order}_order"] = _hbm(ms, 12 * dp.shape[0] + 12 * sp.shape[0], Mpts_per_s=round(0.2 / ms * 1e3, 1))
+        # ---- the data pyramid, 64 pairs of 2 x 30 000 points per call
+        Bp = 64
+        clouds = []
+        for b in range(Bp):
+            r_, s_, _ = pair_pipeline.synthetic_room_pair(b, 30000, dev)
+            clouds += [r_]
+        for b in range(Bp):
+            clouds += [pair_pipeline.synthetic_room_pair(b, 30000, dev)[1]]
+        bp = torch.cat(clouds).contiguous()
+        bl = torch.tensor([30000] * (2 * Bp))
+        for order in ("reference", "cell"):
+            ms = _ms(lambda: precompute_data_stack_mode(bp, bl, 5, 0.025, 0.0625, [89, 30, 43, 49, 49], order=order), 5, 1)
+            out[f"pyramid_64pairs_{order}_order"] = {"ms": round(ms, 3), "pairs_per_s": round(Bp / ms * 1e3, 1)}
+        d = precompute_data_stack_mode(bp[:60000].contiguous(), torch.tensor([30000, 30000]), 5, 0.025, 0.0625, [89, 30, 43, 49, 49])
+        del bp, clouds
+        # ---- point_to_node_partition (12 (N+M) + 8 N + M (1 + 128*9) bytes)
+        nf, nc = d["lengths"][1].tolist(), d["lengths"][-1].tolist()
+        pf, pc = d["points"][1][:nf[0]].contiguous(), d["points"][-1][:nc[0]].contiguous()
+        ms = _ms(lambda: ops.point_to_node_partition(pf, pc, 128), 20)
+        N, M = pf.shape[0], pc.shape[0]
+        out["point_to_node_partition"] = _hbm(ms, 12 * (N + M) + 8 * N + M * (1 + 128 * 9), shape=[N, M, 128])
+        # ---- correspondence matrix / PointMatching.forward (4 P K^2 + 2 P K in, P K^2 out)
+        P, K = 256, 128
+        score = torch.log_softmax(R(P, K, K) * 3, 2)
+        rm = torch.rand(P, K, device=dev, generator=g) > 0.3
+        sm = torch.rand(P, K, device=dev, generator=g) > 0.3
+        rp, sp_ = R(P, K, 3), R(P, K, 3)
+        ri = torch.randint(0, 30000, (P, K), device=dev)
+        si = torch.randint(0, 30000, (P, K), device=dev)
+        gs = torch.rand(P, device=dev)
+        pm = PointMatching(3)
+        ms = _ms(lambda: pm(rp, sp_, rm, sm, ri, si, score, gs), 20)
+        out["point_matching_forward"] = _hbm(ms, 4 * P * K * K + 2 * P * K + P * K * K, shape=[P, K, K])
+        expm = torch.exp(score)
+        ms = _ms(lambda: pm.compute_correspondence_matrix(expm, rm, sm), 20)
+        out["corr_matrix"] = _hbm(ms, 4 * P * K * K + 2 * P * K + P * K * K, shape=[P, K, K])
+        # ---- pairwise_distance on fp32 MFMA: demo size (launch-bound) and a batched-size launch
+        for n in (767, 8192):
+            x, y = R(n, 256), R(n, 256)
+            ms = _ms(lambda: ops.pairwise_distance(x, y), 20)
+            out[f"pairwise_distance_{n}x{n}x256"] = _mfma(ms, 2.0 * n * n * 256)
+        # ---- SuperPointMatching 767 x 767 x 256
+        fr = torch.nn.functional.normalize(R(767, 256), dim=1)
+        fs = torch.nn.functional.normalize(R(767, 256), dim=1)
+        spm = SuperPointMatching(256)
+        ms = _ms(lambda: spm(fr, fs), 20)
+        out["superpoint_matching_767"] = _mfma(ms, 2.0 * 767 * 767 * 256, bytes=4 * 256 * (767 + 767) + 256 * 20)
+        # ---- KPConv: the backbone's 11 layers at their real widths on the demo pyramid
+        Pl, NB, SUB = d["points"], d["neighbors"], d["subsampling"]
+        kp = torch.randn(15, 3) * 0.03
+        layers = [(0, 0, NB[0], 4, 64), (0, 0, NB[0], 32, 32), (1, 0, SUB[0], 32, 32), (1, 1, NB[1], 64, 64), (1, 1, NB[1], 64, 64),
+                  (2, 1, SUB[1], 64, 64), (2, 2, NB[2], 128, 128), (2, 2, NB[2], 128, 128), (3, 2, SUB[2], 128, 128),
+                  (3, 3, NB[3], 256, 256), (3, 3, NB[3], 256, 256)]
+        tot, flops, gbytes = 0.0, 0.0, 0.0
+        for ql, sl, nb, cin, cout in layers:
+            q, s = Pl[ql], Pl[sl]
+            conv = KPConv(cin, cout, 15, 0.0625 * 2 ** sl, 0.05 * 2 ** sl, kernel_points=kp * 2 ** sl).to(dev)
+            f = torch.relu(torch.randn(s.shape[0], cin, device=dev, generator=g))
+            tot += _ms(lambda: conv(f, q, s, nb), 5, 1)
+            Mq, Hn = q.shape[0], nb.shape[1]
+            flops += 2.0 * Mq * 15 * cin * cout + 2.0 * Mq * Hn * 15 * cin
+            gbytes += Mq * Hn * (8 + 4 * cin) + 4 * Mq * cout
+        out["kpconv_backbone_11_layers"] = {"ms": round(tot, 3), "flops": flops, "gather_bytes": int(gbytes), "bound": "hbm (gather)",
+                                            "TFLOP/s": round(flops / tot / 1e9, 2), "frac": round(gbytes / tot / 1e6 / HBM_GBS, 4)}
+        # ---- log-Sinkhorn 256 x 128 x 128, 100 iterations (LDS resident: 2 passes over HBM)
+        ot = LearnableLogOptimalTransport(100).to(dev)
+        sc = R(P, K, K)
+        ms = _ms(lambda: ot(sc, rm, sm), 10)
+        out["sinkhorn_256x128x128_100it"] = _hbm(ms, 4 * P * K * K + 4 * P * (K + 1) * (K + 1), lds_passes=200)
+        # ---- geometric structure embedding N = 767 (308 GFLOP per cloud)
+        gse = GeometricStructureEmbedding(256, 0.2, 15, 3).to(dev)
+        pcs = pc[None].contiguous()
+        ms = _ms(lambda: gse(pcs), 5, 1)
+        n = pcs.shape[1]
+        out["geo_embedding"] = _mfma(ms, 2.0 * n * n * 256 * 256 * 4, shape=[n, 256, 3], note="split-bf16 x6 MFMA, fp32-equivalent flops")
+        # ---- FPS 200 k -> 30 k, two clouds per call
+        r_, s_, _ = pair_pipeline.synthetic_room_pair(0, 200000, dev)
+        big = torch.cat([r_, s_]).contiguous()
+        ms = _ms(lambda: farthest_point_sampling(big, [200000, 200000], [30000, 30000]), 3, 1)
+        out["fps_2x200k_to_30k"] = {"ms": round(ms, 3), "ms_per_cloud": round(ms / 2, 3)}
+        # ---- LocalGlobalRegistration (256 patches, 5 refinement steps)
+        lgr = LocalGlobalRegistration(3, 0.1, True, 0.05, False, False, 3, None, 5)
+        m2 = ot(sc, rm, sm)[:, :-1, :-1]
+        rp2 = R(P, K, 3)
+        sp2 = rp2 + 0.01 * R(P, K, 3)
+        ms = _ms(lambda: lgr(rp2, sp2, rm, sm, m2, gs), 10)
+        out["local_global_registration"] = {"ms": round(ms, 4)}
+    return out
+
+
+if __name__ == "__main__":
+    import json
+    print(json.dumps(run(torch.device("cuda", 0)), indent=1))
