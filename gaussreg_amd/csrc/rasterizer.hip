@@ -10,11 +10,10 @@
 //   preprocess  1 thread / Gaussian, loops over the V cameras (inputs read once per batch;
 //               cov3D built once): cull, project, cov2D, conic, radius, tile rect, SH -> RGB
 //   depth sort  stable radix sort of (view, depth bits) -> per-view front-to-back Gaussian order
-//   scan        exclusive scan of tiles_touched IN THAT ORDER per view      -> R_v on the host
-//   instances   emitted in depth order: key = view*tiles + tile (32 bit), value = Gaussian id
-//   tile sort   stable radix sort on the tile bits only: each tile's run keeps the depth order
-//               (== upstream's single sort of (tile << 32 | depth) keys, at ~half the traffic)
-//   ranges      [start,end) of every (view, tile)
+//   tile bin    NO second sort and no (tile, id) key stream: the per-tile lists are built straight from the depth-ordered
+//               rectangles by a counting pass and a RANKED scatter (see "tile binning" below) -- each tile's list keeps
+//               the depth order, i.e. exactly upstream's single sort of (tile << 32 | depth) keys
+//   ranges      [start,end) of every (view, tile) from the tile totals
 //   blend       1 workgroup / tile (16x16 px, 4 waves): Gaussian parameters staged through LDS in
 //               batches of 256, front-to-back alpha blending, deterministic exp
 #include <vector>
@@ -186,7 +185,11 @@ struct Geom {
   uint64_t* dkeys_b;
   int32_t* order_a;      // (unused: the sort generates ids on the fly); order_b = per-view front-to-back order
   int32_t* order_b;
-  int32_t* offs;         // [V*P] exclusive scan of tiles in depth order
+  uint32_t* rects;       // [V*P] depth-ordered tile rectangles (26-bit packing of the key's high bits)
+  uint16_t* chunk_cnt;   // [V][nchunk][tiles] instances per (chunk of BIN_CHUNK depth-ordered Gaussians, tile)
+  uint32_t* chunk_off;   // same shape: exclusive prefix over the chunks of a view
+  int32_t* tile_total;   // [V][tiles]
+  int32_t* tile_start;   // [V][tiles] exclusive prefix over the tiles of a view
   void* sort_temp;
   size_t sort_temp_bytes;
   int32_t* totals;       // [V] then [V] = depth-overflow flag
@@ -195,45 +198,44 @@ struct Geom {
   size_t bytes;
 };
 
-Geom carve_geom(void* p, int64_t P, int V) {
+constexpr int BIN_T = 256;                          // threads per binning workgroup (4 waves)
+constexpr int BIN_CW = 512;                         // depth-ordered Gaussians per wave
+constexpr int BIN_CHUNK = (BIN_T / WAVE) * BIN_CW;  // per workgroup
+
+Geom carve_geom(void* p, int64_t P, int V, int64_t tiles) {
   Geom g;
   Carver c(p);
+  const int64_t nchunk = (P + BIN_CHUNK - 1) / BIN_CHUNK;
   g.rec = c.take<float4>(P * V * 4);
   g.dkeys_a = c.take<uint64_t>(P * V);
   g.dkeys_b = c.take<uint64_t>(P * V);
   g.order_a = nullptr;
   g.order_b = c.take<int32_t>(P * V);
-  g.offs = c.take<int32_t>(P * V);
+  g.rects = c.take<uint32_t>(P * V);
+  g.chunk_cnt = c.take<uint16_t>(V * nchunk * tiles);
+  g.chunk_off = c.take<uint32_t>(V * nchunk * tiles);
+  g.tile_total = c.take<int32_t>(V * tiles);
+  g.tile_start = c.take<int32_t>(V * tiles);
   g.sort_temp_bytes = sort_pairs_temp_bytes(P * V);
   g.sort_temp = c.take<char>(g.sort_temp_bytes);
   g.totals = c.take<int32_t>(V + 1);
   g.views = c.take<DevView>(MAX_VIEWS);
-  g.scan_ws = c.take<int32_t>(V * scan_ws_ints(P));
+  g.scan_ws = c.take<int32_t>(V * scan_ws_ints(tiles));
   g.bytes = c.used();
   return g;
 }
 
 struct Bin {
-  uint32_t* keys_a;
-  uint32_t* keys_b;
-  int32_t* vals_a;
-  int32_t* vals_b;
-  int2* ranges;  // [V * tiles]
-  void* sort_temp;
-  size_t sort_temp_bytes;
+  int32_t* point_list;  // [R] Gaussian ids, tile-major, depth order inside a tile
+  int2* ranges;         // [V * tiles]
   size_t bytes;
 };
 
 Bin carve_bin(void* p, int64_t R, int64_t vtiles) {
   Bin b;
   Carver c(p);
-  b.keys_a = c.take<uint32_t>(R);
-  b.keys_b = c.take<uint32_t>(R);
-  b.vals_a = c.take<int32_t>(R);
-  b.vals_b = c.take<int32_t>(R);
+  b.point_list = c.take<int32_t>(R);
   b.ranges = c.take<int2>(vtiles);
-  b.sort_temp_bytes = sort_pairs_u32_temp_bytes(R);
-  b.sort_temp = c.take<char>(b.sort_temp_bytes);
   b.bytes = c.used();
   return b;
 }
@@ -427,76 +429,218 @@ __global__ __launch_bounds__(256) void full_keys_kernel(int64_t n, int P, const 
   keys[o] = rect | (v << 32) | dbits;
 }
 
-// ------------------------------------------------------------------------------------ instances
-__device__ __forceinline__ bool rect_of(uint64_t key, int id, int64_t vbase, const float4* __restrict__ rec,
-                                         int gx, int gy, int* rmin, int* rmax) {
-  const int w = (int)((key >> 52) & 63), h = (int)((key >> 58) & 63);
-  rmin[0] = (int)((key >> 38) & 127);
-  rmin[1] = (int)((key >> 45) & 127);
-  if (w == 0 && h == 0 && rmin[0] == 127 && rmin[1] == 127) {  // marker: did not fit, gather the record
+// ------------------------------------------------------------------------------------ tile binning
+// Input: per view the Gaussians in depth order (ids) with their tile rectangles (26-bit packing, RECT_MARKER26 = "did not
+// fit, rebuild from the record").  Output: point_list, tile-major, each tile's run in depth order -- what a stable sort
+// of (tile, depth-rank) keys would give, without ever materialising those keys:
+//   count    a workgroup owns BIN_CHUNK consecutive depth-ordered Gaussians of one view and histograms their tiles in LDS
+//   scan     per (view, tile): exclusive prefix over the chunks (thread per tile), then over the tiles of a view
+//   scatter  the same workgroup shape; wave w owns BIN_CW consecutive Gaussians and a private cursor per tile in LDS
+//            (global start of the tile + chunk prefix + the earlier waves' counts).  The wave walks its Gaussians ONE AT
+//            A TIME in depth order with the lanes spread over the Gaussian's rectangle: one ds_add_rtn_u32 hands every
+//            tile of the rectangle its next slot, one store writes the id there.  A wave's LDS atomics execute in issue
+//            order and the tiles of one rectangle are distinct, so slots are taken in depth order: the list is exactly
+//            the stable-sort result, with no per-instance key traffic (write 4 B per instance, read 8 B per Gaussian).
+// With >= 8 views the workgroups of one view all run on the same XCD (block b sits on XCD b % 8), so the partially
+// written lines of that view's tile lists merge in ONE 4 MiB L2 before they go to HBM.
+constexpr uint32_t RECT_MARKER26 = 127u | (127u << 7);
+
+__device__ __forceinline__ bool rect_decode(uint32_t r, int id, int64_t vbase, const float4* __restrict__ rec, int gx,
+                                            int gy, int& x0, int& y0, int& w, int& h) {
+  x0 = (int)(r & 127u);
+  y0 = (int)((r >> 7) & 127u);
+  w = (int)((r >> 14) & 63u);
+  h = (int)((r >> 20) & 63u);
+  if (r == RECT_MARKER26) {  // wide rectangle: rebuild the reference square from the record
     const float4 r0 = rec[4 * (vbase + id)];
+    int rmin[2], rmax[2];
     get_rect(r0.x, r0.y, __float_as_int(rec[4 * (vbase + id) + 3].x), gx, gy, rmin, rmax);
-    return true;
+    x0 = rmin[0];
+    y0 = rmin[1];
+    w = rmax[0] - rmin[0];
+    h = rmax[1] - rmin[1];
   }
-  rmax[0] = rmin[0] + w;
-  rmax[1] = rmin[1] + h;
   return w * h != 0;
 }
 
-// tiles touched per depth-ordered Gaussian (input of the offsets scan), decoded from the sorted keys
-__global__ __launch_bounds__(256) void tiles_from_keys_kernel(int64_t n, int P, int W, int H,
-                                                              const uint64_t* __restrict__ keys,
-                                                              const int32_t* __restrict__ order,
-                                                              const float4* __restrict__ rec,
-                                                              int32_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void unpack_rects_kernel(int64_t n, const uint64_t* __restrict__ keys,
+                                                           uint32_t* __restrict__ rects) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-  int rmin[2], rmax[2];
-  const bool any = rect_of(keys[t], order[t], (t / P) * P, rec, gx, gy, rmin, rmax);
-  out[t] = any ? (rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) : 0;
+  if (t < n) rects[t] = (uint32_t)(keys[t] >> 38);
 }
 
-// one thread per depth-ordered Gaussian: emits its (view*tiles + tile, id) instances contiguously
-__global__ __launch_bounds__(256) void instances_kernel(
-    int P, int V, int W, int H, const float4* __restrict__ rec, const uint64_t* __restrict__ dkeys,
-    const int32_t* __restrict__ order, const int32_t* __restrict__ offsets /* exclusive, per view, depth order */,
-    const int32_t* __restrict__ totals /* [V] */, uint32_t* __restrict__ keys,
-    int32_t* __restrict__ vals) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int v = blockIdx.y;
-  if (t >= P) return;
+// block -> (view, chunk); XCD-affine when there are at least 8 views
+__device__ __forceinline__ bool bin_block(int V, int nchunk, int& v, int& c) {
+  const int b = blockIdx.x;
+  if (V >= 8) {
+    const int k = b >> 3;
+    v = (b & 7) + 8 * (k / nchunk);
+    c = k % nchunk;
+    return v < V;
+  }
+  v = b / nchunk;
+  c = b % nchunk;
+  return true;
+}
+inline int bin_grid(int V, int nchunk) { return V >= 8 ? 8 * ((V + 7) / 8) * nchunk : V * nchunk; }
+
+__global__ __launch_bounds__(BIN_T) void tile_count_kernel(int P, int V, int gx, int gy, int nchunk,
+                                                           const uint32_t* __restrict__ rects,
+                                                           const int32_t* __restrict__ ids,
+                                                           const float4* __restrict__ rec,
+                                                           uint16_t* __restrict__ chunk_cnt) {
+  extern __shared__ unsigned int s_hist[];
+  int v, c;
+  if (!bin_block(V, nchunk, v, c)) return;
+  const int tiles = gx * gy;
+  for (int T = threadIdx.x; T < tiles; T += BIN_T) s_hist[T] = 0u;
+  __syncthreads();
   const int64_t vbase = (int64_t)v * P;
-  const int i = order[vbase + t];
-  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-  int rmin[2], rmax[2];
-  if (!rect_of(dkeys[vbase + t], i, vbase, rec, gx, gy, rmin, rmax)) return;
-  int64_t off = offsets[vbase + t];
-  for (int u = 0; u < v; ++u) off += totals[u];  // uniform: scalar loads
-  const uint32_t tile_base = (uint32_t)v * (uint32_t)(gx * gy);
-  for (int y = rmin[1]; y < rmax[1]; ++y)
-    for (int x = rmin[0]; x < rmax[0]; ++x) {
-      keys[off] = tile_base + (uint32_t)(y * gx + x);
-      vals[off] = i;
-      ++off;
-    }
+  for (int it = 0; it < BIN_CHUNK / BIN_T; ++it) {
+    const int t = c * BIN_CHUNK + it * BIN_T + threadIdx.x;
+    if (t >= P) break;
+    const uint32_t r = rects[vbase + t];
+    if (r == 0u) continue;
+    int x0, y0, w, h;
+    if (!rect_decode(r, ids[vbase + t], vbase, rec, gx, gy, x0, y0, w, h)) continue;
+    for (int y = y0; y < y0 + h; ++y)
+      for (int x = x0; x < x0 + w; ++x) atomicAdd(&s_hist[y * gx + x], 1u);
+  }
+  __syncthreads();
+  uint16_t* dst = chunk_cnt + ((int64_t)v * nchunk + c) * tiles;
+  for (int T = threadIdx.x; T < tiles; T += BIN_T) dst[T] = (uint16_t)s_hist[T];  // <= BIN_CHUNK < 65536
 }
 
-__global__ __launch_bounds__(256) void ranges_kernel(int64_t R, const uint32_t* __restrict__ keys,
-                                                     int2* __restrict__ ranges) {
-  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= R) return;
-  const uint32_t t = keys[k];
-  if (k == 0) {
-    ranges[t].x = 0;
-  } else {
-    const uint32_t tp = keys[k - 1];
-    if (t != tp) {
-      ranges[tp].y = (int)k;
-      ranges[t].x = (int)k;
+// per (view, tile): exclusive prefix over the chunks
+__global__ __launch_bounds__(256) void chunk_scan_kernel(int V, int tiles, int nchunk,
+                                                         const uint16_t* __restrict__ chunk_cnt,
+                                                         uint32_t* __restrict__ chunk_off,
+                                                         int32_t* __restrict__ tile_total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V * tiles) return;
+  const int v = i / tiles, T = i - v * tiles;
+  const int64_t base = (int64_t)v * nchunk * tiles + T;
+  uint32_t run = 0;
+  int c = 0;
+  for (; c + 4 <= nchunk; c += 4) {
+    uint32_t n[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) n[u] = chunk_cnt[base + (int64_t)(c + u) * tiles];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      chunk_off[base + (int64_t)(c + u) * tiles] = run;
+      run += n[u];
     }
   }
-  if (k == R - 1) ranges[t].y = (int)R;
+  for (; c < nchunk; ++c) {
+    const uint32_t n = chunk_cnt[base + (int64_t)c * tiles];
+    chunk_off[base + (int64_t)c * tiles] = run;
+    run += n;
+  }
+  tile_total[i] = (int32_t)run;
+}
+
+__global__ __launch_bounds__(256) void ranges_kernel(int V, int tiles, const int32_t* __restrict__ tile_start,
+                                                     const int32_t* __restrict__ tile_total,
+                                                     const int32_t* __restrict__ totals, int2* __restrict__ ranges) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V * tiles) return;
+  const int v = i / tiles;
+  int vb = 0;
+  for (int u = 0; u < v; ++u) vb += totals[u];
+  const int a = vb + tile_start[i];
+  ranges[i] = make_int2(a, a + tile_total[i]);
+}
+
+__global__ __launch_bounds__(BIN_T) void tile_scatter_kernel(int P, int V, int gx, int gy, int nchunk,
+                                                             const uint32_t* __restrict__ rects,
+                                                             const int32_t* __restrict__ ids,
+                                                             const float4* __restrict__ rec,
+                                                             const uint32_t* __restrict__ chunk_off,
+                                                             const int32_t* __restrict__ tile_start,
+                                                             const int32_t* __restrict__ totals,
+                                                             int32_t* __restrict__ point_list) {
+  extern __shared__ unsigned int s_cur[];  // [waves][tiles]
+  constexpr int NW = BIN_T / WAVE, STEPS = BIN_CW / WAVE;
+  int v, c;
+  if (!bin_block(V, nchunk, v, c)) return;
+  const int tiles = gx * gy;
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  unsigned int* my = s_cur + wv * tiles;
+  for (int T = threadIdx.x; T < NW * tiles; T += BIN_T) s_cur[T] = 0u;
+  __syncthreads();
+  // ---- phase A: this wave's tile counts; rectangles and ids stay in registers for phase C
+  const int64_t vbase = (int64_t)v * P;
+  const int wbase = c * BIN_CHUNK + wv * BIN_CW;
+  uint32_t pr[STEPS];
+  int pid[STEPS];
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    const int t = wbase + s * WAVE + lane;
+    pr[s] = 0u;
+    pid[s] = 0;
+    if (t < P) {
+      const uint32_t r = rects[vbase + t];
+      if (r != 0u) {
+        const int id = ids[vbase + t];
+        int x0, y0, w, h;
+        if (rect_decode(r, id, vbase, rec, gx, gy, x0, y0, w, h)) {
+          pr[s] = (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)w << 16) | ((uint32_t)h << 24);  // gx, gy <= 255
+          pid[s] = id;
+          for (int y = y0; y < y0 + h; ++y)
+            for (int x = x0; x < x0 + w; ++x) atomicAdd(&my[y * gx + x], 1u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase B: counts -> cursors = (view base + tile start + chunk prefix) + the earlier waves' counts
+  int vb = 0;
+  for (int u = 0; u < v; ++u) vb += totals[u];
+  const uint32_t* coff = chunk_off + ((int64_t)v * nchunk + c) * tiles;
+  const int32_t* tst = tile_start + (int64_t)v * tiles;
+  for (int T = threadIdx.x; T < tiles; T += BIN_T) {
+    unsigned int run = (unsigned int)(vb + tst[T]) + coff[T];
+#pragma unroll
+    for (int w2 = 0; w2 < NW; ++w2) {
+      const unsigned int n = s_cur[w2 * tiles + T];
+      s_cur[w2 * tiles + T] = run;
+      run += n;
+    }
+  }
+  __syncthreads();
+  // ---- phase C: one Gaussian at a time in depth order, lanes over its rectangle
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    const uint32_t r = pr[s];
+    const uint32_t rw = (r >> 16) & 255u;
+    const uint32_t recip = rw ? (65535u + rw) / rw : 0u;  // (k * recip) >> 16 == k / rw for k < 64 <= 65536 / rw
+    unsigned long long bits = __ballot(r != 0u);
+    while (bits) {
+      const int j = __ffsll((long long)bits) - 1;
+      bits &= bits - 1ull;
+      const uint32_t sr = (uint32_t)__builtin_amdgcn_readlane((int)r, j);
+      const uint32_t sm = (uint32_t)__builtin_amdgcn_readlane((int)recip, j);
+      const int sid = __builtin_amdgcn_readlane(pid[s], j);
+      const int x0 = (int)(sr & 255u), y0 = (int)((sr >> 8) & 255u), w = (int)((sr >> 16) & 255u), h = (int)(sr >> 24);
+      const int n = w * h;
+      if (n <= WAVE) {
+        if (lane < n) {
+          const int q = (int)(((uint32_t)lane * sm) >> 16);
+          const int tile = (y0 + q) * gx + x0 + (lane - q * w);
+          const unsigned int pos = atomicAdd(&my[tile], 1u);
+          point_list[pos] = sid;
+        }
+      } else {
+        for (int y = 0; y < h; ++y)
+          for (int xb = 0; xb < w; xb += WAVE)
+            if (xb + lane < w) {
+              const unsigned int pos = atomicAdd(&my[(y0 + y) * gx + x0 + xb + lane], 1u);
+              point_list[pos] = sid;
+            }
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------ blend
@@ -717,15 +861,18 @@ int upload_views(const gr_raster_view* h_views, int num_views, std::vector<DevVi
 
 using namespace gr;
 
-extern "C" size_t gr_raster_geom_bytes(int64_t P, int num_views) {
-  if (P < 0 || num_views < 1) return 0;
-  return carve_geom(nullptr, P, num_views).bytes;
+static int64_t tiles_of(int width, int height) {
+  return (int64_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+}
+
+extern "C" size_t gr_raster_geom_bytes(int64_t P, int num_views, int width, int height) {
+  if (P < 0 || num_views < 1 || width <= 0 || height <= 0) return 0;
+  return carve_geom(nullptr, P, num_views, tiles_of(width, height)).bytes;
 }
 
 extern "C" size_t gr_raster_bin_bytes(int64_t total_rendered, int width, int height, int num_views) {
   if (total_rendered < 0 || width <= 0 || height <= 0 || num_views < 1) return 0;
-  const int64_t tiles = (int64_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
-  return carve_bin(nullptr, total_rendered, tiles * num_views).bytes;
+  return carve_bin(nullptr, total_rendered, tiles_of(width, height) * num_views).bytes;
 }
 
 extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, const float* shs,
@@ -741,7 +888,7 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
   for (int v = 0; v < num_views; ++v) h_num_rendered[v] = 0;
   GR_REQUIRE(P >= 0 && P < (1ll << 31) - 1, "P out of range");
   if (P == 0) {  // nothing to project, but the render call still needs the camera table (background)
-    Geom g0 = carve_geom(geom, 0, num_views);
+    Geom g0 = carve_geom(geom, 0, num_views, tiles_of(h_views[0].image_width, h_views[0].image_height));
     if (!geom || geom_bytes < g0.bytes) {
       set_error("raster geometry buffer too small: need %zu bytes, got %zu", g0.bytes, geom_bytes);
       return GR_ERR_WORKSPACE;
@@ -760,7 +907,13 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
              "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
   const int D = h_views[0].sh_degree;
   if (shs) GR_REQUIRE(M >= (D + 1) * (D + 1), "shs has %d coefficients, sh_degree %d needs %d", M, D, (D + 1) * (D + 1));
-  Geom g = carve_geom(geom, P, num_views);
+  const int W = h_views[0].image_width, H = h_views[0].image_height;
+  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  const int tiles = gx * gy;
+  GR_REQUIRE(gx <= 255 && gy <= 255, "image too large: at most 255 x 255 tiles of 16 px (got %d x %d)", gx, gy);
+  const size_t bin_lds = (size_t)(BIN_T / WAVE) * tiles * sizeof(unsigned int);
+  GR_REQUIRE(bin_lds <= 160 * 1024, "image too large: the per-wave tile cursors (%zu bytes) do not fit in LDS", bin_lds);
+  Geom g = carve_geom(geom, P, num_views, tiles);
   if (!geom || geom_bytes < g.bytes) {
     set_error("raster geometry buffer too small: need %zu bytes, got %zu", g.bytes, geom_bytes);
     return GR_ERR_WORKSPACE;
@@ -768,7 +921,6 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
   std::vector<DevView> dv;  // alive until the synchronise below
   rc = upload_views(h_views, num_views, dv, g.views, stream);
   if (rc != GR_OK) return rc;
-  const int W = h_views[0].image_width, H = h_views[0].image_height;
   const dim3 blk(256), grd((unsigned)((P + 255) / 256));
   const bool sh16 = shs != nullptr && M == 16 && (reinterpret_cast<uintptr_t>(shs) % 16 == 0);
 #define GR_PRE(SH, COV, S16)                                                                       \
@@ -789,18 +941,30 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
   while ((1 << vbits) < num_views) ++vbits;
   static_assert((1 << KEY_VIEW_BITS) >= MAX_VIEWS && KEY_DEPTH_BITS + KEY_VIEW_BITS <= 38, "view id must fit its key field");
   std::vector<int32_t> tot(num_views + 1);
+  const int nchunk = (int)((P + BIN_CHUNK - 1) / BIN_CHUNK);
   auto sort_and_count = [&](int end_bit) -> int {
     {
-      KernelTimer timer("raster_sort", stream);
+      KernelTimer timer("raster_depth_sort", stream);
       int rcs = sort_pairs_u64_iota(g.sort_temp, g.sort_temp_bytes, g.dkeys_a, g.dkeys_b, P, g.order_b,
                                     P * num_views, 0, end_bit, stream);
       if (rcs != GR_OK) return rcs;
     }
-    hipLaunchKernelGGL(tiles_from_keys_kernel, dim3((unsigned)((P * num_views + 255) / 256)), blk, 0, stream,
-                       P * num_views, (int)P, W, H, g.dkeys_b, g.order_b, g.rec, g.offs);
-    GR_LAUNCH_CHECK();
-    int rcs = exclusive_scan_i32(g.offs, g.offs, P, num_views, P, g.scan_ws, g.totals, stream);
-    if (rcs != GR_OK) return rcs;
+    {
+      KernelTimer timer("raster_bin", stream);
+      hipLaunchKernelGGL(unpack_rects_kernel, dim3((unsigned)((P * num_views + 255) / 256)), blk, 0, stream,
+                         P * num_views, g.dkeys_b, g.rects);
+      if (tiles * sizeof(unsigned int) > 64 * 1024)
+        GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tile_count_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      hipLaunchKernelGGL(tile_count_kernel, dim3((unsigned)bin_grid(num_views, nchunk)), dim3(BIN_T),
+                         tiles * sizeof(unsigned int), stream, (int)P, num_views, gx, gy, nchunk, g.rects, g.order_b, g.rec,
+                         g.chunk_cnt);
+      hipLaunchKernelGGL(chunk_scan_kernel, dim3((unsigned)((num_views * tiles + 255) / 256)), blk, 0, stream, num_views,
+                         tiles, nchunk, g.chunk_cnt, g.chunk_off, g.tile_total);
+      GR_LAUNCH_CHECK();
+      int rcs = exclusive_scan_i32(g.tile_total, g.tile_start, tiles, num_views, tiles, g.scan_ws, g.totals, stream);
+      if (rcs != GR_OK) return rcs;
+    }
     GR_HIP(hipMemcpyAsync(tot.data(), g.totals, sizeof(int32_t) * (num_views + 1), hipMemcpyDeviceToHost, stream));
     GR_HIP(hipStreamSynchronize(stream));
     return GR_OK;
@@ -832,29 +996,29 @@ extern "C" int gr_raster_render(int64_t P, const gr_raster_view* h_views, int nu
   int64_t R = 0;
   for (int v = 0; v < num_views; ++v) R += h_num_rendered[v];
   GR_REQUIRE(R < (1ll << 31) - 1, "too many rendered instances (%lld)", (long long)R);
-  Geom g = carve_geom(const_cast<void*>(geom), P, num_views);
+  const int tiles = gx * gy;
+  Geom g = carve_geom(const_cast<void*>(geom), P, num_views, tiles);
   GR_REQUIRE(P == 0 || (geom && geom_bytes >= g.bytes), "geometry buffer missing or too small");
   Bin b = carve_bin(bin, R, vtiles);
   if (!bin || bin_bytes < b.bytes) {
     set_error("raster binning buffer too small: need %zu bytes, got %zu", b.bytes, bin_bytes);
     return GR_ERR_WORKSPACE;
   }
-  GR_HIP(hipMemsetAsync(b.ranges, 0, sizeof(int2) * vtiles, stream));
-  const int32_t* point_list = b.vals_b;
+  const int32_t* point_list = b.point_list;
   if (R > 0) {
-    hipLaunchKernelGGL(instances_kernel, dim3((unsigned)((P + 255) / 256), num_views), dim3(256), 0, stream, (int)P,
-                       num_views, W, H, g.rec, g.dkeys_b, g.order_b, g.offs, g.totals, b.keys_a, b.vals_a);
+    KernelTimer timer("raster_bin", stream);
+    const int nchunk = (int)((P + BIN_CHUNK - 1) / BIN_CHUNK);
+    const size_t lds = (size_t)(BIN_T / WAVE) * tiles * sizeof(unsigned int);
+    auto kern = tile_scatter_kernel;
+    if (lds > 64 * 1024)
+      GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((vtiles + 255) / 256)), dim3(256), 0, stream, num_views, tiles,
+                       g.tile_start, g.tile_total, g.totals, b.ranges);
+    hipLaunchKernelGGL(kern, dim3((unsigned)bin_grid(num_views, nchunk)), dim3(BIN_T), lds, stream, (int)P, num_views, gx, gy,
+                       nchunk, g.rects, g.order_b, g.rec, g.chunk_off, g.tile_start, g.totals, b.point_list);
     GR_LAUNCH_CHECK();
-    int bits = 0;
-    while ((1ll << bits) < vtiles) ++bits;
-    {
-      KernelTimer timer("raster_sort", stream);
-      rc = sort_pairs_u32_i32(b.sort_temp, b.sort_temp_bytes, b.keys_a, b.keys_b, b.vals_a, b.vals_b, R, 0, bits,
-                              stream);
-    }
-    if (rc != GR_OK) return rc;
-    hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, R, b.keys_b, b.ranges);
-    GR_LAUNCH_CHECK();
+  } else {
+    GR_HIP(hipMemsetAsync(b.ranges, 0, sizeof(int2) * vtiles, stream));
   }
   KernelTimer timer("raster_blend", stream);
   hipLaunchKernelGGL(blend_kernel, dim3(gx, gy, num_views), dim3(BLOCK), 0, stream, (int)P, W, H, g.views, b.ranges,

@@ -117,7 +117,7 @@ def rasterize_views(settings, means3D, opacities, shs=None,
     nr = (ctypes.c_int64 * V)()
     with torch.cuda.device(dev):
         st = _lib.stream_ptr(dev)
-        geom = torch.empty(L.gr_raster_geom_bytes(P, V) + 256, dtype=torch.uint8, device=dev)
+        geom = torch.empty(L.gr_raster_geom_bytes(P, V, W, H) + 256, dtype=torch.uint8, device=dev)
         _lib.check(L.gr_raster_preprocess(P, M, _lib.ptr(m), _lib.ptr(sh), _lib.ptr(cp), _lib.ptr(op), _lib.ptr(sc),
                                           _lib.ptr(rot), _lib.ptr(cov), views, V, _lib.ptr(radii), _lib.ptr(geom),
                                           geom.numel(), nr, st))

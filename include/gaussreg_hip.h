@@ -116,13 +116,14 @@ int gr_grid_subsample(const float* points, const int64_t* h_lengths, int64_t n, 
  * Batched over views: one Gaussian set, `num_views` cameras (HOST array of gr_raster_view), so
  * per-Gaussian inputs are read once per batch.  Two calls because the number of (tile, Gaussian)
  * instances R is data dependent (upstream syncs at the same place):
- *   gr_raster_preprocess : cull / project / cov2D / SH->RGB / tile counts / prefix sums into
+ *   gr_raster_preprocess : cull / project / cov2D / SH->RGB / depth order / per-tile counts and prefix sums into
  *                          `geom` (size gr_raster_geom_bytes), SYNCHRONISES `stream`,
  *                          h_num_rendered[v] = R_v = instances binned (<= upstream's count: pairs that
  *                          cannot reach alpha = 1/255 inside the tile are dropped, the image is unaffected).
  *                          Also writes radii (num_views, P) int32, exactly upstream's values.
- *   gr_raster_render     : instance keys, radix sort by (view, tile, depth), tile ranges, per-tile
- *                          front-to-back alpha blend -> out_color (num_views, 3, H, W) fp32.
+ *   gr_raster_render     : ranked scatter of the depth-ordered Gaussians into per-tile lists (== upstream's sort by
+ *                          (tile, depth), without a key stream), tile ranges, per-tile front-to-back alpha blend
+ *                          -> out_color (num_views, 3, H, W) fp32.
  *                          `bin` is scratch of size gr_raster_bin_bytes(sum R_v, ...).
  * Exactly one of shs / colors_precomp and exactly one of (scales, rotations) / cov3D_precomp is
  * non-null.  All views of one call share image size and SH degree (checked).
@@ -140,7 +141,7 @@ typedef struct gr_raster_view {
   int32_t debug;
 } gr_raster_view;
 
-size_t gr_raster_geom_bytes(int64_t P, int num_views);
+size_t gr_raster_geom_bytes(int64_t P, int num_views, int width, int height);
 size_t gr_raster_bin_bytes(int64_t total_rendered, int width, int height, int num_views);
 int gr_raster_preprocess(int64_t P, int sh_coeffs, const float* means3D, const float* shs,
                          const float* colors_precomp, const float* opacities, const float* scales,
