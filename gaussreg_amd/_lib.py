@@ -50,6 +50,7 @@ SIGNATURES.update({
                                                                      c_void, c_size, c_i64p, c_void]),
     "gr_raster_render": (c_int, [c_i64, ctypes.POINTER(RasterView), c_int, c_i64p, c_void, c_size, c_void, c_size,
                                  c_void, c_void]),
+    "gr_raster_lds_atomics_lane_ordered": (c_int, []),
     "gr_raster_mark_visible": (c_int, [c_i64, c_void, ctypes.POINTER(c_f32), c_void, c_void]),
 })
 

@@ -10,12 +10,14 @@
 //   preprocess  1 thread / Gaussian, loops over the V cameras (inputs read once per batch;
 //               cov3D built once): cull, project, cov2D, conic, radius, tile rect, SH -> RGB
 //   depth sort  stable radix sort of (view, depth bits) -> per-view front-to-back Gaussian order
-//   tile bin    NO second sort and no (tile, id) key stream: the per-tile lists are built straight from the depth-ordered
-//               rectangles by a counting pass and a RANKED scatter (see "tile binning" below) -- each tile's list keeps
-//               the depth order, i.e. exactly upstream's single sort of (tile << 32 | depth) keys
-//   ranges      [start,end) of every (view, tile) from the tile totals
-//   blend       1 workgroup / tile (16x16 px, 4 waves): Gaussian parameters staged through LDS in
-//               batches of 256, front-to-back alpha blending, deterministic exp
+//   tile bin    NO second sort and no (tile, id) key stream: chunks of 2048 depth-ordered Gaussians are binned by tile inside
+//               LDS and written out as one contiguous block per chunk (see "tile binning" below); a tile's list is the
+//               concatenation of its per-chunk segments -- in depth order, i.e. exactly upstream's single sort of
+//               (tile << 32 | depth) keys
+//   blend       1 workgroup / tile (16x16 px, 4 waves): walks the tile's segments chunk by chunk, Gaussian parameters
+//               staged through LDS in batches of 256, front-to-back alpha blending, deterministic exp
+#include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "common.hpp"
@@ -187,9 +189,9 @@ struct Geom {
   int32_t* order_b;
   uint32_t* rects;       // [V*P] depth-ordered tile rectangles (26-bit packing of the key's high bits)
   uint16_t* chunk_cnt;   // [V][nchunk][tiles] instances per (chunk of BIN_CHUNK depth-ordered Gaussians, tile)
-  uint32_t* chunk_off;   // same shape: exclusive prefix over the chunks of a view
-  int32_t* tile_total;   // [V][tiles]
-  int32_t* tile_start;   // [V][tiles] exclusive prefix over the tiles of a view
+  uint32_t* seg_off;     // [V][nchunk][tiles + 1] position of segment (chunk, tile) in the point list (+ end sentinel)
+  int32_t* chunk_total;  // [V][nchunk] instances per chunk, then [V][nchunk] exclusive prefix inside the view
+  int32_t* chunk_max;    // [1] largest chunk total
   void* sort_temp;
   size_t sort_temp_bytes;
   int32_t* totals;       // [V] then [V] = depth-overflow flag
@@ -199,8 +201,7 @@ struct Geom {
 };
 
 constexpr int BIN_T = 256;                          // threads per binning workgroup (4 waves)
-constexpr int BIN_CW = 512;                         // depth-ordered Gaussians per wave
-constexpr int BIN_CHUNK = (BIN_T / WAVE) * BIN_CW;  // per workgroup
+constexpr int BIN_CHUNK = 2048;                     // depth-ordered Gaussians per chunk (count: a workgroup, scatter: a wave)
 
 Geom carve_geom(void* p, int64_t P, int V, int64_t tiles) {
   Geom g;
@@ -213,29 +214,28 @@ Geom carve_geom(void* p, int64_t P, int V, int64_t tiles) {
   g.order_b = c.take<int32_t>(P * V);
   g.rects = c.take<uint32_t>(P * V);
   g.chunk_cnt = c.take<uint16_t>(V * nchunk * tiles);
-  g.chunk_off = c.take<uint32_t>(V * nchunk * tiles);
-  g.tile_total = c.take<int32_t>(V * tiles);
-  g.tile_start = c.take<int32_t>(V * tiles);
+  g.seg_off = c.take<uint32_t>(V * nchunk * (tiles + 1));
+  g.chunk_total = c.take<int32_t>(2 * V * nchunk);
+  g.chunk_max = c.take<int32_t>(1);
   g.sort_temp_bytes = sort_pairs_temp_bytes(P * V);
   g.sort_temp = c.take<char>(g.sort_temp_bytes);
   g.totals = c.take<int32_t>(V + 1);
   g.views = c.take<DevView>(MAX_VIEWS);
-  g.scan_ws = c.take<int32_t>(V * scan_ws_ints(tiles));
+  g.scan_ws = c.take<int32_t>(V * scan_ws_ints(nchunk));
   g.bytes = c.used();
   return g;
 }
 
 struct Bin {
-  int32_t* point_list;  // [R] Gaussian ids, tile-major, depth order inside a tile
-  int2* ranges;         // [V * tiles]
+  int32_t* point_list;  // [R] Gaussian ids: chunk-major, tile-sorted inside a chunk, depth order inside a segment
   size_t bytes;
 };
 
 Bin carve_bin(void* p, int64_t R, int64_t vtiles) {
   Bin b;
   Carver c(p);
-  b.point_list = c.take<int32_t>(R);
-  b.ranges = c.take<int2>(vtiles);
+  (void)vtiles;
+  b.point_list = c.take<int32_t>(R + 64);
   b.bytes = c.used();
   return b;
 }
@@ -431,18 +431,28 @@ __global__ __launch_bounds__(256) void full_keys_kernel(int64_t n, int P, const 
 
 // ------------------------------------------------------------------------------------ tile binning
 // Input: per view the Gaussians in depth order (ids) with their tile rectangles (26-bit packing, RECT_MARKER26 = "did not
-// fit, rebuild from the record").  Output: point_list, tile-major, each tile's run in depth order -- what a stable sort
-// of (tile, depth-rank) keys would give, without ever materialising those keys:
-//   count    a workgroup owns BIN_CHUNK consecutive depth-ordered Gaussians of one view and histograms their tiles in LDS
-//   scan     per (view, tile): exclusive prefix over the chunks (thread per tile), then over the tiles of a view
-//   scatter  the same workgroup shape; wave w owns BIN_CW consecutive Gaussians and a private cursor per tile in LDS
-//            (global start of the tile + chunk prefix + the earlier waves' counts).  The wave walks its Gaussians ONE AT
-//            A TIME in depth order with the lanes spread over the Gaussian's rectangle: one ds_add_rtn_u32 hands every
-//            tile of the rectangle its next slot, one store writes the id there.  A wave's LDS atomics execute in issue
-//            order and the tiles of one rectangle are distinct, so slots are taken in depth order: the list is exactly
-//            the stable-sort result, with no per-instance key traffic (write 4 B per instance, read 8 B per Gaussian).
-// With >= 8 views the workgroups of one view all run on the same XCD (block b sits on XCD b % 8), so the partially
-// written lines of that view's tile lists merge in ONE 4 MiB L2 before they go to HBM.
+// fit, rebuild from the record").  Output: point_list, CHUNK-major: the instances of one chunk of BIN_CHUNK consecutive
+// depth-ordered Gaussians form one contiguous block, sorted by tile inside LDS (depth order kept inside every (chunk,
+// tile) segment), and seg_off[view][chunk][tile] says where each segment starts.  The blend walks a tile's segments in
+// chunk order = depth order, so it sees exactly what a stable sort of (tile, depth-rank) keys would give, but no key is
+// ever materialised and every global write is a full coalesced line (scattering 4-byte ids straight into per-tile lists
+// was measured first: 62 M partial-line writes per 32 views cost 1.1 ms in the L2 alone).
+//   count    a workgroup owns a chunk, histograms its tiles in LDS -> chunk_cnt, chunk_total
+//   scan     chunk totals -> chunk bases (per view); per chunk an exclusive scan over the tiles -> seg_off
+//   scatter  a workgroup owns a chunk; wave w owns a quarter of its Gaussians and a private cursor per tile in LDS
+//            (segment start + the earlier waves' counts).  64 Gaussians (lanes) per step:
+//              small rectangles (<= 8 x 8 tiles, wave-uniform test): with M = 2 / 4 / 8 >= the largest side, a rectangle
+//                holds at most ONE tile of every residue class (x mod M, y mod M), so the wave walks the M*M classes and
+//                in each every lane issues the (at most one) tile it has there.  A given tile is therefore requested by
+//                all its Gaussians in the SAME instruction, and LANE_ORDERED (one ds_add_rtn_u32; equal-address lanes
+//                served in lane order -- probed on the device, see below) hands them consecutive slots in lane = depth
+//                order.  Without that property the lanes of a tile find each other with one ballot per tile-id bit and
+//                rank themselves explicitly.
+//              a step containing a larger rectangle is walked one Gaussian at a time, lanes over its tiles.
+//            A wave's LDS instructions execute in issue order, so every segment stays in depth order.  Ids land in an LDS
+//            staging block at their final chunk-local position; the block is then copied out with coalesced stores
+//            (chunks whose instances do not fit the staging block write straight to their final global position).
+// With >= 8 views the workgroups of one view all run on the same XCD (block b sits on XCD b % 8).
 constexpr uint32_t RECT_MARKER26 = 127u | (127u << 7);
 
 __device__ __forceinline__ bool rect_decode(uint32_t r, int id, int64_t vbase, const float4* __restrict__ rec, int gx,
@@ -488,14 +498,17 @@ __global__ __launch_bounds__(BIN_T) void tile_count_kernel(int P, int V, int gx,
                                                            const uint32_t* __restrict__ rects,
                                                            const int32_t* __restrict__ ids,
                                                            const float4* __restrict__ rec,
-                                                           uint16_t* __restrict__ chunk_cnt) {
+                                                           uint16_t* __restrict__ chunk_cnt,
+                                                           int32_t* __restrict__ chunk_total) {
   extern __shared__ unsigned int s_hist[];
+  __shared__ int s_wsum[BIN_T / WAVE];
   int v, c;
   if (!bin_block(V, nchunk, v, c)) return;
   const int tiles = gx * gy;
   for (int T = threadIdx.x; T < tiles; T += BIN_T) s_hist[T] = 0u;
   __syncthreads();
   const int64_t vbase = (int64_t)v * P;
+  int mine = 0;
   for (int it = 0; it < BIN_CHUNK / BIN_T; ++it) {
     const int t = c * BIN_CHUNK + it * BIN_T + threadIdx.x;
     if (t >= P) break;
@@ -503,104 +516,137 @@ __global__ __launch_bounds__(BIN_T) void tile_count_kernel(int P, int V, int gx,
     if (r == 0u) continue;
     int x0, y0, w, h;
     if (!rect_decode(r, ids[vbase + t], vbase, rec, gx, gy, x0, y0, w, h)) continue;
+    mine += w * h;
     for (int y = y0; y < y0 + h; ++y)
       for (int x = x0; x < x0 + w; ++x) atomicAdd(&s_hist[y * gx + x], 1u);
   }
+  const int wsum = wave_sum_i32_dpp(mine);
+  if ((threadIdx.x & (WAVE - 1)) == 0) s_wsum[threadIdx.x / WAVE] = wsum;
   __syncthreads();
   uint16_t* dst = chunk_cnt + ((int64_t)v * nchunk + c) * tiles;
-  for (int T = threadIdx.x; T < tiles; T += BIN_T) dst[T] = (uint16_t)s_hist[T];  // <= BIN_CHUNK < 65536
+  // a tile can appear at most once per Gaussian: counts <= BIN_CHUNK < 65536
+  for (int T = threadIdx.x; T < tiles; T += BIN_T) dst[T] = (uint16_t)s_hist[T];
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int i = 0; i < BIN_T / WAVE; ++i) tot += s_wsum[i];
+    chunk_total[v * nchunk + c] = tot;
+  }
 }
 
-// per (view, tile): exclusive prefix over the chunks
-__global__ __launch_bounds__(256) void chunk_scan_kernel(int V, int tiles, int nchunk,
-                                                         const uint16_t* __restrict__ chunk_cnt,
-                                                         uint32_t* __restrict__ chunk_off,
-                                                         int32_t* __restrict__ tile_total) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= V * tiles) return;
-  const int v = i / tiles, T = i - v * tiles;
-  const int64_t base = (int64_t)v * nchunk * tiles + T;
-  uint32_t run = 0;
-  int c = 0;
-  for (; c + 4 <= nchunk; c += 4) {
-    uint32_t n[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) n[u] = chunk_cnt[base + (int64_t)(c + u) * tiles];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      chunk_off[base + (int64_t)(c + u) * tiles] = run;
-      run += n[u];
-    }
+// largest chunk total (sizes the scatter's LDS staging block); one workgroup, no same-address atomics
+__global__ __launch_bounds__(1024) void chunk_max_kernel(int n, const int32_t* __restrict__ chunk_total,
+                                                         int32_t* __restrict__ chunk_max) {
+  __shared__ int s_m[1024 / WAVE];
+  int m = 0;
+  for (int i = threadIdx.x; i < n; i += 1024) m = max(m, chunk_total[i]);
+  m = wave_max_i32_dpp(m);
+  if ((threadIdx.x & (WAVE - 1)) == 0) s_m[threadIdx.x / WAVE] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 1024 / WAVE; ++i) m = max(m, s_m[i]);
+    *chunk_max = m;
   }
-  for (; c < nchunk; ++c) {
-    const uint32_t n = chunk_cnt[base + (int64_t)c * tiles];
-    chunk_off[base + (int64_t)c * tiles] = run;
-    run += n;
-  }
-  tile_total[i] = (int32_t)run;
 }
 
-__global__ __launch_bounds__(256) void ranges_kernel(int V, int tiles, const int32_t* __restrict__ tile_start,
-                                                     const int32_t* __restrict__ tile_total,
-                                                     const int32_t* __restrict__ totals, int2* __restrict__ ranges) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= V * tiles) return;
-  const int v = i / tiles;
+// per chunk: seg_off[tile] = view base + chunk base + exclusive scan of the chunk's tile counts; [tiles] = end
+__global__ __launch_bounds__(256) void seg_scan_kernel(int V, int tiles, int nchunk, const uint16_t* __restrict__ chunk_cnt,
+                                                       const int32_t* __restrict__ chunk_base /* per view */,
+                                                       const int32_t* __restrict__ totals, uint32_t* __restrict__ seg_off) {
+  __shared__ int s_w[256 / WAVE];
+  __shared__ int s_carry;
+  const int v = blockIdx.x / nchunk, c = blockIdx.x % nchunk;
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   int vb = 0;
   for (int u = 0; u < v; ++u) vb += totals[u];
-  const int a = vb + tile_start[i];
-  ranges[i] = make_int2(a, a + tile_total[i]);
+  const uint16_t* src = chunk_cnt + ((int64_t)v * nchunk + c) * tiles;
+  uint32_t* dst = seg_off + ((int64_t)v * nchunk + c) * (tiles + 1);
+  if (threadIdx.x == 0) s_carry = vb + chunk_base[v * nchunk + c];
+  __syncthreads();
+  for (int T0 = 0; T0 < tiles; T0 += 256) {
+    const int T = T0 + threadIdx.x;
+    const int n = T < tiles ? (int)src[T] : 0;
+    const int incl = wave_incl_scan_add_dpp(n);
+    if (lane == WAVE - 1) s_w[wv] = incl;
+    __syncthreads();
+    int base = s_carry;
+    for (int i = 0; i < wv; ++i) base += s_w[i];
+    if (T < tiles) dst[T] = (uint32_t)(base + incl - n);
+    __syncthreads();
+    if (threadIdx.x == 255) s_carry = base + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dst[tiles] = (uint32_t)s_carry;
 }
 
-__global__ __launch_bounds__(BIN_T) void tile_scatter_kernel(int P, int V, int gx, int gy, int nchunk,
-                                                             const uint32_t* __restrict__ rects,
+// Hardware property probe.  gfx950's LDS resolves the lanes of ONE ds_add_rtn_u32 that hit the same address in ascending
+// lane order (the returned pre-add values grow with the lane id).  That is not an architectural promise, so it is
+// MEASURED once per process on the device in use: 64 lanes x many address patterns (all-same, strided, hashed); if any
+// group of equal-address lanes comes back out of lane order the scatter falls back to explicit ballot ranking.
+__global__ __launch_bounds__(WAVE) void lds_atomic_order_probe_kernel(int* __restrict__ bad) {
+  __shared__ unsigned int cell[256];
+  __shared__ unsigned int got[WAVE];
+  __shared__ unsigned int adr[WAVE];
+  const int lane = threadIdx.x;
+  int nbad = 0;
+  for (int pat = 0; pat < 96; ++pat) {
+    for (int i = lane; i < 256; i += WAVE) cell[i] = 0u;
+    __syncthreads();
+    unsigned int a;
+    if (pat < 64) a = (unsigned int)(lane % (pat + 1));                  // 1 .. 64 distinct addresses, strided
+    else a = ((unsigned int)(lane * 2654435761u + pat * 40503u) >> 7) % (unsigned int)(3 + (pat - 64) * 7);  // hashed
+    const bool take = pat < 80 || ((lane * 7 + pat) % 5) != 0;           // some patterns run with lanes masked off
+    unsigned int r = 0xffffffffu;
+    if (take) r = atomicAdd(&cell[a], 1u);
+    got[lane] = r;
+    adr[lane] = a;
+    __syncthreads();
+    if (take) {
+      unsigned int want = 0;  // lanes below me on the same address that took part
+      for (int l = 0; l < lane; ++l) want += (adr[l] == a && got[l] != 0xffffffffu) ? 1u : 0u;
+      if (want != r) ++nbad;
+    }
+    __syncthreads();
+  }
+  if (nbad) atomicAdd(bad, nbad);
+}
+
+template <bool LANE_ORDERED>
+__global__ __launch_bounds__(BIN_T) void tile_scatter_kernel(int P, int V, int gx, int gy, int nchunk, int tile_bits,
+                                                             int stage_cap, const uint32_t* __restrict__ rects,
                                                              const int32_t* __restrict__ ids,
                                                              const float4* __restrict__ rec,
-                                                             const uint32_t* __restrict__ chunk_off,
-                                                             const int32_t* __restrict__ tile_start,
-                                                             const int32_t* __restrict__ totals,
+                                                             const uint32_t* __restrict__ seg_off,
                                                              int32_t* __restrict__ point_list) {
-  extern __shared__ unsigned int s_cur[];  // [waves][tiles]
-  constexpr int NW = BIN_T / WAVE, STEPS = BIN_CW / WAVE;
+  extern __shared__ unsigned int s_cur[];  // [waves][tiles] counts -> cursors, then [stage_cap] staged chunk-local indices
+  constexpr int NW = BIN_T / WAVE, CW = BIN_CHUNK / NW;
   int v, c;
   if (!bin_block(V, nchunk, v, c)) return;
   const int tiles = gx * gy;
+  const uint32_t* seg = seg_off + ((int64_t)v * nchunk + c) * (tiles + 1);
+  const unsigned int chunk_begin = seg[0];
+  const int total = (int)(seg[tiles] - chunk_begin);
+  if (total == 0) return;  // block-uniform
+  const bool staged = total <= stage_cap;
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   unsigned int* my = s_cur + wv * tiles;
+  // staged entries are 16-bit positions inside the chunk (BIN_CHUNK <= 65536); the ids are looked up on the way out
+  unsigned short* stage = reinterpret_cast<unsigned short*>(s_cur + NW * tiles);
   for (int T = threadIdx.x; T < NW * tiles; T += BIN_T) s_cur[T] = 0u;
   __syncthreads();
-  // ---- phase A: this wave's tile counts; rectangles and ids stay in registers for phase C
   const int64_t vbase = (int64_t)v * P;
-  const int wbase = c * BIN_CHUNK + wv * BIN_CW;
-  uint32_t pr[STEPS];
-  int pid[STEPS];
-#pragma unroll
-  for (int s = 0; s < STEPS; ++s) {
-    const int t = wbase + s * WAVE + lane;
-    pr[s] = 0u;
-    pid[s] = 0;
-    if (t < P) {
-      const uint32_t r = rects[vbase + t];
-      if (r != 0u) {
-        const int id = ids[vbase + t];
-        int x0, y0, w, h;
-        if (rect_decode(r, id, vbase, rec, gx, gy, x0, y0, w, h)) {
-          pr[s] = (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)w << 16) | ((uint32_t)h << 24);  // gx, gy <= 255
-          pid[s] = id;
-          for (int y = y0; y < y0 + h; ++y)
-            for (int x = x0; x < x0 + w; ++x) atomicAdd(&my[y * gx + x], 1u);
-        }
-      }
-    }
+  const int w_begin = c * BIN_CHUNK + wv * CW, w_end = min(P, w_begin + CW);
+  // ---- phase A: this wave's tile counts
+  for (int t = w_begin + lane; t < w_end; t += WAVE) {
+    const uint32_t r = rects[vbase + t];
+    int x0, y0, w, h;
+    if (r != 0u && rect_decode(r, ids[vbase + t], vbase, rec, gx, gy, x0, y0, w, h))
+      for (int y = y0; y < y0 + h; ++y)
+        for (int x = x0; x < x0 + w; ++x) atomicAdd(&my[y * gx + x], 1u);
   }
   __syncthreads();
-  // ---- phase B: counts -> cursors = (view base + tile start + chunk prefix) + the earlier waves' counts
-  int vb = 0;
-  for (int u = 0; u < v; ++u) vb += totals[u];
-  const uint32_t* coff = chunk_off + ((int64_t)v * nchunk + c) * tiles;
-  const int32_t* tst = tile_start + (int64_t)v * tiles;
+  // ---- phase B: counts -> cursors (chunk-local when staged, global otherwise)
   for (int T = threadIdx.x; T < tiles; T += BIN_T) {
-    unsigned int run = (unsigned int)(vb + tst[T]) + coff[T];
+    unsigned int run = seg[T] - (staged ? chunk_begin : 0u);
 #pragma unroll
     for (int w2 = 0; w2 < NW; ++w2) {
       const unsigned int n = s_cur[w2 * tiles + T];
@@ -609,38 +655,107 @@ __global__ __launch_bounds__(BIN_T) void tile_scatter_kernel(int P, int V, int g
     }
   }
   __syncthreads();
-  // ---- phase C: one Gaussian at a time in depth order, lanes over its rectangle
+  // ---- phase C
+  // two typed stores under a block-uniform branch (a generic pointer would turn the LDS case into flat_store)
+  auto put = [&](unsigned int pos, int local, int val) {
+    if (staged) stage[pos] = (unsigned short)local;
+    else point_list[pos] = val;
+  };
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int t0 = w_begin; t0 < w_end; t0 += WAVE) {
+    const int t = t0 + lane;
+    int x0 = 0, y0 = 0, w = 0, h = 0, id = 0;
+    if (t < w_end) {
+      const uint32_t r = rects[vbase + t];
+      if (r != 0u) {
+        id = ids[vbase + t];
+        if (!rect_decode(r, id, vbase, rec, gx, gy, x0, y0, w, h)) w = h = 0;
+      }
+    }
+    unsigned long long live = __ballot(w * h != 0);
+    if (live == 0ull) continue;
+    const int maxd = wave_max_i32_dpp(max(w, h));
+    if (maxd <= 8) {
+      // all requests of a row of residue classes are issued before the first returned slot is used: M LDS atomics in
+      // flight instead of one round trip per class (a wave's LDS instructions still execute in issue order)
+      auto walk = [&](auto mtag) {
+        constexpr int M = decltype(mtag)::value;
 #pragma unroll
-  for (int s = 0; s < STEPS; ++s) {
-    const uint32_t r = pr[s];
-    const uint32_t rw = (r >> 16) & 255u;
-    const uint32_t recip = rw ? (65535u + rw) / rw : 0u;  // (k * recip) >> 16 == k / rw for k < 64 <= 65536 / rw
-    unsigned long long bits = __ballot(r != 0u);
-    while (bits) {
-      const int j = __ffsll((long long)bits) - 1;
-      bits &= bits - 1ull;
-      const uint32_t sr = (uint32_t)__builtin_amdgcn_readlane((int)r, j);
-      const uint32_t sm = (uint32_t)__builtin_amdgcn_readlane((int)recip, j);
-      const int sid = __builtin_amdgcn_readlane(pid[s], j);
-      const int x0 = (int)(sr & 255u), y0 = (int)((sr >> 8) & 255u), w = (int)((sr >> 16) & 255u), h = (int)(sr >> 24);
-      const int n = w * h;
-      if (n <= WAVE) {
-        if (lane < n) {
-          const int q = (int)(((uint32_t)lane * sm) >> 16);
-          const int tile = (y0 + q) * gx + x0 + (lane - q * w);
-          const unsigned int pos = atomicAdd(&my[tile], 1u);
-          point_list[pos] = sid;
-        }
-      } else {
-        for (int y = 0; y < h; ++y)
-          for (int xb = 0; xb < w; xb += WAVE)
-            if (xb + lane < w) {
-              const unsigned int pos = atomicAdd(&my[(y0 + y) * gx + x0 + xb + lane], 1u);
-              point_list[pos] = sid;
+        for (int ry = 0; ry < M; ++ry) {
+          const int dy = (ry - y0) & (M - 1);
+          const int rowbase = (y0 + dy) * gx + x0;
+          const bool vy = dy < h;
+          if (LANE_ORDERED) {
+            unsigned int pos[M];
+            bool act[M];
+#pragma unroll
+            for (int rx = 0; rx < M; ++rx) {
+              const int dx = (rx - x0) & (M - 1);
+              act[rx] = vy && dx < w;
+              pos[rx] = 0u;
+              if (act[rx]) pos[rx] = atomicAdd(&my[rowbase + dx], 1u);
             }
+#pragma unroll
+            for (int rx = 0; rx < M; ++rx)
+              if (act[rx]) put(pos[rx], t - c * BIN_CHUNK, id);
+          } else {
+            for (int rx = 0; rx < M; ++rx) {
+              const int dx = (rx - x0) & (M - 1);
+              const bool act = vy && dx < w;
+              const unsigned int tile = (unsigned int)(rowbase + dx);
+              unsigned long long peers = __ballot(act);
+              if (peers == 0ull) continue;
+              for (int bit = 0; bit < tile_bits; ++bit) {
+                const bool one = (tile >> bit) & 1u;
+                const unsigned long long bal = __ballot(one);
+                peers &= one ? bal : ~bal;
+              }
+              if (act) {
+                const unsigned int base = my[tile];
+                put(base + (unsigned int)__popcll(peers & lt), t - c * BIN_CHUNK, id);
+                if ((peers >> lane) == 1ull) my[tile] = base + (unsigned int)__popcll(peers);  // last lane of the group
+              }
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+          }
+        }
+      };
+      if (maxd <= 2) walk(std::integral_constant<int, 2>{});
+      else if (maxd <= 4) walk(std::integral_constant<int, 4>{});
+      else walk(std::integral_constant<int, 8>{});
+    } else {
+      const uint32_t pr = (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)w << 16) | ((uint32_t)h << 24);  // gx, gy <= 255
+      while (live) {
+        const int j = __ffsll((long long)live) - 1;
+        live &= live - 1ull;
+        const uint32_t sr = (uint32_t)__builtin_amdgcn_readlane((int)pr, j);
+        const int sid = __builtin_amdgcn_readlane(id, j);
+        const int sx = (int)(sr & 255u), sy = (int)((sr >> 8) & 255u), sw = (int)((sr >> 16) & 255u), sh = (int)(sr >> 24);
+        for (int y = 0; y < sh; ++y)
+          for (int xb = 0; xb < sw; xb += WAVE)
+            if (xb + lane < sw) {
+              unsigned int* slot = &my[(sy + y) * gx + sx + xb + lane];
+              if (LANE_ORDERED) {
+                put(atomicAdd(slot, 1u), t0 + j - c * BIN_CHUNK, sid);
+              } else {
+                const unsigned int pos = *slot;  // distinct tiles: no two lanes share a slot here
+                *slot = pos + 1u;
+                put(pos, t0 + j - c * BIN_CHUNK, sid);
+              }
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
     }
   }
+  if (!staged) return;
+  __syncthreads();
+  // ---- phase D: the chunk's block leaves as full coalesced lines
+  const int32_t* cid = ids + vbase + (int64_t)c * BIN_CHUNK;
+  for (int i = threadIdx.x; i < total; i += BIN_T) point_list[chunk_begin + i] = cid[stage[i]];
 }
 
 // ------------------------------------------------------------------------------------ blend
@@ -660,13 +775,15 @@ constexpr int CELL = 4;
 constexpr int NCELL = (TILE / CELL) * (TILE / CELL);  // 16
 
 __global__ __launch_bounds__(BLOCK) void blend_kernel(
-    int P, int W, int H, const DevView* __restrict__ views, const int2* __restrict__ ranges,
+    int P, int W, int H, int nchunk, const DevView* __restrict__ views, const uint32_t* __restrict__ seg_off,
     const int32_t* __restrict__ point_list, const float4* __restrict__ rec, float* __restrict__ out_color) {
   __shared__ float4 s_a[BLOCK];  // {px, py, pc, rc2}
   __shared__ float4 s_b[BLOCK];  // {conic.x, conic.y, conic.z, opacity}
   __shared__ float4 s_c[BLOCK];  // {r, g, b, -}
   __shared__ unsigned char s_list[NCELL][BLOCK];
   __shared__ int s_cnt[NCELL][BLOCK / WAVE + 1];  // per (cell, loading wave) counts -> bases; [.][4] = total
+  __shared__ int s_wpre[WAVE];                    // window of 64 chunks: inclusive prefix of this tile's segment lengths
+  __shared__ unsigned int s_woff[WAVE];           //                      and where each segment starts in point_list
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   const int v = blockIdx.z;
   const int tile = blockIdx.y * gx + blockIdx.x;
@@ -679,17 +796,50 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
   const bool inside = pxi < W && pyi < H;
   const float pfx = (float)pxi, pfy = (float)pyi;
   const float tx0 = (float)(blockIdx.x * TILE), ty0 = (float)(blockIdx.y * TILE);
-  const int2 range = ranges[(int64_t)v * gx * gy + tile];
+  const int tiles = gx * gy;
   const int64_t goff = (int64_t)v * P;
   bool done = !inside;
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
-  for (int start = range.x; start < range.y; start += BLOCK) {
+  // The tile's list = its segments of chunk 0, 1, 2, ... (depth order).  64 chunks are looked up at a time (one wave:
+  // lane = chunk, two 4-byte loads give segment start and end); the batches of 256 entries are cut out of that window.
+  int c_next = 0, w_pos = 0, w_total = 0;  // block-uniform
+  const uint32_t* seg_col = seg_off + (int64_t)v * nchunk * (tiles + 1) + tile;
+  while (true) {
     if (__syncthreads_and(done)) break;
+    bool exhausted = false;
+    while (w_pos >= w_total) {
+      if (c_next >= nchunk) {
+        exhausted = true;
+        break;
+      }
+      if (tid < WAVE) {
+        const int c = c_next + tid;
+        unsigned int a = 0u, b = 0u;
+        if (c < nchunk) {
+          a = seg_col[(int64_t)c * (tiles + 1)];
+          b = seg_col[(int64_t)c * (tiles + 1) + 1];
+        }
+        s_woff[tid] = a;
+        s_wpre[tid] = wave_incl_scan_add_dpp((int)(b - a));
+      }
+      __syncthreads();
+      w_total = s_wpre[WAVE - 1];
+      w_pos = 0;
+      c_next += WAVE;
+      __syncthreads();
+    }
+    if (exhausted) break;
     // ---- load + cutoffs + cell mask
-    const int k = start + tid;
+    const int e = w_pos + tid;
+    w_pos += BLOCK;
     unsigned mask = 0;
-    if (k < range.y) {
-      const float4* r = rec + 4 * (goff + point_list[k]);
+    if (e < w_total) {
+      int lo = 0;  // first chunk of the window whose inclusive prefix exceeds e
+#pragma unroll
+      for (int st = WAVE / 2; st > 0; st >>= 1)
+        if (s_wpre[lo + st - 1] <= e) lo += st;
+      const int before = lo ? s_wpre[lo - 1] : 0;
+      const float4* r = rec + 4 * (goff + point_list[s_woff[lo] + (unsigned int)(e - before)]);
       const float4 r0 = r[0];
       const float4 co = r[1];
       const float4 col = r[2];
@@ -861,8 +1011,44 @@ int upload_views(const gr_raster_view* h_views, int num_views, std::vector<DevVi
 
 using namespace gr;
 
+// 1 = lane-ordered LDS atomics verified on this device, 0 = not (ballot ranking is used), -1 = not probed yet
+static int g_lds_order[64] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+                              -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+                              -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+
+static int lds_atomics_lane_ordered(hipStream_t stream, bool* ordered) {
+  int dev = 0;
+  GR_HIP(hipGetDevice(&dev));
+  const char* force = getenv("GR_RASTER_BALLOT_RANKING");
+  if (force && force[0] == '1') {
+    *ordered = false;
+    return GR_OK;
+  }
+  if (dev < 0 || dev >= 64) dev = 63;
+  if (g_lds_order[dev] < 0) {
+    int* d_bad = nullptr;
+    int h_bad = 1;
+    GR_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_bad), sizeof(int), stream));
+    GR_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), stream));
+    hipLaunchKernelGGL(lds_atomic_order_probe_kernel, dim3(8), dim3(WAVE), 0, stream, d_bad);
+    GR_HIP(hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, stream));
+    GR_HIP(hipStreamSynchronize(stream));
+    GR_HIP(hipFreeAsync(d_bad, stream));
+    g_lds_order[dev] = h_bad == 0 ? 1 : 0;
+  }
+  *ordered = g_lds_order[dev] == 1;
+  return GR_OK;
+}
+
 static int64_t tiles_of(int width, int height) {
   return (int64_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+}
+
+extern "C" int gr_raster_lds_atomics_lane_ordered(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  if (dev < 0 || dev >= 64) dev = 63;
+  return g_lds_order[dev];
 }
 
 extern "C" size_t gr_raster_geom_bytes(int64_t P, int num_views, int width, int height) {
@@ -885,7 +1071,7 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
   int rc = check_views(h_views, num_views);
   if (rc != GR_OK) return rc;
   GR_REQUIRE(h_num_rendered != nullptr, "h_num_rendered is null");
-  for (int v = 0; v < num_views; ++v) h_num_rendered[v] = 0;
+  for (int v = 0; v <= num_views; ++v) h_num_rendered[v] = 0;
   GR_REQUIRE(P >= 0 && P < (1ll << 31) - 1, "P out of range");
   if (P == 0) {  // nothing to project, but the render call still needs the camera table (background)
     Geom g0 = carve_geom(geom, 0, num_views, tiles_of(h_views[0].image_width, h_views[0].image_height));
@@ -912,7 +1098,7 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
   const int tiles = gx * gy;
   GR_REQUIRE(gx <= 255 && gy <= 255, "image too large: at most 255 x 255 tiles of 16 px (got %d x %d)", gx, gy);
   const size_t bin_lds = (size_t)(BIN_T / WAVE) * tiles * sizeof(unsigned int);
-  GR_REQUIRE(bin_lds <= 160 * 1024, "image too large: the per-wave tile cursors (%zu bytes) do not fit in LDS", bin_lds);
+  GR_REQUIRE(bin_lds <= 156 * 1024, "image too large: the per-wave tile cursors (%zu bytes) do not fit in LDS", bin_lds);
   Geom g = carve_geom(geom, P, num_views, tiles);
   if (!geom || geom_bytes < g.bytes) {
     set_error("raster geometry buffer too small: need %zu bytes, got %zu", g.bytes, geom_bytes);
@@ -942,6 +1128,7 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
   static_assert((1 << KEY_VIEW_BITS) >= MAX_VIEWS && KEY_DEPTH_BITS + KEY_VIEW_BITS <= 38, "view id must fit its key field");
   std::vector<int32_t> tot(num_views + 1);
   const int nchunk = (int)((P + BIN_CHUNK - 1) / BIN_CHUNK);
+  int32_t h_chunk_max = 0;
   auto sort_and_count = [&](int end_bit) -> int {
     {
       KernelTimer timer("raster_depth_sort", stream);
@@ -958,14 +1145,19 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       hipLaunchKernelGGL(tile_count_kernel, dim3((unsigned)bin_grid(num_views, nchunk)), dim3(BIN_T),
                          tiles * sizeof(unsigned int), stream, (int)P, num_views, gx, gy, nchunk, g.rects, g.order_b, g.rec,
-                         g.chunk_cnt);
-      hipLaunchKernelGGL(chunk_scan_kernel, dim3((unsigned)((num_views * tiles + 255) / 256)), blk, 0, stream, num_views,
-                         tiles, nchunk, g.chunk_cnt, g.chunk_off, g.tile_total);
+                         g.chunk_cnt, g.chunk_total);
+      hipLaunchKernelGGL(chunk_max_kernel, dim3(1), dim3(1024), 0, stream, num_views * nchunk, g.chunk_total, g.chunk_max);
       GR_LAUNCH_CHECK();
-      int rcs = exclusive_scan_i32(g.tile_total, g.tile_start, tiles, num_views, tiles, g.scan_ws, g.totals, stream);
+      // chunk bases inside each view (+ the per-view totals R_v), then every chunk's per-tile segment starts
+      int rcs = exclusive_scan_i32(g.chunk_total, g.chunk_total + (int64_t)num_views * nchunk, nchunk, num_views, nchunk,
+                                   g.scan_ws, g.totals, stream);
       if (rcs != GR_OK) return rcs;
+      hipLaunchKernelGGL(seg_scan_kernel, dim3((unsigned)(num_views * nchunk)), blk, 0, stream, num_views, tiles, nchunk,
+                         g.chunk_cnt, g.chunk_total + (int64_t)num_views * nchunk, g.totals, g.seg_off);
+      GR_LAUNCH_CHECK();
     }
     GR_HIP(hipMemcpyAsync(tot.data(), g.totals, sizeof(int32_t) * (num_views + 1), hipMemcpyDeviceToHost, stream));
+    GR_HIP(hipMemcpyAsync(&h_chunk_max, g.chunk_max, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     GR_HIP(hipStreamSynchronize(stream));
     return GR_OK;
   };
@@ -979,6 +1171,7 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
     if (rc != GR_OK) return rc;
   }
   for (int v = 0; v < num_views; ++v) h_num_rendered[v] = tot[v];
+  h_num_rendered[num_views] = h_chunk_max;  // sizes the scatter's LDS staging block in gr_raster_render
   return GR_OK;
 }
 
@@ -1005,24 +1198,30 @@ extern "C" int gr_raster_render(int64_t P, const gr_raster_view* h_views, int nu
     return GR_ERR_WORKSPACE;
   }
   const int32_t* point_list = b.point_list;
+  const int nchunk = (int)((P + BIN_CHUNK - 1) / BIN_CHUNK);
   if (R > 0) {
-    KernelTimer timer("raster_bin", stream);
-    const int nchunk = (int)((P + BIN_CHUNK - 1) / BIN_CHUNK);
-    const size_t lds = (size_t)(BIN_T / WAVE) * tiles * sizeof(unsigned int);
-    auto kern = tile_scatter_kernel;
+    // LDS: per-wave tile cursors + a staging block that holds a whole chunk's instances (chunks that do not fit write
+    // straight to global memory); sized for the largest chunk of this call, capped so that two workgroups share a CU
+    const size_t cur_bytes = (size_t)(BIN_T / WAVE) * tiles * sizeof(unsigned int);
+    const int64_t cap_max = ((int64_t)78 * 1024 - (int64_t)cur_bytes) / 2;
+    int stage_cap = (int)std::min<int64_t>(std::max<int64_t>(cap_max, 0), (std::max<int64_t>(h_num_rendered[num_views], 0) + 63) / 64 * 64);
+    const size_t lds = cur_bytes + (size_t)stage_cap * sizeof(unsigned short);
+    bool ordered = false;
+    rc = lds_atomics_lane_ordered(stream, &ordered);
+    if (rc != GR_OK) return rc;
+    auto kern = ordered ? tile_scatter_kernel<true> : tile_scatter_kernel<false>;
+    int tile_bits = 0;
+    while ((1 << tile_bits) < tiles) ++tile_bits;
     if (lds > 64 * 1024)
       GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((vtiles + 255) / 256)), dim3(256), 0, stream, num_views, tiles,
-                       g.tile_start, g.tile_total, g.totals, b.ranges);
+    KernelTimer timer("raster_bin", stream);
     hipLaunchKernelGGL(kern, dim3((unsigned)bin_grid(num_views, nchunk)), dim3(BIN_T), lds, stream, (int)P, num_views, gx, gy,
-                       nchunk, g.rects, g.order_b, g.rec, g.chunk_off, g.tile_start, g.totals, b.point_list);
+                       nchunk, tile_bits, stage_cap, g.rects, g.order_b, g.rec, g.seg_off, b.point_list);
     GR_LAUNCH_CHECK();
-  } else {
-    GR_HIP(hipMemsetAsync(b.ranges, 0, sizeof(int2) * vtiles, stream));
   }
   KernelTimer timer("raster_blend", stream);
-  hipLaunchKernelGGL(blend_kernel, dim3(gx, gy, num_views), dim3(BLOCK), 0, stream, (int)P, W, H, g.views, b.ranges,
-                     point_list, g.rec, out_color);
+  hipLaunchKernelGGL(blend_kernel, dim3(gx, gy, num_views), dim3(BLOCK), 0, stream, (int)P, W, H, R > 0 ? nchunk : 0, g.views,
+                     g.seg_off, point_list, g.rec, out_color);
   GR_LAUNCH_CHECK();
   return GR_OK;
 }

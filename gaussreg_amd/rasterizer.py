@@ -114,7 +114,7 @@ def rasterize_views(settings, means3D, opacities, shs=None,
     M = 0 if sh is None else (sh.shape[1] if sh.dim() == 3 else sh.reshape(max(P, 1), -1, 3).shape[1])
     color = torch.empty((V, 3, H, W), dtype=torch.float32, device=dev)
     radii = torch.empty((V, P), dtype=torch.int32, device=dev)  # every entry is written by preprocess
-    nr = (ctypes.c_int64 * V)()
+    nr = (ctypes.c_int64 * (V + 1))()
     with torch.cuda.device(dev):
         st = _lib.stream_ptr(dev)
         geom = torch.empty(L.gr_raster_geom_bytes(P, V, W, H) + 256, dtype=torch.uint8, device=dev)

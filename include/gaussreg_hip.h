@@ -118,6 +118,8 @@ int gr_grid_subsample(const float* points, const int64_t* h_lengths, int64_t n, 
  * instances R is data dependent (upstream syncs at the same place):
  *   gr_raster_preprocess : cull / project / cov2D / SH->RGB / depth order / per-tile counts and prefix sums into
  *                          `geom` (size gr_raster_geom_bytes), SYNCHRONISES `stream`,
+ *                          h_num_rendered has num_views + 1 entries: [num_views] is a binning hint for
+ *                          gr_raster_render (largest per-chunk instance count); pass the array on unchanged.
  *                          h_num_rendered[v] = R_v = instances binned (<= upstream's count: pairs that
  *                          cannot reach alpha = 1/255 inside the tile are dropped, the image is unaffected).
  *                          Also writes radii (num_views, P) int32, exactly upstream's values.
@@ -151,6 +153,10 @@ int gr_raster_preprocess(int64_t P, int sh_coeffs, const float* means3D, const f
 int gr_raster_render(int64_t P, const gr_raster_view* h_views, int num_views,
                      const int64_t* h_num_rendered, const void* geom, size_t geom_bytes, void* bin,
                      size_t bin_bytes, float* out_color, void* stream);
+/* Which ranking the tile-binning scatter uses on the current device: 1 = one LDS atomic per instance (the device was
+ * probed and serves equal-address lanes of a ds_add_rtn in lane order), 0 = explicit ballot ranking (probe failed, or
+ * GR_RASTER_BALLOT_RANKING=1), -1 = no render call has probed the device yet.  Both produce the same lists. */
+int gr_raster_lds_atomics_lane_ordered(void);
 /* present[i] = 1 iff Gaussian i passes the near-plane test of `viewmatrix` (markVisible). */
 int gr_raster_mark_visible(int64_t P, const float* means3D, const float* h_viewmatrix,
                            uint8_t* present, void* stream);

@@ -5,7 +5,7 @@ import csv
 import json
 import sys
 
-KEEP = ("blend_kernel", "preprocess_kernel", "traverse_kernel", "instances_kernel")
+KEEP = tuple(__import__("os").environ.get("GR_SQ_KEEP", "blend_kernel,preprocess_kernel,traverse_kernel,instances_kernel,tile_scatter_kernel,tile_count_kernel,radix,search").split(","))
 SIMDS, GHZ = 1024, 2.4
 
 
