@@ -233,6 +233,79 @@ int exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int rows, int
   return GR_OK;
 }
 
+
+// ---------------------------------------------------------------- LDS atomic ordering probe
+namespace {
+// Hardware property probe.  gfx950's LDS resolves the lanes of ONE ds_add_rtn_u32 that hit the same address in ascending
+// lane order (the returned pre-add values grow with the lane id).  That is not an architectural promise, so it is
+// MEASURED once per process on the device in use: 64 lanes x many address patterns (all-same, strided, hashed); if any
+// group of equal-address lanes comes back out of lane order the scatter falls back to explicit ballot ranking.
+__global__ __launch_bounds__(WAVE) void lds_atomic_order_probe_kernel(int* __restrict__ bad) {
+  __shared__ unsigned int cell[256];
+  __shared__ unsigned int got[WAVE];
+  __shared__ unsigned int adr[WAVE];
+  const int lane = threadIdx.x;
+  int nbad = 0;
+  for (int pat = 0; pat < 96; ++pat) {
+    for (int i = lane; i < 256; i += WAVE) cell[i] = 0u;
+    __syncthreads();
+    unsigned int a;
+    if (pat < 64) a = (unsigned int)(lane % (pat + 1));                  // 1 .. 64 distinct addresses, strided
+    else a = ((unsigned int)(lane * 2654435761u + pat * 40503u) >> 7) % (unsigned int)(3 + (pat - 64) * 7);  // hashed
+    const bool take = pat < 80 || ((lane * 7 + pat) % 5) != 0;           // some patterns run with lanes masked off
+    unsigned int r = 0xffffffffu;
+    if (take) r = atomicAdd(&cell[a], 1u);
+    got[lane] = r;
+    adr[lane] = a;
+    __syncthreads();
+    if (take) {
+      unsigned int want = 0;  // lanes below me on the same address that took part
+      for (int l = 0; l < lane; ++l) want += (adr[l] == a && got[l] != 0xffffffffu) ? 1u : 0u;
+      if (want != r) ++nbad;
+    }
+    __syncthreads();
+  }
+  if (nbad) atomicAdd(bad, nbad);
+}
+
+}  // namespace
+
+// 1 = lane-ordered LDS atomics verified on this device, 0 = not (ballot ranking is used), -1 = not probed yet
+int g_lds_order[64] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+                              -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+                              -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+
+int lds_atomics_lane_ordered(hipStream_t stream, bool* ordered) {
+  int dev = 0;
+  GR_HIP(hipGetDevice(&dev));
+  const char* force = getenv("GR_RASTER_BALLOT_RANKING");
+  if (force && force[0] == '1') {
+    *ordered = false;
+    return GR_OK;
+  }
+  if (dev < 0 || dev >= 64) dev = 63;
+  if (g_lds_order[dev] < 0) {
+    int* d_bad = nullptr;
+    int h_bad = 1;
+    GR_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_bad), sizeof(int), stream));
+    GR_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), stream));
+    hipLaunchKernelGGL(lds_atomic_order_probe_kernel, dim3(8), dim3(WAVE), 0, stream, d_bad);
+    GR_HIP(hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, stream));
+    GR_HIP(hipStreamSynchronize(stream));
+    GR_HIP(hipFreeAsync(d_bad, stream));
+    g_lds_order[dev] = h_bad == 0 ? 1 : 0;
+  }
+  *ordered = g_lds_order[dev] == 1;
+  return GR_OK;
+}
+
+int lds_atomics_lane_ordered_state() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  if (dev < 0 || dev >= 64) dev = 63;
+  return g_lds_order[dev];
+}
+
 }  // namespace gr
 
 extern "C" const char* gr_last_error(void) { return gr::g_err; }

@@ -97,6 +97,17 @@ int sort_pairs_u64_i32(void* temp, size_t temp_bytes, const uint64_t* keys_in, u
 int sort_pairs_u64_iota(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, int64_t period,
                         int32_t* vals_out, int64_t n, int begin_bit, int end_bit, hipStream_t stream);
 
+// Do the lanes of ONE ds_add_rtn_u32 that hit the same LDS address get their pre-add values in ascending lane order on
+// this device?  Probed once per process and device (common.hip); GR_RASTER_BALLOT_RANKING=1 forces "no".
+int lds_atomics_lane_ordered(hipStream_t stream, bool* ordered);
+int lds_atomics_lane_ordered_state();  // 1 yes, 0 no, -1 not probed yet
+
+// Segmented stable LSD radix sort of the rasterizer's (view, Gaussian) depth keys (depth_sort.hip).
+size_t depth_sort_table_bytes(int64_t P, int V);
+int depth_sort_views(uint64_t* keys_a, uint64_t* keys_b, int32_t* ids_tmp, int32_t* ids_out, uint32_t* hi_out, int out_shift,
+                     int32_t* nvalid_out, int64_t P, int V, int key_bits, void* table, size_t table_bytes,
+                     hipStream_t stream);
+
 // Optional per-kernel HIP-event timing (off by default; bench.py turns it on to measure the
 // dominant kernel's average launch duration on the stream it is launched on).
 struct KernelTimer {

@@ -1,0 +1,308 @@
+// Segmented stable LSD radix sort for the rasterizer's depth ordering, hand-written for gfx950 (replaces the rocPRIM call
+// the round-1 pipeline made for this step).
+//
+// Problem shape: V views x P Gaussians, one u64 key per (view, Gaussian): low `key_bits` bits = depth field (0 = culled),
+// high bits = payload that rides along (the packed tile rectangle).  Wanted per view: the visible Gaussians ordered by
+// depth field, ties by Gaussian id (= stable), as ids + rectangles, plus the visible count.  What is specific here and a
+// general device sort cannot exploit:
+//   * segments (views) are contiguous and equal-stride, so no view bits are sorted: 27 depth bits = THREE 9-bit passes
+//     (the rocPRIM path needed four 8-bit passes over 27 + 5 view bits);
+//   * the first pass drops the culled entries (40 % of the (view, Gaussian) pairs of the benchmark scene) while it
+//     scatters -- compaction costs nothing extra -- and generates the id payload instead of reading an iota array;
+//   * the last pass writes the 4-byte rectangle and the id, not the 8-byte key;
+//   * ranking inside a 2048-key chunk uses one LDS atomic per key: wave w owns a contiguous quarter of the chunk and a
+//     private digit-counter row; keys are taken 64 at a time in position order, and equal-digit lanes of one
+//     ds_add_rtn_u32 are served in lane order (probed on the device, common.hip) -- so the returned counts ARE the stable
+//     ranks.  Without that property the lanes rank themselves with one ballot per digit bit.
+//   * keys are staged in LDS at their chunk-local sorted position and leave as contiguous runs per digit (full lines),
+//     never as scattered 8-byte stores;
+//   * with >= 8 views all chunks of a view run on one XCD (block b sits on XCD b % 8): the 512 write frontiers of a view
+//     stay in that XCD's L2.
+// Per pass: count (per-chunk digit histogram) -> scan (prefix over the chunks of a view, digit bases) -> scatter.
+#include <type_traits>
+
+#include "common.hpp"
+
+namespace gr {
+namespace {
+
+constexpr int DS_T = 256;
+constexpr int DS_NW = DS_T / WAVE;
+constexpr int DS_CHUNK = 2048;
+constexpr int DS_BITS = 9;
+constexpr int DS_BINS = 1 << DS_BITS;
+constexpr int DS_STEPS = DS_CHUNK / DS_T;  // keys per thread
+
+__device__ __forceinline__ bool ds_block(int V, int nchunk, int& v, int& c) {
+  const int b = blockIdx.x;
+  if (V >= 8) {
+    const int k = b >> 3;
+    v = (b & 7) + 8 * (k / nchunk);
+    c = k % nchunk;
+    return v < V;
+  }
+  v = b / nchunk;
+  c = b % nchunk;
+  return true;
+}
+inline int ds_grid(int V, int nchunk) { return V >= 8 ? 8 * ((V + 7) / 8) * nchunk : V * nchunk; }
+
+// FIRST: the source is the raw key array (all P entries of the view, culled ones have a zero depth field)
+template <bool FIRST>
+__global__ __launch_bounds__(DS_T) void ds_count_kernel(int P, int V, int nchunk, const int32_t* __restrict__ nvalid,
+                                                        const uint64_t* __restrict__ keys, int shift, uint32_t dmask,
+                                                        uint64_t field_mask, uint16_t* __restrict__ hist) {
+  __shared__ unsigned int s_h[DS_BINS];
+  int v, c;
+  if (!ds_block(V, nchunk, v, c)) return;
+  for (int d = threadIdx.x; d < DS_BINS; d += DS_T) s_h[d] = 0u;
+  __syncthreads();
+  const int n = FIRST ? P : nvalid[v];
+  const uint64_t* src = keys + (int64_t)v * P;
+#pragma unroll
+  for (int it = 0; it < DS_STEPS; ++it) {
+    const int t = c * DS_CHUNK + it * DS_T + threadIdx.x;
+    if (t < n) {
+      const uint64_t k = src[t];
+      if (!FIRST || (k & field_mask) != 0ull) atomicAdd(&s_h[(uint32_t)(k >> shift) & dmask], 1u);
+    }
+  }
+  __syncthreads();
+  uint16_t* dst = hist + ((int64_t)v * nchunk + c) * DS_BINS;
+  for (int d = threadIdx.x; d < DS_BINS; d += DS_T) dst[d] = (uint16_t)s_h[d];  // <= DS_CHUNK
+}
+
+// per (view, digit): exclusive prefix over the chunks.  A workgroup owns 64 digits of one view; its four waves split the
+// chunk range (two sweeps over the u16 table: sums, then prefixes), lanes = adjacent digits (128-byte rows).
+__global__ __launch_bounds__(DS_T) void ds_scan_kernel(int nchunk, const uint16_t* __restrict__ hist,
+                                                       uint32_t* __restrict__ offs, int32_t* __restrict__ digit_total) {
+  __shared__ unsigned int s_part[DS_NW][WAVE];
+  const int v = blockIdx.x / (DS_BINS / WAVE), dg = blockIdx.x % (DS_BINS / WAVE);
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  const int d = dg * WAVE + lane;
+  const int per = (nchunk + DS_NW - 1) / DS_NW;
+  const int c0 = wv * per, c1 = min(nchunk, c0 + per);
+  const uint16_t* col = hist + (int64_t)v * nchunk * DS_BINS + d;
+  unsigned int sum = 0;
+  for (int c = c0; c < c1; ++c) sum += col[(int64_t)c * DS_BINS];
+  s_part[wv][lane] = sum;
+  __syncthreads();
+  unsigned int run = 0;
+  for (int w = 0; w < wv; ++w) run += s_part[w][lane];
+  uint32_t* ocol = offs + (int64_t)v * nchunk * DS_BINS + d;
+  for (int c = c0; c < c1; ++c) {
+    const unsigned int n = col[(int64_t)c * DS_BINS];
+    ocol[(int64_t)c * DS_BINS] = run;
+    run += n;
+  }
+  if (wv == DS_NW - 1) digit_total[v * DS_BINS + d] = (int32_t)run;
+}
+
+// per view: exclusive scan of the digit totals (in place) and the view's entry count
+__global__ __launch_bounds__(DS_BINS) void ds_digit_base_kernel(int32_t* __restrict__ digit_total,
+                                                                int32_t* __restrict__ nvalid_out) {
+  __shared__ int s_w[DS_BINS / WAVE];
+  const int v = blockIdx.x, d = threadIdx.x;
+  const int lane = d & (WAVE - 1), wv = d / WAVE;
+  const int n = digit_total[v * DS_BINS + d];
+  const int incl = wave_incl_scan_add_dpp(n);
+  if (lane == WAVE - 1) s_w[wv] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int i = 0; i < wv; ++i) base += s_w[i];
+  digit_total[v * DS_BINS + d] = base + incl - n;
+  if (d == DS_BINS - 1 && nvalid_out) nvalid_out[v] = base + incl;
+}
+
+// FIRST: raw source (compaction + generated ids).  LAST: writes (uint32)(key >> out_shift) instead of the key.
+template <bool FIRST, bool LAST, bool LANE_ORDERED>
+__global__ __launch_bounds__(DS_T) void ds_scatter_kernel(int P, int V, int nchunk, const int32_t* __restrict__ nvalid,
+                                                          const uint64_t* __restrict__ keys_in,
+                                                          const int32_t* __restrict__ ids_in, int shift, uint32_t dmask,
+                                                          uint64_t field_mask, const uint32_t* __restrict__ offs,
+                                                          const int32_t* __restrict__ digit_base,
+                                                          uint64_t* __restrict__ keys_out, uint32_t* __restrict__ hi_out,
+                                                          int out_shift, int32_t* __restrict__ ids_out) {
+  __shared__ unsigned int s_cnt[DS_NW][DS_BINS];  // per-wave digit counters -> per-wave bases
+  __shared__ int s_delta[DS_BINS];                // global position of a digit's run minus its chunk-local start
+  __shared__ int s_w[DS_T / WAVE];
+  __shared__ uint64_t s_key[DS_CHUNK];
+  __shared__ int32_t s_id[DS_CHUNK];
+  int v, c;
+  if (!ds_block(V, nchunk, v, c)) return;
+  const int n = FIRST ? P : nvalid[v];
+  if (c * DS_CHUNK >= n) return;
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  for (int i = threadIdx.x; i < DS_NW * DS_BINS; i += DS_T) (&s_cnt[0][0])[i] = 0u;
+  __syncthreads();
+  // ---- phase 1: wave w takes positions [w * 512, (w + 1) * 512) of the chunk, 64 at a time in order
+  const int64_t vbase = (int64_t)v * P;
+  const int wbase = c * DS_CHUNK + wv * (DS_CHUNK / DS_NW);
+  uint64_t key[DS_STEPS];
+  int32_t id[DS_STEPS];
+  int rank[DS_STEPS];  // -1: no entry
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int j = 0; j < DS_STEPS; ++j) {
+    const int t = wbase + j * WAVE + lane;
+    key[j] = 0ull;
+    id[j] = 0;
+    rank[j] = -1;
+    bool have = false;
+    if (t < n) {
+      key[j] = keys_in[vbase + t];
+      have = !FIRST || (key[j] & field_mask) != 0ull;
+      if (have) id[j] = FIRST ? t : ids_in[vbase + t];
+    }
+    const uint32_t d = (uint32_t)(key[j] >> shift) & dmask;
+    if (LANE_ORDERED) {
+      if (have) rank[j] = (int)atomicAdd(&s_cnt[wv][d], 1u);
+    } else {
+      unsigned long long peers = __ballot(have);
+      if (peers != 0ull) {
+#pragma unroll
+        for (int bit = 0; bit < DS_BITS; ++bit) {
+          const bool one = (d >> bit) & 1u;
+          const unsigned long long bal = __ballot(one);
+          peers &= one ? bal : ~bal;
+        }
+        if (have) {
+          const unsigned int base = s_cnt[wv][d];
+          rank[j] = (int)(base + (unsigned int)__popcll(peers & lt));
+          if ((peers >> lane) == 1ull) s_cnt[wv][d] = base + (unsigned int)__popcll(peers);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: chunk-local start of every digit (exclusive scan over 512 digit totals, 2 per thread), the waves'
+  //      bases inside a digit's run, and the run's global position
+  int total = 0;
+  {
+    const int d0 = 2 * threadIdx.x;
+    unsigned int cw[2][DS_NW];
+    int tot[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      tot[u] = 0;
+#pragma unroll
+      for (int w = 0; w < DS_NW; ++w) {
+        cw[u][w] = s_cnt[w][d0 + u];
+        tot[u] += (int)cw[u][w];
+      }
+    }
+    const int mine = tot[0] + tot[1];
+    const int incl = wave_incl_scan_add_dpp(mine);
+    if (lane == WAVE - 1) s_w[wv] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < wv; ++i) base += s_w[i];
+    for (int i = 0; i < DS_T / WAVE; ++i) total += s_w[i];
+    int start = base + incl - mine;
+    const uint32_t* orow = offs + ((int64_t)v * nchunk + c) * DS_BINS;
+    const int32_t* brow = digit_base + v * DS_BINS;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      s_delta[d0 + u] = (int)orow[d0 + u] + brow[d0 + u] - start;
+      unsigned int run = (unsigned int)start;
+#pragma unroll
+      for (int w = 0; w < DS_NW; ++w) {
+        s_cnt[w][d0 + u] = run;
+        run += cw[u][w];
+      }
+      start += tot[u];
+    }
+  }
+  __syncthreads();
+  // ---- phase 3: every key to its chunk-local sorted position
+#pragma unroll
+  for (int j = 0; j < DS_STEPS; ++j)
+    if (rank[j] >= 0) {
+      const uint32_t d = (uint32_t)(key[j] >> shift) & dmask;
+      const unsigned int lp = s_cnt[wv][d] + (unsigned int)rank[j];
+      s_key[lp] = key[j];
+      s_id[lp] = id[j];
+    }
+  __syncthreads();
+  // ---- phase 4: contiguous runs per digit leave as full lines
+  for (int lp = threadIdx.x; lp < total; lp += DS_T) {
+    const uint64_t k = s_key[lp];
+    const int64_t gp = vbase + s_delta[(uint32_t)(k >> shift) & dmask] + lp;
+    if (LAST) hi_out[gp] = (uint32_t)(k >> out_shift);
+    else keys_out[gp] = k;
+    ids_out[gp] = s_id[lp];
+  }
+}
+
+}  // namespace
+
+size_t depth_sort_table_bytes(int64_t P, int V) {
+  const int64_t nchunk = (P + DS_CHUNK - 1) / DS_CHUNK;
+  return align_up((size_t)V * nchunk * DS_BINS * sizeof(uint16_t), 256) +
+         align_up((size_t)V * nchunk * DS_BINS * sizeof(uint32_t), 256) + align_up((size_t)V * DS_BINS * sizeof(int32_t), 256) +
+         256;
+}
+
+// keys_a: [V*P] raw keys (destroyed); keys_b, ids_tmp: [V*P] scratch.  Out: ids_out / hi_out [V*P] (the first
+// nvalid_out[v] entries of every view's stride-P segment), nvalid_out [V] on the device.
+int depth_sort_views(uint64_t* keys_a, uint64_t* keys_b, int32_t* ids_tmp, int32_t* ids_out, uint32_t* hi_out, int out_shift,
+                     int32_t* nvalid_out, int64_t P, int V, int key_bits, void* table, size_t table_bytes,
+                     hipStream_t stream) {
+  if (P <= 0 || V <= 0) return GR_OK;
+  GR_REQUIRE(key_bits >= 1 && key_bits <= 36, "depth_sort: key_bits %d out of range", key_bits);
+  GR_REQUIRE(table && table_bytes >= depth_sort_table_bytes(P, V), "depth_sort: table too small");
+  const int nchunk = (int)((P + DS_CHUNK - 1) / DS_CHUNK);
+  Carver cv(table);
+  uint16_t* hist = cv.take<uint16_t>((size_t)V * nchunk * DS_BINS);
+  uint32_t* offs = cv.take<uint32_t>((size_t)V * nchunk * DS_BINS);
+  int32_t* dbase = cv.take<int32_t>((size_t)V * DS_BINS);
+  bool ordered = false;
+  int rc = lds_atomics_lane_ordered(stream, &ordered);
+  if (rc != GR_OK) return rc;
+  const int passes = (key_bits + DS_BITS - 1) / DS_BITS;
+  const uint64_t field_mask = (key_bits >= 64) ? ~0ull : ((1ull << key_bits) - 1ull);
+  const dim3 grid((unsigned)ds_grid(V, nchunk)), blk(DS_T);
+  // id buffers ping-pong so that the LAST pass writes ids_out
+  int32_t* idbuf[2] = {(passes % 2) ? ids_out : ids_tmp, (passes % 2) ? ids_tmp : ids_out};
+  uint64_t* kbuf[2] = {keys_a, keys_b};
+  for (int p = 0; p < passes; ++p) {
+    const int shift = p * DS_BITS;
+    const int nb = std::min(DS_BITS, key_bits - shift);
+    const uint32_t dmask = (1u << nb) - 1u;
+    const bool first = p == 0, last = p == passes - 1;
+    const uint64_t* kin = kbuf[p % 2];
+    uint64_t* kout = kbuf[(p + 1) % 2];
+    const int32_t* iin = first ? nullptr : idbuf[(p + 1) % 2];
+    int32_t* iout = idbuf[p % 2];
+    if (first)
+      hipLaunchKernelGGL(ds_count_kernel<true>, grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, kin, shift, dmask,
+                         field_mask, hist);
+    else
+      hipLaunchKernelGGL(ds_count_kernel<false>, grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, kin, shift, dmask,
+                         field_mask, hist);
+    hipLaunchKernelGGL(ds_scan_kernel, dim3((unsigned)(V * (DS_BINS / WAVE))), blk, 0, stream, nchunk, hist, offs, dbase);
+    hipLaunchKernelGGL(ds_digit_base_kernel, dim3((unsigned)V), dim3(DS_BINS), 0, stream, dbase, first ? nvalid_out : nullptr);
+#define GR_DS_SCATTER(F, L, O)                                                                                              \
+  hipLaunchKernelGGL((ds_scatter_kernel<F, L, O>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, kin, iin, shift, \
+                     dmask, field_mask, offs, dbase, kout, hi_out, out_shift, iout)
+    if (ordered) {
+      if (first && last) GR_DS_SCATTER(true, true, true);
+      else if (first) GR_DS_SCATTER(true, false, true);
+      else if (last) GR_DS_SCATTER(false, true, true);
+      else GR_DS_SCATTER(false, false, true);
+    } else {
+      if (first && last) GR_DS_SCATTER(true, true, false);
+      else if (first) GR_DS_SCATTER(true, false, false);
+      else if (last) GR_DS_SCATTER(false, true, false);
+      else GR_DS_SCATTER(false, false, false);
+    }
+#undef GR_DS_SCATTER
+    GR_LAUNCH_CHECK();
+  }
+  return GR_OK;
+}
+
+}  // namespace gr

@@ -192,8 +192,10 @@ struct Geom {
   uint32_t* seg_off;     // [V][nchunk][tiles + 1] position of segment (chunk, tile) in the point list (+ end sentinel)
   int32_t* chunk_total;  // [V][nchunk] instances per chunk, then [V][nchunk] exclusive prefix inside the view
   int32_t* chunk_max;    // [1] largest chunk total
-  void* sort_temp;
-  size_t sort_temp_bytes;
+  int32_t* ids_tmp;      // [V*P] id ping-pong buffer of the depth sort
+  void* ds_table;        // depth-sort histograms / offsets
+  size_t ds_table_bytes;
+  int32_t* nvis;         // [V] visible (depth-ordered) Gaussians per view
   int32_t* totals;       // [V] then [V] = depth-overflow flag
   DevView* views;        // [MAX_VIEWS] camera table (uniform loads)
   int32_t* scan_ws;
@@ -217,8 +219,10 @@ Geom carve_geom(void* p, int64_t P, int V, int64_t tiles) {
   g.seg_off = c.take<uint32_t>(V * nchunk * (tiles + 1));
   g.chunk_total = c.take<int32_t>(2 * V * nchunk);
   g.chunk_max = c.take<int32_t>(1);
-  g.sort_temp_bytes = sort_pairs_temp_bytes(P * V);
-  g.sort_temp = c.take<char>(g.sort_temp_bytes);
+  g.ids_tmp = c.take<int32_t>(P * V);
+  g.ds_table_bytes = depth_sort_table_bytes(P, V);
+  g.ds_table = c.take<char>(g.ds_table_bytes);
+  g.nvis = c.take<int32_t>(V);
   g.totals = c.take<int32_t>(V + 1);
   g.views = c.take<DevView>(MAX_VIEWS);
   g.scan_ws = c.take<int32_t>(V * scan_ws_ints(nchunk));
@@ -473,12 +477,6 @@ __device__ __forceinline__ bool rect_decode(uint32_t r, int id, int64_t vbase, c
   return w * h != 0;
 }
 
-__global__ __launch_bounds__(256) void unpack_rects_kernel(int64_t n, const uint64_t* __restrict__ keys,
-                                                           uint32_t* __restrict__ rects) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n) rects[t] = (uint32_t)(keys[t] >> 38);
-}
-
 // block -> (view, chunk); XCD-affine when there are at least 8 views
 __device__ __forceinline__ bool bin_block(int V, int nchunk, int& v, int& c) {
   const int b = blockIdx.x;
@@ -495,6 +493,7 @@ __device__ __forceinline__ bool bin_block(int V, int nchunk, int& v, int& c) {
 inline int bin_grid(int V, int nchunk) { return V >= 8 ? 8 * ((V + 7) / 8) * nchunk : V * nchunk; }
 
 __global__ __launch_bounds__(BIN_T) void tile_count_kernel(int P, int V, int gx, int gy, int nchunk,
+                                                           const int32_t* __restrict__ nvis,
                                                            const uint32_t* __restrict__ rects,
                                                            const int32_t* __restrict__ ids,
                                                            const float4* __restrict__ rec,
@@ -508,10 +507,11 @@ __global__ __launch_bounds__(BIN_T) void tile_count_kernel(int P, int V, int gx,
   for (int T = threadIdx.x; T < tiles; T += BIN_T) s_hist[T] = 0u;
   __syncthreads();
   const int64_t vbase = (int64_t)v * P;
+  const int nv = nvis[v];
   int mine = 0;
   for (int it = 0; it < BIN_CHUNK / BIN_T; ++it) {
     const int t = c * BIN_CHUNK + it * BIN_T + threadIdx.x;
-    if (t >= P) break;
+    if (t >= nv) break;
     const uint32_t r = rects[vbase + t];
     if (r == 0u) continue;
     int x0, y0, w, h;
@@ -578,41 +578,10 @@ __global__ __launch_bounds__(256) void seg_scan_kernel(int V, int tiles, int nch
   if (threadIdx.x == 0) dst[tiles] = (uint32_t)s_carry;
 }
 
-// Hardware property probe.  gfx950's LDS resolves the lanes of ONE ds_add_rtn_u32 that hit the same address in ascending
-// lane order (the returned pre-add values grow with the lane id).  That is not an architectural promise, so it is
-// MEASURED once per process on the device in use: 64 lanes x many address patterns (all-same, strided, hashed); if any
-// group of equal-address lanes comes back out of lane order the scatter falls back to explicit ballot ranking.
-__global__ __launch_bounds__(WAVE) void lds_atomic_order_probe_kernel(int* __restrict__ bad) {
-  __shared__ unsigned int cell[256];
-  __shared__ unsigned int got[WAVE];
-  __shared__ unsigned int adr[WAVE];
-  const int lane = threadIdx.x;
-  int nbad = 0;
-  for (int pat = 0; pat < 96; ++pat) {
-    for (int i = lane; i < 256; i += WAVE) cell[i] = 0u;
-    __syncthreads();
-    unsigned int a;
-    if (pat < 64) a = (unsigned int)(lane % (pat + 1));                  // 1 .. 64 distinct addresses, strided
-    else a = ((unsigned int)(lane * 2654435761u + pat * 40503u) >> 7) % (unsigned int)(3 + (pat - 64) * 7);  // hashed
-    const bool take = pat < 80 || ((lane * 7 + pat) % 5) != 0;           // some patterns run with lanes masked off
-    unsigned int r = 0xffffffffu;
-    if (take) r = atomicAdd(&cell[a], 1u);
-    got[lane] = r;
-    adr[lane] = a;
-    __syncthreads();
-    if (take) {
-      unsigned int want = 0;  // lanes below me on the same address that took part
-      for (int l = 0; l < lane; ++l) want += (adr[l] == a && got[l] != 0xffffffffu) ? 1u : 0u;
-      if (want != r) ++nbad;
-    }
-    __syncthreads();
-  }
-  if (nbad) atomicAdd(bad, nbad);
-}
-
 template <bool LANE_ORDERED>
 __global__ __launch_bounds__(BIN_T) void tile_scatter_kernel(int P, int V, int gx, int gy, int nchunk, int tile_bits,
-                                                             int stage_cap, const uint32_t* __restrict__ rects,
+                                                             int stage_cap, const int32_t* __restrict__ nvis,
+                                                             const uint32_t* __restrict__ rects,
                                                              const int32_t* __restrict__ ids,
                                                              const float4* __restrict__ rec,
                                                              const uint32_t* __restrict__ seg_off,
@@ -634,7 +603,7 @@ __global__ __launch_bounds__(BIN_T) void tile_scatter_kernel(int P, int V, int g
   for (int T = threadIdx.x; T < NW * tiles; T += BIN_T) s_cur[T] = 0u;
   __syncthreads();
   const int64_t vbase = (int64_t)v * P;
-  const int w_begin = c * BIN_CHUNK + wv * CW, w_end = min(P, w_begin + CW);
+  const int w_begin = c * BIN_CHUNK + wv * CW, w_end = min(nvis[v], w_begin + CW);
   // ---- phase A: this wave's tile counts
   for (int t = w_begin + lane; t < w_end; t += WAVE) {
     const uint32_t r = rects[vbase + t];
@@ -1011,45 +980,11 @@ int upload_views(const gr_raster_view* h_views, int num_views, std::vector<DevVi
 
 using namespace gr;
 
-// 1 = lane-ordered LDS atomics verified on this device, 0 = not (ballot ranking is used), -1 = not probed yet
-static int g_lds_order[64] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
-                              -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
-                              -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
-
-static int lds_atomics_lane_ordered(hipStream_t stream, bool* ordered) {
-  int dev = 0;
-  GR_HIP(hipGetDevice(&dev));
-  const char* force = getenv("GR_RASTER_BALLOT_RANKING");
-  if (force && force[0] == '1') {
-    *ordered = false;
-    return GR_OK;
-  }
-  if (dev < 0 || dev >= 64) dev = 63;
-  if (g_lds_order[dev] < 0) {
-    int* d_bad = nullptr;
-    int h_bad = 1;
-    GR_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_bad), sizeof(int), stream));
-    GR_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), stream));
-    hipLaunchKernelGGL(lds_atomic_order_probe_kernel, dim3(8), dim3(WAVE), 0, stream, d_bad);
-    GR_HIP(hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, stream));
-    GR_HIP(hipStreamSynchronize(stream));
-    GR_HIP(hipFreeAsync(d_bad, stream));
-    g_lds_order[dev] = h_bad == 0 ? 1 : 0;
-  }
-  *ordered = g_lds_order[dev] == 1;
-  return GR_OK;
-}
-
 static int64_t tiles_of(int width, int height) {
   return (int64_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
 }
 
-extern "C" int gr_raster_lds_atomics_lane_ordered(void) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return -1;
-  if (dev < 0 || dev >= 64) dev = 63;
-  return g_lds_order[dev];
-}
+extern "C" int gr_raster_lds_atomics_lane_ordered(void) { return lds_atomics_lane_ordered_state(); }
 
 extern "C" size_t gr_raster_geom_bytes(int64_t P, int num_views, int width, int height) {
   if (P < 0 || num_views < 1 || width <= 0 || height <= 0) return 0;
@@ -1113,39 +1048,36 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
   hipLaunchKernelGGL((preprocess_kernel<SH, COV, S16>), grd, blk, 0, stream, (int)P, D, M, num_views, \
                      g.views, means3D, shs, colors_precomp, opacities, scales, rotations,          \
                      cov3D_precomp, W, H, radii, g.rec, g.dkeys_a, g.totals + num_views)
-  GR_HIP(hipMemsetAsync(g.totals + num_views, 0, sizeof(int32_t), stream));  // depth-overflow flag
-  {
+  auto run_preprocess = [&]() {
     KernelTimer timer("raster_preprocess", stream);
     if (shs && cov3D_precomp) { if (sh16) GR_PRE(true, true, true); else GR_PRE(true, true, false); }
     else if (shs) { if (sh16) GR_PRE(true, false, true); else GR_PRE(true, false, false); }
     else if (cov3D_precomp) GR_PRE(false, true, false);
     else GR_PRE(false, false, false);
-  }
-#undef GR_PRE
+  };
+  GR_HIP(hipMemsetAsync(g.totals + num_views, 0, sizeof(int32_t), stream));  // depth-overflow flag
+  run_preprocess();
   GR_LAUNCH_CHECK();
-  int vbits = 0;
-  while ((1 << vbits) < num_views) ++vbits;
   static_assert((1 << KEY_VIEW_BITS) >= MAX_VIEWS && KEY_DEPTH_BITS + KEY_VIEW_BITS <= 38, "view id must fit its key field");
   std::vector<int32_t> tot(num_views + 1);
   const int nchunk = (int)((P + BIN_CHUNK - 1) / BIN_CHUNK);
   int32_t h_chunk_max = 0;
-  auto sort_and_count = [&](int end_bit) -> int {
+  auto sort_and_count = [&](int key_bits) -> int {
     {
       KernelTimer timer("raster_depth_sort", stream);
-      int rcs = sort_pairs_u64_iota(g.sort_temp, g.sort_temp_bytes, g.dkeys_a, g.dkeys_b, P, g.order_b,
-                                    P * num_views, 0, end_bit, stream);
+      // visible Gaussians of every view in depth order (ties: Gaussian id): ids -> order_b, rectangles -> rects
+      int rcs = depth_sort_views(g.dkeys_a, g.dkeys_b, g.ids_tmp, g.order_b, g.rects, 38, g.nvis, P, num_views, key_bits,
+                                 g.ds_table, g.ds_table_bytes, stream);
       if (rcs != GR_OK) return rcs;
     }
     {
       KernelTimer timer("raster_bin", stream);
-      hipLaunchKernelGGL(unpack_rects_kernel, dim3((unsigned)((P * num_views + 255) / 256)), blk, 0, stream,
-                         P * num_views, g.dkeys_b, g.rects);
       if (tiles * sizeof(unsigned int) > 64 * 1024)
         GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tile_count_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       hipLaunchKernelGGL(tile_count_kernel, dim3((unsigned)bin_grid(num_views, nchunk)), dim3(BIN_T),
-                         tiles * sizeof(unsigned int), stream, (int)P, num_views, gx, gy, nchunk, g.rects, g.order_b, g.rec,
-                         g.chunk_cnt, g.chunk_total);
+                         tiles * sizeof(unsigned int), stream, (int)P, num_views, gx, gy, nchunk, g.nvis, g.rects, g.order_b,
+                         g.rec, g.chunk_cnt, g.chunk_total);
       hipLaunchKernelGGL(chunk_max_kernel, dim3(1), dim3(1024), 0, stream, num_views * nchunk, g.chunk_total, g.chunk_max);
       GR_LAUNCH_CHECK();
       // chunk bases inside each view (+ the per-view totals R_v), then every chunk's per-tile segment starts
@@ -1161,15 +1093,17 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
     GR_HIP(hipStreamSynchronize(stream));
     return GR_OK;
   };
-  rc = sort_and_count(KEY_DEPTH_BITS + vbits);
+  rc = sort_and_count(KEY_DEPTH_BITS);
   if (rc != GR_OK) return rc;
   if (tot[num_views] != 0) {  // some depth >= 8192: redo the ordering with full-width keys
+    run_preprocess();         // the sort consumed the key array: regenerate it (deterministic), then widen the depth field
     hipLaunchKernelGGL(full_keys_kernel, dim3((unsigned)((P * num_views + 255) / 256)), blk, 0, stream, P * num_views,
                        (int)P, g.rec, radii, g.dkeys_a);
     GR_LAUNCH_CHECK();
-    rc = sort_and_count(32 + vbits);
+    rc = sort_and_count(32);
     if (rc != GR_OK) return rc;
   }
+#undef GR_PRE
   for (int v = 0; v < num_views; ++v) h_num_rendered[v] = tot[v];
   h_num_rendered[num_views] = h_chunk_max;  // sizes the scatter's LDS staging block in gr_raster_render
   return GR_OK;
@@ -1216,7 +1150,7 @@ extern "C" int gr_raster_render(int64_t P, const gr_raster_view* h_views, int nu
       GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     KernelTimer timer("raster_bin", stream);
     hipLaunchKernelGGL(kern, dim3((unsigned)bin_grid(num_views, nchunk)), dim3(BIN_T), lds, stream, (int)P, num_views, gx, gy,
-                       nchunk, tile_bits, stage_cap, g.rects, g.order_b, g.rec, g.seg_off, b.point_list);
+                       nchunk, tile_bits, stage_cap, g.nvis, g.rects, g.order_b, g.rec, g.seg_off, b.point_list);
     GR_LAUNCH_CHECK();
   }
   KernelTimer timer("raster_blend", stream);
