@@ -72,15 +72,17 @@ __global__ __launch_bounds__(DS_T) void ds_count_kernel(int P, int V, int nchunk
   for (int d = threadIdx.x; d < DS_BINS; d += DS_T) dst[d] = (uint16_t)s_h[d];  // <= DS_CHUNK
 }
 
-// per (view, digit): exclusive prefix over the chunks.  A workgroup owns 64 digits of one view; its four waves split the
+// per (view, digit): exclusive prefix over the chunks.  A workgroup owns 64 digits of one view; its sixteen waves split the
 // chunk range (two sweeps over the u16 table: sums, then prefixes), lanes = adjacent digits (128-byte rows).
-__global__ __launch_bounds__(DS_T) void ds_scan_kernel(int nchunk, const uint16_t* __restrict__ hist,
-                                                       uint32_t* __restrict__ offs, int32_t* __restrict__ digit_total) {
-  __shared__ unsigned int s_part[DS_NW][WAVE];
+constexpr int DS_SCAN_NW = 16;  // waves per scan workgroup
+__global__ __launch_bounds__(DS_SCAN_NW* WAVE) void ds_scan_kernel(int nchunk, const uint16_t* __restrict__ hist,
+                                                                   uint32_t* __restrict__ offs,
+                                                                   int32_t* __restrict__ digit_total) {
+  __shared__ unsigned int s_part[DS_SCAN_NW][WAVE];
   const int v = blockIdx.x / (DS_BINS / WAVE), dg = blockIdx.x % (DS_BINS / WAVE);
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   const int d = dg * WAVE + lane;
-  const int per = (nchunk + DS_NW - 1) / DS_NW;
+  const int per = (nchunk + DS_SCAN_NW - 1) / DS_SCAN_NW;
   const int c0 = wv * per, c1 = min(nchunk, c0 + per);
   const uint16_t* col = hist + (int64_t)v * nchunk * DS_BINS + d;
   unsigned int sum = 0;
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(DS_T) void ds_scan_kernel(int nchunk, const uint16_
     ocol[(int64_t)c * DS_BINS] = run;
     run += n;
   }
-  if (wv == DS_NW - 1) digit_total[v * DS_BINS + d] = (int32_t)run;
+  if (wv == DS_SCAN_NW - 1) digit_total[v * DS_BINS + d] = (int32_t)run;
 }
 
 // per view: exclusive scan of the digit totals (in place) and the view's entry count
@@ -283,7 +285,8 @@ int depth_sort_views(uint64_t* keys_a, uint64_t* keys_b, int32_t* ids_tmp, int32
     else
       hipLaunchKernelGGL(ds_count_kernel<false>, grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, kin, shift, dmask,
                          field_mask, hist);
-    hipLaunchKernelGGL(ds_scan_kernel, dim3((unsigned)(V * (DS_BINS / WAVE))), blk, 0, stream, nchunk, hist, offs, dbase);
+    hipLaunchKernelGGL(ds_scan_kernel, dim3((unsigned)(V * (DS_BINS / WAVE))), dim3(DS_SCAN_NW * WAVE), 0, stream, nchunk, hist,
+                       offs, dbase);
     hipLaunchKernelGGL(ds_digit_base_kernel, dim3((unsigned)V), dim3(DS_BINS), 0, stream, dbase, first ? nvalid_out : nullptr);
 #define GR_DS_SCATTER(F, L, O)                                                                                              \
   hipLaunchKernelGGL((ds_scatter_kernel<F, L, O>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, kin, iin, shift, \

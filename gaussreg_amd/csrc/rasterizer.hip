@@ -743,6 +743,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int CELL = 4;
 constexpr int NCELL = (TILE / CELL) * (TILE / CELL);  // 16
 
+// development statistics (GR_BLEND_STATS=1): [0] tiles, [1] batches, [2] entries loaded, [3] cell-list entries,
+// [4] wave blend steps (two entries each), [5] entries a pixel actually blended
+__device__ unsigned long long g_blend_stats[8];
+
+template <bool STATS>
 __global__ __launch_bounds__(BLOCK) void blend_kernel(
     int P, int W, int H, int nchunk, const DevView* __restrict__ views, const uint32_t* __restrict__ seg_off,
     const int32_t* __restrict__ point_list, const float4* __restrict__ rec, float* __restrict__ out_color) {
@@ -773,6 +778,7 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
   // lane = chunk, two 4-byte loads give segment start and end); the batches of 256 entries are cut out of that window.
   int c_next = 0, w_pos = 0, w_total = 0;  // block-uniform
   const uint32_t* seg_col = seg_off + (int64_t)v * nchunk * (tiles + 1) + tile;
+  if (STATS && tid == 0) atomicAdd(&g_blend_stats[0], 1ull);
   while (true) {
     if (__syncthreads_and(done)) break;
     bool exhausted = false;
@@ -800,6 +806,10 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
     if (exhausted) break;
     // ---- load + cutoffs + cell mask
     const int e = w_pos + tid;
+    if (STATS && tid == 0) {
+      atomicAdd(&g_blend_stats[1], 1ull);
+      atomicAdd(&g_blend_stats[2], (unsigned long long)min(BLOCK, w_total - w_pos));
+    }
     w_pos += BLOCK;
     unsigned mask = 0;
     if (e < w_total) {
@@ -865,6 +875,11 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
     __syncthreads();
     // ---- blend: each 16-lane group walks its own list
     const int n_cell = done ? 0 : s_cnt[cell][BLOCK / WAVE];
+    if (STATS) {
+      if (pin == 0) atomicAdd(&g_blend_stats[3], (unsigned long long)s_cnt[cell][BLOCK / WAVE]);
+      const int mx = wave_max_i32_dpp(n_cell);
+      if (lane == 0) atomicAdd(&g_blend_stats[4], (unsigned long long)((mx + 1) / 2));
+    }
     // Two list entries per step: everything up to alpha is evaluated for both at once with packed fp32 math
     // (v_pk_fma/mul/add_f32 -- the same IEEE operations as the scalar sequence of the oracle, two per lane-slot);
     // only the order-dependent tail (transmittance test, colour accumulation) runs entry by entry.
@@ -893,6 +908,7 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
       const float alpha0 = fminf(0.99f, al.x), alpha1 = fminf(0.99f, al.y);
       const bool ok0 = !(power.x > 0.0f) && !(power.x < a0.z) && !(alpha0 < 1.0f / 255.0f);
       const bool ok1 = have1 && !(power.y > 0.0f) && !(power.y < a1.z) && !(alpha1 < 1.0f / 255.0f);
+      if (STATS) atomicAdd(&g_blend_stats[5], (unsigned long long)((ok0 ? 1 : 0) + (ok1 ? 1 : 0)));
       if (ok0) {
         const float test_T = T * (1.0f - alpha0);
         if (test_T < 0.0001f) {
@@ -982,6 +998,14 @@ using namespace gr;
 
 static int64_t tiles_of(int width, int height) {
   return (int64_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+}
+
+extern "C" int gr_debug_blend_stats(unsigned long long* out8) {
+  GR_HIP(hipDeviceSynchronize());
+  GR_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_blend_stats), sizeof(unsigned long long) * 8));
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  GR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_blend_stats), z, sizeof(z)));
+  return GR_OK;
 }
 
 extern "C" int gr_raster_lds_atomics_lane_ordered(void) { return lds_atomics_lane_ordered_state(); }
@@ -1154,8 +1178,13 @@ extern "C" int gr_raster_render(int64_t P, const gr_raster_view* h_views, int nu
     GR_LAUNCH_CHECK();
   }
   KernelTimer timer("raster_blend", stream);
-  hipLaunchKernelGGL(blend_kernel, dim3(gx, gy, num_views), dim3(BLOCK), 0, stream, (int)P, W, H, R > 0 ? nchunk : 0, g.views,
-                     g.seg_off, point_list, g.rec, out_color);
+  static const bool stats = getenv("GR_BLEND_STATS") && getenv("GR_BLEND_STATS")[0] == '1';
+  if (stats)
+    hipLaunchKernelGGL(blend_kernel<true>, dim3(gx, gy, num_views), dim3(BLOCK), 0, stream, (int)P, W, H, R > 0 ? nchunk : 0,
+                       g.views, g.seg_off, point_list, g.rec, out_color);
+  else
+    hipLaunchKernelGGL(blend_kernel<false>, dim3(gx, gy, num_views), dim3(BLOCK), 0, stream, (int)P, W, H, R > 0 ? nchunk : 0,
+                       g.views, g.seg_off, point_list, g.rec, out_color);
   GR_LAUNCH_CHECK();
   return GR_OK;
 }
