@@ -350,6 +350,47 @@ extern "C" int gr_kpconv_forward(const float* s_feats, const float* q_points, co
   return GR_OK;
 }
 
+namespace gr {
+namespace {
+// out[i, :] = data[index[i], :] for i < m (index_select along dim 0 of a 2-D fp32 tensor); rows move as float4 when the
+// row length allows, one 16-lane group per row so a wave reads four 64-byte-aligned row pieces per instruction
+template <typename VEC>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const VEC* __restrict__ data, int64_t n, int cv,
+                                                          const int64_t* __restrict__ index, int64_t m,
+                                                          VEC* __restrict__ out, int* __restrict__ bad) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = t / cv;
+  if (row >= m) return;
+  const int col = (int)(t - row * cv);
+  const int64_t src = index[row];
+  if (src < 0 || src >= n) {
+    if (col == 0) atomicOr(bad, 1);
+    return;
+  }
+  out[row * cv + col] = data[src * cv + col];
+}
+}  // namespace
+}  // namespace gr
+
+extern "C" int gr_gather_rows(const float* data, int64_t n, int64_t c, const int64_t* index, int64_t m, float* out,
+                              int* d_error_flag, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GR_REQUIRE(n >= 0 && c >= 1 && m >= 0 && c < (1 << 24), "bad arguments");
+  if (m == 0) return GR_OK;
+  GR_REQUIRE(data && index && out && d_error_flag, "null argument");
+  const bool v4 = (c % 4 == 0) && (reinterpret_cast<uintptr_t>(data) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+  if (v4) {
+    const int cv = (int)(c / 4);
+    hipLaunchKernelGGL(gr::gather_rows_kernel<float4>, dim3((unsigned)((m * cv + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const float4*>(data), n, cv, index, m, reinterpret_cast<float4*>(out), d_error_flag);
+  } else {
+    hipLaunchKernelGGL(gr::gather_rows_kernel<float>, dim3((unsigned)((m * c + 255) / 256)), dim3(256), 0, stream, data, n,
+                       (int)c, index, m, out, d_error_flag);
+  }
+  GR_LAUNCH_CHECK();
+  return GR_OK;
+}
+
 extern "C" int gr_neighbor_pool(const float* x, int64_t n, int64_t c, const int64_t* neighbor_indices, int64_t m,
                                 int64_t h, int mode, float* out, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);

@@ -39,17 +39,96 @@ def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, 
             'subsampling': subsampling_list, 'upsampling': upsampling_list}
 
 
-def registration_collate_fn_stack_mode(data_dicts, num_stages, voxel_size, search_radius, neighbor_limits,
-                                       precompute_data=True, device=None):
-    """data.py:139-189 for the registration case: [ref_1..ref_B, src_1..src_B] stacking."""
+def _merge(data_dicts):
     import numpy as np
-    batch_size = len(data_dicts)
     collated = {}
     for d in data_dicts:
         for k, v in d.items():
             if isinstance(v, np.ndarray):
                 v = torch.from_numpy(v)
             collated.setdefault(k, []).append(v)
+    return collated
+
+
+def single_collate_fn_stack_mode(data_dicts, num_stages, voxel_size, search_radius, neighbor_limits, precompute_data=True,
+                                 device=None):
+    """data.py:80-137: one cloud per sample, [P_1 .. P_B] stacking.  `device`: where the pyramid is built and kept."""
+    batch_size = len(data_dicts)
+    collated = _merge(data_dicts)
+    normals = torch.cat(collated.pop('normals'), dim=0) if 'normals' in collated else None
+    feats = torch.cat(collated.pop('feats'), dim=0)
+    points_list = collated.pop('points')
+    lengths = torch.LongTensor([p.shape[0] for p in points_list])
+    points = torch.cat(points_list, dim=0)
+    if device is not None:
+        points, feats = points.to(device), feats.to(device)
+        normals = None if normals is None else normals.to(device)
+    if batch_size == 1:
+        for k, v in collated.items():
+            collated[k] = v[0]
+    if normals is not None:
+        collated['normals'] = normals
+    collated['features'] = feats
+    if precompute_data:
+        collated.update(precompute_data_stack_mode(points, lengths, num_stages, voxel_size, search_radius, neighbor_limits))
+    else:
+        collated['points'] = points
+        collated['lengths'] = lengths
+    collated['batch_size'] = batch_size
+    return collated
+
+
+def calibrate_neighbors_stack_mode(dataset, collate_fn, num_stages, voxel_size, search_radius, keep_ratio=0.8,
+                                   sample_threshold=2000):
+    """data.py:192-217: per-stage neighbour limits = the `keep_ratio` quantile of the neighbourhood sizes over (up to) one
+    pass of the dataset.  The counting (`neighbors < neighbors.shape[0]`, exactly the reference's test, :207) and the
+    histogram run on the device the collate function left the tensors on; only the (num_stages, hist_n) table is
+    accumulated on the host."""
+    import numpy as np
+    hist_n = int(np.ceil(4 / 3 * np.pi * (search_radius / voxel_size + 1) ** 3))
+    neighbor_hists = np.zeros((num_stages, hist_n), dtype=np.int32)
+    max_neighbor_limits = [hist_n] * num_stages
+    for i in range(len(dataset)):
+        data_dict = collate_fn([dataset[i]], num_stages, voxel_size, search_radius, max_neighbor_limits, precompute_data=True)
+        hists = []
+        for neighbors in data_dict['neighbors']:
+            counts = (neighbors < neighbors.shape[0]).sum(dim=1)
+            hists.append(torch.bincount(counts, minlength=hist_n)[:hist_n].cpu().numpy())
+        neighbor_hists += np.vstack(hists).astype(np.int32)
+        if np.min(np.sum(neighbor_hists, axis=1)) > sample_threshold:
+            break
+    cum_sum = np.cumsum(neighbor_hists.T, axis=0)
+    return np.sum(cum_sum < (keep_ratio * cum_sum[hist_n - 1, :]), axis=0)
+
+
+def _reset_seed_worker_init_fn(worker_id):
+    import random
+
+    import numpy as np
+    seed = torch.initial_seed() % (2 ** 32)  # utils/torch.py:39-44
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+def build_dataloader_stack_mode(dataset, collate_fn, num_stages, voxel_size, search_radius, neighbor_limits, batch_size=1,
+                                num_workers=1, shuffle=False, drop_last=False, distributed=False, precompute_data=True):
+    """data.py:219-249 (+ utils/torch.py:47-77).  With the pyramid built by HIP kernels the collate function needs the
+    GPU: DataLoader workers are separate processes, so pass num_workers=0 (collate on the main process, tensors stay on
+    the device) unless the collate function is given precompute_data=False."""
+    from functools import partial
+    sampler = torch.utils.data.DistributedSampler(dataset) if distributed else None
+    return torch.utils.data.DataLoader(
+        dataset, batch_size=batch_size, num_workers=num_workers, shuffle=False if distributed else shuffle, sampler=sampler,
+        collate_fn=partial(collate_fn, num_stages=num_stages, voxel_size=voxel_size, search_radius=search_radius,
+                           neighbor_limits=neighbor_limits, precompute_data=precompute_data),
+        worker_init_fn=_reset_seed_worker_init_fn, pin_memory=False, drop_last=drop_last)
+
+
+def registration_collate_fn_stack_mode(data_dicts, num_stages, voxel_size, search_radius, neighbor_limits,
+                                       precompute_data=True, device=None):
+    """data.py:139-189 for the registration case: [ref_1..ref_B, src_1..src_B] stacking."""
+    batch_size = len(data_dicts)
+    collated = _merge(data_dicts)
     feats = torch.cat(collated.pop('ref_feats') + collated.pop('src_feats'), dim=0)
     points_list = collated.pop('ref_points') + collated.pop('src_points')
     lengths = torch.LongTensor([p.shape[0] for p in points_list])

@@ -1,0 +1,140 @@
+"""Mirror of geotransformer/modules/kpconv/modules.py (inference): the blocks KPConvFPN is assembled from
+(backbone.py:95-162), with the HIP KPConv / maxpool / nearest_upsample inside.  Sub-module names and parameter shapes
+follow the reference so its checkpoints load key for key (`KPConv.weights`, `norm.norm.weight`, `mlp.weight`, ...).
+The dense pieces (nn.Linear, nn.GroupNorm, LeakyReLU) are stock PyTorch-ROCm layers, as in the reference."""
+import torch
+import torch.nn as nn
+
+from .kpconv import KPConv, maxpool, nearest_upsample
+
+
+class GroupNorm(nn.Module):
+    """modules.py:32-50: GroupNorm over the channel axis of a (N, C) point-feature matrix."""
+
+    def __init__(self, num_groups, num_channels):
+        super().__init__()
+        self.num_groups, self.num_channels = num_groups, num_channels
+        self.norm = nn.GroupNorm(num_groups, num_channels)
+
+    def forward(self, x):
+        y = self.norm(x.t().unsqueeze(0))     # (N, C) -> (1, C, N): statistics per group over all points
+        return y.squeeze(0).t().squeeze()     # the trailing squeeze() is the reference's (modules.py:50)
+
+
+def _norm(out_channels, group_norm, layer_norm):
+    return nn.LayerNorm(out_channels) if layer_norm else GroupNorm(group_norm, out_channels)
+
+
+class UnaryBlock(nn.Module):
+    """modules.py:53-83: Linear -> norm -> (LeakyReLU 0.1)."""
+
+    def __init__(self, in_channels, out_channels, group_norm, has_relu=True, bias=True, layer_norm=False):
+        super().__init__()
+        self.in_channels, self.out_channels, self.group_norm = in_channels, out_channels, group_norm
+        self.mlp = nn.Linear(in_channels, out_channels, bias=bias)
+        self.norm = _norm(out_channels, group_norm, layer_norm)
+        self.leaky_relu = nn.LeakyReLU(0.1) if has_relu else None
+
+    def forward(self, x):
+        x = self.norm(self.mlp(x))
+        return x if self.leaky_relu is None else self.leaky_relu(x)
+
+
+class LastUnaryBlock(nn.Module):
+    """modules.py:86-101: a bare Linear."""
+
+    def __init__(self, in_channels, out_channels, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.mlp = nn.Linear(in_channels, out_channels, bias=bias)
+
+    def forward(self, x):
+        return self.mlp(x)
+
+
+class ConvBlock(nn.Module):
+    """modules.py:104-145: KPConv -> norm -> LeakyReLU."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, radius, sigma, group_norm, negative_slope=0.1, bias=True,
+                 layer_norm=False):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.KPConv = KPConv(in_channels, out_channels, kernel_size, radius, sigma, bias=bias)
+        self.norm = _norm(out_channels, group_norm, layer_norm)
+        self.leaky_relu = nn.LeakyReLU(negative_slope=negative_slope)
+
+    def forward(self, s_feats, q_points, s_points, neighbor_indices):
+        return self.leaky_relu(self.norm(self.KPConv(s_feats, q_points, s_points, neighbor_indices)))
+
+
+class ResidualBlock(nn.Module):
+    """modules.py:148-225: bottleneck -- unary1 (C_in -> C_out/4), KPConv on C_out/4 channels, unary2 (-> C_out), plus a
+    shortcut that is max-pooled over the neighbourhood when the block is strided."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, radius, sigma, group_norm, strided=False, bias=True,
+                 layer_norm=False):
+        super().__init__()
+        self.in_channels, self.out_channels, self.strided = in_channels, out_channels, strided
+        mid = out_channels // 4
+        self.unary1 = (UnaryBlock(in_channels, mid, group_norm, bias=bias, layer_norm=layer_norm)
+                       if in_channels != mid else nn.Identity())
+        self.KPConv = KPConv(mid, mid, kernel_size, radius, sigma, bias=bias)
+        self.norm_conv = _norm(mid, group_norm, layer_norm)
+        self.unary2 = UnaryBlock(mid, out_channels, group_norm, has_relu=False, bias=bias, layer_norm=layer_norm)
+        self.unary_shortcut = (UnaryBlock(in_channels, out_channels, group_norm, has_relu=False, bias=bias,
+                                          layer_norm=layer_norm) if in_channels != out_channels else nn.Identity())
+        self.leaky_relu = nn.LeakyReLU(0.1)
+
+    def forward(self, s_feats, q_points, s_points, neighbor_indices):
+        x = self.KPConv(self.unary1(s_feats), q_points, s_points, neighbor_indices)
+        x = self.unary2(self.leaky_relu(self.norm_conv(x)))
+        shortcut = maxpool(s_feats, neighbor_indices) if self.strided else s_feats
+        return self.leaky_relu(x + self.unary_shortcut(shortcut))
+
+
+class KPConvFPN(nn.Module):
+    """experiments/geotransformer.gaussian_splatting.indoor/backbone.py:95-212: 5-stage encoder, 3-stage decoder."""
+
+    def __init__(self, input_dim, output_dim, init_dim, kernel_size, init_radius, init_sigma, group_norm):
+        super().__init__()
+        C, K, r, s, g = init_dim, kernel_size, init_radius, init_sigma, group_norm
+        self.encoder1_1 = ConvBlock(input_dim, C, K, r, s, g)
+        self.encoder1_2 = ResidualBlock(C, C * 2, K, r, s, g)
+        self.encoder2_1 = ResidualBlock(C * 2, C * 2, K, r, s, g, strided=True)
+        self.encoder2_2 = ResidualBlock(C * 2, C * 4, K, r * 2, s * 2, g)
+        self.encoder2_3 = ResidualBlock(C * 4, C * 4, K, r * 2, s * 2, g)
+        self.encoder3_1 = ResidualBlock(C * 4, C * 4, K, r * 2, s * 2, g, strided=True)
+        self.encoder3_2 = ResidualBlock(C * 4, C * 8, K, r * 4, s * 4, g)
+        self.encoder3_3 = ResidualBlock(C * 8, C * 8, K, r * 4, s * 4, g)
+        self.encoder4_1 = ResidualBlock(C * 8, C * 8, K, r * 4, s * 4, g, strided=True)
+        self.encoder4_2 = ResidualBlock(C * 8, C * 16, K, r * 8, s * 8, g)
+        self.encoder4_3 = ResidualBlock(C * 16, C * 16, K, r * 8, s * 8, g)
+        self.encoder5_1 = ResidualBlock(C * 16, C * 16, K, r * 8, s * 8, g, strided=True)
+        self.encoder5_2 = ResidualBlock(C * 16, C * 32, K, r * 16, s * 16, g)
+        self.encoder5_3 = ResidualBlock(C * 32, C * 32, K, r * 16, s * 16, g)
+        self.decoder4 = UnaryBlock(C * 48, C * 16, g)
+        self.decoder3 = UnaryBlock(C * 24, C * 8, g)
+        self.decoder2 = LastUnaryBlock(C * 12, output_dim)
+
+    @torch.no_grad()
+    def forward(self, feats, data_dict):
+        pts, nb, sub, up = data_dict['points'], data_dict['neighbors'], data_dict['subsampling'], data_dict['upsampling']
+        feats_list = []
+        f1 = self.encoder1_2(self.encoder1_1(feats, pts[0], pts[0], nb[0]), pts[0], pts[0], nb[0])
+        f2 = self.encoder2_1(f1, pts[1], pts[0], sub[0])
+        f2 = self.encoder2_3(self.encoder2_2(f2, pts[1], pts[1], nb[1]), pts[1], pts[1], nb[1])
+        f3 = self.encoder3_1(f2, pts[2], pts[1], sub[1])
+        f3 = self.encoder3_3(self.encoder3_2(f3, pts[2], pts[2], nb[2]), pts[2], pts[2], nb[2])
+        f4 = self.encoder4_1(f3, pts[3], pts[2], sub[2])
+        f4 = self.encoder4_3(self.encoder4_2(f4, pts[3], pts[3], nb[3]), pts[3], pts[3], nb[3])
+        f5 = self.encoder5_1(f4, pts[4], pts[3], sub[3])
+        f5 = self.encoder5_3(self.encoder5_2(f5, pts[4], pts[4], nb[4]), pts[4], pts[4], nb[4])
+        feats_list.append(f5)
+        l4 = self.decoder4(torch.cat([nearest_upsample(f5, up[3]), f4], dim=1))
+        feats_list.append(l4)
+        l3 = self.decoder3(torch.cat([nearest_upsample(l4, up[2]), f3], dim=1))
+        feats_list.append(l3)
+        l2 = self.decoder2(torch.cat([nearest_upsample(l3, up[1]), f2], dim=1))
+        feats_list.append(l2)
+        feats_list.reverse()
+        return feats_list

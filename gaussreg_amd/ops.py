@@ -94,3 +94,69 @@ def point_to_node_partition(points, nodes, point_limit, return_count=False):
     if out_device.type != "cuda":
         res = [r.to(out_device) for r in res]
     return tuple(res)
+
+
+_gather_flags = {}
+
+
+def index_select(data, index, dim):
+    """Advanced index select (modules/ops/index_select.py:4-31): `index` may have any shape; the `dim`-th dimension of
+    `data` is replaced by index.shape.  The case the backbone runs (dim 0 of a 2-D fp32 feature / point tensor:
+    kpconv.py:93-105, functional.py:17,63) is a HIP row gather; other dims / dtypes are reshaped onto it or, for
+    non-float data, use torch's own gather on the device."""
+    if not isinstance(index, torch.Tensor) or index.dtype != torch.int64:
+        raise RuntimeError("index must be a LongTensor")
+    nd = data.dim()
+    dim = dim + nd if dim < 0 else dim
+    if not (0 <= dim < nd):
+        raise IndexError("dim out of range")
+    if data.dtype != torch.float32:
+        out = data.index_select(dim, index.reshape(-1))
+    else:
+        dev = _lib.require_gpu()
+        out_device = data.device
+        d = data if data.is_cuda else data.to(dev)
+        dev = d.device
+        # bring `dim` to the front and flatten the rest: (a_dim, rest)
+        moved = d.movedim(dim, 0).contiguous()
+        n = moved.shape[0]
+        rest = moved.shape[1:]
+        c = 1
+        for r in rest:
+            c *= int(r)
+        flat = moved.reshape(n, max(c, 1))
+        idx = index.to(dev).reshape(-1).contiguous()
+        m = idx.shape[0]
+        res = torch.empty((m, max(c, 1)), dtype=torch.float32, device=dev)
+        key = (dev.type, dev.index)
+        flag = _gather_flags.get(key)
+        if flag is None:
+            flag = torch.zeros(1, dtype=torch.int32, device=dev)
+            _gather_flags[key] = flag
+        if m > 0 and c > 0:
+            L = _lib.lib()
+            with torch.cuda.device(dev):
+                _lib.check(L.gr_gather_rows(_lib.ptr(flat), n, max(c, 1), _lib.ptr(idx), m, _lib.ptr(res), _lib.ptr(flag),
+                                            _lib.stream_ptr(dev)))
+            if m <= 65536 and int(flag.item()) != 0:  # small gathers are checked eagerly like torch; large ones lazily
+                flag.zero_()
+                raise IndexError("index out of range in index_select")
+        out = res.reshape((m,) + tuple(rest)).movedim(0, dim)
+        if out_device.type != "cuda":
+            out = out.to(out_device)
+        out = out.contiguous()
+    if index.dim() > 1:
+        out = out.view(*(tuple(data.shape[:dim]) + tuple(index.shape) + tuple(data.shape[dim:][1:])))
+    return out
+
+
+def gather_error_pending(device=None):
+    """True if a large index_select on `device` met an out-of-range index since the last check (torch raises eagerly;
+    the HIP gather records it on the device instead of synchronising every call)."""
+    dev = _lib.require_gpu() if device is None else torch.device(device)
+    flag = _gather_flags.get((dev.type, dev.index))
+    if flag is None:
+        return False
+    bad = int(flag.item()) != 0
+    flag.zero_()
+    return bad

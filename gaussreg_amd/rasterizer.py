@@ -73,6 +73,8 @@ def _dev_f32(t: Optional[torch.Tensor], dev, name):
         return None
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a tensor")
+    if t.device == dev and t.dtype == torch.float32 and t.is_contiguous():
+        return t  # only its pointer is read
     return t.detach().to(device=dev, dtype=torch.float32).contiguous()
 
 
@@ -130,8 +132,9 @@ def rasterize_views(settings, means3D, opacities, shs=None,
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
-    color, radii, _ = rasterize_views([raster_settings], means3D, opacities, sh, colors_precomp, scales, rotations,
-                                      cov3Ds_precomp)
+    """`raster_settings`: GaussianRasterizationSettings, or a one-camera ViewBatch built from it (marshalled once)."""
+    vb = raster_settings if isinstance(raster_settings, ViewBatch) else [raster_settings]
+    color, radii, _ = rasterize_views(vb, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp)
     return color[0], radii[0]
 
 
@@ -139,6 +142,13 @@ class GaussianRasterizer(torch.nn.Module):
     def __init__(self, raster_settings: GaussianRasterizationSettings):
         super().__init__()
         self.raster_settings = raster_settings
+        self._view_batch = None  # (settings object it was built from, ViewBatch): the C camera struct is built once
+
+    def _views(self):
+        rs = self.raster_settings
+        if self._view_batch is None or self._view_batch[0] is not rs:
+            self._view_batch = (rs, ViewBatch([rs]))
+        return self._view_batch[1]
 
     def markVisible(self, positions):
         with torch.no_grad():
@@ -163,4 +173,4 @@ class GaussianRasterizer(torch.nn.Module):
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3D_precomp, rs)
+                                   cov3D_precomp, self._views())

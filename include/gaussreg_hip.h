@@ -197,6 +197,11 @@ int gr_kpconv_forward(const float* s_feats, const float* q_points, const float* 
                       const int64_t* neighbor_indices, int64_t n, int64_t m, int64_t h, int64_t cin, int64_t cout,
                       const float* kernel_points, int64_t k, const float* weights, const float* bias, float sigma,
                       float inf, float* out, void* ws, size_t ws_bytes, void* stream);
+/* gr_gather_rows: geotransformer/modules/ops/index_select.py:4-31 for the case the backbone uses (dim 0 of a 2-D fp32
+ * tensor, any index shape flattened to m entries): out (m, c) = data[index].  *d_error_flag (device int, caller zeroes
+ * it) is set if an index is outside [0, n) -- torch raises there; the wrapper checks the flag lazily. */
+int gr_gather_rows(const float* data, int64_t n, int64_t c, const int64_t* index, int64_t m, float* out,
+                   int* d_error_flag, void* stream);
 int gr_neighbor_pool(const float* x, int64_t n, int64_t c, const int64_t* neighbor_indices, int64_t m, int64_t h,
                      int mode, float* out, void* stream);
 /* gr_gs_fuse ("next" row): gs_fusion.py:231-262 gaussian_fuse on the GS .ply wire format.
