@@ -78,3 +78,17 @@ def oracle_render(g, cam, *, sh_degree=3, bg=(0.0, 0.0, 0.0), scale_modifier=1.0
     else:
         kw["cov3D_precomp"] = cov3D_precomp
     return capi.rasterize_forward(g["means3D"], g["opacities"], **kw)
+
+
+def assert_rel_scale(got, want, rel=1e-5, what="", mask=None):
+    """The north_star float bar: max |got - want| <= rel * max |want| (error relative to the tensor's scale; an
+    elementwise rtol is meaningless for entries that cancel to ~0)."""
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    if mask is not None:
+        got, want = got[mask], want[mask]
+    scale = float(np.abs(want).max()) if want.size else 0.0
+    err = float(np.abs(got - want).max()) if want.size else 0.0
+    assert err <= rel * scale + 1e-30, f"{what}: max |got - want| = {err:.3e} > {rel:g} x scale {scale:.3g} (= {err / max(scale, 1e-300):.2e} rel)"
+    return err / max(scale, 1e-300)
