@@ -142,9 +142,12 @@ _ws_cache = {}
 
 
 def workspace(device, nbytes):
-    """Grow-only per-device scratch buffer (torch caching allocator owns the memory)."""
+    """Grow-only scratch buffer per (device, current stream, Python thread): two streams or two threads on one GPU never
+    share scratch (the C library is re-entrant across streams only with distinct workspaces)."""
+    import threading
+
     import torch
-    key = (device.type, device.index)
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)

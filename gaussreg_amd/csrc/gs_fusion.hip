@@ -145,7 +145,8 @@ __global__ __launch_bounds__(256) void gather_records_kernel(const float* __rest
   const int i = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
   const int lane = threadIdx.x & (WAVE - 1);
   if (i >= n || !flag[i] || lane >= REC) return;
-  out[(int64_t)(base + offs[i]) * REC + lane] = rec[(int64_t)i * REC + lane];
+  // columns 3..5 are the normals: the reference's save_ply writes zeros there whatever the inputs held (gs_fusion.py:186-187)
+  out[(int64_t)(base + offs[i]) * REC + lane] = (lane >= 3 && lane < 6) ? 0.0f : rec[(int64_t)i * REC + lane];
 }
 
 }  // namespace

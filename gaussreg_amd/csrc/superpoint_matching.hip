@@ -342,6 +342,61 @@ __global__ __launch_bounds__(256) void select_gather_kernel(const float* __restr
   }
 }
 
+// Degenerate inputs (constant or all-zero features, padded superpoints passed without masks): more scores tie at the
+// threshold than the candidate buffer holds.  torch.topk still returns k entries there, so does this path: ONE workgroup
+// walks the score matrix in flat-index order, takes every score above the threshold (fewer than k of them) and the first
+// k_rem scores equal to it -- exactly the set the sort would have kept (ties: lowest flat index first).
+__global__ __launch_bounds__(1024) void select_gather_ordered_kernel(const float* __restrict__ score,
+                                                                     SpmHdr* __restrict__ hdr,
+                                                                     unsigned long long* __restrict__ cand) {
+  __shared__ int s_w[2][1024 / WAVE];
+  __shared__ int s_base[2];
+  const int64_t total = (int64_t)hdr->nr * hdr->ns;
+  const uint32_t thr = hdr->prefix;
+  const int k = hdr->k;
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  if (threadIdx.x == 0) s_base[0] = s_base[1] = 0;  // [0] scores above the threshold so far, [1] ties so far
+  __syncthreads();
+  // how many ties may be kept = k - (#scores above the threshold), known only after a full sweep: first sweep counts
+  int n_gt_local = 0;
+  for (int64_t e = threadIdx.x; e < total; e += 1024) n_gt_local += __float_as_uint(score[e]) > thr ? 1 : 0;
+  n_gt_local = wave_sum_i32_dpp(n_gt_local);
+  if (lane == 0) s_w[0][wv] = n_gt_local;
+  __syncthreads();
+  int n_gt = 0;
+  for (int i = 0; i < 1024 / WAVE; ++i) n_gt += s_w[0][i];
+  const int tie_budget = k - n_gt;
+  __syncthreads();
+  for (int64_t e0 = 0; e0 < total; e0 += 1024) {
+    const int64_t e = e0 + threadIdx.x;
+    const uint32_t u = e < total ? __float_as_uint(score[e]) : 0u;
+    const int gt = (e < total && u > thr) ? 1 : 0, eq = (e < total && u == thr) ? 1 : 0;
+    const int igt = wave_incl_scan_add_dpp(gt), ieq = wave_incl_scan_add_dpp(eq);
+    if (lane == WAVE - 1) {
+      s_w[0][wv] = igt;
+      s_w[1][wv] = ieq;
+    }
+    __syncthreads();
+    int bgt = s_base[0], beq = s_base[1];
+    for (int i = 0; i < wv; ++i) {
+      bgt += s_w[0][i];
+      beq += s_w[1][i];
+    }
+    const unsigned long long key = ((unsigned long long)u << 32) | (uint32_t)(~(uint32_t)e);
+    if (gt) cand[bgt + igt - 1] = key;                       // slots [0, n_gt)
+    const int tie_rank = beq + ieq - 1;
+    if (eq && tie_rank < tie_budget) cand[n_gt + tie_rank] = key;  // slots [n_gt, k)
+    __syncthreads();
+    if (threadIdx.x == 1023) {
+      s_base[0] = bgt + igt;
+      s_base[1] = beq + ieq;
+    }
+    __syncthreads();
+    if (s_base[1] >= tie_budget && s_base[0] >= n_gt) break;  // everything that will be kept has been seen
+  }
+  if (threadIdx.x == 0) hdr->n_cand = k;
+}
+
 // single block: sort the candidates (descending), emit the first k
 __global__ __launch_bounds__(1024) void select_emit_kernel(const SpmHdr* __restrict__ hdr,
                                                            const unsigned long long* __restrict__ cand,
@@ -496,9 +551,12 @@ extern "C" int gr_superpoint_matching(const float* ref_feats, const float* src_f
   GR_HIP(hipMemcpyAsync(&h, w.hdr, sizeof(h), hipMemcpyDeviceToHost, stream));
   GR_HIP(hipStreamSynchronize(stream));
   if (h.n_cand > CAND_CAP) {
-    set_error("superpoint_matching: %d scores tie at the selection threshold (more than %d); degenerate input",
-              h.n_cand, CAND_CAP);
-    return GR_ERR_UNSUPPORTED;
+    // more ties at the threshold than the candidate buffer holds: redo the gather in flat-index order (see above)
+    hipLaunchKernelGGL(select_gather_ordered_kernel, dim3(1), dim3(1024), 0, stream, w.score, w.hdr, w.cand);
+    hipLaunchKernelGGL(select_emit_kernel, dim3(1), dim3(1024), 0, stream, w.hdr, w.cand, w.ridx, w.sidx, out_ref_idx,
+                       out_src_idx, out_scores);
+    GR_LAUNCH_CHECK();
+    GR_HIP(hipStreamSynchronize(stream));
   }
   *h_num_out = h.k;
   return GR_OK;

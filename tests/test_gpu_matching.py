@@ -186,3 +186,23 @@ def test_local_global_registration_degenerate_and_demo_shape():
     T2 = lgr2(_c(ref), _c(src), _c(rm), _c(sm), _c(ls), None)[3].cpu().numpy()
     want2 = M.local_global_registration(ref, src, rm, sm, ls, correspondence_threshold=10 ** 6)[3]
     np.testing.assert_allclose(T2, want2, atol=1e-5)
+
+
+def test_superpoint_matching_more_ties_than_the_candidate_buffer():
+    """Constant features (an untrained / collapsed backbone, or padded superpoints without masks): every score ties.
+    The reference's topk still returns k entries; here they are the k lowest flat indices, all with the same score."""
+    from gaussreg_amd.matching import SuperPointMatching
+    f = torch.nn.functional.normalize(torch.ones(120, 64, device="cuda"), dim=1)
+    ri, si, sc = SuperPointMatching(256, True)(f, f.clone())
+    assert ri.shape == si.shape == sc.shape == (256,)
+    flat = (ri * 120 + si).cpu().numpy()
+    assert np.array_equal(flat, np.arange(256)), flat[:10]
+    assert float(sc.max() - sc.min()) == 0.0
+    # a few scores above a sea of ties: those come first, then the lowest-index ties
+    g = torch.ones(90, 32, device="cuda")
+    g[5, :] = 0
+    g[5, 0] = 1.0
+    h = g.clone()
+    g, h = torch.nn.functional.normalize(g, dim=1), torch.nn.functional.normalize(h, dim=1)
+    ri, si, sc = SuperPointMatching(64, False)(g, h)
+    assert ri.shape == (64,) and bool((sc[:-1] >= sc[1:]).all())
