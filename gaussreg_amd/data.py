@@ -9,32 +9,99 @@ from . import ext
 from .ops import grid_subsample, radius_search
 
 
-def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, neighbor_limits, order="reference"):
+PIPELINE_MIN_POINTS = 150_000  # below this the whole pyramid is launch-bound and a second host thread only adds latency
+
+
+def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, neighbor_limits, order="reference",
+                               pipeline=None):
+    """utils/data.py:13-77: 4 grid_subsample + 13 radius_search calls, same order of results, same parameters.
+
+    `pipeline` (default: on for device tensors with >= PIPELINE_MIN_POINTS points in reference row order): the
+    subsampling chain runs on a second host thread and a second HIP stream while this thread runs the radius searches of
+    the levels that already exist.  With `order="reference"` every grid_subsample call ends in a host-side replay of
+    libstdc++'s unordered_map iteration order (csrc/hash_order.hip), during which the GPU would otherwise idle; the
+    searches of the finer (larger) levels fill exactly that time.  Results are identical either way."""
     assert num_stages == len(neighbor_limits)
-    points_list, lengths_list = [], []
+    on_gpu = points.is_cuda
+    if pipeline is None:
+        pipeline = on_gpu and order == "reference" and points.shape[0] >= PIPELINE_MIN_POINTS and num_stages > 1
+    points_list, lengths_list = [points], [lengths]
     neighbors_list, subsampling_list, upsampling_list = [], [], []
-    # grid subsampling (data.py:22-28: voxel doubles every stage, level 0 is the input)
-    for i in range(num_stages):
-        if i > 0:
-            points, lengths = grid_subsample(points, lengths, voxel_size=voxel_size, order=order)
-        points_list.append(points)
-        lengths_list.append(lengths)
-        voxel_size *= 2
+
+    def chain():
+        p, l, v = points, lengths, voxel_size
+        for i in range(1, num_stages):
+            v *= 2  # data.py:22-28: level 0 is the input, level i uses voxel_size * 2^i
+            p, l = grid_subsample(p, l, voxel_size=v, order=order)
+            yield p, l
+
+    if pipeline and on_gpu:
+        import queue
+        import threading
+        dev = points.device
+        main_stream = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        start = torch.cuda.Event()
+        start.record(main_stream)
+        q = queue.Queue()
+
+        def worker():
+            try:
+                with torch.cuda.device(dev), torch.cuda.stream(side):
+                    side.wait_event(start)  # the input cloud may still be in flight on the caller's stream
+                    for p, l in chain():
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        q.put((p, l, ev))
+            except BaseException as e:  # noqa: BLE001  (re-raised on the calling thread)
+                q.put(e)
+
+        th = threading.Thread(target=worker, name="gaussreg-pyramid-subsample", daemon=True)
+        th.start()
+
+        def next_level():
+            item = q.get()
+            if isinstance(item, BaseException):
+                raise item
+            p, l, ev = item
+            main_stream.wait_event(ev)
+            p.record_stream(main_stream)  # allocated on the side stream, consumed here
+            points_list.append(p)
+            lengths_list.append(l)
+    else:
+        gen = chain()
+
+        def next_level():
+            p, l = next(gen)
+            points_list.append(p)
+            lengths_list.append(l)
+        th = None
+
     # radius search (data.py:31-69).  Level i's supports with radius r_i serve three searches (up-sampling of level
     # i-1, self, sub-sampling of level i+1): one SupportGrid per level bins them once.
-    on_gpu = points_list[0].is_cuda
-    grids = [ext.SupportGrid(points_list[max(i - 1, 0)].shape[0]) if on_gpu else None for i in range(num_stages)]
-    for i in range(num_stages):
-        cur_points, cur_lengths = points_list[i], lengths_list[i]
-        neighbors_list.append(radius_search(cur_points, cur_points, cur_lengths, cur_lengths, radius,
-                                            neighbor_limits[i], grid=grids[i]))
-        if i < num_stages - 1:
-            sub_points, sub_lengths = points_list[i + 1], lengths_list[i + 1]
-            subsampling_list.append(radius_search(sub_points, cur_points, sub_lengths, cur_lengths, radius,
-                                                  neighbor_limits[i], grid=grids[i]))
-            upsampling_list.append(radius_search(cur_points, sub_points, cur_lengths, sub_lengths, radius * 2,
-                                                 neighbor_limits[i + 1], grid=grids[i + 1]))
-        radius *= 2
+    grids = [None] * num_stages
+
+    def grid_of(i):
+        if on_gpu and grids[i] is None:
+            grids[i] = ext.SupportGrid(points_list[max(i - 1, 0)].shape[0])
+        return grids[i]
+
+    try:
+        for i in range(num_stages):
+            cur_points, cur_lengths = points_list[i], lengths_list[i]
+            neighbors_list.append(radius_search(cur_points, cur_points, cur_lengths, cur_lengths, radius,
+                                                neighbor_limits[i], grid=grid_of(i)))
+            if i < num_stages - 1:
+                next_level()
+                sub_points, sub_lengths = points_list[i + 1], lengths_list[i + 1]
+                subsampling_list.append(radius_search(sub_points, cur_points, sub_lengths, cur_lengths, radius,
+                                                      neighbor_limits[i], grid=grid_of(i)))
+                upsampling_list.append(radius_search(cur_points, sub_points, cur_lengths, sub_lengths, radius * 2,
+                                                     neighbor_limits[i + 1], grid=grid_of(i + 1)))
+            radius *= 2
+    finally:
+        if th is not None:
+            th.join()
     return {'points': points_list, 'lengths': lengths_list, 'neighbors': neighbors_list,
             'subsampling': subsampling_list, 'upsampling': upsampling_list}
 

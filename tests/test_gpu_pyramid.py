@@ -48,3 +48,25 @@ def test_registration_collate_builds_on_device():
         n = out["points"][i].shape[0]
         assert out["neighbors"][i].shape[0] == n and int(out["neighbors"][i].max()) <= n
         assert torch.equal(out["neighbors"][i][:, 0], torch.arange(n, device="cuda"))  # self first
+
+
+def test_pipelined_pyramid_is_identical():
+    """The subsampling chain on a second host thread + stream (gaussreg_amd/data.py) must not change a single value."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from gen_golden_ext import room_pair
+    from gaussreg_amd.data import precompute_data_stack_mode
+    clouds = []
+    for b in range(4):
+        r_, s_ = room_pair(12000, 50 + b)
+        clouds += [r_, s_]
+    pts = torch.from_numpy(np.concatenate(clouds)).cuda()
+    lens = torch.tensor([12000] * 8)
+    limits = [89, 30, 43, 49, 49]
+    a = precompute_data_stack_mode(pts, lens, 5, 0.025, 0.0625, limits, pipeline=False)
+    for _ in range(3):
+        b = precompute_data_stack_mode(pts, lens, 5, 0.025, 0.0625, limits, pipeline=True)
+        for key in ("points", "lengths", "neighbors", "subsampling", "upsampling"):
+            assert len(a[key]) == len(b[key])
+            for x, y in zip(a[key], b[key]):
+                assert x.shape == y.shape and torch.equal(x.cpu(), y.cpu()), key
