@@ -55,6 +55,7 @@ def parse(argv=None):
     ap.add_argument("--pair-points", type=int, default=200_000, help="points per cloud before FPS")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-radius", action="store_true")
+    ap.add_argument("--no-radius-limited", action="store_true", help="skip the width-limited radius_search timing")
     ap.add_argument("--no-single-view", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     return ap.parse_args(argv)
@@ -305,22 +306,23 @@ def run_gpu(h, args):
                                            kernels_ms_per_step=rk,
                                            end_to_end_frac=round(fill_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4))}
         # the width-limited path the data pyramid calls (radius_search with neighbor_limit, utils/data.py:35-67)
-        lim = 40
+        if not args.no_radius_limited:
+            lim = 40
 
-        def limited_step():
-            out["nbl"] = radius_search(dpts, dpts, lens, lens, 0.0625, lim)
+            def limited_step():
+                out["nbl"] = radius_search(dpts, dpts, lens, lens, 0.0625, lim)
 
-        limited_step()
-        l_elapsed = h.timed(limited_step, args.steps, args.warmup, after_warmup=L.gr_timing_reset)
-        lk = per_step_ms(L, ["radius_bin", "radius_count", "radius_fill", "radius_fused"], args.steps)
+            limited_step()
+            l_elapsed = h.timed(limited_step, args.steps, args.warmup, after_warmup=L.gr_timing_reset)
+            lk = per_step_ms(L, ["radius_bin", "radius_count", "radius_fill", "radius_fused"], args.steps)
+            lw = out["nbl"].shape[1]
+            lbytes = 24.0 * nq + 8.0 * nq * lw
+            radius["limited"] = {"value": round(world * nq * args.steps / l_elapsed / 1e6, 2), "unit": "Mpts/s",
+                                 "ms_per_step": round(l_elapsed / args.steps * 1e3, 4), "neighbor_limit": lim, "width": lw,
+                                 "end_to_end_frac": round(lbytes / (l_elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "kernels_ms_per_step": lk}
         L.gr_timing_enable(0)
         L.gr_timing_reset()
-        lw = out["nbl"].shape[1]
-        lbytes = 24.0 * nq + 8.0 * nq * lw
-        radius["limited"] = {"value": round(world * nq * args.steps / l_elapsed / 1e6, 2), "unit": "Mpts/s",
-                             "ms_per_step": round(l_elapsed / args.steps * 1e3, 4), "neighbor_limit": lim, "width": lw,
-                             "end_to_end_frac": round(lbytes / (l_elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
-                             "kernels_ms_per_step": lk}
         del out, dpts
     line["radius_neighbors"] = radius
 
