@@ -121,6 +121,11 @@ struct KernelTimer {
 // Host: iteration order of std::unordered_map<size_t,...> after inserting `keys` (distinct) in order;
 // perm_out[j] = base + index of the j-th iterated key (hash_order.hip).
 void unordered_map_order(const uint64_t* keys, int64_t n, int32_t base, int32_t* perm_out);
+// The same order for many clouds at once, evaluated on the device (hash_order_device.hip): keys on the device, clouds
+// contiguous (h_begins: batch + 1 host offsets); perm_out[begin_c + j] = global index of the j-th iterated key of cloud c.
+size_t hash_order_device_bytes(int64_t n, int64_t batch);
+int hash_order_device(const uint64_t* keys, const int64_t* h_begins, int64_t batch, int32_t* perm_out, void* ws,
+                      size_t ws_bytes, hipStream_t stream);
 
 size_t sort_pairs_u32_temp_bytes(int64_t n);
 int sort_pairs_u32_i32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,

@@ -54,6 +54,8 @@ struct GridWs {
   int32_t* perm;        // [N]
   void* sort_temp;
   size_t sort_temp_bytes;
+  void* ho_ws;          // device evaluation of the unordered_map iteration order (hash_order_device.hip)
+  size_t ho_bytes;
   size_t bytes;
 };
 
@@ -82,6 +84,8 @@ GridWs carve(void* ws, int64_t n, int64_t batch) {
   w.perm = c.take<int32_t>(n);
   w.sort_temp_bytes = sort_pairs_temp_bytes(n);
   w.sort_temp = c.take<char>(w.sort_temp_bytes);
+  w.ho_bytes = hash_order_device_bytes(n, batch);
+  w.ho_ws = c.take<char>(w.ho_bytes);
   w.bytes = c.used();
   return w;
 }
@@ -372,19 +376,23 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
       hipLaunchKernelGGL(fo_rank_kernel, dim3((unsigned)((h_m + 255) / 256)), blk, 0, stream, w.first_idx, w.cell_key,
                          fo_scan, h_m, w.cell_of_rank, w.keys_fo);
       GR_LAUNCH_CHECK();
+      // The reference inserts keys in first-occurrence order into an unordered_map and emits in its iteration order
+      // (grid_subsampling_cpu.cpp:28-47).  Default: that order is evaluated on the device in closed form
+      // (hash_order_device.hip; the bucket counts come from the real libstdc++ rehash policy).  GR_HASH_ORDER_HOST=1
+      // selects the host replay of the container's linking rules instead (hash_order.hip; the checker of the former).
+      static const bool host_replay = getenv("GR_HASH_ORDER_HOST") && getenv("GR_HASH_ORDER_HOST")[0] == '1';
+      std::vector<int64_t> r0(batch + 1, 0);
+      for (int64_t b = 0; b < batch; ++b) r0[b + 1] = r0[b] + h_mb[b];
+      if (!host_replay) {
+        rc = hash_order_device(w.keys_fo, r0.data(), batch, w.perm, w.ho_ws, w.ho_bytes, stream);
+        if (rc != GR_OK) return rc;
+      } else {
       std::vector<uint64_t> hk(h_m);
       GR_HIP(hipMemcpyAsync(hk.data(), w.keys_fo, sizeof(uint64_t) * h_m, hipMemcpyDeviceToHost, stream));
       GR_HIP(hipStreamSynchronize(stream));
-      // Replay: the reference inserts keys in first-occurrence order into an unordered_map and
-      // emits in its iteration order (grid_subsampling_cpu.cpp:28-47).  hash_order.hip replays the
-      // container's own linking rules with the real libstdc++ rehash policy on flat arrays (no node
-      // allocations).  Ranks are global but clouds are contiguous in rank.
       std::vector<int32_t> perm(h_m);
       {
         // clouds are independent: replay them on several host threads when there is enough work
-        // (128 clouds x 50 k voxels took 110 ms on one core -- 8x the whole device-side pyramid)
-        std::vector<int64_t> r0(batch + 1, 0);
-        for (int64_t b = 0; b < batch; ++b) r0[b + 1] = r0[b] + h_mb[b];
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         const int64_t want = std::min<int64_t>({(int64_t)batch, (int64_t)hw, (int64_t)64, h_m / 40000 + 1});
         std::atomic<int64_t> next_cloud{0};
@@ -398,10 +406,11 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
         for (auto& th : pool) th.join();
       }
       GR_HIP(hipMemcpyAsync(w.perm, perm.data(), sizeof(int32_t) * h_m, hipMemcpyHostToDevice, stream));
+      GR_HIP(hipStreamSynchronize(stream));  // perm (host vector) must outlive the copy
+      }
       hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((h_m + 255) / 256)), blk, 0, stream, w.bary, w.cell_of_rank,
                          w.perm, h_m, out_points);
       GR_LAUNCH_CHECK();
-      GR_HIP(hipStreamSynchronize(stream));  // perm (host vector) must outlive the copy
     }
   }
   for (int64_t b = 0; b < batch; ++b) h_out_lengths[b] = h_mb[b];

@@ -1,0 +1,269 @@
+// The iteration order of std::unordered_map<size_t, T> (libstdc++) after inserting distinct keys in a given order,
+// computed ON THE DEVICE for many clouds at once -- the row order the reference emits subsampled points in
+// (geotransformer/extensions/cpu/grid_subsampling/grid_subsampling_cpu.cpp:28-47).  hash_order.hip replays the container's
+// linking rules on one host thread per cloud (and stays as the checker / fallback); this file evaluates the same order in
+// closed form, which is what makes it parallel:
+//
+//   libstdc++ keeps one singly linked list; a node inserted into an EMPTY bucket becomes the new list head, a node
+//   inserted into a non-empty bucket goes right behind the bucket's before-node, i.e. to the FRONT of its bucket's group
+//   (_M_insert_bucket_begin).  Hence at any time the list reads: groups in DEscending order of their creation time,
+//   inside a group nodes in DEscending insertion time.  A rehash (_M_rehash_aux, unique keys) relinks every node, walking
+//   the old list front to back, by exactly the same two rules -- so after a rehash the same statement holds with
+//   "time" = position in the old list, and later insertions simply continue the clock.
+//
+// So with T(e) = the clock value of element e under the current table (old-list position for elements that lived through
+// the last rehash, insertion index afterwards; T is a permutation of 0 .. m-1), bucket b(e) = key mod n, and
+// first(b) = min T over the bucket, the list position of e is
+//     pos(e) = #{ e' : first(b(e')) > first(b(e)) }  +  #{ e' in the same bucket : T(e') > T(e) }.
+// The first term is a suffix sum over G[f] = (size of the group whose oldest element has clock f, else 0); the second is
+// a walk over the (short) bucket chain.  One such evaluation per rehash of the container's history (the bucket counts
+// come from the REAL _Prime_rehash_policy object of the libstdc++ this library is built against), plus one for the final
+// table; every evaluation is a handful of data-parallel passes over all clouds.
+#include <unordered_map>  // std::__detail::_Prime_rehash_policy
+#include <vector>
+
+#include "common.hpp"
+
+namespace gr {
+namespace {
+
+struct HoCloud {    // per cloud, per stage
+  int32_t begin;    // first element (global rank) of the cloud
+  int32_t m;        // elements taking part in this stage (0 = cloud idle in this stage)
+  uint32_t n;       // bucket count of the table in force
+  int32_t toff;     // where the cloud's bucket table starts
+};
+
+constexpr int HO_T = 256;
+
+__device__ __forceinline__ int ho_cloud_of(const int32_t* __restrict__ begins, int nb, int e) {
+  int lo = 0, hi = nb;  // begins has nb + 1 entries
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (begins[mid] <= e) lo = mid;
+    else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(HO_T) void ho_init_kernel(int n, const int32_t* __restrict__ begins, int nb,
+                                                       int32_t* __restrict__ T, int32_t* __restrict__ cloud) {
+  const int e = blockIdx.x * HO_T + threadIdx.x;
+  if (e >= n) return;
+  const int c = ho_cloud_of(begins, nb, e);
+  cloud[e] = c;
+  T[e] = e - begins[c];
+}
+
+__global__ __launch_bounds__(HO_T) void ho_clear_kernel(const HoCloud* __restrict__ st, int nb, int total_buckets,
+                                                        const int32_t* __restrict__ toffs /* nb + 1 */,
+                                                        int32_t* __restrict__ first, int32_t* __restrict__ cnt,
+                                                        int32_t* __restrict__ head) {
+  const int i = blockIdx.x * HO_T + threadIdx.x;
+  if (i >= total_buckets) return;
+  const int c = ho_cloud_of(toffs, nb, i);
+  if ((uint32_t)(i - toffs[c]) >= st[c].n || st[c].m == 0) return;
+  first[i] = 0x7fffffff;
+  cnt[i] = 0;
+  head[i] = -1;
+}
+
+__global__ __launch_bounds__(HO_T) void ho_bucket_kernel(int n, const HoCloud* __restrict__ st,
+                                                         const int32_t* __restrict__ cloud,
+                                                         const uint64_t* __restrict__ keys, const int32_t* __restrict__ T,
+                                                         int32_t* __restrict__ bkt, int32_t* __restrict__ first,
+                                                         int32_t* __restrict__ cnt, int32_t* __restrict__ head,
+                                                         int32_t* __restrict__ nxt) {
+  const int e = blockIdx.x * HO_T + threadIdx.x;
+  if (e >= n) return;
+  const HoCloud s = st[cloud[e]];
+  const int le = e - s.begin;
+  if (le >= s.m) return;
+  const int b = s.toff + (int)(keys[e] % (uint64_t)s.n);  // std::hash<size_t> is the identity, not cached
+  bkt[e] = b;
+  atomicMin(&first[b], T[e]);
+  atomicAdd(&cnt[b], 1);
+  nxt[e] = atomicExch(&head[b], e);  // chain order is irrelevant: the walk below only counts
+}
+
+__global__ __launch_bounds__(HO_T) void ho_group_kernel(int n, const HoCloud* __restrict__ st,
+                                                        const int32_t* __restrict__ cloud, const int32_t* __restrict__ T,
+                                                        const int32_t* __restrict__ bkt, const int32_t* __restrict__ first,
+                                                        const int32_t* __restrict__ cnt, int32_t* __restrict__ G) {
+  const int e = blockIdx.x * HO_T + threadIdx.x;
+  if (e >= n) return;
+  const HoCloud s = st[cloud[e]];
+  if (e - s.begin >= s.m) return;
+  const int b = bkt[e];
+  G[s.begin + T[e]] = (T[e] == first[b]) ? cnt[b] : 0;  // T is a permutation of 0 .. m-1: every slot written once
+}
+
+// per cloud: S[f] = sum of G over clock values > f (exclusive suffix sum), one workgroup per cloud
+__global__ __launch_bounds__(1024) void ho_suffix_kernel(const HoCloud* __restrict__ st, const int32_t* __restrict__ G,
+                                                         int32_t* __restrict__ S) {
+  __shared__ int s_w[1024 / WAVE];
+  __shared__ int s_carry;
+  const HoCloud s = st[blockIdx.x];
+  if (s.m == 0) return;
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  // walk the clock from the top down in slabs of 1024
+  for (int hi = s.m; hi > 0; hi -= 1024) {
+    const int f = hi - 1 - (int)threadIdx.x;  // thread 0 takes the largest clock of the slab
+    const int g = f >= 0 ? G[s.begin + f] : 0;
+    const int incl = wave_incl_scan_add_dpp(g);
+    if (lane == WAVE - 1) s_w[wv] = incl;
+    __syncthreads();
+    int base = s_carry;
+    for (int i = 0; i < wv; ++i) base += s_w[i];
+    if (f >= 0) S[s.begin + f] = base + incl - g;  // everything with a larger clock
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = base + incl;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(HO_T) void ho_rank_kernel(int n, const HoCloud* __restrict__ st,
+                                                       const int32_t* __restrict__ cloud, const int32_t* __restrict__ T,
+                                                       const int32_t* __restrict__ bkt, const int32_t* __restrict__ first,
+                                                       const int32_t* __restrict__ head, const int32_t* __restrict__ nxt,
+                                                       const int32_t* __restrict__ S, int32_t* __restrict__ T_out) {
+  const int e = blockIdx.x * HO_T + threadIdx.x;
+  if (e >= n) return;
+  const HoCloud s = st[cloud[e]];
+  if (e - s.begin >= s.m) {
+    T_out[e] = T[e];
+    return;
+  }
+  const int b = bkt[e];
+  const int t = T[e];
+  int within = 0;
+  for (int p = head[b]; p >= 0; p = nxt[p]) within += T[p] > t ? 1 : 0;
+  T_out[e] = S[s.begin + first[b]] + within;
+}
+
+__global__ __launch_bounds__(HO_T) void ho_emit_kernel(int n, const int32_t* __restrict__ begins,
+                                                       const int32_t* __restrict__ cloud, const int32_t* __restrict__ pos,
+                                                       int32_t* __restrict__ perm) {
+  const int e = blockIdx.x * HO_T + threadIdx.x;
+  if (e >= n) return;
+  perm[begins[cloud[e]] + pos[e]] = e;  // j-th iterated element of the cloud = the element at list position j
+}
+
+}  // namespace
+
+// (element count at which the container rehashes, new bucket count) for a cloud of m distinct keys
+static void rehash_schedule(int64_t m, std::vector<std::pair<int64_t, uint64_t>>& out) {
+  out.clear();
+  std::__detail::_Prime_rehash_policy policy;
+  std::size_t bkt = 1;
+  int64_t i = 0;
+  while (i < m) {
+    const auto need = policy._M_need_rehash(bkt, static_cast<std::size_t>(i), 1);
+    if (need.first) {
+      out.emplace_back(i, need.second);
+      bkt = need.second;
+    }
+    // _M_need_rehash answers "no" without touching its state until n_elt + 1 exceeds _M_next_resize
+    const int64_t nxt = static_cast<int64_t>(policy._M_next_resize);
+    i = nxt > i ? nxt : i + 1;
+  }
+}
+
+size_t hash_order_device_bytes(int64_t n, int64_t batch) {
+  // worst case bucket table: the policy at most doubles past the element count (+ the prime gap): 4 n + slack per cloud
+  const size_t buckets = (size_t)(4 * n + 64 * batch + 64);
+  return align_up((size_t)n * 4, 256) * 7 + align_up(buckets * 4, 256) * 3 + align_up((size_t)(batch + 1) * 4, 256) * 2 +
+         align_up((size_t)batch * sizeof(HoCloud), 256) * 64 + 4096;
+}
+
+// keys: device, n distinct-per-cloud keys in insertion order, clouds contiguous (h_begins: batch + 1 host offsets).
+// perm_out (device, n): perm_out[begin_c + j] = global index of the j-th element the container would iterate.
+int hash_order_device(const uint64_t* keys, const int64_t* h_begins, int64_t batch, int32_t* perm_out, void* ws,
+                      size_t ws_bytes, hipStream_t stream) {
+  const int64_t n = h_begins[batch];
+  if (n == 0) return GR_OK;
+  GR_REQUIRE(n < (1ll << 30) && batch >= 1, "hash_order_device: bad sizes");
+  // ---- schedules
+  std::vector<std::vector<std::pair<int64_t, uint64_t>>> sched(batch);
+  std::vector<int32_t> begins(batch + 1), toffs(batch + 1, 0);
+  size_t nstage = 0;
+  for (int64_t c = 0; c < batch; ++c) {
+    begins[c] = (int32_t)h_begins[c];
+    rehash_schedule(h_begins[c + 1] - h_begins[c], sched[c]);
+    nstage = std::max(nstage, sched[c].size());
+    const uint64_t nfinal = sched[c].empty() ? 1 : sched[c].back().second;
+    GR_REQUIRE(nfinal < (1ull << 31), "hash_order_device: bucket count out of range");
+    toffs[c + 1] = toffs[c] + (int32_t)nfinal;
+  }
+  begins[batch] = (int32_t)n;
+  GR_REQUIRE(nstage <= 60, "hash_order_device: too many rehash stages");
+  // stage k (k = 0 .. nstage-1): the table installed by rehash k, evaluated over the elements present when rehash k+1
+  // strikes (or all of them for a cloud's last table)
+  std::vector<HoCloud> hs(nstage * batch);
+  for (size_t k = 0; k < nstage; ++k)
+    for (int64_t c = 0; c < batch; ++c) {
+      HoCloud s{begins[c], 0, 1u, toffs[c]};
+      const auto& sc = sched[c];
+      if (k < sc.size()) {
+        s.n = (uint32_t)sc[k].second;
+        s.m = (int32_t)(k + 1 < sc.size() ? sc[k + 1].first : h_begins[c + 1] - h_begins[c]);
+      }
+      hs[k * batch + c] = s;
+    }
+  const size_t buckets = (size_t)toffs[batch];
+  Carver cv(ws);
+  int32_t* Ta = cv.take<int32_t>(n);
+  int32_t* Tb = cv.take<int32_t>(n);
+  int32_t* cloud = cv.take<int32_t>(n);
+  int32_t* bkt = cv.take<int32_t>(n);
+  int32_t* nxt = cv.take<int32_t>(n);
+  int32_t* G = cv.take<int32_t>(n);
+  int32_t* S = cv.take<int32_t>(n);
+  int32_t* first = cv.take<int32_t>(buckets);
+  int32_t* cnt = cv.take<int32_t>(buckets);
+  int32_t* head = cv.take<int32_t>(buckets);
+  int32_t* d_begins = cv.take<int32_t>(batch + 1);
+  int32_t* d_toffs = cv.take<int32_t>(batch + 1);
+  HoCloud* d_st = cv.take<HoCloud>(nstage * batch);
+  GR_REQUIRE(ws && cv.used() <= ws_bytes, "hash_order_device: workspace too small (%zu > %zu)", cv.used(), ws_bytes);
+  GR_HIP(hipMemcpyAsync(d_begins, begins.data(), sizeof(int32_t) * (batch + 1), hipMemcpyHostToDevice, stream));
+  GR_HIP(hipMemcpyAsync(d_toffs, toffs.data(), sizeof(int32_t) * (batch + 1), hipMemcpyHostToDevice, stream));
+  GR_HIP(hipMemcpyAsync(d_st, hs.data(), sizeof(HoCloud) * hs.size(), hipMemcpyHostToDevice, stream));
+  const dim3 blk(HO_T), grd((unsigned)((n + HO_T - 1) / HO_T)), tgrd((unsigned)((buckets + HO_T - 1) / HO_T));
+  hipLaunchKernelGGL(ho_init_kernel, grd, blk, 0, stream, (int)n, d_begins, (int)batch, Ta, cloud);
+  int32_t* Tin = Ta;
+  int32_t* Tout = Tb;
+  for (size_t k = 0; k < nstage; ++k) {
+    const HoCloud* st = d_st + k * batch;
+    hipLaunchKernelGGL(ho_clear_kernel, tgrd, blk, 0, stream, st, (int)batch, (int)buckets, d_toffs, first, cnt, head);
+    hipLaunchKernelGGL(ho_bucket_kernel, grd, blk, 0, stream, (int)n, st, cloud, keys, Tin, bkt, first, cnt, head, nxt);
+    hipLaunchKernelGGL(ho_group_kernel, grd, blk, 0, stream, (int)n, st, cloud, Tin, bkt, first, cnt, G);
+    hipLaunchKernelGGL(ho_suffix_kernel, dim3((unsigned)batch), dim3(1024), 0, stream, st, G, S);
+    hipLaunchKernelGGL(ho_rank_kernel, grd, blk, 0, stream, (int)n, st, cloud, Tin, bkt, first, head, nxt, S, Tout);
+    std::swap(Tin, Tout);
+  }
+  hipLaunchKernelGGL(ho_emit_kernel, grd, blk, 0, stream, (int)n, d_begins, cloud, Tin, perm_out);
+  GR_LAUNCH_CHECK();
+  GR_HIP(hipStreamSynchronize(stream));  // the host staging vectors above must outlive their copies
+  return GR_OK;
+}
+
+}  // namespace gr
+
+// Test hook: the device evaluation on its own (keys on the device, offsets on the host).
+extern "C" size_t gr_hash_order_device_workspace_bytes(int64_t n, int64_t batch) {
+  if (n < 0 || batch < 0) return 0;
+  return gr::hash_order_device_bytes(n, batch);
+}
+
+extern "C" int gr_hash_order_device(const uint64_t* d_keys, const int64_t* h_begins, int64_t batch, int32_t* d_perm,
+                                    void* ws, size_t ws_bytes, void* stream) {
+  GR_REQUIRE(batch >= 0 && (batch == 0 || h_begins), "bad arguments");
+  if (batch == 0) return GR_OK;
+  GR_REQUIRE(h_begins[0] == 0, "h_begins must start at 0");
+  for (int64_t c = 0; c < batch; ++c) GR_REQUIRE(h_begins[c + 1] >= h_begins[c], "h_begins must be non-decreasing");
+  GR_REQUIRE(h_begins[batch] == 0 || (d_keys && d_perm), "null argument");
+  return gr::hash_order_device(d_keys, h_begins, batch, d_perm, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}

@@ -98,6 +98,13 @@ int gr_radius_fill(const float* q, const float* s, int64_t nq, int64_t ns, int64
 int gr_host_unordered_map_order(const uint64_t* h_keys, int64_t n, int32_t* h_perm);
 #define GR_ORDER_REFERENCE 0
 #define GR_ORDER_CELL 1
+/* Test hooks for the row order: gr_host_unordered_map_order replays libstdc++'s container on the host;
+ * gr_hash_order_device evaluates the same order on the device for `batch` clouds at once (d_keys: distinct keys per cloud
+ * in insertion order, clouds contiguous; h_begins: batch + 1 HOST offsets; d_perm[begin_c + j] = global index of the j-th
+ * key the container would iterate). */
+size_t gr_hash_order_device_workspace_bytes(int64_t n, int64_t batch);
+int gr_hash_order_device(const uint64_t* d_keys, const int64_t* h_begins, int64_t batch, int32_t* d_perm, void* ws,
+                         size_t ws_bytes, void* stream);
 size_t gr_grid_subsample_workspace_bytes(int64_t n, int64_t batch);
 int gr_grid_subsample(const float* points, const int64_t* h_lengths, int64_t n, int64_t batch,
                       float voxel_size, int order_mode, float* out_points, int64_t* h_out_lengths,
