@@ -29,8 +29,8 @@ namespace {
 
 struct HoCloud {    // per cloud, per stage
   int32_t begin;    // first element (global rank) of the cloud
-  int32_t m;        // elements taking part in this stage (0 = cloud idle in this stage)
-  uint32_t n;       // bucket count of the table in force
+  int32_t m;        // elements taking part in this stage; for a cloud whose history has ended (n == 0): its size
+  uint32_t n;       // bucket count of the table in force; 0 = the cloud is done, its positions are only carried along
   int32_t toff;     // where the cloud's bucket table starts
 };
 
@@ -47,38 +47,26 @@ __device__ __forceinline__ int ho_cloud_of(const int32_t* __restrict__ begins, i
 }
 
 __global__ __launch_bounds__(HO_T) void ho_init_kernel(int n, const int32_t* __restrict__ begins, int nb,
-                                                       int32_t* __restrict__ T, int32_t* __restrict__ cloud) {
+                                                       int32_t* __restrict__ Ta, int32_t* __restrict__ Tb,
+                                                       int32_t* __restrict__ cloud) {
   const int e = blockIdx.x * HO_T + threadIdx.x;
   if (e >= n) return;
   const int c = ho_cloud_of(begins, nb, e);
   cloud[e] = c;
-  T[e] = e - begins[c];
+  Ta[e] = Tb[e] = e - begins[c];  // both ping-pong buffers: an element keeps T = insertion index until a stage covers it
 }
 
-__global__ __launch_bounds__(HO_T) void ho_clear_kernel(const HoCloud* __restrict__ st, int nb, int total_buckets,
-                                                        const int32_t* __restrict__ toffs /* nb + 1 */,
-                                                        int32_t* __restrict__ first, int32_t* __restrict__ cnt,
-                                                        int32_t* __restrict__ head) {
-  const int i = blockIdx.x * HO_T + threadIdx.x;
-  if (i >= total_buckets) return;
-  const int c = ho_cloud_of(toffs, nb, i);
-  if ((uint32_t)(i - toffs[c]) >= st[c].n || st[c].m == 0) return;
-  first[i] = 0x7fffffff;
-  cnt[i] = 0;
-  head[i] = -1;
-}
-
-__global__ __launch_bounds__(HO_T) void ho_bucket_kernel(int n, const HoCloud* __restrict__ st,
-                                                         const int32_t* __restrict__ cloud,
+// Stage kernels run on 2-D grids: blockIdx.y = cloud, blockIdx.x * HO_T + lane = local element; the grid's x extent is the
+// largest m of the stage, so the early stages (13, 29, 59 ... elements per cloud) cost a launch each and nothing more.
+__global__ __launch_bounds__(HO_T) void ho_bucket_kernel(const HoCloud* __restrict__ st,
                                                          const uint64_t* __restrict__ keys, const int32_t* __restrict__ T,
                                                          int32_t* __restrict__ bkt, int32_t* __restrict__ first,
                                                          int32_t* __restrict__ cnt, int32_t* __restrict__ head,
                                                          int32_t* __restrict__ nxt) {
-  const int e = blockIdx.x * HO_T + threadIdx.x;
-  if (e >= n) return;
-  const HoCloud s = st[cloud[e]];
-  const int le = e - s.begin;
-  if (le >= s.m) return;
+  const HoCloud s = st[blockIdx.y];
+  const int le = blockIdx.x * HO_T + threadIdx.x;
+  if (le >= s.m || s.n == 0) return;
+  const int e = s.begin + le;
   const int b = s.toff + (int)(keys[e] % (uint64_t)s.n);  // std::hash<size_t> is the identity, not cached
   bkt[e] = b;
   atomicMin(&first[b], T[e]);
@@ -86,14 +74,13 @@ __global__ __launch_bounds__(HO_T) void ho_bucket_kernel(int n, const HoCloud* _
   nxt[e] = atomicExch(&head[b], e);  // chain order is irrelevant: the walk below only counts
 }
 
-__global__ __launch_bounds__(HO_T) void ho_group_kernel(int n, const HoCloud* __restrict__ st,
-                                                        const int32_t* __restrict__ cloud, const int32_t* __restrict__ T,
+__global__ __launch_bounds__(HO_T) void ho_group_kernel(const HoCloud* __restrict__ st, const int32_t* __restrict__ T,
                                                         const int32_t* __restrict__ bkt, const int32_t* __restrict__ first,
                                                         const int32_t* __restrict__ cnt, int32_t* __restrict__ G) {
-  const int e = blockIdx.x * HO_T + threadIdx.x;
-  if (e >= n) return;
-  const HoCloud s = st[cloud[e]];
-  if (e - s.begin >= s.m) return;
+  const HoCloud s = st[blockIdx.y];
+  const int le = blockIdx.x * HO_T + threadIdx.x;
+  if (le >= s.m || s.n == 0) return;
+  const int e = s.begin + le;
   const int b = bkt[e];
   G[s.begin + T[e]] = (T[e] == first[b]) ? cnt[b] : 0;  // T is a permutation of 0 .. m-1: every slot written once
 }
@@ -104,7 +91,7 @@ __global__ __launch_bounds__(1024) void ho_suffix_kernel(const HoCloud* __restri
   __shared__ int s_w[1024 / WAVE];
   __shared__ int s_carry;
   const HoCloud s = st[blockIdx.x];
-  if (s.m == 0) return;
+  if (s.m == 0 || s.n == 0) return;
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   if (threadIdx.x == 0) s_carry = 0;
   __syncthreads();
@@ -124,15 +111,16 @@ __global__ __launch_bounds__(1024) void ho_suffix_kernel(const HoCloud* __restri
   }
 }
 
-__global__ __launch_bounds__(HO_T) void ho_rank_kernel(int n, const HoCloud* __restrict__ st,
-                                                       const int32_t* __restrict__ cloud, const int32_t* __restrict__ T,
+// reads the clocks of the whole bucket chain from T, writes the new positions to the OTHER ping-pong buffer
+__global__ __launch_bounds__(HO_T) void ho_rank_kernel(const HoCloud* __restrict__ st, const int32_t* __restrict__ T,
                                                        const int32_t* __restrict__ bkt, const int32_t* __restrict__ first,
                                                        const int32_t* __restrict__ head, const int32_t* __restrict__ nxt,
                                                        const int32_t* __restrict__ S, int32_t* __restrict__ T_out) {
-  const int e = blockIdx.x * HO_T + threadIdx.x;
-  if (e >= n) return;
-  const HoCloud s = st[cloud[e]];
-  if (e - s.begin >= s.m) {
+  const HoCloud s = st[blockIdx.y];
+  const int le = blockIdx.x * HO_T + threadIdx.x;
+  if (le >= s.m) return;
+  const int e = s.begin + le;
+  if (s.n == 0) {  // finished cloud: keep its final positions in the buffer the next stage (or the emit) reads
     T_out[e] = T[e];
     return;
   }
@@ -141,6 +129,71 @@ __global__ __launch_bounds__(HO_T) void ho_rank_kernel(int n, const HoCloud* __r
   int within = 0;
   for (int p = head[b]; p >= 0; p = nxt[p]) within += T[p] > t ? 1 : 0;
   T_out[e] = S[s.begin + first[b]] + within;
+}
+
+// The first stages of every history are tiny (tables of 13, 29, 59 ... 2357 buckets): one workgroup per cloud runs them
+// back to back with everything in LDS -- one launch instead of four per stage.
+constexpr int HO_SMALL = 2357;  // largest m (= bucket count) handled here
+__global__ __launch_bounds__(1024) void ho_small_stages_kernel(const HoCloud* __restrict__ st_all, int batch, int nsmall,
+                                                               const uint64_t* __restrict__ keys,
+                                                               int32_t* __restrict__ T_out_a, int32_t* __restrict__ T_out_b) {
+  __shared__ int sT[HO_SMALL], sTn[HO_SMALL], sB[HO_SMALL], sNx[HO_SMALL], sG[HO_SMALL];
+  __shared__ int sFirst[HO_SMALL], sCnt[HO_SMALL], sHead[HO_SMALL];
+  __shared__ int s_w[1024 / WAVE];
+  __shared__ int s_carry;
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & (WAVE - 1), wv = tid / WAVE;
+  const int begin = st_all[c].begin;
+  int m_done = 0;
+  for (int i = tid; i < HO_SMALL; i += 1024) sT[i] = i;
+  __syncthreads();
+  for (int k = 0; k < nsmall; ++k) {
+    const HoCloud s = st_all[k * batch + c];
+    if (s.n == 0) break;  // block-uniform: this cloud's history has ended
+    const int m = s.m, n = (int)s.n;
+    for (int i = tid; i < n; i += 1024) {
+      sFirst[i] = 0x7fffffff;
+      sCnt[i] = 0;
+      sHead[i] = -1;
+    }
+    __syncthreads();
+    for (int e = tid; e < m; e += 1024) {
+      const int b = (int)(keys[begin + e] % (uint64_t)n);
+      sB[e] = b;
+      atomicMin(&sFirst[b], sT[e]);
+      atomicAdd(&sCnt[b], 1);
+      sNx[e] = atomicExch(&sHead[b], e);
+    }
+    __syncthreads();
+    for (int e = tid; e < m; e += 1024) sG[sT[e]] = (sT[e] == sFirst[sB[e]]) ? sCnt[sB[e]] : 0;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    // exclusive suffix sum of G over the clock, in place (G[f] <- sum over clocks > f)
+    for (int hi = m; hi > 0; hi -= 1024) {
+      const int f = hi - 1 - tid;
+      const int g = f >= 0 ? sG[f] : 0;
+      const int incl = wave_incl_scan_add_dpp(g);
+      if (lane == WAVE - 1) s_w[wv] = incl;
+      __syncthreads();
+      int base = s_carry;
+      for (int i = 0; i < wv; ++i) base += s_w[i];
+      if (f >= 0) sG[f] = base + incl - g;
+      __syncthreads();
+      if (tid == 1023) s_carry = base + incl;
+      __syncthreads();
+    }
+    for (int e = tid; e < m; e += 1024) {
+      const int b = sB[e], t = sT[e];
+      int within = 0;
+      for (int p = sHead[b]; p >= 0; p = sNx[p]) within += sT[p] > t ? 1 : 0;
+      sTn[e] = sG[sFirst[b]] + within;
+    }
+    __syncthreads();
+    for (int e = tid; e < m; e += 1024) sT[e] = sTn[e];
+    m_done = m;
+    __syncthreads();
+  }
+  for (int e = tid; e < m_done; e += 1024) T_out_a[begin + e] = T_out_b[begin + e] = sT[e];
 }
 
 __global__ __launch_bounds__(HO_T) void ho_emit_kernel(int n, const int32_t* __restrict__ begins,
@@ -174,7 +227,7 @@ static void rehash_schedule(int64_t m, std::vector<std::pair<int64_t, uint64_t>>
 size_t hash_order_device_bytes(int64_t n, int64_t batch) {
   // worst case bucket table: the policy at most doubles past the element count (+ the prime gap): 4 n + slack per cloud
   const size_t buckets = (size_t)(4 * n + 64 * batch + 64);
-  return align_up((size_t)n * 4, 256) * 7 + align_up(buckets * 4, 256) * 3 + align_up((size_t)(batch + 1) * 4, 256) * 2 +
+  return align_up((size_t)n * 4, 256) * 7 + align_up(2 * buckets * 4, 256) * 3 + align_up((size_t)(batch + 1) * 4, 256) * 2 +
          align_up((size_t)batch * sizeof(HoCloud), 256) * 64 + 4096;
 }
 
@@ -187,32 +240,37 @@ int hash_order_device(const uint64_t* keys, const int64_t* h_begins, int64_t bat
   GR_REQUIRE(n < (1ll << 30) && batch >= 1, "hash_order_device: bad sizes");
   // ---- schedules
   std::vector<std::vector<std::pair<int64_t, uint64_t>>> sched(batch);
-  std::vector<int32_t> begins(batch + 1), toffs(batch + 1, 0);
+  std::vector<int32_t> begins(batch + 1);
   size_t nstage = 0;
   for (int64_t c = 0; c < batch; ++c) {
     begins[c] = (int32_t)h_begins[c];
     rehash_schedule(h_begins[c + 1] - h_begins[c], sched[c]);
     nstage = std::max(nstage, sched[c].size());
     const uint64_t nfinal = sched[c].empty() ? 1 : sched[c].back().second;
-    GR_REQUIRE(nfinal < (1ull << 31), "hash_order_device: bucket count out of range");
-    toffs[c + 1] = toffs[c] + (int32_t)nfinal;
+    GR_REQUIRE(nfinal < (1ull << 30), "hash_order_device: bucket count out of range");
   }
   begins[batch] = (int32_t)n;
   GR_REQUIRE(nstage <= 60, "hash_order_device: too many rehash stages");
   // stage k (k = 0 .. nstage-1): the table installed by rehash k, evaluated over the elements present when rehash k+1
   // strikes (or all of them for a cloud's last table)
+  // every (stage, cloud) gets its own slice of the bucket tables (the bucket counts roughly double from stage to stage, so
+  // all slices together are about twice the final tables): ONE clear up front instead of one per stage
   std::vector<HoCloud> hs(nstage * batch);
+  int64_t table_entries = 0;
   for (size_t k = 0; k < nstage; ++k)
     for (int64_t c = 0; c < batch; ++c) {
-      HoCloud s{begins[c], 0, 1u, toffs[c]};
+      HoCloud s{begins[c], (int32_t)(h_begins[c + 1] - h_begins[c]), 0u, 0};
       const auto& sc = sched[c];
       if (k < sc.size()) {
         s.n = (uint32_t)sc[k].second;
         s.m = (int32_t)(k + 1 < sc.size() ? sc[k + 1].first : h_begins[c + 1] - h_begins[c]);
+        s.toff = (int32_t)table_entries;
+        table_entries += s.n;
       }
       hs[k * batch + c] = s;
     }
-  const size_t buckets = (size_t)toffs[batch];
+  GR_REQUIRE(table_entries < (1ll << 31), "hash_order_device: bucket tables out of range");
+  const size_t buckets = (size_t)table_entries;
   Carver cv(ws);
   int32_t* Ta = cv.take<int32_t>(n);
   int32_t* Tb = cv.take<int32_t>(n);
@@ -225,23 +283,47 @@ int hash_order_device(const uint64_t* keys, const int64_t* h_begins, int64_t bat
   int32_t* cnt = cv.take<int32_t>(buckets);
   int32_t* head = cv.take<int32_t>(buckets);
   int32_t* d_begins = cv.take<int32_t>(batch + 1);
-  int32_t* d_toffs = cv.take<int32_t>(batch + 1);
   HoCloud* d_st = cv.take<HoCloud>(nstage * batch);
   GR_REQUIRE(ws && cv.used() <= ws_bytes, "hash_order_device: workspace too small (%zu > %zu)", cv.used(), ws_bytes);
   GR_HIP(hipMemcpyAsync(d_begins, begins.data(), sizeof(int32_t) * (batch + 1), hipMemcpyHostToDevice, stream));
-  GR_HIP(hipMemcpyAsync(d_toffs, toffs.data(), sizeof(int32_t) * (batch + 1), hipMemcpyHostToDevice, stream));
+  GR_HIP(hipMemsetAsync(first, 0x7f, sizeof(int32_t) * buckets, stream));  // 0x7f7f7f7f: larger than any clock value
+  GR_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * buckets, stream));
+  GR_HIP(hipMemsetAsync(head, 0xff, sizeof(int32_t) * buckets, stream));    // -1
   GR_HIP(hipMemcpyAsync(d_st, hs.data(), sizeof(HoCloud) * hs.size(), hipMemcpyHostToDevice, stream));
-  const dim3 blk(HO_T), grd((unsigned)((n + HO_T - 1) / HO_T)), tgrd((unsigned)((buckets + HO_T - 1) / HO_T));
-  hipLaunchKernelGGL(ho_init_kernel, grd, blk, 0, stream, (int)n, d_begins, (int)batch, Ta, cloud);
+  const dim3 blk(HO_T), grd((unsigned)((n + HO_T - 1) / HO_T));
+  hipLaunchKernelGGL(ho_init_kernel, grd, blk, 0, stream, (int)n, d_begins, (int)batch, Ta, Tb, cloud);
   int32_t* Tin = Ta;
   int32_t* Tout = Tb;
-  for (size_t k = 0; k < nstage; ++k) {
+  // stages whose largest m fits the LDS kernel (the rehash thresholds are the same prime sequence for every cloud)
+  size_t nsmall = 0;
+  while (nsmall < nstage) {
+    int64_t mm = 0, nn = 0;
+    for (int64_t c = 0; c < batch; ++c)
+      if (hs[nsmall * batch + c].n) {
+        mm = std::max<int64_t>(mm, hs[nsmall * batch + c].m);
+        nn = std::max<int64_t>(nn, hs[nsmall * batch + c].n);
+      }
+    if (mm > HO_SMALL || nn > HO_SMALL) break;
+    ++nsmall;
+  }
+  if (nsmall > 0)
+    hipLaunchKernelGGL(ho_small_stages_kernel, dim3((unsigned)batch), dim3(1024), 0, stream, d_st, (int)batch, (int)nsmall, keys,
+                       Ta, Tb);
+  for (size_t k = nsmall; k < nstage; ++k) {
     const HoCloud* st = d_st + k * batch;
-    hipLaunchKernelGGL(ho_clear_kernel, tgrd, blk, 0, stream, st, (int)batch, (int)buckets, d_toffs, first, cnt, head);
-    hipLaunchKernelGGL(ho_bucket_kernel, grd, blk, 0, stream, (int)n, st, cloud, keys, Tin, bkt, first, cnt, head, nxt);
-    hipLaunchKernelGGL(ho_group_kernel, grd, blk, 0, stream, (int)n, st, cloud, Tin, bkt, first, cnt, G);
+    int64_t max_m = 0, max_n = 0;
+    for (int64_t c = 0; c < batch; ++c) {
+      const HoCloud& hc = hs[k * batch + c];
+      max_m = std::max<int64_t>(max_m, hc.m);
+      max_n = std::max<int64_t>(max_n, hc.n);
+    }
+    if (max_m == 0) continue;
+    (void)max_n;
+    const dim3 eg((unsigned)((max_m + HO_T - 1) / HO_T), (unsigned)batch);
+    hipLaunchKernelGGL(ho_bucket_kernel, eg, blk, 0, stream, st, keys, Tin, bkt, first, cnt, head, nxt);
+    hipLaunchKernelGGL(ho_group_kernel, eg, blk, 0, stream, st, Tin, bkt, first, cnt, G);
     hipLaunchKernelGGL(ho_suffix_kernel, dim3((unsigned)batch), dim3(1024), 0, stream, st, G, S);
-    hipLaunchKernelGGL(ho_rank_kernel, grd, blk, 0, stream, (int)n, st, cloud, Tin, bkt, first, head, nxt, S, Tout);
+    hipLaunchKernelGGL(ho_rank_kernel, eg, blk, 0, stream, st, Tin, bkt, first, head, nxt, S, Tout);
     std::swap(Tin, Tout);
   }
   hipLaunchKernelGGL(ho_emit_kernel, grd, blk, 0, stream, (int)n, d_begins, cloud, Tin, perm_out);
