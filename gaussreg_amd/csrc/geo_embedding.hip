@@ -570,6 +570,200 @@ __global__ __launch_bounds__(256) void rpe_scores_kernel(const float* __restrict
 }  // namespace
 }  // namespace gr
 
+namespace gr {
+namespace {
+
+// ---------------------------------------------------------------- RPE attention, fused (rpe_transformer.py:51-72)
+// One workgroup per query row n does the whole attention row for all heads:
+//   1. raw scores  s[h][m] = (q[h,n,:] . k[h,m,:] + emb[n,m,:] . u[n,h,:] + add[n,h]) / sqrt(ch)   (16 lanes share one
+//      (n, m) pair: float4 loads of the embedding row -- the only N*M*C stream, read exactly once per layer -- and of the
+//      key row, xor-shuffle reduction), then attention_factors, key_weights, key_masks exactly in the reference's order;
+//   2. softmax over m per head in LDS (wave reductions), written out as attention_scores (H, N, M);
+//   3. hidden[n, h*ch + c] = sum_m p[h][m] * v[m, h*ch + c]  (thread = output channel, the value matrix streams from L2).
+// Nothing of size N*M*C or H*N*M is re-read from HBM between the steps; the reference materialises the (N, M, C) projected
+// embedding, two (H, N, M) score tensors and the softmax in separate ATen kernels.
+template <int H, int CV>
+__global__ __launch_bounds__(256) void rpe_attention_kernel(const float* __restrict__ emb, const float* __restrict__ u,
+                                                            const float* __restrict__ add, const float* __restrict__ q,
+                                                            const float* __restrict__ k, const float* __restrict__ v,
+                                                            const float* __restrict__ factors,
+                                                            const float* __restrict__ key_weights,
+                                                            const uint8_t* __restrict__ key_masks, int n_rows, int m_cols,
+                                                            float inv_sqrt_ch, float* __restrict__ out_scores,
+                                                            float* __restrict__ out_hidden) {
+  constexpr int C = CV * 64, CH = C / H;
+  extern __shared__ float s_sc[];  // [H][m_cols]
+  __shared__ float s_red[2][8];
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, sub = lane & 15, grp = lane >> 4;
+  float4 ur[H][CV], qr[CV];
+#pragma unroll
+  for (int i = 0; i < CV; ++i) {
+    qr[i] = *reinterpret_cast<const float4*>(q + (int64_t)n * C + i * 64 + sub * 4);
+#pragma unroll
+    for (int h = 0; h < H; ++h) ur[h][i] = *reinterpret_cast<const float4*>(u + ((int64_t)n * H + h) * C + i * 64 + sub * 4);
+  }
+  // ---- 1. raw scores
+  for (int m = w * 4 + grp; m < m_cols; m += 16) {
+    const float* erow = emb + ((int64_t)n * m_cols + m) * C + sub * 4;
+    const float* krow = k + (int64_t)m * C + sub * 4;
+    float4 e[CV], kk[CV];
+#pragma unroll
+    for (int i = 0; i < CV; ++i) {
+      e[i] = *reinterpret_cast<const float4*>(erow + i * 64);
+      kk[i] = *reinterpret_cast<const float4*>(krow + i * 64);
+    }
+    float acc[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < CV; ++i) {
+        a = fmaf(e[i].x, ur[h][i].x, a);
+        a = fmaf(e[i].y, ur[h][i].y, a);
+        a = fmaf(e[i].z, ur[h][i].z, a);
+        a = fmaf(e[i].w, ur[h][i].w, a);
+      }
+      acc[h] = a;
+    }
+#pragma unroll
+    for (int i = 0; i < CV; ++i) {  // q . k: the four channels of this float4 belong to head (i*64 + sub*4) / CH
+      const float part = fmaf(qr[i].x, kk[i].x, fmaf(qr[i].y, kk[i].y, fmaf(qr[i].z, kk[i].z, qr[i].w * kk[i].w)));
+      const int hd = (i * 64 + sub * 4) / CH;
+#pragma unroll
+      for (int h = 0; h < H; ++h) acc[h] += hd == h ? part : 0.f;
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+#pragma unroll
+      for (int d = 8; d > 0; d >>= 1) acc[h] += __shfl_xor(acc[h], d, 64);
+    }
+    if (sub < H) {
+      float val = acc[0];
+#pragma unroll
+      for (int h = 1; h < H; ++h) val = sub == h ? acc[h] : val;
+      float sc = (val + add[n * H + sub]) * inv_sqrt_ch;
+      if (factors) sc = factors[(int64_t)n * m_cols + m] * sc;
+      if (key_weights) sc = sc * key_weights[m];
+      if (key_masks && key_masks[m]) sc = -INFINITY;
+      s_sc[sub * m_cols + m] = sc;
+    }
+  }
+  __syncthreads();
+  // ---- 2. softmax over m, one wave per head (two heads per wave when H = 8)
+  for (int h = w; h < H; h += 4) {
+    float* row = s_sc + h * m_cols;
+    float mx = -INFINITY;
+    for (int m = lane; m < m_cols; m += 64) mx = fmaxf(mx, row[m]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    float sum = 0.f;
+    for (int m = lane; m < m_cols; m += 64) {
+      const float ev = expf(row[m] - mx);
+      row[m] = ev;
+      sum += ev;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    const float inv = 1.0f / sum;
+    float* dst = out_scores + ((int64_t)h * n_rows + n) * m_cols;
+    for (int m = lane; m < m_cols; m += 64) {
+      const float p = row[m] * inv;
+      row[m] = p;
+      dst[m] = p;
+    }
+  }
+  __syncthreads();
+  // ---- 3. hidden = P V: wave w takes a quarter of the keys, lane l the four channels 4l .. 4l+3 (float4 loads of the
+  //         value rows, eight keys in flight), then the four partial rows are added through LDS
+  __shared__ float4 s_part[4][64];
+  {
+    const int per = (m_cols + 3) / 4;
+    const int m0 = w * per, m1 = min(m_cols, m0 + per);
+    const bool on = lane * 4 < C;
+    const float* prow = s_sc + ((lane * 4) / CH) * m_cols;
+    const float* vcol = v + lane * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on) {
+      int m = m0;
+      for (; m + 8 <= m1; m += 8) {
+        float4 vv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vv[j] = *reinterpret_cast<const float4*>(vcol + (int64_t)(m + j) * C);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float p = prow[m + j];
+          acc.x = fmaf(p, vv[j].x, acc.x);
+          acc.y = fmaf(p, vv[j].y, acc.y);
+          acc.z = fmaf(p, vv[j].z, acc.z);
+          acc.w = fmaf(p, vv[j].w, acc.w);
+        }
+      }
+      for (; m < m1; ++m) {
+        const float4 vv = *reinterpret_cast<const float4*>(vcol + (int64_t)m * C);
+        const float p = prow[m];
+        acc.x = fmaf(p, vv.x, acc.x);
+        acc.y = fmaf(p, vv.y, acc.y);
+        acc.z = fmaf(p, vv.z, acc.z);
+        acc.w = fmaf(p, vv.w, acc.w);
+      }
+    }
+    s_part[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && on) {
+      const float4 a = s_part[0][lane], b2 = s_part[1][lane], c2 = s_part[2][lane], d2 = s_part[3][lane];
+      float4 r;
+      r.x = (a.x + b2.x) + (c2.x + d2.x);
+      r.y = (a.y + b2.y) + (c2.y + d2.y);
+      r.z = (a.z + b2.z) + (c2.z + d2.z);
+      r.w = (a.w + b2.w) + (c2.w + d2.w);
+      *reinterpret_cast<float4*>(out_hidden + (int64_t)n * C + lane * 4) = r;
+    }
+  }
+  (void)s_red;
+}
+
+}  // namespace
+}  // namespace gr
+
+extern "C" int gr_rpe_attention(const float* embed, const float* u, const float* add, const float* q, const float* k,
+                                const float* v, const float* attention_factors, const float* key_weights,
+                                const uint8_t* key_masks, int64_t n, int64_t m, int64_t c, int64_t heads, float* out_scores,
+                                float* out_hidden, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GR_REQUIRE(n >= 0 && m >= 0 && n < (1 << 24) && m < (1 << 24), "rpe_attention: bad sizes");
+  GR_REQUIRE((c == 64 || c == 128 || c == 256) && (heads == 1 || heads == 2 || heads == 4 || heads == 8),
+             "rpe_attention: d_model must be 64/128/256 and num_heads 1/2/4/8 (got %lld, %lld)", (long long)c, (long long)heads);
+  if (n == 0) return GR_OK;
+  GR_REQUIRE(m > 0, "rpe_attention: no keys (softmax over an empty row)");
+  GR_REQUIRE(embed && u && add && q && k && v && out_scores && out_hidden, "null argument");
+  const size_t lds = (size_t)heads * m * sizeof(float);
+  GR_REQUIRE(lds <= 150 * 1024, "rpe_attention: %lld keys x %lld heads do not fit in LDS", (long long)m, (long long)heads);
+  const float inv_sqrt_ch = 1.0f / sqrtf((float)(c / heads));
+  KernelTimer timer("rpe_attention", stream);
+#define GR_RPA(H, CV)                                                                                            \
+  do {                                                                                                           \
+    auto kern = gr::rpe_attention_kernel<H, CV>;                                                                 \
+    if (lds > 64 * 1024)                                                                                         \
+      GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 160 * 1024));                                                                   \
+    hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(256), lds, stream, embed, u, add, q, k, v, attention_factors, \
+                       key_weights, key_masks, (int)n, (int)m, inv_sqrt_ch, out_scores, out_hidden);             \
+  } while (0)
+#define GR_RPA_H(CV)               \
+  switch (heads) {                 \
+    case 1: GR_RPA(1, CV); break;  \
+    case 2: GR_RPA(2, CV); break;  \
+    case 4: GR_RPA(4, CV); break;  \
+    default: GR_RPA(8, CV); break; \
+  }
+  if (c == 64) { GR_RPA_H(1); } else if (c == 128) { GR_RPA_H(2); } else { GR_RPA_H(4); }
+#undef GR_RPA_H
+#undef GR_RPA
+  GR_LAUNCH_CHECK();
+  return GR_OK;
+}
+
 extern "C" int gr_rpe_scores(const float* embed, const float* u, const float* add, int64_t n, int64_t m, int64_t c,
                              int64_t heads, float* out, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);

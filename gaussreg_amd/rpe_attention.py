@@ -2,9 +2,11 @@
 
 The reference projects the (B,N,M,C) relative-position embedding through `proj_p` in every layer (77 GFLOP and a
 602 MB temporary at N=M=767, C=256) before contracting it with q.  The contraction is linear in the embedding, so it
-is re-associated here:  s_p[h,n,m] = emb[n,m,:] . (W_p[h]^T q[h,n,:]) + q[h,n,:] . b_p[h]  -- one memory-bound pass over
-the embedding in a HIP kernel (gaussreg_amd/csrc/geo_embedding.hip: gr_rpe_scores).  The small dense products
-(q/k/v projections, q k^T, softmax, scores @ v) stay plain torch ops (rocBLAS).  State-dict keys are the reference's.
+is re-associated here:  s_p[h,n,m] = emb[n,m,:] . (W_p[h]^T q[h,n,:]) + q[h,n,:] . b_p[h], and everything after the four
+input projections -- q k^T, the positional term, scaling, factors / weights / masks, softmax and scores @ v -- runs in ONE
+HIP kernel per batch element (gaussreg_amd/csrc/geo_embedding.hip: gr_rpe_attention): the embedding is streamed exactly
+once per layer and no (H,N,M) or (N,M,C) intermediate goes through HBM.  The projections (nn.Linear) and the tiny
+u = W_p^T q product stay torch ops.  State-dict keys are the reference's.
 """
 import torch
 import torch.nn as nn
@@ -38,25 +40,26 @@ class RPEMultiHeadAttention(nn.Module):
         B, N, C = input_q.shape
         M = input_k.shape[1]
         H, ch = self.num_heads, self.d_model_per_head
-        q = self.proj_q(input_q).view(B, N, H, ch).permute(0, 2, 1, 3)          # (B,H,N,c)
-        k = self.proj_k(input_k).view(B, M, H, ch).permute(0, 2, 1, 3)
-        v = self.proj_v(input_v).view(B, M, H, ch).permute(0, 2, 1, 3)
+        q2 = self.proj_q(input_q).contiguous()                                   # (B,N,C), heads side by side
+        k2 = self.proj_k(input_k).contiguous()
+        v2 = self.proj_v(input_v).contiguous()
         wp = self.proj_p.weight.view(H, ch, C)                                  # rows h*ch..: head h
-        u = torch.einsum('bhnc,hcj->bnhj', q, wp).contiguous()                  # (B,N,H,C)
-        add = torch.einsum('bhnc,hc->bnh', q, self.proj_p.bias.view(H, ch)).contiguous()
+        qh = q2.view(B, N, H, ch)
+        u = torch.einsum('bnhc,hcj->bnhj', qh, wp).contiguous()                 # (B,N,H,C)
+        add = torch.einsum('bnhc,hc->bnh', qh, self.proj_p.bias.view(H, ch)).contiguous()
         emb = embed_qk.to(torch.float32).contiguous()
-        scores_p = torch.empty((B, H, N, M), dtype=torch.float32, device=dev)
+        scores = torch.empty((B, H, N, M), dtype=torch.float32, device=dev)
+        hidden = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+        fac = None if attention_factors is None else attention_factors.to(torch.float32).contiguous()
+        kw = None if key_weights is None else key_weights.to(torch.float32).contiguous()
+        km = None if key_masks is None else key_masks.to(torch.uint8).contiguous()
         with torch.cuda.device(dev):
+            st = _lib.stream_ptr(dev)
             for b in range(B):
-                _lib.check(L.gr_rpe_scores(_lib.ptr(emb[b]), _lib.ptr(u[b]), _lib.ptr(add[b]), N, M, C, H,
-                                           _lib.ptr(scores_p[b]), _lib.stream_ptr(dev)))
-        scores = (torch.matmul(q, k.transpose(-1, -2)) + scores_p) / ch ** 0.5
-        if attention_factors is not None:
-            scores = attention_factors.unsqueeze(1) * scores
-        if key_weights is not None:
-            scores = scores * key_weights.unsqueeze(1).unsqueeze(1)
-        if key_masks is not None:
-            scores = scores.masked_fill(key_masks.unsqueeze(1).unsqueeze(1), float('-inf'))
-        scores = self.dropout(F.softmax(scores, dim=-1))
-        hidden = torch.matmul(scores, v).permute(0, 2, 1, 3).reshape(B, N, C)
+                _lib.check(L.gr_rpe_attention(_lib.ptr(emb[b]), _lib.ptr(u[b]), _lib.ptr(add[b]), _lib.ptr(q2[b]),
+                                              _lib.ptr(k2[b]), _lib.ptr(v2[b]), _lib.ptr(None if fac is None else fac[b]),
+                                              _lib.ptr(None if kw is None else kw[b]), _lib.ptr(None if km is None else km[b]),
+                                              N, M, C, H, _lib.ptr(scores[b]), _lib.ptr(hidden[b]), st))
+        if not isinstance(self.dropout, nn.Identity):
+            scores = self.dropout(scores)  # inference: identity (the reference applies dropout to the scores before @ v)
         return hidden, scores

@@ -297,6 +297,15 @@ int gr_geo_embedding(const float* points, int64_t n, const float* w_d, const flo
  * by the caller.  embed (n,m,c), u (n,heads,c), add (n,heads) or null, out (heads,n,m).  c in {64,128,256}. */
 int gr_rpe_scores(const float* embed, const float* u, const float* add, int64_t n, int64_t m, int64_t c,
                   int64_t heads, float* out, void* stream);
+/* gr_rpe_attention: the whole RPEMultiHeadAttention row pipeline of rpe_transformer.py:51-72 after the four input
+ * projections, fused per query row: scores = (q k^T + embed . u + add) / sqrt(c / heads), then attention_factors (n,m),
+ * key_weights (m), key_masks (m, uint8, nonzero = masked to -inf) -- each optional (null), applied in the reference's
+ * order -- softmax over the keys, and hidden = scores @ v.  q (n,c), k / v (m,c) are the projected tensors in their
+ * natural (rows, heads*channels) layout; embed (n,m,c); u (n,heads,c) and add (n,heads) as for gr_rpe_scores.
+ * Outputs: out_scores (heads,n,m) = the attention probabilities, out_hidden (n,c). */
+int gr_rpe_attention(const float* embed, const float* u, const float* add, const float* q, const float* k, const float* v,
+                     const float* attention_factors, const float* key_weights, const uint8_t* key_masks, int64_t n,
+                     int64_t m, int64_t c, int64_t heads, float* out_scores, float* out_hidden, void* stream);
 size_t gr_fps_workspace_bytes(int64_t n, int64_t batch);
 int gr_fps(const float* points, const int64_t* h_lengths, const int64_t* h_num_samples,
            const int64_t* h_start_indices, int64_t n, int64_t batch, int64_t* out_indices, void* ws,

@@ -139,6 +139,27 @@ def run(dev):
         ms = _ms(lambda: gse(pcs), 5, 1)
         n = pcs.shape[1]
         out["geo_embedding"] = _mfma(ms, 2.0 * n * n * 256 * 256 * 4, shape=[n, 256, 3], note="split-bf16 x6 MFMA, fp32-equivalent flops")
+        # ---- fused RPE attention (everything after the projections in one kernel; the embedding is the only N*M*C stream)
+        from gaussreg_amd import _lib
+        from gaussreg_amd.rpe_attention import RPEMultiHeadAttention
+        import ctypes
+        emb = gse(pcs)
+        att = RPEMultiHeadAttention(256, 4).to(dev)
+        xin = R(1, n, 256)
+        ms_mod = _ms(lambda: att(xin, xin, xin, emb), 10, 2)
+        Lh = _lib.lib()
+        Lh.gr_timing_reset()
+        Lh.gr_timing_enable(1)
+        for _ in range(5):
+            att(xin, xin, xin, emb)
+        torch.cuda.synchronize()
+        tot, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+        Lh.gr_timing_read(b"rpe_attention", ctypes.byref(tot), ctypes.byref(cnt))
+        Lh.gr_timing_enable(0)
+        Lh.gr_timing_reset()
+        out["rpe_attention_fused"] = _hbm(tot.value / max(cnt.value, 1), 4.0 * n * n * 256 + 4.0 * 4 * n * n + 3 * 4.0 * n * 256,
+                                          module_ms_incl_projections=round(ms_mod, 4), shape=[n, 256, 4])
+        del emb
         # ---- FPS 200 k -> 30 k, two clouds per call
         r_, s_, _ = pair_pipeline.synthetic_room_pair(0, 200000, dev)
         big = torch.cat([r_, s_]).contiguous()
