@@ -98,3 +98,19 @@ def tie_rows(q, s, nb):
     valid = nb != pad
     eq = (dist[:, 1:] == dist[:, :-1]) & valid[:, 1:] & valid[:, :-1]
     return np.nonzero(eq.any(axis=1))[0]
+
+
+def transformer_inputs(n_ref, n_src, c_in, seed=17):
+    """Superpoint-level inputs of the GeometricTransformer: two clouds in a 4 x 3 x 2.5 m room (the second one a rigid
+    motion of a jittered subset-like resample), features ~ N(0, 0.25) as the coarsest backbone stage delivers them."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    box = torch.tensor([4.0, 3.0, 2.5])
+    ref = torch.rand(1, n_ref, 3, generator=g) * box
+    src = torch.rand(1, n_src, 3, generator=g) * box
+    a = 0.4
+    rot = torch.tensor([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
+    src = (src.reshape(-1, 3, 1) * rot.t().reshape(1, 3, 3)).sum(1).reshape(1, n_src, 3) + torch.tensor([0.3, -0.2, 0.1])
+    rf = torch.randn(1, n_ref, c_in, generator=g) * 0.5
+    sf = torch.randn(1, n_src, c_in, generator=g) * 0.5
+    return ref.contiguous(), src.contiguous(), rf, sf

@@ -1,0 +1,43 @@
+"""CPU: the transformer mirrors carry the reference's state-dict keys and, built under the same seed, the reference's
+parameter values (checksums stored by tests/golden/gen_golden_transformer.py).  No compute: forward needs the GPU."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden
+
+
+def _sums(module):
+    return np.array([float(p.detach().double().sum()) for _, p in sorted(module.state_dict().items())], np.float64)
+
+
+def test_geometric_transformer_state_dict_matches_reference():
+    from geotransformer.modules.geotransformer import GeometricTransformer
+    g = load_golden("transformer.npz")
+    torch.manual_seed(int(g["seed"]))
+    net = GeometricTransformer(2048, 256, 256, 4, ['self', 'cross', 'self', 'cross', 'self', 'cross'], 0.2, 15, 3)
+    assert sorted(net.state_dict().keys()) == g["demo_keys"].tolist()
+    assert sum(p.numel() for p in net.parameters()) == int(g["demo_param_count"])
+    np.testing.assert_allclose(_sums(net), g["demo_param_sums"], rtol=0, atol=1e-9)
+
+
+def test_conditional_transformer_rejects_unknown_block():
+    from geotransformer.modules.transformer import RPEConditionalTransformer
+    with pytest.raises(ValueError, match='Unsupported block type "selfish"'):
+        RPEConditionalTransformer(['self', 'selfish'], 64, 4)
+
+
+def test_attention_rejects_bad_head_count():
+    from geotransformer.modules.transformer import MultiHeadAttention, RPEMultiHeadAttention
+    for cls in (MultiHeadAttention, RPEMultiHeadAttention):
+        with pytest.raises(ValueError, match=r"`d_model` \(64\) must be a multiple of `num_heads` \(3\)"):
+            cls(64, 3)
+
+
+def test_forward_without_gpu_fails_loudly():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from geotransformer.modules.transformer import TransformerLayer
+    layer = TransformerLayer(64, 4)
+    with pytest.raises(RuntimeError):
+        layer(torch.zeros(1, 5, 64), torch.zeros(1, 6, 64))
