@@ -29,12 +29,17 @@
 namespace gr {
 namespace {
 
-struct BatchGrid {
+struct BatchGrid {  // 64 bytes: copied to LDS as four int4
   double org[3];
-  double inv_cell;
-  int dim[3];
+  double inv_cell;    // y and z: cells of edge >= r (1 + 2^-10)
+  double inv_cell_x;  // x: `xk` sub-cells per cell -- the x window of a query shrinks from 3 r towards 2 r while every
+                      // (y, z) row of cells stays one contiguous range of the cell-sorted supports (x is the fastest index)
+  int dim[3];         // dim[0] counts the fine x cells
   int cell_base;
+  int xk;
+  int pad;
 };
+static_assert(sizeof(BatchGrid) == 64, "BatchGrid is staged in LDS as four int4");
 
 struct RadiusHdr {
   unsigned int max_count;
@@ -141,6 +146,24 @@ __global__ void grid_setup_kernel(const uint32_t* __restrict__ bbox,
       }
     }
     g.inv_cell = 1.0 / cell;
+    g.inv_cell_x = g.inv_cell;
+    g.xk = 1;
+    g.pad = 0;
+    if (n_b > 0 && isfinite(cell) && isfinite(g.inv_cell) && g.inv_cell > 0.0) {
+      // refine x only: a support within r of a query is within +-k fine cells of it (|dx| k / cell < k / (1 + 2^-10))
+      const double cap = (double)max(4096, 4 * n_b);
+      const double ext = (double)ord2f(bbox[b * 6 + 3]) - (double)ord2f(bbox[b * 6]);
+      for (int k = 8; k > 1; k >>= 1) {
+        const double inv_x = (double)k / cell;
+        const double ex = floor(ext * inv_x) + 1.0;
+        if (isfinite(ex) && ex * (double)g.dim[1] * (double)g.dim[2] <= cap && ex < 2147483647.0) {
+          g.xk = k;
+          g.inv_cell_x = inv_x;
+          g.dim[0] = (int)ex;
+          break;
+        }
+      }
+    }
     g.cell_base = 0;
     grids[b] = g;
   }
@@ -184,7 +207,7 @@ __device__ inline int clamped_cell(const BatchGrid& g, float x, float y, float z
   const float p[3] = {x, y, z};
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    double u = cell_coord(p[k], g.org[k], g.inv_cell);
+    double u = cell_coord(p[k], g.org[k], k == 0 ? g.inv_cell_x : g.inv_cell);
     u = fmin(fmax(u, 0.0), (double)(g.dim[k] - 1));  // NaN -> 0
     c[k] = (int)u;
   }
@@ -264,7 +287,7 @@ struct TravLds {
   // the FILL pass only needs offs, orig and wsum (laid out first): its hit segments start right after them
   static constexpr size_t FILL_OFF = (size_t)(((RQ + 1) + RQ + THREADS / WAVE) * 4 + 15) / 16 * 16;
   // COUNT pass: [int tables | q offsets of `tcap` clouds | their grids | candidate planes]
-  static __host__ __device__ size_t tables_bytes(int tcap) { return tcap > 0 ? ((size_t)(tcap + 1) * 4 + 15) / 16 * 16 + (size_t)tcap * 48 : 0; }
+  static __host__ __device__ size_t tables_bytes(int tcap) { return tcap > 0 ? ((size_t)(tcap + 1) * 4 + 15) / 16 * 16 + (size_t)tcap * sizeof(BatchGrid) : 0; }
   static constexpr size_t STAGE_BYTES = (size_t)STAGE_CAP * 12;  // three coordinate planes
   static size_t count_bytes(int tcap) { return TABLE_OFF + tables_bytes(tcap) + STAGE_BYTES; }
   // FILL: slots = hits + at most one pad slot per query, rounded to 16 so every block's key array stays 16-B aligned
@@ -325,7 +348,7 @@ __global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))
     for (int i = tid; i <= nb; i += L::THREADS) s_qoff[i] = q_off[i];
     const int4* gsrc = reinterpret_cast<const int4*>(grids);
     int4* gdst = reinterpret_cast<int4*>(s_grids);
-    for (int i = tid; i < nb * 3; i += L::THREADS) gdst[i] = gsrc[i];
+    for (int i = tid; i < nb * 4; i += L::THREADS) gdst[i] = gsrc[i];
   }
   int my_off = 0;
   float4 qp = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -387,14 +410,14 @@ __global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))
         b = find_batch(q_off, nb, __float_as_int(qp.w));
         g = grids[b];
       }
-      const double ux = cell_coord(qp.x, g.org[0], g.inv_cell);
+      const double ux = cell_coord(qp.x, g.org[0], g.inv_cell_x), kx = (double)g.xk;
       const double uy = cell_coord(qp.y, g.org[1], g.inv_cell);
       const double cz = cell_coord(qp.z, g.org[2], g.inv_cell) + (double)(j - 1);
       const double tx = (double)(g.dim[0] - 1), ty = (double)(g.dim[1] - 1), tz = (double)(g.dim[2] - 1);
       // the comparisons are written so that NaN coordinates give "no candidates"
-      if ((ux + 1.0 >= 0.0) && (ux - 1.0 <= tx) && cz >= 0.0 && cz <= tz) {
-        const int lx = (int)fmin(fmax(ux - 1.0, 0.0), tx);
-        const int hx = (int)fmin(fmax(ux + 1.0, 0.0), tx);
+      if ((ux + kx >= 0.0) && (ux - kx <= tx) && cz >= 0.0 && cz <= tz) {
+        const int lx = (int)fmin(fmax(ux - kx, 0.0), tx);
+        const int hx = (int)fmin(fmax(ux + kx, 0.0), tx);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           const double cy = uy + (double)(i - 1);
