@@ -227,6 +227,10 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   return ((unsigned long long)mh << 32) | ml;
 }
 
+// PPT = points per thread held in registers; instantiated for 4 / 7 / 10 / 13 / 16 / 20 so that a slab pays for the
+// points it has (a 12.2-point slab in the 20-point variant folded 64 % more distances than it owned).  Smaller
+// workgroups (256 threads, four per CU, to overlap one workgroup's exchange with the others' folding) measured SLOWER:
+// the exchange gets four times the slots to poll.
 template <int PPT>
 __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restrict__ pts, const int32_t* __restrict__ off,
                                                           const int32_t* __restrict__ samp_off,
@@ -520,7 +524,10 @@ extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64
       const void* fn;
       void** args = multi_args;
       if (per <= 4) fn = reinterpret_cast<const void*>(fps_multi_kernel<4>);
-      else if (per <= 12) fn = reinterpret_cast<const void*>(fps_multi_kernel<12>);
+      else if (per <= 7) fn = reinterpret_cast<const void*>(fps_multi_kernel<7>);
+      else if (per <= 10) fn = reinterpret_cast<const void*>(fps_multi_kernel<10>);
+      else if (per <= 13) fn = reinterpret_cast<const void*>(fps_multi_kernel<13>);
+      else if (per <= 16) fn = reinterpret_cast<const void*>(fps_multi_kernel<16>);
       else if (per <= 20) fn = reinterpret_cast<const void*>(fps_multi_kernel<20>);
       else {  // slab too large for registers: one sample per round, distances streamed from L2
         fn = reinterpret_cast<const void*>(fps_kernel<0>);
