@@ -145,7 +145,7 @@ __global__ __launch_bounds__(SCAN_T) void scan_add_kernel(int32_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------ per-cloud bounding boxes
-constexpr int BBOX_CHUNK = 2048;  // points per block
+constexpr int BBOX_CHUNK = 1024;  // points per block (3072 floats = 256 threads x 12: four batches of three independent loads)
 
 // Block `blk` reduces one BBOX_CHUNK-point slice of ONE cloud (blk_off[b] = first block of cloud
 // b), reading it as a flat, fully coalesced float stream, and issues 6 atomics.
@@ -160,15 +160,32 @@ __global__ __launch_bounds__(256) void bbox_kernel(const float* __restrict__ pts
   const int p_end = min(off[b0 + 1], p_first + BBOX_CHUNK);
   const int64_t f0 = (int64_t)p_first * 3, f1 = (int64_t)p_end * 3;
   uint32_t lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
-  for (int64_t f = f0 + threadIdx.x; f < f1; f += 256) {
-    const uint32_t v = f2ord(pts[f]);
-    const int ax = (int)(f % 3);
-    lo[0] = ax == 0 ? min(lo[0], v) : lo[0];
-    lo[1] = ax == 1 ? min(lo[1], v) : lo[1];
-    lo[2] = ax == 2 ? min(lo[2], v) : lo[2];
-    hi[0] = ax == 0 ? max(hi[0], v) : hi[0];
-    hi[1] = ax == 1 ? max(hi[1], v) : hi[1];
-    hi[2] = ax == 2 ? max(hi[2], v) : hi[2];
+  // the axis of element f is f % 3 and the stride is 256 = 1 (mod 3): a thread's elements cycle through the axes, so
+  // three consecutive loads (issued together) feed lo/hi[ax], [ax+1], [ax+2] -- no modulo, no dependent load chain
+  const int ax0 = (int)((f0 + threadIdx.x) % 3);
+  const float* src = pts + f0;
+  const int count = (int)(f1 - f0);
+  uint32_t l3[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, h3[3] = {0u, 0u, 0u};  // indexed by (axis - ax0) mod 3
+  for (int f = threadIdx.x; f < count; f += 3 * 256) {
+    uint32_t v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] = f + k * 256 < count ? f2ord(src[f + k * 256]) : 0u;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (f + k * 256 < count) {
+        l3[k] = min(l3[k], v[k]);
+        h3[k] = max(h3[k], v[k]);
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {  // slot k holds axis (ax0 + k) % 3
+    const int ax = ax0 + k >= 3 ? ax0 + k - 3 : ax0 + k;
+    lo[0] = ax == 0 ? l3[k] : lo[0];
+    lo[1] = ax == 1 ? l3[k] : lo[1];
+    lo[2] = ax == 2 ? l3[k] : lo[2];
+    hi[0] = ax == 0 ? h3[k] : hi[0];
+    hi[1] = ax == 1 ? h3[k] : hi[1];
+    hi[2] = ax == 2 ? h3[k] : hi[2];
   }
 #pragma unroll
   for (int d = WAVE / 2; d > 0; d >>= 1) {
@@ -203,12 +220,18 @@ __global__ void bbox_init_kernel(uint32_t* __restrict__ bbox, int nb) {
 }
 
 
-int compute_bbox(const float* pts, const int32_t* h_off, int32_t* blk, const int32_t* off_dev, int nb,
-                 uint32_t* bbox_dev, int32_t* blk_off_dev, hipStream_t stream) {
-  if (nb <= 0) return GR_OK;
+void bbox_block_offsets(const int32_t* h_off, int32_t* blk, int nb) {
   blk[0] = 0;
   for (int b = 0; b < nb; ++b) blk[b + 1] = blk[b] + (h_off[b + 1] - h_off[b] + BBOX_CHUNK - 1) / BBOX_CHUNK;
-  GR_HIP(hipMemcpyAsync(blk_off_dev, blk, sizeof(int32_t) * (nb + 1), hipMemcpyHostToDevice, stream));
+}
+
+int compute_bbox(const float* pts, const int32_t* h_off, int32_t* blk, const int32_t* off_dev, int nb,
+                 uint32_t* bbox_dev, int32_t* blk_off_dev, hipStream_t stream, bool blk_off_on_device) {
+  if (nb <= 0) return GR_OK;
+  if (!blk_off_on_device) {
+    bbox_block_offsets(h_off, blk, nb);
+    GR_HIP(hipMemcpyAsync(blk_off_dev, blk, sizeof(int32_t) * (nb + 1), hipMemcpyHostToDevice, stream));
+  }
   hipLaunchKernelGGL(bbox_init_kernel, dim3((nb * 6 + 255) / 256), dim3(256), 0, stream, bbox_dev, nb);
   if (blk[nb] > 0)
     hipLaunchKernelGGL(bbox_kernel, dim3(blk[nb]), dim3(256), 0, stream, pts, off_dev, blk_off_dev, nb, bbox_dev);

@@ -85,8 +85,11 @@ int exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int rows, int
 // stored as order-preserving uints (decode with ord2f).  Empty clouds keep (0xffffffff, 0).
 // h_off: host copy of the nb+1 point offsets; h_blk: nb+1 ints of HOST scratch that must stay
 // alive until the stream is synchronised; blk_off_dev: nb+1 ints of device scratch.
+// blk_off_on_device: the caller has filled h_blk with bbox_block_offsets() and copied it to blk_off_dev itself (to
+// merge several small host-to-device copies into one).
+void bbox_block_offsets(const int32_t* h_off, int32_t* h_blk, int nb);
 int compute_bbox(const float* pts, const int32_t* h_off, int32_t* h_blk, const int32_t* off_dev, int nb,
-                 uint32_t* bbox_dev, int32_t* blk_off_dev, hipStream_t stream);
+                 uint32_t* bbox_dev, int32_t* blk_off_dev, hipStream_t stream, bool blk_off_on_device = false);
 
 // Stable LSD radix sort of (u64 key, i32 value) pairs on bits [begin_bit, end_bit) (rocPRIM).
 size_t sort_pairs_temp_bytes(int64_t n);
