@@ -51,7 +51,7 @@ def parse(argv=None):
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--clouds", type=int, default=8, help="200k-point clouds per radius step (per GPU)")
     ap.add_argument("--pairs", type=int, default=128, help="scene pairs per GPU in the configs[4] workload (0 = skip)")
-    ap.add_argument("--pair-batch", type=int, default=16, help="pairs per pyramid call")
+    ap.add_argument("--pair-batch", type=int, default=64, help="pairs per pyramid call")
     ap.add_argument("--pair-points", type=int, default=200_000, help="points per cloud before FPS")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-radius", action="store_true")

@@ -15,6 +15,7 @@ transform can be scored against the ground truth -- without pretending to have r
 Pairs are independent units: `register_pairs` is what one rank runs on its block of the pair list (gaussreg_amd/sharding.py).
 """
 import math
+import time
 
 import torch
 
@@ -90,11 +91,40 @@ def rotation_error_deg(Ra, Rb):
     return torch.rad2deg(torch.arccos(c.clamp(-1.0, 1.0)))
 
 
+class _Section:
+    def __init__(self, owner, name):
+        self.owner, self.name = owner, name
+
+    def __enter__(self):
+        if self.owner.profile:
+            torch.cuda.synchronize(self.owner.device)
+            self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        if self.owner.profile:
+            torch.cuda.synchronize(self.owner.device)
+            d = self.owner.section_ms
+            d[self.name] = d.get(self.name, 0.0) + (time.perf_counter() - self.t0) * 1e3
+        return False
+
+
 class PairRegistrar:
     """Holds the stateless operator modules and the descriptors; `register_pairs` runs a batch."""
 
-    def __init__(self, device, num_samples=30000, fps_clouds_per_call=16, order="reference", use_ransac=True):
+    def __init__(self, device, num_samples=30000, fps_clouds_per_call=16, order="reference", use_ransac=True,
+                 profile=False, pair_streams=4):
+        """`pair_streams`: after the batched stages (FPS, pyramid) every pair runs its own short chain of launch-bound
+        kernels with two host read-backs (correspondence count, RANSAC result); `pair_streams` host threads, each with
+        its own HIP stream, work through the pairs so that one pair's read-back waits while the others' kernels run
+        (results are identical to the sequential order: nothing is shared between pairs).  1 = one after the other.
+        `profile=True`: `section_ms` accumulates wall milliseconds per stage (a device synchronise on both sides of
+        every stage, pairs one after the other: the total is slower than an unprofiled run)."""
         self.device = device
+        self.profile = bool(profile)
+        self.section_ms = {}
+        self.pair_streams = max(1, int(pair_streams))
+        self._pool = None
+        self._streams = None
         self.num_samples = int(num_samples)
         self.fps_clouds_per_call = int(fps_clouds_per_call)
         self.order = order
@@ -106,6 +136,9 @@ class PairRegistrar:
         # fine_matching block of config.py:116-125
         self.lgr = LocalGlobalRegistration(3, 0.1, True, 0.05, False, False, 3, None, 5)
 
+    def _sec(self, name):
+        return _Section(self, name)
+
     @torch.no_grad()
     def register_pairs(self, pairs):
         """pairs: list of (ref (n,3), src (m,3), T_gt (4,4) or None) device tensors.
@@ -115,21 +148,23 @@ class PairRegistrar:
         # ---- FPS, several clouds per call (stack order [ref_1..ref_B, src_1..src_B] like data.py:151-155)
         clouds = [p[0] for p in pairs] + [p[1] for p in pairs]
         sampled = []
-        for i in range(0, 2 * B, self.fps_clouds_per_call):
-            chunk = clouds[i:i + self.fps_clouds_per_call]
-            lens = [c.shape[0] for c in chunk]
-            ks = [min(self.num_samples, n) for n in lens]
-            if all(k == n for k, n in zip(ks, lens)):
-                sampled += chunk
-                continue
-            idx = farthest_point_sampling(torch.cat(chunk, 0), lens, ks)
-            sampled += [c[ix] for c, ix in zip(chunk, idx)]
-        points = torch.cat(sampled, 0).contiguous()
-        lengths = torch.tensor([c.shape[0] for c in sampled], dtype=torch.int64)
+        with self._sec("fps"):
+            for i in range(0, 2 * B, self.fps_clouds_per_call):
+                chunk = clouds[i:i + self.fps_clouds_per_call]
+                lens = [c.shape[0] for c in chunk]
+                ks = [min(self.num_samples, n) for n in lens]
+                if all(k == n for k, n in zip(ks, lens)):
+                    sampled += chunk
+                    continue
+                idx = farthest_point_sampling(torch.cat(chunk, 0), lens, ks)
+                sampled += [c[ix] for c, ix in zip(chunk, idx)]
         # ---- the 5-level pyramid for the whole batch in one stack-mode pass (4 grid_subsample + 13 radius_search)
-        pyr = precompute_data_stack_mode(points, lengths, NUM_STAGES, INIT_VOXEL, INIT_RADIUS, NEIGHBOR_LIMITS,
-                                         order=self.order)
-        len_c, len_f = pyr["lengths"][-1].tolist(), pyr["lengths"][1].tolist()
+        with self._sec("pyramid"):
+            points = torch.cat(sampled, 0).contiguous()
+            lengths = torch.tensor([c.shape[0] for c in sampled], dtype=torch.int64)
+            pyr = precompute_data_stack_mode(points, lengths, NUM_STAGES, INIT_VOXEL, INIT_RADIUS, NEIGHBOR_LIMITS,
+                                             order=self.order)
+            len_c, len_f = pyr["lengths"][-1].tolist(), pyr["lengths"][1].tolist()
         off_c = [0]
         off_f = [0]
         for a, b in zip(len_c, len_f):
@@ -137,23 +172,57 @@ class PairRegistrar:
             off_f.append(off_f[-1] + b)
         pts_c, pts_f = pyr["points"][-1], pyr["points"][1]
         out = torch.zeros((B, RESULT_LEN), dtype=torch.float32, device=dev)
-        for b in range(B):
-            T_gt = pairs[b][2]
-            ref_c = pts_c[off_c[b]:off_c[b + 1]]
-            src_c = pts_c[off_c[B + b]:off_c[B + b + 1]]
-            ref_f = pts_f[off_f[b]:off_f[b + 1]]
-            src_f = pts_f[off_f[B + b]:off_f[B + b + 1]]
-            # model.py:99-104
+        pad = torch.zeros((1, 3), device=dev)                            # model.py:171-172
+        ctx = (pairs, B, pts_c, pts_f, off_c, off_f, pad, out)
+        S = 1 if self.profile else min(self.pair_streams, B)
+        if S <= 1:
+            for b in range(B):
+                self._register_one(b, ctx)
+        else:
+            if self._pool is None:
+                import concurrent.futures
+                self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=self.pair_streams)
+                self._streams = [torch.cuda.Stream(device=dev) for _ in range(self.pair_streams)]
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(dev))
+
+            def work(k):
+                torch.cuda.set_device(dev)
+                st = self._streams[k]
+                st.wait_event(ready)                       # the pyramid was built on the caller's stream
+                with torch.cuda.stream(st):
+                    for b in range(k, B, S):
+                        self._register_one(b, ctx)
+                done = torch.cuda.Event()
+                done.record(st)
+                return done
+
+            for ev in [f.result() for f in [self._pool.submit(work, k) for k in range(S)]]:
+                torch.cuda.current_stream(dev).wait_event(ev)
+        return out
+
+    @torch.no_grad()   # grad mode is per thread: the worker threads need their own
+    def _register_one(self, b, ctx):
+        """Everything after the pyramid for pair b (model.py:99-220), on the current stream."""
+        pairs, B, pts_c, pts_f, off_c, off_f, pad, out = ctx
+        dev = self.device
+        T_gt = pairs[b][2]
+        ref_c = pts_c[off_c[b]:off_c[b + 1]]
+        src_c = pts_c[off_c[B + b]:off_c[B + b + 1]]
+        ref_f = pts_f[off_f[b]:off_f[b + 1]]
+        src_f = pts_f[off_f[B + b]:off_f[B + b + 1]]
+        to_ref = (lambda x: x @ T_gt[:3, :3].T + T_gt[:3, 3]) if T_gt is not None else (lambda x: x)
+        with self._sec("point_to_node"):                            # model.py:99-104
             _, ref_node_masks, ref_knn_idx, ref_knn_masks = point_to_node_partition(ref_f, ref_c, POINT_LIMIT)
             _, src_node_masks, src_knn_idx, src_knn_masks = point_to_node_partition(src_f, src_c, POINT_LIMIT)
+        with self._sec("coarse_features"):
             # stand-in for the learned features (see module docstring): descriptors in the reference frame
-            to_ref = (lambda x: x @ T_gt[:3, :3].T + T_gt[:3, 3]) if T_gt is not None else (lambda x: x)
             ref_feats_c = torch.nn.functional.normalize(self.coarse_desc(ref_c), p=2, dim=1)
             src_feats_c = torch.nn.functional.normalize(self.coarse_desc(to_ref(src_c)), p=2, dim=1)
-            # model.py:152-159
+        with self._sec("superpoint_matching"):                      # model.py:152-159
             ref_ci, src_ci, node_scores = self.spm(ref_feats_c, src_feats_c, ref_node_masks, src_node_masks)
+        with self._sec("patch_features"):
             # model.py:162-190: patches around the matched superpoints (pad row = index N, a far-away point)
-            pad = torch.zeros((1, 3), device=dev)                       # model.py:171-172
             ref_pad, src_pad = torch.cat([ref_f, pad], 0), torch.cat([src_f, pad], 0)
             rk, sk = ref_knn_idx[ref_ci], src_knn_idx[src_ci]
             rkm, skm = ref_knn_masks[ref_ci], src_knn_masks[src_ci]
@@ -161,11 +230,15 @@ class PairRegistrar:
             rkf = self.fine_desc(rkp) * rkm[..., None]
             skf = self.fine_desc(to_ref(skp)) * skm[..., None]
             scores = torch.einsum('bnd,bmd->bnm', rkf, skf) * (rkf.shape[-1] ** 0.5)
+        with self._sec("sinkhorn"):
             matching = self.ot(scores, rkm, skm)[:, :-1, :-1]     # model.py:191-198 (dustbins dropped)
+        with self._sec("local_global_registration"):
             rc, sc, cs, T = self.lgr(rkp, skp, rkm, skm, matching, node_scores)   # model.py:200-207
             n_corr = rc.shape[0]
-            if self.use_ransac and n_corr >= 3:                  # model.py:209-220 (the estimate the reference keeps)
+        with self._sec("ransac"):
+            if self.use_ransac and n_corr >= 3:              # model.py:209-220 (the estimate the reference keeps)
                 T = registration_with_ransac_from_correspondences(sc, rc, None, 0.05, 3, 10000, seed=b)
+        with self._sec("metrics"):
             out[b, :16] = T.reshape(-1)
             out[b, 18] = float(n_corr)
             if T_gt is not None:
@@ -176,4 +249,3 @@ class PairRegistrar:
                 if n_corr > 0:
                     resid = torch.linalg.norm(to_ref(sc) - rc, dim=1)
                     out[b, 19] = (resid < 0.1).float().mean()
-        return out

@@ -7,7 +7,8 @@ import json
 import sys
 
 KEEP = ("blend_kernel", "preprocess_kernel", "traverse_kernel", "ds_scatter_kernel", "ds_count_kernel", "ds_scan_kernel",
-        "tile_scatter_kernel", "tile_count_kernel", "seg_scan_kernel", "scatter_kernel", "bin_count_kernel")
+        "tile_scatter_kernel", "tile_count_kernel", "seg_scan_kernel", "scatter_kernel", "bin_count_kernel",
+        "rpe_attention_kernel", "geo_embedding", "fps_multi_kernel", "kpconv")
 
 
 def short(name):
