@@ -231,13 +231,23 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 // points it has (a 12.2-point slab in the 20-point variant folded 64 % more distances than it owned).  Smaller
 // workgroups (256 threads, four per CU, to overlap one workgroup's exchange with the others' folding) measured SLOWER:
 // the exchange gets four times the slots to poll.
+//
+// Bucket pruning (what fpsample's kd-line buckets do on the CPU, here at wave granularity): the cloud arrives sorted along a
+// Morton curve (`spts`, with `perm` = position -> original index), every wave owns a CONTIGUOUS run of it and keeps that
+// run's bounding box and the largest running distance of its points.  A new sample that is farther from the box than
+// that distance cannot lower any of them: the wave skips the fold, and a wave no sample reached this round also keeps
+// the candidates it published last round.  After the first few hundred samples that is almost every wave in almost
+// every round; results are exactly those of the unpruned algorithm (keys carry the ORIGINAL index).
 template <int PPT>
-__global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restrict__ pts, const int32_t* __restrict__ off,
+__global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restrict__ pts, const float* __restrict__ spts,
+                                                          const int32_t* __restrict__ perm,
+                                                          const int32_t* __restrict__ off,
                                                           const int32_t* __restrict__ samp_off,
                                                           const int32_t* __restrict__ start_idx,
                                                           unsigned long long* __restrict__ slots_all,
                                                           int* __restrict__ err, int G, int64_t* __restrict__ out) {
   constexpr int M = FPS_M, MG = FPS_MG, MW = FPS_MW, NW = FPS_T / WAVE;
+  extern __shared__ int s_perm[];  // [PPT][FPS_T] original (cloud-local) index of every point this workgroup holds
   __shared__ unsigned long long s_wtop[NW * MW];
   __shared__ unsigned long long s_wbound[NW];
   __shared__ float s_acc[MG][4];
@@ -247,20 +257,37 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
   const int p0 = off[b], n = off[b + 1] - p0;
   const int o0 = samp_off[b], k = samp_off[b + 1] - o0;
   if (n <= 0 || k <= 0) return;
-  const float* P = pts + 3 * (int64_t)p0;
+  const float* P = pts + 3 * (int64_t)p0;    // original order: candidate coordinates by original index
+  const float* S = spts + 3 * (int64_t)p0;   // Morton order: the points this thread folds
   const int per = ((n + G - 1) / G + FPS_T - 1) / FPS_T * FPS_T;
   const int lo = min(part * per, n), hi = min(lo + per, n);
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  const int ppt_used = per / FPS_T;              // <= PPT
+  const int wave_lo = lo + wv * ppt_used * WAVE;  // this wave's run: ppt_used * 64 consecutive Morton positions
   float px[PPT], py[PPT], pz[PPT], pd[PPT];
+  float bx0 = INFINITY, by0 = INFINITY, bz0 = INFINITY, bx1 = -INFINITY, by1 = -INFINITY, bz1 = -INFINITY;
+  unsigned valid_mask = 0u;
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
-    const int i = lo + j * FPS_T + threadIdx.x;
-    const bool v = i < hi;
-    px[j] = v ? P[3 * i] : 0.f;
-    py[j] = v ? P[3 * i + 1] : 0.f;
-    pz[j] = v ? P[3 * i + 2] : 0.f;
+    const int i = wave_lo + j * WAVE + lane;
+    const bool v = j < ppt_used && i < hi;
+    px[j] = v ? S[3 * i] : 0.f;
+    py[j] = v ? S[3 * i + 1] : 0.f;
+    pz[j] = v ? S[3 * i + 2] : 0.f;
     pd[j] = INFINITY;
+    s_perm[j * FPS_T + threadIdx.x] = v ? perm[p0 + i] : 0;
+    if (v) {
+      valid_mask |= 1u << j;
+      bx0 = fminf(bx0, px[j]), by0 = fminf(by0, py[j]), bz0 = fminf(bz0, pz[j]);
+      bx1 = fmaxf(bx1, px[j]), by1 = fmaxf(by1, py[j]), bz1 = fmaxf(bz1, pz[j]);
+    }
   }
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) {
+    bx0 = fminf(bx0, __shfl_xor(bx0, d, WAVE)), by0 = fminf(by0, __shfl_xor(by0, d, WAVE)), bz0 = fminf(bz0, __shfl_xor(bz0, d, WAVE));
+    bx1 = fmaxf(bx1, __shfl_xor(bx1, d, WAVE)), by1 = fmaxf(by1, __shfl_xor(by1, d, WAVE)), bz1 = fmaxf(bz1, __shfl_xor(bz1, d, WAVE));
+  }
+  float wave_maxd = INFINITY;  // largest running distance among this wave's points (wave-uniform)
   const int start = start_idx ? min(max(start_idx[b], 0), n - 1) : 0;
   if (threadIdx.x == 0) {
     s_acc[0][0] = P[3 * start];
@@ -280,8 +307,16 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
     const int na = s_na;
     // sample-major: one LDS read of the sample, then all of this thread's points two at a time (packed fp32 --
     // the same sub / mul / add sequence as the scalar form, so distances stay bit-identical)
+    bool touched = round == 2;  // first round: every wave publishes (a wave without points has an empty box: inf >= inf)
     for (int a = 0; a < na; ++a) {
       const float ax = s_acc[a][0], ay = s_acc[a][1], az = s_acc[a][2];
+      // distance from the sample to the wave's box, rounded down by more than the fold's own rounding (8 ulp-steps):
+      // at or beyond wave_maxd no running distance of this wave can drop
+      const float ex = fmaxf(fmaxf(bx0 - ax, ax - bx1), 0.f), ey = fmaxf(fmaxf(by0 - ay, ay - by1), 0.f),
+                  ez = fmaxf(fmaxf(bz0 - az, az - bz1), 0.f);
+      const float lb = ((ex * ex + ey * ey) + ez * ez) * (1.0f - 9.5367431640625e-7f);
+      if (__builtin_amdgcn_readfirstlane(lb >= wave_maxd ? 1 : 0)) continue;
+      touched = true;
       const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
 #pragma unroll
       for (int j = 0; j + 1 < PPT; j += 2) {
@@ -295,31 +330,33 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
         pd[PPT - 1] = fminf(pd[PPT - 1], (dx * dx + dy * dy) + dz * dz);
       }
     }
-    unsigned long long best = 0ull, second = 0ull;
+    if (touched) {  // wave-uniform; otherwise s_wtop / s_wbound still hold this wave's candidates of the last round
+      unsigned long long best = 0ull, second = 0ull;
 #pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      const int i = lo + j * FPS_T + threadIdx.x;
-      if (i < hi) {
-        const unsigned long long kk = fps_key(pd[j], i);
-        if (kk > best) {
-          second = best;
-          best = kk;
-        } else if (kk > second) {
-          second = kk;
+      for (int j = 0; j < PPT; ++j) {
+        if ((valid_mask >> j) & 1u) {
+          const unsigned long long kk = fps_key(pd[j], s_perm[j * FPS_T + threadIdx.x]);
+          if (kk > best) {
+            second = best;
+            best = kk;
+          } else if (kk > second) {
+            second = kk;
+          }
         }
       }
-    }
-    // ---- 2. top-M of the wave's bests (unique keys: exactly one lane owns each maximum); the rest bounds B
-    unsigned long long mine = best;
+      // ---- 2. top-M of the wave's bests (unique keys: exactly one lane owns each maximum); the rest bounds B
+      unsigned long long mine = best;
 #pragma unroll
-    for (int r = 0; r < MW; ++r) {
-      const unsigned long long w = wave_max_u64(mine);
-      if (lane == 0) s_wtop[wv * MW + r] = w;
-      if (mine == w) mine = 0ull;
-    }
-    {
-      const unsigned long long wb = wave_max_u64(mine > second ? mine : second);
-      if (lane == 0) s_wbound[wv] = wb;
+      for (int r = 0; r < MW; ++r) {
+        const unsigned long long w = wave_max_u64(mine);
+        if (lane == 0) s_wtop[wv * MW + r] = w;
+        if (r == 0) wave_maxd = __uint_as_float((unsigned)(w >> 32));  // keys order by distance first
+        if (mine == w) mine = 0ull;
+      }
+      {
+        const unsigned long long wb = wave_max_u64(mine > second ? mine : second);
+        if (lane == 0) s_wbound[wv] = wb;
+      }
     }
     __syncthreads();
     // ---- 3. wave 0: workgroup top-M, exchange, global top-M, acceptance
@@ -443,6 +480,44 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------- Morton order (for the bucket pruning above)
+__device__ __forceinline__ unsigned spread3(unsigned v) {  // 10 bits -> every third bit
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+// key = cloud << 32 | 30-bit Morton code of the point inside its cloud's bounding cube (1024 cells per axis)
+__global__ __launch_bounds__(256) void fps_morton_kernel(const float* __restrict__ pts, const int32_t* __restrict__ off, int nb,
+                                                         const uint32_t* __restrict__ bbox, int n,
+                                                         unsigned long long* __restrict__ keys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = find_batch(off, nb, i);
+  const float mnx = ord2f(bbox[b * 6]), mny = ord2f(bbox[b * 6 + 1]), mnz = ord2f(bbox[b * 6 + 2]);
+  const float ext = fmaxf(fmaxf(ord2f(bbox[b * 6 + 3]) - mnx, ord2f(bbox[b * 6 + 4]) - mny), ord2f(bbox[b * 6 + 5]) - mnz);
+  const float sc = ext > 0.f && isfinite(ext) ? 1023.0f / ext : 0.f;
+  const unsigned cx = (unsigned)fminf(fmaxf((pts[3 * (int64_t)i] - mnx) * sc, 0.f), 1023.f);      // NaN -> 0
+  const unsigned cy = (unsigned)fminf(fmaxf((pts[3 * (int64_t)i + 1] - mny) * sc, 0.f), 1023.f);
+  const unsigned cz = (unsigned)fminf(fmaxf((pts[3 * (int64_t)i + 2] - mnz) * sc, 0.f), 1023.f);
+  keys[i] = ((unsigned long long)(unsigned)b << 32) | (spread3(cx) | (spread3(cy) << 1) | (spread3(cz) << 2));
+}
+
+// sorted position j holds global point vals[j]: copy its coordinates, keep its cloud-local index
+__global__ __launch_bounds__(256) void fps_gather_kernel(const float* __restrict__ pts, const int32_t* __restrict__ off, int nb,
+                                                         const int32_t* __restrict__ vals, int n, float* __restrict__ spts,
+                                                         int32_t* __restrict__ perm) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int g = vals[j];
+  spts[3 * (int64_t)j] = pts[3 * (int64_t)g];
+  spts[3 * (int64_t)j + 1] = pts[3 * (int64_t)g + 1];
+  spts[3 * (int64_t)j + 2] = pts[3 * (int64_t)g + 2];
+  perm[j] = g - off[find_batch(off, nb, j)];  // clouds stay in place: position j and point g belong to the same cloud
+}
+
 }  // namespace
 }  // namespace gr
 
@@ -452,7 +527,11 @@ extern "C" size_t gr_fps_workspace_bytes(int64_t n, int64_t batch) {
   if (n < 0 || batch < 0) return 0;
   return align_up((size_t)n * 4, 256) + 3 * align_up((size_t)(batch + 1) * 4, 256) +
          align_up((size_t)batch * 2 * FPS_GMAX * sizeof(FpsCand), 256) + align_up((size_t)(batch + 1) * 4, 256) +
-         align_up((size_t)batch * 2 * FPS_GMAX * FPS_SLOT_W * 8, 256) + 512;
+         align_up((size_t)batch * 2 * FPS_GMAX * FPS_SLOT_W * 8, 256) +
+         // Morton pre-pass: keys in/out, values out, sorted points, permutation, bounding boxes, rocPRIM scratch
+         2 * align_up((size_t)n * 8, 256) + 2 * align_up((size_t)n * 4, 256) + align_up((size_t)n * 12, 256) +
+         align_up((size_t)batch * 6 * 4, 256) + align_up((size_t)(batch + 1) * 4, 256) + align_up(sort_pairs_temp_bytes(n), 256) +
+         512;
 }
 
 extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64_t* h_num_samples,
@@ -495,6 +574,16 @@ extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64
   FpsCand* cand = c.take<FpsCand>((size_t)batch * 2 * FPS_GMAX);
   unsigned* arrive = c.take<unsigned>(batch + 1);  // [batch] = error flag
   unsigned long long* mslots = c.take<unsigned long long>((size_t)batch * 2 * FPS_GMAX * FPS_SLOT_W);
+  uint64_t* mkeys_a = c.take<uint64_t>(n);
+  uint64_t* mkeys_b = c.take<uint64_t>(n);
+  int32_t* mvals = c.take<int32_t>(n);
+  int32_t* mperm = c.take<int32_t>(n);
+  float* spts = c.take<float>((size_t)n * 3);
+  uint32_t* mbbox = c.take<uint32_t>(batch * 6);
+  int32_t* mblk = c.take<int32_t>(batch + 1);
+  const size_t sort_bytes = sort_pairs_temp_bytes(n);
+  void* sort_tmp = c.take<char>(sort_bytes);
+  bool morton_done = false;
   GR_HIP(hipMemcpyAsync(d_off, off.data(), sizeof(int32_t) * (batch + 1), hipMemcpyHostToDevice, stream));
   GR_HIP(hipMemcpyAsync(d_soff, soff.data(), sizeof(int32_t) * (batch + 1), hipMemcpyHostToDevice, stream));
   GR_HIP(hipMemcpyAsync(d_st, st.data(), sizeof(int32_t) * batch, hipMemcpyHostToDevice, stream));
@@ -514,28 +603,50 @@ extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64
     GR_HIP(hipMemsetAsync(cand, 0, sizeof(FpsCand) * (size_t)batch * 2 * FPS_GMAX, stream));
     GR_HIP(hipMemsetAsync(mslots, 0, sizeof(unsigned long long) * (size_t)batch * 2 * FPS_GMAX * FPS_SLOT_W, stream));
     bool launched = true;
+    if (per <= 20 && !morton_done) {
+      // Morton order for the bucket pruning: boxes, keys, one radix sort over (cloud, code), gather
+      std::vector<int32_t> h_blk(batch + 1);
+      int rc = compute_bbox(points, off.data(), h_blk.data(), d_off, (int)batch, mbbox, mblk, stream);
+      if (rc != GR_OK) return rc;
+      const unsigned nblk = (unsigned)((n + 255) / 256);
+      hipLaunchKernelGGL(fps_morton_kernel, dim3(nblk), dim3(256), 0, stream, points, d_off, (int)batch, mbbox, (int)n,
+                         reinterpret_cast<unsigned long long*>(mkeys_a));
+      int cloud_bits = 1;
+      while ((1ll << cloud_bits) < batch) ++cloud_bits;
+      rc = sort_pairs_u64_iota(sort_tmp, sort_bytes, mkeys_a, mkeys_b, (int64_t)1 << 40, mvals, n, 0, 32 + cloud_bits, stream);
+      if (rc != GR_OK) return rc;
+      hipLaunchKernelGGL(fps_gather_kernel, dim3(nblk), dim3(256), 0, stream, points, d_off, (int)batch, mvals, (int)n, spts, mperm);
+      GR_LAUNCH_CHECK();
+      GR_HIP(hipStreamSynchronize(stream));  // h_blk lives on this stack frame
+      morton_done = true;
+    }
     {
       KernelTimer timer("fps", stream);
       const dim3 grid((unsigned)(batch * G)), block(FPS_T);
       const float* a_points = points;
+      const float* a_spts = spts;
+      const int32_t* a_perm = mperm;
       int a_G = G;
-      void* multi_args[] = {&a_points, &d_off, &d_soff, &d_st, &mslots, &err, &a_G, &out_indices};
+      void* multi_args[] = {&a_points, &a_spts, &a_perm, &d_off, &d_soff, &d_st, &mslots, &err, &a_G, &out_indices};
       void* single_args[] = {&a_points, &d_off, &d_soff, &d_st, &mind, &cand, &err, &a_G, &out_indices};
       const void* fn;
       void** args = multi_args;
-      if (per <= 4) fn = reinterpret_cast<const void*>(fps_multi_kernel<4>);
-      else if (per <= 7) fn = reinterpret_cast<const void*>(fps_multi_kernel<7>);
-      else if (per <= 10) fn = reinterpret_cast<const void*>(fps_multi_kernel<10>);
-      else if (per <= 13) fn = reinterpret_cast<const void*>(fps_multi_kernel<13>);
-      else if (per <= 16) fn = reinterpret_cast<const void*>(fps_multi_kernel<16>);
-      else if (per <= 20) fn = reinterpret_cast<const void*>(fps_multi_kernel<20>);
-      else {  // slab too large for registers: one sample per round, distances streamed from L2
+      size_t lds = 0;  // the workgroup's original indices: PPT * 1024 ints
+      if (per <= 4) fn = reinterpret_cast<const void*>(fps_multi_kernel<4>), lds = 4;
+      else if (per <= 7) fn = reinterpret_cast<const void*>(fps_multi_kernel<7>), lds = 7;
+      else if (per <= 10) fn = reinterpret_cast<const void*>(fps_multi_kernel<10>), lds = 10;
+      else if (per <= 13) fn = reinterpret_cast<const void*>(fps_multi_kernel<13>), lds = 13;
+      else if (per <= 16) fn = reinterpret_cast<const void*>(fps_multi_kernel<16>), lds = 16;
+      else if (per <= 20) fn = reinterpret_cast<const void*>(fps_multi_kernel<20>), lds = 20;
+      lds *= (size_t)FPS_T * sizeof(int);
+      if (lds > 48 * 1024) GR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
+      if (per > 20) {  // slab too large for registers: one sample per round, distances streamed from L2
         fn = reinterpret_cast<const void*>(fps_kernel<0>);
         args = single_args;
       }
       hipError_t le;
-      if (G > 1) le = hipLaunchCooperativeKernel(fn, grid, block, args, 0, stream);
-      else le = hipLaunchKernel(fn, grid, block, args, 0, stream);
+      if (G > 1) le = hipLaunchCooperativeKernel(fn, grid, block, args, (unsigned)lds, stream);
+      else le = hipLaunchKernel(fn, grid, block, args, lds, stream);
       if (le != hipSuccess) {
         (void)hipGetLastError();
         if (G > 1 && attempt == 0) launched = false;  // grid not co-resident on this device: fall back
@@ -550,6 +661,7 @@ extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64
     GR_HIP(hipMemcpyAsync(&h_err, err, sizeof(int), hipMemcpyDeviceToHost, stream));
     GR_HIP(hipStreamSynchronize(stream));  // also keeps the host staging vectors alive past the copies
     if (h_err == 0) return GR_OK;
+    if (getenv("GR_FPS_VERBOSE")) fprintf(stderr, "gr_fps: exchange timed out (G=%d, batch=%lld, per=%lld); retrying with one workgroup per cloud\n", G, (long long)batch, (long long)per);
     GR_REQUIRE(attempt == 0 && G > 1, "fps: exchange timed out with a single workgroup per cloud (internal error)");
   }
   set_error("fps: inter-workgroup exchange timed out and the single-workgroup retry was not possible");
