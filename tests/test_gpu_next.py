@@ -263,3 +263,28 @@ def test_fps_register_and_streaming_slabs(n, batch, k):
     got = farthest_point_sampling(_c(pts), [n] * batch, [k] * batch, start_indices=[b % 7 for b in range(batch)])
     for b in (0, batch // 2, batch - 1):
         assert np.array_equal(got[b].cpu().numpy(), M.farthest_point_sampling(pts[b * n:(b + 1) * n], k, b % 7))
+
+
+@pytest.mark.parametrize("n,batch,k", [(7000, 1, 300), (7000, 2, 300), (50000, 32, 120), (200000, 8, 400)])
+def test_fps_pruned_rounds_stay_exact(n, batch, k):
+    """The bucket pruning (Morton-ordered slabs, per-wave boxes) must not change a single index: clouds with empty waves
+    and empty slabs (the run lengths of these sizes), surface-like clouds (most waves far from any new sample), and
+    exact duplicates (equal distances: the key's ORIGINAL index breaks the tie, not the Morton position)."""
+    from gaussreg_amd.registration import farthest_point_sampling
+    from oracle import matching_np as M
+    rng = np.random.default_rng(7 * n + batch)
+    clouds = []
+    for b in range(batch):
+        uv = rng.random((n, 2)).astype(np.float32)
+        wall = rng.integers(0, 3, n)
+        p = np.zeros((n, 3), np.float32)                      # three walls of a 4 x 3 x 2.5 room, 1 cm of noise
+        p[:, 0] = np.where(wall == 0, 0.0, uv[:, 0] * 4)
+        p[:, 1] = np.where(wall == 1, 0.0, np.where(wall == 0, uv[:, 0] * 3, uv[:, 1] * 3))
+        p[:, 2] = np.where(wall == 2, 0.0, uv[:, 1] * 2.5)
+        p += (rng.standard_normal((n, 3)) * 0.01).astype(np.float32)
+        p[n // 2:n // 2 + 500] = p[:500]                      # exact duplicates
+        clouds.append(p)
+    pts = np.concatenate(clouds)
+    got = farthest_point_sampling(_c(pts), [n] * batch, [k] * batch, start_indices=[(3 * b) % n for b in range(batch)])
+    for b in sorted({0, batch // 2, batch - 1}):
+        assert np.array_equal(got[b].cpu().numpy(), M.farthest_point_sampling(clouds[b], k, (3 * b) % n)), f"cloud {b}"
