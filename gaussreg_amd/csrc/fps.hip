@@ -201,8 +201,8 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ pt
 // Threads contribute their best point; their second best is folded into B, which keeps the rule exact.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int FPS_M = 8;                       // candidates per round (M * M <= 64: pair checks by one wave)
-constexpr int FPS_MG = 16;                     // candidates of the global acceptance chain (a workgroup passes up M = 8:
-                                               // 64 workgroups x 8 keys feed a global top 16)
+constexpr int FPS_MG = 32;                     // candidates of the global acceptance chain (a workgroup passes up M = 8).  With 16
+                                               // four rounds in five accepted all 16: the chain length was the limit, not conflicts
 constexpr int FPS_MW = 4;                      // candidates a single wave passes up (the global top 8 almost never
                                                // holds more than a few points of one wave; the rest raises the bound B)
 constexpr int FPS_SLOT_W = FPS_M + 1;          // words per workgroup slot: M keys + bound, each with a 1-bit tag in bit 63
@@ -220,10 +220,15 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// A single wave runs these reductions back to back (about 7 cycles per dependent instruction), so the instruction count
+// is the cost: the low half only needs its own reduction when two lanes tie on the high half (distances equal to the bit).
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-  const unsigned hi = (unsigned)(v >> 32);
+  const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
   const unsigned mh = wave_max_u32(hi);
-  const unsigned ml = wave_max_u32(hi == mh ? (unsigned)v : 0u);
+  const unsigned long long tie = __ballot(hi == mh);  // never empty
+  unsigned ml;
+  if ((tie & (tie - 1ull)) == 0ull) ml = (unsigned)__builtin_amdgcn_readlane((int)lo, (int)__builtin_ctzll(tie));
+  else ml = wave_max_u32(hi == mh ? lo : 0u);
   return ((unsigned long long)mh << 32) | ml;
 }
 
@@ -251,7 +256,8 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
   __shared__ unsigned long long s_wtop[NW * MW];
   __shared__ unsigned long long s_wbound[NW];
   __shared__ float s_acc[MG][4];
-  __shared__ float s_cand[MG][4];
+  __shared__ __attribute__((aligned(16))) float s_cand[MG][4];
+  __shared__ int s_ok[MG];
   __shared__ int s_na, s_abort;
   const int b = blockIdx.x / G, part = blockIdx.x % G;
   const int p0 = off[b], n = off[b + 1] - p0;
@@ -305,18 +311,25 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
   for (unsigned round = 2; count < k; ++round) {
     // ---- 1. fold the samples accepted last round into the running distances; per-thread best and runner-up
     const int na = s_na;
-    // sample-major: one LDS read of the sample, then all of this thread's points two at a time (packed fp32 --
-    // the same sub / mul / add sequence as the scalar form, so distances stay bit-identical)
-    bool touched = round == 2;  // first round: every wave publishes (a wave without points has an empty box: inf >= inf)
-    for (int a = 0; a < na; ++a) {
-      const float ax = s_acc[a][0], ay = s_acc[a][1], az = s_acc[a][2];
-      // distance from the sample to the wave's box, rounded down by more than the fold's own rounding (8 ulp-steps):
-      // at or beyond wave_maxd no running distance of this wave can drop
+    // lanes = samples: distance from each new sample to the wave's box, rounded down by more than the fold's own
+    // rounding (8 ulp-steps); at or beyond wave_maxd no running distance of this wave can drop.  The first round folds
+    // everything (a wave without points has an empty box: inf >= inf would skip it and leave its slots unwritten).
+    unsigned long long todo;
+    {
+      const int al = min(lane, MG - 1);
+      const float ax = s_acc[al][0], ay = s_acc[al][1], az = s_acc[al][2];
       const float ex = fmaxf(fmaxf(bx0 - ax, ax - bx1), 0.f), ey = fmaxf(fmaxf(by0 - ay, ay - by1), 0.f),
                   ez = fmaxf(fmaxf(bz0 - az, az - bz1), 0.f);
       const float lb = ((ex * ex + ey * ey) + ez * ez) * (1.0f - 9.5367431640625e-7f);
-      if (__builtin_amdgcn_readfirstlane(lb >= wave_maxd ? 1 : 0)) continue;
-      touched = true;
+      todo = __ballot(lane < na && (round == 2 || !(lb >= wave_maxd)));
+    }
+    const bool touched = round == 2 || todo != 0ull;
+    while (todo) {
+      const int a = (int)__builtin_ctzll(todo);
+      todo &= todo - 1ull;
+      // sample-major: one LDS read of the sample, then all of this thread's points two at a time (packed fp32 -- the
+      // same sub / mul / add sequence as the scalar form, so distances stay bit-identical)
+      const float ax = s_acc[a][0], ay = s_acc[a][1], az = s_acc[a][2];
       const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
 #pragma unroll
       for (int j = 0; j + 1 < PPT; j += 2) {
@@ -443,25 +456,37 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
         s_cand[lane][1] = cy;
         s_cand[lane][2] = cz;
         s_cand[lane][3] = cd;
+        s_ok[lane] = live && mykey > bnd ? 1 : 0;  // candidate `lane` beats everything uncollected
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      // candidate i = lane / 4 is checked against the earlier candidates j = (lane % 4) * 4 + u: does accepting c_j
-      // lower d(c_i)?  (a prefix is accepted, so every j < i counts)
-      const int pi = lane >> 2;
+      // candidate i = lane / LPC is checked against the earlier candidates j = (lane % LPC) * JPL + u: does accepting
+      // c_j lower d(c_i)?  (a prefix is accepted, so every j < i counts)
+      constexpr int LPC = WAVE / MG, JPL = MG / LPC;  // lanes per candidate, earlier candidates per lane
+      const int pi = lane / LPC;
+      const float4 ci4 = *reinterpret_cast<const float4*>(s_cand[pi]);
       bool hurts = false;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int pj = (lane & 3) * 4 + u;
-        const float ddx = s_cand[pi][0] - s_cand[pj][0], ddy = s_cand[pi][1] - s_cand[pj][1],
-                    ddz = s_cand[pi][2] - s_cand[pj][2];
-        hurts = hurts || (pj < pi && ((ddx * ddx + ddy * ddy) + ddz * ddz) < s_cand[pi][3]);
+      for (int u = 0; u < JPL; ++u) {
+        const int pj = (lane % LPC) * JPL + u;
+        const float4 cj4 = *reinterpret_cast<const float4*>(s_cand[pj]);
+        const float ddx = ci4.x - cj4.x, ddy = ci4.y - cj4.y, ddz = ci4.z - cj4.z;
+        hurts = hurts || (pj < pi && ((ddx * ddx + ddy * ddy) + ddz * ddz) < ci4.w);
       }
-      const unsigned long long hurt_mask = __ballot(hurts);                  // bits 4i .. 4i+3: candidate i is hurt
-      const unsigned long long ok_mask = __ballot(live && mykey > bnd);      // bit r: candidate r beats everything uncollected
+      // LPC consecutive bits per candidate: set while the candidate is collectable and no earlier one hurts it
+      const unsigned long long good = __ballot(s_ok[pi] != 0 && !hurts);
       int acc = 0;
-      while (acc < NC && count + acc < k && ((ok_mask >> acc) & 1ull) && ((hurt_mask >> (4 * acc)) & 0xfull) == 0ull)
-        ++acc;
+      {
+        unsigned long long g = good;
+#pragma unroll
+        for (int sft = 1; sft < LPC; sft <<= 1) g &= g >> sft;  // bit LPC * i = all LPC lanes of candidate i agree
+        unsigned long long lead = 0ull;                          // keep only the bits at multiples of LPC
+#pragma unroll
+        for (int i = 0; i < MG; ++i) lead |= 1ull << (LPC * i);
+        const unsigned long long stop = ~g & lead;               // first candidate that fails
+        acc = stop ? (int)__builtin_ctzll(stop) / LPC : MG;
+        acc = min(acc, min(NC, k - count));
+      }
       if (__any(bad)) {
         if (lane == 0) s_abort = 1;
         acc = max(acc, 1);
