@@ -206,6 +206,7 @@ constexpr int FPS_MG = 32;                     // candidates of the global accep
 constexpr int FPS_MW = 4;                      // candidates a single wave passes up (the global top 8 almost never
                                                // holds more than a few points of one wave; the rest raises the bound B)
 constexpr int FPS_SLOT_W = FPS_M + 1;          // words per workgroup slot: M keys + bound, each with a 1-bit tag in bit 63
+constexpr int FPS_SLOT_STRIDE = 16;            // words between slots: one 128-byte line per workgroup, so a poll is one line
                                                // (keys use 63 bits: d >= 0 has a clear sign bit)
 
 // Wave-wide maximum through the DPP lanes-shift network (row_shr 1/2/4/8, row_bcast 15/31): six dependent VALU ops
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
     if (part == 0) out[o0] = start;
   }
   __syncthreads();
-  unsigned long long* slots = slots_all + (size_t)b * 2 * FPS_GMAX * FPS_SLOT_W;
+  unsigned long long* slots = slots_all + (size_t)b * 2 * FPS_GMAX * FPS_SLOT_STRIDE;
   int count = 1;
   // rounds start at 2: buffer (round & 1) is reused every second round and its words carry the tag bit
   // (round >> 1) & 1, which flips between consecutive uses; zero-initialised slots read as tag 0, first uses expect 1
@@ -392,19 +393,19 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
       }
       bool bad = false;
       if (G > 1) {
-        unsigned long long* buf = slots + (size_t)(round & 1u) * FPS_GMAX * FPS_SLOT_W;
+        unsigned long long* buf = slots + (size_t)(round & 1u) * FPS_GMAX * FPS_SLOT_STRIDE;
         const unsigned long long tag = (unsigned long long)((round >> 1) & 1u) << 63;
         if (lane < M)
-          __hip_atomic_store(buf + part * FPS_SLOT_W + lane, tag | mykey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(buf + part * FPS_SLOT_STRIDE + lane, tag | mykey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else if (lane == M)
-          __hip_atomic_store(buf + part * FPS_SLOT_W + M, tag | bnd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(buf + part * FPS_SLOT_STRIDE + M, tag | bnd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // lane g polls workgroup g's slot until all its words carry this round's tag bit
         unsigned long long kk[M];
         unsigned long long sb = 0ull;
 #pragma unroll
         for (int r = 0; r < M; ++r) kk[r] = 0ull;
         if (lane < G) {
-          const unsigned long long* w = buf + lane * FPS_SLOT_W;
+          const unsigned long long* w = buf + lane * FPS_SLOT_STRIDE;
           int spins = 0;
           for (;;) {
             unsigned long long rd[FPS_SLOT_W];
@@ -552,7 +553,7 @@ extern "C" size_t gr_fps_workspace_bytes(int64_t n, int64_t batch) {
   if (n < 0 || batch < 0) return 0;
   return align_up((size_t)n * 4, 256) + 3 * align_up((size_t)(batch + 1) * 4, 256) +
          align_up((size_t)batch * 2 * FPS_GMAX * sizeof(FpsCand), 256) + align_up((size_t)(batch + 1) * 4, 256) +
-         align_up((size_t)batch * 2 * FPS_GMAX * FPS_SLOT_W * 8, 256) +
+         align_up((size_t)batch * 2 * FPS_GMAX * FPS_SLOT_STRIDE * 8, 256) +
          // Morton pre-pass: keys in/out, values out, sorted points, permutation, bounding boxes, rocPRIM scratch
          2 * align_up((size_t)n * 8, 256) + 2 * align_up((size_t)n * 4, 256) + align_up((size_t)n * 12, 256) +
          align_up((size_t)batch * 6 * 4, 256) + align_up((size_t)(batch + 1) * 4, 256) + align_up(sort_pairs_temp_bytes(n), 256) +
@@ -598,7 +599,7 @@ extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64
   int32_t* d_st = c.take<int32_t>(batch + 1);
   FpsCand* cand = c.take<FpsCand>((size_t)batch * 2 * FPS_GMAX);
   unsigned* arrive = c.take<unsigned>(batch + 1);  // [batch] = error flag
-  unsigned long long* mslots = c.take<unsigned long long>((size_t)batch * 2 * FPS_GMAX * FPS_SLOT_W);
+  unsigned long long* mslots = c.take<unsigned long long>((size_t)batch * 2 * FPS_GMAX * FPS_SLOT_STRIDE);
   uint64_t* mkeys_a = c.take<uint64_t>(n);
   uint64_t* mkeys_b = c.take<uint64_t>(n);
   int32_t* mvals = c.take<int32_t>(n);
@@ -626,7 +627,7 @@ extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64
     const int64_t per = ((nmax + G - 1) / G + FPS_T - 1) / FPS_T;  // points per thread
     GR_HIP(hipMemsetAsync(arrive, 0, sizeof(unsigned) * (batch + 1), stream));
     GR_HIP(hipMemsetAsync(cand, 0, sizeof(FpsCand) * (size_t)batch * 2 * FPS_GMAX, stream));
-    GR_HIP(hipMemsetAsync(mslots, 0, sizeof(unsigned long long) * (size_t)batch * 2 * FPS_GMAX * FPS_SLOT_W, stream));
+    GR_HIP(hipMemsetAsync(mslots, 0, sizeof(unsigned long long) * (size_t)batch * 2 * FPS_GMAX * FPS_SLOT_STRIDE, stream));
     bool launched = true;
     if (per <= 20 && !morton_done) {
       // Morton order for the bucket pruning: boxes, keys, one radix sort over (cloud, code), gather
