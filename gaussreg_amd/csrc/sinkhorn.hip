@@ -14,6 +14,7 @@ namespace {
 
 constexpr int SK_PARTS = 4;   // threads per row / column
 constexpr int SK_T = 576;     // >= SK_PARTS * (max(M,N)+1) for the demo shape (4 * 129 = 516), 9 waves
+constexpr int SK_PER = (SK_T / SK_PARTS + SK_PARTS - 1) / SK_PARTS;  // elements of a row / column one thread reduces (<= 36)
 
 __device__ __forceinline__ float lse_finish(float mx, float s) { return logf(s) + mx; }
 
@@ -79,11 +80,18 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
   for (int it = 0; it < iters; ++it) {
     if (active && idx < R) {
       const float* row = S + idx * ld;
-      const int j0 = part * cper, j1 = min(C, j0 + cper);
+      // the thread's slice stays in registers between the max pass and the sum pass (one trip through LDS per element)
+      const int j0 = part * cper, len = min(C, j0 + cper) - j0;
+      float x[SK_PER];
       float mx = -INFINITY;
-      for (int j = j0; j < j1; ++j) mx = fmaxf(mx, row[j] + v[j]);
+#pragma unroll
+      for (int t = 0; t < SK_PER; ++t) {
+        x[t] = t < len ? row[j0 + t] + v[j0 + t] : -INFINITY;
+        mx = fmaxf(mx, x[t]);
+      }
       float s = 0.f;
-      for (int j = j0; j < j1; ++j) s += expf((row[j] + v[j]) - mx);
+#pragma unroll
+      for (int t = 0; t < SK_PER; ++t) s += t < len ? __expf(x[t] - mx) : 0.f;
       pm[part * mxd + idx] = mx;
       ps[part * mxd + idx] = s;
     }
@@ -102,11 +110,17 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
     }
     __syncthreads();
     if (active && idx < C) {
-      const int i0 = part * rper, i1 = min(R, i0 + rper);
+      const int i0 = part * rper, len = min(R, i0 + rper) - i0;
+      float x[SK_PER];
       float mx = -INFINITY;
-      for (int i = i0; i < i1; ++i) mx = fmaxf(mx, S[i * ld + idx] + u[i]);
+#pragma unroll
+      for (int t = 0; t < SK_PER; ++t) {
+        x[t] = t < len ? S[(i0 + t) * ld + idx] + u[i0 + t] : -INFINITY;
+        mx = fmaxf(mx, x[t]);
+      }
       float s = 0.f;
-      for (int i = i0; i < i1; ++i) s += expf((S[i * ld + idx] + u[i]) - mx);
+#pragma unroll
+      for (int t = 0; t < SK_PER; ++t) s += t < len ? __expf(x[t] - mx) : 0.f;
       pm[part * mxd + idx] = mx;
       ps[part * mxd + idx] = s;
     }
