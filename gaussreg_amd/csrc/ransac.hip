@@ -7,16 +7,21 @@
 // what is restated is the published algorithm: sample n correspondences, Umeyama similarity, score by the
 // number of correspondences within the distance threshold (ties: lower inlier RMSE), keep the best.
 //   hypotheses  one thread per hypothesis: counter-hash sampling of n distinct correspondences, Umeyama in
-//               fp64 (Horn quaternion rotation, scale = sum(ref_c . R src_c) / sum |src_c|^2), then every
-//               correspondence (staged through LDS, broadcast reads) is tested        -> (inliers, rmse)
+//               fp64 (Horn quaternion rotation, scale = sum(ref_c . R src_c) / sum |src_c|^2)   -> 3x4 transform
+//   score       16 lanes per hypothesis share the correspondences (staged through LDS), counts and squared
+//               errors are added in a fixed order                                          -> (inliers, rmse)
+//               (10 000 hypotheses are 157 waves; scoring inside the hypothesis thread left most of the GPU idle)
 //   best        block reduction over hypotheses; optional refit on the best hypothesis' inliers
 #include "common.hpp"
 
 namespace gr {
 namespace {
 
-constexpr int RS_T = 256;
+constexpr int RS_T = 64;      // hypothesis kernel: a wave per workgroup, so that 10 000 hypotheses spread over 157 CUs
 constexpr int RS_MAXN = 8;
+constexpr int RS_LPH = 16;    // lanes per hypothesis in the scoring kernel
+constexpr int RS_ST = 256;    // scoring kernel threads (16 hypotheses per workgroup)
+constexpr int RS_CHUNK = 1024;  // correspondences staged per round
 
 __host__ __device__ inline uint32_t rs_hash(uint32_t seed, uint32_t h, uint32_t k, uint32_t attempt) {
   uint32_t x = seed ^ (h * 0x9E3779B9u) ^ (k * 0x85EBCA6Bu) ^ (attempt * 0xC2B2AE35u);
@@ -90,8 +95,6 @@ __global__ __launch_bounds__(RS_T) void ransac_hypotheses_kernel(const float* __
                                                                  int C, int n_sample, int num_hyp, uint32_t seed,
                                                                  float thr, int with_scale, float* __restrict__ transforms,
                                                                  int32_t* __restrict__ inliers, float* __restrict__ sqerr) {
-  __shared__ float s_src[RS_T * 3];
-  __shared__ float s_ref[RS_T * 3];
   const int h = blockIdx.x * RS_T + threadIdx.x;
   float T[12];
   bool ok = false;
@@ -120,19 +123,36 @@ __global__ __launch_bounds__(RS_T) void ransac_hypotheses_kernel(const float* __
     }
     ok = umeyama_from_sums((double)n_sample, ss, sr, sxy, s2, with_scale, T);
   }
+  if (h < num_hyp) {
+    inliers[h] = ok ? 0 : -1;
+    sqerr[h] = 0.f;
+    for (int k = 0; k < 12; ++k) transforms[h * 12 + k] = ok ? T[k] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(RS_ST) void ransac_score_kernel(const float* __restrict__ src, const float* __restrict__ ref, int C,
+                                                            int num_hyp, float thr, const float* __restrict__ transforms,
+                                                            int32_t* __restrict__ inliers, float* __restrict__ sqerr) {
+  __shared__ float s_src[RS_CHUNK * 3];
+  __shared__ float s_ref[RS_CHUNK * 3];
+  const int h = blockIdx.x * (RS_ST / RS_LPH) + threadIdx.x / RS_LPH, sub = threadIdx.x % RS_LPH;
+  const bool ok = h < num_hyp && inliers[h] >= 0;
+  float T[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) T[k] = ok ? transforms[h * 12 + k] : 0.f;
   int cnt = 0;
   float err = 0.f;
   const float thr2 = thr * thr;
-  for (int c0 = 0; c0 < C; c0 += RS_T) {
-    const int nn = min(RS_T, C - c0);
+  for (int c0 = 0; c0 < C; c0 += RS_CHUNK) {
+    const int nn = min(RS_CHUNK, C - c0);
     __syncthreads();
-    for (int e = threadIdx.x; e < nn * 3; e += RS_T) {
+    for (int e = threadIdx.x; e < nn * 3; e += RS_ST) {
       s_src[e] = src[3 * (int64_t)c0 + e];
       s_ref[e] = ref[3 * (int64_t)c0 + e];
     }
     __syncthreads();
     if (ok) {
-      for (int i = 0; i < nn; ++i) {
+      for (int i = sub; i < nn; i += RS_LPH) {
         const float x = s_src[3 * i], y = s_src[3 * i + 1], z = s_src[3 * i + 2];
         const float dx = s_ref[3 * i] - (fmaf(T[0], x, fmaf(T[1], y, fmaf(T[2], z, T[3]))));
         const float dy = s_ref[3 * i + 1] - (fmaf(T[4], x, fmaf(T[5], y, fmaf(T[6], z, T[7]))));
@@ -145,10 +165,15 @@ __global__ __launch_bounds__(RS_T) void ransac_hypotheses_kernel(const float* __
       }
     }
   }
-  if (h < num_hyp) {
-    inliers[h] = ok ? cnt : -1;
+  // 16 lanes -> one (count, error): pairwise tree in a fixed order
+#pragma unroll
+  for (int d = RS_LPH / 2; d > 0; d >>= 1) {
+    cnt += __shfl_xor(cnt, d, RS_LPH);
+    err += __shfl_xor(err, d, RS_LPH);
+  }
+  if (ok && sub == 0) {
+    inliers[h] = cnt;
     sqerr[h] = err;
-    for (int k = 0; k < 12; ++k) transforms[h * 12 + k] = ok ? T[k] : 0.f;
   }
 }
 
@@ -272,6 +297,9 @@ extern "C" int gr_ransac_similarity(const float* src_points, const float* ref_po
   hipLaunchKernelGGL(ransac_hypotheses_kernel, dim3((unsigned)((num_hypotheses + RS_T - 1) / RS_T)), dim3(RS_T), 0, stream,
                      src_points, ref_points, (int)num_corr, ransac_n, (int)num_hypotheses, seed, distance_threshold,
                      with_scaling, transforms, inl, err);
+  constexpr int HPB = RS_ST / RS_LPH;
+  hipLaunchKernelGGL(ransac_score_kernel, dim3((unsigned)((num_hypotheses + HPB - 1) / HPB)), dim3(RS_ST), 0, stream, src_points,
+                     ref_points, (int)num_corr, (int)num_hypotheses, distance_threshold, transforms, inl, err);
   hipLaunchKernelGGL(ransac_best_kernel, dim3(1), dim3(1024), 0, stream, src_points, ref_points, (int)num_corr,
                      (int)num_hypotheses, transforms, inl, err, distance_threshold, with_scaling, refine, out_transform,
                      out_stats);
