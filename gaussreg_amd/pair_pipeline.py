@@ -173,7 +173,18 @@ class PairRegistrar:
         pts_c, pts_f = pyr["points"][-1], pyr["points"][1]
         out = torch.zeros((B, RESULT_LEN), dtype=torch.float32, device=dev)
         pad = torch.zeros((1, 3), device=dev)                            # model.py:171-172
-        ctx = (pairs, B, pts_c, pts_f, off_c, off_f, pad, out)
+        gt_mask = torch.tensor([p[2] is not None for p in pairs], device=dev)
+        eye = torch.eye(4, device=dev)
+        with self._sec("coarse_features"):
+            # stand-in for the learned features (see module docstring): descriptors in the reference frame, for all the
+            # superpoints of the batch at once (the per-pair stage is bound by host-side launch overhead)
+            T_all = torch.stack([p[2] if p[2] is not None else eye for p in pairs])         # (B, 4, 4); no GT: identity
+            n_src = torch.tensor(len_c[B:], device=dev)
+            pid = torch.repeat_interleave(torch.arange(B, device=dev), n_src)
+            src_in_ref = torch.einsum('nij,nj->ni', T_all[pid, :3, :3], pts_c[off_c[B]:]) + T_all[pid, :3, 3]
+            frame_c = torch.cat([pts_c[:off_c[B]], src_in_ref], 0)
+            feats_c = torch.nn.functional.normalize(self.coarse_desc(frame_c), p=2, dim=1)
+        ctx = (pairs, B, pts_c, pts_f, off_c, off_f, pad, out, feats_c)
         S = 1 if self.profile else min(self.pair_streams, B)
         if S <= 1:
             for b in range(B):
@@ -199,12 +210,21 @@ class PairRegistrar:
 
             for ev in [f.result() for f in [self._pool.submit(work, k) for k in range(S)]]:
                 torch.cuda.current_stream(dev).wait_event(ev)
+        if bool(gt_mask.any()):
+            with self._sec("metrics"):
+                # RRE / RTE of all pairs at once (similarity estimate: the scale is stripped before the angle)
+                T_est = out[:, :16].reshape(B, 4, 4)
+                R_est = T_est[:, :3, :3]
+                sc_ = torch.linalg.det(R_est).abs().clamp_min(1e-12) ** (1.0 / 3.0)
+                cosv = (torch.einsum('bij,bij->b', R_est / sc_[:, None, None], T_all[:, :3, :3]) - 1.0) * 0.5
+                out[:, 16] = torch.where(gt_mask, torch.rad2deg(torch.arccos(cosv.clamp(-1.0, 1.0))), out[:, 16])
+                out[:, 17] = torch.where(gt_mask, torch.linalg.norm(T_est[:, :3, 3] - T_all[:, :3, 3], dim=1), out[:, 17])
         return out
 
     @torch.no_grad()   # grad mode is per thread: the worker threads need their own
     def _register_one(self, b, ctx):
         """Everything after the pyramid for pair b (model.py:99-220), on the current stream."""
-        pairs, B, pts_c, pts_f, off_c, off_f, pad, out = ctx
+        pairs, B, pts_c, pts_f, off_c, off_f, pad, out, feats_c = ctx
         dev = self.device
         T_gt = pairs[b][2]
         ref_c = pts_c[off_c[b]:off_c[b + 1]]
@@ -215,10 +235,8 @@ class PairRegistrar:
         with self._sec("point_to_node"):                            # model.py:99-104
             _, ref_node_masks, ref_knn_idx, ref_knn_masks = point_to_node_partition(ref_f, ref_c, POINT_LIMIT)
             _, src_node_masks, src_knn_idx, src_knn_masks = point_to_node_partition(src_f, src_c, POINT_LIMIT)
-        with self._sec("coarse_features"):
-            # stand-in for the learned features (see module docstring): descriptors in the reference frame
-            ref_feats_c = torch.nn.functional.normalize(self.coarse_desc(ref_c), p=2, dim=1)
-            src_feats_c = torch.nn.functional.normalize(self.coarse_desc(to_ref(src_c)), p=2, dim=1)
+        ref_feats_c = feats_c[off_c[b]:off_c[b + 1]]
+        src_feats_c = feats_c[off_c[B + b]:off_c[B + b + 1]]
         with self._sec("superpoint_matching"):                      # model.py:152-159
             ref_ci, src_ci, node_scores = self.spm(ref_feats_c, src_feats_c, ref_node_masks, src_node_masks)
         with self._sec("patch_features"):
@@ -241,11 +259,5 @@ class PairRegistrar:
         with self._sec("metrics"):
             out[b, :16] = T.reshape(-1)
             out[b, 18] = float(n_corr)
-            if T_gt is not None:
-                R_est = T[:3, :3]
-                s = torch.linalg.det(R_est).abs().clamp_min(1e-12) ** (1.0 / 3.0)   # similarity: strip the scale
-                out[b, 16] = rotation_error_deg(R_est / s, T_gt[:3, :3])
-                out[b, 17] = torch.linalg.norm(T[:3, 3] - T_gt[:3, 3])
-                if n_corr > 0:
-                    resid = torch.linalg.norm(to_ref(sc) - rc, dim=1)
-                    out[b, 19] = (resid < 0.1).float().mean()
+            if T_gt is not None and n_corr > 0:
+                out[b, 19] = (torch.linalg.norm(to_ref(sc) - rc, dim=1) < 0.1).float().mean()
