@@ -820,9 +820,20 @@ extern "C" int gr_radius_count_cached(const float* q, const float* s, const int6
   }
   if (h_support_sig) memcpy(h_support_sig, sig, sizeof(sig));
   // offsets (host -> device)
-  std::vector<int32_t> tmpv(3 * (batch + 1));  // q offsets | s offsets | bbox block offsets
+  // q offsets | s offsets | bbox block offsets, staged in pinned memory (per host thread, grown on demand; every call ends
+  // with a stream synchronise, so the previous call's copy has left the buffer)
+  static thread_local int32_t* stage = nullptr;
+  static thread_local int64_t stage_cap = 0;
+  if (stage_cap < 3 * (batch + 1)) {
+    if (stage) (void)hipHostFree(stage);
+    stage = nullptr;
+    stage_cap = 0;
+    GR_HIP(hipHostMalloc(reinterpret_cast<void**>(&stage), sizeof(int32_t) * 3 * (batch + 1) * 2, hipHostMallocDefault));
+    stage_cap = 3 * (batch + 1) * 2;
+  }
+  int32_t* const tmpv_data = stage;
   {
-    int32_t* tmp = tmpv.data();
+    int32_t* tmp = tmpv_data;
     tmp[0] = 0;
     tmp[batch + 1] = 0;
     for (int64_t b = 0; b < batch; ++b) {
@@ -843,7 +854,7 @@ extern "C" int gr_radius_count_cached(const float* q, const float* s, const int6
     const int rows = same ? 1 : 2;
     GR_HIP(hipMemsetAsync(w.cnt, 0, sizeof(int32_t) * rows * (w.ccap + 1), stream));
     {
-      int rcb = compute_bbox(s, tmpv.data() + batch + 1, tmpv.data() + 2 * (batch + 1), w.s_off, nb, w.bbox, w.blk_off, stream, true);
+      int rcb = compute_bbox(s, tmpv_data + batch + 1, tmpv_data + 2 * (batch + 1), w.s_off, nb, w.bbox, w.blk_off, stream, true);
       if (rcb != GR_OK) return rcb;
     }
     // x sub-cells per cell: 2 measured best end to end (count pass 0.166 -> 0.157 ms; 8 gives 0.150 ms but the scan and the
@@ -874,9 +885,13 @@ extern "C" int gr_radius_count_cached(const float* q, const float* s, const int6
   const float r2 = radius * radius;  // radius_neighbors_cpu.cpp:12 (fp32 product)
   rc = launch_count<RT>(w, sorted_q, nq, nb, start_s, r2, same, stream);
   if (rc != GR_OK) return rc;
-  RadiusHdr h;
-  GR_HIP(hipMemcpyAsync(&h, w.hdr, sizeof(h), hipMemcpyDeviceToHost, stream));
+  // the read-back lands in pinned memory (one small allocation per host thread, kept for the life of the process): a
+  // copy into pageable memory is staged and synchronised by the runtime on top of the synchronise below
+  static thread_local RadiusHdr* h_pinned = nullptr;
+  if (!h_pinned) GR_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_pinned), sizeof(RadiusHdr), hipHostMallocDefault));
+  GR_HIP(hipMemcpyAsync(h_pinned, w.hdr, sizeof(RadiusHdr), hipMemcpyDeviceToHost, stream));
   GR_HIP(hipStreamSynchronize(stream));
+  const RadiusHdr h = *h_pinned;
   h_info[0] = h.max_count;
   h_info[1] = h.max_block_hits;
   h_info[2] = same ? 1 : 0;
