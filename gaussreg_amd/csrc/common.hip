@@ -44,6 +44,27 @@ KernelTimer::~KernelTimer() {
   (void)hipEventRecord(g_trecs[slot_].stop, stream_);
 }
 
+// ------------------------------------------------------------------ pinned scratch
+void* pinned_scratch(int slot, size_t bytes) {
+  constexpr int SLOTS = 4;
+  static thread_local void* buf[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+  static thread_local size_t cap[SLOTS] = {0, 0, 0, 0};
+  if (slot < 0 || slot >= SLOTS) return nullptr;
+  if (cap[slot] < bytes) {
+    if (buf[slot]) (void)hipHostFree(buf[slot]);
+    buf[slot] = nullptr;
+    cap[slot] = 0;
+    const size_t want = bytes < 4096 ? 4096 : 2 * bytes;
+    if (hipHostMalloc(&buf[slot], want, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      buf[slot] = nullptr;
+      return nullptr;
+    }
+    cap[slot] = want;
+  }
+  return buf[slot];
+}
+
 // ------------------------------------------------------------------ scan
 constexpr int SCAN_T = 256;
 constexpr int SCAN_ITEMS = 8;

@@ -81,6 +81,12 @@ size_t scan_ws_ints(int64_t n);
 int exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int rows, int64_t row_stride,
                        int32_t* scan_ws, int32_t* total, hipStream_t stream, const int32_t* last_dev = nullptr);
 
+// Pinned host scratch, one buffer per (host thread, slot), grown on demand and kept for the life of the process.  A copy
+// to or from pageable memory is staged and synchronised by the runtime; through these buffers the small uploads and
+// read-backs of the API calls are asynchronous for real.  Contract: the caller synchronises the stream before it returns
+// (every entry point that uses this does), so the next call on the thread finds the buffer free.
+void* pinned_scratch(int slot, size_t bytes);
+
 // Per-cloud bounding boxes of stacked points: bbox_dev[b*6 + {0,1,2}] = min xyz, +{3,4,5} = max xyz,
 // stored as order-preserving uints (decode with ord2f).  Empty clouds keep (0xffffffff, 0).
 // h_off: host copy of the nb+1 point offsets; h_blk: nb+1 ints of HOST scratch that must stay

@@ -820,17 +820,10 @@ extern "C" int gr_radius_count_cached(const float* q, const float* s, const int6
   }
   if (h_support_sig) memcpy(h_support_sig, sig, sizeof(sig));
   // offsets (host -> device)
-  // q offsets | s offsets | bbox block offsets, staged in pinned memory (per host thread, grown on demand; every call ends
-  // with a stream synchronise, so the previous call's copy has left the buffer)
-  static thread_local int32_t* stage = nullptr;
-  static thread_local int64_t stage_cap = 0;
-  if (stage_cap < 3 * (batch + 1)) {
-    if (stage) (void)hipHostFree(stage);
-    stage = nullptr;
-    stage_cap = 0;
-    GR_HIP(hipHostMalloc(reinterpret_cast<void**>(&stage), sizeof(int32_t) * 3 * (batch + 1) * 2, hipHostMallocDefault));
-    stage_cap = 3 * (batch + 1) * 2;
-  }
+  // q offsets | s offsets | bbox block offsets, staged in pinned memory (pinned_scratch: every call ends with a stream
+  // synchronise, so the previous call's copy has left the buffer)
+  int32_t* const stage = static_cast<int32_t*>(pinned_scratch(2, sizeof(int32_t) * 3 * (batch + 1)));
+  GR_REQUIRE(stage != nullptr, "pinned staging buffer could not be allocated");
   int32_t* const tmpv_data = stage;
   {
     int32_t* tmp = tmpv_data;
@@ -885,10 +878,10 @@ extern "C" int gr_radius_count_cached(const float* q, const float* s, const int6
   const float r2 = radius * radius;  // radius_neighbors_cpu.cpp:12 (fp32 product)
   rc = launch_count<RT>(w, sorted_q, nq, nb, start_s, r2, same, stream);
   if (rc != GR_OK) return rc;
-  // the read-back lands in pinned memory (one small allocation per host thread, kept for the life of the process): a
-  // copy into pageable memory is staged and synchronised by the runtime on top of the synchronise below
-  static thread_local RadiusHdr* h_pinned = nullptr;
-  if (!h_pinned) GR_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_pinned), sizeof(RadiusHdr), hipHostMallocDefault));
+  // the read-back lands in pinned memory (a copy into pageable memory is staged and synchronised by the runtime on top of
+  // the synchronise below)
+  RadiusHdr* h_pinned = static_cast<RadiusHdr*>(pinned_scratch(3, sizeof(RadiusHdr)));
+  GR_REQUIRE(h_pinned != nullptr, "pinned read-back buffer could not be allocated");
   GR_HIP(hipMemcpyAsync(h_pinned, w.hdr, sizeof(RadiusHdr), hipMemcpyDeviceToHost, stream));
   GR_HIP(hipStreamSynchronize(stream));
   const RadiusHdr h = *h_pinned;

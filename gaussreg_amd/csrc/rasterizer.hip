@@ -973,10 +973,12 @@ int check_views(const gr_raster_view* h_views, int num_views) {
 // dv must stay alive until `stream` is synchronised by the caller
 int upload_views(const gr_raster_view* h_views, int num_views, std::vector<DevView>& dv, DevView* d_views,
                  hipStream_t stream) {
-  dv.resize(num_views);
+  (void)dv;
+  DevView* stage = static_cast<DevView*>(pinned_scratch(0, sizeof(DevView) * num_views));
+  GR_REQUIRE(stage != nullptr, "pinned staging buffer for %d views could not be allocated", num_views);
   for (int v = 0; v < num_views; ++v) {
     const gr_raster_view& s = h_views[v];
-    DevView& d = dv[v];
+    DevView& d = stage[v];
     memcpy(d.view, s.viewmatrix, sizeof(d.view));
     memcpy(d.proj, s.projmatrix, sizeof(d.proj));
     memcpy(d.campos, s.campos, sizeof(d.campos));
@@ -987,7 +989,7 @@ int upload_views(const gr_raster_view* h_views, int num_views, std::vector<DevVi
     d.fy = (float)s.image_height / (2.0f * s.tanfovy);
     d.scale_mod = s.scale_modifier;
   }
-  GR_HIP(hipMemcpyAsync(d_views, dv.data(), sizeof(DevView) * num_views, hipMemcpyHostToDevice, stream));
+  GR_HIP(hipMemcpyAsync(d_views, stage, sizeof(DevView) * num_views, hipMemcpyHostToDevice, stream));
   return GR_OK;
 }
 
@@ -1083,7 +1085,8 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
   run_preprocess();
   GR_LAUNCH_CHECK();
   static_assert((1 << KEY_VIEW_BITS) >= MAX_VIEWS && KEY_DEPTH_BITS + KEY_VIEW_BITS <= 38, "view id must fit its key field");
-  std::vector<int32_t> tot(num_views + 1);
+  int32_t* tot = static_cast<int32_t*>(pinned_scratch(1, sizeof(int32_t) * (num_views + 2)));  // totals, far flag, chunk max
+  GR_REQUIRE(tot != nullptr, "pinned read-back buffer could not be allocated");
   const int nchunk = (int)((P + BIN_CHUNK - 1) / BIN_CHUNK);
   int32_t h_chunk_max = 0;
   auto sort_and_count = [&](int key_bits) -> int {
@@ -1112,9 +1115,10 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
                          g.chunk_cnt, g.chunk_total + (int64_t)num_views * nchunk, g.totals, g.seg_off);
       GR_LAUNCH_CHECK();
     }
-    GR_HIP(hipMemcpyAsync(tot.data(), g.totals, sizeof(int32_t) * (num_views + 1), hipMemcpyDeviceToHost, stream));
-    GR_HIP(hipMemcpyAsync(&h_chunk_max, g.chunk_max, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    GR_HIP(hipMemcpyAsync(tot, g.totals, sizeof(int32_t) * (num_views + 1), hipMemcpyDeviceToHost, stream));
+    GR_HIP(hipMemcpyAsync(tot + num_views + 1, g.chunk_max, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     GR_HIP(hipStreamSynchronize(stream));
+    h_chunk_max = tot[num_views + 1];
     return GR_OK;
   };
   rc = sort_and_count(KEY_DEPTH_BITS);
