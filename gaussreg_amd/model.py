@@ -1,0 +1,133 @@
+"""Mirror of experiments/geotransformer.gaussian_splatting.indoor/model.py:19-248 (`GeoTransformer`, the network GaussReg's
+coarse registration runs: demo.py:128-150, test.py:146-212) -- the INFERENCE branch -- and of the model part of
+config.py:78-125 (`make_cfg`).  It is the caller of every operator of this repository on the point-cloud path:
+
+    collated pyramid (utils/data.py) -> point_to_node_partition x2 -> KPConvFPN -> GeometricTransformer -> normalise ->
+    SuperPointMatching -> patch gather (index_select) -> einsum / sqrt(C) -> LearnableLogOptimalTransport ->
+    LocalGlobalRegistration -> RANSAC with scale on the correspondences
+
+Sub-modules are created in the reference's order and keep its state-dict keys (`backbone.*`, `transformer.*`,
+`optimal_transport.alpha`), so a reference checkpoint loads with `load_state_dict`.  The training branch of the reference
+(ground-truth node correspondences, `SuperPointTargetGenerator`, the losses) is out of scope: `forward` refuses to run in
+training mode.  Output keys are the reference's; `lgr_transform` (the estimate of LocalGlobalRegistration that the reference
+overwrites with the RANSAC one, model.py:200-220) is kept in addition.
+"""
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .kpconv_blocks import KPConvFPN
+from .matching import LocalGlobalRegistration, SuperPointMatching
+from .ops import index_select, point_to_node_partition
+from .registration import registration_with_ransac_from_correspondences
+from .sinkhorn import LearnableLogOptimalTransport
+from .transformer import GeometricTransformer
+
+
+def make_cfg():
+    """The model sections of config.py:78-125 (same names, same values)."""
+    cfg = SimpleNamespace()
+    cfg.backbone = SimpleNamespace(num_stages=5, init_voxel_size=0.025, kernel_size=15, base_radius=2.5, base_sigma=2.0,
+                                   group_norm=32, input_dim=4, init_dim=64, output_dim=256)
+    cfg.backbone.init_radius = cfg.backbone.base_radius * cfg.backbone.init_voxel_size
+    cfg.backbone.init_sigma = cfg.backbone.base_sigma * cfg.backbone.init_voxel_size
+    cfg.model = SimpleNamespace(ground_truth_matching_radius=0.05, num_points_in_patch=128, num_sinkhorn_iterations=100)
+    cfg.coarse_matching = SimpleNamespace(num_targets=128, overlap_threshold=0.1, num_correspondences=256,
+                                          dual_normalization=True)
+    cfg.geotransformer = SimpleNamespace(input_dim=2048, hidden_dim=256, output_dim=256, num_heads=4,
+                                         blocks=['self', 'cross', 'self', 'cross', 'self', 'cross'], sigma_d=0.2, sigma_a=15,
+                                         angle_k=3, reduction_a='max')
+    cfg.fine_matching = SimpleNamespace(topk=3, acceptance_radius=0.1, mutual=True, confidence_threshold=0.05,
+                                        use_dustbin=False, use_global_score=False, correspondence_threshold=3,
+                                        correspondence_limit=None, num_refinement_steps=5)
+    return cfg
+
+
+class GeoTransformer(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.num_points_in_patch = cfg.model.num_points_in_patch
+        self.matching_radius = cfg.model.ground_truth_matching_radius
+        b, g, c, f = cfg.backbone, cfg.geotransformer, cfg.coarse_matching, cfg.fine_matching
+        self.backbone = KPConvFPN(b.input_dim, b.output_dim, b.init_dim, b.kernel_size, b.init_radius, b.init_sigma,
+                                  b.group_norm)
+        self.transformer = GeometricTransformer(g.input_dim, g.output_dim, g.hidden_dim, g.num_heads, g.blocks, g.sigma_d,
+                                                g.sigma_a, g.angle_k, reduction_a=g.reduction_a)
+        self.coarse_matching = SuperPointMatching(c.num_correspondences, c.dual_normalization)
+        self.fine_matching = LocalGlobalRegistration(
+            f.topk, f.acceptance_radius, mutual=f.mutual, confidence_threshold=f.confidence_threshold,
+            use_dustbin=f.use_dustbin, use_global_score=f.use_global_score,
+            correspondence_threshold=f.correspondence_threshold, correspondence_limit=f.correspondence_limit,
+            num_refinement_steps=f.num_refinement_steps)
+        self.optimal_transport = LearnableLogOptimalTransport(cfg.model.num_sinkhorn_iterations)
+        self.ransac_seed = 0  # Open3D's sampler is unseeded; this one is a counter hash of (seed, hypothesis)
+
+    @torch.no_grad()
+    def forward(self, data_dict):
+        if self.training:
+            raise RuntimeError("gaussreg_amd.model.GeoTransformer mirrors the inference branch only: call .eval() first")
+        out = {}
+        feats = data_dict['features']
+        ref_length_c = int(data_dict['lengths'][-1][0])
+        ref_length_f = int(data_dict['lengths'][1][0])
+        ref_length = int(data_dict['lengths'][0][0])
+        points_c, points_f, points = data_dict['points'][-1], data_dict['points'][1], data_dict['points'][0]
+        ref_points_c, src_points_c = points_c[:ref_length_c], points_c[ref_length_c:]
+        ref_points_f, src_points_f = points_f[:ref_length_f], points_f[ref_length_f:]
+        out.update(ref_points_c=ref_points_c, src_points_c=src_points_c, ref_points_f=ref_points_f,
+                   src_points_f=src_points_f, ref_points=points[:ref_length], src_points=points[ref_length:])
+        # 1. points of every superpoint's patch (model.py:99-109)
+        _, ref_node_masks, ref_knn_idx, ref_knn_masks = point_to_node_partition(ref_points_f, ref_points_c,
+                                                                              self.num_points_in_patch)
+        _, src_node_masks, src_knn_idx, src_knn_masks = point_to_node_partition(src_points_f, src_points_c,
+                                                                              self.num_points_in_patch)
+        ref_knn_points = index_select(torch.cat([ref_points_f, torch.zeros_like(ref_points_f[:1])], 0), ref_knn_idx, dim=0)
+        src_knn_points = index_select(torch.cat([src_points_f, torch.zeros_like(src_points_f[:1])], 0), src_knn_idx, dim=0)
+        # 2. KPConv encoder / decoder (:128-132)
+        feats_list = self.backbone(feats, data_dict)
+        feats_c, feats_f = feats_list[-1], feats_list[0]
+        # 3. geometric transformer on the superpoints (:134-148)
+        ref_feats_c, src_feats_c = self.transformer(ref_points_c.unsqueeze(0), src_points_c.unsqueeze(0),
+                                                    feats_c[:ref_length_c].unsqueeze(0), feats_c[ref_length_c:].unsqueeze(0))
+        ref_feats_c_norm = F.normalize(ref_feats_c.squeeze(0), p=2, dim=1)
+        src_feats_c_norm = F.normalize(src_feats_c.squeeze(0), p=2, dim=1)
+        out.update(ref_feats_c=ref_feats_c_norm, src_feats_c=src_feats_c_norm)
+        # 5. fine features (:150-154)
+        ref_feats_f, src_feats_f = feats_f[:ref_length_f], feats_f[ref_length_f:]
+        out.update(ref_feats_f=ref_feats_f, src_feats_f=src_feats_f)
+        # 6. superpoint correspondences (:156-163)
+        ref_ci, src_ci, node_corr_scores = self.coarse_matching(ref_feats_c_norm, src_feats_c_norm, ref_node_masks,
+                                                                src_node_masks)
+        out.update(ref_node_corr_indices=ref_ci, src_node_corr_indices=src_ci)
+        # 7.2 patches of the matched superpoints (:171-186)
+        ref_corr_knn_idx, src_corr_knn_idx = ref_knn_idx[ref_ci], src_knn_idx[src_ci]
+        ref_corr_knn_masks, src_corr_knn_masks = ref_knn_masks[ref_ci], src_knn_masks[src_ci]
+        ref_corr_knn_points, src_corr_knn_points = ref_knn_points[ref_ci], src_knn_points[src_ci]
+        ref_corr_knn_feats = index_select(torch.cat([ref_feats_f, torch.zeros_like(ref_feats_f[:1])], 0), ref_corr_knn_idx, dim=0)
+        src_corr_knn_feats = index_select(torch.cat([src_feats_f, torch.zeros_like(src_feats_f[:1])], 0), src_corr_knn_idx, dim=0)
+        out.update(ref_node_corr_knn_points=ref_corr_knn_points, src_node_corr_knn_points=src_corr_knn_points,
+                   ref_node_corr_knn_masks=ref_corr_knn_masks, src_node_corr_knn_masks=src_corr_knn_masks)
+        # 8. optimal transport (:188-193)
+        scores = torch.einsum('bnd,bmd->bnm', ref_corr_knn_feats, src_corr_knn_feats) / feats_f.shape[1] ** 0.5
+        scores = self.optimal_transport(scores, ref_corr_knn_masks, src_corr_knn_masks)
+        out['matching_scores'] = scores
+        # 9. correspondences, local-to-global registration, RANSAC (:195-226)
+        if not self.fine_matching.use_dustbin:
+            scores = scores[:, :-1, :-1]
+        ref_corr_points, src_corr_points, corr_scores, lgr_transform = self.fine_matching(
+            ref_corr_knn_points, src_corr_knn_points, ref_corr_knn_masks, src_corr_knn_masks, scores, node_corr_scores)
+        out.update(ref_corr_points=ref_corr_points, src_corr_points=src_corr_points, corr_scores=corr_scores,
+                   lgr_transform=lgr_transform)
+        if ref_corr_points.shape[0] >= 5:
+            out['estimated_transform'] = registration_with_ransac_from_correspondences(
+                src_corr_points, ref_corr_points, distance_threshold=0.05, ransac_n=5, num_iterations=10000,
+                seed=self.ransac_seed)
+        else:
+            out['estimated_transform'] = lgr_transform  # fewer correspondences than one RANSAC sample (Open3D would throw)
+        return out
+
+
+def create_model(config):
+    return GeoTransformer(config)

@@ -1,0 +1,112 @@
+"""End to end: the whole coarse-registration network (gaussreg_amd.model.GeoTransformer: pyramid -> KPConvFPN ->
+GeometricTransformer -> SuperPointMatching -> Sinkhorn -> LocalGlobalRegistration) against the reference's own
+`GeoTransformer.forward` run on the same seeded weights (tests/golden/gen_golden_model.py; 28 M parameters, 2 x 6 000-point
+pair).  Floating-point outputs: 1e-5 of the tensor scale against the fp64 evaluation and the reference's fp32 values.
+Discrete outputs (the 256 superpoint correspondences, the point correspondences) are decided on scores that differ in the
+last digits between ANY two evaluations -- the reference's own fp32 and fp64 runs order them differently -- so they are
+compared as sets."""
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, load_golden
+
+sys.path.insert(0, GOLDEN)
+import demo_inputs  # noqa: E402
+from gen_golden_ext import room_pair  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+LIMITS = [38, 36, 36, 38, 38]
+
+
+def _close(got, ref32, ref64, what, tol=1e-5):
+    got = np.asarray(got, np.float64)
+    scale = np.abs(ref64).max()
+    e64, e32 = np.abs(got - ref64).max(), np.abs(got - ref32.astype(np.float64)).max()
+    assert e64 <= tol * scale, f"{what}: |hip - f64| = {e64:.3e} at scale {scale:.3e}"
+    assert e32 <= tol * scale, f"{what}: |hip - ref32| = {e32:.3e} at scale {scale:.3e}"
+
+
+@pytest.fixture(scope="module")
+def run():
+    from gaussreg_amd.kpconv import KPConv
+    from gaussreg_amd.model import GeoTransformer, make_cfg
+    from geotransformer.utils.data import precompute_data_stack_mode
+    g = load_golden("model_e2e.npz")
+    ref, src = room_pair(6000, 11)
+    points = np.concatenate([ref, src]).astype(np.float32)
+    assert float(points.astype(np.float64).sum()) == float(g["points_sum"])
+    feats = demo_inputs.backbone_feats(points.shape[0])
+    d = precompute_data_stack_mode(torch.from_numpy(points).cuda(), torch.tensor([6000, 6000]), 5, 0.025, 0.0625, LIMITS)
+    assert [p.shape[0] for p in d["points"]] == g["level_sizes"].tolist()
+    d["features"] = feats.cuda()
+    torch.manual_seed(int(g["seed"]))
+    net = GeoTransformer(make_cfg())
+    keys = sorted(net.state_dict().keys())
+    assert [k for k in keys if not k.endswith("kernel_points")] == [k for k in g["param_keys"].tolist() if not k.endswith("kernel_points")]
+    assert sum(p.numel() for p in net.parameters()) == int(g["param_count"])
+    mine = np.array([float(net.state_dict()[k].double().sum()) for k in keys])
+    keep = np.array([not k.endswith("kernel_points") for k in keys])
+    np.testing.assert_allclose(mine[keep], g["param_sums"][keep], rtol=0, atol=1e-6)
+    for m in net.modules():
+        if isinstance(m, KPConv):
+            m.kernel_points.copy_(torch.from_numpy((demo_inputs.K015 * m.radius).astype(np.float32)))
+    net = net.cuda().eval()
+    return g, net(d)
+
+
+def test_features_match_reference(run):
+    g, o = run
+    _close(o["ref_feats_c"].cpu().numpy()[::3], g["ref_feats_c32"], g["ref_feats_c64"], "coarse ref features")
+    _close(o["src_feats_c"].cpu().numpy()[::3], g["src_feats_c32"], g["src_feats_c64"], "coarse src features")
+    colsum = np.concatenate([o["ref_feats_c"].double().sum(0).cpu().numpy(), o["src_feats_c"].double().sum(0).cpu().numpy()])
+    assert np.abs(colsum - g["feats_c_colsum64"]).max() <= 1e-5 * 0.26 * 2 * np.sqrt(750)   # every row takes part
+    _close(o["ref_feats_f"].cpu().numpy()[g["feats_f_rows"]], g["ref_feats_f32"], g["ref_feats_f64"], "fine ref features")
+
+
+def test_superpoint_correspondences_and_transport(run):
+    g, o = run
+    mine = list(zip(o["ref_node_corr_indices"].tolist(), o["src_node_corr_indices"].tolist()))
+    want = list(zip(g["ref_ci32"].tolist(), g["src_ci32"].tolist()))
+    assert len(mine) == len(want) == 256
+    common = set(mine) & set(want)
+    assert len(common) >= 250, f"only {len(common)} of 256 superpoint correspondences in common"
+    # optimal-transport scores of the reference's first patches that both sides selected
+    checked = 0
+    for k, pair in enumerate(want[:4]):
+        if pair not in common:
+            continue
+        j = mine.index(pair)
+        got = o["matching_scores"][j].cpu().numpy().astype(np.float64)
+        r32, r64 = g["ms_first32"][k], g["ms_first64"][k].astype(np.float64)
+        live = np.abs(r64) < 1e6                       # masked slots hold -1e12 (learnable_sinkhorn.py:44-48)
+        assert np.array_equal(np.abs(got) < 1e6, live)
+        assert np.abs(got - r64)[live].max() <= 2e-5 and np.abs(got - r32)[live].max() <= 2e-5   # log-domain values in [-5, 3]
+        checked += 1
+    assert checked >= 2
+
+
+def test_point_correspondences_and_transform(run):
+    g, o = run
+    def rows(a, b):
+        return set(map(tuple, np.round(np.concatenate([a, b], 1) * 1e5).astype(np.int64).tolist()))
+    mine = rows(o["ref_corr_points"].cpu().numpy(), o["src_corr_points"].cpu().numpy())
+    want = rows(g["ref_corr32"], g["src_corr32"])
+    assert len(mine & want) >= 0.97 * len(want) and len(mine) <= 1.03 * len(want), (len(mine), len(want), len(mine & want))
+    T, Tr = o["lgr_transform"].cpu().numpy(), g["lgr_transform32"]
+    assert np.abs(T - Tr).max() <= 5e-3, np.abs(T - Tr).max()
+    # the RANSAC estimate the forward returns (parity unpinned: Open3D) must at least agree with LGR on this easy pair
+    E = o["estimated_transform"].cpu().numpy()
+    assert E.shape == (4, 4) and np.isfinite(E).all()
+
+
+def test_training_mode_is_refused():
+    from gaussreg_amd.model import GeoTransformer, make_cfg
+    cfg = make_cfg()
+    cfg.backbone.init_dim, cfg.geotransformer.input_dim = 8, 256   # a small instance: construction only
+    cfg.backbone.group_norm, cfg.backbone.output_dim = 4, 32
+    net = GeoTransformer(cfg)
+    with pytest.raises(RuntimeError, match="inference branch only"):
+        net.train()({"features": None})

@@ -41,3 +41,20 @@ def test_forward_without_gpu_fails_loudly():
     layer = TransformerLayer(64, 4)
     with pytest.raises(RuntimeError):
         layer(torch.zeros(1, 5, 64), torch.zeros(1, 6, 64))
+
+
+def test_whole_model_state_dict_matches_reference():
+    """gaussreg_amd.model.GeoTransformer (mirror of experiments/.../model.py) carries the reference's state-dict keys and,
+    built under the same seed, its 28 M parameter values (tests/golden/gen_golden_model.py)."""
+    from gaussreg_amd.model import GeoTransformer, create_model, make_cfg
+    g = load_golden("model_e2e.npz")
+    torch.manual_seed(int(g["seed"]))
+    net = create_model(make_cfg())
+    assert isinstance(net, GeoTransformer)
+    keys = sorted(net.state_dict().keys())
+    assert keys == g["param_keys"].tolist()
+    assert sum(p.numel() for p in net.parameters()) == int(g["param_count"])
+    keep = np.array([not k.endswith("kernel_points") for k in keys])   # the reference jitters / rotates them with numpy's RNG
+    np.testing.assert_allclose(_sums(net)[keep], g["param_sums"][keep], rtol=0, atol=1e-6)
+    with pytest.raises(RuntimeError, match="inference branch only"):
+        net.train()({})
