@@ -402,3 +402,151 @@ extern "C" int gr_neighbor_pool(const float* x, int64_t n, int64_t c, const int6
   GR_LAUNCH_CHECK();
   return GR_OK;
 }
+
+// ---------------------------------------------------------------- GroupNorm over a (N, C) point-feature matrix
+// geotransformer/modules/kpconv/modules.py:32-50 transposes the matrix to (1, C, N) and calls nn.GroupNorm: one mean and
+// one variance per group of C / G channels over ALL N points.  ATen's kernel gives that shape one workgroup per group (32
+// rows of 60 000 x C/32 values: 5.6 ms of the 16 ms backbone, plus 2.3 ms for the two transposes); here the matrix stays
+// (N, C): pass 1 streams it once with float4 loads and leaves per-workgroup (sum, sum of squares) partials in fp64, one
+// workgroup folds them into mean / rstd per group, pass 2 streams the matrix again and applies (x - mean) * rstd * gamma + beta (+ the LeakyReLU that always follows, modules.py:75,138).
+namespace gr {
+namespace {
+
+constexpr int GN_T = 256;
+constexpr int GN_BLOCKS = 256;  // pass 1 workgroups (grid-stride over row tiles)
+constexpr int GN_MAXG = 64;
+
+// The float4 a thread reads belongs to columns 4*col4 .. 4*col4+3, fixed for the thread when C/4 <= 256 (the row index
+// advances instead); wider rows give every thread C/1024 column positions.
+template <bool APPLY>
+__global__ __launch_bounds__(GN_T) void group_norm_kernel(const float* __restrict__ x, int64_t n, int c, int groups,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float slope, double* __restrict__ partial, int nblk_a,
+                                                          float* __restrict__ out) {
+  __shared__ double s_acc[2 * GN_MAXG];
+  __shared__ float s_mean[GN_MAXG], s_rstd[GN_MAXG];
+  const int cols4 = c / 4, cg = c / groups;
+  const int tid = threadIdx.x;
+  const int npos = cols4 > GN_T ? cols4 / GN_T : 1;          // column positions per thread
+  const int rows_per_pass = cols4 >= GN_T ? 1 : GN_T / cols4;  // rows a workgroup covers per step
+  const int col_base = cols4 >= GN_T ? tid : tid % cols4;
+  const int rsub = cols4 >= GN_T ? 0 : tid / cols4;
+  if (APPLY) {
+    // mean / rstd of every group, left behind the partials by group_norm_stats_kernel
+    const float* stats = reinterpret_cast<const float*>(partial + (int64_t)nblk_a * 2 * groups);
+    if (tid < groups) {
+      s_mean[tid] = stats[tid];
+      s_rstd[tid] = stats[groups + tid];
+    }
+    __syncthreads();
+  } else {
+    for (int i = tid; i < 2 * groups; i += GN_T) s_acc[i] = 0.0;
+    __syncthreads();
+  }
+  for (int p = 0; p < npos; ++p) {
+    const int col4 = col_base + p * GN_T;
+    const int ch = 4 * col4;
+    float4 ga = make_float4(1.f, 1.f, 1.f, 1.f), be = make_float4(0.f, 0.f, 0.f, 0.f);
+    float mean[4], rstd[4];
+    if (APPLY) {
+      if (gamma) ga = *reinterpret_cast<const float4*>(gamma + ch);
+      if (beta) be = *reinterpret_cast<const float4*>(beta + ch);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        mean[j] = s_mean[(ch + j) / cg];
+        rstd[j] = s_rstd[(ch + j) / cg];
+      }
+    }
+    double sum[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
+    for (int64_t r = (int64_t)blockIdx.x * rows_per_pass + rsub; r < n; r += (int64_t)gridDim.x * rows_per_pass) {
+      const float4 v = *reinterpret_cast<const float4*>(x + r * c + ch);
+      if (APPLY) {
+        float4 y;
+        y.x = (v.x - mean[0]) * rstd[0] * ga.x + be.x;
+        y.y = (v.y - mean[1]) * rstd[1] * ga.y + be.y;
+        y.z = (v.z - mean[2]) * rstd[2] * ga.z + be.z;
+        y.w = (v.w - mean[3]) * rstd[3] * ga.w + be.w;
+        y.x = y.x >= 0.f ? y.x : y.x * slope;
+        y.y = y.y >= 0.f ? y.y : y.y * slope;
+        y.z = y.z >= 0.f ? y.z : y.z * slope;
+        y.w = y.w >= 0.f ? y.w : y.w * slope;
+        *reinterpret_cast<float4*>(out + r * c + ch) = y;
+      } else {
+        sum[0] += v.x, sum[1] += v.y, sum[2] += v.z, sum[3] += v.w;
+        sq[0] += (double)v.x * v.x, sq[1] += (double)v.y * v.y, sq[2] += (double)v.z * v.z, sq[3] += (double)v.w * v.w;
+      }
+    }
+    if (!APPLY) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int g = (ch + j) / cg;
+        atomicAdd(&s_acc[g], sum[j]);
+        atomicAdd(&s_acc[groups + g], sq[j]);
+      }
+    }
+  }
+  if (!APPLY) {
+    __syncthreads();
+    for (int i = tid; i < 2 * groups; i += GN_T) partial[(int64_t)blockIdx.x * 2 * groups + i] = s_acc[i];
+  }
+}
+
+// one workgroup: fold the pass-1 partials (nblk x 2G doubles) into mean / rstd per group, four lanes per (group, moment)
+__global__ __launch_bounds__(GN_T) void group_norm_stats_kernel(double* __restrict__ partial, int nblk, int groups, int64_t n,
+                                                                int cg, float eps) {
+  __shared__ double s_tot[2 * GN_MAXG];
+  const int tid = threadIdx.x, item = tid / 4, sub = tid % 4;  // 2 * groups <= 128 items x 4 lanes <= 512: loop below
+  for (int it = item; it < 2 * groups; it += GN_T / 4) {
+    double acc = 0.0;
+    for (int b = sub; b < nblk; b += 4) acc += partial[(int64_t)b * 2 * groups + it];
+    acc += __shfl_xor(acc, 1, WAVE);
+    acc += __shfl_xor(acc, 2, WAVE);
+    if (sub == 0) s_tot[it] = acc;
+  }
+  __syncthreads();
+  float* stats = reinterpret_cast<float*>(partial + (int64_t)nblk * 2 * groups);
+  if (tid < groups) {
+    const double cnt = (double)n * (double)cg;
+    const double mean = s_tot[tid] / cnt;
+    const double var = fmax(s_tot[groups + tid] / cnt - mean * mean, 0.0);
+    stats[tid] = (float)mean;
+    stats[groups + tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+}  // namespace
+}  // namespace gr
+
+extern "C" size_t gr_group_norm_workspace_bytes(int64_t groups) {
+  return groups > 0 ? (size_t)gr::GN_BLOCKS * 2 * (size_t)groups * sizeof(double) + 2 * (size_t)groups * sizeof(float) + 256 : 0;
+}
+
+extern "C" int gr_group_norm(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta,
+                             float eps, float negative_slope, float* out, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GR_REQUIRE(n >= 0 && c >= 4 && groups >= 1 && groups <= gr::GN_MAXG && c % groups == 0, "group_norm: bad sizes");
+  const int64_t cols4 = c / 4;
+  GR_REQUIRE(c % 4 == 0 && ((cols4 <= gr::GN_T && gr::GN_T % cols4 == 0) || (cols4 > gr::GN_T && cols4 % gr::GN_T == 0)),
+             "group_norm: %lld channels are not supported (C / 4 must divide 256 or be a multiple of it)", (long long)c);
+  if (n == 0) return GR_OK;
+  GR_REQUIRE(x && out, "null argument");
+  GR_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0, "group_norm: unaligned tensors");
+  if (!ws || ws_bytes < gr_group_norm_workspace_bytes(groups)) {
+    set_error("group_norm workspace too small");
+    return GR_ERR_WORKSPACE;
+  }
+  const int rows_per_pass = cols4 >= gr::GN_T ? 1 : (int)(gr::GN_T / cols4);
+  const int tiles = (int)std::min<int64_t>((n + rows_per_pass - 1) / rows_per_pass, 1 << 20);
+  const int nblk_a = std::min(gr::GN_BLOCKS, tiles);
+  const int nblk_b = std::min(tiles, 4096);
+  double* partial = static_cast<double*>(ws);
+  KernelTimer timer("group_norm", stream);
+  hipLaunchKernelGGL(gr::group_norm_kernel<false>, dim3(nblk_a), dim3(gr::GN_T), 0, stream, x, n, (int)c, (int)groups, gamma,
+                     beta, eps, negative_slope, partial, nblk_a, out);
+  hipLaunchKernelGGL(gr::group_norm_stats_kernel, dim3(1), dim3(gr::GN_T), 0, stream, partial, nblk_a, (int)groups, n,
+                     (int)(c / groups), eps);
+  hipLaunchKernelGGL(gr::group_norm_kernel<true>, dim3(nblk_b), dim3(gr::GN_T), 0, stream, x, n, (int)c, (int)groups, gamma,
+                     beta, eps, negative_slope, partial, nblk_a, out);
+  GR_LAUNCH_CHECK();
+  return GR_OK;
+}

@@ -1,10 +1,11 @@
 """Mirror of geotransformer/modules/kpconv/modules.py (inference): the blocks KPConvFPN is assembled from
-(backbone.py:95-162), with the HIP KPConv / maxpool / nearest_upsample inside.  Sub-module names and parameter shapes
-follow the reference so its checkpoints load key for key (`KPConv.weights`, `norm.norm.weight`, `mlp.weight`, ...).
-The dense pieces (nn.Linear, nn.GroupNorm, LeakyReLU) are stock PyTorch-ROCm layers, as in the reference."""
+(backbone.py:95-162), with the HIP KPConv / maxpool / nearest_upsample / GroupNorm inside.  Sub-module names and parameter
+shapes follow the reference so its checkpoints load key for key (`KPConv.weights`, `norm.norm.weight`, `mlp.weight`, ...).
+nn.Linear stays the stock PyTorch-ROCm layer (rocBLAS), as in the reference."""
 import torch
 import torch.nn as nn
 
+from . import _lib
 from .kpconv import KPConv, maxpool, nearest_upsample
 
 
@@ -16,13 +17,39 @@ class GroupNorm(nn.Module):
         self.num_groups, self.num_channels = num_groups, num_channels
         self.norm = nn.GroupNorm(num_groups, num_channels)
 
-    def forward(self, x):
-        y = self.norm(x.t().unsqueeze(0))     # (N, C) -> (1, C, N): statistics per group over all points
-        return y.squeeze(0).t().squeeze()     # the trailing squeeze() is the reference's (modules.py:50)
+    def forward(self, x, negative_slope=None):
+        """`negative_slope`: fuse the LeakyReLU that follows the norm in every block (None: plain GroupNorm)."""
+        c = self.num_channels
+        hip_ok = (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and not torch.is_grad_enabled() and c % 4 == 0
+                  and ((c // 4 <= 256 and 256 % (c // 4) == 0) or (c // 4) % 256 == 0) and self.num_groups <= 64)
+        if not hip_ok:
+            y = self.norm(x.t().unsqueeze(0))     # (N, C) -> (1, C, N): statistics per group over all points
+            y = y.squeeze(0).t().squeeze()        # the trailing squeeze() is the reference's (modules.py:50)
+            return y if negative_slope is None else nn.functional.leaky_relu(y, negative_slope)
+        L = _lib.lib()
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        dev = x.device
+        with torch.cuda.device(dev):
+            ws = _lib.workspace(dev, L.gr_group_norm_workspace_bytes(self.num_groups))
+            w, b = self.norm.weight, self.norm.bias
+            _lib.check(L.gr_group_norm(_lib.ptr(x), x.shape[0], c, self.num_groups,
+                                       _lib.ptr(None if w is None else w.detach().contiguous()),
+                                       _lib.ptr(None if b is None else b.detach().contiguous()), float(self.norm.eps),
+                                       1.0 if negative_slope is None else float(negative_slope), _lib.ptr(out), _lib.ptr(ws),
+                                       ws.numel(), _lib.stream_ptr(dev)))
+        return out.squeeze()
 
 
 def _norm(out_channels, group_norm, layer_norm):
     return nn.LayerNorm(out_channels) if layer_norm else GroupNorm(group_norm, out_channels)
+
+
+def _norm_act(norm, x, negative_slope):
+    """norm -> LeakyReLU, in one kernel when the norm is the HIP GroupNorm."""
+    if isinstance(norm, GroupNorm):
+        return norm(x, negative_slope)
+    return nn.functional.leaky_relu(norm(x), negative_slope)
 
 
 class UnaryBlock(nn.Module):
@@ -36,8 +63,8 @@ class UnaryBlock(nn.Module):
         self.leaky_relu = nn.LeakyReLU(0.1) if has_relu else None
 
     def forward(self, x):
-        x = self.norm(self.mlp(x))
-        return x if self.leaky_relu is None else self.leaky_relu(x)
+        x = self.mlp(x)
+        return self.norm(x) if self.leaky_relu is None else _norm_act(self.norm, x, self.leaky_relu.negative_slope)
 
 
 class LastUnaryBlock(nn.Module):
@@ -64,7 +91,7 @@ class ConvBlock(nn.Module):
         self.leaky_relu = nn.LeakyReLU(negative_slope=negative_slope)
 
     def forward(self, s_feats, q_points, s_points, neighbor_indices):
-        return self.leaky_relu(self.norm(self.KPConv(s_feats, q_points, s_points, neighbor_indices)))
+        return _norm_act(self.norm, self.KPConv(s_feats, q_points, s_points, neighbor_indices), self.leaky_relu.negative_slope)
 
 
 class ResidualBlock(nn.Module):
@@ -87,7 +114,7 @@ class ResidualBlock(nn.Module):
 
     def forward(self, s_feats, q_points, s_points, neighbor_indices):
         x = self.KPConv(self.unary1(s_feats), q_points, s_points, neighbor_indices)
-        x = self.unary2(self.leaky_relu(self.norm_conv(x)))
+        x = self.unary2(_norm_act(self.norm_conv, x, self.leaky_relu.negative_slope))
         shortcut = maxpool(s_feats, neighbor_indices) if self.strided else s_feats
         return self.leaky_relu(x + self.unary_shortcut(shortcut))
 

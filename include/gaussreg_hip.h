@@ -211,6 +211,14 @@ int gr_gather_rows(const float* data, int64_t n, int64_t c, const int64_t* index
                    int* d_error_flag, void* stream);
 int gr_neighbor_pool(const float* x, int64_t n, int64_t c, const int64_t* neighbor_indices, int64_t m, int64_t h,
                      int mode, float* out, void* stream);
+/* gr_group_norm: geotransformer/modules/kpconv/modules.py:32-50 GroupNorm.forward on the (N, C) matrix itself (the
+ * reference transposes to (1, C, N) for nn.GroupNorm): statistics per group of C / groups channels over all n rows, biased
+ * variance, y = (x - mean) / sqrt(var + eps) * gamma + beta, then LeakyReLU(negative_slope) -- pass 1.0f for none (the
+ * blocks of modules.py:53-145 always follow the norm with LeakyReLU(0.1)).  gamma / beta (c) may be null.  C must be a
+ * multiple of 4 with C / 4 dividing 256 or a multiple of 256. */
+size_t gr_group_norm_workspace_bytes(int64_t groups);
+int gr_group_norm(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta, float eps,
+                  float negative_slope, float* out, void* ws, size_t ws_bytes, void* stream);
 /* gr_gs_fuse ("next" row): gs_fusion.py:231-262 gaussian_fuse on the GS .ply wire format.
  * rec1 / rec2: device arrays of 62-float vertex records (gs_fusion.py:172-184 property order).  The host
  * passes the similarity transform split as the reference does (:237-240): h_rotation (3x3 row-major, scale

@@ -288,3 +288,27 @@ def test_fps_pruned_rounds_stay_exact(n, batch, k):
     got = farthest_point_sampling(_c(pts), [n] * batch, [k] * batch, start_indices=[(3 * b) % n for b in range(batch)])
     for b in sorted({0, batch // 2, batch - 1}):
         assert np.array_equal(got[b].cpu().numpy(), M.farthest_point_sampling(clouds[b], k, (3 * b) % n)), f"cloud {b}"
+
+
+@pytest.mark.parametrize("n,c,groups,slope", [(60000, 64, 32, 0.1), (49505, 32, 32, None), (28020, 128, 32, 0.1),
+                                              (9034, 512, 32, 0.1), (1534, 2048, 32, None), (7, 256, 8, 0.2), (1, 64, 32, None)])
+def test_group_norm_matches_torch_fp64(n, c, groups, slope):
+    """gr_group_norm (the (N, C) GroupNorm of kpconv/modules.py:32-50, optionally fused with the LeakyReLU that follows)
+    against nn.GroupNorm evaluated in fp64 on the transposed tensor, at the backbone's shapes: 1e-5 of the tensor scale."""
+    from gaussreg_amd.kpconv_blocks import GroupNorm
+    torch.manual_seed(n + c)
+    m = GroupNorm(groups, c).cuda().eval()
+    with torch.no_grad():
+        m.norm.weight.uniform_(0.5, 1.5)
+        m.norm.bias.uniform_(-0.5, 0.5)
+        x = (torch.randn(n, c, device="cuda") * 3 + torch.linspace(-2, 2, c, device="cuda")).contiguous()
+        got = m(x, slope)
+        ref = torch.nn.functional.group_norm(x.double().t().unsqueeze(0), groups, m.norm.weight.double(), m.norm.bias.double(),
+                                             m.norm.eps).squeeze(0).t()
+        if slope is not None:
+            ref = torch.nn.functional.leaky_relu(ref, slope)
+    assert got.shape == ref.squeeze().shape
+    if n == 1:
+        return  # one point: the variance of a single sample per channel group is what torch computes too; shape only
+    err = (got.double().reshape(ref.shape) - ref).abs().max().item()
+    assert err <= 1e-5 * ref.abs().max().item(), (err, ref.abs().max().item())

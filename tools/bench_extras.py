@@ -160,6 +160,16 @@ def run(dev):
         out["rpe_attention_fused"] = _hbm(tot.value / max(cnt.value, 1), 4.0 * n * n * 256 + 4.0 * 4 * n * n + 3 * 4.0 * n * 256,
                                           module_ms_incl_projections=round(ms_mod, 4), shape=[n, 256, 4])
         del emb
+        # ---- the whole network (gaussreg_amd.model.GeoTransformer, random weights) on the 2 x 30 000-pt demo pyramid
+        from gaussreg_amd.model import GeoTransformer, make_cfg
+        torch.manual_seed(0)
+        net = GeoTransformer(make_cfg()).to(dev).eval()
+        dd = dict(d)
+        dd["features"] = torch.rand(d["points"][0].shape[0], 4, device=dev, generator=g)
+        ms = _ms(lambda: net(dd), 5, 2)
+        out["model_forward_2x30k"] = {"ms": round(ms, 3), "superpoints": [int(x) for x in d["lengths"][-1].tolist()],
+                                      "note": "pyramid given; KPConvFPN + GeometricTransformer + matching + Sinkhorn + LGR + RANSAC"}
+        del net, dd
         # ---- FPS 200 k -> 30 k, two clouds per call
         r_, s_, _ = pair_pipeline.synthetic_room_pair(0, 200000, dev)
         big = torch.cat([r_, s_]).contiguous()
