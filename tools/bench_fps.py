@@ -20,4 +20,4 @@ for _ in range(3):
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / 3 * 1e3
 chk = sum(int(i.sum()) for i in idx)
-print(f"T={os.environ.get('GR_FPS_THREADS','auto')} B={B}: {ms:.2f} ms per call, {ms / B:.3f} ms per cloud, checksum {chk}", flush=True)
+print(f"B={B}: {ms:.2f} ms per call, {ms / B:.3f} ms per cloud, checksum {chk}", flush=True)
