@@ -111,7 +111,7 @@ class _Section:
 class PairRegistrar:
     """Holds the stateless operator modules and the descriptors; `register_pairs` runs a batch."""
 
-    def __init__(self, device, num_samples=30000, fps_clouds_per_call=16, order="reference", use_ransac=True,
+    def __init__(self, device, num_samples=30000, fps_clouds_per_call=24, order="reference", use_ransac=True,
                  profile=False, pair_streams=4):
         """`pair_streams`: after the batched stages (FPS, pyramid) every pair runs its own short chain of launch-bound
         kernels with two host read-backs (correspondence count, RANSAC result); `pair_streams` host threads, each with
@@ -149,8 +149,12 @@ class PairRegistrar:
         clouds = [p[0] for p in pairs] + [p[1] for p in pairs]
         sampled = []
         with self._sec("fps"):
-            for i in range(0, 2 * B, self.fps_clouds_per_call):
-                chunk = clouds[i:i + self.fps_clouds_per_call]
+            # at most fps_clouds_per_call clouds per launch (the co-operating workgroups of a call share the 256 CUs; 24
+            # clouds of 200 k points still fit their slabs in registers), in calls of equal size
+            n_calls = -(-2 * B // self.fps_clouds_per_call)
+            bounds = [round(i * 2 * B / n_calls) for i in range(n_calls + 1)]
+            for lo_, hi_ in zip(bounds[:-1], bounds[1:]):
+                chunk = clouds[lo_:hi_]
                 lens = [c.shape[0] for c in chunk]
                 ks = [min(self.num_samples, n) for n in lens]
                 if all(k == n for k, n in zip(ks, lens)):
