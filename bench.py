@@ -347,6 +347,7 @@ def run_gpu(h, args):
         L.gr_timing_enable(0)
         L.gr_timing_reset()
         local = torch.cat(rows, 0)
+        reg.close()
         counts = [sharding.shard_bounds(n_total, r, world)[1] - sharding.shard_bounds(n_total, r, world)[0] for r in range(world)]
         allres = sharding.gather_rows(local, counts)          # ONE all_gather of (pairs, 20) floats (RCCL over xGMI)
         rre, rte = allres[:, 16], allres[:, 17]

@@ -139,6 +139,16 @@ class PairRegistrar:
     def _sec(self, name):
         return _Section(self, name)
 
+    def close(self):
+        """Join the worker threads and drop their streams (so nothing of this object is left for interpreter shutdown)."""
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+        if self._streams is not None:
+            for st in self._streams:
+                st.synchronize()
+            self._streams = None
+
     @torch.no_grad()
     def register_pairs(self, pairs):
         """pairs: list of (ref (n,3), src (m,3), T_gt (4,4) or None) device tensors.
