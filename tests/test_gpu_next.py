@@ -312,3 +312,15 @@ def test_group_norm_matches_torch_fp64(n, c, groups, slope):
         return  # one point: the variance of a single sample per channel group is what torch computes too; shape only
     err = (got.double().reshape(ref.shape) - ref).abs().max().item()
     assert err <= 1e-5 * ref.abs().max().item(), (err, ref.abs().max().item())
+
+
+def test_group_norm_unsupported_width_takes_the_torch_path():
+    """C / 4 = 6 does not divide 256: GroupNorm falls back to nn.GroupNorm on the transposed tensor (still on the GPU)."""
+    from gaussreg_amd.kpconv_blocks import GroupNorm
+    torch.manual_seed(3)
+    m = GroupNorm(8, 24).cuda().eval()
+    x = torch.randn(1000, 24, device="cuda")
+    with torch.no_grad():
+        got = m(x, 0.1)
+        ref = torch.nn.functional.leaky_relu(m.norm(x.t().unsqueeze(0)).squeeze(0).t(), 0.1)
+    assert torch.allclose(got, ref, atol=1e-6)
