@@ -971,9 +971,9 @@ int check_views(const gr_raster_view* h_views, int num_views) {
 }
 
 // dv must stay alive until `stream` is synchronised by the caller
-int upload_views(const gr_raster_view* h_views, int num_views, std::vector<DevView>& dv, DevView* d_views,
+int upload_views(const gr_raster_view* h_views, int num_views, DevView* d_views,
                  hipStream_t stream) {
-  (void)dv;
+  // staged in pinned per-thread scratch: every caller synchronises the stream before it returns
   DevView* stage = static_cast<DevView*>(pinned_scratch(0, sizeof(DevView) * num_views));
   GR_REQUIRE(stage != nullptr, "pinned staging buffer for %d views could not be allocated", num_views);
   for (int v = 0; v < num_views; ++v) {
@@ -1040,8 +1040,7 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
       set_error("raster geometry buffer too small: need %zu bytes, got %zu", g0.bytes, geom_bytes);
       return GR_ERR_WORKSPACE;
     }
-    std::vector<DevView> dv0;
-    rc = upload_views(h_views, num_views, dv0, g0.views, stream);
+    rc = upload_views(h_views, num_views, g0.views, stream);
     if (rc != GR_OK) return rc;
     GR_HIP(hipStreamSynchronize(stream));
     return GR_OK;
@@ -1065,8 +1064,7 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
     set_error("raster geometry buffer too small: need %zu bytes, got %zu", g.bytes, geom_bytes);
     return GR_ERR_WORKSPACE;
   }
-  std::vector<DevView> dv;  // alive until the synchronise below
-  rc = upload_views(h_views, num_views, dv, g.views, stream);
+  rc = upload_views(h_views, num_views, g.views, stream);
   if (rc != GR_OK) return rc;
   const dim3 blk(256), grd((unsigned)((P + 255) / 256));
   const bool sh16 = shs != nullptr && M == 16 && (reinterpret_cast<uintptr_t>(shs) % 16 == 0);
