@@ -154,6 +154,21 @@ __device__ __forceinline__ int wave_incl_scan_add_dpp(int v) {
   return v;
 }
 
+// wave-wide sum of a double on the same network (two 32-bit DPP moves + one v_add_f64 per step; lanes without a source
+// add +0.0), fixed order; the result is valid in every lane.  A __shfl_xor butterfly on doubles is 12 ds_bpermute trips.
+__device__ __forceinline__ double wave_sum_f64_dpp(double x) {
+#define GR_F64_STEP(CTRL, ROWMASK)                                                                         \
+  {                                                                                                        \
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROWMASK, 0xf, false);           \
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROWMASK, 0xf, false);           \
+    x += __hiloint2double(hi, lo);                                                                         \
+  }
+  GR_F64_STEP(0x111, 0xf) GR_F64_STEP(0x112, 0xf) GR_F64_STEP(0x114, 0xf) GR_F64_STEP(0x118, 0xf)
+  GR_F64_STEP(0x142, 0xa) GR_F64_STEP(0x143, 0xc)
+#undef GR_F64_STEP
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
+}
+
 // wave-wide min / max / sum of an int on the same network; the result is valid in every lane (read back from lane 63)
 #define GR_DPP_REDUCE(NAME, OP, IDENT)                                                         \
   __device__ __forceinline__ int NAME(int v) {                                                 \

@@ -71,10 +71,7 @@ template <int NV>
 __device__ void block_sum(double* v, double* sh /* [NV][LG_T/64] + NV */) {
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    double x = v[k];
-#pragma unroll
-    for (int d = WAVE / 2; d > 0; d >>= 1) x += __shfl_xor(x, d, WAVE);
-    v[k] = x;
+    v[k] = wave_sum_f64_dpp(v[k]);
   }
   __syncthreads();
   const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
@@ -196,16 +193,32 @@ __global__ __launch_bounds__(LG_T) void lgr_refine_kernel(const float* __restric
   __shared__ double sh[9 * (LG_T / WAVE) + 16];
   __shared__ float T[12];
   __shared__ int best_sh;
-  if (threadIdx.x == 0) {
-    int best = -1, bn = -1;
-    for (int p = 0; p < B; ++p)
-      if (inliers[p] > bn) {  // first maximum, like argmax
-        bn = inliers[p];
-        best = p;
+  {
+    // first maximum, like argmax: key = (inliers + 1, ~index) so that the largest key is the lowest index of the largest
+    // count (inliers = -1 marks an invalid hypothesis: key 0 .. never beats a valid one, best stays -1)
+    unsigned long long key = 0ull;
+    for (int p = threadIdx.x; p < B; p += LG_T) {
+      const int c = inliers[p];
+      if (c >= 0) {
+        const unsigned long long k = ((unsigned long long)(unsigned)(c + 1) << 32) | (0xffffffffu - (unsigned)p);
+        key = k > key ? k : key;
       }
-    best_sh = best;
+    }
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) {
+      const unsigned long long o = __shfl_xor(key, d, WAVE);
+      key = o > key ? o : key;
+    }
+    unsigned long long* kw = reinterpret_cast<unsigned long long*>(sh);
+    if ((threadIdx.x & (WAVE - 1)) == 0) kw[threadIdx.x / WAVE] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long m = 0ull;
+      for (int w = 0; w < LG_T / WAVE; ++w) m = kw[w] > m ? kw[w] : m;
+      best_sh = m ? (int)(0xffffffffu - (unsigned)(m & 0xffffffffull)) : -1;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const int best = best_sh;
   if (best >= 0) {
     if (threadIdx.x < 12) T[threadIdx.x] = transforms[best * 12 + threadIdx.x];

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(1024) void ransac_best_kernel(const float* __restri
   __shared__ int s_cnt[1024];
   __shared__ float s_err[1024];
   __shared__ int s_id[1024];
-  __shared__ double s_acc[1][1024 / WAVE];
+  __shared__ double s_acc[17][1024 / WAVE];
   __shared__ float T[12];
   int bc = -2, bi = -1;
   float be = INFINITY;
@@ -235,14 +235,14 @@ __global__ __launch_bounds__(1024) void ransac_best_kernel(const float* __restri
       }
     }
     double red[17];
+    for (int k = 0; k < 17; ++k) acc[k] = wave_sum_f64_dpp(acc[k]);
+    __syncthreads();
+    if ((threadIdx.x & (WAVE - 1)) == 0)
+      for (int k = 0; k < 17; ++k) s_acc[k][threadIdx.x / WAVE] = acc[k];
+    __syncthreads();
     for (int k = 0; k < 17; ++k) {
-      double v = acc[k];
-      for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, WAVE);
-      __syncthreads();
-      if ((threadIdx.x & (WAVE - 1)) == 0) s_acc[0][threadIdx.x / WAVE] = v;
-      __syncthreads();
       double t = 0;
-      for (int w = 0; w < 1024 / WAVE; ++w) t += s_acc[0][w];
+      for (int w = 0; w < 1024 / WAVE; ++w) t += s_acc[k][w];
       red[k] = t;
     }
     if (threadIdx.x == 0) {
