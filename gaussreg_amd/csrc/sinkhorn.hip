@@ -12,15 +12,77 @@
 namespace gr {
 namespace {
 
-constexpr int SK_PARTS = 4;   // threads per row / column
-constexpr int SK_T = 576;     // >= SK_PARTS * (max(M,N)+1) for the demo shape (4 * 129 = 516), 9 waves
-constexpr int SK_PER = (SK_T / SK_PARTS + SK_PARTS - 1) / SK_PARTS;  // elements of a row / column one thread reduces (<= 36)
+constexpr int SK_PARTS = 4;   // lanes per row / column (adjacent lanes: their partials meet through two DPP steps)
+constexpr int SK_T = 512;     // 8 waves, two per SIMD: 128 rows (columns) x 4 lanes; the demo shape's 129th row and column
+                              // (the dustbins) are reduced by whole waves on the side
+constexpr int SK_MAIN = SK_T / SK_PARTS;  // rows / columns that get their own four lanes
+constexpr int SK_MAXD = 144;  // largest M + 1 / N + 1 supported
+constexpr int SK_PER = SK_MAXD / SK_PARTS;  // elements of a row / column one lane reduces (<= 36)
 
 __device__ __forceinline__ float lse_finish(float mx, float s) { return logf(s) + mx; }
 
-// Thread (part p, index i) reduces a contiguous quarter of row / column i to a (max, sum-exp) partial;
-// part 0 merges the four partials in fixed order.  Row stride is odd, so lanes that differ in i hit
-// different banks in both passes.
+// row stride of the padded matrix in LDS: the smallest multiple of 4 >= C that is 4 (mod 32)
+__host__ __device__ inline int sinkhorn_ld(int C) {
+  const int c4 = (C + 3) / 4 * 4;
+  return c4 % 32 == 4 ? c4 : c4 + (36 - c4 % 32) % 32;
+}
+
+// (max, sum exp(x - max)) of the four adjacent lanes that share a row / column -> logsumexp, valid in all four
+__device__ __forceinline__ float quad_xor1(float x) {  // DPP quad_perm:[1,0,3,2]
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float quad_xor2(float x) {  // DPP quad_perm:[2,3,0,1]
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true));
+}
+// wave-wide max / sum of a float on the DPP shift network (see common.hpp), valid in every lane
+__device__ __forceinline__ float wave_max_f32_dpp(float x) {
+  const int ninf = __float_as_int(-INFINITY);
+#define GR_FMAX_STEP(CTRL, ROWMASK) x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(x), CTRL, ROWMASK, 0xf, false)));
+  GR_FMAX_STEP(0x111, 0xf) GR_FMAX_STEP(0x112, 0xf) GR_FMAX_STEP(0x114, 0xf) GR_FMAX_STEP(0x118, 0xf)
+  GR_FMAX_STEP(0x142, 0xa) GR_FMAX_STEP(0x143, 0xc)
+#undef GR_FMAX_STEP
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+__device__ __forceinline__ float wave_sum_f32_dpp(float x) {
+#define GR_FADD_STEP(CTRL, ROWMASK) x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROWMASK, 0xf, false));
+  GR_FADD_STEP(0x111, 0xf) GR_FADD_STEP(0x112, 0xf) GR_FADD_STEP(0x114, 0xf) GR_FADD_STEP(0x118, 0xf)
+  GR_FADD_STEP(0x142, 0xa) GR_FADD_STEP(0x143, 0xc)
+#undef GR_FADD_STEP
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+
+// logsumexp of `len` values base[k * stride] + add[k] by one whole wave (the rows / columns beyond SK_MAIN)
+__device__ __forceinline__ float wave_lse(const float* base, int stride, const float* add, int len, int lane) {
+  float x[(SK_MAXD + WAVE - 1) / WAVE];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < (SK_MAXD + WAVE - 1) / WAVE; ++t) {
+    const int k = lane + t * WAVE;
+    const float sv = base[(size_t)k * stride] + add[k];
+    x[t] = k < len ? sv : -INFINITY;
+    mx = fmaxf(mx, x[t]);
+  }
+  mx = wave_max_f32_dpp(mx);
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < (SK_MAXD + WAVE - 1) / WAVE; ++t) s += lane + t * WAVE < len ? __expf(x[t] - mx) : 0.f;
+  return lse_finish(mx, wave_sum_f32_dpp(s));
+}
+
+__device__ __forceinline__ float lse_merge4(float mx, float s) {
+  float m = fmaxf(mx, quad_xor1(mx));
+  m = fmaxf(m, quad_xor2(m));
+  float t = mx > -INFINITY ? s * __expf(mx - m) : 0.f;  // empty part: (-inf, 0)
+  t += quad_xor1(t);
+  t += quad_xor2(t);
+  return lse_finish(m, t);
+}
+
+// Lane (idx, part) = (tid / 4, tid % 4).  Row pass: the lane reduces the elements j = part + 4 t of row idx; column pass:
+// the rows [36 part, 36 part + 36) of column idx.  With a row stride of 132 floats both patterns touch every LDS bank at
+// most twice per wave (the 64-lane minimum): bank = 4 idx + part + 4 t, and 16 part + idx + 4 t (36 * 132 = 16 mod 32).
+// The slice stays in registers between the max pass and the sum pass; the four partials meet through DPP, so an iteration
+// has two barriers (u complete, v complete) and no partial arrays in LDS.
 __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict__ scores, int M, int N,
                                                         const uint8_t* __restrict__ row_masks,
                                                         const uint8_t* __restrict__ col_masks,
@@ -28,16 +90,13 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
                                                         float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int R = M + 1, C = N + 1;
-  const int ld = C | 1;
-  const int mxd = max(R, C);
+  const int ld = sinkhorn_ld(C);
   float* S = reinterpret_cast<float*>(smem);
   float* u = S + (size_t)R * ld;
   float* v = u + R;
   float* log_mu = v + C;
   float* log_nu = log_mu + R;
-  float* pm = log_nu + C;                 // [SK_PARTS][mxd] partial max
-  float* ps = pm + SK_PARTS * mxd;        // [SK_PARTS][mxd] partial sum
-  int* cnt = reinterpret_cast<int*>(ps + SK_PARTS * mxd);
+  int* cnt = reinterpret_cast<int*>(log_nu + C);
   const int b = blockIdx.x;
   const float alpha = alpha_p[0];
   const uint8_t* rm = row_masks ? row_masks + (int64_t)b * M : nullptr;
@@ -74,68 +133,56 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
   }
   __syncthreads();
   // log_sinkhorn_normalization (:13-18); logsumexp = max + log(sum exp(x - max))
-  const int part = threadIdx.x / mxd, idx = threadIdx.x % mxd;  // part >= SK_PARTS: idle thread
-  const bool active = part < SK_PARTS;
-  const int cper = (C + SK_PARTS - 1) / SK_PARTS, rper = (R + SK_PARTS - 1) / SK_PARTS;
+  const int idx = threadIdx.x / SK_PARTS, part = threadIdx.x % SK_PARTS;
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  const int row_len = idx < R ? (C - part + SK_PARTS - 1) / SK_PARTS : 0;       // elements part, part + 4, ... of a row
+  const int i0 = part * SK_PER;
+  const int col_len = idx < C ? max(0, min(R, i0 + SK_PER) - i0) : 0;          // rows [36 part, 36 part + 36) of a column
   for (int it = 0; it < iters; ++it) {
-    if (active && idx < R) {
-      const float* row = S + idx * ld;
-      // the thread's slice stays in registers between the max pass and the sum pass (one trip through LDS per element)
-      const int j0 = part * cper, len = min(C, j0 + cper) - j0;
+    {
+      const float* row = S + idx * ld + part;
       float x[SK_PER];
-      float mx = -INFINITY;
+      float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // four independent chains: two waves per SIMD do not
+#pragma unroll                                                     // hide a 36-deep dependent max / add chain
+      for (int t = 0; t < SK_PER; ++t) {
+        const float sv = row[SK_PARTS * t] + v[part + SK_PARTS * t];  // unconditional: past the row's end the reads land in
+        x[t] = t < row_len ? sv : -INFINITY;                          // the next row / the vectors behind S (or return 0)
+        m4[t & 3] = fmaxf(m4[t & 3], x[t]);
+      }
+      const float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+      float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < SK_PER; ++t) s4[t & 3] += t < row_len ? __expf(x[t] - mx) : 0.f;
+      const float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+      const float lse = lse_merge4(mx, s);
+      if (part == 0 && idx < R) u[idx] = log_mu[idx] - lse;
+      for (int r = SK_MAIN + wv; r < R; r += SK_T / WAVE) {  // rows beyond the 128 that own four lanes: a wave each
+        const float l2 = wave_lse(S + (size_t)r * ld, 1, v, C, lane);
+        if (lane == 0) u[r] = log_mu[r] - l2;
+      }
+    }
+    __syncthreads();
+    {
+      const float* col = S + (size_t)i0 * ld + idx;
+      float x[SK_PER];
+      float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
       for (int t = 0; t < SK_PER; ++t) {
-        x[t] = t < len ? row[j0 + t] + v[j0 + t] : -INFINITY;
-        mx = fmaxf(mx, x[t]);
+        const float sv = col[(size_t)t * ld] + u[i0 + t];
+        x[t] = t < col_len ? sv : -INFINITY;
+        m4[t & 3] = fmaxf(m4[t & 3], x[t]);
       }
-      float s = 0.f;
+      const float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+      float s4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int t = 0; t < SK_PER; ++t) s += t < len ? __expf(x[t] - mx) : 0.f;
-      pm[part * mxd + idx] = mx;
-      ps[part * mxd + idx] = s;
-    }
-    __syncthreads();
-    if (part == 0 && idx < R) {
-      float mx = pm[idx];
-#pragma unroll
-      for (int p = 1; p < SK_PARTS; ++p) mx = fmaxf(mx, pm[p * mxd + idx]);
-      float s = 0.f;
-#pragma unroll
-      for (int p = 0; p < SK_PARTS; ++p) {
-        const float m_p = pm[p * mxd + idx];
-        if (m_p > -INFINITY) s += ps[p * mxd + idx] * expf(m_p - mx);  // empty part: (-inf, 0)
+      for (int t = 0; t < SK_PER; ++t) s4[t & 3] += t < col_len ? __expf(x[t] - mx) : 0.f;
+      const float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+      const float lse = lse_merge4(mx, s);
+      if (part == 0 && idx < C) v[idx] = log_nu[idx] - lse;
+      for (int c = SK_MAIN + wv; c < C; c += SK_T / WAVE) {
+        const float l2 = wave_lse(S + c, ld, u, R, lane);
+        if (lane == 0) v[c] = log_nu[c] - l2;
       }
-      u[idx] = log_mu[idx] - lse_finish(mx, s);
-    }
-    __syncthreads();
-    if (active && idx < C) {
-      const int i0 = part * rper, len = min(R, i0 + rper) - i0;
-      float x[SK_PER];
-      float mx = -INFINITY;
-#pragma unroll
-      for (int t = 0; t < SK_PER; ++t) {
-        x[t] = t < len ? S[(i0 + t) * ld + idx] + u[i0 + t] : -INFINITY;
-        mx = fmaxf(mx, x[t]);
-      }
-      float s = 0.f;
-#pragma unroll
-      for (int t = 0; t < SK_PER; ++t) s += t < len ? __expf(x[t] - mx) : 0.f;
-      pm[part * mxd + idx] = mx;
-      ps[part * mxd + idx] = s;
-    }
-    __syncthreads();
-    if (part == 0 && idx < C) {
-      float mx = pm[idx];
-#pragma unroll
-      for (int p = 1; p < SK_PARTS; ++p) mx = fmaxf(mx, pm[p * mxd + idx]);
-      float s = 0.f;
-#pragma unroll
-      for (int p = 0; p < SK_PARTS; ++p) {
-        const float m_p = pm[p * mxd + idx];
-        if (m_p > -INFINITY) s += ps[p * mxd + idx] * expf(m_p - mx);
-      }
-      v[idx] = log_nu[idx] - lse_finish(mx, s);
     }
     __syncthreads();
   }
@@ -147,8 +194,8 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
 }
 
 size_t sinkhorn_lds(int M, int N) {
-  const int R = M + 1, C = N + 1, ld = C | 1, mxd = R > C ? R : C;
-  return sizeof(float) * ((size_t)R * ld + 2 * R + 2 * C + 2 * SK_PARTS * mxd) + 64;
+  const int R = M + 1, C = N + 1, ld = sinkhorn_ld(C);
+  return sizeof(float) * ((size_t)R * ld + 2 * R + 2 * C) + 64;
 }
 
 }  // namespace
@@ -163,8 +210,7 @@ extern "C" int gr_sinkhorn(const float* scores, int64_t batch, int64_t m, int64_
   GR_REQUIRE(batch >= 0 && m >= 1 && n >= 1 && num_iterations >= 0, "bad sizes");
   if (batch == 0) return GR_OK;
   GR_REQUIRE(scores && alpha_dev && out, "null argument");
-  GR_REQUIRE(SK_PARTS * (std::max(m, n) + 1) <= SK_T, "sinkhorn: matrices larger than %d are not supported",
-             SK_T / SK_PARTS - 1);
+  GR_REQUIRE(std::max(m, n) + 1 <= SK_MAXD, "sinkhorn: matrices larger than %d are not supported", SK_MAXD - 1);
   const size_t lds = sinkhorn_lds((int)m, (int)n);
   if (lds > 160 * 1024) {
     set_error("sinkhorn: a (%lld+1) x (%lld+1) matrix does not fit in LDS (%zu bytes)", (long long)m, (long long)n, lds);
