@@ -27,11 +27,16 @@ __device__ void horn_rotation(const double* H /*3x3: H[a][b] = sum w src_a ref_b
                     {Szx - Sxz, Sxy + Syx, -Sxx + Syy - Szz, Syz + Szy},
                     {Sxy - Syx, Szx + Sxz, Syz + Szy, -Sxx - Syy + Szz}};
   double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+  // stop when the off-diagonal mass is below fp64 resolution of the matrix (1e-15 of its Frobenius norm): waiting for it
+  // to underflow costs four more sweeps of serial fp64 work in the one thread that runs this
+  double fro2 = 0.0;
+  for (int p = 0; p < 4; ++p)
+    for (int q = 0; q < 4; ++q) fro2 += A[p][q] * A[p][q];
   for (int sweep = 0; sweep < 16; ++sweep) {
     double off = 0.0;
     for (int p = 0; p < 4; ++p)
       for (int q = p + 1; q < 4; ++q) off += A[p][q] * A[p][q];
-    if (off < 1e-300) break;
+    if (off <= 1e-30 * fro2) break;
     for (int p = 0; p < 3; ++p)
       for (int q = p + 1; q < 4; ++q) {
         if (fabs(A[p][q]) < 1e-300) continue;
@@ -67,8 +72,8 @@ __device__ void horn_rotation(const double* H /*3x3: H[a][b] = sum w src_a ref_b
 }
 
 // block-wide sum of NV doubles per thread -> result in sh[0..NV) (valid for all threads after return)
-template <int NV>
-__device__ void block_sum(double* v, double* sh /* [NV][LG_T/64] + NV */) {
+template <int NV, int T>
+__device__ void block_sum(double* v, double* sh /* [NV][T/64] + NV */) {
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     v[k] = wave_sum_f64_dpp(v[k]);
@@ -76,25 +81,25 @@ __device__ void block_sum(double* v, double* sh /* [NV][LG_T/64] + NV */) {
   __syncthreads();
   const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
   if (lane == 0)
-    for (int k = 0; k < NV; ++k) sh[k * (LG_T / WAVE) + w] = v[k];
+    for (int k = 0; k < NV; ++k) sh[k * (T / WAVE) + w] = v[k];
   __syncthreads();
   if (threadIdx.x < NV) {
     double s = 0;
-    for (int i = 0; i < LG_T / WAVE; ++i) s += sh[threadIdx.x * (LG_T / WAVE) + i];
-    sh[NV * (LG_T / WAVE) + threadIdx.x] = s;
+    for (int i = 0; i < T / WAVE; ++i) s += sh[threadIdx.x * (T / WAVE) + i];
+    sh[NV * (T / WAVE) + threadIdx.x] = s;
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < NV; ++k) v[k] = sh[NV * (LG_T / WAVE) + k];
+  for (int k = 0; k < NV; ++k) v[k] = sh[NV * (T / WAVE) + k];
 }
 
 // weighted Kabsch over correspondences [a, b) with weight(i); thread 0 ends up with (R, t) in T[12]
 // procrustes.py:41-66: w = w / (sum w + eps); centroids; H = sum w (src - cs)(ref - cr)^T
-template <typename WF>
+template <int NT, typename WF>
 __device__ void block_procrustes(const float* __restrict__ src, const float* __restrict__ ref, int a, int b, WF weight,
                                  float eps, double* sh, float* T /* shared [12] */) {
   double acc[7] = {0, 0, 0, 0, 0, 0, 0};  // sum w, sum w*src (3), sum w*ref (3)
-  for (int i = a + threadIdx.x; i < b; i += LG_T) {
+  for (int i = a + threadIdx.x; i < b; i += NT) {
     const double w = weight(i);
     acc[0] += w;
     for (int k = 0; k < 3; ++k) {
@@ -102,11 +107,11 @@ __device__ void block_procrustes(const float* __restrict__ src, const float* __r
       acc[4 + k] += w * ref[3 * (int64_t)i + k];
     }
   }
-  block_sum<7>(acc, sh);
+  block_sum<7, NT>(acc, sh);
   const double wn = 1.0 / (acc[0] + (double)eps);
   const double cs[3] = {acc[1] * wn, acc[2] * wn, acc[3] * wn}, cr[3] = {acc[4] * wn, acc[5] * wn, acc[6] * wn};
   double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = a + threadIdx.x; i < b; i += LG_T) {
+  for (int i = a + threadIdx.x; i < b; i += NT) {
     const double w = weight(i) * wn;
     double s[3], r[3];
     for (int k = 0; k < 3; ++k) {
@@ -116,7 +121,7 @@ __device__ void block_procrustes(const float* __restrict__ src, const float* __r
     for (int p = 0; p < 3; ++p)
       for (int q = 0; q < 3; ++q) h[p * 3 + q] += s[p] * w * r[q];
   }
-  block_sum<9>(h, sh);
+  block_sum<9, NT>(h, sh);
   if (threadIdx.x == 0) {
     double R[9];
     horn_rotation(h, R);
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(LG_T) void lgr_local_kernel(const float* __restrict
     return;
   }
   const int a = offsets[p];
-  block_procrustes(src, ref, a, a + n, [&](int i) { return (double)fmaxf(scores[i], 0.0f); }, 1e-5f, sh, T);
+  block_procrustes<LG_T>(src, ref, a, a + n, [&](int i) { return (double)fmaxf(scores[i], 0.0f); }, 1e-5f, sh, T);
   if (threadIdx.x < 12) transforms[p * 12 + threadIdx.x] = T[threadIdx.x];
   if (threadIdx.x == 0) valid[p] = 1;
 }
@@ -184,20 +189,22 @@ __global__ __launch_bounds__(LG_T) void lgr_verify_kernel(const float* __restric
   }
 }
 
-// best hypothesis + global refinement (local_global_registration.py:171-192)
-__global__ __launch_bounds__(LG_T) void lgr_refine_kernel(const float* __restrict__ src, const float* __restrict__ ref,
+// best hypothesis + global refinement (local_global_registration.py:171-192): one workgroup, so a wide one (the two passes
+// of every refinement step stream all correspondences)
+constexpr int LG_RT = 1024;
+__global__ __launch_bounds__(LG_RT) void lgr_refine_kernel(const float* __restrict__ src, const float* __restrict__ ref,
                                                           const float* __restrict__ scores, int C, int B,
                                                           const float* __restrict__ transforms,
                                                           const int32_t* __restrict__ inliers, float radius, int steps,
                                                           float* __restrict__ out_transform /* 4x4 row-major */) {
-  __shared__ double sh[9 * (LG_T / WAVE) + 16];
+  __shared__ double sh[9 * (LG_RT / WAVE) + 16];
   __shared__ float T[12];
   __shared__ int best_sh;
   {
     // first maximum, like argmax: key = (inliers + 1, ~index) so that the largest key is the lowest index of the largest
     // count (inliers = -1 marks an invalid hypothesis: key 0 .. never beats a valid one, best stays -1)
     unsigned long long key = 0ull;
-    for (int p = threadIdx.x; p < B; p += LG_T) {
+    for (int p = threadIdx.x; p < B; p += LG_RT) {
       const int c = inliers[p];
       if (c >= 0) {
         const unsigned long long k = ((unsigned long long)(unsigned)(c + 1) << 32) | (0xffffffffu - (unsigned)p);
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(LG_T) void lgr_refine_kernel(const float* __restric
     __syncthreads();
     if (threadIdx.x == 0) {
       unsigned long long m = 0ull;
-      for (int w = 0; w < LG_T / WAVE; ++w) m = kw[w] > m ? kw[w] : m;
+      for (int w = 0; w < LG_RT / WAVE; ++w) m = kw[w] > m ? kw[w] : m;
       best_sh = m ? (int)(0xffffffffu - (unsigned)(m & 0xffffffffull)) : -1;
     }
     __syncthreads();
@@ -225,14 +232,14 @@ __global__ __launch_bounds__(LG_T) void lgr_refine_kernel(const float* __restric
     __syncthreads();
   } else {
     // degenerate: no patch qualifies -> all correspondences, plain scores (:176-180)
-    block_procrustes(src, ref, 0, C, [&](int i) { return (double)fmaxf(scores[i], 0.0f); }, 1e-5f, sh, T);
+    block_procrustes<LG_RT>(src, ref, 0, C, [&](int i) { return (double)fmaxf(scores[i], 0.0f); }, 1e-5f, sh, T);
   }
   for (int s = 0; s < steps; ++s) {
     // scores * inlier mask of the current transform, then weighted Kabsch (:183-190)
     float Tc[12];
     for (int k = 0; k < 12; ++k) Tc[k] = T[k];
     __syncthreads();
-    block_procrustes(src, ref, 0, C,
+    block_procrustes<LG_RT>(src, ref, 0, C,
                      [&](int i) { return inlier(Tc, src, ref, i, radius) ? (double)fmaxf(scores[i], 0.0f) : 0.0; },
                      1e-5f, sh, T);
   }
@@ -285,7 +292,7 @@ extern "C" int gr_lgr_register_verify(const float* ref_corr_points, const float*
   }
   // the first refinement step of the reference is "procrustes with the best hypothesis' mask" (:183), the
   // remaining num_refinement_steps - 1 recompute the mask from the running estimate (:184-190)
-  hipLaunchKernelGGL(lgr_refine_kernel, dim3(1), dim3(LG_T), 0, stream, verify_src_points, verify_ref_points,
+  hipLaunchKernelGGL(lgr_refine_kernel, dim3(1), dim3(LG_RT), 0, stream, verify_src_points, verify_ref_points,
                      verify_scores, (int)num_verify, (int)batch, transforms, inl, acceptance_radius, num_refinement_steps,
                      out_transform);
   GR_LAUNCH_CHECK();

@@ -31,11 +31,14 @@ __host__ __device__ inline uint32_t rs_hash(uint32_t seed, uint32_t h, uint32_t 
 
 __device__ void jacobi_maxvec4(double A[4][4], double* q) {
   double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+  double fro2 = 0.0;  // stop at fp64 resolution of the matrix (see lgr.hip)
+  for (int p = 0; p < 4; ++p)
+    for (int r = 0; r < 4; ++r) fro2 += A[p][r] * A[p][r];
   for (int sweep = 0; sweep < 16; ++sweep) {
     double off = 0.0;
     for (int p = 0; p < 4; ++p)
       for (int r = p + 1; r < 4; ++r) off += A[p][r] * A[p][r];
-    if (off < 1e-300) break;
+    if (off <= 1e-30 * fro2) break;
     for (int p = 0; p < 3; ++p)
       for (int r = p + 1; r < 4; ++r) {
         if (fabs(A[p][r]) < 1e-300) continue;
