@@ -9,22 +9,21 @@ from . import ext
 from .ops import grid_subsample, radius_search
 
 
-PIPELINE_MIN_POINTS = 150_000  # below this the whole pyramid is launch-bound and a second host thread only adds latency
 
 
 def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, neighbor_limits, order="reference",
                                pipeline=None):
     """utils/data.py:13-77: 4 grid_subsample + 13 radius_search calls, same order of results, same parameters.
 
-    `pipeline` (default: on for device tensors with >= PIPELINE_MIN_POINTS points in reference row order): the
-    subsampling chain runs on a second host thread and a second HIP stream while this thread runs the radius searches of
-    the levels that already exist.  With `order="reference"` every grid_subsample call ends in a host-side replay of
-    libstdc++'s unordered_map iteration order (csrc/hash_order.hip), during which the GPU would otherwise idle; the
-    searches of the finer (larger) levels fill exactly that time.  Results are identical either way."""
+    `pipeline=True`: the subsampling chain runs on a second host thread and a second HIP stream while this thread runs
+    the radius searches of the levels that already exist.  That paid while every grid_subsample call ended in a host-side
+    replay of libstdc++'s unordered_map iteration order (the GPU idled meanwhile); with the order evaluated on the device
+    it is worth 4 % at 64 pairs per call on a quiet host and costs 3x when the two host threads fight for cores, so it is
+    off by default.  Results are identical either way."""
     assert num_stages == len(neighbor_limits)
     on_gpu = points.is_cuda
     if pipeline is None:
-        pipeline = on_gpu and order == "reference" and points.shape[0] >= PIPELINE_MIN_POINTS and num_stages > 1
+        pipeline = False
     points_list, lengths_list = [points], [lengths]
     neighbors_list, subsampling_list, upsampling_list = [], [], []
 
