@@ -665,7 +665,7 @@ extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64
       else if (per <= 16) fn = reinterpret_cast<const void*>(fps_multi_kernel<16>), lds = 16;
       else if (per <= 20) fn = reinterpret_cast<const void*>(fps_multi_kernel<20>), lds = 20;
       lds *= (size_t)FPS_T * sizeof(int);
-      if (lds > 48 * 1024) GR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
+      if (lds > 48 * 1024) GR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       if (per > 20) {  // slab too large for registers: one sample per round, distances streamed from L2
         fn = reinterpret_cast<const void*>(fps_kernel<0>);
         args = single_args;
