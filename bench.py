@@ -178,6 +178,24 @@ def pmc_traffic(key, ok, units=None):
         return None
 
 
+def sq_valu_busy(kernel_substr, ok):
+    """VALU-issue time / kernel duration of a kernel, from the newest committed SQ-counter summary (profiles/*_sq_counters
+    .json: SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / 2.4 GHz over the profiled duration) -- what actually bounds the kernels the
+    HBM roofline above is quoted for.  None when the summary is missing or was taken on another configuration."""
+    if not ok:
+        return None
+    try:
+        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_sq_counters.json"))
+        with open(os.path.join(ROOT, "profiles", cands[-1])) as fh:
+            doc = json.load(fh)
+        for k in doc["kernels"]:
+            if kernel_substr in k["kernel"]:
+                return round(k["valu_issue_us_at_2p4GHz"] / k["profiled_duration_us_avg"], 3)
+    except Exception:
+        pass
+    return None
+
+
 def timing_read(L, name):
     tot = ctypes.c_double(0)
     n = ctypes.c_int64(0)
@@ -254,7 +272,8 @@ def run_gpu(h, args):
                     "instances_per_view": round(R_total / V, 1), "parallelism": f"per-view sharding x{world}"},
          "roofline": hbm_roofline("raster_blend", blend_bytes, blend_ms, blend_n,
                                   pmc_traffic("raster_blend", (P, W, H) == (1_000_000, 640, 480), V),
-                                  kernels_ms_per_step=raster_kernels)})
+                                  kernels_ms_per_step=raster_kernels,
+                                  valu_busy=sq_valu_busy("blend_kernel<false>", (P, W, H) == (1_000_000, 640, 480)))})
 
     # ------------------------------------------------------------------ the boundary: one camera per forward() call
     if not args.no_single_view:
@@ -303,7 +322,7 @@ def run_gpu(h, args):
                   "unit": "Mpts/s", "ms_per_step": round(step_s * 1e3, 4),
                   "config": {"workload": f"{B} x 200k-pt clouds per GPU per step, r=0.0625, self-search, width {width}"},
                   "roofline": hbm_roofline("radius_fill", fill_bytes, fill_ms, fill_n, pmc_traffic("radius_fill", True, B),
-                                           kernels_ms_per_step=rk,
+                                           kernels_ms_per_step=rk, valu_busy=sq_valu_busy("traverse_kernel<128, false, true>", True),
                                            end_to_end_frac=round(fill_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4))}
         # the width-limited path the data pyramid calls (radius_search with neighbor_limit, utils/data.py:35-67)
         if not args.no_radius_limited:

@@ -747,14 +747,37 @@ constexpr int NCELL = (TILE / CELL) * (TILE / CELL);  // 16
 // [4] wave blend steps (two entries each), [5] entries a pixel actually blended
 __device__ unsigned long long g_blend_stats[8];
 
+__device__ __forceinline__ float lds_f32(const float* plane, unsigned int byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane) + byte_off);
+}
+// fmaxf without the canonicalising v_max(x, x) in front (x is the result of an fma here: never a signalling NaN)
+__device__ __forceinline__ float max_f32_raw(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+__device__ __forceinline__ float min_f32_raw(float a, float b) {  // fminf, same remark (a NaN operand yields the other one)
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 template <bool STATS>
 __global__ __launch_bounds__(BLOCK) void blend_kernel(
     int P, int W, int H, int nchunk, const DevView* __restrict__ views, const uint32_t* __restrict__ seg_off,
     const int32_t* __restrict__ point_list, const float4* __restrict__ rec, float* __restrict__ out_color) {
-  __shared__ float4 s_a[BLOCK];  // {px, py, pc, rc2}
-  __shared__ float4 s_b[BLOCK];  // {conic.x, conic.y, conic.z, opacity}
-  __shared__ float4 s_c[BLOCK];  // {r, g, b, -}
-  __shared__ unsigned char s_list[NCELL][BLOCK];
+  // One plane per field: the blend reads field f of two different entries into the two halves of a register pair
+  // (ds_read_b32 x 2), which is the operand layout of the packed fp32 instructions -- no register shuffling.
+  // (Plane stride 257 dwords: neither <= 255 nor a multiple of 64, so the compiler cannot fuse two fields of ONE entry
+  // into a ds_read2[st64]_b32 -- that would hand back exactly the wrong pairing.)
+  constexpr int PL = BLOCK + 1;
+  __shared__ float s_pl[10 * PL];
+  float* const s_px = s_pl, * const s_py = s_pl + PL, * const s_pc = s_pl + 2 * PL;          // centre, power cutoff
+  float* const s_cx = s_pl + 3 * PL, * const s_cy = s_pl + 4 * PL, * const s_cz = s_pl + 5 * PL;  // conic
+  float* const s_op = s_pl + 6 * PL;                                                          // opacity
+  float* const s_cr = s_pl + 7 * PL, * const s_cg = s_pl + 8 * PL, * const s_cb = s_pl + 9 * PL;  // colour
+  __shared__ unsigned short s_list[NCELL][BLOCK];                       // byte offsets (4 * entry) into the planes
   __shared__ int s_cnt[NCELL][BLOCK / WAVE + 1];  // per (cell, loading wave) counts -> bases; [.][4] = total
   __shared__ int s_wpre[WAVE];                    // window of 64 chunks: inclusive prefix of this tile's segment lengths
   __shared__ unsigned int s_woff[WAVE];           //                      and where each segment starts in point_list
@@ -773,7 +796,8 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
   const int tiles = gx * gy;
   const int64_t goff = (int64_t)v * P;
   bool done = !inside;
-  float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+  float T = 1.0f, C0 = 0.f;
+  f32x2 C12 = {0.f, 0.f};
   // The tile's list = its segments of chunk 0, 1, 2, ... (depth order).  64 chunks are looked up at a time (one wave:
   // lane = chunk, two 4-byte loads give segment start and end); the batches of 256 entries are cut out of that window.
   int c_next = 0, w_pos = 0, w_total = 0;  // block-uniform
@@ -831,9 +855,16 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
       // exact level set of the quadratic form, per axis (see preprocess): c' = |pc| + 2e-6 rc2 covers the fp32 error
       const float cpr = -pc + 1.0e-3f + 2.0e-6f * rc2;
       const float hx2 = cpr * r0.z, hy2 = cpr * r0.w;
-      s_a[tid] = make_float4(r0.x, r0.y, pc, rc2);
-      s_b[tid] = co;
-      s_c[tid] = col;
+      s_px[tid] = r0.x;
+      s_py[tid] = r0.y;
+      s_pc[tid] = pc;
+      s_cx[tid] = co.x;
+      s_cy[tid] = co.y;
+      s_cz[tid] = co.z;
+      s_op[tid] = co.w;
+      s_cr[tid] = col.x;
+      s_cg[tid] = col.y;
+      s_cb[tid] = col.z;
       float ex2[TILE / CELL], ey2[TILE / CELL];
 #pragma unroll
       for (int c = 0; c < TILE / CELL; ++c) {
@@ -871,7 +902,7 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < NCELL; ++c)
-      if ((mask >> c) & 1u) s_list[c][s_cnt[c][lw] + myrank[c]] = (unsigned char)tid;
+      if ((mask >> c) & 1u) s_list[c][s_cnt[c][lw] + myrank[c]] = (unsigned short)(4 * tid);
     __syncthreads();
     // ---- blend: each 16-lane group walks its own list
     const int n_cell = done ? 0 : s_cnt[cell][BLOCK / WAVE];
@@ -883,16 +914,20 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
     // Two list entries per step: everything up to alpha is evaluated for both at once with packed fp32 math
     // (v_pk_fma/mul/add_f32 -- the same IEEE operations as the scalar sequence of the oracle, two per lane-slot);
     // only the order-dependent tail (transmittance test, colour accumulation) runs entry by entry.
-    for (int i = 0; i < n_cell; i += 2) {
+    const unsigned int* lp = reinterpret_cast<const unsigned int*>(&s_list[cell][0]);
+    int n_lim = n_cell;
+    for (int i = 0; i < n_lim; i += 2) {
       const bool have1 = i + 1 < n_cell;
-      const int j0 = s_list[cell][i], j1 = s_list[cell][min(i + 1, BLOCK - 1)];
-      const float4 a0 = s_a[j0], b0 = s_b[j0], a1 = s_a[j1], b1 = s_b[j1];
-      const f32x2 dx = f32x2{a0.x, a1.x} - pfx, dy = f32x2{a0.y, a1.y} - pfy;
-      const f32x2 cx = {b0.x, b1.x}, cy = {b0.y, b1.y}, cz = {b0.z, b1.z}, cw = {b0.w, b1.w};
+      const unsigned int jj = lp[i >> 1];  // two list entries; the second one is stale (but a valid offset) past the end
+      const unsigned int o0 = jj & 0xffffu, o1 = (jj >> 16) & (4u * BLOCK - 4u);
+      const f32x2 dx = f32x2{lds_f32(s_px, o0), lds_f32(s_px, o1)} - pfx, dy = f32x2{lds_f32(s_py, o0), lds_f32(s_py, o1)} - pfy;
+      const f32x2 cx = {lds_f32(s_cx, o0), lds_f32(s_cx, o1)}, cy = {lds_f32(s_cy, o0), lds_f32(s_cy, o1)};
+      const f32x2 cz = {lds_f32(s_cz, o0), lds_f32(s_cz, o1)}, cw = {lds_f32(s_op, o0), lds_f32(s_op, o1)};
+      const float pc0 = lds_f32(s_pc, o0), pc1 = lds_f32(s_pc, o1);
       const f32x2 q = __builtin_elementwise_fma(cx * dx, dx, (cz * dy) * dy);
       const f32x2 power = __builtin_elementwise_fma(f32x2{-0.5f, -0.5f}, q, -((cy * dx) * dy));
       // exp_det(), two at a time
-      const f32x2 x = {fmaxf(power.x, -100.0f), fmaxf(power.y, -100.0f)};
+      const f32x2 x = {max_f32_raw(power.x, -100.0f), max_f32_raw(power.y, -100.0f)};
       const f32x2 t = x * 1.44269504088896341f;
       const f32x2 n = {rintf(t.x), rintf(t.y)};
       f32x2 r = __builtin_elementwise_fma(n, f32x2{-0.693359375f, -0.693359375f}, x);
@@ -905,35 +940,35 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
       pl = __builtin_elementwise_fma(pl, r, f32x2{5.0000001201e-1f, 5.0000001201e-1f});
       const f32x2 y = __builtin_elementwise_fma(pl, r * r, r) + 1.0f;
       const f32x2 al = cw * f32x2{ldexpf(y.x, (int)n.x), ldexpf(y.y, (int)n.y)};
-      const float alpha0 = fminf(0.99f, al.x), alpha1 = fminf(0.99f, al.y);
-      const bool ok0 = !(power.x > 0.0f) && !(power.x < a0.z) && !(alpha0 < 1.0f / 255.0f);
-      const bool ok1 = have1 && !(power.y > 0.0f) && !(power.y < a1.z) && !(alpha1 < 1.0f / 255.0f);
+      const float alpha0 = min_f32_raw(al.x, 0.99f), alpha1 = min_f32_raw(al.y, 0.99f);
+      const bool ok0 = !(power.x > 0.0f) && !(power.x < pc0) && !(alpha0 < 1.0f / 255.0f);
+      const bool ok1 = have1 && !(power.y > 0.0f) && !(power.y < pc1) && !(alpha1 < 1.0f / 255.0f);
       if (STATS) atomicAdd(&g_blend_stats[5], (unsigned long long)((ok0 ? 1 : 0) + (ok1 ? 1 : 0)));
+      // A pixel that saturates leaves the walk through its own trip count (n_lim), not through a `break`: the wave's
+      // control flow stays one counted loop with two predicated regions.
       if (ok0) {
         const float test_T = T * (1.0f - alpha0);
         if (test_T < 0.0001f) {
           done = true;
-          break;
+          n_lim = 0;
+        } else {
+          const float w = alpha0 * T;
+          C0 = fmaf(lds_f32(s_cr, o0), w, C0);
+          C12 = __builtin_elementwise_fma(f32x2{lds_f32(s_cg, o0), lds_f32(s_cb, o0)}, f32x2{w, w}, C12);
+          T = test_T;
         }
-        const float4 col = s_c[j0];
-        const float w = alpha0 * T;
-        C0 = fmaf(col.x, w, C0);
-        C1 = fmaf(col.y, w, C1);
-        C2 = fmaf(col.z, w, C2);
-        T = test_T;
       }
-      if (ok1) {
+      if (ok1 && !done) {
         const float test_T = T * (1.0f - alpha1);
         if (test_T < 0.0001f) {
           done = true;
-          break;
+          n_lim = 0;
+        } else {
+          const float w = alpha1 * T;
+          C0 = fmaf(lds_f32(s_cr, o1), w, C0);
+          C12 = __builtin_elementwise_fma(f32x2{lds_f32(s_cg, o1), lds_f32(s_cb, o1)}, f32x2{w, w}, C12);
+          T = test_T;
         }
-        const float4 col = s_c[j1];
-        const float w = alpha1 * T;
-        C0 = fmaf(col.x, w, C0);
-        C1 = fmaf(col.y, w, C1);
-        C2 = fmaf(col.z, w, C2);
-        T = test_T;
       }
     }
   }
@@ -941,8 +976,8 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
     const DevView& cam = views[v];
     float* o = out_color + (int64_t)v * 3 * H * W + (int64_t)pyi * W + pxi;
     o[0] = fmaf(T, cam.bg[0], C0);
-    o[(int64_t)H * W] = fmaf(T, cam.bg[1], C1);
-    o[2 * (int64_t)H * W] = fmaf(T, cam.bg[2], C2);
+    o[(int64_t)H * W] = fmaf(T, cam.bg[1], C12.x);
+    o[2 * (int64_t)H * W] = fmaf(T, cam.bg[2], C12.y);
   }
 }
 
