@@ -777,7 +777,7 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
   float* const s_cx = s_pl + 3 * PL, * const s_cy = s_pl + 4 * PL, * const s_cz = s_pl + 5 * PL;  // conic
   float* const s_op = s_pl + 6 * PL;                                                          // opacity
   float* const s_cr = s_pl + 7 * PL, * const s_cg = s_pl + 8 * PL, * const s_cb = s_pl + 9 * PL;  // colour
-  __shared__ unsigned short s_list[NCELL][BLOCK];                       // byte offsets (4 * entry) into the planes
+  __shared__ unsigned short s_list[NCELL][BLOCK + 2];                   // byte offsets (4 * entry) into the planes
   __shared__ int s_cnt[NCELL][BLOCK / WAVE + 1];  // per (cell, loading wave) counts -> bases; [.][4] = total
   __shared__ int s_wpre[WAVE];                    // window of 64 chunks: inclusive prefix of this tile's segment lengths
   __shared__ unsigned int s_woff[WAVE];           //                      and where each segment starts in point_list
@@ -796,6 +796,8 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
   const int tiles = gx * gy;
   const int64_t goff = (int64_t)v * P;
   bool done = !inside;
+  // entry BLOCK of every plane: the pad entry of odd-length lists.  Cutoff +inf: `power < pc` holds, it never blends.
+  if (tid < 10) s_pl[tid * PL + BLOCK] = tid == 2 ? INFINITY : 0.0f;
   float T = 1.0f, C0 = 0.f;
   f32x2 C12 = {0.f, 0.f};
   // The tile's list = its segments of chunk 0, 1, 2, ... (depth order).  64 chunks are looked up at a time (one wave:
@@ -835,7 +837,10 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
       atomicAdd(&g_blend_stats[2], (unsigned long long)min(BLOCK, w_total - w_pos));
     }
     w_pos += BLOCK;
-    unsigned mask = 0;
+    // reach[c]: the lanes of this wave whose entry can reach cell c -- 16 lane masks in scalar registers.  The rank of an
+    // entry in a cell's list is a masked bit count of that mask and the list write runs under it as the exec mask
+    // (inverse ballot): no per-lane bit field is built or taken apart.
+    float ctr_x = 0.0f, ctr_y = 0.0f, rc2 = -1.0f, hx2 = 0.0f, hy2 = 0.0f;  // past the end of the list: reaches no cell
     if (e < w_total) {
       int lo = 0;  // first chunk of the window whose inclusive prefix exceeds e
 #pragma unroll
@@ -851,10 +856,13 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
       //   |d|^2 > |pc| * col.w              ==>   power < pc            (see preprocess)
       // NaN / non-positive opacity make every comparison false: nothing is skipped early.
       const float pc = -__logf(255.0f * co.w) - 1.0e-3f;
-      const float rc2 = -pc * col.w;
+      rc2 = -pc * col.w;
       // exact level set of the quadratic form, per axis (see preprocess): c' = |pc| + 2e-6 rc2 covers the fp32 error
       const float cpr = -pc + 1.0e-3f + 2.0e-6f * rc2;
-      const float hx2 = cpr * r0.z, hy2 = cpr * r0.w;
+      hx2 = cpr * r0.z;
+      hy2 = cpr * r0.w;
+      ctr_x = r0.x;
+      ctr_y = r0.y;
       s_px[tid] = r0.x;
       s_py[tid] = r0.y;
       s_pc[tid] = pc;
@@ -865,29 +873,29 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
       s_cr[tid] = col.x;
       s_cg[tid] = col.y;
       s_cb[tid] = col.z;
-      float ex2[TILE / CELL], ey2[TILE / CELL];
+    }
+    float ex2[TILE / CELL], ey2[TILE / CELL];
+    bool xin[TILE / CELL], yin[TILE / CELL];
 #pragma unroll
-      for (int c = 0; c < TILE / CELL; ++c) {
-        const float xlo = tx0 + (float)(c * CELL), ylo = ty0 + (float)(c * CELL);
-        const float ex = fmaxf(fmaxf(xlo - r0.x, r0.x - (xlo + (float)(CELL - 1))), 0.0f);
-        const float ey = fmaxf(fmaxf(ylo - r0.y, r0.y - (ylo + (float)(CELL - 1))), 0.0f);
-        ex2[c] = ex * ex;
-        ey2[c] = ey * ey;
-      }
-#pragma unroll
-      for (int c = 0; c < NCELL; ++c)
-        if (!(ex2[c % (TILE / CELL)] + ey2[c / (TILE / CELL)] > rc2) && !(ex2[c % (TILE / CELL)] > hx2) &&
-            !(ey2[c / (TILE / CELL)] > hy2))
-          mask |= 1u << c;
+    for (int c = 0; c < TILE / CELL; ++c) {
+      const float xlo = tx0 + (float)(c * CELL), ylo = ty0 + (float)(c * CELL);
+      const float ex = fmaxf(fmaxf(xlo - ctr_x, ctr_x - (xlo + (float)(CELL - 1))), 0.0f);
+      const float ey = fmaxf(fmaxf(ylo - ctr_y, ctr_y - (ylo + (float)(CELL - 1))), 0.0f);
+      ex2[c] = ex * ex;
+      ey2[c] = ey * ey;
+      xin[c] = !(ex2[c] > hx2);
+      yin[c] = !(ey2[c] > hy2);
     }
     // ---- order-preserving per-cell lists
-    unsigned char myrank[NCELL];
+    unsigned long long reach[NCELL];
+    int cnt_lane = 0;  // lane c: how many entries of this wave reach cell c
 #pragma unroll
     for (int c = 0; c < NCELL; ++c) {
-      const unsigned long long bal = __ballot((mask >> c) & 1u);
-      myrank[c] = (unsigned char)__popcll(bal & ((1ull << lane) - 1ull));
-      if (lane == 0) s_cnt[c][lw] = __popcll(bal);
+      reach[c] = __ballot(!(ex2[c % (TILE / CELL)] + ey2[c / (TILE / CELL)] > rc2) && xin[c % (TILE / CELL)] &&
+                          yin[c / (TILE / CELL)]);
+      asm("v_writelane_b32 %0, %1, %2" : "+v"(cnt_lane) : "s"((int)__popcll(reach[c])), "n"(c));
     }
+    if (lane < NCELL) s_cnt[lane][lw] = cnt_lane;
     __syncthreads();
     if (tid < NCELL) {
       int acc = 0;
@@ -898,11 +906,17 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
         acc += n;
       }
       s_cnt[tid][BLOCK / WAVE] = acc;
+      if (acc & 1) s_list[tid][acc] = (unsigned short)(4 * BLOCK);  // lists are walked in pairs: pad with the never-hit entry
     }
     __syncthreads();
+    const int base_lane = lane < NCELL ? s_cnt[lane][lw] : 0;  // lane c: where this wave's entries start in list c
 #pragma unroll
-    for (int c = 0; c < NCELL; ++c)
-      if ((mask >> c) & 1u) s_list[c][s_cnt[c][lw] + myrank[c]] = (unsigned short)(4 * tid);
+    for (int c = 0; c < NCELL; ++c) {
+      const int base = __builtin_amdgcn_readlane(base_lane, c);
+      const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(reach[c] >> 32),
+                                                          __builtin_amdgcn_mbcnt_lo((unsigned int)reach[c], 0u));
+      if (__builtin_amdgcn_inverse_ballot_w64(reach[c])) s_list[c][base + rank] = (unsigned short)(4 * tid);
+    }
     __syncthreads();
     // ---- blend: each 16-lane group walks its own list
     const int n_cell = done ? 0 : s_cnt[cell][BLOCK / WAVE];
@@ -914,12 +928,9 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
     // Two list entries per step: everything up to alpha is evaluated for both at once with packed fp32 math
     // (v_pk_fma/mul/add_f32 -- the same IEEE operations as the scalar sequence of the oracle, two per lane-slot);
     // only the order-dependent tail (transmittance test, colour accumulation) runs entry by entry.
-    const unsigned int* lp = reinterpret_cast<const unsigned int*>(&s_list[cell][0]);
-    int n_lim = n_cell;
-    for (int i = 0; i < n_lim; i += 2) {
-      const bool have1 = i + 1 < n_cell;
-      const unsigned int jj = lp[i >> 1];  // two list entries; the second one is stale (but a valid offset) past the end
-      const unsigned int o0 = jj & 0xffffu, o1 = (jj >> 16) & (4u * BLOCK - 4u);
+    const unsigned short* lp = &s_list[cell][0];
+    for (int i = 0; i < n_cell && !done; i += 2) {
+      const unsigned int o0 = lp[i], o1 = lp[i + 1];  // byte offsets of two list entries (an odd list ends with the pad entry)
       const f32x2 dx = f32x2{lds_f32(s_px, o0), lds_f32(s_px, o1)} - pfx, dy = f32x2{lds_f32(s_py, o0), lds_f32(s_py, o1)} - pfy;
       const f32x2 cx = {lds_f32(s_cx, o0), lds_f32(s_cx, o1)}, cy = {lds_f32(s_cy, o0), lds_f32(s_cy, o1)};
       const f32x2 cz = {lds_f32(s_cz, o0), lds_f32(s_cz, o1)}, cw = {lds_f32(s_op, o0), lds_f32(s_op, o1)};
@@ -942,15 +953,14 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
       const f32x2 al = cw * f32x2{ldexpf(y.x, (int)n.x), ldexpf(y.y, (int)n.y)};
       const float alpha0 = min_f32_raw(al.x, 0.99f), alpha1 = min_f32_raw(al.y, 0.99f);
       const bool ok0 = !(power.x > 0.0f) && !(power.x < pc0) && !(alpha0 < 1.0f / 255.0f);
-      const bool ok1 = have1 && !(power.y > 0.0f) && !(power.y < pc1) && !(alpha1 < 1.0f / 255.0f);
+      const bool ok1 = !(power.y > 0.0f) && !(power.y < pc1) && !(alpha1 < 1.0f / 255.0f);
       if (STATS) atomicAdd(&g_blend_stats[5], (unsigned long long)((ok0 ? 1 : 0) + (ok1 ? 1 : 0)));
-      // A pixel that saturates leaves the walk through its own trip count (n_lim), not through a `break`: the wave's
-      // control flow stays one counted loop with two predicated regions.
+      // A pixel that saturates leaves the walk through the loop condition, not through a `break`: the wave's control flow
+      // stays one counted loop with two predicated regions.
       if (ok0) {
         const float test_T = T * (1.0f - alpha0);
         if (test_T < 0.0001f) {
           done = true;
-          n_lim = 0;
         } else {
           const float w = alpha0 * T;
           C0 = fmaf(lds_f32(s_cr, o0), w, C0);
@@ -962,7 +972,6 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
         const float test_T = T * (1.0f - alpha1);
         if (test_T < 0.0001f) {
           done = true;
-          n_lim = 0;
         } else {
           const float w = alpha1 * T;
           C0 = fmaf(lds_f32(s_cr, o1), w, C0);
