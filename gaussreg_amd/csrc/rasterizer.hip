@@ -744,7 +744,8 @@ constexpr int CELL = 4;
 constexpr int NCELL = (TILE / CELL) * (TILE / CELL);  // 16
 
 // development statistics (GR_BLEND_STATS=1): [0] tiles, [1] batches, [2] entries loaded, [3] cell-list entries,
-// [4] wave blend steps (two entries each), [5] entries a pixel actually blended
+// [4] wave blend steps (two entries each), [5] entries a pixel actually blended, [6] sum over (wave, batch) of the largest
+// per-pixel blend count, [7] sum over lanes of the list lengths they set out to walk
 __device__ unsigned long long g_blend_stats[8];
 
 __device__ __forceinline__ float lds_f32(const float* plane, unsigned int byte_off) {
@@ -779,6 +780,7 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
   float* const s_cr = s_pl + 7 * PL, * const s_cg = s_pl + 8 * PL, * const s_cb = s_pl + 9 * PL;  // colour
   __shared__ unsigned short s_list[NCELL][BLOCK + 2];                   // byte offsets (4 * entry) into the planes
   __shared__ int s_cnt[NCELL][BLOCK / WAVE + 1];  // per (cell, loading wave) counts -> bases; [.][4] = total
+  __shared__ int s_alldone[BLOCK / WAVE];
   __shared__ int s_wpre[WAVE];                    // window of 64 chunks: inclusive prefix of this tile's segment lengths
   __shared__ unsigned int s_woff[WAVE];           //                      and where each segment starts in point_list
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
@@ -806,7 +808,12 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
   const uint32_t* seg_col = seg_off + (int64_t)v * nchunk * (tiles + 1) + tile;
   if (STATS && tid == 0) atomicAdd(&g_blend_stats[0], 1ull);
   while (true) {
-    if (__syncthreads_and(done)) break;
+    // all 256 pixels saturated?  One ballot per wave, one flag per wave, one barrier (the later barriers of the batch
+    // separate this read from the next write)
+    const unsigned long long live = __ballot(!done);
+    if (lane == 0) s_alldone[lw] = live == 0ull ? 1 : 0;
+    __syncthreads();
+    if (s_alldone[0] & s_alldone[1] & s_alldone[2] & s_alldone[3]) break;
     bool exhausted = false;
     while (w_pos >= w_total) {
       if (c_next >= nchunk) {
@@ -929,6 +936,7 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
     // (v_pk_fma/mul/add_f32 -- the same IEEE operations as the scalar sequence of the oracle, two per lane-slot);
     // only the order-dependent tail (transmittance test, colour accumulation) runs entry by entry.
     const unsigned short* lp = &s_list[cell][0];
+    int stat_hits = 0;
     for (int i = 0; i < n_cell && !done; i += 2) {
       const unsigned int o0 = lp[i], o1 = lp[i + 1];  // byte offsets of two list entries (an odd list ends with the pad entry)
       const f32x2 dx = f32x2{lds_f32(s_px, o0), lds_f32(s_px, o1)} - pfx, dy = f32x2{lds_f32(s_py, o0), lds_f32(s_py, o1)} - pfy;
@@ -954,7 +962,10 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
       const float alpha0 = min_f32_raw(al.x, 0.99f), alpha1 = min_f32_raw(al.y, 0.99f);
       const bool ok0 = !(power.x > 0.0f) && !(power.x < pc0) && !(alpha0 < 1.0f / 255.0f);
       const bool ok1 = !(power.y > 0.0f) && !(power.y < pc1) && !(alpha1 < 1.0f / 255.0f);
-      if (STATS) atomicAdd(&g_blend_stats[5], (unsigned long long)((ok0 ? 1 : 0) + (ok1 ? 1 : 0)));
+      if (STATS) {
+        atomicAdd(&g_blend_stats[5], (unsigned long long)((ok0 ? 1 : 0) + (ok1 ? 1 : 0)));
+        stat_hits += (ok0 ? 1 : 0) + (ok1 ? 1 : 0);
+      }
       // A pixel that saturates leaves the walk through the loop condition, not through a `break`: the wave's control flow
       // stays one counted loop with two predicated regions.
       if (ok0) {
@@ -979,6 +990,11 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
           T = test_T;
         }
       }
+    }
+    if (STATS) {  // [6] per wave: the largest number of blends any one pixel did in this batch; [7] lanes x list entries walked
+      const int mh = wave_max_i32_dpp(stat_hits);
+      if (lane == 0) atomicAdd(&g_blend_stats[6], (unsigned long long)mh);
+      atomicAdd(&g_blend_stats[7], (unsigned long long)n_cell);
     }
   }
   if (inside) {

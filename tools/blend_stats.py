@@ -18,8 +18,10 @@ out = (ctypes.c_ulonglong * 8)()
 fn = L.gr_debug_blend_stats
 fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 fn(out)
-tiles, batches, loaded, cell_entries, steps, blended = [int(out[i]) for i in range(6)]
+tiles, batches, loaded, cell_entries, steps, blended, maxhits, lane_entries = [int(out[i]) for i in range(8)]
 R_ = sum(nr)
 print(f"views {V}: instances {R_}, tiles {tiles}, batches/tile {batches/tiles:.2f}, entries loaded {loaded} = {loaded/R_:.3f} of all,"
       f" cell-list entries per loaded entry {cell_entries/max(loaded,1):.2f} (of 16), wave blend steps/tile {steps/tiles:.1f},"
-      f" blended (entry,pixel) pairs {blended} = {blended/max(cell_entries*16,1):.3f} of cell-list entry x 16 px")
+      f" blended (entry,pixel) pairs {blended} = {blended/max(cell_entries*16,1):.3f} of cell-list entry x 16 px;"
+      f" per (wave, batch): longest list walked {2*steps/max(4*batches,1):.1f} entries, most blends by one pixel {maxhits/max(4*batches,1):.1f};"
+      f" hit rate of live lanes {blended/max(lane_entries,1):.3f}")
