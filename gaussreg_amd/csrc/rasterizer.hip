@@ -264,6 +264,7 @@ __device__ __forceinline__ uint64_t pack_rect(const int* rmin, const int* rmax) 
   return ((uint64_t)rmin[0] << 38) | ((uint64_t)rmin[1] << 45) | ((uint64_t)w << 52) | ((uint64_t)h << 58);
 }
 
+constexpr int REC_PLANE = 66;  // float4 per record-piece plane (64 + 2): the transposed ds_read_b128 are conflict-free
 constexpr int SH_ROW = 13;  // float4 per staged Gaussian: 12 used + 1 pad -> conflict-free ds_read_b128
 
 template <bool HAS_SH, bool HAS_COV, bool SH16>
@@ -274,32 +275,47 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, int W, int H,
     int32_t* __restrict__ radii, float4* __restrict__ rec, uint64_t* __restrict__ dkeys,
     int32_t* __restrict__ far_flag) {
-  __shared__ float4 s_sh[SH16 ? 256 * SH_ROW : 1];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float4 s_sh[SH16 ? WAVE * SH_ROW : 1];
+  __shared__ float4 s_rec[256 / WAVE][4 * REC_PLANE];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
   float shr[SH16 ? 48 : 1];
   if (SH16) {
-    // degree-3 SH = 192 B per Gaussian: read the block's 48 KB as one coalesced float4 stream,
-    // transpose through LDS (row stride 13 float4 keeps the per-thread ds_read_b128 conflict-free)
+    // degree-3 SH = 192 B per Gaussian: the block's 48 KB are read as a coalesced float4 stream and transposed through
+    // LDS (row stride 13 float4 keeps the per-thread ds_read_b128 conflict-free), one wave's 64 Gaussians at a time through
+    // the same 13 KB -- a 52 KB staging area for all four waves capped the CU at 12 resident waves for the whole view loop.
     const int g0 = blockIdx.x * 256;
     const int n_here = min(256, P - g0);
     const float4* src = reinterpret_cast<const float4*>(shs + (int64_t)g0 * 48);
-    for (int f = threadIdx.x; f < n_here * 12; f += 256) {
-      const int g = f / 12, j = f - g * 12;
-      s_sh[g * SH_ROW + j] = src[f];
-    }
-    __syncthreads();
-    if (i < P) {
+#pragma unroll 1
+    for (int w = 0; w < 256 / WAVE; ++w) {
+      const int lim = min(WAVE, n_here - w * WAVE) * 12;
 #pragma unroll
-      for (int j = 0; j < 12; ++j) {
-        const float4 t = s_sh[threadIdx.x * SH_ROW + j];
-        shr[4 * j] = t.x;
-        shr[4 * j + 1] = t.y;
-        shr[4 * j + 2] = t.z;
-        shr[4 * j + 3] = t.w;
+      for (int u = 0; u < 3; ++u) {
+        const int f = threadIdx.x + u * 256;
+        if (f < lim) {
+          const int g = f / 12, j = f - g * 12;
+          s_sh[g * SH_ROW + j] = src[w * WAVE * 12 + f];
+        }
       }
+      __syncthreads();
+      if ((int)threadIdx.x / WAVE == w && i < P) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+          const float4 t = s_sh[(threadIdx.x & (WAVE - 1)) * SH_ROW + j];
+          shr[4 * j] = t.x;
+          shr[4 * j + 1] = t.y;
+          shr[4 * j + 2] = t.z;
+          shr[4 * j + 3] = t.w;
+        }
+      }
+      __syncthreads();
     }
   }
-  if (i >= P) return;
+  // Threads past the end stay alive (they help to write their wave's records below) on a clamped index and store nothing.
+  const bool valid = i < P;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave_first = i - lane;  // first Gaussian of this wave
+  i = min(i, P - 1);
   const float p[3] = {means3D[3 * (int64_t)i], means3D[3 * (int64_t)i + 1], means3D[3 * (int64_t)i + 2]};
   const float opacity = opacities[i];
   float c6[6];
@@ -410,15 +426,33 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         }
       }
     }
-    radii[o] = out_radius;
-    dkeys[o] = out_key;
-    float4* r = rec + 4 * o;
-    if (out_radius > 0) {  // culled Gaussians are never gathered: their 64-B line is not touched at all
-      r[0] = make_float4(out_xy.x, out_xy.y, out_sxx, out_syy);
-      r[1] = out_co;
-      r[2] = out_rgb;
-      r[3] = make_float4(__int_as_float(out_radius), out_depth, 0.f, 0.f);  // read by the wide-rectangle fallback only
+    if (valid) {
+      radii[o] = out_radius;
+      dkeys[o] = out_key;
     }
+    // The wave's 64 records (4 KB, contiguous) leave through LDS: lane l stores piece l % 4 of record 16 k + l / 4 in
+    // store k, so every store instruction covers whole lines.  (Each lane writing its own record piece by piece costs four
+    // partial-line writes per record: measured 0.26 ms of the 0.77 ms kernel at 32 views.)  Culled Gaussians are never
+    // gathered: their 64-B line is not touched at all.
+    const unsigned long long vis = __ballot(valid && out_radius > 0);
+    float4* wrec = s_rec[threadIdx.x / WAVE];
+    wrec[0 * REC_PLANE + lane] = make_float4(out_xy.x, out_xy.y, out_sxx, out_syy);
+    wrec[1 * REC_PLANE + lane] = out_co;
+    wrec[2 * REC_PLANE + lane] = out_rgb;
+    wrec[3 * REC_PLANE + lane] = make_float4(__int_as_float(out_radius), out_depth, 0.f, 0.f);  // wide-rectangle fallback only
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float4* wout = rec + 4 * ((int64_t)v * P + wave_first);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rl = 16 * k + lane / 4;
+      const float4 piece = wrec[(lane & 3) * REC_PLANE + rl];
+      if ((vis >> rl) & 1ull) wout[4 * rl + (lane & 3)] = piece;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
