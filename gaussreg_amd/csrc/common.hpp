@@ -113,8 +113,8 @@ int lds_atomics_lane_ordered_state();  // 1 yes, 0 no, -1 not probed yet
 
 // Segmented stable LSD radix sort of the rasterizer's (view, Gaussian) depth keys (depth_sort.hip).
 size_t depth_sort_table_bytes(int64_t P, int V);
-int depth_sort_views(uint64_t* keys_a, uint64_t* keys_b, int32_t* ids_tmp, int32_t* ids_out, uint32_t* hi_out, int out_shift,
-                     int32_t* nvalid_out, int64_t P, int V, int key_bits, void* table, size_t table_bytes,
+int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* keys_a, uint64_t* keys_b, int32_t* ids_out,
+                     uint32_t* rect_out, int32_t* nvalid_out, int64_t P, int V, int key_bits, void* table, size_t table_bytes,
                      hipStream_t stream);
 
 // Optional per-kernel HIP-event timing (off by default; bench.py turns it on to measure the

@@ -1,21 +1,27 @@
 // Segmented stable LSD radix sort for the rasterizer's depth ordering, hand-written for gfx950 (replaces the rocPRIM call
 // the round-1 pipeline made for this step).
 //
-// Problem shape: V views x P Gaussians, one u64 key per (view, Gaussian): low `key_bits` bits = depth field (0 = culled),
-// high bits = payload that rides along (the packed tile rectangle).  Wanted per view: the visible Gaussians ordered by
-// depth field, ties by Gaussian id (= stable), as ids + rectangles, plus the visible count.  What is specific here and a
-// general device sort cannot exploit:
+// Problem shape: V views x P Gaussians, per (view, Gaussian) a 32-bit depth field (0 = culled; `key_bits` significant
+// bits) and a packed tile rectangle.  Wanted per view: the visible Gaussians ordered by depth field, ties by Gaussian id
+// (= stable), as ids + rectangles, plus the visible count.  The sort moves ONE 8-byte word per entry.  The first pass
+// consumes the low 9 field bits, so from then on the word only has to hold the REMAINING field bits:
+//   packed   (remaining field bits + id bits + 26 rectangle bits <= 64, e.g. 18 + 20 + 26 for 2^20 Gaussians): the first
+//            pass picks the rectangle up with a coalesced read (ids are still sequential there) and the word is
+//            [field >> 9 | id | rectangle]; the last pass just unpacks it;
+//   gather   (otherwise): the word is (field << 32 | id) and the last pass looks the rectangle up by id -- a random 4-byte
+//            gather that costs as much as a whole pass (measured: last pass 0.12 -> 0.24 ms at 32 views x 1 M).
+// What is specific here and a general device sort cannot exploit:
 //   * segments (views) are contiguous and equal-stride, so no view bits are sorted: 27 depth bits = THREE 9-bit passes
 //     (the rocPRIM path needed four 8-bit passes over 27 + 5 view bits);
-//   * the first pass drops the culled entries (40 % of the (view, Gaussian) pairs of the benchmark scene) while it
-//     scatters -- compaction costs nothing extra -- and generates the id payload instead of reading an iota array;
-//   * the last pass writes the 4-byte rectangle and the id, not the 8-byte key;
+//   * the first pass reads the bare 4-byte fields, drops the culled entries (40 % of the (view, Gaussian) pairs of the
+//     benchmark scene) while it scatters -- compaction costs nothing extra -- and generates the id half of the word;
+//   * the last pass writes the id and the 4-byte rectangle it looks up, not the 8-byte word;
 //   * ranking inside a 2048-key chunk uses one LDS atomic per key: wave w owns a contiguous quarter of the chunk and a
 //     private digit-counter row; keys are taken 64 at a time in position order, and equal-digit lanes of one
 //     ds_add_rtn_u32 are served in lane order (probed on the device, common.hip) -- so the returned counts ARE the stable
 //     ranks.  Without that property the lanes rank themselves with one ballot per digit bit.
-//   * keys are staged in LDS at their chunk-local sorted position and leave as contiguous runs per digit (full lines),
-//     never as scattered 8-byte stores;
+//   * words are staged in LDS at their chunk-local sorted position and leave as contiguous runs per digit, never as
+//     scattered 8-byte stores (one stream of 8-byte words: a separate 4-byte id stream halved the run length in bytes);
 //   * with >= 8 views all chunks of a view run on one XCD (block b sits on XCD b % 8): the 512 write frontiers of a view
 //     stay in that XCD's L2.
 // Per pass: count (per-chunk digit histogram) -> scan (prefix over the chunks of a view, digit bases) -> scatter.
@@ -50,21 +56,25 @@ inline int ds_grid(int V, int nchunk) { return V >= 8 ? 8 * ((V + 7) / 8) * nchu
 // FIRST: the source is the raw key array (all P entries of the view, culled ones have a zero depth field)
 template <bool FIRST>
 __global__ __launch_bounds__(DS_T) void ds_count_kernel(int P, int V, int nchunk, const int32_t* __restrict__ nvalid,
-                                                        const uint64_t* __restrict__ keys, int shift, uint32_t dmask,
-                                                        uint64_t field_mask, uint16_t* __restrict__ hist) {
+                                                        const uint32_t* __restrict__ field, const uint64_t* __restrict__ keys,
+                                                        int word_shift, uint32_t dmask, uint16_t* __restrict__ hist) {
   __shared__ unsigned int s_h[DS_BINS];
   int v, c;
   if (!ds_block(V, nchunk, v, c)) return;
   for (int d = threadIdx.x; d < DS_BINS; d += DS_T) s_h[d] = 0u;
   __syncthreads();
   const int n = FIRST ? P : nvalid[v];
-  const uint64_t* src = keys + (int64_t)v * P;
+  const int64_t vbase = (int64_t)v * P;
 #pragma unroll
   for (int it = 0; it < DS_STEPS; ++it) {
     const int t = c * DS_CHUNK + it * DS_T + threadIdx.x;
     if (t < n) {
-      const uint64_t k = src[t];
-      if (!FIRST || (k & field_mask) != 0ull) atomicAdd(&s_h[(uint32_t)(k >> shift) & dmask], 1u);
+      if (FIRST) {
+        const uint32_t f = field[vbase + t];
+        if (f != 0u) atomicAdd(&s_h[f & dmask], 1u);
+      } else {
+        atomicAdd(&s_h[(uint32_t)(keys[vbase + t] >> word_shift) & dmask], 1u);
+      }
     }
   }
   __syncthreads();
@@ -116,20 +126,23 @@ __global__ __launch_bounds__(DS_BINS) void ds_digit_base_kernel(int32_t* __restr
   if (d == DS_BINS - 1 && nvalid_out) nvalid_out[v] = base + incl;
 }
 
-// FIRST: raw source (compaction + generated ids).  LAST: writes (uint32)(key >> out_shift) instead of the key.
+// FIRST: raw 4-byte fields (compaction, word assembly).  LAST: writes the id and the rectangle.
+// id_bits > 0: packed words [field >> 9 | id (id_bits) | rectangle (26)]; id_bits == 0: (field << 32 | id) words.
+// word_shift: where this pass's digit sits in the word (passes after the first).
 template <bool FIRST, bool LAST, bool LANE_ORDERED>
 __global__ __launch_bounds__(DS_T) void ds_scatter_kernel(int P, int V, int nchunk, const int32_t* __restrict__ nvalid,
-                                                          const uint64_t* __restrict__ keys_in,
-                                                          const int32_t* __restrict__ ids_in, int shift, uint32_t dmask,
-                                                          uint64_t field_mask, const uint32_t* __restrict__ offs,
+                                                          const uint32_t* __restrict__ field,
+                                                          const uint64_t* __restrict__ keys_in, int word_shift, int id_bits,
+                                                          uint32_t dmask,
+                                                          const uint32_t* __restrict__ offs,
                                                           const int32_t* __restrict__ digit_base,
-                                                          uint64_t* __restrict__ keys_out, uint32_t* __restrict__ hi_out,
-                                                          int out_shift, int32_t* __restrict__ ids_out) {
+                                                          uint64_t* __restrict__ keys_out, const uint32_t* __restrict__ rect_raw,
+                                                          uint32_t* __restrict__ rect_out, int32_t* __restrict__ ids_out) {
   __shared__ unsigned int s_cnt[DS_NW][DS_BINS];  // per-wave digit counters -> per-wave bases
   __shared__ int s_delta[DS_BINS];                // global position of a digit's run minus its chunk-local start
   __shared__ int s_w[DS_T / WAVE];
   __shared__ uint64_t s_key[DS_CHUNK];
-  __shared__ int32_t s_id[DS_CHUNK];
+  __shared__ unsigned short s_dig[FIRST ? DS_CHUNK : 1];
   int v, c;
   if (!ds_block(V, nchunk, v, c)) return;
   const int n = FIRST ? P : nvalid[v];
@@ -141,22 +154,30 @@ __global__ __launch_bounds__(DS_T) void ds_scatter_kernel(int P, int V, int nchu
   const int64_t vbase = (int64_t)v * P;
   const int wbase = c * DS_CHUNK + wv * (DS_CHUNK / DS_NW);
   uint64_t key[DS_STEPS];
-  int32_t id[DS_STEPS];
+  unsigned short digit[DS_STEPS];
   int rank[DS_STEPS];  // -1: no entry
   const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
   for (int j = 0; j < DS_STEPS; ++j) {
     const int t = wbase + j * WAVE + lane;
     key[j] = 0ull;
-    id[j] = 0;
     rank[j] = -1;
     bool have = false;
+    uint32_t d = 0u;
     if (t < n) {
-      key[j] = keys_in[vbase + t];
-      have = !FIRST || (key[j] & field_mask) != 0ull;
-      if (have) id[j] = FIRST ? t : ids_in[vbase + t];
+      if (FIRST) {
+        const uint32_t f = field[vbase + t];
+        have = f != 0u;
+        d = f & dmask;
+        key[j] = id_bits > 0 ? ((uint64_t)(f >> DS_BITS) << (id_bits + 26)) | ((uint64_t)(uint32_t)t << 26) | rect_raw[vbase + t]
+                             : ((uint64_t)f << 32) | (uint32_t)t;
+      } else {
+        key[j] = keys_in[vbase + t];
+        have = true;
+        d = (uint32_t)(key[j] >> word_shift) & dmask;
+      }
     }
-    const uint32_t d = (uint32_t)(key[j] >> shift) & dmask;
+    digit[j] = (unsigned short)d;
     if (LANE_ORDERED) {
       if (have) rank[j] = (int)atomicAdd(&s_cnt[wv][d], 1u);
     } else {
@@ -223,19 +244,23 @@ __global__ __launch_bounds__(DS_T) void ds_scatter_kernel(int P, int V, int nchu
 #pragma unroll
   for (int j = 0; j < DS_STEPS; ++j)
     if (rank[j] >= 0) {
-      const uint32_t d = (uint32_t)(key[j] >> shift) & dmask;
-      const unsigned int lp = s_cnt[wv][d] + (unsigned int)rank[j];
+      const unsigned int lp = s_cnt[wv][digit[j]] + (unsigned int)rank[j];
       s_key[lp] = key[j];
-      s_id[lp] = id[j];
+      if (FIRST) s_dig[lp] = digit[j];  // a packed word no longer holds the bits this pass sorts on
     }
   __syncthreads();
   // ---- phase 4: contiguous runs per digit leave as full lines
   for (int lp = threadIdx.x; lp < total; lp += DS_T) {
     const uint64_t k = s_key[lp];
-    const int64_t gp = vbase + s_delta[(uint32_t)(k >> shift) & dmask] + lp;
-    if (LAST) hi_out[gp] = (uint32_t)(k >> out_shift);
-    else keys_out[gp] = k;
-    ids_out[gp] = s_id[lp];
+    const uint32_t d = FIRST ? (uint32_t)s_dig[lp] : (uint32_t)(k >> word_shift) & dmask;
+    const int64_t gp = vbase + s_delta[d] + lp;
+    if (LAST) {
+      const uint32_t id = id_bits > 0 ? (uint32_t)(k >> 26) & ((1u << id_bits) - 1u) : (uint32_t)k;
+      ids_out[gp] = (int32_t)id;
+      rect_out[gp] = id_bits > 0 ? (uint32_t)k & 0x3ffffffu : rect_raw[vbase + id];
+    } else {
+      keys_out[gp] = k;
+    }
   }
 }
 
@@ -248,13 +273,13 @@ size_t depth_sort_table_bytes(int64_t P, int V) {
          256;
 }
 
-// keys_a: [V*P] raw keys (destroyed); keys_b, ids_tmp: [V*P] scratch.  Out: ids_out / hi_out [V*P] (the first
-// nvalid_out[v] entries of every view's stride-P segment), nvalid_out [V] on the device.
-int depth_sort_views(uint64_t* keys_a, uint64_t* keys_b, int32_t* ids_tmp, int32_t* ids_out, uint32_t* hi_out, int out_shift,
-                     int32_t* nvalid_out, int64_t P, int V, int key_bits, void* table, size_t table_bytes,
+// field, rect_raw: [V*P] per (view, Gaussian), left untouched.  keys_a, keys_b: [V*P] scratch.  Out: ids_out / rect_out
+// [V*P] (the first nvalid_out[v] entries of every view's stride-P segment), nvalid_out [V] on the device.
+int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* keys_a, uint64_t* keys_b, int32_t* ids_out,
+                     uint32_t* rect_out, int32_t* nvalid_out, int64_t P, int V, int key_bits, void* table, size_t table_bytes,
                      hipStream_t stream) {
   if (P <= 0 || V <= 0) return GR_OK;
-  GR_REQUIRE(key_bits >= 1 && key_bits <= 36, "depth_sort: key_bits %d out of range", key_bits);
+  GR_REQUIRE(key_bits >= 1 && key_bits <= 32, "depth_sort: key_bits %d out of range", key_bits);
   GR_REQUIRE(table && table_bytes >= depth_sort_table_bytes(P, V), "depth_sort: table too small");
   const int nchunk = (int)((P + DS_CHUNK - 1) / DS_CHUNK);
   Carver cv(table);
@@ -265,32 +290,33 @@ int depth_sort_views(uint64_t* keys_a, uint64_t* keys_b, int32_t* ids_tmp, int32
   int rc = lds_atomics_lane_ordered(stream, &ordered);
   if (rc != GR_OK) return rc;
   const int passes = (key_bits + DS_BITS - 1) / DS_BITS;
-  const uint64_t field_mask = (key_bits >= 64) ? ~0ull : ((1ull << key_bits) - 1ull);
   const dim3 grid((unsigned)ds_grid(V, nchunk)), blk(DS_T);
-  // id buffers ping-pong so that the LAST pass writes ids_out
-  int32_t* idbuf[2] = {(passes % 2) ? ids_out : ids_tmp, (passes % 2) ? ids_tmp : ids_out};
+  int id_bits = 1;
+  while (id_bits < 32 && (1ll << id_bits) < P) ++id_bits;
+  const int rest_bits = std::max(0, key_bits - DS_BITS);  // field bits still to be sorted after the first pass
+  const bool packed = rest_bits + id_bits + 26 <= 64;
+  if (!packed) id_bits = 0;
   uint64_t* kbuf[2] = {keys_a, keys_b};
   for (int p = 0; p < passes; ++p) {
     const int shift = p * DS_BITS;
+    const int word_shift = packed ? id_bits + 26 + (p - 1) * DS_BITS : 32 + shift;  // passes after the first
     const int nb = std::min(DS_BITS, key_bits - shift);
     const uint32_t dmask = (1u << nb) - 1u;
     const bool first = p == 0, last = p == passes - 1;
-    const uint64_t* kin = kbuf[p % 2];
-    uint64_t* kout = kbuf[(p + 1) % 2];
-    const int32_t* iin = first ? nullptr : idbuf[(p + 1) % 2];
-    int32_t* iout = idbuf[p % 2];
+    const uint64_t* kin = first ? nullptr : kbuf[(p + 1) % 2];
+    uint64_t* kout = kbuf[p % 2];
     if (first)
-      hipLaunchKernelGGL(ds_count_kernel<true>, grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, kin, shift, dmask,
-                         field_mask, hist);
+      hipLaunchKernelGGL(ds_count_kernel<true>, grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field, kin, word_shift,
+                         dmask, hist);
     else
-      hipLaunchKernelGGL(ds_count_kernel<false>, grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, kin, shift, dmask,
-                         field_mask, hist);
+      hipLaunchKernelGGL(ds_count_kernel<false>, grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field, kin, word_shift,
+                         dmask, hist);
     hipLaunchKernelGGL(ds_scan_kernel, dim3((unsigned)(V * (DS_BINS / WAVE))), dim3(DS_SCAN_NW * WAVE), 0, stream, nchunk, hist,
                        offs, dbase);
     hipLaunchKernelGGL(ds_digit_base_kernel, dim3((unsigned)V), dim3(DS_BINS), 0, stream, dbase, first ? nvalid_out : nullptr);
-#define GR_DS_SCATTER(F, L, O)                                                                                              \
-  hipLaunchKernelGGL((ds_scatter_kernel<F, L, O>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, kin, iin, shift, \
-                     dmask, field_mask, offs, dbase, kout, hi_out, out_shift, iout)
+#define GR_DS_SCATTER(F, L, O)                                                                                            \
+  hipLaunchKernelGGL((ds_scatter_kernel<F, L, O>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field, kin, \
+                     word_shift, id_bits, dmask, offs, dbase, kout, rect_raw, rect_out, ids_out)
     if (ordered) {
       if (first && last) GR_DS_SCATTER(true, true, true);
       else if (first) GR_DS_SCATTER(true, false, true);

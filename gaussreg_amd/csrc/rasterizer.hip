@@ -183,8 +183,10 @@ __device__ __forceinline__ void get_rect(float px, float py, int radius, int gx,
 //   rec[2] = {r, g, b, kc (cull factor)}          rec[3] = unused
 struct Geom {
   float4* rec;           // [V][P][4]
-  uint64_t* dkeys_a;     // [V*P] rect bits | view << 27 | rebased depth bits (see KEY_DEPTH_BITS)
-  uint64_t* dkeys_b;
+  uint32_t* dfield;      // [V*P] depth-sort field: rebased depth bits (see KEY_DEPTH_BITS), 0 = culled
+  uint32_t* rect_raw;    // [V*P] packed tile rectangle of every (view, Gaussian), Gaussian order
+  uint64_t* keys_a;      // [V*P] x 2: (field << 32 | id) ping-pong buffers of the depth sort
+  uint64_t* keys_b;
   int32_t* order_a;      // (unused: the sort generates ids on the fly); order_b = per-view front-to-back order
   int32_t* order_b;
   uint32_t* rects;       // [V*P] depth-ordered tile rectangles (26-bit packing of the key's high bits)
@@ -192,7 +194,6 @@ struct Geom {
   uint32_t* seg_off;     // [V][nchunk][tiles + 1] position of segment (chunk, tile) in the point list (+ end sentinel)
   int32_t* chunk_total;  // [V][nchunk] instances per chunk, then [V][nchunk] exclusive prefix inside the view
   int32_t* chunk_max;    // [1] largest chunk total
-  int32_t* ids_tmp;      // [V*P] id ping-pong buffer of the depth sort
   void* ds_table;        // depth-sort histograms / offsets
   size_t ds_table_bytes;
   int32_t* nvis;         // [V] visible (depth-ordered) Gaussians per view
@@ -210,8 +211,10 @@ Geom carve_geom(void* p, int64_t P, int V, int64_t tiles) {
   Carver c(p);
   const int64_t nchunk = (P + BIN_CHUNK - 1) / BIN_CHUNK;
   g.rec = c.take<float4>(P * V * 4);
-  g.dkeys_a = c.take<uint64_t>(P * V);
-  g.dkeys_b = c.take<uint64_t>(P * V);
+  g.dfield = c.take<uint32_t>(P * V);
+  g.rect_raw = c.take<uint32_t>(P * V);
+  g.keys_a = c.take<uint64_t>(P * V);
+  g.keys_b = c.take<uint64_t>(P * V);
   g.order_a = nullptr;
   g.order_b = c.take<int32_t>(P * V);
   g.rects = c.take<uint32_t>(P * V);
@@ -219,7 +222,6 @@ Geom carve_geom(void* p, int64_t P, int V, int64_t tiles) {
   g.seg_off = c.take<uint32_t>(V * nchunk * (tiles + 1));
   g.chunk_total = c.take<int32_t>(2 * V * nchunk);
   g.chunk_max = c.take<int32_t>(1);
-  g.ids_tmp = c.take<int32_t>(P * V);
   g.ds_table_bytes = depth_sort_table_bytes(P, V);
   g.ds_table = c.take<char>(g.ds_table_bytes);
   g.nvis = c.take<int32_t>(V);
@@ -245,23 +247,20 @@ Bin carve_bin(void* p, int64_t R, int64_t vtiles) {
 }
 
 // ------------------------------------------------------------------------------------ preprocess
-// The depth-sort key carries the tile rectangle in the bits the sort ignores, so the instance
-// emission (which runs in depth order) never has to gather the geometry records:
-//   bits  0..31 depth bits | 32..37 view | 38..44 rect.x | 45..51 rect.y | 52..57 w | 58..63 h
-// Rectangles that do not fit (w or h > 63, x or y > 126) store the marker below and are gathered.
-constexpr int KEY_VIEW_BITS = 6;
-// Depth-sort key: [0,27) = float bits of depth minus those of 0.125 (visible depths are > 0.2, so this is >= 0 and
-// order-preserving; < 2^27 while depth < 8192), [27, 27+view bits) = view.  27 + 4 view bits sort in four 8-bit radix
-// passes instead of the five that (view << 32 | depth bits) needs.  A depth >= 8192 raises a flag and the call
-// re-sorts with full keys (slow path, never taken by sane scenes).
+// Per (view, Gaussian) the preprocess emits a 32-bit depth-sort field and the packed tile rectangle (26 bits:
+// x:7 | y:7 | w:6 | h:6; rectangles that do not fit store RECT_MARKER26 and are rebuilt from the record).  The sort moves
+// (field << 32 | Gaussian id) words and looks the rectangle up by id in its last pass.
+// Field: float bits of depth minus those of 0.125 (visible depths are > 0.2, so this is > 0 and order-preserving; < 2^27
+// while depth < 8192): 27 bits sort in three 9-bit passes.  A depth >= 8192 raises a flag and the call re-sorts on the
+// full 32 depth bits (slow path, never taken by sane scenes).
 constexpr int KEY_DEPTH_BITS = 27;
 constexpr uint32_t KEY_DEPTH_BASE = 0x3E000000u;  // bits of 0.125f
-constexpr uint64_t RECT_MARKER = (127ull << 38) | (127ull << 45);  // w = h = 0
+constexpr uint32_t RECT_MARKER26 = 127u | (127u << 7);  // w = h = 0
 
-__device__ __forceinline__ uint64_t pack_rect(const int* rmin, const int* rmax) {
+__device__ __forceinline__ uint32_t pack_rect(const int* rmin, const int* rmax) {
   const int w = rmax[0] - rmin[0], h = rmax[1] - rmin[1];
-  if (w > 63 || h > 63 || rmin[0] > 126 || rmin[1] > 126) return RECT_MARKER;
-  return ((uint64_t)rmin[0] << 38) | ((uint64_t)rmin[1] << 45) | ((uint64_t)w << 52) | ((uint64_t)h << 58);
+  if (w > 63 || h > 63 || rmin[0] > 126 || rmin[1] > 126) return RECT_MARKER26;
+  return (uint32_t)rmin[0] | ((uint32_t)rmin[1] << 7) | ((uint32_t)w << 14) | ((uint32_t)h << 20);
 }
 
 constexpr int REC_PLANE = 66;  // float4 per record-piece plane (64 + 2): the transposed ds_read_b128 are conflict-free
@@ -273,8 +272,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const float* __restrict__ shs, const float* __restrict__ colors_precomp,
     const float* __restrict__ opacities, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, int W, int H,
-    int32_t* __restrict__ radii, float4* __restrict__ rec, uint64_t* __restrict__ dkeys,
-    int32_t* __restrict__ far_flag) {
+    int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ dfield,
+    uint32_t* __restrict__ rect_raw, int32_t* __restrict__ far_flag) {
   __shared__ float4 s_sh[SH16 ? WAVE * SH_ROW : 1];
   __shared__ float4 s_rec[256 / WAVE][4 * REC_PLANE];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -342,7 +341,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const DevView& cam = views[v];
     const int64_t o = (int64_t)v * P + i;
     int out_radius = 0;
-    uint64_t out_key = (uint64_t)v << KEY_DEPTH_BITS;  // culled: depth key 0, empty rectangle
+    uint32_t out_field = 0u, out_rect = 0u;  // culled: depth field 0
     float out_depth = 0.f, out_sxx = INFINITY, out_syy = INFINITY;
     float2 out_xy = make_float2(0.f, 0.f);
     float4 out_co = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -422,13 +421,15 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
             dk = (1u << KEY_DEPTH_BITS) - 1;
             atomicOr(far_flag, 1);
           }
-          out_key |= (uint64_t)dk | pack_rect(rmin, rmax);
+          out_field = dk;
+          out_rect = pack_rect(rmin, rmax);
         }
       }
     }
     if (valid) {
       radii[o] = out_radius;
-      dkeys[o] = out_key;
+      dfield[o] = out_field;
+      rect_raw[o] = out_rect;
     }
     // The wave's 64 records (4 KB, contiguous) leave through LDS: lane l stores piece l % 4 of record 16 k + l / 4 in
     // store k, so every store instruction covers whole lines.  (Each lane writing its own record piece by piece costs four
@@ -456,15 +457,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
   }
 }
 
-// slow path of the depth sort: keys with the full 32 depth bits (view << 32 | depth bits), rectangle bits kept
-__global__ __launch_bounds__(256) void full_keys_kernel(int64_t n, int P, const float4* __restrict__ rec,
-                                                        const int32_t* __restrict__ radii, uint64_t* __restrict__ keys) {
+// slow path of the depth sort: the field becomes the full 32 depth bits (visible depths are > 0.2: non-zero)
+__global__ __launch_bounds__(256) void full_keys_kernel(int64_t n, const float4* __restrict__ rec,
+                                                        const int32_t* __restrict__ radii, uint32_t* __restrict__ dfield) {
   const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= n) return;
-  const uint64_t v = (uint64_t)(o / P);
-  const uint64_t rect = keys[o] & ~((1ull << 38) - 1ull);
-  const uint32_t dbits = radii[o] > 0 ? __float_as_uint(rec[4 * o + 3].y) : 0u;
-  keys[o] = rect | (v << 32) | dbits;
+  dfield[o] = radii[o] > 0 ? __float_as_uint(rec[4 * o + 3].y) : 0u;
 }
 
 // ------------------------------------------------------------------------------------ tile binning
@@ -491,7 +489,6 @@ __global__ __launch_bounds__(256) void full_keys_kernel(int64_t n, int P, const 
 //            staging block at their final chunk-local position; the block is then copied out with coalesced stores
 //            (chunks whose instances do not fit the staging block write straight to their final global position).
 // With >= 8 views the workgroups of one view all run on the same XCD (block b sits on XCD b % 8).
-constexpr uint32_t RECT_MARKER26 = 127u | (127u << 7);
 
 __device__ __forceinline__ bool rect_decode(uint32_t r, int id, int64_t vbase, const float4* __restrict__ rec, int gx,
                                             int gy, int& x0, int& y0, int& w, int& h) {
@@ -1165,7 +1162,7 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
 #define GR_PRE(SH, COV, S16)                                                                       \
   hipLaunchKernelGGL((preprocess_kernel<SH, COV, S16>), grd, blk, 0, stream, (int)P, D, M, num_views, \
                      g.views, means3D, shs, colors_precomp, opacities, scales, rotations,          \
-                     cov3D_precomp, W, H, radii, g.rec, g.dkeys_a, g.totals + num_views)
+                     cov3D_precomp, W, H, radii, g.rec, g.dfield, g.rect_raw, g.totals + num_views)
   auto run_preprocess = [&]() {
     KernelTimer timer("raster_preprocess", stream);
     if (shs && cov3D_precomp) { if (sh16) GR_PRE(true, true, true); else GR_PRE(true, true, false); }
@@ -1176,7 +1173,6 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
   GR_HIP(hipMemsetAsync(g.totals + num_views, 0, sizeof(int32_t), stream));  // depth-overflow flag
   run_preprocess();
   GR_LAUNCH_CHECK();
-  static_assert((1 << KEY_VIEW_BITS) >= MAX_VIEWS && KEY_DEPTH_BITS + KEY_VIEW_BITS <= 38, "view id must fit its key field");
   int32_t* tot = static_cast<int32_t*>(pinned_scratch(1, sizeof(int32_t) * (num_views + 2)));  // totals, far flag, chunk max
   GR_REQUIRE(tot != nullptr, "pinned read-back buffer could not be allocated");
   const int nchunk = (int)((P + BIN_CHUNK - 1) / BIN_CHUNK);
@@ -1185,7 +1181,7 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
     {
       KernelTimer timer("raster_depth_sort", stream);
       // visible Gaussians of every view in depth order (ties: Gaussian id): ids -> order_b, rectangles -> rects
-      int rcs = depth_sort_views(g.dkeys_a, g.dkeys_b, g.ids_tmp, g.order_b, g.rects, 38, g.nvis, P, num_views, key_bits,
+      int rcs = depth_sort_views(g.dfield, g.rect_raw, g.keys_a, g.keys_b, g.order_b, g.rects, g.nvis, P, num_views, key_bits,
                                  g.ds_table, g.ds_table_bytes, stream);
       if (rcs != GR_OK) return rcs;
     }
@@ -1216,9 +1212,8 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
   rc = sort_and_count(KEY_DEPTH_BITS);
   if (rc != GR_OK) return rc;
   if (tot[num_views] != 0) {  // some depth >= 8192: redo the ordering with full-width keys
-    run_preprocess();         // the sort consumed the key array: regenerate it (deterministic), then widen the depth field
     hipLaunchKernelGGL(full_keys_kernel, dim3((unsigned)((P * num_views + 255) / 256)), blk, 0, stream, P * num_views,
-                       (int)P, g.rec, radii, g.dkeys_a);
+                       g.rec, radii, g.dfield);
     GR_LAUNCH_CHECK();
     rc = sort_and_count(32);
     if (rc != GR_OK) return rc;
