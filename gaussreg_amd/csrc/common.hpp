@@ -84,7 +84,8 @@ int exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int rows, int
 // Pinned host scratch, one buffer per (host thread, slot), grown on demand and kept for the life of the process.  A copy
 // to or from pageable memory is staged and synchronised by the runtime; through these buffers the small uploads and
 // read-backs of the API calls are asynchronous for real.  Contract: the caller synchronises the stream before it returns
-// (every entry point that uses this does), so the next call on the thread finds the buffer free.
+// (slots 0-3: every entry point that uses them does) or guards the slot with an event it waits on before the next use
+// (slot 4, hash_order_device), so the next call on the thread finds the buffer free.
 void* pinned_scratch(int slot, size_t bytes);
 
 // Per-cloud bounding boxes of stacked points: bbox_dev[b*6 + {0,1,2}] = min xyz, +{3,4,5} = max xyz,

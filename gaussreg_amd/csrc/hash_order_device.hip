@@ -58,31 +58,35 @@ __global__ __launch_bounds__(HO_T) void ho_init_kernel(int n, const int32_t* __r
 
 // Stage kernels run on 2-D grids: blockIdx.y = cloud, blockIdx.x * HO_T + lane = local element; the grid's x extent is the
 // largest m of the stage, so the early stages (13, 29, 59 ... elements per cloud) cost a launch each and nothing more.
+// One device-scope atomic per element (returning global atomics are served behind the L2s and are what this step costs):
+// the exchange threads the element onto its bucket's chain; the bucket's size and oldest clock, which used to be an
+// atomicAdd and an atomicMin next to it, are read off the (short) chain by the two kernels that need them.
 __global__ __launch_bounds__(HO_T) void ho_bucket_kernel(const HoCloud* __restrict__ st,
-                                                         const uint64_t* __restrict__ keys, const int32_t* __restrict__ T,
-                                                         int32_t* __restrict__ bkt, int32_t* __restrict__ first,
-                                                         int32_t* __restrict__ cnt, int32_t* __restrict__ head,
-                                                         int32_t* __restrict__ nxt) {
+                                                         const uint64_t* __restrict__ keys, int32_t* __restrict__ bkt,
+                                                         int32_t* __restrict__ head, int32_t* __restrict__ nxt) {
   const HoCloud s = st[blockIdx.y];
   const int le = blockIdx.x * HO_T + threadIdx.x;
   if (le >= s.m || s.n == 0) return;
   const int e = s.begin + le;
   const int b = s.toff + (int)(keys[e] % (uint64_t)s.n);  // std::hash<size_t> is the identity, not cached
   bkt[e] = b;
-  atomicMin(&first[b], T[e]);
-  atomicAdd(&cnt[b], 1);
-  nxt[e] = atomicExch(&head[b], e);  // chain order is irrelevant: the walk below only counts
+  nxt[e] = atomicExch(&head[b], e);  // chain order is irrelevant: the walks below only count and take minima
 }
 
 __global__ __launch_bounds__(HO_T) void ho_group_kernel(const HoCloud* __restrict__ st, const int32_t* __restrict__ T,
-                                                        const int32_t* __restrict__ bkt, const int32_t* __restrict__ first,
-                                                        const int32_t* __restrict__ cnt, int32_t* __restrict__ G) {
+                                                        const int32_t* __restrict__ bkt, const int32_t* __restrict__ head,
+                                                        const int32_t* __restrict__ nxt, int32_t* __restrict__ G) {
   const HoCloud s = st[blockIdx.y];
   const int le = blockIdx.x * HO_T + threadIdx.x;
   if (le >= s.m || s.n == 0) return;
   const int e = s.begin + le;
-  const int b = bkt[e];
-  G[s.begin + T[e]] = (T[e] == first[b]) ? cnt[b] : 0;  // T is a permutation of 0 .. m-1: every slot written once
+  const int t = T[e];
+  int first = t, cnt = 0;
+  for (int p = head[bkt[e]]; p >= 0; p = nxt[p]) {
+    first = min(first, T[p]);
+    ++cnt;
+  }
+  G[s.begin + t] = (t == first) ? cnt : 0;  // T is a permutation of 0 .. m-1: every slot written once
 }
 
 // per cloud: S[f] = sum of G over clock values > f (exclusive suffix sum), one workgroup per cloud
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(1024) void ho_suffix_kernel(const HoCloud* __restri
 
 // reads the clocks of the whole bucket chain from T, writes the new positions to the OTHER ping-pong buffer
 __global__ __launch_bounds__(HO_T) void ho_rank_kernel(const HoCloud* __restrict__ st, const int32_t* __restrict__ T,
-                                                       const int32_t* __restrict__ bkt, const int32_t* __restrict__ first,
+                                                       const int32_t* __restrict__ bkt,
                                                        const int32_t* __restrict__ head, const int32_t* __restrict__ nxt,
                                                        const int32_t* __restrict__ S, int32_t* __restrict__ T_out) {
   const HoCloud s = st[blockIdx.y];
@@ -126,9 +130,13 @@ __global__ __launch_bounds__(HO_T) void ho_rank_kernel(const HoCloud* __restrict
   }
   const int b = bkt[e];
   const int t = T[e];
-  int within = 0;
-  for (int p = head[b]; p >= 0; p = nxt[p]) within += T[p] > t ? 1 : 0;
-  T_out[e] = S[s.begin + first[b]] + within;
+  int within = 0, first = t;
+  for (int p = head[b]; p >= 0; p = nxt[p]) {
+    const int tp = T[p];
+    within += tp > t ? 1 : 0;
+    first = min(first, tp);
+  }
+  T_out[e] = S[s.begin + first] + within;
 }
 
 // The first stages of every history are tiny (tables of 13, 29, 59 ... 2357 buckets): one workgroup per cloud runs them
@@ -227,7 +235,7 @@ static void rehash_schedule(int64_t m, std::vector<std::pair<int64_t, uint64_t>>
 size_t hash_order_device_bytes(int64_t n, int64_t batch) {
   // worst case bucket table: the policy at most doubles past the element count (+ the prime gap): 4 n + slack per cloud
   const size_t buckets = (size_t)(4 * n + 64 * batch + 64);
-  return align_up((size_t)n * 4, 256) * 7 + align_up(2 * buckets * 4, 256) * 3 + align_up((size_t)(batch + 1) * 4, 256) * 2 +
+  return align_up((size_t)n * 4, 256) * 7 + align_up(2 * buckets * 4, 256) + align_up((size_t)(batch + 1) * 4, 256) * 2 +
          align_up((size_t)batch * sizeof(HoCloud), 256) * 64 + 4096;
 }
 
@@ -279,17 +287,24 @@ int hash_order_device(const uint64_t* keys, const int64_t* h_begins, int64_t bat
   int32_t* nxt = cv.take<int32_t>(n);
   int32_t* G = cv.take<int32_t>(n);
   int32_t* S = cv.take<int32_t>(n);
-  int32_t* first = cv.take<int32_t>(buckets);
-  int32_t* cnt = cv.take<int32_t>(buckets);
   int32_t* head = cv.take<int32_t>(buckets);
   int32_t* d_begins = cv.take<int32_t>(batch + 1);
   HoCloud* d_st = cv.take<HoCloud>(nstage * batch);
   GR_REQUIRE(ws && cv.used() <= ws_bytes, "hash_order_device: workspace too small (%zu > %zu)", cv.used(), ws_bytes);
-  GR_HIP(hipMemcpyAsync(d_begins, begins.data(), sizeof(int32_t) * (batch + 1), hipMemcpyHostToDevice, stream));
-  GR_HIP(hipMemsetAsync(first, 0x7f, sizeof(int32_t) * buckets, stream));  // 0x7f7f7f7f: larger than any clock value
-  GR_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * buckets, stream));
+  // The two small tables go up through pinned per-thread staging; an event says when the copies have left it, so the
+  // call returns without a stream synchronise and the next call on this thread waits (normally not at all) before reuse.
+  static thread_local hipEvent_t staged = nullptr;
+  if (staged == nullptr) GR_HIP(hipEventCreateWithFlags(&staged, hipEventDisableTiming));
+  else GR_HIP(hipEventSynchronize(staged));
+  const size_t begins_bytes = sizeof(int32_t) * (batch + 1), hs_bytes = sizeof(HoCloud) * hs.size();
+  char* stage = static_cast<char*>(pinned_scratch(4, align_up(begins_bytes, 256) + hs_bytes));
+  GR_REQUIRE(stage != nullptr, "hash_order_device: pinned staging buffer could not be allocated");
+  memcpy(stage, begins.data(), begins_bytes);
+  memcpy(stage + align_up(begins_bytes, 256), hs.data(), hs_bytes);
+  GR_HIP(hipMemcpyAsync(d_begins, stage, begins_bytes, hipMemcpyHostToDevice, stream));
   GR_HIP(hipMemsetAsync(head, 0xff, sizeof(int32_t) * buckets, stream));    // -1
-  GR_HIP(hipMemcpyAsync(d_st, hs.data(), sizeof(HoCloud) * hs.size(), hipMemcpyHostToDevice, stream));
+  GR_HIP(hipMemcpyAsync(d_st, stage + align_up(begins_bytes, 256), hs_bytes, hipMemcpyHostToDevice, stream));
+  GR_HIP(hipEventRecord(staged, stream));
   const dim3 blk(HO_T), grd((unsigned)((n + HO_T - 1) / HO_T));
   hipLaunchKernelGGL(ho_init_kernel, grd, blk, 0, stream, (int)n, d_begins, (int)batch, Ta, Tb, cloud);
   int32_t* Tin = Ta;
@@ -320,15 +335,14 @@ int hash_order_device(const uint64_t* keys, const int64_t* h_begins, int64_t bat
     if (max_m == 0) continue;
     (void)max_n;
     const dim3 eg((unsigned)((max_m + HO_T - 1) / HO_T), (unsigned)batch);
-    hipLaunchKernelGGL(ho_bucket_kernel, eg, blk, 0, stream, st, keys, Tin, bkt, first, cnt, head, nxt);
-    hipLaunchKernelGGL(ho_group_kernel, eg, blk, 0, stream, st, Tin, bkt, first, cnt, G);
+    hipLaunchKernelGGL(ho_bucket_kernel, eg, blk, 0, stream, st, keys, bkt, head, nxt);
+    hipLaunchKernelGGL(ho_group_kernel, eg, blk, 0, stream, st, Tin, bkt, head, nxt, G);
     hipLaunchKernelGGL(ho_suffix_kernel, dim3((unsigned)batch), dim3(1024), 0, stream, st, G, S);
-    hipLaunchKernelGGL(ho_rank_kernel, eg, blk, 0, stream, st, Tin, bkt, first, head, nxt, S, Tout);
+    hipLaunchKernelGGL(ho_rank_kernel, eg, blk, 0, stream, st, Tin, bkt, head, nxt, S, Tout);
     std::swap(Tin, Tout);
   }
   hipLaunchKernelGGL(ho_emit_kernel, grd, blk, 0, stream, (int)n, d_begins, cloud, Tin, perm_out);
   GR_LAUNCH_CHECK();
-  GR_HIP(hipStreamSynchronize(stream));  // the host staging vectors above must outlive their copies
   return GR_OK;
 }
 
