@@ -810,7 +810,7 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
   float* const s_op = s_pl + 6 * PL;                                                          // opacity
   float* const s_cr = s_pl + 7 * PL, * const s_cg = s_pl + 8 * PL, * const s_cb = s_pl + 9 * PL;  // colour
   __shared__ unsigned short s_list[NCELL][BLOCK + 2];                   // byte offsets (4 * entry) into the planes
-  __shared__ int s_cnt[NCELL][BLOCK / WAVE + 1];  // per (cell, loading wave) counts -> bases; [.][4] = total
+  __shared__ int s_cnt[NCELL][BLOCK / WAVE];      // per (cell, loading wave) counts
   __shared__ int s_alldone[BLOCK / WAVE];
   __shared__ int s_wpre[WAVE];                    // window of 64 chunks: inclusive prefix of this tile's segment lengths
   __shared__ unsigned int s_woff[WAVE];           //                      and where each segment starts in point_list
@@ -935,19 +935,18 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
     }
     if (lane < NCELL) s_cnt[lane][lw] = cnt_lane;
     __syncthreads();
-    if (tid < NCELL) {
-      int acc = 0;
+    // every wave adds up the four per-wave counts itself (lane c: cell c) -- no second barrier for a 16-thread scan
+    int base_lane = 0, tot_lane = 0;  // lane c: where this wave's entries start in list c; the list's length
+    if (lane < NCELL) {
 #pragma unroll
       for (int w = 0; w < BLOCK / WAVE; ++w) {
-        const int n = s_cnt[tid][w];
-        s_cnt[tid][w] = acc;
-        acc += n;
+        const int n = s_cnt[lane][w];
+        base_lane += w < lw ? n : 0;
+        tot_lane += n;
       }
-      s_cnt[tid][BLOCK / WAVE] = acc;
-      if (acc & 1) s_list[tid][acc] = (unsigned short)(4 * BLOCK);  // lists are walked in pairs: pad with the never-hit entry
+      // lists are walked in pairs: pad an odd one with the never-hit entry
+      if (lw == 0 && (tot_lane & 1)) s_list[lane][tot_lane] = (unsigned short)(4 * BLOCK);
     }
-    __syncthreads();
-    const int base_lane = lane < NCELL ? s_cnt[lane][lw] : 0;  // lane c: where this wave's entries start in list c
 #pragma unroll
     for (int c = 0; c < NCELL; ++c) {
       const int base = __builtin_amdgcn_readlane(base_lane, c);
@@ -957,9 +956,10 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
     }
     __syncthreads();
     // ---- blend: each 16-lane group walks its own list
-    const int n_cell = done ? 0 : s_cnt[cell][BLOCK / WAVE];
+    const int len_cell = __shfl(tot_lane, (BLOCK / WAVE) * lw + lane / (CELL * CELL));  // cell = 4 lw + lane / 16
+    const int n_cell = done ? 0 : len_cell;
     if (STATS) {
-      if (pin == 0) atomicAdd(&g_blend_stats[3], (unsigned long long)s_cnt[cell][BLOCK / WAVE]);
+      if (pin == 0) atomicAdd(&g_blend_stats[3], (unsigned long long)len_cell);
       const int mx = wave_max_i32_dpp(n_cell);
       if (lane == 0) atomicAdd(&g_blend_stats[4], (unsigned long long)((mx + 1) / 2));
     }
