@@ -34,6 +34,7 @@ NUM_CORRESPONDENCES = 256               # coarse_matching.num_correspondences
 POINT_LIMIT = 128                       # model.num_points_in_patch
 NUM_SINKHORN_ITERATIONS = 100
 RESULT_LEN = 16 + 4                     # flattened 4x4 + (RRE deg, RTE m, #correspondences, inlier ratio)
+PATCH_CHUNK = 4096                      # patches per descriptor / Sinkhorn pass (4096 x 128 x 256 floats = 0.5 GB per side)
 
 
 def synthetic_room_pair(seed, n_per_cloud, device):
@@ -153,15 +154,17 @@ class PairRegistrar:
     def register_pairs(self, pairs):
         """pairs: list of (ref (n,3), src (m,3), T_gt (4,4) or None) device tensors.
         Returns (len(pairs), RESULT_LEN) float32: [T.flatten(), RRE deg, RTE m, #correspondences, inlier ratio]."""
+        return self._register_sampled(pairs, self._sample(pairs, self.fps_clouds_per_call))
+
+    def _sample(self, pairs, clouds_per_call):
+        """FPS, several clouds per call (stack order [ref_1..ref_B, src_1..src_B] like data.py:151-155)."""
         B = len(pairs)
-        dev = self.device
-        # ---- FPS, several clouds per call (stack order [ref_1..ref_B, src_1..src_B] like data.py:151-155)
         clouds = [p[0] for p in pairs] + [p[1] for p in pairs]
         sampled = []
         with self._sec("fps"):
-            # at most fps_clouds_per_call clouds per launch (the co-operating workgroups of a call share the 256 CUs; 24
+            # at most clouds_per_call clouds per launch (the co-operating workgroups of a call share the 256 CUs; 24
             # clouds of 200 k points still fit their slabs in registers), in calls of equal size
-            n_calls = -(-2 * B // self.fps_clouds_per_call)
+            n_calls = -(-2 * B // clouds_per_call)
             bounds = [round(i * 2 * B / n_calls) for i in range(n_calls + 1)]
             for lo_, hi_ in zip(bounds[:-1], bounds[1:]):
                 chunk = clouds[lo_:hi_]
@@ -172,6 +175,11 @@ class PairRegistrar:
                     continue
                 idx = farthest_point_sampling(torch.cat(chunk, 0), lens, ks)
                 sampled += [c[ix] for c, ix in zip(chunk, idx)]
+        return sampled
+
+    def _register_sampled(self, pairs, sampled):
+        B = len(pairs)
+        dev = self.device
         # ---- the 5-level pyramid for the whole batch in one stack-mode pass (4 grid_subsample + 13 radius_search)
         with self._sec("pyramid"):
             points = torch.cat(sampled, 0).contiguous()
@@ -198,32 +206,44 @@ class PairRegistrar:
             src_in_ref = torch.einsum('nij,nj->ni', T_all[pid, :3, :3], pts_c[off_c[B]:]) + T_all[pid, :3, 3]
             frame_c = torch.cat([pts_c[:off_c[B]], src_in_ref], 0)
             feats_c = torch.nn.functional.normalize(self.coarse_desc(frame_c), p=2, dim=1)
-        ctx = (pairs, B, pts_c, pts_f, off_c, off_f, pad, out, feats_c)
-        S = 1 if self.profile else min(self.pair_streams, B)
-        if S <= 1:
-            for b in range(B):
-                self._register_one(b, ctx)
-        else:
-            if self._pool is None:
-                import concurrent.futures
-                self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=self.pair_streams)
-                self._streams = [torch.cuda.Stream(device=dev) for _ in range(self.pair_streams)]
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(dev))
-
-            def work(k):
-                torch.cuda.set_device(dev)
-                st = self._streams[k]
-                st.wait_event(ready)                       # the pyramid was built on the caller's stream
-                with torch.cuda.stream(st):
-                    for b in range(k, B, S):
-                        self._register_one(b, ctx)
-                done = torch.cuda.Event()
-                done.record(st)
-                return done
-
-            for ev in [f.result() for f in [self._pool.submit(work, k) for k in range(S)]]:
-                torch.cuda.current_stream(dev).wait_event(ev)
+        ctx = (pairs, B, pts_c, pts_f, off_c, off_f, out, feats_c)
+        # ---- stage 1, per pair: point_to_node_partition x 2, SuperPointMatching, the patches of the matched superpoints
+        st1 = [None] * B
+        self._fan_out(lambda b: st1.__setitem__(b, self._match_superpoints(b, ctx)), B)
+        # ---- stage 2, all pairs at once: patch coordinates -> descriptors -> scores -> log-Sinkhorn.  (One pair at a time
+        #      these are 256-workgroup launches behind ~35 host calls; over the batch they fill the machine.)
+        K = [t[0].shape[0] for t in st1]
+        k_off = [0]
+        for k in K:
+            k_off.append(k_off[-1] + k)
+        with self._sec("patch_features"):
+            n_f = pts_f.shape[0]
+            pts_pad = torch.cat([pts_f, pad], 0)                                           # model.py:171-172: pad row = index N
+            Kt = torch.tensor(K, device=dev)
+            pid = torch.repeat_interleave(torch.arange(B, device=dev), Kt)                 # patch -> pair
+            n_ref = torch.tensor([off_f[b + 1] - off_f[b] for b in range(B)], device=dev)[pid][:, None]
+            n_src = torch.tensor([off_f[B + b + 1] - off_f[B + b] for b in range(B)], device=dev)[pid][:, None]
+            o_ref = torch.tensor(off_f[:B], device=dev)[pid][:, None]
+            o_src = torch.tensor(off_f[B:2 * B], device=dev)[pid][:, None]
+            rk, rkm = torch.cat([t[0] for t in st1]), torch.cat([t[1] for t in st1])
+            sk, skm = torch.cat([t[2] for t in st1]), torch.cat([t[3] for t in st1])
+            rkp = pts_pad[torch.where(rk == n_ref, n_f, rk + o_ref)]                       # (sum K, 128, 3), local -> stacked index
+            skp = pts_pad[torch.where(sk == n_src, n_f, sk + o_src)]
+        matching = torch.empty((k_off[-1], POINT_LIMIT, POINT_LIMIT), dtype=torch.float32, device=dev)
+        for a in range(0, k_off[-1], PATCH_CHUNK):
+            e = min(k_off[-1], a + PATCH_CHUNK)
+            with self._sec("patch_features"):
+                R, t = T_all[pid[a:e], :3, :3], T_all[pid[a:e], :3, 3]
+                rkf = self.fine_desc(rkp[a:e]) * rkm[a:e, :, None]
+                skf = self.fine_desc(torch.einsum('kij,knj->kni', R, skp[a:e]) + t[:, None, :]) * skm[a:e, :, None]
+                scores = torch.einsum('bnd,bmd->bnm', rkf, skf) * (rkf.shape[-1] ** 0.5)
+                del rkf, skf
+            with self._sec("sinkhorn"):
+                matching[a:e] = self.ot(scores, rkm[a:e], skm[a:e])[:, :-1, :-1]           # model.py:191-198 (dustbins dropped)
+                del scores
+        # ---- stage 3, per pair: LocalGlobalRegistration, RANSAC, the result row
+        st3 = (pairs, out, rkp, skp, rkm, skm, matching, k_off, [t[4] for t in st1])
+        self._fan_out(lambda b: self._estimate(b, st3), B)
         if bool(gt_mask.any()):
             with self._sec("metrics"):
                 # RRE / RTE of all pairs at once (similarity estimate: the scale is stripped before the angle)
@@ -235,17 +255,44 @@ class PairRegistrar:
                 out[:, 17] = torch.where(gt_mask, torch.linalg.norm(T_est[:, :3, 3] - T_all[:, :3, 3], dim=1), out[:, 17])
         return out
 
-    @torch.no_grad()   # grad mode is per thread: the worker threads need their own
-    def _register_one(self, b, ctx):
-        """Everything after the pyramid for pair b (model.py:99-220), on the current stream."""
-        pairs, B, pts_c, pts_f, off_c, off_f, pad, out, feats_c = ctx
+    def _fan_out(self, fn, B):
+        """fn(b) for b in range(B): on `pair_streams` host threads, each with its own stream (thread k takes pairs k, k + S,
+        ...), or one after the other on the caller's stream."""
         dev = self.device
-        T_gt = pairs[b][2]
+        S = 1 if self.profile else min(self.pair_streams, B)
+        if S <= 1:
+            for b in range(B):
+                fn(b)
+            return
+        if self._pool is None:
+            import concurrent.futures
+            self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=self.pair_streams)
+            self._streams = [torch.cuda.Stream(device=dev) for _ in range(self.pair_streams)]
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
+
+        def work(k):
+            torch.cuda.set_device(dev)
+            st = self._streams[k]
+            st.wait_event(ready)                       # everything so far was issued on the caller's stream
+            with torch.cuda.stream(st), torch.no_grad():   # grad mode is per thread
+                for b in range(k, B, S):
+                    fn(b)
+            done = torch.cuda.Event()
+            done.record(st)
+            return done
+
+        for ev in [f.result() for f in [self._pool.submit(work, k) for k in range(S)]]:
+            torch.cuda.current_stream(dev).wait_event(ev)
+
+    def _match_superpoints(self, b, ctx):
+        """model.py:99-104, 152-159, 162-170 for pair b, on the current stream -> (ref patch indices (K, 128) local to the
+        pair's fine cloud, their masks, the same for src, node correspondence scores (K,))."""
+        pairs, B, pts_c, pts_f, off_c, off_f, out, feats_c = ctx
         ref_c = pts_c[off_c[b]:off_c[b + 1]]
         src_c = pts_c[off_c[B + b]:off_c[B + b + 1]]
         ref_f = pts_f[off_f[b]:off_f[b + 1]]
         src_f = pts_f[off_f[B + b]:off_f[B + b + 1]]
-        to_ref = (lambda x: x @ T_gt[:3, :3].T + T_gt[:3, 3]) if T_gt is not None else (lambda x: x)
         with self._sec("point_to_node"):                            # model.py:99-104
             _, ref_node_masks, ref_knn_idx, ref_knn_masks = point_to_node_partition(ref_f, ref_c, POINT_LIMIT)
             _, src_node_masks, src_knn_idx, src_knn_masks = point_to_node_partition(src_f, src_c, POINT_LIMIT)
@@ -253,19 +300,16 @@ class PairRegistrar:
         src_feats_c = feats_c[off_c[B + b]:off_c[B + b + 1]]
         with self._sec("superpoint_matching"):                      # model.py:152-159
             ref_ci, src_ci, node_scores = self.spm(ref_feats_c, src_feats_c, ref_node_masks, src_node_masks)
-        with self._sec("patch_features"):
-            # model.py:162-190: patches around the matched superpoints (pad row = index N, a far-away point)
-            ref_pad, src_pad = torch.cat([ref_f, pad], 0), torch.cat([src_f, pad], 0)
-            rk, sk = ref_knn_idx[ref_ci], src_knn_idx[src_ci]
-            rkm, skm = ref_knn_masks[ref_ci], src_knn_masks[src_ci]
-            rkp, skp = ref_pad[rk], src_pad[sk]
-            rkf = self.fine_desc(rkp) * rkm[..., None]
-            skf = self.fine_desc(to_ref(skp)) * skm[..., None]
-            scores = torch.einsum('bnd,bmd->bnm', rkf, skf) * (rkf.shape[-1] ** 0.5)
-        with self._sec("sinkhorn"):
-            matching = self.ot(scores, rkm, skm)[:, :-1, :-1]     # model.py:191-198 (dustbins dropped)
+        with self._sec("patch_features"):                           # model.py:162-170
+            return ref_knn_idx[ref_ci], ref_knn_masks[ref_ci], src_knn_idx[src_ci], src_knn_masks[src_ci], node_scores
+
+    def _estimate(self, b, st3):
+        """model.py:200-220 for pair b, on the current stream: correspondences + LGR, RANSAC with scale, the result row."""
+        pairs, out, rkp, skp, rkm, skm, matching, k_off, node_scores = st3
+        a, e = k_off[b], k_off[b + 1]
+        T_gt = pairs[b][2]
         with self._sec("local_global_registration"):
-            rc, sc, cs, T = self.lgr(rkp, skp, rkm, skm, matching, node_scores)   # model.py:200-207
+            rc, sc, cs, T = self.lgr(rkp[a:e], skp[a:e], rkm[a:e], skm[a:e], matching[a:e], node_scores[b])
             n_corr = rc.shape[0]
         with self._sec("ransac"):
             if self.use_ransac and n_corr >= 3:              # model.py:209-220 (the estimate the reference keeps)
@@ -274,4 +318,4 @@ class PairRegistrar:
             out[b, :16] = T.reshape(-1)
             out[b, 18] = float(n_corr)
             if T_gt is not None and n_corr > 0:
-                out[b, 19] = (torch.linalg.norm(to_ref(sc) - rc, dim=1) < 0.1).float().mean()
+                out[b, 19] = (torch.linalg.norm(sc @ T_gt[:3, :3].T + T_gt[:3, 3] - rc, dim=1) < 0.1).float().mean()
