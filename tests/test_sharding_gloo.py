@@ -30,7 +30,8 @@ def _worker(rank, world, port, n_units, q):
         out = sharding.run_sharded(units, _unit_result)
         a, b = sharding.shard_bounds(n_units, rank, world)
         ragged = sharding.gather_rows(torch.arange(a, b, dtype=torch.float32).reshape(-1, 1))
-        q.put((rank, out, ragged.reshape(-1), (a, b)))
+        # by value (numpy), not as shared-memory tensors: a worker may exit before the parent has read the queue
+        q.put((rank, out.numpy().copy(), ragged.reshape(-1).numpy().copy(), (a, b)))
     finally:
         dist.destroy_process_group()
 
@@ -43,12 +44,12 @@ def _run_world2(n_units):
     for p in procs:
         p.start()
     try:
-        res = [q.get(timeout=120) for _ in range(2)]
+        res = [q.get(timeout=300) for _ in range(2)]
     finally:
         for p in procs:
-            p.join(timeout=60)
-    assert all(p.exitcode == 0 for p in procs)
-    return res
+            p.join(timeout=120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return [(r, torch.from_numpy(o), torch.from_numpy(g), ab) for r, o, g, ab in res]
 
 
 @pytest.mark.parametrize("n_units", [7, 1, 2])
