@@ -96,12 +96,14 @@ __global__ __launch_bounds__(DS_SCAN_NW* WAVE) void ds_scan_kernel(int nchunk, c
   const int c0 = wv * per, c1 = min(nchunk, c0 + per);
   const uint16_t* col = hist + (int64_t)v * nchunk * DS_BINS + d;
   unsigned int sum = 0;
-  for (int c = c0; c < c1; ++c) sum += col[(int64_t)c * DS_BINS];
+#pragma unroll 8
+  for (int c = c0; c < c1; ++c) sum += col[(int64_t)c * DS_BINS];  // (unrolled: eight independent loads in flight)
   s_part[wv][lane] = sum;
   __syncthreads();
   unsigned int run = 0;
   for (int w = 0; w < wv; ++w) run += s_part[w][lane];
   uint32_t* ocol = offs + (int64_t)v * nchunk * DS_BINS + d;
+#pragma unroll 8
   for (int c = c0; c < c1; ++c) {
     const unsigned int n = col[(int64_t)c * DS_BINS];
     ocol[(int64_t)c * DS_BINS] = run;
