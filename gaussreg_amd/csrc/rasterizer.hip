@@ -540,13 +540,20 @@ __global__ __launch_bounds__(BIN_T) void tile_count_kernel(int P, int V, int gx,
   const int64_t vbase = (int64_t)v * P;
   const int nv = nvis[v];
   int mine = 0;
+  // all of a thread's rectangles are requested before the first one is used: one memory round trip instead of eight
+  uint32_t rr[BIN_CHUNK / BIN_T];
+#pragma unroll
   for (int it = 0; it < BIN_CHUNK / BIN_T; ++it) {
     const int t = c * BIN_CHUNK + it * BIN_T + threadIdx.x;
-    if (t >= nv) break;
-    const uint32_t r = rects[vbase + t];
+    rr[it] = t < nv ? rects[vbase + t] : 0u;
+  }
+#pragma unroll
+  for (int it = 0; it < BIN_CHUNK / BIN_T; ++it) {
+    const int t = c * BIN_CHUNK + it * BIN_T + threadIdx.x;
+    const uint32_t r = rr[it];
     if (r == 0u) continue;
     int x0, y0, w, h;
-    if (!rect_decode(r, ids[vbase + t], vbase, rec, gx, gy, x0, y0, w, h)) continue;
+    if (!rect_decode(r, r == RECT_MARKER26 ? ids[vbase + t] : 0, vbase, rec, gx, gy, x0, y0, w, h)) continue;
     mine += w * h;
     for (int y = y0; y < y0 + h; ++y)
       for (int x = x0; x < x0 + w; ++x) atomicAdd(&s_hist[y * gx + x], 1u);
@@ -635,11 +642,22 @@ __global__ __launch_bounds__(BIN_T) void tile_scatter_kernel(int P, int V, int g
   __syncthreads();
   const int64_t vbase = (int64_t)v * P;
   const int w_begin = c * BIN_CHUNK + wv * CW, w_end = min(nvis[v], w_begin + CW);
+  // the wave's rectangles and ids, requested up front: both walks below run out of registers (one memory round trip
+  // instead of one per 64-Gaussian step and walk)
+  uint32_t rr[CW / WAVE];
+  int32_t ii[CW / WAVE];
+#pragma unroll
+  for (int j = 0; j < CW / WAVE; ++j) {
+    const int t = w_begin + j * WAVE + lane;
+    rr[j] = t < w_end ? rects[vbase + t] : 0u;
+    ii[j] = t < w_end ? ids[vbase + t] : 0;
+  }
   // ---- phase A: this wave's tile counts
-  for (int t = w_begin + lane; t < w_end; t += WAVE) {
-    const uint32_t r = rects[vbase + t];
+#pragma unroll
+  for (int j = 0; j < CW / WAVE; ++j) {
+    const uint32_t r = rr[j];
     int x0, y0, w, h;
-    if (r != 0u && rect_decode(r, ids[vbase + t], vbase, rec, gx, gy, x0, y0, w, h))
+    if (r != 0u && rect_decode(r, ii[j], vbase, rec, gx, gy, x0, y0, w, h))
       for (int y = y0; y < y0 + h; ++y)
         for (int x = x0; x < x0 + w; ++x) atomicAdd(&my[y * gx + x], 1u);
   }
@@ -662,16 +680,19 @@ __global__ __launch_bounds__(BIN_T) void tile_scatter_kernel(int P, int V, int g
     else point_list[pos] = val;
   };
   const unsigned long long lt = (1ull << lane) - 1ull;
+  // (rolled: the body is large; the preloaded values move down one register per step instead of being indexed)
+#pragma unroll 1
   for (int t0 = w_begin; t0 < w_end; t0 += WAVE) {
     const int t = t0 + lane;
-    int x0 = 0, y0 = 0, w = 0, h = 0, id = 0;
-    if (t < w_end) {
-      const uint32_t r = rects[vbase + t];
-      if (r != 0u) {
-        id = ids[vbase + t];
-        if (!rect_decode(r, id, vbase, rec, gx, gy, x0, y0, w, h)) w = h = 0;
-      }
+    int x0 = 0, y0 = 0, w = 0, h = 0;
+    const int id = ii[0];
+    const uint32_t r_now = rr[0];
+#pragma unroll
+    for (int k = 0; k + 1 < CW / WAVE; ++k) {
+      rr[k] = rr[k + 1];
+      ii[k] = ii[k + 1];
     }
+    if (r_now != 0u && !rect_decode(r_now, id, vbase, rec, gx, gy, x0, y0, w, h)) w = h = 0;
     unsigned long long live = __ballot(w * h != 0);
     if (live == 0ull) continue;
     const int maxd = wave_max_i32_dpp(max(w, h));
