@@ -65,18 +65,26 @@ __global__ __launch_bounds__(DS_T) void ds_count_kernel(int P, int V, int nchunk
   __syncthreads();
   const int n = FIRST ? P : nvalid[v];
   const int64_t vbase = (int64_t)v * P;
+  // all loads first, on clamped indices and without branches (the compiler keeps a conditional load behind the LDS atomic
+  // of the previous step: eight memory round trips per workgroup instead of one), then the histogram
+  uint32_t dg[DS_STEPS];
+  bool have[DS_STEPS];
 #pragma unroll
   for (int it = 0; it < DS_STEPS; ++it) {
     const int t = c * DS_CHUNK + it * DS_T + threadIdx.x;
-    if (t < n) {
-      if (FIRST) {
-        const uint32_t f = field[vbase + t];
-        if (f != 0u) atomicAdd(&s_h[f & dmask], 1u);
-      } else {
-        atomicAdd(&s_h[(uint32_t)(keys[vbase + t] >> word_shift) & dmask], 1u);
-      }
+    const int tc = max(min(t, n - 1), 0);
+    if (FIRST) {
+      const uint32_t f = field[vbase + tc];
+      have[it] = t < n && f != 0u;
+      dg[it] = f & dmask;
+    } else {
+      have[it] = t < n;
+      dg[it] = (uint32_t)(keys[vbase + tc] >> word_shift) & dmask;
     }
   }
+#pragma unroll
+  for (int it = 0; it < DS_STEPS; ++it)
+    if (have[it]) atomicAdd(&s_h[dg[it]], 1u);
   __syncthreads();
   uint16_t* dst = hist + ((int64_t)v * nchunk + c) * DS_BINS;
   for (int d = threadIdx.x; d < DS_BINS; d += DS_T) dst[d] = (uint16_t)s_h[d];  // <= DS_CHUNK
@@ -159,27 +167,39 @@ __global__ __launch_bounds__(DS_T) void ds_scatter_kernel(int P, int V, int nchu
   unsigned short digit[DS_STEPS];
   int rank[DS_STEPS];  // -1: no entry
   const unsigned long long lt = (1ull << lane) - 1ull;
+  // all loads first, on clamped indices and without branches (see ds_count_kernel), then the ranking
+  bool present[DS_STEPS];
+  uint32_t fv[FIRST ? DS_STEPS : 1], rv[FIRST ? DS_STEPS : 1];
+  if (FIRST) {
+#pragma unroll
+    for (int j = 0; j < DS_STEPS; ++j) {
+      const int64_t o = vbase + min(wbase + j * WAVE + lane, n - 1);
+      fv[j] = field[o];
+      rv[j] = rect_raw[o];  // unconditional (a branch here would serialise the loads again)
+    }
+  }
 #pragma unroll
   for (int j = 0; j < DS_STEPS; ++j) {
     const int t = wbase + j * WAVE + lane;
-    key[j] = 0ull;
-    rank[j] = -1;
-    bool have = false;
-    uint32_t d = 0u;
-    if (t < n) {
-      if (FIRST) {
-        const uint32_t f = field[vbase + t];
-        have = f != 0u;
-        d = f & dmask;
-        key[j] = id_bits > 0 ? ((uint64_t)(f >> DS_BITS) << (id_bits + 26)) | ((uint64_t)(uint32_t)t << 26) | rect_raw[vbase + t]
-                             : ((uint64_t)f << 32) | (uint32_t)t;
-      } else {
-        key[j] = keys_in[vbase + t];
-        have = true;
-        d = (uint32_t)(key[j] >> word_shift) & dmask;
-      }
+    const int tc = min(t, n - 1);  // n > c * DS_CHUNK >= 0 here
+    if (FIRST) {
+      const uint32_t f = fv[j];
+      const uint32_t rct = rv[j];
+      present[j] = t < n && f != 0u;
+      digit[j] = (unsigned short)(f & dmask);
+      key[j] = id_bits > 0 ? ((uint64_t)(f >> DS_BITS) << (id_bits + 26)) | ((uint64_t)(uint32_t)t << 26) | rct
+                           : ((uint64_t)f << 32) | (uint32_t)t;
+    } else {
+      key[j] = keys_in[vbase + tc];
+      present[j] = t < n;
+      digit[j] = (unsigned short)((uint32_t)(key[j] >> word_shift) & dmask);
     }
-    digit[j] = (unsigned short)d;
+  }
+#pragma unroll
+  for (int j = 0; j < DS_STEPS; ++j) {
+    rank[j] = -1;
+    const bool have = present[j];
+    const uint32_t d = digit[j];
     if (LANE_ORDERED) {
       if (have) rank[j] = (int)atomicAdd(&s_cnt[wv][d], 1u);
     } else {
