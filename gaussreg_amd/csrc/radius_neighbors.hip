@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int NBAND = 9;
 constexpr int NSUB = 3;  // threads per query (one per z-slab)
-constexpr int GB = 4;    // hit loads in flight per thread in the FILL gather
+constexpr int GB = 8;    // hit loads in flight per thread in the FILL gather
 
 template <int RQ>
 struct TravLds {
@@ -602,10 +602,11 @@ __global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))
             pos[u] = bpos < len0 ? p0[0] + bpos : (bpos < len0 + len1 ? p0[1] + (bpos - len0) : p0[2] + (bpos - len0 - len1));
           }
         }
+        // unconditional loads (a spent slot re-reads support 0): behind a branch the compiler waits for every load before
+        // it issues the next one, and the point of this loop is GB random reads in flight
         float4 sp[GB];
 #pragma unroll
-        for (int u = 0; u < GB; ++u)
-          if (pos[u] >= 0) sp[u] = sorted_s[pos[u]];
+        for (int u = 0; u < GB; ++u) sp[u] = sorted_s[max(pos[u], 0)];
 #pragma unroll
         for (int u = 0; u < GB; ++u)
           if (pos[u] >= 0) emit(sp[u]);
