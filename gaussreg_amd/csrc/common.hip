@@ -69,6 +69,7 @@ void* pinned_scratch(int slot, size_t bytes) {
 constexpr int SCAN_T = 256;
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = SCAN_T * SCAN_ITEMS;  // 2048 elements per block
+static_assert(SCAN_TILE == SCAN_SINGLE_ROW, "common.hpp promises single-launch scans up to this row length");
 
 __device__ inline int wave_incl_scan(int v, int lane) {
   (void)lane;
@@ -99,7 +100,11 @@ __global__ __launch_bounds__(SCAN_T) void scan_tiles_kernel(const int32_t* __res
                                                             int32_t* __restrict__ out, int64_t n,
                                                             int64_t row_stride,
                                                             int32_t* __restrict__ partial,
-                                                            int tiles, const int32_t* __restrict__ last_dev) {
+                                                            int tiles, const int32_t* __restrict__ last_dev,
+                                                            int32_t* __restrict__ total_single,
+                                                            int32_t* __restrict__ row_max) {
+  // total_single / row_max: single-tile rows only (tiles == 1) -- the row's total and its largest element are written
+  // here and the other two phases are not launched
   const int row = blockIdx.y;
   const int64_t tile0 = (int64_t)blockIdx.x * SCAN_TILE;
   if (last_dev) {  // only entries 0..*last_dev are wanted (the array is sized for a worst case)
@@ -112,12 +117,25 @@ __global__ __launch_bounds__(SCAN_T) void scan_tiles_kernel(const int32_t* __res
   const int32_t* src = in + row * row_stride;
   int32_t* dst = out + row * row_stride;
   int v[SCAN_ITEMS];
-  int sum = 0;
+  int sum = 0, mx = INT32_MIN;
   const int64_t base = tile0 + (int64_t)threadIdx.x * SCAN_ITEMS;
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; ++k) {
     v[k] = (base + k < n) ? src[base + k] : 0;
     sum += v[k];
+    if (base + k < n) mx = max(mx, v[k]);
+  }
+  if (row_max) {
+    __shared__ int s_mx[SCAN_T / WAVE];
+    const int wm = wave_max_i32_dpp(mx);
+    if ((threadIdx.x & (WAVE - 1)) == 0) s_mx[threadIdx.x / WAVE] = wm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int m = s_mx[0];
+#pragma unroll
+      for (int i = 1; i < SCAN_T / WAVE; ++i) m = max(m, s_mx[i]);
+      row_max[row] = m;
+    }
   }
   int tot;
   int ex = block_excl_scan(sum, &tot);
@@ -126,7 +144,10 @@ __global__ __launch_bounds__(SCAN_T) void scan_tiles_kernel(const int32_t* __res
     if (base + k < n) dst[base + k] = ex;
     ex += v[k];
   }
-  if (threadIdx.x == 0) partial[(int64_t)row * tiles + blockIdx.x] = tot;
+  if (threadIdx.x == 0) {
+    partial[(int64_t)row * tiles + blockIdx.x] = tot;
+    if (total_single) total_single[row] = tot;
+  }
 }
 
 // phase 2: one block per row scans the tile sums in place (exclusive), writes row total
@@ -263,11 +284,18 @@ int compute_bbox(const float* pts, const int32_t* h_off, int32_t* blk, const int
 size_t scan_ws_ints(int64_t n) { return (size_t)((n + SCAN_TILE - 1) / SCAN_TILE) + 1; }
 
 int exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int rows, int64_t row_stride,
-                       int32_t* scan_ws, int32_t* total, hipStream_t stream, const int32_t* last_dev) {
+                       int32_t* scan_ws, int32_t* total, hipStream_t stream, const int32_t* last_dev, int32_t* row_max) {
   if (n <= 0 || rows <= 0) return GR_OK;
   const int tiles = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
+  GR_REQUIRE(row_max == nullptr || tiles == 1, "exclusive_scan_i32: row maxima need rows of at most %d elements", SCAN_TILE);
+  if (tiles == 1) {  // one workgroup per row does everything: one launch instead of two
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1, rows), dim3(SCAN_T), 0, stream, in, out, n, row_stride, scan_ws, 1,
+                       last_dev, total, row_max);
+    GR_LAUNCH_CHECK();
+    return GR_OK;
+  }
   hipLaunchKernelGGL(scan_tiles_kernel, dim3(tiles, rows), dim3(SCAN_T), 0, stream, in, out, n,
-                     row_stride, scan_ws, tiles, last_dev);
+                     row_stride, scan_ws, tiles, last_dev, (int32_t*)nullptr, (int32_t*)nullptr);
   hipLaunchKernelGGL(scan_partials_kernel, dim3(rows), dim3(SCAN_T), 0, stream, scan_ws, tiles,
                      total);
   if (tiles > 1)

@@ -78,8 +78,11 @@ size_t scan_ws_ints(int64_t n);
 // in/out may alias.  out[i] = sum_{j<i} in[j]; total[r] (optional, device) = row sum.
 // last_dev (optional, device): only out[0..*last_dev] is needed -- tiles past it are skipped (arrays sized for a
 // worst case whose real extent is only known on the device).
+// Rows of at most SCAN_SINGLE_ROW elements take one launch; for those, row_max[r] (optional, device) = largest element.
+constexpr int SCAN_SINGLE_ROW = 2048;
 int exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int rows, int64_t row_stride,
-                       int32_t* scan_ws, int32_t* total, hipStream_t stream, const int32_t* last_dev = nullptr);
+                       int32_t* scan_ws, int32_t* total, hipStream_t stream, const int32_t* last_dev = nullptr,
+                       int32_t* row_max = nullptr);
 
 // Pinned host scratch, one buffer per (host thread, slot), grown on demand and kept for the life of the process.  A copy
 // to or from pageable memory is staged and synchronised by the runtime; through these buffers the small uploads and

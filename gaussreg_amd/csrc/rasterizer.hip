@@ -197,7 +197,7 @@ struct Geom {
   void* ds_table;        // depth-sort histograms / offsets
   size_t ds_table_bytes;
   int32_t* nvis;         // [V] visible (depth-ordered) Gaussians per view
-  int32_t* totals;       // [V] then [V] = depth-overflow flag
+  int32_t* totals;       // [V] instances per view, [1] depth-overflow flag, [V] largest chunk total of every view
   DevView* views;        // [MAX_VIEWS] camera table (uniform loads)
   int32_t* scan_ws;
   size_t bytes;
@@ -225,7 +225,7 @@ Geom carve_geom(void* p, int64_t P, int V, int64_t tiles) {
   g.ds_table_bytes = depth_sort_table_bytes(P, V);
   g.ds_table = c.take<char>(g.ds_table_bytes);
   g.nvis = c.take<int32_t>(V);
-  g.totals = c.take<int32_t>(V + 1);
+  g.totals = c.take<int32_t>(2 * V + 1);
   g.views = c.take<DevView>(MAX_VIEWS);
   g.scan_ws = c.take<int32_t>(V * scan_ws_ints(nchunk));
   g.bytes = c.used();
@@ -1194,7 +1194,7 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
   GR_HIP(hipMemsetAsync(g.totals + num_views, 0, sizeof(int32_t), stream));  // depth-overflow flag
   run_preprocess();
   GR_LAUNCH_CHECK();
-  int32_t* tot = static_cast<int32_t*>(pinned_scratch(1, sizeof(int32_t) * (num_views + 2)));  // totals, far flag, chunk max
+  int32_t* tot = static_cast<int32_t*>(pinned_scratch(1, sizeof(int32_t) * (2 * num_views + 2)));  // totals, far flag, chunk maxima
   GR_REQUIRE(tot != nullptr, "pinned read-back buffer could not be allocated");
   const int nchunk = (int)((P + BIN_CHUNK - 1) / BIN_CHUNK);
   int32_t h_chunk_max = 0;
@@ -1214,20 +1214,30 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
       hipLaunchKernelGGL(tile_count_kernel, dim3((unsigned)bin_grid(num_views, nchunk)), dim3(BIN_T),
                          tiles * sizeof(unsigned int), stream, (int)P, num_views, gx, gy, nchunk, g.nvis, g.rects, g.order_b,
                          g.rec, g.chunk_cnt, g.chunk_total);
-      hipLaunchKernelGGL(chunk_max_kernel, dim3(1), dim3(1024), 0, stream, num_views * nchunk, g.chunk_total, g.chunk_max);
+      // chunk bases inside each view (+ the per-view totals R_v and the largest chunk total, which sizes the scatter's
+      // staging block), then every chunk's per-tile segment starts
+      const bool short_rows = nchunk <= SCAN_SINGLE_ROW;  // one launch does scan, totals and maxima
+      if (!short_rows)
+        hipLaunchKernelGGL(chunk_max_kernel, dim3(1), dim3(1024), 0, stream, num_views * nchunk, g.chunk_total, g.chunk_max);
       GR_LAUNCH_CHECK();
-      // chunk bases inside each view (+ the per-view totals R_v), then every chunk's per-tile segment starts
       int rcs = exclusive_scan_i32(g.chunk_total, g.chunk_total + (int64_t)num_views * nchunk, nchunk, num_views, nchunk,
-                                   g.scan_ws, g.totals, stream);
+                                   g.scan_ws, g.totals, stream, nullptr, short_rows ? g.totals + num_views + 1 : nullptr);
       if (rcs != GR_OK) return rcs;
       hipLaunchKernelGGL(seg_scan_kernel, dim3((unsigned)(num_views * nchunk)), blk, 0, stream, num_views, tiles, nchunk,
                          g.chunk_cnt, g.chunk_total + (int64_t)num_views * nchunk, g.totals, g.seg_off);
       GR_LAUNCH_CHECK();
     }
-    GR_HIP(hipMemcpyAsync(tot, g.totals, sizeof(int32_t) * (num_views + 1), hipMemcpyDeviceToHost, stream));
-    GR_HIP(hipMemcpyAsync(tot + num_views + 1, g.chunk_max, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    const bool short_rows = nchunk <= SCAN_SINGLE_ROW;
+    if (short_rows) {
+      GR_HIP(hipMemcpyAsync(tot, g.totals, sizeof(int32_t) * (2 * num_views + 1), hipMemcpyDeviceToHost, stream));
+    } else {
+      GR_HIP(hipMemcpyAsync(tot, g.totals, sizeof(int32_t) * (num_views + 1), hipMemcpyDeviceToHost, stream));
+      GR_HIP(hipMemcpyAsync(tot + num_views + 1, g.chunk_max, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    }
     GR_HIP(hipStreamSynchronize(stream));
     h_chunk_max = tot[num_views + 1];
+    if (short_rows)
+      for (int v = 1; v < num_views; ++v) h_chunk_max = std::max(h_chunk_max, tot[num_views + 1 + v]);
     return GR_OK;
   };
   rc = sort_and_count(KEY_DEPTH_BITS);
