@@ -101,7 +101,7 @@ int gr_host_unordered_map_order(const uint64_t* h_keys, int64_t n, int32_t* h_pe
 /* Test hooks for the row order: gr_host_unordered_map_order replays libstdc++'s container on the host;
  * gr_hash_order_device evaluates the same order on the device for `batch` clouds at once (d_keys: distinct keys per cloud
  * in insertion order, clouds contiguous; h_begins: batch + 1 HOST offsets; d_perm[begin_c + j] = global index of the j-th
- * key the container would iterate). */
+ * key the container would iterate).  gr_hash_order_device is asynchronous: d_perm is complete in `stream` order. */
 size_t gr_hash_order_device_workspace_bytes(int64_t n, int64_t batch);
 int gr_hash_order_device(const uint64_t* d_keys, const int64_t* h_begins, int64_t batch, int32_t* d_perm, void* ws,
                          size_t ws_bytes, void* stream);
