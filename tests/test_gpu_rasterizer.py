@@ -215,3 +215,21 @@ def test_fuzz_extreme_gaussians_bit_exact():
             assert np.array_equal(radii[v].cpu().numpy(), wr), (it, v)
             assert nr[v] <= wR
             _assert_bit_equal(imgs[v].cpu().numpy(), want, f"fuzz scene {it} view {v} ({P} Gaussians, {W}x{H})")
+
+
+def test_ragged_sizes_bit_exact():
+    """Gaussian counts around the wave / workgroup / chunk boundaries (1, 63 .. 65, 255 .. 257, 2047 .. 2049) with 1-9 views:
+    the preprocess writes records wave-cooperatively, the depth sort packs ids into its words, the binning preloads
+    whole 512-Gaussian wave slices -- none of it may depend on full waves, workgroups or chunks."""
+    from gaussreg_amd.rasterizer import rasterize_views
+    rng = np.random.default_rng(4242)
+    for it, P in enumerate([1, 3, 63, 64, 65, 255, 257, 2047, 2049]):
+        W, H, V = int(rng.integers(16, 120)), int(rng.integers(16, 90)), int(rng.integers(1, 10))
+        g, cams = raster_scene(P, W, H, seed=1000 + it, V=V)
+        d = _cu(g)
+        imgs, radii, nr = rasterize_views([_settings(c) for c in cams], d["means3D"], d["opacities"], shs=d["shs"],
+                                          scales=d["scales"], rotations=d["rotations"])
+        for v in range(V):
+            want, wr, _ = oracle_render(g, cams[v])
+            assert np.array_equal(radii[v].cpu().numpy(), wr), (P, v)
+            _assert_bit_equal(imgs[v].cpu().numpy(), want, f"{P} Gaussians, view {v} of {V}, {W}x{H}")
