@@ -315,8 +315,8 @@ __global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))
     const float4* __restrict__ sorted_q, int nq, const int32_t* __restrict__ q_off, int nb,
     const BatchGrid* __restrict__ grids, const int32_t* __restrict__ start_s,
     const float4* __restrict__ sorted_s, float r2, int32_t* __restrict__ q_cnt, int2* __restrict__ q_rng,
-    unsigned long long* __restrict__ q_mask, int32_t* __restrict__ blk_stats, int width, int64_t pad_value, int64_t* __restrict__ out,
-    int max_block_hits, unsigned long long* __restrict__ g_hits, unsigned char* __restrict__ g_rows, int mono) {
+    unsigned long long* __restrict__ q_mask, int32_t* __restrict__ blk_stats, int width, int row_stride, int64_t pad_value,
+    int64_t* __restrict__ out, int max_block_hits, unsigned long long* __restrict__ g_hits, unsigned char* __restrict__ g_rows, int mono) {
   using L = TravLds<RQ>;
   static_assert(RQ % WAVE == 0 && RQ <= 256, "row ids are bytes; waves must not straddle slabs");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -666,15 +666,419 @@ __global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))
       const ulonglong2 h = seg[jj];
       rank += (h.x < key ? 1 : 0) + (h.y < key ? 1 : 0);
     }
-    if (rank < width) out[(int64_t)orig[r] * width + rank] = (int64_t)(unsigned int)(key & 0xffffffffull);
+    if (rank < width) out[(int64_t)orig[r] * row_stride + rank] = (int64_t)(unsigned int)(key & 0xffffffffull);
   }
   // ---- padding: one row per wave iteration, lanes along the row
   const int rows_here = min(RQ, nq - blk * RQ);
   for (int r = tid / 32; r < rows_here; r += L::THREADS / 32) {  // half a wave per row
     int cnt = offs[r + 1] - offs[r];
     if (cnt > 0 && rows[offs[r + 1] - 1] == 0xff) --cnt;  // the segment ends in a pad slot
-    int64_t* row = out + (int64_t)orig[r] * width;
-    for (int c = cnt + (lane & 31); c < width; c += 32) row[c] = pad_value;
+    int64_t* row = out + (int64_t)orig[r] * row_stride;
+    for (int c = min(cnt, width) + (lane & 31); c < row_stride; c += 32) row[c] = pad_value;
+  }
+}
+
+// ---------------------------------------------------------------- single pass for a width known before the launch
+// radius_search(..., neighbor_limit) (modules/ops/radius_search.py:7-27) keeps min(max_count, neighbor_limit) columns, so the
+// caller can allocate (nq, limit) rows BEFORE anything is counted and one kernel does the whole search: set-up, staging
+// and candidate tests as in the COUNT pass above (hit masks stay in registers), a block scan of the hit counts, the hits
+// re-read from the staged candidates (LDS, not a second trip to memory) into per-query key segments, ranking by counting
+// and the row stores.  Nothing per query goes through global memory in between (the two-pass path writes and re-reads
+// 180 bytes of ranges / masks / counts per query) and the host does not sit between two launches.
+//   blk_stats[2 blk]     = largest hit count of a query in the block   (max -> the width the reference would return)
+//   blk_stats[2 blk + 1] = 1 if a single query had more hits than the block's key area holds (the caller then repeats
+//                          the search on the two-pass path; never seen below ~3 500 neighbours per query)
+// A block whose hits do not fit its key area at once works through its queries in groups.
+template <int RQ>
+struct FusedLds {
+  static constexpr int THREADS = NSUB * RQ;
+  static constexpr int STAGE_CAP = 12 * RQ;
+  static constexpr int TABLE_MAX = 256;
+  // ints: offs[RQ+1], orig[RQ], qtot[RQ], wsum[2 * THREADS/64], sub[3*RQ], band_lo[9], band_hi[9], band_base[10], misc[4]
+  static constexpr int N_INTS = (RQ + 1) + RQ + RQ + 2 * (THREADS / WAVE) + NSUB * RQ + 9 + 9 + 10 + 4;
+  static constexpr size_t STAGE_OFF = (size_t)(N_INTS * 4 + 15) / 16 * 16;
+  static size_t region_bytes(int width) {  // candidate planes x, y, z, index; the row buffer takes their place later
+    const size_t st = (size_t)STAGE_CAP * 16, rb = ((size_t)RQ * width * 4 + 15) / 16 * 16;
+    return st > rb ? st : rb;
+  }
+  static size_t tables_bytes(int tcap) { return tcap > 0 ? ((size_t)(tcap + 1) * 4 + 15) / 16 * 16 + (size_t)tcap * sizeof(BatchGrid) : 0; }
+  static size_t total(int width, int cap, int tcap) {
+    const size_t hits = (size_t)cap * 9, tb = tables_bytes(tcap);
+    return STAGE_OFF + region_bytes(width) + (hits > tb ? hits : tb);
+  }
+};
+
+template <int RQ, bool ROWBUF>
+__global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
+    const float4* __restrict__ sorted_q, int nq, const int32_t* __restrict__ q_off, int nb,
+    const BatchGrid* __restrict__ grids, const int32_t* __restrict__ start_s, const float4* __restrict__ sorted_s, float r2,
+    int32_t* __restrict__ blk_stats, int width, int64_t pad_value, int64_t* __restrict__ out, int cap, int region_bytes,
+    int mono) {
+  using L = FusedLds<RQ>;
+  static_assert(RQ % WAVE == 0 && RQ <= 256, "row ids are bytes; waves must not straddle slabs");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* offs = reinterpret_cast<int*>(smem);
+  int* orig = offs + (RQ + 1);
+  int* qtot = orig + RQ;
+  int* wsum = qtot + RQ;
+  int* sub = wsum + 2 * (L::THREADS / WAVE);  // [NSUB][RQ]
+  int* band_lo = sub + NSUB * RQ;
+  int* band_hi = band_lo + NBAND;
+  int* band_base = band_hi + NBAND;
+  int* misc = band_base + NBAND + 1;
+  float* sx = reinterpret_cast<float*>(smem + L::STAGE_OFF);
+  float* sy = sx + L::STAGE_CAP;
+  float* sz = sy + L::STAGE_CAP;
+  int* si = reinterpret_cast<int*>(sz + L::STAGE_CAP);
+  unsigned int* rowbuf = reinterpret_cast<unsigned int*>(smem + L::STAGE_OFF);  // takes the planes' place after the emission
+  char* hreg = smem + L::STAGE_OFF + region_bytes;
+  unsigned long long* hits = reinterpret_cast<unsigned long long*>(hreg);
+  unsigned char* rows = reinterpret_cast<unsigned char*>(hreg + (size_t)cap * 8);
+  // per-cloud tables for the set-up live where the keys go later
+  const int tcap = nb <= L::TABLE_MAX ? nb : 0;
+  int* s_qoff = reinterpret_cast<int*>(hreg);
+  BatchGrid* s_grids = reinterpret_cast<BatchGrid*>(hreg + ((size_t)(tcap + 1) * 4 + 15) / 16 * 16);
+
+  const int tid = threadIdx.x;
+  const int slot = tid % RQ, j = tid / RQ;
+  const int nblk = (nq + RQ - 1) / RQ;
+  const int per_xcd = gridDim.x / 8;
+  const int blk = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;  // one contiguous eighth of the cell-ordered queries per XCD
+  if (blk >= nblk) return;
+  const int t = blk * RQ + slot;
+  const int lane = tid & (WAVE - 1);
+  const bool valid = t < nq;
+
+  if (tid < NBAND) {
+    band_lo[tid] = 0x7fffffff;
+    band_hi[tid] = 0;
+  }
+  const bool tables_in_lds = tcap > 0;
+  if (tables_in_lds) {
+    for (int i = tid; i <= nb; i += L::THREADS) s_qoff[i] = q_off[i];
+    const int4* gsrc = reinterpret_cast<const int4*>(grids);
+    int4* gdst = reinterpret_cast<int4*>(s_grids);
+    for (int i = tid; i < nb * 4; i += L::THREADS) gdst[i] = gsrc[i];
+  }
+  float4 qp = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid) qp = sorted_q[t];
+  __syncthreads();
+  int p0[3] = {0, 0, 0}, p1[3] = {0, 0, 0};
+  if (valid) {
+    int b;
+    BatchGrid g;
+    if (tables_in_lds) {
+      b = find_batch(s_qoff, nb, __float_as_int(qp.w));
+      g = s_grids[b];
+    } else {
+      b = find_batch(q_off, nb, __float_as_int(qp.w));
+      g = grids[b];
+    }
+    const double ux = cell_coord(qp.x, g.org[0], g.inv_cell_x), kx = (double)g.xk;
+    const double uy = cell_coord(qp.y, g.org[1], g.inv_cell);
+    const double cz = cell_coord(qp.z, g.org[2], g.inv_cell) + (double)(j - 1);
+    const double tx = (double)(g.dim[0] - 1), ty = (double)(g.dim[1] - 1), tz = (double)(g.dim[2] - 1);
+    if ((ux + kx >= 0.0) && (ux - kx <= tx) && cz >= 0.0 && cz <= tz) {  // NaN coordinates: no candidates
+      const int lx = (int)fmin(fmax(ux - kx, 0.0), tx);
+      const int hx = (int)fmin(fmax(ux + kx, 0.0), tx);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double cy = uy + (double)(i - 1);
+        if (cy >= 0.0 && cy <= ty) {
+          const int base = g.cell_base + g.dim[0] * ((int)cy + g.dim[1] * (int)cz);
+          p0[i] = start_s[base + lx];
+          p1[i] = start_s[base + hx + 1];
+        }
+      }
+    }
+    if (j == 0) orig[slot] = __float_as_int(qp.w);
+  } else if (j == 0) {
+    orig[slot] = -1;
+  }
+  // ---- block-wide extent of every band (waves are slab-uniform: band index = 3*j + i)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const bool has = p1[i] > p0[i];
+    int lo, hi;
+    if (mono) {
+      const unsigned long long m = __ballot(has);
+      lo = 0x7fffffff;
+      hi = 0;
+      if (m) {
+        lo = __builtin_amdgcn_readlane(p0[i], __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1));
+        hi = __builtin_amdgcn_readlane(p1[i], __builtin_amdgcn_readfirstlane(63 - __clzll((long long)m)));
+      }
+    } else {
+      lo = wave_min_i32_dpp(has ? p0[i] : 0x7fffffff);
+      hi = wave_max_i32_dpp(has ? p1[i] : 0);
+    }
+    if (lane == 0 && hi > 0) {
+      atomicMin(&band_lo[3 * j + i], lo);
+      atomicMax(&band_hi[3 * j + i], hi);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int k = 0; k < NBAND; ++k) {
+      band_base[k] = acc;
+      acc += band_hi[k] > band_lo[k] ? band_hi[k] - band_lo[k] : 0;
+    }
+    band_base[NBAND] = acc;
+  }
+  __syncthreads();
+  const bool staged = band_base[NBAND] <= L::STAGE_CAP;
+  if (staged) {
+    const int total = band_base[NBAND];
+    int bl[NBAND], bs[NBAND];
+#pragma unroll
+    for (int k = 0; k < NBAND; ++k) {
+      bl[k] = band_lo[k];
+      bs[k] = band_base[k];
+    }
+    constexpr int PER = L::STAGE_CAP / L::THREADS;
+    float4 v[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int f = tid + u * L::THREADS;
+      if (f < total) {
+        int src = bl[0] + f;
+#pragma unroll
+        for (int k = 1; k < NBAND; ++k) src = f >= bs[k] ? bl[k] + (f - bs[k]) : src;
+        v[u] = sorted_s[src];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int f = tid + u * L::THREADS;
+      if (f < total) {
+        sx[f] = v[u].x;
+        sy[f] = v[u].y;
+        sz[f] = v[u].z;
+        si[f] = __float_as_int(v[u].w);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- test every candidate; hits are remembered as a bit mask in enumeration order (band 0, 1, 2)
+  unsigned long long mask = 0ull;
+  int n = 0;
+  int rel[3] = {0, 0, 0};
+  if (staged) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rel[i] = band_base[3 * j + i] - band_lo[3 * j + i];
+  }
+  if (valid && staged) {
+    int bitpos = 0;
+    const f32x2 qx = {qp.x, qp.x}, qy = {qp.y, qp.y}, qz = {qp.z, qp.z};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      int p = p0[i] + rel[i];
+      const int e = p1[i] + rel[i];
+      for (; p + 4 <= e; p += 4) {
+        const f32x2 xa = {sx[p], sx[p + 1]}, xb = {sx[p + 2], sx[p + 3]};
+        const f32x2 ya = {sy[p], sy[p + 1]}, yb = {sy[p + 2], sy[p + 3]};
+        const f32x2 za = {sz[p], sz[p + 1]}, zb = {sz[p + 2], sz[p + 3]};
+        // nanoflann.hpp:432-440: result += diff*diff for x, y, z starting from 0 (two lanes per op)
+        const f32x2 dxa = qx - xa, dya = qy - ya, dza = qz - za;
+        const f32x2 dxb = qx - xb, dyb = qy - yb, dzb = qz - zb;
+        const f32x2 da = (dxa * dxa + dya * dya) + dza * dza;
+        const f32x2 db = (dxb * dxb + dyb * dyb) + dzb * dzb;
+        const unsigned hb = (da.x < r2 ? 1u : 0u) | (da.y < r2 ? 2u : 0u) | (db.x < r2 ? 4u : 0u) | (db.y < r2 ? 8u : 0u);
+        if (bitpos < 64) mask |= (unsigned long long)hb << bitpos;
+        n += __popc(hb);
+        bitpos += 4;
+      }
+      for (; p < e; ++p) {
+        const float dx = qp.x - sx[p], dy = qp.y - sy[p], dz = qp.z - sz[p];
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        const bool hit = d < r2;
+        if (hit && bitpos < 64) mask |= 1ull << bitpos;
+        n += hit ? 1 : 0;
+        ++bitpos;
+      }
+    }
+  } else if (valid) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      for (int p = p0[i]; p < p1[i]; ++p) {
+        const float4 sp = sorted_s[p];
+        const float dx = qp.x - sp.x, dy = qp.y - sp.y, dz = qp.z - sp.z;
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        n += d < r2 ? 1 : 0;
+      }
+  }
+  sub[tid] = n;
+  __syncthreads();
+  // ---- block scan of the per-query totals; every slab group does it redundantly (no cross-group sync)
+  int c[NSUB];
+#pragma unroll
+  for (int i = 0; i < NSUB; ++i) c[i] = sub[i * RQ + slot];
+  const int tot = c[0] + c[1] + c[2];
+  const int tot2 = (tot + 1) & ~1;  // segments start on even slots: the rank loop reads two keys per ds_read_b128
+  const int inc = wave_incl_scan_add_dpp(tot2);
+  const int wmx = wave_max_i32_dpp(tot);
+  if (lane == WAVE - 1) wsum[tid / WAVE] = inc;
+  if (lane == 0) wsum[L::THREADS / WAVE + tid / WAVE] = wmx;
+  __syncthreads();
+  int base = 0, total2 = 0;
+#pragma unroll
+  for (int i = 0; i < RQ / WAVE; ++i) {
+    const int w = wsum[j * (RQ / WAVE) + i];
+    if (i < slot / WAVE) base += w;
+    total2 += w;
+  }
+  const int q_start = base + inc - tot2;
+  const int my_off = q_start + (j > 0 ? c[0] : 0) + (j > 1 ? c[1] : 0);
+  if (j == 0) {
+    offs[slot] = q_start;
+    qtot[slot] = tot;
+    if (slot == RQ - 1) offs[RQ] = q_start + tot2;
+  }
+  int blk_flag = 0;
+  const bool multi = total2 > cap;
+  const bool use_rowbuf = ROWBUF && !multi;
+  const int rows_here = min(RQ, nq - blk * RQ);
+  const int len0 = p1[0] - p0[0], len1 = p1[1] - p0[1], len2 = p1[2] - p0[2];
+  const bool by_mask = staged && (len0 + len1 + len2 <= 64);
+  if (multi) __syncthreads();  // offs complete
+  int glo = 0;
+  while (glo < RQ) {
+    int ghi = RQ;
+    bool skip = false;
+    if (multi) {
+      if (tid == 0) misc[0] = RQ;
+      __syncthreads();
+      if (tid >= glo && tid < RQ && offs[tid + 1] - offs[glo] > cap) atomicMin(&misc[0], tid);
+      __syncthreads();
+      ghi = misc[0];
+      if (ghi == glo) {  // one query alone overflows the key area: the caller repeats the call on the two-pass path
+        blk_flag = 1;
+        skip = true;
+        ghi = glo + 1;
+      }
+    }
+    const int gbase = multi ? offs[glo] : 0;
+    // ---- emission: (distance, index) keys of my hits into my query's segment
+    if (valid && !skip && slot >= glo && slot < ghi && n > 0) {
+      int w = my_off - gbase;
+      if (tot2 != tot && j == NSUB - 1) {  // pad slot: larger than every real key, skipped by the rank phase
+        hits[q_start - gbase + tot] = ~0ull;
+        rows[q_start - gbase + tot] = 0xff;
+      }
+      auto emit = [&](float x, float y, float z, int idx) {
+        const float dx = qp.x - x, dy = qp.y - y, dz = qp.z - z;
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        if (d < r2) {
+          hits[w] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)idx;  // d >= 0: bit pattern is monotone
+          rows[w] = (unsigned char)slot;
+          ++w;
+        }
+      };
+      if (by_mask) {
+        unsigned long long bits = mask;
+        const int s0 = p0[0] + rel[0], s1 = p0[1] + rel[1] - len0, s2 = p0[2] + rel[2] - len0 - len1;
+        while (bits) {
+          const int b0 = __ffsll((long long)bits) - 1;
+          bits &= bits - 1;
+          int b1 = -1;
+          if (bits) {
+            b1 = __ffsll((long long)bits) - 1;
+            bits &= bits - 1;
+          }
+          const int pa = b0 + (b0 < len0 ? s0 : (b0 < len0 + len1 ? s1 : s2));
+          const int pb = b1 < 0 ? pa : b1 + (b1 < len0 ? s0 : (b1 < len0 + len1 ? s1 : s2));
+          const float xa = sx[pa], ya = sy[pa], za = sz[pa], xb = sx[pb], yb = sy[pb], zb = sz[pb];
+          const int ia = si[pa], ib = si[pb];
+          emit(xa, ya, za, ia);
+          if (b1 >= 0) emit(xb, yb, zb, ib);
+        }
+      } else if (staged) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          for (int p = p0[i] + rel[i]; p < p1[i] + rel[i]; ++p) emit(sx[p], sy[p], sz[p], si[p]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          for (int p = p0[i]; p < p1[i]; ++p) {
+            const float4 sp = sorted_s[p];
+            emit(sp.x, sp.y, sp.z, __float_as_int(sp.w));
+          }
+      }
+    } else if (valid && !skip && slot >= glo && slot < ghi && tot2 != tot && j == NSUB - 1) {
+      hits[q_start - gbase + tot] = ~0ull;
+      rows[q_start - gbase + tot] = 0xff;
+    }
+    __syncthreads();
+    // ---- one thread per hit: rank inside the segment by counting, then the final slot (or the row buffer)
+    const int group_hits = skip ? 0 : offs[ghi] - gbase;
+    for (int e = tid; e < group_hits; e += L::THREADS) {
+      const int r = rows[e];
+      if (r == 0xff) continue;
+      const int a = offs[r] - gbase, len = offs[r + 1] - offs[r];  // both even
+      const unsigned long long key = hits[e];
+      const ulonglong2* seg = reinterpret_cast<const ulonglong2*>(hits + a);
+      int rank = 0;
+      int jj = 0;
+      for (; jj + 4 <= len / 2; jj += 4) {
+        ulonglong2 hk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) hk[u] = seg[jj + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rank += (hk[u].x < key ? 1 : 0) + (hk[u].y < key ? 1 : 0);
+      }
+      for (; jj < len / 2; ++jj) {
+        const ulonglong2 h = seg[jj];
+        rank += (h.x < key ? 1 : 0) + (h.y < key ? 1 : 0);
+      }
+      if (rank < width) {
+        if (use_rowbuf) rowbuf[r * width + rank] = (unsigned int)(key & 0xffffffffull);
+        else out[(int64_t)orig[r] * width + rank] = (int64_t)(unsigned int)(key & 0xffffffffull);
+      }
+    }
+    if (use_rowbuf) {
+      __syncthreads();
+      // whole rows leave as contiguous runs: consecutive lanes, consecutive 16-byte pieces of a row
+      if ((width & 1) == 0) {
+        const int w2 = width >> 1, total_pairs = rows_here * w2;
+        const float inv = 1.0f / (float)w2;
+        for (int i = tid; i < total_pairs; i += L::THREADS) {
+          int r = (int)((float)i * inv);
+          r = r * w2 > i ? r - 1 : ((r + 1) * w2 <= i ? r + 1 : r);
+          const int cc = (i - r * w2) * 2;
+          const int cnt = qtot[r];
+          const uint2 v = *reinterpret_cast<const uint2*>(rowbuf + r * width + cc);
+          longlong2 o;
+          o.x = cc < cnt ? (long long)v.x : (long long)pad_value;
+          o.y = cc + 1 < cnt ? (long long)v.y : (long long)pad_value;
+          *reinterpret_cast<longlong2*>(out + (int64_t)orig[r] * width + cc) = o;
+        }
+      } else {
+        const int total_el = rows_here * width;
+        const float inv = 1.0f / (float)width;
+        for (int i = tid; i < total_el; i += L::THREADS) {
+          int r = (int)((float)i * inv);
+          r = r * width > i ? r - 1 : ((r + 1) * width <= i ? r + 1 : r);
+          const int cc = i - r * width;
+          out[(int64_t)orig[r] * width + cc] = cc < qtot[r] ? (long long)rowbuf[r * width + cc] : (long long)pad_value;
+        }
+      }
+    } else {
+      // ---- padding of the group's rows: half a wave per row
+      for (int r = glo + tid / 32; r < min(ghi, rows_here); r += L::THREADS / 32) {
+        int64_t* row = out + (int64_t)orig[r] * width;
+        for (int cc = (skip ? 0 : min(qtot[r], width)) + (lane & 31); cc < width; cc += 32) row[cc] = pad_value;
+      }
+      if (multi) __syncthreads();  // the next group overwrites the key area
+    }
+    glo = ghi;
+  }
+  if (tid == 0) {
+    int mx = 0;
+#pragma unroll
+    for (int i = 0; i < RQ / WAVE; ++i) mx = max(mx, wsum[L::THREADS / WAVE + i]);
+    blk_stats[2 * blk] = mx;
+    blk_stats[2 * blk + 1] = blk_flag;
   }
 }
 
@@ -721,7 +1125,7 @@ int launch_count(const RadiusWs& w, const float4* sorted_q, int64_t nq, int nb, 
   KernelTimer timer("radius_count", stream);
   hipLaunchKernelGGL((traverse_kernel<RQ, false, true>), dim3(grid), dim3(L::THREADS), L::count_bytes(nb <= L::TABLE_MAX ? nb : 0), stream, sorted_q,
                      (int)nq, w.q_off, nb, w.grids, start_s, w.sorted_s, r2, w.q_count, w.q_rng, w.q_mask, w.blk_stats,
-                     0, (int64_t)0, (int64_t*)nullptr, 0, (unsigned long long*)nullptr, (unsigned char*)nullptr, mono ? 1 : 0);
+                     0, 0, (int64_t)0, (int64_t*)nullptr, 0, (unsigned long long*)nullptr, (unsigned char*)nullptr, mono ? 1 : 0);
   hipLaunchKernelGGL(reduce_stats_kernel, dim3(1), dim3(1024), 0, stream, w.blk_stats, blocks, w.hdr);
   GR_LAUNCH_CHECK();
   return GR_OK;
@@ -729,7 +1133,7 @@ int launch_count(const RadiusWs& w, const float4* sorted_q, int64_t nq, int nb, 
 
 template <int RQ>
 int launch_fill(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns, int nb, float r2, int64_t width,
-                int64_t max_block_hits, int64_t* out, hipStream_t stream) {
+                int64_t row_stride, int64_t max_block_hits, int64_t* out, hipStream_t stream) {
   using L = TravLds<RQ>;
   const int blocks = (int)((nq + RQ - 1) / RQ);
   const int grid = (blocks + 7) / 8 * 8;
@@ -742,7 +1146,7 @@ int launch_fill(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t n
       GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  160 * 1024));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(L::THREADS), lds, stream, sorted_q, (int)nq, w.q_off, nb, w.grids,
-                       w.start, w.sorted_s, r2, w.q_count, w.q_rng, w.q_mask, w.blk_stats, (int)width, ns, out,
+                       w.start, w.sorted_s, r2, w.q_count, w.q_rng, w.q_mask, w.blk_stats, (int)width, (int)row_stride, ns, out,
                        (int)cap, (unsigned long long*)nullptr, (unsigned char*)nullptr, 0);
   } else {
     // very dense neighbourhoods: hit lists live in a scratch allocation owned by this call
@@ -753,11 +1157,71 @@ int launch_fill(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t n
     unsigned char* g_rows = reinterpret_cast<unsigned char*>(scratch + (size_t)grid * per_block * 8);
     hipLaunchKernelGGL((traverse_kernel<RQ, true, false>), dim3(grid), dim3(L::THREADS), L::FILL_OFF, stream,
                        sorted_q, (int)nq, w.q_off, nb, w.grids, w.start, w.sorted_s, r2, w.q_count, w.q_rng,
-                       w.q_mask, w.blk_stats, (int)width, ns, out, (int)cap, g_hits, g_rows, 0);
+                       w.q_mask, w.blk_stats, (int)width, (int)row_stride, ns, out, (int)cap, g_hits, g_rows, 0);
     GR_HIP(hipFreeAsync(scratch, stream));
   }
   GR_LAUNCH_CHECK();
   return GR_OK;
+}
+
+struct FusedCfg {
+  int rq;      // queries per block: 64 or 128
+  int rowbuf;  // rows leave through an LDS row buffer as contiguous 16-byte pieces (else: one 8-byte store per hit)
+  int per_q;   // key slots per query in a block's key area
+};
+inline FusedCfg fused_cfg() {
+  static const FusedCfg cfg = [] {
+    FusedCfg c{128, 1, 28};
+    if (const char* e = getenv("GR_RADIUS_FUSED_RQ")) c.rq = atoi(e) == 64 ? 64 : 128;
+    if (const char* e = getenv("GR_RADIUS_FUSED_ROWBUF")) c.rowbuf = atoi(e) != 0;
+    if (const char* e = getenv("GR_RADIUS_FUSED_SLOTS")) c.per_q = max(8, min(512, atoi(e)));
+    return c;
+  }();
+  return cfg;
+}
+
+template <int RQ, bool ROWBUF>
+int launch_fused_t(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns, int nb, const int32_t* start_s,
+                   float r2, int64_t width, int per_q, int64_t* out, bool mono, hipStream_t stream) {
+  using L = FusedLds<RQ>;
+  const int blocks = (int)((nq + RQ - 1) / RQ);
+  const int grid = (blocks + 7) / 8 * 8;
+  const int tcap = nb <= L::TABLE_MAX ? nb : 0;
+  // key area: `per_q` slots per query, never less than two full rows, within the 160 KB of a CU
+  int cap = max(per_q * RQ, (int)(2 * width + 2));
+  cap = (cap + 15) / 16 * 16;
+  while (L::total((int)width, cap, tcap) > 160 * 1024 && cap > 64) cap -= 16;
+  const size_t region = L::region_bytes((int)width);
+  const size_t lds = L::total((int)width, cap, tcap);
+  GR_REQUIRE(lds <= 160 * 1024, "radius_search: neighbor_limit %lld does not fit the single-pass kernel", (long long)width);
+  auto kern = fused_kernel<RQ, ROWBUF>;
+  if (lds > 64 * 1024)
+    GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  {
+    KernelTimer timer("radius_fused", stream);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(L::THREADS), lds, stream, sorted_q, (int)nq, w.q_off, nb, w.grids, start_s,
+                       w.sorted_s, r2, w.blk_stats, (int)width, ns, out, cap, (int)region, mono ? 1 : 0);
+  }
+  hipLaunchKernelGGL(reduce_stats_kernel, dim3(1), dim3(1024), 0, stream, w.blk_stats, blocks, w.hdr);
+  GR_LAUNCH_CHECK();
+  return GR_OK;
+}
+
+inline bool fused_fits(int64_t width) {
+  // the row buffer / key area of the largest configuration must fit next to the candidate planes
+  return width >= 1 && FusedLds<64>::total((int)width, (int)((2 * width + 2 + 15) / 16 * 16), 0) <= 160 * 1024;
+}
+
+int launch_fused(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns, int nb, const int32_t* start_s,
+                 float r2, int64_t width, int64_t* out, bool mono, hipStream_t stream) {
+  const FusedCfg c = fused_cfg();
+  int rq = c.rq;
+  if (rq == 128 && FusedLds<128>::total((int)width, (int)((2 * width + 2 + 15) / 16 * 16), 0) > 160 * 1024) rq = 64;
+  if (rq == 128)
+    return c.rowbuf ? launch_fused_t<128, true>(w, sorted_q, nq, ns, nb, start_s, r2, width, c.per_q, out, mono, stream)
+                    : launch_fused_t<128, false>(w, sorted_q, nq, ns, nb, start_s, r2, width, c.per_q, out, mono, stream);
+  return c.rowbuf ? launch_fused_t<64, true>(w, sorted_q, nq, ns, nb, start_s, r2, width, c.per_q, out, mono, stream)
+                  : launch_fused_t<64, false>(w, sorted_q, nq, ns, nb, start_s, r2, width, c.per_q, out, mono, stream);
 }
 
 }  // namespace
@@ -778,13 +1242,24 @@ extern "C" int gr_radius_count(const float* q, const float* s, const int64_t* h_
                                 stream_);
 }
 
-extern "C" int gr_radius_count_cached(const float* q, const float* s, const int64_t* h_q_lengths,
-                                      const int64_t* h_s_lengths, int64_t nq, int64_t ns, int64_t batch,
-                                      float radius, void* ws, size_t ws_bytes, int64_t* h_info,
-                                      int64_t* h_support_sig, int reuse_support, void* stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  GR_REQUIRE(h_info != nullptr, "h_info is null");
-  h_info[0] = h_info[1] = h_info[2] = h_info[3] = 0;
+namespace gr {
+namespace {
+struct Prepared {
+  RadiusWs w;
+  const float4* sorted_q;
+  const int32_t* start_s;
+  float r2;
+  int nb;
+  bool same;
+  bool empty;  // nothing to search: width 0
+};
+
+// Everything up to the first traversal: argument checks, offsets, support (and query) binning.  `same` = self-search.
+int radius_prepare(const float* q, const float* s, const int64_t* h_q_lengths, const int64_t* h_s_lengths, int64_t nq,
+                   int64_t ns, int64_t batch, float radius, void* ws, size_t ws_bytes, int64_t* h_support_sig,
+                   int reuse_support, hipStream_t stream, Prepared* out_p) {
+  Prepared& P = *out_p;
+  P.empty = true;
   GR_REQUIRE(nq >= 0 && ns >= 0 && batch >= 0, "negative size");
   GR_REQUIRE(nq < (1ll << 31) - 1 && ns < (1ll << 31) - 1 && batch < (1 << 20),
              "radius_neighbors: sizes must fit int32 (nq=%lld ns=%lld)", (long long)nq, (long long)ns);
@@ -842,6 +1317,7 @@ extern "C" int gr_radius_count_cached(const float* q, const float* s, const int6
   int32_t* start_s = w.start;
   int32_t* start_q = same ? w.start : w.start + (w.ccap + 1);
   int rc = GR_OK;
+  KernelTimer bin_timer("radius_bin", stream);  // bbox .. scatter (nothing is launched when the grid is reused in a self-search)
   if (!reuse) {
     // ---- supports (and, in the same launches, the queries): bbox, grid, histogram, scan, scatter
     const int rows = same ? 1 : 2;
@@ -874,9 +1350,33 @@ extern "C" int gr_radius_count_cached(const float* q, const float* s, const int6
     hipLaunchKernelGGL(scatter_kernel, dim3((nq + 255) / 256), dim3(256), 0, stream, s, 0, q, (int)nq, w.s_cell,
                        w.q_cell, start_s, start_q, w.s_rank, w.q_rank, w.sorted_s, w.sorted_q);
   }
-  const float4* sorted_q = same ? w.sorted_s : w.sorted_q;
-  const float r2 = radius * radius;  // radius_neighbors_cpu.cpp:12 (fp32 product)
-  rc = launch_count<RT>(w, sorted_q, nq, nb, start_s, r2, same, stream);
+  P.w = w;
+  P.sorted_q = same ? w.sorted_s : w.sorted_q;
+  P.start_s = start_s;
+  P.r2 = radius * radius;  // radius_neighbors_cpu.cpp:12 (fp32 product)
+  P.nb = nb;
+  P.same = same;
+  P.empty = false;
+  return GR_OK;
+}
+}  // namespace
+}  // namespace gr
+
+extern "C" int gr_radius_count_cached(const float* q, const float* s, const int64_t* h_q_lengths,
+                                      const int64_t* h_s_lengths, int64_t nq, int64_t ns, int64_t batch,
+                                      float radius, void* ws, size_t ws_bytes, int64_t* h_info,
+                                      int64_t* h_support_sig, int reuse_support, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GR_REQUIRE(h_info != nullptr, "h_info is null");
+  h_info[0] = h_info[1] = h_info[2] = h_info[3] = 0;
+  Prepared P;
+  int rc = radius_prepare(q, s, h_q_lengths, h_s_lengths, nq, ns, batch, radius, ws, ws_bytes, h_support_sig, reuse_support,
+                          stream, &P);
+  if (rc != GR_OK) return rc;
+  if (P.empty) return GR_OK;  // width 0
+  const RadiusWs& w = P.w;
+  const bool same = P.same;
+  rc = launch_count<RT>(w, P.sorted_q, nq, P.nb, P.start_s, P.r2, same, stream);
   if (rc != GR_OK) return rc;
   // the read-back lands in pinned memory (a copy into pageable memory is staged and synchronised by the runtime on top of
   // the synchronise below)
@@ -917,5 +1417,54 @@ extern "C" int gr_radius_fill(const float* q, const float* s, int64_t nq, int64_
   const bool same = h_info[2] != 0;
   const float4* sorted_q = same ? w.sorted_s : w.sorted_q;
   const float r2 = radius * radius;
-  return launch_fill<RT>(w, sorted_q, nq, ns, (int)batch, r2, width, h_info[1], out, stream);
+  return launch_fill<RT>(w, sorted_q, nq, ns, (int)batch, r2, width, width, h_info[1], out, stream);
+}
+
+extern "C" int gr_radius_search(const float* q, const float* s, const int64_t* h_q_lengths, const int64_t* h_s_lengths,
+                                int64_t nq, int64_t ns, int64_t batch, float radius, int64_t limit, int64_t* out,
+                                void* ws, size_t ws_bytes, int64_t* h_info, int64_t* h_support_sig, int reuse_support,
+                                void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GR_REQUIRE(h_info != nullptr, "h_info is null");
+  for (int i = 0; i < 6; ++i) h_info[i] = 0;
+  GR_REQUIRE(limit >= 1 && limit <= (1 << 20), "radius_search: neighbor_limit must be positive (got %lld)", (long long)limit);
+  GR_REQUIRE(out != nullptr || nq == 0, "out is null");
+  Prepared P;
+  int rc = radius_prepare(q, s, h_q_lengths, h_s_lengths, nq, ns, batch, radius, ws, ws_bytes, h_support_sig, reuse_support,
+                          stream, &P);
+  if (rc != GR_OK) return rc;
+  if (P.empty) return GR_OK;  // width 0
+  const RadiusWs& w = P.w;
+  RadiusHdr* h_pinned = static_cast<RadiusHdr*>(pinned_scratch(3, sizeof(RadiusHdr)));
+  GR_REQUIRE(h_pinned != nullptr, "pinned read-back buffer could not be allocated");
+  const char* force2 = getenv("GR_RADIUS_TWO_PASS");
+  bool fused = fused_fits(limit) && !(force2 && force2[0] == '1');
+  if (fused) {
+    rc = launch_fused(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, out, P.same, stream);
+    if (rc != GR_OK) return rc;
+    GR_HIP(hipMemcpyAsync(h_pinned, w.hdr, sizeof(RadiusHdr), hipMemcpyDeviceToHost, stream));
+    GR_HIP(hipStreamSynchronize(stream));
+    h_info[0] = h_pinned->max_count;
+    h_info[2] = P.same ? 1 : 0;
+    h_info[3] = h_pinned->total_cells;
+    if (h_pinned->max_block_hits == 0) {  // no query overflowed its block's key area: `out` is complete
+      h_info[4] = 1;
+      return GR_OK;
+    }
+  }
+  // two passes (a neighbourhood too dense for the key area, or a limit too wide for the row buffer): count, then fill the
+  // first min(max_count, limit) columns of the same (nq, limit) rows
+  rc = launch_count<RT>(w, P.sorted_q, nq, P.nb, P.start_s, P.r2, P.same, stream);
+  if (rc != GR_OK) return rc;
+  GR_HIP(hipMemcpyAsync(h_pinned, w.hdr, sizeof(RadiusHdr), hipMemcpyDeviceToHost, stream));
+  GR_HIP(hipStreamSynchronize(stream));
+  const RadiusHdr h = *h_pinned;
+  h_info[0] = h.max_count;
+  h_info[1] = h.max_block_hits;
+  h_info[2] = P.same ? 1 : 0;
+  h_info[3] = h.total_cells;
+  h_info[4] = 0;
+  const int64_t width = h.max_count < (uint64_t)limit ? (int64_t)h.max_count : limit;
+  if (width == 0) return GR_OK;
+  return launch_fill<RT>(w, P.sorted_q, nq, ns, P.nb, P.r2, width, limit, h.max_block_hits, out, stream);
 }

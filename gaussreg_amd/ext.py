@@ -110,14 +110,55 @@ def _radius(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, gr
     return out if out_device.type == "cuda" else out.to(out_device)
 
 
+def _radius_limited(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, grid):
+    """radius_search with neighbor_limit > 0: the (nq, limit) rows are allocated before anything is counted and ONE
+    kernel searches, ranks and writes them (gr_radius_search); the read-back of max_count only decides whether the
+    reference would have returned fewer columns (radius_search.py:25-26 keeps min(max_count, limit))."""
+    dev = _lib.require_gpu()
+    L = _lib.lib()
+    out_device = q_points.device
+    same = s_points is q_points or (s_points.data_ptr() == q_points.data_ptr() and s_points.shape == q_points.shape)
+    q = q_points if q_points.is_cuda else q_points.to(dev)
+    s = q if same else (s_points if s_points.is_cuda else s_points.to(dev))
+    dev = q.device
+    ql, sl = q_lengths.tolist(), s_lengths.tolist()
+    nq, ns, nb = q.shape[0], s.shape[0], len(ql)
+    limit = int(neighbor_limit)
+    hq, hs = _lib.host_i64(ql), _lib.host_i64(sl)
+    with torch.cuda.device(dev):
+        info = (ctypes.c_int64 * 6)()
+        st = _lib.stream_ptr(dev)
+        out = torch.empty((nq, limit), dtype=torch.int64, device=dev)
+        if grid is None:
+            ws = _lib.workspace(dev, L.gr_radius_workspace_bytes(nq, ns, nb))
+            sig, reuse = None, 0
+        else:
+            ws = grid.workspace(L, dev, nq, ns, nb)
+            key = (s.data_ptr(), ns, nb, float(radius), tuple(sl))
+            reuse = 1 if (grid.key == key and ns > 0 and nq > 0) else 0
+            sig = grid.sig
+        _lib.check(L.gr_radius_search(_lib.ptr(q), _lib.ptr(s), hq, hs, nq, ns, nb, float(radius), limit, _lib.ptr(out),
+                                      _lib.ptr(ws), ws.numel(), info, sig, reuse, st))
+        if grid is not None:
+            grid.key = key if (ns > 0 and nq > 0 and nb > 0) else None
+            grid._keep = s
+        width = min(int(info[0]), limit)
+        if width < limit:
+            out = out[:, :width].contiguous()
+    return out if out_device.type == "cuda" else out.to(out_device)
+
+
 def radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius, grid=None):
     """`grid`: optional SupportGrid shared by consecutive searches over the same supports and radius."""
     return _radius(q_points, s_points, q_lengths, s_lengths, radius, None, grid, True)
 
 
-def radius_neighbors_limited(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, grid=None):
+def radius_neighbors_limited(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, grid=None, two_pass=False):
     """radius_neighbors + the column truncation of modules/ops/radius_search.py:25-26 done inside the
-    fill kernel: only min(max_count, neighbor_limit) columns are ever written (contiguous result)."""
+    kernel: only min(max_count, neighbor_limit) columns are ever written (contiguous result).  With a positive limit the
+    search is ONE pass (gr_radius_search); `two_pass=True` forces the count + fill pair the bare radius_neighbors uses."""
+    if neighbor_limit is not None and neighbor_limit > 0 and not two_pass:
+        return _radius_limited(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, grid)
     return _radius(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, grid, False)
 
 

@@ -35,8 +35,9 @@ const char* gr_last_error(void);
 int gr_version(void);
 
 /* Optional per-kernel timing with HIP events recorded on the launch stream (measurement aid, off
- * by default).  Timed kernels: "radius_fill", "radius_count", "raster_preprocess", "raster_sort",
- * "raster_blend".  gr_timing_read waits for the recorded events and returns total ms / launches. */
+ * by default).  Timer names: "radius_bin", "radius_count", "radius_fill", "radius_fused", "raster_preprocess",
+ * "raster_depth_sort", "raster_bin", "raster_blend", "fps", "sinkhorn", "lgr", "ransac", "kpconv", "group_norm",
+ * "geo_embedding", "rpe_attention", "rpe_scores", "gs_fuse".  gr_timing_read waits for the recorded events and returns total ms / launches. */
 void gr_timing_enable(int on);
 void gr_timing_reset(void);
 int gr_timing_read(const char* name, double* total_ms, int64_t* calls);
@@ -76,6 +77,20 @@ int gr_radius_count_cached(const float* q, const float* s, const int64_t* h_q_le
 int gr_radius_fill(const float* q, const float* s, int64_t nq, int64_t ns, int64_t batch,
                    float radius, int64_t width, const int64_t* h_info /*[4]*/, int64_t* out,
                    void* ws, size_t ws_bytes, void* stream);
+/* radius_search with a positive neighbor_limit -- replaces the wrapper
+ *   geotransformer/modules/ops/radius_search.py:7-27  (ext.radius_neighbors, then `[:, :neighbor_limit]`, :25-26)
+ * in ONE pass: the kept width min(max_count, limit) is at most `limit`, so the caller allocates `out` as (nq, limit)
+ * int64 BEFORE anything is counted and a single kernel tests the candidates, ranks the hits in LDS and writes whole rows
+ * (row stride = limit; columns past a query's hit count hold the padding value ns).  No per-query metadata goes through
+ * global memory and the host does not sit between two launches.  SYNCHRONISES `stream` once, after the kernel, to return
+ *   h_info[0] = max_count (the reference's untruncated width): the result is out[:, :min(max_count, limit)];
+ *   h_info[4] = 1 if the single-pass kernel produced `out`, 0 if the call fell back to count + fill (one query with more
+ *               hits than a workgroup's LDS key area holds, or a limit too wide for the LDS row buffer) -- same result.
+ * h_support_sig / reuse_support as in gr_radius_count_cached (may be NULL / 0).  `ws`: gr_radius_workspace_bytes. */
+int gr_radius_search(const float* q, const float* s, const int64_t* h_q_lengths, const int64_t* h_s_lengths,
+                     int64_t nq, int64_t ns, int64_t batch, float radius, int64_t limit, int64_t* out /* nq x limit */,
+                     void* ws, size_t ws_bytes, int64_t* h_info /*[6]*/, int64_t* h_support_sig /*[4] or NULL*/,
+                     int reuse_support, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * grid_subsampling -- replaces
@@ -86,9 +101,9 @@ int gr_radius_fill(const float* q, const float* s, int64_t nq, int64_t ns, int64
  * out_points has capacity (n,3); h_out_lengths (host, int64[batch]) receives m_b; *h_total_m the
  * total.  Barycentres are bit-identical to the reference (sequential fp32 sums in input order,
  * times float(1.0/count)).  order_mode selects the ROW ORDER inside each cloud:
- *   GR_ORDER_REFERENCE  the reference's std::unordered_map iteration order (replayed on the host
- *                       through the same libstdc++ container; one extra D2H/H2D hop), bit-for-bit
- *                       the tensor the reference returns;
+ *   GR_ORDER_REFERENCE  the reference's std::unordered_map iteration order, evaluated on the device in closed form
+ *                       (csrc/hash_order_device.hip; GR_HASH_ORDER_HOST=1 selects the host replay of libstdc++'s
+ *                       linking rules instead), bit-for-bit the tensor the reference returns;
  *   GR_ORDER_CELL       ascending voxel key -- fully on device, same multiset of rows.
  * Synchronises `stream` (the output size is data dependent).
  */

@@ -1,0 +1,134 @@
+"""GPU parity of the single-pass radius_search (gr_radius_search: width = neighbor_limit known before the launch) against
+the oracle's full-width result truncated the way the reference truncates it (modules/ops/radius_search.py:25-26), and
+against this library's own two-pass path.  Bit-exact (indices)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _info(q, s, ql, sl, radius, limit):
+    """Call the C entry point directly to read h_info[4] (did the single pass produce the rows?)."""
+    from gaussreg_amd import _lib
+    L = _lib.lib()
+    nq, ns, nb = q.shape[0], s.shape[0], len(ql)
+    info = (ctypes.c_int64 * 6)()
+    out = torch.empty((nq, limit), dtype=torch.int64, device=q.device)
+    ws = torch.empty(L.gr_radius_workspace_bytes(nq, ns, nb), dtype=torch.uint8, device=q.device)
+    _lib.check(L.gr_radius_search(_lib.ptr(q), _lib.ptr(s), _lib.host_i64(ql), _lib.host_i64(sl), nq, ns, nb, float(radius),
+                                  limit, _lib.ptr(out), _lib.ptr(ws), ws.numel(), info, None, 0, _lib.stream_ptr(q.device)))
+    torch.cuda.synchronize()
+    return list(info), out
+
+
+@pytest.mark.parametrize("seed,nq,ns,batch,radius", [(0, 5000, 7000, 3, 0.08), (1, 3000, 3000, 1, 0.2),
+                                                     (2, 4000, 1000, 4, 0.5), (3, 777, 12345, 2, 0.03)])
+@pytest.mark.parametrize("limit", [1, 7, 30, 64, 89, 400])
+def test_limited_vs_oracle(seed, nq, ns, batch, radius, limit):
+    from gaussreg_amd import ext
+    from oracle import capi
+    rng = np.random.default_rng(seed)
+    s = (rng.random((ns, 3)) * [2.0, 1.0, 0.5]).astype(np.float32)
+    q = (rng.random((nq, 3)) * [2.4, 1.0, 0.5] - [0.2, 0, 0]).astype(np.float32)
+
+    def split(n):
+        cuts = np.sort(rng.integers(0, n + 1, batch - 1))
+        return np.diff(np.concatenate([[0], cuts, [n]])).astype(np.int64)
+
+    ql, sl = split(nq), split(ns)
+    want = capi.radius_neighbors(q, s, ql, sl, radius)[:, :limit]
+    tq, ts, tql, tsl = _t(q), _t(s), torch.from_numpy(ql), torch.from_numpy(sl)
+    got = ext.radius_neighbors_limited(tq, ts, tql, tsl, radius, limit)
+    assert got.is_contiguous() and got.shape == want.shape
+    assert np.array_equal(got.cpu().numpy(), want)
+    two = ext.radius_neighbors_limited(tq, ts, tql, tsl, radius, limit, two_pass=True)
+    assert torch.equal(two, got)
+
+
+def test_self_search_c1_golden_truncated():
+    from gaussreg_amd import ext
+    from helpers import c1_points, load_golden
+    g = load_golden("ext_c1.npz")
+    pts = torch.from_numpy(c1_points()).cuda()
+    lens = torch.tensor([pts.shape[0]])
+    for limit in (16, 38, 39, 40, 89):
+        nb = ext.radius_neighbors_limited(pts, pts, lens, lens, float(g["radius"]), limit)
+        assert np.array_equal(nb.cpu().numpy(), g["neighbors"][:, :limit])
+
+
+def test_dense_blocks_work_in_groups_and_giant_queries_fall_back():
+    """~600 hits per query: a block's 128 queries need several passes over its key area (groups); then a radius that
+    makes every support a neighbour of every query: one query alone overflows the key area and the call repeats itself
+    on the two-pass path.  Same rows either way."""
+    from gaussreg_amd import ext
+    from oracle import capi
+    rng = np.random.default_rng(11)
+    s = rng.random((6000, 3)).astype(np.float32)
+    q = rng.random((900, 3)).astype(np.float32)
+    ql, sl = np.array([500, 400], np.int64), np.array([4000, 2000], np.int64)
+    tq, ts = _t(q), _t(s)
+    for radius, limit, single in ((0.35, 50, True), (0.35, 333, True), (2.0, 64, False), (2.0, 7, False)):
+        want = capi.radius_neighbors(q, s, ql, sl, radius)
+        info, out = _info(tq, ts, ql.tolist(), sl.tolist(), radius, limit)
+        assert info[0] == want.shape[1]
+        assert (info[4] == 1) == single, (radius, limit, info)
+        w = min(limit, want.shape[1])
+        assert np.array_equal(out[:, :w].cpu().numpy(), want[:, :w])
+        if w < limit:
+            assert bool((out[:, w:] == s.shape[0]).all())
+        got = ext.radius_neighbors_limited(tq, ts, torch.from_numpy(ql), torch.from_numpy(sl), radius, limit)
+        assert np.array_equal(got.cpu().numpy(), want[:, :limit])
+
+
+def test_limit_wider_than_max_count_and_no_neighbour():
+    from gaussreg_amd import ext
+    from oracle import capi
+    rng = np.random.default_rng(3)
+    s = rng.random((2000, 3)).astype(np.float32)
+    q = rng.random((1500, 3)).astype(np.float32)
+    ql, sl = np.array([1500], np.int64), np.array([2000], np.int64)
+    want = capi.radius_neighbors(q, s, ql, sl, 0.1)
+    got = ext.radius_neighbors_limited(_t(q), _t(s), torch.from_numpy(ql), torch.from_numpy(sl), 0.1, 200)
+    assert got.shape == want.shape and got.is_contiguous() and np.array_equal(got.cpu().numpy(), want)
+    far = _t(q + 10.0)
+    none = ext.radius_neighbors_limited(far, _t(s), torch.from_numpy(ql), torch.from_numpy(sl), 0.1, 30)
+    assert none.shape == (1500, 0)
+    empty = ext.radius_neighbors_limited(_t(q[:0]), _t(s), torch.tensor([0]), torch.from_numpy(sl), 0.1, 30)
+    assert empty.shape == (0, 0)
+
+
+def test_ragged_batches_odd_limits_and_grid_reuse():
+    from gaussreg_amd import ext
+    from oracle import capi
+    rng = np.random.default_rng(8)
+    s = rng.random((3000, 3)).astype(np.float32)
+    sl = np.array([0, 1300, 1, 1699, 0], np.int64)
+    ts, tsl = _t(s), torch.from_numpy(sl)
+    grid = ext.SupportGrid(2000)
+    for k, limit in enumerate((5, 33, 41)):
+        q = rng.random((1000 + 300 * k, 3)).astype(np.float32)
+        ql = np.array([10, 500 + 300 * k, 0, 489, 1], np.int64)
+        want = capi.radius_neighbors(q, s, ql, sl, 0.12)[:, :limit]
+        got = ext.radius_neighbors_limited(_t(q), ts, torch.from_numpy(ql), tsl, 0.12, limit, grid=grid)
+        assert np.array_equal(got.cpu().numpy(), want)
+    # self-search through the cached grid
+    want = capi.radius_neighbors(s, s, sl, sl, 0.12)[:, :17]
+    got = ext.radius_neighbors_limited(ts, ts, tsl, tsl, 0.12, 17, grid=grid)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_200k_limited_equals_two_pass_and_properties():
+    from gaussreg_amd import ext, synthetic
+    pts, lens = synthetic.cloud_200k(2, seed=3)
+    d = pts.cuda()
+    a = ext.radius_neighbors_limited(d, d, lens, lens, 0.0625, 40)
+    b = ext.radius_neighbors_limited(d, d, lens, lens, 0.0625, 40, two_pass=True)
+    assert a.shape == (400000, 40) and torch.equal(a, b)
+    assert bool((a[:, 0] == torch.arange(400000, device=a.device)).all())  # self first (d = 0)
