@@ -30,6 +30,7 @@ SIGNATURES = {
                                c_size, c_void]),
     "gr_radius_search": (c_int, [c_void, c_void, c_i64p, c_i64p, c_i64, c_i64, c_i64, c_f32, c_i64, c_void, c_void, c_size,
                                  c_i64p, c_i64p, c_int, c_void]),
+    "gr_radius_search_mode": (c_int, [c_int]),
     "gr_host_unordered_map_order": (c_int, [ctypes.POINTER(ctypes.c_uint64), c_i64, ctypes.POINTER(ctypes.c_int32)]),
     "gr_hash_order_device_workspace_bytes": (c_size, [c_i64, c_i64]),
     "gr_hash_order_device": (c_int, [c_void, c_i64p, c_i64, c_void, c_void, c_size, c_void]),

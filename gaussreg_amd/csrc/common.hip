@@ -268,13 +268,13 @@ void bbox_block_offsets(const int32_t* h_off, int32_t* blk, int nb) {
 }
 
 int compute_bbox(const float* pts, const int32_t* h_off, int32_t* blk, const int32_t* off_dev, int nb,
-                 uint32_t* bbox_dev, int32_t* blk_off_dev, hipStream_t stream, bool blk_off_on_device) {
+                 uint32_t* bbox_dev, int32_t* blk_off_dev, hipStream_t stream, bool blk_off_on_device, bool init_bbox) {
   if (nb <= 0) return GR_OK;
   if (!blk_off_on_device) {
     bbox_block_offsets(h_off, blk, nb);
     GR_HIP(hipMemcpyAsync(blk_off_dev, blk, sizeof(int32_t) * (nb + 1), hipMemcpyHostToDevice, stream));
   }
-  hipLaunchKernelGGL(bbox_init_kernel, dim3((nb * 6 + 255) / 256), dim3(256), 0, stream, bbox_dev, nb);
+  if (init_bbox) hipLaunchKernelGGL(bbox_init_kernel, dim3((nb * 6 + 255) / 256), dim3(256), 0, stream, bbox_dev, nb);
   if (blk[nb] > 0)
     hipLaunchKernelGGL(bbox_kernel, dim3(blk[nb]), dim3(256), 0, stream, pts, off_dev, blk_off_dev, nb, bbox_dev);
   GR_LAUNCH_CHECK();

@@ -99,7 +99,8 @@ void* pinned_scratch(int slot, size_t bytes);
 // merge several small host-to-device copies into one).
 void bbox_block_offsets(const int32_t* h_off, int32_t* h_blk, int nb);
 int compute_bbox(const float* pts, const int32_t* h_off, int32_t* h_blk, const int32_t* off_dev, int nb,
-                 uint32_t* bbox_dev, int32_t* blk_off_dev, hipStream_t stream, bool blk_off_on_device = false);
+                 uint32_t* bbox_dev, int32_t* blk_off_dev, hipStream_t stream, bool blk_off_on_device = false,
+                 bool init_bbox = true);  // init_bbox = false: the caller has set bbox_dev to (0xffffffff x3, 0 x3) per cloud
 
 // Stable LSD radix sort of (u64 key, i32 value) pairs on bits [begin_bit, end_bit) (rocPRIM).
 size_t sort_pairs_temp_bytes(int64_t n);

@@ -22,12 +22,25 @@
 //               segment by counting (one thread per hit) and stores it at out[query][rank]; pads the rows
 // gr_radius_count_cached lets consecutive searches over the same supports and radius skip bbox .. scatter for the
 // support side (the data pyramid searches every level's supports three times).
+#include <algorithm>
+#include <atomic>
 #include <vector>
 
 #include "common.hpp"
 
 namespace gr {
 namespace {
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d, WAVE));
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, WAVE));
+  return v;
+}
 
 struct BatchGrid {  // 64 bytes: copied to LDS as four int4
   double org[3];
@@ -37,7 +50,7 @@ struct BatchGrid {  // 64 bytes: copied to LDS as four int4
   int dim[3];         // dim[0] counts the fine x cells
   int cell_base;
   int xk;
-  int pad;
+  int sup_base;  // first super-cell (SUP_CELLS consecutive cells) of this cloud
 };
 static_assert(sizeof(BatchGrid) == 64, "BatchGrid is staged in LDS as four int4");
 
@@ -45,25 +58,33 @@ struct RadiusHdr {
   unsigned int max_count;
   unsigned int max_block_hits;
   int total_cells;
-  int pad;
+  int total_sup;  // super-cells of all clouds
 };
 
-constexpr int RT = 128;  // queries per block in count/fill (3 threads per query)
+constexpr int RT = 128;
+// binning: counting sort in two levels -- points -> super-cells of SUP_CELLS consecutive cells (block-local LDS histograms,
+// one global atomic per block and non-empty super-cell), then one workgroup per super-cell sorts its points by cell in LDS
+constexpr int SUP_SHIFT = 9, SUP_CELLS = 1 << SUP_SHIFT;
+constexpr int COARSE_PTS = 2048;   // points per block of the coarse passes
+constexpr int COARSE_BINS = 4096;  // super-cell range a block can histogram in LDS
+constexpr int BBOX_PTS = 2048;     // points per block of the bounding-box pass  // queries per block in count/fill (3 threads per query)
 
 struct RadiusWs {
   RadiusHdr* hdr;
   int32_t* q_off;
   int32_t* s_off;
   uint32_t* bbox;
+  uint32_t* bbox_partial;  // [blocks][6]
   int32_t* blk_off;
   BatchGrid* grids;
+  int32_t* sup_off;    // [batch+1] first super-cell of every cloud
+  int32_t* sup_zero;   // [4][nsup+1]: counts (s, q) and cursors (s, q) -- cleared per call
+  int32_t* sup_start;  // [2][nsup+1]
   int32_t* s_cell;
   int32_t* q_cell;
-  int32_t* s_rank;  // arrival order of a point inside its cell (from the histogram atomics)
-  int32_t* q_rank;
-  int32_t* cnt;    // [2][ccap+1]
-  int32_t* start;  // [2][ccap+1]
-  int32_t* scan_ws;
+  int2* pairs_s;  // (point index, cell), grouped by super-cell
+  int2* pairs_q;
+  int32_t* start;  // [2][ccap+1] cell starts in the sorted arrays (supports; the query row is unused)
   float4* sorted_s;
   float4* sorted_q;
   int32_t* q_count;    // [3][nq] hits per (z-slab, query)
@@ -71,6 +92,7 @@ struct RadiusWs {
   unsigned long long* q_mask;  // [3 slab][nq] hit bits in candidate enumeration order
   int32_t* blk_stats;  // [blocks][2]
   int64_t ccap;
+  int64_t nsup;  // upper bound of the number of super-cells
   size_t bytes;
 };
 
@@ -78,22 +100,25 @@ RadiusWs carve(void* ws, int64_t nq, int64_t ns, int64_t batch) {
   RadiusWs w;
   Carver c(ws);
   w.ccap = 4096 * batch + 4 * ns;
+  w.nsup = w.ccap / SUP_CELLS + batch + 2;
   w.hdr = c.take<RadiusHdr>(1);
   w.q_off = c.take<int32_t>(3 * (batch + 1));  // q offsets | s offsets | bbox block offsets: one host-to-device copy
   w.s_off = w.q_off + (batch + 1);
   w.blk_off = w.s_off + (batch + 1);
   w.bbox = c.take<uint32_t>(batch * 6);
+  w.bbox_partial = c.take<uint32_t>(6 * (ns / BBOX_PTS + batch + 1));
   w.grids = c.take<BatchGrid>(batch);
+  w.sup_off = c.take<int32_t>(batch + 1);
   // support side first (sizes depend on ns and batch only): a later call with other queries finds it in place
+  w.sup_zero = c.take<int32_t>(4 * (w.nsup + 1));
+  w.sup_start = c.take<int32_t>(2 * (w.nsup + 1));
   w.s_cell = c.take<int32_t>(ns);
-  w.s_rank = c.take<int32_t>(ns);
-  w.cnt = c.take<int32_t>(2 * (w.ccap + 1));
+  w.pairs_s = c.take<int2>(ns);
   w.start = c.take<int32_t>(2 * (w.ccap + 1));
-  w.scan_ws = c.take<int32_t>(2 * scan_ws_ints(w.ccap + 1));
   w.sorted_s = c.take<float4>(ns);
   // query side
   w.q_cell = c.take<int32_t>(nq);
-  w.q_rank = c.take<int32_t>(nq);
+  w.pairs_q = c.take<int2>(nq);
   w.sorted_q = c.take<float4>(nq);
   w.q_count = c.take<int32_t>(3 * nq);
   w.q_rng = c.take<int2>(9 * nq);
@@ -104,9 +129,95 @@ RadiusWs carve(void* ws, int64_t nq, int64_t ns, int64_t batch) {
 }
 
 // ---------------------------------------------------------------- grid setup
-__global__ void grid_setup_kernel(const uint32_t* __restrict__ bbox,
+// Per-cloud bounding boxes without atomics: a block reduces one BBOX_PTS-point slice of ONE cloud into six words of
+// `partial` (same-address global atomics cost ~60 ns each across XCDs: the shared bbox_kernel of common.hip, six atomics
+// per 1024 points, took 32 us of the 8 x 200 k binning); grid_setup_kernel folds the partials.
+__global__ __launch_bounds__(256) void bbox_partial_kernel(const float* __restrict__ pts, const int32_t* __restrict__ off,
+                                                           const int32_t* __restrict__ blk_off, int nb,
+                                                           uint32_t* __restrict__ partial) {
+  __shared__ uint32_t red[6][256 / WAVE];
+  const int b0 = find_batch(blk_off, nb, (int)blockIdx.x);
+  const int p_first = off[b0] + ((int)blockIdx.x - blk_off[b0]) * BBOX_PTS;
+  const int p_end = min(off[b0 + 1], p_first + BBOX_PTS);
+  const int64_t f0 = (int64_t)p_first * 3;
+  const int count = (p_end - p_first) * 3;
+  // element f of the flat float stream belongs to axis (f0 + f) % 3; the stride 256 = 1 (mod 3), so a thread's
+  // consecutive elements cycle through the axes: slot k of (l3, h3) holds axis (ax0 + k) % 3
+  const int ax0 = (int)((f0 + threadIdx.x) % 3);
+  const float* src = pts + f0;
+  uint32_t l3[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, h3[3] = {0u, 0u, 0u};
+  for (int f = threadIdx.x; f < count; f += 6 * 256) {
+    uint32_t v[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] = f2ord(src[min(f + k * 256, count - 1)]);  // six independent loads in flight
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      if (f + k * 256 < count) {
+        l3[k % 3] = min(l3[k % 3], v[k]);
+        h3[k % 3] = max(h3[k % 3], v[k]);
+      }
+  }
+  uint32_t lo[3], hi[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int k = a - ax0 < 0 ? a - ax0 + 3 : a - ax0;  // slot that holds axis a
+    lo[a] = k == 0 ? l3[0] : (k == 1 ? l3[1] : l3[2]);
+    hi[a] = k == 0 ? h3[0] : (k == 1 ? h3[1] : h3[2]);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = (uint32_t)wave_min_u32(lo[a]);
+    hi[a] = (uint32_t)wave_max_u32(hi[a]);
+  }
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      red[a][w] = lo[a];
+      red[3 + a][w] = hi[a];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    uint32_t v = red[threadIdx.x][0];
+#pragma unroll
+    for (int i = 1; i < 256 / WAVE; ++i) v = threadIdx.x < 3 ? min(v, red[threadIdx.x][i]) : max(v, red[threadIdx.x][i]);
+    partial[(int64_t)blockIdx.x * 6 + threadIdx.x] = v;
+  }
+}
+
+__global__ void grid_setup_kernel(uint32_t* __restrict__ bbox, const uint32_t* __restrict__ partial,
+                                  const int32_t* __restrict__ blk_off,
                                   const int32_t* __restrict__ s_off, int nb, float radius, int xk_max,
-                                  BatchGrid* __restrict__ grids, RadiusHdr* __restrict__ hdr) {
+                                  BatchGrid* __restrict__ grids, RadiusHdr* __restrict__ hdr,
+                                  int32_t* __restrict__ sup_off) {
+  // fold the per-block partial boxes: one wave per cloud (looped), lanes over the cloud's blocks
+  {
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE, nw = blockDim.x / WAVE;
+    for (int b = w; b < nb; b += nw) {
+      uint32_t lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
+      for (int k = blk_off[b] + lane; k < blk_off[b + 1]; k += WAVE) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          lo[a] = min(lo[a], partial[(int64_t)k * 6 + a]);
+          hi[a] = max(hi[a], partial[(int64_t)k * 6 + 3 + a]);
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        lo[a] = (uint32_t)wave_min_u32(lo[a]);
+        hi[a] = (uint32_t)wave_max_u32(hi[a]);
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          bbox[b * 6 + a] = lo[a];
+          bbox[b * 6 + 3 + a] = hi[a];
+        }
+      }
+    }
+    __syncthreads();
+  }
   // one thread per cloud (looped), then a serial prefix by thread 0 (nb is small)
   for (int b = threadIdx.x; b < nb; b += blockDim.x) {
     BatchGrid g;
@@ -148,7 +259,7 @@ __global__ void grid_setup_kernel(const uint32_t* __restrict__ bbox,
     g.inv_cell = 1.0 / cell;
     g.inv_cell_x = g.inv_cell;
     g.xk = 1;
-    g.pad = 0;
+    g.sup_base = 0;
     if (n_b > 0 && isfinite(cell) && isfinite(g.inv_cell) && g.inv_cell > 0.0) {
       // refine x only: a support within r of a query is within +-k fine cells of it (|dx| k / cell < k / (1 + 2^-10))
       const double cap = (double)max(4096, 4 * n_b);
@@ -165,36 +276,47 @@ __global__ void grid_setup_kernel(const uint32_t* __restrict__ bbox,
       }
     }
     g.cell_base = 0;
+    g.sup_base = 0;
     grids[b] = g;
   }
   // exclusive prefix of the per-cloud cell counts: chunks of blockDim clouds, running carry in LDS
   // (a serial loop over global memory cost ~0.2 us per cloud)
-  __shared__ int s_cnt[256];
-  __shared__ int s_carry;
-  if (threadIdx.x == 0) s_carry = 0;
+  __shared__ int s_cnt[256], s_sup[256];
+  __shared__ int s_carry, s_carry_sup;
+  if (threadIdx.x == 0) s_carry = s_carry_sup = 0;
   __syncthreads();
   for (int b0 = 0; b0 < nb; b0 += blockDim.x) {
     const int b = b0 + threadIdx.x;
     const int cells = b < nb ? grids[b].dim[0] * grids[b].dim[1] * grids[b].dim[2] : 0;
     s_cnt[threadIdx.x] = cells;
+    s_sup[threadIdx.x] = (cells + SUP_CELLS - 1) >> SUP_SHIFT;
     __syncthreads();
     if (threadIdx.x == 0) {
-      int acc = s_carry;
+      int acc = s_carry, acs = s_carry_sup;
       for (int k = 0; k < (int)blockDim.x; ++k) {
-        const int c = s_cnt[k];
+        const int c = s_cnt[k], u = s_sup[k];
         s_cnt[k] = acc;
+        s_sup[k] = acs;
         acc += c;
+        acs += u;
       }
       s_carry = acc;
+      s_carry_sup = acs;
     }
     __syncthreads();
-    if (b < nb) grids[b].cell_base = s_cnt[threadIdx.x];
+    if (b < nb) {
+      grids[b].cell_base = s_cnt[threadIdx.x];
+      grids[b].sup_base = s_sup[threadIdx.x];
+      sup_off[b] = s_sup[threadIdx.x];
+    }
     __syncthreads();
   }
   if (threadIdx.x == 0) {
     hdr->total_cells = s_carry;
+    hdr->total_sup = s_carry_sup;
     hdr->max_count = 0;
     hdr->max_block_hits = 0;
+    sup_off[nb] = s_carry_sup;
   }
 }
 
@@ -214,61 +336,217 @@ __device__ inline int clamped_cell(const BatchGrid& g, float x, float y, float z
   return g.cell_base + c[0] + g.dim[0] * (c[1] + g.dim[1] * c[2]);
 }
 
-// ---------------------------------------------------------------- bin + histogram
-__global__ __launch_bounds__(256) void bin_count_kernel(
-    const float* __restrict__ s, int ns, const float* __restrict__ q, int nq,
-    const int32_t* __restrict__ s_off, const int32_t* __restrict__ q_off, int nb,
-    const BatchGrid* __restrict__ grids, int32_t* __restrict__ s_cell, int32_t* __restrict__ q_cell,
-    int32_t* __restrict__ s_rank, int32_t* __restrict__ q_rank, int32_t* __restrict__ cnt_s,
-    int32_t* __restrict__ cnt_q) {
-  // a block's 256 consecutive points belong to one cloud or two neighbours almost always: wave-uniform cloud lookup for
-  // the block's first and last point, and only blocks that straddle more clouds search per thread
-  const int i0 = blockIdx.x * blockDim.x, i = i0 + threadIdx.x;
-  const bool is_s = i0 < ns;  // blocks never mix supports and queries unless ns is not a multiple of 256
-  __shared__ int s_lohi[2];
-  if (threadIdx.x == 0) {
-    const int last = min(i0 + (int)blockDim.x, is_s ? ns : ns + nq) - 1;
-    s_lohi[0] = is_s ? find_batch(s_off, nb, i0) : find_batch(q_off, nb, i0 - ns);
-    s_lohi[1] = is_s ? find_batch(s_off, nb, last) : find_batch(q_off, nb, last - ns);
+// ---------------------------------------------------------------- binning: two-level counting sort
+// (Round 1-2 counted with one returning global atomic per point: device-scope atomics are served behind the per-XCD L2s,
+// 1.6 M of them took 64 us, plus a 25 MB clear of the cell table and a three-launch scan over it.)
+struct BinSide {
+  const float* pts;
+  int n;
+  const int32_t* off;     // [nb+1] cloud offsets
+  int32_t* cell;          // [n] cell of every point (written by the counting pass, read by the scatter pass)
+  int2* pairs;            // [n] (point, cell) grouped by super-cell
+  int32_t* sup_cnt;       // [nsup+1]
+  int32_t* sup_cur;       // [nsup+1]
+  int32_t* sup_start;     // [nsup+1]
+  float4* sorted;         // [n] {x, y, z, original index} in cell order
+  int32_t* cell_start;    // [cells+1] or null (queries need no cell table)
+};
+
+__global__ void bin_init_kernel(uint32_t* __restrict__ bbox, int nb, int32_t* __restrict__ zero, int nzero) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bbox && i < nb * 6) bbox[i] = (i % 6) < 3 ? 0xffffffffu : 0u;
+  for (int k = i; k < nzero; k += gridDim.x * blockDim.x) zero[k] = 0;
+}
+
+// COUNT: cell of every point, LDS histogram over the block's super-cells, one global add per non-empty super-cell.
+// SCATTER: the same histogram hands every point its rank inside (block, super-cell); one returning global add per
+// non-empty super-cell reserves the block's span; (point, cell) pairs go to their super-cell's range.
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void coarse_kernel(BinSide A, BinSide B, int blocks_a, int nb,
+                                                     const BatchGrid* __restrict__ grids) {
+  __shared__ int hist[COARSE_BINS];
+  __shared__ int s_info[4];
+  const bool second = (int)blockIdx.x >= blocks_a;
+  const BinSide& S = second ? B : A;
+  const int i0 = ((int)blockIdx.x - (second ? blocks_a : 0)) * COARSE_PTS;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    const int last = min(i0 + COARSE_PTS, S.n) - 1;
+    const int blo = find_batch(S.off, nb, i0), bhi = find_batch(S.off, nb, last);
+    const BatchGrid& gh = grids[bhi];
+    s_info[0] = blo;
+    s_info[1] = bhi;
+    s_info[2] = grids[blo].sup_base;
+    s_info[3] = gh.sup_base + ((gh.dim[0] * gh.dim[1] * gh.dim[2] + SUP_CELLS - 1) >> SUP_SHIFT);
   }
   __syncthreads();
-  const int blo = s_lohi[0], bhi = s_lohi[1];
-  if (i < ns) {
-    int b = blo;
-    if (is_s && bhi != blo) b = bhi == blo + 1 ? (i >= s_off[bhi] ? bhi : blo) : find_batch(s_off, nb, i);
-    if (!is_s) b = find_batch(s_off, nb, i);
-    const int c = clamped_cell(grids[b], s[3 * (int64_t)i], s[3 * (int64_t)i + 1], s[3 * (int64_t)i + 2]);
-    s_cell[i] = c;
-    s_rank[i] = atomicAdd(&cnt_s[c], 1);  // the returned count doubles as the slot inside the cell
-  } else if (i < ns + nq) {
-    const int j = i - ns;
-    int b = blo;
-    if (is_s) b = find_batch(q_off, nb, j);  // the one block that holds the last supports and the first queries
-    else if (bhi != blo) b = bhi == blo + 1 ? (j >= q_off[bhi] ? bhi : blo) : find_batch(q_off, nb, j);
-    const int c = clamped_cell(grids[b], q[3 * (int64_t)j], q[3 * (int64_t)j + 1], q[3 * (int64_t)j + 2]);
-    q_cell[j] = c;
-    q_rank[j] = atomicAdd(&cnt_q[c], 1);
+  const int blo = s_info[0], bhi = s_info[1], smin = s_info[2], smax = s_info[3];
+  const bool in_lds = smax - smin <= COARSE_BINS;  // else: a global atomic per point (clouds with > 2 M cells per block span)
+  if (in_lds)
+    for (int k = tid; k < smax - smin; k += 256) hist[k] = 0;
+  __syncthreads();
+  constexpr int PER = COARSE_PTS / 256;
+  int sup[PER], rk[PER], cc[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = i0 + k * 256 + tid;
+    sup[k] = -1;
+    rk[k] = 0;
+    cc[k] = 0;
+    if (i < S.n) {
+      int b = blo;
+      if (bhi != blo) b = bhi == blo + 1 ? (i >= S.off[bhi] ? bhi : blo) : find_batch(S.off, nb, i);
+      const BatchGrid& g = grids[b];
+      int c;
+      if (SCATTER) {
+        c = S.cell[i];
+      } else {
+        c = clamped_cell(g, S.pts[3 * (int64_t)i], S.pts[3 * (int64_t)i + 1], S.pts[3 * (int64_t)i + 2]);
+        S.cell[i] = c;
+      }
+      cc[k] = c;
+      sup[k] = g.sup_base + ((c - g.cell_base) >> SUP_SHIFT);
+      if (in_lds) {
+        if (SCATTER) rk[k] = atomicAdd(&hist[sup[k] - smin], 1);
+        else atomicAdd(&hist[sup[k] - smin], 1);
+      } else {
+        if (SCATTER) rk[k] = atomicAdd(&S.sup_cur[sup[k]], 1);
+        else atomicAdd(&S.sup_cnt[sup[k]], 1);
+      }
+    }
+  }
+  __syncthreads();
+  if (in_lds) {
+    for (int k = tid; k < smax - smin; k += 256) {
+      const int cnt = hist[k];
+      if (cnt) {
+        if (SCATTER) hist[k] = atomicAdd(&S.sup_cur[smin + k], cnt);  // the block's span inside the super-cell
+        else atomicAdd(&S.sup_cnt[smin + k], cnt);
+      }
+    }
+  }
+  if (!SCATTER) return;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = i0 + k * 256 + tid;
+    if (sup[k] >= 0) {
+      const int dst = S.sup_start[sup[k]] + (in_lds ? hist[sup[k] - smin] : 0) + rk[k];
+      S.pairs[dst] = make_int2(i, cc[k]);
+    }
   }
 }
 
-__global__ __launch_bounds__(256) void scatter_kernel(
-    const float* __restrict__ s, int ns, const float* __restrict__ q, int nq,
-    const int32_t* __restrict__ s_cell, const int32_t* __restrict__ q_cell,
-    const int32_t* __restrict__ start_s, const int32_t* __restrict__ start_q,
-    const int32_t* __restrict__ s_rank, const int32_t* __restrict__ q_rank, float4* __restrict__ sorted_s,
-    float4* __restrict__ sorted_q) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < ns) {
-    const int c = s_cell[i];
-    const int slot = start_s[c] + s_rank[i];
-    sorted_s[slot] = make_float4(s[3 * (int64_t)i], s[3 * (int64_t)i + 1], s[3 * (int64_t)i + 2],
-                                 __int_as_float(i));
-  } else if (i < ns + nq) {
-    const int j = i - ns;
-    const int c = q_cell[j];
-    const int slot = start_q[c] + q_rank[j];
-    sorted_q[slot] = make_float4(q[3 * (int64_t)j], q[3 * (int64_t)j + 1], q[3 * (int64_t)j + 2],
-                                 __int_as_float(j));
+// exclusive scan of the super-cell counts (one block per side; total_sup is only known on the device)
+__global__ __launch_bounds__(1024) void sup_scan_kernel(BinSide A, BinSide B, int first_side, const RadiusHdr* __restrict__ hdr) {
+  const BinSide& S = ((int)blockIdx.x + first_side) ? B : A;
+  __shared__ int wsum[1024 / WAVE];
+  __shared__ int s_carry;
+  const int n = hdr->total_sup, tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + tid;
+    const int v = i < n ? S.sup_cnt[i] : 0;
+    const int inc = wave_incl_scan_add_dpp(v);
+    if (lane == WAVE - 1) wsum[w] = inc;
+    __syncthreads();
+    int base = s_carry, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 1024 / WAVE; ++k) {
+      const int x = wsum[k];
+      if (k < w) base += x;
+      tot += x;
+    }
+    if (i < n) S.sup_start[i] = base + inc - v;
+    __syncthreads();
+    if (tid == 0) s_carry += tot;
+    __syncthreads();
+  }
+  if (tid == 0) S.sup_start[n] = s_carry;
+}
+
+// one workgroup per super-cell (grid-stride: the number of super-cells is only known on the device): LDS histogram of its
+// <= SUP_CELLS cells, scan -> cell starts, scatter into cell order.  A thread keeps up to FINE_PER of the super-cell's points
+// in registers: the (point, cell) pairs are read once and the coordinates are requested before the LDS work starts.
+constexpr int FINE_PER = 8;
+
+__global__ __launch_bounds__(256) void fine_kernel(BinSide A, BinSide B, int blocks_a, int nb,
+                                                   const BatchGrid* __restrict__ grids, const int32_t* __restrict__ sup_off,
+                                                   const RadiusHdr* __restrict__ hdr) {
+  __shared__ int hist[SUP_CELLS];
+  __shared__ int wsum[256 / WAVE];
+  const bool second = (int)blockIdx.x >= blocks_a;
+  const BinSide& S = second ? B : A;
+  const int stride = second ? (int)gridDim.x - blocks_a : blocks_a;
+  const int total_sup = hdr->total_sup;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+  for (int sc = (int)blockIdx.x - (second ? blocks_a : 0); sc < total_sup; sc += stride) {
+    const int a = S.sup_start[sc], e = S.sup_start[sc + 1];
+    const int b = find_batch(sup_off, nb, sc);
+    const BatchGrid& g = grids[b];
+    const int ls = sc - g.sup_base;
+    const int first = g.cell_base + ls * SUP_CELLS;
+    const int ncell = min(SUP_CELLS, g.dim[0] * g.dim[1] * g.dim[2] - ls * SUP_CELLS);
+    hist[tid] = 0;
+    hist[tid + 256] = 0;
+    const bool in_regs = e > a && e - a <= 256 * FINE_PER;
+    int2 pr[FINE_PER];
+    float cx[FINE_PER], cy[FINE_PER], cz[FINE_PER];
+    if (in_regs) {
+#pragma unroll
+      for (int k = 0; k < FINE_PER; ++k) pr[k] = S.pairs[min(a + k * 256 + tid, e - 1)];
+#pragma unroll
+      for (int k = 0; k < FINE_PER; ++k) {
+        const float* src = S.pts + 3 * (int64_t)pr[k].x;
+        cx[k] = src[0];
+        cy[k] = src[1];
+        cz[k] = src[2];
+      }
+    }
+    __syncthreads();
+    if (in_regs) {
+#pragma unroll
+      for (int k = 0; k < FINE_PER; ++k)
+        if (a + k * 256 + tid < e) atomicAdd(&hist[pr[k].y - first], 1);
+    } else {
+      for (int p = a + tid; p < e; p += 256) atomicAdd(&hist[S.pairs[p].y - first], 1);
+    }
+    __syncthreads();
+    const int v0 = hist[2 * tid], v1 = hist[2 * tid + 1];
+    const int inc = wave_incl_scan_add_dpp(v0 + v1);
+    if (lane == WAVE - 1) wsum[w] = inc;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < 256 / WAVE; ++k)
+      if (k < w) base += wsum[k];
+    const int ex = base + inc - (v0 + v1);
+    hist[2 * tid] = ex;  // becomes the cursor of the cell
+    hist[2 * tid + 1] = ex + v0;
+    if (S.cell_start) {
+      if (2 * tid < ncell) S.cell_start[first + 2 * tid] = a + ex;
+      if (2 * tid + 1 < ncell) S.cell_start[first + 2 * tid + 1] = a + ex + v0;
+      if (sc == total_sup - 1 && tid == 0) S.cell_start[first + ncell] = e;  // end of the last cell of the last cloud
+    }
+    __syncthreads();
+    // order inside a cell: arrival (the search results do not depend on it)
+    if (in_regs) {
+#pragma unroll
+      for (int k = 0; k < FINE_PER; ++k)
+        if (a + k * 256 + tid < e) {
+          const int slot = atomicAdd(&hist[pr[k].y - first], 1);
+          S.sorted[a + slot] = make_float4(cx[k], cy[k], cz[k], __int_as_float(pr[k].x));
+        }
+    } else {
+      for (int p = a + tid; p < e; p += 256) {
+        const int2 q = S.pairs[p];
+        const int slot = atomicAdd(&hist[q.y - first], 1);
+        const float* src = S.pts + 3 * (int64_t)q.x;
+        S.sorted[a + slot] = make_float4(src[0], src[1], src[2], __int_as_float(q.x));
+      }
+    }
+    __syncthreads();  // hist is cleared by the next super-cell of this workgroup
   }
 }
 
@@ -503,15 +781,16 @@ __global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))
       }
       constexpr int PER = L::STAGE_CAP / L::THREADS;
       float4 v[PER];
+      // unconditional loads on a clamped index (pad_value = number of supports): behind `if (f < total)` the compiler
+      // keeps every load behind the previous one's use -- four memory round trips instead of one
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
         const int f = tid + u * L::THREADS;
-        if (f < total) {
-          int src = bl[0] + f;
+        unsigned src = (unsigned)bl[0] + (unsigned)f;
 #pragma unroll
-          for (int k = 1; k < NBAND; ++k) src = f >= bs[k] ? bl[k] + (f - bs[k]) : src;
-          v[u] = sorted_s[src];
-        }
+        for (int k = 1; k < NBAND; ++k) src = f >= bs[k] ? (unsigned)bl[k] + (unsigned)(f - bs[k]) : src;
+        src = f < total ? src : 0u;
+        v[u] = sorted_s[min(src, (unsigned)((int)pad_value - 1))];
       }
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
@@ -680,30 +959,41 @@ __global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))
 
 // ---------------------------------------------------------------- single pass for a width known before the launch
 // radius_search(..., neighbor_limit) (modules/ops/radius_search.py:7-27) keeps min(max_count, neighbor_limit) columns, so the
-// caller can allocate (nq, limit) rows BEFORE anything is counted and one kernel does the whole search: set-up, staging
-// and candidate tests as in the COUNT pass above (hit masks stay in registers), a block scan of the hit counts, the hits
-// re-read from the staged candidates (LDS, not a second trip to memory) into per-query key segments, ranking by counting
-// and the row stores.  Nothing per query goes through global memory in between (the two-pass path writes and re-reads
-// 180 bytes of ranges / masks / counts per query) and the host does not sit between two launches.
+// caller can allocate (nq, limit) rows BEFORE anything is counted and one kernel does the whole search:
+//   set-up, staging  as in the COUNT pass above
+//   tests            hits are remembered in two 32-bit masks per thread (even / odd candidates of its enumeration)
+//   scan             hit counts -> per-query segments in the block's key area (LDS)
+//   decode           every thread walks its masks, one even and one odd hit per step, and leaves (query slot, staged
+//                    position) words in its part of the segment -- no arithmetic in the loop whose trip count diverges
+//   keys             one thread per hit (balanced): distance bits and support index from the staged planes
+//   ranking          one thread per hit: rank = number of smaller distance words in the segment (32-bit compares, four keys
+//                    per ds_read_b128).  The index goes to row[rank] in an LDS row buffer with ds_min: equal distances
+//                    collide there, leave a hole behind them, and only such rows are ranked again on (distance, index)
+//   rows             whole rows leave as contiguous 16-byte pieces
+// Nothing per query goes through global memory in between (the two-pass path writes and re-reads 180 bytes of ranges /
+// masks / counts per query) and the host does not sit between two launches.
 //   blk_stats[2 blk]     = largest hit count of a query in the block   (max -> the width the reference would return)
 //   blk_stats[2 blk + 1] = 1 if a single query had more hits than the block's key area holds (the caller then repeats
-//                          the search on the two-pass path; never seen below ~3 500 neighbours per query)
-// A block whose hits do not fit its key area at once works through its queries in groups.
+//                          the search on the two-pass path)
+// A block whose hits do not fit its key area at once works through its queries in groups (direct stores, exact compare).
 template <int RQ>
 struct FusedLds {
   static constexpr int THREADS = NSUB * RQ;
   static constexpr int STAGE_CAP = 12 * RQ;
   static constexpr int TABLE_MAX = 256;
-  // ints: offs[RQ+1], orig[RQ], qtot[RQ], wsum[2 * THREADS/64], sub[3*RQ], band_lo[9], band_hi[9], band_base[10], misc[4]
-  static constexpr int N_INTS = (RQ + 1) + RQ + RQ + 2 * (THREADS / WAVE) + NSUB * RQ + 9 + 9 + 10 + 4;
-  static constexpr size_t STAGE_OFF = (size_t)(N_INTS * 4 + 15) / 16 * 16;
-  static size_t region_bytes(int width) {  // candidate planes x, y, z, index; the row buffer takes their place later
-    const size_t st = (size_t)STAGE_CAP * 16, rb = ((size_t)RQ * width * 4 + 15) / 16 * 16;
+  // ints: offs[RQ+1], orig[RQ], qtot[RQ], wsum[2 * THREADS/64], sub[3*RQ], band_lo[9], band_hi[9], band_base[10], misc[4],
+  //       tie flags[RQ]
+  static constexpr int N_INTS = (RQ + 1) + RQ + RQ + 2 * (THREADS / WAVE) + NSUB * RQ + 9 + 9 + 10 + 4 + RQ;
+  static constexpr size_t QBUF_OFF = (size_t)(N_INTS * 4 + 15) / 16 * 16;  // float4 per query slot
+  static constexpr size_t STAGE_OFF = QBUF_OFF + (size_t)RQ * 16;
+  static size_t region_bytes(int width) {  // candidate planes x, y, z, index (+ slack for the 4-wide tail reads); the row
+    const size_t st = (size_t)STAGE_CAP * 16 + 16, rb = ((size_t)RQ * width * 4 + 15) / 16 * 16;  // buffer takes their place
     return st > rb ? st : rb;
   }
   static size_t tables_bytes(int tcap) { return tcap > 0 ? ((size_t)(tcap + 1) * 4 + 15) / 16 * 16 + (size_t)tcap * sizeof(BatchGrid) : 0; }
+  static size_t hits_bytes(int cap) { return (size_t)(cap + 16) * 9; }  // distance words, (slot, position) / index words, row bytes
   static size_t total(int width, int cap, int tcap) {
-    const size_t hits = (size_t)cap * 9, tb = tables_bytes(tcap);
+    const size_t hits = hits_bytes(cap), tb = tables_bytes(tcap);
     return STAGE_OFF + region_bytes(width) + (hits > tb ? hits : tb);
   }
 };
@@ -711,11 +1001,19 @@ struct FusedLds {
 template <int RQ, bool ROWBUF>
 __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
     const float4* __restrict__ sorted_q, int nq, const int32_t* __restrict__ q_off, int nb,
-    const BatchGrid* __restrict__ grids, const int32_t* __restrict__ start_s, const float4* __restrict__ sorted_s, float r2,
-    int32_t* __restrict__ blk_stats, int width, int64_t pad_value, int64_t* __restrict__ out, int cap, int region_bytes,
-    int mono) {
+    const BatchGrid* __restrict__ grids, const int32_t* __restrict__ start_s, const float4* __restrict__ sorted_s, int ns_total,
+    float r2, int32_t* __restrict__ blk_stats, int width, int64_t pad_value, int64_t* __restrict__ out, int cap,
+    int region_bytes, int mono, int dbg_stop) {
+  // dbg_stop (GR_RADIUS_FUSED_STOP, measurement only): leave after phase k -- 1 set-up, 2 staging, 3 tests, 4 scan,
+  // 5 decode, 6 keys, 7 ranking; 0 = the whole kernel
+#define GR_FUSED_STOP(K, VALUE)                                    \
+  if (dbg_stop == (K)) {                                           \
+    if ((VALUE) == 0x7fffffff) blk_stats[2 * blk] = tid;           \
+    return;                                                        \
+  }
   using L = FusedLds<RQ>;
   static_assert(RQ % WAVE == 0 && RQ <= 256, "row ids are bytes; waves must not straddle slabs");
+  constexpr unsigned PADMARK = 0xffffffffu;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* offs = reinterpret_cast<int*>(smem);
   int* orig = offs + (RQ + 1);
@@ -725,15 +1023,19 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
   int* band_lo = sub + NSUB * RQ;
   int* band_hi = band_lo + NBAND;
   int* band_base = band_hi + NBAND;
-  int* misc = band_base + NBAND + 1;
+  int* misc = band_base + NBAND + 1;  // [0] group search, [1] number of rows with equal distances
+  int* tie_rows = misc + 4;
+  float4* qbuf = reinterpret_cast<float4*>(smem + L::QBUF_OFF);
   float* sx = reinterpret_cast<float*>(smem + L::STAGE_OFF);
   float* sy = sx + L::STAGE_CAP;
   float* sz = sy + L::STAGE_CAP;
   int* si = reinterpret_cast<int*>(sz + L::STAGE_CAP);
-  unsigned int* rowbuf = reinterpret_cast<unsigned int*>(smem + L::STAGE_OFF);  // takes the planes' place after the emission
+  unsigned int* rowbuf = reinterpret_cast<unsigned int*>(smem + L::STAGE_OFF);  // takes the planes' place after the keys pass
   char* hreg = smem + L::STAGE_OFF + region_bytes;
-  unsigned long long* hits = reinterpret_cast<unsigned long long*>(hreg);
-  unsigned char* rows = reinterpret_cast<unsigned char*>(hreg + (size_t)cap * 8);
+  unsigned int* hd = reinterpret_cast<unsigned int*>(hreg);      // distance bits per hit slot
+  unsigned int* hm = hd + (cap + 16);                            // (slot << 16 | staged position), then the support index
+  unsigned char* hrow = reinterpret_cast<unsigned char*>(hm + (cap + 16));
+  const int dummy = cap + 8;  // a slot nobody reads: the target of the decode's "no hit" lanes
   // per-cloud tables for the set-up live where the keys go later
   const int tcap = nb <= L::TABLE_MAX ? nb : 0;
   int* s_qoff = reinterpret_cast<int*>(hreg);
@@ -753,6 +1055,8 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
     band_lo[tid] = 0x7fffffff;
     band_hi[tid] = 0;
   }
+  if (tid == 0) misc[1] = 0;
+  if (tid < RQ) tie_rows[tid] = 0;
   const bool tables_in_lds = tcap > 0;
   if (tables_in_lds) {
     for (int i = tid; i <= nb; i += L::THREADS) s_qoff[i] = q_off[i];
@@ -791,10 +1095,14 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
         }
       }
     }
-    if (j == 0) orig[slot] = __float_as_int(qp.w);
+    if (j == 0) {
+      orig[slot] = __float_as_int(qp.w);
+      qbuf[slot] = qp;
+    }
   } else if (j == 0) {
     orig[slot] = -1;
   }
+  GR_FUSED_STOP(1, p0[0] + p0[1] + p0[2] + p1[0] + p1[1] + p1[2])
   // ---- block-wide extent of every band (waves are slab-uniform: band index = 3*j + i)
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -829,6 +1137,8 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
   __syncthreads();
   const bool staged = band_base[NBAND] <= L::STAGE_CAP;
   if (staged) {
+    // one flat pass over the union of the nine bands.  The loads are UNCONDITIONAL (index clamped into the support array):
+    // behind `if (f < total)` the compiler keeps every load behind the previous one's use -- four memory round trips
     const int total = band_base[NBAND];
     int bl[NBAND], bs[NBAND];
 #pragma unroll
@@ -841,12 +1151,11 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int f = tid + u * L::THREADS;
-      if (f < total) {
-        int src = bl[0] + f;
+      unsigned src = (unsigned)bl[0] + (unsigned)f;
 #pragma unroll
-        for (int k = 1; k < NBAND; ++k) src = f >= bs[k] ? bl[k] + (f - bs[k]) : src;
-        v[u] = sorted_s[src];
-      }
+      for (int k = 1; k < NBAND; ++k) src = f >= bs[k] ? (unsigned)bl[k] + (unsigned)(f - bs[k]) : src;
+      src = f < total ? src : 0u;
+      v[u] = sorted_s[min(src, (unsigned)(ns_total - 1))];
     }
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
@@ -860,42 +1169,45 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
     }
     __syncthreads();
   }
-  // ---- test every candidate; hits are remembered as a bit mask in enumeration order (band 0, 1, 2)
-  unsigned long long mask = 0ull;
+  GR_FUSED_STOP(2, (int)sx[tid])
+  // ---- test every candidate, four per step.  Enumeration slot c = 4 * step + k (k = 0..3; a band's last step is padded);
+  //      even slots go to `lo` (bit c / 2), odd slots to `hi`: the decode below takes one hit from each per step
+  unsigned lo = 0u, hi = 0u;
   int n = 0;
   int rel[3] = {0, 0, 0};
   if (staged) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) rel[i] = band_base[3 * j + i] - band_lo[3 * j + i];
   }
+  const int len0 = p1[0] - p0[0], len1 = p1[1] - p0[1], len2 = p1[2] - p0[2];
+  const int nit0 = (len0 + 3) >> 2, nit1 = (len1 + 3) >> 2, nit2 = (len2 + 3) >> 2;
   if (valid && staged) {
-    int bitpos = 0;
+    int sh = 0;  // 2 * step
     const f32x2 qx = {qp.x, qp.x}, qy = {qp.y, qp.y}, qz = {qp.z, qp.z};
+    auto step4 = [&](int p, unsigned va, unsigned vb) {
+      const f32x2 xa = {sx[p], sx[p + 1]}, xb = {sx[p + 2], sx[p + 3]};
+      const f32x2 ya = {sy[p], sy[p + 1]}, yb = {sy[p + 2], sy[p + 3]};
+      const f32x2 za = {sz[p], sz[p + 1]}, zb = {sz[p + 2], sz[p + 3]};
+      // nanoflann.hpp:432-440: result += diff*diff for x, y, z starting from 0 (two candidates per op)
+      const f32x2 dxa = qx - xa, dya = qy - ya, dza = qz - za;
+      const f32x2 dxb = qx - xb, dyb = qy - yb, dzb = qz - zb;
+      const f32x2 da = (dxa * dxa + dya * dya) + dza * dza;
+      const f32x2 db = (dxb * dxb + dyb * dyb) + dzb * dzb;
+      const unsigned ha = ((da.x < r2 ? 1u : 0u) | (db.x < r2 ? 2u : 0u)) & va;  // candidates p, p + 2
+      const unsigned hb = ((da.y < r2 ? 1u : 0u) | (db.y < r2 ? 2u : 0u)) & vb;  // candidates p + 1, p + 3
+      lo |= ha << sh;  // steps past 16 shift out of range; such threads re-walk their candidates instead (by_mask below)
+      hi |= hb << sh;
+      n += __popc(ha) + __popc(hb);
+      sh += 2;
+    };
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       int p = p0[i] + rel[i];
       const int e = p1[i] + rel[i];
-      for (; p + 4 <= e; p += 4) {
-        const f32x2 xa = {sx[p], sx[p + 1]}, xb = {sx[p + 2], sx[p + 3]};
-        const f32x2 ya = {sy[p], sy[p + 1]}, yb = {sy[p + 2], sy[p + 3]};
-        const f32x2 za = {sz[p], sz[p + 1]}, zb = {sz[p + 2], sz[p + 3]};
-        // nanoflann.hpp:432-440: result += diff*diff for x, y, z starting from 0 (two lanes per op)
-        const f32x2 dxa = qx - xa, dya = qy - ya, dza = qz - za;
-        const f32x2 dxb = qx - xb, dyb = qy - yb, dzb = qz - zb;
-        const f32x2 da = (dxa * dxa + dya * dya) + dza * dza;
-        const f32x2 db = (dxb * dxb + dyb * dyb) + dzb * dzb;
-        const unsigned hb = (da.x < r2 ? 1u : 0u) | (da.y < r2 ? 2u : 0u) | (db.x < r2 ? 4u : 0u) | (db.y < r2 ? 8u : 0u);
-        if (bitpos < 64) mask |= (unsigned long long)hb << bitpos;
-        n += __popc(hb);
-        bitpos += 4;
-      }
-      for (; p < e; ++p) {
-        const float dx = qp.x - sx[p], dy = qp.y - sy[p], dz = qp.z - sz[p];
-        const float d = (dx * dx + dy * dy) + dz * dz;
-        const bool hit = d < r2;
-        if (hit && bitpos < 64) mask |= 1ull << bitpos;
-        n += hit ? 1 : 0;
-        ++bitpos;
+      for (; p + 4 <= e; p += 4) step4(p, 3u, 3u);
+      if (p < e) {  // padded last step: 1..3 candidates left (the reads past the band stay inside the planes)
+        const int left = e - p;
+        step4(p, left >= 3 ? 3u : 1u, left >= 2 ? 1u : 0u);
       }
     }
   } else if (valid) {
@@ -908,6 +1220,7 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
         n += d < r2 ? 1 : 0;
       }
   }
+  GR_FUSED_STOP(3, n + (int)(lo >> 20) + (int)(hi >> 20))
   sub[tid] = n;
   __syncthreads();
   // ---- block scan of the per-query totals; every slab group does it redundantly (no cross-group sync)
@@ -915,32 +1228,32 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
 #pragma unroll
   for (int i = 0; i < NSUB; ++i) c[i] = sub[i * RQ + slot];
   const int tot = c[0] + c[1] + c[2];
-  const int tot2 = (tot + 1) & ~1;  // segments start on even slots: the rank loop reads two keys per ds_read_b128
-  const int inc = wave_incl_scan_add_dpp(tot2);
+  const int tot4 = (tot + 3) & ~3;  // segments start on multiples of four slots: the rank loop reads four keys per ds_read_b128
+  const int inc = wave_incl_scan_add_dpp(tot4);
   const int wmx = wave_max_i32_dpp(tot);
   if (lane == WAVE - 1) wsum[tid / WAVE] = inc;
   if (lane == 0) wsum[L::THREADS / WAVE + tid / WAVE] = wmx;
   __syncthreads();
-  int base = 0, total2 = 0;
+  int base = 0, total4 = 0;
 #pragma unroll
   for (int i = 0; i < RQ / WAVE; ++i) {
     const int w = wsum[j * (RQ / WAVE) + i];
     if (i < slot / WAVE) base += w;
-    total2 += w;
+    total4 += w;
   }
-  const int q_start = base + inc - tot2;
+  const int q_start = base + inc - tot4;
   const int my_off = q_start + (j > 0 ? c[0] : 0) + (j > 1 ? c[1] : 0);
   if (j == 0) {
     offs[slot] = q_start;
     qtot[slot] = tot;
-    if (slot == RQ - 1) offs[RQ] = q_start + tot2;
+    if (slot == RQ - 1) offs[RQ] = q_start + tot4;
   }
+  GR_FUSED_STOP(4, my_off + total4)
   int blk_flag = 0;
-  const bool multi = total2 > cap;
+  const bool multi = total4 > cap;
   const bool use_rowbuf = ROWBUF && !multi;
   const int rows_here = min(RQ, nq - blk * RQ);
-  const int len0 = p1[0] - p0[0], len1 = p1[1] - p0[1], len2 = p1[2] - p0[2];
-  const bool by_mask = staged && (len0 + len1 + len2 <= 64);
+  const bool by_mask = staged && (nit0 + nit1 + nit2 <= 16);
   if (multi) __syncthreads();  // offs complete
   int glo = 0;
   while (glo < RQ) {
@@ -959,86 +1272,138 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
       }
     }
     const int gbase = multi ? offs[glo] : 0;
-    // ---- emission: (distance, index) keys of my hits into my query's segment
-    if (valid && !skip && slot >= glo && slot < ghi && n > 0) {
+    const bool mine = valid && !skip && slot >= glo && slot < ghi;
+    // ---- decode: (query slot, staged position) words of my hits into my part of my query's segment
+    if (mine && j == NSUB - 1)
+      for (int k = tot; k < tot4; ++k) hm[q_start - gbase + k] = PADMARK;
+    if (mine && n > 0) {
       int w = my_off - gbase;
-      if (tot2 != tot && j == NSUB - 1) {  // pad slot: larger than every real key, skipped by the rank phase
-        hits[q_start - gbase + tot] = ~0ull;
-        rows[q_start - gbase + tot] = 0xff;
-      }
-      auto emit = [&](float x, float y, float z, int idx) {
-        const float dx = qp.x - x, dy = qp.y - y, dz = qp.z - z;
-        const float d = (dx * dx + dy * dy) + dz * dz;
-        if (d < r2) {
-          hits[w] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)idx;  // d >= 0: bit pattern is monotone
-          rows[w] = (unsigned char)slot;
-          ++w;
-        }
-      };
+      const unsigned tag = (unsigned)slot << 16;
       if (by_mask) {
-        unsigned long long bits = mask;
-        const int s0 = p0[0] + rel[0], s1 = p0[1] + rel[1] - len0, s2 = p0[2] + rel[2] - len0 - len1;
-        while (bits) {
-          const int b0 = __ffsll((long long)bits) - 1;
-          bits &= bits - 1;
-          int b1 = -1;
-          if (bits) {
-            b1 = __ffsll((long long)bits) - 1;
-            bits &= bits - 1;
-          }
-          const int pa = b0 + (b0 < len0 ? s0 : (b0 < len0 + len1 ? s1 : s2));
-          const int pb = b1 < 0 ? pa : b1 + (b1 < len0 ? s0 : (b1 < len0 + len1 ? s1 : s2));
-          const float xa = sx[pa], ya = sy[pa], za = sz[pa], xb = sx[pb], yb = sy[pb], zb = sz[pb];
-          const int ia = si[pa], ib = si[pb];
-          emit(xa, ya, za, ia);
-          if (b1 >= 0) emit(xb, yb, zb, ib);
+        const int c1 = 4 * nit0, c2 = 4 * (nit0 + nit1);
+        const int s0 = p0[0] + rel[0], s1 = p0[1] + rel[1] - c1, s2 = p0[2] + rel[2] - c2;
+        unsigned ml = lo, mh = hi;
+        while (ml | mh) {
+          const int ba = __ffs((int)ml) - 1, bb = __ffs((int)mh) - 1;  // -1: none left on that side
+          ml &= ml - 1u;
+          mh &= mh - 1u;
+          const int ca = 2 * ba, cb = 2 * bb + 1;
+          const int pa = ca + (ca < c1 ? s0 : (ca < c2 ? s1 : s2));
+          const int pb = cb + (cb < c1 ? s0 : (cb < c2 ? s1 : s2));
+          const int wa = ba >= 0 ? w : dummy;
+          w += ba >= 0 ? 1 : 0;
+          const int wb = bb >= 0 ? w : dummy;
+          w += bb >= 0 ? 1 : 0;
+          hm[wa] = tag | (unsigned)pa;
+          hm[wb] = tag | (unsigned)pb;
         }
       } else if (staged) {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-          for (int p = p0[i] + rel[i]; p < p1[i] + rel[i]; ++p) emit(sx[p], sy[p], sz[p], si[p]);
+          for (int p = p0[i] + rel[i]; p < p1[i] + rel[i]; ++p) {
+            const float dx = qp.x - sx[p], dy = qp.y - sy[p], dz = qp.z - sz[p];
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            if (d < r2) hm[w++] = tag | (unsigned)p;
+          }
       } else {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
           for (int p = p0[i]; p < p1[i]; ++p) {
             const float4 sp = sorted_s[p];
-            emit(sp.x, sp.y, sp.z, __float_as_int(sp.w));
+            const float dx = qp.x - sp.x, dy = qp.y - sp.y, dz = qp.z - sp.z;
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            if (d < r2) {
+              hm[w] = (unsigned)p;  // position in the cell-ordered support array
+              hrow[w] = (unsigned char)slot;
+              ++w;
+            }
           }
       }
-    } else if (valid && !skip && slot >= glo && slot < ghi && tot2 != tot && j == NSUB - 1) {
-      hits[q_start - gbase + tot] = ~0ull;
-      rows[q_start - gbase + tot] = 0xff;
     }
     __syncthreads();
-    // ---- one thread per hit: rank inside the segment by counting, then the final slot (or the row buffer)
+    GR_FUSED_STOP(5, (int)hm[tid])
+    // ---- keys: one thread per hit slot -- distance bits and support index (balanced: no lane waits for a longer list)
     const int group_hits = skip ? 0 : offs[ghi] - gbase;
     for (int e = tid; e < group_hits; e += L::THREADS) {
-      const int r = rows[e];
+      const unsigned m = hm[e];
+      if (m == PADMARK) {  // larger than every real key; skipped by the ranking
+        hd[e] = 0xffffffffu;
+        hrow[e] = 0xff;
+        continue;
+      }
+      float x, y, z;
+      int idx, r;
+      if (staged) {
+        const int pp = (int)(m & 0xffffu);
+        r = (int)(m >> 16);
+        x = sx[pp];
+        y = sy[pp];
+        z = sz[pp];
+        idx = si[pp];
+        hrow[e] = (unsigned char)r;
+      } else {
+        const float4 sp = sorted_s[m];
+        r = hrow[e];
+        x = sp.x;
+        y = sp.y;
+        z = sp.z;
+        idx = __float_as_int(sp.w);
+      }
+      const float4 qq = qbuf[r];
+      const float dx = qq.x - x, dy = qq.y - y, dz = qq.z - z;
+      const float d = (dx * dx + dy * dy) + dz * dz;
+      hd[e] = __float_as_uint(d);  // d >= 0: the bit pattern is monotone
+      hm[e] = (unsigned)idx;
+    }
+    __syncthreads();
+    GR_FUSED_STOP(6, (int)hd[tid])
+    if (use_rowbuf) {
+      // the planes are dead: their place becomes the row buffer, every entry "not written"
+      const int quads = (rows_here * width + 3) >> 2;
+      for (int i = tid; i < quads; i += L::THREADS) reinterpret_cast<uint4*>(rowbuf)[i] = make_uint4(PADMARK, PADMARK, PADMARK, PADMARK);
+      __syncthreads();
+    }
+    // ---- ranking: one thread per hit
+    for (int e = tid; e < group_hits; e += L::THREADS) {
+      const int r = hrow[e];
       if (r == 0xff) continue;
-      const int a = offs[r] - gbase, len = offs[r + 1] - offs[r];  // both even
-      const unsigned long long key = hits[e];
-      const ulonglong2* seg = reinterpret_cast<const ulonglong2*>(hits + a);
+      const int a = offs[r] - gbase, quads = (offs[r + 1] - offs[r]) >> 2;
+      const unsigned d = hd[e];
+      const unsigned idx = hm[e];
+      const uint4* seg = reinterpret_cast<const uint4*>(hd + a);
       int rank = 0;
-      int jj = 0;
-      for (; jj + 4 <= len / 2; jj += 4) {
-        ulonglong2 hk[4];
+      if (use_rowbuf) {
+        int jj = 0;
+        for (; jj + 4 <= quads; jj += 4) {
+          uint4 k4[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) hk[u] = seg[jj + u];
+          for (int u = 0; u < 4; ++u) k4[u] = seg[jj + u];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) rank += (hk[u].x < key ? 1 : 0) + (hk[u].y < key ? 1 : 0);
-      }
-      for (; jj < len / 2; ++jj) {
-        const ulonglong2 h = seg[jj];
-        rank += (h.x < key ? 1 : 0) + (h.y < key ? 1 : 0);
-      }
-      if (rank < width) {
-        if (use_rowbuf) rowbuf[r * width + rank] = (unsigned int)(key & 0xffffffffull);
-        else out[(int64_t)orig[r] * width + rank] = (int64_t)(unsigned int)(key & 0xffffffffull);
+          for (int u = 0; u < 4; ++u)
+            rank += (k4[u].x < d ? 1 : 0) + (k4[u].y < d ? 1 : 0) + (k4[u].z < d ? 1 : 0) + (k4[u].w < d ? 1 : 0);
+        }
+        for (; jj < quads; ++jj) {
+          const uint4 k = seg[jj];
+          rank += (k.x < d ? 1 : 0) + (k.y < d ? 1 : 0) + (k.z < d ? 1 : 0) + (k.w < d ? 1 : 0);
+        }
+        // equal distances meet in one entry (the smallest index stays) and leave the next one unwritten
+        if (rank < width) atomicMin(&rowbuf[r * width + rank], idx);
+      } else {
+        // direct stores: exact (distance, index) order in one go
+        const uint4* segi = reinterpret_cast<const uint4*>(hm + a);
+        for (int jj = 0; jj < quads; ++jj) {
+          const uint4 k = seg[jj], ki = segi[jj];
+          rank += (k.x < d || (k.x == d && ki.x < idx) ? 1 : 0) + (k.y < d || (k.y == d && ki.y < idx) ? 1 : 0) +
+                  (k.z < d || (k.z == d && ki.z < idx) ? 1 : 0) + (k.w < d || (k.w == d && ki.w < idx) ? 1 : 0);
+        }
+        if (rank < width) out[(int64_t)orig[r] * width + rank] = (int64_t)idx;
       }
     }
     if (use_rowbuf) {
       __syncthreads();
-      // whole rows leave as contiguous runs: consecutive lanes, consecutive 16-byte pieces of a row
+      GR_FUSED_STOP(7, (int)rowbuf[tid])
+      // whole rows leave as contiguous runs: consecutive lanes, consecutive 16-byte pieces of a row.  An unwritten entry
+      // below the row's hit count means two hits of that row have the same distance: the row is noted and redone below
       if ((width & 1) == 0) {
         const int w2 = width >> 1, total_pairs = rows_here * w2;
         const float inv = 1.0f / (float)w2;
@@ -1048,6 +1413,10 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
           const int cc = (i - r * w2) * 2;
           const int cnt = qtot[r];
           const uint2 v = *reinterpret_cast<const uint2*>(rowbuf + r * width + cc);
+          if ((cc < cnt && v.x == PADMARK) || (cc + 1 < cnt && v.y == PADMARK)) {
+            tie_rows[r] = 1;
+            misc[1] = 1;
+          }
           longlong2 o;
           o.x = cc < cnt ? (long long)v.x : (long long)pad_value;
           o.y = cc + 1 < cnt ? (long long)v.y : (long long)pad_value;
@@ -1060,7 +1429,29 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
           int r = (int)((float)i * inv);
           r = r * width > i ? r - 1 : ((r + 1) * width <= i ? r + 1 : r);
           const int cc = i - r * width;
-          out[(int64_t)orig[r] * width + cc] = cc < qtot[r] ? (long long)rowbuf[r * width + cc] : (long long)pad_value;
+          const unsigned v = rowbuf[r * width + cc];
+          if (cc < qtot[r] && v == PADMARK) {
+            tie_rows[r] = 1;
+            misc[1] = 1;
+          }
+          out[(int64_t)orig[r] * width + cc] = cc < qtot[r] ? (long long)v : (long long)pad_value;
+        }
+      }
+      __syncthreads();
+      // rows with equal distances (rare): rank their hits again on (distance, index) and overwrite the row's entries
+      if (misc[1]) {
+        for (int r = 0; r < rows_here; ++r) {
+          if (!tie_rows[r]) continue;
+          const int a = offs[r], len = qtot[r];
+          for (int e = tid; e < len; e += L::THREADS) {
+            const unsigned d = hd[a + e], idx = hm[a + e];
+            int rank = 0;
+            for (int q2 = 0; q2 < len; ++q2) {
+              const unsigned dk = hd[a + q2], ik = hm[a + q2];
+              rank += (dk < d || (dk == d && ik < idx)) ? 1 : 0;
+            }
+            if (rank < width) out[(int64_t)orig[r] * width + rank] = (int64_t)idx;
+          }
         }
       }
     } else {
@@ -1080,6 +1471,7 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
     blk_stats[2 * blk] = mx;
     blk_stats[2 * blk + 1] = blk_flag;
   }
+#undef GR_FUSED_STOP
 }
 
 // max / max over the per-block (max hits per query, hits per block) pairs -> hdr
@@ -1117,15 +1509,15 @@ __global__ void pad_fill_kernel(int64_t* __restrict__ out, int64_t n, int64_t v)
 }
 
 template <int RQ>
-int launch_count(const RadiusWs& w, const float4* sorted_q, int64_t nq, int nb, const int32_t* start_s, float r2,
-                 bool mono, hipStream_t stream) {
+int launch_count(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns, int nb, const int32_t* start_s,
+                 float r2, bool mono, hipStream_t stream) {
   using L = TravLds<RQ>;
   const int blocks = (int)((nq + RQ - 1) / RQ);
   const int grid = (blocks + 7) / 8 * 8;
   KernelTimer timer("radius_count", stream);
   hipLaunchKernelGGL((traverse_kernel<RQ, false, true>), dim3(grid), dim3(L::THREADS), L::count_bytes(nb <= L::TABLE_MAX ? nb : 0), stream, sorted_q,
                      (int)nq, w.q_off, nb, w.grids, start_s, w.sorted_s, r2, w.q_count, w.q_rng, w.q_mask, w.blk_stats,
-                     0, 0, (int64_t)0, (int64_t*)nullptr, 0, (unsigned long long*)nullptr, (unsigned char*)nullptr, mono ? 1 : 0);
+                     0, 0, ns, (int64_t*)nullptr, 0, (unsigned long long*)nullptr, (unsigned char*)nullptr, mono ? 1 : 0);
   hipLaunchKernelGGL(reduce_stats_kernel, dim3(1), dim3(1024), 0, stream, w.blk_stats, blocks, w.hdr);
   GR_LAUNCH_CHECK();
   return GR_OK;
@@ -1168,10 +1560,12 @@ struct FusedCfg {
   int rq;      // queries per block: 64 or 128
   int rowbuf;  // rows leave through an LDS row buffer as contiguous 16-byte pieces (else: one 8-byte store per hit)
   int per_q;   // key slots per query in a block's key area
+  int dbg_stop;
 };
 inline FusedCfg fused_cfg() {
   static const FusedCfg cfg = [] {
-    FusedCfg c{128, 1, 28};
+    FusedCfg c{128, 1, 28, 0};
+    if (const char* e = getenv("GR_RADIUS_FUSED_STOP")) c.dbg_stop = atoi(e);
     if (const char* e = getenv("GR_RADIUS_FUSED_RQ")) c.rq = atoi(e) == 64 ? 64 : 128;
     if (const char* e = getenv("GR_RADIUS_FUSED_ROWBUF")) c.rowbuf = atoi(e) != 0;
     if (const char* e = getenv("GR_RADIUS_FUSED_SLOTS")) c.per_q = max(8, min(512, atoi(e)));
@@ -1200,7 +1594,7 @@ int launch_fused_t(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_
   {
     KernelTimer timer("radius_fused", stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(L::THREADS), lds, stream, sorted_q, (int)nq, w.q_off, nb, w.grids, start_s,
-                       w.sorted_s, r2, w.blk_stats, (int)width, ns, out, cap, (int)region, mono ? 1 : 0);
+                       w.sorted_s, (int)ns, r2, w.blk_stats, (int)width, ns, out, cap, (int)region, mono ? 1 : 0, fused_cfg().dbg_stop);
   }
   hipLaunchKernelGGL(reduce_stats_kernel, dim3(1), dim3(1024), 0, stream, w.blk_stats, blocks, w.hdr);
   GR_LAUNCH_CHECK();
@@ -1308,47 +1702,55 @@ int radius_prepare(const float* q, const float* s, const int64_t* h_q_lengths, c
       tmp[b + 1] = tmp[b] + (int32_t)h_q_lengths[b];
       tmp[batch + 1 + b + 1] = tmp[batch + 1 + b] + (int32_t)h_s_lengths[b];
     }
-    if (!reuse) bbox_block_offsets(tmp + batch + 1, tmp + 2 * (batch + 1), (int)batch);
+    if (!reuse) {  // first bounding-box block of every cloud
+      int32_t* blk = tmp + 2 * (batch + 1);
+      blk[0] = 0;
+      for (int64_t b = 0; b < batch; ++b) blk[b + 1] = blk[b] + (int32_t)((h_s_lengths[b] + BBOX_PTS - 1) / BBOX_PTS);
+    }
     GR_HIP(hipMemcpyAsync(w.q_off, tmp, sizeof(int32_t) * (reuse ? 1 : 3) * (batch + 1), hipMemcpyHostToDevice, stream));
   }
   const int nb = (int)batch;
-  int32_t* cnt_s = w.cnt;
-  int32_t* cnt_q = same ? w.cnt : w.cnt + (w.ccap + 1);
   int32_t* start_s = w.start;
-  int32_t* start_q = same ? w.start : w.start + (w.ccap + 1);
-  int rc = GR_OK;
-  KernelTimer bin_timer("radius_bin", stream);  // bbox .. scatter (nothing is launched when the grid is reused in a self-search)
+  KernelTimer bin_timer("radius_bin", stream);  // bbox .. cell order (nothing is launched when the grid is reused in a self-search)
+  const int64_t su = w.nsup + 1;
+  BinSide A{s, (int)ns, w.s_off, w.s_cell, w.pairs_s, w.sup_zero, w.sup_zero + 2 * su, w.sup_start, w.sorted_s, start_s};
+  BinSide B{q, (int)nq, w.q_off, w.q_cell, w.pairs_q, w.sup_zero + su, w.sup_zero + 3 * su, w.sup_start + su, w.sorted_q, nullptr};
+  const int blocks_s = (int)((ns + COARSE_PTS - 1) / COARSE_PTS), blocks_q = (int)((nq + COARSE_PTS - 1) / COARSE_PTS);
   if (!reuse) {
-    // ---- supports (and, in the same launches, the queries): bbox, grid, histogram, scan, scatter
-    const int rows = same ? 1 : 2;
-    GR_HIP(hipMemsetAsync(w.cnt, 0, sizeof(int32_t) * rows * (w.ccap + 1), stream));
+    // ---- supports (and, in the same launches, the queries): bbox, grid, two-level counting sort
     {
-      int rcb = compute_bbox(s, h_offsets + batch + 1, h_offsets + 2 * (batch + 1), w.s_off, nb, w.bbox, w.blk_off, stream, true);
-      if (rcb != GR_OK) return rcb;
+      const int nzero = (int)(4 * su);
+      hipLaunchKernelGGL(bin_init_kernel, dim3(std::min(256, (nzero + 255) / 256)), dim3(256), 0, stream, (uint32_t*)nullptr, 0,
+                         w.sup_zero, nzero);
+      const int bbox_blocks = h_offsets[2 * (batch + 1) + batch];
+      hipLaunchKernelGGL(bbox_partial_kernel, dim3(bbox_blocks), dim3(256), 0, stream, s, w.s_off, w.blk_off, nb, w.bbox_partial);
     }
     // x sub-cells per cell: 2 measured best end to end (count pass 0.166 -> 0.157 ms; 8 gives 0.150 ms but the scan and the
     // scatter over an 8x larger cell table take the difference back)
     constexpr int xk_max = 2;
-    hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(256), 0, stream, w.bbox, w.s_off, nb, radius, xk_max, w.grids, w.hdr);
-    const int nq_bin = same ? 0 : (int)nq;
-    hipLaunchKernelGGL(bin_count_kernel, dim3((ns + nq_bin + 255) / 256), dim3(256), 0, stream, s, (int)ns, q, nq_bin,
-                       w.s_off, w.q_off, nb, w.grids, w.s_cell, w.q_cell, w.s_rank, w.q_rank, cnt_s, cnt_q);
+    hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(256), 0, stream, w.bbox, w.bbox_partial, w.blk_off, w.s_off, nb, radius,
+                       xk_max, w.grids, w.hdr, w.sup_off);
+    const int bq = same ? 0 : blocks_q;
+    hipLaunchKernelGGL((coarse_kernel<false>), dim3(blocks_s + bq), dim3(256), 0, stream, A, B, blocks_s, nb, w.grids);
+    hipLaunchKernelGGL(sup_scan_kernel, dim3(same ? 1 : 2), dim3(1024), 0, stream, A, B, 0, w.hdr);
+    hipLaunchKernelGGL((coarse_kernel<true>), dim3(blocks_s + bq), dim3(256), 0, stream, A, B, blocks_s, nb, w.grids);
+    const int fine_blocks = (int)std::min<int64_t>(w.nsup, 4096);
+    hipLaunchKernelGGL(fine_kernel, dim3((unsigned)(fine_blocks * (same ? 1 : 2))), dim3(256), 0, stream, A, B, fine_blocks, nb, w.grids,
+                       w.sup_off, w.hdr);
     GR_LAUNCH_CHECK();
-    rc = exclusive_scan_i32(w.cnt, w.start, w.ccap + 1, rows, w.ccap + 1, w.scan_ws, nullptr, stream,
-                            &w.hdr->total_cells);
-    if (rc != GR_OK) return rc;
-    hipLaunchKernelGGL(scatter_kernel, dim3((ns + nq_bin + 255) / 256), dim3(256), 0, stream, s, (int)ns, q, nq_bin,
-                       w.s_cell, w.q_cell, start_s, start_q, w.s_rank, w.q_rank, w.sorted_s, w.sorted_q);
   } else if (!same) {
     // ---- the support grid is in place: only the queries are binned into it
-    GR_HIP(hipMemsetAsync(cnt_q, 0, sizeof(int32_t) * (w.ccap + 1), stream));
-    hipLaunchKernelGGL(bin_count_kernel, dim3((nq + 255) / 256), dim3(256), 0, stream, s, 0, q, (int)nq, w.s_off,
-                       w.q_off, nb, w.grids, w.s_cell, w.q_cell, w.s_rank, w.q_rank, cnt_s, cnt_q);
+    const int nzero = (int)su;
+    hipLaunchKernelGGL(bin_init_kernel, dim3(std::min(256, (nzero + 255) / 256)), dim3(256), 0, stream, (uint32_t*)nullptr, 0,
+                       w.sup_zero + su, nzero);
+    hipLaunchKernelGGL(bin_init_kernel, dim3(std::min(256, (nzero + 255) / 256)), dim3(256), 0, stream, (uint32_t*)nullptr, 0,
+                       w.sup_zero + 3 * su, nzero);
+    hipLaunchKernelGGL((coarse_kernel<false>), dim3(blocks_q), dim3(256), 0, stream, A, B, 0, nb, w.grids);
+    hipLaunchKernelGGL(sup_scan_kernel, dim3(1), dim3(1024), 0, stream, A, B, 1, w.hdr);
+    hipLaunchKernelGGL((coarse_kernel<true>), dim3(blocks_q), dim3(256), 0, stream, A, B, 0, nb, w.grids);
+    hipLaunchKernelGGL(fine_kernel, dim3((unsigned)std::min<int64_t>(w.nsup, 4096)), dim3(256), 0, stream, A, B, 0, nb, w.grids, w.sup_off,
+                       w.hdr);
     GR_LAUNCH_CHECK();
-    rc = exclusive_scan_i32(cnt_q, start_q, w.ccap + 1, 1, w.ccap + 1, w.scan_ws, nullptr, stream, &w.hdr->total_cells);
-    if (rc != GR_OK) return rc;
-    hipLaunchKernelGGL(scatter_kernel, dim3((nq + 255) / 256), dim3(256), 0, stream, s, 0, q, (int)nq, w.s_cell,
-                       w.q_cell, start_s, start_q, w.s_rank, w.q_rank, w.sorted_s, w.sorted_q);
   }
   P.w = w;
   P.sorted_q = same ? w.sorted_s : w.sorted_q;
@@ -1376,7 +1778,7 @@ extern "C" int gr_radius_count_cached(const float* q, const float* s, const int6
   if (P.empty) return GR_OK;  // width 0
   const RadiusWs& w = P.w;
   const bool same = P.same;
-  rc = launch_count<RT>(w, P.sorted_q, nq, P.nb, P.start_s, P.r2, same, stream);
+  rc = launch_count<RT>(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, same, stream);
   if (rc != GR_OK) return rc;
   // the read-back lands in pinned memory (a copy into pageable memory is staged and synchronised by the runtime on top of
   // the synchronise below)
@@ -1420,6 +1822,25 @@ extern "C" int gr_radius_fill(const float* q, const float* s, int64_t nq, int64_
   return launch_fill<RT>(w, sorted_q, nq, ns, (int)batch, r2, width, width, h_info[1], out, stream);
 }
 
+namespace gr {
+namespace {
+// 0 = count, host, fill (default); 1 = the single-pass kernel.  Initialised from GR_RADIUS_SINGLE_PASS.
+std::atomic<int>& search_mode() {
+  static std::atomic<int> mode{[] {
+    const char* a = getenv("GR_RADIUS_SINGLE_PASS");
+    return (a && a[0] == '1') ? 1 : 0;
+  }()};
+  return mode;
+}
+}  // namespace
+}  // namespace gr
+
+extern "C" int gr_radius_search_mode(int mode) {
+  const int old = search_mode().load();
+  if (mode >= 0 && mode <= 1) search_mode().store(mode);
+  return old;
+}
+
 extern "C" int gr_radius_search(const float* q, const float* s, const int64_t* h_q_lengths, const int64_t* h_s_lengths,
                                 int64_t nq, int64_t ns, int64_t batch, float radius, int64_t limit, int64_t* out,
                                 void* ws, size_t ws_bytes, int64_t* h_info, int64_t* h_support_sig, int reuse_support,
@@ -1437,8 +1858,10 @@ extern "C" int gr_radius_search(const float* q, const float* s, const int64_t* h
   const RadiusWs& w = P.w;
   RadiusHdr* h_pinned = static_cast<RadiusHdr*>(pinned_scratch(3, sizeof(RadiusHdr)));
   GR_REQUIRE(h_pinned != nullptr, "pinned read-back buffer could not be allocated");
-  const char* force2 = getenv("GR_RADIUS_TWO_PASS");
-  bool fused = fused_fits(limit) && !(force2 && force2[0] == '1');
+  // GR_RADIUS_SINGLE_PASS=1 selects the single-pass kernel (fused_kernel above).  It is not the default: on 8 x 200 k points it
+  // runs as long as count + fill together (both are bound by VALU issue: ~3 000 instructions per wave either way)
+  const int mode = search_mode().load();
+  bool fused = mode == 1 && fused_fits(limit);
   if (fused) {
     rc = launch_fused(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, out, P.same, stream);
     if (rc != GR_OK) return rc;
@@ -1452,9 +1875,11 @@ extern "C" int gr_radius_search(const float* q, const float* s, const int64_t* h
       return GR_OK;
     }
   }
-  // two passes (a neighbourhood too dense for the key area, or a limit too wide for the row buffer): count, then fill the
-  // first min(max_count, limit) columns of the same (nq, limit) rows
-  rc = launch_count<RT>(w, P.sorted_q, nq, P.nb, P.start_s, P.r2, P.same, stream);
+  // count, host, fill: the first min(max_count, limit) columns of the (nq, limit) rows.  (Measured and dropped: launching the
+  // fill behind the count with an LDS key area sized from the previous call of the same shape, to take the host out of the
+  // middle -- 0.594 vs 0.579 ms per 8 x 200 k points: the host prepares the fill while the count runs; what is left of it
+  // sits between calls, not between the kernels.)
+  rc = launch_count<RT>(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, P.same, stream);
   if (rc != GR_OK) return rc;
   GR_HIP(hipMemcpyAsync(h_pinned, w.hdr, sizeof(RadiusHdr), hipMemcpyDeviceToHost, stream));
   GR_HIP(hipStreamSynchronize(stream));
@@ -1464,7 +1889,7 @@ extern "C" int gr_radius_search(const float* q, const float* s, const int64_t* h
   h_info[2] = P.same ? 1 : 0;
   h_info[3] = h.total_cells;
   h_info[4] = 0;
+  if (h.max_count == 0) return GR_OK;  // width 0
   const int64_t width = h.max_count < (uint64_t)limit ? (int64_t)h.max_count : limit;
-  if (width == 0) return GR_OK;
   return launch_fill<RT>(w, P.sorted_q, nq, ns, P.nb, P.r2, width, limit, h.max_block_hits, out, stream);
 }

@@ -79,14 +79,18 @@ int gr_radius_fill(const float* q, const float* s, int64_t nq, int64_t ns, int64
                    void* ws, size_t ws_bytes, void* stream);
 /* radius_search with a positive neighbor_limit -- replaces the wrapper
  *   geotransformer/modules/ops/radius_search.py:7-27  (ext.radius_neighbors, then `[:, :neighbor_limit]`, :25-26)
- * in ONE pass: the kept width min(max_count, limit) is at most `limit`, so the caller allocates `out` as (nq, limit)
- * int64 BEFORE anything is counted and a single kernel tests the candidates, ranks the hits in LDS and writes whole rows
- * (row stride = limit; columns past a query's hit count hold the padding value ns).  No per-query metadata goes through
- * global memory and the host does not sit between two launches.  SYNCHRONISES `stream` once, after the kernel, to return
+ * The kept width min(max_count, limit) is at most `limit`, so the caller allocates `out` as (nq, limit) int64 BEFORE
+ * anything is counted (row stride = limit; columns past a query's hit count hold the padding value ns) and the host is
+ * not needed between the kernels.  SYNCHRONISES `stream` once, at the end, to return
  *   h_info[0] = max_count (the reference's untruncated width): the result is out[:, :min(max_count, limit)];
- *   h_info[4] = 1 if the single-pass kernel produced `out`, 0 if the call fell back to count + fill (one query with more
- *               hits than a workgroup's LDS key area holds, or a limit too wide for the LDS row buffer) -- same result.
+ *   h_info[4] = 1 if the single-pass kernel produced `out` (mode 1 below).
+ * Modes (gr_radius_search_mode; returns the previous mode; a negative argument only queries):
+ *   0  count, host, fill -- the kernels of gr_radius_count / gr_radius_fill with the rows allocated up front (default);
+ *   1  ONE kernel (tests, LDS ranking, whole-row stores; no per-query metadata through global memory).  Same result; falls
+ *      back to count + fill when one query has more hits than a workgroup's key area or the limit is too wide for LDS.
+ *      Not the default: both designs are bound by VALU issue and take the same time.
  * h_support_sig / reuse_support as in gr_radius_count_cached (may be NULL / 0).  `ws`: gr_radius_workspace_bytes. */
+int gr_radius_search_mode(int mode);
 int gr_radius_search(const float* q, const float* s, const int64_t* h_q_lengths, const int64_t* h_s_lengths,
                      int64_t nq, int64_t ns, int64_t batch, float radius, int64_t limit, int64_t* out /* nq x limit */,
                      void* ws, size_t ws_bytes, int64_t* h_info /*[6]*/, int64_t* h_support_sig /*[4] or NULL*/,

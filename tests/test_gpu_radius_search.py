@@ -14,6 +14,15 @@ def _t(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
+@pytest.fixture(params=[0, 1], ids=["count+fill", "single-pass"], autouse=True)
+def search_mode(request):
+    """Every test of this file runs in both modes of gr_radius_search (include/gaussreg_hip.h)."""
+    from gaussreg_amd import _lib
+    old = _lib.lib().gr_radius_search_mode(request.param)
+    yield request.param
+    _lib.lib().gr_radius_search_mode(old)
+
+
 def _info(q, s, ql, sl, radius, limit):
     """Call the C entry point directly to read h_info[4] (did the single pass produce the rows?)."""
     from gaussreg_amd import _lib
@@ -63,7 +72,7 @@ def test_self_search_c1_golden_truncated():
         assert np.array_equal(nb.cpu().numpy(), g["neighbors"][:, :limit])
 
 
-def test_dense_blocks_work_in_groups_and_giant_queries_fall_back():
+def test_dense_blocks_work_in_groups_and_giant_queries_fall_back(search_mode):
     """~600 hits per query: a block's 128 queries need several passes over its key area (groups); then a radius that
     makes every support a neighbour of every query: one query alone overflows the key area and the call repeats itself
     on the two-pass path.  Same rows either way."""
@@ -78,7 +87,7 @@ def test_dense_blocks_work_in_groups_and_giant_queries_fall_back():
         want = capi.radius_neighbors(q, s, ql, sl, radius)
         info, out = _info(tq, ts, ql.tolist(), sl.tolist(), radius, limit)
         assert info[0] == want.shape[1]
-        assert (info[4] == 1) == single, (radius, limit, info)
+        assert (info[4] == 1) == (single and search_mode == 1), (radius, limit, info)
         w = min(limit, want.shape[1])
         assert np.array_equal(out[:, :w].cpu().numpy(), want[:, :w])
         if w < limit:
@@ -124,11 +133,38 @@ def test_ragged_batches_odd_limits_and_grid_reuse():
     assert np.array_equal(got.cpu().numpy(), want)
 
 
-def test_200k_limited_equals_two_pass_and_properties():
+def test_200k_limited_equals_two_pass_and_properties(search_mode):
     from gaussreg_amd import ext, synthetic
     pts, lens = synthetic.cloud_200k(2, seed=3)
     d = pts.cuda()
     a = ext.radius_neighbors_limited(d, d, lens, lens, 0.0625, 40)
+    a2 = ext.radius_neighbors_limited(d, d, lens, lens, 0.0625, 40)
+    assert torch.equal(a, a2)
     b = ext.radius_neighbors_limited(d, d, lens, lens, 0.0625, 40, two_pass=True)
     assert a.shape == (400000, 40) and torch.equal(a, b)
     assert bool((a[:, 0] == torch.arange(400000, device=a.device)).all())  # self first (d = 0)
+
+
+@pytest.mark.parametrize("limit", [6, 13, 40])
+def test_equal_distances_follow_the_index_order(limit):
+    """Duplicated points and an integer lattice: many exactly equal distances per row.  This library's rule for them
+    (ascending support index, the oracle's rule) must hold on the single-pass path too -- its 32-bit ranking sees them as
+    collisions and redoes such rows on (distance, index)."""
+    from gaussreg_amd import ext
+    from oracle import capi
+    rng = np.random.default_rng(21)
+    base = rng.random((700, 3)).astype(np.float32)
+    dup = np.concatenate([base, base[:400], base[100:300]])                      # duplicates, shuffled below
+    lattice = (np.stack(np.meshgrid(*[np.arange(9)] * 3, indexing="ij"), -1).reshape(-1, 3) * 0.125).astype(np.float32)
+    s = np.concatenate([dup[rng.permutation(dup.shape[0])], lattice[rng.permutation(lattice.shape[0])]])
+    sl = np.array([dup.shape[0], lattice.shape[0]], np.int64)
+    for radius in (0.13, 0.26):
+        want = capi.radius_neighbors(s, s, sl, sl, radius)[:, :limit]
+        ts, tsl = _t(s), torch.from_numpy(sl)
+        got = ext.radius_neighbors_limited(ts, ts, tsl, tsl, radius, limit)
+        assert np.array_equal(got.cpu().numpy(), want)
+        q = np.concatenate([base[:300] + np.float32(1e-3), lattice[:200]])
+        ql = np.array([300, 200], np.int64)
+        want = capi.radius_neighbors(q, s, ql, sl, radius)[:, :limit]
+        got = ext.radius_neighbors_limited(_t(q), ts, torch.from_numpy(ql), tsl, radius, limit)
+        assert np.array_equal(got.cpu().numpy(), want)

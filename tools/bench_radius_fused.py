@@ -18,7 +18,8 @@ def child():
     L = _lib.lib()
     B = int(os.environ.get("BRF_CLOUDS", "8"))
     lim = int(os.environ.get("BRF_LIMIT", "40"))
-    two = os.environ.get("BRF_TWO_PASS", "0") == "1"
+    two = False
+    L.gr_radius_search_mode(int(os.environ.get("BRF_MODE", "1")))
     pts, lens = synthetic.cloud_200k(B, seed=0)
     d = pts.cuda()
     fn = lambda: ext.radius_neighbors_limited(d, d, lens, lens, 0.0625, lim, two_pass=two)  # noqa: E731
@@ -45,7 +46,18 @@ def child():
 
 
 def main():
-    configs = [{"BRF_TWO_PASS": "1"}]
+    configs = [{"BRF_MODE": "0"}]
+    if "--ablate" in sys.argv:  # cumulative time of the fused kernel's phases (radius_fused timer; totals are meaningless)
+        configs = []
+        for rq, slots in (("64", "28"),):
+            for stop in ("1", "2", "3", "4", "5", "6", "7", "0"):
+                configs.append({"GR_RADIUS_FUSED_RQ": rq, "GR_RADIUS_FUSED_SLOTS": slots, "GR_RADIUS_FUSED_STOP": stop})
+        for c in configs:
+            env = dict(os.environ, BRF_CHILD="1", **c)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)
+            line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+            print(json.dumps(c), line[0][7:] if line else ("FAILED " + r.stderr[-400:]), flush=True)
+        return
     for rq in ("128", "64"):
         for rb in ("1", "0"):
             for slots in (("28", "40") if rq == "128" else ("28", "40", "56")):
