@@ -55,6 +55,10 @@ SIGNATURES.update({
                                                                      c_void, c_size, c_i64p, c_void]),
     "gr_raster_render": (c_int, [c_i64, ctypes.POINTER(RasterView), c_int, c_i64p, c_void, c_size, c_void, c_size,
                                  c_void, c_void]),
+    "gr_raster_render_ex": (c_int, [c_i64, ctypes.POINTER(RasterView), c_int, c_i64p, c_void, c_size, c_void, c_size,
+                                    c_void, c_int, c_void]),
+    "gr_raster_forward": (c_int, [c_i64, c_int] + [c_void] * 7 + [ctypes.POINTER(RasterView), c_int, c_void, c_void, c_size,
+                                  c_void, c_size, c_void, c_int, c_i64p, c_void]),
     "gr_raster_lds_atomics_lane_ordered": (c_int, []),
     "gr_raster_mark_visible": (c_int, [c_i64, c_void, ctypes.POINTER(c_f32), c_void, c_void]),
 })
@@ -133,7 +137,7 @@ def lib():
 
 
 def check(rc):
-    if rc != 0:
+    if rc < 0 or rc > 1:
         msg = lib().gr_last_error()
         raise RuntimeError("gaussreg_hip: " + (msg.decode() if msg else f"error {rc}"))
 

@@ -816,7 +816,11 @@ __device__ __forceinline__ float min_f32_raw(float a, float b) {  // fminf, same
   return r;
 }
 
-template <bool STATS>
+// FAST_EXP: alpha = opacity * 2^(power * log2 e) on the hardware exponential (v_exp_f32, 1 ulp) instead of the oracle's
+// deterministic polynomial exp_det() -- 3 issue slots per pair of entries instead of 20.  The image is no longer bit-equal
+// to oracle/rasterizer_oracle.c but stays within 1e-5 relative of it (tests/test_gpu_rasterizer_fast.py); opt-in
+// (GR_RASTER_FAST_EXP flag of gr_raster_render_ex).
+template <bool STATS, bool FAST_EXP>
 __global__ __launch_bounds__(BLOCK) void blend_kernel(
     int P, int W, int H, int nchunk, const DevView* __restrict__ views, const uint32_t* __restrict__ seg_off,
     const int32_t* __restrict__ point_list, const float4* __restrict__ rec, float* __restrict__ out_color) {
@@ -997,20 +1001,26 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
       const float pc0 = lds_f32(s_pc, o0), pc1 = lds_f32(s_pc, o1);
       const f32x2 q = __builtin_elementwise_fma(cx * dx, dx, (cz * dy) * dy);
       const f32x2 power = __builtin_elementwise_fma(f32x2{-0.5f, -0.5f}, q, -((cy * dx) * dy));
-      // exp_det(), two at a time
-      const f32x2 x = {max_f32_raw(power.x, -100.0f), max_f32_raw(power.y, -100.0f)};
-      const f32x2 t = x * 1.44269504088896341f;
-      const f32x2 n = {rintf(t.x), rintf(t.y)};
-      f32x2 r = __builtin_elementwise_fma(n, f32x2{-0.693359375f, -0.693359375f}, x);
-      r = __builtin_elementwise_fma(n, f32x2{2.12194440e-4f, 2.12194440e-4f}, r);
-      f32x2 pl = {1.9875691500e-4f, 1.9875691500e-4f};
-      pl = __builtin_elementwise_fma(pl, r, f32x2{1.3981999507e-3f, 1.3981999507e-3f});
-      pl = __builtin_elementwise_fma(pl, r, f32x2{8.3334519073e-3f, 8.3334519073e-3f});
-      pl = __builtin_elementwise_fma(pl, r, f32x2{4.1665795894e-2f, 4.1665795894e-2f});
-      pl = __builtin_elementwise_fma(pl, r, f32x2{1.6666665459e-1f, 1.6666665459e-1f});
-      pl = __builtin_elementwise_fma(pl, r, f32x2{5.0000001201e-1f, 5.0000001201e-1f});
-      const f32x2 y = __builtin_elementwise_fma(pl, r * r, r) + 1.0f;
-      const f32x2 al = cw * f32x2{ldexpf(y.x, (int)n.x), ldexpf(y.y, (int)n.y)};
+      f32x2 al;
+      if (FAST_EXP) {
+        const f32x2 t = power * 1.44269504088896341f;
+        al = cw * f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+      } else {
+        // exp_det(), two at a time
+        const f32x2 x = {max_f32_raw(power.x, -100.0f), max_f32_raw(power.y, -100.0f)};
+        const f32x2 t = x * 1.44269504088896341f;
+        const f32x2 n = {rintf(t.x), rintf(t.y)};
+        f32x2 r = __builtin_elementwise_fma(n, f32x2{-0.693359375f, -0.693359375f}, x);
+        r = __builtin_elementwise_fma(n, f32x2{2.12194440e-4f, 2.12194440e-4f}, r);
+        f32x2 pl = {1.9875691500e-4f, 1.9875691500e-4f};
+        pl = __builtin_elementwise_fma(pl, r, f32x2{1.3981999507e-3f, 1.3981999507e-3f});
+        pl = __builtin_elementwise_fma(pl, r, f32x2{8.3334519073e-3f, 8.3334519073e-3f});
+        pl = __builtin_elementwise_fma(pl, r, f32x2{4.1665795894e-2f, 4.1665795894e-2f});
+        pl = __builtin_elementwise_fma(pl, r, f32x2{1.6666665459e-1f, 1.6666665459e-1f});
+        pl = __builtin_elementwise_fma(pl, r, f32x2{5.0000001201e-1f, 5.0000001201e-1f});
+        const f32x2 y = __builtin_elementwise_fma(pl, r * r, r) + 1.0f;
+        al = cw * f32x2{ldexpf(y.x, (int)n.x), ldexpf(y.y, (int)n.y)};
+      }
       const float alpha0 = min_f32_raw(al.x, 0.99f), alpha1 = min_f32_raw(al.y, 0.99f);
       const bool ok0 = !(power.x > 0.0f) && !(power.x < pc0) && !(alpha0 < 1.0f / 255.0f);
       const bool ok1 = !(power.y > 0.0f) && !(power.y < pc1) && !(alpha1 < 1.0f / 255.0f);
@@ -1258,6 +1268,14 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
 extern "C" int gr_raster_render(int64_t P, const gr_raster_view* h_views, int num_views,
                                 const int64_t* h_num_rendered, const void* geom, size_t geom_bytes,
                                 void* bin, size_t bin_bytes, float* out_color, void* stream_) {
+  static const int env_flags = (getenv("GR_RASTER_FAST_EXP") && getenv("GR_RASTER_FAST_EXP")[0] == '1') ? GR_RASTER_FAST_EXP : 0;
+  return gr_raster_render_ex(P, h_views, num_views, h_num_rendered, geom, geom_bytes, bin, bin_bytes, out_color, env_flags,
+                             stream_);
+}
+
+extern "C" int gr_raster_render_ex(int64_t P, const gr_raster_view* h_views, int num_views,
+                                   const int64_t* h_num_rendered, const void* geom, size_t geom_bytes,
+                                   void* bin, size_t bin_bytes, float* out_color, int flags, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   int rc = check_views(h_views, num_views);
   if (rc != GR_OK) return rc;
@@ -1301,14 +1319,33 @@ extern "C" int gr_raster_render(int64_t P, const gr_raster_view* h_views, int nu
   }
   KernelTimer timer("raster_blend", stream);
   static const bool stats = getenv("GR_BLEND_STATS") && getenv("GR_BLEND_STATS")[0] == '1';
-  if (stats)
-    hipLaunchKernelGGL(blend_kernel<true>, dim3(gx, gy, num_views), dim3(BLOCK), 0, stream, (int)P, W, H, R > 0 ? nchunk : 0,
-                       g.views, g.seg_off, point_list, g.rec, out_color);
-  else
-    hipLaunchKernelGGL(blend_kernel<false>, dim3(gx, gy, num_views), dim3(BLOCK), 0, stream, (int)P, W, H, R > 0 ? nchunk : 0,
-                       g.views, g.seg_off, point_list, g.rec, out_color);
+  const bool fast = (flags & GR_RASTER_FAST_EXP) != 0;
+#define GR_BLEND(ST, FE)                                                                                                  \
+  hipLaunchKernelGGL((blend_kernel<ST, FE>), dim3(gx, gy, num_views), dim3(BLOCK), 0, stream, (int)P, W, H, R > 0 ? nchunk : 0, \
+                     g.views, g.seg_off, point_list, g.rec, out_color)
+  if (stats) {
+    if (fast) GR_BLEND(true, true); else GR_BLEND(true, false);
+  } else {
+    if (fast) GR_BLEND(false, true); else GR_BLEND(false, false);
+  }
+#undef GR_BLEND
   GR_LAUNCH_CHECK();
   return GR_OK;
+}
+
+extern "C" int gr_raster_forward(int64_t P, int M, const float* means3D, const float* shs, const float* colors_precomp,
+                                 const float* opacities, const float* scales, const float* rotations,
+                                 const float* cov3D_precomp, const gr_raster_view* h_views, int num_views, int32_t* radii,
+                                 void* geom, size_t geom_bytes, void* bin, size_t bin_bytes, float* out_color, int flags,
+                                 int64_t* h_num_rendered, void* stream) {
+  int rc = gr_raster_preprocess(P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, h_views,
+                                num_views, radii, geom, geom_bytes, h_num_rendered, stream);
+  if (rc != GR_OK) return rc;
+  int64_t R = 0;
+  for (int v = 0; v < num_views; ++v) R += h_num_rendered[v];
+  if (bin == nullptr || bin_bytes < gr_raster_bin_bytes(R, h_views[0].image_width, h_views[0].image_height, num_views))
+    return GR_RETRY_BIN;  // the caller allocates gr_raster_bin_bytes(sum h_num_rendered) and calls gr_raster_render_ex
+  return gr_raster_render_ex(P, h_views, num_views, h_num_rendered, geom, geom_bytes, bin, bin_bytes, out_color, flags, stream);
 }
 
 extern "C" int gr_raster_mark_visible(int64_t P, const float* means3D, const float* h_viewmatrix,

@@ -36,6 +36,22 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
+FAST_EXP = 1  # GR_RASTER_FAST_EXP (include/gaussreg_hip.h)
+_ENV_FAST = None
+_bin_hint = {}  # (device, P, V, W, H) -> bytes of the binning buffer the last call of that shape needed
+
+
+def _flags(fast_exp):
+    """fast_exp None: the library default (environment variable GR_RASTER_FAST_EXP=1 switches it on)."""
+    global _ENV_FAST
+    if fast_exp is None:
+        if _ENV_FAST is None:
+            import os
+            _ENV_FAST = os.environ.get("GR_RASTER_FAST_EXP", "0")[:1] == "1"
+        fast_exp = _ENV_FAST
+    return FAST_EXP if fast_exp else 0
+
+
 def _view_struct(rs: GaussianRasterizationSettings) -> _lib.RasterView:
     v = _lib.RasterView()
     v.image_height, v.image_width = int(rs.image_height), int(rs.image_width)
@@ -79,13 +95,16 @@ def _dev_f32(t: Optional[torch.Tensor], dev, name):
 
 
 def rasterize_views(settings, means3D, opacities, shs=None,
-                    colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+                    colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, fast_exp=None):
     """Render the same Gaussians from len(settings) cameras (`settings`: a sequence of
     GaussianRasterizationSettings, or a prebuilt ViewBatch).
 
     Returns (color (V,3,H,W) f32, radii (V,P) i32, num_rendered list[int]).  num_rendered = (tile, Gaussian)
     instances actually binned per view: at most the reference's count (pairs that cannot reach alpha = 1/255
-    anywhere in the tile are dropped before the sort; the image is unaffected)."""
+    anywhere in the tile are dropped before the sort; the image is unaffected).
+
+    `fast_exp=True`: the blend uses the hardware exponential (v_exp_f32) instead of the deterministic polynomial of the
+    oracle -- the image is within 1e-5 relative of the bit-exact one (default False: bit-exact)."""
     dev = _lib.require_gpu()
     L = _lib.lib()
     if means3D.is_cuda:
@@ -120,35 +139,57 @@ def rasterize_views(settings, means3D, opacities, shs=None,
     with torch.cuda.device(dev):
         st = _lib.stream_ptr(dev)
         geom = torch.empty(L.gr_raster_geom_bytes(P, V, W, H) + 256, dtype=torch.uint8, device=dev)
-        _lib.check(L.gr_raster_preprocess(P, M, _lib.ptr(m), _lib.ptr(sh), _lib.ptr(cp), _lib.ptr(op), _lib.ptr(sc),
-                                          _lib.ptr(rot), _lib.ptr(cov), views, V, _lib.ptr(radii), _lib.ptr(geom),
-                                          geom.numel(), nr, st))
+        flags = _flags(fast_exp)
+        # the binning buffer is sized from the last call of this shape (+ 25 %): the library is entered once per frame, and
+        # only a frame that needs more comes back for a larger buffer
+        key = (dev.index, P, V, W, H)
+        hint = _bin_hint.get(key, 0)
+        binb = torch.empty(hint + 256, dtype=torch.uint8, device=dev) if hint else None
+        rc = L.gr_raster_forward(P, M, _lib.ptr(m), _lib.ptr(sh), _lib.ptr(cp), _lib.ptr(op), _lib.ptr(sc), _lib.ptr(rot),
+                                 _lib.ptr(cov), views, V, _lib.ptr(radii), _lib.ptr(geom), geom.numel(), _lib.ptr(binb),
+                                 binb.numel() if binb is not None else 0, _lib.ptr(color), flags, nr, st)
+        _lib.check(rc)
         total = sum(int(nr[v]) for v in range(V))
-        binb = torch.empty(L.gr_raster_bin_bytes(total, W, H, V) + 256, dtype=torch.uint8, device=dev)
-        _lib.check(L.gr_raster_render(P, views, V, nr, _lib.ptr(geom), geom.numel(), _lib.ptr(binb), binb.numel(),
-                                      _lib.ptr(color), st))
+        need = L.gr_raster_bin_bytes(total, W, H, V)
+        if rc == 1:  # GR_RETRY_BIN
+            binb = torch.empty(need + 256, dtype=torch.uint8, device=dev)
+            _lib.check(L.gr_raster_render_ex(P, views, V, nr, _lib.ptr(geom), geom.numel(), _lib.ptr(binb), binb.numel(),
+                                             _lib.ptr(color), flags, st))
+        if len(_bin_hint) > 64:
+            _bin_hint.clear()
+        _bin_hint[key] = need + need // 4
     return color, radii, [int(nr[v]) for v in range(V)]
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings):
+                        raster_settings, fast_exp=None):
     """`raster_settings`: GaussianRasterizationSettings, or a one-camera ViewBatch built from it (marshalled once)."""
     vb = raster_settings if isinstance(raster_settings, ViewBatch) else [raster_settings]
-    color, radii, _ = rasterize_views(vb, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp)
+    color, radii, _ = rasterize_views(vb, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp,
+                                      fast_exp=fast_exp)
     return color[0], radii[0]
 
 
 class GaussianRasterizer(torch.nn.Module):
-    def __init__(self, raster_settings: GaussianRasterizationSettings):
+    def __init__(self, raster_settings: GaussianRasterizationSettings, fast_exp=None):
+        """`fast_exp` (extension, upstream has no such argument): see rasterize_views."""
         super().__init__()
         self.raster_settings = raster_settings
-        self._view_batch = None  # (settings object it was built from, ViewBatch): the C camera struct is built once
+        self.fast_exp = fast_exp
+        self._view_batch = None  # (settings object, tensor versions, ViewBatch): the C camera struct is built once
+
+    @staticmethod
+    def _stamp(rs):
+        # the camera tensors may be updated in place between frames (pose optimisation): their storage and version
+        # counters are part of the cache key, so a stale marshalled copy is never rendered
+        return tuple((t.data_ptr(), t._version) for t in (rs.viewmatrix, rs.projmatrix, rs.campos, rs.bg))
 
     def _views(self):
         rs = self.raster_settings
-        if self._view_batch is None or self._view_batch[0] is not rs:
-            self._view_batch = (rs, ViewBatch([rs]))
-        return self._view_batch[1]
+        stamp = self._stamp(rs)
+        if self._view_batch is None or self._view_batch[0] is not rs or self._view_batch[1] != stamp:
+            self._view_batch = (rs, stamp, ViewBatch([rs]))
+        return self._view_batch[2]
 
     def markVisible(self, positions):
         with torch.no_grad():
@@ -173,4 +214,4 @@ class GaussianRasterizer(torch.nn.Module):
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3D_precomp, self._views())
+                                   cov3D_precomp, self._views(), fast_exp=self.fast_exp)
