@@ -623,7 +623,9 @@ __global__ __launch_bounds__(BIN_T) void tile_scatter_kernel(int P, int V, int g
                                                              const int32_t* __restrict__ ids,
                                                              const float4* __restrict__ rec,
                                                              const uint32_t* __restrict__ seg_off,
-                                                             int32_t* __restrict__ point_list) {
+                                                             int32_t* __restrict__ point_list, unsigned int list_cap) {
+  // list_cap: entries the point list holds.  A speculative launch (gr_raster_forward) sizes the list before the instance
+  // count is known: a chunk that would end past it writes nothing (the host then repeats the render with a larger list)
   extern __shared__ unsigned int s_cur[];  // [waves][tiles] counts -> cursors, then [stage_cap] staged chunk-local indices
   constexpr int NW = BIN_T / WAVE, CW = BIN_CHUNK / NW;
   int v, c;
@@ -632,7 +634,7 @@ __global__ __launch_bounds__(BIN_T) void tile_scatter_kernel(int P, int V, int g
   const uint32_t* seg = seg_off + ((int64_t)v * nchunk + c) * (tiles + 1);
   const unsigned int chunk_begin = seg[0];
   const int total = (int)(seg[tiles] - chunk_begin);
-  if (total == 0) return;  // block-uniform
+  if (total == 0 || seg[tiles] > list_cap) return;  // block-uniform
   const bool staged = total <= stage_cap;
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   unsigned int* my = s_cur + wv * tiles;
@@ -823,7 +825,8 @@ __device__ __forceinline__ float min_f32_raw(float a, float b) {  // fminf, same
 template <bool STATS, bool FAST_EXP>
 __global__ __launch_bounds__(BLOCK) void blend_kernel(
     int P, int W, int H, int nchunk, const DevView* __restrict__ views, const uint32_t* __restrict__ seg_off,
-    const int32_t* __restrict__ point_list, const float4* __restrict__ rec, float* __restrict__ out_color) {
+    const int32_t* __restrict__ point_list, const float4* __restrict__ rec, float* __restrict__ out_color,
+    unsigned int list_cap) {
   // One plane per field: the blend reads field f of two different entries into the two halves of a register pair
   // (ds_read_b32 x 2), which is the operand layout of the packed fp32 instructions -- no register shuffling.
   // (Plane stride 257 dwords: neither <= 255 nor a multiple of 64, so the compiler cannot fuse two fields of ONE entry
@@ -840,6 +843,10 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
   __shared__ int s_wpre[WAVE];                    // window of 64 chunks: inclusive prefix of this tile's segment lengths
   __shared__ unsigned int s_woff[WAVE];           //                      and where each segment starts in point_list
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  // speculative launch: the list was sized before the instance count was known; if it is too short nothing is drawn (the
+  // host repeats the render).  The grand total is the end of the last segment of the last view.
+  if (list_cap != 0xffffffffu && nchunk > 0 &&
+      seg_off[(int64_t)gridDim.z * nchunk * (gx * gy + 1) - 1] > list_cap) return;
   const int v = blockIdx.z;
   const int tile = blockIdx.y * gx + blockIdx.x;
   const int tid = threadIdx.x;
@@ -1144,13 +1151,14 @@ extern "C" size_t gr_raster_bin_bytes(int64_t total_rendered, int width, int hei
   return carve_bin(nullptr, total_rendered, tiles_of(width, height) * num_views).bytes;
 }
 
-extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, const float* shs,
-                                    const float* colors_precomp, const float* opacities,
-                                    const float* scales, const float* rotations,
-                                    const float* cov3D_precomp, const gr_raster_view* h_views,
-                                    int num_views, int32_t* radii, void* geom, size_t geom_bytes,
-                                    int64_t* h_num_rendered, void* stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
+// defer_ev != nullptr: everything is enqueued, the read-back of the counts is followed by this event instead of a stream
+// synchronise, and h_num_rendered is NOT filled -- the caller waits for the event and calls preprocess_collect().
+static int preprocess_impl(int64_t P, int M, const float* means3D, const float* shs,
+                           const float* colors_precomp, const float* opacities,
+                           const float* scales, const float* rotations,
+                           const float* cov3D_precomp, const gr_raster_view* h_views,
+                           int num_views, int32_t* radii, void* geom, size_t geom_bytes,
+                           int64_t* h_num_rendered, hipStream_t stream, hipEvent_t defer_ev) {
   int rc = check_views(h_views, num_views);
   if (rc != GR_OK) return rc;
   GR_REQUIRE(h_num_rendered != nullptr, "h_num_rendered is null");
@@ -1244,6 +1252,10 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
       GR_HIP(hipMemcpyAsync(tot, g.totals, sizeof(int32_t) * (num_views + 1), hipMemcpyDeviceToHost, stream));
       GR_HIP(hipMemcpyAsync(tot + num_views + 1, g.chunk_max, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     }
+    if (defer_ev != nullptr) {
+      GR_HIP(hipEventRecord(defer_ev, stream));
+      return GR_OK;
+    }
     GR_HIP(hipStreamSynchronize(stream));
     h_chunk_max = tot[num_views + 1];
     if (short_rows)
@@ -1252,6 +1264,7 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
   };
   rc = sort_and_count(KEY_DEPTH_BITS);
   if (rc != GR_OK) return rc;
+  if (defer_ev != nullptr) return GR_OK;
   if (tot[num_views] != 0) {  // some depth >= 8192: redo the ordering with full-width keys
     hipLaunchKernelGGL(full_keys_kernel, dim3((unsigned)((P * num_views + 255) / 256)), blk, 0, stream, P * num_views,
                        g.rec, radii, g.dfield);
@@ -1273,19 +1286,50 @@ extern "C" int gr_raster_render(int64_t P, const gr_raster_view* h_views, int nu
                              stream_);
 }
 
-extern "C" int gr_raster_render_ex(int64_t P, const gr_raster_view* h_views, int num_views,
-                                   const int64_t* h_num_rendered, const void* geom, size_t geom_bytes,
-                                   void* bin, size_t bin_bytes, float* out_color, int flags, void* stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
+extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, const float* shs,
+                                    const float* colors_precomp, const float* opacities,
+                                    const float* scales, const float* rotations,
+                                    const float* cov3D_precomp, const gr_raster_view* h_views,
+                                    int num_views, int32_t* radii, void* geom, size_t geom_bytes,
+                                    int64_t* h_num_rendered, void* stream_) {
+  return preprocess_impl(P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, h_views, num_views,
+                         radii, geom, geom_bytes, h_num_rendered, static_cast<hipStream_t>(stream_), nullptr);
+}
+
+// after the event of a deferred preprocess_impl: counts -> h_num_rendered; *far_depth = the depth-overflow flag
+static int preprocess_collect(int64_t P, int num_views, int64_t* h_num_rendered, bool* far_depth) {
+  const int32_t* tot = static_cast<const int32_t*>(pinned_scratch(1, sizeof(int32_t) * (2 * num_views + 2)));
+  GR_REQUIRE(tot != nullptr, "pinned read-back buffer missing");
+  const int nchunk = (int)((P + BIN_CHUNK - 1) / BIN_CHUNK);
+  const bool short_rows = nchunk <= SCAN_SINGLE_ROW;
+  int32_t cm = tot[num_views + 1];
+  if (short_rows)
+    for (int v = 1; v < num_views; ++v) cm = std::max(cm, tot[num_views + 1 + v]);
+  for (int v = 0; v < num_views; ++v) h_num_rendered[v] = tot[v];
+  h_num_rendered[num_views] = cm;
+  *far_depth = tot[num_views] != 0;
+  return GR_OK;
+}
+
+// spec_entries < 0: the instance counts in h_num_rendered are this call's (the normal render).
+// spec_entries >= 0: speculative launch for gr_raster_forward -- the counts are not known on the host yet; `bin` holds
+// spec_entries list entries, h_num_rendered[num_views] is only a hint for the staging block, and the kernels themselves
+// refuse to run past the list (tile_scatter_kernel / blend_kernel list_cap).
+static int render_impl(int64_t P, const gr_raster_view* h_views, int num_views, const int64_t* h_num_rendered,
+                       const void* geom, size_t geom_bytes, void* bin, size_t bin_bytes, float* out_color, int flags,
+                       int64_t spec_entries, hipStream_t stream) {
   int rc = check_views(h_views, num_views);
   if (rc != GR_OK) return rc;
   GR_REQUIRE(out_color != nullptr && h_num_rendered != nullptr, "null argument");
+  const bool spec = spec_entries >= 0;
   const int W = h_views[0].image_width, H = h_views[0].image_height;
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   const int64_t vtiles = (int64_t)gx * gy * num_views;
   GR_REQUIRE(vtiles < (1ll << 31), "too many tiles");
   int64_t R = 0;
-  for (int v = 0; v < num_views; ++v) R += h_num_rendered[v];
+  if (spec) R = spec_entries;
+  else
+    for (int v = 0; v < num_views; ++v) R += h_num_rendered[v];
   GR_REQUIRE(R < (1ll << 31) - 1, "too many rendered instances (%lld)", (long long)R);
   const int tiles = gx * gy;
   Geom g = carve_geom(const_cast<void*>(geom), P, num_views, tiles);
@@ -1297,12 +1341,15 @@ extern "C" int gr_raster_render_ex(int64_t P, const gr_raster_view* h_views, int
   }
   const int32_t* point_list = b.point_list;
   const int nchunk = (int)((P + BIN_CHUNK - 1) / BIN_CHUNK);
-  if (R > 0) {
+  const unsigned int list_cap = spec ? (unsigned int)R : 0xffffffffu;
+  if (R > 0 || (spec && P > 0)) {
     // LDS: per-wave tile cursors + a staging block that holds a whole chunk's instances (chunks that do not fit write
     // straight to global memory); sized for the largest chunk of this call, capped so that two workgroups share a CU
     const size_t cur_bytes = (size_t)(BIN_T / WAVE) * tiles * sizeof(unsigned int);
     const int64_t cap_max = ((int64_t)78 * 1024 - (int64_t)cur_bytes) / 2;
-    int stage_cap = (int)std::min<int64_t>(std::max<int64_t>(cap_max, 0), (std::max<int64_t>(h_num_rendered[num_views], 0) + 63) / 64 * 64);
+    int64_t want = std::max<int64_t>(h_num_rendered[num_views], 0);
+    if (spec) want = want > 0 ? want + want / 4 : cap_max;  // the hint is last frame's figure
+    int stage_cap = (int)std::min<int64_t>(std::max<int64_t>(cap_max, 0), (want + 63) / 64 * 64);
     const size_t lds = cur_bytes + (size_t)stage_cap * sizeof(unsigned short);
     bool ordered = false;
     rc = lds_atomics_lane_ordered(stream, &ordered);
@@ -1314,15 +1361,16 @@ extern "C" int gr_raster_render_ex(int64_t P, const gr_raster_view* h_views, int
       GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     KernelTimer timer("raster_bin", stream);
     hipLaunchKernelGGL(kern, dim3((unsigned)bin_grid(num_views, nchunk)), dim3(BIN_T), lds, stream, (int)P, num_views, gx, gy,
-                       nchunk, tile_bits, stage_cap, g.nvis, g.rects, g.order_b, g.rec, g.seg_off, b.point_list);
+                       nchunk, tile_bits, stage_cap, g.nvis, g.rects, g.order_b, g.rec, g.seg_off, b.point_list, list_cap);
     GR_LAUNCH_CHECK();
   }
   KernelTimer timer("raster_blend", stream);
   static const bool stats = getenv("GR_BLEND_STATS") && getenv("GR_BLEND_STATS")[0] == '1';
   const bool fast = (flags & GR_RASTER_FAST_EXP) != 0;
+  const int blend_chunks = (R > 0 || (spec && P > 0)) ? nchunk : 0;
 #define GR_BLEND(ST, FE)                                                                                                  \
-  hipLaunchKernelGGL((blend_kernel<ST, FE>), dim3(gx, gy, num_views), dim3(BLOCK), 0, stream, (int)P, W, H, R > 0 ? nchunk : 0, \
-                     g.views, g.seg_off, point_list, g.rec, out_color)
+  hipLaunchKernelGGL((blend_kernel<ST, FE>), dim3(gx, gy, num_views), dim3(BLOCK), 0, stream, (int)P, W, H, blend_chunks, \
+                     g.views, g.seg_off, point_list, g.rec, out_color, list_cap)
   if (stats) {
     if (fast) GR_BLEND(true, true); else GR_BLEND(true, false);
   } else {
@@ -1333,11 +1381,45 @@ extern "C" int gr_raster_render_ex(int64_t P, const gr_raster_view* h_views, int
   return GR_OK;
 }
 
+extern "C" int gr_raster_render_ex(int64_t P, const gr_raster_view* h_views, int num_views,
+                                   const int64_t* h_num_rendered, const void* geom, size_t geom_bytes,
+                                   void* bin, size_t bin_bytes, float* out_color, int flags, void* stream_) {
+  return render_impl(P, h_views, num_views, h_num_rendered, geom, geom_bytes, bin, bin_bytes, out_color, flags, -1,
+                     static_cast<hipStream_t>(stream_));
+}
+
 extern "C" int gr_raster_forward(int64_t P, int M, const float* means3D, const float* shs, const float* colors_precomp,
                                  const float* opacities, const float* scales, const float* rotations,
                                  const float* cov3D_precomp, const gr_raster_view* h_views, int num_views, int32_t* radii,
                                  void* geom, size_t geom_bytes, void* bin, size_t bin_bytes, float* out_color, int flags,
-                                 int64_t* h_num_rendered, void* stream) {
+                                 int64_t* h_num_rendered, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GR_REQUIRE(h_num_rendered != nullptr, "h_num_rendered is null");
+  const int64_t stage_hint = h_num_rendered[num_views > 0 ? num_views : 0];  // in: last frame's largest chunk (0 = unknown)
+  const int64_t entries = bin && bin_bytes > 512 ? (int64_t)((bin_bytes - 512) / sizeof(int32_t)) - 64 : -1;
+  static const bool no_spec = getenv("GR_RASTER_NO_SPECULATION") && getenv("GR_RASTER_NO_SPECULATION")[0] == '1';
+  if (P > 0 && entries > 0 && entries < (1ll << 31) - 1 && !no_spec) {
+    // The host is not needed between the two halves of a frame: the counts are read back behind an event while the
+    // binning scatter and the blend are launched right behind the counting kernels on a list sized by the caller
+    // (last frame's count + 25 %).  The host then waits for the EVENT -- the GPU is still drawing -- and only a frame whose
+    // count turns out larger than the list (the kernels refuse to run past it) is rendered again.
+    static thread_local hipEvent_t ev = nullptr;
+    if (ev == nullptr) GR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    int rc = preprocess_impl(P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, h_views,
+                             num_views, radii, geom, geom_bytes, h_num_rendered, stream, ev);
+    if (rc != GR_OK) return rc;
+    h_num_rendered[num_views] = stage_hint;
+    rc = render_impl(P, h_views, num_views, h_num_rendered, geom, geom_bytes, bin, bin_bytes, out_color, flags, entries, stream);
+    if (rc != GR_OK) return rc;
+    GR_HIP(hipEventSynchronize(ev));
+    bool far_depth = false;
+    rc = preprocess_collect(P, num_views, h_num_rendered, &far_depth);
+    if (rc != GR_OK) return rc;
+    int64_t R = 0;
+    for (int v = 0; v < num_views; ++v) R += h_num_rendered[v];
+    if (!far_depth) return R <= entries ? GR_OK : GR_RETRY_BIN;
+    // a depth >= 8192: the ordering has to be redone on full-width keys -- take the plain path for this frame
+  }
   int rc = gr_raster_preprocess(P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, h_views,
                                 num_views, radii, geom, geom_bytes, h_num_rendered, stream);
   if (rc != GR_OK) return rc;

@@ -38,7 +38,7 @@ class GaussianRasterizationSettings(NamedTuple):
 
 FAST_EXP = 1  # GR_RASTER_FAST_EXP (include/gaussreg_hip.h)
 _ENV_FAST = None
-_bin_hint = {}  # (device, P, V, W, H) -> bytes of the binning buffer the last call of that shape needed
+_bin_hint = {}  # (device, P, V, W, H) -> (bytes of the binning buffer, largest chunk) the last call of that shape needed
 
 
 def _flags(fast_exp):
@@ -143,8 +143,9 @@ def rasterize_views(settings, means3D, opacities, shs=None,
         # the binning buffer is sized from the last call of this shape (+ 25 %): the library is entered once per frame, and
         # only a frame that needs more comes back for a larger buffer
         key = (dev.index, P, V, W, H)
-        hint = _bin_hint.get(key, 0)
+        hint, chunk_hint = _bin_hint.get(key, (0, 0))
         binb = torch.empty(hint + 256, dtype=torch.uint8, device=dev) if hint else None
+        nr[V] = chunk_hint  # in: sizes the scatter's staging block of the speculative launch; out: this call's figure
         rc = L.gr_raster_forward(P, M, _lib.ptr(m), _lib.ptr(sh), _lib.ptr(cp), _lib.ptr(op), _lib.ptr(sc), _lib.ptr(rot),
                                  _lib.ptr(cov), views, V, _lib.ptr(radii), _lib.ptr(geom), geom.numel(), _lib.ptr(binb),
                                  binb.numel() if binb is not None else 0, _lib.ptr(color), flags, nr, st)
@@ -157,7 +158,7 @@ def rasterize_views(settings, means3D, opacities, shs=None,
                                              _lib.ptr(color), flags, st))
         if len(_bin_hint) > 64:
             _bin_hint.clear()
-        _bin_hint[key] = need + need // 4
+        _bin_hint[key] = (need + need // 4 + 1024, int(nr[V]))
     return color, radii, [int(nr[v]) for v in range(V)]
 
 
