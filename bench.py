@@ -162,14 +162,22 @@ def self_spawn(args, argv):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+def newest_profile(suffix):
+    try:
+        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(suffix))
+        return cands[-1] if cands else None
+    except Exception:
+        return None
+
+
 def pmc_traffic(key, ok, units=None):
-    """HBM bytes per launch from the newest committed rocprofv3 --pmc summary (separate FETCH_SIZE / WRITE_SIZE passes,
-    FETCH doubled per MI355X_MICROARCH.md); only valid for the configuration it was taken on."""
+    """HBM bytes per launch from the newest COMMITTED rocprofv3 --pmc summary (profiles/*_pmc_hbm.json: separate FETCH_SIZE /
+    WRITE_SIZE passes, FETCH doubled per MI355X_MICROARCH.md) -- not measured in this run; only valid for the configuration
+    it was taken on.  The file it came from is reported next to it (`traffic_source`)."""
     if not ok:
         return None
     try:
-        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_hbm.json"))
-        with open(os.path.join(ROOT, "profiles", cands[-1])) as fh:
+        with open(os.path.join(ROOT, "profiles", newest_profile("_pmc_hbm.json"))) as fh:
             doc = json.load(fh)
         if units is not None and doc.get("units_per_launch", {}).get(key) != units:
             return None
@@ -185,8 +193,7 @@ def sq_valu_busy(kernel_substr, ok):
     if not ok:
         return None
     try:
-        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_sq_counters.json"))
-        with open(os.path.join(ROOT, "profiles", cands[-1])) as fh:
+        with open(os.path.join(ROOT, "profiles", newest_profile("_sq_counters.json"))) as fh:
             doc = json.load(fh)
         for k in doc["kernels"]:
             if kernel_substr in k["kernel"]:
@@ -194,6 +201,57 @@ def sq_valu_busy(kernel_substr, ok):
     except Exception:
         pass
     return None
+
+
+def cpu_identity():
+    """CPU model and core counts of this host ("state the core count and CPU model")."""
+    model, phys = None, set()
+    try:
+        pid = cid = None
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("model name") and model is None:
+                    model = ln.split(":", 1)[1].strip()
+                elif ln.startswith("physical id"):
+                    pid = ln.split(":", 1)[1].strip()
+                elif ln.startswith("core id"):
+                    cid = ln.split(":", 1)[1].strip()
+                elif not ln.strip():
+                    if pid is not None and cid is not None:
+                        phys.add((pid, cid))
+                    pid = cid = None
+    except Exception:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except Exception:
+        usable = os.cpu_count() or 1
+    return {"cpu_model": model, "logical_cpus": os.cpu_count(), "physical_cores": len(phys) or None, "cores_available": usable}
+
+
+def all_cores(task, units_per_task, unit, workers, tasks_per_worker=1, lead_s=12.0):
+    """`workers` PROCESSES (tools/cpu_worker.py), each `tasks_per_worker` units of `task`, started together (the reference's
+    model: one DataLoader worker process per core, config.py:40 num_workers).  Returns units/s over the common interval."""
+    start = time.time() + lead_s   # the workers import numpy / torch first and then wait for this instant
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "cpu_worker.py"), task, str(tasks_per_worker),
+                               repr(start), str(i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                              env=dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+             for i in range(workers)]
+    t_first, t_last, ok = None, None, 0
+    for pr in procs:
+        out, _ = pr.communicate()
+        for ln in out.splitlines():
+            if ln.startswith("DONE "):
+                _, a, b = ln.split()
+                t_first = float(a) if t_first is None else min(t_first, float(a))
+                t_last = float(b) if t_last is None else max(t_last, float(b))
+                ok += 1
+    if not ok:
+        return {"error": "no CPU worker finished"}
+    late = max(0.0, t_first - start)
+    dt = t_last - start
+    return {"value": round(ok * tasks_per_worker * units_per_task / dt, 4), "unit": unit, "cores": ok, "tasks": ok * tasks_per_worker,
+            "seconds": round(dt, 2), "workers_late_s": round(late, 2)}
 
 
 def timing_read(L, name):
@@ -208,6 +266,7 @@ def hbm_roofline(kernel, bytes_per_launch, total_ms, launches, traffic=None, **m
     ach = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else None
     r = {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 2) if ach else None, "peak": HBM_PEAK_GBS,
          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None, "traffic": traffic,
+         "traffic_source": ("profiles/" + str(newest_profile("_pmc_hbm.json")) + " (committed PMC summary, not this run)") if traffic else None,
          "bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(avg_s * 1e3, 4)}
     r.update(more)
     return r
@@ -273,7 +332,8 @@ def run_gpu(h, args):
          "roofline": hbm_roofline("raster_blend", blend_bytes, blend_ms, blend_n,
                                   pmc_traffic("raster_blend", (P, W, H) == (1_000_000, 640, 480), V),
                                   kernels_ms_per_step=raster_kernels,
-                                  valu_busy=sq_valu_busy("blend_kernel<false>", (P, W, H) == (1_000_000, 640, 480)))})
+                                  valu_busy=sq_valu_busy("blend_kernel<false", (P, W, H) == (1_000_000, 640, 480)),
+                                  valu_busy_source="profiles/" + str(newest_profile("_sq_counters.json")))})
 
     # ------------------------------------------------------------------ the boundary: one camera per forward() call
     if not args.no_single_view:
@@ -287,8 +347,13 @@ def run_gpu(h, args):
 
         single_step()
         n_sv = max(args.steps, 20)
+        # throughput with the per-kernel event timers OFF (ten event records per frame are a measurable share of a 0.3 ms
+        # frame); the per-kernel figures come from a second, instrumented pass of the same loop
+        L.gr_timing_enable(0)
+        sv_elapsed = h.timed(single_step, n_sv, max(args.warmup, 3))
         L.gr_timing_enable(1)
-        sv_elapsed = h.timed(single_step, n_sv, max(args.warmup, 3), after_warmup=L.gr_timing_reset)
+        L.gr_timing_reset()
+        h.timed(single_step, n_sv, 1, after_warmup=L.gr_timing_reset)
         sv_kernels = per_step_ms(L, ["raster_preprocess", "raster_depth_sort", "raster_bin", "raster_sort", "raster_blend"], n_sv)
         L.gr_timing_enable(0)
         L.gr_timing_reset()
@@ -296,6 +361,36 @@ def run_gpu(h, args):
                                "ms_per_view": round(sv_elapsed / n_sv * 1e3, 4),
                                "api": "diff_gaussian_rasterization.GaussianRasterizer.forward, one camera per call, "
                                       "same 1M-Gaussian scene", "kernels_ms_per_view": sv_kernels}
+        # the opt-in fast-exponential blend (1e-5 relative of the bit-exact image, tests/test_gpu_rasterizer_fast.py)
+        rast_f = [GaussianRasterizer(s, fast_exp=True) for s in settings_list[: min(V, 8)]]
+
+        def single_fast():
+            r = rast_f[k["i"] % len(rast_f)]
+            k["i"] += 1
+            last["sv"] = r(t["means3D"], None, t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+
+        single_fast()
+        svf = h.timed(single_fast, n_sv, max(args.warmup, 3))
+        line["single_view"]["fast_exp"] = {"value": round(world * n_sv / svf, 2), "ms_per_view": round(svf / n_sv * 1e3, 4)}
+
+        def fast_step():
+            img, radii, nr = rasterize_views(settings, t["means3D"], t["opacities"], shs=t["shs"], scales=t["scales"],
+                                             rotations=t["rotations"], fast_exp=True)
+            last["imgf"] = img
+
+        fast_step()
+        L.gr_timing_enable(1)
+        f_elapsed = h.timed(fast_step, args.steps, args.warmup, after_warmup=L.gr_timing_reset)
+        fb_ms, fb_n = timing_read(L, "raster_blend")
+        L.gr_timing_enable(0)
+        L.gr_timing_reset()
+        line["fast_exp"] = {"value": round(world * V * args.steps / f_elapsed, 2), "unit": "views/s",
+                            "ms_per_step": round(f_elapsed / args.steps * 1e3, 4),
+                            "blend_avg_launch_ms": round(fb_ms / max(fb_n, 1), 4),
+                            "blend_frac_of_hbm_peak": round(blend_bytes / (fb_ms / max(fb_n, 1) / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "note": "opt-in GR_RASTER_FAST_EXP / fast_exp=True: v_exp_f32 in the blend; image within 1e-6 + 1e-5 rel "
+                                    "of the float64 renderer on >= 99.9 % of the pixels (tests/test_gpu_rasterizer_fast.py); the "
+                                    "headline `value` is the bit-exact mode"}
 
     # ------------------------------------------------------------------ radius_neighbors (2nd half of the metric)
     radius = None
@@ -322,7 +417,9 @@ def run_gpu(h, args):
                   "unit": "Mpts/s", "ms_per_step": round(step_s * 1e3, 4),
                   "config": {"workload": f"{B} x 200k-pt clouds per GPU per step, r=0.0625, self-search, width {width}"},
                   "roofline": hbm_roofline("radius_fill", fill_bytes, fill_ms, fill_n, pmc_traffic("radius_fill", True, B),
-                                           kernels_ms_per_step=rk, valu_busy=sq_valu_busy("traverse_kernel<128, false, true>", True),
+                                           kernels_ms_per_step=rk, valu_busy=sq_valu_busy("traverse_kernel<128, true, true>", True),
+                                           count_valu_busy=sq_valu_busy("traverse_kernel<128, false, true>", True),
+                                           valu_busy_source="profiles/" + str(newest_profile("_sq_counters.json")),
                                            end_to_end_frac=round(fill_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4))}
         # the width-limited path the data pyramid calls (radius_search with neighbor_limit, utils/data.py:35-67)
         if not args.no_radius_limited:
@@ -339,7 +436,18 @@ def run_gpu(h, args):
             radius["limited"] = {"value": round(world * nq * args.steps / l_elapsed / 1e6, 2), "unit": "Mpts/s",
                                  "ms_per_step": round(l_elapsed / args.steps * 1e3, 4), "neighbor_limit": lim, "width": lw,
                                  "end_to_end_frac": round(lbytes / (l_elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
-                                 "kernels_ms_per_step": lk}
+                                 "kernels_ms_per_step": lk, "mode": "count + fill (default)"}
+            # the same call through the single-pass kernel (gr_radius_search mode 1)
+            old_mode = L.gr_radius_search_mode(1)
+            limited_step()
+            s_elapsed = h.timed(limited_step, args.steps, args.warmup, after_warmup=L.gr_timing_reset)
+            sk = per_step_ms(L, ["radius_bin", "radius_fused"], args.steps)
+            L.gr_radius_search_mode(old_mode)
+            fused_ms = sk.get("radius_fused", 0.0)
+            radius["limited"]["single_pass"] = {
+                "value": round(world * nq * args.steps / s_elapsed / 1e6, 2), "ms_per_step": round(s_elapsed / args.steps * 1e3, 4),
+                "end_to_end_frac": round(lbytes / (s_elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4), "kernels_ms_per_step": sk,
+                "roofline": hbm_roofline("radius_fused", lbytes, fused_ms * args.steps, args.steps) if fused_ms else None}
         L.gr_timing_enable(0)
         L.gr_timing_reset()
         del out, dpts
@@ -402,9 +510,12 @@ def run_gpu(h, args):
                                bg=np.zeros(3, np.float32), W=W, H=H, tanfovx=c["tanfovx"], tanfovy=c["tanfovy"],
                                sh_degree=3)
         dt = time.perf_counter() - tc
+        ident = cpu_identity()
+        workers = max(1, min(ident["cores_available"], ident["physical_cores"] or ident["cores_available"], 64))
         cpu_baseline = {"value": round(1.0 / dt, 4), "unit": "views/s", "cores": 1, "kind": "port",
                         "sample": f"1 view of the same {P}-Gaussian {W}x{H} scene through oracle/rasterizer_oracle.c "
                                   f"({dt:.2f} s; the rasterizer has no reference implementation in the GaussReg tree)"}
+        cpu_baseline.update(ident)
         kind = "reference" if capi.have_ref() else "port"
         if radius is not None:
             p1, l1 = synthetic.cloud_200k(1, seed=0)
@@ -416,6 +527,11 @@ def run_gpu(h, args):
                                       "sample": "one 200k-pt cloud, single thread ("
                                                 + ("reference C++ core compiled in oracle/_ref" if kind == "reference"
                                                    else "oracle/radius_neighbors_oracle.c") + f", {dt:.2f} s)"}
+            radius["cpu_baseline"].update(ident)
+            ac = all_cores("radius200k", 0.2, "Mpts/s", workers, tasks_per_worker=8)
+            ac["sample"] = (f"{ac.get('tasks')} searches of independent 200k-pt clouds, 8 per worker process, one process per core "
+                            f"on {workers} cores, same {kind} core")
+            radius["cpu_baseline"]["all_cores"] = ac
         if "pairs" in line:
             # the reference's per-pair CPU work on this path: the collate pyramid (utils/data.py:13-77) on one core
             from gaussreg_amd import pair_pipeline
@@ -424,23 +540,38 @@ def run_gpu(h, args):
             lens = np.array([30000, 30000], np.int64)
             gs = capi.ref_grid_subsampling if kind == "reference" else capi.grid_subsampling
             rn = capi.ref_radius_neighbors if kind == "reference" else capi.radius_neighbors
+
+            def one_pyramid(_i=0):
+                plist, llist, voxel, rad = [pts], [lens], 0.025, 0.0625
+                for i in range(1, 5):
+                    voxel *= 2
+                    p2, l2 = gs(plist[-1], llist[-1], voxel)
+                    plist.append(p2)
+                    llist.append(l2)
+                for i in range(5):
+                    rn(plist[i], plist[i], llist[i], llist[i], rad)
+                    if i < 4:
+                        rn(plist[i + 1], plist[i], llist[i + 1], llist[i], rad)
+                        rn(plist[i], plist[i + 1], llist[i], llist[i + 1], 2 * rad)
+                    rad *= 2
+
             tc = time.perf_counter()
-            plist, llist, voxel, rad = [pts], [lens], 0.025, 0.0625
-            for i in range(1, 5):
-                voxel *= 2
-                p2, l2 = gs(plist[-1], llist[-1], voxel)
-                plist.append(p2)
-                llist.append(l2)
-            for i in range(5):
-                rn(plist[i], plist[i], llist[i], llist[i], rad)
-                if i < 4:
-                    rn(plist[i + 1], plist[i], llist[i + 1], llist[i], rad)
-                    rn(plist[i], plist[i + 1], llist[i], llist[i + 1], 2 * rad)
-                rad *= 2
+            one_pyramid()
             dt = time.perf_counter() - tc
             line["pairs"]["cpu_baseline"] = {"value": round(1.0 / dt, 4), "unit": "pairs/s", "cores": 1, "kind": kind,
+                                             "scope": "pyramid_only",
                                              "sample": f"the collate pyramid (4 grid_subsample + 13 radius_search) of ONE 2x30000-pt "
-                                                       f"pair on one core ({dt:.2f} s); FPS and the network are not included"}
+                                                       f"pair on one core ({dt:.2f} s); FPS, the network, matching and RANSAC are NOT "
+                                                       f"included -- compare with pairs.pyramid_only_gpu, not with pairs.value"}
+            line["pairs"]["cpu_baseline"].update(ident)
+            ac = all_cores("pyramid", 1.0, "pairs/s", workers, tasks_per_worker=4)
+            ac["sample"] = f"{ac.get('tasks')} pyramids, 4 per worker process, one process per core on {workers} cores (pyramid only)"
+            line["pairs"]["cpu_baseline"]["all_cores"] = ac
+            ex = line.get("extras") or {}
+            for kname, kval in ex.items():
+                if "pyramid" in kname and isinstance(kval, dict) and "ms" in kval:
+                    line["pairs"]["pyramid_only_gpu"] = {"extras_key": kname, **{kk: kval[kk] for kk in kval if kk in ("ms", "pairs", "pairs_per_s", "ms_per_pair")}}
+                    break
     line["cpu_baseline"] = cpu_baseline
     return line
 

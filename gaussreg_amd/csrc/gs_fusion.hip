@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void transform_kernel(const float* __restrict_
   if (i >= n) return;
   const float* v = in + (int64_t)i * REC;
   float* o = out + (int64_t)i * REC;
-  for (int k = 3; k < 9; ++k) o[k] = v[k];       // normals, f_dc unchanged
+  for (int k = 3; k < 9; ++k) o[k] = v[k];       // f_dc unchanged (the normals are zeroed when the records are gathered)
   o[54] = v[54];                                   // opacity
   // xyz (fp64, like the reference's float32 @ float64 product)
   const double x = v[0], y = v[1], z = v[2];

@@ -1564,9 +1564,9 @@ struct FusedCfg {
 };
 inline FusedCfg fused_cfg() {
   static const FusedCfg cfg = [] {
-    FusedCfg c{128, 1, 28, 0};
+    FusedCfg c{64, 1, 28, 0};  // 64 queries per block: 30 KB of LDS, five blocks per CU (0.43 ms per 8 x 200 k; 128: 0.50 ms)
     if (const char* e = getenv("GR_RADIUS_FUSED_STOP")) c.dbg_stop = atoi(e);
-    if (const char* e = getenv("GR_RADIUS_FUSED_RQ")) c.rq = atoi(e) == 64 ? 64 : 128;
+    if (const char* e = getenv("GR_RADIUS_FUSED_RQ")) c.rq = atoi(e) == 128 ? 128 : 64;
     if (const char* e = getenv("GR_RADIUS_FUSED_ROWBUF")) c.rowbuf = atoi(e) != 0;
     if (const char* e = getenv("GR_RADIUS_FUSED_SLOTS")) c.per_q = max(8, min(512, atoi(e)));
     return c;

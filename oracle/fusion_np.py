@@ -62,4 +62,6 @@ def gaussian_fuse(rec1, rec2, T):
     c2 = xyz2.mean(0)
     k1 = np.linalg.norm(rec1[:, 0:3] - c1, axis=1) < np.linalg.norm(rec1[:, 0:3] - c2, axis=1)
     k2 = np.linalg.norm(xyz2 - c2, axis=1) < np.linalg.norm(xyz2 - c1, axis=1)
-    return np.concatenate([rec1[k1], out2[k2].astype(np.float32)], 0)
+    fused = np.concatenate([rec1[k1], out2[k2].astype(np.float32)], 0)
+    fused[:, 3:6] = 0.0  # save_ply writes zero normals whatever the inputs held (gs_fusion.py:186-187)
+    return fused

@@ -76,6 +76,10 @@ def main():
         return rec
 
     rec1, rec2 = cloud(700, [0, 0, 0]), cloud(600, [0.5, 0.2, -0.1])
+    # non-zero input normals: the reference's save_ply writes zeros whatever the inputs held (gs_fusion.py:186-187)
+    nrng = np.random.default_rng(77)
+    rec1[:, 3:6] = nrng.normal(0, 1.0, (700, 3))
+    rec2[:, 3:6] = nrng.normal(0, 1.0, (600, 3))
     # similarity transform: rotation * 1.37 + translation
     ax = np.array([0.3, -0.5, 0.8]); ax /= np.linalg.norm(ax); ang = 0.9
     Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
