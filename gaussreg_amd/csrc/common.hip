@@ -1,4 +1,5 @@
 // Error plumbing + a small multi-row exclusive scan used by the binning kernels.
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -310,29 +311,35 @@ int exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int rows, int
 namespace {
 // Hardware property probe.  gfx950's LDS resolves the lanes of ONE ds_add_rtn_u32 that hit the same address in ascending
 // lane order (the returned pre-add values grow with the lane id).  That is not an architectural promise, so it is
-// MEASURED once per process on the device in use: 64 lanes x many address patterns (all-same, strided, hashed); if any
-// group of equal-address lanes comes back out of lane order the scatter falls back to explicit ballot ranking.
-__global__ __launch_bounds__(WAVE) void lds_atomic_order_probe_kernel(int* __restrict__ bad) {
-  __shared__ unsigned int cell[256];
-  __shared__ unsigned int got[WAVE];
-  __shared__ unsigned int adr[WAVE];
-  const int lane = threadIdx.x;
+// MEASURED once per process and device, in the shape the production kernels use it: 16 waves per workgroup, every wave on
+// its own 512-counter row (the depth sort's layout), 256 workgroups in flight so that all waves of a CU contend for the
+// LDS at once, 96 address patterns (strided, hashed, with lanes masked off).  If any group of equal-address lanes comes
+// back out of lane order the sorts use explicit ballot ranking.  The probe is backed by a check of the real output: the
+// rasterizer verifies the depth order and the per-tile lists of its first frames (rasterizer.hip) and demotes the device
+// (lds_order_demote) if they are not sorted.
+constexpr int PROBE_WAVES = 16, PROBE_ROW = 512;
+
+__global__ __launch_bounds__(PROBE_WAVES* WAVE) void lds_atomic_order_probe_kernel(int* __restrict__ bad) {
+  __shared__ unsigned int cell[PROBE_WAVES][PROBE_ROW];
+  __shared__ unsigned int got[PROBE_WAVES][WAVE];
+  __shared__ unsigned int adr[PROBE_WAVES][WAVE];
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
   int nbad = 0;
   for (int pat = 0; pat < 96; ++pat) {
-    for (int i = lane; i < 256; i += WAVE) cell[i] = 0u;
+    for (int i = lane; i < PROBE_ROW; i += WAVE) cell[w][i] = 0u;
     __syncthreads();
     unsigned int a;
-    if (pat < 64) a = (unsigned int)(lane % (pat + 1));                  // 1 .. 64 distinct addresses, strided
-    else a = ((unsigned int)(lane * 2654435761u + pat * 40503u) >> 7) % (unsigned int)(3 + (pat - 64) * 7);  // hashed
-    const bool take = pat < 80 || ((lane * 7 + pat) % 5) != 0;           // some patterns run with lanes masked off
+    if (pat < 64) a = (unsigned int)(lane % (pat + 1)) * 7u;                 // 1 .. 64 distinct addresses, strided
+    else a = ((unsigned int)((lane + 64 * w) * 2654435761u + (pat + blockIdx.x) * 40503u) >> 7) % (unsigned int)(3 + (pat - 64) * 15);
+    const bool take = pat < 80 || ((lane * 7 + pat + w) % 5) != 0;            // some patterns run with lanes masked off
     unsigned int r = 0xffffffffu;
-    if (take) r = atomicAdd(&cell[a], 1u);
-    got[lane] = r;
-    adr[lane] = a;
+    if (take) r = atomicAdd(&cell[w][a], 1u);
+    got[w][lane] = r;
+    adr[w][lane] = a;
     __syncthreads();
     if (take) {
       unsigned int want = 0;  // lanes below me on the same address that took part
-      for (int l = 0; l < lane; ++l) want += (adr[l] == a && got[l] != 0xffffffffu) ? 1u : 0u;
+      for (int l = 0; l < lane; ++l) want += (adr[w][l] == a && got[w][l] != 0xffffffffu) ? 1u : 0u;
       if (want != r) ++nbad;
     }
     __syncthreads();
@@ -343,39 +350,53 @@ __global__ __launch_bounds__(WAVE) void lds_atomic_order_probe_kernel(int* __res
 }  // namespace
 
 // 1 = lane-ordered LDS atomics verified on this device, 0 = not (ballot ranking is used), -1 = not probed yet
-int g_lds_order[64] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
-                              -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
-                              -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+static std::atomic<int> g_lds_order[64];
+static std::once_flag g_lds_once;
+static void lds_order_init() {
+  for (auto& v : g_lds_order) v.store(-1);
+}
+
+static int lds_device_slot() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  return (dev < 0 || dev >= 64) ? 63 : dev;
+}
 
 int lds_atomics_lane_ordered(hipStream_t stream, bool* ordered) {
-  int dev = 0;
-  GR_HIP(hipGetDevice(&dev));
+  std::call_once(g_lds_once, lds_order_init);
+  const int dev = lds_device_slot();
+  GR_REQUIRE(dev >= 0, "hipGetDevice failed");
   const char* force = getenv("GR_RASTER_BALLOT_RANKING");
   if (force && force[0] == '1') {
     *ordered = false;
     return GR_OK;
   }
-  if (dev < 0 || dev >= 64) dev = 63;
-  if (g_lds_order[dev] < 0) {
+  if (g_lds_order[dev].load() < 0) {
     int* d_bad = nullptr;
     int h_bad = 1;
     GR_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_bad), sizeof(int), stream));
     GR_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), stream));
-    hipLaunchKernelGGL(lds_atomic_order_probe_kernel, dim3(8), dim3(WAVE), 0, stream, d_bad);
+    hipLaunchKernelGGL(lds_atomic_order_probe_kernel, dim3(256), dim3(PROBE_WAVES * WAVE), 0, stream, d_bad);
     GR_HIP(hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, stream));
     GR_HIP(hipStreamSynchronize(stream));
     GR_HIP(hipFreeAsync(d_bad, stream));
-    g_lds_order[dev] = h_bad == 0 ? 1 : 0;
+    int expect = -1;
+    g_lds_order[dev].compare_exchange_strong(expect, h_bad == 0 ? 1 : 0);  // a concurrent demotion is not overwritten
   }
-  *ordered = g_lds_order[dev] == 1;
+  *ordered = g_lds_order[dev].load() == 1;
   return GR_OK;
 }
 
 int lds_atomics_lane_ordered_state() {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return -1;
-  if (dev < 0 || dev >= 64) dev = 63;
-  return g_lds_order[dev];
+  std::call_once(g_lds_once, lds_order_init);
+  const int dev = lds_device_slot();
+  return dev < 0 ? -1 : g_lds_order[dev].load();
+}
+
+void lds_order_demote() {
+  std::call_once(g_lds_once, lds_order_init);
+  const int dev = lds_device_slot();
+  if (dev >= 0) g_lds_order[dev].store(0);
 }
 
 }  // namespace gr

@@ -115,6 +115,7 @@ int sort_pairs_u64_iota(void* temp, size_t temp_bytes, const uint64_t* keys_in, 
 // this device?  Probed once per process and device (common.hip); GR_RASTER_BALLOT_RANKING=1 forces "no".
 int lds_atomics_lane_ordered(hipStream_t stream, bool* ordered);
 int lds_atomics_lane_ordered_state();  // 1 yes, 0 no, -1 not probed yet
+void lds_order_demote();                // a sort that relied on the property came out unsorted: use ballot ranking from now on
 
 // Segmented stable LSD radix sort of the rasterizer's (view, Gaussian) depth keys (depth_sort.hip).
 size_t depth_sort_table_bytes(int64_t P, int V);

@@ -20,6 +20,8 @@
 #include <type_traits>
 #include <vector>
 
+#include <atomic>
+
 #include "common.hpp"
 
 namespace gr {
@@ -1099,6 +1101,80 @@ int check_views(const gr_raster_view* h_views, int num_views) {
   return GR_OK;
 }
 
+// ------------------------------------------------------------------------------------ self-check of the ordered outputs
+// The depth sort and the tile scatter take their stable ranks from the lane order of LDS atomics (a measured property of
+// the device, common.hip).  The first frames of a process are therefore CHECKED on the device: depth order (ties: id) of
+// every view, and every (chunk, tile) segment of the point list in depth order.  A failure demotes the device to explicit
+// ballot ranking and the stage is redone.  GR_RASTER_VERIFY=1 checks every frame.
+__global__ __launch_bounds__(256) void verify_depth_order_kernel(int P, int V, const int32_t* __restrict__ nvis,
+                                                                 const uint32_t* __restrict__ dfield,
+                                                                 const int32_t* __restrict__ ids, int32_t* __restrict__ rank,
+                                                                 int* __restrict__ bad) {
+  const int v = blockIdx.y;
+  const int n = nvis[v];
+  const int64_t o = (int64_t)v * P;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int a = ids[o + i];
+    rank[o + a] = i;
+    if (i + 1 < n) {
+      const int b = ids[o + i + 1];
+      const uint32_t fa = dfield[o + a], fb = dfield[o + b];
+      if (fa > fb || (fa == fb && a >= b)) atomicOr(bad, 1);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void verify_tile_lists_kernel(int P, int V, int nchunk, int tiles,
+                                                                const uint32_t* __restrict__ seg_off,
+                                                                const int32_t* __restrict__ point_list,
+                                                                const int32_t* __restrict__ rank, int* __restrict__ bad) {
+  const int v = blockIdx.x / nchunk;
+  const uint32_t* seg = seg_off + (int64_t)blockIdx.x * (tiles + 1);
+  const int32_t* rk = rank + (int64_t)v * P;
+  for (int t = threadIdx.x; t < tiles; t += 256) {
+    int prev = -1;
+    for (uint32_t e = seg[t]; e < seg[t + 1]; ++e) {
+      const int r = rk[point_list[e]];
+      if (r <= prev) atomicOr(bad, 2);
+      prev = r;
+    }
+  }
+}
+
+}  // namespace
+}  // namespace gr
+
+namespace gr {
+namespace {
+std::atomic<int> g_verified_frames[64];
+
+bool verify_this_frame() {
+  static const bool always = getenv("GR_RASTER_VERIFY") && getenv("GR_RASTER_VERIFY")[0] == '1';
+  if (lds_atomics_lane_ordered_state() != 1) return always;  // ballot ranking needs no such check (but may be asked for)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
+  return always || g_verified_frames[dev].load() < 3;
+}
+
+void frame_verified() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
+  g_verified_frames[dev].fetch_add(1);
+}
+
+// runs `launch_check(d_flag)` (which enqueues the check kernels), waits, returns the flag word
+template <typename F>
+int device_check(hipStream_t stream, F&& launch_check, int* h_flag) {
+  int* d_bad = nullptr;
+  GR_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_bad), sizeof(int), stream));
+  GR_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), stream));
+  launch_check(d_bad);
+  GR_HIP(hipMemcpyAsync(h_flag, d_bad, sizeof(int), hipMemcpyDeviceToHost, stream));
+  GR_HIP(hipStreamSynchronize(stream));
+  GR_HIP(hipFreeAsync(d_bad, stream));
+  return GR_OK;
+}
+
 // dv must stay alive until `stream` is synchronised by the caller
 int upload_views(const gr_raster_view* h_views, int num_views, DevView* d_views,
                  hipStream_t stream) {
@@ -1265,6 +1341,21 @@ static int preprocess_impl(int64_t P, int M, const float* means3D, const float* 
   rc = sort_and_count(KEY_DEPTH_BITS);
   if (rc != GR_OK) return rc;
   if (defer_ev != nullptr) return GR_OK;
+  auto check_depth_order = [&]() -> int {  // first frames of the process: is every view really in (depth, id) order?
+    if (!verify_this_frame()) return GR_OK;
+    int h_bad = 0;
+    int rcv = device_check(stream, [&](int* d_bad) {
+      hipLaunchKernelGGL(verify_depth_order_kernel, dim3((unsigned)std::min<int64_t>((P + 255) / 256, 4096), num_views), blk, 0,
+                         stream, (int)P, num_views, g.nvis, g.dfield, g.order_b, reinterpret_cast<int32_t*>(g.keys_a), d_bad);
+    }, &h_bad);
+    if (rcv != GR_OK) return rcv;
+    if (h_bad != 0 && lds_atomics_lane_ordered_state() == 1) {
+      lds_order_demote();  // the lane-order property did not hold under load: explicit ranking from now on
+      return 1;
+    }
+    GR_REQUIRE(h_bad == 0, "depth sort produced an unsorted order (internal error)");
+    return GR_OK;
+  };
   if (tot[num_views] != 0) {  // some depth >= 8192: redo the ordering with full-width keys
     hipLaunchKernelGGL(full_keys_kernel, dim3((unsigned)((P * num_views + 255) / 256)), blk, 0, stream, P * num_views,
                        g.rec, radii, g.dfield);
@@ -1272,6 +1363,14 @@ static int preprocess_impl(int64_t P, int M, const float* means3D, const float* 
     rc = sort_and_count(32);
     if (rc != GR_OK) return rc;
   }
+  rc = check_depth_order();
+  if (rc == 1) {
+    rc = sort_and_count(tot[num_views] != 0 ? 32 : KEY_DEPTH_BITS);
+    if (rc != GR_OK) return rc;
+    rc = check_depth_order();
+    if (rc == 1) rc = GR_OK;
+  }
+  if (rc != GR_OK) return rc;
 #undef GR_PRE
   for (int v = 0; v < num_views; ++v) h_num_rendered[v] = tot[v];
   h_num_rendered[num_views] = h_chunk_max;  // sizes the scatter's LDS staging block in gr_raster_render
@@ -1359,10 +1458,31 @@ static int render_impl(int64_t P, const gr_raster_view* h_views, int num_views, 
     while ((1 << tile_bits) < tiles) ++tile_bits;
     if (lds > 64 * 1024)
       GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    KernelTimer timer("raster_bin", stream);
-    hipLaunchKernelGGL(kern, dim3((unsigned)bin_grid(num_views, nchunk)), dim3(BIN_T), lds, stream, (int)P, num_views, gx, gy,
-                       nchunk, tile_bits, stage_cap, g.nvis, g.rects, g.order_b, g.rec, g.seg_off, b.point_list, list_cap);
-    GR_LAUNCH_CHECK();
+    {
+      KernelTimer timer("raster_bin", stream);
+      hipLaunchKernelGGL(kern, dim3((unsigned)bin_grid(num_views, nchunk)), dim3(BIN_T), lds, stream, (int)P, num_views, gx, gy,
+                         nchunk, tile_bits, stage_cap, g.nvis, g.rects, g.order_b, g.rec, g.seg_off, b.point_list, list_cap);
+      GR_LAUNCH_CHECK();
+    }
+    if (!spec && verify_this_frame()) {  // first frames: every (chunk, tile) segment in depth order?
+      int h_bad = 0;
+      rc = device_check(stream, [&](int* d_bad) {
+        // (the depth check of gr_raster_preprocess left the depth rank of every Gaussian in keys_a)
+        hipLaunchKernelGGL(verify_tile_lists_kernel, dim3((unsigned)(num_views * nchunk)), dim3(256), 0, stream, (int)P, num_views,
+                           nchunk, tiles, g.seg_off, b.point_list, reinterpret_cast<const int32_t*>(g.keys_a), d_bad);
+      }, &h_bad);
+      if (rc != GR_OK) return rc;
+      if (h_bad != 0 && ordered) {
+        lds_order_demote();
+        hipLaunchKernelGGL(tile_scatter_kernel<false>, dim3((unsigned)bin_grid(num_views, nchunk)), dim3(BIN_T), lds, stream, (int)P,
+                           num_views, gx, gy, nchunk, tile_bits, stage_cap, g.nvis, g.rects, g.order_b, g.rec, g.seg_off,
+                           b.point_list, list_cap);
+        GR_LAUNCH_CHECK();
+      } else {
+        GR_REQUIRE(h_bad == 0, "tile binning produced an unsorted list (internal error)");
+        frame_verified();
+      }
+    }
   }
   KernelTimer timer("raster_blend", stream);
   static const bool stats = getenv("GR_BLEND_STATS") && getenv("GR_BLEND_STATS")[0] == '1';
@@ -1398,7 +1518,7 @@ extern "C" int gr_raster_forward(int64_t P, int M, const float* means3D, const f
   const int64_t stage_hint = h_num_rendered[num_views > 0 ? num_views : 0];  // in: last frame's largest chunk (0 = unknown)
   const int64_t entries = bin && bin_bytes > 512 ? (int64_t)((bin_bytes - 512) / sizeof(int32_t)) - 64 : -1;
   static const bool no_spec = getenv("GR_RASTER_NO_SPECULATION") && getenv("GR_RASTER_NO_SPECULATION")[0] == '1';
-  if (P > 0 && entries > 0 && entries < (1ll << 31) - 1 && !no_spec) {
+  if (P > 0 && entries > 0 && entries < (1ll << 31) - 1 && !no_spec && !verify_this_frame()) {
     // The host is not needed between the two halves of a frame: the counts are read back behind an event while the
     // binning scatter and the blend are launched right behind the counting kernels on a list sized by the caller
     // (last frame's count + 25 %).  The host then waits for the EVENT -- the GPU is still drawing -- and only a frame whose

@@ -116,3 +116,38 @@ def test_camera_updated_in_place_is_rendered():
     a1, _ = call(rast)
     b1, _ = call(GaussianRasterizer(_settings(c1, W, H)))
     assert torch.equal(a1, b1) and not torch.equal(a0, a1)
+
+
+def test_sorted_output_self_check_passes_on_every_frame():
+    """GR_RASTER_VERIFY=1: the device-side check of the depth order and of every per-tile list runs on every frame (by default
+    only on the first three of a process) -- with lane-ordered LDS atomics and with explicit ballot ranking -- and the
+    image stays bit-equal to the oracle's."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch
+from gaussreg_amd import synthetic, _lib
+from gaussreg_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from oracle import capi
+P, W, H = 60000, 320, 240
+g = synthetic.gaussians_c2(P, 2)
+cam = synthetic.camera(W, H)
+rs = GaussianRasterizationSettings(H, W, cam["tanfovx"], cam["tanfovy"], torch.zeros(3), 1.0, torch.from_numpy(cam["viewmatrix"]),
+                                   torch.from_numpy(cam["projmatrix"]), 3, torch.from_numpy(cam["campos"]), False, False)
+t = {k: torch.from_numpy(v).cuda() for k, v in g.items()}
+r = GaussianRasterizer(rs)
+for _ in range(5):
+    img, radii = r(t["means3D"], None, t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+wimg, wr, _ = capi.rasterize_forward(g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"],
+                                     viewmatrix=cam["viewmatrix"], projmatrix=cam["projmatrix"], campos=cam["campos"],
+                                     bg=np.zeros(3, np.float32), W=W, H=H, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], sh_degree=3)
+assert np.array_equal(img.cpu().numpy().view(np.uint32), wimg.view(np.uint32))
+print("STATE", _lib.lib().gr_raster_lds_atomics_lane_ordered())
+'''
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    for extra in ({}, {"GR_RASTER_BALLOT_RANKING": "1"}):
+        env = dict(os.environ, GR_RASTER_VERIFY="1", PYTHONPATH=root, **extra)
+        res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=root)
+        assert res.returncode == 0, res.stderr[-2000:]
+        assert "STATE" in res.stdout
