@@ -6,6 +6,8 @@ the GPU through gaussreg_amd:
     GS .ply -> opacity / percentile filter -> FPS to --num_sample -> [opacity, SH colour] features -> volume normalisation
     -> 5-level pyramid (collate) -> GeoTransformer (KPConvFPN, GeometricTransformer, matching, Sinkhorn, LGR, RANSAC)
     -> similarity transform between the ORIGINAL scenes -> estimated_transform.npz, fused scene (gaussian_fuse)
+    -> (--render N) N views of the fused scene through diff_gaussian_rasterization, written as .ppm  (the "render + fuse" of
+       gs_fusion.py's use: BASELINE.json configs[3])
 
     python examples/register_scenes.py --ref_file A/point_cloud.ply --src_file B/point_cloud.ply --weights ckpt.pth.tar
     python examples/register_scenes.py --synthetic            # two views of one synthetic scene, random-init network
@@ -76,6 +78,8 @@ def main():
     ap.add_argument("--weights")
     ap.add_argument("--num_sample", type=int, default=30000)
     ap.add_argument("--synthetic", action="store_true")
+    ap.add_argument("--render", type=int, default=0, help="render this many views of the fused scene (orbit around its centre)")
+    ap.add_argument("--render_size", default="640x480")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     os.makedirs(args.output_path, exist_ok=True)
@@ -115,7 +119,40 @@ def main():
     print("estimated transform (src -> ref):\n", np.array_str(T, precision=4, suppress_small=True))
     if T_gt is not None:
         print("ground truth:\n", np.array_str(T_gt, precision=4, suppress_small=True))
+    if args.render > 0:
+        render_fused(fused, args.render, args.render_size, args.output_path)
     return T
+
+
+def render_fused(fused, n_views, size, output_path):
+    """Render the fused scene from `n_views` cameras on a ring around its centre through the drop-in rasterizer API
+    (diff_gaussian_rasterization.GaussianRasterizationSettings / GaussianRasterizer) and write fused_view_XX.ppm."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    W, H = (int(v) for v in size.lower().split("x"))
+    parts = gs_io.split_records(fused)
+    xyz = parts["means3D"]
+    centre = xyz.mean(0)
+    radius = float((xyz - centre).norm(dim=1).quantile(0.9)) * 2.2 + 1e-3
+    c_np = centre.double().cpu().numpy()
+    t0 = time.perf_counter()
+    for k in range(n_views):
+        ang = 2 * np.pi * k / n_views
+        eye = c_np + radius * np.array([np.cos(ang), 0.25, np.sin(ang)])
+        z = (c_np - eye) / np.linalg.norm(c_np - eye)          # camera looks along +z (3DGS convention)
+        x = np.cross([0.0, 1.0, 0.0], z)
+        x = x / np.linalg.norm(x) if np.linalg.norm(x) > 1e-6 else np.array([1.0, 0.0, 0.0])
+        cam = synthetic.camera(W, H, 60.0, np.stack([x, np.cross(z, x), z], 1), eye)
+        rs = GaussianRasterizationSettings(H, W, cam["tanfovx"], cam["tanfovy"], torch.zeros(3), 1.0,
+                                           torch.from_numpy(cam["viewmatrix"]), torch.from_numpy(cam["projmatrix"]), 3,
+                                           torch.from_numpy(cam["campos"]), False, False)
+        img, _ = GaussianRasterizer(rs)(xyz, None, parts["opacities"], shs=parts["shs"], scales=parts["scales"],
+                                        rotations=parts["rotations"])
+        rgb = (img.clamp(0, 1) * 255.0 + 0.5).to(torch.uint8).permute(1, 2, 0).contiguous().cpu().numpy()
+        with open(os.path.join(output_path, f"fused_view_{k:02d}.ppm"), "wb") as fh:
+            fh.write(b"P6 %d %d 255\n" % (W, H))
+            fh.write(rgb.tobytes())
+    torch.cuda.synchronize()
+    print(f"rendered {n_views} views of the fused scene at {W}x{H} in {1e3 * (time.perf_counter() - t0):.1f} ms (incl. file output)")
 
 
 if __name__ == "__main__":

@@ -60,9 +60,12 @@ def main():
     spec.loader.exec_module(ref_model)
     ref_model.registration_with_ransac_from_correspondences = lambda *a, **k: np.eye(4)
 
-    ref, src = room_pair(6000, 11)
+    # default: 2 x 6 000 points -> model_e2e.npz; `gen_golden_model.py 30000` = the demo size (767-ish superpoints) ->
+    # model_e2e_30000.npz
+    n_per = int(sys.argv[1]) if len(sys.argv) > 1 else 6000
+    ref, src = room_pair(n_per, 11)
     points = np.concatenate([ref, src]).astype(np.float32)
-    lengths = np.array([6000, 6000], np.int64)
+    lengths = np.array([n_per, n_per], np.int64)
     pts, lens, nb, sub, up = pyramid(points, lengths)
     feats = demo_inputs.backbone_feats(points.shape[0])
 
@@ -124,9 +127,10 @@ def main():
     print("node correspondences equal (f32 vs f64):", np.array_equal(out["ref_ci32"], out["ref_ci64"]) and
           np.array_equal(out["src_ci32"], out["src_ci64"]), "corr points:", out["ref_corr32"].shape)
     print("lgr transform\n", out["lgr_transform32"])
-    path = os.path.join(HERE, "model_e2e.npz")
+    out["n_per_cloud"] = np.int64(n_per)
+    path = os.path.join(HERE, "model_e2e.npz" if n_per == 6000 else f"model_e2e_{n_per}.npz")
     np.savez_compressed(path, **out)
-    print("model_e2e.npz", os.path.getsize(path) // 1024, "KiB")
+    print(os.path.basename(path), os.path.getsize(path) // 1024, "KiB")
 
 
 if __name__ == "__main__":

@@ -1,7 +1,7 @@
 """End to end: the whole coarse-registration network (gaussreg_amd.model.GeoTransformer: pyramid -> KPConvFPN ->
 GeometricTransformer -> SuperPointMatching -> Sinkhorn -> LocalGlobalRegistration) against the reference's own
-`GeoTransformer.forward` run on the same seeded weights (tests/golden/gen_golden_model.py; 28 M parameters, 2 x 6 000-point
-pair).  Floating-point outputs: 1e-5 of the tensor scale against the fp64 evaluation and the reference's fp32 values.
+`GeoTransformer.forward` run on the same seeded weights (tests/golden/gen_golden_model.py; 28 M parameters), on a
+2 x 6 000-point pair and at the demo size: 2 x 30 000 points, 767-ish superpoints (model_e2e_30000.npz).  Floating-point outputs: 1e-5 of the tensor scale against the fp64 evaluation and the reference's fp32 values.
 Discrete outputs (the 256 superpoint correspondences, the point correspondences) are decided on scores that differ in the
 last digits between ANY two evaluations -- the reference's own fp32 and fp64 runs order them differently -- so they are
 compared as sets."""
@@ -29,17 +29,18 @@ def _close(got, ref32, ref64, what, tol=1e-5):
     assert e32 <= tol * scale, f"{what}: |hip - ref32| = {e32:.3e} at scale {scale:.3e}"
 
 
-@pytest.fixture(scope="module")
-def run():
+@pytest.fixture(scope="module", params=[("model_e2e.npz", 6000), ("model_e2e_30000.npz", 30000)], ids=["2x6000", "2x30000"])
+def run(request):
     from gaussreg_amd.kpconv import KPConv
     from gaussreg_amd.model import GeoTransformer, make_cfg
     from geotransformer.utils.data import precompute_data_stack_mode
-    g = load_golden("model_e2e.npz")
-    ref, src = room_pair(6000, 11)
+    name, n_per = request.param
+    g = load_golden(name)
+    ref, src = room_pair(n_per, 11)
     points = np.concatenate([ref, src]).astype(np.float32)
     assert float(points.astype(np.float64).sum()) == float(g["points_sum"])
     feats = demo_inputs.backbone_feats(points.shape[0])
-    d = precompute_data_stack_mode(torch.from_numpy(points).cuda(), torch.tensor([6000, 6000]), 5, 0.025, 0.0625, LIMITS)
+    d = precompute_data_stack_mode(torch.from_numpy(points).cuda(), torch.tensor([n_per, n_per]), 5, 0.025, 0.0625, LIMITS)
     assert [p.shape[0] for p in d["points"]] == g["level_sizes"].tolist()
     d["features"] = feats.cuda()
     torch.manual_seed(int(g["seed"]))

@@ -188,6 +188,82 @@ def run(dev):
         sp2 = rp2 + 0.01 * R(P, K, 3)
         ms = _ms(lambda: lgr(rp2, sp2, rm, sm, m2, gs), 10)
         out["local_global_registration"] = {"ms": round(ms, 4)}
+        del rp2, sp2, m2, sc
+        # ---- configs[3]: gs_fusion.py render + fuse -- two 1.5 M-Gaussian scenes fused on the .ply wire format
+        #      (gs_fusion.py:231-262), the ~3 M-Gaussian result rendered at 1920 x 1080, 8 cameras per call
+        out.update(config3(dev))
+    return out
+
+
+def config3(dev, P=1_500_000, W=1920, H=1080, V=8):
+    import ctypes
+    import numpy as np
+    from gaussreg_amd import _lib, synthetic
+    from gaussreg_amd.gs_io import gaussian_fuse_records, split_records
+    from gaussreg_amd.rasterizer import GaussianRasterizationSettings, ViewBatch, rasterize_views
+
+    def records(seed):
+        g = synthetic.gaussians_c2(P, seed=seed, sh_degree=3)
+        rec = np.zeros((P, 62), np.float32)
+        rec[:, 0:3] = g["means3D"]
+        rec[:, 3:6] = 1.0                                                      # input normals: the fused file carries zeros
+        rec[:, 6:9] = g["shs"][:, 0, :]
+        rec[:, 9:54] = g["shs"][:, 1:, :].transpose(0, 2, 1).reshape(P, 45)   # f_rest: channel-major (gs_fusion.py:180)
+        rec[:, 54] = np.log(g["opacities"][:, 0] / (1 - g["opacities"][:, 0]))
+        rec[:, 55:58] = np.log(g["scales"])
+        rec[:, 58:62] = g["rotations"]
+        return torch.from_numpy(rec).to(dev)
+
+    out = {}
+    r1, r2 = records(0), records(1)
+    c, s = np.cos(0.3), np.sin(0.3)
+    T = np.eye(4)
+    T[:3, :3] = 1.1 * np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+    T[:3, 3] = [0.2, -0.1, 0.05]
+    ms = _ms(lambda: gaussian_fuse_records(r1, r2, T), 5, 2)
+    fused = gaussian_fuse_records(r1, r2, T)
+    kept = int(fused.shape[0])
+    # algorithmic bytes: both inputs read once (248 B per record), the kept records written once
+    out["gs_fuse_2x1p5M"] = _hbm(ms, 248.0 * (2 * P + kept), kept=kept)
+    del r1, r2
+    parts = split_records(fused)
+    del fused
+    cams = synthetic.camera_ring(V, W, H, seed=0)
+    st = ViewBatch([GaussianRasterizationSettings(H, W, cm["tanfovx"], cm["tanfovy"], torch.zeros(3), 1.0,
+                                                  torch.from_numpy(cm["viewmatrix"]), torch.from_numpy(cm["projmatrix"]), 3,
+                                                  torch.from_numpy(cm["campos"]), False, False) for cm in cams])
+    last = {}
+
+    def render():
+        last["r"] = rasterize_views(st, parts["means3D"], parts["opacities"], shs=parts["shs"], scales=parts["scales"],
+                                    rotations=parts["rotations"])
+
+    L = _lib.lib()
+    render()
+    L.gr_timing_enable(1)
+    L.gr_timing_reset()
+    n = 5
+    torch.cuda.synchronize()
+    L.gr_timing_reset()
+    import time
+    t0 = time.perf_counter()
+    for _ in range(n):
+        render()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    k = {}
+    for name in ("raster_preprocess", "raster_depth_sort", "raster_bin", "raster_blend"):
+        tot, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+        L.gr_timing_read(name.encode(), ctypes.byref(tot), ctypes.byref(cnt))
+        k[name] = round(tot.value / n, 4)
+    L.gr_timing_enable(0)
+    L.gr_timing_reset()
+    R = float(sum(last["r"][2]))
+    blend_bytes = R * 40.0 + 12.0 * H * W * V
+    out["raster_3M_1080p"] = {"ms": round(ms, 3), "views_per_call": V, "views_per_s": round(V / ms * 1e3, 1), "gaussians": kept,
+                              "instances_per_view": round(R / V, 1), "kernels_ms_per_call": k, "blend_bytes": blend_bytes,
+                              "bound": "hbm", "frac": round(blend_bytes / (k["raster_blend"] / 1e3) / 1e9 / HBM_GBS, 4),
+                              "note": "configs[3] stand-in: the fused scene of gs_fuse_2x1p5M, bit-exact blend mode"}
     return out
 
 
