@@ -102,7 +102,7 @@ int compute_bbox(const float* pts, const int32_t* h_off, int32_t* h_blk, const i
                  uint32_t* bbox_dev, int32_t* blk_off_dev, hipStream_t stream, bool blk_off_on_device = false,
                  bool init_bbox = true);  // init_bbox = false: the caller has set bbox_dev to (0xffffffff x3, 0 x3) per cloud
 
-// Stable LSD radix sort of (u64 key, i32 value) pairs on bits [begin_bit, end_bit) (rocPRIM).
+// Stable LSD radix sort of (u64 key, i32 value) pairs on bits [begin_bit, end_bit) (sort.hip: this library's own kernels).
 size_t sort_pairs_temp_bytes(int64_t n);
 int sort_pairs_u64_i32(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out,
                        const int32_t* vals_in, int32_t* vals_out, int64_t n, int begin_bit,
@@ -141,11 +141,6 @@ void unordered_map_order(const uint64_t* keys, int64_t n, int32_t base, int32_t*
 size_t hash_order_device_bytes(int64_t n, int64_t batch);
 int hash_order_device(const uint64_t* keys, const int64_t* h_begins, int64_t batch, int32_t* perm_out, void* ws,
                       size_t ws_bytes, hipStream_t stream);
-
-size_t sort_pairs_u32_temp_bytes(int64_t n);
-int sort_pairs_u32_i32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
-                       const int32_t* vals_in, int32_t* vals_out, int64_t n, int begin_bit,
-                       int end_bit, hipStream_t stream);
 
 // lower_bound over a small ascending int32 offsets table: largest b with off[b] <= i (b < nb)
 // ---- wave64 scan / reduction on the DPP shift network (row_shr 1/2/4/8 inside 16-lane rows, row_bcast 15/31 across

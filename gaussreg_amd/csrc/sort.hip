@@ -1,23 +1,219 @@
-// Device-wide stable radix sort of (u64 key, i32 value) pairs.  The sort itself is rocPRIM's
-// (header-only, compiled for gfx950 into this library) -- the same role cub::DeviceRadixSort plays
-// in the public 3DGS rasterizer; everything around it is this repo's own kernels.
-#include <cstring>
+// Device-wide STABLE LSD radix sort of (u64 key, i32 value) pairs on bits [begin_bit, end_bit) -- this library's own
+// kernels (rounds 1-2 passed through to rocPRIM here).  Users: grid_subsample's (cloud, voxel key) sort and the Morton
+// pre-sort of the farthest point sampling.
+//
+// One pass per digit of up to 11 bits (the digit width is chosen so that all passes are equally wide):
+//   rs_hist_kernel     per-chunk digit histogram (2048 keys per workgroup, LDS atomics) -> hist[chunk][bins]
+//   rs_scan_kernel     one workgroup per 64 digits: exclusive prefix over the chunks of every digit (in place) and the
+//                      digit totals
+//   rs_scatter_kernel  every workgroup scans the digit totals itself (<= 2048 values), then ranks its chunk: wave w owns a
+//                      contiguous quarter of the chunk and a private row of running digit counters in LDS; keys are
+//                      taken 64 at a time in position order and ranked among the equal-digit lanes of the step by
+//                      explicit ballots (one per digit bit) -- stable by construction, no reliance on the lane order of
+//                      LDS atomics.  Three launches per pass.
+#include <algorithm>
 
 #include "common.hpp"
-// (common.hpp first: rocprim's texture iterator needs <cstring>'s memset declared)
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
 
 namespace gr {
+namespace {
+
+constexpr int RS_T = 256;                 // threads per workgroup
+constexpr int RS_PER = 8;                 // keys per thread
+constexpr int RS_CHUNK = RS_T * RS_PER;   // 2048 keys per workgroup
+constexpr int RS_NW = RS_T / WAVE;        // 4 waves
+constexpr int RS_WKEYS = RS_CHUNK / RS_NW;  // 512 keys per wave, in position order
+constexpr int RS_MAX_BITS = 11;
+constexpr int RS_MAX_BINS = 1 << RS_MAX_BITS;
+
+__device__ __forceinline__ unsigned digit_of(uint64_t k, int shift, unsigned mask) { return (unsigned)(k >> shift) & mask; }
+
+__global__ __launch_bounds__(RS_T) void rs_hist_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift, unsigned mask,
+                                                       int bins, uint32_t* __restrict__ hist) {
+  extern __shared__ unsigned int s_h[];
+  for (int i = threadIdx.x; i < bins; i += RS_T) s_h[i] = 0u;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * RS_CHUNK;
+  uint64_t k[RS_PER];
+#pragma unroll
+  for (int u = 0; u < RS_PER; ++u) k[u] = keys[min(base + u * RS_T + threadIdx.x, n - 1)];  // all loads first
+#pragma unroll
+  for (int u = 0; u < RS_PER; ++u)
+    if (base + u * RS_T + threadIdx.x < n) atomicAdd(&s_h[digit_of(k[u], shift, mask)], 1u);
+  __syncthreads();
+  uint32_t* dst = hist + (int64_t)blockIdx.x * bins;
+  for (int i = threadIdx.x; i < bins; i += RS_T) dst[i] = s_h[i];
+}
+
+// block b owns digits [64 b, 64 b + 64): wave w of 4 takes 16 of them; lanes run over the chunks
+__global__ __launch_bounds__(RS_T) void rs_scan_kernel(uint32_t* __restrict__ hist, int nchunk, int bins,
+                                                       uint32_t* __restrict__ totals) {
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  for (int dd = 0; dd < 64 / RS_NW; ++dd) {
+    const int d = blockIdx.x * 64 + w * (64 / RS_NW) + dd;
+    if (d >= bins) return;
+    unsigned int carry = 0u;
+    for (int c0 = 0; c0 < nchunk; c0 += WAVE) {
+      const int c = c0 + lane;
+      const unsigned int v = c < nchunk ? hist[(int64_t)c * bins + d] : 0u;
+      const unsigned int inc = (unsigned int)wave_incl_scan_add_dpp((int)v);
+      if (c < nchunk) hist[(int64_t)c * bins + d] = carry + inc - v;
+      carry += (unsigned int)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+    }
+    if (lane == 0) totals[d] = carry;
+  }
+}
+
+template <bool IOTA>
+__global__ __launch_bounds__(RS_T) void rs_scatter_kernel(const uint64_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
+                                                          int64_t iota_period, int64_t n, int shift, int nbits, int bins,
+                                                          const uint32_t* __restrict__ offs, const uint32_t* __restrict__ totals,
+                                                          uint64_t* __restrict__ keys_out, int32_t* __restrict__ vals_out) {
+  extern __shared__ unsigned int s_mem[];
+  unsigned int* s_dbase = s_mem;               // [bins] exclusive prefix of the digit totals
+  unsigned int* s_cnt = s_mem + bins;          // [RS_NW][bins] per-wave counts, then running destinations
+  __shared__ unsigned int s_wsum[RS_NW];
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+  const unsigned mask = (1u << nbits) - 1u;
+  // ---- digit bases: scan of <= 2048 totals (8 per thread)
+  {
+    const int per = (bins + RS_T - 1) / RS_T;
+    unsigned int loc[RS_MAX_BINS / RS_T];
+    unsigned int sum = 0u;
+#pragma unroll
+    for (int u = 0; u < RS_MAX_BINS / RS_T; ++u) {
+      const int d = tid * per + u;
+      loc[u] = (u < per && d < bins) ? totals[d] : 0u;
+      sum += loc[u];
+    }
+    const unsigned int inc = (unsigned int)wave_incl_scan_add_dpp((int)sum);
+    if (lane == WAVE - 1) s_wsum[w] = inc;
+    for (int i = tid; i < RS_NW * bins; i += RS_T) s_cnt[i] = 0u;
+    __syncthreads();
+    unsigned int ex = inc - sum;
+    for (int i = 0; i < w; ++i) ex += s_wsum[i];
+#pragma unroll
+    for (int u = 0; u < RS_MAX_BINS / RS_T; ++u) {
+      const int d = tid * per + u;
+      if (u < per && d < bins) s_dbase[d] = ex;
+      ex += loc[u];
+    }
+  }
+  // ---- the wave's 512 keys in position order: step r, lane l <-> position chunk + 512 w + 64 r + l
+  const int64_t wbase = (int64_t)blockIdx.x * RS_CHUNK + (int64_t)w * RS_WKEYS;
+  uint64_t k[RS_PER];
+  int32_t v[RS_PER];
+#pragma unroll
+  for (int r = 0; r < RS_PER; ++r) {
+    const int64_t p = min(wbase + r * WAVE + lane, n - 1);
+    k[r] = keys_in[p];
+    v[r] = IOTA ? (int32_t)(p % iota_period) : vals_in[p];
+  }
+  unsigned int* row = s_cnt + w * bins;
+#pragma unroll
+  for (int r = 0; r < RS_PER; ++r)
+    if (wbase + r * WAVE + lane < n) atomicAdd(&row[digit_of(k[r], shift, mask)], 1u);
+  __syncthreads();
+  // ---- running destinations: row[w][d] = global offset of (chunk, d) + digit base + keys of earlier waves with digit d
+  const uint32_t* off_c = offs + (int64_t)blockIdx.x * bins;
+  for (int d = tid; d < bins; d += RS_T) {
+    unsigned int acc = s_dbase[d] + off_c[d];
+#pragma unroll
+    for (int i = 0; i < RS_NW; ++i) {
+      const unsigned int c = s_cnt[i * bins + d];
+      s_cnt[i * bins + d] = acc;
+      acc += c;
+    }
+  }
+  __syncthreads();
+  // ---- stable ranking, 64 keys per step: lanes with my digit (one ballot per digit bit), my rank among them
+#pragma unroll
+  for (int r = 0; r < RS_PER; ++r) {
+    const bool live = wbase + r * WAVE + lane < n;
+    const unsigned d = digit_of(k[r], shift, mask);
+    unsigned long long same = __ballot(live);
+    for (int b = 0; b < nbits; ++b) {
+      const unsigned long long mb = __ballot((d >> b) & 1u);
+      same &= ((d >> b) & 1u) ? mb : ~mb;
+    }
+    if (live) {
+      const unsigned long long below = same & ((1ull << lane) - 1ull);
+      const unsigned int dst = row[d] + (unsigned int)__popcll(below);
+      keys_out[dst] = k[r];
+      vals_out[dst] = v[r];
+      if ((same >> lane) >> 1 == 0ull) row[d] += (unsigned int)__popcll(same);  // the group's last lane moves the counter on
+    }
+    // (a wave executes in lockstep and the counter of a digit is touched by one lane per step: no barrier needed)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+struct Plan {
+  int passes, digit_bits, nchunk;
+};
+
+Plan plan_of(int64_t n, int begin_bit, int end_bit) {
+  Plan p;
+  const int bits = end_bit - begin_bit;
+  p.passes = (bits + RS_MAX_BITS - 1) / RS_MAX_BITS;
+  p.digit_bits = (bits + p.passes - 1) / p.passes;
+  p.nchunk = (int)((n + RS_CHUNK - 1) / RS_CHUNK);
+  return p;
+}
+
+int radix_sort(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const int32_t* vals_in,
+               int64_t iota_period, int32_t* vals_out, int64_t n, int begin_bit, int end_bit, hipStream_t stream) {
+  GR_REQUIRE(begin_bit >= 0 && end_bit <= 64 && end_bit > begin_bit, "radix sort: bad bit range [%d, %d)", begin_bit, end_bit);
+  GR_REQUIRE(n < (1ll << 31), "radix sort: too many keys");
+  GR_REQUIRE(temp != nullptr && temp_bytes >= sort_pairs_temp_bytes(n), "sort temp storage too small");
+  const Plan pl = plan_of(n, begin_bit, end_bit);
+  // temp: [keys ping | vals ping | hist (nchunk x bins) | totals (bins)]  (an odd number of passes ends in keys_out either way)
+  Carver cv(temp);
+  uint64_t* kt = cv.take<uint64_t>(n);
+  int32_t* vt = cv.take<int32_t>(n);
+  uint32_t* hist = cv.take<uint32_t>((size_t)pl.nchunk * RS_MAX_BINS);
+  uint32_t* totals = cv.take<uint32_t>(RS_MAX_BINS);
+  // ping-pong so that the LAST pass writes keys_out / vals_out
+  const uint64_t* kin = keys_in;
+  const int32_t* vin = vals_in;
+  for (int p = 0; p < pl.passes; ++p) {
+    const int shift = begin_bit + p * pl.digit_bits;
+    const int nb = std::min(pl.digit_bits, end_bit - shift);
+    const int bins = 1 << nb;
+    const bool to_out = ((pl.passes - 1 - p) % 2) == 0;
+    uint64_t* ko = to_out ? keys_out : kt;
+    int32_t* vo = to_out ? vals_out : vt;
+    const bool iota = p == 0 && iota_period > 0;
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(pl.nchunk), dim3(RS_T), bins * sizeof(unsigned int), stream, kin, n, shift,
+                       (unsigned)(bins - 1), bins, hist);
+    hipLaunchKernelGGL(rs_scan_kernel, dim3((bins + 63) / 64), dim3(RS_T), 0, stream, hist, pl.nchunk, bins, totals);
+    const size_t lds = (size_t)(1 + RS_NW) * bins * sizeof(unsigned int);
+    if (iota)
+      hipLaunchKernelGGL(rs_scatter_kernel<true>, dim3(pl.nchunk), dim3(RS_T), lds, stream, kin, vin, iota_period, n, shift, nb,
+                         bins, hist, totals, ko, vo);
+    else
+      hipLaunchKernelGGL(rs_scatter_kernel<false>, dim3(pl.nchunk), dim3(RS_T), lds, stream, kin, vin, (int64_t)1, n, shift, nb,
+                         bins, hist, totals, ko, vo);
+    GR_LAUNCH_CHECK();
+    kin = ko;
+    vin = vo;
+  }
+  return GR_OK;
+}
+
+}  // namespace
 
 size_t sort_pairs_temp_bytes(int64_t n) {
-  size_t bytes = 0;
   if (n <= 0) return 256;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
-                                  (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)n, 0u, 64u,
-                                  (hipStream_t)0);
-  return align_up(bytes + 256, 256);
+  const int64_t nchunk = (n + RS_CHUNK - 1) / RS_CHUNK;
+  Carver cv(nullptr);
+  cv.take<uint64_t>(n);
+  cv.take<int32_t>(n);
+  cv.take<uint32_t>((size_t)nchunk * RS_MAX_BINS);
+  cv.take<uint32_t>(RS_MAX_BINS);
+  return cv.used() + 256;
 }
 
 int sort_pairs_u64_i32(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out,
@@ -29,58 +225,16 @@ int sort_pairs_u64_i32(void* temp, size_t temp_bytes, const uint64_t* keys_in, u
     GR_HIP(hipMemcpyAsync(vals_out, vals_in, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, stream));
     return GR_OK;
   }
-  size_t bytes = temp_bytes;
-  GR_HIP(rocprim::radix_sort_pairs(temp, bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n,
-                                   (unsigned)begin_bit, (unsigned)end_bit, stream));
-  return GR_OK;
+  return radix_sort(temp, temp_bytes, keys_in, keys_out, vals_in, 0, vals_out, n, begin_bit, end_bit, stream);
 }
 
-// Same sort with the value stream generated on the fly: value(i) = i mod period (the depth sort's payload is the
-// Gaussian id, i.e. the position inside its view) -- nobody has to write or read a 4 B/entry iota array.
-namespace {
-struct ModPeriod {
-  int64_t period;
-  __host__ __device__ int32_t operator()(int64_t i) const { return (int32_t)(i % period); }
-};
-}  // namespace
-
+// Same sort with the value stream generated on the fly: value(i) = i mod period -- nobody has to write or read a
+// 4 B/entry iota array.
 int sort_pairs_u64_iota(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, int64_t period,
                         int32_t* vals_out, int64_t n, int begin_bit, int end_bit, hipStream_t stream) {
   if (n <= 0) return GR_OK;
   GR_REQUIRE(end_bit > begin_bit && period > 0, "sort_pairs_u64_iota: empty bit range or period");
-  auto vals_in = rocprim::make_transform_iterator(rocprim::counting_iterator<int64_t>(0), ModPeriod{period});
-  size_t need = 0;
-  GR_HIP(rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, vals_in, vals_out, (size_t)n, (unsigned)begin_bit,
-                                   (unsigned)end_bit, stream));
-  GR_REQUIRE(need <= temp_bytes, "sort temp storage too small: need %zu, have %zu", need, temp_bytes);
-  size_t bytes = temp_bytes;
-  GR_HIP(rocprim::radix_sort_pairs(temp, bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, (unsigned)begin_bit,
-                                   (unsigned)end_bit, stream));
-  return GR_OK;
-}
-
-size_t sort_pairs_u32_temp_bytes(int64_t n) {
-  size_t bytes = 0;
-  if (n <= 0) return 256;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                  (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)n, 0u, 32u,
-                                  (hipStream_t)0);
-  return align_up(bytes + 256, 256);
-}
-
-int sort_pairs_u32_i32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
-                       const int32_t* vals_in, int32_t* vals_out, int64_t n, int begin_bit,
-                       int end_bit, hipStream_t stream) {
-  if (n <= 0) return GR_OK;
-  if (end_bit <= begin_bit) {
-    GR_HIP(hipMemcpyAsync(keys_out, keys_in, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, stream));
-    GR_HIP(hipMemcpyAsync(vals_out, vals_in, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, stream));
-    return GR_OK;
-  }
-  size_t bytes = temp_bytes;
-  GR_HIP(rocprim::radix_sort_pairs(temp, bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n,
-                                   (unsigned)begin_bit, (unsigned)end_bit, stream));
-  return GR_OK;
+  return radix_sort(temp, temp_bytes, keys_in, keys_out, nullptr, period, vals_out, n, begin_bit, end_bit, stream);
 }
 
 }  // namespace gr
