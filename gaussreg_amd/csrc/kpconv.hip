@@ -418,12 +418,21 @@ constexpr int GN_MAXG = 64;
 
 // The float4 a thread reads belongs to columns 4*col4 .. 4*col4+3, fixed for the thread when C/4 <= 256 (the row index
 // advances instead); wider rows give every thread C/1024 column positions.
+// seg_off (optional, device, gridDim.y + 1 entries): rows [seg_off[s], seg_off[s+1]) are normalised on their own -- several
+// stack-mode batches (scene pairs) in one launch, each with the statistics it would have had alone.
 template <bool APPLY>
 __global__ __launch_bounds__(GN_T) void group_norm_kernel(const float* __restrict__ x, int64_t n, int c, int groups,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, float slope, double* __restrict__ partial, int nblk_a,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, const int64_t* __restrict__ seg_off) {
   __shared__ double s_acc[2 * GN_MAXG];
+  if (seg_off != nullptr) {
+    const int64_t r0 = seg_off[blockIdx.y];
+    n = seg_off[blockIdx.y + 1] - r0;
+    x += r0 * c;
+    out += r0 * c;
+    partial += (int64_t)blockIdx.y * ((int64_t)nblk_a * 2 * groups + groups);  // partials, then 2 G floats (= G doubles) of stats
+  }
   __shared__ float s_mean[GN_MAXG], s_rstd[GN_MAXG];
   const int cols4 = c / 4, cg = c / groups;
   const int tid = threadIdx.x;
@@ -493,8 +502,12 @@ __global__ __launch_bounds__(GN_T) void group_norm_kernel(const float* __restric
 
 // one workgroup: fold the pass-1 partials (nblk x 2G doubles) into mean / rstd per group, four lanes per (group, moment)
 __global__ __launch_bounds__(GN_T) void group_norm_stats_kernel(double* __restrict__ partial, int nblk, int groups, int64_t n,
-                                                                int cg, float eps) {
+                                                                int cg, float eps, const int64_t* __restrict__ seg_off) {
   __shared__ double s_tot[2 * GN_MAXG];
+  if (seg_off != nullptr) {
+    n = seg_off[blockIdx.x + 1] - seg_off[blockIdx.x];
+    partial += (int64_t)blockIdx.x * ((int64_t)nblk * 2 * groups + groups);
+  }
   const int tid = threadIdx.x, item = tid / 4, sub = tid % 4;  // 2 * groups <= 128 items x 4 lanes <= 512: loop below
   for (int it = item; it < 2 * groups; it += GN_T / 4) {
     double acc = 0.0;
@@ -506,7 +519,7 @@ __global__ __launch_bounds__(GN_T) void group_norm_stats_kernel(double* __restri
   __syncthreads();
   float* stats = reinterpret_cast<float*>(partial + (int64_t)nblk * 2 * groups);
   if (tid < groups) {
-    const double cnt = (double)n * (double)cg;
+    const double cnt = fmax((double)n * (double)cg, 1.0);
     const double mean = s_tot[tid] / cnt;
     const double var = fmax(s_tot[groups + tid] / cnt - mean * mean, 0.0);
     stats[tid] = (float)mean;
@@ -518,35 +531,58 @@ __global__ __launch_bounds__(GN_T) void group_norm_stats_kernel(double* __restri
 }  // namespace gr
 
 extern "C" size_t gr_group_norm_workspace_bytes(int64_t groups) {
-  return groups > 0 ? (size_t)gr::GN_BLOCKS * 2 * (size_t)groups * sizeof(double) + 2 * (size_t)groups * sizeof(float) + 256 : 0;
+  return groups > 0 ? ((size_t)gr::GN_BLOCKS * 2 * (size_t)groups + (size_t)groups) * sizeof(double) + 512 : 0;
 }
 
-extern "C" int gr_group_norm(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta,
-                             float eps, float negative_slope, float* out, void* ws, size_t ws_bytes, void* stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
+static int group_norm_impl(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta,
+                           float eps, float negative_slope, float* out, const int64_t* seg_off, int64_t nseg, int64_t max_seg_rows,
+                           void* ws, size_t ws_bytes, hipStream_t stream) {
   GR_REQUIRE(n >= 0 && c >= 4 && groups >= 1 && groups <= gr::GN_MAXG && c % groups == 0, "group_norm: bad sizes");
   const int64_t cols4 = c / 4;
   GR_REQUIRE(c % 4 == 0 && ((cols4 <= gr::GN_T && gr::GN_T % cols4 == 0) || (cols4 > gr::GN_T && cols4 % gr::GN_T == 0)),
              "group_norm: %lld channels are not supported (C / 4 must divide 256 or be a multiple of it)", (long long)c);
-  if (n == 0) return GR_OK;
+  if (n == 0 || nseg == 0) return GR_OK;
   GR_REQUIRE(x && out, "null argument");
   GR_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0, "group_norm: unaligned tensors");
-  if (!ws || ws_bytes < gr_group_norm_workspace_bytes(groups)) {
-    set_error("group_norm workspace too small");
+  const bool seg = seg_off != nullptr;
+  const int64_t rows = seg ? max_seg_rows : n;  // rows of the longest segment: sizes the grid
+  const int rows_per_pass = cols4 >= gr::GN_T ? 1 : (int)(gr::GN_T / cols4);
+  const int tiles = (int)std::min<int64_t>(std::max<int64_t>((rows + rows_per_pass - 1) / rows_per_pass, 1), 1 << 20);
+  const int cap_a = seg ? std::max(1, gr::GN_BLOCKS / (int)std::min<int64_t>(nseg, 16)) : gr::GN_BLOCKS;
+  const int nblk_a = std::min(cap_a, tiles);
+  const int nblk_b = std::min(tiles, seg ? std::max(8, 4096 / (int)std::min<int64_t>(nseg, 512)) : 4096);
+  const size_t per_seg = ((size_t)nblk_a * 2 * groups + groups) * sizeof(double);
+  if (!ws || ws_bytes < per_seg * (size_t)(seg ? nseg : 1) + 256) {
+    gr::set_error("group_norm workspace too small");
     return GR_ERR_WORKSPACE;
   }
-  const int rows_per_pass = cols4 >= gr::GN_T ? 1 : (int)(gr::GN_T / cols4);
-  const int tiles = (int)std::min<int64_t>((n + rows_per_pass - 1) / rows_per_pass, 1 << 20);
-  const int nblk_a = std::min(gr::GN_BLOCKS, tiles);
-  const int nblk_b = std::min(tiles, 4096);
   double* partial = static_cast<double*>(ws);
-  KernelTimer timer("group_norm", stream);
-  hipLaunchKernelGGL(gr::group_norm_kernel<false>, dim3(nblk_a), dim3(gr::GN_T), 0, stream, x, n, (int)c, (int)groups, gamma,
-                     beta, eps, negative_slope, partial, nblk_a, out);
-  hipLaunchKernelGGL(gr::group_norm_stats_kernel, dim3(1), dim3(gr::GN_T), 0, stream, partial, nblk_a, (int)groups, n,
-                     (int)(c / groups), eps);
-  hipLaunchKernelGGL(gr::group_norm_kernel<true>, dim3(nblk_b), dim3(gr::GN_T), 0, stream, x, n, (int)c, (int)groups, gamma,
-                     beta, eps, negative_slope, partial, nblk_a, out);
+  const unsigned gy = seg ? (unsigned)nseg : 1u;
+  gr::KernelTimer timer("group_norm", stream);
+  hipLaunchKernelGGL(gr::group_norm_kernel<false>, dim3(nblk_a, gy), dim3(gr::GN_T), 0, stream, x, n, (int)c, (int)groups, gamma,
+                     beta, eps, negative_slope, partial, nblk_a, out, seg_off);
+  hipLaunchKernelGGL(gr::group_norm_stats_kernel, dim3(gy), dim3(gr::GN_T), 0, stream, partial, nblk_a, (int)groups, n,
+                     (int)(c / groups), eps, seg_off);
+  hipLaunchKernelGGL(gr::group_norm_kernel<true>, dim3(nblk_b, gy), dim3(gr::GN_T), 0, stream, x, n, (int)c, (int)groups, gamma,
+                     beta, eps, negative_slope, partial, nblk_a, out, seg_off);
   GR_LAUNCH_CHECK();
   return GR_OK;
+}
+
+extern "C" int gr_group_norm(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta,
+                             float eps, float negative_slope, float* out, void* ws, size_t ws_bytes, void* stream_) {
+  return group_norm_impl(x, n, c, groups, gamma, beta, eps, negative_slope, out, nullptr, 1, n, ws, ws_bytes,
+                         static_cast<hipStream_t>(stream_));
+}
+
+extern "C" size_t gr_group_norm_seg_workspace_bytes(int64_t groups, int64_t nseg) {
+  return groups > 0 && nseg > 0 ? (size_t)nseg * ((size_t)gr::GN_BLOCKS * 2 * groups + groups) * sizeof(double) + 256 : 0;
+}
+
+extern "C" int gr_group_norm_seg(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta,
+                                 float eps, float negative_slope, float* out, const int64_t* seg_off, int64_t nseg,
+                                 int64_t max_seg_rows, void* ws, size_t ws_bytes, void* stream_) {
+  GR_REQUIRE(seg_off != nullptr && nseg >= 0 && nseg < 65536 && max_seg_rows >= 0, "group_norm_seg: bad segments");
+  return group_norm_impl(x, n, c, groups, gamma, beta, eps, negative_slope, out, seg_off, nseg, max_seg_rows, ws, ws_bytes,
+                         static_cast<hipStream_t>(stream_));
 }

@@ -9,6 +9,27 @@ from . import _lib
 from .kpconv import KPConv, maxpool, nearest_upsample
 
 
+import contextlib
+import threading
+
+_segments = threading.local()
+
+
+@contextlib.contextmanager
+def norm_segments(table):
+    """Several stack-mode batches (scene pairs) through the backbone in ONE pass: `table` maps the row count of a pyramid
+    level to (device int64 offsets of the pairs' row ranges at that level, rows of the longest range).  Inside the context
+    every GroupNorm whose input has such a row count normalises each range with its own statistics -- what the reference
+    computes when every pair goes through the network alone (modules.py:32-50: the statistics run over ALL points of the
+    collated batch, i.e. of one pair)."""
+    old = getattr(_segments, "table", None)
+    _segments.table = table
+    try:
+        yield
+    finally:
+        _segments.table = old
+
+
 class GroupNorm(nn.Module):
     """modules.py:32-50: GroupNorm over the channel axis of a (N, C) point-feature matrix."""
 
@@ -30,9 +51,22 @@ class GroupNorm(nn.Module):
         x = x.contiguous()
         out = torch.empty_like(x)
         dev = x.device
+        table = getattr(_segments, "table", None)
+        seg = table.get(x.shape[0]) if table else None
         with torch.cuda.device(dev):
-            ws = _lib.workspace(dev, L.gr_group_norm_workspace_bytes(self.num_groups))
             w, b = self.norm.weight, self.norm.bias
+            if seg is not None:
+                seg_off, max_rows = seg
+                nseg = seg_off.numel() - 1
+                ws = _lib.workspace(dev, L.gr_group_norm_seg_workspace_bytes(self.num_groups, nseg))
+                _lib.check(L.gr_group_norm_seg(_lib.ptr(x), x.shape[0], c, self.num_groups,
+                                               _lib.ptr(None if w is None else w.detach().contiguous()),
+                                               _lib.ptr(None if b is None else b.detach().contiguous()), float(self.norm.eps),
+                                               1.0 if negative_slope is None else float(negative_slope), _lib.ptr(out),
+                                               _lib.ptr(seg_off), nseg, int(max_rows), _lib.ptr(ws), ws.numel(),
+                                               _lib.stream_ptr(dev)))
+                return out.squeeze()
+            ws = _lib.workspace(dev, L.gr_group_norm_workspace_bytes(self.num_groups))
             _lib.check(L.gr_group_norm(_lib.ptr(x), x.shape[0], c, self.num_groups,
                                        _lib.ptr(None if w is None else w.detach().contiguous()),
                                        _lib.ptr(None if b is None else b.detach().contiguous()), float(self.norm.eps),

@@ -12,7 +12,13 @@ random Fourier features of the point's coordinates in the reference frame (the s
 known ground-truth transform first).  That keeps the matching stack meaningful -- correspondences are real, the estimated
 transform can be scored against the ground truth -- without pretending to have run the network.
 
+`PairRegistrar(features="model")` runs the network instead (gaussreg_amd.model.GeoTransformer, 28 M parameters, seeded random
+weights -- timing does not need a checkpoint; the estimates are then meaningless and are not scored): KPConvFPN over all
+clouds of the batch in ONE pass (GroupNorm statistics per pair, kpconv_blocks.norm_segments), GeometricTransformer per pair,
+the fine features of the backbone in the patch scores.
+
 Pairs are independent units: `register_pairs` is what one rank runs on its block of the pair list (gaussreg_amd/sharding.py).
+The clouds of a batch are stacked pair by pair: [ref_1, src_1, ref_2, src_2, ...] (cloud 2 b = ref of pair b, 2 b + 1 = src).
 """
 import math
 import time
@@ -113,13 +119,21 @@ class PairRegistrar:
     """Holds the stateless operator modules and the descriptors; `register_pairs` runs a batch."""
 
     def __init__(self, device, num_samples=30000, fps_clouds_per_call=24, order="reference", use_ransac=True,
-                 profile=False, pair_streams=4):
+                 profile=False, pair_streams=4, features="descriptor"):
         """`pair_streams`: after the batched stages (FPS, pyramid) every pair runs its own short chain of launch-bound
         kernels with two host read-backs (correspondence count, RANSAC result); `pair_streams` host threads, each with
         its own HIP stream, work through the pairs so that one pair's read-back waits while the others' kernels run
         (results are identical to the sequential order: nothing is shared between pairs).  1 = one after the other.
         `profile=True`: `section_ms` accumulates wall milliseconds per stage (a device synchronise on both sides of
         every stage, pairs one after the other: the total is slower than an unprofiled run)."""
+        if features not in ("descriptor", "model"):
+            raise ValueError("features must be 'descriptor' or 'model'")
+        self.features = features
+        self.net = None
+        if features == "model":
+            from .model import GeoTransformer, make_cfg
+            torch.manual_seed(20240301)
+            self.net = GeoTransformer(make_cfg()).to(device).eval()
         self.device = device
         self.profile = bool(profile)
         self.section_ms = {}
@@ -157,9 +171,10 @@ class PairRegistrar:
         return self._register_sampled(pairs, self._sample(pairs, self.fps_clouds_per_call))
 
     def _sample(self, pairs, clouds_per_call):
-        """FPS, several clouds per call (stack order [ref_1..ref_B, src_1..src_B] like data.py:151-155)."""
+        """FPS, several clouds per call; stack order [ref_1, src_1, ref_2, src_2, ...]: a pair's two clouds are adjacent at
+        every pyramid level (data.py:151-155 stacks [ref, src] of ONE pair the same way)."""
         B = len(pairs)
-        clouds = [p[0] for p in pairs] + [p[1] for p in pairs]
+        clouds = [c for p in pairs for c in (p[0], p[1])]
         sampled = []
         with self._sec("fps"):
             # at most clouds_per_call clouds per launch (the co-operating workgroups of a call share the 256 CUs; 24
@@ -189,7 +204,7 @@ class PairRegistrar:
             len_c, len_f = pyr["lengths"][-1].tolist(), pyr["lengths"][1].tolist()
         off_c = [0]
         off_f = [0]
-        for a, b in zip(len_c, len_f):
+        for a, b in zip(len_c, len_f):          # cloud 2 b = ref of pair b, cloud 2 b + 1 = its src
             off_c.append(off_c[-1] + a)
             off_f.append(off_f[-1] + b)
         pts_c, pts_f = pyr["points"][-1], pyr["points"][1]
@@ -197,17 +212,38 @@ class PairRegistrar:
         pad = torch.zeros((1, 3), device=dev)                            # model.py:171-172
         gt_mask = torch.tensor([p[2] is not None for p in pairs], device=dev)
         eye = torch.eye(4, device=dev)
-        with self._sec("coarse_features"):
-            # stand-in for the learned features (see module docstring): descriptors in the reference frame, for all the
-            # superpoints of the batch at once (the per-pair stage is bound by host-side launch overhead)
-            T_all = torch.stack([p[2] if p[2] is not None else eye for p in pairs])         # (B, 4, 4); no GT: identity
-            n_src = torch.tensor(len_c[B:], device=dev)
-            pid = torch.repeat_interleave(torch.arange(B, device=dev), n_src)
-            src_in_ref = torch.einsum('nij,nj->ni', T_all[pid, :3, :3], pts_c[off_c[B]:]) + T_all[pid, :3, 3]
-            frame_c = torch.cat([pts_c[:off_c[B]], src_in_ref], 0)
-            feats_c = torch.nn.functional.normalize(self.coarse_desc(frame_c), p=2, dim=1)
+        T_all = torch.stack([p[2] if p[2] is not None else eye for p in pairs])             # (B, 4, 4); no GT: identity
+        feats_f = None
+        if self.features == "model":
+            with self._sec("backbone"):
+                # KPConvFPN over all 2 B clouds at once; every GroupNorm normalises pair by pair
+                from .kpconv_blocks import norm_segments
+                table = {}
+                for lv in range(NUM_STAGES):
+                    ll = pyr["lengths"][lv].tolist()
+                    offs = [0]
+                    for b in range(B):
+                        offs.append(offs[-1] + ll[2 * b] + ll[2 * b + 1])
+                    table[offs[-1]] = (torch.tensor(offs, dtype=torch.int64, device=dev),
+                                       max(offs[i + 1] - offs[i] for i in range(B)))
+                feats_in = torch.ones((points.shape[0], 4), device=dev)   # demo.py:109-118: [1, r, g, b]-style 4-d input
+                dd = dict(pyr)
+                with norm_segments(table):
+                    fl = self.net.backbone(feats_in, dd)
+                feats_c, feats_f = fl[-1], fl[0]                           # (sum Nc, 2048-d in), (sum Nf, 256)
+        else:
+            with self._sec("coarse_features"):
+                # stand-in for the learned features (see module docstring): descriptors in the reference frame, for all the
+                # superpoints of the batch at once (the per-pair stage is bound by host-side launch overhead)
+                n_c = torch.tensor(len_c, device=dev)
+                cloud = torch.repeat_interleave(torch.arange(2 * B, device=dev), n_c)       # superpoint -> cloud
+                pid, is_src = cloud // 2, (cloud % 2 == 1)
+                moved = torch.einsum('nij,nj->ni', T_all[pid, :3, :3], pts_c) + T_all[pid, :3, 3]
+                frame_c = torch.where(is_src[:, None], moved, pts_c)
+                feats_c = torch.nn.functional.normalize(self.coarse_desc(frame_c), p=2, dim=1)
         ctx = (pairs, B, pts_c, pts_f, off_c, off_f, out, feats_c)
-        # ---- stage 1, per pair: point_to_node_partition x 2, SuperPointMatching, the patches of the matched superpoints
+        # ---- stage 1, per pair: point_to_node_partition x 2, (GeometricTransformer), SuperPointMatching, the patches of the
+        #      matched superpoints
         st1 = [None] * B
         self._fan_out(lambda b: st1.__setitem__(b, self._match_superpoints(b, ctx)), B)
         # ---- stage 2, all pairs at once: patch coordinates -> descriptors -> scores -> log-Sinkhorn.  (One pair at a time
@@ -221,22 +257,31 @@ class PairRegistrar:
             pts_pad = torch.cat([pts_f, pad], 0)                                           # model.py:171-172: pad row = index N
             Kt = torch.tensor(K, device=dev)
             pid = torch.repeat_interleave(torch.arange(B, device=dev), Kt)                 # patch -> pair
-            n_ref = torch.tensor([off_f[b + 1] - off_f[b] for b in range(B)], device=dev)[pid][:, None]
-            n_src = torch.tensor([off_f[B + b + 1] - off_f[B + b] for b in range(B)], device=dev)[pid][:, None]
-            o_ref = torch.tensor(off_f[:B], device=dev)[pid][:, None]
-            o_src = torch.tensor(off_f[B:2 * B], device=dev)[pid][:, None]
+            n_ref = torch.tensor([off_f[2 * b + 1] - off_f[2 * b] for b in range(B)], device=dev)[pid][:, None]
+            n_src = torch.tensor([off_f[2 * b + 2] - off_f[2 * b + 1] for b in range(B)], device=dev)[pid][:, None]
+            o_ref = torch.tensor([off_f[2 * b] for b in range(B)], device=dev)[pid][:, None]
+            o_src = torch.tensor([off_f[2 * b + 1] for b in range(B)], device=dev)[pid][:, None]
             rk, rkm = torch.cat([t[0] for t in st1]), torch.cat([t[1] for t in st1])
             sk, skm = torch.cat([t[2] for t in st1]), torch.cat([t[3] for t in st1])
-            rkp = pts_pad[torch.where(rk == n_ref, n_f, rk + o_ref)]                       # (sum K, 128, 3), local -> stacked index
-            skp = pts_pad[torch.where(sk == n_src, n_f, sk + o_src)]
+            rki = torch.where(rk == n_ref, n_f, rk + o_ref)                                # (sum K, 128): local -> stacked index
+            ski = torch.where(sk == n_src, n_f, sk + o_src)
+            rkp, skp = pts_pad[rki], pts_pad[ski]
+            if feats_f is not None:
+                feats_pad = torch.cat([feats_f, torch.zeros_like(feats_f[:1])], 0)         # model.py:181-184
         matching = torch.empty((k_off[-1], POINT_LIMIT, POINT_LIMIT), dtype=torch.float32, device=dev)
         for a in range(0, k_off[-1], PATCH_CHUNK):
             e = min(k_off[-1], a + PATCH_CHUNK)
             with self._sec("patch_features"):
-                R, t = T_all[pid[a:e], :3, :3], T_all[pid[a:e], :3, 3]
-                rkf = self.fine_desc(rkp[a:e]) * rkm[a:e, :, None]
-                skf = self.fine_desc(torch.einsum('kij,knj->kni', R, skp[a:e]) + t[:, None, :]) * skm[a:e, :, None]
-                scores = torch.einsum('bnd,bmd->bnm', rkf, skf) * (rkf.shape[-1] ** 0.5)
+                if feats_f is not None:                                                    # model.py:186-190
+                    rkf, skf = feats_pad[rki[a:e]], feats_pad[ski[a:e]]
+                    scores = torch.einsum('bnd,bmd->bnm', rkf, skf) / (rkf.shape[-1] ** 0.5)
+                else:
+                    # synthetic descriptors: position features in the reference frame, a x16 temperature instead of the
+                    # network's 1 / sqrt(C) (descriptor stand-in only -- see the module docstring)
+                    R, t = T_all[pid[a:e], :3, :3], T_all[pid[a:e], :3, 3]
+                    rkf = self.fine_desc(rkp[a:e]) * rkm[a:e, :, None]
+                    skf = self.fine_desc(torch.einsum('kij,knj->kni', R, skp[a:e]) + t[:, None, :]) * skm[a:e, :, None]
+                    scores = torch.einsum('bnd,bmd->bnm', rkf, skf) * (rkf.shape[-1] ** 0.5)
                 del rkf, skf
             with self._sec("sinkhorn"):
                 matching[a:e] = self.ot(scores, rkm[a:e], skm[a:e])[:, :-1, :-1]           # model.py:191-198 (dustbins dropped)
@@ -289,15 +334,21 @@ class PairRegistrar:
         """model.py:99-104, 152-159, 162-170 for pair b, on the current stream -> (ref patch indices (K, 128) local to the
         pair's fine cloud, their masks, the same for src, node correspondence scores (K,))."""
         pairs, B, pts_c, pts_f, off_c, off_f, out, feats_c = ctx
-        ref_c = pts_c[off_c[b]:off_c[b + 1]]
-        src_c = pts_c[off_c[B + b]:off_c[B + b + 1]]
-        ref_f = pts_f[off_f[b]:off_f[b + 1]]
-        src_f = pts_f[off_f[B + b]:off_f[B + b + 1]]
+        r0, r1, s1 = off_c[2 * b], off_c[2 * b + 1], off_c[2 * b + 2]
+        ref_c, src_c = pts_c[r0:r1], pts_c[r1:s1]
+        ref_f = pts_f[off_f[2 * b]:off_f[2 * b + 1]]
+        src_f = pts_f[off_f[2 * b + 1]:off_f[2 * b + 2]]
         with self._sec("point_to_node"):                            # model.py:99-104
             _, ref_node_masks, ref_knn_idx, ref_knn_masks = point_to_node_partition(ref_f, ref_c, POINT_LIMIT)
             _, src_node_masks, src_knn_idx, src_knn_masks = point_to_node_partition(src_f, src_c, POINT_LIMIT)
-        ref_feats_c = feats_c[off_c[b]:off_c[b + 1]]
-        src_feats_c = feats_c[off_c[B + b]:off_c[B + b + 1]]
+        if self.net is not None:
+            with self._sec("transformer"):                          # model.py:134-148
+                rf, sf = self.net.transformer(ref_c.unsqueeze(0), src_c.unsqueeze(0), feats_c[r0:r1].unsqueeze(0),
+                                              feats_c[r1:s1].unsqueeze(0))
+                ref_feats_c = torch.nn.functional.normalize(rf.squeeze(0), p=2, dim=1)
+                src_feats_c = torch.nn.functional.normalize(sf.squeeze(0), p=2, dim=1)
+        else:
+            ref_feats_c, src_feats_c = feats_c[r0:r1], feats_c[r1:s1]
         with self._sec("superpoint_matching"):                      # model.py:152-159
             ref_ci, src_ci, node_scores = self.spm(ref_feats_c, src_feats_c, ref_node_masks, src_node_masks)
         with self._sec("patch_features"):                           # model.py:162-170
@@ -312,8 +363,8 @@ class PairRegistrar:
             rc, sc, cs, T = self.lgr(rkp[a:e], skp[a:e], rkm[a:e], skm[a:e], matching[a:e], node_scores[b])
             n_corr = rc.shape[0]
         with self._sec("ransac"):
-            if self.use_ransac and n_corr >= 3:              # model.py:209-220 (the estimate the reference keeps)
-                T = registration_with_ransac_from_correspondences(sc, rc, None, 0.05, 3, 10000, seed=b)
+            if self.use_ransac and n_corr >= 5:              # model.py:209-220: ransac_n = 5 (the estimate the reference keeps)
+                T = registration_with_ransac_from_correspondences(sc, rc, None, 0.05, 5, 10000, seed=b)
         with self._sec("metrics"):
             out[b, :16] = T.reshape(-1)
             out[b, 18] = float(n_corr)

@@ -255,6 +255,13 @@ int gr_neighbor_pool(const float* x, int64_t n, int64_t c, const int64_t* neighb
 size_t gr_group_norm_workspace_bytes(int64_t groups);
 int gr_group_norm(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta, float eps,
                   float negative_slope, float* out, void* ws, size_t ws_bytes, void* stream);
+/* The same normalisation for several stack-mode batches at once: rows [seg_off[s], seg_off[s+1]) (device array, nseg + 1
+ * entries) are normalised with their own statistics -- what modules.py:32-50 computes when every batch (scene pair) goes
+ * through the network alone.  max_seg_rows = rows of the longest segment (sizes the grid). */
+size_t gr_group_norm_seg_workspace_bytes(int64_t groups, int64_t nseg);
+int gr_group_norm_seg(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta, float eps,
+                      float negative_slope, float* out, const int64_t* seg_off, int64_t nseg, int64_t max_seg_rows, void* ws,
+                      size_t ws_bytes, void* stream);
 /* gr_gs_fuse ("next" row): gs_fusion.py:231-262 gaussian_fuse on the GS .ply wire format.
  * rec1 / rec2: device arrays of 62-float vertex records (gs_fusion.py:172-184 property order).  The host
  * passes the similarity transform split as the reference does (:237-240): h_rotation (3x3 row-major, scale
