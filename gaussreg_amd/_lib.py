@@ -104,6 +104,8 @@ SIGNATURES.update({
     "gr_geo_embedding_workspace_bytes": (c_size, [c_i64, c_i64]),
     "gr_geo_embedding": (c_int, [c_void, c_i64, c_void, c_void, c_void, c_void, c_void, c_i64, c_f32, c_f32, c_i64,
                                  c_int, c_void, c_void, c_size, c_void]),
+    "gr_geo_embedding_table": (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_f32, c_void, c_void, c_void, c_void, c_void,
+                                       c_i64, c_f32, c_f32, c_i64, c_int, c_void, c_void, c_size, c_void]),
     "gr_rpe_attention": (c_int, [c_void] * 9 + [c_i64] * 4 + [c_void, c_void, c_void]),
     "gr_rpe_scores": (c_int, [c_void, c_void, c_void, c_i64, c_i64, c_i64, c_i64, c_void, c_void]),
     "gr_fps_workspace_bytes": (c_size, [c_i64, c_i64]),

@@ -342,6 +342,15 @@ size_t gr_geo_embedding_workspace_bytes(int64_t n, int64_t angle_k);
 int gr_geo_embedding(const float* points, int64_t n, const float* w_d, const float* b_d, const float* w_a,
                      const float* b_a, const float* div_term, int64_t c, float sigma_d, float factor_a,
                      int64_t angle_k, int reduction_mean, float* out, void* ws, size_t ws_bytes, void* stream);
+/* The same embedding from two function tables.  Both projections act on the sinusoidal embedding of ONE scalar, so
+ * F_d(x) = W_d phi(x) + b_d and F_a(x) = W_a phi(x) + b_a are smooth maps R -> R^c: the caller tabulates them once per set
+ * of weights on a uniform grid (tab[j] = F((j - 1) / inv_h), rows x c fp32, 16-byte aligned) and the kernel evaluates them
+ * by 4-point Lagrange interpolation (error ~ 2e-8 at inv_h = 32) instead of 2 (1 + k) n^2 c^2 flop of GEMM; an index beyond
+ * a table is evaluated directly from the weights.  Same result as gr_geo_embedding within fp32 rounding. */
+int gr_geo_embedding_table(const float* points, int64_t n, const float* tab_d, int64_t rows_d, const float* tab_a,
+                           int64_t rows_a, float inv_h, const float* w_d, const float* b_d, const float* w_a, const float* b_a,
+                           const float* div_term, int64_t c, float sigma_d, float factor_a, int64_t angle_k, int reduction_mean,
+                           float* out, void* ws, size_t ws_bytes, void* stream);
 /* gr_rpe_scores: positional score term of RPEMultiHeadAttention (geotransformer/modules/transformer/
  * rpe_transformer.py:55-57) re-associated so the (N,M,C) embedding is read once and never projected:
  * out[h][n][m] = sum_j embed[n][m][j] * u[n][h][j] + add[n][h], with u = q W_p (per head) and add = q . b_p computed

@@ -193,22 +193,22 @@ def test_fps_multi_workgroup_paths(n, k, batch):
 
 
 # ---------------------------------------------------------------- RPE rows (geo embedding, attention score term)
-def _gse(g, tag, fp32_mfma=False):
+def _gse(g, tag, fp32_mfma=False, mode="table"):
     from gaussreg_amd.embedding import GeometricStructureEmbedding
     c, k, mean = (int(x) for x in g[f"gse_{tag}_cfg"])
-    m = GeometricStructureEmbedding(c, 0.2, 15, k, reduction_a="mean" if mean else "max", fp32_mfma=fp32_mfma)
+    m = GeometricStructureEmbedding(c, 0.2, 15, k, reduction_a="mean" if mean else "max", fp32_mfma=fp32_mfma, mode=mode)
     m.load_state_dict({"embedding.div_term": torch.from_numpy(g[f"gse_{tag}_div"]),
                        "proj_d.weight": torch.from_numpy(g[f"gse_{tag}_w_d"]), "proj_d.bias": torch.from_numpy(g[f"gse_{tag}_b_d"]),
                        "proj_a.weight": torch.from_numpy(g[f"gse_{tag}_w_a"]), "proj_a.bias": torch.from_numpy(g[f"gse_{tag}_b_a"])})
     return m.cuda()
 
 
-@pytest.mark.parametrize("fp32_mfma", [False, True])
+@pytest.mark.parametrize("mode,fp32_mfma", [("table", False), ("gemm", False), ("gemm", True)])
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
-def test_geo_embedding_matches_reference_golden(tag, fp32_mfma):
-    """Both projection kernels: split-bf16 (default) and fp32 MFMA."""
+def test_geo_embedding_matches_reference_golden(tag, mode, fp32_mfma):
+    """All three evaluations: function tables (default), split-bf16 GEMM and fp32-MFMA GEMM."""
     g = load_golden("rpe.npz")
-    out = _gse(g, tag, fp32_mfma)(_c(g[f"gse_{tag}_points"])).cpu().numpy()
+    out = _gse(g, tag, fp32_mfma, mode)(_c(g[f"gse_{tag}_points"])).cpu().numpy()
     ref = g[f"gse_{tag}_out"]
     n = ref.shape[1]
     off = ~np.eye(n, dtype=bool)
@@ -231,9 +231,20 @@ def test_geo_embedding_demo_shape_vs_oracle():
                                           m.embedding.div_term.cpu().numpy(), 0.2, 15, 3)
     off = ~np.eye(n, dtype=bool)
     np.testing.assert_allclose(out[off], ref[off], rtol=5e-5, atol=5e-5)
-    m.fp32_mfma = True                          # the two kernels agree far inside the tolerance
+    assert m.mode == "table"
+    m.mode = "gemm"                             # the evaluations agree far inside the tolerance
+    outg = m(pts.cuda())[0].cpu().numpy()
+    assert np.abs(outg - out)[off].max() < 5e-6
+    m.fp32_mfma = True
     out32 = m(pts.cuda())[0].cpu().numpy()
     assert np.abs(out32 - out)[off].max() < 5e-6
+    # a cloud 400 m across: distance indices far beyond the table are evaluated directly from the weights
+    m.mode, m.fp32_mfma = "table", False
+    big = pts * 80.0
+    o_t = m(big.cuda())[0].cpu().numpy()
+    m.mode = "gemm"
+    o_g = m(big.cuda())[0].cpu().numpy()
+    assert np.abs(o_t - o_g)[off].max() < 2e-4          # sin / cos of arguments ~ 2 000: both sides lose digits there
 
 
 def test_rpe_attention_matches_reference_golden():

@@ -133,18 +133,24 @@ def run(dev):
         sc = R(P, K, K)
         ms = _ms(lambda: ot(sc, rm, sm), 10)
         out["sinkhorn_256x128x128_100it"] = _hbm(ms, 4 * P * K * K + 4 * P * (K + 1) * (K + 1), lds_passes=200)
-        # ---- geometric structure embedding N = 767 (308 GFLOP per cloud)
+        # ---- geometric structure embedding N = 767: function tables (default; bound by the 4 N^2 C bytes written) and the
+        #      sinusoid -> matrix-core GEMM it replaced (308 GFLOP per cloud)
         gse = GeometricStructureEmbedding(256, 0.2, 15, 3).to(dev)
         pcs = pc[None].contiguous()
         ms = _ms(lambda: gse(pcs), 5, 1)
         n = pcs.shape[1]
-        # the kernel runs SIX bf16 MFMAs per fp32 product on the bf16 matrix pipe (dense peak 2 500 TFLOP/s): `frac` is quoted
-        # against the pipe it uses; the fp32-equivalent rate is a second figure, not a fraction of the fp32 pipe
+        out["geo_embedding"] = _hbm(ms, 4.0 * n * n * 256, shape=[n, 256, 3],
+                                    note="function tables + 4-point interpolation (gr_geo_embedding_table); bytes = the (N, N, C) result")
+        gse_g = GeometricStructureEmbedding(256, 0.2, 15, 3, mode="gemm").to(dev)
+        ms = _ms(lambda: gse_g(pcs), 5, 1)
+        # the GEMM kernel runs SIX bf16 MFMAs per fp32 product on the bf16 matrix pipe (dense peak 2 500 TFLOP/s): `frac` is
+        # quoted against the pipe it uses; the fp32-equivalent rate is a second figure, not a fraction of the fp32 pipe
         fe = 2.0 * n * n * 256 * 256 * 4
-        out["geo_embedding"] = {"ms": round(ms, 4), "flops_fp32_equivalent": fe, "flops_bf16_executed": 6.0 * fe, "bound": "mfma_bf16",
-                                "TFLOP/s_bf16_executed": round(6.0 * fe / ms / 1e9, 2), "peak_TFLOP/s": 2500.0,
-                                "frac": round(6.0 * fe / ms / 1e9 / 2500.0, 4), "TFLOP/s_fp32_equivalent": round(fe / ms / 1e9, 2),
-                                "shape": [n, 256, 3], "note": "split-bf16 x6 MFMA; bound by LDS operand traffic, not the matrix pipe"}
+        out["geo_embedding_gemm"] = {"ms": round(ms, 4), "flops_fp32_equivalent": fe, "flops_bf16_executed": 6.0 * fe, "bound": "mfma_bf16",
+                                     "TFLOP/s_bf16_executed": round(6.0 * fe / ms / 1e9, 2), "peak_TFLOP/s": 2500.0,
+                                     "frac": round(6.0 * fe / ms / 1e9 / 2500.0, 4), "TFLOP/s_fp32_equivalent": round(fe / ms / 1e9, 2),
+                                     "shape": [n, 256, 3], "note": "mode='gemm': split-bf16 x6 MFMA; bound by LDS operand traffic, not the matrix pipe"}
+        del gse_g
         # ---- fused RPE attention (everything after the projections in one kernel; the embedding is the only N*M*C stream)
         from gaussreg_amd import _lib
         from gaussreg_amd.rpe_attention import RPEMultiHeadAttention
