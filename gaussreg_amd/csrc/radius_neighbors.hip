@@ -1171,7 +1171,9 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
   }
   GR_FUSED_STOP(2, (int)sx[tid])
   // ---- test every candidate, four per step.  Enumeration slot c = 4 * step + k (k = 0..3; a band's last step is padded);
-  //      even slots go to `lo` (bit c / 2), odd slots to `hi`: the decode below takes one hit from each per step
+  //      even slots are remembered in `lo`, odd slots in `hi`: two 32-bit SHIFT REGISTERS -- a hit is the sign bit of
+  //      (distance bits - r2 bits) (both are non-negative floats: their bit patterns order like the values, NaN sorts above
+  //      everything), shifted in with one v_alignbit; the decode below takes one hit from each side per step
   unsigned lo = 0u, hi = 0u;
   int n = 0;
   int rel[3] = {0, 0, 0};
@@ -1181,10 +1183,11 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
   }
   const int len0 = p1[0] - p0[0], len1 = p1[1] - p0[1], len2 = p1[2] - p0[2];
   const int nit0 = (len0 + 3) >> 2, nit1 = (len1 + 3) >> 2, nit2 = (len2 + 3) >> 2;
-  if (valid && staged) {
-    int sh = 0;  // 2 * step
+  const bool by_mask = staged && (nit0 + nit1 + nit2 <= 16);  // else: counted here, re-walked in the decode
+  const unsigned r2b = r2 == r2 ? __float_as_uint(r2) : 0u;      // NaN radius: nothing is a neighbour
+  if (valid && by_mask) {
     const f32x2 qx = {qp.x, qp.x}, qy = {qp.y, qp.y}, qz = {qp.z, qp.z};
-    auto step4 = [&](int p, unsigned va, unsigned vb) {
+    auto step4 = [&](int p) {
       const f32x2 xa = {sx[p], sx[p + 1]}, xb = {sx[p + 2], sx[p + 3]};
       const f32x2 ya = {sy[p], sy[p + 1]}, yb = {sy[p + 2], sy[p + 3]};
       const f32x2 za = {sz[p], sz[p + 1]}, zb = {sz[p + 2], sz[p + 3]};
@@ -1193,23 +1196,48 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
       const f32x2 dxb = qx - xb, dyb = qy - yb, dzb = qz - zb;
       const f32x2 da = (dxa * dxa + dya * dya) + dza * dza;
       const f32x2 db = (dxb * dxb + dyb * dyb) + dzb * dzb;
-      const unsigned ha = ((da.x < r2 ? 1u : 0u) | (db.x < r2 ? 2u : 0u)) & va;  // candidates p, p + 2
-      const unsigned hb = ((da.y < r2 ? 1u : 0u) | (db.y < r2 ? 2u : 0u)) & vb;  // candidates p + 1, p + 3
-      lo |= ha << sh;  // steps past 16 shift out of range; such threads re-walk their candidates instead (by_mask below)
-      hi |= hb << sh;
-      n += __popc(ha) + __popc(hb);
-      sh += 2;
+      const unsigned t0 = __float_as_uint(da.x) - r2b, t1 = __float_as_uint(da.y) - r2b;
+      const unsigned t2 = __float_as_uint(db.x) - r2b, t3 = __float_as_uint(db.y) - r2b;
+      lo = __builtin_amdgcn_alignbit(lo, t0, 31);  // (lo << 1) | sign(t0)
+      lo = __builtin_amdgcn_alignbit(lo, t2, 31);
+      hi = __builtin_amdgcn_alignbit(hi, t1, 31);
+      hi = __builtin_amdgcn_alignbit(hi, t3, 31);
     };
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       int p = p0[i] + rel[i];
       const int e = p1[i] + rel[i];
-      for (; p + 4 <= e; p += 4) step4(p, 3u, 3u);
+      for (; p + 4 <= e; p += 4) step4(p);
       if (p < e) {  // padded last step: 1..3 candidates left (the reads past the band stay inside the planes)
         const int left = e - p;
-        step4(p, left >= 3 ? 3u : 1u, left >= 2 ? 1u : 0u);
+        // (same arithmetic; slots past the band shift in a zero)
+        {
+          const f32x2 xa = {sx[p], sx[p + 1]}, xb = {sx[p + 2], sx[p + 3]};
+          const f32x2 ya = {sy[p], sy[p + 1]}, yb = {sy[p + 2], sy[p + 3]};
+          const f32x2 za = {sz[p], sz[p + 1]}, zb = {sz[p + 2], sz[p + 3]};
+          const f32x2 dxa = qx - xa, dya = qy - ya, dza = qz - za;
+          const f32x2 dxb = qx - xb, dyb = qy - yb, dzb = qz - zb;
+          const f32x2 da = (dxa * dxa + dya * dya) + dza * dza;
+          const f32x2 db = (dxb * dxb + dyb * dyb) + dzb * dzb;
+          const unsigned t0 = __float_as_uint(da.x) - r2b;
+          const unsigned t1 = left >= 2 ? __float_as_uint(da.y) - r2b : 0u;
+          const unsigned t2 = left >= 3 ? __float_as_uint(db.x) - r2b : 0u;
+          lo = __builtin_amdgcn_alignbit(lo, t0, 31);
+          lo = __builtin_amdgcn_alignbit(lo, t2, 31);
+          hi = __builtin_amdgcn_alignbit(hi, t1, 31);
+          hi = __builtin_amdgcn_alignbit(hi, 0u, 31);
+        }
       }
     }
+    n = __popc(lo) + __popc(hi);
+  } else if (valid && staged) {  // more than 64 enumeration slots: count now, walk again in the decode
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      for (int p = p0[i] + rel[i]; p < p1[i] + rel[i]; ++p) {
+        const float dx = qp.x - sx[p], dy = qp.y - sy[p], dz = qp.z - sz[p];
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        n += d < r2 ? 1 : 0;
+      }
   } else if (valid) {
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -1253,7 +1281,6 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
   const bool multi = total4 > cap;
   const bool use_rowbuf = ROWBUF && !multi;
   const int rows_here = min(RQ, nq - blk * RQ);
-  const bool by_mask = staged && (nit0 + nit1 + nit2 <= 16);
   if (multi) __syncthreads();  // offs complete
   int glo = 0;
   while (glo < RQ) {
@@ -1282,18 +1309,20 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
       if (by_mask) {
         const int c1 = 4 * nit0, c2 = 4 * (nit0 + nit1);
         const int s0 = p0[0] + rel[0], s1 = p0[1] + rel[1] - c1, s2 = p0[2] + rel[2] - c2;
+        // the shift registers hold 2 bits per step: the side's first candidate sits in bit 2 S - 1 (S = steps of this thread)
+        const int top = 2 * (nit0 + nit1 + nit2) - 1;
         unsigned ml = lo, mh = hi;
         while (ml | mh) {
-          const int ba = __ffs((int)ml) - 1, bb = __ffs((int)mh) - 1;  // -1: none left on that side
-          ml &= ml - 1u;
-          mh &= mh - 1u;
-          const int ca = 2 * ba, cb = 2 * bb + 1;
+          const int qa = 31 - __clz((int)ml), qb = 31 - __clz((int)mh);  // -1: none left on that side
+          ml &= ~(qa >= 0 ? 1u << qa : 0u);
+          mh &= ~(qb >= 0 ? 1u << qb : 0u);
+          const int ca = 2 * (top - qa), cb = 2 * (top - qb) + 1;      // enumeration slots
           const int pa = ca + (ca < c1 ? s0 : (ca < c2 ? s1 : s2));
           const int pb = cb + (cb < c1 ? s0 : (cb < c2 ? s1 : s2));
-          const int wa = ba >= 0 ? w : dummy;
-          w += ba >= 0 ? 1 : 0;
-          const int wb = bb >= 0 ? w : dummy;
-          w += bb >= 0 ? 1 : 0;
+          const int wa = qa >= 0 ? w : dummy;
+          w += qa >= 0 ? 1 : 0;
+          const int wb = qb >= 0 ? w : dummy;
+          w += qb >= 0 ? 1 : 0;
           hm[wa] = tag | (unsigned)pa;
           hm[wb] = tag | (unsigned)pb;
         }
