@@ -355,6 +355,16 @@ namespace {
 // out[i, :] = data[index[i], :] for i < m (index_select along dim 0 of a 2-D fp32 tensor); rows move as float4 when the
 // row length allows, one 16-lane group per row so a wave reads four 64-byte-aligned row pieces per instruction
 template <typename VEC>
+__device__ __forceinline__ VEC gather_poison();
+template <>
+__device__ __forceinline__ float gather_poison<float>() { return __uint_as_float(0x7fc00000u); }
+template <>
+__device__ __forceinline__ float4 gather_poison<float4>() {
+  const float q = __uint_as_float(0x7fc00000u);
+  return make_float4(q, q, q, q);
+}
+
+template <typename VEC>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const VEC* __restrict__ data, int64_t n, int cv,
                                                           const int64_t* __restrict__ index, int64_t m,
                                                           VEC* __restrict__ out, int* __restrict__ bad) {
@@ -365,6 +375,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const VEC* __restrict_
   const int64_t src = index[row];
   if (src < 0 || src >= n) {
     if (col == 0) atomicOr(bad, 1);
+    out[row * cv + col] = gather_poison<VEC>();  // never leave the row uninitialised: a quiet NaN marks it until the flag is read
     return;
   }
   out[row * cv + col] = data[src * cv + col];

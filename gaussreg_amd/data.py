@@ -65,6 +65,8 @@ def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, 
             p, l, ev = item
             main_stream.wait_event(ev)
             p.record_stream(main_stream)  # allocated on the side stream, consumed here
+            if l.is_cuda:
+                l.record_stream(main_stream)
             points_list.append(p)
             lengths_list.append(l)
     else:
@@ -101,6 +103,12 @@ def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, 
     finally:
         if th is not None:
             th.join()
+            # everything the side stream allocated (intermediates included) is settled before its thread-local scratch is
+            # reused by anybody else; the worker's workspace entry is dropped with the thread
+            side.synchronize()
+            from . import _lib as _l
+            for k in [k for k in _l._ws_cache if k[2] == side.cuda_stream]:
+                del _l._ws_cache[k]
     return {'points': points_list, 'lengths': lengths_list, 'neighbors': neighbors_list,
             'subsampling': subsampling_list, 'upsampling': upsampling_list}
 

@@ -88,6 +88,9 @@ class GeoTransformer(nn.Module):
         # 2. KPConv encoder / decoder (:128-132)
         feats_list = self.backbone(feats, data_dict)
         feats_c, feats_f = feats_list[-1], feats_list[0]
+        from .ops import gather_error_pending
+        if gather_error_pending(feats_c.device):  # the backbone's large index_selects record a bad index instead of raising
+            raise IndexError("index out of range in index_select (neighbour / subsampling / upsampling indices of the pyramid)")
         # 3. geometric transformer on the superpoints (:134-148)
         ref_feats_c, src_feats_c = self.transformer(ref_points_c.unsqueeze(0), src_points_c.unsqueeze(0),
                                                     feats_c[:ref_length_c].unsqueeze(0), feats_c[ref_length_c:].unsqueeze(0))

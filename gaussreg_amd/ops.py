@@ -135,11 +135,16 @@ def index_select(data, index, dim):
             _gather_flags[key] = flag
         if m > 0 and c > 0:
             L = _lib.lib()
+            eager = m <= 65536
+            if eager:
+                # a small gather is checked eagerly like torch's: its own flag word, so an earlier LARGE gather's pending
+                # error is neither raised here nor lost (that one poisons its rows with NaN and is reported by
+                # gather_error_pending)
+                own = torch.zeros(1, dtype=torch.int32, device=dev)
             with torch.cuda.device(dev):
-                _lib.check(L.gr_gather_rows(_lib.ptr(flat), n, max(c, 1), _lib.ptr(idx), m, _lib.ptr(res), _lib.ptr(flag),
-                                            _lib.stream_ptr(dev)))
-            if m <= 65536 and int(flag.item()) != 0:  # small gathers are checked eagerly like torch; large ones lazily
-                flag.zero_()
+                _lib.check(L.gr_gather_rows(_lib.ptr(flat), n, max(c, 1), _lib.ptr(idx), m, _lib.ptr(res),
+                                            _lib.ptr(own if eager else flag), _lib.stream_ptr(dev)))
+            if eager and int(own.item()) != 0:
                 raise IndexError("index out of range in index_select")
         out = res.reshape((m,) + tuple(rest)).movedim(0, dim)
         if out_device.type != "cuda":
@@ -151,8 +156,10 @@ def index_select(data, index, dim):
 
 
 def gather_error_pending(device=None):
-    """True if a large index_select on `device` met an out-of-range index since the last check (torch raises eagerly;
-    the HIP gather records it on the device instead of synchronising every call)."""
+    """True if a large index_select (more than 65 536 rows) on `device` met an out-of-range index since the last check.  torch
+    raises eagerly; the HIP gather records it on the device instead of synchronising every call, and fills the offending
+    rows with NaN so that nothing downstream can mistake them for data.  GeoTransformer.forward checks this at its first
+    natural synchronisation point."""
     dev = _lib.require_gpu() if device is None else torch.device(device)
     flag = _gather_flags.get((dev.type, dev.index))
     if flag is None:
