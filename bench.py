@@ -492,8 +492,9 @@ def run_gpu(h, args):
         try:
             n_net = min(len(pairs), 64)
             regm = pair_pipeline.PairRegistrar(dev, features="model")
-            regm.register_pairs(pairs[: min(2, n_net)])
             net_batch = min(args.pair_batch, 32)
+            torch.cuda.empty_cache()                     # the earlier sections' cached blocks are of other sizes
+            regm.register_pairs(pairs[:net_batch])       # warm-up at the timed batch size (allocator, lazy kernels)
 
             def net_pass():
                 for i in range(0, n_net, net_batch):

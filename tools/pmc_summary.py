@@ -7,8 +7,8 @@ import json
 import sys
 
 KEEP = ("blend_kernel", "preprocess_kernel", "traverse_kernel", "ds_scatter_kernel", "ds_count_kernel", "ds_scan_kernel",
-        "tile_scatter_kernel", "tile_count_kernel", "seg_scan_kernel", "scatter_kernel", "bin_count_kernel",
-        "rpe_attention_kernel", "geo_embedding", "fps_multi_kernel", "kpconv")
+        "tile_scatter_kernel", "tile_count_kernel", "seg_scan_kernel", "coarse_kernel", "fine_kernel", "bbox_partial_kernel",
+        "fused_kernel", "rpe_attention_kernel", "geo_embedding", "fps_multi_kernel", "kpconv")
 
 
 def short(name):
@@ -46,7 +46,7 @@ def main():
                    "--steps 3 --warmup 1 --no-cpu-baseline --pairs 0 --no-extras --no-single-view; values in KB per launch as reported. Per MI355X_MICROARCH.md (HBM "
                    "section) FETCH_SIZE on gfx950 counts wide coalesced reads at 1/2 -> hbm_bytes ~= (2*FETCH_SIZE + WRITE_SIZE)*1024.",
            "config": {"raster": f"1M Gaussians, 640x480, {views} views/launch", "radius": f"{clouds} x 200k-pt clouds/launch, r=0.0625"},
-           "units_per_launch": {"raster_blend": views, "radius_fill": clouds},
+           "units_per_launch": {"raster_blend": views, "radius_fill": clouds, "radius_count": clouds, "radius_fused": clouds},
            "kernels": kernels, "traffic_bytes_per_launch": {}}
     for k in kernels:  # the two kernels bench.py prices against the HBM roofline
         hbm = int((2 * k["fetch_size_kb_avg"] + k["write_size_kb_avg"]) * 1024)
@@ -54,6 +54,10 @@ def main():
             doc["traffic_bytes_per_launch"]["raster_blend"] = hbm
         if k["kernel"].startswith("traverse_kernel<128, true"):
             doc["traffic_bytes_per_launch"]["radius_fill"] = hbm
+        if k["kernel"].startswith("traverse_kernel<128, false"):
+            doc["traffic_bytes_per_launch"]["radius_count"] = hbm
+        if k["kernel"].startswith("fused_kernel"):
+            doc["traffic_bytes_per_launch"]["radius_fused"] = hbm
     json.dump(doc, open(out, "w"), indent=1)
     for k in kernels:
         print(k)
