@@ -10,7 +10,7 @@ a = starts[-2]; b = starts[-1]
 t0 = int(rows[a]["Start_Timestamp"]); prev_end = t0
 for r in rows[a:b]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("gr::(anonymous namespace)::", "").replace("gr::", "")[:46]
+    name = r["Kernel_Name"].replace("void ", "").replace("gr::(anonymous namespace)::", "").replace("gr::", "").split("(")[0][:46]
     print(f"{name:46s} start {(s - t0) / 1e3:8.1f} us  dur {(e - s) / 1e3:7.1f}  gap {(s - prev_end) / 1e3:7.1f}")
     prev_end = e
 print("iteration total", (int(rows[b]["Start_Timestamp"]) - t0) / 1e3, "us")
