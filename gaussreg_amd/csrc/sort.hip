@@ -3,8 +3,8 @@
 // pre-sort of the farthest point sampling.
 //
 // One pass per digit of up to 11 bits (the digit width is chosen so that all passes are equally wide):
-//   rs_hist_kernel     per-chunk digit histogram (2048 keys per workgroup, LDS atomics) -> hist[chunk][bins]
-//   rs_scan_kernel     one workgroup per 64 digits: exclusive prefix over the chunks of every digit (in place) and the
+//   rs_hist_kernel     per-chunk digit histogram (2048 keys per workgroup, LDS atomics) -> hist[digit][chunk]
+//   rs_scan_kernel     one wave per digit: exclusive prefix over the chunks of the digit (contiguous; in place) and the
 //                      digit totals
 //   rs_scatter_kernel  every workgroup scans the digit totals itself (<= 2048 values), then ranks its chunk: wave w owns a
 //                      contiguous quarter of the chunk and a private row of running digit counters in LDS; keys are
@@ -41,43 +41,50 @@ __global__ __launch_bounds__(RS_T) void rs_hist_kernel(const uint64_t* __restric
   for (int u = 0; u < RS_PER; ++u)
     if (base + u * RS_T + threadIdx.x < n) atomicAdd(&s_h[digit_of(k[u], shift, mask)], 1u);
   __syncthreads();
-  uint32_t* dst = hist + (int64_t)blockIdx.x * bins;
-  for (int i = threadIdx.x; i < bins; i += RS_T) dst[i] = s_h[i];
+  // digit-major: hist[d][chunk] -- the scan over the chunks of a digit reads contiguous words
+  for (int i = threadIdx.x; i < bins; i += RS_T) hist[(int64_t)i * gridDim.x + blockIdx.x] = s_h[i];
 }
 
-// block b owns digits [64 b, 64 b + 64): wave w of 4 takes 16 of them; lanes run over the chunks
+// one wave per digit: exclusive prefix over the chunks of that digit (contiguous in the digit-major table), in place
 __global__ __launch_bounds__(RS_T) void rs_scan_kernel(uint32_t* __restrict__ hist, int nchunk, int bins,
                                                        uint32_t* __restrict__ totals) {
   const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
-  for (int dd = 0; dd < 64 / RS_NW; ++dd) {
-    const int d = blockIdx.x * 64 + w * (64 / RS_NW) + dd;
-    if (d >= bins) return;
-    unsigned int carry = 0u;
-    for (int c0 = 0; c0 < nchunk; c0 += WAVE) {
-      const int c = c0 + lane;
-      const unsigned int v = c < nchunk ? hist[(int64_t)c * bins + d] : 0u;
-      const unsigned int inc = (unsigned int)wave_incl_scan_add_dpp((int)v);
-      if (c < nchunk) hist[(int64_t)c * bins + d] = carry + inc - v;
-      carry += (unsigned int)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
-    }
-    if (lane == 0) totals[d] = carry;
+  const int d = blockIdx.x * RS_NW + w;
+  if (d >= bins) return;
+  uint32_t* row = hist + (int64_t)d * nchunk;
+  unsigned int carry = 0u;
+  for (int c0 = 0; c0 < nchunk; c0 += WAVE) {
+    const int c = c0 + lane;
+    const unsigned int v = c < nchunk ? row[c] : 0u;
+    const unsigned int inc = (unsigned int)wave_incl_scan_add_dpp((int)v);
+    if (c < nchunk) row[c] = carry + inc - v;
+    carry += (unsigned int)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
   }
+  if (lane == 0) totals[d] = carry;
 }
 
-template <bool IOTA>
+// STAGE: the chunk is first sorted inside LDS and leaves as per-digit runs (consecutive keys of a digit go to consecutive
+// addresses: with 8-bit digits a run is 8 keys = one 64-byte sector).  Without it every key is one scattered 8 + 4 byte
+// write -- fine for the launch-bound sizes (<= 500 k keys, 11-bit digits: a run would be one key anyway), 2-3x slower at
+// millions of keys.
+template <bool IOTA, bool STAGE>
 __global__ __launch_bounds__(RS_T) void rs_scatter_kernel(const uint64_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
                                                           int64_t iota_period, int64_t n, int shift, int nbits, int bins,
                                                           const uint32_t* __restrict__ offs, const uint32_t* __restrict__ totals,
                                                           uint64_t* __restrict__ keys_out, int32_t* __restrict__ vals_out) {
-  extern __shared__ unsigned int s_mem[];
+  extern __shared__ __attribute__((aligned(16))) unsigned int s_mem[];
   unsigned int* s_dbase = s_mem;               // [bins] exclusive prefix of the digit totals
   unsigned int* s_cnt = s_mem + bins;          // [RS_NW][bins] per-wave counts, then running destinations
+  // STAGE: [bins] global destination minus local position per digit, then the staged chunk
+  unsigned int* s_delta = s_cnt + RS_NW * bins;
+  uint64_t* s_keys = reinterpret_cast<uint64_t*>(s_delta + bins + (bins & 1));
+  int32_t* s_vals = reinterpret_cast<int32_t*>(s_keys + RS_CHUNK);
   __shared__ unsigned int s_wsum[RS_NW];
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
   const unsigned mask = (1u << nbits) - 1u;
+  const int per = (bins + RS_T - 1) / RS_T;
   // ---- digit bases: scan of <= 2048 totals (8 per thread)
   {
-    const int per = (bins + RS_T - 1) / RS_T;
     unsigned int loc[RS_MAX_BINS / RS_T];
     unsigned int sum = 0u;
 #pragma unroll
@@ -100,7 +107,8 @@ __global__ __launch_bounds__(RS_T) void rs_scatter_kernel(const uint64_t* __rest
     }
   }
   // ---- the wave's 512 keys in position order: step r, lane l <-> position chunk + 512 w + 64 r + l
-  const int64_t wbase = (int64_t)blockIdx.x * RS_CHUNK + (int64_t)w * RS_WKEYS;
+  const int64_t cbase = (int64_t)blockIdx.x * RS_CHUNK;
+  const int64_t wbase = cbase + (int64_t)w * RS_WKEYS;
   uint64_t k[RS_PER];
   int32_t v[RS_PER];
 #pragma unroll
@@ -114,15 +122,51 @@ __global__ __launch_bounds__(RS_T) void rs_scatter_kernel(const uint64_t* __rest
   for (int r = 0; r < RS_PER; ++r)
     if (wbase + r * WAVE + lane < n) atomicAdd(&row[digit_of(k[r], shift, mask)], 1u);
   __syncthreads();
-  // ---- running destinations: row[w][d] = global offset of (chunk, d) + digit base + keys of earlier waves with digit d
-  const uint32_t* off_c = offs + (int64_t)blockIdx.x * bins;
-  for (int d = tid; d < bins; d += RS_T) {
-    unsigned int acc = s_dbase[d] + off_c[d];
+  const uint32_t* off_c = offs + blockIdx.x;  // digit-major table: entry of digit d at off_c[d * gridDim.x]
+  const int64_t ostr = gridDim.x;
+  if (STAGE) {
+    // local exclusive prefix over the digits of the chunk (thread t owns digits t*per .. t*per+per-1, like the scan above)
+    unsigned int loc[RS_MAX_BINS / RS_T];
+    unsigned int sum = 0u;
 #pragma unroll
-    for (int i = 0; i < RS_NW; ++i) {
-      const unsigned int c = s_cnt[i * bins + d];
-      s_cnt[i * bins + d] = acc;
-      acc += c;
+    for (int u = 0; u < RS_MAX_BINS / RS_T; ++u) {
+      const int d = tid * per + u;
+      unsigned int c = 0u;
+      if (u < per && d < bins)
+        for (int i = 0; i < RS_NW; ++i) c += s_cnt[i * bins + d];
+      loc[u] = c;
+      sum += c;
+    }
+    const unsigned int inc = (unsigned int)wave_incl_scan_add_dpp((int)sum);
+    __syncthreads();  // s_wsum is reused
+    if (lane == WAVE - 1) s_wsum[w] = inc;
+    __syncthreads();
+    unsigned int ex = inc - sum;
+    for (int i = 0; i < w; ++i) ex += s_wsum[i];
+#pragma unroll
+    for (int u = 0; u < RS_MAX_BINS / RS_T; ++u) {
+      const int d = tid * per + u;
+      if (u < per && d < bins) {
+        s_delta[d] = s_dbase[d] + off_c[d * ostr] - ex;  // global destination of the digit's first key minus its local position
+        unsigned int acc = ex;                      // running LOCAL destinations per wave
+        for (int i = 0; i < RS_NW; ++i) {
+          const unsigned int c = s_cnt[i * bins + d];
+          s_cnt[i * bins + d] = acc;
+          acc += c;
+        }
+      }
+      ex += loc[u];
+    }
+  } else {
+    // ---- running destinations: row[w][d] = global offset of (chunk, d) + digit base + keys of earlier waves with digit d
+    for (int d = tid; d < bins; d += RS_T) {
+      unsigned int acc = s_dbase[d] + off_c[d * ostr];
+#pragma unroll
+      for (int i = 0; i < RS_NW; ++i) {
+        const unsigned int c = s_cnt[i * bins + d];
+        s_cnt[i * bins + d] = acc;
+        acc += c;
+      }
     }
   }
   __syncthreads();
@@ -139,8 +183,13 @@ __global__ __launch_bounds__(RS_T) void rs_scatter_kernel(const uint64_t* __rest
     if (live) {
       const unsigned long long below = same & ((1ull << lane) - 1ull);
       const unsigned int dst = row[d] + (unsigned int)__popcll(below);
-      keys_out[dst] = k[r];
-      vals_out[dst] = v[r];
+      if (STAGE) {
+        s_keys[dst] = k[r];
+        s_vals[dst] = v[r];
+      } else {
+        keys_out[dst] = k[r];
+        vals_out[dst] = v[r];
+      }
       if ((same >> lane) >> 1 == 0ull) row[d] += (unsigned int)__popcll(same);  // the group's last lane moves the counter on
     }
     // (a wave executes in lockstep and the counter of a digit is touched by one lane per step: no barrier needed)
@@ -148,16 +197,31 @@ __global__ __launch_bounds__(RS_T) void rs_scatter_kernel(const uint64_t* __rest
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
+  if (STAGE) {
+    __syncthreads();
+    const int here = (int)min((int64_t)RS_CHUNK, n - cbase);
+    for (int i = tid; i < here; i += RS_T) {
+      const uint64_t key = s_keys[i];
+      const unsigned int dst = (unsigned int)i + s_delta[digit_of(key, shift, mask)];
+      keys_out[dst] = key;
+      vals_out[dst] = s_vals[i];
+    }
+  }
 }
 
 struct Plan {
   int passes, digit_bits, nchunk;
+  bool stage;
 };
 
 Plan plan_of(int64_t n, int begin_bit, int end_bit) {
   Plan p;
   const int bits = end_bit - begin_bit;
-  p.passes = (bits + RS_MAX_BITS - 1) / RS_MAX_BITS;
+  // launch-bound sizes: as few passes as possible (11-bit digits); millions of keys: 8-bit digits whose runs are whole
+  // sectors, written out of an LDS-sorted chunk
+  p.stage = n >= (1 << 19);
+  const int max_bits = p.stage ? 8 : RS_MAX_BITS;
+  p.passes = (bits + max_bits - 1) / max_bits;
   p.digit_bits = (bits + p.passes - 1) / p.passes;
   p.nchunk = (int)((n + RS_CHUNK - 1) / RS_CHUNK);
   return p;
@@ -188,14 +252,18 @@ int radix_sort(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t*
     const bool iota = p == 0 && iota_period > 0;
     hipLaunchKernelGGL(rs_hist_kernel, dim3(pl.nchunk), dim3(RS_T), bins * sizeof(unsigned int), stream, kin, n, shift,
                        (unsigned)(bins - 1), bins, hist);
-    hipLaunchKernelGGL(rs_scan_kernel, dim3((bins + 63) / 64), dim3(RS_T), 0, stream, hist, pl.nchunk, bins, totals);
-    const size_t lds = (size_t)(1 + RS_NW) * bins * sizeof(unsigned int);
-    if (iota)
-      hipLaunchKernelGGL(rs_scatter_kernel<true>, dim3(pl.nchunk), dim3(RS_T), lds, stream, kin, vin, iota_period, n, shift, nb,
-                         bins, hist, totals, ko, vo);
-    else
-      hipLaunchKernelGGL(rs_scatter_kernel<false>, dim3(pl.nchunk), dim3(RS_T), lds, stream, kin, vin, (int64_t)1, n, shift, nb,
-                         bins, hist, totals, ko, vo);
+    hipLaunchKernelGGL(rs_scan_kernel, dim3((bins + RS_NW - 1) / RS_NW), dim3(RS_T), 0, stream, hist, pl.nchunk, bins, totals);
+    size_t lds = (size_t)(1 + RS_NW) * bins * sizeof(unsigned int);
+    if (pl.stage) lds += (size_t)(bins + (bins & 1)) * sizeof(unsigned int) + (size_t)RS_CHUNK * 12;
+#define GR_RS_SCATTER(IO, ST)                                                                                              \
+  hipLaunchKernelGGL((rs_scatter_kernel<IO, ST>), dim3(pl.nchunk), dim3(RS_T), lds, stream, kin, vin, iota ? iota_period : (int64_t)1, \
+                     n, shift, nb, bins, hist, totals, ko, vo)
+    if (iota) {
+      if (pl.stage) GR_RS_SCATTER(true, true); else GR_RS_SCATTER(true, false);
+    } else {
+      if (pl.stage) GR_RS_SCATTER(false, true); else GR_RS_SCATTER(false, false);
+    }
+#undef GR_RS_SCATTER
     GR_LAUNCH_CHECK();
     kin = ko;
     vin = vo;

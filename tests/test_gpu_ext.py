@@ -236,3 +236,35 @@ def test_small_shape_fuzz_vs_oracle():
             wp, wl = capi.grid_subsampling(s, sl, max(radius / 2, 0.01))
             gp, gl = ext.grid_subsampling(ts, torch.from_numpy(sl), max(radius / 2, 0.01))
             assert np.array_equal(gl.numpy(), wl) and np.array_equal(gp.cpu().numpy().view(np.uint32), wp.view(np.uint32))
+
+
+def test_large_clouds_take_the_staged_radix_sort():
+    """>= 2^19 keys: csrc/sort.hip switches to 8-bit digits and LDS-staged runs.  grid_subsampling of 3 x 250 k points against
+    the oracle (bit-exact incl. the reference row order), and FPS of the stacked clouds against FPS of every cloud alone
+    (whose Morton pre-sort takes the small-size path)."""
+    from oracle import capi
+    from gaussreg_amd.registration import farthest_point_sampling
+    rng = np.random.default_rng(17)
+    lens = np.array([250000, 250000, 250000], np.int64)
+    pts = (rng.random((int(lens.sum()), 3)) * [5, 4, 3]).astype(np.float32)
+    t = _t(pts)
+    for order in ("reference", "cell"):
+        gp, gl = _ext().grid_subsampling(t, torch.from_numpy(lens), 0.05, order=order)
+        wp, wl = capi.grid_subsampling(pts, lens, 0.05)
+        assert np.array_equal(gl.numpy(), wl)
+        got = gp.cpu().numpy()
+        if order == "reference":
+            assert np.array_equal(got.view(np.uint32), wp.view(np.uint32))
+        else:  # same multiset of rows per cloud
+            o = 0
+            for m in wl:
+                a = np.sort(got[o:o + m].view([("x", "f4"), ("y", "f4"), ("z", "f4")]), axis=0)
+                b = np.sort(wp[o:o + m].view([("x", "f4"), ("y", "f4"), ("z", "f4")]), axis=0)
+                assert np.array_equal(a, b)
+                o += m
+    both = farthest_point_sampling(t, lens.tolist(), [2000] * 3, start_indices=[0, 1, 2])
+    o = 0
+    for b, n in enumerate(lens.tolist()):
+        alone = farthest_point_sampling(t[o:o + n].contiguous(), [n], [2000], start_indices=[b])
+        assert torch.equal(both[b], alone[0])
+        o += n
