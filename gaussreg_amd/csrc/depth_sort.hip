@@ -120,22 +120,6 @@ __global__ __launch_bounds__(DS_SCAN_NW* WAVE) void ds_scan_kernel(int nchunk, c
   if (wv == DS_SCAN_NW - 1) digit_total[v * DS_BINS + d] = (int32_t)run;
 }
 
-// per view: exclusive scan of the digit totals (in place) and the view's entry count
-__global__ __launch_bounds__(DS_BINS) void ds_digit_base_kernel(int32_t* __restrict__ digit_total,
-                                                                int32_t* __restrict__ nvalid_out) {
-  __shared__ int s_w[DS_BINS / WAVE];
-  const int v = blockIdx.x, d = threadIdx.x;
-  const int lane = d & (WAVE - 1), wv = d / WAVE;
-  const int n = digit_total[v * DS_BINS + d];
-  const int incl = wave_incl_scan_add_dpp(n);
-  if (lane == WAVE - 1) s_w[wv] = incl;
-  __syncthreads();
-  int base = 0;
-  for (int i = 0; i < wv; ++i) base += s_w[i];
-  digit_total[v * DS_BINS + d] = base + incl - n;
-  if (d == DS_BINS - 1 && nvalid_out) nvalid_out[v] = base + incl;
-}
-
 // FIRST: raw 4-byte fields (compaction, word assembly).  LAST: writes the id and the rectangle.
 // id_bits > 0: packed words [field >> 9 | id (id_bits) | rectangle (26)]; id_bits == 0: (field << 32 | id) words.
 // word_shift: where this pass's digit sits in the word (passes after the first).
@@ -145,12 +129,14 @@ __global__ __launch_bounds__(DS_T) void ds_scatter_kernel(int P, int V, int nchu
                                                           const uint64_t* __restrict__ keys_in, int word_shift, int id_bits,
                                                           uint32_t dmask,
                                                           const uint32_t* __restrict__ offs,
-                                                          const int32_t* __restrict__ digit_base,
+                                                          const int32_t* __restrict__ digit_total,
                                                           uint64_t* __restrict__ keys_out, const uint32_t* __restrict__ rect_raw,
-                                                          uint32_t* __restrict__ rect_out, int32_t* __restrict__ ids_out) {
+                                                          uint32_t* __restrict__ rect_out, int32_t* __restrict__ ids_out,
+                                                          int32_t* __restrict__ nvalid_out) {
   __shared__ unsigned int s_cnt[DS_NW][DS_BINS];  // per-wave digit counters -> per-wave bases
   __shared__ int s_delta[DS_BINS];                // global position of a digit's run minus its chunk-local start
   __shared__ int s_w[DS_T / WAVE];
+  __shared__ int s_wt[DS_T / WAVE];               // wave sums of the view's digit totals
   __shared__ uint64_t s_key[DS_CHUNK];
   __shared__ unsigned short s_dig[FIRST ? DS_CHUNK : 1];
   int v, c;
@@ -242,16 +228,23 @@ __global__ __launch_bounds__(DS_T) void ds_scatter_kernel(int P, int V, int nchu
     const int mine = tot[0] + tot[1];
     const int incl = wave_incl_scan_add_dpp(mine);
     if (lane == WAVE - 1) s_w[wv] = incl;
+    // the view's digit bases = exclusive scan of its 512 digit totals, done here by every workgroup (it used to be a
+    // launch of its own: three launches per frame whose only work was 512 additions)
+    const int32_t* trow = digit_total + v * DS_BINS;
+    const int t0 = trow[d0], t1 = trow[d0 + 1];
+    const int tincl = wave_incl_scan_add_dpp(t0 + t1);
+    if (lane == WAVE - 1) s_wt[wv] = tincl;
     __syncthreads();
-    int base = 0;
-    for (int i = 0; i < wv; ++i) base += s_w[i];
-    for (int i = 0; i < DS_T / WAVE; ++i) total += s_w[i];
+    int base = 0, tbase = 0, view_total = 0;
+    for (int i = 0; i < wv; ++i) base += s_w[i], tbase += s_wt[i];
+    for (int i = 0; i < DS_T / WAVE; ++i) total += s_w[i], view_total += s_wt[i];
+    if (FIRST && c == 0 && threadIdx.x == 0 && nvalid_out) nvalid_out[v] = view_total;  // entries that survived the culling
+    const int dbase[2] = {tbase + tincl - (t0 + t1), tbase + tincl - t1};
     int start = base + incl - mine;
     const uint32_t* orow = offs + ((int64_t)v * nchunk + c) * DS_BINS;
-    const int32_t* brow = digit_base + v * DS_BINS;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      s_delta[d0 + u] = (int)orow[d0 + u] + brow[d0 + u] - start;
+      s_delta[d0 + u] = (int)orow[d0 + u] + dbase[u] - start;
       unsigned int run = (unsigned int)start;
 #pragma unroll
       for (int w = 0; w < DS_NW; ++w) {
@@ -335,10 +328,9 @@ int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* 
                          dmask, hist);
     hipLaunchKernelGGL(ds_scan_kernel, dim3((unsigned)(V * (DS_BINS / WAVE))), dim3(DS_SCAN_NW * WAVE), 0, stream, nchunk, hist,
                        offs, dbase);
-    hipLaunchKernelGGL(ds_digit_base_kernel, dim3((unsigned)V), dim3(DS_BINS), 0, stream, dbase, first ? nvalid_out : nullptr);
 #define GR_DS_SCATTER(F, L, O)                                                                                            \
   hipLaunchKernelGGL((ds_scatter_kernel<F, L, O>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field, kin, \
-                     word_shift, id_bits, dmask, offs, dbase, kout, rect_raw, rect_out, ids_out)
+                     word_shift, id_bits, dmask, offs, dbase, kout, rect_raw, rect_out, ids_out, first ? nvalid_out : nullptr)
     if (ordered) {
       if (first && last) GR_DS_SCATTER(true, true, true);
       else if (first) GR_DS_SCATTER(true, false, true);
