@@ -199,8 +199,8 @@ struct Geom {
   void* ds_table;        // depth-sort histograms / offsets
   size_t ds_table_bytes;
   int32_t* nvis;         // [V] visible (depth-ordered) Gaussians per view
-  int32_t* totals;       // [V] instances per view, [1] depth-overflow flag, [V] largest chunk total of every view
-  DevView* views;        // [MAX_VIEWS] camera table (uniform loads)
+  int32_t* totals;       // [V] instances per view, [V] largest chunk total of every view, [1] depth-overflow flag, [3] pad --
+  DevView* views;        // -- immediately followed by the [MAX_VIEWS] camera table: ONE upload clears the flag and sets the cameras
   int32_t* scan_ws;
   size_t bytes;
 };
@@ -227,8 +227,9 @@ Geom carve_geom(void* p, int64_t P, int V, int64_t tiles) {
   g.ds_table_bytes = depth_sort_table_bytes(P, V);
   g.ds_table = c.take<char>(g.ds_table_bytes);
   g.nvis = c.take<int32_t>(V);
-  g.totals = c.take<int32_t>(2 * V + 1);
-  g.views = c.take<DevView>(MAX_VIEWS);
+  g.totals = c.take<int32_t>(2 * V + 4 + MAX_VIEWS * (sizeof(DevView) / sizeof(int32_t)));
+  g.views = reinterpret_cast<DevView*>(g.totals ? g.totals + 2 * V + 4 : nullptr);
+  static_assert(sizeof(DevView) % sizeof(int32_t) == 0, "camera table follows an int array");
   g.scan_ws = c.take<int32_t>(V * scan_ws_ints(nchunk));
   g.bytes = c.used();
   return g;
@@ -268,7 +269,11 @@ __device__ __forceinline__ uint32_t pack_rect(const int* rmin, const int* rmax) 
 constexpr int REC_PLANE = 66;  // float4 per record-piece plane (64 + 2): the transposed ds_read_b128 are conflict-free
 constexpr int SH_ROW = 13;  // float4 per staged Gaussian: 12 used + 1 pad -> conflict-free ds_read_b128
 
-template <bool HAS_SH, bool HAS_COV, bool SH16>
+// SH16: 16 coefficients per Gaussian, 16-byte aligned.  LATE (one view per call): the 192 bytes are fetched only by the
+// Gaussians that survive the culling of THE view (12 float4 loads per visible lane, straight into registers) -- with a
+// single camera 40 % of the benchmark scene never reads its SH; with several views every Gaussian is visible somewhere,
+// and the coalesced stream through LDS below is the better way.
+template <bool HAS_SH, bool HAS_COV, bool SH16, bool LATE>
 __global__ __launch_bounds__(256) void preprocess_kernel(
     int P, int D, int M, int V, const DevView* __restrict__ views, const float* __restrict__ means3D,
     const float* __restrict__ shs, const float* __restrict__ colors_precomp,
@@ -276,11 +281,11 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, int W, int H,
     int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ dfield,
     uint32_t* __restrict__ rect_raw, int32_t* __restrict__ far_flag) {
-  __shared__ float4 s_sh[SH16 ? WAVE * SH_ROW : 1];
+  __shared__ float4 s_sh[(SH16 && !LATE) ? WAVE * SH_ROW : 1];
   __shared__ float4 s_rec[256 / WAVE][4 * REC_PLANE];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   float shr[SH16 ? 48 : 1];
-  if (SH16) {
+  if (SH16 && !LATE) {
     // degree-3 SH = 192 B per Gaussian: the block's 48 KB are read as a coalesced float4 stream and transposed through
     // LDS (row stride 13 float4 keeps the per-thread ds_read_b128 conflict-free), one wave's 64 Gaussians at a time through
     // the same 13 KB -- a 52 KB staging area for all four waves capped the CU at 12 resident waves for the whole view loop.
@@ -377,6 +382,17 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         if (ntile != 0) {
           float rgb[3];
           if (HAS_SH) {
+            if (SH16 && LATE) {
+              const float4* s4 = reinterpret_cast<const float4*>(shs + (int64_t)i * 48);
+#pragma unroll
+              for (int jj = 0; jj < 12; ++jj) {
+                const float4 t4 = s4[jj];
+                shr[4 * jj] = t4.x;
+                shr[4 * jj + 1] = t4.y;
+                shr[4 * jj + 2] = t4.z;
+                shr[4 * jj + 3] = t4.w;
+              }
+            }
             if (SH16) sh_to_rgb(D, p, cam.campos, [&](int k, int c) { return shr[k * 3 + c]; }, rgb);
             else sh_to_rgb(D, p, cam.campos, [&](int k, int c) { return sh[k * 3 + c]; }, rgb);
           } else {
@@ -1175,12 +1191,13 @@ int device_check(hipStream_t stream, F&& launch_check, int* h_flag) {
   return GR_OK;
 }
 
-// dv must stay alive until `stream` is synchronised by the caller
-int upload_views(const gr_raster_view* h_views, int num_views, DevView* d_views,
-                 hipStream_t stream) {
-  // staged in pinned per-thread scratch: every caller synchronises the stream before it returns
-  DevView* stage = static_cast<DevView*>(pinned_scratch(0, sizeof(DevView) * num_views));
-  GR_REQUIRE(stage != nullptr, "pinned staging buffer for %d views could not be allocated", num_views);
+// One host-to-device copy: the depth-overflow flag (cleared) and the camera table that follows it in the geometry buffer
+// (Geom::totals layout).  The pinned staging buffer must stay untouched until the caller has synchronised the stream / event.
+int upload_views(const gr_raster_view* h_views, int num_views, int32_t* d_flag, hipStream_t stream) {
+  char* raw = static_cast<char*>(pinned_scratch(0, 16 + sizeof(DevView) * num_views));
+  GR_REQUIRE(raw != nullptr, "pinned staging buffer for %d views could not be allocated", num_views);
+  memset(raw, 0, 16);
+  DevView* stage = reinterpret_cast<DevView*>(raw + 16);
   for (int v = 0; v < num_views; ++v) {
     const gr_raster_view& s = h_views[v];
     DevView& d = stage[v];
@@ -1194,7 +1211,7 @@ int upload_views(const gr_raster_view* h_views, int num_views, DevView* d_views,
     d.fy = (float)s.image_height / (2.0f * s.tanfovy);
     d.scale_mod = s.scale_modifier;
   }
-  GR_HIP(hipMemcpyAsync(d_views, stage, sizeof(DevView) * num_views, hipMemcpyHostToDevice, stream));
+  GR_HIP(hipMemcpyAsync(d_flag, raw, 16 + sizeof(DevView) * num_views, hipMemcpyHostToDevice, stream));
   return GR_OK;
 }
 
@@ -1246,7 +1263,7 @@ static int preprocess_impl(int64_t P, int M, const float* means3D, const float* 
       set_error("raster geometry buffer too small: need %zu bytes, got %zu", g0.bytes, geom_bytes);
       return GR_ERR_WORKSPACE;
     }
-    rc = upload_views(h_views, num_views, g0.views, stream);
+    rc = upload_views(h_views, num_views, g0.totals + 2 * num_views, stream);
     if (rc != GR_OK) return rc;
     GR_HIP(hipStreamSynchronize(stream));
     return GR_OK;
@@ -1270,14 +1287,19 @@ static int preprocess_impl(int64_t P, int M, const float* means3D, const float* 
     set_error("raster geometry buffer too small: need %zu bytes, got %zu", g.bytes, geom_bytes);
     return GR_ERR_WORKSPACE;
   }
-  rc = upload_views(h_views, num_views, g.views, stream);
+  rc = upload_views(h_views, num_views, g.totals + 2 * num_views, stream);  // cameras + the cleared depth-overflow flag
   if (rc != GR_OK) return rc;
   const dim3 blk(256), grd((unsigned)((P + 255) / 256));
   const bool sh16 = shs != nullptr && M == 16 && (reinterpret_cast<uintptr_t>(shs) % 16 == 0);
 #define GR_PRE(SH, COV, S16)                                                                       \
-  hipLaunchKernelGGL((preprocess_kernel<SH, COV, S16>), grd, blk, 0, stream, (int)P, D, M, num_views, \
+  if (S16 && num_views == 1)                                                                       \
+    hipLaunchKernelGGL((preprocess_kernel<SH, COV, S16, S16>), grd, blk, 0, stream, (int)P, D, M, num_views, \
+                       g.views, means3D, shs, colors_precomp, opacities, scales, rotations,        \
+                       cov3D_precomp, W, H, radii, g.rec, g.dfield, g.rect_raw, g.totals + 2 * num_views); \
+  else                                                                                             \
+  hipLaunchKernelGGL((preprocess_kernel<SH, COV, S16, false>), grd, blk, 0, stream, (int)P, D, M, num_views, \
                      g.views, means3D, shs, colors_precomp, opacities, scales, rotations,          \
-                     cov3D_precomp, W, H, radii, g.rec, g.dfield, g.rect_raw, g.totals + num_views)
+                     cov3D_precomp, W, H, radii, g.rec, g.dfield, g.rect_raw, g.totals + 2 * num_views)
   auto run_preprocess = [&]() {
     KernelTimer timer("raster_preprocess", stream);
     if (shs && cov3D_precomp) { if (sh16) GR_PRE(true, true, true); else GR_PRE(true, true, false); }
@@ -1285,7 +1307,6 @@ static int preprocess_impl(int64_t P, int M, const float* means3D, const float* 
     else if (cov3D_precomp) GR_PRE(false, true, false);
     else GR_PRE(false, false, false);
   };
-  GR_HIP(hipMemsetAsync(g.totals + num_views, 0, sizeof(int32_t), stream));  // depth-overflow flag
   run_preprocess();
   GR_LAUNCH_CHECK();
   int32_t* tot = static_cast<int32_t*>(pinned_scratch(1, sizeof(int32_t) * (2 * num_views + 2)));  // totals, far flag, chunk maxima
@@ -1315,27 +1336,25 @@ static int preprocess_impl(int64_t P, int M, const float* means3D, const float* 
         hipLaunchKernelGGL(chunk_max_kernel, dim3(1), dim3(1024), 0, stream, num_views * nchunk, g.chunk_total, g.chunk_max);
       GR_LAUNCH_CHECK();
       int rcs = exclusive_scan_i32(g.chunk_total, g.chunk_total + (int64_t)num_views * nchunk, nchunk, num_views, nchunk,
-                                   g.scan_ws, g.totals, stream, nullptr, short_rows ? g.totals + num_views + 1 : nullptr);
+                                   g.scan_ws, g.totals, stream, nullptr, short_rows ? g.totals + num_views : nullptr);
       if (rcs != GR_OK) return rcs;
       hipLaunchKernelGGL(seg_scan_kernel, dim3((unsigned)(num_views * nchunk)), blk, 0, stream, num_views, tiles, nchunk,
                          g.chunk_cnt, g.chunk_total + (int64_t)num_views * nchunk, g.totals, g.seg_off);
       GR_LAUNCH_CHECK();
     }
     const bool short_rows = nchunk <= SCAN_SINGLE_ROW;
-    if (short_rows) {
-      GR_HIP(hipMemcpyAsync(tot, g.totals, sizeof(int32_t) * (2 * num_views + 1), hipMemcpyDeviceToHost, stream));
-    } else {
-      GR_HIP(hipMemcpyAsync(tot, g.totals, sizeof(int32_t) * (num_views + 1), hipMemcpyDeviceToHost, stream));
-      GR_HIP(hipMemcpyAsync(tot + num_views + 1, g.chunk_max, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-    }
+    // tot: [V] totals, [V] per-view chunk maxima (short rows), [1] depth-overflow flag, [1] chunk maximum (long rows)
+    GR_HIP(hipMemcpyAsync(tot, g.totals, sizeof(int32_t) * (2 * num_views + 1), hipMemcpyDeviceToHost, stream));
+    if (!short_rows)
+      GR_HIP(hipMemcpyAsync(tot + 2 * num_views + 1, g.chunk_max, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     if (defer_ev != nullptr) {
       GR_HIP(hipEventRecord(defer_ev, stream));
       return GR_OK;
     }
     GR_HIP(hipStreamSynchronize(stream));
-    h_chunk_max = tot[num_views + 1];
+    h_chunk_max = short_rows ? tot[num_views] : tot[2 * num_views + 1];
     if (short_rows)
-      for (int v = 1; v < num_views; ++v) h_chunk_max = std::max(h_chunk_max, tot[num_views + 1 + v]);
+      for (int v = 1; v < num_views; ++v) h_chunk_max = std::max(h_chunk_max, tot[num_views + v]);
     return GR_OK;
   };
   rc = sort_and_count(KEY_DEPTH_BITS);
@@ -1356,7 +1375,7 @@ static int preprocess_impl(int64_t P, int M, const float* means3D, const float* 
     GR_REQUIRE(h_bad == 0, "depth sort produced an unsorted order (internal error)");
     return GR_OK;
   };
-  if (tot[num_views] != 0) {  // some depth >= 8192: redo the ordering with full-width keys
+  if (tot[2 * num_views] != 0) {  // some depth >= 8192: redo the ordering with full-width keys
     hipLaunchKernelGGL(full_keys_kernel, dim3((unsigned)((P * num_views + 255) / 256)), blk, 0, stream, P * num_views,
                        g.rec, radii, g.dfield);
     GR_LAUNCH_CHECK();
@@ -1365,7 +1384,7 @@ static int preprocess_impl(int64_t P, int M, const float* means3D, const float* 
   }
   rc = check_depth_order();
   if (rc == 1) {
-    rc = sort_and_count(tot[num_views] != 0 ? 32 : KEY_DEPTH_BITS);
+    rc = sort_and_count(tot[2 * num_views] != 0 ? 32 : KEY_DEPTH_BITS);
     if (rc != GR_OK) return rc;
     rc = check_depth_order();
     if (rc == 1) rc = GR_OK;
@@ -1401,12 +1420,12 @@ static int preprocess_collect(int64_t P, int num_views, int64_t* h_num_rendered,
   GR_REQUIRE(tot != nullptr, "pinned read-back buffer missing");
   const int nchunk = (int)((P + BIN_CHUNK - 1) / BIN_CHUNK);
   const bool short_rows = nchunk <= SCAN_SINGLE_ROW;
-  int32_t cm = tot[num_views + 1];
+  int32_t cm = short_rows ? tot[num_views] : tot[2 * num_views + 1];
   if (short_rows)
-    for (int v = 1; v < num_views; ++v) cm = std::max(cm, tot[num_views + 1 + v]);
+    for (int v = 1; v < num_views; ++v) cm = std::max(cm, tot[num_views + v]);
   for (int v = 0; v < num_views; ++v) h_num_rendered[v] = tot[v];
   h_num_rendered[num_views] = cm;
-  *far_depth = tot[num_views] != 0;
+  *far_depth = tot[2 * num_views] != 0;
   return GR_OK;
 }
 
