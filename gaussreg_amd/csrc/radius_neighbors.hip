@@ -1137,34 +1137,47 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
   __syncthreads();
   const bool staged = band_base[NBAND] <= L::STAGE_CAP;
   if (staged) {
-    // one flat pass over the union of the nine bands.  The loads are UNCONDITIONAL (index clamped into the support array):
-    // behind `if (f < total)` the compiler keeps every load behind the previous one's use -- four memory round trips
-    const int total = band_base[NBAND];
-    int bl[NBAND], bs[NBAND];
+    // wave w copies bands w, w + NWV, ...; lanes run over the band's elements.  (A flat pass over the union of the bands had
+    // every element find its band with eight compare / select pairs: ~130 instructions per thread for four elements.)  All
+    // loads of a wave are issued before its first LDS write, on clamped indices (no load sits behind a branch).
+    constexpr int NWV = L::THREADS / WAVE, KMAX = (NBAND + NWV - 1) / NWV, UNR = 2;
+    const int wvi = tid / WAVE;
+    float4 v[KMAX][UNR];
+    int blo[KMAX], blen[KMAX], bdst[KMAX];
 #pragma unroll
-    for (int k = 0; k < NBAND; ++k) {
-      bl[k] = band_lo[k];
-      bs[k] = band_base[k];
+    for (int kk = 0; kk < KMAX; ++kk) {
+      const int k = wvi + kk * NWV;
+      blo[kk] = 0;
+      blen[kk] = 0;
+      bdst[kk] = 0;
+      if (k < NBAND) {
+        const int l0 = band_lo[k], h0 = band_hi[k];
+        blen[kk] = h0 > l0 ? h0 - l0 : 0;
+        blo[kk] = blen[kk] > 0 ? l0 : 0;
+        bdst[kk] = band_base[k];
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+        v[kk][u] = sorted_s[min(blo[kk] + u * WAVE + lane, ns_total - 1)];
     }
-    constexpr int PER = L::STAGE_CAP / L::THREADS;
-    float4 v[PER];
 #pragma unroll
-    for (int u = 0; u < PER; ++u) {
-      const int f = tid + u * L::THREADS;
-      unsigned src = (unsigned)bl[0] + (unsigned)f;
+    for (int kk = 0; kk < KMAX; ++kk) {
 #pragma unroll
-      for (int k = 1; k < NBAND; ++k) src = f >= bs[k] ? (unsigned)bl[k] + (unsigned)(f - bs[k]) : src;
-      src = f < total ? src : 0u;
-      v[u] = sorted_s[min(src, (unsigned)(ns_total - 1))];
-    }
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-      const int f = tid + u * L::THREADS;
-      if (f < total) {
-        sx[f] = v[u].x;
-        sy[f] = v[u].y;
-        sz[f] = v[u].z;
-        si[f] = __float_as_int(v[u].w);
+      for (int u = 0; u < UNR; ++u) {
+        const int f = u * WAVE + lane;
+        if (f < blen[kk]) {
+          sx[bdst[kk] + f] = v[kk][u].x;
+          sy[bdst[kk] + f] = v[kk][u].y;
+          sz[bdst[kk] + f] = v[kk][u].z;
+          si[bdst[kk] + f] = __float_as_int(v[kk][u].w);
+        }
+      }
+      for (int f = UNR * WAVE + lane; f < blen[kk]; f += WAVE) {  // a band longer than 128 elements
+        const float4 t4 = sorted_s[blo[kk] + f];
+        sx[bdst[kk] + f] = t4.x;
+        sy[bdst[kk] + f] = t4.y;
+        sz[bdst[kk] + f] = t4.z;
+        si[bdst[kk] + f] = __float_as_int(t4.w);
       }
     }
     __syncthreads();
