@@ -605,18 +605,54 @@ __global__ __launch_bounds__(1024) void chunk_max_kernel(int n, const int32_t* _
 }
 
 // per chunk: seg_off[tile] = view base + chunk base + exclusive scan of the chunk's tile counts; [tiles] = end
+// SELF (a few views per call): no scan launch ran before this kernel -- every workgroup sums the raw chunk totals in front
+// of its own (at most a few thousand values), and the first chunk of every view leaves the view's total and its largest
+// chunk total for the host.  One launch less in a frame that is a chain of launches.
+template <bool SELF>
 __global__ __launch_bounds__(256) void seg_scan_kernel(int V, int tiles, int nchunk, const uint16_t* __restrict__ chunk_cnt,
-                                                       const int32_t* __restrict__ chunk_base /* per view */,
-                                                       const int32_t* __restrict__ totals, uint32_t* __restrict__ seg_off) {
+                                                       const int32_t* __restrict__ chunk_base /* per view; SELF: raw totals */,
+                                                       int32_t* __restrict__ totals, uint32_t* __restrict__ seg_off) {
   __shared__ int s_w[256 / WAVE];
   __shared__ int s_carry;
   const int v = blockIdx.x / nchunk, c = blockIdx.x % nchunk;
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   int vb = 0;
-  for (int u = 0; u < v; ++u) vb += totals[u];
+  if (SELF) {
+    const int me = (int)blockIdx.x;  // = v * nchunk + c: everything in front belongs to earlier views / chunks
+    int part = 0;
+    for (int i = threadIdx.x; i < me; i += 256) part += chunk_base[i];
+    part = wave_sum_i32_dpp(part);
+    if (lane == 0) s_w[wv] = part;
+    __syncthreads();
+    vb = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+    if (c == 0) {  // block-uniform
+      int sum = 0, mx = 0;
+      for (int i = threadIdx.x; i < nchunk; i += 256) {
+        const int t = chunk_base[v * nchunk + i];
+        sum += t;
+        mx = max(mx, t);
+      }
+      sum = wave_sum_i32_dpp(sum);
+      mx = wave_max_i32_dpp(mx);
+      if (lane == 0) {
+        s_w[wv] = sum;
+      }
+      __shared__ int s_m[256 / WAVE];
+      if (lane == 0) s_m[wv] = mx;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        totals[v] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        totals[V + v] = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+      }
+      __syncthreads();
+    }
+  } else {
+    for (int u = 0; u < v; ++u) vb += totals[u];
+  }
   const uint16_t* src = chunk_cnt + ((int64_t)v * nchunk + c) * tiles;
   uint32_t* dst = seg_off + ((int64_t)v * nchunk + c) * (tiles + 1);
-  if (threadIdx.x == 0) s_carry = vb + chunk_base[v * nchunk + c];
+  if (threadIdx.x == 0) s_carry = SELF ? vb : vb + chunk_base[v * nchunk + c];
   __syncthreads();
   for (int T0 = 0; T0 < tiles; T0 += 256) {
     const int T = T0 + threadIdx.x;
@@ -1332,15 +1368,22 @@ static int preprocess_impl(int64_t P, int M, const float* means3D, const float* 
       // chunk bases inside each view (+ the per-view totals R_v and the largest chunk total, which sizes the scatter's
       // staging block), then every chunk's per-tile segment starts
       const bool short_rows = nchunk <= SCAN_SINGLE_ROW;  // one launch does scan, totals and maxima
-      if (!short_rows)
-        hipLaunchKernelGGL(chunk_max_kernel, dim3(1), dim3(1024), 0, stream, num_views * nchunk, g.chunk_total, g.chunk_max);
-      GR_LAUNCH_CHECK();
-      int rcs = exclusive_scan_i32(g.chunk_total, g.chunk_total + (int64_t)num_views * nchunk, nchunk, num_views, nchunk,
-                                   g.scan_ws, g.totals, stream, nullptr, short_rows ? g.totals + num_views : nullptr);
-      if (rcs != GR_OK) return rcs;
-      hipLaunchKernelGGL(seg_scan_kernel, dim3((unsigned)(num_views * nchunk)), blk, 0, stream, num_views, tiles, nchunk,
-                         g.chunk_cnt, g.chunk_total + (int64_t)num_views * nchunk, g.totals, g.seg_off);
-      GR_LAUNCH_CHECK();
+      const bool self_scan = short_rows && num_views <= 4;  // ... or none at all: seg_scan_kernel<true> sums what it needs
+      if (self_scan) {
+        hipLaunchKernelGGL(seg_scan_kernel<true>, dim3((unsigned)(num_views * nchunk)), blk, 0, stream, num_views, tiles, nchunk,
+                           g.chunk_cnt, g.chunk_total, g.totals, g.seg_off);
+        GR_LAUNCH_CHECK();
+      } else {
+        if (!short_rows)
+          hipLaunchKernelGGL(chunk_max_kernel, dim3(1), dim3(1024), 0, stream, num_views * nchunk, g.chunk_total, g.chunk_max);
+        GR_LAUNCH_CHECK();
+        int rcs = exclusive_scan_i32(g.chunk_total, g.chunk_total + (int64_t)num_views * nchunk, nchunk, num_views, nchunk,
+                                     g.scan_ws, g.totals, stream, nullptr, short_rows ? g.totals + num_views : nullptr);
+        if (rcs != GR_OK) return rcs;
+        hipLaunchKernelGGL(seg_scan_kernel<false>, dim3((unsigned)(num_views * nchunk)), blk, 0, stream, num_views, tiles, nchunk,
+                           g.chunk_cnt, g.chunk_total + (int64_t)num_views * nchunk, g.totals, g.seg_off);
+        GR_LAUNCH_CHECK();
+      }
     }
     const bool short_rows = nchunk <= SCAN_SINGLE_ROW;
     // tot: [V] totals, [V] per-view chunk maxima (short rows), [1] depth-overflow flag, [1] chunk maximum (long rows)
