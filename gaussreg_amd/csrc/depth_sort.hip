@@ -103,19 +103,41 @@ __global__ __launch_bounds__(DS_SCAN_NW* WAVE) void ds_scan_kernel(int nchunk, c
   const int per = (nchunk + DS_SCAN_NW - 1) / DS_SCAN_NW;
   const int c0 = wv * per, c1 = min(nchunk, c0 + per);
   const uint16_t* col = hist + (int64_t)v * nchunk * DS_BINS + d;
-  unsigned int sum = 0;
-#pragma unroll 8
-  for (int c = c0; c < c1; ++c) sum += col[(int64_t)c * DS_BINS];  // (unrolled: eight independent loads in flight)
-  s_part[wv][lane] = sum;
-  __syncthreads();
-  unsigned int run = 0;
-  for (int w = 0; w < wv; ++w) run += s_part[w][lane];
   uint32_t* ocol = offs + (int64_t)v * nchunk * DS_BINS + d;
+  constexpr int KEEP = 32;  // a wave's share of the chunks, kept in registers between the two sweeps when it fits
+  unsigned int sum = 0;
+  unsigned int run = 0;
+  if (per <= KEEP) {
+    // one trip to memory: all loads up front (clamped, unconditional), the prefix comes out of registers
+    unsigned int val[KEEP];
+#pragma unroll
+    for (int i = 0; i < KEEP; ++i) {
+      const int c = min(c0 + i, nchunk - 1);
+      val[i] = col[(int64_t)c * DS_BINS];
+    }
+#pragma unroll
+    for (int i = 0; i < KEEP; ++i) sum += c0 + i < c1 ? val[i] : 0u;
+    s_part[wv][lane] = sum;
+    __syncthreads();
+    for (int w = 0; w < wv; ++w) run += s_part[w][lane];
+#pragma unroll
+    for (int i = 0; i < KEEP; ++i)
+      if (c0 + i < c1) {
+        ocol[(int64_t)(c0 + i) * DS_BINS] = run;
+        run += val[i];
+      }
+  } else {
 #pragma unroll 8
-  for (int c = c0; c < c1; ++c) {
-    const unsigned int n = col[(int64_t)c * DS_BINS];
-    ocol[(int64_t)c * DS_BINS] = run;
-    run += n;
+    for (int c = c0; c < c1; ++c) sum += col[(int64_t)c * DS_BINS];  // (unrolled: eight independent loads in flight)
+    s_part[wv][lane] = sum;
+    __syncthreads();
+    for (int w = 0; w < wv; ++w) run += s_part[w][lane];
+#pragma unroll 8
+    for (int c = c0; c < c1; ++c) {
+      const unsigned int n = col[(int64_t)c * DS_BINS];
+      ocol[(int64_t)c * DS_BINS] = run;
+      run += n;
+    }
   }
   if (wv == DS_SCAN_NW - 1) digit_total[v * DS_BINS + d] = (int32_t)run;
 }
