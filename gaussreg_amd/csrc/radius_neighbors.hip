@@ -10,17 +10,18 @@
 // compiled with -ffp-contract=off so (1) stays three multiplies and two adds.
 //
 // Pipeline (all on `stream`):
-//   bbox        per-cloud bounding box of the supports (block reductions, six atomics per block)
-//   grid_setup  per-cloud cell edge (>= radius, coarsened so cells <= max(4096, 4 n_b)), dims, bases
-//   bin_count   cell id per support / per query; the histogram atomic returns the point's slot inside its cell
-//   scan        exclusive scan of the histograms, stopped at the real cell count (common.hip)
-//   scatter     counting-sort supports and queries into cell order as float4 {x,y,z,orig index} (no atomics)
+//   bbox        per-cloud bounding box of the supports: per-block partial boxes, folded by grid_setup (no atomics)
+//   grid_setup  per-cloud cell edge (>= radius, coarsened so cells <= max(4096, 4 n_b)), dims, cell and super-cell bases
+//   binning     counting sort in two levels: points -> super-cells of 512 consecutive cells (block-local LDS histograms, one
+//               global atomic per block and non-empty super-cell), then one workgroup per super-cell sorts its points by
+//               cell in LDS and writes the cell table and the cell-ordered float4 {x,y,z,orig index} array
 //   count       thread per (cell-ordered query, z-slab): candidates staged in LDS as coordinate planes, tested two at
 //               a time with packed fp32 math; per thread a hit count, the nine candidate ranges and a hit bit mask;
 //               max over queries -> host (the row width the reference returns)
 //   fill        gathers only the hits named by the masks into per-query LDS segments, ranks every hit inside its
 //               segment by counting (one thread per hit) and stores it at out[query][rank]; pads the rows
-// gr_radius_count_cached lets consecutive searches over the same supports and radius skip bbox .. scatter for the
+//   fused       (gr_radius_search mode 1) count + fill in ONE kernel for a width known before the launch
+// gr_radius_count_cached lets consecutive searches over the same supports and radius skip bbox .. binning for the
 // support side (the data pyramid searches every level's supports three times).
 #include <algorithm>
 #include <atomic>
