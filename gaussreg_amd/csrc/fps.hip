@@ -190,27 +190,27 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ pt
 }
 
 
-// ---------------------------------------------------------------- several samples per exchange round
-// FPS is a chain of global arg-max steps, and one step costs a whole inter-workgroup exchange (~3 us).  But after a
-// round's global top-M candidates c_1 > c_2 > ... are known (keys (d, index) are unique, so the order is strict),
-// c_i is EXACTLY the next sample as long as
-//   (a) every c_j, j < i, was accepted,   (b) key(c_i) > B, the largest key NOT among the candidates, and
-//   (c) |c_i - c_j|^2 >= d(c_i) for all j < i (accepting c_j leaves d(c_i) unchanged),
-// because accepting samples only lowers other points' distances.  So every round accepts the longest such prefix
-// (always >= 1: c_1 is the arg-max) -- at 30 000 of 200 000 points about 7 of 8 candidates, i.e. 7x fewer rounds.
-// Threads contribute their best point; their second best is folded into B, which keeps the rule exact.
+// ---------------------------------------------------------------- many samples per exchange round
+// FPS is a chain of global arg-max steps, and one step costs a whole inter-workgroup exchange (~3 us).  But a round can run
+// the chain on a small CANDIDATE SET exactly: let E be the published keys (per-thread bests that survived the wave / workgroup
+// selections) above B, where B bounds every key that is not in E (threads' runner-ups, what waves and workgroups held back).
+// Points outside E only ever lose distance, so as long as the largest CURRENT key inside E beats B it is the global arg-max:
+//   repeat { c = arg max of the current keys in E; stop if key(c) <= B; accept c; d(e) = min(d(e), |e - c|^2) for e in E }
+// is the sequential algorithm, restricted to E.  Nearly all of E is isolated (no other candidate within sqrt(d) of it, in
+// either direction): those keep their key, are accepted outright and only have to be RANKED by key for the output order
+// (accepted keys are strictly decreasing along the exact sequence).  The sequential loop runs over the few candidates that
+// are in some conflict.  At 30 000 of 200 000 points a round accepts ~90 samples (tools/fps_round_model.py: 338 rounds;
+// the round-2 rule -- sorted top-32, longest conflict-free prefix -- needed 1 299).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int FPS_M = 8;                       // candidates per round (M * M <= 64: pair checks by one wave)
-constexpr int FPS_MG = 32;                     // candidates of the global acceptance chain (a workgroup passes up M = 8).  With 16
-                                               // four rounds in five accepted all 16: the chain length was the limit, not conflicts
-constexpr int FPS_MW = 4;                      // candidates a single wave passes up (the global top 8 almost never
-                                               // holds more than a few points of one wave; the rest raises the bound B)
+constexpr int FPS_M = 8;                       // keys a workgroup publishes per round (sorted, largest first)
+constexpr int FPS_MW = 4;                      // candidates a single wave passes up (the rest raises the bound B)
+constexpr int FPS_EC = 256;                    // capacity of the candidate set E (B is raised to the largest 5th key if needed)
 constexpr int FPS_SLOT_W = FPS_M + 1;          // words per workgroup slot: M keys + bound, each with a 1-bit tag in bit 63
 constexpr int FPS_SLOT_STRIDE = 16;            // words between slots: one 128-byte line per workgroup, so a poll is one line
                                                // (keys use 63 bits: d >= 0 has a clear sign bit)
 
 // Wave-wide maximum through the DPP lanes-shift network (row_shr 1/2/4/8, row_bcast 15/31): six dependent VALU ops
-// instead of six ds_bpermute round trips (~0.4 us each way for a 64-bit butterfly) -- the rounds below call it 27 times.
+// instead of six ds_bpermute round trips (~0.4 us each way for a 64-bit butterfly).
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
   v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));  // row_shr:1
   v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));  // row_shr:2
@@ -233,6 +233,82 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   return ((unsigned long long)mh << 32) | ml;
 }
 
+// The sequential part of a round, by ONE wave, over the nq candidates that are in some conflict (s_q lists their positions in
+// E).  Every step accepts the largest current key while it beats `bound` and lowers the others; what is left at the end is
+// rejected (s_fkey = 0: the points stay in the cloud with the distances the next fold gives them).  Returns the number of
+// rejected candidates.  This form keeps one candidate per lane in registers (nq <= 64, nearly every round).
+__device__ __forceinline__ int fps_resolve_conflicts(int nq, unsigned long long bound, const int* __restrict__ s_q,
+                                                     const float4* __restrict__ s_cand,
+                                                     const unsigned long long* __restrict__ s_ekey,
+                                                     unsigned long long* __restrict__ s_fkey, int lane) {
+  bool live = lane < nq;
+  const int qi = s_q[live ? lane : 0];
+  const float4 c = s_cand[qi];
+  float cur = c.w;
+  const unsigned lo = (unsigned)s_ekey[qi];
+  for (int step = 0; step < nq; ++step) {
+    const unsigned long long mine = live ? ((unsigned long long)__float_as_uint(cur) << 32) | lo : 0ull;
+    const unsigned long long w = wave_max_u64(mine);
+    if (w <= bound) break;  // also when nothing is live (w = 0)
+    const bool own = mine == w;  // keys are unique: one lane
+    if (own) {
+      live = false;
+      s_fkey[qi] = w;  // retired with its final key
+    }
+    const int ol = (int)__builtin_ctzll(__ballot(own));
+    const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.x), ol));
+    const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.y), ol));
+    const float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.z), ol));
+    const float dx = c.x - wx, dy = c.y - wy, dz = c.z - wz;
+    cur = fminf(cur, (dx * dx + dy * dy) + dz * dz);  // the fold's own expression: the same bits
+  }
+  if (live) s_fkey[qi] = 0ull;
+  return (int)__builtin_popcountll(__ballot(live));
+}
+
+// The same for any nq (up to the capacity of E): current distances live in s_cur, a retired entry has s_cur < 0.
+__device__ __forceinline__ int fps_resolve_conflicts_lds(int nq, unsigned long long bound, const int* __restrict__ s_q,
+                                                         const float4* __restrict__ s_cand,
+                                                         const unsigned long long* __restrict__ s_ekey,
+                                                         unsigned long long* __restrict__ s_fkey, float* __restrict__ s_cur,
+                                                         int lane) {
+  for (int t = lane; t < nq; t += WAVE) s_cur[t] = s_cand[s_q[t]].w;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int np = (nq + WAVE - 1) / WAVE * WAVE;
+  int accepted = 0;
+  for (int step = 0; step < nq; ++step) {
+    unsigned long long mine = 0ull;
+    int mt = 0;
+    for (int t = lane; t < nq; t += WAVE) {
+      const float cu = s_cur[t];
+      const unsigned long long kk = cu >= 0.f ? ((unsigned long long)__float_as_uint(cu) << 32) | (unsigned)s_ekey[s_q[t]] : 0ull;
+      if (kk > mine) mine = kk, mt = t;
+    }
+    const unsigned long long w = wave_max_u64(mine);
+    if (w <= bound) break;
+    const bool own = mine == w;
+    const int wt = __builtin_amdgcn_readlane(mt, (int)__builtin_ctzll(__ballot(own)));
+    const int wq = s_q[wt];
+    const float4 wc = s_cand[wq];
+    if (lane == 0) s_fkey[wq] = w;
+    ++accepted;
+    for (int t = lane; t < np; t += WAVE) {
+      if (t < nq) {
+        const float4 c = s_cand[s_q[t]];
+        const float dx = c.x - wc.x, dy = c.y - wc.y, dz = c.z - wc.z;
+        const float cu = s_cur[t];
+        s_cur[t] = t == wt ? -1.0f : (cu >= 0.f ? fminf(cu, (dx * dx + dy * dy) + dz * dz) : cu);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int t = lane; t < nq; t += WAVE)
+    if (s_cur[t] >= 0.f) s_fkey[s_q[t]] = 0ull;
+  return nq - accepted;
+}
+
 // PPT = points per thread held in registers; instantiated for 4 / 7 / 10 / 13 / 16 / 20 so that a slab pays for the
 // points it has (a 12.2-point slab in the 20-point variant folded 64 % more distances than it owned).  Smaller
 // workgroups (256 threads, four per CU, to overlap one workgroup's exchange with the others' folding) measured SLOWER:
@@ -252,14 +328,17 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
                                                           const int32_t* __restrict__ start_idx,
                                                           unsigned long long* __restrict__ slots_all,
                                                           int* __restrict__ err, int G, int64_t* __restrict__ out) {
-  constexpr int M = FPS_M, MG = FPS_MG, MW = FPS_MW, NW = FPS_T / WAVE;
+  constexpr int M = FPS_M, MW = FPS_MW, NW = FPS_T / WAVE, EC = FPS_EC;
   extern __shared__ int s_perm[];  // [PPT][FPS_T] original (cloud-local) index of every point this workgroup holds
   __shared__ unsigned long long s_wtop[NW * MW];
   __shared__ unsigned long long s_wbound[NW];
-  __shared__ float s_acc[MG][4];
-  __shared__ __attribute__((aligned(16))) float s_cand[MG][4];
-  __shared__ int s_ok[MG];
-  __shared__ int s_na, s_abort;
+  __shared__ __attribute__((aligned(16))) float4 s_acc[EC];   // the samples accepted in the last round
+  __shared__ __attribute__((aligned(16))) float4 s_cand[EC];  // E: {x, y, z, d}
+  __shared__ unsigned long long s_ekey[EC], s_fkey[EC];       // key on entry / when accepted (0: rejected)
+  __shared__ int s_rank[EC], s_flag[EC], s_q[EC];
+  __shared__ float s_cur[EC];
+  __shared__ int s_na, s_abort, s_c, s_nq;
+  __shared__ unsigned long long s_bound;
   const int b = blockIdx.x / G, part = blockIdx.x % G;
   const int p0 = off[b], n = off[b + 1] - p0;
   const int o0 = samp_off[b], k = samp_off[b + 1] - o0;
@@ -297,9 +376,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
   float wave_maxd = INFINITY;  // largest running distance among this wave's points (wave-uniform)
   const int start = start_idx ? min(max(start_idx[b], 0), n - 1) : 0;
   if (threadIdx.x == 0) {
-    s_acc[0][0] = P[3 * start];
-    s_acc[0][1] = P[3 * start + 1];
-    s_acc[0][2] = P[3 * start + 2];
+    s_acc[0] = make_float4(P[3 * start], P[3 * start + 1], P[3 * start + 2], 0.f);
     s_na = 1;
     s_abort = 0;
     if (part == 0) out[o0] = start;
@@ -312,36 +389,39 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
   for (unsigned round = 2; count < k; ++round) {
     // ---- 1. fold the samples accepted last round into the running distances; per-thread best and runner-up
     const int na = s_na;
-    // lanes = samples: distance from each new sample to the wave's box, rounded down by more than the fold's own
-    // rounding (8 ulp-steps); at or beyond wave_maxd no running distance of this wave can drop.  The first round folds
-    // everything (a wave without points has an empty box: inf >= inf would skip it and leave its slots unwritten).
-    unsigned long long todo;
-    {
-      const int al = min(lane, MG - 1);
-      const float ax = s_acc[al][0], ay = s_acc[al][1], az = s_acc[al][2];
-      const float ex = fmaxf(fmaxf(bx0 - ax, ax - bx1), 0.f), ey = fmaxf(fmaxf(by0 - ay, ay - by1), 0.f),
-                  ez = fmaxf(fmaxf(bz0 - az, az - bz1), 0.f);
-      const float lb = ((ex * ex + ey * ey) + ez * ez) * (1.0f - 9.5367431640625e-7f);
-      todo = __ballot(lane < na && (round == 2 || !(lb >= wave_maxd)));
-    }
-    const bool touched = round == 2 || todo != 0ull;
-    while (todo) {
-      const int a = (int)__builtin_ctzll(todo);
-      todo &= todo - 1ull;
-      // sample-major: one LDS read of the sample, then all of this thread's points two at a time (packed fp32 -- the
-      // same sub / mul / add sequence as the scalar form, so distances stay bit-identical)
-      const float ax = s_acc[a][0], ay = s_acc[a][1], az = s_acc[a][2];
-      const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
-#pragma unroll
-      for (int j = 0; j + 1 < PPT; j += 2) {
-        const f32x2 dx = f32x2{px[j], px[j + 1]} - ax2, dy = f32x2{py[j], py[j + 1]} - ay2, dz = f32x2{pz[j], pz[j + 1]} - az2;
-        const f32x2 dd = (dx * dx + dy * dy) + dz * dz;
-        pd[j] = fminf(pd[j], dd.x);
-        pd[j + 1] = fminf(pd[j + 1], dd.y);
+    if (threadIdx.x < EC) s_rank[threadIdx.x] = 0, s_flag[threadIdx.x] = 0;  // for stage 4 (read after two barriers)
+    bool touched = round == 2;
+    for (int base = 0; base < na; base += WAVE) {
+      // lanes = samples: distance from each new sample to the wave's box, rounded down by more than the fold's own
+      // rounding (8 ulp-steps); at or beyond wave_maxd no running distance of this wave can drop.  The first round folds
+      // everything (a wave without points has an empty box: inf >= inf would skip it and leave its slots unwritten).
+      unsigned long long todo;
+      {
+        const float4 a4 = s_acc[min(base + lane, EC - 1)];
+        const float ex = fmaxf(fmaxf(bx0 - a4.x, a4.x - bx1), 0.f), ey = fmaxf(fmaxf(by0 - a4.y, a4.y - by1), 0.f),
+                    ez = fmaxf(fmaxf(bz0 - a4.z, a4.z - bz1), 0.f);
+        const float lb = ((ex * ex + ey * ey) + ez * ez) * (1.0f - 9.5367431640625e-7f);
+        todo = __ballot(base + lane < na && (round == 2 || !(lb >= wave_maxd)));
       }
-      if (PPT & 1) {
-        const float dx = px[PPT - 1] - ax, dy = py[PPT - 1] - ay, dz = pz[PPT - 1] - az;
-        pd[PPT - 1] = fminf(pd[PPT - 1], (dx * dx + dy * dy) + dz * dz);
+      touched = touched || todo != 0ull;
+      while (todo) {
+        const int a = base + (int)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        // sample-major: one LDS read of the sample, then all of this thread's points two at a time (packed fp32 -- the
+        // same sub / mul / add sequence as the scalar form, so distances stay bit-identical)
+        const float4 a4 = s_acc[a];
+        const f32x2 ax2 = {a4.x, a4.x}, ay2 = {a4.y, a4.y}, az2 = {a4.z, a4.z};
+#pragma unroll
+        for (int j = 0; j + 1 < PPT; j += 2) {
+          const f32x2 dx = f32x2{px[j], px[j + 1]} - ax2, dy = f32x2{py[j], py[j + 1]} - ay2, dz = f32x2{pz[j], pz[j + 1]} - az2;
+          const f32x2 dd = (dx * dx + dy * dy) + dz * dz;
+          pd[j] = fminf(pd[j], dd.x);
+          pd[j + 1] = fminf(pd[j + 1], dd.y);
+        }
+        if (PPT & 1) {
+          const float dx = px[PPT - 1] - a4.x, dy = py[PPT - 1] - a4.y, dz = pz[PPT - 1] - a4.z;
+          pd[PPT - 1] = fminf(pd[PPT - 1], (dx * dx + dy * dy) + dz * dz);
+        }
       }
     }
     if (touched) {  // wave-uniform; otherwise s_wtop / s_wbound still hold this wave's candidates of the last round
@@ -358,7 +438,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
           }
         }
       }
-      // ---- 2. top-M of the wave's bests (unique keys: exactly one lane owns each maximum); the rest bounds B
+      // ---- 2. top-MW of the wave's bests (unique keys: exactly one lane owns each maximum); the rest bounds B
       unsigned long long mine = best;
 #pragma unroll
       for (int r = 0; r < MW; ++r) {
@@ -373,25 +453,25 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
       }
     }
     __syncthreads();
-    // ---- 3. wave 0: workgroup top-M, exchange, global top-M, acceptance
+    // ---- 3. wave 0: workgroup top-M, exchange, the candidate set E
     if (wv == 0) {
       static_assert(NW * MW == WAVE, "one wave-level candidate per lane");
-      unsigned long long v0 = s_wtop[lane], v1 = 0ull;
+      static_assert(EC == 4 * WAVE && M > EC / WAVE, "E holds at most EC / 64 keys of one workgroup once B is raised");
+      unsigned long long v0 = s_wtop[lane];
       unsigned long long bnd = lane < NW ? s_wbound[lane] : 0ull;
       unsigned long long mykey = 0ull;  // lane r < M ends up with the r-th largest key
 #pragma unroll
       for (int r = 0; r < M; ++r) {
-        const unsigned long long w = wave_max_u64(v0 > v1 ? v0 : v1);
+        const unsigned long long w = wave_max_u64(v0);
         if (lane == r) mykey = w;
         if (v0 == w) v0 = 0ull;
-        if (v1 == w) v1 = 0ull;
       }
-      {
-        unsigned long long rest = v0 > v1 ? v0 : v1;
-        rest = rest > bnd ? rest : bnd;
-        bnd = wave_max_u64(rest);
-      }
+      bnd = wave_max_u64(v0 > bnd ? v0 : bnd);
       bool bad = false;
+      unsigned long long kk[M];  // lane g: workgroup g's keys, largest first
+      unsigned long long sb = bnd;
+#pragma unroll
+      for (int r = 0; r < M; ++r) kk[r] = 0ull;
       if (G > 1) {
         unsigned long long* buf = slots + (size_t)(round & 1u) * FPS_GMAX * FPS_SLOT_STRIDE;
         const unsigned long long tag = (unsigned long long)((round >> 1) & 1u) << 63;
@@ -400,10 +480,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
         else if (lane == M)
           __hip_atomic_store(buf + part * FPS_SLOT_STRIDE + M, tag | bnd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // lane g polls workgroup g's slot until all its words carry this round's tag bit
-        unsigned long long kk[M];
-        unsigned long long sb = 0ull;
-#pragma unroll
-        for (int r = 0; r < M; ++r) kk[r] = 0ull;
+        sb = 0ull;
         if (lane < G) {
           const unsigned long long* w = buf + lane * FPS_SLOT_STRIDE;
           int spins = 0;
@@ -427,81 +504,122 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
             }
           }
         }
-        // global top-MG over G x M keys: every lane's M keys arrive sorted (largest first), so this is a 64-way merge
-        // of sorted lists -- the wave maximum of the heads, then the owning lane shifts its list up
+      } else {
+        kk[0] = mykey;  // a single workgroup: one key per lane (lanes >= M hold 0)
+      }
+      // B: nothing outside the published keys exceeds the largest workgroup bound
+      unsigned long long bound = wave_max_u64(sb);
+      int cnt = 0;
 #pragma unroll
-        for (int r = 0; r < MG; ++r) {
-          const unsigned long long w = wave_max_u64(kk[0]);
-          if (lane == r) mykey = w;
-          if (kk[0] == w && w != 0ull) {
+      for (int r = 0; r < M; ++r) cnt += kk[r] > bound ? 1 : 0;  // sorted lists: a prefix
+      int incl = wave_incl_scan_add_dpp(cnt);
+      int total = __builtin_amdgcn_readlane(incl, WAVE - 1);
+      if (total > EC) {  // keep at most EC / 64 keys of a workgroup: the largest dropped key joins the bound
+        const unsigned long long cut = wave_max_u64(kk[EC / WAVE]);
+        bound = cut > bound ? cut : bound;
+        cnt = 0;
 #pragma unroll
-            for (int u = 0; u + 1 < M; ++u) kk[u] = kk[u + 1];
-            kk[M - 1] = 0ull;
-          }
-        }
-        bnd = wave_max_u64(kk[0] > sb ? kk[0] : sb);  // the largest key left anywhere, or a workgroup's own bound
+        for (int r = 0; r < M; ++r) cnt += kk[r] > bound ? 1 : 0;
+        incl = wave_incl_scan_add_dpp(cnt);
+        total = __builtin_amdgcn_readlane(incl, WAVE - 1);
       }
-      // ---- acceptance: lane r < NC owns candidate r (mykey), fetches its coordinates (the cloud is read-only)
-      const int NC = G > 1 ? MG : M;  // a single workgroup only has its own M candidates
-      const int ci = (int)(0xffffffffu - (unsigned)(mykey & 0xffffffffull));
-      const bool live = lane < NC && mykey != 0ull;
-      float cx = 0.f, cy = 0.f, cz = 0.f;
-      if (live) {
-        cx = P[3 * ci];
-        cy = P[3 * ci + 1];
-        cz = P[3 * ci + 2];
-      }
-      const float cd = __uint_as_float((unsigned)(mykey >> 32));
-      if (lane < MG) {
-        s_cand[lane][0] = cx;
-        s_cand[lane][1] = cy;
-        s_cand[lane][2] = cz;
-        s_cand[lane][3] = cd;
-        s_ok[lane] = live && mykey > bnd ? 1 : 0;  // candidate `lane` beats everything uncollected
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      // candidate i = lane / LPC is checked against the earlier candidates j = (lane % LPC) * JPL + u: does accepting
-      // c_j lower d(c_i)?  (a prefix is accepted, so every j < i counts)
-      constexpr int LPC = WAVE / MG, JPL = MG / LPC;  // lanes per candidate, earlier candidates per lane
-      const int pi = lane / LPC;
-      const float4 ci4 = *reinterpret_cast<const float4*>(s_cand[pi]);
-      bool hurts = false;
-#pragma unroll
-      for (int u = 0; u < JPL; ++u) {
-        const int pj = (lane % LPC) * JPL + u;
-        const float4 cj4 = *reinterpret_cast<const float4*>(s_cand[pj]);
-        const float ddx = ci4.x - cj4.x, ddy = ci4.y - cj4.y, ddz = ci4.z - cj4.z;
-        hurts = hurts || (pj < pi && ((ddx * ddx + ddy * ddy) + ddz * ddz) < ci4.w);
-      }
-      // LPC consecutive bits per candidate: set while the candidate is collectable and no earlier one hurts it
-      const unsigned long long good = __ballot(s_ok[pi] != 0 && !hurts);
-      int acc = 0;
       {
-        unsigned long long g = good;
+        const int at = incl - cnt;
 #pragma unroll
-        for (int sft = 1; sft < LPC; sft <<= 1) g &= g >> sft;  // bit LPC * i = all LPC lanes of candidate i agree
-        unsigned long long lead = 0ull;                          // keep only the bits at multiples of LPC
-#pragma unroll
-        for (int i = 0; i < MG; ++i) lead |= 1ull << (LPC * i);
-        const unsigned long long stop = ~g & lead;               // first candidate that fails
-        acc = stop ? (int)__builtin_ctzll(stop) / LPC : MG;
-        acc = min(acc, min(NC, k - count));
+        for (int r = 0; r < M; ++r) {
+          if (r < cnt) s_ekey[at + r] = kk[r];
+        }
       }
       if (__any(bad)) {
         if (lane == 0) s_abort = 1;
-        acc = max(acc, 1);
       }
-      if (lane < acc) {
-        s_acc[lane][0] = cx;
-        s_acc[lane][1] = cy;
-        s_acc[lane][2] = cz;
-        if (part == 0) out[o0 + count + lane] = ci;
-      }
-      if (lane == 0) s_na = acc;
+      if (lane == 0) s_c = total, s_bound = bound;
     }
     __syncthreads();
     if (s_abort) return;
+    if ((int)threadIdx.x < s_c) {  // coordinates by original index (the cloud is read-only: plain cached loads)
+      const unsigned long long ek = s_ekey[threadIdx.x];
+      const int ci = (int)(0xffffffffu - (unsigned)(ek & 0xffffffffull));
+      s_cand[threadIdx.x] = make_float4(P[3 * ci], P[3 * ci + 1], P[3 * ci + 2], __uint_as_float((unsigned)(ek >> 32)));
+      s_fkey[threadIdx.x] = ek;
+    }
+    __syncthreads();
+    // ---- 4. all waves: which candidates are in a conflict (some other candidate within sqrt(d) of either of the two), and
+    // every candidate's rank among the keys on entry.  Thread = (candidate i, share of the partners j).
+    const int C = s_c;
+    const int cpad = (C + WAVE - 1) & ~(WAVE - 1);
+    const int groups = cpad ? FPS_T / cpad : 1;
+    const int ci_ = cpad ? (int)threadIdx.x % cpad : 0, cg = cpad ? (int)threadIdx.x / cpad : 0;
+    if (C > 1 && ci_ < C && cg < groups) {
+      const int share = (C + groups - 1) / groups;
+      const int j0 = cg * share, j1 = min(C, j0 + share);
+      const float4 me = s_cand[ci_];
+      const unsigned long long mk = s_ekey[ci_];
+      bool conflict = false;
+      int above = 0;
+      for (int j = j0; j < j1; ++j) {
+        const float4 o = s_cand[j];
+        const unsigned long long ok = s_ekey[j];
+        const float dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;
+        const float dd = (dx * dx + dy * dy) + dz * dz;
+        conflict = conflict || (j != ci_ && (dd < me.w || dd < o.w));
+        above += ok > mk ? 1 : 0;
+      }
+      if (conflict) s_flag[ci_] = 1;
+      if (above) atomicAdd(&s_rank[ci_], above);
+    }
+    __syncthreads();
+    // ---- 5. wave 0: the exact chain over the candidates in conflict
+    if (wv == 0) {
+      int nq = 0;
+#pragma unroll
+      for (int u = 0; u < EC / WAVE; ++u) {
+        const int t = lane + u * WAVE;
+        const bool f = t < C && s_flag[t] != 0;
+        const unsigned long long m = __ballot(f);
+        if (f) s_q[nq + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = t;
+        nq += (int)__builtin_popcountll(m);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const unsigned long long bound = s_bound;
+      int rejected = 0;
+      if (nq > WAVE) rejected = fps_resolve_conflicts_lds(nq, bound, s_q, s_cand, s_ekey, s_fkey, s_cur, lane);
+      else if (nq > 0) rejected = fps_resolve_conflicts(nq, bound, s_q, s_cand, s_ekey, s_fkey, lane);
+      if (lane == 0) s_nq = nq, s_na = min(C - rejected, k - count);
+    }
+    __syncthreads();
+    // ---- 6. all waves: output positions.  Accepted keys decrease strictly along the exact sequence, so a sample's
+    // position is its rank among the accepted keys.  A candidate without conflict kept its key: its rank on entry minus
+    // the conflict candidates that dropped below it.  A candidate in conflict is ranked from scratch (one wave each).
+    {
+      const int nq = s_nq, room = k - count;
+      if ((int)threadIdx.x < C && s_flag[threadIdx.x] == 0) {
+        const unsigned long long mk = s_ekey[threadIdx.x];
+        int r = s_rank[threadIdx.x];
+        for (int u = 0; u < nq; ++u) {
+          const int q = s_q[u];
+          r -= s_ekey[q] > mk && s_fkey[q] < mk ? 1 : 0;
+        }
+        if (r < room) {
+          s_acc[r] = s_cand[threadIdx.x];
+          if (part == 0) out[o0 + count + r] = (int)(0xffffffffu - (unsigned)(mk & 0xffffffffull));
+        }
+      }
+      for (int u = wv; u < nq; u += NW) {
+        const int q = s_q[u];
+        const unsigned long long fk = s_fkey[q];
+        if (fk == 0ull) continue;  // wave-uniform
+        int r = 0;
+        for (int j = lane; j < cpad; j += WAVE) r += (int)__builtin_popcountll(__ballot(j < C && s_fkey[j] > fk));
+        if (lane == 0 && r < room) {
+          const float4 c = s_cand[q];
+          s_acc[r] = make_float4(c.x, c.y, c.z, 0.f);
+          if (part == 0) out[o0 + count + r] = (int)(0xffffffffu - (unsigned)(fk & 0xffffffffull));
+        }
+      }
+    }
+    __syncthreads();
     count += s_na;
   }
 }
