@@ -329,14 +329,16 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
                                                           unsigned long long* __restrict__ slots_all,
                                                           int* __restrict__ err, int G, int64_t* __restrict__ out) {
   constexpr int M = FPS_M, MW = FPS_MW, NW = FPS_T / WAVE, EC = FPS_EC;
+  constexpr int UN = PPT <= 10 ? 4 : 2;  // partners in flight in stages 4 and 6: the large slabs have no registers to spare
   extern __shared__ int s_perm[];  // [PPT][FPS_T] original (cloud-local) index of every point this workgroup holds
   __shared__ unsigned long long s_wtop[NW * MW];
   __shared__ unsigned long long s_wbound[NW];
   __shared__ __attribute__((aligned(16))) float4 s_acc[EC];   // the samples accepted in the last round
-  __shared__ __attribute__((aligned(16))) float4 s_cand[EC];  // E: {x, y, z, d}
-  __shared__ unsigned long long s_ekey[EC], s_fkey[EC];       // key on entry / when accepted (0: rejected)
+  __shared__ __attribute__((aligned(16))) float4 s_cand[EC + WAVE];  // E: {x, y, z, d}; padded for stage 4
+  __shared__ unsigned long long s_ekey[EC + WAVE], s_fkey[EC];   // key on entry / when accepted (0: rejected)
   __shared__ int s_rank[EC], s_flag[EC], s_q[EC];
   __shared__ float s_cur[EC];
+  __shared__ unsigned long long s_qe[EC], s_qf[EC];     // the conflict candidates' keys on entry / when accepted
   __shared__ int s_na, s_abort, s_c, s_nq;
   __shared__ unsigned long long s_bound;
   const int b = blockIdx.x / G, part = blockIdx.x % G;
@@ -537,35 +539,45 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
     }
     __syncthreads();
     if (s_abort) return;
-    if ((int)threadIdx.x < s_c) {  // coordinates by original index (the cloud is read-only: plain cached loads)
+    // ---- 4. all waves: which candidates are in a conflict (some other candidate within sqrt(d) of either of the two), and
+    // every candidate's rank among the keys on entry.  Thread = (candidate i, share of the partners j); shares are
+    // multiples of four partners, the tail of E is padded with points at infinity (no conflict, key 0).
+    const int C = s_c;
+    const int cshift = C <= 64 ? 6 : C <= 128 ? 7 : 8;  // candidates padded to a power of two, FPS_T >> cshift partner shares
+    const int cpad = 1 << cshift;
+    const int share = (((C + (FPS_T >> cshift) - 1) >> (10 - cshift)) + 3) & ~3;
+    if ((int)threadIdx.x < C) {  // coordinates by original index (the cloud is read-only: plain cached loads)
       const unsigned long long ek = s_ekey[threadIdx.x];
       const int ci = (int)(0xffffffffu - (unsigned)(ek & 0xffffffffull));
       s_cand[threadIdx.x] = make_float4(P[3 * ci], P[3 * ci + 1], P[3 * ci + 2], __uint_as_float((unsigned)(ek >> 32)));
       s_fkey[threadIdx.x] = ek;
+    } else if ((int)threadIdx.x < share * (FPS_T >> cshift)) {  // <= C + 4 * 16
+      s_cand[threadIdx.x] = make_float4(INFINITY, 0.f, 0.f, 0.f);
+      s_ekey[threadIdx.x] = 0ull;
     }
     __syncthreads();
-    // ---- 4. all waves: which candidates are in a conflict (some other candidate within sqrt(d) of either of the two), and
-    // every candidate's rank among the keys on entry.  Thread = (candidate i, share of the partners j).
-    const int C = s_c;
-    const int cpad = (C + WAVE - 1) & ~(WAVE - 1);
-    const int groups = cpad ? FPS_T / cpad : 1;
-    const int ci_ = cpad ? (int)threadIdx.x % cpad : 0, cg = cpad ? (int)threadIdx.x / cpad : 0;
-    if (C > 1 && ci_ < C && cg < groups) {
-      const int share = (C + groups - 1) / groups;
-      const int j0 = cg * share, j1 = min(C, j0 + share);
+    const int ci_ = (int)threadIdx.x & (cpad - 1), cg = (int)threadIdx.x >> cshift;
+    if (C > 1 && ci_ < C) {
+      const int j0 = cg * share, j1 = j0 + share;
       const float4 me = s_cand[ci_];
       const unsigned long long mk = s_ekey[ci_];
-      bool conflict = false;
-      int above = 0;
-      for (int j = j0; j < j1; ++j) {
-        const float4 o = s_cand[j];
-        const unsigned long long ok = s_ekey[j];
-        const float dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;
-        const float dd = (dx * dx + dy * dy) + dz * dz;
-        conflict = conflict || (j != ci_ && (dd < me.w || dd < o.w));
-        above += ok > mk ? 1 : 0;
+      // the candidate meets itself in one share: |e - e|^2 = 0 < d counts unless d = 0
+      int near = ci_ >= j0 && ci_ < j1 && me.w > 0.f ? -1 : 0, above = 0;
+      for (int j = j0; j < j1; j += UN) {  // loads first, no short circuits (a conditional load costs an LDS round trip)
+        float4 o[UN];
+        unsigned long long ok[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) o[u] = s_cand[j + u], ok[u] = s_ekey[j + u];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const float dx = me.x - o[u].x, dy = me.y - o[u].y, dz = me.z - o[u].z;
+          const float dd = (dx * dx + dy * dy) + dz * dz;
+          // distances are >= 0 (or +inf for the padding): their bit patterns order like the values
+          near += (int)(__float_as_uint(dd) < max(__float_as_uint(me.w), __float_as_uint(o[u].w)));
+          above += (int)(ok[u] > mk);
+        }
       }
-      if (conflict) s_flag[ci_] = 1;
+      if (near > 0) s_flag[ci_] = 1;
       if (above) atomicAdd(&s_rank[ci_], above);
     }
     __syncthreads();
@@ -586,6 +598,13 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
       int rejected = 0;
       if (nq > WAVE) rejected = fps_resolve_conflicts_lds(nq, bound, s_q, s_cand, s_ekey, s_fkey, s_cur, lane);
       else if (nq > 0) rejected = fps_resolve_conflicts(nq, bound, s_q, s_cand, s_ekey, s_fkey, lane);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int t = lane; t < ((nq + 3) & ~3); t += WAVE) {  // keys of the conflict candidates, padded with zeros to four
+        const int q = s_q[t < nq ? t : 0];
+        s_qe[t] = t < nq ? s_ekey[q] : 0ull;
+        s_qf[t] = t < nq ? s_fkey[q] : 0ull;
+      }
       if (lane == 0) s_nq = nq, s_na = min(C - rejected, k - count);
     }
     __syncthreads();
@@ -597,9 +616,12 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
       if ((int)threadIdx.x < C && s_flag[threadIdx.x] == 0) {
         const unsigned long long mk = s_ekey[threadIdx.x];
         int r = s_rank[threadIdx.x];
-        for (int u = 0; u < nq; ++u) {
-          const int q = s_q[u];
-          r -= s_ekey[q] > mk && s_fkey[q] < mk ? 1 : 0;
+        for (int u = 0; u < nq; u += UN) {  // (nq is padded to a multiple of four)
+          unsigned long long qe[UN], qf[UN];
+#pragma unroll
+          for (int v = 0; v < UN; ++v) qe[v] = s_qe[u + v], qf[v] = s_qf[u + v];
+#pragma unroll
+          for (int v = 0; v < UN; ++v) r -= (int)(qe[v] > mk) & (int)(qf[v] < mk);
         }
         if (r < room) {
           s_acc[r] = s_cand[threadIdx.x];
