@@ -202,11 +202,12 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ pt
 // are in some conflict.  At 30 000 of 200 000 points a round accepts ~90 samples (tools/fps_round_model.py: 338 rounds;
 // the round-2 rule -- sorted top-32, longest conflict-free prefix -- needed 1 299).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int FPS_M = 8;                       // keys a workgroup publishes per round (sorted, largest first)
+constexpr int FPS_KPL = 8;                     // keys of one slot a polling lane holds (sorted, largest first)
 constexpr int FPS_MW = 4;                      // candidates a single wave passes up (the rest raises the bound B)
 constexpr int FPS_EC = 256;                    // capacity of the candidate set E (B is raised to the largest 5th key if needed)
-constexpr int FPS_SLOT_W = FPS_M + 1;          // words per workgroup slot: M keys + bound, each with a 1-bit tag in bit 63
-constexpr int FPS_SLOT_STRIDE = 16;            // words between slots: one 128-byte line per workgroup, so a poll is one line
+constexpr int FPS_SLOT_STRIDE = 32;            // words between slots.  A workgroup publishes M = 8 keys + its bound (one 128-byte
+                                               // line) or, when few workgroups share a cloud, M = 16 + bound (two lines, polled by
+                                               // two lanes); every word carries a 1-bit tag in bit 63
                                                // (keys use 63 bits: d >= 0 has a clear sign bit)
 
 // Wave-wide maximum through the DPP lanes-shift network (row_shr 1/2/4/8, row_bcast 15/31): six dependent VALU ops
@@ -320,7 +321,7 @@ __device__ __forceinline__ int fps_resolve_conflicts_lds(int nq, unsigned long l
 // that distance cannot lower any of them: the wave skips the fold, and a wave no sample reached this round also keeps
 // the candidates it published last round.  After the first few hundred samples that is almost every wave in almost
 // every round; results are exactly those of the unpruned algorithm (keys carry the ORIGINAL index).
-template <int PPT>
+template <int PPT, int M>
 __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restrict__ pts, const float* __restrict__ spts,
                                                           const int32_t* __restrict__ perm,
                                                           const int32_t* __restrict__ off,
@@ -328,7 +329,8 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
                                                           const int32_t* __restrict__ start_idx,
                                                           unsigned long long* __restrict__ slots_all,
                                                           int* __restrict__ err, int G, int64_t* __restrict__ out) {
-  constexpr int M = FPS_M, MW = FPS_MW, NW = FPS_T / WAVE, EC = FPS_EC;
+  constexpr int KPL = FPS_KPL, LPS = M / KPL, MW = FPS_MW, NW = FPS_T / WAVE, EC = FPS_EC;  // LPS: polling lanes per slot
+  static_assert(M % KPL == 0 && FPS_SLOT_STRIDE > M, "slot layout");
   constexpr int UN = PPT <= 10 ? 4 : 2;  // partners in flight in stages 4 and 6: the large slabs have no registers to spare
   extern __shared__ int s_perm[];  // [PPT][FPS_T] original (cloud-local) index of every point this workgroup holds
   __shared__ unsigned long long s_wtop[NW * MW];
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
     // ---- 3. wave 0: workgroup top-M, exchange, the candidate set E
     if (wv == 0) {
       static_assert(NW * MW == WAVE, "one wave-level candidate per lane");
-      static_assert(EC == 4 * WAVE && M > EC / WAVE, "E holds at most EC / 64 keys of one workgroup once B is raised");
+      static_assert(EC == 4 * WAVE && KPL > EC / WAVE, "E holds at most EC / 64 keys per polling lane once B is raised");
       unsigned long long v0 = s_wtop[lane];
       unsigned long long bnd = lane < NW ? s_wbound[lane] : 0ull;
       unsigned long long mykey = 0ull;  // lane r < M ends up with the r-th largest key
@@ -470,10 +472,10 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
       }
       bnd = wave_max_u64(v0 > bnd ? v0 : bnd);
       bool bad = false;
-      unsigned long long kk[M];  // lane g: workgroup g's keys, largest first
+      unsigned long long kk[KPL];  // lane g * LPS + h: keys [8 h, 8 h + 8) of workgroup g, largest first
       unsigned long long sb = bnd;
 #pragma unroll
-      for (int r = 0; r < M; ++r) kk[r] = 0ull;
+      for (int r = 0; r < KPL; ++r) kk[r] = 0ull;
       if (G > 1) {
         unsigned long long* buf = slots + (size_t)(round & 1u) * FPS_GMAX * FPS_SLOT_STRIDE;
         const unsigned long long tag = (unsigned long long)((round >> 1) & 1u) << 63;
@@ -481,22 +483,24 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
           __hip_atomic_store(buf + part * FPS_SLOT_STRIDE + lane, tag | mykey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else if (lane == M)
           __hip_atomic_store(buf + part * FPS_SLOT_STRIDE + M, tag | bnd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // lane g polls workgroup g's slot until all its words carry this round's tag bit
+        // lane g * LPS + h polls its eight keys of workgroup g's slot (and the bound) until they carry this round's tag bit
         sb = 0ull;
-        if (lane < G) {
-          const unsigned long long* w = buf + lane * FPS_SLOT_STRIDE;
+        if (lane < G * LPS) {
+          const unsigned long long* w = buf + (lane / LPS) * FPS_SLOT_STRIDE;
+          const int h = lane % LPS;
           int spins = 0;
           for (;;) {
-            unsigned long long rd[FPS_SLOT_W];
+            unsigned long long rd[KPL + 1];
 #pragma unroll
-            for (int u = 0; u < FPS_SLOT_W; ++u) rd[u] = __hip_atomic_load(w + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int u = 0; u < KPL; ++u) rd[u] = __hip_atomic_load(w + h * KPL + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            rd[KPL] = __hip_atomic_load(w + M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             bool ok = true;
 #pragma unroll
-            for (int u = 0; u < FPS_SLOT_W; ++u) ok = ok && ((rd[u] ^ tag) >> 63) == 0ull;
+            for (int u = 0; u < KPL + 1; ++u) ok = ok && ((rd[u] ^ tag) >> 63) == 0ull;
             if (ok) {
 #pragma unroll
-              for (int r = 0; r < M; ++r) kk[r] = rd[r] & ~(1ull << 63);
-              sb = rd[M] & ~(1ull << 63);
+              for (int r = 0; r < KPL; ++r) kk[r] = rd[r] & ~(1ull << 63);
+              sb = rd[KPL] & ~(1ull << 63);
               break;
             }
             if (++spins > (1 << 22) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
@@ -513,7 +517,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
       unsigned long long bound = wave_max_u64(sb);
       int cnt = 0;
 #pragma unroll
-      for (int r = 0; r < M; ++r) cnt += kk[r] > bound ? 1 : 0;  // sorted lists: a prefix
+      for (int r = 0; r < KPL; ++r) cnt += kk[r] > bound ? 1 : 0;  // sorted lists: a prefix
       int incl = wave_incl_scan_add_dpp(cnt);
       int total = __builtin_amdgcn_readlane(incl, WAVE - 1);
       if (total > EC) {  // keep at most EC / 64 keys of a workgroup: the largest dropped key joins the bound
@@ -521,14 +525,14 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
         bound = cut > bound ? cut : bound;
         cnt = 0;
 #pragma unroll
-        for (int r = 0; r < M; ++r) cnt += kk[r] > bound ? 1 : 0;
+        for (int r = 0; r < KPL; ++r) cnt += kk[r] > bound ? 1 : 0;
         incl = wave_incl_scan_add_dpp(cnt);
         total = __builtin_amdgcn_readlane(incl, WAVE - 1);
       }
       {
         const int at = incl - cnt;
 #pragma unroll
-        for (int r = 0; r < M; ++r) {
+        for (int r = 0; r < KPL; ++r) {
           if (r < cnt) s_ekey[at + r] = kk[r];
         }
       }
@@ -798,12 +802,15 @@ extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64
       const void* fn;
       void** args = multi_args;
       size_t lds = 0;  // the workgroup's original indices: PPT * 1024 ints
-      if (per <= 4) fn = reinterpret_cast<const void*>(fps_multi_kernel<4>), lds = 4;
-      else if (per <= 7) fn = reinterpret_cast<const void*>(fps_multi_kernel<7>), lds = 7;
-      else if (per <= 10) fn = reinterpret_cast<const void*>(fps_multi_kernel<10>), lds = 10;
-      else if (per <= 13) fn = reinterpret_cast<const void*>(fps_multi_kernel<13>), lds = 13;
-      else if (per <= 16) fn = reinterpret_cast<const void*>(fps_multi_kernel<16>), lds = 16;
-      else if (per <= 20) fn = reinterpret_cast<const void*>(fps_multi_kernel<20>), lds = 20;
+      // sixteen keys per workgroup when few workgroups share a cloud (large slabs): more candidates per round
+      static const bool m16_off = getenv("GR_FPS_M16") && atoi(getenv("GR_FPS_M16")) == 0;
+      const bool m16 = G <= 16 && per > 10 && !m16_off;
+      if (per <= 4) fn = reinterpret_cast<const void*>(fps_multi_kernel<4, 8>), lds = 4;
+      else if (per <= 7) fn = reinterpret_cast<const void*>(fps_multi_kernel<7, 8>), lds = 7;
+      else if (per <= 10) fn = reinterpret_cast<const void*>(fps_multi_kernel<10, 8>), lds = 10;
+      else if (per <= 13) fn = m16 ? reinterpret_cast<const void*>(fps_multi_kernel<13, 16>) : reinterpret_cast<const void*>(fps_multi_kernel<13, 8>), lds = 13;
+      else if (per <= 16) fn = m16 ? reinterpret_cast<const void*>(fps_multi_kernel<16, 16>) : reinterpret_cast<const void*>(fps_multi_kernel<16, 8>), lds = 16;
+      else if (per <= 20) fn = m16 ? reinterpret_cast<const void*>(fps_multi_kernel<20, 16>) : reinterpret_cast<const void*>(fps_multi_kernel<20, 8>), lds = 20;
       lds *= (size_t)FPS_T * sizeof(int);
       if (lds > 48 * 1024) GR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       if (per > 20) {  // slab too large for registers: one sample per round, distances streamed from L2

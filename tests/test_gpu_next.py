@@ -276,6 +276,24 @@ def test_fps_register_and_streaming_slabs(n, batch, k):
         assert np.array_equal(got[b].cpu().numpy(), M.farthest_point_sampling(pts[b * n:(b + 1) * n], k, b % 7))
 
 
+@pytest.mark.parametrize("n,batch,k", [(100000, 2, 6000), (200000, 16, 2500)])
+def test_fps_long_runs_with_large_candidate_sets(n, batch, k):
+    """Thousands of samples, so that rounds carry ~100 candidates, conflicts between candidates (the exact chain inside a
+    round), rank corrections and the raised bound all occur many times; 64 workgroups per cloud with 8 published keys, and
+    16 workgroups per cloud with 16 published keys (two polling lanes per slot)."""
+    from gaussreg_amd.registration import farthest_point_sampling
+    from oracle import matching_np as M
+    from gaussreg_amd import pair_pipeline
+    clouds = []
+    for i in range((batch + 1) // 2):
+        r_, s_, _ = pair_pipeline.synthetic_room_pair(100 + i, n, torch.device("cuda:0"))
+        clouds += [r_, s_]
+    clouds = clouds[:batch]
+    got = farthest_point_sampling(torch.cat(clouds).contiguous(), [n] * batch, [k] * batch, start_indices=[5 * b for b in range(batch)])
+    for b in sorted({0, batch - 1}):
+        assert np.array_equal(got[b].cpu().numpy(), M.farthest_point_sampling(clouds[b].cpu().numpy(), k, 5 * b)), f"cloud {b}"
+
+
 @pytest.mark.parametrize("n,batch,k", [(7000, 1, 300), (7000, 2, 300), (50000, 32, 120), (200000, 8, 400)])
 def test_fps_pruned_rounds_stay_exact(n, batch, k):
     """The bucket pruning (Morton-ordered slabs, per-wave boxes) must not change a single index: clouds with empty waves
