@@ -111,6 +111,17 @@ SIGNATURES.update({
     "gr_fps_workspace_bytes": (c_size, [c_i64, c_i64]),
     "gr_fps": (c_int, [c_void, c_i64p, c_i64p, c_i64p, c_i64, c_i64, c_void, c_void, c_size, c_void]),
     "gr_point_to_node_workspace_bytes": (c_size, [c_i64, c_i64]),
+    "gr_point_to_node_batch_workspace_bytes": (c_size, [c_i64p, c_i64p, c_i64]),
+    "gr_point_to_node_partition_batch": (c_int, [c_void, c_i64p, c_void, c_i64p, c_i64, c_int, c_void, c_void, c_void, c_void,
+                                                 c_void, c_size, c_void]),
+    "gr_superpoint_matching_batch_workspace_bytes": (c_size, [c_i64p, c_i64]),
+    "gr_superpoint_matching_batch": (c_int, [c_void, c_i64p, c_i64, c_i64, c_void, c_int, c_int, c_void, c_void, c_void,
+                                             c_i64p, c_void, c_size, c_void]),
+    "gr_lgr_register_seg": (c_int, [c_void, c_void, c_void, c_i64, c_i64, c_void, c_void, c_i64, c_f32, c_int, c_int,
+                                    c_void, c_void, c_void, c_size, c_void]),
+    "gr_ransac_seg_workspace_bytes": (c_size, [c_i64, c_i64]),
+    "gr_ransac_similarity_seg": (c_int, [c_void, c_void, c_void, c_i64, c_int, c_i64, ctypes.c_uint32, c_f32, c_int, c_int,
+                                         c_void, c_void, c_void, c_void, c_size, c_void]),
     "gr_point_to_node_partition": (c_int, [c_void, c_i64, c_void, c_i64, c_int, c_void, c_void, c_void, c_void,
                                            c_void, c_size, c_void]),
 })

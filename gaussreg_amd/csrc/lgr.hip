@@ -163,13 +163,24 @@ __global__ __launch_bounds__(LG_T) void lgr_local_kernel(const float* __restrict
 }
 
 // per hypothesis: number of inliers over all C correspondences
+// (segmented form: seg_patch_off lists the first patch of each scene pair, row_off the first correspondence of every patch
+//  -- the hypothesis of patch p is scored on the correspondences of p's own pair)
 __global__ __launch_bounds__(LG_T) void lgr_verify_kernel(const float* __restrict__ src, const float* __restrict__ ref, int C,
                                                           const float* __restrict__ transforms,
                                                           const int32_t* __restrict__ valid, float radius,
-                                                          int32_t* __restrict__ inliers) {
+                                                          int32_t* __restrict__ inliers,
+                                                          const int32_t* __restrict__ seg_patch_off, int nseg,
+                                                          const int32_t* __restrict__ row_off) {
   __shared__ int wsum[LG_T / WAVE];
   __shared__ float T[12];
   const int p = blockIdx.x;
+  if (seg_patch_off) {
+    const int sgm = find_batch(seg_patch_off, nseg, p);
+    const int a = row_off[seg_patch_off[sgm]];
+    C = row_off[seg_patch_off[sgm + 1]] - a;
+    src += 3 * (int64_t)a;
+    ref += 3 * (int64_t)a;
+  }
   if (!valid[p]) {
     if (threadIdx.x == 0) inliers[p] = -1;
     return;
@@ -196,10 +207,33 @@ __global__ __launch_bounds__(LG_RT) void lgr_refine_kernel(const float* __restri
                                                           const float* __restrict__ scores, int C, int B,
                                                           const float* __restrict__ transforms,
                                                           const int32_t* __restrict__ inliers, float radius, int steps,
-                                                          float* __restrict__ out_transform /* 4x4 row-major */) {
+                                                          float* __restrict__ out_transform /* 4x4 row-major */,
+                                                          const int32_t* __restrict__ seg_patch_off,
+                                                          const int32_t* __restrict__ row_off,
+                                                          int32_t* __restrict__ out_seg_rows) {
   __shared__ double sh[9 * (LG_RT / WAVE) + 16];
   __shared__ float T[12];
   __shared__ int best_sh;
+  if (seg_patch_off) {  // workgroup = scene pair: its patches [pa, pe), its correspondences [a, a + C)
+    const int pa = seg_patch_off[blockIdx.x], pe = seg_patch_off[blockIdx.x + 1];
+    const int a = row_off[pa];
+    C = row_off[pe] - a;
+    B = pe - pa;
+    src += 3 * (int64_t)a;
+    ref += 3 * (int64_t)a;
+    scores += a;
+    transforms += (int64_t)pa * 12;
+    inliers += pa;
+    out_transform += 16 * (int64_t)blockIdx.x;
+    if (out_seg_rows && threadIdx.x == 0) {
+      out_seg_rows[blockIdx.x] = a;
+      if (blockIdx.x == gridDim.x - 1) out_seg_rows[gridDim.x] = a + C;
+    }
+    if (C == 0) {  // a pair without correspondences: identity (the single-pair entry point refuses this case)
+      if (threadIdx.x < 16) out_transform[threadIdx.x] = threadIdx.x % 5 == 0 ? 1.0f : 0.0f;
+      return;
+    }
+  }
   {
     // first maximum, like argmax: key = (inliers + 1, ~index) so that the largest key is the lowest index of the largest
     // count (inliers = -1 marks an invalid hypothesis: key 0 .. never beats a valid one, best stays -1)
@@ -288,13 +322,14 @@ extern "C" int gr_lgr_register_verify(const float* ref_corr_points, const float*
     hipLaunchKernelGGL(lgr_local_kernel, dim3((unsigned)batch), dim3(LG_T), 0, stream, src_corr_points, ref_corr_points,
                        corr_scores, counts, offsets, correspondence_threshold, transforms, valid);
     hipLaunchKernelGGL(lgr_verify_kernel, dim3((unsigned)batch), dim3(LG_T), 0, stream, verify_src_points,
-                       verify_ref_points, (int)num_verify, transforms, valid, acceptance_radius, inl);
+                       verify_ref_points, (int)num_verify, transforms, valid, acceptance_radius, inl,
+                       (const int32_t*)nullptr, 0, (const int32_t*)nullptr);
   }
   // the first refinement step of the reference is "procrustes with the best hypothesis' mask" (:183), the
   // remaining num_refinement_steps - 1 recompute the mask from the running estimate (:184-190)
   hipLaunchKernelGGL(lgr_refine_kernel, dim3(1), dim3(LG_RT), 0, stream, verify_src_points, verify_ref_points,
                      verify_scores, (int)num_verify, (int)batch, transforms, inl, acceptance_radius, num_refinement_steps,
-                     out_transform);
+                     out_transform, (const int32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr);
   GR_LAUNCH_CHECK();
   return GR_OK;
 }
@@ -306,4 +341,44 @@ extern "C" int gr_lgr_register(const float* ref_corr_points, const float* src_co
   return gr_lgr_register_verify(ref_corr_points, src_corr_points, corr_scores, num_corr, batch, pm_ws, ref_corr_points,
                                 src_corr_points, corr_scores, num_corr, acceptance_radius, correspondence_threshold,
                                 num_refinement_steps, out_transform, ws, ws_bytes, stream_);
+}
+
+// Stack mode over scene pairs (test.py:146-212 runs local_global_registration.py:135-193 once per pair): the `batch` patches
+// and their correspondences (gr_corr_matrix / gr_corr_gather over ALL patches of the batch) belong to `nseg` pairs, pair s
+// owning patches [seg_patch_off[s], seg_patch_off[s + 1]) (device int32, nseg + 1 entries).  out_transforms: nseg x 16
+// floats; out_seg_rows (optional, device int32[nseg + 1]): first correspondence row of every pair, last entry = num_corr.
+// A pair without correspondences gets the identity.  Three launches for the whole batch, no host synchronisation.
+extern "C" int gr_lgr_register_seg(const float* ref_corr_points, const float* src_corr_points, const float* corr_scores,
+                                   int64_t num_corr, int64_t batch, const void* pm_ws, const int32_t* seg_patch_off,
+                                   int64_t nseg, float acceptance_radius, int correspondence_threshold,
+                                   int num_refinement_steps, float* out_transforms, int32_t* out_seg_rows, void* ws,
+                                   size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GR_REQUIRE(num_corr >= 0 && batch >= 0 && nseg >= 0 && num_refinement_steps >= 1 && num_corr < (1ll << 31) &&
+             nseg < (1 << 24), "bad arguments");
+  if (nseg == 0) return GR_OK;
+  GR_REQUIRE(out_transforms && pm_ws && seg_patch_off, "null argument");
+  GR_REQUIRE(num_corr == 0 || (ref_corr_points && src_corr_points && corr_scores), "null argument");
+  if (!ws || ws_bytes < gr_lgr_workspace_bytes(batch)) {
+    set_error("lgr workspace too small");
+    return GR_ERR_WORKSPACE;
+  }
+  Carver c(ws);
+  float* transforms = c.take<float>(batch * 12);
+  int32_t* valid = c.take<int32_t>(batch);
+  int32_t* inl = c.take<int32_t>(batch);
+  const int32_t* counts = static_cast<const int32_t*>(pm_ws);  // layout of gr_corr_matrix's workspace:
+  const int32_t* offsets = counts + batch;                     // counts[batch], offsets[batch], total -- offsets[batch] = total
+  KernelTimer timer("lgr", stream);
+  if (batch > 0) {
+    hipLaunchKernelGGL(lgr_local_kernel, dim3((unsigned)batch), dim3(LG_T), 0, stream, src_corr_points, ref_corr_points,
+                       corr_scores, counts, offsets, correspondence_threshold, transforms, valid);
+    hipLaunchKernelGGL(lgr_verify_kernel, dim3((unsigned)batch), dim3(LG_T), 0, stream, src_corr_points, ref_corr_points,
+                       0, transforms, valid, acceptance_radius, inl, seg_patch_off, (int)nseg, offsets);
+  }
+  hipLaunchKernelGGL(lgr_refine_kernel, dim3((unsigned)nseg), dim3(LG_RT), 0, stream, src_corr_points, ref_corr_points,
+                     corr_scores, 0, 0, transforms, inl, acceptance_radius, num_refinement_steps, out_transforms,
+                     seg_patch_off, offsets, out_seg_rows);
+  GR_LAUNCH_CHECK();
+  return GR_OK;
 }

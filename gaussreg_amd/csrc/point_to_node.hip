@@ -8,6 +8,8 @@
 //   select   one workgroup per node: its points' (d, index) keys bitonic-sorted in LDS, the
 //            point_limit smallest emitted in ascending order, the rest padded with N / False
 // Algorithmic traffic: 12(N+M) + 8N + M(1 + 9K) bytes instead of >= 5 N M bytes.
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace gr {
@@ -181,5 +183,34 @@ extern "C" int gr_point_to_node_partition(const float* points, int64_t n, const 
   hipLaunchKernelGGL(select_kernel, dim3((unsigned)m), dim3(256), 0, stream, (int)n, point_limit, w.node_start, w.keys,
                      node_knn_indices, node_knn_masks);
   GR_LAUNCH_CHECK();
+  return GR_OK;
+}
+
+// Stack mode over `nclouds` (fine cloud, its coarse nodes) pairs -- every cloud of a batch of scene pairs in one call
+// (model.py:99-104 runs the single-cloud form twice per pair).  The clouds are worked one after the other on `stream`
+// with no host synchronisation in between, so one workspace (sized for the largest cloud) serves all of them.  Outputs are
+// the single-cloud outputs concatenated; indices stay LOCAL to their cloud (padding value = that cloud's point count).
+extern "C" size_t gr_point_to_node_batch_workspace_bytes(const int64_t* h_point_off, const int64_t* h_node_off,
+                                                         int64_t nclouds) {
+  size_t need = 0;
+  if (!h_point_off || !h_node_off) return 0;
+  for (int64_t c = 0; c < nclouds; ++c)
+    need = std::max(need, gr_point_to_node_workspace_bytes(h_point_off[c + 1] - h_point_off[c], h_node_off[c + 1] - h_node_off[c]));
+  return need;
+}
+
+extern "C" int gr_point_to_node_partition_batch(const float* points, const int64_t* h_point_off, const float* nodes,
+                                                const int64_t* h_node_off, int64_t nclouds, int point_limit,
+                                                int64_t* point_to_node, uint8_t* node_masks, int64_t* node_knn_indices,
+                                                uint8_t* node_knn_masks, void* ws, size_t ws_bytes, void* stream_) {
+  GR_REQUIRE(nclouds >= 0 && h_point_off && h_node_off, "bad arguments");
+  for (int64_t c = 0; c < nclouds; ++c) {
+    const int64_t po = h_point_off[c], n = h_point_off[c + 1] - po, no = h_node_off[c], m = h_node_off[c + 1] - no;
+    GR_REQUIRE(n >= 0 && m >= 0 && po >= 0 && no >= 0, "cloud %lld: offsets must ascend", (long long)c);
+    const int rc = gr_point_to_node_partition(points + 3 * po, n, nodes + 3 * no, m, point_limit, point_to_node + po,
+                                              node_masks + no, node_knn_indices + no * point_limit,
+                                              node_knn_masks + no * point_limit, ws, ws_bytes, stream_);
+    if (rc != GR_OK) return rc;
+  }
   return GR_OK;
 }

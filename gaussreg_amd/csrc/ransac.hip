@@ -97,11 +97,22 @@ __device__ bool umeyama_from_sums(double n, const double* ss, const double* sr, 
 __global__ __launch_bounds__(RS_T) void ransac_hypotheses_kernel(const float* __restrict__ src, const float* __restrict__ ref,
                                                                  int C, int n_sample, int num_hyp, uint32_t seed,
                                                                  float thr, int with_scale, float* __restrict__ transforms,
-                                                                 int32_t* __restrict__ inliers, float* __restrict__ sqerr) {
+                                                                 int32_t* __restrict__ inliers, float* __restrict__ sqerr,
+                                                                 const int32_t* __restrict__ seg_row_off) {
+  if (seg_row_off) {  // blockIdx.y = scene pair: its correspondences, its share of the hypothesis tables, its own seed
+    const int a = seg_row_off[blockIdx.y];
+    C = seg_row_off[blockIdx.y + 1] - a;
+    src += 3 * (int64_t)a;
+    ref += 3 * (int64_t)a;
+    transforms += (int64_t)blockIdx.y * num_hyp * 12;
+    inliers += (int64_t)blockIdx.y * num_hyp;
+    sqerr += (int64_t)blockIdx.y * num_hyp;
+    seed += blockIdx.y;
+  }
   const int h = blockIdx.x * RS_T + threadIdx.x;
   float T[12];
   bool ok = false;
-  if (h < num_hyp) {
+  if (h < num_hyp && C >= n_sample) {  // (fewer correspondences than one sample: every hypothesis invalid)
     int idx[RS_MAXN];
     for (int k = 0; k < n_sample; ++k) {
       uint32_t attempt = 0;
@@ -135,9 +146,19 @@ __global__ __launch_bounds__(RS_T) void ransac_hypotheses_kernel(const float* __
 
 __global__ __launch_bounds__(RS_ST) void ransac_score_kernel(const float* __restrict__ src, const float* __restrict__ ref, int C,
                                                             int num_hyp, float thr, const float* __restrict__ transforms,
-                                                            int32_t* __restrict__ inliers, float* __restrict__ sqerr) {
+                                                            int32_t* __restrict__ inliers, float* __restrict__ sqerr,
+                                                            const int32_t* __restrict__ seg_row_off) {
   __shared__ float s_src[RS_CHUNK * 3];
   __shared__ float s_ref[RS_CHUNK * 3];
+  if (seg_row_off) {
+    const int a = seg_row_off[blockIdx.y];
+    C = seg_row_off[blockIdx.y + 1] - a;
+    src += 3 * (int64_t)a;
+    ref += 3 * (int64_t)a;
+    transforms += (int64_t)blockIdx.y * num_hyp * 12;
+    inliers += (int64_t)blockIdx.y * num_hyp;
+    sqerr += (int64_t)blockIdx.y * num_hyp;
+  }
   const int h = blockIdx.x * (RS_ST / RS_LPH) + threadIdx.x / RS_LPH, sub = threadIdx.x % RS_LPH;
   const bool ok = h < num_hyp && inliers[h] >= 0;
   float T[12];
@@ -186,7 +207,25 @@ __global__ __launch_bounds__(1024) void ransac_best_kernel(const float* __restri
                                                            const int32_t* __restrict__ inliers,
                                                            const float* __restrict__ sqerr, float thr, int with_scale,
                                                            int refine, float* __restrict__ out /* 4x4 */,
-                                                           int32_t* __restrict__ out_stats /* [2]: inliers, best id */) {
+                                                           int32_t* __restrict__ out_stats /* [2]: inliers, best id */,
+                                                           const int32_t* __restrict__ seg_row_off, int n_sample,
+                                                           const float* __restrict__ fallback) {
+  if (seg_row_off) {  // blockIdx.x = scene pair
+    const int a = seg_row_off[blockIdx.x];
+    C = seg_row_off[blockIdx.x + 1] - a;
+    src += 3 * (int64_t)a;
+    ref += 3 * (int64_t)a;
+    transforms += (int64_t)blockIdx.x * num_hyp * 12;
+    inliers += (int64_t)blockIdx.x * num_hyp;
+    sqerr += (int64_t)blockIdx.x * num_hyp;
+    out += 16 * (int64_t)blockIdx.x;
+    if (out_stats) out_stats += 2 * (int64_t)blockIdx.x;
+    if (C < n_sample) {  // model.py:209-220 keeps the LocalGlobalRegistration estimate for such a pair
+      if (threadIdx.x < 16) out[threadIdx.x] = fallback ? fallback[16 * (int64_t)blockIdx.x + threadIdx.x] : (threadIdx.x % 5 == 0 ? 1.f : 0.f);
+      if (threadIdx.x == 0 && out_stats) out_stats[0] = -1, out_stats[1] = -1;
+      return;
+    }
+  }
   __shared__ int s_cnt[1024];
   __shared__ float s_err[1024];
   __shared__ int s_id[1024];
@@ -299,13 +338,57 @@ extern "C" int gr_ransac_similarity(const float* src_points, const float* ref_po
   KernelTimer timer("ransac", stream);
   hipLaunchKernelGGL(ransac_hypotheses_kernel, dim3((unsigned)((num_hypotheses + RS_T - 1) / RS_T)), dim3(RS_T), 0, stream,
                      src_points, ref_points, (int)num_corr, ransac_n, (int)num_hypotheses, seed, distance_threshold,
-                     with_scaling, transforms, inl, err);
+                     with_scaling, transforms, inl, err, (const int32_t*)nullptr);
   constexpr int HPB = RS_ST / RS_LPH;
   hipLaunchKernelGGL(ransac_score_kernel, dim3((unsigned)((num_hypotheses + HPB - 1) / HPB)), dim3(RS_ST), 0, stream, src_points,
-                     ref_points, (int)num_corr, (int)num_hypotheses, distance_threshold, transforms, inl, err);
+                     ref_points, (int)num_corr, (int)num_hypotheses, distance_threshold, transforms, inl, err,
+                     (const int32_t*)nullptr);
   hipLaunchKernelGGL(ransac_best_kernel, dim3(1), dim3(1024), 0, stream, src_points, ref_points, (int)num_corr,
                      (int)num_hypotheses, transforms, inl, err, distance_threshold, with_scaling, refine, out_transform,
-                     out_stats);
+                     out_stats, (const int32_t*)nullptr, ransac_n, (const float*)nullptr);
+  GR_LAUNCH_CHECK();
+  return GR_OK;
+}
+
+// Stack mode over `nseg` scene pairs (model.py:209-215 once per pair of test.py:146-212): pair s owns the correspondence rows
+// [seg_row_off[s], seg_row_off[s + 1]) (device int32, nseg + 1 entries, e.g. gr_lgr_register_seg's out_seg_rows) and draws its
+// hypotheses with seed + s.  A pair with fewer than ransac_n correspondences keeps fallback_transforms[s] (nseg x 16, e.g.
+// the LocalGlobalRegistration estimates; null = identity).  out_transforms: nseg x 16, out_stats (optional): nseg x 2.
+// Three launches for the whole batch, no host synchronisation.
+extern "C" size_t gr_ransac_seg_workspace_bytes(int64_t num_hypotheses, int64_t nseg) {
+  if (num_hypotheses < 0 || nseg < 0) return 0;
+  return align_up((size_t)nseg * num_hypotheses * 12 * 4, 256) + 2 * align_up((size_t)nseg * num_hypotheses * 4, 256) + 256;
+}
+
+extern "C" int gr_ransac_similarity_seg(const float* src_points, const float* ref_points, const int32_t* seg_row_off,
+                                        int64_t nseg, int ransac_n, int64_t num_hypotheses, uint32_t seed,
+                                        float distance_threshold, int with_scaling, int refine,
+                                        const float* fallback_transforms, float* out_transforms, int32_t* out_stats,
+                                        void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GR_REQUIRE(nseg >= 0 && nseg < 65536 && num_hypotheses >= 1 && num_hypotheses < (1 << 24), "bad sizes");
+  GR_REQUIRE(ransac_n >= 3 && ransac_n <= RS_MAXN, "ransac_n must be in [3, %d]", RS_MAXN);
+  if (nseg == 0) return GR_OK;
+  GR_REQUIRE(src_points && ref_points && seg_row_off && out_transforms, "null argument");
+  if (!ws || ws_bytes < gr_ransac_seg_workspace_bytes(num_hypotheses, nseg)) {
+    set_error("ransac workspace too small");
+    return GR_ERR_WORKSPACE;
+  }
+  Carver c(ws);
+  float* transforms = c.take<float>(nseg * num_hypotheses * 12);
+  int32_t* inl = c.take<int32_t>(nseg * num_hypotheses);
+  float* err = c.take<float>(nseg * num_hypotheses);
+  KernelTimer timer("ransac", stream);
+  hipLaunchKernelGGL(ransac_hypotheses_kernel, dim3((unsigned)((num_hypotheses + RS_T - 1) / RS_T), (unsigned)nseg), dim3(RS_T),
+                     0, stream, src_points, ref_points, 0, ransac_n, (int)num_hypotheses, seed, distance_threshold,
+                     with_scaling, transforms, inl, err, seg_row_off);
+  constexpr int HPB = RS_ST / RS_LPH;
+  hipLaunchKernelGGL(ransac_score_kernel, dim3((unsigned)((num_hypotheses + HPB - 1) / HPB), (unsigned)nseg), dim3(RS_ST), 0,
+                     stream, src_points, ref_points, 0, (int)num_hypotheses, distance_threshold, transforms, inl, err,
+                     seg_row_off);
+  hipLaunchKernelGGL(ransac_best_kernel, dim3((unsigned)nseg), dim3(1024), 0, stream, src_points, ref_points, 0,
+                     (int)num_hypotheses, transforms, inl, err, distance_threshold, with_scaling, refine, out_transforms,
+                     out_stats, seg_row_off, ransac_n, fallback_transforms);
   GR_LAUNCH_CHECK();
   return GR_OK;
 }

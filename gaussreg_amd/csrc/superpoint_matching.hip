@@ -9,6 +9,8 @@
 // no float atomics: results are reproducible run to run) -> score = (S/rowsum)*(S/colsum) ->
 // exact global top-k by a 3-pass radix select on the score bits (ties: lowest flat index first)
 // -> sorted (score desc) -> indices mapped back through the compaction tables.
+#include <vector>
+
 #include "common.hpp"
 
 namespace gr {
@@ -507,24 +509,11 @@ extern "C" size_t gr_superpoint_matching_workspace_bytes(int64_t nr, int64_t ns)
   return carve_spm(nullptr, nr, ns).bytes;
 }
 
-extern "C" int gr_superpoint_matching(const float* ref_feats, const float* src_feats, int64_t nr, int64_t ns,
-                                      int64_t c, const uint8_t* ref_masks, const uint8_t* src_masks,
-                                      int num_correspondences, int dual_normalization, int64_t* out_ref_idx,
-                                      int64_t* out_src_idx, float* out_scores, int64_t* h_num_out, void* ws,
-                                      size_t ws_bytes, void* stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  GR_REQUIRE(h_num_out != nullptr, "h_num_out is null");
-  *h_num_out = 0;
-  GR_REQUIRE(nr >= 0 && ns >= 0 && c >= 0 && num_correspondences >= 0, "bad sizes");
-  GR_REQUIRE(nr * ns < (1ll << 32), "score matrix too large (%lld x %lld)", (long long)nr, (long long)ns);
-  GR_REQUIRE(num_correspondences <= CAND_CAP / 2, "num_correspondences must be <= %d", CAND_CAP / 2);
-  if (nr == 0 || ns == 0 || num_correspondences == 0) return GR_OK;
-  GR_REQUIRE(ref_feats && src_feats && out_ref_idx && out_src_idx && out_scores, "null argument");
-  SpmWs w = carve_spm(ws, nr, ns);
-  if (!ws || ws_bytes < w.bytes) {
-    set_error("superpoint_matching workspace too small: need %zu bytes, got %zu", w.bytes, ws_bytes);
-    return GR_ERR_WORKSPACE;
-  }
+// the launches of one pair, asynchronous; the header (counts) stays in w.hdr
+static int spm_launch(const float* ref_feats, const float* src_feats, int64_t nr, int64_t ns, int64_t c,
+                      const uint8_t* ref_masks, const uint8_t* src_masks, int num_correspondences,
+                      int dual_normalization, int64_t* out_ref_idx, int64_t* out_src_idx, float* out_scores,
+                      const SpmWs& w, hipStream_t stream) {
   GR_HIP(hipMemsetAsync(w.hist, 0, 3 * 2048 * sizeof(uint32_t), stream));
   hipLaunchKernelGGL(compact_masks_kernel, dim3(1), dim3(1024), 0, stream, ref_masks, (int)nr, src_masks, (int)ns,
                      num_correspondences, w.ridx, w.sidx, w.hdr);
@@ -547,6 +536,36 @@ extern "C" int gr_superpoint_matching(const float* ref_feats, const float* src_f
   hipLaunchKernelGGL(select_emit_kernel, dim3(1), dim3(1024), 0, stream, w.hdr, w.cand, w.ridx, w.sidx, out_ref_idx,
                      out_src_idx, out_scores);
   GR_LAUNCH_CHECK();
+  return GR_OK;
+}
+
+static int spm_check_args(int64_t nr, int64_t ns, int64_t c, int num_correspondences) {
+  GR_REQUIRE(nr >= 0 && ns >= 0 && c >= 0 && num_correspondences >= 0, "bad sizes");
+  GR_REQUIRE(nr * ns < (1ll << 32), "score matrix too large (%lld x %lld)", (long long)nr, (long long)ns);
+  GR_REQUIRE(num_correspondences <= CAND_CAP / 2, "num_correspondences must be <= %d", CAND_CAP / 2);
+  return GR_OK;
+}
+
+extern "C" int gr_superpoint_matching(const float* ref_feats, const float* src_feats, int64_t nr, int64_t ns,
+                                      int64_t c, const uint8_t* ref_masks, const uint8_t* src_masks,
+                                      int num_correspondences, int dual_normalization, int64_t* out_ref_idx,
+                                      int64_t* out_src_idx, float* out_scores, int64_t* h_num_out, void* ws,
+                                      size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GR_REQUIRE(h_num_out != nullptr, "h_num_out is null");
+  *h_num_out = 0;
+  int rc = spm_check_args(nr, ns, c, num_correspondences);
+  if (rc != GR_OK) return rc;
+  if (nr == 0 || ns == 0 || num_correspondences == 0) return GR_OK;
+  GR_REQUIRE(ref_feats && src_feats && out_ref_idx && out_src_idx && out_scores, "null argument");
+  SpmWs w = carve_spm(ws, nr, ns);
+  if (!ws || ws_bytes < w.bytes) {
+    set_error("superpoint_matching workspace too small: need %zu bytes, got %zu", w.bytes, ws_bytes);
+    return GR_ERR_WORKSPACE;
+  }
+  rc = spm_launch(ref_feats, src_feats, nr, ns, c, ref_masks, src_masks, num_correspondences, dual_normalization,
+                  out_ref_idx, out_src_idx, out_scores, w, stream);
+  if (rc != GR_OK) return rc;
   SpmHdr h;
   GR_HIP(hipMemcpyAsync(&h, w.hdr, sizeof(h), hipMemcpyDeviceToHost, stream));
   GR_HIP(hipStreamSynchronize(stream));
@@ -559,5 +578,72 @@ extern "C" int gr_superpoint_matching(const float* ref_feats, const float* src_f
     GR_HIP(hipStreamSynchronize(stream));
   }
   *h_num_out = h.k;
+  return GR_OK;
+}
+
+// Stack mode over `npairs` scene pairs (test.py:146-212 runs model.py:156-160 once per pair): the superpoint features of the
+// batch are stacked as [ref_0, src_0, ref_1, src_1, ...] with h_node_off (2 npairs + 1 offsets), masks likewise (null =
+// all true).  Pair b's matches go to row b of the (npairs, num_correspondences) outputs; h_num_out[b] = how many are valid.
+// All pairs are launched back to back on `stream` out of one workspace; their headers are collected on the device and
+// read back ONCE.  (A pair with more ties at the selection threshold than the candidate buffer holds is redone through the
+// single-pair path afterwards.)
+extern "C" size_t gr_superpoint_matching_batch_workspace_bytes(const int64_t* h_node_off, int64_t npairs) {
+  size_t need = 0;
+  if (!h_node_off || npairs < 0) return 0;
+  for (int64_t b = 0; b < npairs; ++b)
+    need = std::max(need, carve_spm(nullptr, h_node_off[2 * b + 1] - h_node_off[2 * b],
+                                    h_node_off[2 * b + 2] - h_node_off[2 * b + 1]).bytes);
+  return align_up(need, 256) + align_up((size_t)std::max<int64_t>(npairs, 1) * sizeof(SpmHdr), 256);
+}
+
+extern "C" int gr_superpoint_matching_batch(const float* feats, const int64_t* h_node_off, int64_t npairs, int64_t c,
+                                            const uint8_t* masks, int num_correspondences, int dual_normalization,
+                                            int64_t* out_ref_idx, int64_t* out_src_idx, float* out_scores,
+                                            int64_t* h_num_out, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GR_REQUIRE(npairs >= 0 && h_node_off && h_num_out, "bad arguments");
+  for (int64_t b = 0; b < npairs; ++b) h_num_out[b] = 0;
+  if (npairs == 0 || num_correspondences == 0) return GR_OK;
+  GR_REQUIRE(feats && out_ref_idx && out_src_idx && out_scores, "null argument");
+  if (!ws || ws_bytes < gr_superpoint_matching_batch_workspace_bytes(h_node_off, npairs)) {
+    set_error("superpoint_matching batch workspace too small");
+    return GR_ERR_WORKSPACE;
+  }
+  const size_t pair_bytes = gr_superpoint_matching_batch_workspace_bytes(h_node_off, npairs) -
+                            align_up((size_t)npairs * sizeof(SpmHdr), 256);
+  SpmHdr* d_hdrs = reinterpret_cast<SpmHdr*>(static_cast<char*>(ws) + pair_bytes);
+  std::vector<char> live(npairs, 0);
+  for (int64_t b = 0; b < npairs; ++b) {
+    const int64_t r0 = h_node_off[2 * b], nr = h_node_off[2 * b + 1] - r0, s0 = h_node_off[2 * b + 1],
+                  ns = h_node_off[2 * b + 2] - s0;
+    GR_REQUIRE(nr >= 0 && ns >= 0 && r0 >= 0, "pair %lld: offsets must ascend", (long long)b);
+    int rc = spm_check_args(nr, ns, c, num_correspondences);
+    if (rc != GR_OK) return rc;
+    if (nr == 0 || ns == 0) continue;
+    SpmWs w = carve_spm(ws, nr, ns);
+    rc = spm_launch(feats + r0 * c, feats + s0 * c, nr, ns, c, masks ? masks + r0 : nullptr, masks ? masks + s0 : nullptr,
+                    num_correspondences, dual_normalization, out_ref_idx + b * num_correspondences,
+                    out_src_idx + b * num_correspondences, out_scores + b * num_correspondences, w, stream);
+    if (rc != GR_OK) return rc;
+    GR_HIP(hipMemcpyAsync(d_hdrs + b, w.hdr, sizeof(SpmHdr), hipMemcpyDeviceToDevice, stream));
+    live[b] = 1;
+  }
+  std::vector<SpmHdr> h(npairs);
+  GR_HIP(hipMemcpyAsync(h.data(), d_hdrs, sizeof(SpmHdr) * (size_t)npairs, hipMemcpyDeviceToHost, stream));
+  GR_HIP(hipStreamSynchronize(stream));
+  for (int64_t b = 0; b < npairs; ++b) {
+    if (!live[b]) continue;
+    if (h[b].n_cand > CAND_CAP) {
+      const int64_t r0 = h_node_off[2 * b], nr = h_node_off[2 * b + 1] - r0, s0 = h_node_off[2 * b + 1],
+                    ns = h_node_off[2 * b + 2] - s0;
+      const int rc = gr_superpoint_matching(feats + r0 * c, feats + s0 * c, nr, ns, c, masks ? masks + r0 : nullptr,
+                                            masks ? masks + s0 : nullptr, num_correspondences, dual_normalization,
+                                            out_ref_idx + b * num_correspondences, out_src_idx + b * num_correspondences,
+                                            out_scores + b * num_correspondences, h_num_out + b, ws, pair_bytes, stream_);
+      if (rc != GR_OK) return rc;
+    } else {
+      h_num_out[b] = h[b].k;
+    }
+  }
   return GR_OK;
 }

@@ -65,6 +65,37 @@ class SuperPointMatching(nn.Module):
         return ri, si, sc
 
 
+    @torch.no_grad()
+    def forward_batch(self, feats, node_lengths, masks=None):
+        """The same for a batch of scene pairs in one call (gr_superpoint_matching_batch): `feats` (sum M, C) stacks the
+        L2-normalised superpoint features as [ref_0, src_0, ref_1, src_1, ...], `node_lengths` their 2 B sizes, `masks`
+        (sum M,) likewise.  -> (ref_corr_indices (B, k), src_corr_indices (B, k), corr_scores (B, k), counts: list of B ints
+        -- row b is valid up to counts[b]).  One host read-back for the whole batch."""
+        dev = _lib.require_gpu()
+        L = _lib.lib()
+        f = _f32c(feats, dev)
+        dev = f.device
+        m = None if masks is None else _boolc(masks, dev)
+        off = [0]
+        for n in node_lengths:
+            off.append(off[-1] + int(n))
+        if len(off) % 2 != 1 or off[-1] != f.shape[0]:
+            raise ValueError("node_lengths must list ref and src sizes of every pair and sum to feats.shape[0]")
+        B = (len(off) - 1) // 2
+        k = int(self.num_correspondences)
+        ri = torch.zeros((B, k), dtype=torch.int64, device=dev)
+        si = torch.zeros((B, k), dtype=torch.int64, device=dev)
+        sc = torch.zeros((B, k), dtype=torch.float32, device=dev)
+        h_off = _lib.host_i64(off)
+        h_n = _lib.host_i64([0] * B)
+        with torch.cuda.device(dev):
+            ws = _lib.workspace(dev, L.gr_superpoint_matching_batch_workspace_bytes(h_off, B))
+            _lib.check(L.gr_superpoint_matching_batch(_lib.ptr(f), h_off, B, f.shape[1], _lib.ptr(m), k,
+                                                      int(bool(self.dual_normalization)), _lib.ptr(ri), _lib.ptr(si),
+                                                      _lib.ptr(sc), h_n, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)))
+        return ri, si, sc, [int(h_n[b]) for b in range(B)]
+
+
 class PointMatching(nn.Module):
     def __init__(self, k: int, mutual: bool = True, confidence_threshold: float = 0.05, use_dustbin: bool = False,
                  use_global_score: bool = False, remove_duplicate: bool = False):
@@ -199,3 +230,48 @@ class LocalGlobalRegistration(nn.Module):
         if out_device.type != "cuda":
             outs = tuple(o.to(out_device) for o in outs)
         return outs
+
+    @torch.no_grad()
+    def forward_batch(self, ref_knn_points, src_knn_points, ref_knn_masks, src_knn_masks, score_mat, global_scores,
+                      patches_per_pair):
+        """forward for a batch of scene pairs in one pass: the P patches of all pairs are stacked along dim 0, pair b owning
+        the next patches_per_pair[b] of them.  -> (ref_corr_points (C,3), src_corr_points (C,3), corr_scores (C,),
+        estimated_transforms (B,4,4), row_offsets (B+1,) int32 on the device: pair b's correspondences are rows
+        [row_offsets[b], row_offsets[b+1]) -- the single-pair outputs concatenated).  ONE host read-back (C, which sizes the
+        outputs) for the whole batch; correspondence_limit is not supported here (the GaussReg config leaves it None)."""
+        if self.correspondence_limit is not None:
+            raise NotImplementedError("forward_batch: correspondence_limit must be None")
+        s, corr, n, pm_ws = self._pm._corr(score_mat, ref_knn_masks, src_knn_masks, True)
+        dev = s.device
+        L = _lib.lib()
+        P, K1, K2 = s.shape
+        poff = [0]
+        for c in patches_per_pair:
+            poff.append(poff[-1] + int(c))
+        if poff[-1] != P:
+            raise ValueError("patches_per_pair must sum to the number of patches")
+        B = len(poff) - 1
+        rp, sp = _f32c(ref_knn_points, dev), _f32c(src_knn_points, dev)
+        gs = _f32c(global_scores, dev) if (self.use_global_score and global_scores is not None) else None
+        o_rp = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        o_sp = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        o_sc = torch.empty((n,), dtype=torch.float32, device=dev)
+        transforms = torch.eye(4, dtype=torch.float32, device=dev).repeat(B, 1, 1)
+        rows = torch.zeros((B + 1,), dtype=torch.int32, device=dev)
+        if P > 0 and B > 0:
+            idx_dummy = torch.zeros((P, max(K1, K2)), dtype=torch.int64, device=dev)
+            o_i = torch.empty((2, max(n, 1)), dtype=torch.int64, device=dev)
+            d_poff = torch.tensor(poff, dtype=torch.int32).to(dev, non_blocking=False)
+            with torch.cuda.device(dev):
+                st = _lib.stream_ptr(dev)
+                if n > 0:
+                    _lib.check(L.gr_corr_gather(_lib.ptr(s), P, K1, K2, _lib.ptr(corr), _lib.ptr(rp), _lib.ptr(sp),
+                                                _lib.ptr(idx_dummy), _lib.ptr(idx_dummy), _lib.ptr(gs), int(gs is not None),
+                                                _lib.ptr(o_rp), _lib.ptr(o_sp), _lib.ptr(o_i[0]), _lib.ptr(o_i[1]),
+                                                _lib.ptr(o_sc), _lib.ptr(pm_ws), pm_ws.numel(), st))
+                ws2 = torch.empty(L.gr_lgr_workspace_bytes(P) + 256, dtype=torch.uint8, device=dev)
+                _lib.check(L.gr_lgr_register_seg(_lib.ptr(o_rp), _lib.ptr(o_sp), _lib.ptr(o_sc), n, P, _lib.ptr(pm_ws),
+                                                 _lib.ptr(d_poff), B, float(self.acceptance_radius),
+                                                 int(self.correspondence_threshold), int(self.num_refinement_steps),
+                                                 _lib.ptr(transforms), _lib.ptr(rows), _lib.ptr(ws2), ws2.numel(), st))
+        return o_rp, o_sp, o_sc, transforms, rows

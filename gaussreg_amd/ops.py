@@ -96,6 +96,38 @@ def point_to_node_partition(points, nodes, point_limit, return_count=False):
     return tuple(res)
 
 
+@torch.no_grad()
+def point_to_node_partition_batch(points, point_lengths, nodes, node_lengths, point_limit):
+    """point_to_node_partition (pointcloud_partition.py:61-111) for every (cloud, superpoints) pair of a stack in one call
+    (gr_point_to_node_partition_batch): `points` (sum N_c, 3) / `nodes` (sum M_c, 3) with per-cloud lengths.  Returns
+    (point_to_node (sum N,), node_masks (sum M,), node_knn_indices (sum M, K), node_knn_masks (sum M, K)); indices are LOCAL
+    to their cloud, exactly what the single-cloud call returns for it."""
+    p = _cuda_f32(points, "points")
+    nd = _cuda_f32(nodes, "nodes")
+    L = _lib.lib()
+    K = int(point_limit)
+    dev = p.device
+    po, no = [0], [0]
+    for n in point_lengths:
+        po.append(po[-1] + int(n))
+    for m in node_lengths:
+        no.append(no[-1] + int(m))
+    if len(po) != len(no) or po[-1] != p.shape[0] or no[-1] != nd.shape[0]:
+        raise ValueError("lengths do not match the stacked tensors")
+    nclouds = len(po) - 1
+    p2n = torch.empty((po[-1],), dtype=torch.int64, device=dev)
+    masks = torch.empty((no[-1],), dtype=torch.bool, device=dev)
+    knn_idx = torch.empty((no[-1], K), dtype=torch.int64, device=dev)
+    knn_masks = torch.empty((no[-1], K), dtype=torch.bool, device=dev)
+    h_po, h_no = _lib.host_i64(po), _lib.host_i64(no)
+    with torch.cuda.device(dev):
+        ws = _lib.workspace(dev, L.gr_point_to_node_batch_workspace_bytes(h_po, h_no, nclouds))
+        _lib.check(L.gr_point_to_node_partition_batch(_lib.ptr(p), h_po, _lib.ptr(nd), h_no, nclouds, K, _lib.ptr(p2n),
+                                                      _lib.ptr(masks), _lib.ptr(knn_idx), _lib.ptr(knn_masks), _lib.ptr(ws),
+                                                      ws.numel(), _lib.stream_ptr(dev)))
+    return p2n, masks, knn_idx, knn_masks
+
+
 _gather_flags = {}
 
 

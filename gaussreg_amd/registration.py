@@ -35,6 +35,34 @@ def registration_with_ransac_from_correspondences(src_points, ref_points, corres
 
 
 @torch.no_grad()
+def registration_with_ransac_batch(src_points, ref_points, row_offsets, fallback_transforms=None, distance_threshold=0.05,
+                                   ransac_n=3, num_iterations=10000, with_scaling=True, refine=True, seed=0,
+                                   return_stats=False):
+    """registration_with_ransac_from_correspondences for a batch of scene pairs in one call (gr_ransac_similarity_seg):
+    row i of src_points corresponds to row i of ref_points; pair b owns rows [row_offsets[b], row_offsets[b+1]) (int32
+    tensor on the device, B + 1 entries) and uses seed + b.  A pair with fewer than ransac_n rows keeps
+    fallback_transforms[b] (model.py:209-220; default identity).  Returns (B,4,4) float32 on the device, no host
+    synchronisation."""
+    L = _lib.lib()
+    s = src_points.contiguous()
+    r = ref_points.contiguous()
+    dev = s.device
+    off = row_offsets.to(device=dev, dtype=torch.int32).contiguous()
+    B = off.shape[0] - 1
+    out = torch.empty((B, 4, 4), dtype=torch.float32, device=dev)
+    stats = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+    fb = None if fallback_transforms is None else fallback_transforms.to(device=dev, dtype=torch.float32).contiguous()
+    if B > 0:
+        with torch.cuda.device(dev):
+            ws = _lib.workspace(dev, L.gr_ransac_seg_workspace_bytes(int(num_iterations), B))
+            _lib.check(L.gr_ransac_similarity_seg(_lib.ptr(s), _lib.ptr(r), _lib.ptr(off), B, int(ransac_n),
+                                                  int(num_iterations), int(seed), float(distance_threshold),
+                                                  int(bool(with_scaling)), int(bool(refine)), _lib.ptr(fb), _lib.ptr(out),
+                                                  _lib.ptr(stats), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)))
+    return (out, stats) if return_stats else out
+
+
+@torch.no_grad()
 def farthest_point_sampling(points, lengths, num_samples, start_indices=None):
     """Exact FPS in stack mode (stand-in for fpsample.bucket_fps_kdline_sampling, demo.py:46; parity unpinned).
     points (N,3); lengths / num_samples: per-cloud sizes (lists or 1-D tensors).  Returns a list of int64

@@ -279,6 +279,15 @@ int gr_superpoint_matching(const float* ref_feats, const float* src_feats, int64
                            const uint8_t* ref_masks, const uint8_t* src_masks, int num_correspondences,
                            int dual_normalization, int64_t* out_ref_idx, int64_t* out_src_idx,
                            float* out_scores, int64_t* h_num_out, void* ws, size_t ws_bytes, void* stream);
+/* Stack mode over `npairs` scene pairs (test.py:146-212 runs model.py:156-160 once per pair): superpoint features stacked as
+ * [ref_0, src_0, ref_1, src_1, ...] with 2 npairs + 1 host offsets, masks likewise (null = all true).  Pair b's matches go
+ * to row b of the (npairs, num_correspondences) outputs; h_num_out[b] = how many of them are valid.  All pairs are launched
+ * back to back; ONE read-back (their headers) at the end. */
+size_t gr_superpoint_matching_batch_workspace_bytes(const int64_t* h_node_off, int64_t npairs);
+int gr_superpoint_matching_batch(const float* feats, const int64_t* h_node_off, int64_t npairs, int64_t c,
+                                 const uint8_t* masks, int num_correspondences, int dual_normalization,
+                                 int64_t* out_ref_idx, int64_t* out_src_idx, float* out_scores, int64_t* h_num_out,
+                                 void* ws, size_t ws_bytes, void* stream);
 size_t gr_point_matching_workspace_bytes(int64_t batch);
 int gr_corr_matrix(const float* score_mat, int64_t batch, int64_t k1, int64_t k2,
                    const uint8_t* ref_knn_masks, const uint8_t* src_knn_masks, int k, int mutual,
@@ -314,6 +323,15 @@ int gr_lgr_register(const float* ref_corr_points, const float* src_corr_points, 
                     int64_t num_corr, int64_t batch, const void* pm_ws, float acceptance_radius,
                     int correspondence_threshold, int num_refinement_steps, float* out_transform, void* ws,
                     size_t ws_bytes, void* stream);
+/* Stack mode over `nseg` scene pairs: the `batch` patches (gr_corr_matrix / gr_corr_gather over ALL patches of the batch)
+ * belong to pairs, pair s owning patches [seg_patch_off[s], seg_patch_off[s+1]) (DEVICE int32, nseg + 1 entries).
+ * out_transforms: nseg x 16 floats on the device; out_seg_rows (optional, device int32[nseg + 1]): first correspondence row
+ * of every pair, last entry = num_corr.  A pair without correspondences gets the identity.  Three launches, no host
+ * synchronisation. */
+int gr_lgr_register_seg(const float* ref_corr_points, const float* src_corr_points, const float* corr_scores,
+                        int64_t num_corr, int64_t batch, const void* pm_ws, const int32_t* seg_patch_off, int64_t nseg,
+                        float acceptance_radius, int correspondence_threshold, int num_refinement_steps,
+                        float* out_transforms, int32_t* out_seg_rows, void* ws, size_t ws_bytes, void* stream);
 /* gr_ransac_similarity ("next" row; PARITY UNPINNED -- Open3D is not in the reference tree):
  * stands in for geotransformer/utils/open3d.py:169-198 (registration_ransac_based_on_correspondence with
  * TransformationEstimationPointToPoint(with_scaling)), called from model.py:209-215.  Row i of src_points
@@ -327,6 +345,15 @@ int gr_ransac_similarity(const float* src_points, const float* ref_points, int64
                          int64_t num_hypotheses, uint32_t seed, float distance_threshold, int with_scaling,
                          int refine, float* out_transform, int32_t* out_stats, void* ws, size_t ws_bytes,
                          void* stream);
+/* Stack mode over `nseg` scene pairs: pair s owns the correspondence rows [seg_row_off[s], seg_row_off[s+1]) (DEVICE int32,
+ * nseg + 1 entries, e.g. gr_lgr_register_seg's out_seg_rows) and draws its hypotheses with seed + s.  A pair with fewer than
+ * ransac_n correspondences keeps fallback_transforms[s] (nseg x 16, null = identity) -- model.py:209-220.  Three launches,
+ * no host synchronisation. */
+size_t gr_ransac_seg_workspace_bytes(int64_t num_hypotheses, int64_t nseg);
+int gr_ransac_similarity_seg(const float* src_points, const float* ref_points, const int32_t* seg_row_off, int64_t nseg,
+                             int ransac_n, int64_t num_hypotheses, uint32_t seed, float distance_threshold,
+                             int with_scaling, int refine, const float* fallback_transforms, float* out_transforms,
+                             int32_t* out_stats, void* ws, size_t ws_bytes, void* stream);
 /* gr_fps ("next" row; PARITY UNPINNED -- fpsample is not in the reference tree): exact farthest
  * point sampling in stack mode, stands in for fpsample.bucket_fps_kdline_sampling (demo.py:46, test.py:46,
  * dataset.py:127).  points (n,3) hold `batch` clouds (h_lengths); cloud b yields h_num_samples[b] LOCAL indices
@@ -374,6 +401,15 @@ size_t gr_point_to_node_workspace_bytes(int64_t n, int64_t m);
 int gr_point_to_node_partition(const float* points, int64_t n, const float* nodes, int64_t m, int point_limit,
                                int64_t* point_to_node, uint8_t* node_masks, int64_t* node_knn_indices,
                                uint8_t* node_knn_masks, void* ws, size_t ws_bytes, void* stream);
+/* Stack mode over `nclouds` (fine cloud, coarse nodes) pairs -- model.py:99-104 for every cloud of a batch of scene pairs
+ * (test.py:146-212) in one call: h_point_off / h_node_off hold nclouds + 1 ascending host offsets into points / nodes;
+ * outputs are the single-cloud outputs concatenated (node_knn_* at row h_node_off[c]); indices stay LOCAL to their cloud
+ * (padding value = that cloud's point count).  Asynchronous on `stream`, no host synchronisation. */
+size_t gr_point_to_node_batch_workspace_bytes(const int64_t* h_point_off, const int64_t* h_node_off, int64_t nclouds);
+int gr_point_to_node_partition_batch(const float* points, const int64_t* h_point_off, const float* nodes,
+                                     const int64_t* h_node_off, int64_t nclouds, int point_limit,
+                                     int64_t* point_to_node, uint8_t* node_masks, int64_t* node_knn_indices,
+                                     uint8_t* node_knn_masks, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,111 @@
+"""The stack-mode (batch of scene pairs) entry points of the per-pair stages must return exactly what the single-pair entry
+points return pair by pair -- same kernels, same arithmetic, same order: bit-equal, floats included.
+    gr_point_to_node_partition_batch   vs gr_point_to_node_partition      (model.py:99-104)
+    gr_superpoint_matching_batch       vs gr_superpoint_matching          (model.py:156-160)
+    gr_lgr_register_seg                vs gr_lgr_register                 (model.py:195-207)
+    gr_ransac_similarity_seg           vs gr_ransac_similarity            (model.py:209-220)
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _c(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_point_to_node_partition_batch_equals_single_calls():
+    from gaussreg_amd.ops import point_to_node_partition, point_to_node_partition_batch
+    rng = np.random.default_rng(3)
+    n_pts = [6000, 5000, 130, 20000]
+    n_nodes = [150, 90, 3, 700]
+    clouds = [(rng.random((n, 3)) * [4, 3, 2.5]).astype(np.float32) for n in n_pts]
+    nodes = [c[rng.choice(len(c), m, replace=False)] + rng.normal(0, 0.02, (m, 3)).astype(np.float32) for c, m in zip(clouds, n_nodes)]
+    nodes[1][5] = [50, 50, 50]  # a superpoint that owns no point: node mask False, an all-padding row
+    got = point_to_node_partition_batch(_c(np.concatenate(clouds)), n_pts, _c(np.concatenate(nodes).astype(np.float32)), n_nodes, 128)
+    po, no = np.cumsum([0] + n_pts), np.cumsum([0] + n_nodes)
+    for i in range(len(n_pts)):
+        want = point_to_node_partition(_c(clouds[i]), _c(nodes[i].astype(np.float32)), 128)
+        assert torch.equal(got[0][po[i]:po[i + 1]], want[0]), f"cloud {i}: point_to_node"
+        assert torch.equal(got[1][no[i]:no[i + 1]], want[1]), f"cloud {i}: node masks"
+        assert torch.equal(got[2][no[i]:no[i + 1]], want[2]), f"cloud {i}: knn indices"
+        assert torch.equal(got[3][no[i]:no[i + 1]], want[3]), f"cloud {i}: knn masks"
+    assert not bool(got[1][no[1] + 5])
+
+
+def test_superpoint_matching_batch_equals_single_calls():
+    from gaussreg_amd.matching import SuperPointMatching
+    g = torch.Generator(device="cuda").manual_seed(5)
+    sizes = [700, 650, 40, 300, 10, 12, 768, 767]                       # (ref, src) of four pairs; 10 x 12 < 256 candidates
+    feats = torch.nn.functional.normalize(torch.randn(sum(sizes), 256, device="cuda", generator=g), dim=1)
+    masks = torch.rand(sum(sizes), device="cuda", generator=g) > 0.1
+    spm = SuperPointMatching(256, True)
+    ri, si, sc, counts = spm.forward_batch(feats, sizes, masks)
+    off = np.cumsum([0] + sizes)
+    for b in range(4):
+        r0, r1, s1 = off[2 * b], off[2 * b + 1], off[2 * b + 2]
+        wr, ws_, wsc = spm(feats[r0:r1], feats[r1:s1], masks[r0:r1], masks[r1:s1])
+        assert counts[b] == wr.shape[0]
+        assert torch.equal(ri[b, :counts[b]], wr) and torch.equal(si[b, :counts[b]], ws_), f"pair {b}"
+        assert torch.equal(sc[b, :counts[b]], wsc), f"pair {b}: scores"
+    assert counts[2] < 256 and counts[0] == 256
+    # without masks, without dual normalisation
+    spm2 = SuperPointMatching(64, False)
+    ri, si, sc, counts = spm2.forward_batch(feats, sizes)
+    for b in range(4):
+        r0, r1, s1 = off[2 * b], off[2 * b + 1], off[2 * b + 2]
+        wr, ws_, wsc = spm2(feats[r0:r1], feats[r1:s1])
+        assert torch.equal(ri[b, :counts[b]], wr) and torch.equal(si[b, :counts[b]], ws_) and torch.equal(sc[b, :counts[b]], wsc)
+
+
+def _patches(rng, P, K, angle, bad=()):
+    Rm = np.array([[np.cos(angle), 0, np.sin(angle)], [0, 1, 0], [-np.sin(angle), 0, np.cos(angle)]])
+    src = rng.random((P, K, 3)) * 3
+    ref = src @ Rm.T + [0.1, 0.2, -0.3] + rng.normal(0, 0.01, (P, K, 3))
+    logits = rng.normal(size=(P, K, K)) - 8.0
+    logits[:, np.arange(K), np.arange(K)] = 4.0 + rng.normal(size=(P, K))
+    for p in bad:
+        logits[p] = -20.0                                              # no entry passes the confidence threshold
+    ls = logits - np.log(np.exp(logits).sum(2, keepdims=True))
+    ls = ((ls + logits - np.log(np.exp(logits).sum(1, keepdims=True))) * 0.5).astype(np.float32)
+    rm, sm = rng.random((P, K)) > 0.2, rng.random((P, K)) > 0.2
+    return ref.astype(np.float32), src.astype(np.float32), rm, sm, ls
+
+
+def test_lgr_and_ransac_batch_equal_single_calls():
+    from gaussreg_amd.matching import LocalGlobalRegistration
+    from gaussreg_amd.registration import registration_with_ransac_batch, registration_with_ransac_from_correspondences
+    rng = np.random.default_rng(17)
+    K = 128
+    per_pair = [60, 1, 256, 9]
+    parts = [_patches(rng, 60, K, 0.4), _patches(rng, 1, K, 0.1, bad=(0,)),      # pair 1: no correspondence at all
+             _patches(rng, 256, K, -0.7), _patches(rng, 9, K, 1.1, bad=range(1, 9))]
+    ref, src, rm, sm, ls = (np.concatenate([p[i] for p in parts]) for i in range(5))
+    lgr = LocalGlobalRegistration(3, 0.1)
+    rc, sc, cs, T, rows = lgr.forward_batch(_c(ref), _c(src), _c(rm), _c(sm), _c(ls), None, per_pair)
+    rows_h = rows.cpu().numpy()
+    assert rows_h[0] == 0 and rows_h[-1] == rc.shape[0] and rows_h[1] == rows_h[2]  # pair 1 is empty
+    poff = np.cumsum([0] + per_pair)
+    singles = []
+    for b in range(4):
+        a, e = poff[b], poff[b + 1]
+        w = lgr(_c(ref[a:e]), _c(src[a:e]), _c(rm[a:e]), _c(sm[a:e]), _c(ls[a:e]), None)
+        singles.append(w)
+        r0, r1 = rows_h[b], rows_h[b + 1]
+        assert r1 - r0 == w[0].shape[0], f"pair {b}: {r1 - r0} vs {w[0].shape[0]} correspondences"
+        assert torch.equal(rc[r0:r1], w[0]) and torch.equal(sc[r0:r1], w[1]) and torch.equal(cs[r0:r1], w[2]), f"pair {b}"
+        assert torch.equal(T[b], w[3]), f"pair {b}: transform\n{T[b]}\n{w[3]}"
+    assert torch.equal(T[1], torch.eye(4, device="cuda"))
+    # RANSAC with scale on the same correspondences, seed = pair index; pair 1 (0 rows) keeps the fallback
+    Tr, stats = registration_with_ransac_batch(sc, rc, rows, fallback_transforms=T, distance_threshold=0.05, ransac_n=5,
+                                               num_iterations=2000, seed=0, return_stats=True)
+    for b in range(4):
+        w = singles[b]
+        if w[0].shape[0] >= 5:
+            want, wst = registration_with_ransac_from_correspondences(w[1], w[0], None, 0.05, 5, 2000, seed=b, return_stats=True)
+            assert torch.equal(Tr[b], want), f"pair {b}: RANSAC transform"
+            assert torch.equal(stats[b], wst)
+        else:
+            assert torch.equal(Tr[b], T[b]) and int(stats[b, 0]) == -1
