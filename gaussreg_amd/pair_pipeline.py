@@ -27,8 +27,9 @@ import torch
 
 from .data import precompute_data_stack_mode
 from .matching import LocalGlobalRegistration, SuperPointMatching
-from .ops import point_to_node_partition
-from .registration import farthest_point_sampling, registration_with_ransac_from_correspondences
+from .ops import point_to_node_partition, point_to_node_partition_batch
+from .registration import (farthest_point_sampling, registration_with_ransac_batch,
+                           registration_with_ransac_from_correspondences)
 from .sinkhorn import LearnableLogOptimalTransport
 
 # experiments/geotransformer.gaussian_splatting.indoor/config.py:78-125
@@ -119,8 +120,13 @@ class PairRegistrar:
     """Holds the stateless operator modules and the descriptors; `register_pairs` runs a batch."""
 
     def __init__(self, device, num_samples=30000, fps_clouds_per_call=24, order="reference", use_ransac=True,
-                 profile=False, pair_streams=4, features="descriptor"):
-        """`pair_streams`: after the batched stages (FPS, pyramid) every pair runs its own short chain of launch-bound
+                 profile=False, pair_streams=0, features="descriptor"):
+        """`pair_streams` = 0 (default): the per-pair stages (point_to_node_partition, SuperPointMatching, correspondences +
+        LocalGlobalRegistration, RANSAC) run for all pairs of a batch through the stack-mode entry points
+        (gr_point_to_node_partition_batch, gr_superpoint_matching_batch, gr_lgr_register_seg, gr_ransac_similarity_seg): two
+        host read-backs per BATCH (match counts, number of correspondences), no host threads.  The results are those of the
+        per-pair path bit for bit (tests/test_gpu_batch_ops.py, tests/test_gpu_pair_pipeline.py).
+        `pair_streams` >= 1 (the round-2 path, kept for comparison): after the batched stages (FPS, pyramid) every pair runs its own short chain of launch-bound
         kernels with two host read-backs (correspondence count, RANSAC result); `pair_streams` host threads, each with
         its own HIP stream, work through the pairs so that one pair's read-back waits while the others' kernels run
         (results are identical to the sequential order: nothing is shared between pairs).  1 = one after the other.
@@ -137,7 +143,7 @@ class PairRegistrar:
         self.device = device
         self.profile = bool(profile)
         self.section_ms = {}
-        self.pair_streams = max(1, int(pair_streams))
+        self.pair_streams = max(0, int(pair_streams))
         self._pool = None
         self._streams = None
         self.num_samples = int(num_samples)
@@ -242,13 +248,43 @@ class PairRegistrar:
                 frame_c = torch.where(is_src[:, None], moved, pts_c)
                 feats_c = torch.nn.functional.normalize(self.coarse_desc(frame_c), p=2, dim=1)
         ctx = (pairs, B, pts_c, pts_f, off_c, off_f, out, feats_c)
-        # ---- stage 1, per pair: point_to_node_partition x 2, (GeometricTransformer), SuperPointMatching, the patches of the
-        #      matched superpoints
-        st1 = [None] * B
-        self._fan_out(lambda b: st1.__setitem__(b, self._match_superpoints(b, ctx)), B)
+        batched = self.pair_streams == 0
+        if batched:
+            # ---- stage 1, all pairs at once through the stack-mode entry points: point_to_node_partition of the 2 B clouds,
+            #      (GeometricTransformer per pair), SuperPointMatching of the B pairs -- ONE host read-back (the match counts)
+            with self._sec("point_to_node"):                            # model.py:99-104
+                _, node_masks, knn_idx, knn_masks = point_to_node_partition_batch(pts_f, len_f, pts_c, len_c, POINT_LIMIT)
+            if self.net is not None:
+                with self._sec("transformer"):                          # model.py:134-148
+                    parts = []
+                    for b in range(B):
+                        r0, r1, s1 = off_c[2 * b], off_c[2 * b + 1], off_c[2 * b + 2]
+                        rf, sf = self.net.transformer(pts_c[r0:r1].unsqueeze(0), pts_c[r1:s1].unsqueeze(0),
+                                                      feats_c[r0:r1].unsqueeze(0), feats_c[r1:s1].unsqueeze(0))
+                        parts += [rf.squeeze(0), sf.squeeze(0)]
+                    feats_cn = torch.nn.functional.normalize(torch.cat(parts, 0), p=2, dim=1)
+                    del parts
+            else:
+                feats_cn = feats_c
+            with self._sec("superpoint_matching"):                      # model.py:152-159
+                ri, si, nsc, K = self.spm.forward_batch(feats_cn, len_c, node_masks)
+            with self._sec("patch_features"):                           # model.py:162-170
+                Kt = torch.tensor(K, device=dev)
+                sel = torch.arange(ri.shape[1], device=dev)[None, :] < Kt[:, None]        # valid matches, pair-major order
+                g_ref = (ri + torch.tensor(off_c[0:2 * B:2], device=dev)[:, None])[sel]   # stacked superpoint indices
+                g_src = (si + torch.tensor(off_c[1:2 * B:2], device=dev)[:, None])[sel]
+                st1_cat = (knn_idx[g_ref], knn_masks[g_ref], knn_idx[g_src], knn_masks[g_src])
+                node_scores_flat = nsc[sel]
+        else:
+            # ---- stage 1, per pair on `pair_streams` host threads: point_to_node_partition x 2, (GeometricTransformer),
+            #      SuperPointMatching, the patches of the matched superpoints
+            st1 = [None] * B
+            self._fan_out(lambda b: st1.__setitem__(b, self._match_superpoints(b, ctx)), B)
+            K = [t[0].shape[0] for t in st1]
+            st1_cat = (torch.cat([t[0] for t in st1]), torch.cat([t[1] for t in st1]),
+                       torch.cat([t[2] for t in st1]), torch.cat([t[3] for t in st1]))
         # ---- stage 2, all pairs at once: patch coordinates -> descriptors -> scores -> log-Sinkhorn.  (One pair at a time
         #      these are 256-workgroup launches behind ~35 host calls; over the batch they fill the machine.)
-        K = [t[0].shape[0] for t in st1]
         k_off = [0]
         for k in K:
             k_off.append(k_off[-1] + k)
@@ -261,8 +297,7 @@ class PairRegistrar:
             n_src = torch.tensor([off_f[2 * b + 2] - off_f[2 * b + 1] for b in range(B)], device=dev)[pid][:, None]
             o_ref = torch.tensor([off_f[2 * b] for b in range(B)], device=dev)[pid][:, None]
             o_src = torch.tensor([off_f[2 * b + 1] for b in range(B)], device=dev)[pid][:, None]
-            rk, rkm = torch.cat([t[0] for t in st1]), torch.cat([t[1] for t in st1])
-            sk, skm = torch.cat([t[2] for t in st1]), torch.cat([t[3] for t in st1])
+            rk, rkm, sk, skm = st1_cat
             rki = torch.where(rk == n_ref, n_f, rk + o_ref)                                # (sum K, 128): local -> stacked index
             ski = torch.where(sk == n_src, n_f, sk + o_src)
             rkp, skp = pts_pad[rki], pts_pad[ski]
@@ -286,9 +321,29 @@ class PairRegistrar:
             with self._sec("sinkhorn"):
                 matching[a:e] = self.ot(scores, rkm[a:e], skm[a:e])[:, :-1, :-1]           # model.py:191-198 (dustbins dropped)
                 del scores
-        # ---- stage 3, per pair: LocalGlobalRegistration, RANSAC, the result row
-        st3 = (pairs, out, rkp, skp, rkm, skm, matching, k_off, [t[4] for t in st1])
-        self._fan_out(lambda b: self._estimate(b, st3), B)
+        if batched:
+            # ---- stage 3, all pairs at once: correspondences + LocalGlobalRegistration (one read-back: the number of
+            #      correspondences, which sizes the outputs), RANSAC with scale, the result rows -- model.py:200-220
+            with self._sec("local_global_registration"):
+                rc, sc, cs, T_lgr, rows = self.lgr.forward_batch(rkp, skp, rkm, skm, matching, node_scores_flat, K)
+            with self._sec("ransac"):
+                T_est = T_lgr
+                if self.use_ransac:                                      # ransac_n = 5 (the estimate the reference keeps)
+                    T_est = registration_with_ransac_batch(sc, rc, rows, T_lgr, 0.05, 5, 10000, seed=0)
+            with self._sec("metrics"):
+                n_corr = (rows[1:] - rows[:-1]).to(torch.float32)
+                out[:, :16] = T_est.reshape(B, 16)
+                out[:, 18] = n_corr
+                if rc.shape[0] > 0:
+                    rid = torch.bucketize(torch.arange(rc.shape[0], device=dev, dtype=torch.int32), rows[1:], right=True)
+                    moved = torch.einsum('nij,nj->ni', T_all[rid, :3, :3], sc) + T_all[rid, :3, 3]
+                    hit = (torch.linalg.norm(moved - rc, dim=1) < 0.1).to(torch.float32)
+                    hits = torch.zeros((B,), dtype=torch.float32, device=dev).index_add_(0, rid.to(torch.int64), hit)
+                    out[:, 19] = torch.where(gt_mask & (n_corr > 0), hits / n_corr.clamp_min(1.0), out[:, 19])
+        else:
+            # ---- stage 3, per pair: LocalGlobalRegistration, RANSAC, the result row
+            st3 = (pairs, out, rkp, skp, rkm, skm, matching, k_off, [t[4] for t in st1])
+            self._fan_out(lambda b: self._estimate(b, st3), B)
         if bool(gt_mask.any()):
             with self._sec("metrics"):
                 # RRE / RTE of all pairs at once (similarity estimate: the scale is stripped before the angle)
@@ -304,7 +359,7 @@ class PairRegistrar:
         """fn(b) for b in range(B): on `pair_streams` host threads, each with its own stream (thread k takes pairs k, k + S,
         ...), or one after the other on the caller's stream."""
         dev = self.device
-        S = 1 if self.profile else min(self.pair_streams, B)
+        S = 1 if self.profile else max(1, min(self.pair_streams, B))
         if S <= 1:
             for b in range(B):
                 fn(b)

@@ -28,6 +28,17 @@ def test_pairs_register_and_streams_do_not_change_results(pairs):
         reg = pair_pipeline.PairRegistrar(dev, pair_streams=S)
         assert torch.equal(reg.register_pairs(pairs), seq)
         assert torch.equal(reg.register_pairs(pairs), seq)      # the pool and its streams are reused
+    # the default: every per-pair stage through the stack-mode entry points (two read-backs per batch, no host threads)
+    batched = pair_pipeline.PairRegistrar(dev)
+    assert batched.pair_streams == 0
+    got = batched.register_pairs(pairs)
+    # transform, RRE, RTE, number of correspondences: bit for bit; the inlier ratio against the ground truth is a metric of
+    # this pipeline (not of the reference) and is summed differently in the batched form
+    assert torch.equal(got[:, :19], seq[:, :19]), (got - seq).abs().max(0).values
+    assert torch.allclose(got[:, 19], seq[:, 19], atol=1e-3)
+    sub = batched.register_pairs(pairs[1:4])       # another batch composition: same correspondences; RANSAC draws with the
+    assert torch.equal(sub[:, 18], seq[1:4, 18])   # pair's position in the batch as seed, so its estimate moves a little
+    assert torch.allclose(sub[:, :16], seq[1:4, :16], atol=2e-2)
 
 
 def test_stage_profile_covers_the_pipeline(pairs):
@@ -71,6 +82,10 @@ def test_network_features_batched_backbone_equals_the_pair_alone(pairs):
     reg = pair_pipeline.PairRegistrar(dev, features="model", pair_streams=2)
     out = reg.register_pairs(pairs[:3])
     assert out.shape == (3, pair_pipeline.RESULT_LEN) and torch.isfinite(out[:, :16]).all()
+    regb = pair_pipeline.PairRegistrar(dev, features="model")          # stack-mode per-pair stages, same weights (seeded)
+    outb = regb.register_pairs(pairs[:3])
+    # (random weights: the estimates are noise and amplify any difference in summation order, so only the contract is checked)
+    assert outb.shape == out.shape and torch.isfinite(outb[:, :16]).all()
     # batched vs alone, on the FPS-sampled clouds of two pairs
     sampled = reg._sample(pairs[:2], 24)
 
