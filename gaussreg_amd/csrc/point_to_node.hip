@@ -26,8 +26,22 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ p
                                                      const float* __restrict__ nodes, int m,
                                                      int64_t* __restrict__ point_to_node,
                                                      int32_t* __restrict__ owner, float* __restrict__ owner_d,
-                                                     int32_t* __restrict__ node_cnt, uint8_t* __restrict__ node_masks) {
+                                                     int32_t* __restrict__ node_cnt, uint8_t* __restrict__ node_masks,
+                                                     const int32_t* __restrict__ point_off,
+                                                     const int32_t* __restrict__ node_off) {
   __shared__ float4 s_nodes[P2N_CHUNK];
+  // stack mode: blockIdx.y = cloud; its points may only go to its own nodes.  `owner` and the node tables use GLOBAL node
+  // ids (node_off[cloud] + local id), point_to_node the local id the reference returns.
+  int pbase = 0, nbase = 0;
+  if (point_off) {
+    pbase = point_off[blockIdx.y];
+    n = point_off[blockIdx.y + 1] - pbase;
+    nbase = node_off[blockIdx.y];
+    m = node_off[blockIdx.y + 1] - nbase;
+    if ((int)blockIdx.x * 256 >= n) return;  // the grid is sized for the largest cloud
+    pts += 3 * (int64_t)pbase;
+    nodes += 3 * (int64_t)nbase;
+  }
   const int i = blockIdx.x * 256 + threadIdx.x;
   float px = 0.f, py = 0.f, pz = 0.f, p2 = 0.f;
   if (i < n) {
@@ -56,12 +70,13 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ p
       }
     }
   }
-  if (i < n) {
-    point_to_node[i] = bm;
-    owner[i] = bm;
-    owner_d[i] = best;
-    atomicAdd(&node_cnt[bm], 1);
-    node_masks[bm] = 1;  // pointcloud_partition.py:88-89 index_fill_(True)
+  if (i < n && m == 0) owner[pbase + i] = -1;  // (stack mode only: a cloud without nodes)
+  if (i < n && m > 0) {
+    point_to_node[pbase + i] = bm;
+    owner[pbase + i] = nbase + bm;
+    owner_d[pbase + i] = best;
+    atomicAdd(&node_cnt[nbase + bm], 1);
+    node_masks[nbase + bm] = 1;  // pointcloud_partition.py:88-89 index_fill_(True)
   }
 }
 
@@ -73,6 +88,7 @@ __global__ __launch_bounds__(256) void scatter_points_kernel(int n, const int32_
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int m = owner[i];
+  if (m < 0) return;
   const int slot = node_start[m] + atomicSub(&node_cnt[m], 1) - 1;
   keys[slot] = ((unsigned long long)__float_as_uint(owner_d[i]) << 32) | (unsigned int)i;  // d >= 0: bits are monotone
 }
@@ -83,9 +99,17 @@ constexpr unsigned long long KEY_INF = ~0ull;
 // one block per node: K smallest (d, index) keys, ascending
 __global__ __launch_bounds__(256) void select_kernel(int n, int K, const int32_t* __restrict__ node_start,
                                                      const unsigned long long* __restrict__ keys,
-                                                     int64_t* __restrict__ knn_idx, uint8_t* __restrict__ knn_mask) {
+                                                     int64_t* __restrict__ knn_idx, uint8_t* __restrict__ knn_mask,
+                                                     const int32_t* __restrict__ point_off,
+                                                     const int32_t* __restrict__ node_off, int nclouds) {
   __shared__ unsigned long long sk[SEL_N];
   const int m = blockIdx.x;
+  int pbase = 0;  // stack mode: keys carry global point indices; the output is local to the node's cloud
+  if (point_off) {
+    const int c = find_batch(node_off, nclouds, m);
+    pbase = point_off[c];
+    n = point_off[c + 1] - pbase;
+  }
   const int a = node_start[m], b = node_start[m + 1];
   // best-K kept in sk[0..K); each round appends up to SEL_N - K fresh keys and re-sorts
   for (int i = threadIdx.x; i < SEL_N; i += 256) sk[i] = KEY_INF;
@@ -118,7 +142,7 @@ __global__ __launch_bounds__(256) void select_kernel(int n, int K, const int32_t
   for (int j = threadIdx.x; j < K; j += 256) {
     const unsigned long long key = sk[j];
     const bool ok = key != KEY_INF;
-    knn_idx[(int64_t)m * K + j] = ok ? (int64_t)(unsigned int)(key & 0xffffffffull) : (int64_t)n;  // :102 pad = N
+    knn_idx[(int64_t)m * K + j] = ok ? (int64_t)((unsigned int)(key & 0xffffffffull) - (unsigned)pbase) : (int64_t)n;  // :102 pad = N
     knn_mask[(int64_t)m * K + j] = ok ? 1 : 0;                                                      // :101
   }
 }
@@ -174,43 +198,83 @@ extern "C" int gr_point_to_node_partition(const float* points, int64_t n, const 
   GR_HIP(hipMemsetAsync(w.node_cnt, 0, sizeof(int32_t) * (m + 1), stream));
   GR_HIP(hipMemsetAsync(node_masks, 0, (size_t)m, stream));
   hipLaunchKernelGGL(assign_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, points, (int)n, nodes, (int)m,
-                     point_to_node, w.owner, w.owner_d, w.node_cnt, node_masks);
+                     point_to_node, w.owner, w.owner_d, w.node_cnt, node_masks, (const int32_t*)nullptr, (const int32_t*)nullptr);
   GR_LAUNCH_CHECK();
   int rc = exclusive_scan_i32(w.node_cnt, w.node_start, m + 1, 1, m + 1, w.scan_ws, nullptr, stream);
   if (rc != GR_OK) return rc;
   hipLaunchKernelGGL(scatter_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (int)n, w.owner,
                      w.owner_d, w.node_start, w.node_cnt, w.keys);
   hipLaunchKernelGGL(select_kernel, dim3((unsigned)m), dim3(256), 0, stream, (int)n, point_limit, w.node_start, w.keys,
-                     node_knn_indices, node_knn_masks);
+                     node_knn_indices, node_knn_masks, (const int32_t*)nullptr, (const int32_t*)nullptr, 0);
   GR_LAUNCH_CHECK();
   return GR_OK;
 }
 
 // Stack mode over `nclouds` (fine cloud, its coarse nodes) pairs -- every cloud of a batch of scene pairs in one call
-// (model.py:99-104 runs the single-cloud form twice per pair).  The clouds are worked one after the other on `stream`
-// with no host synchronisation in between, so one workspace (sized for the largest cloud) serves all of them.  Outputs are
-// the single-cloud outputs concatenated; indices stay LOCAL to their cloud (padding value = that cloud's point count).
+// (model.py:99-104 runs the single-cloud form twice per pair).  The batch is ONE problem for the kernels above: a point may
+// only be assigned to the nodes of its own cloud (grid.y = cloud), the node histogram / scan / scatter run over the stacked
+// node list, every node's selection finds its cloud in the offset table.  Six stream operations for the whole batch, no host
+// synchronisation.  Outputs are the single-cloud outputs concatenated; indices stay LOCAL to their cloud (padding value =
+// that cloud's point count).
+static size_t p2n_batch_bytes(int64_t total_n, int64_t total_m, int64_t nclouds) {
+  return align_up(carve_p2n(nullptr, total_n, total_m).bytes, 256) + 2 * align_up((size_t)(nclouds + 1) * sizeof(int32_t), 256);
+}
+
 extern "C" size_t gr_point_to_node_batch_workspace_bytes(const int64_t* h_point_off, const int64_t* h_node_off,
                                                          int64_t nclouds) {
-  size_t need = 0;
-  if (!h_point_off || !h_node_off) return 0;
-  for (int64_t c = 0; c < nclouds; ++c)
-    need = std::max(need, gr_point_to_node_workspace_bytes(h_point_off[c + 1] - h_point_off[c], h_node_off[c + 1] - h_node_off[c]));
-  return need;
+  if (!h_point_off || !h_node_off || nclouds < 0) return 0;
+  return p2n_batch_bytes(h_point_off[nclouds] - h_point_off[0], h_node_off[nclouds] - h_node_off[0], nclouds);
 }
 
 extern "C" int gr_point_to_node_partition_batch(const float* points, const int64_t* h_point_off, const float* nodes,
                                                 const int64_t* h_node_off, int64_t nclouds, int point_limit,
                                                 int64_t* point_to_node, uint8_t* node_masks, int64_t* node_knn_indices,
                                                 uint8_t* node_knn_masks, void* ws, size_t ws_bytes, void* stream_) {
-  GR_REQUIRE(nclouds >= 0 && h_point_off && h_node_off, "bad arguments");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GR_REQUIRE(nclouds >= 0 && nclouds < 65536 && h_point_off && h_node_off, "bad arguments");
+  GR_REQUIRE(point_limit >= 1 && point_limit <= SEL_N / 2, "point_limit must be in [1, %d]", SEL_N / 2);
+  GR_REQUIRE(h_point_off[0] == 0 && h_node_off[0] == 0, "offsets start at 0");
+  if (nclouds == 0) return GR_OK;
+  int64_t max_n = 0;
   for (int64_t c = 0; c < nclouds; ++c) {
-    const int64_t po = h_point_off[c], n = h_point_off[c + 1] - po, no = h_node_off[c], m = h_node_off[c + 1] - no;
-    GR_REQUIRE(n >= 0 && m >= 0 && po >= 0 && no >= 0, "cloud %lld: offsets must ascend", (long long)c);
-    const int rc = gr_point_to_node_partition(points + 3 * po, n, nodes + 3 * no, m, point_limit, point_to_node + po,
-                                              node_masks + no, node_knn_indices + no * point_limit,
-                                              node_knn_masks + no * point_limit, ws, ws_bytes, stream_);
-    if (rc != GR_OK) return rc;
+    const int64_t n = h_point_off[c + 1] - h_point_off[c], m = h_node_off[c + 1] - h_node_off[c];
+    GR_REQUIRE(n >= 0 && m >= 0, "cloud %lld: offsets must ascend", (long long)c);
+    GR_REQUIRE(m == 0 || n >= point_limit, "cloud %lld: need at least point_limit points (torch.topk would fail too)", (long long)c);
+    max_n = std::max(max_n, n);
   }
+  const int64_t total_n = h_point_off[nclouds], total_m = h_node_off[nclouds];
+  GR_REQUIRE(total_n < (1ll << 31) - 1 && total_m < (1ll << 31) - 1, "bad sizes");
+  if (total_m == 0) return GR_OK;
+  GR_REQUIRE(points && nodes && point_to_node && node_masks && node_knn_indices && node_knn_masks, "null argument");
+  if (!ws || ws_bytes < p2n_batch_bytes(total_n, total_m, nclouds)) {
+    set_error("point_to_node workspace too small");
+    return GR_ERR_WORKSPACE;
+  }
+  P2nWs w = carve_p2n(ws, total_n, total_m);
+  char* tail = static_cast<char*>(ws) + align_up(w.bytes, 256);
+  int32_t* d_po = reinterpret_cast<int32_t*>(tail);
+  int32_t* d_no = reinterpret_cast<int32_t*>(tail + align_up((size_t)(nclouds + 1) * sizeof(int32_t), 256));
+  // the two offset tables go up through pinned per-thread staging; an event says when the copies have left it
+  static thread_local hipEvent_t staged = nullptr;
+  if (staged == nullptr) GR_HIP(hipEventCreateWithFlags(&staged, hipEventDisableTiming));
+  else GR_HIP(hipEventSynchronize(staged));
+  int32_t* stage = static_cast<int32_t*>(pinned_scratch(5, 2 * sizeof(int32_t) * (nclouds + 1)));
+  GR_REQUIRE(stage != nullptr, "pinned staging buffer could not be allocated");
+  for (int64_t c = 0; c <= nclouds; ++c) stage[c] = (int32_t)h_point_off[c], stage[nclouds + 1 + c] = (int32_t)h_node_off[c];
+  GR_HIP(hipMemcpyAsync(d_po, stage, sizeof(int32_t) * (nclouds + 1), hipMemcpyHostToDevice, stream));
+  GR_HIP(hipMemcpyAsync(d_no, stage + nclouds + 1, sizeof(int32_t) * (nclouds + 1), hipMemcpyHostToDevice, stream));
+  GR_HIP(hipEventRecord(staged, stream));
+  GR_HIP(hipMemsetAsync(w.node_cnt, 0, sizeof(int32_t) * (total_m + 1), stream));
+  GR_HIP(hipMemsetAsync(node_masks, 0, (size_t)total_m, stream));
+  hipLaunchKernelGGL(assign_kernel, dim3((unsigned)((max_n + 255) / 256), (unsigned)nclouds), dim3(256), 0, stream, points, 0,
+                     nodes, 0, point_to_node, w.owner, w.owner_d, w.node_cnt, node_masks, d_po, d_no);
+  GR_LAUNCH_CHECK();
+  int rc = exclusive_scan_i32(w.node_cnt, w.node_start, total_m + 1, 1, total_m + 1, w.scan_ws, nullptr, stream);
+  if (rc != GR_OK) return rc;
+  hipLaunchKernelGGL(scatter_points_kernel, dim3((unsigned)((total_n + 255) / 256)), dim3(256), 0, stream, (int)total_n,
+                     w.owner, w.owner_d, w.node_start, w.node_cnt, w.keys);
+  hipLaunchKernelGGL(select_kernel, dim3((unsigned)total_m), dim3(256), 0, stream, 0, point_limit, w.node_start, w.keys,
+                     node_knn_indices, node_knn_masks, d_po, d_no, (int)nclouds);
+  GR_LAUNCH_CHECK();
   return GR_OK;
 }
