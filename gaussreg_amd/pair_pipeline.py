@@ -120,7 +120,7 @@ class PairRegistrar:
     """Holds the stateless operator modules and the descriptors; `register_pairs` runs a batch."""
 
     def __init__(self, device, num_samples=30000, fps_clouds_per_call=24, order="reference", use_ransac=True,
-                 profile=False, pair_streams=0, features="descriptor"):
+                 profile=False, pair_streams=0, features="descriptor", transformer_batch=8):
         """`pair_streams` = 0 (default): the per-pair stages (point_to_node_partition, SuperPointMatching, correspondences +
         LocalGlobalRegistration, RANSAC) run for all pairs of a batch through the stack-mode entry points
         (gr_point_to_node_partition_batch, gr_superpoint_matching_batch, gr_lgr_register_seg, gr_ransac_similarity_seg): two
@@ -144,6 +144,7 @@ class PairRegistrar:
         self.profile = bool(profile)
         self.section_ms = {}
         self.pair_streams = max(0, int(pair_streams))
+        self.transformer_batch = max(1, int(transformer_batch))
         self._pool = None
         self._streams = None
         self.num_samples = int(num_samples)
@@ -256,12 +257,24 @@ class PairRegistrar:
                 _, node_masks, knn_idx, knn_masks = point_to_node_partition_batch(pts_f, len_f, pts_c, len_c, POINT_LIMIT)
             if self.net is not None:
                 with self._sec("transformer"):                          # model.py:134-148
+                    # `transformer_batch` pairs at a time as one padded batch (one pair alone is ~150 launch-bound kernels
+                    # on 2 x ~770 superpoints: host-bound): the embedding and the self-attention run per cloud at its true
+                    # size, the projections / cross-attention / feed-forward layers over the padded stack with key masks
+                    from torch.nn.utils.rnn import pad_sequence
                     parts = []
-                    for b in range(B):
-                        r0, r1, s1 = off_c[2 * b], off_c[2 * b + 1], off_c[2 * b + 2]
-                        rf, sf = self.net.transformer(pts_c[r0:r1].unsqueeze(0), pts_c[r1:s1].unsqueeze(0),
-                                                      feats_c[r0:r1].unsqueeze(0), feats_c[r1:s1].unsqueeze(0))
-                        parts += [rf.squeeze(0), sf.squeeze(0)]
+                    for a in range(0, B, self.transformer_batch):
+                        bs = list(range(a, min(B, a + self.transformer_batch)))
+                        rl = [off_c[2 * b + 1] - off_c[2 * b] for b in bs]
+                        sl = [off_c[2 * b + 2] - off_c[2 * b + 1] for b in bs]
+                        rp = pad_sequence([pts_c[off_c[2 * b]:off_c[2 * b + 1]] for b in bs], batch_first=True)
+                        sp = pad_sequence([pts_c[off_c[2 * b + 1]:off_c[2 * b + 2]] for b in bs], batch_first=True)
+                        rfe = pad_sequence([feats_c[off_c[2 * b]:off_c[2 * b + 1]] for b in bs], batch_first=True)
+                        sfe = pad_sequence([feats_c[off_c[2 * b + 1]:off_c[2 * b + 2]] for b in bs], batch_first=True)
+                        rmask = torch.arange(rp.shape[1], device=dev)[None, :] >= torch.tensor(rl, device=dev)[:, None]
+                        smask = torch.arange(sp.shape[1], device=dev)[None, :] >= torch.tensor(sl, device=dev)[:, None]
+                        rf, sf = self.net.transformer(rp, sp, rfe, sfe, rmask, smask, ref_lengths=rl, src_lengths=sl)
+                        for i in range(len(bs)):
+                            parts += [rf[i, :rl[i]], sf[i, :sl[i]]]
                     feats_cn = torch.nn.functional.normalize(torch.cat(parts, 0), p=2, dim=1)
                     del parts
             else:

@@ -138,10 +138,10 @@ class RPEAttentionLayer(nn.Module):
 
     @torch.no_grad()
     def forward(self, input_states, memory_states, position_states, memory_weights=None, memory_masks=None,
-                attention_factors=None):
+                attention_factors=None, lengths=None):
         hidden, scores = self.attention(input_states, memory_states, memory_states, position_states,
                                         key_weights=memory_weights, key_masks=memory_masks,
-                                        attention_factors=attention_factors)
+                                        attention_factors=attention_factors, lengths=lengths)
         return self.norm(self.dropout(self.linear(hidden)) + input_states), scores
 
 
@@ -153,9 +153,9 @@ class RPETransformerLayer(nn.Module):
 
     @torch.no_grad()
     def forward(self, input_states, memory_states, position_states, memory_weights=None, memory_masks=None,
-                attention_factors=None):
+                attention_factors=None, lengths=None):
         hidden, scores = self.attention(input_states, memory_states, position_states, memory_weights=memory_weights,
-                                        memory_masks=memory_masks, attention_factors=attention_factors)
+                                        memory_masks=memory_masks, attention_factors=attention_factors, lengths=lengths)
         return self.output(hidden), scores
 
 
@@ -175,12 +175,15 @@ class RPEConditionalTransformer(nn.Module):
         self.parallel = parallel
 
     @torch.no_grad()
-    def forward(self, feats0, feats1, embeddings0, embeddings1, masks0=None, masks1=None):
+    def forward(self, feats0, feats1, embeddings0, embeddings1, masks0=None, masks1=None, lengths0=None, lengths1=None):
+        """lengths0 / lengths1 (not in the reference): a padded stack of clouds of different sizes -- the self blocks then
+        take one (n_b, n_b, C) embedding per element (lists) and run every element at its true size (RPEMultiHeadAttention);
+        the cross blocks use masks0 / masks1 (True = padding) as the reference does."""
         kept = []
         for layer, block in zip(self.layers, self.blocks):
             if block == 'self':
-                feats0, scores0 = layer(feats0, feats0, embeddings0, memory_masks=masks0)
-                feats1, scores1 = layer(feats1, feats1, embeddings1, memory_masks=masks1)
+                feats0, scores0 = layer(feats0, feats0, embeddings0, memory_masks=masks0, lengths=lengths0)
+                feats1, scores1 = layer(feats1, feats1, embeddings1, memory_masks=masks1, lengths=lengths1)
             elif self.parallel:
                 # both directions read the features of the previous layer
                 out0, scores0 = layer(feats0, feats1, memory_masks=masks1)
@@ -208,10 +211,21 @@ class GeometricTransformer(nn.Module):
         self.out_proj = nn.Linear(hidden_dim, output_dim)
 
     @torch.no_grad()
-    def forward(self, ref_points, src_points, ref_feats, src_feats, ref_masks=None, src_masks=None):
-        """(B,N,3), (B,M,3), (B,N,Cin), (B,M,Cin) -> (B,N,Cout), (B,M,Cout)."""
-        ref_embeddings = self.embedding(ref_points)
-        src_embeddings = self.embedding(src_points)
+    def forward(self, ref_points, src_points, ref_feats, src_feats, ref_masks=None, src_masks=None, ref_lengths=None,
+                src_lengths=None):
+        """(B,N,3), (B,M,3), (B,N,Cin), (B,M,Cin) -> (B,N,Cout), (B,M,Cout).
+
+        ref_lengths / src_lengths (not in the reference; lists of B ints, together with ref_masks / src_masks = True on the
+        padding): several scene pairs of different sizes as one padded batch -- the structure embedding and the
+        self-attention run per cloud at its true size (no padded point can become a neighbour or a key), the cross-attention
+        masks the padding; the rows of the real superpoints are those of the pair alone up to GEMM summation order."""
+        if ref_lengths is not None:
+            ref_embeddings = [self.embedding(ref_points[b:b + 1, :n])[0] for b, n in enumerate(ref_lengths)]
+            src_embeddings = [self.embedding(src_points[b:b + 1, :n])[0] for b, n in enumerate(src_lengths)]
+        else:
+            ref_embeddings = self.embedding(ref_points)
+            src_embeddings = self.embedding(src_points)
         ref_feats, src_feats = self.transformer(self.in_proj(ref_feats), self.in_proj(src_feats), ref_embeddings,
-                                                src_embeddings, masks0=ref_masks, masks1=src_masks)
+                                                src_embeddings, masks0=ref_masks, masks1=src_masks, lengths0=ref_lengths,
+                                                lengths1=src_lengths)
         return self.out_proj(ref_feats), self.out_proj(src_feats)

@@ -109,3 +109,30 @@ def test_lgr_and_ransac_batch_equal_single_calls():
             assert torch.equal(stats[b], wst)
         else:
             assert torch.equal(Tr[b], T[b]) and int(stats[b, 0]) == -1
+
+
+def test_transformer_padded_batch_equals_pairs_alone():
+    """GeometricTransformer over several pairs of different sizes as one padded batch (ref_lengths / src_lengths + masks):
+    the rows of the real superpoints are those of each pair alone (up to the summation order of the batched GEMMs)."""
+    from gaussreg_amd.transformer import GeometricTransformer
+    torch.manual_seed(7)
+    net = GeometricTransformer(64, 32, 64, 4, ['self', 'cross', 'self', 'cross'], 0.2, 15, 3, reduction_a='max').cuda().eval()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    rl, sl = [150, 97, 200], [140, 201, 33]
+    pts_r = [torch.rand(n, 3, device="cuda", generator=g) * 3 for n in rl]
+    pts_s = [torch.rand(n, 3, device="cuda", generator=g) * 3 for n in sl]
+    f_r = [torch.randn(n, 64, device="cuda", generator=g) for n in rl]
+    f_s = [torch.randn(n, 64, device="cuda", generator=g) for n in sl]
+    from torch.nn.utils.rnn import pad_sequence
+    rp, sp = pad_sequence(pts_r, batch_first=True), pad_sequence(pts_s, batch_first=True)
+    rf, sf = pad_sequence(f_r, batch_first=True), pad_sequence(f_s, batch_first=True)
+    rm = torch.arange(rp.shape[1], device="cuda")[None, :] >= torch.tensor(rl, device="cuda")[:, None]
+    sm = torch.arange(sp.shape[1], device="cuda")[None, :] >= torch.tensor(sl, device="cuda")[:, None]
+    with torch.no_grad():
+        got_r, got_s = net(rp, sp, rf, sf, rm, sm, ref_lengths=rl, src_lengths=sl)
+        for b in range(3):
+            want_r, want_s = net(pts_r[b][None], pts_s[b][None], f_r[b][None], f_s[b][None])
+            scale = float(want_r.abs().max())
+            assert float((got_r[b, :rl[b]] - want_r[0]).abs().max()) <= 2e-5 * scale, b
+            assert float((got_s[b, :sl[b]] - want_s[0]).abs().max()) <= 2e-5 * scale, b
+        assert torch.isfinite(got_r).all() and torch.isfinite(got_s).all()
