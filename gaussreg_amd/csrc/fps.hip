@@ -513,6 +513,11 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
       } else {
         kk[0] = mykey;  // a single workgroup: one key per lane (lanes >= M hold 0)
       }
+      // every point already at distance zero (more samples asked for than the cloud has distinct points): the arg-max is the
+      // lowest index, and stays it -- the sequential algorithm returns index 0 from here on
+      if ((wave_max_u64(kk[0]) >> 32) == 0ull && !__any(bad)) {
+        if (lane == 0) s_c = -1;
+      } else {
       // B: nothing outside the published keys exceeds the largest workgroup bound
       unsigned long long bound = wave_max_u64(sb);
       int cnt = 0;
@@ -540,9 +545,15 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
         if (lane == 0) s_abort = 1;
       }
       if (lane == 0) s_c = total, s_bound = bound;
+      }
     }
     __syncthreads();
     if (s_abort) return;
+    if (s_c < 0) {
+      if (part == 0)
+        for (int i = count + (int)threadIdx.x; i < k; i += FPS_T) out[o0 + i] = 0;
+      return;
+    }
     // ---- 4. all waves: which candidates are in a conflict (some other candidate within sqrt(d) of either of the two), and
     // every candidate's rank among the keys on entry.  Thread = (candidate i, share of the partners j); shares are
     // multiples of four partners, the tail of E is padded with points at infinity (no conflict, key 0).

@@ -294,6 +294,23 @@ def test_fps_long_runs_with_large_candidate_sets(n, batch, k):
         assert np.array_equal(got[b].cpu().numpy(), M.farthest_point_sampling(clouds[b].cpu().numpy(), k, 5 * b)), f"cloud {b}"
 
 
+def test_fps_single_workgroup_exhaustion_and_identical_points():
+    """One workgroup per cloud (no exchange); every point sampled (the last rounds run on zero distances: lowest index
+    first); a cloud of identical points (all distances zero after the first sample, no candidate in conflict)."""
+    from gaussreg_amd.registration import farthest_point_sampling
+    from oracle import matching_np as M
+    rng = np.random.default_rng(21)
+    a = rng.random((1500, 3)).astype(np.float32)
+    b = np.repeat(rng.random((1, 3)).astype(np.float32), 900, 0)
+    c = rng.random((4000, 3)).astype(np.float32)
+    c[1000:3000] = c[:2000]                                   # half of the cloud is a copy of the other half
+    got = farthest_point_sampling(_c(np.concatenate([a, b, c])), [1500, 900, 4000], [1500, 200, 3000], start_indices=[7, 0, 3])
+    assert np.array_equal(got[0].cpu().numpy(), M.farthest_point_sampling(a, 1500, 7))
+    assert np.array_equal(got[1].cpu().numpy(), M.farthest_point_sampling(b, 200, 0))
+    assert np.array_equal(got[2].cpu().numpy(), M.farthest_point_sampling(c, 3000, 3))
+    assert sorted(got[0].cpu().tolist()) == list(range(1500))
+
+
 @pytest.mark.parametrize("n,batch,k", [(7000, 1, 300), (7000, 2, 300), (50000, 32, 120), (200000, 8, 400)])
 def test_fps_pruned_rounds_stay_exact(n, batch, k):
     """The bucket pruning (Morton-ordered slabs, per-wave boxes) must not change a single index: clouds with empty waves
