@@ -1,0 +1,17 @@
+"""Dev tool: the descriptor-mode pair path, 64 pairs per call (for rocprofv3 --kernel-trace --stats): prints the wall time
+per pair so that the kernel total of the trace can be set against it."""
+import sys, os, time, torch
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+from gaussreg_amd import pair_pipeline
+dev = torch.device("cuda", 0)
+pairs = [pair_pipeline.synthetic_room_pair(i, 200000, dev) for i in range(64)]
+reg = pair_pipeline.PairRegistrar(dev)
+reg.register_pairs(pairs[:4])
+reg.register_pairs(pairs)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(2):
+    reg.register_pairs(pairs)
+torch.cuda.synchronize()
+print("wall ms per pair", (time.perf_counter() - t0) / 128 * 1e3)
+reg.close()
