@@ -294,6 +294,21 @@ def test_fps_long_runs_with_large_candidate_sets(n, batch, k):
         assert np.array_equal(got[b].cpu().numpy(), M.farthest_point_sampling(clouds[b].cpu().numpy(), k, 5 * b)), f"cloud {b}"
 
 
+def test_fps_clustered_cloud_many_candidates_in_conflict():
+    """300 tight clusters far apart: once every cluster has a sample, the candidates of a round sit in the same clusters and
+    lie within each other's reach -- the exact chain then runs over (nearly) the whole candidate set, more than one
+    candidate per lane (the LDS form of the conflict resolution), and many candidates end a round rejected."""
+    from gaussreg_amd.registration import farthest_point_sampling
+    from oracle import matching_np as M
+    rng = np.random.default_rng(33)
+    centres = rng.random((300, 3)) * 40.0
+    pts = (centres[:, None, :] + rng.normal(0, 0.01, (300, 600, 3))).reshape(-1, 3).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    got = farthest_point_sampling(_c(np.concatenate([pts, pts[::-1]])), [len(pts)] * 2, [1500, 900], start_indices=[11, 0])
+    assert np.array_equal(got[0].cpu().numpy(), M.farthest_point_sampling(pts, 1500, 11))
+    assert np.array_equal(got[1].cpu().numpy(), M.farthest_point_sampling(pts[::-1].copy(), 900, 0))
+
+
 def test_fps_single_workgroup_exhaustion_and_identical_points():
     """One workgroup per cloud (no exchange); every point sampled (the last rounds run on zero distances: lowest index
     first); a cloud of identical points (all distances zero after the first sample, no candidate in conflict)."""
