@@ -87,7 +87,7 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
                                                         const uint8_t* __restrict__ row_masks,
                                                         const uint8_t* __restrict__ col_masks,
                                                         const float* __restrict__ alpha_p, int iters, float inf,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, int scaling_form) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int R = M + 1, C = N + 1;
   const int ld = sinkhorn_ld(C);
@@ -96,12 +96,17 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
   float* v = u + R;
   float* log_mu = v + C;
   float* log_nu = log_mu + R;
-  int* cnt = reinterpret_cast<int*>(log_nu + C);
+  int* cnt = reinterpret_cast<int*>(log_nu + C);      // [0], [1]: valid rows / columns; [2]: the scaling form gave up
+  // scaling form: row maxima, exp(v - c) grouped by part, exp(u + rmax - c'), u + rmax -- 16-byte aligned (read as float4)
+  // (an offset from S, not a pointer rounded through an integer: that would turn every access into a flat load)
+  float* rmax = S + (((size_t)R * ld + 2 * (size_t)R + 2 * (size_t)C + 4 + 3) & ~(size_t)3);
+  float* Ep = rmax + SK_MAXD;
+  float* Fv = Ep + SK_MAXD;
   const int b = blockIdx.x;
   const float alpha = alpha_p[0];
   const uint8_t* rm = row_masks ? row_masks + (int64_t)b * M : nullptr;
   const uint8_t* cm = col_masks ? col_masks + (int64_t)b * N : nullptr;
-  if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+  if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
   __syncthreads();
   // valid row / column counts (learnable_sinkhorn.py:50-51)
   int nr = 0, nc = 0;
@@ -138,7 +143,157 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
   const int row_len = idx < R ? (C - part + SK_PARTS - 1) / SK_PARTS : 0;       // elements part, part + 4, ... of a row
   const int i0 = part * SK_PER;
   const int col_len = idx < C ? max(0, min(R, i0 + SK_PER) - i0) : 0;          // rows [36 part, 36 part + 36) of a column
-  for (int it = 0; it < iters; ++it) {
+  // ---- the same iteration in scaling form.  u = log_mu - logsumexp_j(S + v) is, for any constant c,
+  //   u_i = log_mu_i - (rmax_i + c + log sum_j K_ij exp(v_j - c)),  K_ij = exp(S_ij - rmax_i)  (rmax_i = max_j S_ij),
+  // and likewise v_j = log_nu_j - (c' + log sum_i K_ij exp(u_i + rmax_i - c')).  K does not change: every lane keeps its
+  // 36 elements of the row slice and its 36 of the column slice in registers, and a half-iteration is 36 FMAs with the
+  // 129 exponentials exp(v_j - c) / exp(u_i + rmax_i - c') (one per row / column, written by the lane that owns it) -- the
+  // log-domain form evaluates 129 x 129 exponentials per half-iteration.  c, c' = the maxima of the PREVIOUS iteration's
+  // vectors (any constant is exact; these keep the exponents near zero without a third barrier).  Masked rows / columns
+  // (scores = -inf = -1e12) have K = 0 and keep u = v = 0: their outputs are the -1e12 stand-ins either way.  If a sum
+  // leaves the normal range (score ranges beyond ~80) the matrix is redone in the log domain below.
+  bool scaled = false;
+  if (scaling_form && iters > 0) {
+    float kr[SK_PER], kc[SK_PER];
+    constexpr int NSIDE = (SK_MAXD + WAVE - 1) / WAVE;  // elements per lane of a row / column reduced by a whole wave
+    float ks[NSIDE];                                    // wave 0: the side row's K, wave 1: the side column's
+    static_assert(SK_MAXD - SK_MAIN <= 2 * (SK_T / WAVE), "one side row per wave");
+    const bool row_ok = idx < R && (idx >= M || !rm || rm[idx]);
+    const bool col_ok = idx < C && (idx >= N || !cm || cm[idx]);
+    // rows / columns beyond the 128 that own four lanes (the dustbins at the demo shape): side row r_side by wave
+    // `wv` (even waves), side column c_side by the odd waves -- the two side reductions of an iteration sit on different waves
+    const int r_side = SK_MAIN + wv / 2, c_side = SK_MAIN + wv / 2;
+    const bool has_rside = (wv & 1) == 0 && r_side < R, has_cside = (wv & 1) == 1 && c_side < C;
+    {
+      const float* row = S + idx * ld + part;
+      float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+      for (int t = 0; t < SK_PER; ++t) {
+        kr[t] = t < row_len ? row[SK_PARTS * t] : -INFINITY;
+        m4[t & 3] = fmaxf(m4[t & 3], kr[t]);
+      }
+      float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+      mx = fmaxf(mx, quad_xor1(mx));
+      mx = fmaxf(mx, quad_xor2(mx));
+#pragma unroll
+      for (int t = 0; t < SK_PER; ++t) kr[t] = (t < row_len && row_ok) ? __expf(kr[t] - mx) : 0.f;  // masked columns: exp(-1e12 - mx) = 0
+      if (part == 0 && idx < R) rmax[idx] = row_ok ? mx : 0.f;
+      for (int r = SK_MAIN + wv; r < R; r += SK_T / WAVE) {  // (rows beyond M are never masked)
+        float m = -INFINITY;
+        for (int k = lane; k < C; k += WAVE) m = fmaxf(m, S[(size_t)r * ld + k]);
+        m = wave_max_f32_dpp(m);
+        if (lane == 0) rmax[r] = m;
+      }
+      // v = 0: exp(v) = 1 on the live columns
+      for (int j = threadIdx.x; j < SK_MAXD; j += SK_T) {
+        const bool live = j < C && (j >= N || !cm || cm[j]);
+        Ep[(j & 3) * SK_PER + (j >> 2)] = live ? 1.f : 0.f;
+        Fv[j] = 0.f;
+      }
+    }
+    __syncthreads();
+    {
+      const float* col = S + (size_t)i0 * ld + idx;
+#pragma unroll
+      for (int t = 0; t < SK_PER; ++t) {
+        const int i = i0 + t;
+        const bool live = t < col_len && col_ok && (i >= M || !rm || rm[i]);
+        kc[t] = live ? __expf(col[(size_t)t * ld] - rmax[min(i, R - 1)]) : 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < NSIDE; ++t) {
+        const int k = lane + t * WAVE;
+        ks[t] = 0.f;
+        if (has_rside && k < C) ks[t] = __expf(S[(size_t)r_side * ld + k] - rmax[r_side]);  // masked columns give 0
+        if (has_cside && k < R && (k >= M || !rm || rm[k])) ks[t] = __expf(S[(size_t)k * ld + c_side] - rmax[k]);
+      }
+    }
+    const float cw = norm;  // reference point of exp(u + rmax - cw): u + rmax = log_mu - log(row sum) stays near log_mu
+    bool bad = false;
+    for (int it = 0; it < iters; ++it) {
+      {  // rows
+        const float4* e4 = reinterpret_cast<const float4*>(Ep + part * SK_PER);
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t4 = 0; t4 < SK_PER / 4; ++t4) {
+          const float4 e = e4[t4];
+          s4[0] = fmaf(kr[4 * t4], e.x, s4[0]);
+          s4[1] = fmaf(kr[4 * t4 + 1], e.y, s4[1]);
+          s4[2] = fmaf(kr[4 * t4 + 2], e.z, s4[2]);
+          s4[3] = fmaf(kr[4 * t4 + 3], e.w, s4[3]);
+        }
+        float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        sum += quad_xor1(sum);
+        sum += quad_xor2(sum);
+        if (part == 0 && row_ok) {
+          bad = bad || !(sum > 1e-30f && sum < 1e30f);
+          const float w = log_mu[idx] - __logf(sum);  // = u + rmax  (v's reference point is 0)
+          u[idx] = w - rmax[idx];
+          Fv[idx] = __expf(w - cw);
+        }
+        if (has_rside) {
+          float acc = 0.f;
+#pragma unroll
+          for (int t = 0; t < NSIDE; ++t) {
+            const int k = min(lane + t * WAVE, SK_MAXD - 1);
+            acc = fmaf(ks[t], Ep[(k & 3) * SK_PER + (k >> 2)], acc);
+          }
+          acc = wave_sum_f32_dpp(acc);
+          if (lane == 0) {
+            bad = bad || !(acc > 1e-30f && acc < 1e30f);
+            const float w = log_mu[r_side] - __logf(acc);
+            u[r_side] = w - rmax[r_side];
+            Fv[r_side] = __expf(w - cw);
+          }
+        }
+      }
+      __syncthreads();
+      {  // columns
+        const float4* f4 = reinterpret_cast<const float4*>(Fv + i0);
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t4 = 0; t4 < SK_PER / 4; ++t4) {
+          const float4 f = f4[t4];
+          s4[0] = fmaf(kc[4 * t4], f.x, s4[0]);
+          s4[1] = fmaf(kc[4 * t4 + 1], f.y, s4[1]);
+          s4[2] = fmaf(kc[4 * t4 + 2], f.z, s4[2]);
+          s4[3] = fmaf(kc[4 * t4 + 3], f.w, s4[3]);
+        }
+        float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        sum += quad_xor1(sum);
+        sum += quad_xor2(sum);
+        // (Ep was last read by the row pass, before the barrier above; Fv is not written here: no hazard)
+        if (part == 0 && col_ok) {
+          bad = bad || !(sum > 1e-30f && sum < 1e30f);
+          const float vn = log_nu[idx] - (cw + __logf(sum));
+          v[idx] = vn;
+          Ep[(idx & 3) * SK_PER + (idx >> 2)] = __expf(vn);
+        }
+        if (has_cside) {
+          float acc = 0.f;
+#pragma unroll
+          for (int t = 0; t < NSIDE; ++t) acc = fmaf(ks[t], Fv[min(lane + t * WAVE, SK_MAXD - 1)], acc);
+          acc = wave_sum_f32_dpp(acc);
+          if (lane == 0) {
+            bad = bad || !(acc > 1e-30f && acc < 1e30f);
+            const float vn = log_nu[c_side] - (cw + __logf(acc));
+            v[c_side] = vn;
+            Ep[(c_side & 3) * SK_PER + (c_side >> 2)] = __expf(vn);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (bad) cnt[2] = 1;
+    __syncthreads();
+    scaled = cnt[2] == 0;
+    if (!scaled) {  // start over in the log domain
+      for (int i = threadIdx.x; i < R; i += SK_T) u[i] = 0.f;
+      for (int j = threadIdx.x; j < C; j += SK_T) v[j] = 0.f;
+      __syncthreads();
+    }
+  }
+  for (int it = 0; it < (scaled ? 0 : iters); ++it) {
     {
       const float* row = S + idx * ld + part;
       float x[SK_PER];
@@ -195,7 +350,7 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
 
 size_t sinkhorn_lds(int M, int N) {
   const int R = M + 1, C = N + 1, ld = sinkhorn_ld(C);
-  return sizeof(float) * ((size_t)R * ld + 2 * R + 2 * C) + 64;
+  return sizeof(float) * ((size_t)R * ld + 2 * R + 2 * C + 4 * SK_MAXD) + 96;
 }
 
 }  // namespace
@@ -219,9 +374,11 @@ extern "C" int gr_sinkhorn(const float* scores, int64_t batch, int64_t m, int64_
   if (lds > 64 * 1024)
     GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  // GR_SINKHORN_LOG_DOMAIN=1: every iteration as logsumexp (the fall-back of the scaling form, see the kernel)
+  static const int scaling_form = (getenv("GR_SINKHORN_LOG_DOMAIN") && atoi(getenv("GR_SINKHORN_LOG_DOMAIN")) != 0) ? 0 : 1;
   KernelTimer timer("sinkhorn", stream);
   hipLaunchKernelGGL(sinkhorn_kernel, dim3((unsigned)batch), dim3(SK_T), lds, stream, scores, (int)m, (int)n, row_masks,
-                     col_masks, alpha_dev, num_iterations, inf, out);
+                     col_masks, alpha_dev, num_iterations, inf, out, scaling_form);
   GR_LAUNCH_CHECK();
   return GR_OK;
 }

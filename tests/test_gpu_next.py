@@ -47,6 +47,26 @@ def test_sinkhorn_demo_shape_vs_oracle():
     assert_rel_scale(got, want, 1e-5, "sinkhorn 16x128x128 vs oracle", mask=live)
 
 
+@pytest.mark.parametrize("sigma", [6.0, 40.0])
+def test_sinkhorn_wide_score_ranges(sigma):
+    """The iteration runs in scaling form (K = exp(S - rowmax) kept in registers, 36 FMAs per half-iteration instead of
+    129 x 129 exponentials) and falls back to logsumexp iterations for a matrix whose sums leave the normal range: scores
+    spread over +-25 stay in the fast form, +-150 must take the fall-back -- both against the float64 oracle."""
+    from gaussreg_amd.sinkhorn import LearnableLogOptimalTransport
+    from oracle import matching_np as M
+    rng = np.random.default_rng(5)
+    B, K = 12, 128
+    s = (rng.normal(size=(B, K, K)) * sigma).astype(np.float32)
+    rm, cm = rng.random((B, K)) > 0.3, rng.random((B, K)) > 0.3
+    rm[3] = True
+    cm[3] = True
+    want = M.sinkhorn(s, rm, cm, alpha=1.0, num_iterations=100)
+    got = LearnableLogOptimalTransport(100)(_c(s), _c(rm), _c(cm)).cpu().numpy()
+    live = want > -1e6
+    assert np.isfinite(got).all()
+    assert_rel_scale(got, want, 1e-5, f"sinkhorn, scores ~ N(0, {sigma}^2)", mask=live)
+
+
 def test_kpconv_vs_reference_golden():
     from geotransformer.modules.kpconv import KPConv, maxpool, nearest_upsample
     g = load_golden("next_rows.npz")
