@@ -333,7 +333,8 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
   static_assert(M % KPL == 0 && FPS_SLOT_STRIDE > M, "slot layout");
   constexpr int UN = PPT <= 10 ? 4 : 2;  // partners in flight in stages 4 and 6: the large slabs have no registers to spare
   extern __shared__ int s_perm[];  // [PPT][FPS_T] original (cloud-local) index of every point this workgroup holds
-  __shared__ unsigned long long s_wtop[NW * MW];
+  __shared__ __attribute__((aligned(16))) unsigned long long s_wtop[NW * MW];
+  __shared__ unsigned long long s_sel[WAVE];                      // the same keys in descending order
   __shared__ unsigned long long s_wbound[NW];
   __shared__ __attribute__((aligned(16))) float4 s_acc[EC];   // the samples accepted in the last round
   __shared__ __attribute__((aligned(16))) float4 s_cand[EC + WAVE];  // E: {x, y, z, d}; padded for stage 4
@@ -461,16 +462,31 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
     if (wv == 0) {
       static_assert(NW * MW == WAVE, "one wave-level candidate per lane");
       static_assert(EC == 4 * WAVE && KPL > EC / WAVE, "E holds at most EC / 64 keys per polling lane once B is raised");
-      unsigned long long v0 = s_wtop[lane];
-      unsigned long long bnd = lane < NW ? s_wbound[lane] : 0ull;
-      unsigned long long mykey = 0ull;  // lane r < M ends up with the r-th largest key
-#pragma unroll
-      for (int r = 0; r < M; ++r) {
-        const unsigned long long w = wave_max_u64(v0);
-        if (lane == r) mykey = w;
-        if (v0 == w) v0 = 0ull;
+      // the 64 wave-level candidates, one per lane, ranked by counting (keys of points are unique; empty slots are 0): 32
+      // independent LDS reads and 64 compares per lane instead of M dependent wave maxima (1.7 us for M = 16)
+      const unsigned long long v0 = s_wtop[lane];
+      int rk = 0;
+      {
+        const ulonglong2* w2 = reinterpret_cast<const ulonglong2*>(s_wtop);
+#pragma unroll 8
+        for (int t = 0; t < WAVE / 2; ++t) {
+          const ulonglong2 q = w2[t];
+          rk += (int)(q.x > v0) + (int)(q.y > v0);
+        }
       }
-      bnd = wave_max_u64(v0 > bnd ? v0 : bnd);
+      s_sel[lane] = 0ull;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (v0 != 0ull) s_sel[rk] = v0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      static_assert(M < WAVE, "s_sel[M] is the largest key a workgroup holds back");
+      const unsigned long long mykey = lane < M ? s_sel[lane] : 0ull;  // lane r < M: the r-th largest key
+      unsigned long long bnd = wave_max_u64(lane < NW ? s_wbound[lane] : 0ull);
+      {
+        const unsigned long long rest = s_sel[M];
+        bnd = rest > bnd ? rest : bnd;
+      }
       bool bad = false;
       unsigned long long kk[KPL];  // lane g * LPS + h: keys [8 h, 8 h + 8) of workgroup g, largest first
       unsigned long long sb = bnd;
