@@ -357,7 +357,6 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
   const int wave_lo = lo + wv * ppt_used * WAVE;  // this wave's run: ppt_used * 64 consecutive Morton positions
   float px[PPT], py[PPT], pz[PPT], pd[PPT];
   float bx0 = INFINITY, by0 = INFINITY, bz0 = INFINITY, bx1 = -INFINITY, by1 = -INFINITY, bz1 = -INFINITY;
-  unsigned valid_mask = 0u;
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
     const int i = wave_lo + j * WAVE + lane;
@@ -365,10 +364,9 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
     px[j] = v ? S[3 * i] : 0.f;
     py[j] = v ? S[3 * i + 1] : 0.f;
     pz[j] = v ? S[3 * i + 2] : 0.f;
-    pd[j] = INFINITY;
+    pd[j] = v ? INFINITY : -1.0f;  // an empty slot never becomes a candidate (the fold's min keeps the -1)
     s_perm[j * FPS_T + threadIdx.x] = v ? perm[p0 + i] : 0;
     if (v) {
-      valid_mask |= 1u << j;
       bx0 = fminf(bx0, px[j]), by0 = fminf(by0, py[j]), bz0 = fminf(bz0, pz[j]);
       bx1 = fmaxf(bx1, px[j]), by1 = fmaxf(by1, py[j]), bz1 = fmaxf(bz1, pz[j]);
     }
@@ -430,16 +428,41 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
       }
     }
     if (touched) {  // wave-uniform; otherwise s_wtop / s_wbound still hold this wave's candidates of the last round
-      unsigned long long best = 0ull, second = 0ull;
+      // the thread's best key and a bound for its runner-up.  Distances are >= 0 (empty slots hold -1), so their bit
+      // patterns order like the values: the largest distance by integer maxima, then one pass that counts its occurrences,
+      // keeps the largest OTHER distance and the slot -- five instructions per point, ONE index read from LDS (building
+      // all the 64-bit keys was 13 instructions and a read per point).  The runner-up only feeds the bound B, so
+      // (distance, lowest index) bounds its key from above.  Equal distances inside a thread: the exact keys decide.
+      int bdi = __float_as_int(pd[0]);
+#pragma unroll
+      for (int j = 1; j < PPT; ++j) bdi = max(bdi, __float_as_int(pd[j]));
+      const int none = __float_as_int(-1.0f);
+      int cnt = 0, bj = 0, sdi = none;
 #pragma unroll
       for (int j = 0; j < PPT; ++j) {
-        if ((valid_mask >> j) & 1u) {
-          const unsigned long long kk = fps_key(pd[j], s_perm[j * FPS_T + threadIdx.x]);
-          if (kk > best) {
-            second = best;
-            best = kk;
-          } else if (kk > second) {
-            second = kk;
+        const int dv = __float_as_int(pd[j]);
+        const bool e = dv == bdi;
+        cnt += e ? 1 : 0;
+        sdi = max(sdi, e ? none : dv);
+        bj = e ? j : bj;
+      }
+      unsigned long long best = 0ull, second = 0ull;
+      if (bdi >= 0) {
+        best = ((unsigned long long)(unsigned)bdi << 32) | (0xffffffffu - (unsigned)s_perm[bj * FPS_T + threadIdx.x]);
+        second = sdi >= 0 ? ((unsigned long long)(unsigned)sdi << 32) | 0xffffffffull : 0ull;
+      }
+      if (cnt > 1 && bdi >= 0) {
+        best = 0ull, second = 0ull;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+          if (__float_as_int(pd[j]) >= 0) {
+            const unsigned long long kk = fps_key(pd[j], s_perm[j * FPS_T + threadIdx.x]);
+            if (kk > best) {
+              second = best;
+              best = kk;
+            } else if (kk > second) {
+              second = kk;
+            }
           }
         }
       }
