@@ -505,8 +505,9 @@ def run_gpu(h, args):
             line["pairs"]["with_network"] = {
                 "value": round(world * n_net / m_elapsed, 2), "unit": "pairs/s", "pairs_per_gpu": n_net, "pair_batch": net_batch,
                 "ms_per_pair_per_gpu": round(m_elapsed / n_net * 1e3, 3),
-                "config": "same pairs; KPConvFPN (one pass per batch, GroupNorm per pair) + GeometricTransformer per pair + backbone "
-                          "features in the patch scores instead of the synthetic descriptors; 28 M seeded random parameters"}
+                "config": "same pairs; KPConvFPN (one pass per batch, GroupNorm per pair) + GeometricTransformer (padded batches of "
+                          "16 pairs: embedding and self-attention per cloud, the rest over the batch) + backbone features in the "
+                          "patch scores instead of the synthetic descriptors; 28 M seeded random parameters"}
             del regm
         except Exception as e:  # never takes the headline down with it
             line["pairs"]["with_network"] = {"error": repr(e)}

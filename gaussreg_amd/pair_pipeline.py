@@ -120,7 +120,7 @@ class PairRegistrar:
     """Holds the stateless operator modules and the descriptors; `register_pairs` runs a batch."""
 
     def __init__(self, device, num_samples=30000, fps_clouds_per_call=24, order="reference", use_ransac=True,
-                 profile=False, pair_streams=0, features="descriptor", transformer_batch=8):
+                 profile=False, pair_streams=0, features="descriptor", transformer_batch=16):
         """`pair_streams` = 0 (default): the per-pair stages (point_to_node_partition, SuperPointMatching, correspondences +
         LocalGlobalRegistration, RANSAC) run for all pairs of a batch through the stack-mode entry points
         (gr_point_to_node_partition_batch, gr_superpoint_matching_batch, gr_lgr_register_seg, gr_ransac_similarity_seg): two
