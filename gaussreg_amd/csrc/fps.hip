@@ -6,14 +6,15 @@
 // is the caller's (the package draws it at random).  Contract here: sample 0 = start_idx; sample k+1 =
 // arg max_i min_{j<=k} |p_i - p_sample_j|^2 in fp32 ((dx*dx + dy*dy) + dz*dz), lowest index on ties.
 //
-// FPS is sequential in k, so one iteration has to be as short as the hardware allows:
+// FPS is sequential in k, and a global arg-max costs an exchange between the workgroups of a cloud:
 //   * a cloud is split over G workgroups (G*batch <= 256, so all of them are co-resident), each keeping its
-//     points AND their running min-distance in registers (PPT <= 20 per thread); beyond that the slab streams
-//     from L2 with 4 loads in flight;
-//   * per iteration a workgroup publishes its best candidate {d, idx, x, y, z} in a double-buffered slot, every
-//     word tagged with the iteration number; lane g of wave 0 in every workgroup polls slot g until all five
-//     tags are current, then the wave reduces the G candidates and everybody continues with the winner's
-//     coordinates -- one store + one load round trip per iteration, no fences, no counters.
+//     points AND their running min-distance in registers (PPT <= 20 per thread);
+//   * fps_multi_kernel (the path every call of this repo takes): one exchange per ROUND, and a round accepts every sample
+//     the sequential algorithm would take from the round's candidate set -- ~90 at 30 000 of 200 000 (see below);
+//   * fps_kernel<0> (slabs of more than 20 points per thread: distances streamed from L2, 4 loads in flight): one sample
+//     per exchange -- a workgroup publishes its best candidate {d, idx, x, y, z} in a double-buffered slot, every word
+//     tagged with the iteration number; lane g of wave 0 in every workgroup polls slot g until all five tags are current,
+//     then the wave reduces the G candidates -- one store + one load round trip per iteration, no fences, no counters;
 //   * the spin is bounded: a lane that waits > 2^22 polls raises an error flag and all leave (no GPU hang).
 #include <vector>
 
