@@ -47,9 +47,9 @@ KernelTimer::~KernelTimer() {
 
 // ------------------------------------------------------------------ pinned scratch
 void* pinned_scratch(int slot, size_t bytes) {
-  constexpr int SLOTS = 6;
-  static thread_local void* buf[SLOTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  static thread_local size_t cap[SLOTS] = {0, 0, 0, 0, 0, 0};
+  constexpr int SLOTS = 8;
+  static thread_local void* buf[SLOTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  static thread_local size_t cap[SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (slot < 0 || slot >= SLOTS) return nullptr;
   if (cap[slot] < bytes) {
     if (buf[slot]) (void)hipHostFree(buf[slot]);

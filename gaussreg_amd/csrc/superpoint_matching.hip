@@ -9,6 +9,7 @@
 // no float atomics: results are reproducible run to run) -> score = (S/rowsum)*(S/colsum) ->
 // exact global top-k by a 3-pass radix select on the score bits (ties: lowest flat index first)
 // -> sorted (score desc) -> indices mapped back through the compaction tables.
+#include <type_traits>
 #include <vector>
 
 #include "common.hpp"
@@ -24,6 +25,17 @@ constexpr int PD_LD = PD_K + 1;
 
 enum { EPI_DIST = 0, EPI_EXPNEG = 1 };
 
+// Stack mode (gr_superpoint_matching_batch): the kernels of one pair, launched once for all pairs of a batch.  Pair z
+// (blockIdx.z, or blockIdx.x for the single-workgroup kernels) finds its superpoints in the stacked inputs through
+// `stack[z]`; its workspace is the one the pointer arguments name, `zstride` bytes further per pair.
+struct SpmStack {
+  int32_t r0, nr, s0, ns;  // first ref / src superpoint in the stack, their counts
+};
+template <class T>
+__device__ __forceinline__ T* z_shift(T* p, size_t bytes) {  // (pointer arithmetic, not integers: the address space stays known)
+  return p ? reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(p)) + bytes) : p;
+}
+
 // out[i][j] = epilogue(dist(x[xi[i]], y[yi[j]]));  xi / yi optional gather tables (nullptr = identity).
 // n_dev / m_dev (optional) hold the row / column counts on the device (after a compaction).
 template <int EPI>
@@ -31,9 +43,19 @@ __global__ __launch_bounds__(256) void pairwise_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const int32_t* __restrict__ xi,
     const int32_t* __restrict__ yi, int n, int m, const int32_t* __restrict__ nm_dev, int C,
     int normalized, const float* __restrict__ x2, const float* __restrict__ y2,
-    float* __restrict__ out, int ld_out) {
+    float* __restrict__ out, int ld_out, const SpmStack* __restrict__ stack, size_t zstride) {
   __shared__ float sx[PD_T][PD_LD];
   __shared__ float sy[PD_T][PD_LD];
+  if (stack) {  // x = y = the stacked features; the gather tables, counts and the output belong to pair blockIdx.z
+    const SpmStack P = stack[blockIdx.z];
+    y = x + (int64_t)P.s0 * C;
+    x = x + (int64_t)P.r0 * C;
+    n = P.nr;
+    m = P.ns;
+    ld_out = P.ns;
+    const size_t zo = (size_t)blockIdx.z * zstride;
+    xi = z_shift(xi, zo), yi = z_shift(yi, zo), nm_dev = z_shift(nm_dev, zo), out = z_shift(out, zo);
+  }
   if (nm_dev) {
     n = nm_dev[0];
     m = nm_dev[1];
@@ -110,9 +132,20 @@ __global__ __launch_bounds__(1024) void compact_masks_kernel(const uint8_t* __re
                                                              const uint8_t* __restrict__ sm, int ns_all,
                                                              int num_corr, int32_t* __restrict__ ridx,
                                                              int32_t* __restrict__ sidx,
-                                                             SpmHdr* __restrict__ hdr) {
+                                                             SpmHdr* __restrict__ hdr, uint32_t* __restrict__ hist,
+                                                             const SpmStack* __restrict__ stack, size_t zstride) {
   __shared__ int wsum[1024 / WAVE];
   __shared__ int carry;
+  if (stack) {  // rm = sm = the stacked masks (or null); workgroup = pair; also clears the pair's selection histograms
+    const SpmStack P = stack[blockIdx.x];
+    sm = sm ? sm + P.s0 : sm;
+    rm = rm ? rm + P.r0 : rm;
+    nr_all = P.nr;
+    ns_all = P.ns;
+    const size_t zo = (size_t)blockIdx.x * zstride;
+    ridx = z_shift(ridx, zo), sidx = z_shift(sidx, zo), hdr = z_shift(hdr, zo), hist = z_shift(hist, zo);
+    for (int i = threadIdx.x; i < 3 * 2048; i += 1024) hist[i] = 0u;
+  }
   for (int which = 0; which < 2; ++which) {
     const uint8_t* mask = which ? sm : rm;
     const int n = which ? ns_all : nr_all;
@@ -154,7 +187,13 @@ __global__ __launch_bounds__(1024) void compact_masks_kernel(const uint8_t* __re
 // row sums: one wave per row, lanes stride the columns, fixed-shape tree reduce
 __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ S, int ld,
                                                      const SpmHdr* __restrict__ hdr,
-                                                     float* __restrict__ rs) {
+                                                     float* __restrict__ rs, const SpmStack* __restrict__ stack,
+                                                     size_t zstride) {
+  if (stack) {
+    ld = stack[blockIdx.z].ns;
+    const size_t zo = (size_t)blockIdx.z * zstride;
+    S = z_shift(S, zo), hdr = z_shift(hdr, zo), rs = z_shift(rs, zo);
+  }
   const int nr = hdr->nr, ns = hdr->ns;
   const int r = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
   const int lane = threadIdx.x & (WAVE - 1);
@@ -170,8 +209,14 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ S
 // (coalesced across lanes), partials combined in fixed order -> reproducible
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ S, int ld,
                                                      const SpmHdr* __restrict__ hdr,
-                                                     float* __restrict__ cs) {
+                                                     float* __restrict__ cs, const SpmStack* __restrict__ stack,
+                                                     size_t zstride) {
   __shared__ float part[4][WAVE];
+  if (stack) {
+    ld = stack[blockIdx.z].ns;
+    const size_t zo = (size_t)blockIdx.z * zstride;
+    S = z_shift(S, zo), hdr = z_shift(hdr, zo), cs = z_shift(cs, zo);
+  }
   const int nr = hdr->nr, ns = hdr->ns;
   const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
   const int c = blockIdx.x * WAVE + lane;
@@ -199,7 +244,13 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict_
                                                         const float* __restrict__ rs,
                                                         const float* __restrict__ cs, int dual,
                                                         const SpmHdr* __restrict__ hdr,
-                                                        float* __restrict__ score) {
+                                                        float* __restrict__ score, const SpmStack* __restrict__ stack,
+                                                        size_t zstride) {
+  if (stack) {
+    ld = stack[blockIdx.z].ns;
+    const size_t zo = (size_t)blockIdx.z * zstride;
+    S = z_shift(S, zo), rs = z_shift(rs, zo), cs = z_shift(cs, zo), hdr = z_shift(hdr, zo), score = z_shift(score, zo);
+  }
   const int nr = hdr->nr, ns = hdr->ns;
   const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
   if (r >= nr || c >= ns) return;
@@ -287,8 +338,12 @@ __device__ inline Pick pick_from_hist(const uint32_t* __restrict__ hist_prev, in
 // pass 0: plain histogram of the top digit.  pass 1/2: pick digit pass-1 first (from hist[pass-1]).
 __global__ __launch_bounds__(256) void select_hist_kernel(const float* __restrict__ score,
                                                           SpmHdr* __restrict__ hdr, int pass,
-                                                          uint32_t* __restrict__ hist /* [3][2048] */) {
+                                                          uint32_t* __restrict__ hist /* [3][2048] */, size_t zstride) {
   __shared__ uint32_t sh[2048];
+  {
+    const size_t zo = (size_t)blockIdx.z * zstride;
+    score = z_shift(score, zo), hdr = z_shift(hdr, zo), hist = z_shift(hist, zo);
+  }
   uint32_t prefix = 0;
   int k_rem = hdr->k;
   for (int pp = 0; pp < pass; ++pp) {  // replay the picks of the earlier digits (deterministic)
@@ -321,8 +376,12 @@ constexpr int CAND_CAP = 4096;
 __global__ __launch_bounds__(256) void select_gather_kernel(const float* __restrict__ score,
                                                             SpmHdr* __restrict__ hdr,
                                                             const uint32_t* __restrict__ hist,
-                                                            unsigned long long* __restrict__ cand) {
+                                                            unsigned long long* __restrict__ cand, size_t zstride) {
   __shared__ uint32_t sh[2048];
+  {
+    const size_t zo = (size_t)blockIdx.z * zstride;
+    score = z_shift(score, zo), hdr = z_shift(hdr, zo), hist = z_shift(hist, zo), cand = z_shift(cand, zo);
+  }
   uint32_t prefix = 0;
   int k_rem = hdr->k;
   for (int pp = 0; pp < 3; ++pp) {
@@ -406,8 +465,14 @@ __global__ __launch_bounds__(1024) void select_emit_kernel(const SpmHdr* __restr
                                                            const int32_t* __restrict__ sidx,
                                                            int64_t* __restrict__ out_ref,
                                                            int64_t* __restrict__ out_src,
-                                                           float* __restrict__ out_score) {
+                                                           float* __restrict__ out_score, size_t zstride, int out_stride) {
   __shared__ unsigned long long sk[CAND_CAP];
+  {  // stack mode: workgroup = pair, its outputs are row blockIdx.x of the (pairs, num_correspondences) arrays
+    const size_t zo = (size_t)blockIdx.x * zstride;
+    hdr = z_shift(hdr, zo), cand = z_shift(cand, zo), ridx = z_shift(ridx, zo), sidx = z_shift(sidx, zo);
+    out_ref += (int64_t)blockIdx.x * out_stride, out_src += (int64_t)blockIdx.x * out_stride;
+    out_score += (int64_t)blockIdx.x * out_stride;
+  }
   const int n = min(hdr->n_cand, CAND_CAP);
   int np2 = 2;
   while (np2 < n) np2 <<= 1;
@@ -499,7 +564,7 @@ extern "C" int gr_pairwise_distance(const float* x, const float* y, int64_t n, i
   const dim3 grid((unsigned)((m + PD_T - 1) / PD_T), (unsigned)((n + PD_T - 1) / PD_T));
   hipLaunchKernelGGL((pairwise_kernel<EPI_DIST>), grid, dim3(256), 0, stream, x, y, (const int32_t*)nullptr,
                      (const int32_t*)nullptr, (int)n, (int)m, (const int32_t*)nullptr, (int)c, normalized, x2, y2, out,
-                     (int)m);
+                     (int)m, (const SpmStack*)nullptr, (size_t)0);
   GR_LAUNCH_CHECK();
   return GR_OK;
 }
@@ -509,32 +574,38 @@ extern "C" size_t gr_superpoint_matching_workspace_bytes(int64_t nr, int64_t ns)
   return carve_spm(nullptr, nr, ns).bytes;
 }
 
-// the launches of one pair, asynchronous; the header (counts) stays in w.hdr
+// the launches of one pair -- or, with `stack`, of `npairs` pairs at once (nr / ns are then the largest counts, feats / masks
+// the stacked arrays, w the first pair's workspace and zstride the distance to the next) -- asynchronous; the header
+// (counts) stays in w.hdr
 static int spm_launch(const float* ref_feats, const float* src_feats, int64_t nr, int64_t ns, int64_t c,
                       const uint8_t* ref_masks, const uint8_t* src_masks, int num_correspondences,
                       int dual_normalization, int64_t* out_ref_idx, int64_t* out_src_idx, float* out_scores,
-                      const SpmWs& w, hipStream_t stream) {
-  GR_HIP(hipMemsetAsync(w.hist, 0, 3 * 2048 * sizeof(uint32_t), stream));
-  hipLaunchKernelGGL(compact_masks_kernel, dim3(1), dim3(1024), 0, stream, ref_masks, (int)nr, src_masks, (int)ns,
-                     num_correspondences, w.ridx, w.sidx, w.hdr);
-  const dim3 grid((unsigned)((ns + PD_T - 1) / PD_T), (unsigned)((nr + PD_T - 1) / PD_T));
+                      const SpmWs& w, hipStream_t stream, const SpmStack* stack = nullptr, size_t zstride = 0,
+                      int npairs = 1) {
+  const unsigned z = (unsigned)npairs;
+  if (!stack) GR_HIP(hipMemsetAsync(w.hist, 0, 3 * 2048 * sizeof(uint32_t), stream));
+  hipLaunchKernelGGL(compact_masks_kernel, dim3(z), dim3(1024), 0, stream, ref_masks, (int)nr, src_masks, (int)ns,
+                     num_correspondences, w.ridx, w.sidx, w.hdr, w.hist, stack, zstride);
+  const dim3 grid((unsigned)((ns + PD_T - 1) / PD_T), (unsigned)((nr + PD_T - 1) / PD_T), z);
   // features are L2-normalised by the caller (model.py:143-144): d = 2 - 2 xy  (superpoint_matching.py:37)
   hipLaunchKernelGGL((pairwise_kernel<EPI_EXPNEG>), grid, dim3(256), 0, stream, ref_feats, src_feats, w.ridx, w.sidx,
                      (int)nr, (int)ns, reinterpret_cast<const int32_t*>(w.hdr), (int)c, 1, (const float*)nullptr,
-                     (const float*)nullptr, w.S, (int)ns);
+                     (const float*)nullptr, w.S, (int)ns, stack, zstride);
   if (dual_normalization) {
-    hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, stream, w.S, (int)ns, w.hdr, w.rs);
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((ns + WAVE - 1) / WAVE)), dim3(256), 0, stream, w.S, (int)ns, w.hdr,
-                       w.cs);
+    hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)((nr + 3) / 4), 1, z), dim3(256), 0, stream, w.S, (int)ns, w.hdr, w.rs,
+                       stack, zstride);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((ns + WAVE - 1) / WAVE), 1, z), dim3(256), 0, stream, w.S, (int)ns,
+                       w.hdr, w.cs, stack, zstride);
   }
-  hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((ns + 255) / 256), (unsigned)nr), dim3(256), 0, stream, w.S,
-                     (int)ns, w.rs, w.cs, dual_normalization, w.hdr, w.score);
-  const int sel_blocks = (int)std::min<int64_t>(512, (nr * ns + 1023) / 1024);
+  hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((ns + 255) / 256), (unsigned)nr, z), dim3(256), 0, stream, w.S,
+                     (int)ns, w.rs, w.cs, dual_normalization, w.hdr, w.score, stack, zstride);
+  const int sel_blocks = (int)std::min<int64_t>(stack ? 64 : 512, (nr * ns + 1023) / 1024);
   for (int pass = 0; pass < 3; ++pass)
-    hipLaunchKernelGGL(select_hist_kernel, dim3(sel_blocks), dim3(256), 0, stream, w.score, w.hdr, pass, w.hist);
-  hipLaunchKernelGGL(select_gather_kernel, dim3(sel_blocks), dim3(256), 0, stream, w.score, w.hdr, w.hist, w.cand);
-  hipLaunchKernelGGL(select_emit_kernel, dim3(1), dim3(1024), 0, stream, w.hdr, w.cand, w.ridx, w.sidx, out_ref_idx,
-                     out_src_idx, out_scores);
+    hipLaunchKernelGGL(select_hist_kernel, dim3(sel_blocks, 1, z), dim3(256), 0, stream, w.score, w.hdr, pass, w.hist, zstride);
+  hipLaunchKernelGGL(select_gather_kernel, dim3(sel_blocks, 1, z), dim3(256), 0, stream, w.score, w.hdr, w.hist, w.cand,
+                     zstride);
+  hipLaunchKernelGGL(select_emit_kernel, dim3(z), dim3(1024), 0, stream, w.hdr, w.cand, w.ridx, w.sidx, out_ref_idx,
+                     out_src_idx, out_scores, zstride, num_correspondences);
   GR_LAUNCH_CHECK();
   return GR_OK;
 }
@@ -573,7 +644,7 @@ extern "C" int gr_superpoint_matching(const float* ref_feats, const float* src_f
     // more ties at the threshold than the candidate buffer holds: redo the gather in flat-index order (see above)
     hipLaunchKernelGGL(select_gather_ordered_kernel, dim3(1), dim3(1024), 0, stream, w.score, w.hdr, w.cand);
     hipLaunchKernelGGL(select_emit_kernel, dim3(1), dim3(1024), 0, stream, w.hdr, w.cand, w.ridx, w.sidx, out_ref_idx,
-                       out_src_idx, out_scores);
+                       out_src_idx, out_scores, (size_t)0, 0);
     GR_LAUNCH_CHECK();
     GR_HIP(hipStreamSynchronize(stream));
   }
@@ -584,16 +655,23 @@ extern "C" int gr_superpoint_matching(const float* ref_feats, const float* src_f
 // Stack mode over `npairs` scene pairs (test.py:146-212 runs model.py:156-160 once per pair): the superpoint features of the
 // batch are stacked as [ref_0, src_0, ref_1, src_1, ...] with h_node_off (2 npairs + 1 offsets), masks likewise (null =
 // all true).  Pair b's matches go to row b of the (npairs, num_correspondences) outputs; h_num_out[b] = how many are valid.
-// All pairs are launched back to back on `stream` out of one workspace; their headers are collected on the device and
-// read back ONCE.  (A pair with more ties at the selection threshold than the candidate buffer holds is redone through the
-// single-pair path afterwards.)
+// ONE set of twelve launches for the whole batch (grid.z = pair; every pair owns an equally laid out slice of the
+// workspace, sized for the largest pair), the pairs' headers read back ONCE.  (A pair with more ties at the selection
+// threshold than the candidate buffer holds is redone through the single-pair path afterwards.)
+static void spm_max_sizes(const int64_t* h_node_off, int64_t npairs, int64_t* max_nr, int64_t* max_ns) {
+  *max_nr = *max_ns = 0;
+  for (int64_t b = 0; b < npairs; ++b) {
+    *max_nr = std::max(*max_nr, h_node_off[2 * b + 1] - h_node_off[2 * b]);
+    *max_ns = std::max(*max_ns, h_node_off[2 * b + 2] - h_node_off[2 * b + 1]);
+  }
+}
+
 extern "C" size_t gr_superpoint_matching_batch_workspace_bytes(const int64_t* h_node_off, int64_t npairs) {
-  size_t need = 0;
   if (!h_node_off || npairs < 0) return 0;
-  for (int64_t b = 0; b < npairs; ++b)
-    need = std::max(need, carve_spm(nullptr, h_node_off[2 * b + 1] - h_node_off[2 * b],
-                                    h_node_off[2 * b + 2] - h_node_off[2 * b + 1]).bytes);
-  return align_up(need, 256) + align_up((size_t)std::max<int64_t>(npairs, 1) * sizeof(SpmHdr), 256);
+  int64_t mr, ms;
+  spm_max_sizes(h_node_off, npairs, &mr, &ms);
+  return (size_t)std::max<int64_t>(npairs, 1) * align_up(carve_spm(nullptr, mr, ms).bytes, 256) +
+         align_up((size_t)std::max<int64_t>(npairs, 1) * sizeof(SpmStack), 256);
 }
 
 extern "C" int gr_superpoint_matching_batch(const float* feats, const int64_t* h_node_off, int64_t npairs, int64_t c,
@@ -601,45 +679,57 @@ extern "C" int gr_superpoint_matching_batch(const float* feats, const int64_t* h
                                             int64_t* out_ref_idx, int64_t* out_src_idx, float* out_scores,
                                             int64_t* h_num_out, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  GR_REQUIRE(npairs >= 0 && h_node_off && h_num_out, "bad arguments");
+  GR_REQUIRE(npairs >= 0 && npairs < 65536 && h_node_off && h_num_out, "bad arguments");
   for (int64_t b = 0; b < npairs; ++b) h_num_out[b] = 0;
   if (npairs == 0 || num_correspondences == 0) return GR_OK;
   GR_REQUIRE(feats && out_ref_idx && out_src_idx && out_scores, "null argument");
+  int64_t mr, ms;
+  spm_max_sizes(h_node_off, npairs, &mr, &ms);
+  for (int64_t b = 0; b < npairs; ++b) {
+    const int64_t nr = h_node_off[2 * b + 1] - h_node_off[2 * b], ns = h_node_off[2 * b + 2] - h_node_off[2 * b + 1];
+    GR_REQUIRE(nr >= 0 && ns >= 0 && h_node_off[2 * b] >= 0, "pair %lld: offsets must ascend", (long long)b);
+    GR_REQUIRE(h_node_off[2 * b + 2] < (1ll << 31), "too many superpoints");
+  }
+  int rc = spm_check_args(mr, ms, c, num_correspondences);
+  if (rc != GR_OK) return rc;
   if (!ws || ws_bytes < gr_superpoint_matching_batch_workspace_bytes(h_node_off, npairs)) {
     set_error("superpoint_matching batch workspace too small");
     return GR_ERR_WORKSPACE;
   }
-  const size_t pair_bytes = gr_superpoint_matching_batch_workspace_bytes(h_node_off, npairs) -
-                            align_up((size_t)npairs * sizeof(SpmHdr), 256);
-  SpmHdr* d_hdrs = reinterpret_cast<SpmHdr*>(static_cast<char*>(ws) + pair_bytes);
-  std::vector<char> live(npairs, 0);
+  if (mr == 0 || ms == 0) return GR_OK;
+  const size_t pair_bytes = align_up(carve_spm(nullptr, mr, ms).bytes, 256);
+  SpmStack* d_stack = reinterpret_cast<SpmStack*>(static_cast<char*>(ws) + (size_t)npairs * pair_bytes);
+  // the pair table goes up through pinned per-thread staging; an event says when the copy has left it
+  static thread_local hipEvent_t staged = nullptr;
+  if (staged == nullptr) GR_HIP(hipEventCreateWithFlags(&staged, hipEventDisableTiming));
+  else GR_HIP(hipEventSynchronize(staged));
+  SpmStack* h_stack = static_cast<SpmStack*>(pinned_scratch(6, sizeof(SpmStack) * (size_t)npairs));
+  GR_REQUIRE(h_stack != nullptr, "pinned staging buffer could not be allocated");
+  for (int64_t b = 0; b < npairs; ++b) {
+    h_stack[b].r0 = (int32_t)h_node_off[2 * b];
+    h_stack[b].nr = (int32_t)(h_node_off[2 * b + 1] - h_node_off[2 * b]);
+    h_stack[b].s0 = (int32_t)h_node_off[2 * b + 1];
+    h_stack[b].ns = (int32_t)(h_node_off[2 * b + 2] - h_node_off[2 * b + 1]);
+  }
+  GR_HIP(hipMemcpyAsync(d_stack, h_stack, sizeof(SpmStack) * (size_t)npairs, hipMemcpyHostToDevice, stream));
+  GR_HIP(hipEventRecord(staged, stream));
+  SpmWs w = carve_spm(ws, mr, ms);  // pair 0's slice; pair z's is zstride = pair_bytes further
+  rc = spm_launch(feats, feats, mr, ms, c, masks, masks, num_correspondences, dual_normalization, out_ref_idx, out_src_idx,
+                  out_scores, w, stream, d_stack, pair_bytes, (int)npairs);
+  if (rc != GR_OK) return rc;
+  std::vector<SpmHdr> h(npairs);
+  GR_HIP(hipMemcpy2DAsync(h.data(), sizeof(SpmHdr), w.hdr, pair_bytes, sizeof(SpmHdr), (size_t)npairs, hipMemcpyDeviceToHost,
+                          stream));
+  GR_HIP(hipStreamSynchronize(stream));
   for (int64_t b = 0; b < npairs; ++b) {
     const int64_t r0 = h_node_off[2 * b], nr = h_node_off[2 * b + 1] - r0, s0 = h_node_off[2 * b + 1],
                   ns = h_node_off[2 * b + 2] - s0;
-    GR_REQUIRE(nr >= 0 && ns >= 0 && r0 >= 0, "pair %lld: offsets must ascend", (long long)b);
-    int rc = spm_check_args(nr, ns, c, num_correspondences);
-    if (rc != GR_OK) return rc;
-    if (nr == 0 || ns == 0) continue;
-    SpmWs w = carve_spm(ws, nr, ns);
-    rc = spm_launch(feats + r0 * c, feats + s0 * c, nr, ns, c, masks ? masks + r0 : nullptr, masks ? masks + s0 : nullptr,
-                    num_correspondences, dual_normalization, out_ref_idx + b * num_correspondences,
-                    out_src_idx + b * num_correspondences, out_scores + b * num_correspondences, w, stream);
-    if (rc != GR_OK) return rc;
-    GR_HIP(hipMemcpyAsync(d_hdrs + b, w.hdr, sizeof(SpmHdr), hipMemcpyDeviceToDevice, stream));
-    live[b] = 1;
-  }
-  std::vector<SpmHdr> h(npairs);
-  GR_HIP(hipMemcpyAsync(h.data(), d_hdrs, sizeof(SpmHdr) * (size_t)npairs, hipMemcpyDeviceToHost, stream));
-  GR_HIP(hipStreamSynchronize(stream));
-  for (int64_t b = 0; b < npairs; ++b) {
-    if (!live[b]) continue;
+    if (nr == 0 || ns == 0) continue;  // (its header says k = 0 as well)
     if (h[b].n_cand > CAND_CAP) {
-      const int64_t r0 = h_node_off[2 * b], nr = h_node_off[2 * b + 1] - r0, s0 = h_node_off[2 * b + 1],
-                    ns = h_node_off[2 * b + 2] - s0;
-      const int rc = gr_superpoint_matching(feats + r0 * c, feats + s0 * c, nr, ns, c, masks ? masks + r0 : nullptr,
-                                            masks ? masks + s0 : nullptr, num_correspondences, dual_normalization,
-                                            out_ref_idx + b * num_correspondences, out_src_idx + b * num_correspondences,
-                                            out_scores + b * num_correspondences, h_num_out + b, ws, pair_bytes, stream_);
+      rc = gr_superpoint_matching(feats + r0 * c, feats + s0 * c, nr, ns, c, masks ? masks + r0 : nullptr,
+                                  masks ? masks + s0 : nullptr, num_correspondences, dual_normalization,
+                                  out_ref_idx + b * num_correspondences, out_src_idx + b * num_correspondences,
+                                  out_scores + b * num_correspondences, h_num_out + b, ws, pair_bytes, stream_);
       if (rc != GR_OK) return rc;
     } else {
       h_num_out[b] = h[b].k;
