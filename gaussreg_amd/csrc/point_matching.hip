@@ -88,6 +88,92 @@ __global__ __launch_bounds__(PM_T) void corr_matrix_kernel(
   }
 }
 
+// The same for k <= 4 (GaussReg: k = 3) in ONE scan per row and per column: the k largest entries of a line, ties to the
+// lowest index, are what k rounds of "largest not yet taken" (strict >) pick.  A thread keeps them in registers as a sorted
+// list and bubbles every element down it (strict >, so an equal later element never displaces an earlier one); threads
+// 0..127 take the rows while threads 128..255 take the columns; the selections are k indices per line instead of a flag byte
+// per entry, so the matrix alone is in LDS and two workgroups share a CU.  (The k-round kernel above spent 3 x 128 dependent
+// LDS round trips per line, rows and columns one after the other, on half of its threads: 4.3 ms per 16 384 patches.)
+constexpr int PM_KMAX = 4;
+
+__device__ __forceinline__ void pm_topk_line(const float* __restrict__ base, int stride, int len, int k, int* __restrict__ picks) {
+  float tv[PM_KMAX];
+  int ti[PM_KMAX];
+#pragma unroll
+  for (int s = 0; s < PM_KMAX; ++s) tv[s] = 0.f, ti[s] = -1;
+  for (int t0 = 0; t0 < len; t0 += 4) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = base[(size_t)min(t0 + u, len - 1) * stride];  // loads first; a repeat is filtered below
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float cv = v[u];
+      int ci = t0 + u < len ? t0 + u : -1;
+#pragma unroll
+      for (int s = 0; s < PM_KMAX; ++s) {
+        // the carried element takes slot s if the slot is empty or holds a strictly smaller value; what it displaces moves on
+        const bool take = s < k && ci >= 0 && (ti[s] < 0 || cv > tv[s]);
+        const float ov = tv[s];
+        const int oi = ti[s];
+        tv[s] = take ? cv : ov;
+        ti[s] = take ? ci : oi;
+        cv = take ? ov : cv;
+        ci = take ? oi : ci;
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < PM_KMAX; ++s) picks[s] = s < k ? ti[s] : -1;
+}
+
+__global__ __launch_bounds__(PM_T) void corr_matrix_topk_kernel(
+    const float* __restrict__ score, int K1, int K2, const uint8_t* __restrict__ ref_masks,
+    const uint8_t* __restrict__ src_masks, int k, int mutual, float thr, uint8_t* __restrict__ corr,
+    int32_t* __restrict__ counts, int scores_are_exp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ld = K2 + 1;  // +1: a thread walking down a row-major column / along a row stays conflict-free
+  float* E = reinterpret_cast<float*>(smem);
+  int* rpick = reinterpret_cast<int*>(smem + (sizeof(float) * (size_t)K1 * ld + 15) / 16 * 16);  // [K1][4]
+  int* cpick = rpick + (size_t)K1 * PM_KMAX;                                                     // [K2][4]
+  int* wsum = cpick + (size_t)K2 * PM_KMAX;
+  const int b = blockIdx.x;
+  const float* sm = score + (int64_t)b * K1 * K2;
+  for (int e = threadIdx.x; e < K1 * K2; e += PM_T) E[(e / K2) * ld + (e % K2)] = scores_are_exp ? sm[e] : expf(sm[e]);
+  __syncthreads();
+  // lines: rows 0..K1-1 then columns 0..K2-1, dealt out over the workgroup (with K1 = K2 = 128: half the threads each)
+  for (int l = threadIdx.x; l < K1 + K2; l += PM_T) {
+    if (l < K1) pm_topk_line(E + (size_t)l * ld, 1, K2, k, rpick + (size_t)l * PM_KMAX);
+    else pm_topk_line(E + (l - K1), ld, K1, k, cpick + (size_t)(l - K1) * PM_KMAX);
+  }
+  __syncthreads();
+  int n = 0;
+  for (int e = threadIdx.x; e < K1 * K2; e += PM_T) {
+    const int i = e / K2, j = e % K2;
+    const bool over = E[i * ld + j] > thr;  // torch.gt(score_mat, confidence_threshold)
+    const int4 rp = *reinterpret_cast<const int4*>(rpick + (size_t)i * PM_KMAX);
+    const int4 cp = *reinterpret_cast<const int4*>(cpick + (size_t)j * PM_KMAX);
+    const bool r = over && (rp.x == j || rp.y == j || rp.z == j || rp.w == j);
+    const bool c = over && (cp.x == i || cp.y == i || cp.z == i || cp.w == i);
+    bool m = mutual ? (r && c) : (r || c);
+    m = m && ref_masks[(int64_t)b * K1 + i] && src_masks[(int64_t)b * K2 + j];
+    corr[(int64_t)b * K1 * K2 + e] = m ? 1 : 0;
+    n += m ? 1 : 0;
+  }
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) n += __shfl_xor(n, d, WAVE);
+  if ((threadIdx.x & (WAVE - 1)) == 0) wsum[threadIdx.x / WAVE] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < PM_T / WAVE; ++w) t += wsum[w];
+    counts[b] = t;
+  }
+}
+
+size_t corr_topk_lds_bytes(int K1, int K2) {
+  return (sizeof(float) * (size_t)K1 * (K2 + 1) + 15) / 16 * 16 + sizeof(int) * (size_t)(K1 + K2) * PM_KMAX + 64;
+}
+
 // emit the true entries of patch b in row-major order at offsets[b] (exclusive scan of counts)
 __global__ __launch_bounds__(PM_T) void corr_gather_kernel(
     const float* __restrict__ score, int K1, int K2, const uint8_t* __restrict__ corr,
@@ -162,17 +248,23 @@ static int corr_matrix_impl(int scores_are_exp, const float* score_mat, int64_t 
     set_error("point_matching workspace too small");
     return GR_ERR_WORKSPACE;
   }
-  const size_t lds = corr_lds_bytes((int)k1, (int)k2);
+  const bool topk = k <= PM_KMAX;  // one scan per line (see corr_matrix_topk_kernel); larger k: k rounds per line
+  const size_t lds = topk ? corr_topk_lds_bytes((int)k1, (int)k2) : corr_lds_bytes((int)k1, (int)k2);
   GR_REQUIRE(lds <= 160 * 1024, "patch %lld x %lld does not fit in LDS", (long long)k1, (long long)k2);
   if (lds > 64 * 1024)
-    GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_matrix_kernel),
+    GR_HIP(hipFuncSetAttribute(topk ? reinterpret_cast<const void*>(&corr_matrix_topk_kernel)
+                                    : reinterpret_cast<const void*>(&corr_matrix_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   int32_t* counts = static_cast<int32_t*>(ws);
   int32_t* offsets = counts + batch;
   int32_t* total = offsets + batch;
   int32_t* scan_ws = total + 2;
-  hipLaunchKernelGGL(corr_matrix_kernel, dim3((unsigned)batch), dim3(PM_T), lds, stream, score_mat, (int)k1, (int)k2,
-                     ref_knn_masks, src_knn_masks, k, mutual, confidence_threshold, corr_mat, counts, scores_are_exp);
+  if (topk)
+    hipLaunchKernelGGL(corr_matrix_topk_kernel, dim3((unsigned)batch), dim3(PM_T), lds, stream, score_mat, (int)k1, (int)k2,
+                       ref_knn_masks, src_knn_masks, k, mutual, confidence_threshold, corr_mat, counts, scores_are_exp);
+  else
+    hipLaunchKernelGGL(corr_matrix_kernel, dim3((unsigned)batch), dim3(PM_T), lds, stream, score_mat, (int)k1, (int)k2,
+                       ref_knn_masks, src_knn_masks, k, mutual, confidence_threshold, corr_mat, counts, scores_are_exp);
   GR_LAUNCH_CHECK();
   int rc = exclusive_scan_i32(counts, offsets, batch, 1, batch, scan_ws, total, stream);
   if (rc != GR_OK) return rc;
