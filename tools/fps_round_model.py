@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--eligible", type=int, default=0,
                     help="U > 0: no global top-MG selection; candidates = every published key above max(workgroup bounds, "
                          "the largest (U+1)-th key of a workgroup), i.e. at most U per workgroup (greedy rule)")
+    ap.add_argument("--per-thread", type=int, default=1, help="how many of its points a thread offers (the next one bounds)")
     ap.add_argument("--check", type=int, default=300, help="samples compared with the plain arg-max loop")
     a = ap.parse_args()
     P0 = room(a.n, 0)
@@ -84,7 +85,7 @@ def main():
     acc = [P0[0]]
     out = [0]
     rounds, hist, stops = 0, np.zeros(G * a.m + 1, np.int64), {"bound": 0, "hurt": 0, "all": 0, "k": 0}
-    esize, involved = [], []
+    esize, involved, which = [], [], []
     t0 = time.time()
     while len(out) < a.k:
         A = np.asarray(acc, np.float32)
@@ -93,11 +94,13 @@ def main():
             d = np.minimum(d, (diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]) + diff[:, 2] * diff[:, 2])
         kk = np.where(valid, keys_of(d[pos], orig), np.uint64(0))          # (G, nw, ppt, 64)
         ks = np.sort(kk, axis=2)
-        best = ks[:, :, -1, :]
-        second = ks[:, :, -2, :] if ppt > 1 else np.zeros_like(best)
-        wb = np.sort(best, axis=2)[:, :, ::-1]                              # (G, nw, 64) descending
+        pt = min(a.per_thread, ppt)
+        offered = ks[:, :, ppt - pt:, :].reshape(G, nw, -1)                 # the pt best points of every thread
+        second = ks[:, :, ppt - pt - 1, :] if ppt > pt else np.zeros_like(ks[:, :, 0, :])
+        wb = np.sort(offered, axis=2)[:, :, ::-1]                           # (G, nw, 64 pt) descending
         wtop = wb[:, :, :a.mw]
         wbound = np.maximum(wb[:, :, a.mw], second.max(2))                  # (G, nw)
+        which.append(int(np.argmax([wb[:, :, a.mw].max(), second.max()])))
         gl = np.sort(wtop.reshape(G, -1), axis=1)[:, ::-1]                  # (G, nw*mw)
         gtop = gl[:, :a.m]
         gbound = np.maximum(gl[:, a.m] if gl.shape[1] > a.m else 0, wbound.max(1))
@@ -176,6 +179,7 @@ def main():
            "per_round": round(a.k / rounds, 2), "stops": stops,
            "accepted_hist_deciles": [int(x) for x in np.percentile(np.repeat(np.arange(len(hist)), hist), [10, 50, 90])],
            "eligible_deciles": [int(x) for x in np.percentile(esize, [10, 50, 90, 100])] if esize else None,
+           "bound_from_thread_runner_up": round(float(np.mean(which)), 3),
            "in_conflict_deciles": [int(x) for x in np.percentile(involved, [10, 50, 90, 100])] if involved else None})
 
 
