@@ -177,7 +177,20 @@ class PairRegistrar:
         Returns (len(pairs), RESULT_LEN) float32: [T.flatten(), RRE deg, RTE m, #correspondences, inlier ratio]."""
         return self._register_sampled(pairs, self._sample(pairs, self.fps_clouds_per_call))
 
-    def _sample(self, pairs, clouds_per_call):
+    @torch.no_grad()
+    def register_many(self, pairs, batch=64):
+        """register_pairs for a whole rank's list: the farthest point sampling runs over ALL clouds first, in calls of
+        `fps_clouds_per_call` clouds (a call's cost per cloud is lowest when its co-operating workgroups fill the device: 24
+        clouds x 10 workgroups; a block of 64 pairs alone would make six calls of 21 - 22), then the pairs go through the other
+        stages in blocks of `batch`.  Same rows as register_pairs block by block, except that RANSAC's seed is the pair's
+        position in its block either way."""
+        if len(pairs) == 0:
+            return torch.zeros((0, RESULT_LEN), dtype=torch.float32, device=self.device)
+        sampled = self._sample(pairs, self.fps_clouds_per_call, equal_calls=False)
+        rows = [self._register_sampled(pairs[i:i + batch], sampled[2 * i:2 * (i + batch)]) for i in range(0, len(pairs), batch)]
+        return torch.cat(rows, 0)
+
+    def _sample(self, pairs, clouds_per_call, equal_calls=True):
         """FPS, several clouds per call; stack order [ref_1, src_1, ref_2, src_2, ...]: a pair's two clouds are adjacent at
         every pyramid level (data.py:151-155 stacks [ref, src] of ONE pair the same way)."""
         B = len(pairs)
@@ -187,7 +200,10 @@ class PairRegistrar:
             # at most clouds_per_call clouds per launch (the co-operating workgroups of a call share the 256 CUs; 24
             # clouds of 200 k points still fit their slabs in registers), in calls of equal size
             n_calls = -(-2 * B // clouds_per_call)
-            bounds = [round(i * 2 * B / n_calls) for i in range(n_calls + 1)]
+            if equal_calls:
+                bounds = [round(i * 2 * B / n_calls) for i in range(n_calls + 1)]
+            else:  # full calls, the remainder last
+                bounds = [min(i * clouds_per_call, 2 * B) for i in range(n_calls + 1)]
             for lo_, hi_ in zip(bounds[:-1], bounds[1:]):
                 chunk = clouds[lo_:hi_]
                 lens = [c.shape[0] for c in chunk]
