@@ -36,6 +36,9 @@ def test_pairs_register_and_streams_do_not_change_results(pairs):
     # this pipeline (not of the reference) and is summed differently in the batched form
     assert torch.equal(got[:, :19], seq[:, :19]), (got - seq).abs().max(0).values
     assert torch.allclose(got[:, 19], seq[:, 19], atol=1e-3)
+    many = batched.register_many(pairs, 2)         # FPS over all clouds first, then blocks of two pairs
+    blocks = torch.cat([batched.register_pairs(pairs[i:i + 2]) for i in range(0, 5, 2)])
+    assert torch.equal(many[:, :19], blocks[:, :19])
     sub = batched.register_pairs(pairs[1:4])       # another batch composition: same correspondences; RANSAC draws with the
     assert torch.equal(sub[:, 18], seq[1:4, 18])   # pair's position in the batch as seed, so its estimate moves a little
     assert torch.allclose(sub[:, :16], seq[1:4, :16], atol=2e-2)
