@@ -280,6 +280,43 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ x, 
   out[e] = best;
 }
 
+// The same for C % 4 == 0 with four channels per thread and the neighbours four at a time: the indices of a step are loaded
+// first (one broadcast address per row), then the four feature rows are in flight together -- the scalar kernel above walks
+// H dependent (index -> row) round trips one after the other.
+__global__ __launch_bounds__(256) void pool4_kernel(const float4* __restrict__ x, int N, int CV /* C / 4 */,
+                                                    const int64_t* __restrict__ nbr, int M, int H, int mode,
+                                                    float4* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)M * CV) return;
+  const int m = (int)(e / CV), c = (int)(e % CV);
+  const int64_t* row = nbr + (int64_t)m * H;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (mode == 1) {  // nearest upsample: first neighbour only
+    const int64_t idx = row[0];
+    out[e] = (idx >= N || idx < 0) ? zero : x[idx * CV + c];
+    return;
+  }
+  float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  for (int h0 = 0; h0 < H; h0 += 4) {
+    int64_t idx[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) idx[u] = row[min(h0 + u, H - 1)];  // past the end: the last neighbour again (max is idempotent)
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool pad = idx[u] >= N || idx[u] < 0;
+      v[u] = x[(pad ? 0 : idx[u]) * CV + c];  // unconditional load, the shadow row's zeros selected afterwards
+      if (pad) v[u] = zero;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      best.x = fmaxf(best.x, v[u].x), best.y = fmaxf(best.y, v[u].y);
+      best.z = fmaxf(best.z, v[u].z), best.w = fmaxf(best.w, v[u].w);
+    }
+  }
+  out[e] = best;
+}
+
 }  // namespace
 }  // namespace gr
 
@@ -408,8 +445,13 @@ extern "C" int gr_neighbor_pool(const float* x, int64_t n, int64_t c, const int6
   GR_REQUIRE(n >= 0 && c >= 1 && m >= 0 && h >= 1 && (mode == 0 || mode == 1), "bad arguments");
   if (m == 0) return GR_OK;
   GR_REQUIRE(x && neighbor_indices && out, "null argument");
-  hipLaunchKernelGGL(pool_kernel, dim3((unsigned)((m * c + 255) / 256)), dim3(256), 0, stream, x, (int)n, (int)c,
-                     neighbor_indices, (int)m, (int)h, mode, out);
+  if (c % 4 == 0 && n > 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
+    hipLaunchKernelGGL(pool4_kernel, dim3((unsigned)((m * (c / 4) + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const float4*>(x), (int)n, (int)(c / 4), neighbor_indices, (int)m, (int)h, mode,
+                       reinterpret_cast<float4*>(out));
+  else
+    hipLaunchKernelGGL(pool_kernel, dim3((unsigned)((m * c + 255) / 256)), dim3(256), 0, stream, x, (int)n, (int)c,
+                       neighbor_indices, (int)m, (int)h, mode, out);
   GR_LAUNCH_CHECK();
   return GR_OK;
 }
