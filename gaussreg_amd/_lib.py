@@ -76,6 +76,8 @@ SIGNATURES.update({
     "gr_group_norm_seg_workspace_bytes": (c_size, [c_i64, c_i64]),
     "gr_group_norm_seg": (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_void, c_f32, c_f32, c_void, c_void, c_i64, c_i64, c_void,
                                   c_size, c_void]),
+    "gr_group_norm_res": (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_void, c_f32, c_f32, c_void, c_void, c_void, c_i64, c_i64,
+                                  c_void, c_size, c_void]),
     "gr_gs_fuse_workspace_bytes": (c_size, [c_i64, c_i64]),
     "gr_gs_fuse": (c_int, [c_void, c_i64, c_void, c_i64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                            ctypes.c_double, ctypes.POINTER(c_f32), ctypes.POINTER(c_f32), ctypes.POINTER(c_f32), c_void,

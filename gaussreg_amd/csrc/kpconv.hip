@@ -477,13 +477,15 @@ template <bool APPLY>
 __global__ __launch_bounds__(GN_T) void group_norm_kernel(const float* __restrict__ x, int64_t n, int c, int groups,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, float slope, double* __restrict__ partial, int nblk_a,
-                                                          float* __restrict__ out, const int64_t* __restrict__ seg_off) {
+                                                          float* __restrict__ out, const int64_t* __restrict__ seg_off,
+                                                          const float* __restrict__ residual) {
   __shared__ double s_acc[2 * GN_MAXG];
   if (seg_off != nullptr) {
     const int64_t r0 = seg_off[blockIdx.y];
     n = seg_off[blockIdx.y + 1] - r0;
     x += r0 * c;
     out += r0 * c;
+    if (residual) residual += r0 * c;
     partial += (int64_t)blockIdx.y * ((int64_t)nblk_a * 2 * groups + groups);  // partials, then 2 G floats (= G doubles) of stats
   }
   __shared__ float s_mean[GN_MAXG], s_rstd[GN_MAXG];
@@ -528,6 +530,10 @@ __global__ __launch_bounds__(GN_T) void group_norm_kernel(const float* __restric
         y.y = (v.y - mean[1]) * rstd[1] * ga.y + be.y;
         y.z = (v.z - mean[2]) * rstd[2] * ga.z + be.z;
         y.w = (v.w - mean[3]) * rstd[3] * ga.w + be.w;
+        if (residual) {  // the residual block's shortcut, added before the activation (modules.py:138: leaky_relu(x + shortcut))
+          const float4 sc = *reinterpret_cast<const float4*>(residual + r * c + ch);
+          y.x += sc.x, y.y += sc.y, y.z += sc.z, y.w += sc.w;
+        }
         y.x = y.x >= 0.f ? y.x : y.x * slope;
         y.y = y.y >= 0.f ? y.y : y.y * slope;
         y.z = y.z >= 0.f ? y.z : y.z * slope;
@@ -589,7 +595,7 @@ extern "C" size_t gr_group_norm_workspace_bytes(int64_t groups) {
 
 static int group_norm_impl(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta,
                            float eps, float negative_slope, float* out, const int64_t* seg_off, int64_t nseg, int64_t max_seg_rows,
-                           void* ws, size_t ws_bytes, hipStream_t stream) {
+                           void* ws, size_t ws_bytes, hipStream_t stream, const float* residual = nullptr) {
   GR_REQUIRE(n >= 0 && c >= 4 && groups >= 1 && groups <= gr::GN_MAXG && c % groups == 0, "group_norm: bad sizes");
   const int64_t cols4 = c / 4;
   GR_REQUIRE(c % 4 == 0 && ((cols4 <= gr::GN_T && gr::GN_T % cols4 == 0) || (cols4 > gr::GN_T && cols4 % gr::GN_T == 0)),
@@ -613,11 +619,12 @@ static int group_norm_impl(const float* x, int64_t n, int64_t c, int64_t groups,
   const unsigned gy = seg ? (unsigned)nseg : 1u;
   gr::KernelTimer timer("group_norm", stream);
   hipLaunchKernelGGL(gr::group_norm_kernel<false>, dim3(nblk_a, gy), dim3(gr::GN_T), 0, stream, x, n, (int)c, (int)groups, gamma,
-                     beta, eps, negative_slope, partial, nblk_a, out, seg_off);
+                     beta, eps, negative_slope, partial, nblk_a, out, seg_off, (const float*)nullptr);
   hipLaunchKernelGGL(gr::group_norm_stats_kernel, dim3(gy), dim3(gr::GN_T), 0, stream, partial, nblk_a, (int)groups, n,
                      (int)(c / groups), eps, seg_off);
+  GR_REQUIRE(residual == nullptr || reinterpret_cast<uintptr_t>(residual) % 16 == 0, "group_norm: unaligned residual");
   hipLaunchKernelGGL(gr::group_norm_kernel<true>, dim3(nblk_b, gy), dim3(gr::GN_T), 0, stream, x, n, (int)c, (int)groups, gamma,
-                     beta, eps, negative_slope, partial, nblk_a, out, seg_off);
+                     beta, eps, negative_slope, partial, nblk_a, out, seg_off, residual);
   GR_LAUNCH_CHECK();
   return GR_OK;
 }
@@ -638,4 +645,18 @@ extern "C" int gr_group_norm_seg(const float* x, int64_t n, int64_t c, int64_t g
   GR_REQUIRE(seg_off != nullptr && nseg >= 0 && nseg < 65536 && max_seg_rows >= 0, "group_norm_seg: bad segments");
   return group_norm_impl(x, n, c, groups, gamma, beta, eps, negative_slope, out, seg_off, nseg, max_seg_rows, ws, ws_bytes,
                          static_cast<hipStream_t>(stream_));
+}
+
+// GroupNorm -> + residual -> LeakyReLU in the apply pass: the tail of a residual block (modules.py:135-138: unary2's norm
+// has no activation, then leaky_relu(x + shortcut)) without the two extra passes over the (N, C) matrix.  seg_off null: one
+// segment (nseg and max_seg_rows ignored); residual null: plain gr_group_norm(_seg).
+extern "C" int gr_group_norm_res(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta,
+                                 float eps, float negative_slope, const float* residual, float* out, const int64_t* seg_off,
+                                 int64_t nseg, int64_t max_seg_rows, void* ws, size_t ws_bytes, void* stream_) {
+  if (seg_off == nullptr)
+    return group_norm_impl(x, n, c, groups, gamma, beta, eps, negative_slope, out, nullptr, 1, n, ws, ws_bytes,
+                           static_cast<hipStream_t>(stream_), residual);
+  GR_REQUIRE(nseg >= 0 && nseg < 65536 && max_seg_rows >= 0, "group_norm_res: bad segments");
+  return group_norm_impl(x, n, c, groups, gamma, beta, eps, negative_slope, out, seg_off, nseg, max_seg_rows, ws, ws_bytes,
+                         static_cast<hipStream_t>(stream_), residual);
 }

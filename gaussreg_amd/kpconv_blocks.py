@@ -38,14 +38,17 @@ class GroupNorm(nn.Module):
         self.num_groups, self.num_channels = num_groups, num_channels
         self.norm = nn.GroupNorm(num_groups, num_channels)
 
-    def forward(self, x, negative_slope=None):
-        """`negative_slope`: fuse the LeakyReLU that follows the norm in every block (None: plain GroupNorm)."""
+    def forward(self, x, negative_slope=None, residual=None):
+        """`negative_slope`: fuse the LeakyReLU that follows the norm in every block (None: plain GroupNorm).
+        `residual` (same shape as x): added between the norm and the activation -- the tail of a residual block."""
         c = self.num_channels
         hip_ok = (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and not torch.is_grad_enabled() and c % 4 == 0
                   and ((c // 4 <= 256 and 256 % (c // 4) == 0) or (c // 4) % 256 == 0) and self.num_groups <= 64)
         if not hip_ok:
             y = self.norm(x.t().unsqueeze(0))     # (N, C) -> (1, C, N): statistics per group over all points
             y = y.squeeze(0).t().squeeze()        # the trailing squeeze() is the reference's (modules.py:50)
+            if residual is not None:
+                y = y + residual
             return y if negative_slope is None else nn.functional.leaky_relu(y, negative_slope)
         L = _lib.lib()
         x = x.contiguous()
@@ -55,6 +58,18 @@ class GroupNorm(nn.Module):
         seg = table.get(x.shape[0]) if table else None
         with torch.cuda.device(dev):
             w, b = self.norm.weight, self.norm.bias
+            if residual is not None:
+                res = residual.reshape(x.shape).contiguous()
+                seg_off, max_rows = seg if seg is not None else (None, 0)
+                nseg = seg_off.numel() - 1 if seg is not None else 1
+                ws = _lib.workspace(dev, L.gr_group_norm_seg_workspace_bytes(self.num_groups, nseg))
+                _lib.check(L.gr_group_norm_res(_lib.ptr(x), x.shape[0], c, self.num_groups,
+                                               _lib.ptr(None if w is None else w.detach().contiguous()),
+                                               _lib.ptr(None if b is None else b.detach().contiguous()), float(self.norm.eps),
+                                               1.0 if negative_slope is None else float(negative_slope), _lib.ptr(res),
+                                               _lib.ptr(out), _lib.ptr(seg_off), nseg, int(max_rows), _lib.ptr(ws), ws.numel(),
+                                               _lib.stream_ptr(dev)))
+                return out.squeeze()
             if seg is not None:
                 seg_off, max_rows = seg
                 nseg = seg_off.numel() - 1
@@ -148,9 +163,15 @@ class ResidualBlock(nn.Module):
 
     def forward(self, s_feats, q_points, s_points, neighbor_indices):
         x = self.KPConv(self.unary1(s_feats), q_points, s_points, neighbor_indices)
-        x = self.unary2(_norm_act(self.norm_conv, x, self.leaky_relu.negative_slope))
+        h = _norm_act(self.norm_conv, x, self.leaky_relu.negative_slope)
         shortcut = maxpool(s_feats, neighbor_indices) if self.strided else s_feats
-        return self.leaky_relu(x + self.unary_shortcut(shortcut))
+        sc = self.unary_shortcut(shortcut)
+        if isinstance(self.unary2.norm, GroupNorm) and not torch.is_grad_enabled():
+            # unary2's GroupNorm (no activation), + shortcut, LeakyReLU: one apply pass instead of three
+            y = self.unary2.mlp(h)
+            if sc.shape == y.shape:
+                return self.unary2.norm(y, self.leaky_relu.negative_slope, residual=sc)
+        return self.leaky_relu(self.unary2(h) + sc)
 
 
 class KPConvFPN(nn.Module):

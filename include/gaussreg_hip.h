@@ -262,6 +262,11 @@ size_t gr_group_norm_seg_workspace_bytes(int64_t groups, int64_t nseg);
 int gr_group_norm_seg(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta, float eps,
                       float negative_slope, float* out, const int64_t* seg_off, int64_t nseg, int64_t max_seg_rows, void* ws,
                       size_t ws_bytes, void* stream);
+/* GroupNorm -> + residual -> LeakyReLU in one apply pass: the tail of a residual block (kpconv/modules.py:135-138).
+ * seg_off null = one segment (gr_group_norm's workspace), else gr_group_norm_seg's arguments; residual (n,c) or null. */
+int gr_group_norm_res(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta, float eps,
+                      float negative_slope, const float* residual, float* out, const int64_t* seg_off, int64_t nseg,
+                      int64_t max_seg_rows, void* ws, size_t ws_bytes, void* stream);
 /* gr_gs_fuse ("next" row): gs_fusion.py:231-262 gaussian_fuse on the GS .ply wire format.
  * rec1 / rec2: device arrays of 62-float vertex records (gs_fusion.py:172-184 property order).  The host
  * passes the similarity transform split as the reference does (:237-240): h_rotation (3x3 row-major, scale
