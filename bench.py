@@ -460,7 +460,8 @@ def run_gpu(h, args):
         a, b = sharding.shard_bounds(n_total, rank, world)
         reg = pair_pipeline.PairRegistrar(dev)
         pairs = [pair_pipeline.synthetic_room_pair(i, args.pair_points, dev) for i in range(a, b)]
-        reg.register_pairs(pairs[: min(2, len(pairs))])  # warm-up: allocator, lazy kernels
+        reg.register_many(pairs, args.pair_batch)  # warm-up at the timed sizes: the caching allocator then holds every block the
+        # timed pass asks for (a first-time hipMalloc of a 64-pair buffer costs more than the kernels that fill it)
         rows = []
 
         def pairs_pass():
