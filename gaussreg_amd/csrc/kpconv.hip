@@ -607,7 +607,8 @@ static int group_norm_impl(const float* x, int64_t n, int64_t c, int64_t groups,
   const int64_t rows = seg ? max_seg_rows : n;  // rows of the longest segment: sizes the grid
   const int rows_per_pass = cols4 >= gr::GN_T ? 1 : (int)(gr::GN_T / cols4);
   const int tiles = (int)std::min<int64_t>(std::max<int64_t>((rows + rows_per_pass - 1) / rows_per_pass, 1), 1 << 20);
-  const int cap_a = seg ? std::max(1, gr::GN_BLOCKS / (int)std::min<int64_t>(nseg, 16)) : gr::GN_BLOCKS;
+  // pass 1 (read-only) wants the whole device streaming: ~2 048 workgroups over all segments, at most GN_BLOCKS partials each
+  const int cap_a = seg ? std::min(gr::GN_BLOCKS, std::max(1, 2048 / (int)nseg)) : gr::GN_BLOCKS;
   const int nblk_a = std::min(cap_a, tiles);
   const int nblk_b = std::min(tiles, seg ? std::max(8, 4096 / (int)std::min<int64_t>(nseg, 512)) : 4096);
   const size_t per_seg = ((size_t)nblk_a * 2 * groups + groups) * sizeof(double);
