@@ -48,7 +48,7 @@ struct GridWs {
   int32_t* first_idx;   // [N]
   uint64_t* cell_key;   // [N]  raw voxel key per cell
   int32_t* cell_batch;  // [N]
-  int32_t* m_b;         // [B]
+  int32_t* m_b;         // [B + 1]
   int32_t* cell_of_rank;  // [N]
   uint64_t* keys_fo;    // [N]  keys in first-occurrence order
   int32_t* perm;        // [N]
@@ -78,7 +78,7 @@ GridWs carve(void* ws, int64_t n, int64_t batch) {
   w.first_idx = c.take<int32_t>(n);
   w.cell_key = c.take<uint64_t>(n);
   w.cell_batch = c.take<int32_t>(n);
-  w.m_b = c.take<int32_t>(batch);
+  w.m_b = c.take<int32_t>(batch + 1);  // [batch] = the total (one read-back for counts and total)
   w.cell_of_rank = c.take<int32_t>(n);
   w.keys_fo = c.take<uint64_t>(n);
   w.perm = c.take<int32_t>(n);
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void cells_kernel(
   cell_batch[cell] = b;
   const unsigned long long k = keys[t];
   cell_key[cell] = key_bits < 64 ? (k & ((1ull << key_bits) - 1ull)) : k;
-  fo_flags[first] = 1;
+  if (fo_flags) fo_flags[first] = 1;  // (reference order only)
 }
 
 // m_b = number of voxel runs of cloud b: sorted positions [off[b], off[b+1]) belong to cloud b,
@@ -198,17 +198,12 @@ __global__ void cloud_counts_kernel(const int32_t* __restrict__ head_scan,
                                     const int32_t* __restrict__ off, int nb,
                                     int32_t* __restrict__ m_b) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b == 0) m_b[nb] = total[0];
   if (b >= nb) return;
   const int a = off[b], e = off[b + 1];
   const int ca = a < n ? head_scan[a] : total[0];
   const int ce = e < n ? head_scan[e] : total[0];
   m_b[b] = ce - ca;
-}
-
-__global__ __launch_bounds__(256) void copy_cells_kernel(const float* __restrict__ bary, int m,
-                                                         float* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 3 * m) out[i] = bary[i];
 }
 
 // rank cells by first occurrence: rank = (#cells whose first point index is smaller)
@@ -318,7 +313,7 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
   const bool composite = key_bits + b_bits <= 64 && key_bits < 64;
   if (!composite) key_bits = 64;
 
-  GR_HIP(hipMemsetAsync(w.flags, 0, sizeof(int32_t) * n, stream));
+  if (order_mode != GR_ORDER_CELL) GR_HIP(hipMemsetAsync(w.flags, 0, sizeof(int32_t) * n, stream));  // first-occurrence flags
   const dim3 blk(256), grd((unsigned)((n + 255) / 256));
   hipLaunchKernelGGL(keys_kernel, grd, blk, 0, stream, points, (int)n, w.off, nb, w.grids, key_bits, w.keys_a, w.vals_a);
   GR_LAUNCH_CHECK();
@@ -350,28 +345,28 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
                      composite ? 1 : 0, head);
   rc = exclusive_scan_i32(head, head_scan, n, 1, n, w.scan_ws, w.totals, stream);
   if (rc != GR_OK) return rc;
-  int32_t* fo_flags = w.flags;  // zeroed above
+  int32_t* fo_flags = order_mode == GR_ORDER_CELL ? nullptr : w.flags;  // zeroed above
+  // cell order: the barycentres ARE the output rows (cell = rank of the voxel key), written in place
   hipLaunchKernelGGL(cells_kernel, grd, blk, 0, stream, points, keys_sorted, vals_sorted, head, head_scan, (int)n,
-                     w.off, nb, composite ? key_bits : 64, w.bary, w.first_idx, w.cell_key, w.cell_batch, fo_flags);
+                     w.off, nb, composite ? key_bits : 64, order_mode == GR_ORDER_CELL ? out_points : w.bary, w.first_idx,
+                     w.cell_key, w.cell_batch, fo_flags);
   hipLaunchKernelGGL(cloud_counts_kernel, dim3((nb + 255) / 256), blk, 0, stream, head_scan, w.totals, (int)n, w.off,
                      nb, w.m_b);
   GR_LAUNCH_CHECK();
-  std::vector<int32_t> h_mb(batch);
+  std::vector<int32_t> h_mb(batch + 1);
   int32_t h_m = 0;
-  GR_HIP(hipMemcpyAsync(&h_m, w.totals, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-  GR_HIP(hipMemcpyAsync(h_mb.data(), w.m_b, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, stream));
+  GR_HIP(hipMemcpyAsync(h_mb.data(), w.m_b, sizeof(int32_t) * (batch + 1), hipMemcpyDeviceToHost, stream));
 
   if (order_mode == GR_ORDER_CELL) {
     GR_HIP(hipStreamSynchronize(stream));
-    hipLaunchKernelGGL(copy_cells_kernel, dim3((unsigned)((3 * (int64_t)h_m + 255) / 256)), blk, 0, stream, w.bary, h_m,
-                       out_points);
-    GR_LAUNCH_CHECK();
+    h_m = h_mb[batch];
   } else {
     // first-occurrence rank of every cell, keys in that order -> host
     int32_t* fo_scan = w.scan;  // head flags no longer needed
     rc = exclusive_scan_i32(fo_flags, fo_scan, n, 1, n, w.scan_ws, w.totals + 1, stream);
     if (rc != GR_OK) return rc;
-    GR_HIP(hipStreamSynchronize(stream));  // h_m valid
+    GR_HIP(hipStreamSynchronize(stream));
+    h_m = h_mb[batch];
     if (h_m > 0) {
       hipLaunchKernelGGL(fo_rank_kernel, dim3((unsigned)((h_m + 255) / 256)), blk, 0, stream, w.first_idx, w.cell_key,
                          fo_scan, h_m, w.cell_of_rank, w.keys_fo);
