@@ -378,6 +378,8 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
     bx1 = fmaxf(bx1, __shfl_xor(bx1, d, WAVE)), by1 = fmaxf(by1, __shfl_xor(by1, d, WAVE)), bz1 = fmaxf(bz1, __shfl_xor(bz1, d, WAVE));
   }
   float wave_maxd = INFINITY;  // largest running distance among this wave's points (wave-uniform)
+  bool owner = false;          // this lane's best point is one of the wave's published candidates ...
+  int owner_bdi = 0;           // ... and had these distance bits when it was selected
   const int start = start_idx ? min(max(start_idx[b], 0), n - 1) : 0;
   if (threadIdx.x == 0) {
     s_acc[0] = make_float4(P[3 * start], P[3 * start + 1], P[3 * start + 2], 0.f);
@@ -437,6 +439,15 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
       int bdi = __float_as_int(pd[0]);
 #pragma unroll
       for (int j = 1; j < PPT; ++j) bdi = max(bdi, __float_as_int(pd[j]));
+      // The wave's published keys belong to `owner` lanes.  If none of THEIR best distances moved, the top-MW keys are what
+      // they were (a key = distance + index of the same point) and the old bound still bounds (distances only fall): the
+      // samples of this round lowered points the wave never offered, and the selection below can be skipped.
+      if (round > 2 && !__any(owner && bdi != owner_bdi)) touched = false;
+    }
+    if (touched) {
+      int bdi = __float_as_int(pd[0]);
+#pragma unroll
+      for (int j = 1; j < PPT; ++j) bdi = max(bdi, __float_as_int(pd[j]));
       const int none = __float_as_int(-1.0f);
       int cnt = 0, bj = 0, sdi = none;
 #pragma unroll
@@ -469,12 +480,17 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
       }
       // ---- 2. top-MW of the wave's bests (unique keys: exactly one lane owns each maximum); the rest bounds B
       unsigned long long mine = best;
+      owner = false;
+      owner_bdi = bdi;
 #pragma unroll
       for (int r = 0; r < MW; ++r) {
         const unsigned long long w = wave_max_u64(mine);
         if (lane == 0) s_wtop[wv * MW + r] = w;
         if (r == 0) wave_maxd = __uint_as_float((unsigned)(w >> 32));  // keys order by distance first
-        if (mine == w) mine = 0ull;
+        if (mine == w && w != 0ull) {
+          mine = 0ull;
+          owner = true;
+        }
       }
       {
         const unsigned long long wb = wave_max_u64(mine > second ? mine : second);
