@@ -395,6 +395,35 @@ def test_group_norm_matches_torch_fp64(n, c, groups, slope):
     assert err <= 1e-5 * ref.abs().max().item(), (err, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("n,c,segments", [(50000, 128, None), (30000, 256, [0, 9000, 9001, 30000]), (7, 64, None)])
+def test_group_norm_with_residual_and_activation(n, c, segments):
+    """gr_group_norm_res: leaky_relu(GroupNorm(x) + shortcut) in the apply pass (the tail of a residual block,
+    kpconv/modules.py:135-138), plain and with per-segment statistics, against the three torch ops in fp64."""
+    from gaussreg_amd.kpconv_blocks import GroupNorm, norm_segments
+    torch.manual_seed(n + c)
+    m = GroupNorm(32, c).cuda().eval()
+    with torch.no_grad():
+        m.norm.weight.uniform_(0.5, 1.5)
+        m.norm.bias.uniform_(-0.5, 0.5)
+        x = (torch.randn(n, c, device="cuda") * 2 + 0.5).contiguous()
+        res = torch.randn(n, c, device="cuda")
+        bounds = segments or [0, n]
+
+        def ref_of(a, b):
+            y = torch.nn.functional.group_norm(x[a:b].double().t().unsqueeze(0), 32, m.norm.weight.double(), m.norm.bias.double(),
+                                               m.norm.eps).squeeze(0).t()
+            return torch.nn.functional.leaky_relu(y + res[a:b].double(), 0.1)
+        want = torch.cat([ref_of(a, b) for a, b in zip(bounds[:-1], bounds[1:])])
+        if segments:
+            table = {n: (torch.tensor(segments, dtype=torch.int64, device="cuda"), max(b - a for a, b in zip(segments[:-1], segments[1:])))}
+            with norm_segments(table):
+                got = m(x, 0.1, residual=res)
+        else:
+            got = m(x, 0.1, residual=res)
+    err = (got.double().reshape(want.shape) - want).abs().max().item()
+    assert err <= 1e-5 * want.abs().max().item(), (err, want.abs().max().item())
+
+
 def test_group_norm_unsupported_width_takes_the_torch_path():
     """C / 4 = 6 does not divide 256: GroupNorm falls back to nn.GroupNorm on the transposed tensor (still on the GPU)."""
     from gaussreg_amd.kpconv_blocks import GroupNorm
