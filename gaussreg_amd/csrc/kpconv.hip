@@ -116,6 +116,106 @@ __global__ __launch_bounds__(T) void kp_gather_kernel(
   if (threadIdx.x == 0) inv_num[m] = (float)max(s_cnt, 1);                // :114 max(neighbor_num, 1)
 }
 
+// The same on the matrix cores, for Cin a multiple of 16: WF[m] (K x Cin) = A^T (K x H) . F (H x Cin) with A[h][k] the kernel-point
+// influence of neighbour h and F its feature row -- a tiny GEMM per query, one WAVE per query.  v_mfma_f32_16x16x4f32 takes
+// A as (16 kernel points x 4 neighbours) with lane l supplying A[l % 16][l / 16] and B as (4 neighbours x 16 channels) with
+// lane l supplying B[l / 16][l % 16]: every lane computes ONE influence per step (its neighbour, its kernel point; nothing
+// staged in LDS) and loads one feature word per 16-channel tile; shadow neighbours contribute an influence of exactly 0 and
+// a feature of 0.  Cin / 16 MFMAs per four neighbours replace 15 x 4 FMAs per lane: the VALU form above is bound by those
+// FMAs (0.88 ms per layer at 960 k queries x 64 channels), not by the gathers.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int KP_STEPS = 16;  // steps of four neighbours the MFMA gather holds indices for: H <= 64
+
+// Channel <-> (tile, lane) mapping: a lane loads VEC = min(4, NT) consecutive channels of its neighbour's row in one request
+// (16 lanes x 16 bytes = a whole 256-byte row at Cin = 64) and component c of that vector is its B value for tile c of the
+// group -- a tile is the strided channel set {VEC j + c}, which is as good a 16-channel tile as a contiguous one; the D
+// registers then leave as the same vectors.
+template <int NT>  // 16-channel tiles: Cin = 16 NT
+__global__ __launch_bounds__(256) void kp_gather_mfma_kernel(
+    const float* __restrict__ s_feats, const float* __restrict__ q_points, const float* __restrict__ s_points,
+    const int64_t* __restrict__ nbr, int N, int M, int H, int K, const float* __restrict__ kpts, float sigma, float inf,
+    const uint8_t* __restrict__ flag, float* __restrict__ WF, float* __restrict__ inv_num) {
+  constexpr int Cin = 16 * NT;
+  constexpr int VEC = NT < 4 ? NT : 4;  // channels per load (1, 2 or 4)
+  constexpr int NG = NT / VEC;          // loads per neighbour: groups of 16 VEC channels
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int m = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
+  if (m >= M) return;  // wave-uniform; the kernel has no barrier
+  const int kk = lane & 15, hq = lane >> 4;  // this lane's kernel point / neighbour of the step (A), channel column (B)
+  const float qx = q_points[3 * (int64_t)m], qy = q_points[3 * (int64_t)m + 1], qz = q_points[3 * (int64_t)m + 2];
+  const bool kreal = kk < K;
+  const float kx = kreal ? kpts[3 * kk] : 0.f, ky = kreal ? kpts[3 * kk + 1] : 0.f, kz = kreal ? kpts[3 * kk + 2] : 0.f;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int cnt = 0;
+  const int64_t* row = nbr + (int64_t)m * H;
+  // A step is a chain index -> (support point, feature row) -> MFMAs.  All indices of the row are requested first, and the
+  // loads of step s + 1 are issued before the MFMAs of step s, so the wave waits for one memory round trip per row plus
+  // one per step that the arithmetic of the step before does not cover (H <= 4 KP_STEPS; the host checks).
+  int idxs[KP_STEPS];
+#pragma unroll
+  for (int sidx = 0; sidx < KP_STEPS; ++sidx) {
+    const int h = 4 * sidx + hq;
+    const int64_t v = h < H ? row[h] : -1;
+    idxs[sidx] = (v >= N || v < 0) ? -1 : (int)v;
+  }
+  const int nsteps = (H + 3) / 4;
+  float nxn, nyn, nzn;
+  vec_t bn[NG];
+  int fln;
+  auto fetch = [&](int sidx) {
+    const int id = idxs[sidx];
+    const int64_t si = id < 0 ? 0 : id;
+    nxn = s_points[3 * si], nyn = s_points[3 * si + 1], nzn = s_points[3 * si + 2];
+    fln = flag[si];
+    const vec_t* frow = reinterpret_cast<const vec_t*>(s_feats + si * Cin) + kk;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) bn[g] = frow[16 * g];                    // unconditional loads, zeros selected below (:103)
+  };
+  fetch(0);
+#pragma unroll
+  for (int sidx = 0; sidx < KP_STEPS; ++sidx) {
+    if (sidx < nsteps) {  // wave-uniform
+      const bool pad = idxs[sidx] < 0;
+      const float px_ = nxn, py_ = nyn, pz_ = nzn;
+      const int fl = fln;
+      vec_t b[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) b[g] = bn[g];
+      if (sidx + 1 < KP_STEPS && sidx + 1 < nsteps) fetch(sidx + 1);
+      // kpconv.py:90-98: shadow support at +inf, neighbours centred on the query, influence max(1 - |.|/sigma, 0)
+      const float nx = (pad ? inf : px_) - qx, ny = (pad ? inf : py_) - qy, nz = (pad ? inf : pz_) - qz;
+      const float dx = nx - kx, dy = ny - ky, dz = nz - kz;
+      const float sq = (dx * dx + dy * dy) + dz * dz;
+      const float a = (kreal && !pad) ? fmaxf(1.0f - sqrtf(sq) / sigma, 0.0f) : 0.0f;
+      cnt += (kk == 0 && !pad && fl) ? 1 : 0;                             // :112-113, one lane per neighbour
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+          const float bv = b[g][c];
+          acc[g * VEC + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, pad ? 0.0f : bv, acc[g * VEC + c], 0, 0, 0);
+        }
+    }
+  }
+  // D[i][j]: lane l holds rows i = 4 (l / 16) + r, column j = l % 16  ->  WF[m][kernel point i][channels 16 VEC g + VEC j + c]
+  vec_t* dst = reinterpret_cast<vec_t*>(WF + (int64_t)m * K * Cin) + kk;
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 4 * hq + r;
+      vec_t o;
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) o[c] = acc[g * VEC + c][r];
+      if (i < K) dst[(int64_t)i * (Cin / VEC) + 16 * g] = o;
+    }
+  cnt = wave_sum_i32_dpp(cnt);
+  if (lane == 0) inv_num[m] = (float)max(cnt, 1);                         // :114 max(neighbor_num, 1)
+}
+
 constexpr int GT = 64, GK = 32, GLD = GK + 1;
 
 // C (M x N) = A (M x Kd, row-major) . B (Kd x N, row-major);  out = C / den[m] + bias[n]
@@ -353,7 +453,20 @@ extern "C" int gr_kpconv_forward(const float* s_feats, const float* q_points, co
   if (n > 0)
     hipLaunchKernelGGL(rowflag_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, s_feats, (int)n, (int)cin, flag);
   const size_t kp_lds = (size_t)std::min<int64_t>(h, KP_HMAX) * (KP_MAX + 2) * sizeof(float);
-  if (cin <= 64)
+  static const bool mfma_off = getenv("GR_KPCONV_VALU_GATHER") && atoi(getenv("GR_KPCONV_VALU_GATHER")) != 0;
+  const bool mfma = !mfma_off && n > 0 && h <= 4 * KP_STEPS && (cin == 16 || cin == 32 || cin == 64 || cin == 128 || cin == 256);
+  if (mfma) {
+    const dim3 grid((unsigned)((m + 3) / 4)), blk(256);
+#define GR_KP_MFMA(NT)                                                                                                       \
+  hipLaunchKernelGGL((kp_gather_mfma_kernel<NT>), grid, blk, 0, stream, s_feats, q_points, s_points, neighbor_indices, (int)n, \
+                     (int)m, (int)h, (int)k, kernel_points, sigma, inf, flag, WF, num)
+    if (cin == 16) GR_KP_MFMA(1);
+    else if (cin == 32) GR_KP_MFMA(2);
+    else if (cin == 64) GR_KP_MFMA(4);
+    else if (cin == 128) GR_KP_MFMA(8);
+    else GR_KP_MFMA(16);
+#undef GR_KP_MFMA
+  } else if (cin <= 64)
     hipLaunchKernelGGL((kp_gather_kernel<64>), dim3((unsigned)m), dim3(64), kp_lds, stream, s_feats, q_points, s_points,
                        neighbor_indices, (int)n, (int)h, (int)cin, (int)k, kernel_points, sigma, inf, flag, WF, num);
   else if (cin <= 128)
