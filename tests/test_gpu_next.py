@@ -118,6 +118,38 @@ def test_gs_fusion_vs_reference_golden(tmp_path):
     assert np.array_equal(read_gs_ply(po), fused)
 
 
+@pytest.mark.parametrize("n1,n2,layout", [(1001, 333, "mixed"), (5, 3, "mixed"), (64, 65, "mixed"), (640, 449, "runs"),
+                                          (130, 127, "far")])
+def test_gs_fusion_chunk_edges_vs_oracle(n1, n2, layout):
+    """The transform+gather pass works on chunks of 64 vertices fetched as 16-byte vectors: odd sizes (the last vector of
+    the array is partial), clouds smaller than a chunk, whole chunks dropped ("runs": the vertices are sorted along x, so
+    kept and dropped ones come in long runs), everything kept ("far")."""
+    from gaussreg_amd.gs_io import gaussian_fuse_records
+    from oracle import fusion_np
+    rng = np.random.default_rng(n1 * 1000 + n2)
+
+    def records(n, shift):
+        rec = rng.normal(size=(n, 62)).astype(np.float32)
+        rec[:, 0:3] = rng.random((n, 3)) * [4, 3, 2.5] + shift
+        rec[:, 58:62] += np.sign(rec[:, 58:62]) * 0.2
+        return rec
+    rec1, rec2 = records(n1, [0, 0, 0]), records(n2, [100, 0, 0] if layout == "far" else [1.5, 0.2, 0])
+    if layout == "runs":
+        rec1, rec2 = rec1[np.argsort(rec1[:, 0])], rec2[np.argsort(rec2[:, 0])]
+    c, s_ = np.cos(0.2), np.sin(0.2)
+    T = np.eye(4)
+    T[:3, :3] = 1.07 * np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]])
+    T[:3, 3] = [0.1, -0.05, 0.02]
+    want = fusion_np.gaussian_fuse(rec1, rec2, T)
+    got = gaussian_fuse_records(rec1, rec2, T).cpu().numpy()
+    assert got.shape == want.shape
+    if layout == "far":
+        assert got.shape[0] == n1 + n2
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
+    assert np.array_equal(got[:, 0:3].view(np.uint32), want[:, 0:3].view(np.uint32))
+    assert not got[:, 3:6].any()
+
+
 def _planted_similarity(n, outlier_frac, seed):
     rng = np.random.default_rng(seed)
     ax = rng.normal(size=3); ax /= np.linalg.norm(ax); ang = 1.1
