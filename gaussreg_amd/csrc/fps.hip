@@ -206,9 +206,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int FPS_KPL = 8;                     // keys of one slot a polling lane holds (sorted, largest first)
 constexpr int FPS_MW = 4;                      // candidates a single wave passes up (the rest raises the bound B)
 constexpr int FPS_EC = 256;                    // capacity of the candidate set E (B is raised to the largest 5th key if needed)
-constexpr int FPS_SLOT_STRIDE = 32;            // words between slots.  A workgroup publishes M = 8 keys + its bound (one 128-byte
-                                               // line) or, when few workgroups share a cloud, M = 16 + bound (two lines, polled by
-                                               // two lanes); every word carries a 1-bit tag in bit 63
+constexpr int FPS_SLOT_STRIDE = 40;            // words between slots.  A workgroup publishes M = 8 keys + its bound (one 128-byte
+                                               // line) or, when few workgroups share a cloud, M = 16 / 32 + bound (polled by two /
+                                               // four lanes, 64 bytes each); every word carries a 1-bit tag in bit 63
                                                // (keys use 63 bits: d >= 0 has a clear sign bit)
 
 // Wave-wide maximum through the DPP lanes-shift network (row_shr 1/2/4/8, row_bcast 15/31): six dependent VALU ops
@@ -322,7 +322,12 @@ __device__ __forceinline__ int fps_resolve_conflicts_lds(int nq, unsigned long l
 // that distance cannot lower any of them: the wave skips the fold, and a wave no sample reached this round also keeps
 // the candidates it published last round.  After the first few hundred samples that is almost every wave in almost
 // every round; results are exactly those of the unpruned algorithm (keys carry the ORIGINAL index).
-template <int PPT, int M>
+//
+// MW = keys a wave passes up, PT = points a thread offers.  The "wide" variant (M = 32, MW = 8, PT = 2; at most 16
+// workgroups per cloud, i.e. the batched calls) needs 219 rounds where M = 16 / MW = 4 / PT = 1 needs 476 for 200 k -> 30 k
+// with ten workgroups (tools/fps_round_model.py --g 10): with large M the bound B was set by some thread's SECOND point in
+// 79 % of the rounds, so a thread now offers its two best points and only its third bounds.
+template <int PPT, int M, int MW = FPS_MW, int PT = 1>
 __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restrict__ pts, const float* __restrict__ spts,
                                                           const int32_t* __restrict__ perm,
                                                           const int32_t* __restrict__ off,
@@ -330,12 +335,14 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
                                                           const int32_t* __restrict__ start_idx,
                                                           unsigned long long* __restrict__ slots_all,
                                                           int* __restrict__ err, int G, int64_t* __restrict__ out) {
-  constexpr int KPL = FPS_KPL, LPS = M / KPL, MW = FPS_MW, NW = FPS_T / WAVE, EC = FPS_EC;  // LPS: polling lanes per slot
-  static_assert(M % KPL == 0 && FPS_SLOT_STRIDE > M, "slot layout");
+  constexpr int KPL = FPS_KPL, LPS = M / KPL, NW = FPS_T / WAVE;  // LPS: polling lanes per slot
+  constexpr int EC = M > 16 ? 512 : FPS_EC;                       // M = 32 runs with <= 16 workgroups: E never exceeds 512
+  constexpr int NWK = NW * MW, KL = NWK / WAVE;                   // wave-level candidates of the workgroup; per lane of wave 0
+  static_assert(M % KPL == 0 && FPS_SLOT_STRIDE > M && NWK % WAVE == 0 && M < NWK && (PT == 1 || PT == 2), "layout");
   constexpr int UN = PPT <= 10 ? 4 : 2;  // partners in flight in stages 4 and 6: the large slabs have no registers to spare
   extern __shared__ int s_perm[];  // [PPT][FPS_T] original (cloud-local) index of every point this workgroup holds
-  __shared__ __attribute__((aligned(16))) unsigned long long s_wtop[NW * MW];
-  __shared__ unsigned long long s_sel[WAVE];                      // the same keys in descending order
+  __shared__ __attribute__((aligned(16))) unsigned long long s_wtop[NWK];
+  __shared__ unsigned long long s_sel[NWK];                       // the same keys in descending order
   __shared__ unsigned long long s_wbound[NW];
   __shared__ __attribute__((aligned(16))) float4 s_acc[EC];   // the samples accepted in the last round
   __shared__ __attribute__((aligned(16))) float4 s_cand[EC + WAVE];  // E: {x, y, z, d}; padded for stage 4
@@ -380,6 +387,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
   float wave_maxd = INFINITY;  // largest running distance among this wave's points (wave-uniform)
   bool owner = false;          // this lane's best point is one of the wave's published candidates ...
   int owner_bdi = 0;           // ... and had these distance bits when it was selected
+  int owner_sdi = 0;           // (PT = 2: the bits of its second point)
   const int start = start_idx ? min(max(start_idx[b], 0), n - 1) : 0;
   if (threadIdx.x == 0) {
     s_acc[0] = make_float4(P[3 * start], P[3 * start + 1], P[3 * start + 2], 0.f);
@@ -430,7 +438,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
         }
       }
     }
-    if (touched) {  // wave-uniform; otherwise s_wtop / s_wbound still hold this wave's candidates of the last round
+    if (PT == 1 && touched) {  // wave-uniform; otherwise s_wtop / s_wbound still hold this wave's candidates of the last round
       // the thread's best key and a bound for its runner-up.  Distances are >= 0 (empty slots hold -1), so their bit
       // patterns order like the values: the largest distance by integer maxima, then one pass that counts its occurrences,
       // keeps the largest OTHER distance and the slot -- five instructions per point, ONE index read from LDS (building
@@ -444,7 +452,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
       // samples of this round lowered points the wave never offered, and the selection below can be skipped.
       if (round > 2 && !__any(owner && bdi != owner_bdi)) touched = false;
     }
-    if (touched) {
+    if (PT == 1 && touched) {
       int bdi = __float_as_int(pd[0]);
 #pragma unroll
       for (int j = 1; j < PPT; ++j) bdi = max(bdi, __float_as_int(pd[j]));
@@ -497,27 +505,98 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
         if (lane == 0) s_wbound[wv] = wb;
       }
     }
+    if (PT == 2 && touched) {
+      // PT = 2: the thread offers its TWO best points, the third bounds.  m1 >= m2 >= m3: its largest distances as bit
+      // patterns, with multiplicity (distances are >= 0, empty slots hold -1: the patterns order like the values).
+      const int none = __float_as_int(-1.0f);
+      int m1 = none, m2 = none, m3 = none;
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) {
+        int t = __float_as_int(pd[j]);
+        const int a = max(m1, t);
+        t = min(m1, t);
+        m1 = a;
+        const int b2 = max(m2, t);
+        t = min(m2, t);
+        m2 = b2;
+        m3 = max(m3, t);
+      }
+      // published keys belong to `owner` lanes; if neither of THEIR two best distances moved, the wave's top-MW keys are
+      // what they were and the old bound still bounds (distances only fall): skip the selection
+      if (round > 2 && !__any(owner && (m1 != owner_bdi || m2 != owner_sdi))) touched = false;
+      if (touched) {
+        int bj = 0, sj = 0;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+          const int dv = __float_as_int(pd[j]);
+          bj = dv == m1 ? j : bj;
+          sj = dv == m2 ? j : sj;
+        }
+        unsigned long long k1 = 0ull, k2 = 0ull, k3 = 0ull;
+        if (m1 >= 0) k1 = ((unsigned long long)(unsigned)m1 << 32) | (0xffffffffu - (unsigned)s_perm[bj * FPS_T + threadIdx.x]);
+        if (m2 >= 0) k2 = ((unsigned long long)(unsigned)m2 << 32) | (0xffffffffu - (unsigned)s_perm[sj * FPS_T + threadIdx.x]);
+        if (m3 >= 0) k3 = ((unsigned long long)(unsigned)m3 << 32) | 0xffffffffull;  // bounds the key from above
+        if (m1 >= 0 && (m1 == m2 || (m2 >= 0 && m2 == m3))) {  // equal distances inside the thread: the exact keys decide
+          k1 = 0ull, k2 = 0ull, k3 = 0ull;
+#pragma unroll
+          for (int j = 0; j < PPT; ++j) {
+            if (__float_as_int(pd[j]) >= 0) {
+              unsigned long long kk = fps_key(pd[j], s_perm[j * FPS_T + threadIdx.x]);
+              if (kk > k1) { const unsigned long long t = k1; k1 = kk; kk = t; }
+              if (kk > k2) { const unsigned long long t = k2; k2 = kk; kk = t; }
+              if (kk > k3) k3 = kk;
+            }
+          }
+        }
+        // ---- 2. top-MW of the wave's offers (unique keys: exactly one lane owns each maximum; a lane whose first key
+        // went up presents its second); what is left, and every third point, bounds B
+        unsigned long long mine = k1, nxt = k2;
+        owner = false;
+        owner_bdi = m1;
+        owner_sdi = m2;
+#pragma unroll
+        for (int r = 0; r < MW; ++r) {
+          const unsigned long long w = wave_max_u64(mine);
+          if (lane == 0) s_wtop[wv * MW + r] = w;
+          if (r == 0) wave_maxd = __uint_as_float((unsigned)(w >> 32));  // keys order by distance first
+          if (mine == w && w != 0ull) {
+            mine = nxt;
+            nxt = 0ull;
+            owner = true;
+          }
+        }
+        {
+          const unsigned long long wb = wave_max_u64(mine > k3 ? mine : k3);
+          if (lane == 0) s_wbound[wv] = wb;
+        }
+      }
+    }
     __syncthreads();
     // ---- 3. wave 0: workgroup top-M, exchange, the candidate set E
     if (wv == 0) {
-      static_assert(NW * MW == WAVE, "one wave-level candidate per lane");
-      static_assert(EC == 4 * WAVE && KPL > EC / WAVE, "E holds at most EC / 64 keys per polling lane once B is raised");
-      // the 64 wave-level candidates, one per lane, ranked by counting (keys of points are unique; empty slots are 0): 32
-      // independent LDS reads and 64 compares per lane instead of M dependent wave maxima (1.7 us for M = 16)
-      const unsigned long long v0 = s_wtop[lane];
-      int rk = 0;
+      static_assert(KPL >= EC / WAVE, "E holds at most EC / 64 keys per polling lane once B is raised");
+      // the NWK wave-level candidates, KL per lane, ranked by counting (keys of points are unique; empty slots are 0):
+      // independent LDS reads and NWK compares per key instead of M dependent wave maxima (1.7 us for M = 16)
+      unsigned long long v0[KL];
+      int rk[KL];
+#pragma unroll
+      for (int u = 0; u < KL; ++u) v0[u] = s_wtop[lane + u * WAVE], rk[u] = 0;
       {
         const ulonglong2* w2 = reinterpret_cast<const ulonglong2*>(s_wtop);
 #pragma unroll 8
-        for (int t = 0; t < WAVE / 2; ++t) {
+        for (int t = 0; t < NWK / 2; ++t) {
           const ulonglong2 q = w2[t];
-          rk += (int)(q.x > v0) + (int)(q.y > v0);
+#pragma unroll
+          for (int u = 0; u < KL; ++u) rk[u] += (int)(q.x > v0[u]) + (int)(q.y > v0[u]);
         }
       }
-      s_sel[lane] = 0ull;
+#pragma unroll
+      for (int u = 0; u < KL; ++u) s_sel[lane + u * WAVE] = 0ull;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      if (v0 != 0ull) s_sel[rk] = v0;
+#pragma unroll
+      for (int u = 0; u < KL; ++u)
+        if (v0[u] != 0ull) s_sel[rk[u]] = v0[u];
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       static_assert(M < WAVE, "s_sel[M] is the largest key a workgroup holds back");
@@ -581,8 +660,8 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
       for (int r = 0; r < KPL; ++r) cnt += kk[r] > bound ? 1 : 0;  // sorted lists: a prefix
       int incl = wave_incl_scan_add_dpp(cnt);
       int total = __builtin_amdgcn_readlane(incl, WAVE - 1);
-      if (total > EC) {  // keep at most EC / 64 keys of a workgroup: the largest dropped key joins the bound
-        const unsigned long long cut = wave_max_u64(kk[EC / WAVE]);
+      if (EC / WAVE < KPL && total > EC) {  // keep at most EC / 64 keys per polling lane: the largest dropped key joins the bound
+        const unsigned long long cut = wave_max_u64(kk[EC / WAVE < KPL ? EC / WAVE : 0]);
         bound = cut > bound ? cut : bound;
         cnt = 0;
 #pragma unroll
@@ -614,7 +693,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
     // every candidate's rank among the keys on entry.  Thread = (candidate i, share of the partners j); shares are
     // multiples of four partners, the tail of E is padded with points at infinity (no conflict, key 0).
     const int C = s_c;
-    const int cshift = C <= 64 ? 6 : C <= 128 ? 7 : 8;  // candidates padded to a power of two, FPS_T >> cshift partner shares
+    const int cshift = C <= 64 ? 6 : C <= 128 ? 7 : C <= 256 ? 8 : 9;  // candidates padded to a power of two, FPS_T >> cshift partner shares
     const int cpad = 1 << cshift;
     const int share = (((C + (FPS_T >> cshift) - 1) >> (10 - cshift)) + 3) & ~3;
     if ((int)threadIdx.x < C) {  // coordinates by original index (the cloud is read-only: plain cached loads)
@@ -726,9 +805,38 @@ __device__ __forceinline__ unsigned spread3(unsigned v) {  // 10 bits -> every t
   return v;
 }
 
-// key = cloud << 32 | 30-bit Morton code of the point inside its cloud's bounding cube (1024 cells per axis)
+// Position of cell (x, y, z) of a 1024^3 grid along the 3-D Hilbert curve (Skilling's transpose form: undo the excess
+// work of the Gray code bit plane by bit plane, Gray-encode, interleave).  Consecutive positions are ADJACENT cells, so a
+// run of the sorted points is one connected blob; runs of a Morton curve regularly straddle one of its jumps and get a
+// bounding box as large as the room -- which no sample misses (tools/fps_round_model.py --fold-stats: over a 200 k -> 30 k
+// run with ten workgroups the busiest wave folds 18 991 samples in Morton order, 4 144 in Hilbert order).
+__device__ __forceinline__ unsigned hilbert3_code(unsigned x0, unsigned x1, unsigned x2) {
+  unsigned X[3] = {x0, x1, x2};
+#pragma unroll
+  for (unsigned Q = 512u; Q > 1u; Q >>= 1) {
+    const unsigned P = Q - 1u;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (X[i] & Q) X[0] ^= P;
+      else {
+        const unsigned t = (X[0] ^ X[i]) & P;
+        X[0] ^= t;
+        X[i] ^= t;
+      }
+    }
+  }
+  X[1] ^= X[0];
+  X[2] ^= X[1];
+  unsigned t = 0u;
+#pragma unroll
+  for (unsigned Q = 512u; Q > 1u; Q >>= 1)
+    if (X[2] & Q) t ^= Q - 1u;
+  return (spread3(X[0] ^ t) << 2) | (spread3(X[1] ^ t) << 1) | spread3(X[2] ^ t);
+}
+
+// key = cloud << 32 | 30-bit Hilbert (or Morton) code of the point inside its cloud's bounding cube (1024 cells per axis)
 __global__ __launch_bounds__(256) void fps_morton_kernel(const float* __restrict__ pts, const int32_t* __restrict__ off, int nb,
-                                                         const uint32_t* __restrict__ bbox, int n,
+                                                         const uint32_t* __restrict__ bbox, int n, int hilbert,
                                                          unsigned long long* __restrict__ keys) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -739,7 +847,8 @@ __global__ __launch_bounds__(256) void fps_morton_kernel(const float* __restrict
   const unsigned cx = (unsigned)fminf(fmaxf((pts[3 * (int64_t)i] - mnx) * sc, 0.f), 1023.f);      // NaN -> 0
   const unsigned cy = (unsigned)fminf(fmaxf((pts[3 * (int64_t)i + 1] - mny) * sc, 0.f), 1023.f);
   const unsigned cz = (unsigned)fminf(fmaxf((pts[3 * (int64_t)i + 2] - mnz) * sc, 0.f), 1023.f);
-  keys[i] = ((unsigned long long)(unsigned)b << 32) | (spread3(cx) | (spread3(cy) << 1) | (spread3(cz) << 2));
+  const unsigned code = hilbert ? hilbert3_code(cx, cy, cz) : (spread3(cx) | (spread3(cy) << 1) | (spread3(cz) << 2));
+  keys[i] = ((unsigned long long)(unsigned)b << 32) | code;
 }
 
 // sorted position j holds global point vals[j]: copy its coordinates, keep its cloud-local index
@@ -846,8 +955,9 @@ extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64
       int rc = compute_bbox(points, off.data(), h_blk.data(), d_off, (int)batch, mbbox, mblk, stream);
       if (rc != GR_OK) return rc;
       const unsigned nblk = (unsigned)((n + 255) / 256);
+      static const bool morton = getenv("GR_FPS_ORDER") && !strcmp(getenv("GR_FPS_ORDER"), "morton");
       hipLaunchKernelGGL(fps_morton_kernel, dim3(nblk), dim3(256), 0, stream, points, d_off, (int)batch, mbbox, (int)n,
-                         reinterpret_cast<unsigned long long*>(mkeys_a));
+                         morton ? 0 : 1, reinterpret_cast<unsigned long long*>(mkeys_a));
       int cloud_bits = 1;
       while ((1ll << cloud_bits) < batch) ++cloud_bits;
       rc = sort_pairs_u64_iota(sort_tmp, sort_bytes, mkeys_a, mkeys_b, (int64_t)1 << 40, mvals, n, 0, 32 + cloud_bits, stream);
@@ -871,13 +981,15 @@ extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64
       size_t lds = 0;  // the workgroup's original indices: PPT * 1024 ints
       // sixteen keys per workgroup when few workgroups share a cloud (large slabs): more candidates per round
       static const bool m16_off = getenv("GR_FPS_M16") && atoi(getenv("GR_FPS_M16")) == 0;
+      static const bool wide_on = getenv("GR_FPS_WIDE") && atoi(getenv("GR_FPS_WIDE")) != 0;
       const bool m16 = G <= 16 && per > 10 && !m16_off;
+      const bool wide = m16 && wide_on;  // 32 keys per workgroup, 8 per wave, two points per thread (opt-in: see DESIGN 3.5)
       if (per <= 4) fn = reinterpret_cast<const void*>(fps_multi_kernel<4, 8>), lds = 4;
       else if (per <= 7) fn = reinterpret_cast<const void*>(fps_multi_kernel<7, 8>), lds = 7;
       else if (per <= 10) fn = reinterpret_cast<const void*>(fps_multi_kernel<10, 8>), lds = 10;
-      else if (per <= 13) fn = m16 ? reinterpret_cast<const void*>(fps_multi_kernel<13, 16>) : reinterpret_cast<const void*>(fps_multi_kernel<13, 8>), lds = 13;
-      else if (per <= 16) fn = m16 ? reinterpret_cast<const void*>(fps_multi_kernel<16, 16>) : reinterpret_cast<const void*>(fps_multi_kernel<16, 8>), lds = 16;
-      else if (per <= 20) fn = m16 ? reinterpret_cast<const void*>(fps_multi_kernel<20, 16>) : reinterpret_cast<const void*>(fps_multi_kernel<20, 8>), lds = 20;
+      else if (per <= 13) fn = wide ? reinterpret_cast<const void*>(fps_multi_kernel<13, 32, 8, 2>) : m16 ? reinterpret_cast<const void*>(fps_multi_kernel<13, 16>) : reinterpret_cast<const void*>(fps_multi_kernel<13, 8>), lds = 13;
+      else if (per <= 16) fn = wide ? reinterpret_cast<const void*>(fps_multi_kernel<16, 32, 8, 2>) : m16 ? reinterpret_cast<const void*>(fps_multi_kernel<16, 16>) : reinterpret_cast<const void*>(fps_multi_kernel<16, 8>), lds = 16;
+      else if (per <= 20) fn = wide ? reinterpret_cast<const void*>(fps_multi_kernel<20, 32, 8, 2>) : m16 ? reinterpret_cast<const void*>(fps_multi_kernel<20, 16>) : reinterpret_cast<const void*>(fps_multi_kernel<20, 8>), lds = 20;
       lds *= (size_t)FPS_T * sizeof(int);
       if (lds > 48 * 1024) GR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       if (per > 20) {  // slab too large for registers: one sample per round, distances streamed from L2

@@ -49,6 +49,38 @@ def morton_order(p):
     return np.argsort(code, kind="stable")
 
 
+def hilbert_order(p, bits=10):
+    """Position along a 3-D Hilbert curve (Skilling's transpose algorithm) of the 1024^3 cell a point lies in."""
+    mn = p.min(0)
+    ext = (p.max(0) - mn).max()
+    X = np.clip((p - mn) * (((1 << bits) - 1) / ext), 0, (1 << bits) - 1).astype(np.int64)
+    M = 1 << (bits - 1)
+    Q = M
+    while Q > 1:
+        P = Q - 1
+        for i in range(3):
+            m = (X[:, i] & Q) != 0
+            X[m, 0] ^= P
+            t = (X[~m, 0] ^ X[~m, i]) & P
+            X[~m, 0] ^= t
+            X[~m, i] ^= t
+        Q >>= 1
+    for i in range(1, 3):
+        X[:, i] ^= X[:, i - 1]
+    t = np.zeros(len(X), np.int64)
+    Q = M
+    while Q > 1:
+        m = (X[:, 2] & Q) != 0
+        t[m] ^= Q - 1
+        Q >>= 1
+    X ^= t[:, None]
+    key = np.zeros(len(X), np.int64)
+    for b in range(bits - 1, -1, -1):
+        for i in range(3):
+            key = (key << 1) | ((X[:, i] >> b) & 1)
+    return np.argsort(key, kind="stable")
+
+
 def keys_of(d, idx):
     return (d.astype(np.float32).view(np.uint32).astype(np.uint64) << np.uint64(32)) | (np.uint64(0xffffffff) - idx.astype(np.uint64))
 
@@ -67,9 +99,12 @@ def main():
                          "the largest (U+1)-th key of a workgroup), i.e. at most U per workgroup (greedy rule)")
     ap.add_argument("--per-thread", type=int, default=1, help="how many of its points a thread offers (the next one bounds)")
     ap.add_argument("--check", type=int, default=300, help="samples compared with the plain arg-max loop")
+    ap.add_argument("--order", default="morton", choices=["morton", "hilbert"], help="order of the points along the slabs")
+    ap.add_argument("--fold-stats", action="store_true",
+                    help="per round: how many of the accepted samples pass each wave's box test (the fold's critical path)")
     a = ap.parse_args()
     P0 = room(a.n, 0)
-    order = morton_order(P0)
+    order = hilbert_order(P0) if a.order == "hilbert" else morton_order(P0)
     S = P0[order]                       # Morton order; keys carry the ORIGINAL index
     n, G = a.n, a.g
     per = -(-(-(-n // G)) // T) * T
@@ -87,8 +122,21 @@ def main():
     rounds, hist, stops = 0, np.zeros(G * a.m + 1, np.int64), {"bound": 0, "hurt": 0, "all": 0, "k": 0}
     esize, involved, which = [], [], []
     t0 = time.time()
+    # boxes of the waves' runs (static) for --fold-stats
+    SP = np.where(valid[..., None], S[pos], np.nan)                       # (G, nw, ppt, 64, 3)
+    box_lo = np.nanmin(SP, axis=(2, 3)).reshape(-1, 3)
+    box_hi = np.nanmax(SP, axis=(2, 3)).reshape(-1, 3)
+    fold_max, fold_sum, fold_rounds = 0, 0, 0
     while len(out) < a.k:
         A = np.asarray(acc, np.float32)
+        if a.fold_stats and rounds > 0:
+            wmax = np.where(valid, d[pos], -1.0).max(axis=(2, 3)).reshape(-1)    # largest running distance of every wave
+            e = np.maximum(np.maximum(box_lo[:, None, :] - A[None], A[None] - box_hi[:, None, :]), 0.0)
+            lb = (e * e).sum(2)                                                   # (waves, samples)
+            hit = (lb < wmax[:, None]).sum(1)
+            fold_max += int(hit.max())
+            fold_sum += int(hit.sum())
+            fold_rounds += 1
         for s in A:
             diff = S - s
             d = np.minimum(d, (diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]) + diff[:, 2] * diff[:, 2])
@@ -180,7 +228,10 @@ def main():
            "accepted_hist_deciles": [int(x) for x in np.percentile(np.repeat(np.arange(len(hist)), hist), [10, 50, 90])],
            "eligible_deciles": [int(x) for x in np.percentile(esize, [10, 50, 90, 100])] if esize else None,
            "bound_from_thread_runner_up": round(float(np.mean(which)), 3),
-           "in_conflict_deciles": [int(x) for x in np.percentile(involved, [10, 50, 90, 100])] if involved else None})
+           "in_conflict_deciles": [int(x) for x in np.percentile(involved, [10, 50, 90, 100])] if involved else None,
+           "fold": {"order": a.order, "sum_over_rounds_of_the_busiest_wave": fold_max,
+                    "sum_over_rounds_of_the_mean_wave": round(fold_sum / (G * nw), 1),
+                    "sample_wave_pairs": fold_sum} if a.fold_stats else None})
 
 
 if __name__ == "__main__":
