@@ -317,7 +317,7 @@ __device__ __forceinline__ int fps_resolve_conflicts_lds(int nq, unsigned long l
 // the exchange gets four times the slots to poll.
 //
 // Bucket pruning (what fpsample's kd-line buckets do on the CPU, here at wave granularity): the cloud arrives sorted along a
-// Morton curve (`spts`, with `perm` = position -> original index), every wave owns a CONTIGUOUS run of it and keeps that
+// Hilbert curve (`spts`, with `perm` = position -> original index), every wave owns a CONTIGUOUS run of it and keeps that
 // run's bounding box and the largest running distance of its points.  A new sample that is farther from the box than
 // that distance cannot lower any of them: the wave skips the fold, and a wave no sample reached this round also keeps
 // the candidates it published last round.  After the first few hundred samples that is almost every wave in almost
@@ -337,12 +337,12 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
                                                           int* __restrict__ err, int G, int64_t* __restrict__ out) {
   constexpr int KPL = FPS_KPL, LPS = M / KPL, NW = FPS_T / WAVE;  // LPS: polling lanes per slot
   constexpr int EC = M > 16 ? 512 : FPS_EC;                       // M = 32 runs with <= 16 workgroups: E never exceeds 512
-  constexpr int NWK = NW * MW, KL = NWK / WAVE;                   // wave-level candidates of the workgroup; per lane of wave 0
-  static_assert(M % KPL == 0 && FPS_SLOT_STRIDE > M && NWK % WAVE == 0 && M < NWK && (PT == 1 || PT == 2), "layout");
+  constexpr int NWK = NW * MW, KL = (NWK + WAVE - 1) / WAVE;      // wave-level candidates of the workgroup; per lane of wave 0
+  static_assert(M % KPL == 0 && FPS_SLOT_STRIDE > M && NWK % 2 == 0 && M < NWK && (PT == 1 || PT == 2), "layout");
   constexpr int UN = PPT <= 10 ? 4 : 2;  // partners in flight in stages 4 and 6: the large slabs have no registers to spare
   extern __shared__ int s_perm[];  // [PPT][FPS_T] original (cloud-local) index of every point this workgroup holds
   __shared__ __attribute__((aligned(16))) unsigned long long s_wtop[NWK];
-  __shared__ unsigned long long s_sel[NWK];                       // the same keys in descending order
+  __shared__ unsigned long long s_sel[KL * WAVE];                 // the same keys in descending order
   __shared__ unsigned long long s_wbound[NW];
   __shared__ __attribute__((aligned(16))) float4 s_acc[EC];   // the samples accepted in the last round
   __shared__ __attribute__((aligned(16))) float4 s_cand[EC + WAVE];  // E: {x, y, z, d}; padded for stage 4
@@ -357,12 +357,12 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
   const int o0 = samp_off[b], k = samp_off[b + 1] - o0;
   if (n <= 0 || k <= 0) return;
   const float* P = pts + 3 * (int64_t)p0;    // original order: candidate coordinates by original index
-  const float* S = spts + 3 * (int64_t)p0;   // Morton order: the points this thread folds
+  const float* S = spts + 3 * (int64_t)p0;   // curve order: the points this thread folds
   const int per = ((n + G - 1) / G + FPS_T - 1) / FPS_T * FPS_T;
   const int lo = min(part * per, n), hi = min(lo + per, n);
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   const int ppt_used = per / FPS_T;              // <= PPT
-  const int wave_lo = lo + wv * ppt_used * WAVE;  // this wave's run: ppt_used * 64 consecutive Morton positions
+  const int wave_lo = lo + wv * ppt_used * WAVE;  // this wave's run: ppt_used * 64 consecutive curve positions
   float px[PPT], py[PPT], pz[PPT], pd[PPT];
   float bx0 = INFINITY, by0 = INFINITY, bz0 = INFINITY, bx1 = -INFINITY, by1 = -INFINITY, bz1 = -INFINITY;
 #pragma unroll
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
       unsigned long long v0[KL];
       int rk[KL];
 #pragma unroll
-      for (int u = 0; u < KL; ++u) v0[u] = s_wtop[lane + u * WAVE], rk[u] = 0;
+      for (int u = 0; u < KL; ++u) v0[u] = lane + u * WAVE < NWK ? s_wtop[lane + u * WAVE] : 0ull, rk[u] = 0;
       {
         const ulonglong2* w2 = reinterpret_cast<const ulonglong2*>(s_wtop);
 #pragma unroll 8
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
   }
 }
 
-// ---------------------------------------------------------------- Morton order (for the bucket pruning above)
+// ---------------------------------------------------------------- space-filling-curve order (for the bucket pruning above)
 __device__ __forceinline__ unsigned spread3(unsigned v) {  // 10 bits -> every third bit
   v = (v | (v << 16)) & 0x030000ffu;
   v = (v | (v << 8)) & 0x0300f00fu;
@@ -835,7 +835,7 @@ __device__ __forceinline__ unsigned hilbert3_code(unsigned x0, unsigned x1, unsi
 }
 
 // key = cloud << 32 | 30-bit Hilbert (or Morton) code of the point inside its cloud's bounding cube (1024 cells per axis)
-__global__ __launch_bounds__(256) void fps_morton_kernel(const float* __restrict__ pts, const int32_t* __restrict__ off, int nb,
+__global__ __launch_bounds__(256) void fps_curve_kernel(const float* __restrict__ pts, const int32_t* __restrict__ off, int nb,
                                                          const uint32_t* __restrict__ bbox, int n, int hilbert,
                                                          unsigned long long* __restrict__ keys) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -874,7 +874,7 @@ extern "C" size_t gr_fps_workspace_bytes(int64_t n, int64_t batch) {
   return align_up((size_t)n * 4, 256) + 3 * align_up((size_t)(batch + 1) * 4, 256) +
          align_up((size_t)batch * 2 * FPS_GMAX * sizeof(FpsCand), 256) + align_up((size_t)(batch + 1) * 4, 256) +
          align_up((size_t)batch * 2 * FPS_GMAX * FPS_SLOT_STRIDE * 8, 256) +
-         // Morton pre-pass: keys in/out, values out, sorted points, permutation, bounding boxes, rocPRIM scratch
+         // curve pre-pass: keys in/out, values out, sorted points, permutation, bounding boxes, sort scratch
          2 * align_up((size_t)n * 8, 256) + 2 * align_up((size_t)n * 4, 256) + align_up((size_t)n * 12, 256) +
          align_up((size_t)batch * 6 * 4, 256) + align_up((size_t)(batch + 1) * 4, 256) + align_up(sort_pairs_temp_bytes(n), 256) +
          512;
@@ -929,7 +929,7 @@ extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64
   int32_t* mblk = c.take<int32_t>(batch + 1);
   const size_t sort_bytes = sort_pairs_temp_bytes(n);
   void* sort_tmp = c.take<char>(sort_bytes);
-  bool morton_done = false;
+  bool curve_done = false;
   GR_HIP(hipMemcpyAsync(d_off, off.data(), sizeof(int32_t) * (batch + 1), hipMemcpyHostToDevice, stream));
   GR_HIP(hipMemcpyAsync(d_soff, soff.data(), sizeof(int32_t) * (batch + 1), hipMemcpyHostToDevice, stream));
   GR_HIP(hipMemcpyAsync(d_st, st.data(), sizeof(int32_t) * batch, hipMemcpyHostToDevice, stream));
@@ -949,14 +949,14 @@ extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64
     GR_HIP(hipMemsetAsync(cand, 0, sizeof(FpsCand) * (size_t)batch * 2 * FPS_GMAX, stream));
     GR_HIP(hipMemsetAsync(mslots, 0, sizeof(unsigned long long) * (size_t)batch * 2 * FPS_GMAX * FPS_SLOT_STRIDE, stream));
     bool launched = true;
-    if (per <= 20 && !morton_done) {
-      // Morton order for the bucket pruning: boxes, keys, one radix sort over (cloud, code), gather
+    if (per <= 20 && !curve_done) {
+      // curve order for the bucket pruning: boxes, keys, one radix sort over (cloud, code), gather
       std::vector<int32_t> h_blk(batch + 1);
       int rc = compute_bbox(points, off.data(), h_blk.data(), d_off, (int)batch, mbbox, mblk, stream);
       if (rc != GR_OK) return rc;
       const unsigned nblk = (unsigned)((n + 255) / 256);
       static const bool morton = getenv("GR_FPS_ORDER") && !strcmp(getenv("GR_FPS_ORDER"), "morton");
-      hipLaunchKernelGGL(fps_morton_kernel, dim3(nblk), dim3(256), 0, stream, points, d_off, (int)batch, mbbox, (int)n,
+      hipLaunchKernelGGL(fps_curve_kernel, dim3(nblk), dim3(256), 0, stream, points, d_off, (int)batch, mbbox, (int)n,
                          morton ? 0 : 1, reinterpret_cast<unsigned long long*>(mkeys_a));
       int cloud_bits = 1;
       while ((1ll << cloud_bits) < batch) ++cloud_bits;
@@ -965,7 +965,7 @@ extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64
       hipLaunchKernelGGL(fps_gather_kernel, dim3(nblk), dim3(256), 0, stream, points, d_off, (int)batch, mvals, (int)n, spts, mperm);
       GR_LAUNCH_CHECK();
       GR_HIP(hipStreamSynchronize(stream));  // h_blk lives on this stack frame
-      morton_done = true;
+      curve_done = true;
     }
     {
       KernelTimer timer("fps", stream);
@@ -981,9 +981,9 @@ extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64
       size_t lds = 0;  // the workgroup's original indices: PPT * 1024 ints
       // sixteen keys per workgroup when few workgroups share a cloud (large slabs): more candidates per round
       static const bool m16_off = getenv("GR_FPS_M16") && atoi(getenv("GR_FPS_M16")) == 0;
-      static const bool wide_on = getenv("GR_FPS_WIDE") && atoi(getenv("GR_FPS_WIDE")) != 0;
+      static const int wide_mode = getenv("GR_FPS_WIDE") ? atoi(getenv("GR_FPS_WIDE")) : 0;
       const bool m16 = G <= 16 && per > 10 && !m16_off;
-      const bool wide = m16 && wide_on;  // 32 keys per workgroup, 8 per wave, two points per thread (opt-in: see DESIGN 3.5)
+      const bool wide = m16 && wide_mode == 1;  // 32 keys per workgroup, 8 per wave, two points per thread (opt-in: see DESIGN 3.5)
       if (per <= 4) fn = reinterpret_cast<const void*>(fps_multi_kernel<4, 8>), lds = 4;
       else if (per <= 7) fn = reinterpret_cast<const void*>(fps_multi_kernel<7, 8>), lds = 7;
       else if (per <= 10) fn = reinterpret_cast<const void*>(fps_multi_kernel<10, 8>), lds = 10;
