@@ -119,7 +119,7 @@ class _Section:
 class PairRegistrar:
     """Holds the stateless operator modules and the descriptors; `register_pairs` runs a batch."""
 
-    def __init__(self, device, num_samples=30000, fps_clouds_per_call=24, order="reference", use_ransac=True,
+    def __init__(self, device, num_samples=30000, fps_clouds_per_call=None, order="reference", use_ransac=True,
                  profile=False, pair_streams=0, features="descriptor", transformer_batch=16):
         """`pair_streams` = 0 (default): the per-pair stages (point_to_node_partition, SuperPointMatching, correspondences +
         LocalGlobalRegistration, RANSAC) run for all pairs of a batch through the stack-mode entry points
@@ -130,6 +130,8 @@ class PairRegistrar:
         kernels with two host read-backs (correspondence count, RANSAC result); `pair_streams` host threads, each with
         its own HIP stream, work through the pairs so that one pair's read-back waits while the others' kernels run
         (results are identical to the sequential order: nothing is shared between pairs).  1 = one after the other.
+        `fps_clouds_per_call` = None: as many clouds per farthest-point-sampling call as keep every cloud's slabs in registers
+        (20 480 points per workgroup, one workgroup per CU: 25 clouds of 200 k points on 256 CUs).
         `profile=True`: `section_ms` accumulates wall milliseconds per stage (a device synchronise on both sides of
         every stage, pairs one after the other: the total is slower than an unprofiled run)."""
         if features not in ("descriptor", "model"):
@@ -148,7 +150,7 @@ class PairRegistrar:
         self._pool = None
         self._streams = None
         self.num_samples = int(num_samples)
-        self.fps_clouds_per_call = int(fps_clouds_per_call)
+        self.fps_clouds_per_call = None if fps_clouds_per_call is None else int(fps_clouds_per_call)
         self.order = order
         self.use_ransac = use_ransac
         self.coarse_desc = PositionDescriptor(256, 0.35, device, 11)
@@ -180,7 +182,7 @@ class PairRegistrar:
     @torch.no_grad()
     def register_many(self, pairs, batch=64):
         """register_pairs for a whole rank's list: the farthest point sampling runs over ALL clouds first, in calls of
-        `fps_clouds_per_call` clouds (a call's cost per cloud is lowest when its co-operating workgroups fill the device: 24
+        `fps_clouds_per_call` clouds (a call's cost per cloud is lowest when its co-operating workgroups fill the device: 25
         clouds x 10 workgroups; a block of 64 pairs alone would make six calls of 21 - 22), then the pairs go through the other
         stages in blocks of `batch`.  Same rows as register_pairs block by block, except that RANSAC's seed is the pair's
         position in its block either way."""
@@ -196,8 +198,13 @@ class PairRegistrar:
         B = len(pairs)
         clouds = [c for p in pairs for c in (p[0], p[1])]
         sampled = []
+        if clouds_per_call is None:
+            # gr_fps gives a cloud n_cu // clouds workgroups and a workgroup keeps at most 20 x 1024 points in registers
+            n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
+            need = max(1, -(-max(c.shape[0] for c in clouds) // 20480))
+            clouds_per_call = max(1, n_cu // need)
         with self._sec("fps"):
-            # at most clouds_per_call clouds per launch (the co-operating workgroups of a call share the 256 CUs; 24
+            # at most clouds_per_call clouds per launch (the co-operating workgroups of a call share the 256 CUs; 25
             # clouds of 200 k points still fit their slabs in registers), in calls of equal size
             n_calls = -(-2 * B // clouds_per_call)
             if equal_calls:
