@@ -339,6 +339,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
   constexpr int EC = M > 16 ? 512 : FPS_EC;                       // M = 32 runs with <= 16 workgroups: E never exceeds 512
   constexpr int NWK = NW * MW, KL = (NWK + WAVE - 1) / WAVE;      // wave-level candidates of the workgroup; per lane of wave 0
   static_assert(M % KPL == 0 && FPS_SLOT_STRIDE > M && NWK % 2 == 0 && M < NWK && (PT == 1 || PT == 2), "layout");
+  constexpr bool ROWS = PPT >= 13 && PPT <= 16;  // pays where a wave's run is long; the 20-point variant has no registers left for it (+11 spills: +1 %)
   constexpr int UN = PPT <= 10 ? 4 : 2;  // partners in flight in stages 4 and 6: the large slabs have no registers to spare
   extern __shared__ int s_perm[];  // [PPT][FPS_T] original (cloud-local) index of every point this workgroup holds
   __shared__ __attribute__((aligned(16))) unsigned long long s_wtop[NWK];
@@ -384,6 +385,36 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
     bx0 = fminf(bx0, __shfl_xor(bx0, d, WAVE)), by0 = fminf(by0, __shfl_xor(by0, d, WAVE)), bz0 = fminf(bz0, __shfl_xor(bz0, d, WAVE));
     bx1 = fmaxf(bx1, __shfl_xor(bx1, d, WAVE)), by1 = fmaxf(by1, __shfl_xor(by1, d, WAVE)), bz1 = fmaxf(bz1, __shfl_xor(bz1, d, WAVE));
   }
+  // Second level of the pruning: lane r < NP keeps the box of ROW PAIR r (points 2r and 2r + 1 of every lane: 128
+  // consecutive curve positions, the unit of the packed fold).  A sample that reaches the wave's box is tested against
+  // the row pairs before it is folded: the busiest waves are those with sparse or stretched runs, where a sample passes
+  // the wave test but lowers one or two rows (tools/fps_round_model.py --fold-stats: 20 % of the row pairs, and the
+  // critical path of the folds -- the busiest wave of every round -- shrinks by 47 %).
+  constexpr int NP = (PPT + 1) / 2;
+  __shared__ float s_rbox[ROWS ? NW * 6 * 16 : 1];  // [wave][6][row pair]: read back at the start of every round (kept in
+                                                    // registers across the round they cost the 20-point variant 30 spills)
+#pragma unroll
+  for (int r = 0; ROWS && r < NP; ++r) {
+    float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = 2 * r + u;
+      if (j < PPT && pd[j < PPT ? j : 0] >= 0.f) {
+        lo3[0] = fminf(lo3[0], px[j < PPT ? j : 0]), lo3[1] = fminf(lo3[1], py[j < PPT ? j : 0]), lo3[2] = fminf(lo3[2], pz[j < PPT ? j : 0]);
+        hi3[0] = fmaxf(hi3[0], px[j < PPT ? j : 0]), hi3[1] = fmaxf(hi3[1], py[j < PPT ? j : 0]), hi3[2] = fmaxf(hi3[2], pz[j < PPT ? j : 0]);
+      }
+    }
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        lo3[c] = fminf(lo3[c], __shfl_xor(lo3[c], d, WAVE));
+        hi3[c] = fmaxf(hi3[c], __shfl_xor(hi3[c], d, WAVE));
+      }
+    }
+    if (lane < 3) s_rbox[(wv * 6 + lane) * 16 + r] = lane == 0 ? lo3[0] : lane == 1 ? lo3[1] : lo3[2];
+    else if (lane < 6) s_rbox[(wv * 6 + lane) * 16 + r] = lane == 3 ? hi3[0] : lane == 4 ? hi3[1] : hi3[2];
+  }
   float wave_maxd = INFINITY;  // largest running distance among this wave's points (wave-uniform)
   bool owner = false;          // this lane's best point is one of the wave's published candidates ...
   int owner_bdi = 0;           // ... and had these distance bits when it was selected
@@ -405,6 +436,11 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
     const int na = s_na;
     if (threadIdx.x < EC) s_rank[threadIdx.x] = 0, s_flag[threadIdx.x] = 0;  // for stage 4 (read after two barriers)
     bool touched = round == 2;
+    float rb0x = 0.f, rb0y = 0.f, rb0z = 0.f, rb1x = 0.f, rb1y = 0.f, rb1z = 0.f;
+    if (ROWS) {
+      const float* rb = s_rbox + wv * 6 * 16 + min(lane, NP - 1);
+      rb0x = rb[0], rb0y = rb[16], rb0z = rb[32], rb1x = rb[48], rb1y = rb[64], rb1z = rb[80];
+    }
     for (int base = 0; base < na; base += WAVE) {
       // lanes = samples: distance from each new sample to the wave's box, rounded down by more than the fold's own
       // rounding (8 ulp-steps); at or beyond wave_maxd no running distance of this wave can drop.  The first round folds
@@ -424,15 +460,24 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
         // sample-major: one LDS read of the sample, then all of this thread's points two at a time (packed fp32 -- the
         // same sub / mul / add sequence as the scalar form, so distances stay bit-identical)
         const float4 a4 = s_acc[a];
+        unsigned rows = 0xffffffffu;  // row pairs the sample can reach (same bound as the wave test, lanes = row pairs)
+        if (ROWS) {
+          const float ex = fmaxf(fmaxf(rb0x - a4.x, a4.x - rb1x), 0.f), ey = fmaxf(fmaxf(rb0y - a4.y, a4.y - rb1y), 0.f),
+                      ez = fmaxf(fmaxf(rb0z - a4.z, a4.z - rb1z), 0.f);
+          const float lb = ((ex * ex + ey * ey) + ez * ez) * (1.0f - 9.5367431640625e-7f);
+          rows = (unsigned)__ballot(lane < NP && (round == 2 || !(lb >= wave_maxd)));
+        }
         const f32x2 ax2 = {a4.x, a4.x}, ay2 = {a4.y, a4.y}, az2 = {a4.z, a4.z};
 #pragma unroll
         for (int j = 0; j + 1 < PPT; j += 2) {
-          const f32x2 dx = f32x2{px[j], px[j + 1]} - ax2, dy = f32x2{py[j], py[j + 1]} - ay2, dz = f32x2{pz[j], pz[j + 1]} - az2;
-          const f32x2 dd = (dx * dx + dy * dy) + dz * dz;
-          pd[j] = fminf(pd[j], dd.x);
-          pd[j + 1] = fminf(pd[j + 1], dd.y);
+          if ((rows >> (j / 2)) & 1u) {  // wave-uniform
+            const f32x2 dx = f32x2{px[j], px[j + 1]} - ax2, dy = f32x2{py[j], py[j + 1]} - ay2, dz = f32x2{pz[j], pz[j + 1]} - az2;
+            const f32x2 dd = (dx * dx + dy * dy) + dz * dz;
+            pd[j] = fminf(pd[j], dd.x);
+            pd[j + 1] = fminf(pd[j + 1], dd.y);
+          }
         }
-        if (PPT & 1) {
+        if ((PPT & 1) && ((rows >> (PPT / 2)) & 1u)) {
           const float dx = px[PPT - 1] - a4.x, dy = py[PPT - 1] - a4.y, dz = pz[PPT - 1] - a4.z;
           pd[PPT - 1] = fminf(pd[PPT - 1], (dx * dx + dy * dy) + dz * dz);
         }

@@ -127,16 +127,34 @@ def main():
     box_lo = np.nanmin(SP, axis=(2, 3)).reshape(-1, 3)
     box_hi = np.nanmax(SP, axis=(2, 3)).reshape(-1, 3)
     fold_max, fold_sum, fold_rounds = 0, 0, 0
+    npair = (ppt + 1) // 2
+    SPp = np.full((G, nw, 2 * npair, WAVE, 3), np.nan)
+    SPp[:, :, :ppt] = SP
+    SPp = SPp.reshape(G * nw, npair, 2 * WAVE, 3)
+    with np.errstate(all="ignore"):
+        rbox_lo, rbox_hi = np.nanmin(SPp, axis=2), np.nanmax(SPp, axis=2)        # (waves, row pairs, 3)
+    rbox_lo, rbox_hi = np.where(np.isnan(rbox_lo), np.inf, rbox_lo), np.where(np.isnan(rbox_hi), -np.inf, rbox_hi)
+    row_cost = [0, 0, 0]
     while len(out) < a.k:
         A = np.asarray(acc, np.float32)
         if a.fold_stats and rounds > 0:
             wmax = np.where(valid, d[pos], -1.0).max(axis=(2, 3)).reshape(-1)    # largest running distance of every wave
             e = np.maximum(np.maximum(box_lo[:, None, :] - A[None], A[None] - box_hi[:, None, :]), 0.0)
             lb = (e * e).sum(2)                                                   # (waves, samples)
-            hit = (lb < wmax[:, None]).sum(1)
+            passed = lb < wmax[:, None]
+            hit = passed.sum(1)
             fold_max += int(hit.max())
             fold_sum += int(hit.sum())
             fold_rounds += 1
+            # what a second test per PAIR OF ROWS (128 consecutive points, the unit of the packed fold) would leave: cost of a
+            # wave = passed samples x (row tests + loop skeleton) + 8 per (sample, row pair) that still has to be folded
+            e2 = np.maximum(np.maximum(rbox_lo[:, :, None, :] - A[None, None], A[None, None] - rbox_hi[:, :, None, :]), 0.0)
+            rhit = ((e2 * e2).sum(3) < wmax[:, None, None]) & passed[:, None, :]       # (waves, row pairs, samples)
+            cost_now = hit * 8 * rbox_lo.shape[1]
+            cost_rows = hit * 30 + rhit.sum((1, 2)) * 8
+            row_cost[0] += int(cost_now.max())
+            row_cost[1] += int(cost_rows.max())
+            row_cost[2] += int(rhit.sum())
         for s in A:
             diff = S - s
             d = np.minimum(d, (diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]) + diff[:, 2] * diff[:, 2])
@@ -231,7 +249,9 @@ def main():
            "in_conflict_deciles": [int(x) for x in np.percentile(involved, [10, 50, 90, 100])] if involved else None,
            "fold": {"order": a.order, "sum_over_rounds_of_the_busiest_wave": fold_max,
                     "sum_over_rounds_of_the_mean_wave": round(fold_sum / (G * nw), 1),
-                    "sample_wave_pairs": fold_sum} if a.fold_stats else None})
+                    "sample_wave_pairs": fold_sum,
+                    "critical_path_cost_units": {"wave_test_only": row_cost[0], "with_row_pair_tests": row_cost[1],
+                                                 "sample_rowpair_folds": row_cost[2]}} if a.fold_stats else None})
 
 
 if __name__ == "__main__":
