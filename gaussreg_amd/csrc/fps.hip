@@ -339,7 +339,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
   constexpr int EC = M > 16 ? 512 : FPS_EC;                       // M = 32 runs with <= 16 workgroups: E never exceeds 512
   constexpr int NWK = NW * MW, KL = (NWK + WAVE - 1) / WAVE;      // wave-level candidates of the workgroup; per lane of wave 0
   static_assert(M % KPL == 0 && FPS_SLOT_STRIDE > M && NWK % 2 == 0 && M < NWK && (PT == 1 || PT == 2), "layout");
-  constexpr bool ROWS = PPT >= 13 && PPT <= 16;  // pays where a wave's run is long; the 20-point variant has no registers left for it (+11 spills: +1 %)
+  constexpr bool ROWS = PPT >= 13;  // pays where a wave's run is long; the 20-point variant has no registers left for it (+11 spills: +1 %)
   constexpr int UN = PPT <= 10 ? 4 : 2;  // partners in flight in stages 4 and 6: the large slabs have no registers to spare
   extern __shared__ int s_perm[];  // [PPT][FPS_T] original (cloud-local) index of every point this workgroup holds
   __shared__ __attribute__((aligned(16))) unsigned long long s_wtop[NWK];
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
   const float* S = spts + 3 * (int64_t)p0;   // curve order: the points this thread folds
   const int per = ((n + G - 1) / G + FPS_T - 1) / FPS_T * FPS_T;
   const int lo = min(part * per, n), hi = min(lo + per, n);
-  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x / WAVE);  // scalar: a wave's index
   const int ppt_used = per / FPS_T;              // <= PPT
   const int wave_lo = lo + wv * ppt_used * WAVE;  // this wave's run: ppt_used * 64 consecutive curve positions
   float px[PPT], py[PPT], pz[PPT], pd[PPT];
@@ -385,6 +385,13 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
     bx0 = fminf(bx0, __shfl_xor(bx0, d, WAVE)), by0 = fminf(by0, __shfl_xor(by0, d, WAVE)), bz0 = fminf(bz0, __shfl_xor(bz0, d, WAVE));
     bx1 = fmaxf(bx1, __shfl_xor(bx1, d, WAVE)), by1 = fmaxf(by1, __shfl_xor(by1, d, WAVE)), bz1 = fmaxf(bz1, __shfl_xor(bz1, d, WAVE));
   }
+  // wave-uniform from here on: keep the box in scalar registers (six vector registers matter at 20 points per thread)
+  bx0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bx0)));
+  by0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(by0)));
+  bz0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bz0)));
+  bx1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bx1)));
+  by1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(by1)));
+  bz1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bz1)));
   // Second level of the pruning: lane r < NP keeps the box of ROW PAIR r (points 2r and 2r + 1 of every lane: 128
   // consecutive curve positions, the unit of the packed fold).  A sample that reaches the wave's box is tested against
   // the row pairs before it is folded: the busiest waves are those with sparse or stretched runs, where a sample passes
@@ -432,13 +439,17 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
   // rounds start at 2: buffer (round & 1) is reused every second round and its words carry the tag bit
   // (round >> 1) & 1, which flips between consecutive uses; zero-initialised slots read as tag 0, first uses expect 1
   for (unsigned round = 2; count < k; ++round) {
+    // Values derived from the thread / lane index (LDS addresses, masks) are recomputed every round: hoisted out of the loop
+    // they were spilled, and a scratch reload costs more than the one or two instructions that rebuild them.
+    int tid = (int)threadIdx.x, ln = lane;
+    if (PPT > 10) asm volatile("" : "+v"(tid), "+v"(ln));  // (the small variants have registers to spare)
     // ---- 1. fold the samples accepted last round into the running distances; per-thread best and runner-up
     const int na = s_na;
-    if (threadIdx.x < EC) s_rank[threadIdx.x] = 0, s_flag[threadIdx.x] = 0;  // for stage 4 (read after two barriers)
+    if (tid < EC) s_rank[tid] = 0, s_flag[tid] = 0;  // for stage 4 (read after two barriers)
     bool touched = round == 2;
     float rb0x = 0.f, rb0y = 0.f, rb0z = 0.f, rb1x = 0.f, rb1y = 0.f, rb1z = 0.f;
     if (ROWS) {
-      const float* rb = s_rbox + wv * 6 * 16 + min(lane, NP - 1);
+      const float* rb = s_rbox + wv * 6 * 16 + min(ln, NP - 1);
       rb0x = rb[0], rb0y = rb[16], rb0z = rb[32], rb1x = rb[48], rb1y = rb[64], rb1z = rb[80];
     }
     for (int base = 0; base < na; base += WAVE) {
@@ -447,11 +458,11 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
       // everything (a wave without points has an empty box: inf >= inf would skip it and leave its slots unwritten).
       unsigned long long todo;
       {
-        const float4 a4 = s_acc[min(base + lane, EC - 1)];
+        const float4 a4 = s_acc[min(base + ln, EC - 1)];
         const float ex = fmaxf(fmaxf(bx0 - a4.x, a4.x - bx1), 0.f), ey = fmaxf(fmaxf(by0 - a4.y, a4.y - by1), 0.f),
                     ez = fmaxf(fmaxf(bz0 - a4.z, a4.z - bz1), 0.f);
         const float lb = ((ex * ex + ey * ey) + ez * ez) * (1.0f - 9.5367431640625e-7f);
-        todo = __ballot(base + lane < na && (round == 2 || !(lb >= wave_maxd)));
+        todo = __ballot(base + ln < na && (round == 2 || !(lb >= wave_maxd)));
       }
       touched = touched || todo != 0ull;
       while (todo) {
@@ -465,7 +476,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
           const float ex = fmaxf(fmaxf(rb0x - a4.x, a4.x - rb1x), 0.f), ey = fmaxf(fmaxf(rb0y - a4.y, a4.y - rb1y), 0.f),
                       ez = fmaxf(fmaxf(rb0z - a4.z, a4.z - rb1z), 0.f);
           const float lb = ((ex * ex + ey * ey) + ez * ez) * (1.0f - 9.5367431640625e-7f);
-          rows = (unsigned)__ballot(lane < NP && (round == 2 || !(lb >= wave_maxd)));
+          rows = (unsigned)__ballot(ln < NP && (round == 2 || !(lb >= wave_maxd)));
         }
         const f32x2 ax2 = {a4.x, a4.x}, ay2 = {a4.y, a4.y}, az2 = {a4.z, a4.z};
 #pragma unroll
@@ -513,7 +524,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
       }
       unsigned long long best = 0ull, second = 0ull;
       if (bdi >= 0) {
-        best = ((unsigned long long)(unsigned)bdi << 32) | (0xffffffffu - (unsigned)s_perm[bj * FPS_T + threadIdx.x]);
+        best = ((unsigned long long)(unsigned)bdi << 32) | (0xffffffffu - (unsigned)s_perm[bj * FPS_T + tid]);
         second = sdi >= 0 ? ((unsigned long long)(unsigned)sdi << 32) | 0xffffffffull : 0ull;
       }
       if (cnt > 1 && bdi >= 0) {
@@ -521,7 +532,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
           if (__float_as_int(pd[j]) >= 0) {
-            const unsigned long long kk = fps_key(pd[j], s_perm[j * FPS_T + threadIdx.x]);
+            const unsigned long long kk = fps_key(pd[j], s_perm[j * FPS_T + tid]);
             if (kk > best) {
               second = best;
               best = kk;
@@ -538,7 +549,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
 #pragma unroll
       for (int r = 0; r < MW; ++r) {
         const unsigned long long w = wave_max_u64(mine);
-        if (lane == 0) s_wtop[wv * MW + r] = w;
+        if (ln == 0) s_wtop[wv * MW + r] = w;
         if (r == 0) wave_maxd = __uint_as_float((unsigned)(w >> 32));  // keys order by distance first
         if (mine == w && w != 0ull) {
           mine = 0ull;
@@ -547,7 +558,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
       }
       {
         const unsigned long long wb = wave_max_u64(mine > second ? mine : second);
-        if (lane == 0) s_wbound[wv] = wb;
+        if (ln == 0) s_wbound[wv] = wb;
       }
     }
     if (PT == 2 && touched) {
@@ -578,15 +589,15 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
           sj = dv == m2 ? j : sj;
         }
         unsigned long long k1 = 0ull, k2 = 0ull, k3 = 0ull;
-        if (m1 >= 0) k1 = ((unsigned long long)(unsigned)m1 << 32) | (0xffffffffu - (unsigned)s_perm[bj * FPS_T + threadIdx.x]);
-        if (m2 >= 0) k2 = ((unsigned long long)(unsigned)m2 << 32) | (0xffffffffu - (unsigned)s_perm[sj * FPS_T + threadIdx.x]);
+        if (m1 >= 0) k1 = ((unsigned long long)(unsigned)m1 << 32) | (0xffffffffu - (unsigned)s_perm[bj * FPS_T + tid]);
+        if (m2 >= 0) k2 = ((unsigned long long)(unsigned)m2 << 32) | (0xffffffffu - (unsigned)s_perm[sj * FPS_T + tid]);
         if (m3 >= 0) k3 = ((unsigned long long)(unsigned)m3 << 32) | 0xffffffffull;  // bounds the key from above
         if (m1 >= 0 && (m1 == m2 || (m2 >= 0 && m2 == m3))) {  // equal distances inside the thread: the exact keys decide
           k1 = 0ull, k2 = 0ull, k3 = 0ull;
 #pragma unroll
           for (int j = 0; j < PPT; ++j) {
             if (__float_as_int(pd[j]) >= 0) {
-              unsigned long long kk = fps_key(pd[j], s_perm[j * FPS_T + threadIdx.x]);
+              unsigned long long kk = fps_key(pd[j], s_perm[j * FPS_T + tid]);
               if (kk > k1) { const unsigned long long t = k1; k1 = kk; kk = t; }
               if (kk > k2) { const unsigned long long t = k2; k2 = kk; kk = t; }
               if (kk > k3) k3 = kk;
@@ -602,7 +613,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
 #pragma unroll
         for (int r = 0; r < MW; ++r) {
           const unsigned long long w = wave_max_u64(mine);
-          if (lane == 0) s_wtop[wv * MW + r] = w;
+          if (ln == 0) s_wtop[wv * MW + r] = w;
           if (r == 0) wave_maxd = __uint_as_float((unsigned)(w >> 32));  // keys order by distance first
           if (mine == w && w != 0ull) {
             mine = nxt;
@@ -612,20 +623,20 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
         }
         {
           const unsigned long long wb = wave_max_u64(mine > k3 ? mine : k3);
-          if (lane == 0) s_wbound[wv] = wb;
+          if (ln == 0) s_wbound[wv] = wb;
         }
       }
     }
     __syncthreads();
     // ---- 3. wave 0: workgroup top-M, exchange, the candidate set E
     if (wv == 0) {
-      static_assert(KPL >= EC / WAVE, "E holds at most EC / 64 keys per polling lane once B is raised");
+      static_assert(KPL >= EC / WAVE, "E holds at most EC / 64 keys per polling ln once B is raised");
       // the NWK wave-level candidates, KL per lane, ranked by counting (keys of points are unique; empty slots are 0):
       // independent LDS reads and NWK compares per key instead of M dependent wave maxima (1.7 us for M = 16)
       unsigned long long v0[KL];
       int rk[KL];
 #pragma unroll
-      for (int u = 0; u < KL; ++u) v0[u] = lane + u * WAVE < NWK ? s_wtop[lane + u * WAVE] : 0ull, rk[u] = 0;
+      for (int u = 0; u < KL; ++u) v0[u] = ln + u * WAVE < NWK ? s_wtop[ln + u * WAVE] : 0ull, rk[u] = 0;
       {
         const ulonglong2* w2 = reinterpret_cast<const ulonglong2*>(s_wtop);
 #pragma unroll 8
@@ -636,7 +647,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
         }
       }
 #pragma unroll
-      for (int u = 0; u < KL; ++u) s_sel[lane + u * WAVE] = 0ull;
+      for (int u = 0; u < KL; ++u) s_sel[ln + u * WAVE] = 0ull;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -645,8 +656,8 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       static_assert(M < WAVE, "s_sel[M] is the largest key a workgroup holds back");
-      const unsigned long long mykey = lane < M ? s_sel[lane] : 0ull;  // lane r < M: the r-th largest key
-      unsigned long long bnd = wave_max_u64(lane < NW ? s_wbound[lane] : 0ull);
+      const unsigned long long mykey = ln < M ? s_sel[ln] : 0ull;  // lane r < M: the r-th largest key
+      unsigned long long bnd = wave_max_u64(ln < NW ? s_wbound[ln] : 0ull);
       {
         const unsigned long long rest = s_sel[M];
         bnd = rest > bnd ? rest : bnd;
@@ -659,15 +670,15 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
       if (G > 1) {
         unsigned long long* buf = slots + (size_t)(round & 1u) * FPS_GMAX * FPS_SLOT_STRIDE;
         const unsigned long long tag = (unsigned long long)((round >> 1) & 1u) << 63;
-        if (lane < M)
-          __hip_atomic_store(buf + part * FPS_SLOT_STRIDE + lane, tag | mykey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else if (lane == M)
+        if (ln < M)
+          __hip_atomic_store(buf + part * FPS_SLOT_STRIDE + ln, tag | mykey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (ln == M)
           __hip_atomic_store(buf + part * FPS_SLOT_STRIDE + M, tag | bnd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // lane g * LPS + h polls its eight keys of workgroup g's slot (and the bound) until they carry this round's tag bit
         sb = 0ull;
-        if (lane < G * LPS) {
-          const unsigned long long* w = buf + (lane / LPS) * FPS_SLOT_STRIDE;
-          const int h = lane % LPS;
+        if (ln < G * LPS) {
+          const unsigned long long* w = buf + (ln / LPS) * FPS_SLOT_STRIDE;
+          const int h = ln % LPS;
           int spins = 0;
           for (;;) {
             unsigned long long rd[KPL + 1];
@@ -696,7 +707,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
       // every point already at distance zero (more samples asked for than the cloud has distinct points): the arg-max is the
       // lowest index, and stays it -- the sequential algorithm returns index 0 from here on
       if ((wave_max_u64(kk[0]) >> 32) == 0ull && !__any(bad)) {
-        if (lane == 0) s_c = -1;
+        if (ln == 0) s_c = -1;
       } else {
       // B: nothing outside the published keys exceeds the largest workgroup bound
       unsigned long long bound = wave_max_u64(sb);
@@ -722,16 +733,16 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
         }
       }
       if (__any(bad)) {
-        if (lane == 0) s_abort = 1;
+        if (ln == 0) s_abort = 1;
       }
-      if (lane == 0) s_c = total, s_bound = bound;
+      if (ln == 0) s_c = total, s_bound = bound;
       }
     }
     __syncthreads();
     if (s_abort) return;
     if (s_c < 0) {
       if (part == 0)
-        for (int i = count + (int)threadIdx.x; i < k; i += FPS_T) out[o0 + i] = 0;
+        for (int i = count + tid; i < k; i += FPS_T) out[o0 + i] = 0;
       return;
     }
     // ---- 4. all waves: which candidates are in a conflict (some other candidate within sqrt(d) of either of the two), and
@@ -741,17 +752,17 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
     const int cshift = C <= 64 ? 6 : C <= 128 ? 7 : C <= 256 ? 8 : 9;  // candidates padded to a power of two, FPS_T >> cshift partner shares
     const int cpad = 1 << cshift;
     const int share = (((C + (FPS_T >> cshift) - 1) >> (10 - cshift)) + 3) & ~3;
-    if ((int)threadIdx.x < C) {  // coordinates by original index (the cloud is read-only: plain cached loads)
-      const unsigned long long ek = s_ekey[threadIdx.x];
+    if (tid < C) {  // coordinates by original index (the cloud is read-only: plain cached loads)
+      const unsigned long long ek = s_ekey[tid];
       const int ci = (int)(0xffffffffu - (unsigned)(ek & 0xffffffffull));
-      s_cand[threadIdx.x] = make_float4(P[3 * ci], P[3 * ci + 1], P[3 * ci + 2], __uint_as_float((unsigned)(ek >> 32)));
-      s_fkey[threadIdx.x] = ek;
-    } else if ((int)threadIdx.x < share * (FPS_T >> cshift)) {  // <= C + 4 * 16
-      s_cand[threadIdx.x] = make_float4(INFINITY, 0.f, 0.f, 0.f);
-      s_ekey[threadIdx.x] = 0ull;
+      s_cand[tid] = make_float4(P[3 * ci], P[3 * ci + 1], P[3 * ci + 2], __uint_as_float((unsigned)(ek >> 32)));
+      s_fkey[tid] = ek;
+    } else if (tid < share * (FPS_T >> cshift)) {  // <= C + 4 * 16
+      s_cand[tid] = make_float4(INFINITY, 0.f, 0.f, 0.f);
+      s_ekey[tid] = 0ull;
     }
     __syncthreads();
-    const int ci_ = (int)threadIdx.x & (cpad - 1), cg = (int)threadIdx.x >> cshift;
+    const int ci_ = tid & (cpad - 1), cg = tid >> cshift;
     if (C > 1 && ci_ < C) {
       const int j0 = cg * share, j1 = j0 + share;
       const float4 me = s_cand[ci_];
@@ -781,26 +792,26 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
       int nq = 0;
 #pragma unroll
       for (int u = 0; u < EC / WAVE; ++u) {
-        const int t = lane + u * WAVE;
+        const int t = ln + u * WAVE;
         const bool f = t < C && s_flag[t] != 0;
         const unsigned long long m = __ballot(f);
-        if (f) s_q[nq + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = t;
+        if (f) s_q[nq + (int)__builtin_popcountll(m & ((1ull << ln) - 1ull))] = t;
         nq += (int)__builtin_popcountll(m);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       const unsigned long long bound = s_bound;
       int rejected = 0;
-      if (nq > WAVE) rejected = fps_resolve_conflicts_lds(nq, bound, s_q, s_cand, s_ekey, s_fkey, s_cur, lane);
-      else if (nq > 0) rejected = fps_resolve_conflicts(nq, bound, s_q, s_cand, s_ekey, s_fkey, lane);
+      if (nq > WAVE) rejected = fps_resolve_conflicts_lds(nq, bound, s_q, s_cand, s_ekey, s_fkey, s_cur, ln);
+      else if (nq > 0) rejected = fps_resolve_conflicts(nq, bound, s_q, s_cand, s_ekey, s_fkey, ln);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      for (int t = lane; t < ((nq + 3) & ~3); t += WAVE) {  // keys of the conflict candidates, padded with zeros to four
+      for (int t = ln; t < ((nq + 3) & ~3); t += WAVE) {  // keys of the conflict candidates, padded with zeros to four
         const int q = s_q[t < nq ? t : 0];
         s_qe[t] = t < nq ? s_ekey[q] : 0ull;
         s_qf[t] = t < nq ? s_fkey[q] : 0ull;
       }
-      if (lane == 0) s_nq = nq, s_na = min(C - rejected, k - count);
+      if (ln == 0) s_nq = nq, s_na = min(C - rejected, k - count);
     }
     __syncthreads();
     // ---- 6. all waves: output positions.  Accepted keys decrease strictly along the exact sequence, so a sample's
@@ -808,9 +819,9 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
     // the conflict candidates that dropped below it.  A candidate in conflict is ranked from scratch (one wave each).
     {
       const int nq = s_nq, room = k - count;
-      if ((int)threadIdx.x < C && s_flag[threadIdx.x] == 0) {
-        const unsigned long long mk = s_ekey[threadIdx.x];
-        int r = s_rank[threadIdx.x];
+      if (tid < C && s_flag[tid] == 0) {
+        const unsigned long long mk = s_ekey[tid];
+        int r = s_rank[tid];
         for (int u = 0; u < nq; u += UN) {  // (nq is padded to a multiple of four)
           unsigned long long qe[UN], qf[UN];
 #pragma unroll
@@ -819,7 +830,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
           for (int v = 0; v < UN; ++v) r -= (int)(qe[v] > mk) & (int)(qf[v] < mk);
         }
         if (r < room) {
-          s_acc[r] = s_cand[threadIdx.x];
+          s_acc[r] = s_cand[tid];
           if (part == 0) out[o0 + count + r] = (int)(0xffffffffu - (unsigned)(mk & 0xffffffffull));
         }
       }
@@ -828,8 +839,8 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
         const unsigned long long fk = s_fkey[q];
         if (fk == 0ull) continue;  // wave-uniform
         int r = 0;
-        for (int j = lane; j < cpad; j += WAVE) r += (int)__builtin_popcountll(__ballot(j < C && s_fkey[j] > fk));
-        if (lane == 0 && r < room) {
+        for (int j = ln; j < cpad; j += WAVE) r += (int)__builtin_popcountll(__ballot(j < C && s_fkey[j] > fk));
+        if (ln == 0 && r < room) {
           const float4 c = s_cand[q];
           s_acc[r] = make_float4(c.x, c.y, c.z, 0.f);
           if (part == 0) out[o0 + count + r] = (int)(0xffffffffu - (unsigned)(fk & 0xffffffffull));
