@@ -466,7 +466,7 @@ def run_gpu(h, args):
 
         def pairs_pass():
             rows.clear()
-            rows.append(reg.register_many(pairs, args.pair_batch))  # FPS over all clouds of the rank (24 per call), then blocks
+            rows.append(reg.register_many(pairs, args.pair_batch))  # FPS over all clouds of the rank (25 per call), then blocks
 
         L.gr_timing_enable(1)
         p_elapsed = h.timed(pairs_pass, 1, 0, after_warmup=L.gr_timing_reset)
