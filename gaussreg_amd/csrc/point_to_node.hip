@@ -111,6 +111,34 @@ __global__ __launch_bounds__(256) void select_kernel(int n, int K, const int32_t
     n = point_off[c + 1] - pbase;
   }
   const int a = node_start[m], b = node_start[m + 1];
+  if (b - a <= WAVE) {
+    // A node with at most 64 points (nearly every node of GaussReg's pyramid: 9 000 fine points over 770 nodes): one wave
+    // sorts them in registers, one key per lane (bitonic network over ds_bpermute; 21 exchange steps), no LDS, no barrier.
+    // The 2048-wide LDS sort below costs 66 barrier-separated passes whatever the node holds: 2.1 ms per 98 000 nodes.
+    if (threadIdx.x >= WAVE) return;
+    const int lane = threadIdx.x;
+    unsigned long long key = lane < b - a ? keys[a + lane] : KEY_INF;
+#pragma unroll
+    for (int size = 2; size <= WAVE; size <<= 1) {
+#pragma unroll
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        const unsigned lo_o = (unsigned)__shfl_xor((int)(unsigned)key, stride, WAVE);
+        const unsigned hi_o = (unsigned)__shfl_xor((int)(unsigned)(key >> 32), stride, WAVE);
+        const unsigned long long other = ((unsigned long long)hi_o << 32) | lo_o;
+        const bool asc = (lane & size) == 0, lower = (lane & stride) == 0;
+        const bool take_min = lower == asc;
+        key = (other < key) == take_min ? other : key;
+      }
+    }
+    // lane j holds the j-th smallest key; outputs past the node's points are padding
+    for (int j = lane; j < K; j += WAVE) {
+      const unsigned long long kj = j < WAVE ? key : KEY_INF;  // (j < 64 only in the first trip, where j == lane)
+      const bool ok = kj != KEY_INF;
+      knn_idx[(int64_t)m * K + j] = ok ? (int64_t)((unsigned int)(kj & 0xffffffffull) - (unsigned)pbase) : (int64_t)n;
+      knn_mask[(int64_t)m * K + j] = ok ? 1 : 0;
+    }
+    return;
+  }
   // best-K kept in sk[0..K); each round appends up to SEL_N - K fresh keys and re-sorts
   for (int i = threadIdx.x; i < SEL_N; i += 256) sk[i] = KEY_INF;
   __syncthreads();
