@@ -96,7 +96,8 @@ __global__ __launch_bounds__(PM_T) void corr_matrix_kernel(
 // LDS round trips per line, rows and columns one after the other, on half of its threads: 4.3 ms per 16 384 patches.)
 constexpr int PM_KMAX = 4;
 
-__device__ __forceinline__ void pm_topk_line(const float* __restrict__ base, int stride, int len, int k, int* __restrict__ picks) {
+__device__ __forceinline__ void pm_topk_line(const float* __restrict__ base, int stride, int len, int k, float thr,
+                                             int* __restrict__ picks) {
   float tv[PM_KMAX];
   int ti[PM_KMAX];
 #pragma unroll
@@ -105,10 +106,15 @@ __device__ __forceinline__ void pm_topk_line(const float* __restrict__ base, int
     float v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) v[u] = base[(size_t)min(t0 + u, len - 1) * stride];  // loads first; a repeat is filtered below
+    // Only entries above the confidence threshold can become correspondences, and everything ranked ahead of such an entry is
+    // above the threshold too: the top-k of the entries above the threshold decides exactly what the top-k of the whole line
+    // decides.  After the Sinkhorn normalisation a line holds one or two of them, so most steps end here for the whole wave.
+    const bool any4 = (v[0] > thr) | (v[1] > thr) | (v[2] > thr) | (v[3] > thr);
+    if (!__any(any4)) continue;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       float cv = v[u];
-      int ci = t0 + u < len ? t0 + u : -1;
+      int ci = (t0 + u < len && cv > thr) ? t0 + u : -1;
 #pragma unroll
       for (int s = 0; s < PM_KMAX; ++s) {
         // the carried element takes slot s if the slot is empty or holds a strictly smaller value; what it displaces moves on
@@ -142,8 +148,8 @@ __global__ __launch_bounds__(PM_T) void corr_matrix_topk_kernel(
   __syncthreads();
   // lines: rows 0..K1-1 then columns 0..K2-1, dealt out over the workgroup (with K1 = K2 = 128: half the threads each)
   for (int l = threadIdx.x; l < K1 + K2; l += PM_T) {
-    if (l < K1) pm_topk_line(E + (size_t)l * ld, 1, K2, k, rpick + (size_t)l * PM_KMAX);
-    else pm_topk_line(E + (l - K1), ld, K1, k, cpick + (size_t)(l - K1) * PM_KMAX);
+    if (l < K1) pm_topk_line(E + (size_t)l * ld, 1, K2, k, thr, rpick + (size_t)l * PM_KMAX);
+    else pm_topk_line(E + (l - K1), ld, K1, k, thr, cpick + (size_t)(l - K1) * PM_KMAX);
   }
   __syncthreads();
   int n = 0;
