@@ -19,6 +19,10 @@ constexpr int SK_MAIN = SK_T / SK_PARTS;  // rows / columns that get their own f
 constexpr int SK_MAXD = 144;  // largest M + 1 / N + 1 supported
 constexpr int SK_PER = SK_MAXD / SK_PARTS;  // elements of a row / column one lane reduces (<= 36)
 
+constexpr int SS_MAX = 63;                   // sinkhorn_small_kernel: valid rows / columns (+ the dustbin = 64 lanes)
+constexpr int SS_LD = 65;                    // row stride of its compacted matrix in LDS (conflict-free rows and columns)
+constexpr unsigned SS_REDO = 0x7fc0deadu;    // NaN payload: "the wave-sized form gave up on this matrix"
+
 __device__ __forceinline__ float lse_finish(float mx, float s) { return logf(s) + mx; }
 
 // row stride of the padded matrix in LDS: the smallest multiple of 4 >= C that is 4 (mod 32)
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
                                                         const uint8_t* __restrict__ row_masks,
                                                         const uint8_t* __restrict__ col_masks,
                                                         const float* __restrict__ alpha_p, int iters, float inf,
-                                                        float* __restrict__ out, int scaling_form) {
+                                                        float* __restrict__ out, int scaling_form, int after_small) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int R = M + 1, C = N + 1;
   const int ld = sinkhorn_ld(C);
@@ -114,6 +118,11 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
   for (int j = threadIdx.x; j < N; j += SK_T) nc += (!cm || cm[j]) ? 1 : 0;
   if (nr) atomicAdd(&cnt[0], nr);
   if (nc) atomicAdd(&cnt[1], nc);
+  __syncthreads();
+  // behind sinkhorn_small_kernel: a matrix that fits one wave is done, unless that kernel marked it (range guard)
+  if (after_small && cnt[0] <= SS_MAX && cnt[1] <= SS_MAX &&
+      reinterpret_cast<const unsigned*>(out)[(int64_t)b * R * C] != SS_REDO)
+    return;
   // padded scores: [scores | alpha ; alpha ... alpha], masked rows / columns -> -inf (:44-48)
   for (int e = threadIdx.x; e < R * C; e += SK_T) {
     const int i = e / C, j = e % C;
@@ -157,6 +166,7 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
     float kr[SK_PER], kc[SK_PER];
     constexpr int NSIDE = (SK_MAXD + WAVE - 1) / WAVE;  // elements per lane of a row / column reduced by a whole wave
     float ks[NSIDE];                                    // wave 0: the side row's K, wave 1: the side column's
+    bool bad = false;
     static_assert(SK_MAXD - SK_MAIN <= 2 * (SK_T / WAVE), "one side row per wave");
     const bool row_ok = idx < R && (idx >= M || !rm || rm[idx]);
     const bool col_ok = idx < C && (idx >= N || !cm || cm[idx]);
@@ -175,8 +185,17 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
       float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
       mx = fmaxf(mx, quad_xor1(mx));
       mx = fmaxf(mx, quad_xor2(mx));
+      // An entry of K that UNDERFLOWS drops a term of the column sums which its other factor (up to 1e30) could have made the
+      // largest one: the range guard on the sums does not see that, so a matrix with such an entry on a live row and column
+      // takes the log-domain iterations (rows spanning more than ~87: found with 30 % valid slots and scores ~ N(0, 40^2),
+      // where the sums stayed in range and the result was off by 1.5e-3 of the scale).
 #pragma unroll
-      for (int t = 0; t < SK_PER; ++t) kr[t] = (t < row_len && row_ok) ? __expf(kr[t] - mx) : 0.f;  // masked columns: exp(-1e12 - mx) = 0
+      for (int t = 0; t < SK_PER; ++t) {
+        const int j = part + SK_PARTS * t;
+        const bool live = t < row_len && row_ok;
+        kr[t] = live ? __expf(kr[t] - mx) : 0.f;  // masked columns: exp(-1e12 - mx) = 0
+        bad = bad || (live && kr[t] == 0.f && (j >= N || !cm || cm[j]));
+      }
       if (part == 0 && idx < R) rmax[idx] = row_ok ? mx : 0.f;
       for (int r = SK_MAIN + wv; r < R; r += SK_T / WAVE) {  // (rows beyond M are never masked)
         float m = -INFINITY;
@@ -204,13 +223,18 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
       for (int t = 0; t < NSIDE; ++t) {
         const int k = lane + t * WAVE;
         ks[t] = 0.f;
-        if (has_rside && k < C) ks[t] = __expf(S[(size_t)r_side * ld + k] - rmax[r_side]);  // masked columns give 0
+        if (has_rside && k < C) {
+          ks[t] = __expf(S[(size_t)r_side * ld + k] - rmax[r_side]);  // masked columns give 0
+          bad = bad || (ks[t] == 0.f && (k >= N || !cm || cm[k]));
+        }
         if (has_cside && k < R && (k >= M || !rm || rm[k])) ks[t] = __expf(S[(size_t)k * ld + c_side] - rmax[k]);
       }
     }
     const float cw = norm;  // reference point of exp(u + rmax - cw): u + rmax = log_mu - log(row sum) stays near log_mu
-    bool bad = false;
-    for (int it = 0; it < iters; ++it) {
+    if (bad) cnt[3] = 1;
+    __syncthreads();
+    const int fast_iters = cnt[3] ? 0 : iters;  // (an underflowed entry: straight to the log domain)
+    for (int it = 0; it < fast_iters; ++it) {
       {  // rows
         const float4* e4 = reinterpret_cast<const float4*>(Ep + part * SK_PER);
         float s4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -286,7 +310,7 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
     }
     if (bad) cnt[2] = 1;
     __syncthreads();
-    scaled = cnt[2] == 0;
+    scaled = cnt[2] == 0 && cnt[3] == 0;
     if (!scaled) {  // start over in the log domain
       for (int i = threadIdx.x; i < R; i += SK_T) u[i] = 0.f;
       for (int j = threadIdx.x; j < C; j += SK_T) v[j] = 0.f;
@@ -348,6 +372,167 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
   }
 }
 
+// ---------------------------------------------------------------- the same transport for SMALL problems: one wave per matrix
+// A patch of GaussReg's fine matching has 128 slots per side, but a superpoint owns ~30 points: three quarters of the rows and
+// columns are masked, and the masked ones take no part in the iteration (K = 0, u = v = 0).  When at most 63 rows and 63
+// columns are valid, the valid (rows + dustbin) x (columns + dustbin) problem fits ONE wave: lane l owns compacted row l AND
+// compacted column l, keeps both (64 + 64 values of K = exp(S - rowmax)) in registers, and a half-iteration is 64 FMAs against
+// a vector read from LDS as broadcast float4 -- no workgroup barrier, no work on masked entries (the 512-thread kernel above
+// spends 129 x 129 FMAs per half-iteration whatever the masks say: 8.3 ms per 16 384 patches of the pair path).  Same
+// scaling-form arithmetic and the same range guard; a matrix the guard rejects gets a NaN mark in out[0] and is redone by the
+// kernel above, which is launched behind this one and leaves everything else alone.  Masked entries of the output are
+// ((-inf + u_i) + v_j) - norm with u = v = 0 on masked rows / columns, as above.
+
+__global__ __launch_bounds__(WAVE) void sinkhorn_small_kernel(const float* __restrict__ scores, int M, int N,
+                                                              const uint8_t* __restrict__ row_masks,
+                                                              const uint8_t* __restrict__ col_masks,
+                                                              const float* __restrict__ alpha_p, int iters, float inf,
+                                                              float* __restrict__ out) {
+  __shared__ float S[WAVE * SS_LD];
+  __shared__ __attribute__((aligned(16))) float Ev[WAVE];
+  __shared__ __attribute__((aligned(16))) float Fu[WAVE];
+  __shared__ float uu[WAVE], vv[WAVE], rmaxv[WAVE];
+  __shared__ short rlist[WAVE], clist[WAVE], rinv[SK_MAXD], cinv[SK_MAXD];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int R = M + 1, C = N + 1;
+  const uint8_t* rm = row_masks ? row_masks + (int64_t)b * M : nullptr;
+  const uint8_t* cm = col_masks ? col_masks + (int64_t)b * N : nullptr;
+  const float alpha = alpha_p[0];
+  // compacted lists of the valid rows / columns (in index order), and their inverses (-1: masked)
+  int nr = 0, nc = 0;
+  for (int base = 0; base < M; base += WAVE) {
+    const int i = base + lane;
+    const bool ok = i < M && (!rm || rm[i]);
+    const unsigned long long m = __ballot(ok);
+    const int pos = nr + (int)__popcll(m & ((1ull << lane) - 1ull));
+    if (ok && pos < WAVE) rlist[pos] = (short)i;
+    if (i < M) rinv[i] = ok && pos < WAVE ? (short)pos : (short)-1;
+    nr += (int)__popcll(m);
+  }
+  for (int base = 0; base < N; base += WAVE) {
+    const int j = base + lane;
+    const bool ok = j < N && (!cm || cm[j]);
+    const unsigned long long m = __ballot(ok);
+    const int pos = nc + (int)__popcll(m & ((1ull << lane) - 1ull));
+    if (ok && pos < WAVE) clist[pos] = (short)j;
+    if (j < N) cinv[j] = ok && pos < WAVE ? (short)pos : (short)-1;
+    nc += (int)__popcll(m);
+  }
+  if (nr > SS_MAX || nc > SS_MAX) return;  // the 512-thread kernel takes this matrix
+  if (lane == 0) rinv[M] = (short)nr, cinv[N] = (short)nc;  // the dustbins close the compacted lists
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // compacted padded scores: lanes = columns, one row per step (coalesced when the valid columns are a prefix, as the
+  // neighbour lists of point_to_node_partition make them)
+  {
+    const int gj = lane < nc ? clist[lane] : N;
+#pragma unroll 4
+    for (int r = 0; r <= nr; ++r) {
+      const int gi = r < nr ? rlist[r] : M;
+      if (lane <= nc) S[r * SS_LD + lane] = (gi < M && gj < N) ? scores[((int64_t)b * M + gi) * N + gj] : alpha;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const float nvr = (float)nr, nvc = (float)nc;
+  const float norm = -logf(nvr + nvc);                                                    // learnable_sinkhorn.py:52
+  const bool rowl = lane <= nr, coll = lane <= nc;
+  const float log_mu = lane < nr ? norm : logf(nvc) + norm;                               // :54-56 (lane nr: the dustbin row)
+  const float log_nu = lane < nc ? norm : logf(nvr) + norm;                               // :59-61
+  float kr[WAVE], kc[WAVE];
+  float rmax = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < WAVE; ++t) {
+    const float x = S[lane * SS_LD + t];  // (unconditional: past the row's end the value is dropped)
+    kr[t] = (rowl && t <= nc) ? x : -INFINITY;
+    rmax = fmaxf(rmax, kr[t]);
+  }
+  if (!rowl) rmax = 0.f;
+  // An entry of K that underflows drops a term of the sums that the other factor (up to 1e30) could have made the largest:
+  // the range guard on the sums does not see that, so a matrix whose rows span more than ~87 takes the log-domain kernel.
+  bool bad = false;
+#pragma unroll
+  for (int t = 0; t < WAVE; ++t) {
+    const bool live = rowl && t <= nc;
+    kr[t] = live ? __expf(kr[t] - rmax) : 0.f;
+    bad = bad || (live && kr[t] == 0.f);
+  }
+  rmaxv[lane] = rmax;
+  Ev[lane] = coll ? 1.f : 0.f;  // v = 0
+  Fu[lane] = 0.f;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int t = 0; t < WAVE; ++t) {
+    const float x = S[t * SS_LD + lane];
+    kc[t] = (coll && t <= nr) ? __expf(x - rmaxv[t]) : 0.f;
+  }
+  const float cw = norm;
+  float u = 0.f, v = 0.f;
+  for (int it = 0; it < (__any(bad) ? 0 : iters); ++it) {
+    {  // rows: lane l = compacted row l
+      const float4* e4 = reinterpret_cast<const float4*>(Ev);
+      float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t4 = 0; t4 < WAVE / 4; ++t4) {
+        const float4 e = e4[t4];
+        s4[0] = fmaf(kr[4 * t4], e.x, s4[0]);
+        s4[1] = fmaf(kr[4 * t4 + 1], e.y, s4[1]);
+        s4[2] = fmaf(kr[4 * t4 + 2], e.z, s4[2]);
+        s4[3] = fmaf(kr[4 * t4 + 3], e.w, s4[3]);
+      }
+      const float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+      if (rowl) {
+        bad = bad || !(sum > 1e-30f && sum < 1e30f);
+        const float w = log_mu - __logf(sum);  // = u + rmax
+        u = w - rmax;
+        Fu[lane] = __expf(w - cw);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {  // columns: lane l = compacted column l
+      const float4* f4 = reinterpret_cast<const float4*>(Fu);
+      float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t4 = 0; t4 < WAVE / 4; ++t4) {
+        const float4 f = f4[t4];
+        s4[0] = fmaf(kc[4 * t4], f.x, s4[0]);
+        s4[1] = fmaf(kc[4 * t4 + 1], f.y, s4[1]);
+        s4[2] = fmaf(kc[4 * t4 + 2], f.z, s4[2]);
+        s4[3] = fmaf(kc[4 * t4 + 3], f.w, s4[3]);
+      }
+      const float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+      if (coll) {
+        bad = bad || !(sum > 1e-30f && sum < 1e30f);
+        v = log_nu - (cw + __logf(sum));
+        Ev[lane] = __expf(v);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (__any(bad)) {  // out of the normal range: the log-domain iterations of the 512-thread kernel redo this matrix
+    if (lane == 0) reinterpret_cast<unsigned*>(out)[(int64_t)b * R * C] = SS_REDO;
+    return;
+  }
+  uu[lane] = rowl ? u : 0.f;
+  vv[lane] = coll ? v : 0.f;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // scores + u + v - norm (:18, :65) for the whole padded matrix
+  float* o = out + (int64_t)b * R * C;
+  for (int i = 0; i < R; ++i) {
+    const int ri = rinv[i];  // uniform
+    const float ui = ri >= 0 ? uu[ri] : 0.f;
+    for (int j = lane; j < C; j += WAVE) {
+      const int cj = cinv[j];
+      const float sv = (ri >= 0 && cj >= 0) ? S[ri * SS_LD + cj] : -inf;
+      o[(int64_t)i * C + j] = ((sv + ui) + (cj >= 0 ? vv[cj] : 0.f)) - norm;
+    }
+  }
+}
+
 size_t sinkhorn_lds(int M, int N) {
   const int R = M + 1, C = N + 1, ld = sinkhorn_ld(C);
   return sizeof(float) * ((size_t)R * ld + 2 * R + 2 * C + 4 * SK_MAXD) + 96;
@@ -376,9 +561,15 @@ extern "C" int gr_sinkhorn(const float* scores, int64_t batch, int64_t m, int64_
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   // GR_SINKHORN_LOG_DOMAIN=1: every iteration as logsumexp (the fall-back of the scaling form, see the kernel)
   static const int scaling_form = (getenv("GR_SINKHORN_LOG_DOMAIN") && atoi(getenv("GR_SINKHORN_LOG_DOMAIN")) != 0) ? 0 : 1;
+  // matrices with at most 63 valid rows and columns: one wave each (GR_SINKHORN_SMALL=0: everything through the 512-thread kernel)
+  static const int small_on = (getenv("GR_SINKHORN_SMALL") && atoi(getenv("GR_SINKHORN_SMALL")) == 0) ? 0 : 1;
+  const int small = small_on && scaling_form && num_iterations > 0 && (row_masks || col_masks || std::max(m, n) <= SS_MAX);
   KernelTimer timer("sinkhorn", stream);
+  if (small)
+    hipLaunchKernelGGL(sinkhorn_small_kernel, dim3((unsigned)batch), dim3(WAVE), 0, stream, scores, (int)m, (int)n, row_masks,
+                       col_masks, alpha_dev, num_iterations, inf, out);
   hipLaunchKernelGGL(sinkhorn_kernel, dim3((unsigned)batch), dim3(SK_T), lds, stream, scores, (int)m, (int)n, row_masks,
-                     col_masks, alpha_dev, num_iterations, inf, out, scaling_form);
+                     col_masks, alpha_dev, num_iterations, inf, out, scaling_form, small);
   GR_LAUNCH_CHECK();
   return GR_OK;
 }

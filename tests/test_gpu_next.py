@@ -67,6 +67,39 @@ def test_sinkhorn_wide_score_ranges(sigma):
     assert_rel_scale(got, want, 1e-5, f"sinkhorn, scores ~ N(0, {sigma}^2)", mask=live)
 
 
+@pytest.mark.parametrize("sigma,keep", [(1.5, 0.25), (6.0, 0.45), (40.0, 0.3), (1.5, 0.02)])
+def test_sinkhorn_wave_sized_problems(sigma, keep):
+    """Matrices with at most 63 valid rows and columns run one wave each on the compacted valid problem (the patches of
+    the fine matching: ~30 valid of 128 slots per side); the others, and those the range guard of the wave-sized form rejects
+    (scores spread over +-150), go through the 512-thread kernel behind it.  Random (non-prefix) masks around the 63 limit,
+    prefix masks like point_to_node_partition's, a matrix with a single valid row, one without masks at all -- all against
+    the oracle; masked entries are the -1e12 stand-ins."""
+    from gaussreg_amd.sinkhorn import LearnableLogOptimalTransport
+    from oracle import matching_np as M
+    rng = np.random.default_rng(int(sigma * 10) + int(keep * 100))
+    B, K = 24, 128
+    s = (rng.normal(size=(B, K, K)) * sigma).astype(np.float32)
+    rm, cm = rng.random((B, K)) < keep, rng.random((B, K)) < keep
+    rm[:, 0] = True
+    cm[:, 5] = True                                      # (no empty side: the reference divides by log(0) there)
+    rm[1], cm[1] = np.arange(K) < 63, np.arange(K) < 63  # prefix masks at the limit
+    rm[2], cm[2] = np.arange(K) < 64, np.arange(K) < 20  # one side over the limit: the 512-thread kernel
+    rm[3], cm[3] = np.arange(K) == 77, np.arange(K) < 9  # a single valid row
+    rm[4], cm[4] = True, True                            # nothing masked
+    want = M.sinkhorn(s, rm, cm, alpha=1.0, num_iterations=100)
+    got = LearnableLogOptimalTransport(100)(_c(s), _c(rm), _c(cm)).cpu().numpy()
+    live = want > -1e6
+    assert np.isfinite(got).all()
+    assert np.array_equal(got > -1e6, live)
+    assert_rel_scale(got, want, 1e-5, f"sinkhorn, wave-sized, scores ~ N(0, {sigma}^2), {keep} kept", mask=live)
+    np.testing.assert_allclose(got[~live], want[~live], rtol=1e-6)
+    # no masks, 40 x 50: every matrix is wave-sized
+    s2 = (rng.normal(size=(7, 40, 50)) * sigma).astype(np.float32)
+    want2 = M.sinkhorn(s2, None, None, alpha=1.0, num_iterations=100)
+    got2 = LearnableLogOptimalTransport(100)(_c(s2)).cpu().numpy()
+    assert_rel_scale(got2, want2, 1e-5, "sinkhorn 7x40x50, no masks")
+
+
 def test_kpconv_vs_reference_golden():
     from geotransformer.modules.kpconv import KPConv, maxpool, nearest_upsample
     g = load_golden("next_rows.npz")
