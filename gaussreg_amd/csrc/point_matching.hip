@@ -144,26 +144,68 @@ __global__ __launch_bounds__(PM_T) void corr_matrix_topk_kernel(
   int* wsum = cpick + (size_t)K2 * PM_KMAX;
   const int b = blockIdx.x;
   const float* sm = score + (int64_t)b * K1 * K2;
-  for (int e = threadIdx.x; e < K1 * K2; e += PM_T) E[(e / K2) * ld + (e % K2)] = scores_are_exp ? sm[e] : expf(sm[e]);
+  // Masked slots (three quarters of a patch of the fine matching) can never be correspondences: their outputs are written as
+  // zeros without a look at the picks.  (Their scores still take part in the top-k of the live lines, as in the reference:
+  // point_matching.py applies the masks after the selection.)
+  uint8_t* rmk = reinterpret_cast<uint8_t*>(wsum + PM_T / WAVE);  // [K1] then [K2]
+  uint8_t* cmk = rmk + K1;
+  for (int i = threadIdx.x; i < K1; i += PM_T) rmk[i] = ref_masks[(int64_t)b * K1 + i];
+  for (int j = threadIdx.x; j < K2; j += PM_T) cmk[j] = src_masks[(int64_t)b * K2 + j];
+  __syncthreads();
+  const bool quad = (K2 & 3) == 0 && (reinterpret_cast<uintptr_t>(sm) & 15) == 0 && (reinterpret_cast<uintptr_t>(corr) & 3) == 0;
+  if (quad) {
+    for (int q = threadIdx.x; q < K1 * K2 / 4; q += PM_T) {
+      const int i = (4 * q) / K2, j = 4 * q - i * K2;
+      float4 x = reinterpret_cast<const float4*>(sm)[q];
+      if (!scores_are_exp) x = make_float4(expf(x.x), expf(x.y), expf(x.z), expf(x.w));
+      float* d = E + i * ld + j;
+      d[0] = x.x, d[1] = x.y, d[2] = x.z, d[3] = x.w;
+    }
+  } else {
+    for (int e = threadIdx.x; e < K1 * K2; e += PM_T) {
+      const int i = e / K2, j = e % K2;
+      E[i * ld + j] = scores_are_exp ? sm[e] : expf(sm[e]);
+    }
+  }
   __syncthreads();
   // lines: rows 0..K1-1 then columns 0..K2-1, dealt out over the workgroup (with K1 = K2 = 128: half the threads each)
   for (int l = threadIdx.x; l < K1 + K2; l += PM_T) {
+    const bool live = l < K1 ? rmk[l] != 0 : cmk[l - K1] != 0;  // a masked line's picks are never looked at
+    if (!live) continue;
     if (l < K1) pm_topk_line(E + (size_t)l * ld, 1, K2, k, thr, rpick + (size_t)l * PM_KMAX);
     else pm_topk_line(E + (l - K1), ld, K1, k, thr, cpick + (size_t)(l - K1) * PM_KMAX);
   }
   __syncthreads();
   int n = 0;
-  for (int e = threadIdx.x; e < K1 * K2; e += PM_T) {
-    const int i = e / K2, j = e % K2;
+  auto entry = [&](int i, int j) -> bool {
+    if (!(rmk[i] && cmk[j])) return false;
     const bool over = E[i * ld + j] > thr;  // torch.gt(score_mat, confidence_threshold)
     const int4 rp = *reinterpret_cast<const int4*>(rpick + (size_t)i * PM_KMAX);
     const int4 cp = *reinterpret_cast<const int4*>(cpick + (size_t)j * PM_KMAX);
     const bool r = over && (rp.x == j || rp.y == j || rp.z == j || rp.w == j);
     const bool c = over && (cp.x == i || cp.y == i || cp.z == i || cp.w == i);
-    bool m = mutual ? (r && c) : (r || c);
-    m = m && ref_masks[(int64_t)b * K1 + i] && src_masks[(int64_t)b * K2 + j];
-    corr[(int64_t)b * K1 * K2 + e] = m ? 1 : 0;
-    n += m ? 1 : 0;
+    return mutual ? (r && c) : (r || c);
+  };
+  if (quad) {
+    for (int q = threadIdx.x; q < K1 * K2 / 4; q += PM_T) {
+      const int i = (4 * q) / K2, j = 4 * q - i * K2;
+      unsigned word = 0u;
+      if (rmk[i] && (cmk[j] | cmk[j + 1] | cmk[j + 2] | cmk[j + 3])) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const bool m = entry(i, j + c);
+          word |= m ? 1u << (8 * c) : 0u;
+          n += m ? 1 : 0;
+        }
+      }
+      reinterpret_cast<unsigned*>(corr + (int64_t)b * K1 * K2)[q] = word;
+    }
+  } else {
+    for (int e = threadIdx.x; e < K1 * K2; e += PM_T) {
+      const bool m = entry(e / K2, e % K2);
+      corr[(int64_t)b * K1 * K2 + e] = m ? 1 : 0;
+      n += m ? 1 : 0;
+    }
   }
 #pragma unroll
   for (int d = WAVE / 2; d > 0; d >>= 1) n += __shfl_xor(n, d, WAVE);
@@ -177,7 +219,8 @@ __global__ __launch_bounds__(PM_T) void corr_matrix_topk_kernel(
 }
 
 size_t corr_topk_lds_bytes(int K1, int K2) {
-  return (sizeof(float) * (size_t)K1 * (K2 + 1) + 15) / 16 * 16 + sizeof(int) * (size_t)(K1 + K2) * PM_KMAX + 64;
+  return (sizeof(float) * (size_t)K1 * (K2 + 1) + 15) / 16 * 16 + sizeof(int) * (size_t)(K1 + K2) * PM_KMAX + 64 +
+         (((size_t)K1 + K2 + 15) / 16) * 16;  // + the patch's masks
 }
 
 // emit the true entries of patch b in row-major order at offsets[b] (exclusive scan of counts)
@@ -193,8 +236,20 @@ __global__ __launch_bounds__(PM_T) void corr_gather_kernel(
   const int per = (total + PM_T - 1) / PM_T;  // contiguous chunk per thread keeps row-major order
   const int e0 = threadIdx.x * per, e1 = min(total, e0 + per);
   const uint8_t* cm = corr + (int64_t)b * total;
+  // a thread's chunk as 16-byte vectors when it is 64 bytes (128 x 128 patches, 256 threads): the 0 / 1 bytes are counted
+  // with popcounts and the set ones are walked bit by bit -- byte loads made this kernel 0.8 ms per 16 384 patches
+  const bool vec = per == 64 && e1 - e0 == 64 && ((reinterpret_cast<uintptr_t>(cm) + e0) & 15) == 0;
+  uint4 cv[4] = {};
   int n = 0;
-  for (int e = e0; e < e1; ++e) n += cm[e];
+  if (vec) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      cv[q] = reinterpret_cast<const uint4*>(cm + e0)[q];
+      n += __popc(cv[q].x) + __popc(cv[q].y) + __popc(cv[q].z) + __popc(cv[q].w);
+    }
+  } else {
+    for (int e = e0; e < e1; ++e) n += cm[e];
+  }
   const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
   int inc = n;
 #pragma unroll
@@ -208,8 +263,7 @@ __global__ __launch_bounds__(PM_T) void corr_gather_kernel(
   for (int u = 0; u < w; ++u) base += wsum[u];
   int pos = base + inc - n;
   const float gsc = use_global ? global_scores[b] : 1.0f;
-  for (int e = e0; e < e1; ++e) {
-    if (!cm[e]) continue;
+  auto emit = [&](int e) {
     const int i = e / K2, j = e % K2;
     const int64_t ri = (int64_t)b * K1 + i, sj = (int64_t)b * K2 + j;
 #pragma unroll
@@ -223,6 +277,25 @@ __global__ __launch_bounds__(PM_T) void corr_gather_kernel(
     if (use_global) s = s * gsc;  // point_matching.py:103
     o_scores[pos] = s;            // :105 (times corr_mat.float() == 1 here)
     ++pos;
+  };
+  if (vec) {
+    if (n == 0) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned wd[4] = {cv[q].x, cv[q].y, cv[q].z, cv[q].w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        unsigned bits = wd[c];
+        while (bits) {
+          const int k = (__ffs((int)bits) - 1) >> 3;  // bytes are 0 or 1: bit 0 of byte k
+          emit(e0 + 16 * q + 4 * c + k);
+          bits &= bits - 1u;
+        }
+      }
+    }
+  } else {
+    for (int e = e0; e < e1; ++e)
+      if (cm[e]) emit(e);
   }
 }
 
