@@ -446,6 +446,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
     // ---- 1. fold the samples accepted last round into the running distances; per-thread best and runner-up
     const int na = s_na;
     if (tid < EC) s_rank[tid] = 0, s_flag[tid] = 0;  // for stage 4 (read after two barriers)
+    if (tid < KL * WAVE) s_sel[tid] = 0ull;          // for stage 3a (last read in stage 3 of the previous round)
     bool touched = round == 2;
     float rb0x = 0.f, rb0y = 0.f, rb0z = 0.f, rb1x = 0.f, rb1y = 0.f, rb1z = 0.f;
     if (ROWS) {
@@ -628,33 +629,29 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
       }
     }
     __syncthreads();
-    // ---- 3. wave 0: workgroup top-M, exchange, the candidate set E
-    if (wv == 0) {
-      static_assert(KPL >= EC / WAVE, "E holds at most EC / 64 keys per polling ln once B is raised");
-      // the NWK wave-level candidates, KL per lane, ranked by counting (keys of points are unique; empty slots are 0):
-      // independent LDS reads and NWK compares per key instead of M dependent wave maxima (1.7 us for M = 16)
-      unsigned long long v0[KL];
-      int rk[KL];
+    // ---- 3a. all waves: the workgroup's NWK wave-level candidates in descending order, ranked by counting (keys of points are
+    // unique; empty slots are 0).  Wave w ranks its own MW keys, 64 / MW lanes per key, each lane against its share of the
+    // NWK keys; the partial counts meet through lane shuffles.  (One wave ranking all of them -- one key per lane, NWK
+    // compares each -- was 1.1 us of every round with the other fifteen waves waiting at the barrier.)
+    {
+      constexpr int LPK = WAVE / MW, TPL = NWK / LPK;  // lanes per key, keys a lane compares against
+      static_assert(WAVE % MW == 0 && NWK % LPK == 0 && TPL % 2 == 0, "ranking layout");
+      const unsigned long long mine = s_wtop[wv * MW + ln / LPK];
+      const ulonglong2* w2 = reinterpret_cast<const ulonglong2*>(s_wtop) + (ln % LPK) * (TPL / 2);
+      int rk = 0;
 #pragma unroll
-      for (int u = 0; u < KL; ++u) v0[u] = ln + u * WAVE < NWK ? s_wtop[ln + u * WAVE] : 0ull, rk[u] = 0;
-      {
-        const ulonglong2* w2 = reinterpret_cast<const ulonglong2*>(s_wtop);
-#pragma unroll 8
-        for (int t = 0; t < NWK / 2; ++t) {
-          const ulonglong2 q = w2[t];
-#pragma unroll
-          for (int u = 0; u < KL; ++u) rk[u] += (int)(q.x > v0[u]) + (int)(q.y > v0[u]);
-        }
+      for (int t = 0; t < TPL / 2; ++t) {
+        const ulonglong2 q = w2[t];
+        rk += (int)(q.x > mine) + (int)(q.y > mine);
       }
 #pragma unroll
-      for (int u = 0; u < KL; ++u) s_sel[ln + u * WAVE] = 0ull;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int u = 0; u < KL; ++u)
-        if (v0[u] != 0ull) s_sel[rk[u]] = v0[u];
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      for (int d = LPK / 2; d > 0; d >>= 1) rk += __shfl_xor(rk, d, WAVE);
+      if (ln % LPK == 0 && mine != 0ull) s_sel[rk] = mine;
+    }
+    __syncthreads();
+    // ---- 3. wave 0: workgroup top-M, exchange, the candidate set E
+    if (wv == 0) {
+      static_assert(KPL >= EC / WAVE, "E holds at most EC / 64 keys per polling lane once B is raised");
       static_assert(M < WAVE, "s_sel[M] is the largest key a workgroup holds back");
       const unsigned long long mykey = ln < M ? s_sel[ln] : 0ull;  // lane r < M: the r-th largest key
       unsigned long long bnd = wave_max_u64(ln < NW ? s_wbound[ln] : 0ull);
