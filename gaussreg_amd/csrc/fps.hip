@@ -351,7 +351,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
   __shared__ int s_rank[EC], s_flag[EC], s_q[EC];
   __shared__ float s_cur[EC];
   __shared__ unsigned long long s_qe[EC], s_qf[EC];     // the conflict candidates' keys on entry / when accepted
-  __shared__ int s_na, s_abort, s_c, s_nq;
+  __shared__ int s_na, s_abort, s_c, s_nq, s_nqc;
   __shared__ unsigned long long s_bound;
   const int b = blockIdx.x / G, part = blockIdx.x % G;
   const int p0 = off[b], n = off[b + 1] - p0;
@@ -447,6 +447,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
     const int na = s_na;
     if (tid < EC) s_rank[tid] = 0, s_flag[tid] = 0;  // for stage 4 (read after two barriers)
     if (tid < KL * WAVE) s_sel[tid] = 0ull;          // for stage 3a (last read in stage 3 of the previous round)
+    if (tid == 0) s_nqc = 0;                         // stage 4's list of the candidates in conflict
     bool touched = round == 2;
     float rb0x = 0.f, rb0y = 0.f, rb0z = 0.f, rb1x = 0.f, rb1y = 0.f, rb1z = 0.f;
     if (ROWS) {
@@ -780,23 +781,15 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
           above += (int)(ok[u] > mk);
         }
       }
-      if (near > 0) s_flag[ci_] = 1;
+      // the first share that sees a conflict of candidate ci_ appends it to the list of stage 5 (any order: the chain goes by
+      // keys) -- wave 0 collecting the flags with ballots afterwards was 0.3 us of its serial section
+      if (near > 0 && atomicExch(&s_flag[ci_], 1) == 0) s_q[atomicAdd(&s_nqc, 1)] = ci_;
       if (above) atomicAdd(&s_rank[ci_], above);
     }
     __syncthreads();
     // ---- 5. wave 0: the exact chain over the candidates in conflict
     if (wv == 0) {
-      int nq = 0;
-#pragma unroll
-      for (int u = 0; u < EC / WAVE; ++u) {
-        const int t = ln + u * WAVE;
-        const bool f = t < C && s_flag[t] != 0;
-        const unsigned long long m = __ballot(f);
-        if (f) s_q[nq + (int)__builtin_popcountll(m & ((1ull << ln) - 1ull))] = t;
-        nq += (int)__builtin_popcountll(m);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      const int nq = s_nqc;
       const unsigned long long bound = s_bound;
       int rejected = 0;
       if (nq > WAVE) rejected = fps_resolve_conflicts_lds(nq, bound, s_q, s_cand, s_ekey, s_fkey, s_cur, ln);
