@@ -21,7 +21,6 @@ constexpr int SK_PER = SK_MAXD / SK_PARTS;  // elements of a row / column one la
 
 constexpr int SS_MAX = 63;                   // sinkhorn_small_kernel: valid rows / columns (+ the dustbin = 64 lanes)
 constexpr int SS_LD = 65;                    // row stride of its compacted matrix in LDS (conflict-free rows and columns)
-constexpr unsigned SS_REDO = 0x7fc0deadu;    // NaN payload: "the wave-sized form gave up on this matrix"
 
 __device__ __forceinline__ float lse_finish(float mx, float s) { return logf(s) + mx; }
 
@@ -87,11 +86,11 @@ __device__ __forceinline__ float lse_merge4(float mx, float s) {
 // most twice per wave (the 64-lane minimum): bank = 4 idx + part + 4 t, and 16 part + idx + 4 t (36 * 132 = 16 mod 32).
 // The slice stays in registers between the max pass and the sum pass; the four partials meet through DPP, so an iteration
 // has two barriers (u complete, v complete) and no partial arrays in LDS.
-__global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict__ scores, int M, int N,
-                                                        const uint8_t* __restrict__ row_masks,
-                                                        const uint8_t* __restrict__ col_masks,
-                                                        const float* __restrict__ alpha_p, int iters, float inf,
-                                                        float* __restrict__ out, int scaling_form, int after_small) {
+__device__ __forceinline__ void sinkhorn_matrix(const int b, const float* __restrict__ scores, int M, int N,
+                                                const uint8_t* __restrict__ row_masks,
+                                                const uint8_t* __restrict__ col_masks,
+                                                const float* __restrict__ alpha_p, int iters, float inf,
+                                                float* __restrict__ out, int scaling_form) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int R = M + 1, C = N + 1;
   const int ld = sinkhorn_ld(C);
@@ -106,7 +105,6 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
   float* rmax = S + (((size_t)R * ld + 2 * (size_t)R + 2 * (size_t)C + 4 + 3) & ~(size_t)3);
   float* Ep = rmax + SK_MAXD;
   float* Fv = Ep + SK_MAXD;
-  const int b = blockIdx.x;
   const float alpha = alpha_p[0];
   const uint8_t* rm = row_masks ? row_masks + (int64_t)b * M : nullptr;
   const uint8_t* cm = col_masks ? col_masks + (int64_t)b * N : nullptr;
@@ -119,10 +117,6 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
   if (nr) atomicAdd(&cnt[0], nr);
   if (nc) atomicAdd(&cnt[1], nc);
   __syncthreads();
-  // behind sinkhorn_small_kernel: a matrix that fits one wave is done, unless that kernel marked it (range guard)
-  if (after_small && cnt[0] <= SS_MAX && cnt[1] <= SS_MAX &&
-      reinterpret_cast<const unsigned*>(out)[(int64_t)b * R * C] != SS_REDO)
-    return;
   // padded scores: [scores | alpha ; alpha ... alpha], masked rows / columns -> -inf (:44-48)
   for (int e = threadIdx.x; e < R * C; e += SK_T) {
     const int i = e / C, j = e % C;
@@ -372,6 +366,24 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
   }
 }
 
+// One workgroup per matrix -- or, behind sinkhorn_small_kernel, a few hundred workgroups that walk the list of the matrices
+// that kernel left (more than 63 valid rows or columns, or rejected by its range guard): worklist[0] = their number,
+// worklist[1..] = their indices.  (A grid of one 70 KB workgroup per matrix that exits at once where nothing is to do still
+// took 0.2 ms per 4 096 matrices to dispatch.)
+__global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict__ scores, int M, int N,
+                                                        const uint8_t* __restrict__ row_masks,
+                                                        const uint8_t* __restrict__ col_masks,
+                                                        const float* __restrict__ alpha_p, int iters, float inf,
+                                                        float* __restrict__ out, int scaling_form,
+                                                        const int32_t* __restrict__ worklist, int batch) {
+  const int n_items = worklist ? worklist[0] : batch;
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    sinkhorn_matrix(worklist ? worklist[1 + item] : item, scores, M, N, row_masks, col_masks, alpha_p, iters, inf, out,
+                    scaling_form);
+    __syncthreads();  // the next matrix reuses the LDS image
+  }
+}
+
 // ---------------------------------------------------------------- the same transport for SMALL problems: one wave per matrix
 // A patch of GaussReg's fine matching has 128 slots per side, but a superpoint owns ~30 points: three quarters of the rows and
 // columns are masked, and the masked ones take no part in the iteration (K = 0, u = v = 0).  When at most 63 rows and 63
@@ -379,15 +391,15 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
 // compacted column l, keeps both (64 + 64 values of K = exp(S - rowmax)) in registers, and a half-iteration is 64 FMAs against
 // a vector read from LDS as broadcast float4 -- no workgroup barrier, no work on masked entries (the 512-thread kernel above
 // spends 129 x 129 FMAs per half-iteration whatever the masks say: 8.3 ms per 16 384 patches of the pair path).  Same
-// scaling-form arithmetic and the same range guard; a matrix the guard rejects gets a NaN mark in out[0] and is redone by the
-// kernel above, which is launched behind this one and leaves everything else alone.  Masked entries of the output are
+// scaling-form arithmetic and the same range guard; a matrix the guard rejects, like one that is too large, is appended to a work
+// list for the kernel above, which is launched behind this one with a few hundred workgroups that walk that list.  Masked entries of the output are
 // ((-inf + u_i) + v_j) - norm with u = v = 0 on masked rows / columns, as above.
 
 __global__ __launch_bounds__(WAVE) void sinkhorn_small_kernel(const float* __restrict__ scores, int M, int N,
                                                               const uint8_t* __restrict__ row_masks,
                                                               const uint8_t* __restrict__ col_masks,
                                                               const float* __restrict__ alpha_p, int iters, float inf,
-                                                              float* __restrict__ out) {
+                                                              float* __restrict__ out, int32_t* __restrict__ worklist) {
   __shared__ float S[WAVE * SS_LD];
   __shared__ __attribute__((aligned(16))) float Ev[WAVE];
   __shared__ __attribute__((aligned(16))) float Fu[WAVE];
@@ -418,7 +430,10 @@ __global__ __launch_bounds__(WAVE) void sinkhorn_small_kernel(const float* __res
     if (j < N) cinv[j] = ok && pos < WAVE ? (short)pos : (short)-1;
     nc += (int)__popcll(m);
   }
-  if (nr > SS_MAX || nc > SS_MAX) return;  // the 512-thread kernel takes this matrix
+  if (nr > SS_MAX || nc > SS_MAX) {  // the 512-thread kernel takes this matrix
+    if (lane == 0) worklist[1 + atomicAdd(&worklist[0], 1)] = b;
+    return;
+  }
   if (lane == 0) rinv[M] = (short)nr, cinv[N] = (short)nc;  // the dustbins close the compacted lists
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -513,7 +528,7 @@ __global__ __launch_bounds__(WAVE) void sinkhorn_small_kernel(const float* __res
     __builtin_amdgcn_wave_barrier();
   }
   if (__any(bad)) {  // out of the normal range: the log-domain iterations of the 512-thread kernel redo this matrix
-    if (lane == 0) reinterpret_cast<unsigned*>(out)[(int64_t)b * R * C] = SS_REDO;
+    if (lane == 0) worklist[1 + atomicAdd(&worklist[0], 1)] = b;
     return;
   }
   uu[lane] = rowl ? u : 0.f;
@@ -565,11 +580,20 @@ extern "C" int gr_sinkhorn(const float* scores, int64_t batch, int64_t m, int64_
   static const int small_on = (getenv("GR_SINKHORN_SMALL") && atoi(getenv("GR_SINKHORN_SMALL")) == 0) ? 0 : 1;
   const int small = small_on && scaling_form && num_iterations > 0 && (row_masks || col_masks || std::max(m, n) <= SS_MAX);
   KernelTimer timer("sinkhorn", stream);
-  if (small)
+  if (small) {
+    int32_t* worklist = nullptr;  // [0] = number of matrices left for the 512-thread kernel, then their indices
+    GR_HIP(hipMallocAsync(reinterpret_cast<void**>(&worklist), sizeof(int32_t) * (size_t)(batch + 1), stream));
+    GR_HIP(hipMemsetAsync(worklist, 0, sizeof(int32_t), stream));
     hipLaunchKernelGGL(sinkhorn_small_kernel, dim3((unsigned)batch), dim3(WAVE), 0, stream, scores, (int)m, (int)n, row_masks,
-                       col_masks, alpha_dev, num_iterations, inf, out);
+                       col_masks, alpha_dev, num_iterations, inf, out, worklist);
+    hipLaunchKernelGGL(sinkhorn_kernel, dim3((unsigned)std::min<int64_t>(batch, 512)), dim3(SK_T), lds, stream, scores, (int)m,
+                       (int)n, row_masks, col_masks, alpha_dev, num_iterations, inf, out, scaling_form, worklist, (int)batch);
+    GR_LAUNCH_CHECK();
+    GR_HIP(hipFreeAsync(worklist, stream));
+    return GR_OK;
+  }
   hipLaunchKernelGGL(sinkhorn_kernel, dim3((unsigned)batch), dim3(SK_T), lds, stream, scores, (int)m, (int)n, row_masks,
-                     col_masks, alpha_dev, num_iterations, inf, out, scaling_form, small);
+                     col_masks, alpha_dev, num_iterations, inf, out, scaling_form, (const int32_t*)nullptr, (int)batch);
   GR_LAUNCH_CHECK();
   return GR_OK;
 }
