@@ -105,6 +105,11 @@ def gaussian_fuse_records(rec1, rec2, estimated_transform):
     L = _lib.lib()
     r1 = torch.as_tensor(rec1, dtype=torch.float32).to(dev).contiguous()
     r2 = torch.as_tensor(rec2, dtype=torch.float32).to(dev).contiguous()
+    # gr_gs_fuse fetches records as 16-byte vectors: a view that starts at an odd row (248-byte records) is copied
+    if r1.data_ptr() % 16:
+        r1 = r1.clone()
+    if r2.data_ptr() % 16:
+        r2 = r2.clone()
     T = np.asarray(estimated_transform, np.float64)
     rotation = T[:3, :3]
     translation = np.ascontiguousarray(T[:3, 3])

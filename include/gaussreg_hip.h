@@ -271,7 +271,8 @@ int gr_group_norm_res(const float* x, int64_t n, int64_t c, int64_t groups, cons
  * rec1 / rec2: device arrays of 62-float vertex records (gs_fusion.py:172-184 property order).  The host
  * passes the similarity transform split as the reference does (:237-240): h_rotation (3x3 row-major, scale
  * divided out), h_translation (3), h_scale, and the three SH band transforms (3x3, 5x5, 7x7 row-major,
- * new = old @ T).  out_rec has room for n1 + n2 records; *h_num_out = kept vertices.  Synchronises. */
+ * new = old @ T).  out_rec has room for n1 + n2 records; *h_num_out = kept vertices.  Synchronises.
+ * rec1 / rec2 must be 16-byte aligned (records are fetched as 16-byte vectors), out_rec 8-byte aligned. */
 size_t gr_gs_fuse_workspace_bytes(int64_t n1, int64_t n2);
 int gr_gs_fuse(const float* rec1, int64_t n1, const float* rec2, int64_t n2, const double* h_rotation,
                const double* h_translation, double h_scale, const float* h_sh_t1, const float* h_sh_t2,
