@@ -135,8 +135,11 @@ RadiusWs carve(void* ws, int64_t nq, int64_t ns, int64_t batch) {
 // per 1024 points, took 32 us of the 8 x 200 k binning); grid_setup_kernel folds the partials.
 __global__ __launch_bounds__(256) void bbox_partial_kernel(const float* __restrict__ pts, const int32_t* __restrict__ off,
                                                            const int32_t* __restrict__ blk_off, int nb,
-                                                           uint32_t* __restrict__ partial) {
+                                                           uint32_t* __restrict__ partial, int32_t* __restrict__ zero,
+                                                           int nzero) {
   __shared__ uint32_t red[6][256 / WAVE];
+  // (the super-cell counters of the counting sort are cleared here, by the way: one launch less in front of every search)
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < nzero; k += gridDim.x * 256) zero[k] = 0;
   const int b0 = find_batch(blk_off, nb, (int)blockIdx.x);
   const int p_first = off[b0] + ((int)blockIdx.x - blk_off[b0]) * BBOX_PTS;
   const int p_end = min(off[b0 + 1], p_first + BBOX_PTS);
@@ -357,6 +360,10 @@ __global__ void bin_init_kernel(uint32_t* __restrict__ bbox, int nb, int32_t* __
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (bbox && i < nb * 6) bbox[i] = (i % 6) < 3 ? 0xffffffffu : 0u;
   for (int k = i; k < nzero; k += gridDim.x * blockDim.x) zero[k] = 0;
+}
+
+__global__ void bin_init2_kernel(int32_t* __restrict__ a, int32_t* __restrict__ b, int n) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) a[k] = 0, b[k] = 0;
 }
 
 // COUNT: cell of every point, LDS histogram over the block's super-cells, one global add per non-empty super-cell.
@@ -1763,10 +1770,9 @@ int radius_prepare(const float* q, const float* s, const int64_t* h_q_lengths, c
     // ---- supports (and, in the same launches, the queries): bbox, grid, two-level counting sort
     {
       const int nzero = (int)(4 * su);
-      hipLaunchKernelGGL(bin_init_kernel, dim3(std::min(256, (nzero + 255) / 256)), dim3(256), 0, stream, (uint32_t*)nullptr, 0,
-                         w.sup_zero, nzero);
       const int bbox_blocks = h_offsets[2 * (batch + 1) + batch];
-      hipLaunchKernelGGL(bbox_partial_kernel, dim3(bbox_blocks), dim3(256), 0, stream, s, w.s_off, w.blk_off, nb, w.bbox_partial);
+      hipLaunchKernelGGL(bbox_partial_kernel, dim3(bbox_blocks), dim3(256), 0, stream, s, w.s_off, w.blk_off, nb, w.bbox_partial,
+                         w.sup_zero, nzero);
     }
     // x sub-cells per cell: 2 measured best end to end (count pass 0.166 -> 0.157 ms; 8 gives 0.150 ms but the scan and the
     // scatter over an 8x larger cell table take the difference back)
@@ -1784,9 +1790,7 @@ int radius_prepare(const float* q, const float* s, const int64_t* h_q_lengths, c
   } else if (!same) {
     // ---- the support grid is in place: only the queries are binned into it
     const int nzero = (int)su;
-    hipLaunchKernelGGL(bin_init_kernel, dim3(std::min(256, (nzero + 255) / 256)), dim3(256), 0, stream, (uint32_t*)nullptr, 0,
-                       w.sup_zero + su, nzero);
-    hipLaunchKernelGGL(bin_init_kernel, dim3(std::min(256, (nzero + 255) / 256)), dim3(256), 0, stream, (uint32_t*)nullptr, 0,
+    hipLaunchKernelGGL(bin_init2_kernel, dim3(std::min(256, (nzero + 255) / 256)), dim3(256), 0, stream, w.sup_zero + su,
                        w.sup_zero + 3 * su, nzero);
     hipLaunchKernelGGL((coarse_kernel<false>), dim3(blocks_q), dim3(256), 0, stream, A, B, 0, nb, w.grids);
     hipLaunchKernelGGL(sup_scan_kernel, dim3(1), dim3(1024), 0, stream, A, B, 1, w.hdr);
