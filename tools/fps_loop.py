@@ -1,5 +1,5 @@
-"""FPS timings on the GPU box: 2 x (200 k -> 30 k) and the batched call of the configs[4] pipeline (22 clouds per call).
-    python tools/fps_loop.py [--clouds 22]"""
+"""FPS timings on the GPU box: 2 x (200 k -> 30 k) and the batched call of the configs[4] pipeline (25 clouds per call: ten workgroups per cloud on 256 CUs).
+    python tools/fps_loop.py [--clouds 25]"""
 import argparse
 import json
 import os
@@ -26,7 +26,7 @@ def ms_of(fn, iters, warm):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--clouds", type=int, default=22)
+    ap.add_argument("--clouds", type=int, default=25)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     out = {}
