@@ -65,7 +65,9 @@ SIGNATURES.update({
 
 
 SIGNATURES.update({
-    "gr_sinkhorn": (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_void, c_void, c_int, c_f32, c_void, c_void]),
+    "gr_sinkhorn_workspace_bytes": (c_size, [c_i64]),
+    "gr_sinkhorn": (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_void, c_void, c_int, c_f32, c_void, c_void, c_size,
+                            c_void]),
     "gr_kpconv_workspace_bytes": (c_size, [c_i64, c_i64, c_i64, c_i64]),
     "gr_kpconv_forward": (c_int, [c_void] * 4 + [c_i64] * 5 + [c_void, c_i64, c_void, c_void, c_f32, c_f32, c_void,
                                                             c_void, c_size, c_void]),
@@ -154,10 +156,27 @@ def lib():
     return _lib
 
 
-def check(rc):
-    if rc < 0 or rc > 1:
+GR_RETRY_BIN = 1   # include/gaussreg_hip.h: gr_raster_forward's "bin buffer too small, call gr_raster_render_ex" status
+
+
+def check(rc, allow=()):
+    """Strict: every status but 0 raises, except the positive codes the call site names in `allow`."""
+    if rc != 0 and rc not in allow:
         msg = lib().gr_last_error()
         raise RuntimeError("gaussreg_hip: " + (msg.decode() if msg else f"error {rc}"))
+    return rc
+
+
+def tensor_stamp(tensors):
+    """Cache key for objects derived from tensors that may be updated in place: (storage address, version counter) per
+    tensor, or None when any of them is an inference tensor (torch.inference_mode(): no version counter exists, reading
+    `_version` raises) -- the caller then rebuilds instead of caching."""
+    out = []
+    for t in tensors:
+        if t.is_inference():
+            return None
+        out.append((t.data_ptr(), t._version))
+    return tuple(out)
 
 
 def require_gpu():

@@ -558,9 +558,13 @@ size_t sinkhorn_lds(int M, int N) {
 
 using namespace gr;
 
+extern "C" size_t gr_sinkhorn_workspace_bytes(int64_t batch) {
+  return sizeof(int32_t) * (size_t)(std::max<int64_t>(batch, 0) + 1) + 256;
+}
+
 extern "C" int gr_sinkhorn(const float* scores, int64_t batch, int64_t m, int64_t n, const uint8_t* row_masks,
                            const uint8_t* col_masks, const float* alpha_dev, int num_iterations, float inf,
-                           float* out, void* stream_) {
+                           float* out, void* workspace, size_t workspace_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   GR_REQUIRE(batch >= 0 && m >= 1 && n >= 1 && num_iterations >= 0, "bad sizes");
   if (batch == 0) return GR_OK;
@@ -581,15 +585,19 @@ extern "C" int gr_sinkhorn(const float* scores, int64_t batch, int64_t m, int64_
   const int small = small_on && scaling_form && num_iterations > 0 && (row_masks || col_masks || std::max(m, n) <= SS_MAX);
   KernelTimer timer("sinkhorn", stream);
   if (small) {
-    int32_t* worklist = nullptr;  // [0] = number of matrices left for the 512-thread kernel, then their indices
-    GR_HIP(hipMallocAsync(reinterpret_cast<void**>(&worklist), sizeof(int32_t) * (size_t)(batch + 1), stream));
+    // [0] = number of matrices left for the 512-thread kernel, then their indices (caller's workspace: no allocation
+    // inside the call, so it can be captured into a graph and nothing can leak on an error path)
+    if (!workspace || workspace_bytes < gr_sinkhorn_workspace_bytes(batch)) {
+      set_error("sinkhorn: workspace too small (%zu < %zu bytes)", workspace_bytes, gr_sinkhorn_workspace_bytes(batch));
+      return GR_ERR_WORKSPACE;
+    }
+    int32_t* worklist = reinterpret_cast<int32_t*>(workspace);
     GR_HIP(hipMemsetAsync(worklist, 0, sizeof(int32_t), stream));
     hipLaunchKernelGGL(sinkhorn_small_kernel, dim3((unsigned)batch), dim3(WAVE), 0, stream, scores, (int)m, (int)n, row_masks,
                        col_masks, alpha_dev, num_iterations, inf, out, worklist);
     hipLaunchKernelGGL(sinkhorn_kernel, dim3((unsigned)std::min<int64_t>(batch, 512)), dim3(SK_T), lds, stream, scores, (int)m,
                        (int)n, row_masks, col_masks, alpha_dev, num_iterations, inf, out, scaling_form, worklist, (int)batch);
     GR_LAUNCH_CHECK();
-    GR_HIP(hipFreeAsync(worklist, stream));
     return GR_OK;
   }
   hipLaunchKernelGGL(sinkhorn_kernel, dim3((unsigned)batch), dim3(SK_T), lds, stream, scores, (int)m, (int)n, row_masks,

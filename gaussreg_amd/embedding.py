@@ -57,8 +57,9 @@ class GeometricStructureEmbedding(nn.Module):
         """F_d(x) = proj_d(embedding(x)) and F_a(x) = proj_a(embedding(x)) on the grid x = (j - 1) / TABLE_INV_H, evaluated
         in fp64 and stored as fp32 (rows x hidden_dim); rebuilt when a weight changes (version counters) or moves."""
         ps = (self.proj_d.weight, self.proj_d.bias, self.proj_a.weight, self.proj_a.bias, self.embedding.div_term)
-        stamp = tuple((t.data_ptr(), t._version) for t in ps) + (str(dev),)
-        if self._tables is None or self._tables[0] != stamp:
+        stamp = _lib.tensor_stamp(ps)          # None: inference tensors, no version counters -> rebuild every call
+        stamp = None if stamp is None else stamp + (str(dev),)
+        if stamp is None or self._tables is None or self._tables[0] != stamp:
             div = self.embedding.div_term.detach().to(dev, torch.float64)
 
             def table(lin, x_max):

@@ -23,6 +23,9 @@ def norm_segments(table):
     computes when every pair goes through the network alone (modules.py:32-50: the statistics run over ALL points of the
     collated batch, i.e. of one pair)."""
     old = getattr(_segments, "table", None)
+    for n, (seg_off, _) in table.items():
+        if seg_off.dim() != 1 or seg_off.numel() < 2:
+            raise ValueError("norm_segments: offsets must be a 1-D tensor of B + 1 entries")
     _segments.table = table
     try:
         yield
@@ -69,7 +72,9 @@ class GroupNorm(nn.Module):
                                                1.0 if negative_slope is None else float(negative_slope), _lib.ptr(res),
                                                _lib.ptr(out), _lib.ptr(seg_off), nseg, int(max_rows), _lib.ptr(ws), ws.numel(),
                                                _lib.stream_ptr(dev)))
-                return out.squeeze()
+                # the reference squeezes the norm's output BEFORE the shortcut is added (modules.py:50, :217-222): for a
+                # single row the sum broadcasts back to the shortcut's (1, C)
+                return out.reshape(torch.broadcast_shapes(out.squeeze().shape, residual.shape))
             if seg is not None:
                 seg_off, max_rows = seg
                 nseg = seg_off.numel() - 1
@@ -88,6 +93,23 @@ class GroupNorm(nn.Module):
                                        1.0 if negative_slope is None else float(negative_slope), _lib.ptr(out), _lib.ptr(ws),
                                        ws.numel(), _lib.stream_ptr(dev)))
         return out.squeeze()
+
+
+def segment_table(level_lengths, device):
+    """The table norm_segments takes, from the pyramid's per-level `lengths` (clouds stacked pair by pair: cloud 2 b = ref,
+    2 b + 1 = src of pair b).  Two levels with the same total row count would be indistinguishable by row count (the key the
+    GroupNorm layers look their segments up by) -- that raises here instead of normalising with the wrong offsets."""
+    table = {}
+    for lengths in level_lengths:
+        ll = [int(v) for v in (lengths.tolist() if hasattr(lengths, "tolist") else lengths)]
+        offs = [0]
+        for b in range(len(ll) // 2):
+            offs.append(offs[-1] + ll[2 * b] + ll[2 * b + 1])
+        entry = (torch.tensor(offs, dtype=torch.int64, device=device), max(offs[i + 1] - offs[i] for i in range(len(offs) - 1)))
+        if offs[-1] in table and table[offs[-1]][0].tolist() != offs:
+            raise ValueError(f"norm_segments: two pyramid levels have {offs[-1]} rows in total but different pair boundaries")
+        table[offs[-1]] = entry
+    return table
 
 
 def _norm(out_channels, group_norm, layer_norm):

@@ -247,15 +247,8 @@ class PairRegistrar:
         if self.features == "model":
             with self._sec("backbone"):
                 # KPConvFPN over all 2 B clouds at once; every GroupNorm normalises pair by pair
-                from .kpconv_blocks import norm_segments
-                table = {}
-                for lv in range(NUM_STAGES):
-                    ll = pyr["lengths"][lv].tolist()
-                    offs = [0]
-                    for b in range(B):
-                        offs.append(offs[-1] + ll[2 * b] + ll[2 * b + 1])
-                    table[offs[-1]] = (torch.tensor(offs, dtype=torch.int64, device=dev),
-                                       max(offs[i + 1] - offs[i] for i in range(B)))
+                from .kpconv_blocks import norm_segments, segment_table
+                table = segment_table([pyr["lengths"][lv] for lv in range(NUM_STAGES)], dev)
                 feats_in = torch.ones((points.shape[0], 4), device=dev)   # demo.py:109-118: [1, r, g, b]-style 4-d input
                 dd = dict(pyr)
                 with norm_segments(table):

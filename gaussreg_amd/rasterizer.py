@@ -149,10 +149,10 @@ def rasterize_views(settings, means3D, opacities, shs=None,
         rc = L.gr_raster_forward(P, M, _lib.ptr(m), _lib.ptr(sh), _lib.ptr(cp), _lib.ptr(op), _lib.ptr(sc), _lib.ptr(rot),
                                  _lib.ptr(cov), views, V, _lib.ptr(radii), _lib.ptr(geom), geom.numel(), _lib.ptr(binb),
                                  binb.numel() if binb is not None else 0, _lib.ptr(color), flags, nr, st)
-        _lib.check(rc)
+        _lib.check(rc, allow=(_lib.GR_RETRY_BIN,))
         total = sum(int(nr[v]) for v in range(V))
         need = L.gr_raster_bin_bytes(total, W, H, V)
-        if rc == 1:  # GR_RETRY_BIN
+        if rc == _lib.GR_RETRY_BIN:
             binb = torch.empty(need + 256, dtype=torch.uint8, device=dev)
             _lib.check(L.gr_raster_render_ex(P, views, V, nr, _lib.ptr(geom), geom.numel(), _lib.ptr(binb), binb.numel(),
                                              _lib.ptr(color), flags, st))
@@ -183,11 +183,15 @@ class GaussianRasterizer(torch.nn.Module):
     def _stamp(rs):
         # the camera tensors may be updated in place between frames (pose optimisation): their storage and version
         # counters are part of the cache key, so a stale marshalled copy is never rendered
-        return tuple((t.data_ptr(), t._version) for t in (rs.viewmatrix, rs.projmatrix, rs.campos, rs.bg))
+        # (None for inference tensors, which carry no version counter: nothing is cached for them)
+        return _lib.tensor_stamp((rs.viewmatrix, rs.projmatrix, rs.campos, rs.bg))
 
     def _views(self):
         rs = self.raster_settings
         stamp = self._stamp(rs)
+        if stamp is None:
+            self._view_batch = None
+            return ViewBatch([rs])
         if self._view_batch is None or self._view_batch[0] is not rs or self._view_batch[1] != stamp:
             self._view_batch = (rs, stamp, ViewBatch([rs]))
         return self._view_batch[2]

@@ -27,8 +27,10 @@ class LearnableLogOptimalTransport(nn.Module):
         alpha = self.alpha.detach().to(device=dev, dtype=torch.float32).reshape(1).contiguous()
         out = torch.empty((B, M + 1, N + 1), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
+            ws = _lib.workspace(dev, L.gr_sinkhorn_workspace_bytes(B))
             _lib.check(L.gr_sinkhorn(_lib.ptr(s), B, M, N, _lib.ptr(rm), _lib.ptr(cm), _lib.ptr(alpha),
-                                     int(self.num_iterations), float(self.inf), _lib.ptr(out), _lib.stream_ptr(dev)))
+                                     int(self.num_iterations), float(self.inf), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                     _lib.stream_ptr(dev)))
         return out if out_device.type == "cuda" else out.to(out_device)
 
     def __repr__(self):

@@ -1,1 +1,4 @@
-from gaussreg_amd.sinkhorn import LearnableLogOptimalTransport  # noqa: F401
+from gaussreg_amd._alias import chain as _chain
+
+_chain(globals())   # sub-modules this repo does not override resolve to GaussReg's own package, if on sys.path
+from gaussreg_amd.sinkhorn import LearnableLogOptimalTransport  # noqa: E402,F401

@@ -227,10 +227,12 @@ int gr_raster_mark_visible(int64_t P, const float* means3D, const float* h_viewm
  */
 /* gr_sinkhorn ("next" row): geotransformer/modules/sinkhorn/learnable_sinkhorn.py:20-66
  * LearnableLogOptimalTransport.forward: scores (batch,m,n), masks uint8 (null = all valid), alpha read
- * from DEVICE memory (the module's learnable parameter), out (batch, m+1, n+1). */
+ * from DEVICE memory (the module's learnable parameter), out (batch, m+1, n+1).  `workspace`: device
+ * scratch of gr_sinkhorn_workspace_bytes(batch) (the work list of matrices too large for the one-wave kernel). */
+size_t gr_sinkhorn_workspace_bytes(int64_t batch);
 int gr_sinkhorn(const float* scores, int64_t batch, int64_t m, int64_t n, const uint8_t* row_masks,
                 const uint8_t* col_masks, const float* alpha_dev, int num_iterations, float inf, float* out,
-                void* stream);
+                void* workspace, size_t workspace_bytes, void* stream);
 /* gr_kpconv_forward ("next" row): geotransformer/modules/kpconv/kpconv.py:79-122 KPConv.forward
  * (rigid kernel points): s_feats (n,cin), q_points (m,3), s_points (n,3), neighbor_indices (m,h) int64 padded
  * with n, kernel_points (k,3), weights (k,cin,cout), bias (cout) or null -> out (m,cout).

@@ -21,7 +21,7 @@ def build(force=False):
     """Compile liboracle.so (and _ref when /root/reference is mounted)."""
     so = os.path.join(_HERE, "liboracle.so")
     srcs = [os.path.join(_HERE, f) for f in
-            ("radius_neighbors_oracle.c", "grid_subsample_oracle.cpp", "rasterizer_oracle.c", "Makefile")]
+            ("radius_neighbors_oracle.c", "grid_subsample_oracle.cpp", "rasterizer_oracle.c", "fps_oracle.c", "Makefile")]
     stale = force or not os.path.exists(so) or any(
         os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     need_ref = os.path.isdir("/root/reference/geotransformer/extensions") and (
@@ -70,6 +70,8 @@ def lib():
             [c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p])
         L.oracle_mark_visible.restype = None
         L.oracle_mark_visible.argtypes = [ctypes.c_int, c_f32p, c_f32p, ctypes.POINTER(ctypes.c_uint8)]
+        L.oracle_fps.restype = ctypes.c_int64
+        L.oracle_fps.argtypes = [c_f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_i64p]
         _LIB = L
     return _LIB
 
@@ -197,3 +199,12 @@ def mark_visible(means3D, viewmatrix):
     lib().oracle_mark_visible(m.shape[0], _p(m, c_f32p), _p(_f32(viewmatrix).reshape(-1), c_f32p),
                               out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)))
     return out.astype(bool)
+
+
+def farthest_point_sampling(points, k, start=0):
+    """Sequential exact FPS (oracle/fps_oracle.c); == matching_np.farthest_point_sampling, in C."""
+    p = _f32(points)
+    out = np.empty(int(k), np.int64)
+    got = lib().oracle_fps(_p(p, c_f32p), p.shape[0], int(k), int(start), _p(out, c_i64p))
+    assert got == k
+    return out

@@ -95,3 +95,56 @@ def test_one_rendered_view_through_diff_gaussian_rasterization():
                                         scales=t["scales"], rotations=t["rotations"])
     assert img.shape == (3, 64, 96) and radii.shape == (3000,) and img.is_cuda and torch.isfinite(img).all()
     assert int((radii > 0).sum()) > 100 and float(img.std()) > 0
+
+
+def test_forward_under_inference_mode_and_in_place_camera_updates():
+    """Tensors created under torch.inference_mode() have no version counter (reading `_version` raises): the marshalled-camera
+    cache of GaussianRasterizer and the function-table cache of GeometricStructureEmbedding must not depend on it.  The
+    images must equal the ones rendered from ordinary tensors, also after the camera is changed IN PLACE."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from geotransformer.modules.geotransformer import GeometricStructureEmbedding
+    from helpers import raster_scene
+    g, cams = raster_scene(2500, 96, 64, seed=9, V=2)
+    t = {k: torch.from_numpy(v).cuda() for k, v in g.items()}
+
+    def settings(c, make):
+        return GaussianRasterizationSettings(image_height=64, image_width=96, tanfovx=c["tanfovx"], tanfovy=c["tanfovy"],
+                                             bg=make(np.float32([0.1, 0.2, 0.3])), scale_modifier=1.0,
+                                             viewmatrix=make(c["viewmatrix"]), projmatrix=make(c["projmatrix"]), sh_degree=3,
+                                             campos=make(c["campos"]), prefiltered=False, debug=False)
+
+    def render(r):
+        return r(means3D=t["means3D"], means2D=None, opacities=t["opacities"], shs=t["shs"], scales=t["scales"],
+                 rotations=t["rotations"])[0].clone()
+    plain = [render(GaussianRasterizer(settings(c, lambda a: torch.from_numpy(np.array(a)).cuda()))) for c in cams]
+    assert not torch.equal(plain[0], plain[1])
+    with torch.inference_mode():
+        st = settings(cams[0], lambda a: torch.from_numpy(np.array(a)).cuda().clone())
+        assert st.viewmatrix.is_inference()
+        r = GaussianRasterizer(st)
+        a = render(r)
+        a2 = render(r)
+        for name in ("viewmatrix", "projmatrix", "campos"):          # the second camera, written into the same tensors
+            getattr(st, name).copy_(torch.from_numpy(cams[1][name]))
+        b = render(r)
+    assert torch.equal(a, plain[0]) and torch.equal(a2, plain[0]) and torch.equal(b, plain[1])
+    # ordinary tensors: the cache must notice the in-place update through the version counter
+    st = settings(cams[0], lambda a: torch.from_numpy(np.array(a)).cuda())
+    r = GaussianRasterizer(st)
+    assert torch.equal(render(r), plain[0])
+    for name in ("viewmatrix", "projmatrix", "campos"):
+        getattr(st, name).copy_(torch.from_numpy(cams[1][name]))
+    assert torch.equal(render(r), plain[1])
+    # the embedding's function tables with inference-tensor weights
+    pts = torch.rand(1, 200, 3, device="cuda")
+    torch.manual_seed(3)
+    m = GeometricStructureEmbedding(64, 0.2, 15, 3).cuda()
+    want = m(pts)
+    with torch.inference_mode():
+        torch.manual_seed(3)
+        mi = GeometricStructureEmbedding(64, 0.2, 15, 3).cuda()
+        assert mi.proj_d.weight.is_inference()
+        got = mi(pts)
+        mi.proj_d.bias.add_(1.0)
+        moved = mi(pts)
+    assert torch.equal(got, want) and not torch.equal(moved, want)

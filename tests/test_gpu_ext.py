@@ -179,6 +179,25 @@ def test_200k_properties():
     # grid subsample: count as on the reference, rows of every voxel average back into the voxel
     sp, sl = _ext().grid_subsampling(d, lens, 0.05)
     assert sl.tolist() == [74011]
+    # the whole (200 000, 45) tensor and the 74 011 subsampled rows against the CPU oracle, bit for bit
+    # (radius_neighbors_cpu.cpp:3-91, grid_subsampling_cpu.cpp:3-48); the tie-free input makes the order unique
+    from oracle import capi
+    lens_np = np.array([200000], np.int64)
+    want = capi.radius_neighbors(pts.numpy(), pts.numpy(), lens_np, lens_np, r)
+    assert want.shape == (200000, 45)
+    assert np.array_equal(nb.cpu().numpy(), want)
+    wp, wl = capi.grid_subsampling(pts.numpy(), lens_np, 0.05)
+    assert wl.tolist() == [74011]
+    assert np.array_equal(sp.cpu().numpy().view(np.uint32), wp.view(np.uint32))
+    # the radius_search(limit=40) wrapper, both search modes, against the truncated oracle rows
+    from gaussreg_amd import _lib, ext as gext
+    for mode in (0, 1):
+        old = _lib.lib().gr_radius_search_mode(mode)
+        try:
+            lim = gext.radius_neighbors_limited(d, d, lens, lens, r, 40)
+        finally:
+            _lib.lib().gr_radius_search_mode(old)
+        assert lim.is_contiguous() and np.array_equal(lim.cpu().numpy(), want[:, :40]), mode
 
 
 def test_support_grid_reuse_gives_identical_results():

@@ -187,6 +187,44 @@ def test_gs_fusion_chunk_edges_vs_oracle(n1, n2, layout):
         assert np.array_equal(got_v, gaussian_fuse_records(rec1[1:], rec2[3:], T).cpu().numpy())
 
 
+def test_gs_fusion_full_size_vs_oracle():
+    """BASELINE configs[3] size: 2 x 2.55 M records through gr_gs_fuse against oracle/fusion_np.gaussian_fuse
+    (gs_fusion.py:231-262).  The keep rule compares two fp32 distances to two cloud centres; the centres are means
+    over millions of rows, whose last bits depend on the summation order, so records within 1e-3 of the bisecting plane
+    are taken out of the INPUT (then every keep decision has a margin ~1000x the centre's rounding noise and the row
+    sets must agree exactly)."""
+    from gaussreg_amd.gs_io import gaussian_fuse_records
+    from oracle import fusion_np
+    n = 2_550_000
+    rng = np.random.default_rng(77)
+    c, s_ = np.cos(0.3), np.sin(0.3)
+    T = np.eye(4)
+    T[:3, :3] = 0.93 * np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]])
+    T[:3, 3] = [0.2, -0.1, 0.05]
+
+    def records(shift):
+        rec = rng.standard_normal((n, 62), dtype=np.float32)
+        rec[:, 0:3] = rng.random((n, 3), dtype=np.float32) * np.float32([4, 3, 2.5]) + np.float32(shift)
+        rec[:, 58:62] += np.sign(rec[:, 58:62]) * np.float32(0.2)
+        return rec
+    rec1, rec2 = records([0, 0, 0]), records([1.5, 0.2, 0])
+    for _ in range(2):   # drop near-plane records, twice (the centres move a little after the first cut)
+        x1 = rec1[:, 0:3].astype(np.float64)
+        x2 = rec2[:, 0:3].astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+        c1, c2 = x1.mean(0), x2.mean(0)
+        m1 = np.abs(np.linalg.norm(x1 - c1, axis=1) - np.linalg.norm(x1 - c2, axis=1)) > 1e-3
+        m2 = np.abs(np.linalg.norm(x2 - c1, axis=1) - np.linalg.norm(x2 - c2, axis=1)) > 1e-3
+        rec1, rec2 = rec1[m1], rec2[m2]
+    assert rec1.shape[0] > 2_500_000 and rec2.shape[0] > 2_500_000
+    want = fusion_np.gaussian_fuse(rec1, rec2, T)
+    got = gaussian_fuse_records(rec1, rec2, T).cpu().numpy()
+    assert got.shape == want.shape and 2_000_000 < got.shape[0] < rec1.shape[0] + rec2.shape[0]
+    assert np.array_equal(got[:, 0:3].view(np.uint32), want[:, 0:3].view(np.uint32))
+    assert not got[:, 3:6].any()
+    for lo in range(0, got.shape[0], 500_000):
+        np.testing.assert_allclose(got[lo:lo + 500_000], want[lo:lo + 500_000], rtol=2e-5, atol=2e-6)
+
+
 def _planted_similarity(n, outlier_frac, seed):
     rng = np.random.default_rng(seed)
     ax = rng.normal(size=3); ax /= np.linalg.norm(ax); ang = 1.1
@@ -381,6 +419,32 @@ def test_fps_long_runs_with_large_candidate_sets(n, batch, k):
     got = farthest_point_sampling(torch.cat(clouds).contiguous(), [n] * batch, [k] * batch, start_indices=[5 * b for b in range(batch)])
     for b in sorted({0, batch - 1}):
         assert np.array_equal(got[b].cpu().numpy(), M.farthest_point_sampling(clouds[b].cpu().numpy(), k, 5 * b)), f"cloud {b}"
+
+
+def test_fps_production_shape_to_the_end():
+    """demo.py:46 at its real size: 200 000 -> 30 000 samples (338 rounds; in the late rounds every candidate lies within
+    another's reach), for clouds of a 25-cloud call -- the shape tools/fps_loop.py and the pair path use -- compared over
+    ALL 30 000 indices with the sequential restatement (oracle/fps_oracle.c == matching_np.farthest_point_sampling)."""
+    from gaussreg_amd.registration import farthest_point_sampling
+    from gaussreg_amd import pair_pipeline
+    from oracle import capi
+    n, k, batch = 200000, 30000, 25
+    clouds = []
+    for i in range((batch + 1) // 2):
+        r_, s_, _ = pair_pipeline.synthetic_room_pair(300 + i, n, torch.device("cuda:0"))
+        clouds += [r_, s_]
+    clouds = clouds[:batch]
+    starts = [(7 * b) % n for b in range(batch)]
+    got = farthest_point_sampling(torch.cat(clouds).contiguous(), [n] * batch, [k] * batch, start_indices=starts)
+    for b in (0, 13, 24):
+        g = got[b].cpu().numpy()
+        assert len(set(g.tolist())) == k
+        want = capi.farthest_point_sampling(clouds[b].cpu().numpy(), k, starts[b])
+        bad = np.nonzero(g != want)[0]
+        assert bad.size == 0, f"cloud {b}: first difference at sample {bad[0]}"
+    # and a single-cloud call (64 workgroups on one cloud)
+    one = farthest_point_sampling(clouds[1], [n], [k], start_indices=[11])[0].cpu().numpy()
+    assert np.array_equal(one, capi.farthest_point_sampling(clouds[1].cpu().numpy(), k, 11))
 
 
 @pytest.mark.parametrize("env", [{"GR_FPS_ORDER": "morton"}, {"GR_FPS_WIDE": "1"}, {"GR_FPS_WIDE": "1", "GR_FPS_ORDER": "morton"},

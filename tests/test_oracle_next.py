@@ -22,3 +22,13 @@ def test_kpconv_and_pools():
     np.testing.assert_allclose(y, g["kp_out"], rtol=1e-4, atol=1e-5)
     assert np.array_equal(M.maxpool(g["kp_s_feats"], g["kp_neighbors"]), g["kp_maxpool"])
     assert np.array_equal(M.nearest_upsample(g["kp_s_feats"], g["kp_neighbors"]), g["kp_upsample"])
+
+
+def test_fps_c_restatement_equals_the_numpy_one():
+    """oracle/fps_oracle.c (used for the 200 000 -> 30 000 GPU test) against the NumPy definition it restates."""
+    from oracle import capi
+    rng = np.random.default_rng(4)
+    p = (rng.random((7000, 3)) * [6, 5, 3]).astype(np.float32)
+    p[100] = p[7]; p[2000] = p[7]                       # identical points: equal distances, first maximum wins
+    for k, start in ((1, 0), (2, 5), (900, 0), (7000, 6999)):
+        assert np.array_equal(capi.farthest_point_sampling(p, k, start), M.farthest_point_sampling(p, k, start))
