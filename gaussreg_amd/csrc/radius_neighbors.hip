@@ -124,7 +124,7 @@ RadiusWs carve(void* ws, int64_t nq, int64_t ns, int64_t batch) {
   w.q_count = c.take<int32_t>(3 * nq);
   w.q_rng = c.take<int2>(9 * nq);
   w.q_mask = c.take<unsigned long long>(3 * nq);
-  w.blk_stats = c.take<int32_t>(2 * ((nq + RT - 1) / RT + 1));
+  w.blk_stats = c.take<int32_t>(2 * ((nq + 63) / 64 + 8));  // the single-pass kernels run 64 queries per workgroup
   w.bytes = c.used();
   return w;
 }
@@ -1524,6 +1524,438 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
 #undef GR_FUSED_STOP
 }
 
+// ---------------------------------------------------------------- round 4: tests by three threads per query, everything
+// after the tests by HALF A WAVE per query
+// The kernels above spend most of their time after the tests: the hit masks of the (query, slab) threads are decoded by the
+// threads that own them (trip counts diverge: a wave waits for its longest list), keys are re-derived in a third mapping,
+// hits are ranked one thread per hit with three dependent LDS round trips in front of every segment scan, and rows leave
+// through a row buffer -- five phases, each behind a workgroup barrier, at 15 waves per CU.  Here every query is finished
+// by ONE half-wave with no barrier in between:
+//   lane l of the half-wave = hit ordinal l of the query (32 per round; a second round only for queries with more than 32
+//   hits).  The lane finds "its" hit as the k-th set bit of the three slab masks (branch-free binary search on popcounts:
+//   no loop whose trip count depends on the data), reads the candidate from the staged planes, recomputes the distance
+//   (same arithmetic, same bits), drops the distance word into the half-wave's 512-byte key scratch and counts the smaller
+//   words of the segment -- every lane of the half-wave reads the SAME addresses (LDS broadcast, no bank conflicts, no
+//   dependent address chain) -- and stores its index straight at out[row][rank]; lanes past the hit count write the
+//   padding of their column, so one store instruction per half-wave covers 32 columns of one 360-byte row.  Equal
+//   distance words are detected by the sum of the ranks (sum != n (n - 1) / 2) and only such rows are ranked again on
+//   (distance, index).
+// Modes: COUNT (tests -> masks to global memory, per-block maximum), FILL (masks from global memory -> rows), FUSED (both
+// in one launch, for a width known before the launch).  A workgroup that cannot use the masks (more than 64 enumeration
+// slots in a thread, candidates that do not fit the staging planes, a query with more than Q2_KCAP hits) raises a flag and
+// the caller repeats the call on the kernels above.
+constexpr int Q2_KCAP = 128;  // hits of one query the key scratch of a half-wave holds
+constexpr int Q2_KR = Q2_KCAP / 32;
+constexpr int Q2_COUNT = 0, Q2_FILL = 1, Q2_FUSED = 2;
+
+template <int RQ>
+struct Q2Lds {
+  static constexpr int THREADS = NSUB * RQ;
+  static constexpr int STAGE_CAP = 12 * RQ;
+  static constexpr int NH = THREADS / 32;  // half-waves
+  static constexpr int TABLE_MAX = 256;
+  static constexpr size_t QBUF_OFF = 160;  // ints: band_lo[9] band_hi[9] band_base[10] misc[4]
+  static constexpr size_t RECA_OFF = QBUF_OFF + (size_t)RQ * 16;
+  static constexpr size_t RECB_OFF = RECA_OFF + (size_t)THREADS * 16;
+  static constexpr size_t KEYS_OFF = RECB_OFF + (size_t)THREADS * 8;
+  static constexpr size_t IDXS_OFF = KEYS_OFF + (size_t)NH * Q2_KCAP * 4;
+  static constexpr size_t STAGE_OFF = IDXS_OFF + (size_t)NH * Q2_KCAP * 4;
+  static size_t tables_bytes(int tcap) { return tcap > 0 ? ((size_t)(tcap + 1) * 4 + 15) / 16 * 16 + (size_t)tcap * sizeof(BatchGrid) : 0; }
+  static size_t total(int tcap) {  // the per-cloud tables of the set-up lie where the candidate planes go afterwards
+    const size_t st = (size_t)STAGE_CAP * 16 + 16, tb = tables_bytes(tcap);
+    return STAGE_OFF + (st > tb ? st : tb);
+  }
+};
+
+// position (from the least significant end) of the k-th set bit of x, k < popcount(x): five compare / select levels
+__device__ __forceinline__ int kth_set_bit32(unsigned x, int k) {
+  int b = 0;
+#pragma unroll
+  for (int w = 16; w >= 1; w >>= 1) {
+    const int t = __popc((x >> b) & ((1u << w) - 1u));
+    const bool up = k >= t;
+    k -= up ? t : 0;
+    b += up ? w : 0;
+  }
+  return b;
+}
+
+// sum over the 32 lanes of each half of the wave, valid in every lane of the half
+__device__ __forceinline__ int half_wave_sum(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3: lanes 31 / 63 hold the sums
+  const int a = __builtin_amdgcn_readlane(v, 31), b = __builtin_amdgcn_readlane(v, 63);
+  return (threadIdx.x & 32) ? b : a;
+}
+
+template <int RQ, int MODE>
+__global__ __launch_bounds__(NSUB* RQ) void q2_kernel(
+    const float4* __restrict__ sorted_q, int nq, const int32_t* __restrict__ q_off, int nb,
+    const BatchGrid* __restrict__ grids, const int32_t* __restrict__ start_s, const float4* __restrict__ sorted_s, int ns_total,
+    float r2, uint2* __restrict__ g_mask, int32_t* __restrict__ blk_stats, int width, int row_stride, int64_t pad_value,
+    int64_t* __restrict__ out, int mono, int dbg_stop) {
+  // dbg_stop (GR_RADIUS_Q2_STOP, measurement only): leave after 1 set-up, 2 staging, 3 tests, 4 keys, 5 ranking
+#define GR_Q2_STOP(K, VALUE)                                       \
+  if (dbg_stop == (K)) {                                           \
+    if ((VALUE) == 0x7fffffff) blk_stats[2 * blk] = tid;           \
+    return;                                                        \
+  }
+  using L = Q2Lds<RQ>;
+  static_assert(RQ % WAVE == 0, "waves must not straddle slabs");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* band_lo = reinterpret_cast<int*>(smem);
+  int* band_hi = band_lo + NBAND;
+  int* band_base = band_hi + NBAND;
+  int* misc = band_base + NBAND + 1;  // [0] largest hit count of a query, [1] "repeat the call on the old kernels"
+  float4* qbuf = reinterpret_cast<float4*>(smem + L::QBUF_OFF);
+  uint4* recA = reinterpret_cast<uint4*>(smem + L::RECA_OFF);  // per thread: mask lo, mask hi, plane base of band 0, of band 1
+  uint2* recB = reinterpret_cast<uint2*>(smem + L::RECB_OFF);  // plane base of band 2, (4 nit0) | (4 (nit0 + nit1)) << 8 | top << 16
+  unsigned* keys = reinterpret_cast<unsigned*>(smem + L::KEYS_OFF);
+  unsigned* idxs = reinterpret_cast<unsigned*>(smem + L::IDXS_OFF);
+  float* sx = reinterpret_cast<float*>(smem + L::STAGE_OFF);
+  float* sy = sx + L::STAGE_CAP;
+  float* sz = sy + L::STAGE_CAP;
+  int* si = reinterpret_cast<int*>(sz + L::STAGE_CAP);
+  const int tcap = nb <= L::TABLE_MAX ? nb : 0;
+  int* s_qoff = reinterpret_cast<int*>(smem + L::STAGE_OFF);
+  BatchGrid* s_grids = reinterpret_cast<BatchGrid*>(smem + L::STAGE_OFF + ((size_t)(tcap + 1) * 4 + 15) / 16 * 16);
+
+  const int tid = threadIdx.x;
+  const int slot = tid % RQ, j = tid / RQ;
+  const int nblk = (nq + RQ - 1) / RQ;
+  const int per_xcd = gridDim.x / 8;
+  const int blk = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;  // one contiguous eighth of the cell-ordered queries per XCD
+  if (blk >= nblk) return;
+  const int t = blk * RQ + slot;
+  const int lane = tid & (WAVE - 1);
+  const bool valid = t < nq;
+
+  if (tid < NBAND) {
+    band_lo[tid] = 0x7fffffff;
+    band_hi[tid] = 0;
+  }
+  if (tid == 0) misc[0] = misc[1] = 0;
+  const bool tables_in_lds = tcap > 0;
+  if (tables_in_lds) {
+    for (int i = tid; i <= nb; i += L::THREADS) s_qoff[i] = q_off[i];
+    const int4* gsrc = reinterpret_cast<const int4*>(grids);
+    int4* gdst = reinterpret_cast<int4*>(s_grids);
+    for (int i = tid; i < nb * 4; i += L::THREADS) gdst[i] = gsrc[i];
+  }
+  float4 qp = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+  if (valid) qp = sorted_q[t];
+  uint2 gm = make_uint2(0u, 0u);
+  if (MODE == Q2_FILL && valid) gm = g_mask[(int64_t)j * nq + t];  // requested now, used after the staging
+  __syncthreads();
+  int p0[3] = {0, 0, 0}, p1[3] = {0, 0, 0};
+  if (valid) {
+    int b;
+    BatchGrid g;
+    if (tables_in_lds) {
+      b = find_batch(s_qoff, nb, __float_as_int(qp.w));
+      g = s_grids[b];
+    } else {
+      b = find_batch(q_off, nb, __float_as_int(qp.w));
+      g = grids[b];
+    }
+    const double ux = cell_coord(qp.x, g.org[0], g.inv_cell_x), kx = (double)g.xk;
+    const double uy = cell_coord(qp.y, g.org[1], g.inv_cell);
+    const double cz = cell_coord(qp.z, g.org[2], g.inv_cell) + (double)(j - 1);
+    const double tx = (double)(g.dim[0] - 1), ty = (double)(g.dim[1] - 1), tz = (double)(g.dim[2] - 1);
+    if ((ux + kx >= 0.0) && (ux - kx <= tx) && cz >= 0.0 && cz <= tz) {  // NaN coordinates: no candidates
+      const int lx = (int)fmin(fmax(ux - kx, 0.0), tx);
+      const int hx = (int)fmin(fmax(ux + kx, 0.0), tx);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double cy = uy + (double)(i - 1);
+        if (cy >= 0.0 && cy <= ty) {
+          const int base = g.cell_base + g.dim[0] * ((int)cy + g.dim[1] * (int)cz);
+          p0[i] = start_s[base + lx];
+          p1[i] = start_s[base + hx + 1];
+        }
+      }
+    }
+  }
+  if (j == 0) qbuf[slot] = qp;
+  GR_Q2_STOP(1, p0[0] + p0[1] + p0[2] + p1[0] + p1[1] + p1[2])
+  // ---- block-wide extent of every band (waves are slab-uniform: band index = 3*j + i)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const bool has = p1[i] > p0[i];
+    int lo, hi;
+    if (mono) {  // self-search: ranges are non-decreasing along the wave
+      const unsigned long long m = __ballot(has);
+      lo = 0x7fffffff;
+      hi = 0;
+      if (m) {
+        lo = __builtin_amdgcn_readlane(p0[i], __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1));
+        hi = __builtin_amdgcn_readlane(p1[i], __builtin_amdgcn_readfirstlane(63 - __clzll((long long)m)));
+      }
+    } else {
+      lo = wave_min_i32_dpp(has ? p0[i] : 0x7fffffff);
+      hi = wave_max_i32_dpp(has ? p1[i] : 0);
+    }
+    if (lane == 0 && hi > 0) {
+      atomicMin(&band_lo[3 * j + i], lo);
+      atomicMax(&band_hi[3 * j + i], hi);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int k = 0; k < NBAND; ++k) {
+      band_base[k] = acc;
+      acc += band_hi[k] > band_lo[k] ? band_hi[k] - band_lo[k] : 0;
+    }
+    band_base[NBAND] = acc;
+  }
+  __syncthreads();
+  const bool staged = band_base[NBAND] <= L::STAGE_CAP;
+  if (staged) {
+    // wave w copies bands w, w + NWV, ...; every load of a wave is issued before its first LDS write, on clamped indices
+    constexpr int NWV = L::THREADS / WAVE, KMAX = (NBAND + NWV - 1) / NWV, UNR = 2;
+    const int wvi = tid / WAVE;
+    float4 v[KMAX][UNR];
+    int blo[KMAX], blen[KMAX], bdst[KMAX];
+#pragma unroll
+    for (int kk = 0; kk < KMAX; ++kk) {
+      const int k = wvi + kk * NWV;
+      blo[kk] = 0;
+      blen[kk] = 0;
+      bdst[kk] = 0;
+      if (k < NBAND) {
+        const int l0 = band_lo[k], h0 = band_hi[k];
+        blen[kk] = h0 > l0 ? h0 - l0 : 0;
+        blo[kk] = blen[kk] > 0 ? l0 : 0;
+        bdst[kk] = band_base[k];
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) v[kk][u] = sorted_s[min(blo[kk] + u * WAVE + lane, ns_total - 1)];
+    }
+#pragma unroll
+    for (int kk = 0; kk < KMAX; ++kk) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int f = u * WAVE + lane;
+        if (f < blen[kk]) {
+          sx[bdst[kk] + f] = v[kk][u].x;
+          sy[bdst[kk] + f] = v[kk][u].y;
+          sz[bdst[kk] + f] = v[kk][u].z;
+          si[bdst[kk] + f] = __float_as_int(v[kk][u].w);
+        }
+      }
+      for (int f = UNR * WAVE + lane; f < blen[kk]; f += WAVE) {  // a band longer than 128 elements
+        const float4 t4 = sorted_s[blo[kk] + f];
+        sx[bdst[kk] + f] = t4.x;
+        sy[bdst[kk] + f] = t4.y;
+        sz[bdst[kk] + f] = t4.z;
+        si[bdst[kk] + f] = __float_as_int(t4.w);
+      }
+    }
+    __syncthreads();
+  }
+  GR_Q2_STOP(2, (int)sx[tid])
+  // ---- tests, four candidates per step; hits are the sign bits of (distance bits - r2 bits), shifted into two 32-bit
+  //      registers (even / odd candidates of the thread's enumeration), as in fused_kernel
+  unsigned lo = 0u, hi = 0u;
+  int rel[3] = {0, 0, 0};
+  if (staged) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rel[i] = band_base[3 * j + i] - band_lo[3 * j + i];
+  }
+  const int len0 = p1[0] - p0[0], len1 = p1[1] - p0[1], len2 = p1[2] - p0[2];
+  const int nit0 = (len0 + 3) >> 2, nit1 = (len1 + 3) >> 2, nit2 = (len2 + 3) >> 2;
+  const bool by_mask = staged && (nit0 + nit1 + nit2 <= 16);
+  if (valid && !by_mask) misc[1] = 1;
+  const unsigned r2b = r2 == r2 ? __float_as_uint(r2) : 0u;  // NaN radius: nothing is a neighbour
+  if (MODE == Q2_FILL) {
+    lo = gm.x;
+    hi = gm.y;
+  } else if (valid && by_mask) {
+    const f32x2 qx = {qp.x, qp.x}, qy = {qp.y, qp.y}, qz = {qp.z, qp.z};
+    auto step4 = [&](int p, int left) {  // left >= 4 except in a band's last step (the reads past the band stay inside the planes)
+      const f32x2 xa = {sx[p], sx[p + 1]}, xb = {sx[p + 2], sx[p + 3]};
+      const f32x2 ya = {sy[p], sy[p + 1]}, yb = {sy[p + 2], sy[p + 3]};
+      const f32x2 za = {sz[p], sz[p + 1]}, zb = {sz[p + 2], sz[p + 3]};
+      // nanoflann.hpp:432-440: result += diff*diff for x, y, z starting from 0 (two candidates per op)
+      const f32x2 dxa = qx - xa, dya = qy - ya, dza = qz - za;
+      const f32x2 dxb = qx - xb, dyb = qy - yb, dzb = qz - zb;
+      const f32x2 da = (dxa * dxa + dya * dya) + dza * dza;
+      const f32x2 db = (dxb * dxb + dyb * dyb) + dzb * dzb;
+      const unsigned t0 = __float_as_uint(da.x) - r2b;
+      const unsigned t1 = left >= 2 ? __float_as_uint(da.y) - r2b : 0u;
+      const unsigned t2 = left >= 3 ? __float_as_uint(db.x) - r2b : 0u;
+      const unsigned t3 = left >= 4 ? __float_as_uint(db.y) - r2b : 0u;
+      lo = __builtin_amdgcn_alignbit(lo, t0, 31);  // (lo << 1) | sign(t0)
+      lo = __builtin_amdgcn_alignbit(lo, t2, 31);
+      hi = __builtin_amdgcn_alignbit(hi, t1, 31);
+      hi = __builtin_amdgcn_alignbit(hi, t3, 31);
+    };
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      int p = p0[i] + rel[i];
+      const int e = p1[i] + rel[i];
+      for (; p + 4 <= e; p += 4) step4(p, 4);
+      if (p < e) step4(p, e - p);
+    }
+  }
+  GR_Q2_STOP(3, (int)(lo >> 20) + (int)(hi >> 20))
+  if (MODE == Q2_COUNT && valid) g_mask[(int64_t)j * nq + t] = make_uint2(lo, hi);
+  {
+    const int c1 = 4 * nit0, c2 = 4 * (nit0 + nit1), top = 2 * (nit0 + nit1 + nit2) - 1;
+    recA[tid] = make_uint4(lo, hi, (unsigned)(p0[0] + rel[0]), (unsigned)(p0[1] + rel[1] - c1));
+    recB[tid] = make_uint2((unsigned)(p0[2] + rel[2] - c2), (unsigned)((c1 & 0xff) | ((c2 & 0xff) << 8) | ((top & 0xff) << 16)));
+  }
+  __syncthreads();
+  if (misc[1]) {  // this block cannot use the masks: the caller repeats the call on the kernels above
+    if (tid == 0) {
+      blk_stats[2 * blk] = 0;
+      blk_stats[2 * blk + 1] = 1;
+    }
+    return;
+  }
+  const int rows_here = min(RQ, nq - blk * RQ);
+  if (MODE == Q2_COUNT) {
+    if (tid < RQ) {
+      int tot = 0;
+      if (tid < rows_here) {
+#pragma unroll
+        for (int i = 0; i < NSUB; ++i) {
+          const uint4 a = recA[i * RQ + tid];
+          tot += __popc(a.x) + __popc(a.y);
+        }
+      }
+      const int mx = wave_max_i32_dpp(tot);
+      if (lane == 0) atomicMax(&misc[0], mx);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      blk_stats[2 * blk] = misc[0];
+      blk_stats[2 * blk + 1] = misc[0] > Q2_KCAP ? 1 : 0;
+    }
+    return;
+  }
+  // ---- one half-wave per query
+  const int hw = tid >> 5, l = tid & 31;
+  unsigned* ks = keys + hw * Q2_KCAP;
+  unsigned* is = idxs + hw * Q2_KCAP;
+  int hmax = 0;
+  for (int r = hw; r < rows_here; r += L::NH) {
+    const uint4 a0 = recA[r], a1 = recA[RQ + r], a2 = recA[2 * RQ + r];
+    const uint2 b0 = recB[r], b1 = recB[RQ + r], b2 = recB[2 * RQ + r];
+    const float4 qq = qbuf[r];
+    const int c0 = __popc(a0.x) + __popc(a0.y), c1 = __popc(a1.x) + __popc(a1.y), c2 = __popc(a2.x) + __popc(a2.y);
+    const int tot = c0 + c1 + c2;
+    hmax = max(hmax, tot);
+    if (tot > Q2_KCAP) {
+      misc[1] = 1;
+      continue;
+    }
+    int64_t* const row = out + (int64_t)__float_as_int(qq.w) * row_stride;
+    unsigned dk[Q2_KR], ix[Q2_KR];
+#pragma unroll
+    for (int rd = 0; rd < Q2_KR; ++rd) {
+      dk[rd] = 0xffffffffu;
+      ix[rd] = 0u;
+      if (rd * 32 < tot) {
+        const int k = rd * 32 + l;
+        if (k < tot) {
+          const bool g1 = k >= c0, g2 = k >= c0 + c1;
+          int kk = k - (g2 ? c0 + c1 : (g1 ? c0 : 0));
+          const unsigned mlo = g2 ? a2.x : (g1 ? a1.x : a0.x), mhi = g2 ? a2.y : (g1 ? a1.y : a0.y);
+          const int s0 = (int)(g2 ? a2.z : (g1 ? a1.z : a0.z)), s1 = (int)(g2 ? a2.w : (g1 ? a1.w : a0.w));
+          const int s2 = (int)(g2 ? b2.x : (g1 ? b1.x : b0.x));
+          const unsigned meta = g2 ? b2.y : (g1 ? b1.y : b0.y);
+          const int clo = __popc(mlo);
+          const bool side = kk >= clo;
+          kk -= side ? clo : 0;
+          const int qbit = kth_set_bit32(side ? mhi : mlo, kk);
+          // register bit q holds enumeration slot 2 (top - q) (+ 1 on the odd side); slots 0 .. 4 nit0 - 1 are band 0, ...
+          const int c = 2 * ((int)(meta >> 16) - qbit) + (side ? 1 : 0);
+          const int p = c + (c < (int)(meta & 0xffu) ? s0 : (c < (int)((meta >> 8) & 0xffu) ? s1 : s2));
+          const float dx = qq.x - sx[p], dy = qq.y - sy[p], dz = qq.z - sz[p];
+          const float d = (dx * dx + dy * dy) + dz * dz;
+          dk[rd] = __float_as_uint(d);  // d >= 0: the bit pattern orders like the value
+          ix[rd] = (unsigned)si[p];
+        }
+        ks[k] = dk[rd];
+      }
+    }
+    if (dbg_stop == 4) {  // measurement: keys only
+      if (dk[0] == 0x12345u) row[0] = 1;
+      continue;
+    }
+    __builtin_amdgcn_wave_barrier();  // the segment is read by the other lanes of the half-wave (LDS executes a wave's
+                                      // operations in order)
+    int rk[Q2_KR];
+#pragma unroll
+    for (int rd = 0; rd < Q2_KR; ++rd) rk[rd] = 0;
+    const int quads = (tot + 3) >> 2;
+    const uint4* seg = reinterpret_cast<const uint4*>(ks);
+    if (tot <= 32) {
+      for (int jj = 0; jj < quads; ++jj) {
+        const uint4 k4 = seg[jj];
+        rk[0] += (k4.x < dk[0] ? 1 : 0) + (k4.y < dk[0] ? 1 : 0) + (k4.z < dk[0] ? 1 : 0) + (k4.w < dk[0] ? 1 : 0);
+      }
+    } else {
+      for (int jj = 0; jj < quads; ++jj) {
+        const uint4 k4 = seg[jj];
+#pragma unroll
+        for (int rd = 0; rd < Q2_KR; ++rd)
+          rk[rd] += (k4.x < dk[rd] ? 1 : 0) + (k4.y < dk[rd] ? 1 : 0) + (k4.z < dk[rd] ? 1 : 0) + (k4.w < dk[rd] ? 1 : 0);
+      }
+    }
+    // equal distance words: two hits share a rank and the ranks no longer add up to n (n - 1) / 2
+    int rsum = 0;
+#pragma unroll
+    for (int rd = 0; rd < Q2_KR; ++rd) rsum += (rd * 32 + l < tot) ? rk[rd] : 0;
+    rsum = half_wave_sum(rsum);
+    if (rsum != tot * (tot - 1) / 2) {
+#pragma unroll
+      for (int rd = 0; rd < Q2_KR; ++rd)
+        if (rd * 32 < tot) is[rd * 32 + l] = ix[rd];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int rd = 0; rd < Q2_KR; ++rd) {
+        if (rd * 32 + l < tot) {
+          int rank = 0;
+          for (int k2 = 0; k2 < tot; ++k2) {
+            const unsigned dd = ks[k2], ii = is[k2];
+            rank += (dd < dk[rd] || (dd == dk[rd] && ii < ix[rd])) ? 1 : 0;
+          }
+          rk[rd] = rank;
+        }
+      }
+    }
+    if (dbg_stop == 5) {  // measurement: no row stores
+      if (rk[0] == 0x12345) row[0] = 1;
+      continue;
+    }
+    // ---- the row: hits at their rank, the lanes past the hit count pad their own column
+#pragma unroll
+    for (int rd = 0; rd < Q2_KR; ++rd) {
+      const int k = rd * 32 + l;
+      if (k < tot) {
+        if (rk[rd] < width) row[rk[rd]] = (int64_t)ix[rd];
+      } else if (k < row_stride) {
+        row[k] = pad_value;
+      }
+    }
+    for (int k = Q2_KCAP + l; k < row_stride; k += 32) row[k] = pad_value;
+    __builtin_amdgcn_wave_barrier();  // the next query overwrites the key scratch
+  }
+  if (l == 0) atomicMax(&misc[0], hmax);
+  __syncthreads();
+  if (tid == 0) {
+    blk_stats[2 * blk] = misc[0];
+    blk_stats[2 * blk + 1] = misc[1];
+  }
+#undef GR_Q2_STOP
+}
+
 // max / max over the per-block (max hits per query, hits per block) pairs -> hdr
 __global__ __launch_bounds__(1024) void reduce_stats_kernel(const int32_t* __restrict__ blk_stats,
                                                             int blocks, RadiusHdr* __restrict__ hdr) {
@@ -1606,6 +2038,50 @@ int launch_fill(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t n
   return GR_OK;
 }
 
+struct Q2Cfg {
+  int rq;
+  int dbg_stop;
+};
+inline Q2Cfg q2_cfg() {
+  static const Q2Cfg cfg = [] {
+    Q2Cfg c{64, 0};
+    if (const char* e = getenv("GR_RADIUS_Q2_RQ")) c.rq = atoi(e) == 128 ? 128 : 64;
+    if (const char* e = getenv("GR_RADIUS_Q2_STOP")) c.dbg_stop = atoi(e);
+    return c;
+  }();
+  return cfg;
+}
+
+// One launch of q2_kernel + the reduction of its per-block (max hits, flag) pairs into hdr->max_count / hdr->max_block_hits
+// (the latter = 1: some workgroup could not use the masks, the caller repeats the call on the older kernels).
+template <int RQ, int MODE>
+int launch_q2_t(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns, int nb, const int32_t* start_s, float r2,
+                int64_t width, int64_t row_stride, int64_t* out, bool mono, hipStream_t stream) {
+  using L = Q2Lds<RQ>;
+  const int blocks = (int)((nq + RQ - 1) / RQ);
+  const int grid = (blocks + 7) / 8 * 8;
+  const size_t lds = L::total(nb <= L::TABLE_MAX ? nb : 0);
+  auto kern = q2_kernel<RQ, MODE>;
+  if (lds > 64 * 1024)
+    GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  {
+    KernelTimer timer(MODE == Q2_COUNT ? "radius_count" : (MODE == Q2_FILL ? "radius_fill" : "radius_fused"), stream);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(L::THREADS), lds, stream, sorted_q, (int)nq, w.q_off, nb, w.grids, start_s,
+                       w.sorted_s, (int)ns, r2, reinterpret_cast<uint2*>(w.q_mask), w.blk_stats, (int)width, (int)row_stride, ns,
+                       out, mono ? 1 : 0, q2_cfg().dbg_stop);
+  }
+  if (MODE != Q2_FILL) hipLaunchKernelGGL(reduce_stats_kernel, dim3(1), dim3(1024), 0, stream, w.blk_stats, blocks, w.hdr);
+  GR_LAUNCH_CHECK();
+  return GR_OK;
+}
+
+template <int MODE>
+int launch_q2(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns, int nb, const int32_t* start_s, float r2,
+              int64_t width, int64_t row_stride, int64_t* out, bool mono, hipStream_t stream) {
+  return q2_cfg().rq == 128 ? launch_q2_t<128, MODE>(w, sorted_q, nq, ns, nb, start_s, r2, width, row_stride, out, mono, stream)
+                            : launch_q2_t<64, MODE>(w, sorted_q, nq, ns, nb, start_s, r2, width, row_stride, out, mono, stream);
+}
+
 struct FusedCfg {
   int rq;      // queries per block: 64 or 128
   int rowbuf;  // rows leave through an LDS row buffer as contiguous 16-byte pieces (else: one 8-byte store per hit)
@@ -1668,6 +2144,23 @@ int launch_fused(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t 
                   : launch_fused_t<64, false>(w, sorted_q, nq, ns, nb, start_s, r2, width, c.per_q, out, mono, stream);
 }
 
+}  // namespace
+}  // namespace gr
+
+namespace gr {
+namespace {
+// 0 (default) = count, host, fill on traverse_kernel; 1 = fused_kernel; 2 = q2_kernel: one launch for radius_search, COUNT +
+// FILL launches for radius_neighbors.  Initialised from GR_RADIUS_MODE (GR_RADIUS_SINGLE_PASS=1 still selects mode 1).
+// All three are VALU-issue bound and within 5 % of each other on 8 x 200 k points.
+std::atomic<int>& search_mode() {
+  static std::atomic<int> mode{[] {
+    if (const char* m = getenv("GR_RADIUS_MODE")) return std::max(0, std::min(2, atoi(m)));
+    const char* a = getenv("GR_RADIUS_SINGLE_PASS");
+    return (a && a[0] == '1') ? 1 : 0;
+  }()};
+  return mode;
+}
+constexpr int64_t Q2_PLAN = -2;  // h_info[1] of a count that ran on q2_kernel: the fill consumes its masks
 }  // namespace
 }  // namespace gr
 
@@ -1825,17 +2318,27 @@ extern "C" int gr_radius_count_cached(const float* q, const float* s, const int6
   if (P.empty) return GR_OK;  // width 0
   const RadiusWs& w = P.w;
   const bool same = P.same;
-  rc = launch_count<RT>(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, same, stream);
-  if (rc != GR_OK) return rc;
   // the read-back lands in pinned memory (a copy into pageable memory is staged and synchronised by the runtime on top of
   // the synchronise below)
   RadiusHdr* h_pinned = static_cast<RadiusHdr*>(pinned_scratch(3, sizeof(RadiusHdr)));
   GR_REQUIRE(h_pinned != nullptr, "pinned read-back buffer could not be allocated");
-  GR_HIP(hipMemcpyAsync(h_pinned, w.hdr, sizeof(RadiusHdr), hipMemcpyDeviceToHost, stream));
-  GR_HIP(hipStreamSynchronize(stream));
+  bool q2 = search_mode().load() == 2;
+  if (q2) {
+    rc = launch_q2<Q2_COUNT>(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, 0, 0, nullptr, same, stream);
+    if (rc != GR_OK) return rc;
+    GR_HIP(hipMemcpyAsync(h_pinned, w.hdr, sizeof(RadiusHdr), hipMemcpyDeviceToHost, stream));
+    GR_HIP(hipStreamSynchronize(stream));
+    q2 = h_pinned->max_block_hits == 0;  // else: a workgroup could not use the masks -- count again on traverse_kernel
+  }
+  if (!q2) {
+    rc = launch_count<RT>(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, same, stream);
+    if (rc != GR_OK) return rc;
+    GR_HIP(hipMemcpyAsync(h_pinned, w.hdr, sizeof(RadiusHdr), hipMemcpyDeviceToHost, stream));
+    GR_HIP(hipStreamSynchronize(stream));
+  }
   const RadiusHdr h = *h_pinned;
   h_info[0] = h.max_count;
-  h_info[1] = h.max_block_hits;
+  h_info[1] = q2 ? Q2_PLAN : (int64_t)h.max_block_hits;
   h_info[2] = same ? 1 : 0;
   h_info[3] = h.total_cells;
   return GR_OK;
@@ -1866,25 +2369,13 @@ extern "C" int gr_radius_fill(const float* q, const float* s, int64_t nq, int64_
   const bool same = h_info[2] != 0;
   const float4* sorted_q = same ? w.sorted_s : w.sorted_q;
   const float r2 = radius * radius;
+  if (h_info[1] == Q2_PLAN) return launch_q2<Q2_FILL>(w, sorted_q, nq, ns, (int)batch, w.start, r2, width, width, out, same, stream);
   return launch_fill<RT>(w, sorted_q, nq, ns, (int)batch, r2, width, width, h_info[1], out, stream);
 }
 
-namespace gr {
-namespace {
-// 0 = count, host, fill (default); 1 = the single-pass kernel.  Initialised from GR_RADIUS_SINGLE_PASS.
-std::atomic<int>& search_mode() {
-  static std::atomic<int> mode{[] {
-    const char* a = getenv("GR_RADIUS_SINGLE_PASS");
-    return (a && a[0] == '1') ? 1 : 0;
-  }()};
-  return mode;
-}
-}  // namespace
-}  // namespace gr
-
 extern "C" int gr_radius_search_mode(int mode) {
   const int old = search_mode().load();
-  if (mode >= 0 && mode <= 1) search_mode().store(mode);
+  if (mode >= 0 && mode <= 2) search_mode().store(mode);
   return old;
 }
 
@@ -1908,9 +2399,10 @@ extern "C" int gr_radius_search(const float* q, const float* s, const int64_t* h
   // GR_RADIUS_SINGLE_PASS=1 selects the single-pass kernel (fused_kernel above).  It is not the default: on 8 x 200 k points it
   // runs as long as count + fill together (both are bound by VALU issue: ~3 000 instructions per wave either way)
   const int mode = search_mode().load();
-  bool fused = mode == 1 && fused_fits(limit);
+  bool fused = (mode == 1 && fused_fits(limit)) || mode == 2;
   if (fused) {
-    rc = launch_fused(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, out, P.same, stream);
+    rc = mode == 2 ? launch_q2<Q2_FUSED>(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, limit, out, P.same, stream)
+                   : launch_fused(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, out, P.same, stream);
     if (rc != GR_OK) return rc;
     GR_HIP(hipMemcpyAsync(h_pinned, w.hdr, sizeof(RadiusHdr), hipMemcpyDeviceToHost, stream));
     GR_HIP(hipStreamSynchronize(stream));
