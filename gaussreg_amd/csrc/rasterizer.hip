@@ -280,7 +280,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const float* __restrict__ opacities, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, int W, int H,
     int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ dfield,
-    uint32_t* __restrict__ rect_raw, int32_t* __restrict__ far_flag) {
+    uint32_t* __restrict__ rect_raw, int32_t* __restrict__ far_flag, DevView cam1, int far_seq) {
+  // LATE (one camera per call): the camera arrives in the kernel arguments `cam1` (no upload in front of the frame); the first
+  // block leaves it in `views` for the kernels behind this one.  far_seq: the value a far depth stores into *far_flag
+  // (a per-call stamp when nobody cleared the flag, else 1).
+  if (LATE && blockIdx.x == 0 && threadIdx.x < (int)(sizeof(DevView) / 4))
+    reinterpret_cast<float*>(const_cast<DevView*>(views))[threadIdx.x] = reinterpret_cast<const float*>(&cam1)[threadIdx.x];
   __shared__ float4 s_sh[(SH16 && !LATE) ? WAVE * SH_ROW : 1];
   __shared__ float4 s_rec[256 / WAVE][4 * REC_PLANE];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
   float mod_prev = 0.f;
   bool have_cov = HAS_COV;
   for (int v = 0; v < V; ++v) {
-    const DevView& cam = views[v];
+    const DevView& cam = LATE ? cam1 : views[v];
     const int64_t o = (int64_t)v * P + i;
     int out_radius = 0;
     uint32_t out_field = 0u, out_rect = 0u;  // culled: depth field 0
@@ -437,7 +442,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
           uint32_t dk = __float_as_uint(out_depth) - KEY_DEPTH_BASE;  // out_depth > 0.2 > 0.125
           if (dk >= (1u << KEY_DEPTH_BITS)) {
             dk = (1u << KEY_DEPTH_BITS) - 1;
-            atomicOr(far_flag, 1);
+            if (LATE) *far_flag = far_seq; else atomicOr(far_flag, 1);
           }
           out_field = dk;
           out_rect = pack_rect(rmin, rmax);
@@ -611,7 +616,11 @@ __global__ __launch_bounds__(1024) void chunk_max_kernel(int n, const int32_t* _
 template <bool SELF>
 __global__ __launch_bounds__(256) void seg_scan_kernel(int V, int tiles, int nchunk, const uint16_t* __restrict__ chunk_cnt,
                                                        const int32_t* __restrict__ chunk_base /* per view; SELF: raw totals */,
-                                                       int32_t* __restrict__ totals, uint32_t* __restrict__ seg_off) {
+                                                       int32_t* __restrict__ totals, uint32_t* __restrict__ seg_off,
+                                                       int32_t* __restrict__ mail, int mail_seq) {
+  // mail (SELF only; host-mapped pinned memory or null): [V] totals, [V] chunk maxima, [1] far flag word, [V] stamps -- the host
+  // polls the stamps instead of waiting for a device-to-host copy behind an event (both sat in the stream in front of the
+  // scatter: 4 us of copy + a 6 - 8 us hand-over gap per frame)
   __shared__ int s_w[256 / WAVE];
   __shared__ int s_carry;
   const int v = blockIdx.x / nchunk, c = blockIdx.x % nchunk;
@@ -642,8 +651,15 @@ __global__ __launch_bounds__(256) void seg_scan_kernel(int V, int tiles, int nch
       if (lane == 0) s_m[wv] = mx;
       __syncthreads();
       if (threadIdx.x == 0) {
-        totals[v] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-        totals[V + v] = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+        const int tv = s_w[0] + s_w[1] + s_w[2] + s_w[3], mv = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+        totals[v] = tv;
+        totals[V + v] = mv;
+        if (mail != nullptr) {
+          __hip_atomic_store(&mail[v], tv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&mail[V + v], mv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (v == 0) __hip_atomic_store(&mail[2 * V], totals[2 * V], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&mail[2 * V + 1 + v], mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
       }
       __syncthreads();
     }
@@ -1198,20 +1214,27 @@ __global__ __launch_bounds__(256) void verify_tile_lists_kernel(int P, int V, in
 
 namespace gr {
 namespace {
-std::atomic<int> g_verified_frames[64];
+std::atomic<int> g_frames[64];  // frames rendered per device
 
+// The lane-ordered ranking (one ds_add_rtn per key, equal-address lanes served in lane order) rests on a measured property of
+// the LDS, not on an architectural guarantee: besides the probe (common.hip), the REAL outputs of a frame -- every view's
+// depth order, every per-tile list -- are checked on the device for the first three frames of a process and device and
+// again on one frame in every 256 from then on (other occupancy, clocks or partition mode later in the life of a process
+// would otherwise go unnoticed); a failed check demotes the process to ballot ranking and renders the frame again.
+// GR_RASTER_VERIFY=1 checks every frame.
 bool verify_this_frame() {
   static const bool always = getenv("GR_RASTER_VERIFY") && getenv("GR_RASTER_VERIFY")[0] == '1';
   if (lds_atomics_lane_ordered_state() != 1) return always;  // ballot ranking needs no such check (but may be asked for)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
-  return always || g_verified_frames[dev].load() < 3;
+  const int f = g_frames[dev].load();
+  return always || f < 3 || (f & 255) == 0;
 }
 
-void frame_verified() {
+void frame_done() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
-  g_verified_frames[dev].fetch_add(1);
+  g_frames[dev].fetch_add(1);
 }
 
 // runs `launch_check(d_flag)` (which enqueues the check kernels), waits, returns the flag word
@@ -1229,24 +1252,49 @@ int device_check(hipStream_t stream, F&& launch_check, int* h_flag) {
 
 // One host-to-device copy: the depth-overflow flag (cleared) and the camera table that follows it in the geometry buffer
 // (Geom::totals layout).  The pinned staging buffer must stay untouched until the caller has synchronised the stream / event.
+// Up to four cameras travel as KERNEL ARGUMENTS: a one-wave kernel writes the cleared flag words and the DevView records.
+// (An H2D copy of the same 200 bytes occupies the stream for 4.6 us in front of every one-camera frame -- copy engine
+// hand-over; the kernel costs a launch boundary.)  More cameras: one copy out of pinned staging, as before.
+constexpr int VIEW_PACK = 4;
+struct ViewPack {
+  DevView v[VIEW_PACK];
+};
+__global__ void upload_views_kernel(ViewPack pack, int num_views, int32_t* __restrict__ d_flag) {
+  const int t = threadIdx.x;
+  if (t < 4) d_flag[t] = 0;
+  constexpr int WORDS = sizeof(DevView) / 4;
+  float* dst = reinterpret_cast<float*>(d_flag + 4);
+  const float* src = reinterpret_cast<const float*>(&pack);
+  for (int i = t; i < num_views * WORDS; i += blockDim.x) dst[i] = src[i];
+}
+
+static void fill_view(DevView& d, const gr_raster_view& s) {
+  memcpy(d.view, s.viewmatrix, sizeof(d.view));
+  memcpy(d.proj, s.projmatrix, sizeof(d.proj));
+  memcpy(d.campos, s.campos, sizeof(d.campos));
+  memcpy(d.bg, s.bg, sizeof(d.bg));
+  d.tanx = s.tanfovx;
+  d.tany = s.tanfovy;
+  d.fx = (float)s.image_width / (2.0f * s.tanfovx);
+  d.fy = (float)s.image_height / (2.0f * s.tanfovy);
+  d.scale_mod = s.scale_modifier;
+}
+
 int upload_views(const gr_raster_view* h_views, int num_views, int32_t* d_flag, hipStream_t stream) {
+  static_assert(sizeof(DevView) % 4 == 0, "DevView is copied word by word");
+  if (num_views <= VIEW_PACK) {
+    ViewPack pack;
+    memset(&pack, 0, sizeof(pack));
+    for (int v = 0; v < num_views; ++v) fill_view(pack.v[v], h_views[v]);
+    hipLaunchKernelGGL(upload_views_kernel, dim3(1), dim3(WAVE), 0, stream, pack, num_views, d_flag);
+    GR_LAUNCH_CHECK();
+    return GR_OK;
+  }
   char* raw = static_cast<char*>(pinned_scratch(0, 16 + sizeof(DevView) * num_views));
   GR_REQUIRE(raw != nullptr, "pinned staging buffer for %d views could not be allocated", num_views);
   memset(raw, 0, 16);
   DevView* stage = reinterpret_cast<DevView*>(raw + 16);
-  for (int v = 0; v < num_views; ++v) {
-    const gr_raster_view& s = h_views[v];
-    DevView& d = stage[v];
-    memcpy(d.view, s.viewmatrix, sizeof(d.view));
-    memcpy(d.proj, s.projmatrix, sizeof(d.proj));
-    memcpy(d.campos, s.campos, sizeof(d.campos));
-    memcpy(d.bg, s.bg, sizeof(d.bg));
-    d.tanx = s.tanfovx;
-    d.tany = s.tanfovy;
-    d.fx = (float)s.image_width / (2.0f * s.tanfovx);
-    d.fy = (float)s.image_height / (2.0f * s.tanfovy);
-    d.scale_mod = s.scale_modifier;
-  }
+  for (int v = 0; v < num_views; ++v) fill_view(stage[v], h_views[v]);
   GR_HIP(hipMemcpyAsync(d_flag, raw, 16 + sizeof(DevView) * num_views, hipMemcpyHostToDevice, stream));
   return GR_OK;
 }
@@ -1280,6 +1328,18 @@ extern "C" size_t gr_raster_bin_bytes(int64_t total_rendered, int width, int hei
   return carve_bin(nullptr, total_rendered, tiles_of(width, height) * num_views).bytes;
 }
 
+// How the counts of a deferred (speculative) frame reach the host:
+//   mail    the counting kernel itself stores them into host-mapped pinned memory and stamps them with `seq`; the host polls
+//           the stamps (a few views per call on the self-scanning path: nothing but kernels sits in the stream)
+//   event   a device-to-host copy on a side stream, followed by `ev`
+struct Deferred {
+  hipEvent_t ev;
+  volatile int32_t* mail;  // [V] totals, [V] chunk maxima, [1] far word, [V] stamps
+  int seq;                 // this frame's stamp (never 0)
+  int far_seq;             // the far word equals this value iff a depth overflowed the compact keys
+  bool by_mail;            // out: which of the two ways this frame took
+};
+
 // defer_ev != nullptr: everything is enqueued, the read-back of the counts is followed by this event instead of a stream
 // synchronise, and h_num_rendered is NOT filled -- the caller waits for the event and calls preprocess_collect().
 static int preprocess_impl(int64_t P, int M, const float* means3D, const float* shs,
@@ -1287,7 +1347,7 @@ static int preprocess_impl(int64_t P, int M, const float* means3D, const float* 
                            const float* scales, const float* rotations,
                            const float* cov3D_precomp, const gr_raster_view* h_views,
                            int num_views, int32_t* radii, void* geom, size_t geom_bytes,
-                           int64_t* h_num_rendered, hipStream_t stream, hipEvent_t defer_ev) {
+                           int64_t* h_num_rendered, hipStream_t stream, Deferred* defer_ev) {
   int rc = check_views(h_views, num_views);
   if (rc != GR_OK) return rc;
   GR_REQUIRE(h_num_rendered != nullptr, "h_num_rendered is null");
@@ -1323,19 +1383,31 @@ static int preprocess_impl(int64_t P, int M, const float* means3D, const float* 
     set_error("raster geometry buffer too small: need %zu bytes, got %zu", g.bytes, geom_bytes);
     return GR_ERR_WORKSPACE;
   }
-  rc = upload_views(h_views, num_views, g.totals + 2 * num_views, stream);  // cameras + the cleared depth-overflow flag
-  if (rc != GR_OK) return rc;
   const dim3 blk(256), grd((unsigned)((P + 255) / 256));
   const bool sh16 = shs != nullptr && M == 16 && (reinterpret_cast<uintptr_t>(shs) % 16 == 0);
+  // one camera, deferred frame: the camera rides in the kernel arguments of the preprocess kernel and a far depth stores
+  // this call's stamp into the flag word -- no upload, no clear in front of the frame
+  const bool cam_in_args = sh16 && num_views == 1 && defer_ev != nullptr && defer_ev->mail != nullptr;
+  DevView cam1;
+  memset(&cam1, 0, sizeof(cam1));
+  int far_seq = 1;
+  if (sh16 && num_views == 1) fill_view(cam1, h_views[0]);  // the one-view kernel variant always reads the camera from its arguments
+  if (cam_in_args) {
+    far_seq = defer_ev->seq;
+  } else {
+    rc = upload_views(h_views, num_views, g.totals + 2 * num_views, stream);  // cameras + the cleared depth-overflow flag
+    if (rc != GR_OK) return rc;
+  }
+  if (defer_ev != nullptr) defer_ev->far_seq = far_seq;
 #define GR_PRE(SH, COV, S16)                                                                       \
   if (S16 && num_views == 1)                                                                       \
     hipLaunchKernelGGL((preprocess_kernel<SH, COV, S16, S16>), grd, blk, 0, stream, (int)P, D, M, num_views, \
                        g.views, means3D, shs, colors_precomp, opacities, scales, rotations,        \
-                       cov3D_precomp, W, H, radii, g.rec, g.dfield, g.rect_raw, g.totals + 2 * num_views); \
+                       cov3D_precomp, W, H, radii, g.rec, g.dfield, g.rect_raw, g.totals + 2 * num_views, cam1, far_seq); \
   else                                                                                             \
   hipLaunchKernelGGL((preprocess_kernel<SH, COV, S16, false>), grd, blk, 0, stream, (int)P, D, M, num_views, \
                      g.views, means3D, shs, colors_precomp, opacities, scales, rotations,          \
-                     cov3D_precomp, W, H, radii, g.rec, g.dfield, g.rect_raw, g.totals + 2 * num_views)
+                     cov3D_precomp, W, H, radii, g.rec, g.dfield, g.rect_raw, g.totals + 2 * num_views, cam1, far_seq)
   auto run_preprocess = [&]() {
     KernelTimer timer("raster_preprocess", stream);
     if (shs && cov3D_precomp) { if (sh16) GR_PRE(true, true, true); else GR_PRE(true, true, false); }
@@ -1370,8 +1442,11 @@ static int preprocess_impl(int64_t P, int M, const float* means3D, const float* 
       const bool short_rows = nchunk <= SCAN_SINGLE_ROW;  // one launch does scan, totals and maxima
       const bool self_scan = short_rows && num_views <= 4;  // ... or none at all: seg_scan_kernel<true> sums what it needs
       if (self_scan) {
+        const bool by_mail = defer_ev != nullptr && defer_ev->mail != nullptr;
         hipLaunchKernelGGL(seg_scan_kernel<true>, dim3((unsigned)(num_views * nchunk)), blk, 0, stream, num_views, tiles, nchunk,
-                           g.chunk_cnt, g.chunk_total, g.totals, g.seg_off);
+                           g.chunk_cnt, g.chunk_total, g.totals, g.seg_off, by_mail ? const_cast<int32_t*>(defer_ev->mail) : nullptr,
+                           by_mail ? defer_ev->seq : 0);
+        if (by_mail) defer_ev->by_mail = true;
         GR_LAUNCH_CHECK();
       } else {
         if (!short_rows)
@@ -1381,19 +1456,31 @@ static int preprocess_impl(int64_t P, int M, const float* means3D, const float* 
                                      g.scan_ws, g.totals, stream, nullptr, short_rows ? g.totals + num_views : nullptr);
         if (rcs != GR_OK) return rcs;
         hipLaunchKernelGGL(seg_scan_kernel<false>, dim3((unsigned)(num_views * nchunk)), blk, 0, stream, num_views, tiles, nchunk,
-                           g.chunk_cnt, g.chunk_total + (int64_t)num_views * nchunk, g.totals, g.seg_off);
+                           g.chunk_cnt, g.chunk_total + (int64_t)num_views * nchunk, g.totals, g.seg_off, (int32_t*)nullptr, 0);
         GR_LAUNCH_CHECK();
       }
     }
     const bool short_rows = nchunk <= SCAN_SINGLE_ROW;
     // tot: [V] totals, [V] per-view chunk maxima (short rows), [1] depth-overflow flag, [1] chunk maximum (long rows)
+    if (defer_ev != nullptr) {
+      if (defer_ev->by_mail) return GR_OK;  // the counting kernel mails the counts itself
+      // else: a device-to-host copy on a SIDE stream, so the scatter and the blend that follow on `stream` do not queue
+      // behind it (it held the stream for 4.2 us + a 5.7 us hand-over gap, profiles/r03_single_view_timeline.txt)
+      static thread_local hipStream_t side = nullptr;
+      static thread_local hipEvent_t counted = nullptr;
+      if (side == nullptr) GR_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+      if (counted == nullptr) GR_HIP(hipEventCreateWithFlags(&counted, hipEventDisableTiming));
+      GR_HIP(hipEventRecord(counted, stream));
+      GR_HIP(hipStreamWaitEvent(side, counted, 0));
+      GR_HIP(hipMemcpyAsync(tot, g.totals, sizeof(int32_t) * (2 * num_views + 1), hipMemcpyDeviceToHost, side));
+      if (!short_rows)
+        GR_HIP(hipMemcpyAsync(tot + 2 * num_views + 1, g.chunk_max, sizeof(int32_t), hipMemcpyDeviceToHost, side));
+      GR_HIP(hipEventRecord(defer_ev->ev, side));
+      return GR_OK;
+    }
     GR_HIP(hipMemcpyAsync(tot, g.totals, sizeof(int32_t) * (2 * num_views + 1), hipMemcpyDeviceToHost, stream));
     if (!short_rows)
       GR_HIP(hipMemcpyAsync(tot + 2 * num_views + 1, g.chunk_max, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-    if (defer_ev != nullptr) {
-      GR_HIP(hipEventRecord(defer_ev, stream));
-      return GR_OK;
-    }
     GR_HIP(hipStreamSynchronize(stream));
     h_chunk_max = short_rows ? tot[num_views] : tot[2 * num_views + 1];
     if (short_rows)
@@ -1457,11 +1544,39 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
                          radii, geom, geom_bytes, h_num_rendered, static_cast<hipStream_t>(stream_), nullptr);
 }
 
-// after the event of a deferred preprocess_impl: counts -> h_num_rendered; *far_depth = the depth-overflow flag
-static int preprocess_collect(int64_t P, int num_views, int64_t* h_num_rendered, bool* far_depth) {
+// waits for the counts of a deferred preprocess_impl (mailbox stamps or the event): counts -> h_num_rendered;
+// *far_depth = the depth-overflow flag
+static int preprocess_collect(int64_t P, int num_views, int64_t* h_num_rendered, bool* far_depth, Deferred& d, hipStream_t stream) {
+  const int nchunk = (int)((P + BIN_CHUNK - 1) / BIN_CHUNK);
+  if (d.by_mail) {
+    const volatile int32_t* m = d.mail;
+    // the GPU is still drawing while the host spins here; bounded: a device fault must not hang the caller
+    bool ready = false;
+    for (long spin = 0; spin < 400000000L && !ready; ++spin) {
+      ready = true;
+      for (int v = 0; v < num_views; ++v) ready = ready && __atomic_load_n(&m[2 * num_views + 1 + v], __ATOMIC_ACQUIRE) == d.seq;
+      if (!ready && (spin & 0xffff) == 0xffff && hipStreamQuery(stream) != hipErrorNotReady) {
+        // the stream has drained (or failed): the stamps must be there now
+        ready = true;
+        for (int v = 0; v < num_views; ++v) ready = ready && __atomic_load_n(&m[2 * num_views + 1 + v], __ATOMIC_ACQUIRE) == d.seq;
+        GR_HIP(hipStreamSynchronize(stream));
+        GR_REQUIRE(ready, "rasterizer: the counting kernel did not report its totals");
+      }
+    }
+    GR_REQUIRE(ready, "rasterizer: timed out waiting for the counts of the frame");
+    int32_t cm = m[num_views];
+    for (int v = 1; v < num_views; ++v) {
+      const int32_t mv = m[num_views + v];
+      cm = std::max(cm, mv);
+    }
+    for (int v = 0; v < num_views; ++v) h_num_rendered[v] = m[v];
+    h_num_rendered[num_views] = cm;
+    *far_depth = m[2 * num_views] == d.far_seq;
+    return GR_OK;
+  }
+  GR_HIP(hipEventSynchronize(d.ev));
   const int32_t* tot = static_cast<const int32_t*>(pinned_scratch(1, sizeof(int32_t) * (2 * num_views + 2)));
   GR_REQUIRE(tot != nullptr, "pinned read-back buffer missing");
-  const int nchunk = (int)((P + BIN_CHUNK - 1) / BIN_CHUNK);
   const bool short_rows = nchunk <= SCAN_SINGLE_ROW;
   int32_t cm = short_rows ? tot[num_views] : tot[2 * num_views + 1];
   if (short_rows)
@@ -1543,7 +1658,6 @@ static int render_impl(int64_t P, const gr_raster_view* h_views, int num_views, 
         GR_LAUNCH_CHECK();
       } else {
         GR_REQUIRE(h_bad == 0, "tile binning produced an unsorted list (internal error)");
-        frame_verified();
       }
     }
   }
@@ -1561,6 +1675,7 @@ static int render_impl(int64_t P, const gr_raster_view* h_views, int num_views, 
   }
 #undef GR_BLEND
   GR_LAUNCH_CHECK();
+  frame_done();
   return GR_OK;
 }
 
@@ -1590,15 +1705,32 @@ extern "C" int gr_raster_forward(int64_t P, int M, const float* means3D, const f
     // count turns out larger than the list (the kernels refuse to run past it) is rendered again.
     static thread_local hipEvent_t ev = nullptr;
     if (ev == nullptr) GR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    static thread_local int32_t* mail = nullptr;  // host-mapped, coherent: the counting kernel writes it, the host polls it
+    if (mail == nullptr) {
+      static const bool no_mail = getenv("GR_RASTER_NO_MAILBOX") && getenv("GR_RASTER_NO_MAILBOX")[0] == '1';
+      void* mp = nullptr;
+      if (!no_mail && hipHostMalloc(&mp, 4096, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+        memset(mp, 0, 4096);
+        mail = static_cast<int32_t*>(mp);
+      } else {
+        (void)hipGetLastError();
+      }
+    }
+    static std::atomic<int> frame_seq{0};
+    int seq = frame_seq.fetch_add(1) + 1;
+    if (seq > 0x7ffffff0) {  // (two billion frames: start over; a stale stamp of that age cannot be in flight)
+      frame_seq.store(1);
+      seq = 1;
+    }
+    Deferred d{ev, mail, seq, 1, false};
     int rc = preprocess_impl(P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, h_views,
-                             num_views, radii, geom, geom_bytes, h_num_rendered, stream, ev);
+                             num_views, radii, geom, geom_bytes, h_num_rendered, stream, &d);
     if (rc != GR_OK) return rc;
     h_num_rendered[num_views] = stage_hint;
     rc = render_impl(P, h_views, num_views, h_num_rendered, geom, geom_bytes, bin, bin_bytes, out_color, flags, entries, stream);
     if (rc != GR_OK) return rc;
-    GR_HIP(hipEventSynchronize(ev));
     bool far_depth = false;
-    rc = preprocess_collect(P, num_views, h_num_rendered, &far_depth);
+    rc = preprocess_collect(P, num_views, h_num_rendered, &far_depth, d, stream);
     if (rc != GR_OK) return rc;
     int64_t R = 0;
     for (int v = 0; v < num_views; ++v) R += h_num_rendered[v];

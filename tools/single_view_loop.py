@@ -15,3 +15,13 @@ for i in range(16):
     img, radii = rast[i % 4](t["means3D"], None, t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
 torch.cuda.synchronize()
 print(img.shape)
+if "--time" in sys.argv:  # views/s of the drop-in forward, one camera per call (the bench's `single_view` figure)
+    import time
+    n = 400
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        img, radii = rast[i % 4](t["means3D"], None, t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print("single view: %.4f ms per call = %.0f views/s" % (dt * 1e3, 1.0 / dt))
