@@ -86,6 +86,8 @@ SIGNATURES.update({
                            c_i64p, c_void, c_size, c_void]),
     "gr_pairwise_distance_workspace_bytes": (c_size, [c_i64, c_i64]),
     "gr_pairwise_distance": (c_int, [c_void, c_void, c_i64, c_i64, c_i64, c_int, c_void, c_void, c_size, c_void]),
+    "gr_pairwise_distance_batch_workspace_bytes": (c_size, [c_i64, c_i64, c_i64]),
+    "gr_pairwise_distance_batch": (c_int, [c_void, c_void, c_i64, c_i64, c_i64, c_i64, c_int, c_void, c_void, c_size, c_void]),
     "gr_superpoint_matching_workspace_bytes": (c_size, [c_i64, c_i64]),
     "gr_superpoint_matching": (c_int, [c_void, c_void, c_i64, c_i64, c_i64, c_void, c_void, c_int, c_int, c_void,
                                        c_void, c_void, c_i64p, c_void, c_size, c_void]),

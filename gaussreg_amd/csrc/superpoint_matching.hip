@@ -31,6 +31,10 @@ enum { EPI_DIST = 0, EPI_EXPNEG = 1 };
 struct SpmStack {
   int32_t r0, nr, s0, ns;  // first ref / src superpoint in the stack, their counts
 };
+// plain batches (pairwise_distance on (B, N, C) x (B, M, C)): element strides from one matrix of the batch to the next
+struct PdBatch {
+  int64_t x, y, out, x2, y2;
+};
 template <class T>
 __device__ __forceinline__ T* z_shift(T* p, size_t bytes) {  // (pointer arithmetic, not integers: the address space stays known)
   return p ? reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(p)) + bytes) : p;
@@ -43,7 +47,7 @@ __global__ __launch_bounds__(256) void pairwise_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const int32_t* __restrict__ xi,
     const int32_t* __restrict__ yi, int n, int m, const int32_t* __restrict__ nm_dev, int C,
     int normalized, const float* __restrict__ x2, const float* __restrict__ y2,
-    float* __restrict__ out, int ld_out, const SpmStack* __restrict__ stack, size_t zstride) {
+    float* __restrict__ out, int ld_out, const SpmStack* __restrict__ stack, size_t zstride, PdBatch bs) {
   __shared__ float sx[PD_T][PD_LD];
   __shared__ float sy[PD_T][PD_LD];
   if (stack) {  // x = y = the stacked features; the gather tables, counts and the output belong to pair blockIdx.z
@@ -55,6 +59,11 @@ __global__ __launch_bounds__(256) void pairwise_kernel(
     ld_out = P.ns;
     const size_t zo = (size_t)blockIdx.z * zstride;
     xi = z_shift(xi, zo), yi = z_shift(yi, zo), nm_dev = z_shift(nm_dev, zo), out = z_shift(out, zo);
+  }
+  if (!stack && gridDim.z > 1) {  // plain batch: matrix blockIdx.z
+    const int64_t z = blockIdx.z;
+    x += z * bs.x, y += z * bs.y, out += z * bs.out;
+    if (x2) x2 += z * bs.x2, y2 += z * bs.y2;
   }
   if (nm_dev) {
     n = nm_dev[0];
@@ -105,16 +114,186 @@ __global__ __launch_bounds__(256) void pairwise_kernel(
   }
 }
 
+// The same contraction for LARGE outputs (and for the batched SuperPointMatching launch): 128 x 128 per workgroup, 64 x 64 per
+// wave = four 32 x 32 accumulators, so one pair of LDS reads feeds two MFMAs instead of one (the 64 x 64 kernel above issues
+// two ds_read_b32 per v_mfma_f32_32x32x2_f32 and waits for a global round trip per k-slab with nothing to cover it: 56 TF at
+// 8192^2); k-slabs of 16 through TWO LDS buffers: the global loads of slab s + 1 are issued before the MFMAs of slab s and
+// land in registers while they run, one barrier per slab.  Same arithmetic per output element (an fmaf chain over k in
+// ascending order), so the two kernels return the same bits.
+constexpr int PB_T = 128;  // output tile per workgroup
+constexpr int PB_K = 16;   // k-slab
+constexpr int PB_LD = PB_K + 1;
+
+// ALIGNED: C is a multiple of the k-slab and both matrices are 16-byte aligned -- every fetch is one unconditional float4
+// load on a clamped row (behind a branch the compiler waits for each load before it issues the next: four memory round
+// trips per slab instead of one).
+template <int EPI, bool ALIGNED>
+__global__ __launch_bounds__(256, 2) void pairwise_big_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, const int32_t* __restrict__ xi,
+    const int32_t* __restrict__ yi, int n, int m, const int32_t* __restrict__ nm_dev, int C,
+    int normalized, const float* __restrict__ x2, const float* __restrict__ y2,
+    float* __restrict__ out, int ld_out, const SpmStack* __restrict__ stack, size_t zstride, PdBatch bs) {
+  __shared__ float sx[2][PB_T][PB_LD];
+  __shared__ float sy[2][PB_T][PB_LD];
+  if (stack) {
+    const SpmStack P = stack[blockIdx.z];
+    y = x + (int64_t)P.s0 * C;
+    x = x + (int64_t)P.r0 * C;
+    n = P.nr;
+    m = P.ns;
+    ld_out = P.ns;
+    const size_t zo = (size_t)blockIdx.z * zstride;
+    xi = z_shift(xi, zo), yi = z_shift(yi, zo), nm_dev = z_shift(nm_dev, zo), out = z_shift(out, zo);
+  }
+  if (!stack && gridDim.z > 1) {  // plain batch: matrix blockIdx.z
+    const int64_t z = blockIdx.z;
+    x += z * bs.x, y += z * bs.y, out += z * bs.out;
+    if (x2) x2 += z * bs.x2, y2 += z * bs.y2;
+  }
+  if (nm_dev) {
+    n = nm_dev[0];
+    m = nm_dev[1];
+  }
+  const int i0 = blockIdx.y * PB_T, j0 = blockIdx.x * PB_T;
+  if (i0 >= n || j0 >= m) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wi = (w >> 1) * 64, wj = (w & 1) * 64;  // wave's 64 x 64 sub-tile
+  // staging: thread -> (row r0 + 64 u, four consecutive k); the row's address is fixed for the whole k loop
+  const int sr = tid >> 2, sk = (tid & 3) * 4;
+  const float* xrow[2];
+  const float* yrow[2];
+  bool xok[2], yok[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int gi = i0 + sr + 64 * u, gj = j0 + sr + 64 * u;
+    xok[u] = gi < n;
+    yok[u] = gj < m;
+    xrow[u] = x + (int64_t)(xok[u] ? (xi ? xi[gi] : gi) : 0) * C;
+    yrow[u] = y + (int64_t)(yok[u] ? (yi ? yi[gj] : gj) : 0) * C;
+  }
+  const bool vec = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) % 16 == 0);
+  auto fetch = [&](const float* row, bool ok, int k0) -> float4 {
+    const int gk = k0 + sk;
+    if (ALIGNED) {
+      const float4 t = *reinterpret_cast<const float4*>(row + gk);  // rows out of range read row 0 and are zeroed here
+      return ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+      if (vec && gk + 4 <= C) {
+        v = *reinterpret_cast<const float4*>(row + gk);
+      } else {
+        if (gk < C) v.x = row[gk];
+        if (gk + 1 < C) v.y = row[gk + 1];
+        if (gk + 2 < C) v.z = row[gk + 2];
+        if (gk + 3 < C) v.w = row[gk + 3];
+      }
+    }
+    return v;
+  };
+  auto stash = [&](float (*dst)[PB_LD], int u, const float4 v) {
+    float* d = &dst[sr + 64 * u][sk];
+    d[0] = v.x;
+    d[1] = v.y;
+    d[2] = v.z;
+    d[3] = v.w;
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float4 rx[2], ry[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    rx[u] = fetch(xrow[u], xok[u], 0);
+    ry[u] = fetch(yrow[u], yok[u], 0);
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    stash(sx[0], u, rx[u]);
+    stash(sy[0], u, ry[u]);
+  }
+  __syncthreads();
+  const int slabs = (C + PB_K - 1) / PB_K;
+  for (int sidx = 0; sidx < slabs; ++sidx) {
+    const int cur = sidx & 1;
+    const bool more = sidx + 1 < slabs;
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        rx[u] = fetch(xrow[u], xok[u], (sidx + 1) * PB_K);
+        ry[u] = fetch(yrow[u], yok[u], (sidx + 1) * PB_K);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < PB_K; k += 2) {
+      // A[i = lane & 31][k = lane >> 5],  B[k = lane >> 5][j = lane & 31]
+      const int kk = k + (lane >> 5), rr = lane & 31;
+      const float a0 = sx[cur][wi + rr][kk], a1 = sx[cur][wi + 32 + rr][kk];
+      const float b0 = sy[cur][wj + rr][kk], b1 = sy[cur][wj + 32 + rr][kk];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        stash(sx[cur ^ 1], u, rx[u]);
+        stash(sy[cur ^ 1], u, ry[u]);
+      }
+    }
+    __syncthreads();
+  }
+  // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  // the squared norms of the lane's rows and columns, requested up front on clamped indices (one memory round trip)
+  float xx[2][16], yy[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int gi = i0 + wi + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      xx[a][r] = normalized ? 0.f : x2[min(gi, n - 1)];
+    }
+#pragma unroll
+  for (int b = 0; b < 2; ++b) yy[b] = normalized ? 0.f : y2[min(j0 + wj + 32 * b + (lane & 31), m - 1)];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int gj = j0 + wj + 32 * b + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gi = i0 + wi + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const float xy = acc[a][b][r];
+        float d;
+        if (normalized) d = 2.0f - 2.0f * xy;      // pairwise_distance.py:26
+        else d = (xx[a][r] - 2.0f * xy) + yy[b];   // pairwise_distance.py:30
+        d = fmaxf(d, 0.0f);                        // :31 clamp(min=0)
+        if (EPI == EPI_EXPNEG) d = expf(-d);       // superpoint_matching.py:37
+        if (gi < n && gj < m) out[(int64_t)gi * ld_out + gj] = d;
+      }
+    }
+}
+
+// squared norms of the rows: one wave per row, lanes stride the channels (coalesced; a thread per row read its 1 KB row on
+// its own: 64 separate lines per load instruction, ~45 us of the 8192 x 256 call), fixed-shape reduction
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x, int n, int C,
                                                      float* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const int row = blockIdx.x * (256 / WAVE) + (int)(threadIdx.x / WAVE), lane = threadIdx.x & (WAVE - 1);
+  if (row >= n) return;
+  const float* r = x + (int64_t)row * C;
   float s = 0.f;
-  for (int k = 0; k < C; ++k) {
-    const float v = x[(int64_t)i * C + k];
+  for (int k = lane; k < C; k += WAVE) {
+    const float v = r[k];
     s += v * v;
   }
-  out[i] = s;
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) s += __shfl_xor(s, d, WAVE);
+  if (lane == 0) out[row] = s;
 }
 
 // ---------------------------------------------------------------- SuperPointMatching pieces
@@ -543,30 +722,67 @@ extern "C" size_t gr_pairwise_distance_workspace_bytes(int64_t n, int64_t m) {
   return align_up((size_t)(n + m) * sizeof(float) + 512, 256);
 }
 
-extern "C" int gr_pairwise_distance(const float* x, const float* y, int64_t n, int64_t m, int64_t c,
-                                    int normalized, float* out, void* ws, size_t ws_bytes, void* stream_) {
+extern "C" size_t gr_pairwise_distance_batch_workspace_bytes(int64_t batch, int64_t n, int64_t m) {
+  if (n < 0 || m < 0 || batch < 0) return 0;
+  return align_up((size_t)std::max<int64_t>(batch, 1) * (align_up((size_t)n, 64) + align_up((size_t)m, 64)) * sizeof(float) + 512, 256);
+}
+
+namespace gr {
+namespace {
+// tile choice: 128 x 128 per workgroup once that still leaves every CU a workgroup or so; else 64 x 64
+inline bool pd_use_big(int64_t n, int64_t m, int64_t batch) {
+  static const int force = getenv("GR_PAIRWISE_TILE") ? atoi(getenv("GR_PAIRWISE_TILE")) : 0;  // 64 / 128: measurement only
+  if (force == 64) return false;
+  if (force == 128) return true;
+  return ((n + PB_T - 1) / PB_T) * ((m + PB_T - 1) / PB_T) * batch >= 192;
+}
+}  // namespace
+}  // namespace gr
+
+extern "C" int gr_pairwise_distance_batch(const float* x, const float* y, int64_t batch, int64_t n, int64_t m, int64_t c,
+                                          int normalized, float* out, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  GR_REQUIRE(n >= 0 && m >= 0 && c >= 0 && n < (1ll << 31) && m < (1ll << 31) && c < (1ll << 31), "bad sizes");
-  if (n == 0 || m == 0) return GR_OK;
+  GR_REQUIRE(batch >= 0 && n >= 0 && m >= 0 && c >= 0 && n < (1ll << 31) && m < (1ll << 31) && c < (1ll << 31) && batch < 65536 &&
+                 batch * std::max(n, m) < (1ll << 31),
+             "bad sizes");
+  if (n == 0 || m == 0 || batch == 0) return GR_OK;
   GR_REQUIRE(x && y && out, "null argument");
   float* x2 = nullptr;
   float* y2 = nullptr;
+  PdBatch bs{n * c, m * c, n * m, 0, 0};
   if (!normalized) {
-    if (!ws || ws_bytes < gr_pairwise_distance_workspace_bytes(n, m)) {
+    if (!ws || ws_bytes < gr_pairwise_distance_batch_workspace_bytes(batch, n, m)) {
       set_error("pairwise_distance workspace too small");
       return GR_ERR_WORKSPACE;
     }
     x2 = static_cast<float*>(ws);
-    y2 = x2 + align_up((size_t)n, 64);
-    hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, (int)n, (int)c, x2);
-    hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, y, (int)m, (int)c, y2);
+    y2 = x2 + align_up((size_t)(batch * n), 64);
+    bs.x2 = n;
+    bs.y2 = m;
+    hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((batch * n + 3) / 4)), dim3(256), 0, stream, x, (int)(batch * n), (int)c, x2);
+    hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((batch * m + 3) / 4)), dim3(256), 0, stream, y, (int)(batch * m), (int)c, y2);
   }
-  const dim3 grid((unsigned)((m + PD_T - 1) / PD_T), (unsigned)((n + PD_T - 1) / PD_T));
-  hipLaunchKernelGGL((pairwise_kernel<EPI_DIST>), grid, dim3(256), 0, stream, x, y, (const int32_t*)nullptr,
-                     (const int32_t*)nullptr, (int)n, (int)m, (const int32_t*)nullptr, (int)c, normalized, x2, y2, out,
-                     (int)m, (const SpmStack*)nullptr, (size_t)0);
+  KernelTimer timer("pairwise_distance", stream);
+  if (pd_use_big(n, m, batch)) {
+    const dim3 grid((unsigned)((m + PB_T - 1) / PB_T), (unsigned)((n + PB_T - 1) / PB_T), (unsigned)batch);
+    const bool aligned = c % PB_K == 0 && (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) % 16 == 0;
+    auto kern = aligned ? pairwise_big_kernel<EPI_DIST, true> : pairwise_big_kernel<EPI_DIST, false>;
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream, x, y, (const int32_t*)nullptr,
+                       (const int32_t*)nullptr, (int)n, (int)m, (const int32_t*)nullptr, (int)c, normalized, x2, y2, out,
+                       (int)m, (const SpmStack*)nullptr, (size_t)0, bs);
+  } else {
+    const dim3 grid((unsigned)((m + PD_T - 1) / PD_T), (unsigned)((n + PD_T - 1) / PD_T), (unsigned)batch);
+    hipLaunchKernelGGL((pairwise_kernel<EPI_DIST>), grid, dim3(256), 0, stream, x, y, (const int32_t*)nullptr,
+                       (const int32_t*)nullptr, (int)n, (int)m, (const int32_t*)nullptr, (int)c, normalized, x2, y2, out,
+                       (int)m, (const SpmStack*)nullptr, (size_t)0, bs);
+  }
   GR_LAUNCH_CHECK();
   return GR_OK;
+}
+
+extern "C" int gr_pairwise_distance(const float* x, const float* y, int64_t n, int64_t m, int64_t c,
+                                    int normalized, float* out, void* ws, size_t ws_bytes, void* stream_) {
+  return gr_pairwise_distance_batch(x, y, 1, n, m, c, normalized, out, ws, ws_bytes, stream_);
 }
 
 extern "C" size_t gr_superpoint_matching_workspace_bytes(int64_t nr, int64_t ns) {
@@ -586,11 +802,24 @@ static int spm_launch(const float* ref_feats, const float* src_feats, int64_t nr
   if (!stack) GR_HIP(hipMemsetAsync(w.hist, 0, 3 * 2048 * sizeof(uint32_t), stream));
   hipLaunchKernelGGL(compact_masks_kernel, dim3(z), dim3(1024), 0, stream, ref_masks, (int)nr, src_masks, (int)ns,
                      num_correspondences, w.ridx, w.sidx, w.hdr, w.hist, stack, zstride);
-  const dim3 grid((unsigned)((ns + PD_T - 1) / PD_T), (unsigned)((nr + PD_T - 1) / PD_T), z);
   // features are L2-normalised by the caller (model.py:143-144): d = 2 - 2 xy  (superpoint_matching.py:37)
-  hipLaunchKernelGGL((pairwise_kernel<EPI_EXPNEG>), grid, dim3(256), 0, stream, ref_feats, src_feats, w.ridx, w.sidx,
-                     (int)nr, (int)ns, reinterpret_cast<const int32_t*>(w.hdr), (int)c, 1, (const float*)nullptr,
-                     (const float*)nullptr, w.S, (int)ns, stack, zstride);
+  {
+    KernelTimer timer("spm_distance", stream);
+    const PdBatch none{0, 0, 0, 0, 0};
+    if (pd_use_big(nr, ns, npairs)) {
+      const dim3 grid((unsigned)((ns + PB_T - 1) / PB_T), (unsigned)((nr + PB_T - 1) / PB_T), z);
+      const bool aligned = c % PB_K == 0 && (reinterpret_cast<uintptr_t>(ref_feats) | reinterpret_cast<uintptr_t>(src_feats)) % 16 == 0;
+      auto kern = aligned ? pairwise_big_kernel<EPI_EXPNEG, true> : pairwise_big_kernel<EPI_EXPNEG, false>;
+      hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream, ref_feats, src_feats, w.ridx, w.sidx,
+                         (int)nr, (int)ns, reinterpret_cast<const int32_t*>(w.hdr), (int)c, 1, (const float*)nullptr,
+                         (const float*)nullptr, w.S, (int)ns, stack, zstride, none);
+    } else {
+      const dim3 grid((unsigned)((ns + PD_T - 1) / PD_T), (unsigned)((nr + PD_T - 1) / PD_T), z);
+      hipLaunchKernelGGL((pairwise_kernel<EPI_EXPNEG>), grid, dim3(256), 0, stream, ref_feats, src_feats, w.ridx, w.sidx,
+                         (int)nr, (int)ns, reinterpret_cast<const int32_t*>(w.hdr), (int)c, 1, (const float*)nullptr,
+                         (const float*)nullptr, w.S, (int)ns, stack, zstride, none);
+    }
+  }
   if (dual_normalization) {
     hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)((nr + 3) / 4), 1, z), dim3(256), 0, stream, w.S, (int)ns, w.hdr, w.rs,
                        stack, zstride);

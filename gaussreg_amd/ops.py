@@ -46,7 +46,7 @@ def _cuda_f32(t, name):
 
 
 def pairwise_distance(x, y, normalized=False, channel_first=False):
-    """pairwise_distance.py:4-31.  (*, N, C) x (*, M, C) -> (*, N, M); leading dims are looped."""
+    """pairwise_distance.py:4-31.  (*, N, C) x (*, M, C) -> (*, N, M); the leading dims are one launch (grid.z)."""
     if channel_first:
         x, y = x.transpose(-1, -2), y.transpose(-1, -2)
     out_device = x.device
@@ -60,11 +60,9 @@ def pairwise_distance(x, y, normalized=False, channel_first=False):
     M = ys.shape[1]
     out = torch.empty((B, N, M), dtype=torch.float32, device=xs.device)
     with torch.cuda.device(xs.device):
-        ws = _lib.workspace(xs.device, L.gr_pairwise_distance_workspace_bytes(N, M))
-        st = _lib.stream_ptr(xs.device)
-        for b in range(B):
-            _lib.check(L.gr_pairwise_distance(_lib.ptr(xs[b]), _lib.ptr(ys[b]), N, M, C, int(bool(normalized)),
-                                              _lib.ptr(out[b]), _lib.ptr(ws), ws.numel(), st))
+        ws = _lib.workspace(xs.device, L.gr_pairwise_distance_batch_workspace_bytes(B, N, M))
+        _lib.check(L.gr_pairwise_distance_batch(_lib.ptr(xs), _lib.ptr(ys), B, N, M, C, int(bool(normalized)), _lib.ptr(out),
+                                                _lib.ptr(ws), ws.numel(), _lib.stream_ptr(xs.device)))
     out = out.reshape(*lead, N, M)
     return out if out_device.type == "cuda" else out.to(out_device)
 

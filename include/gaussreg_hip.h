@@ -282,6 +282,12 @@ int gr_gs_fuse(const float* rec1, int64_t n1, const float* rec2, int64_t n2, con
 size_t gr_pairwise_distance_workspace_bytes(int64_t n, int64_t m);
 int gr_pairwise_distance(const float* x, const float* y, int64_t n, int64_t m, int64_t c, int normalized,
                          float* out, void* ws, size_t ws_bytes, void* stream);
+/* The same over a batch: x (batch, n, c), y (batch, m, c) -> out (batch, n, m) in ONE launch (grid.z = matrix); the
+ * leading dimensions of pairwise_distance.py:4-31.  Outputs of at least ~192 tiles of 128 x 128 (over the whole batch) take
+ * the 128 x 128-per-workgroup kernel, smaller ones 64 x 64 tiles; both return the same bits. */
+size_t gr_pairwise_distance_batch_workspace_bytes(int64_t batch, int64_t n, int64_t m);
+int gr_pairwise_distance_batch(const float* x, const float* y, int64_t batch, int64_t n, int64_t m, int64_t c, int normalized,
+                               float* out, void* workspace, size_t workspace_bytes, void* stream);
 size_t gr_superpoint_matching_workspace_bytes(int64_t nr, int64_t ns);
 int gr_superpoint_matching(const float* ref_feats, const float* src_feats, int64_t nr, int64_t ns, int64_t c,
                            const uint8_t* ref_masks, const uint8_t* src_masks, int num_correspondences,

@@ -111,6 +111,41 @@ def run(dev):
         spm = SuperPointMatching(256)
         ms = _ms(lambda: spm(fr, fs), 20)
         out["superpoint_matching_767"] = _mfma(ms, 2.0 * 767 * 767 * 256, bytes=4 * 256 * (767 + 767) + 256 * 20)
+        # ---- the same at the configs[4] shape: 64 pairs x (767 + 767) superpoints through gr_superpoint_matching_batch (ONE set of
+        #      launches, grid.z = pair), and the distance kernel's own share of it (HIP events around that launch: "spm_distance")
+        import ctypes
+        from gaussreg_amd import _lib
+        L = _lib.lib()
+
+        def kernel_ms(name, fn, n=10):
+            L.gr_timing_enable(1)
+            fn()
+            L.gr_timing_reset()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            tot, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+            L.gr_timing_read(name.encode(), ctypes.byref(tot), ctypes.byref(cnt))
+            L.gr_timing_enable(0)
+            L.gr_timing_reset()
+            return tot.value / max(cnt.value, 1)
+        npair = 64
+        fb = torch.nn.functional.normalize(R(npair * 2 * 767, 256), dim=1)
+        nl = [767] * (2 * npair)
+        ms = _ms(lambda: spm.forward_batch(fb, nl), 10)
+        kms = kernel_ms("spm_distance", lambda: spm.forward_batch(fb, nl))
+        fl = 2.0 * npair * 767 * 767 * 256
+        out["superpoint_matching_batch_64x767"] = _mfma(ms, fl, pairs=npair, distance_kernel=_mfma(kms, fl),
+                                                        note="whole op = mask compaction, distance + exp (fp32 MFMA, 128 x 128 tiles), row / column "
+                                                             "sums, normalisation, 3-pass radix select of the top 256, sort -- per pair, grid.z = pair")
+        xb, yb = R(npair, 767, 256), R(npair, 767, 256)
+        ms = _ms(lambda: ops.pairwise_distance(xb, yb), 10)
+        kms = kernel_ms("pairwise_distance", lambda: ops.pairwise_distance(xb, yb))
+        out["pairwise_distance_batch_64x767x767x256"] = _mfma(ms, fl, distance_kernel=_mfma(kms, fl), note="(B, N, C) x (B, M, C) in one launch, grid.z = matrix")
+        x8, y8 = R(8192, 256), R(8192, 256)
+        kms = kernel_ms("pairwise_distance", lambda: ops.pairwise_distance(x8, y8))
+        out["pairwise_distance_8192x8192x256"]["distance_kernel"] = _mfma(kms, 2.0 * 8192 * 8192 * 256)
+        del xb, yb, x8, y8, fb
         # ---- KPConv: the backbone's 11 layers at their real widths on the demo pyramid
         Pl, NB, SUB = d["points"], d["neighbors"], d["subsampling"]
         kp = torch.randn(15, 3) * 0.03

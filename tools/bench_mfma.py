@@ -28,6 +28,15 @@ for n, c in ((767, 256), (8192, 256)):
     y = torch.randn(n, c, device="cuda", generator=g)
     t = timeit(lambda: ops.pairwise_distance(x, y))
     rows.append((f"pairwise_distance {n}x{n}x{c}", 2.0 * n * n * c, t))
+# the configs[4] shape: 64 pairs x 767 superpoints in one launch -- SuperPointMatching (distance + exp on the MFMA kernel) and the bare batch
+from gaussreg_amd.matching import SuperPointMatching
+fb = torch.nn.functional.normalize(torch.randn(64 * 2 * 767, 256, device="cuda", generator=g), dim=1)
+spm = SuperPointMatching(256)
+t = timeit(lambda: spm.forward_batch(fb, [767] * 128), 5)
+rows.append(("superpoint_matching_batch 64 x 767x767x256 (whole op)", 2.0 * 64 * 767 * 767 * 256, t))
+xb = torch.randn(64, 767, 256, device="cuda", generator=g)
+t = timeit(lambda: ops.pairwise_distance(xb, xb), 5)
+rows.append(("pairwise_distance batch 64 x 767x767x256", 2.0 * 64 * 767 * 767 * 256, t))
 pc = torch.rand(1, 767, 3, device="cuda", generator=g) * 5
 for fp32 in (True, False):
     gse = GeometricStructureEmbedding(256, 0.2, 15, 3, fp32_mfma=fp32).cuda()
