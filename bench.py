@@ -490,6 +490,25 @@ def run_gpu(h, args):
                                                       "geometric stages (matching ops, Sinkhorn, LGR, RANSAC) are wired correctly",
                          "median_rre_deg": round(float(rre.median()), 4), "median_rte_m": round(float(rte.median()), 5),
                          "kernel_ms_total_per_gpu": pk}
+        # ---- where a pair's time goes: one more pass over the first block of pairs with a device synchronise around every stage
+        #      (slower than the timed pass: nothing overlaps; the SHARES are what this is for).  `standin_descriptors` is harness
+        #      work (random Fourier features in place of the learned features), everything else is the reference's pipeline.
+        try:
+            regp = pair_pipeline.PairRegistrar(dev, profile=True)
+            nprof = min(len(pairs), args.pair_batch)
+            regp.register_pairs(pairs[:nprof])
+            regp.section_ms.clear()
+            regp.register_pairs(pairs[:nprof])
+            tot_ms = sum(regp.section_ms.values())
+            line["pairs"]["stage_share"] = {k: round(v / tot_ms, 4) for k, v in sorted(regp.section_ms.items(), key=lambda kv: -kv[1])}
+            line["pairs"]["stage_ms_per_pair_synchronised"] = {k: round(v / nprof, 4) for k, v in regp.section_ms.items()}
+            line["pairs"]["stage_note"] = ("standin_descriptors = harness work (one HIP launch per call, csrc/standin.hip); patch_scores = the "
+                                           "128 x 128 x 256 contraction of model.py:186-190 (rocBLAS through torch.bmm, as in the reference); "
+                                           "patch_features / metrics = index bookkeeping in stock PyTorch, as in the reference")
+            regp.close()
+            del regp
+        except Exception as e:
+            line["pairs"]["stage_share"] = {"error": repr(e)}
         # ---- the same workload with the real network (random seeded weights: timing does not need a checkpoint; the estimates
         #      are not scored).  Fewer pairs: 18 ms of network per pair
         try:

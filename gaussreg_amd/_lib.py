@@ -66,7 +66,7 @@ SIGNATURES.update({
 
 SIGNATURES.update({
     "gr_sinkhorn_workspace_bytes": (c_size, [c_i64]),
-    "gr_sinkhorn": (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_void, c_void, c_int, c_f32, c_void, c_void, c_size,
+    "gr_sinkhorn": (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_void, c_void, c_int, c_f32, c_int, c_void, c_void, c_size,
                             c_void]),
     "gr_kpconv_workspace_bytes": (c_size, [c_i64, c_i64, c_i64, c_i64]),
     "gr_kpconv_forward": (c_int, [c_void] * 4 + [c_i64] * 5 + [c_void, c_i64, c_void, c_void, c_f32, c_f32, c_void,
@@ -86,6 +86,7 @@ SIGNATURES.update({
                            c_i64p, c_void, c_size, c_void]),
     "gr_pairwise_distance_workspace_bytes": (c_size, [c_i64, c_i64]),
     "gr_pairwise_distance": (c_int, [c_void, c_void, c_i64, c_i64, c_i64, c_int, c_void, c_void, c_size, c_void]),
+    "gr_standin_descriptors": (c_int, [c_void, c_i64, c_void, c_void, c_void, c_void, c_void, c_i64, c_f32, c_int, c_void, c_void]),
     "gr_pairwise_distance_batch_workspace_bytes": (c_size, [c_i64, c_i64, c_i64]),
     "gr_pairwise_distance_batch": (c_int, [c_void, c_void, c_i64, c_i64, c_i64, c_i64, c_int, c_void, c_void, c_size, c_void]),
     "gr_superpoint_matching_workspace_bytes": (c_size, [c_i64, c_i64]),

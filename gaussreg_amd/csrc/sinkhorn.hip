@@ -90,7 +90,7 @@ __device__ __forceinline__ void sinkhorn_matrix(const int b, const float* __rest
                                                 const uint8_t* __restrict__ row_masks,
                                                 const uint8_t* __restrict__ col_masks,
                                                 const float* __restrict__ alpha_p, int iters, float inf,
-                                                float* __restrict__ out, int scaling_form) {
+                                                float* __restrict__ out, int scaling_form, int drop) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int R = M + 1, C = N + 1;
   const int ld = sinkhorn_ld(C);
@@ -359,10 +359,11 @@ __device__ __forceinline__ void sinkhorn_matrix(const int b, const float* __rest
     }
     __syncthreads();
   }
-  // scores + u + v - norm (:18, :65)
-  for (int e = threadIdx.x; e < R * C; e += SK_T) {
-    const int i = e / C, j = e % C;
-    out[(int64_t)b * R * C + e] = ((S[i * ld + j] + u[i]) + v[j]) - norm;
+  // scores + u + v - norm (:18, :65); drop: without the dustbin row and column (what model.py:197-198 slices off)
+  const int OR = drop ? M : R, OC = drop ? N : C;
+  for (int e = threadIdx.x; e < OR * OC; e += SK_T) {
+    const int i = e / OC, j = e % OC;
+    out[(int64_t)b * OR * OC + e] = ((S[i * ld + j] + u[i]) + v[j]) - norm;
   }
 }
 
@@ -375,11 +376,11 @@ __global__ __launch_bounds__(SK_T) void sinkhorn_kernel(const float* __restrict_
                                                         const uint8_t* __restrict__ col_masks,
                                                         const float* __restrict__ alpha_p, int iters, float inf,
                                                         float* __restrict__ out, int scaling_form,
-                                                        const int32_t* __restrict__ worklist, int batch) {
+                                                        const int32_t* __restrict__ worklist, int batch, int drop) {
   const int n_items = worklist ? worklist[0] : batch;
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
     sinkhorn_matrix(worklist ? worklist[1 + item] : item, scores, M, N, row_masks, col_masks, alpha_p, iters, inf, out,
-                    scaling_form);
+                    scaling_form, drop);
     __syncthreads();  // the next matrix reuses the LDS image
   }
 }
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(WAVE) void sinkhorn_small_kernel(const float* __res
                                                               const uint8_t* __restrict__ row_masks,
                                                               const uint8_t* __restrict__ col_masks,
                                                               const float* __restrict__ alpha_p, int iters, float inf,
-                                                              float* __restrict__ out, int32_t* __restrict__ worklist) {
+                                                              float* __restrict__ out, int32_t* __restrict__ worklist, int drop) {
   __shared__ float S[WAVE * SS_LD];
   __shared__ __attribute__((aligned(16))) float Ev[WAVE];
   __shared__ __attribute__((aligned(16))) float Fu[WAVE];
@@ -536,14 +537,15 @@ __global__ __launch_bounds__(WAVE) void sinkhorn_small_kernel(const float* __res
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   // scores + u + v - norm (:18, :65) for the whole padded matrix
-  float* o = out + (int64_t)b * R * C;
-  for (int i = 0; i < R; ++i) {
+  const int OR = drop ? M : R, OC = drop ? N : C;  // drop: without the dustbin row and column (model.py:197-198)
+  float* o = out + (int64_t)b * OR * OC;
+  for (int i = 0; i < OR; ++i) {
     const int ri = rinv[i];  // uniform
     const float ui = ri >= 0 ? uu[ri] : 0.f;
-    for (int j = lane; j < C; j += WAVE) {
+    for (int j = lane; j < OC; j += WAVE) {
       const int cj = cinv[j];
       const float sv = (ri >= 0 && cj >= 0) ? S[ri * SS_LD + cj] : -inf;
-      o[(int64_t)i * C + j] = ((sv + ui) + (cj >= 0 ? vv[cj] : 0.f)) - norm;
+      o[(int64_t)i * OC + j] = ((sv + ui) + (cj >= 0 ? vv[cj] : 0.f)) - norm;
     }
   }
 }
@@ -564,7 +566,7 @@ extern "C" size_t gr_sinkhorn_workspace_bytes(int64_t batch) {
 
 extern "C" int gr_sinkhorn(const float* scores, int64_t batch, int64_t m, int64_t n, const uint8_t* row_masks,
                            const uint8_t* col_masks, const float* alpha_dev, int num_iterations, float inf,
-                           float* out, void* workspace, size_t workspace_bytes, void* stream_) {
+                           int drop_dustbin, float* out, void* workspace, size_t workspace_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   GR_REQUIRE(batch >= 0 && m >= 1 && n >= 1 && num_iterations >= 0, "bad sizes");
   if (batch == 0) return GR_OK;
@@ -594,14 +596,14 @@ extern "C" int gr_sinkhorn(const float* scores, int64_t batch, int64_t m, int64_
     int32_t* worklist = reinterpret_cast<int32_t*>(workspace);
     GR_HIP(hipMemsetAsync(worklist, 0, sizeof(int32_t), stream));
     hipLaunchKernelGGL(sinkhorn_small_kernel, dim3((unsigned)batch), dim3(WAVE), 0, stream, scores, (int)m, (int)n, row_masks,
-                       col_masks, alpha_dev, num_iterations, inf, out, worklist);
+                       col_masks, alpha_dev, num_iterations, inf, out, worklist, drop_dustbin ? 1 : 0);
     hipLaunchKernelGGL(sinkhorn_kernel, dim3((unsigned)std::min<int64_t>(batch, 512)), dim3(SK_T), lds, stream, scores, (int)m,
-                       (int)n, row_masks, col_masks, alpha_dev, num_iterations, inf, out, scaling_form, worklist, (int)batch);
+                       (int)n, row_masks, col_masks, alpha_dev, num_iterations, inf, out, scaling_form, worklist, (int)batch, drop_dustbin ? 1 : 0);
     GR_LAUNCH_CHECK();
     return GR_OK;
   }
   hipLaunchKernelGGL(sinkhorn_kernel, dim3((unsigned)batch), dim3(SK_T), lds, stream, scores, (int)m, (int)n, row_masks,
-                     col_masks, alpha_dev, num_iterations, inf, out, scaling_form, (const int32_t*)nullptr, (int)batch);
+                     col_masks, alpha_dev, num_iterations, inf, out, scaling_form, (const int32_t*)nullptr, (int)batch, drop_dustbin ? 1 : 0);
   GR_LAUNCH_CHECK();
   return GR_OK;
 }

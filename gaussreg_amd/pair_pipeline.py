@@ -81,17 +81,33 @@ def synthetic_room_pair(seed, n_per_cloud, device):
 
 
 class PositionDescriptor:
-    """Random Fourier features of a 3-D position: cos(W x + b) / sqrt(C).  `bandwidth` (metres) sets how fast the
-    descriptor decorrelates with distance."""
+    """Random Fourier features of a 3-D position: cos(W x + b) * sqrt(2 / C).  `bandwidth` (metres) sets how fast the
+    descriptor decorrelates with distance.  ONE HIP launch (csrc/standin.hip, harness support -- not a reference operator):
+    optional per-row transform (the pair's ground-truth pose), row mask and L2 normalisation included."""
 
     def __init__(self, channels, bandwidth, device, seed):
         g = torch.Generator(device=device).manual_seed(seed)
-        self.W = torch.randn((3, channels), generator=g, device=device) / bandwidth
-        self.b = torch.rand((channels,), generator=g, device=device) * (2 * math.pi)
+        self.W = (torch.randn((3, channels), generator=g, device=device) / bandwidth).contiguous()
+        self.b = (torch.rand((channels,), generator=g, device=device) * (2 * math.pi)).contiguous()
         self.scale = math.sqrt(2.0 / channels)
 
-    def __call__(self, x):
-        return torch.cos(x @ self.W + self.b) * self.scale
+    def __call__(self, x, transforms=None, transform_id=None, mask=None, normalize=False):
+        """x (..., 3) -> (..., C).  transforms (k, 3, 4) / transform_id (...,) int32 (-1: identity): the row's pose;
+        mask (...,) bool: rows to zero."""
+        from . import _lib
+        L = _lib.lib()
+        lead = x.shape[:-1]
+        p = x.reshape(-1, 3).to(torch.float32).contiguous()
+        n, C = p.shape[0], self.W.shape[1]
+        out = torch.empty((n, C), dtype=torch.float32, device=p.device)
+        T = None if transforms is None else transforms.reshape(-1, 12).to(torch.float32).contiguous()
+        tid = None if transform_id is None else transform_id.reshape(-1).to(torch.int32).contiguous()
+        m = None if mask is None else mask.reshape(-1).to(torch.bool).contiguous()
+        with torch.cuda.device(p.device):
+            _lib.check(L.gr_standin_descriptors(_lib.ptr(p), n, _lib.ptr(T), _lib.ptr(tid), _lib.ptr(m), _lib.ptr(self.W),
+                                                _lib.ptr(self.b), C, float(self.scale), int(bool(normalize)), _lib.ptr(out),
+                                                _lib.stream_ptr(p.device)))
+        return out.reshape(*lead, C)
 
 
 def rotation_error_deg(Ra, Rb):
@@ -218,8 +234,7 @@ class PairRegistrar:
                 if all(k == n for k, n in zip(ks, lens)):
                     sampled += chunk
                     continue
-                idx = farthest_point_sampling(torch.cat(chunk, 0), lens, ks)
-                sampled += [c[ix] for c, ix in zip(chunk, idx)]
+                sampled += farthest_point_sampling(torch.cat(chunk, 0), lens, ks, gather=True)
         return sampled
 
     def _register_sampled(self, pairs, sampled):
@@ -255,15 +270,13 @@ class PairRegistrar:
                     fl = self.net.backbone(feats_in, dd)
                 feats_c, feats_f = fl[-1], fl[0]                           # (sum Nc, 2048-d in), (sum Nf, 256)
         else:
-            with self._sec("coarse_features"):
+            with self._sec("standin_descriptors"):
                 # stand-in for the learned features (see module docstring): descriptors in the reference frame, for all the
                 # superpoints of the batch at once (the per-pair stage is bound by host-side launch overhead)
                 n_c = torch.tensor(len_c, device=dev)
-                cloud = torch.repeat_interleave(torch.arange(2 * B, device=dev), n_c)       # superpoint -> cloud
-                pid, is_src = cloud // 2, (cloud % 2 == 1)
-                moved = torch.einsum('nij,nj->ni', T_all[pid, :3, :3], pts_c) + T_all[pid, :3, 3]
-                frame_c = torch.where(is_src[:, None], moved, pts_c)
-                feats_c = torch.nn.functional.normalize(self.coarse_desc(frame_c), p=2, dim=1)
+                cloud = torch.repeat_interleave(torch.arange(2 * B, device=dev, dtype=torch.int32), n_c)   # superpoint -> cloud
+                tid = torch.where(cloud % 2 == 1, cloud // 2, torch.full_like(cloud, -1))    # src clouds move into the ref frame
+                feats_c = self.coarse_desc(pts_c, T_all[:, :3, :], tid, normalize=True)
         ctx = (pairs, B, pts_c, pts_f, off_c, off_f, out, feats_c)
         batched = self.pair_streams == 0
         if batched:
@@ -322,6 +335,7 @@ class PairRegistrar:
             pts_pad = torch.cat([pts_f, pad], 0)                                           # model.py:171-172: pad row = index N
             Kt = torch.tensor(K, device=dev)
             pid = torch.repeat_interleave(torch.arange(B, device=dev), Kt)                 # patch -> pair
+            pid32 = pid.to(torch.int32)
             n_ref = torch.tensor([off_f[2 * b + 1] - off_f[2 * b] for b in range(B)], device=dev)[pid][:, None]
             n_src = torch.tensor([off_f[2 * b + 2] - off_f[2 * b + 1] for b in range(B)], device=dev)[pid][:, None]
             o_ref = torch.tensor([off_f[2 * b] for b in range(B)], device=dev)[pid][:, None]
@@ -335,20 +349,21 @@ class PairRegistrar:
         matching = torch.empty((k_off[-1], POINT_LIMIT, POINT_LIMIT), dtype=torch.float32, device=dev)
         for a in range(0, k_off[-1], PATCH_CHUNK):
             e = min(k_off[-1], a + PATCH_CHUNK)
-            with self._sec("patch_features"):
-                if feats_f is not None:                                                    # model.py:186-190
+            if feats_f is not None:                                                        # model.py:186-190
+                with self._sec("patch_scores"):
                     rkf, skf = feats_pad[rki[a:e]], feats_pad[ski[a:e]]
                     scores = torch.einsum('bnd,bmd->bnm', rkf, skf) / (rkf.shape[-1] ** 0.5)
-                else:
-                    # synthetic descriptors: position features in the reference frame, a x16 temperature instead of the
-                    # network's 1 / sqrt(C) (descriptor stand-in only -- see the module docstring)
-                    R, t = T_all[pid[a:e], :3, :3], T_all[pid[a:e], :3, 3]
-                    rkf = self.fine_desc(rkp[a:e]) * rkm[a:e, :, None]
-                    skf = self.fine_desc(torch.einsum('kij,knj->kni', R, skp[a:e]) + t[:, None, :]) * skm[a:e, :, None]
-                    scores = torch.einsum('bnd,bmd->bnm', rkf, skf) * (rkf.shape[-1] ** 0.5)
-                del rkf, skf
+            else:
+                # synthetic descriptors: position features in the reference frame (one HIP launch per side), a x16 temperature
+                # instead of the network's 1 / sqrt(C) (descriptor stand-in only -- see the module docstring)
+                with self._sec("standin_descriptors"):
+                    rkf = self.fine_desc(rkp[a:e], mask=rkm[a:e])
+                    skf = self.fine_desc(skp[a:e], T_all[:, :3, :], pid32[a:e, None].expand(-1, POINT_LIMIT), mask=skm[a:e])
+                with self._sec("patch_scores"):                                            # the contraction of model.py:186-190
+                    scores = torch.bmm(rkf, skf.transpose(1, 2)) * (rkf.shape[-1] ** 0.5)
+            del rkf, skf
             with self._sec("sinkhorn"):
-                matching[a:e] = self.ot(scores, rkm[a:e], skm[a:e])[:, :-1, :-1]           # model.py:191-198 (dustbins dropped)
+                self.ot(scores, rkm[a:e], skm[a:e], drop_dustbin=True, out=matching[a:e])   # model.py:191-198 (dustbins dropped)
                 del scores
         if batched:
             # ---- stage 3, all pairs at once: correspondences + LocalGlobalRegistration (one read-back: the number of

@@ -63,10 +63,12 @@ def registration_with_ransac_batch(src_points, ref_points, row_offsets, fallback
 
 
 @torch.no_grad()
-def farthest_point_sampling(points, lengths, num_samples, start_indices=None):
+def farthest_point_sampling(points, lengths, num_samples, start_indices=None, gather=False):
     """Exact FPS in stack mode (stand-in for fpsample.bucket_fps_kdline_sampling, demo.py:46; parity unpinned).
     points (N,3); lengths / num_samples: per-cloud sizes (lists or 1-D tensors).  Returns a list of int64
-    CUDA tensors with LOCAL indices, one per cloud, in sampling order (first = start index, default 0)."""
+    CUDA tensors with LOCAL indices, one per cloud, in sampling order (first = start index, default 0).
+    `gather=True`: returns the sampled POINTS instead, a list of (k_b, 3) views of one stacked tensor (one row gather for
+    the whole call instead of one indexing launch per cloud)."""
     dev = _lib.require_gpu()
     L = _lib.lib()
     p = torch.as_tensor(points, dtype=torch.float32)
@@ -80,4 +82,9 @@ def farthest_point_sampling(points, lengths, num_samples, start_indices=None):
         ws = _lib.workspace(dev, L.gr_fps_workspace_bytes(p.shape[0], len(lens)))
         _lib.check(L.gr_fps(_lib.ptr(p), _lib.host_i64(lens), _lib.host_i64(ks), st, p.shape[0], len(lens), _lib.ptr(out),
                             _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)))
+    if gather:
+        from .ops import index_select
+        base = torch.tensor([0] + lens[:-1], dtype=torch.int64).cumsum(0).to(dev)        # first row of every cloud in the stack
+        glob = out + torch.repeat_interleave(base, torch.tensor(ks, device=dev))
+        return list(torch.split(index_select(p, glob, 0), ks))
     return list(torch.split(out, ks))

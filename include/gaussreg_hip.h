@@ -227,12 +227,13 @@ int gr_raster_mark_visible(int64_t P, const float* means3D, const float* h_viewm
  */
 /* gr_sinkhorn ("next" row): geotransformer/modules/sinkhorn/learnable_sinkhorn.py:20-66
  * LearnableLogOptimalTransport.forward: scores (batch,m,n), masks uint8 (null = all valid), alpha read
- * from DEVICE memory (the module's learnable parameter), out (batch, m+1, n+1).  `workspace`: device
+ * from DEVICE memory (the module's learnable parameter), out (batch, m+1, n+1) -- or, with drop_dustbin != 0,
+ * (batch, m, n): the matrix without its dustbin row and column, which is all GaussReg keeps (model.py:197-198).  `workspace`: device
  * scratch of gr_sinkhorn_workspace_bytes(batch) (the work list of matrices too large for the one-wave kernel). */
 size_t gr_sinkhorn_workspace_bytes(int64_t batch);
 int gr_sinkhorn(const float* scores, int64_t batch, int64_t m, int64_t n, const uint8_t* row_masks,
-                const uint8_t* col_masks, const float* alpha_dev, int num_iterations, float inf, float* out,
-                void* workspace, size_t workspace_bytes, void* stream);
+                const uint8_t* col_masks, const float* alpha_dev, int num_iterations, float inf, int drop_dustbin,
+                float* out, void* workspace, size_t workspace_bytes, void* stream);
 /* gr_kpconv_forward ("next" row): geotransformer/modules/kpconv/kpconv.py:79-122 KPConv.forward
  * (rigid kernel points): s_feats (n,cin), q_points (m,3), s_points (n,3), neighbor_indices (m,h) int64 padded
  * with n, kernel_points (k,3), weights (k,cin,cout), bias (cout) or null -> out (m,cout).
@@ -424,6 +425,15 @@ int gr_point_to_node_partition_batch(const float* points, const int64_t* h_point
                                      const int64_t* h_node_off, int64_t nclouds, int point_limit,
                                      int64_t* point_to_node, uint8_t* node_masks, int64_t* node_knn_indices,
                                      uint8_t* node_knn_masks, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Harness support, NOT a reference interface: stand-in position descriptors of the configs[4] pair pipeline
+ * (gaussreg_amd/pair_pipeline.py; the learned features are not available offline).  out (n, c) =
+ * mask * scale * cos((T[transform_id] p) W + b), rows optionally L2-normalised; transforms (k, 3, 4) row-major or NULL,
+ * transform_id (n) int32 (-1 = identity) or NULL, mask (n) uint8 or NULL, w (3, c), b (c). */
+int gr_standin_descriptors(const float* pts, int64_t n, const float* transforms, const int32_t* transform_id,
+                           const uint8_t* mask, const float* w, const float* b, int64_t c, float scale, int normalize,
+                           float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -48,8 +48,9 @@ def test_stage_profile_covers_the_pipeline(pairs):
     from gaussreg_amd import pair_pipeline
     reg = pair_pipeline.PairRegistrar(torch.device("cuda", 0), profile=True)
     reg.register_pairs(pairs[:2])
-    assert set(reg.section_ms) == {"fps", "pyramid", "point_to_node", "coarse_features", "superpoint_matching",
-                                   "patch_features", "sinkhorn", "local_global_registration", "ransac", "metrics"}
+    assert set(reg.section_ms) == {"fps", "pyramid", "point_to_node", "standin_descriptors", "superpoint_matching",
+                                   "patch_features", "patch_scores", "sinkhorn", "local_global_registration", "ransac",
+                                   "metrics"}
     assert all(v > 0 for v in reg.section_ms.values())
 
 
