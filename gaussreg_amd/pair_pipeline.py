@@ -80,6 +80,20 @@ def synthetic_room_pair(seed, n_per_cloud, device):
     return ref.float().contiguous(), src.float().contiguous(), T
 
 
+def spatial_sort(points, lengths, voxel):
+    """Rows of a stack-mode cloud list sorted by (cloud, voxel z, y, x) at edge `voxel` (stable inside a voxel): the order
+    grid_subsample(order="cell") gives the coarser levels, applied to the input level.  Clouds stay contiguous."""
+    dev = points.device
+    n = points.shape[0]
+    cloud = torch.repeat_interleave(torch.arange(lengths.numel(), device=dev), lengths.to(dev))
+    lo = points.amin(0)
+    q = torch.floor((points - lo) / voxel).to(torch.int64)
+    dim = q.amax(0) + 1
+    key = ((cloud * dim[2] + q[:, 2]) * dim[1] + q[:, 1]) * dim[0] + q[:, 0]
+    perm = torch.sort(key, stable=True).indices
+    return points[perm].contiguous()
+
+
 class PositionDescriptor:
     """Random Fourier features of a 3-D position: cos(W x + b) * sqrt(2 / C).  `bandwidth` (metres) sets how fast the
     descriptor decorrelates with distance.  ONE HIP launch (csrc/standin.hip, harness support -- not a reference operator):
@@ -135,7 +149,7 @@ class _Section:
 class PairRegistrar:
     """Holds the stateless operator modules and the descriptors; `register_pairs` runs a batch."""
 
-    def __init__(self, device, num_samples=30000, fps_clouds_per_call=None, order="reference", use_ransac=True,
+    def __init__(self, device, num_samples=30000, fps_clouds_per_call=None, order=None, use_ransac=True,
                  profile=False, pair_streams=0, features="descriptor", transformer_batch=16):
         """`pair_streams` = 0 (default): the per-pair stages (point_to_node_partition, SuperPointMatching, correspondences +
         LocalGlobalRegistration, RANSAC) run for all pairs of a batch through the stack-mode entry points
@@ -152,6 +166,18 @@ class PairRegistrar:
         every stage, pairs one after the other: the total is slower than an unprofiled run)."""
         if features not in ("descriptor", "model"):
             raise ValueError("features must be 'descriptor' or 'model'")
+        # Row order of the pyramid INSIDE the pipeline (nothing of it crosses an API boundary: a pair goes in, a transform comes
+        # out).  "reference" (default) = the reference's unordered_map iteration order at every level (what geotransformer.ext
+        # returns); "cell" = rows sorted by voxel key, and the sampled input points sorted the same way, so that neighbouring
+        # rows are neighbours in space.  Measured with the network (round 4, 64 pairs, tools/pairs_net_time.py): 110.6 vs 110.9
+        # pairs/s, backbone 6.03 vs 5.96 ms per pair -- the KPConv gathers are 5 % of the network's kernel time
+        # (profiles/r04_pairs_network_kernel_stats.csv), its GEMMs and attention kernels do not care about row order: not
+        # worth a different default.  Same estimates either way up to fp32 summation order
+        # (tests/test_gpu_model_e2e.py::test_cell_order_network_equals_reference_order).
+        if order is None:
+            order = "reference"
+        if order not in ("reference", "cell"):
+            raise ValueError("order must be 'reference' or 'cell'")
         self.features = features
         self.net = None
         if features == "model":
@@ -244,6 +270,8 @@ class PairRegistrar:
         with self._sec("pyramid"):
             points = torch.cat(sampled, 0).contiguous()
             lengths = torch.tensor([c.shape[0] for c in sampled], dtype=torch.int64)
+            if self.order == "cell":
+                points = spatial_sort(points, lengths, 2 * INIT_VOXEL)
             pyr = precompute_data_stack_mode(points, lengths, NUM_STAGES, INIT_VOXEL, INIT_RADIUS, NEIGHBOR_LIMITS,
                                              order=self.order)
             len_c, len_f = pyr["lengths"][-1].tolist(), pyr["lengths"][1].tolist()

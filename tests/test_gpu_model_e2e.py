@@ -120,3 +120,53 @@ def test_training_mode_is_refused():
     net = GeoTransformer(cfg)
     with pytest.raises(RuntimeError, match="inference branch only"):
         net.train()({"features": None})
+
+
+def test_cell_order_network_equals_reference_order():
+    """PairRegistrar(order="cell") builds its pyramid in CELL order (rows sorted by voxel key, the input level sorted the same
+    way: neighbouring rows are neighbours in space); at the API boundary the order is always the reference's.  Same weights,
+    same pair, both orders: the features of every point must agree to 2e-5 of their scale once the rows are matched up by
+    coordinates (the input's order decides the summation order of the barycentres and of every neighbourhood sum), the
+    superpoint correspondences must be the same pairs of points, and the estimated transform the same."""
+    from gaussreg_amd.kpconv import KPConv
+    from gaussreg_amd.model import GeoTransformer, make_cfg
+    from gaussreg_amd.pair_pipeline import spatial_sort
+    from geotransformer.utils.data import precompute_data_stack_mode
+    n_per = 6000
+    ref, src = room_pair(n_per, 11)
+    points = torch.from_numpy(np.concatenate([ref, src]).astype(np.float32)).cuda()
+    lengths = torch.tensor([n_per, n_per])
+    torch.manual_seed(5)
+    net = GeoTransformer(make_cfg())
+    for m in net.modules():
+        if isinstance(m, KPConv):
+            m.kernel_points.copy_(torch.from_numpy((demo_inputs.K015 * m.radius).astype(np.float32)))
+    net = net.cuda().eval()
+
+    def forward(order):
+        p = points if order == "reference" else spatial_sort(points, lengths, 0.05)
+        d = precompute_data_stack_mode(p, lengths, 5, 0.025, 0.0625, LIMITS, order=order)
+        d["features"] = torch.ones((p.shape[0], 1), device="cuda")
+        return net(d)
+
+    a, b = forward("reference"), forward("cell")
+
+    def key(t):   # rows -> canonical order by coordinates rounded to 10 um (sorting the input level changes the summation order
+        x = np.round(t.cpu().numpy().astype(np.float64) * 1e5).astype(np.int64)   # of the barycentres: last-bit differences)
+        return np.lexsort((x[:, 2], x[:, 1], x[:, 0]))
+    for side in ("ref", "src"):
+        for lvl in ("c", "f"):
+            pa, pb = a[f"{side}_points_{lvl}"], b[f"{side}_points_{lvl}"]
+            ka, kb = key(pa), key(pb)
+            assert pa.shape == pb.shape and np.abs(pa.cpu().numpy()[ka] - pb.cpu().numpy()[kb]).max() <= 2e-6, (side, lvl)
+            fa, fb = a[f"{side}_feats_{lvl}"].cpu().numpy()[ka], b[f"{side}_feats_{lvl}"].cpu().numpy()[kb]
+            scale = np.abs(fa).max()
+            assert np.abs(fa - fb).max() <= 2e-5 * scale, (side, lvl, np.abs(fa - fb).max(), scale)
+
+    def corr_points(o):   # superpoint correspondences as coordinate pairs (the indices differ between the orders)
+        r = o["ref_points_c"][o["ref_node_corr_indices"]].cpu().numpy()
+        s = o["src_points_c"][o["src_node_corr_indices"]].cpu().numpy()
+        return set(map(tuple, np.round(np.concatenate([r, s], 1) * 1e5).astype(np.int64).tolist()))
+    ca, cb = corr_points(a), corr_points(b)
+    assert len(ca & cb) >= 250, len(ca & cb)
+    assert np.abs(a["lgr_transform"].cpu().numpy() - b["lgr_transform"].cpu().numpy()).max() <= 5e-3

@@ -64,6 +64,16 @@ def run(dev):
             sp, _ = ext.grid_subsampling(dp, lens, 0.05, order=order)
             ms = _ms(lambda: ext.grid_subsampling(dp, lens, 0.05, order=order))
             out[f"grid_subsample_200k_{order}_order"] = _hbm(ms, 12 * dp.shape[0] + 12 * sp.shape[0], Mpts_per_s=round(0.2 / ms * 1e3, 1))
+        # ---- the same, 64 clouds of 200 k points per call (launch overheads amortised: what is left is the sort + the cell passes)
+        pts64, lens64 = synthetic.cloud_200k(64, seed=1)
+        dp64 = pts64.to(dev)
+        for order in ("reference", "cell"):
+            sp, _ = ext.grid_subsampling(dp64, lens64, 0.05, order=order)
+            ms = _ms(lambda: ext.grid_subsampling(dp64, lens64, 0.05, order=order), 5, 1)
+            out[f"grid_subsample_64x200k_{order}_order"] = _hbm(ms, 12 * dp64.shape[0] + 12 * sp.shape[0], Mpts_per_s=round(12.8 / ms * 1e3, 1),
+                                                                note="algorithmic bytes 12 N + 12 M; the implementation is a stable radix sort of (cloud, voxel key, index) "
+                                                                     "+ run passes: ~12 x the algorithmic traffic by construction")
+        del pts64, dp64, sp
         # ---- the data pyramid, 64 pairs of 2 x 30 000 points per call
         Bp = 64
         clouds = []
@@ -146,23 +156,32 @@ def run(dev):
         kms = kernel_ms("pairwise_distance", lambda: ops.pairwise_distance(x8, y8))
         out["pairwise_distance_8192x8192x256"]["distance_kernel"] = _mfma(kms, 2.0 * 8192 * 8192 * 256)
         del xb, yb, x8, y8, fb
-        # ---- KPConv: the backbone's 11 layers at their real widths on the demo pyramid
-        Pl, NB, SUB = d["points"], d["neighbors"], d["subsampling"]
+        # ---- KPConv: the backbone's 11 layers at their real widths on the demo pyramid, in the reference's row order (the API
+        #      boundary's order) and in cell order (rows sorted by voxel key + spatially sorted input: what the network path runs on)
         kp = torch.randn(15, 3) * 0.03
-        layers = [(0, 0, NB[0], 4, 64), (0, 0, NB[0], 32, 32), (1, 0, SUB[0], 32, 32), (1, 1, NB[1], 64, 64), (1, 1, NB[1], 64, 64),
-                  (2, 1, SUB[1], 64, 64), (2, 2, NB[2], 128, 128), (2, 2, NB[2], 128, 128), (3, 2, SUB[2], 128, 128),
-                  (3, 3, NB[3], 256, 256), (3, 3, NB[3], 256, 256)]
-        tot, flops, gbytes = 0.0, 0.0, 0.0
-        for ql, sl, nb, cin, cout in layers:
-            q, s = Pl[ql], Pl[sl]
-            conv = KPConv(cin, cout, 15, 0.0625 * 2 ** sl, 0.05 * 2 ** sl, kernel_points=kp * 2 ** sl).to(dev)
-            f = torch.relu(torch.randn(s.shape[0], cin, device=dev, generator=g))
-            tot += _ms(lambda: conv(f, q, s, nb), 5, 1)
-            Mq, Hn = q.shape[0], nb.shape[1]
-            flops += 2.0 * Mq * 15 * cin * cout + 2.0 * Mq * Hn * 15 * cin
-            gbytes += Mq * Hn * (8 + 4 * cin) + 4 * Mq * cout
-        out["kpconv_backbone_11_layers"] = {"ms": round(tot, 3), "flops": flops, "gather_bytes": int(gbytes), "bound": "hbm (gather)",
-                                            "TFLOP/s": round(flops / tot / 1e9, 2), "frac": round(gbytes / tot / 1e6 / HBM_GBS, 4)}
+        for order in ("reference", "cell"):
+            if order == "reference":
+                dd = d
+            else:
+                pp = d["points"][0]
+                dd = precompute_data_stack_mode(pair_pipeline.spatial_sort(pp, torch.tensor([30000, 30000]), 0.05), torch.tensor([30000, 30000]), 5,
+                                                0.025, 0.0625, [89, 30, 43, 49, 49], order="cell")
+            Pl, NB, SUB = dd["points"], dd["neighbors"], dd["subsampling"]
+            layers = [(0, 0, NB[0], 4, 64), (0, 0, NB[0], 32, 32), (1, 0, SUB[0], 32, 32), (1, 1, NB[1], 64, 64), (1, 1, NB[1], 64, 64),
+                      (2, 1, SUB[1], 64, 64), (2, 2, NB[2], 128, 128), (2, 2, NB[2], 128, 128), (3, 2, SUB[2], 128, 128),
+                      (3, 3, NB[3], 256, 256), (3, 3, NB[3], 256, 256)]
+            tot, flops, gbytes = 0.0, 0.0, 0.0
+            for ql, sl, nb, cin, cout in layers:
+                q, s = Pl[ql], Pl[sl]
+                conv = KPConv(cin, cout, 15, 0.0625 * 2 ** sl, 0.05 * 2 ** sl, kernel_points=kp * 2 ** sl).to(dev)
+                f = torch.relu(torch.randn(s.shape[0], cin, device=dev, generator=g))
+                tot += _ms(lambda: conv(f, q, s, nb), 5, 1)
+                Mq, Hn = q.shape[0], nb.shape[1]
+                flops += 2.0 * Mq * 15 * cin * cout + 2.0 * Mq * Hn * 15 * cin
+                gbytes += Mq * Hn * (8 + 4 * cin) + 4 * Mq * cout
+            name = "kpconv_backbone_11_layers" + ("" if order == "reference" else "_cell_order")
+            out[name] = {"ms": round(tot, 3), "flops": flops, "gather_bytes": int(gbytes), "bound": "hbm (gather)", "row_order": order,
+                         "TFLOP/s": round(flops / tot / 1e9, 2), "frac": round(gbytes / tot / 1e6 / HBM_GBS, 4)}
         # ---- log-Sinkhorn 256 x 128 x 128, 100 iterations (LDS resident: 2 passes over HBM)
         ot = LearnableLogOptimalTransport(100).to(dev)
         sc = R(P, K, K)
