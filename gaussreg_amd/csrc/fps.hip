@@ -18,10 +18,17 @@
 //   * the spin is bounded: a lane that waits > 2^22 polls raises an error flag and all leave (no GPU hang).
 #include <vector>
 
+#include <atomic>
+
 #include "common.hpp"
 
 namespace gr {
 namespace {
+// Test switch (gr_fps_debug_force_fallback): 0 = normal; 1 = the co-operative launch of attempt 0 counts as refused by the
+// runtime; 2 = attempt 0 runs and its result is discarded as if the inter-workgroup exchange had timed out.  Either way the
+// call must finish through the one-workgroup-per-cloud retry with the same indices.
+std::atomic<int> g_fps_force{0};
+
 
 constexpr int FPS_T = 1024;
 constexpr int FPS_GMAX = 64;
@@ -913,6 +920,11 @@ __global__ __launch_bounds__(256) void fps_gather_kernel(const float* __restrict
 }  // namespace
 }  // namespace gr
 
+namespace gr {
+int g_fps_force_get() { return g_fps_force.load(); }
+void g_fps_force_set(int m) { g_fps_force.store(m); }
+}  // namespace gr
+
 using namespace gr;
 
 extern "C" size_t gr_fps_workspace_bytes(int64_t n, int64_t batch) {
@@ -1043,7 +1055,8 @@ extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64
         args = single_args;
       }
       hipError_t le;
-      if (G > 1) le = hipLaunchCooperativeKernel(fn, grid, block, args, (unsigned)lds, stream);
+      if (G > 1 && attempt == 0 && g_fps_force.load() == 1) le = hipErrorCooperativeLaunchTooLarge;  // test switch: "refused"
+      else if (G > 1) le = hipLaunchCooperativeKernel(fn, grid, block, args, (unsigned)lds, stream);
       else le = hipLaunchKernel(fn, grid, block, args, lds, stream);
       if (le != hipSuccess) {
         (void)hipGetLastError();
@@ -1058,10 +1071,17 @@ extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64
     int h_err = 0;
     GR_HIP(hipMemcpyAsync(&h_err, err, sizeof(int), hipMemcpyDeviceToHost, stream));
     GR_HIP(hipStreamSynchronize(stream));  // also keeps the host staging vectors alive past the copies
+    if (G > 1 && attempt == 0 && g_fps_force.load() == 2) h_err = 1;  // test switch: treat the co-operative run as timed out
     if (h_err == 0) return GR_OK;
     if (getenv("GR_FPS_VERBOSE")) fprintf(stderr, "gr_fps: exchange timed out (G=%d, batch=%lld, per=%lld); retrying with one workgroup per cloud\n", G, (long long)batch, (long long)per);
     GR_REQUIRE(attempt == 0 && G > 1, "fps: exchange timed out with a single workgroup per cloud (internal error)");
   }
   set_error("fps: inter-workgroup exchange timed out and the single-workgroup retry was not possible");
   return GR_ERR_HIP;
+}
+
+extern "C" int gr_fps_debug_force_fallback(int mode) {
+  const int old = gr::g_fps_force_get();
+  if (mode >= 0 && mode <= 2) gr::g_fps_force_set(mode);
+  return old;
 }

@@ -31,6 +31,9 @@ def gather_rows(local: torch.Tensor, counts: Sequence[int] = None) -> torch.Tens
     rank, w = world()
     if w == 1:
         return local
+    if local.is_cuda and dist.get_backend() == "gloo":
+        # gloo has no all_gather on device tensors (the CPU tests and a one-GPU box with two processes): stage through the host
+        return gather_rows(local.cpu(), counts).to(local.device)
     n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     if counts is None:
         all_n = [torch.zeros_like(n_local) for _ in range(w)]

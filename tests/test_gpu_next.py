@@ -421,6 +421,26 @@ def test_fps_long_runs_with_large_candidate_sets(n, batch, k):
         assert np.array_equal(got[b].cpu().numpy(), M.farthest_point_sampling(clouds[b].cpu().numpy(), k, 5 * b)), f"cloud {b}"
 
 
+@pytest.mark.parametrize("mode", [1, 2], ids=["launch-refused", "exchange-timed-out"])
+def test_fps_single_workgroup_retry_gives_the_same_indices(mode):
+    """gr_fps runs G co-operating workgroups per cloud (co-operative launch, bounded spins on the exchange slots); when the
+    runtime refuses the grid or the exchange times out -- another job holds CUs -- the call retries with one workgroup per
+    cloud.  The test switch forces each of the two ways into the retry: same indices as the co-operative run."""
+    from gaussreg_amd import _lib
+    from gaussreg_amd.registration import farthest_point_sampling
+    rng = np.random.default_rng(50 + mode)
+    lens = [60000, 45000, 20000]
+    pts = _c((rng.random((sum(lens), 3)) * [5, 4, 3]).astype(np.float32))
+    want = farthest_point_sampling(pts, lens, [900, 700, 500], start_indices=[3, 2, 1])
+    old = _lib.lib().gr_fps_debug_force_fallback(mode)
+    try:
+        got = farthest_point_sampling(pts, lens, [900, 700, 500], start_indices=[3, 2, 1])
+    finally:
+        _lib.lib().gr_fps_debug_force_fallback(old)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+
+
 def test_fps_production_shape_to_the_end():
     """demo.py:46 at its real size: 200 000 -> 30 000 samples (338 rounds; in the late rounds every candidate lies within
     another's reach), for clouds of a 25-cloud call -- the shape tools/fps_loop.py and the pair path use -- compared over
