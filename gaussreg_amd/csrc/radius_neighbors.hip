@@ -123,7 +123,7 @@ RadiusWs carve(void* ws, int64_t nq, int64_t ns, int64_t batch) {
   w.sorted_q = c.take<float4>(nq);
   w.q_count = c.take<int32_t>(3 * nq);
   w.q_rng = c.take<int2>(9 * nq);
-  w.q_mask = c.take<unsigned long long>(3 * nq);
+  w.q_mask = c.take<unsigned long long>(6 * nq);  // q2_kernel: 16 bytes per (query, slab); traverse_kernel: 8
   w.blk_stats = c.take<int32_t>(2 * ((nq + 63) / 64 + 8));  // the single-pass kernels run 64 queries per workgroup
   w.bytes = c.used();
   return w;
@@ -1524,42 +1524,70 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
 #undef GR_FUSED_STOP
 }
 
-// ---------------------------------------------------------------- round 4: tests by three threads per query, everything
-// after the tests by HALF A WAVE per query
-// The kernels above spend most of their time after the tests: the hit masks of the (query, slab) threads are decoded by the
-// threads that own them (trip counts diverge: a wave waits for its longest list), keys are re-derived in a third mapping,
-// hits are ranked one thread per hit with three dependent LDS round trips in front of every segment scan, and rows leave
-// through a row buffer -- five phases, each behind a workgroup barrier, at 15 waves per CU.  Here every query is finished
-// by ONE half-wave with no barrier in between:
-//   lane l of the half-wave = hit ordinal l of the query (32 per round; a second round only for queries with more than 32
-//   hits).  The lane finds "its" hit as the k-th set bit of the three slab masks (branch-free binary search on popcounts:
-//   no loop whose trip count depends on the data), reads the candidate from the staged planes, recomputes the distance
-//   (same arithmetic, same bits), drops the distance word into the half-wave's 512-byte key scratch and counts the smaller
-//   words of the segment -- every lane of the half-wave reads the SAME addresses (LDS broadcast, no bank conflicts, no
-//   dependent address chain) -- and stores its index straight at out[row][rank]; lanes past the hit count write the
-//   padding of their column, so one store instruction per half-wave covers 32 columns of one 360-byte row.  Equal
-//   distance words are detected by the sum of the ranks (sum != n (n - 1) / 2) and only such rows are ranked again on
-//   (distance, index).
-// Modes: COUNT (tests -> masks to global memory, per-block maximum), FILL (masks from global memory -> rows), FUSED (both
-// in one launch, for a width known before the launch).  A workgroup that cannot use the masks (more than 64 enumeration
-// slots in a thread, candidates that do not fit the staging planes, a query with more than Q2_KCAP hits) raises a flag and
-// the caller repeats the call on the kernels above.
-constexpr int Q2_KCAP = 128;  // hits of one query the key scratch of a half-wave holds
+// ---------------------------------------------------------------- round 4: q2_kernel -- hits are SORTED, not ranked
+// The kernels above spend two thirds of their time after the tests: hit masks are decoded, keys re-derived in a third mapping,
+// and every hit is ranked by counting the smaller keys of its query -- two VALU instructions per (hit, key) pair, 43 issue slots
+// per query out of 129 (SQ counters per phase, tools/radius_phase_counters.sh; a wave64 VALU instruction occupies its SIMD for
+// four cycles: 1.6 M queries x 1 slot = 2.6 us of the whole chip).  Here:
+//   tests      as before: three threads per query (one per z-slab), candidates staged in LDS planes, four per step, hits as
+//              sign bits shifted into 32-bit registers -- two register pairs per thread now (bands 0 + 1, band 2): 128
+//              enumeration slots instead of 64
+//   decode     the threads that own the masks write (distance bits << 32 | support index) words into their query's list
+//   sort       ONE THREAD PER QUERY (the workgroup's first wave): the list goes into 32 register pairs and through Batcher's
+//              odd-even merge sort network (191 compare-exchanges): every lane a different query -- no divergence, no LDS
+//              traffic, 6 instructions per comparator = 18 slots per query.  The order of the words IS the reference's order
+//              (distance, then index): equal distances need no second pass.
+//   rows       the sorted indices go back to LDS as rows and leave as contiguous runs
+//   the rest   queries with more than 32 hits (1 % at 21 expected neighbours) are finished by HALF A WAVE each on the waves
+//              that do not sort: lane = hit, k-th set bit of the masks by a branch-free binary search on popcounts, rank by
+//              counting over the half-wave's key scratch (every lane reads the same addresses: LDS broadcast).  A workgroup
+//              whose candidates do not fit the planes, or with a thread of more than 128 enumeration slots, takes the same
+//              half-wave path for all its queries with the candidates read from global memory (slow, rare, in place).
+// Modes: COUNT (tests -> masks to global memory, per-block maximum), FILL (masks from global memory -> rows), FUSED (both in
+// one launch, for a width known before the launch).  Only a query with more than Q2_KCAP hits makes the caller repeat the call
+// on the kernels above (flag in blk_stats).
+constexpr int Q2_RQ = 64;      // queries per workgroup (three threads each)
+constexpr int Q2_KCAP = 128;   // hits of one query the key scratch of a half-wave holds
 constexpr int Q2_KR = Q2_KCAP / 32;
+constexpr int Q2_NET = 32;     // hits of one query the sorting network takes
+constexpr int Q2_NET_CE = 191;
+constexpr int Q2_WMAX = 64;    // widest row staged in LDS
 constexpr int Q2_COUNT = 0, Q2_FILL = 1, Q2_FUSED = 2;
+static constexpr unsigned char Q2_NET_PAIRS[Q2_NET_CE][2] = {
+    {0, 1}, {2, 3}, {0, 2}, {1, 3}, {1, 2}, {4, 5}, {6, 7}, {4, 6}, {5, 7}, {5, 6}, {0, 4}, {2, 6},
+    {2, 4}, {1, 5}, {3, 7}, {3, 5}, {1, 2}, {3, 4}, {5, 6}, {8, 9}, {10, 11}, {8, 10}, {9, 11}, {9, 10},
+    {12, 13}, {14, 15}, {12, 14}, {13, 15}, {13, 14}, {8, 12}, {10, 14}, {10, 12}, {9, 13}, {11, 15}, {11, 13}, {9, 10},
+    {11, 12}, {13, 14}, {0, 8}, {4, 12}, {4, 8}, {2, 10}, {6, 14}, {6, 10}, {2, 4}, {6, 8}, {10, 12}, {1, 9},
+    {5, 13}, {5, 9}, {3, 11}, {7, 15}, {7, 11}, {3, 5}, {7, 9}, {11, 13}, {1, 2}, {3, 4}, {5, 6}, {7, 8},
+    {9, 10}, {11, 12}, {13, 14}, {16, 17}, {18, 19}, {16, 18}, {17, 19}, {17, 18}, {20, 21}, {22, 23}, {20, 22}, {21, 23},
+    {21, 22}, {16, 20}, {18, 22}, {18, 20}, {17, 21}, {19, 23}, {19, 21}, {17, 18}, {19, 20}, {21, 22}, {24, 25}, {26, 27},
+    {24, 26}, {25, 27}, {25, 26}, {28, 29}, {30, 31}, {28, 30}, {29, 31}, {29, 30}, {24, 28}, {26, 30}, {26, 28}, {25, 29},
+    {27, 31}, {27, 29}, {25, 26}, {27, 28}, {29, 30}, {16, 24}, {20, 28}, {20, 24}, {18, 26}, {22, 30}, {22, 26}, {18, 20},
+    {22, 24}, {26, 28}, {17, 25}, {21, 29}, {21, 25}, {19, 27}, {23, 31}, {23, 27}, {19, 21}, {23, 25}, {27, 29}, {17, 18},
+    {19, 20}, {21, 22}, {23, 24}, {25, 26}, {27, 28}, {29, 30}, {0, 16}, {8, 24}, {8, 16}, {4, 20}, {12, 28}, {12, 20},
+    {4, 8}, {12, 16}, {20, 24}, {2, 18}, {10, 26}, {10, 18}, {6, 22}, {14, 30}, {14, 22}, {6, 10}, {14, 18}, {22, 26},
+    {2, 4}, {6, 8}, {10, 12}, {14, 16}, {18, 20}, {22, 24}, {26, 28}, {1, 17}, {9, 25}, {9, 17}, {5, 21}, {13, 29},
+    {13, 21}, {5, 9}, {13, 17}, {21, 25}, {3, 19}, {11, 27}, {11, 19}, {7, 23}, {15, 31}, {15, 23}, {7, 11}, {15, 19},
+    {23, 27}, {3, 5}, {7, 9}, {11, 13}, {15, 17}, {19, 21}, {23, 25}, {27, 29}, {1, 2}, {3, 4}, {5, 6}, {7, 8},
+    {9, 10}, {11, 12}, {13, 14}, {15, 16}, {17, 18}, {19, 20}, {21, 22}, {23, 24}, {25, 26}, {27, 28}, {29, 30}};
 
-template <int RQ>
 struct Q2Lds {
+  static constexpr int RQ = Q2_RQ;
   static constexpr int THREADS = NSUB * RQ;
   static constexpr int STAGE_CAP = 12 * RQ;
   static constexpr int NH = THREADS / 32;  // half-waves
   static constexpr int TABLE_MAX = 256;
   static constexpr size_t QBUF_OFF = 160;  // ints: band_lo[9] band_hi[9] band_base[10] misc[4]
-  static constexpr size_t RECA_OFF = QBUF_OFF + (size_t)RQ * 16;
-  static constexpr size_t RECB_OFF = RECA_OFF + (size_t)THREADS * 16;
-  static constexpr size_t KEYS_OFF = RECB_OFF + (size_t)THREADS * 8;
-  static constexpr size_t IDXS_OFF = KEYS_OFF + (size_t)NH * Q2_KCAP * 4;
-  static constexpr size_t STAGE_OFF = IDXS_OFF + (size_t)NH * Q2_KCAP * 4;
+  static constexpr size_t RECA_OFF = QBUF_OFF + (size_t)RQ * 16;         // per thread: masks of bands 0 + 1 (even, odd), of band 2
+  static constexpr size_t RECB_OFF = RECA_OFF + (size_t)THREADS * 16;    // per thread: plane bases of the three bands, step counts
+  static constexpr size_t QTOT_OFF = RECB_OFF + (size_t)THREADS * 16;    // hits per query, then the list of the half-wave queries
+  static constexpr size_t KEYS_OFF = QTOT_OFF + (size_t)RQ * 8;          // key + index scratch of the half-waves of waves 1, 2
+  static constexpr size_t LIST_OFF = KEYS_OFF + (size_t)(NH - 2) * Q2_KCAP * 8;
+  // [RQ][Q2_NET] 8-byte words, later the row buffer; a workgroup on the slow path keeps its ranges and six scratches here
+  static constexpr size_t LIST_BYTES = (size_t)RQ * Q2_NET * 8;
+  static constexpr size_t STAGE_OFF = LIST_OFF + LIST_BYTES;
+  static_assert((size_t)THREADS * 24 + (size_t)NH * Q2_KCAP * 8 <= LIST_BYTES, "slow-path ranges + scratch live in the list area");
+  static_assert((size_t)RQ * Q2_WMAX * 4 <= LIST_BYTES, "the row buffer takes the lists' place");
   static size_t tables_bytes(int tcap) { return tcap > 0 ? ((size_t)(tcap + 1) * 4 + 15) / 16 * 16 + (size_t)tcap * sizeof(BatchGrid) : 0; }
   static size_t total(int tcap) {  // the per-cloud tables of the set-up lie where the candidate planes go afterwards
     const size_t st = (size_t)STAGE_CAP * 16 + 16, tb = tables_bytes(tcap);
@@ -1591,30 +1619,46 @@ __device__ __forceinline__ int half_wave_sum(int v) {
   return (threadIdx.x & 32) ? b : a;
 }
 
-template <int RQ, int MODE>
-__global__ __launch_bounds__(NSUB* RQ) void q2_kernel(
+// Masks of one (query, slab) thread.  Register pair A = bands 0 and 1 (dy = -1, 0), pair B = band 2; in each pair the even
+// candidates of the thread's enumeration are shifted into .lo, the odd ones into .hi: after S steps bit q of a register holds
+// enumeration slot 2 (2 S - 1 - q) (+ 1 on the odd side).  Bases: plane position of slot c = c + base of its band.
+struct Q2Rec {
+  unsigned a_lo, a_hi, b_lo, b_hi;
+  int s0, s1, s2;      // band bases, already shifted by the band's first slot
+  unsigned meta;       // 4 nit0 | (2 (nit0 + nit1) - 1) << 8 | (2 nit2 - 1) << 16   (the tops are -1 when a pair is empty: 0xff)
+};
+__device__ __forceinline__ int q2_count(const uint4 m) { return __popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w); }
+// plane position of the hit behind bit `qbit` of register `word` (0 a_lo, 1 a_hi, 2 b_lo, 3 b_hi)
+__device__ __forceinline__ int q2_plane_pos(int word, int qbit, const int4 rb) {
+  const unsigned meta = (unsigned)rb.w;
+  const int c1 = (int)(meta & 0xffu), top_a = (int)((meta >> 8) & 0xffu), top_b = (int)((meta >> 16) & 0xffu);
+  const bool pair_b = word >= 2;
+  const int c = 2 * ((pair_b ? top_b : top_a) - qbit) + (word & 1);
+  return c + (pair_b ? rb.z : (c < c1 ? rb.x : rb.y));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(NSUB* Q2_RQ) void q2_kernel(
     const float4* __restrict__ sorted_q, int nq, const int32_t* __restrict__ q_off, int nb,
     const BatchGrid* __restrict__ grids, const int32_t* __restrict__ start_s, const float4* __restrict__ sorted_s, int ns_total,
-    float r2, uint2* __restrict__ g_mask, int32_t* __restrict__ blk_stats, int width, int row_stride, int64_t pad_value,
+    float r2, uint4* __restrict__ g_mask, int32_t* __restrict__ blk_stats, int width, int row_stride, int64_t pad_value,
     int64_t* __restrict__ out, int mono, int dbg_stop) {
-  // dbg_stop (GR_RADIUS_Q2_STOP, measurement only): leave after 1 set-up, 2 staging, 3 tests, 4 keys, 5 ranking
-#define GR_Q2_STOP(K, VALUE)                                       \
-  if (dbg_stop == (K)) {                                           \
-    if ((VALUE) == 0x7fffffff) blk_stats[2 * blk] = tid;           \
-    return;                                                        \
-  }
-  using L = Q2Lds<RQ>;
-  static_assert(RQ % WAVE == 0, "waves must not straddle slabs");
+  // dbg_stop (GR_RADIUS_Q2_STOP, measurement only): leave after 1 set-up, 2 staging, 3 tests, 4 decode, 5 sort
+  using L = Q2Lds;
+  constexpr int RQ = Q2_RQ;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* band_lo = reinterpret_cast<int*>(smem);
   int* band_hi = band_lo + NBAND;
   int* band_base = band_hi + NBAND;
-  int* misc = band_base + NBAND + 1;  // [0] largest hit count of a query, [1] "repeat the call on the old kernels"
+  int* misc = band_base + NBAND + 1;  // [0] largest hit count of a query, [1] a query beyond Q2_KCAP, [2] half-wave queries, [3] slow path
   float4* qbuf = reinterpret_cast<float4*>(smem + L::QBUF_OFF);
-  uint4* recA = reinterpret_cast<uint4*>(smem + L::RECA_OFF);  // per thread: mask lo, mask hi, plane base of band 0, of band 1
-  uint2* recB = reinterpret_cast<uint2*>(smem + L::RECB_OFF);  // plane base of band 2, (4 nit0) | (4 (nit0 + nit1)) << 8 | top << 16
-  unsigned* keys = reinterpret_cast<unsigned*>(smem + L::KEYS_OFF);
-  unsigned* idxs = reinterpret_cast<unsigned*>(smem + L::IDXS_OFF);
+  uint4* recA = reinterpret_cast<uint4*>(smem + L::RECA_OFF);
+  int4* recB = reinterpret_cast<int4*>(smem + L::RECB_OFF);
+  int* qtot = reinterpret_cast<int*>(smem + L::QTOT_OFF);
+  int* biglist = qtot + RQ;
+  unsigned long long* lists = reinterpret_cast<unsigned long long*>(smem + L::LIST_OFF);
+  unsigned int* rowbuf = reinterpret_cast<unsigned int*>(smem + L::LIST_OFF);  // takes the lists' place after the sort
+  int2* slow_rng = reinterpret_cast<int2*>(smem + L::LIST_OFF);                // slow path: [3][THREADS] candidate ranges
   float* sx = reinterpret_cast<float*>(smem + L::STAGE_OFF);
   float* sy = sx + L::STAGE_CAP;
   float* sz = sy + L::STAGE_CAP;
@@ -1632,12 +1676,13 @@ __global__ __launch_bounds__(NSUB* RQ) void q2_kernel(
   const int t = blk * RQ + slot;
   const int lane = tid & (WAVE - 1);
   const bool valid = t < nq;
+  const int rows_here = min(RQ, nq - blk * RQ);
 
   if (tid < NBAND) {
     band_lo[tid] = 0x7fffffff;
     band_hi[tid] = 0;
   }
-  if (tid == 0) misc[0] = misc[1] = 0;
+  if (tid < 4) misc[tid] = 0;
   const bool tables_in_lds = tcap > 0;
   if (tables_in_lds) {
     for (int i = tid; i <= nb; i += L::THREADS) s_qoff[i] = q_off[i];
@@ -1647,7 +1692,7 @@ __global__ __launch_bounds__(NSUB* RQ) void q2_kernel(
   }
   float4 qp = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
   if (valid) qp = sorted_q[t];
-  uint2 gm = make_uint2(0u, 0u);
+  uint4 gm = make_uint4(0u, 0u, 0u, 0u);
   if (MODE == Q2_FILL && valid) gm = g_mask[(int64_t)j * nq + t];  // requested now, used after the staging
   __syncthreads();
   int p0[3] = {0, 0, 0}, p1[3] = {0, 0, 0};
@@ -1680,7 +1725,10 @@ __global__ __launch_bounds__(NSUB* RQ) void q2_kernel(
     }
   }
   if (j == 0) qbuf[slot] = qp;
-  GR_Q2_STOP(1, p0[0] + p0[1] + p0[2] + p1[0] + p1[1] + p1[2])
+  if (dbg_stop == 1) {
+    if (p0[0] + p1[2] == 0x7fffffff) blk_stats[2 * blk] = tid;
+    return;
+  }
   // ---- block-wide extent of every band (waves are slab-uniform: band index = 3*j + i)
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -1755,12 +1803,14 @@ __global__ __launch_bounds__(NSUB* RQ) void q2_kernel(
         si[bdst[kk] + f] = __float_as_int(t4.w);
       }
     }
-    __syncthreads();
   }
-  GR_Q2_STOP(2, (int)sx[tid])
-  // ---- tests, four candidates per step; hits are the sign bits of (distance bits - r2 bits), shifted into two 32-bit
-  //      registers (even / odd candidates of the thread's enumeration), as in fused_kernel
-  unsigned lo = 0u, hi = 0u;
+  if (dbg_stop == 2) {
+    __syncthreads();
+    if ((int)sx[tid] == 0x7fffffff) blk_stats[2 * blk] = tid;
+    return;
+  }
+  // ---- tests, four candidates per step; hits are the sign bits of (distance bits - r2 bits), shifted into 32-bit registers
+  unsigned m_lo[2] = {0u, 0u}, m_hi[2] = {0u, 0u};
   int rel[3] = {0, 0, 0};
   if (staged) {
 #pragma unroll
@@ -1768,69 +1818,73 @@ __global__ __launch_bounds__(NSUB* RQ) void q2_kernel(
   }
   const int len0 = p1[0] - p0[0], len1 = p1[1] - p0[1], len2 = p1[2] - p0[2];
   const int nit0 = (len0 + 3) >> 2, nit1 = (len1 + 3) >> 2, nit2 = (len2 + 3) >> 2;
-  const bool by_mask = staged && (nit0 + nit1 + nit2 <= 16);
-  if (valid && !by_mask) misc[1] = 1;
+  const bool by_mask = staged && nit0 + nit1 <= 16 && nit2 <= 16;
+  if (valid && !by_mask) misc[3] = 1;  // (benign race: everybody stores 1)
   const unsigned r2b = r2 == r2 ? __float_as_uint(r2) : 0u;  // NaN radius: nothing is a neighbour
+  __syncthreads();  // planes complete; the slow-path flag is final
+  const bool slow = misc[3] != 0;
   if (MODE == Q2_FILL) {
-    lo = gm.x;
-    hi = gm.y;
-  } else if (valid && by_mask) {
+    m_lo[0] = gm.x, m_hi[0] = gm.y, m_lo[1] = gm.z, m_hi[1] = gm.w;
+  } else if (valid && !slow) {
     const f32x2 qx = {qp.x, qp.x}, qy = {qp.y, qp.y}, qz = {qp.z, qp.z};
-    auto step4 = [&](int p, int left) {  // left >= 4 except in a band's last step (the reads past the band stay inside the planes)
-      const f32x2 xa = {sx[p], sx[p + 1]}, xb = {sx[p + 2], sx[p + 3]};
-      const f32x2 ya = {sy[p], sy[p + 1]}, yb = {sy[p + 2], sy[p + 3]};
-      const f32x2 za = {sz[p], sz[p + 1]}, zb = {sz[p + 2], sz[p + 3]};
-      // nanoflann.hpp:432-440: result += diff*diff for x, y, z starting from 0 (two candidates per op)
-      const f32x2 dxa = qx - xa, dya = qy - ya, dza = qz - za;
-      const f32x2 dxb = qx - xb, dyb = qy - yb, dzb = qz - zb;
-      const f32x2 da = (dxa * dxa + dya * dya) + dza * dza;
-      const f32x2 db = (dxb * dxb + dyb * dyb) + dzb * dzb;
-      const unsigned t0 = __float_as_uint(da.x) - r2b;
-      const unsigned t1 = left >= 2 ? __float_as_uint(da.y) - r2b : 0u;
-      const unsigned t2 = left >= 3 ? __float_as_uint(db.x) - r2b : 0u;
-      const unsigned t3 = left >= 4 ? __float_as_uint(db.y) - r2b : 0u;
-      lo = __builtin_amdgcn_alignbit(lo, t0, 31);  // (lo << 1) | sign(t0)
-      lo = __builtin_amdgcn_alignbit(lo, t2, 31);
-      hi = __builtin_amdgcn_alignbit(hi, t1, 31);
-      hi = __builtin_amdgcn_alignbit(hi, t3, 31);
-    };
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
+      unsigned lo = m_lo[i >> 1], hi = m_hi[i >> 1];
+      auto step4 = [&](int p, int left) {  // left >= 4 except in a band's last step (the reads past the band stay inside the planes)
+        const f32x2 xa = {sx[p], sx[p + 1]}, xb = {sx[p + 2], sx[p + 3]};
+        const f32x2 ya = {sy[p], sy[p + 1]}, yb = {sy[p + 2], sy[p + 3]};
+        const f32x2 za = {sz[p], sz[p + 1]}, zb = {sz[p + 2], sz[p + 3]};
+        // nanoflann.hpp:432-440: result += diff*diff for x, y, z starting from 0 (two candidates per op)
+        const f32x2 dxa = qx - xa, dya = qy - ya, dza = qz - za;
+        const f32x2 dxb = qx - xb, dyb = qy - yb, dzb = qz - zb;
+        const f32x2 da = (dxa * dxa + dya * dya) + dza * dza;
+        const f32x2 db = (dxb * dxb + dyb * dyb) + dzb * dzb;
+        const unsigned t0 = __float_as_uint(da.x) - r2b;
+        const unsigned t1 = left >= 2 ? __float_as_uint(da.y) - r2b : 0u;
+        const unsigned t2 = left >= 3 ? __float_as_uint(db.x) - r2b : 0u;
+        const unsigned t3 = left >= 4 ? __float_as_uint(db.y) - r2b : 0u;
+        lo = __builtin_amdgcn_alignbit(lo, t0, 31);  // (lo << 1) | sign(t0)
+        lo = __builtin_amdgcn_alignbit(lo, t2, 31);
+        hi = __builtin_amdgcn_alignbit(hi, t1, 31);
+        hi = __builtin_amdgcn_alignbit(hi, t3, 31);
+      };
       int p = p0[i] + rel[i];
       const int e = p1[i] + rel[i];
       for (; p + 4 <= e; p += 4) step4(p, 4);
       if (p < e) step4(p, e - p);
+      m_lo[i >> 1] = lo, m_hi[i >> 1] = hi;
     }
   }
-  GR_Q2_STOP(3, (int)(lo >> 20) + (int)(hi >> 20))
-  if (MODE == Q2_COUNT && valid) g_mask[(int64_t)j * nq + t] = make_uint2(lo, hi);
-  {
-    const int c1 = 4 * nit0, c2 = 4 * (nit0 + nit1), top = 2 * (nit0 + nit1 + nit2) - 1;
-    recA[tid] = make_uint4(lo, hi, (unsigned)(p0[0] + rel[0]), (unsigned)(p0[1] + rel[1] - c1));
-    recB[tid] = make_uint2((unsigned)(p0[2] + rel[2] - c2), (unsigned)((c1 & 0xff) | ((c2 & 0xff) << 8) | ((top & 0xff) << 16)));
-  }
-  __syncthreads();
-  if (misc[1]) {  // this block cannot use the masks: the caller repeats the call on the kernels above
-    if (tid == 0) {
-      blk_stats[2 * blk] = 0;
-      blk_stats[2 * blk + 1] = 1;
-    }
+  if (dbg_stop == 3) {
+    if ((m_lo[0] ^ m_hi[1]) == 0x12345u) blk_stats[2 * blk] = tid;
     return;
   }
-  const int rows_here = min(RQ, nq - blk * RQ);
-  if (MODE == Q2_COUNT) {
-    if (tid < RQ) {
-      int tot = 0;
-      if (tid < rows_here) {
+  if (MODE == Q2_COUNT && valid && !slow) g_mask[(int64_t)j * nq + t] = make_uint4(m_lo[0], m_hi[0], m_lo[1], m_hi[1]);
+  {
+    const int c1 = 4 * nit0;
+    recA[tid] = make_uint4(m_lo[0], m_hi[0], m_lo[1], m_hi[1]);
+    recB[tid] = make_int4(p0[0] + rel[0], p0[1] + rel[1] - c1, p0[2] + rel[2],
+                          (int)((unsigned)(c1 & 0xff) | ((unsigned)((2 * (nit0 + nit1) - 1) & 0xff) << 8) |
+                                ((unsigned)((2 * nit2 - 1) & 0xff) << 16)));
+  }
+  if (slow) {  // the half-waves below read the candidates from global memory: they need every thread's ranges
 #pragma unroll
-        for (int i = 0; i < NSUB; ++i) {
-          const uint4 a = recA[i * RQ + tid];
-          tot += __popc(a.x) + __popc(a.y);
-        }
-      }
-      const int mx = wave_max_i32_dpp(tot);
-      if (lane == 0) atomicMax(&misc[0], mx);
+    for (int i = 0; i < 3; ++i) slow_rng[i * L::THREADS + tid] = make_int2(p0[i], p1[i]);
+  }
+  __syncthreads();
+  // ---- hits per query (normal path: from the masks)
+  int n_before = 0, tot = 0;
+  if (!slow) {
+#pragma unroll
+    for (int i = 0; i < NSUB; ++i) {
+      const int c = q2_count(recA[i * RQ + slot]);
+      n_before += i < j ? c : 0;
+      tot += c;
     }
+  }
+  if (MODE == Q2_COUNT && !slow) {
+    const int mx = wave_max_i32_dpp(valid ? tot : 0);
+    if (lane == 0) atomicMax(&misc[0], mx);
     __syncthreads();
     if (tid == 0) {
       blk_stats[2 * blk] = misc[0];
@@ -1838,91 +1892,185 @@ __global__ __launch_bounds__(NSUB* RQ) void q2_kernel(
     }
     return;
   }
-  // ---- one half-wave per query
-  const int hw = tid >> 5, l = tid & 31;
-  unsigned* ks = keys + hw * Q2_KCAP;
-  unsigned* is = idxs + hw * Q2_KCAP;
-  int hmax = 0;
-  for (int r = hw; r < rows_here; r += L::NH) {
-    const uint4 a0 = recA[r], a1 = recA[RQ + r], a2 = recA[2 * RQ + r];
-    const uint2 b0 = recB[r], b1 = recB[RQ + r], b2 = recB[2 * RQ + r];
-    const float4 qq = qbuf[r];
-    const int c0 = __popc(a0.x) + __popc(a0.y), c1 = __popc(a1.x) + __popc(a1.y), c2 = __popc(a2.x) + __popc(a2.y);
-    const int tot = c0 + c1 + c2;
-    hmax = max(hmax, tot);
-    if (tot > Q2_KCAP) {
-      misc[1] = 1;
-      continue;
+  int my_tot = 0;  // threads of wave 0: hits of query `tid` if the network takes it
+  if (!slow) {
+    // ---- decode by the threads that own the masks: (distance, index) words into the query's list; thread j starts behind
+    //      the hits of the slabs before it
+    const bool netq = valid && tot <= Q2_NET;
+    if (j == 0) {
+      my_tot = netq ? tot : 0;
+      qtot[slot] = valid ? tot : 0;
+      if (valid && !netq) biglist[atomicAdd(&misc[2], 1)] = slot;
     }
-    int64_t* const row = out + (int64_t)__float_as_int(qq.w) * row_stride;
-    unsigned dk[Q2_KR], ix[Q2_KR];
+    if (netq && MODE != Q2_COUNT) {
+      const uint4 a = recA[tid];
+      const int4 rb = recB[tid];
+      unsigned long long* dst = lists + slot * Q2_NET + n_before;
+      const f32x2 qx = {qp.x, qp.x}, qy = {qp.y, qp.y}, qz = {qp.z, qp.z};
 #pragma unroll
-    for (int rd = 0; rd < Q2_KR; ++rd) {
-      dk[rd] = 0xffffffffu;
-      ix[rd] = 0u;
-      if (rd * 32 < tot) {
-        const int k = rd * 32 + l;
-        if (k < tot) {
-          const bool g1 = k >= c0, g2 = k >= c0 + c1;
-          int kk = k - (g2 ? c0 + c1 : (g1 ? c0 : 0));
-          const unsigned mlo = g2 ? a2.x : (g1 ? a1.x : a0.x), mhi = g2 ? a2.y : (g1 ? a1.y : a0.y);
-          const int s0 = (int)(g2 ? a2.z : (g1 ? a1.z : a0.z)), s1 = (int)(g2 ? a2.w : (g1 ? a1.w : a0.w));
-          const int s2 = (int)(g2 ? b2.x : (g1 ? b1.x : b0.x));
-          const unsigned meta = g2 ? b2.y : (g1 ? b1.y : b0.y);
-          const int clo = __popc(mlo);
-          const bool side = kk >= clo;
-          kk -= side ? clo : 0;
-          const int qbit = kth_set_bit32(side ? mhi : mlo, kk);
-          // register bit q holds enumeration slot 2 (top - q) (+ 1 on the odd side); slots 0 .. 4 nit0 - 1 are band 0, ...
-          const int c = 2 * ((int)(meta >> 16) - qbit) + (side ? 1 : 0);
-          const int p = c + (c < (int)(meta & 0xffu) ? s0 : (c < (int)((meta >> 8) & 0xffu) ? s1 : s2));
-          const float dx = qq.x - sx[p], dy = qq.y - sy[p], dz = qq.z - sz[p];
-          const float d = (dx * dx + dy * dy) + dz * dz;
-          dk[rd] = __float_as_uint(d);  // d >= 0: the bit pattern orders like the value
-          ix[rd] = (unsigned)si[p];
+      for (int pr = 0; pr < 2; ++pr) {
+        unsigned ml = pr ? a.z : a.x, mh = pr ? a.w : a.y;
+        while (ml | mh) {  // one hit of the even and one of the odd side per step
+          const int qa = 31 - __clz((int)ml), qb = 31 - __clz((int)mh);  // -1: none left on that side
+          ml &= ~(qa >= 0 ? 1u << qa : 0u);
+          mh &= ~(qb >= 0 ? 1u << qb : 0u);
+          const int pa = q2_plane_pos(2 * pr, max(qa, 0), rb), pb = q2_plane_pos(2 * pr + 1, max(qb, 0), rb);
+          const f32x2 dx = qx - f32x2{sx[pa], sx[pb]}, dy = qy - f32x2{sy[pa], sy[pb]}, dz = qz - f32x2{sz[pa], sz[pb]};
+          const f32x2 d = (dx * dx + dy * dy) + dz * dz;  // same arithmetic as the test: same bits
+          const unsigned long long ka = ((unsigned long long)__float_as_uint(d.x) << 32) | (unsigned int)si[pa];
+          const unsigned long long kb = ((unsigned long long)__float_as_uint(d.y) << 32) | (unsigned int)si[pb];
+          if (qa >= 0) *dst++ = ka;
+          if (qb >= 0) *dst++ = kb;
         }
-        ks[k] = dk[rd];
       }
     }
-    if (dbg_stop == 4) {  // measurement: keys only
-      if (dk[0] == 0x12345u) row[0] = 1;
-      continue;
+    __syncthreads();
+    if (dbg_stop == 4) return;
+  }
+  if (!slow && tid < RQ) {
+    // ---- wave 0: thread = query.  The list (padded with words larger than any real one) goes into registers, through the
+    //      sorting network, and comes back as the row: indices in rising (distance, index) order, then the padding value.
+    unsigned long long k[Q2_NET];
+    const unsigned long long* src = lists + tid * Q2_NET;
+#pragma unroll
+    for (int i = 0; i < Q2_NET; ++i) k[i] = i < my_tot ? src[i] : ~0ull;
+    if (__any(my_tot > 1)) {
+#pragma unroll
+      for (int c = 0; c < Q2_NET_CE; ++c) {
+        const unsigned long long a = k[Q2_NET_PAIRS[c][0]], b = k[Q2_NET_PAIRS[c][1]];
+        const bool sw = b < a;
+        k[Q2_NET_PAIRS[c][0]] = sw ? b : a;
+        k[Q2_NET_PAIRS[c][1]] = sw ? a : b;
+      }
     }
+    if (dbg_stop == 5) {
+      if (k[0] == 0x12345ull) blk_stats[0] = 1;
+      return;
+    }
+    // (every lane of this wave has its list in registers: the lists' place becomes the row buffer)
+    if (tid < rows_here) {
+      unsigned int* rrow = rowbuf + tid * width;
+#pragma unroll
+      for (int i = 0; i < Q2_NET; ++i)
+        if (i < width) rrow[i] = i < my_tot ? (unsigned int)k[i] : 0xffffffffu;
+      for (int i = Q2_NET; i < width; ++i) rrow[i] = 0xffffffffu;
+    }
+  }
+  // ---- one half-wave per query: the queries the network does not take (waves 1, 2), or all of them (slow path, every wave)
+  const int hw = slow ? tid >> 5 : (tid >> 5) - 2, l = tid & 31;
+  const int nhw = slow ? L::NH : L::NH - 2;
+  unsigned* ks = slow ? reinterpret_cast<unsigned*>(smem + L::LIST_OFF + (size_t)L::THREADS * 24) + max(hw, 0) * 2 * Q2_KCAP
+                      : reinterpret_cast<unsigned*>(smem + L::KEYS_OFF) + max(hw, 0) * 2 * Q2_KCAP;
+  unsigned* is = ks + Q2_KCAP;
+  int hmax = my_tot;
+  const int n_items = slow ? rows_here : misc[2];
+  for (int item = hw; hw >= 0 && item < n_items; item += nhw) {
+    const int r = slow ? item : biglist[item];
+    const float4 qq = qbuf[r];
+    int64_t* const row = out + (int64_t)__float_as_int(qq.w) * row_stride;
+    unsigned dk[Q2_KR], ix[Q2_KR];
+    int htot = 0;
+    if (!slow) {
+      const uint4 a0 = recA[r], a1 = recA[RQ + r], a2 = recA[2 * RQ + r];
+      const int c0 = q2_count(a0), c1 = q2_count(a1), c2 = q2_count(a2);
+      htot = c0 + c1 + c2;
+      hmax = max(hmax, htot);
+      if (htot > Q2_KCAP) {
+        misc[1] = 1;
+        continue;
+      }
+#pragma unroll
+      for (int rd = 0; rd < Q2_KR; ++rd) {
+        dk[rd] = 0x7fffffffu;
+        ix[rd] = 0u;
+        if (rd * 32 < htot) {
+          const int k = rd * 32 + l;
+          if (k < htot) {
+            const bool g1 = k >= c0, g2 = k >= c0 + c1;
+            int kk = k - (g2 ? c0 + c1 : (g1 ? c0 : 0));
+            const uint4 m = g2 ? a2 : (g1 ? a1 : a0);
+            const int4 rb = recB[(g2 ? 2 : (g1 ? 1 : 0)) * RQ + r];
+            const int n0 = __popc(m.x), n1 = __popc(m.y), n2 = __popc(m.z);
+            const int word = (kk >= n0) + (kk >= n0 + n1) + (kk >= n0 + n1 + n2);
+            kk -= word == 0 ? 0 : (word == 1 ? n0 : (word == 2 ? n0 + n1 : n0 + n1 + n2));
+            const unsigned mw = word == 0 ? m.x : (word == 1 ? m.y : (word == 2 ? m.z : m.w));
+            const int p = q2_plane_pos(word, kth_set_bit32(mw, kk), rb);
+            const float dx = qq.x - sx[p], dy = qq.y - sy[p], dz = qq.z - sz[p];
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            dk[rd] = __float_as_uint(d);  // d >= 0: the bit pattern orders like the value
+            ix[rd] = (unsigned)si[p];
+          }
+          ks[k] = dk[rd];
+        }
+      }
+    } else {
+      // slow path: the nine candidate ranges of the query straight from global memory, 32 candidates per step, hits
+      // compacted behind each other by the half-wave's ballot
+      const unsigned long long half = (tid & 32) ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+      for (int band = 0; band < NBAND; ++band) {
+        const int2 rg = slow_rng[(band % 3) * L::THREADS + (band / 3) * RQ + r];
+        for (int pbase = rg.x; pbase < rg.y; pbase += 32) {
+          const int p = pbase + l;
+          const float4 sp = sorted_s[min(p, ns_total - 1)];
+          const float dx = qq.x - sp.x, dy = qq.y - sp.y, dz = qq.z - sp.z;
+          const float d = (dx * dx + dy * dy) + dz * dz;
+          const bool hit = p < rg.y && d < r2;
+          const unsigned long long bal = __ballot(hit) & half;
+          const int pos = htot + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+          if (hit && pos < Q2_KCAP) {
+            ks[pos] = __float_as_uint(d);
+            is[pos] = (unsigned)__float_as_int(sp.w);
+          }
+          htot += __popcll(bal);
+        }
+      }
+      hmax = max(hmax, htot);
+      if (htot > Q2_KCAP) {
+        misc[1] = 1;
+        continue;
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int rd = 0; rd < Q2_KR; ++rd) {
+        const int k = rd * 32 + l;
+        dk[rd] = k < htot ? ks[k] : 0x7fffffffu;
+        ix[rd] = k < htot ? is[k] : 0u;
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int k = htot + l; k < ((htot + 31) & ~31); k += 32) ks[k] = 0x7fffffffu;  // the rank loop reads whole quads
+    }
+    if (MODE == Q2_COUNT) continue;  // (slow path of the counting launch: only the maximum is wanted)
     __builtin_amdgcn_wave_barrier();  // the segment is read by the other lanes of the half-wave (LDS executes a wave's
                                       // operations in order)
     int rk[Q2_KR];
 #pragma unroll
     for (int rd = 0; rd < Q2_KR; ++rd) rk[rd] = 0;
-    const int quads = (tot + 3) >> 2;
+    const int quads = (htot + 3) >> 2;
     const uint4* seg = reinterpret_cast<const uint4*>(ks);
-    if (tot <= 32) {
-      for (int jj = 0; jj < quads; ++jj) {
-        const uint4 k4 = seg[jj];
-        rk[0] += (k4.x < dk[0] ? 1 : 0) + (k4.y < dk[0] ? 1 : 0) + (k4.z < dk[0] ? 1 : 0) + (k4.w < dk[0] ? 1 : 0);
-      }
-    } else {
-      for (int jj = 0; jj < quads; ++jj) {
-        const uint4 k4 = seg[jj];
+    for (int jj = 0; jj < quads; ++jj) {
+      const uint4 k4 = seg[jj];
 #pragma unroll
-        for (int rd = 0; rd < Q2_KR; ++rd)
+      for (int rd = 0; rd < Q2_KR; ++rd)
+        if (rd * 32 < htot)
           rk[rd] += (k4.x < dk[rd] ? 1 : 0) + (k4.y < dk[rd] ? 1 : 0) + (k4.z < dk[rd] ? 1 : 0) + (k4.w < dk[rd] ? 1 : 0);
-      }
     }
     // equal distance words: two hits share a rank and the ranks no longer add up to n (n - 1) / 2
     int rsum = 0;
 #pragma unroll
-    for (int rd = 0; rd < Q2_KR; ++rd) rsum += (rd * 32 + l < tot) ? rk[rd] : 0;
+    for (int rd = 0; rd < Q2_KR; ++rd) rsum += (rd * 32 + l < htot) ? rk[rd] : 0;
     rsum = half_wave_sum(rsum);
-    if (rsum != tot * (tot - 1) / 2) {
+    if (rsum != htot * (htot - 1) / 2) {
+      if (!slow) {
 #pragma unroll
-      for (int rd = 0; rd < Q2_KR; ++rd)
-        if (rd * 32 < tot) is[rd * 32 + l] = ix[rd];
+        for (int rd = 0; rd < Q2_KR; ++rd)
+          if (rd * 32 < htot) is[rd * 32 + l] = ix[rd];
+      }
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int rd = 0; rd < Q2_KR; ++rd) {
-        if (rd * 32 + l < tot) {
+        if (rd * 32 + l < htot) {
           int rank = 0;
-          for (int k2 = 0; k2 < tot; ++k2) {
+          for (int k2 = 0; k2 < htot; ++k2) {
             const unsigned dd = ks[k2], ii = is[k2];
             rank += (dd < dk[rd] || (dd == dk[rd] && ii < ix[rd])) ? 1 : 0;
           }
@@ -1930,15 +2078,11 @@ __global__ __launch_bounds__(NSUB* RQ) void q2_kernel(
         }
       }
     }
-    if (dbg_stop == 5) {  // measurement: no row stores
-      if (rk[0] == 0x12345) row[0] = 1;
-      continue;
-    }
     // ---- the row: hits at their rank, the lanes past the hit count pad their own column
 #pragma unroll
     for (int rd = 0; rd < Q2_KR; ++rd) {
       const int k = rd * 32 + l;
-      if (k < tot) {
+      if (k < htot) {
         if (rk[rd] < width) row[rk[rd]] = (int64_t)ix[rd];
       } else if (k < row_stride) {
         row[k] = pad_value;
@@ -1947,13 +2091,25 @@ __global__ __launch_bounds__(NSUB* RQ) void q2_kernel(
     for (int k = Q2_KCAP + l; k < row_stride; k += 32) row[k] = pad_value;
     __builtin_amdgcn_wave_barrier();  // the next query overwrites the key scratch
   }
-  if (l == 0) atomicMax(&misc[0], hmax);
+  if (l == 0 || tid < RQ) atomicMax(&misc[0], hmax);
   __syncthreads();
+  if (!slow && MODE != Q2_COUNT) {
+    // ---- rows of the sorted queries leave as contiguous runs (consecutive lanes, consecutive entries of a row)
+    const int total_el = rows_here * width;
+    const float inv = 1.0f / (float)width;
+    for (int i = tid; i < total_el; i += L::THREADS) {
+      int r = (int)((float)i * inv);
+      r = r * width > i ? r - 1 : ((r + 1) * width <= i ? r + 1 : r);
+      const int cc = i - r * width;
+      if (qtot[r] > Q2_NET) continue;  // written by a half-wave above
+      const unsigned v = rowbuf[r * width + cc];
+      out[(int64_t)__float_as_int(qbuf[r].w) * row_stride + cc] = v == 0xffffffffu ? pad_value : (int64_t)v;
+    }
+  }
   if (tid == 0) {
     blk_stats[2 * blk] = misc[0];
     blk_stats[2 * blk + 1] = misc[1];
   }
-#undef GR_Q2_STOP
 }
 
 // max / max over the per-block (max hits per query, hits per block) pairs -> hdr
@@ -2039,47 +2195,41 @@ int launch_fill(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t n
 }
 
 struct Q2Cfg {
-  int rq;
   int dbg_stop;
 };
 inline Q2Cfg q2_cfg() {
   static const Q2Cfg cfg = [] {
-    Q2Cfg c{64, 0};
-    if (const char* e = getenv("GR_RADIUS_Q2_RQ")) c.rq = atoi(e) == 128 ? 128 : 64;
+    Q2Cfg c{0};
     if (const char* e = getenv("GR_RADIUS_Q2_STOP")) c.dbg_stop = atoi(e);
     return c;
   }();
   return cfg;
 }
 
+// does the sorted path apply?  rows are staged in LDS up to Q2_WMAX entries, stored at stride == width
+inline bool q2_fits(int64_t width, int64_t row_stride) { return width >= 1 && width <= Q2_WMAX && width == row_stride; }
+
 // One launch of q2_kernel + the reduction of its per-block (max hits, flag) pairs into hdr->max_count / hdr->max_block_hits
-// (the latter = 1: some workgroup could not use the masks, the caller repeats the call on the older kernels).
-template <int RQ, int MODE>
-int launch_q2_t(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns, int nb, const int32_t* start_s, float r2,
-                int64_t width, int64_t row_stride, int64_t* out, bool mono, hipStream_t stream) {
-  using L = Q2Lds<RQ>;
-  const int blocks = (int)((nq + RQ - 1) / RQ);
+// (the latter = 1: a query had more than Q2_KCAP hits, the caller repeats the call on the older kernels).
+template <int MODE>
+int launch_q2(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns, int nb, const int32_t* start_s, float r2,
+              int64_t width, int64_t row_stride, int64_t* out, bool mono, hipStream_t stream) {
+  using L = Q2Lds;
+  const int blocks = (int)((nq + L::RQ - 1) / L::RQ);
   const int grid = (blocks + 7) / 8 * 8;
   const size_t lds = L::total(nb <= L::TABLE_MAX ? nb : 0);
-  auto kern = q2_kernel<RQ, MODE>;
+  auto kern = q2_kernel<MODE>;
   if (lds > 64 * 1024)
     GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   {
     KernelTimer timer(MODE == Q2_COUNT ? "radius_count" : (MODE == Q2_FILL ? "radius_fill" : "radius_fused"), stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(L::THREADS), lds, stream, sorted_q, (int)nq, w.q_off, nb, w.grids, start_s,
-                       w.sorted_s, (int)ns, r2, reinterpret_cast<uint2*>(w.q_mask), w.blk_stats, (int)width, (int)row_stride, ns,
+                       w.sorted_s, (int)ns, r2, reinterpret_cast<uint4*>(w.q_mask), w.blk_stats, (int)width, (int)row_stride, ns,
                        out, mono ? 1 : 0, q2_cfg().dbg_stop);
   }
   if (MODE != Q2_FILL) hipLaunchKernelGGL(reduce_stats_kernel, dim3(1), dim3(1024), 0, stream, w.blk_stats, blocks, w.hdr);
   GR_LAUNCH_CHECK();
   return GR_OK;
-}
-
-template <int MODE>
-int launch_q2(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns, int nb, const int32_t* start_s, float r2,
-              int64_t width, int64_t row_stride, int64_t* out, bool mono, hipStream_t stream) {
-  return q2_cfg().rq == 128 ? launch_q2_t<128, MODE>(w, sorted_q, nq, ns, nb, start_s, r2, width, row_stride, out, mono, stream)
-                            : launch_q2_t<64, MODE>(w, sorted_q, nq, ns, nb, start_s, r2, width, row_stride, out, mono, stream);
 }
 
 struct FusedCfg {
@@ -2328,7 +2478,9 @@ extern "C" int gr_radius_count_cached(const float* q, const float* s, const int6
     if (rc != GR_OK) return rc;
     GR_HIP(hipMemcpyAsync(h_pinned, w.hdr, sizeof(RadiusHdr), hipMemcpyDeviceToHost, stream));
     GR_HIP(hipStreamSynchronize(stream));
-    q2 = h_pinned->max_block_hits == 0;  // else: a workgroup could not use the masks -- count again on traverse_kernel
+    // else: a query has more hits than q2_kernel's key scratch, or the rows are wider than it stages -- count again on
+    // traverse_kernel, whose fill takes anything
+    q2 = h_pinned->max_block_hits == 0 && h_pinned->max_count <= (unsigned)Q2_WMAX;
   }
   if (!q2) {
     rc = launch_count<RT>(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, same, stream);
@@ -2369,7 +2521,10 @@ extern "C" int gr_radius_fill(const float* q, const float* s, int64_t nq, int64_
   const bool same = h_info[2] != 0;
   const float4* sorted_q = same ? w.sorted_s : w.sorted_q;
   const float r2 = radius * radius;
-  if (h_info[1] == Q2_PLAN) return launch_q2<Q2_FILL>(w, sorted_q, nq, ns, (int)batch, w.start, r2, width, width, out, same, stream);
+  if (h_info[1] == Q2_PLAN) {
+    GR_REQUIRE(q2_fits(width, width), "radius_fill: width %lld exceeds the counted width", (long long)width);
+    return launch_q2<Q2_FILL>(w, sorted_q, nq, ns, (int)batch, w.start, r2, width, width, out, same, stream);
+  }
   return launch_fill<RT>(w, sorted_q, nq, ns, (int)batch, r2, width, width, h_info[1], out, stream);
 }
 
@@ -2399,9 +2554,9 @@ extern "C" int gr_radius_search(const float* q, const float* s, const int64_t* h
   // GR_RADIUS_SINGLE_PASS=1 selects the single-pass kernel (fused_kernel above).  It is not the default: on 8 x 200 k points it
   // runs as long as count + fill together (both are bound by VALU issue: ~3 000 instructions per wave either way)
   const int mode = search_mode().load();
-  bool fused = (mode == 1 && fused_fits(limit)) || mode == 2;
+  bool fused = (mode == 1 && fused_fits(limit)) || (mode == 2 && q2_fits(limit, limit));
   if (fused) {
-    rc = mode == 2 ? launch_q2<Q2_FUSED>(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, limit, out, P.same, stream)
+    rc = (mode == 2 && q2_fits(limit, limit)) ? launch_q2<Q2_FUSED>(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, limit, out, P.same, stream)
                    : launch_fused(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, out, P.same, stream);
     if (rc != GR_OK) return rc;
     GR_HIP(hipMemcpyAsync(h_pinned, w.hdr, sizeof(RadiusHdr), hipMemcpyDeviceToHost, stream));

@@ -1,7 +1,7 @@
 """Dev tool: the round-4 search kernel (q2_kernel, gr_radius_search_mode 2) against the older paths on the bench workload
 (8 x 200 k-point clouds, r = 0.0625): `radius_search(limit 40)` and the bare `ext.radius_neighbors`.  Environment switches
 are read once per process, so every configuration runs in its own interpreter.
-    python tools/bench_radius_q2.py            modes 0 / 1 / 2, RQ 64 / 128
+    python tools/bench_radius_q2.py            modes 0 / 1 / 2
     python tools/bench_radius_q2.py --ablate   cumulative time of the fused launch stopped after each phase"""
 import json
 import os
@@ -60,12 +60,10 @@ def run(c):
 
 def main():
     if "--ablate" in sys.argv:
-        for rq in ("64", "128"):
-            for stop in ("1", "2", "3", "4", "5", "0"):
-                run({"GR_RADIUS_MODE": "2", "GR_RADIUS_Q2_RQ": rq, "GR_RADIUS_Q2_STOP": stop})
+        for stop in ("1", "2", "3", "4", "5", "0"):
+            run({"GR_RADIUS_MODE": "2", "GR_RADIUS_Q2_STOP": stop})
         return
-    for c in ({"GR_RADIUS_MODE": "0"}, {"GR_RADIUS_MODE": "1"}, {"GR_RADIUS_MODE": "2", "GR_RADIUS_Q2_RQ": "64"},
-              {"GR_RADIUS_MODE": "2", "GR_RADIUS_Q2_RQ": "128"}):
+    for c in ({"GR_RADIUS_MODE": "0"}, {"GR_RADIUS_MODE": "1"}, {"GR_RADIUS_MODE": "2"}):
         run(c)
 
 
