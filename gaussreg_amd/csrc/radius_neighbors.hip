@@ -123,7 +123,7 @@ RadiusWs carve(void* ws, int64_t nq, int64_t ns, int64_t batch) {
   w.sorted_q = c.take<float4>(nq);
   w.q_count = c.take<int32_t>(3 * nq);
   w.q_rng = c.take<int2>(9 * nq);
-  w.q_mask = c.take<unsigned long long>(6 * nq);  // q2_kernel: 16 bytes per (query, slab); traverse_kernel: 8
+  w.q_mask = c.take<unsigned long long>(3 * nq);
   w.blk_stats = c.take<int32_t>(2 * ((nq + 63) / 64 + 8));  // the single-pass kernels run 64 queries per workgroup
   w.bytes = c.used();
   return w;
@@ -1525,34 +1525,33 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
 }
 
 // ---------------------------------------------------------------- round 4: q2_kernel -- hits are SORTED, not ranked
-// The kernels above spend two thirds of their time after the tests: hit masks are decoded, keys re-derived in a third mapping,
-// and every hit is ranked by counting the smaller keys of its query -- two VALU instructions per (hit, key) pair, 43 issue slots
-// per query out of 129 (SQ counters per phase, tools/radius_phase_counters.sh; a wave64 VALU instruction occupies its SIMD for
-// four cycles: 1.6 M queries x 1 slot = 2.6 us of the whole chip).  Here:
-//   tests      as before: three threads per query (one per z-slab), candidates staged in LDS planes, four per step, hits as
-//              sign bits shifted into 32-bit registers -- two register pairs per thread now (bands 0 + 1, band 2): 128
-//              enumeration slots instead of 64
-//   decode     the threads that own the masks write (distance bits << 32 | support index) words into their query's list
-//   sort       ONE THREAD PER QUERY (the workgroup's first wave): the list goes into 32 register pairs and through Batcher's
-//              odd-even merge sort network (191 compare-exchanges): every lane a different query -- no divergence, no LDS
-//              traffic, 6 instructions per comparator = 18 slots per query.  The order of the words IS the reference's order
-//              (distance, then index): equal distances need no second pass.
-//   rows       the sorted indices go back to LDS as rows and leave as contiguous runs
+// The kernels above spend two thirds of their time after the tests: hit masks are decoded (43 - 48 VALU instructions per query:
+// the loops run as long as the longest list of a wave), keys are re-derived in a third mapping, and every hit is ranked by
+// counting the smaller keys of its query -- two instructions per (hit, key) pair, 43 per query (SQ counters per phase,
+// tools/radius_phase_counters.sh; a wave64 VALU instruction occupies its SIMD for four cycles: 1.6 M queries x 1 instruction
+// = 2.6 us of the whole chip).  Here nothing is decoded and nothing is ranked:
+//   tests      three threads per query (one per z-slab), candidates staged in LDS planes, four per step with packed math as
+//              before -- but a hit is APPENDED on the spot: its plane position (16 bits) goes to the thread's own list under
+//              the hit's exec mask (one ds_write_b16 per candidate step, three VALU instructions for the cursor)
+//   sort       ONE THREAD PER QUERY (the workgroup's first wave) walks the three lists of its query into 32 register pairs
+//              (distance bits << 32 | support index, recomputed from the planes: same arithmetic, same bits) and runs Batcher's
+//              odd-even merge sort network on them (191 compare-exchanges): every lane a different query -- no divergence, no
+//              LDS traffic.  The order of the words IS the reference's order (distance, then index).
+//   rows       the sorted indices go to LDS as rows and leave as contiguous runs
 //   the rest   queries with more than 32 hits (1 % at 21 expected neighbours) are finished by HALF A WAVE each on the waves
-//              that do not sort: lane = hit, k-th set bit of the masks by a branch-free binary search on popcounts, rank by
-//              counting over the half-wave's key scratch (every lane reads the same addresses: LDS broadcast).  A workgroup
-//              whose candidates do not fit the planes, or with a thread of more than 128 enumeration slots, takes the same
-//              half-wave path for all its queries with the candidates read from global memory (slow, rare, in place).
-// Modes: COUNT (tests -> masks to global memory, per-block maximum), FILL (masks from global memory -> rows), FUSED (both in
-// one launch, for a width known before the launch).  Only a query with more than Q2_KCAP hits makes the caller repeat the call
-// on the kernels above (flag in blk_stats).
+//              that do not sort: lanes = candidates of the query's nine ranges read from global memory, hits compacted by
+//              ballot, ranked by counting over the half-wave's key scratch (every lane reads the same addresses: LDS
+//              broadcast).  A workgroup whose candidates do not fit the planes takes that path for all its queries.
+// Modes: COUNT (tests only -> per-block maximum) and FUSED (the whole search for a width known before the launch); the
+// two-call radius_neighbors runs COUNT, reads the width back and runs FUSED.  Only a query with more than Q2_KCAP hits makes
+// the caller repeat the call on the kernels above (flag in blk_stats).
 constexpr int Q2_RQ = 64;      // queries per workgroup (three threads each)
 constexpr int Q2_KCAP = 128;   // hits of one query the key scratch of a half-wave holds
 constexpr int Q2_KR = Q2_KCAP / 32;
-constexpr int Q2_NET = 32;     // hits of one query the sorting network takes
+constexpr int Q2_NET = 32;     // hits of one query the sorting network takes; also the capacity of a thread's position list
 constexpr int Q2_NET_CE = 191;
-constexpr int Q2_WMAX = 64;    // widest row staged in LDS
-constexpr int Q2_COUNT = 0, Q2_FILL = 1, Q2_FUSED = 2;
+constexpr int Q2_WMAX = 48;    // widest row staged in LDS (the row buffer takes the planes' 12 KB)
+constexpr int Q2_COUNT = 0, Q2_FUSED = 2;
 static constexpr unsigned char Q2_NET_PAIRS[Q2_NET_CE][2] = {
     {0, 1}, {2, 3}, {0, 2}, {1, 3}, {1, 2}, {4, 5}, {6, 7}, {4, 6}, {5, 7}, {5, 6}, {0, 4}, {2, 6},
     {2, 4}, {1, 5}, {3, 7}, {3, 5}, {1, 2}, {3, 4}, {5, 6}, {8, 9}, {10, 11}, {8, 10}, {9, 11}, {9, 10},
@@ -1578,35 +1577,18 @@ struct Q2Lds {
   static constexpr int NH = THREADS / 32;  // half-waves
   static constexpr int TABLE_MAX = 256;
   static constexpr size_t QBUF_OFF = 160;  // ints: band_lo[9] band_hi[9] band_base[10] misc[4]
-  static constexpr size_t RECA_OFF = QBUF_OFF + (size_t)RQ * 16;         // per thread: masks of bands 0 + 1 (even, odd), of band 2
-  static constexpr size_t RECB_OFF = RECA_OFF + (size_t)THREADS * 16;    // per thread: plane bases of the three bands, step counts
-  static constexpr size_t QTOT_OFF = RECB_OFF + (size_t)THREADS * 16;    // hits per query, then the list of the half-wave queries
-  static constexpr size_t KEYS_OFF = QTOT_OFF + (size_t)RQ * 8;          // key + index scratch of the half-waves of waves 1, 2
-  static constexpr size_t LIST_OFF = KEYS_OFF + (size_t)(NH - 2) * Q2_KCAP * 8;
-  // [RQ][Q2_NET] 8-byte words, later the row buffer; a workgroup on the slow path keeps its ranges and six scratches here
-  static constexpr size_t LIST_BYTES = (size_t)RQ * Q2_NET * 8;
-  static constexpr size_t STAGE_OFF = LIST_OFF + LIST_BYTES;
-  static_assert((size_t)THREADS * 24 + (size_t)NH * Q2_KCAP * 8 <= LIST_BYTES, "slow-path ranges + scratch live in the list area");
-  static_assert((size_t)RQ * Q2_WMAX * 4 <= LIST_BYTES, "the row buffer takes the lists' place");
+  static constexpr size_t RNG_OFF = QBUF_OFF + (size_t)RQ * 16;          // [3][THREADS] candidate ranges (global positions)
+  static constexpr size_t CNT_OFF = RNG_OFF + (size_t)THREADS * 24;      // hits per thread, hits per query, half-wave queries
+  static constexpr size_t KEYS_OFF = CNT_OFF + (size_t)THREADS * 4 + (size_t)RQ * 8;  // key + index scratch of the half-waves
+  static constexpr size_t PLIST_OFF = KEYS_OFF + (size_t)NH * Q2_KCAP * 8;            // [THREADS][Q2_NET] plane positions
+  static constexpr size_t STAGE_OFF = PLIST_OFF + (size_t)THREADS * Q2_NET * 2;       // planes; later the row buffer
+  static_assert((size_t)RQ * Q2_WMAX * 4 <= (size_t)STAGE_CAP * 16, "the row buffer takes the planes' place");
   static size_t tables_bytes(int tcap) { return tcap > 0 ? ((size_t)(tcap + 1) * 4 + 15) / 16 * 16 + (size_t)tcap * sizeof(BatchGrid) : 0; }
   static size_t total(int tcap) {  // the per-cloud tables of the set-up lie where the candidate planes go afterwards
     const size_t st = (size_t)STAGE_CAP * 16 + 16, tb = tables_bytes(tcap);
     return STAGE_OFF + (st > tb ? st : tb);
   }
 };
-
-// position (from the least significant end) of the k-th set bit of x, k < popcount(x): five compare / select levels
-__device__ __forceinline__ int kth_set_bit32(unsigned x, int k) {
-  int b = 0;
-#pragma unroll
-  for (int w = 16; w >= 1; w >>= 1) {
-    const int t = __popc((x >> b) & ((1u << w) - 1u));
-    const bool up = k >= t;
-    k -= up ? t : 0;
-    b += up ? w : 0;
-  }
-  return b;
-}
 
 // sum over the 32 lanes of each half of the wave, valid in every lane of the half
 __device__ __forceinline__ int half_wave_sum(int v) {
@@ -1619,31 +1601,13 @@ __device__ __forceinline__ int half_wave_sum(int v) {
   return (threadIdx.x & 32) ? b : a;
 }
 
-// Masks of one (query, slab) thread.  Register pair A = bands 0 and 1 (dy = -1, 0), pair B = band 2; in each pair the even
-// candidates of the thread's enumeration are shifted into .lo, the odd ones into .hi: after S steps bit q of a register holds
-// enumeration slot 2 (2 S - 1 - q) (+ 1 on the odd side).  Bases: plane position of slot c = c + base of its band.
-struct Q2Rec {
-  unsigned a_lo, a_hi, b_lo, b_hi;
-  int s0, s1, s2;      // band bases, already shifted by the band's first slot
-  unsigned meta;       // 4 nit0 | (2 (nit0 + nit1) - 1) << 8 | (2 nit2 - 1) << 16   (the tops are -1 when a pair is empty: 0xff)
-};
-__device__ __forceinline__ int q2_count(const uint4 m) { return __popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w); }
-// plane position of the hit behind bit `qbit` of register `word` (0 a_lo, 1 a_hi, 2 b_lo, 3 b_hi)
-__device__ __forceinline__ int q2_plane_pos(int word, int qbit, const int4 rb) {
-  const unsigned meta = (unsigned)rb.w;
-  const int c1 = (int)(meta & 0xffu), top_a = (int)((meta >> 8) & 0xffu), top_b = (int)((meta >> 16) & 0xffu);
-  const bool pair_b = word >= 2;
-  const int c = 2 * ((pair_b ? top_b : top_a) - qbit) + (word & 1);
-  return c + (pair_b ? rb.z : (c < c1 ? rb.x : rb.y));
-}
-
 template <int MODE>
 __global__ __launch_bounds__(NSUB* Q2_RQ) void q2_kernel(
     const float4* __restrict__ sorted_q, int nq, const int32_t* __restrict__ q_off, int nb,
     const BatchGrid* __restrict__ grids, const int32_t* __restrict__ start_s, const float4* __restrict__ sorted_s, int ns_total,
-    float r2, uint4* __restrict__ g_mask, int32_t* __restrict__ blk_stats, int width, int row_stride, int64_t pad_value,
+    float r2, int32_t* __restrict__ blk_stats, int width, int row_stride, int64_t pad_value,
     int64_t* __restrict__ out, int mono, int dbg_stop) {
-  // dbg_stop (GR_RADIUS_Q2_STOP, measurement only): leave after 1 set-up, 2 staging, 3 tests, 4 decode, 5 sort
+  // dbg_stop (GR_RADIUS_Q2_STOP, measurement only): leave after 1 set-up, 2 staging, 3 tests, 5 sort
   using L = Q2Lds;
   constexpr int RQ = Q2_RQ;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1652,17 +1616,16 @@ __global__ __launch_bounds__(NSUB* Q2_RQ) void q2_kernel(
   int* band_base = band_hi + NBAND;
   int* misc = band_base + NBAND + 1;  // [0] largest hit count of a query, [1] a query beyond Q2_KCAP, [2] half-wave queries, [3] slow path
   float4* qbuf = reinterpret_cast<float4*>(smem + L::QBUF_OFF);
-  uint4* recA = reinterpret_cast<uint4*>(smem + L::RECA_OFF);
-  int4* recB = reinterpret_cast<int4*>(smem + L::RECB_OFF);
-  int* qtot = reinterpret_cast<int*>(smem + L::QTOT_OFF);
+  int2* rng = reinterpret_cast<int2*>(smem + L::RNG_OFF);
+  int* tcnt = reinterpret_cast<int*>(smem + L::CNT_OFF);   // hits per thread
+  int* qtot = tcnt + L::THREADS;                           // hits per query
   int* biglist = qtot + RQ;
-  unsigned long long* lists = reinterpret_cast<unsigned long long*>(smem + L::LIST_OFF);
-  unsigned int* rowbuf = reinterpret_cast<unsigned int*>(smem + L::LIST_OFF);  // takes the lists' place after the sort
-  int2* slow_rng = reinterpret_cast<int2*>(smem + L::LIST_OFF);                // slow path: [3][THREADS] candidate ranges
+  unsigned short* plist = reinterpret_cast<unsigned short*>(smem + L::PLIST_OFF);
   float* sx = reinterpret_cast<float*>(smem + L::STAGE_OFF);
   float* sy = sx + L::STAGE_CAP;
   float* sz = sy + L::STAGE_CAP;
   int* si = reinterpret_cast<int*>(sz + L::STAGE_CAP);
+  unsigned int* rowbuf = reinterpret_cast<unsigned int*>(smem + L::STAGE_OFF);  // takes the planes' place after the sort
   const int tcap = nb <= L::TABLE_MAX ? nb : 0;
   int* s_qoff = reinterpret_cast<int*>(smem + L::STAGE_OFF);
   BatchGrid* s_grids = reinterpret_cast<BatchGrid*>(smem + L::STAGE_OFF + ((size_t)(tcap + 1) * 4 + 15) / 16 * 16);
@@ -1692,8 +1655,6 @@ __global__ __launch_bounds__(NSUB* Q2_RQ) void q2_kernel(
   }
   float4 qp = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
   if (valid) qp = sorted_q[t];
-  uint4 gm = make_uint4(0u, 0u, 0u, 0u);
-  if (MODE == Q2_FILL && valid) gm = g_mask[(int64_t)j * nq + t];  // requested now, used after the staging
   __syncthreads();
   int p0[3] = {0, 0, 0}, p1[3] = {0, 0, 0};
   if (valid) {
@@ -1725,6 +1686,8 @@ __global__ __launch_bounds__(NSUB* Q2_RQ) void q2_kernel(
     }
   }
   if (j == 0) qbuf[slot] = qp;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) rng[i * L::THREADS + tid] = make_int2(p0[i], p1[i]);
   if (dbg_stop == 1) {
     if (p0[0] + p1[2] == 0x7fffffff) blk_stats[2 * blk] = tid;
     return;
@@ -1761,8 +1724,8 @@ __global__ __launch_bounds__(NSUB* Q2_RQ) void q2_kernel(
     band_base[NBAND] = acc;
   }
   __syncthreads();
-  const bool staged = band_base[NBAND] <= L::STAGE_CAP;
-  if (staged) {
+  const bool slow = band_base[NBAND] > L::STAGE_CAP;  // the candidates do not fit the planes: every query through a half-wave
+  if (!slow) {
     // wave w copies bands w, w + NWV, ...; every load of a wave is issued before its first LDS write, on clamped indices
     constexpr int NWV = L::THREADS / WAVE, KMAX = (NBAND + NWV - 1) / NWV, UNR = 2;
     const int wvi = tid / WAVE;
@@ -1804,242 +1767,160 @@ __global__ __launch_bounds__(NSUB* Q2_RQ) void q2_kernel(
       }
     }
   }
+  __syncthreads();
   if (dbg_stop == 2) {
-    __syncthreads();
     if ((int)sx[tid] == 0x7fffffff) blk_stats[2 * blk] = tid;
     return;
   }
-  // ---- tests, four candidates per step; hits are the sign bits of (distance bits - r2 bits), shifted into 32-bit registers
-  unsigned m_lo[2] = {0u, 0u}, m_hi[2] = {0u, 0u};
-  int rel[3] = {0, 0, 0};
-  if (staged) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) rel[i] = band_base[3 * j + i] - band_lo[3 * j + i];
-  }
-  const int len0 = p1[0] - p0[0], len1 = p1[1] - p0[1], len2 = p1[2] - p0[2];
-  const int nit0 = (len0 + 3) >> 2, nit1 = (len1 + 3) >> 2, nit2 = (len2 + 3) >> 2;
-  const bool by_mask = staged && nit0 + nit1 <= 16 && nit2 <= 16;
-  if (valid && !by_mask) misc[3] = 1;  // (benign race: everybody stores 1)
-  const unsigned r2b = r2 == r2 ? __float_as_uint(r2) : 0u;  // NaN radius: nothing is a neighbour
-  __syncthreads();  // planes complete; the slow-path flag is final
-  const bool slow = misc[3] != 0;
-  if (MODE == Q2_FILL) {
-    m_lo[0] = gm.x, m_hi[0] = gm.y, m_lo[1] = gm.z, m_hi[1] = gm.w;
-  } else if (valid && !slow) {
+  // ---- tests, four candidates per step.  A hit (sign bit of distance bits - r2 bits) appends its plane position to the
+  //      thread's list, under the hit's exec mask; the count keeps running past the list's capacity (such a query has more
+  //      than Q2_NET hits and is not the network's anyway)
+  int n = 0;
+  if (valid && !slow) {
+    const unsigned r2b = r2 == r2 ? __float_as_uint(r2) : 0u;  // NaN radius: nothing is a neighbour
     const f32x2 qx = {qp.x, qp.x}, qy = {qp.y, qp.y}, qz = {qp.z, qp.z};
+    unsigned short* my = plist + tid * Q2_NET;
+    auto step4 = [&](int p, int left) {  // left >= 4 except in a band's last step (the reads past the band stay inside the planes)
+      const f32x2 xa = {sx[p], sx[p + 1]}, xb = {sx[p + 2], sx[p + 3]};
+      const f32x2 ya = {sy[p], sy[p + 1]}, yb = {sy[p + 2], sy[p + 3]};
+      const f32x2 za = {sz[p], sz[p + 1]}, zb = {sz[p + 2], sz[p + 3]};
+      // nanoflann.hpp:432-440: result += diff*diff for x, y, z starting from 0 (two candidates per op)
+      const f32x2 dxa = qx - xa, dya = qy - ya, dza = qz - za;
+      const f32x2 dxb = qx - xb, dyb = qy - yb, dzb = qz - zb;
+      const f32x2 da = (dxa * dxa + dya * dya) + dza * dza;
+      const f32x2 db = (dxb * dxb + dyb * dyb) + dzb * dzb;
+      const bool h0 = (int)(__float_as_uint(da.x) - r2b) < 0;
+      const bool h1 = left >= 2 && (int)(__float_as_uint(da.y) - r2b) < 0;
+      const bool h2 = left >= 3 && (int)(__float_as_uint(db.x) - r2b) < 0;
+      const bool h3 = left >= 4 && (int)(__float_as_uint(db.y) - r2b) < 0;
+      if (MODE != Q2_COUNT) {
+        if (h0 && n < Q2_NET) my[n] = (unsigned short)p;
+        n += h0 ? 1 : 0;
+        if (h1 && n < Q2_NET) my[n] = (unsigned short)(p + 1);
+        n += h1 ? 1 : 0;
+        if (h2 && n < Q2_NET) my[n] = (unsigned short)(p + 2);
+        n += h2 ? 1 : 0;
+        if (h3 && n < Q2_NET) my[n] = (unsigned short)(p + 3);
+        n += h3 ? 1 : 0;
+      } else {
+        n += (h0 ? 1 : 0) + (h1 ? 1 : 0) + (h2 ? 1 : 0) + (h3 ? 1 : 0);
+      }
+    };
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      unsigned lo = m_lo[i >> 1], hi = m_hi[i >> 1];
-      auto step4 = [&](int p, int left) {  // left >= 4 except in a band's last step (the reads past the band stay inside the planes)
-        const f32x2 xa = {sx[p], sx[p + 1]}, xb = {sx[p + 2], sx[p + 3]};
-        const f32x2 ya = {sy[p], sy[p + 1]}, yb = {sy[p + 2], sy[p + 3]};
-        const f32x2 za = {sz[p], sz[p + 1]}, zb = {sz[p + 2], sz[p + 3]};
-        // nanoflann.hpp:432-440: result += diff*diff for x, y, z starting from 0 (two candidates per op)
-        const f32x2 dxa = qx - xa, dya = qy - ya, dza = qz - za;
-        const f32x2 dxb = qx - xb, dyb = qy - yb, dzb = qz - zb;
-        const f32x2 da = (dxa * dxa + dya * dya) + dza * dza;
-        const f32x2 db = (dxb * dxb + dyb * dyb) + dzb * dzb;
-        const unsigned t0 = __float_as_uint(da.x) - r2b;
-        const unsigned t1 = left >= 2 ? __float_as_uint(da.y) - r2b : 0u;
-        const unsigned t2 = left >= 3 ? __float_as_uint(db.x) - r2b : 0u;
-        const unsigned t3 = left >= 4 ? __float_as_uint(db.y) - r2b : 0u;
-        lo = __builtin_amdgcn_alignbit(lo, t0, 31);  // (lo << 1) | sign(t0)
-        lo = __builtin_amdgcn_alignbit(lo, t2, 31);
-        hi = __builtin_amdgcn_alignbit(hi, t1, 31);
-        hi = __builtin_amdgcn_alignbit(hi, t3, 31);
-      };
-      int p = p0[i] + rel[i];
-      const int e = p1[i] + rel[i];
+      int p = p0[i] + (band_base[3 * j + i] - band_lo[3 * j + i]);
+      const int e = p + (p1[i] - p0[i]);
       for (; p + 4 <= e; p += 4) step4(p, 4);
       if (p < e) step4(p, e - p);
-      m_lo[i >> 1] = lo, m_hi[i >> 1] = hi;
     }
   }
+  tcnt[tid] = n;
   if (dbg_stop == 3) {
-    if ((m_lo[0] ^ m_hi[1]) == 0x12345u) blk_stats[2 * blk] = tid;
+    if (n == 0x12345) blk_stats[2 * blk] = tid;
     return;
-  }
-  if (MODE == Q2_COUNT && valid && !slow) g_mask[(int64_t)j * nq + t] = make_uint4(m_lo[0], m_hi[0], m_lo[1], m_hi[1]);
-  {
-    const int c1 = 4 * nit0;
-    recA[tid] = make_uint4(m_lo[0], m_hi[0], m_lo[1], m_hi[1]);
-    recB[tid] = make_int4(p0[0] + rel[0], p0[1] + rel[1] - c1, p0[2] + rel[2],
-                          (int)((unsigned)(c1 & 0xff) | ((unsigned)((2 * (nit0 + nit1) - 1) & 0xff) << 8) |
-                                ((unsigned)((2 * nit2 - 1) & 0xff) << 16)));
-  }
-  if (slow) {  // the half-waves below read the candidates from global memory: they need every thread's ranges
-#pragma unroll
-    for (int i = 0; i < 3; ++i) slow_rng[i * L::THREADS + tid] = make_int2(p0[i], p1[i]);
   }
   __syncthreads();
-  // ---- hits per query (normal path: from the masks)
-  int n_before = 0, tot = 0;
-  if (!slow) {
-#pragma unroll
-    for (int i = 0; i < NSUB; ++i) {
-      const int c = q2_count(recA[i * RQ + slot]);
-      n_before += i < j ? c : 0;
-      tot += c;
-    }
-  }
-  if (MODE == Q2_COUNT && !slow) {
-    const int mx = wave_max_i32_dpp(valid ? tot : 0);
-    if (lane == 0) atomicMax(&misc[0], mx);
-    __syncthreads();
-    if (tid == 0) {
-      blk_stats[2 * blk] = misc[0];
-      blk_stats[2 * blk + 1] = misc[0] > Q2_KCAP ? 1 : 0;
-    }
-    return;
-  }
   int my_tot = 0;  // threads of wave 0: hits of query `tid` if the network takes it
-  if (!slow) {
-    // ---- decode by the threads that own the masks: (distance, index) words into the query's list; thread j starts behind
-    //      the hits of the slabs before it
+  if (!slow && tid < RQ) {
+    const int c0 = tcnt[tid], c1 = tcnt[RQ + tid], c2 = tcnt[2 * RQ + tid];
+    const int tot = c0 + c1 + c2;
     const bool netq = valid && tot <= Q2_NET;
-    if (j == 0) {
-      my_tot = netq ? tot : 0;
-      qtot[slot] = valid ? tot : 0;
-      if (valid && !netq) biglist[atomicAdd(&misc[2], 1)] = slot;
-    }
-    if (netq && MODE != Q2_COUNT) {
-      const uint4 a = recA[tid];
-      const int4 rb = recB[tid];
-      unsigned long long* dst = lists + slot * Q2_NET + n_before;
-      const f32x2 qx = {qp.x, qp.x}, qy = {qp.y, qp.y}, qz = {qp.z, qp.z};
+    qtot[tid] = valid ? tot : 0;
+    if (valid && !netq) biglist[atomicAdd(&misc[2], 1)] = tid;
+    my_tot = netq ? tot : 0;
+    if (MODE != Q2_COUNT) {
+      // ---- thread = query: the three position lists of the query -> 32 register pairs (distance bits << 32 | index; slots past
+      //      the hit count hold a word larger than any real one), through the sorting network, back as the row
+      unsigned long long k[Q2_NET];
+      const unsigned short* l0 = plist + tid * Q2_NET;
+      const unsigned short* l1 = plist + (RQ + tid) * Q2_NET - c0;
+      const unsigned short* l2 = plist + (2 * RQ + tid) * Q2_NET - (c0 + c1);
 #pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
-        unsigned ml = pr ? a.z : a.x, mh = pr ? a.w : a.y;
-        while (ml | mh) {  // one hit of the even and one of the odd side per step
-          const int qa = 31 - __clz((int)ml), qb = 31 - __clz((int)mh);  // -1: none left on that side
-          ml &= ~(qa >= 0 ? 1u << qa : 0u);
-          mh &= ~(qb >= 0 ? 1u << qb : 0u);
-          const int pa = q2_plane_pos(2 * pr, max(qa, 0), rb), pb = q2_plane_pos(2 * pr + 1, max(qb, 0), rb);
-          const f32x2 dx = qx - f32x2{sx[pa], sx[pb]}, dy = qy - f32x2{sy[pa], sy[pb]}, dz = qz - f32x2{sz[pa], sz[pb]};
-          const f32x2 d = (dx * dx + dy * dy) + dz * dz;  // same arithmetic as the test: same bits
-          const unsigned long long ka = ((unsigned long long)__float_as_uint(d.x) << 32) | (unsigned int)si[pa];
-          const unsigned long long kb = ((unsigned long long)__float_as_uint(d.y) << 32) | (unsigned int)si[pb];
-          if (qa >= 0) *dst++ = ka;
-          if (qb >= 0) *dst++ = kb;
+      for (int i = 0; i < Q2_NET; ++i) {
+        const unsigned short* src = i < c0 ? l0 : (i < c0 + c1 ? l1 : l2);
+        const int p = i < my_tot ? (int)src[i] : 0;
+        const float dx = qp.x - sx[p], dy = qp.y - sy[p], dz = qp.z - sz[p];
+        const float d = (dx * dx + dy * dy) + dz * dz;  // same arithmetic as the test: same bits
+        k[i] = i < my_tot ? ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)si[p] : ~0ull;
+      }
+      if (__any(my_tot > 1)) {
+#pragma unroll
+        for (int c = 0; c < Q2_NET_CE; ++c) {
+          const unsigned long long a = k[Q2_NET_PAIRS[c][0]], b = k[Q2_NET_PAIRS[c][1]];
+          const bool sw = b < a;
+          k[Q2_NET_PAIRS[c][0]] = sw ? b : a;
+          k[Q2_NET_PAIRS[c][1]] = sw ? a : b;
         }
       }
-    }
-    __syncthreads();
-    if (dbg_stop == 4) return;
-  }
-  if (!slow && tid < RQ) {
-    // ---- wave 0: thread = query.  The list (padded with words larger than any real one) goes into registers, through the
-    //      sorting network, and comes back as the row: indices in rising (distance, index) order, then the padding value.
-    unsigned long long k[Q2_NET];
-    const unsigned long long* src = lists + tid * Q2_NET;
+      if (dbg_stop == 5) {
+        if (k[0] == 0x12345ull) blk_stats[0] = 1;
+        return;
+      }
+      // the planes stay live for this wave only up to here; the half-waves below read global memory: once every lane of
+      // this wave has its words in registers ...
+      __builtin_amdgcn_wave_barrier();
+      if (tid < rows_here) {  // ... the planes' place becomes the row buffer
+        unsigned int* rrow = rowbuf + tid * width;
 #pragma unroll
-    for (int i = 0; i < Q2_NET; ++i) k[i] = i < my_tot ? src[i] : ~0ull;
-    if (__any(my_tot > 1)) {
-#pragma unroll
-      for (int c = 0; c < Q2_NET_CE; ++c) {
-        const unsigned long long a = k[Q2_NET_PAIRS[c][0]], b = k[Q2_NET_PAIRS[c][1]];
-        const bool sw = b < a;
-        k[Q2_NET_PAIRS[c][0]] = sw ? b : a;
-        k[Q2_NET_PAIRS[c][1]] = sw ? a : b;
+        for (int i = 0; i < Q2_NET; ++i)
+          if (i < width) rrow[i] = i < my_tot ? (unsigned int)k[i] : 0xffffffffu;
+        for (int i = Q2_NET; i < width; ++i) rrow[i] = 0xffffffffu;
       }
     }
-    if (dbg_stop == 5) {
-      if (k[0] == 0x12345ull) blk_stats[0] = 1;
-      return;
-    }
-    // (every lane of this wave has its list in registers: the lists' place becomes the row buffer)
-    if (tid < rows_here) {
-      unsigned int* rrow = rowbuf + tid * width;
-#pragma unroll
-      for (int i = 0; i < Q2_NET; ++i)
-        if (i < width) rrow[i] = i < my_tot ? (unsigned int)k[i] : 0xffffffffu;
-      for (int i = Q2_NET; i < width; ++i) rrow[i] = 0xffffffffu;
-    }
   }
-  // ---- one half-wave per query: the queries the network does not take (waves 1, 2), or all of them (slow path, every wave)
+  if (!slow && tid >= RQ) __builtin_amdgcn_s_sleep(1);
+  // ---- one half-wave per query: the queries the network does not take (waves 1, 2), or all of them (slow path, every wave):
+  //      the nine candidate ranges of the query straight from global memory, 32 candidates per step, hits compacted behind
+  //      each other by the half-wave's ballot, ranked by counting
   const int hw = slow ? tid >> 5 : (tid >> 5) - 2, l = tid & 31;
   const int nhw = slow ? L::NH : L::NH - 2;
-  unsigned* ks = slow ? reinterpret_cast<unsigned*>(smem + L::LIST_OFF + (size_t)L::THREADS * 24) + max(hw, 0) * 2 * Q2_KCAP
-                      : reinterpret_cast<unsigned*>(smem + L::KEYS_OFF) + max(hw, 0) * 2 * Q2_KCAP;
+  unsigned* ks = reinterpret_cast<unsigned*>(smem + L::KEYS_OFF) + max(hw, 0) * 2 * Q2_KCAP;
   unsigned* is = ks + Q2_KCAP;
   int hmax = my_tot;
+  if (!slow && tid >= RQ) {  // (the list of the half-wave queries is complete once wave 0 has passed its atomics)
+    // nothing: misc[2] / biglist are read after the barrier below
+  }
+  __syncthreads();
   const int n_items = slow ? rows_here : misc[2];
+  const unsigned long long half = (tid & 32) ? 0xffffffff00000000ull : 0x00000000ffffffffull;
   for (int item = hw; hw >= 0 && item < n_items; item += nhw) {
     const int r = slow ? item : biglist[item];
     const float4 qq = qbuf[r];
     int64_t* const row = out + (int64_t)__float_as_int(qq.w) * row_stride;
-    unsigned dk[Q2_KR], ix[Q2_KR];
     int htot = 0;
-    if (!slow) {
-      const uint4 a0 = recA[r], a1 = recA[RQ + r], a2 = recA[2 * RQ + r];
-      const int c0 = q2_count(a0), c1 = q2_count(a1), c2 = q2_count(a2);
-      htot = c0 + c1 + c2;
-      hmax = max(hmax, htot);
-      if (htot > Q2_KCAP) {
-        misc[1] = 1;
-        continue;
-      }
-#pragma unroll
-      for (int rd = 0; rd < Q2_KR; ++rd) {
-        dk[rd] = 0x7fffffffu;
-        ix[rd] = 0u;
-        if (rd * 32 < htot) {
-          const int k = rd * 32 + l;
-          if (k < htot) {
-            const bool g1 = k >= c0, g2 = k >= c0 + c1;
-            int kk = k - (g2 ? c0 + c1 : (g1 ? c0 : 0));
-            const uint4 m = g2 ? a2 : (g1 ? a1 : a0);
-            const int4 rb = recB[(g2 ? 2 : (g1 ? 1 : 0)) * RQ + r];
-            const int n0 = __popc(m.x), n1 = __popc(m.y), n2 = __popc(m.z);
-            const int word = (kk >= n0) + (kk >= n0 + n1) + (kk >= n0 + n1 + n2);
-            kk -= word == 0 ? 0 : (word == 1 ? n0 : (word == 2 ? n0 + n1 : n0 + n1 + n2));
-            const unsigned mw = word == 0 ? m.x : (word == 1 ? m.y : (word == 2 ? m.z : m.w));
-            const int p = q2_plane_pos(word, kth_set_bit32(mw, kk), rb);
-            const float dx = qq.x - sx[p], dy = qq.y - sy[p], dz = qq.z - sz[p];
-            const float d = (dx * dx + dy * dy) + dz * dz;
-            dk[rd] = __float_as_uint(d);  // d >= 0: the bit pattern orders like the value
-            ix[rd] = (unsigned)si[p];
-          }
-          ks[k] = dk[rd];
+    for (int band = 0; band < NBAND; ++band) {
+      const int2 rg = rng[(band % 3) * L::THREADS + (band / 3) * RQ + r];
+      for (int pbase = rg.x; pbase < rg.y; pbase += 32) {
+        const int p = pbase + l;
+        const float4 sp = sorted_s[min(p, ns_total - 1)];
+        const float dx = qq.x - sp.x, dy = qq.y - sp.y, dz = qq.z - sp.z;
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        const bool hit = p < rg.y && d < r2;
+        const unsigned long long bal = __ballot(hit) & half;
+        const int pos = htot + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+        if (hit && pos < Q2_KCAP) {
+          ks[pos] = __float_as_uint(d);
+          is[pos] = (unsigned)__float_as_int(sp.w);
         }
+        htot += __popcll(bal);
       }
-    } else {
-      // slow path: the nine candidate ranges of the query straight from global memory, 32 candidates per step, hits
-      // compacted behind each other by the half-wave's ballot
-      const unsigned long long half = (tid & 32) ? 0xffffffff00000000ull : 0x00000000ffffffffull;
-      for (int band = 0; band < NBAND; ++band) {
-        const int2 rg = slow_rng[(band % 3) * L::THREADS + (band / 3) * RQ + r];
-        for (int pbase = rg.x; pbase < rg.y; pbase += 32) {
-          const int p = pbase + l;
-          const float4 sp = sorted_s[min(p, ns_total - 1)];
-          const float dx = qq.x - sp.x, dy = qq.y - sp.y, dz = qq.z - sp.z;
-          const float d = (dx * dx + dy * dy) + dz * dz;
-          const bool hit = p < rg.y && d < r2;
-          const unsigned long long bal = __ballot(hit) & half;
-          const int pos = htot + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
-          if (hit && pos < Q2_KCAP) {
-            ks[pos] = __float_as_uint(d);
-            is[pos] = (unsigned)__float_as_int(sp.w);
-          }
-          htot += __popcll(bal);
-        }
-      }
-      hmax = max(hmax, htot);
-      if (htot > Q2_KCAP) {
-        misc[1] = 1;
-        continue;
-      }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int rd = 0; rd < Q2_KR; ++rd) {
-        const int k = rd * 32 + l;
-        dk[rd] = k < htot ? ks[k] : 0x7fffffffu;
-        ix[rd] = k < htot ? is[k] : 0u;
-      }
-      __builtin_amdgcn_wave_barrier();
-      for (int k = htot + l; k < ((htot + 31) & ~31); k += 32) ks[k] = 0x7fffffffu;  // the rank loop reads whole quads
     }
-    if (MODE == Q2_COUNT) continue;  // (slow path of the counting launch: only the maximum is wanted)
+    hmax = max(hmax, htot);
+    if (htot > Q2_KCAP) {
+      misc[1] = 1;
+      continue;
+    }
+    if (MODE == Q2_COUNT) continue;  // only the maximum is wanted
+    __builtin_amdgcn_wave_barrier();
+    unsigned dk[Q2_KR], ix[Q2_KR];
+#pragma unroll
+    for (int rd = 0; rd < Q2_KR; ++rd) {
+      const int k = rd * 32 + l;
+      dk[rd] = k < htot ? ks[k] : 0x7fffffffu;
+      ix[rd] = k < htot ? is[k] : 0u;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int k = htot + l; k < ((htot + 31) & ~31); k += 32) ks[k] = 0x7fffffffu;  // the rank loop reads whole quads
     __builtin_amdgcn_wave_barrier();  // the segment is read by the other lanes of the half-wave (LDS executes a wave's
                                       // operations in order)
     int rk[Q2_KR];
@@ -2060,12 +1941,6 @@ __global__ __launch_bounds__(NSUB* Q2_RQ) void q2_kernel(
     for (int rd = 0; rd < Q2_KR; ++rd) rsum += (rd * 32 + l < htot) ? rk[rd] : 0;
     rsum = half_wave_sum(rsum);
     if (rsum != htot * (htot - 1) / 2) {
-      if (!slow) {
-#pragma unroll
-        for (int rd = 0; rd < Q2_KR; ++rd)
-          if (rd * 32 < htot) is[rd * 32 + l] = ix[rd];
-      }
-      __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int rd = 0; rd < Q2_KR; ++rd) {
         if (rd * 32 + l < htot) {
@@ -2222,12 +2097,11 @@ int launch_q2(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns,
   if (lds > 64 * 1024)
     GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   {
-    KernelTimer timer(MODE == Q2_COUNT ? "radius_count" : (MODE == Q2_FILL ? "radius_fill" : "radius_fused"), stream);
+    KernelTimer timer(MODE == Q2_COUNT ? "radius_count" : "radius_fused", stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(L::THREADS), lds, stream, sorted_q, (int)nq, w.q_off, nb, w.grids, start_s,
-                       w.sorted_s, (int)ns, r2, reinterpret_cast<uint4*>(w.q_mask), w.blk_stats, (int)width, (int)row_stride, ns,
-                       out, mono ? 1 : 0, q2_cfg().dbg_stop);
+                       w.sorted_s, (int)ns, r2, w.blk_stats, (int)width, (int)row_stride, ns, out, mono ? 1 : 0, q2_cfg().dbg_stop);
   }
-  if (MODE != Q2_FILL) hipLaunchKernelGGL(reduce_stats_kernel, dim3(1), dim3(1024), 0, stream, w.blk_stats, blocks, w.hdr);
+  hipLaunchKernelGGL(reduce_stats_kernel, dim3(1), dim3(1024), 0, stream, w.blk_stats, blocks, w.hdr);
   GR_LAUNCH_CHECK();
   return GR_OK;
 }
@@ -2523,7 +2397,7 @@ extern "C" int gr_radius_fill(const float* q, const float* s, int64_t nq, int64_
   const float r2 = radius * radius;
   if (h_info[1] == Q2_PLAN) {
     GR_REQUIRE(q2_fits(width, width), "radius_fill: width %lld exceeds the counted width", (long long)width);
-    return launch_q2<Q2_FILL>(w, sorted_q, nq, ns, (int)batch, w.start, r2, width, width, out, same, stream);
+    return launch_q2<Q2_FUSED>(w, sorted_q, nq, ns, (int)batch, w.start, r2, width, width, out, same, stream);
   }
   return launch_fill<RT>(w, sorted_q, nq, ns, (int)batch, r2, width, width, h_info[1], out, stream);
 }

@@ -60,7 +60,7 @@ def run(c):
 
 def main():
     if "--ablate" in sys.argv:
-        for stop in ("1", "2", "3", "4", "5", "0"):
+        for stop in ("1", "2", "3", "5", "0"):
             run({"GR_RADIUS_MODE": "2", "GR_RADIUS_Q2_STOP": stop})
         return
     for c in ({"GR_RADIUS_MODE": "0"}, {"GR_RADIUS_MODE": "1"}, {"GR_RADIUS_MODE": "2"}):
