@@ -124,7 +124,7 @@ RadiusWs carve(void* ws, int64_t nq, int64_t ns, int64_t batch) {
   w.q_count = c.take<int32_t>(3 * nq);
   w.q_rng = c.take<int2>(9 * nq);
   w.q_mask = c.take<unsigned long long>(3 * nq);
-  w.blk_stats = c.take<int32_t>(2 * ((nq + 63) / 64 + 8));  // the single-pass kernels run 64 queries per workgroup
+  w.blk_stats = c.take<int32_t>(2 * ((nq + 63) / 64 + 8));  // fused_kernel runs 64 queries per workgroup
   w.bytes = c.used();
   return w;
 }
@@ -1524,469 +1524,6 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
 #undef GR_FUSED_STOP
 }
 
-// ---------------------------------------------------------------- round 4: q2_kernel -- hits are SORTED, not ranked
-// The kernels above spend two thirds of their time after the tests: hit masks are decoded (43 - 48 VALU instructions per query:
-// the loops run as long as the longest list of a wave), keys are re-derived in a third mapping, and every hit is ranked by
-// counting the smaller keys of its query -- two instructions per (hit, key) pair, 43 per query (SQ counters per phase,
-// tools/radius_phase_counters.sh; a wave64 VALU instruction occupies its SIMD for four cycles: 1.6 M queries x 1 instruction
-// = 2.6 us of the whole chip).  Here nothing is decoded and nothing is ranked:
-//   tests      three threads per query (one per z-slab), candidates staged in LDS planes, four per step with packed math as
-//              before -- but a hit is APPENDED on the spot: its plane position (16 bits) goes to the thread's own list under
-//              the hit's exec mask (one ds_write_b16 per candidate step, three VALU instructions for the cursor)
-//   sort       ONE THREAD PER QUERY (the workgroup's first wave) walks the three lists of its query into 32 register pairs
-//              (distance bits << 32 | support index, recomputed from the planes: same arithmetic, same bits) and runs Batcher's
-//              odd-even merge sort network on them (191 compare-exchanges): every lane a different query -- no divergence, no
-//              LDS traffic.  The order of the words IS the reference's order (distance, then index).
-//   rows       the sorted indices go to LDS as rows and leave as contiguous runs
-//   the rest   queries with more than 32 hits (1 % at 21 expected neighbours) are finished by HALF A WAVE each on the waves
-//              that do not sort: lanes = candidates of the query's nine ranges read from global memory, hits compacted by
-//              ballot, ranked by counting over the half-wave's key scratch (every lane reads the same addresses: LDS
-//              broadcast).  A workgroup whose candidates do not fit the planes takes that path for all its queries.
-// Modes: COUNT (tests only -> per-block maximum) and FUSED (the whole search for a width known before the launch); the
-// two-call radius_neighbors runs COUNT, reads the width back and runs FUSED.  Only a query with more than Q2_KCAP hits makes
-// the caller repeat the call on the kernels above (flag in blk_stats).
-constexpr int Q2_RQ = 64;      // queries per workgroup (three threads each)
-constexpr int Q2_KCAP = 128;   // hits of one query the key scratch of a half-wave holds
-constexpr int Q2_KR = Q2_KCAP / 32;
-constexpr int Q2_NET = 32;     // hits of one query the sorting network takes; also the capacity of a thread's position list
-constexpr int Q2_NET_CE = 191;
-constexpr int Q2_WMAX = 48;    // widest row staged in LDS (the row buffer takes the planes' 12 KB)
-constexpr int Q2_COUNT = 0, Q2_FUSED = 2;
-static constexpr unsigned char Q2_NET_PAIRS[Q2_NET_CE][2] = {
-    {0, 1}, {2, 3}, {0, 2}, {1, 3}, {1, 2}, {4, 5}, {6, 7}, {4, 6}, {5, 7}, {5, 6}, {0, 4}, {2, 6},
-    {2, 4}, {1, 5}, {3, 7}, {3, 5}, {1, 2}, {3, 4}, {5, 6}, {8, 9}, {10, 11}, {8, 10}, {9, 11}, {9, 10},
-    {12, 13}, {14, 15}, {12, 14}, {13, 15}, {13, 14}, {8, 12}, {10, 14}, {10, 12}, {9, 13}, {11, 15}, {11, 13}, {9, 10},
-    {11, 12}, {13, 14}, {0, 8}, {4, 12}, {4, 8}, {2, 10}, {6, 14}, {6, 10}, {2, 4}, {6, 8}, {10, 12}, {1, 9},
-    {5, 13}, {5, 9}, {3, 11}, {7, 15}, {7, 11}, {3, 5}, {7, 9}, {11, 13}, {1, 2}, {3, 4}, {5, 6}, {7, 8},
-    {9, 10}, {11, 12}, {13, 14}, {16, 17}, {18, 19}, {16, 18}, {17, 19}, {17, 18}, {20, 21}, {22, 23}, {20, 22}, {21, 23},
-    {21, 22}, {16, 20}, {18, 22}, {18, 20}, {17, 21}, {19, 23}, {19, 21}, {17, 18}, {19, 20}, {21, 22}, {24, 25}, {26, 27},
-    {24, 26}, {25, 27}, {25, 26}, {28, 29}, {30, 31}, {28, 30}, {29, 31}, {29, 30}, {24, 28}, {26, 30}, {26, 28}, {25, 29},
-    {27, 31}, {27, 29}, {25, 26}, {27, 28}, {29, 30}, {16, 24}, {20, 28}, {20, 24}, {18, 26}, {22, 30}, {22, 26}, {18, 20},
-    {22, 24}, {26, 28}, {17, 25}, {21, 29}, {21, 25}, {19, 27}, {23, 31}, {23, 27}, {19, 21}, {23, 25}, {27, 29}, {17, 18},
-    {19, 20}, {21, 22}, {23, 24}, {25, 26}, {27, 28}, {29, 30}, {0, 16}, {8, 24}, {8, 16}, {4, 20}, {12, 28}, {12, 20},
-    {4, 8}, {12, 16}, {20, 24}, {2, 18}, {10, 26}, {10, 18}, {6, 22}, {14, 30}, {14, 22}, {6, 10}, {14, 18}, {22, 26},
-    {2, 4}, {6, 8}, {10, 12}, {14, 16}, {18, 20}, {22, 24}, {26, 28}, {1, 17}, {9, 25}, {9, 17}, {5, 21}, {13, 29},
-    {13, 21}, {5, 9}, {13, 17}, {21, 25}, {3, 19}, {11, 27}, {11, 19}, {7, 23}, {15, 31}, {15, 23}, {7, 11}, {15, 19},
-    {23, 27}, {3, 5}, {7, 9}, {11, 13}, {15, 17}, {19, 21}, {23, 25}, {27, 29}, {1, 2}, {3, 4}, {5, 6}, {7, 8},
-    {9, 10}, {11, 12}, {13, 14}, {15, 16}, {17, 18}, {19, 20}, {21, 22}, {23, 24}, {25, 26}, {27, 28}, {29, 30}};
-
-struct Q2Lds {
-  static constexpr int RQ = Q2_RQ;
-  static constexpr int THREADS = NSUB * RQ;
-  static constexpr int STAGE_CAP = 12 * RQ;
-  static constexpr int NH = THREADS / 32;  // half-waves
-  static constexpr int TABLE_MAX = 256;
-  static constexpr size_t QBUF_OFF = 160;  // ints: band_lo[9] band_hi[9] band_base[10] misc[4]
-  static constexpr size_t RNG_OFF = QBUF_OFF + (size_t)RQ * 16;          // [3][THREADS] candidate ranges (global positions)
-  static constexpr size_t CNT_OFF = RNG_OFF + (size_t)THREADS * 24;      // hits per thread, hits per query, half-wave queries
-  static constexpr size_t KEYS_OFF = CNT_OFF + (size_t)THREADS * 4 + (size_t)RQ * 8;  // key + index scratch of the half-waves
-  static constexpr size_t PLIST_OFF = KEYS_OFF + (size_t)NH * Q2_KCAP * 8;            // [THREADS][Q2_NET] plane positions
-  static constexpr size_t STAGE_OFF = PLIST_OFF + (size_t)THREADS * Q2_NET * 2;       // planes; later the row buffer
-  static_assert((size_t)RQ * Q2_WMAX * 4 <= (size_t)STAGE_CAP * 16, "the row buffer takes the planes' place");
-  static size_t tables_bytes(int tcap) { return tcap > 0 ? ((size_t)(tcap + 1) * 4 + 15) / 16 * 16 + (size_t)tcap * sizeof(BatchGrid) : 0; }
-  static size_t total(int tcap) {  // the per-cloud tables of the set-up lie where the candidate planes go afterwards
-    const size_t st = (size_t)STAGE_CAP * 16 + 16, tb = tables_bytes(tcap);
-    return STAGE_OFF + (st > tb ? st : tb);
-  }
-};
-
-// sum over the 32 lanes of each half of the wave, valid in every lane of the half
-__device__ __forceinline__ int half_wave_sum(int v) {
-  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
-  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
-  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
-  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
-  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3: lanes 31 / 63 hold the sums
-  const int a = __builtin_amdgcn_readlane(v, 31), b = __builtin_amdgcn_readlane(v, 63);
-  return (threadIdx.x & 32) ? b : a;
-}
-
-template <int MODE>
-__global__ __launch_bounds__(NSUB* Q2_RQ) void q2_kernel(
-    const float4* __restrict__ sorted_q, int nq, const int32_t* __restrict__ q_off, int nb,
-    const BatchGrid* __restrict__ grids, const int32_t* __restrict__ start_s, const float4* __restrict__ sorted_s, int ns_total,
-    float r2, int32_t* __restrict__ blk_stats, int width, int row_stride, int64_t pad_value,
-    int64_t* __restrict__ out, int mono, int dbg_stop) {
-  // dbg_stop (GR_RADIUS_Q2_STOP, measurement only): leave after 1 set-up, 2 staging, 3 tests, 5 sort
-  using L = Q2Lds;
-  constexpr int RQ = Q2_RQ;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int* band_lo = reinterpret_cast<int*>(smem);
-  int* band_hi = band_lo + NBAND;
-  int* band_base = band_hi + NBAND;
-  int* misc = band_base + NBAND + 1;  // [0] largest hit count of a query, [1] a query beyond Q2_KCAP, [2] half-wave queries, [3] slow path
-  float4* qbuf = reinterpret_cast<float4*>(smem + L::QBUF_OFF);
-  int2* rng = reinterpret_cast<int2*>(smem + L::RNG_OFF);
-  int* tcnt = reinterpret_cast<int*>(smem + L::CNT_OFF);   // hits per thread
-  int* qtot = tcnt + L::THREADS;                           // hits per query
-  int* biglist = qtot + RQ;
-  unsigned short* plist = reinterpret_cast<unsigned short*>(smem + L::PLIST_OFF);
-  float* sx = reinterpret_cast<float*>(smem + L::STAGE_OFF);
-  float* sy = sx + L::STAGE_CAP;
-  float* sz = sy + L::STAGE_CAP;
-  int* si = reinterpret_cast<int*>(sz + L::STAGE_CAP);
-  unsigned int* rowbuf = reinterpret_cast<unsigned int*>(smem + L::STAGE_OFF);  // takes the planes' place after the sort
-  const int tcap = nb <= L::TABLE_MAX ? nb : 0;
-  int* s_qoff = reinterpret_cast<int*>(smem + L::STAGE_OFF);
-  BatchGrid* s_grids = reinterpret_cast<BatchGrid*>(smem + L::STAGE_OFF + ((size_t)(tcap + 1) * 4 + 15) / 16 * 16);
-
-  const int tid = threadIdx.x;
-  const int slot = tid % RQ, j = tid / RQ;
-  const int nblk = (nq + RQ - 1) / RQ;
-  const int per_xcd = gridDim.x / 8;
-  const int blk = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;  // one contiguous eighth of the cell-ordered queries per XCD
-  if (blk >= nblk) return;
-  const int t = blk * RQ + slot;
-  const int lane = tid & (WAVE - 1);
-  const bool valid = t < nq;
-  const int rows_here = min(RQ, nq - blk * RQ);
-
-  if (tid < NBAND) {
-    band_lo[tid] = 0x7fffffff;
-    band_hi[tid] = 0;
-  }
-  if (tid < 4) misc[tid] = 0;
-  const bool tables_in_lds = tcap > 0;
-  if (tables_in_lds) {
-    for (int i = tid; i <= nb; i += L::THREADS) s_qoff[i] = q_off[i];
-    const int4* gsrc = reinterpret_cast<const int4*>(grids);
-    int4* gdst = reinterpret_cast<int4*>(s_grids);
-    for (int i = tid; i < nb * 4; i += L::THREADS) gdst[i] = gsrc[i];
-  }
-  float4 qp = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-  if (valid) qp = sorted_q[t];
-  __syncthreads();
-  int p0[3] = {0, 0, 0}, p1[3] = {0, 0, 0};
-  if (valid) {
-    int b;
-    BatchGrid g;
-    if (tables_in_lds) {
-      b = find_batch(s_qoff, nb, __float_as_int(qp.w));
-      g = s_grids[b];
-    } else {
-      b = find_batch(q_off, nb, __float_as_int(qp.w));
-      g = grids[b];
-    }
-    const double ux = cell_coord(qp.x, g.org[0], g.inv_cell_x), kx = (double)g.xk;
-    const double uy = cell_coord(qp.y, g.org[1], g.inv_cell);
-    const double cz = cell_coord(qp.z, g.org[2], g.inv_cell) + (double)(j - 1);
-    const double tx = (double)(g.dim[0] - 1), ty = (double)(g.dim[1] - 1), tz = (double)(g.dim[2] - 1);
-    if ((ux + kx >= 0.0) && (ux - kx <= tx) && cz >= 0.0 && cz <= tz) {  // NaN coordinates: no candidates
-      const int lx = (int)fmin(fmax(ux - kx, 0.0), tx);
-      const int hx = (int)fmin(fmax(ux + kx, 0.0), tx);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const double cy = uy + (double)(i - 1);
-        if (cy >= 0.0 && cy <= ty) {
-          const int base = g.cell_base + g.dim[0] * ((int)cy + g.dim[1] * (int)cz);
-          p0[i] = start_s[base + lx];
-          p1[i] = start_s[base + hx + 1];
-        }
-      }
-    }
-  }
-  if (j == 0) qbuf[slot] = qp;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) rng[i * L::THREADS + tid] = make_int2(p0[i], p1[i]);
-  if (dbg_stop == 1) {
-    if (p0[0] + p1[2] == 0x7fffffff) blk_stats[2 * blk] = tid;
-    return;
-  }
-  // ---- block-wide extent of every band (waves are slab-uniform: band index = 3*j + i)
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const bool has = p1[i] > p0[i];
-    int lo, hi;
-    if (mono) {  // self-search: ranges are non-decreasing along the wave
-      const unsigned long long m = __ballot(has);
-      lo = 0x7fffffff;
-      hi = 0;
-      if (m) {
-        lo = __builtin_amdgcn_readlane(p0[i], __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1));
-        hi = __builtin_amdgcn_readlane(p1[i], __builtin_amdgcn_readfirstlane(63 - __clzll((long long)m)));
-      }
-    } else {
-      lo = wave_min_i32_dpp(has ? p0[i] : 0x7fffffff);
-      hi = wave_max_i32_dpp(has ? p1[i] : 0);
-    }
-    if (lane == 0 && hi > 0) {
-      atomicMin(&band_lo[3 * j + i], lo);
-      atomicMax(&band_hi[3 * j + i], hi);
-    }
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int k = 0; k < NBAND; ++k) {
-      band_base[k] = acc;
-      acc += band_hi[k] > band_lo[k] ? band_hi[k] - band_lo[k] : 0;
-    }
-    band_base[NBAND] = acc;
-  }
-  __syncthreads();
-  const bool slow = band_base[NBAND] > L::STAGE_CAP;  // the candidates do not fit the planes: every query through a half-wave
-  if (!slow) {
-    // wave w copies bands w, w + NWV, ...; every load of a wave is issued before its first LDS write, on clamped indices
-    constexpr int NWV = L::THREADS / WAVE, KMAX = (NBAND + NWV - 1) / NWV, UNR = 2;
-    const int wvi = tid / WAVE;
-    float4 v[KMAX][UNR];
-    int blo[KMAX], blen[KMAX], bdst[KMAX];
-#pragma unroll
-    for (int kk = 0; kk < KMAX; ++kk) {
-      const int k = wvi + kk * NWV;
-      blo[kk] = 0;
-      blen[kk] = 0;
-      bdst[kk] = 0;
-      if (k < NBAND) {
-        const int l0 = band_lo[k], h0 = band_hi[k];
-        blen[kk] = h0 > l0 ? h0 - l0 : 0;
-        blo[kk] = blen[kk] > 0 ? l0 : 0;
-        bdst[kk] = band_base[k];
-      }
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) v[kk][u] = sorted_s[min(blo[kk] + u * WAVE + lane, ns_total - 1)];
-    }
-#pragma unroll
-    for (int kk = 0; kk < KMAX; ++kk) {
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int f = u * WAVE + lane;
-        if (f < blen[kk]) {
-          sx[bdst[kk] + f] = v[kk][u].x;
-          sy[bdst[kk] + f] = v[kk][u].y;
-          sz[bdst[kk] + f] = v[kk][u].z;
-          si[bdst[kk] + f] = __float_as_int(v[kk][u].w);
-        }
-      }
-      for (int f = UNR * WAVE + lane; f < blen[kk]; f += WAVE) {  // a band longer than 128 elements
-        const float4 t4 = sorted_s[blo[kk] + f];
-        sx[bdst[kk] + f] = t4.x;
-        sy[bdst[kk] + f] = t4.y;
-        sz[bdst[kk] + f] = t4.z;
-        si[bdst[kk] + f] = __float_as_int(t4.w);
-      }
-    }
-  }
-  __syncthreads();
-  if (dbg_stop == 2) {
-    if ((int)sx[tid] == 0x7fffffff) blk_stats[2 * blk] = tid;
-    return;
-  }
-  // ---- tests, four candidates per step.  A hit (sign bit of distance bits - r2 bits) appends its plane position to the
-  //      thread's list, under the hit's exec mask; the count keeps running past the list's capacity (such a query has more
-  //      than Q2_NET hits and is not the network's anyway)
-  int n = 0;
-  if (valid && !slow) {
-    const unsigned r2b = r2 == r2 ? __float_as_uint(r2) : 0u;  // NaN radius: nothing is a neighbour
-    const f32x2 qx = {qp.x, qp.x}, qy = {qp.y, qp.y}, qz = {qp.z, qp.z};
-    unsigned short* my = plist + tid * Q2_NET;
-    auto step4 = [&](int p, int left) {  // left >= 4 except in a band's last step (the reads past the band stay inside the planes)
-      const f32x2 xa = {sx[p], sx[p + 1]}, xb = {sx[p + 2], sx[p + 3]};
-      const f32x2 ya = {sy[p], sy[p + 1]}, yb = {sy[p + 2], sy[p + 3]};
-      const f32x2 za = {sz[p], sz[p + 1]}, zb = {sz[p + 2], sz[p + 3]};
-      // nanoflann.hpp:432-440: result += diff*diff for x, y, z starting from 0 (two candidates per op)
-      const f32x2 dxa = qx - xa, dya = qy - ya, dza = qz - za;
-      const f32x2 dxb = qx - xb, dyb = qy - yb, dzb = qz - zb;
-      const f32x2 da = (dxa * dxa + dya * dya) + dza * dza;
-      const f32x2 db = (dxb * dxb + dyb * dyb) + dzb * dzb;
-      const bool h0 = (int)(__float_as_uint(da.x) - r2b) < 0;
-      const bool h1 = left >= 2 && (int)(__float_as_uint(da.y) - r2b) < 0;
-      const bool h2 = left >= 3 && (int)(__float_as_uint(db.x) - r2b) < 0;
-      const bool h3 = left >= 4 && (int)(__float_as_uint(db.y) - r2b) < 0;
-      if (MODE != Q2_COUNT) {
-        if (h0 && n < Q2_NET) my[n] = (unsigned short)p;
-        n += h0 ? 1 : 0;
-        if (h1 && n < Q2_NET) my[n] = (unsigned short)(p + 1);
-        n += h1 ? 1 : 0;
-        if (h2 && n < Q2_NET) my[n] = (unsigned short)(p + 2);
-        n += h2 ? 1 : 0;
-        if (h3 && n < Q2_NET) my[n] = (unsigned short)(p + 3);
-        n += h3 ? 1 : 0;
-      } else {
-        n += (h0 ? 1 : 0) + (h1 ? 1 : 0) + (h2 ? 1 : 0) + (h3 ? 1 : 0);
-      }
-    };
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      int p = p0[i] + (band_base[3 * j + i] - band_lo[3 * j + i]);
-      const int e = p + (p1[i] - p0[i]);
-      for (; p + 4 <= e; p += 4) step4(p, 4);
-      if (p < e) step4(p, e - p);
-    }
-  }
-  tcnt[tid] = n;
-  if (dbg_stop == 3) {
-    if (n == 0x12345) blk_stats[2 * blk] = tid;
-    return;
-  }
-  __syncthreads();
-  int my_tot = 0;  // threads of wave 0: hits of query `tid` if the network takes it
-  if (!slow && tid < RQ) {
-    const int c0 = tcnt[tid], c1 = tcnt[RQ + tid], c2 = tcnt[2 * RQ + tid];
-    const int tot = c0 + c1 + c2;
-    const bool netq = valid && tot <= Q2_NET;
-    qtot[tid] = valid ? tot : 0;
-    if (valid && !netq) biglist[atomicAdd(&misc[2], 1)] = tid;
-    my_tot = netq ? tot : 0;
-    if (MODE != Q2_COUNT) {
-      // ---- thread = query: the three position lists of the query -> 32 register pairs (distance bits << 32 | index; slots past
-      //      the hit count hold a word larger than any real one), through the sorting network, back as the row
-      unsigned long long k[Q2_NET];
-      const unsigned short* l0 = plist + tid * Q2_NET;
-      const unsigned short* l1 = plist + (RQ + tid) * Q2_NET - c0;
-      const unsigned short* l2 = plist + (2 * RQ + tid) * Q2_NET - (c0 + c1);
-#pragma unroll
-      for (int i = 0; i < Q2_NET; ++i) {
-        const unsigned short* src = i < c0 ? l0 : (i < c0 + c1 ? l1 : l2);
-        const int p = i < my_tot ? (int)src[i] : 0;
-        const float dx = qp.x - sx[p], dy = qp.y - sy[p], dz = qp.z - sz[p];
-        const float d = (dx * dx + dy * dy) + dz * dz;  // same arithmetic as the test: same bits
-        k[i] = i < my_tot ? ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)si[p] : ~0ull;
-      }
-      if (__any(my_tot > 1)) {
-#pragma unroll
-        for (int c = 0; c < Q2_NET_CE; ++c) {
-          const unsigned long long a = k[Q2_NET_PAIRS[c][0]], b = k[Q2_NET_PAIRS[c][1]];
-          const bool sw = b < a;
-          k[Q2_NET_PAIRS[c][0]] = sw ? b : a;
-          k[Q2_NET_PAIRS[c][1]] = sw ? a : b;
-        }
-      }
-      if (dbg_stop == 5) {
-        if (k[0] == 0x12345ull) blk_stats[0] = 1;
-        return;
-      }
-      // the planes stay live for this wave only up to here; the half-waves below read global memory: once every lane of
-      // this wave has its words in registers ...
-      __builtin_amdgcn_wave_barrier();
-      if (tid < rows_here) {  // ... the planes' place becomes the row buffer
-        unsigned int* rrow = rowbuf + tid * width;
-#pragma unroll
-        for (int i = 0; i < Q2_NET; ++i)
-          if (i < width) rrow[i] = i < my_tot ? (unsigned int)k[i] : 0xffffffffu;
-        for (int i = Q2_NET; i < width; ++i) rrow[i] = 0xffffffffu;
-      }
-    }
-  }
-  if (!slow && tid >= RQ) __builtin_amdgcn_s_sleep(1);
-  // ---- one half-wave per query: the queries the network does not take (waves 1, 2), or all of them (slow path, every wave):
-  //      the nine candidate ranges of the query straight from global memory, 32 candidates per step, hits compacted behind
-  //      each other by the half-wave's ballot, ranked by counting
-  const int hw = slow ? tid >> 5 : (tid >> 5) - 2, l = tid & 31;
-  const int nhw = slow ? L::NH : L::NH - 2;
-  unsigned* ks = reinterpret_cast<unsigned*>(smem + L::KEYS_OFF) + max(hw, 0) * 2 * Q2_KCAP;
-  unsigned* is = ks + Q2_KCAP;
-  int hmax = my_tot;
-  if (!slow && tid >= RQ) {  // (the list of the half-wave queries is complete once wave 0 has passed its atomics)
-    // nothing: misc[2] / biglist are read after the barrier below
-  }
-  __syncthreads();
-  const int n_items = slow ? rows_here : misc[2];
-  const unsigned long long half = (tid & 32) ? 0xffffffff00000000ull : 0x00000000ffffffffull;
-  for (int item = hw; hw >= 0 && item < n_items; item += nhw) {
-    const int r = slow ? item : biglist[item];
-    const float4 qq = qbuf[r];
-    int64_t* const row = out + (int64_t)__float_as_int(qq.w) * row_stride;
-    int htot = 0;
-    for (int band = 0; band < NBAND; ++band) {
-      const int2 rg = rng[(band % 3) * L::THREADS + (band / 3) * RQ + r];
-      for (int pbase = rg.x; pbase < rg.y; pbase += 32) {
-        const int p = pbase + l;
-        const float4 sp = sorted_s[min(p, ns_total - 1)];
-        const float dx = qq.x - sp.x, dy = qq.y - sp.y, dz = qq.z - sp.z;
-        const float d = (dx * dx + dy * dy) + dz * dz;
-        const bool hit = p < rg.y && d < r2;
-        const unsigned long long bal = __ballot(hit) & half;
-        const int pos = htot + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
-        if (hit && pos < Q2_KCAP) {
-          ks[pos] = __float_as_uint(d);
-          is[pos] = (unsigned)__float_as_int(sp.w);
-        }
-        htot += __popcll(bal);
-      }
-    }
-    hmax = max(hmax, htot);
-    if (htot > Q2_KCAP) {
-      misc[1] = 1;
-      continue;
-    }
-    if (MODE == Q2_COUNT) continue;  // only the maximum is wanted
-    __builtin_amdgcn_wave_barrier();
-    unsigned dk[Q2_KR], ix[Q2_KR];
-#pragma unroll
-    for (int rd = 0; rd < Q2_KR; ++rd) {
-      const int k = rd * 32 + l;
-      dk[rd] = k < htot ? ks[k] : 0x7fffffffu;
-      ix[rd] = k < htot ? is[k] : 0u;
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (int k = htot + l; k < ((htot + 31) & ~31); k += 32) ks[k] = 0x7fffffffu;  // the rank loop reads whole quads
-    __builtin_amdgcn_wave_barrier();  // the segment is read by the other lanes of the half-wave (LDS executes a wave's
-                                      // operations in order)
-    int rk[Q2_KR];
-#pragma unroll
-    for (int rd = 0; rd < Q2_KR; ++rd) rk[rd] = 0;
-    const int quads = (htot + 3) >> 2;
-    const uint4* seg = reinterpret_cast<const uint4*>(ks);
-    for (int jj = 0; jj < quads; ++jj) {
-      const uint4 k4 = seg[jj];
-#pragma unroll
-      for (int rd = 0; rd < Q2_KR; ++rd)
-        if (rd * 32 < htot)
-          rk[rd] += (k4.x < dk[rd] ? 1 : 0) + (k4.y < dk[rd] ? 1 : 0) + (k4.z < dk[rd] ? 1 : 0) + (k4.w < dk[rd] ? 1 : 0);
-    }
-    // equal distance words: two hits share a rank and the ranks no longer add up to n (n - 1) / 2
-    int rsum = 0;
-#pragma unroll
-    for (int rd = 0; rd < Q2_KR; ++rd) rsum += (rd * 32 + l < htot) ? rk[rd] : 0;
-    rsum = half_wave_sum(rsum);
-    if (rsum != htot * (htot - 1) / 2) {
-#pragma unroll
-      for (int rd = 0; rd < Q2_KR; ++rd) {
-        if (rd * 32 + l < htot) {
-          int rank = 0;
-          for (int k2 = 0; k2 < htot; ++k2) {
-            const unsigned dd = ks[k2], ii = is[k2];
-            rank += (dd < dk[rd] || (dd == dk[rd] && ii < ix[rd])) ? 1 : 0;
-          }
-          rk[rd] = rank;
-        }
-      }
-    }
-    // ---- the row: hits at their rank, the lanes past the hit count pad their own column
-#pragma unroll
-    for (int rd = 0; rd < Q2_KR; ++rd) {
-      const int k = rd * 32 + l;
-      if (k < htot) {
-        if (rk[rd] < width) row[rk[rd]] = (int64_t)ix[rd];
-      } else if (k < row_stride) {
-        row[k] = pad_value;
-      }
-    }
-    for (int k = Q2_KCAP + l; k < row_stride; k += 32) row[k] = pad_value;
-    __builtin_amdgcn_wave_barrier();  // the next query overwrites the key scratch
-  }
-  if (l == 0 || tid < RQ) atomicMax(&misc[0], hmax);
-  __syncthreads();
-  if (!slow && MODE != Q2_COUNT) {
-    // ---- rows of the sorted queries leave as contiguous runs (consecutive lanes, consecutive entries of a row)
-    const int total_el = rows_here * width;
-    const float inv = 1.0f / (float)width;
-    for (int i = tid; i < total_el; i += L::THREADS) {
-      int r = (int)((float)i * inv);
-      r = r * width > i ? r - 1 : ((r + 1) * width <= i ? r + 1 : r);
-      const int cc = i - r * width;
-      if (qtot[r] > Q2_NET) continue;  // written by a half-wave above
-      const unsigned v = rowbuf[r * width + cc];
-      out[(int64_t)__float_as_int(qbuf[r].w) * row_stride + cc] = v == 0xffffffffu ? pad_value : (int64_t)v;
-    }
-  }
-  if (tid == 0) {
-    blk_stats[2 * blk] = misc[0];
-    blk_stats[2 * blk + 1] = misc[1];
-  }
-}
-
 // max / max over the per-block (max hits per query, hits per block) pairs -> hdr
 __global__ __launch_bounds__(1024) void reduce_stats_kernel(const int32_t* __restrict__ blk_stats,
                                                             int blocks, RadiusHdr* __restrict__ hdr) {
@@ -2069,43 +1606,6 @@ int launch_fill(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t n
   return GR_OK;
 }
 
-struct Q2Cfg {
-  int dbg_stop;
-};
-inline Q2Cfg q2_cfg() {
-  static const Q2Cfg cfg = [] {
-    Q2Cfg c{0};
-    if (const char* e = getenv("GR_RADIUS_Q2_STOP")) c.dbg_stop = atoi(e);
-    return c;
-  }();
-  return cfg;
-}
-
-// does the sorted path apply?  rows are staged in LDS up to Q2_WMAX entries, stored at stride == width
-inline bool q2_fits(int64_t width, int64_t row_stride) { return width >= 1 && width <= Q2_WMAX && width == row_stride; }
-
-// One launch of q2_kernel + the reduction of its per-block (max hits, flag) pairs into hdr->max_count / hdr->max_block_hits
-// (the latter = 1: a query had more than Q2_KCAP hits, the caller repeats the call on the older kernels).
-template <int MODE>
-int launch_q2(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns, int nb, const int32_t* start_s, float r2,
-              int64_t width, int64_t row_stride, int64_t* out, bool mono, hipStream_t stream) {
-  using L = Q2Lds;
-  const int blocks = (int)((nq + L::RQ - 1) / L::RQ);
-  const int grid = (blocks + 7) / 8 * 8;
-  const size_t lds = L::total(nb <= L::TABLE_MAX ? nb : 0);
-  auto kern = q2_kernel<MODE>;
-  if (lds > 64 * 1024)
-    GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  {
-    KernelTimer timer(MODE == Q2_COUNT ? "radius_count" : "radius_fused", stream);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(L::THREADS), lds, stream, sorted_q, (int)nq, w.q_off, nb, w.grids, start_s,
-                       w.sorted_s, (int)ns, r2, w.blk_stats, (int)width, (int)row_stride, ns, out, mono ? 1 : 0, q2_cfg().dbg_stop);
-  }
-  hipLaunchKernelGGL(reduce_stats_kernel, dim3(1), dim3(1024), 0, stream, w.blk_stats, blocks, w.hdr);
-  GR_LAUNCH_CHECK();
-  return GR_OK;
-}
-
 struct FusedCfg {
   int rq;      // queries per block: 64 or 128
   int rowbuf;  // rows leave through an LDS row buffer as contiguous 16-byte pieces (else: one 8-byte store per hit)
@@ -2168,23 +1668,6 @@ int launch_fused(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t 
                   : launch_fused_t<64, false>(w, sorted_q, nq, ns, nb, start_s, r2, width, c.per_q, out, mono, stream);
 }
 
-}  // namespace
-}  // namespace gr
-
-namespace gr {
-namespace {
-// 0 (default) = count, host, fill on traverse_kernel; 1 = fused_kernel; 2 = q2_kernel: one launch for radius_search, COUNT +
-// FILL launches for radius_neighbors.  Initialised from GR_RADIUS_MODE (GR_RADIUS_SINGLE_PASS=1 still selects mode 1).
-// All three are VALU-issue bound and within 5 % of each other on 8 x 200 k points.
-std::atomic<int>& search_mode() {
-  static std::atomic<int> mode{[] {
-    if (const char* m = getenv("GR_RADIUS_MODE")) return std::max(0, std::min(2, atoi(m)));
-    const char* a = getenv("GR_RADIUS_SINGLE_PASS");
-    return (a && a[0] == '1') ? 1 : 0;
-  }()};
-  return mode;
-}
-constexpr int64_t Q2_PLAN = -2;  // h_info[1] of a count that ran on q2_kernel: the fill consumes its masks
 }  // namespace
 }  // namespace gr
 
@@ -2342,29 +1825,17 @@ extern "C" int gr_radius_count_cached(const float* q, const float* s, const int6
   if (P.empty) return GR_OK;  // width 0
   const RadiusWs& w = P.w;
   const bool same = P.same;
+  rc = launch_count<RT>(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, same, stream);
+  if (rc != GR_OK) return rc;
   // the read-back lands in pinned memory (a copy into pageable memory is staged and synchronised by the runtime on top of
   // the synchronise below)
   RadiusHdr* h_pinned = static_cast<RadiusHdr*>(pinned_scratch(3, sizeof(RadiusHdr)));
   GR_REQUIRE(h_pinned != nullptr, "pinned read-back buffer could not be allocated");
-  bool q2 = search_mode().load() == 2;
-  if (q2) {
-    rc = launch_q2<Q2_COUNT>(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, 0, 0, nullptr, same, stream);
-    if (rc != GR_OK) return rc;
-    GR_HIP(hipMemcpyAsync(h_pinned, w.hdr, sizeof(RadiusHdr), hipMemcpyDeviceToHost, stream));
-    GR_HIP(hipStreamSynchronize(stream));
-    // else: a query has more hits than q2_kernel's key scratch, or the rows are wider than it stages -- count again on
-    // traverse_kernel, whose fill takes anything
-    q2 = h_pinned->max_block_hits == 0 && h_pinned->max_count <= (unsigned)Q2_WMAX;
-  }
-  if (!q2) {
-    rc = launch_count<RT>(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, same, stream);
-    if (rc != GR_OK) return rc;
-    GR_HIP(hipMemcpyAsync(h_pinned, w.hdr, sizeof(RadiusHdr), hipMemcpyDeviceToHost, stream));
-    GR_HIP(hipStreamSynchronize(stream));
-  }
+  GR_HIP(hipMemcpyAsync(h_pinned, w.hdr, sizeof(RadiusHdr), hipMemcpyDeviceToHost, stream));
+  GR_HIP(hipStreamSynchronize(stream));
   const RadiusHdr h = *h_pinned;
   h_info[0] = h.max_count;
-  h_info[1] = q2 ? Q2_PLAN : (int64_t)h.max_block_hits;
+  h_info[1] = h.max_block_hits;
   h_info[2] = same ? 1 : 0;
   h_info[3] = h.total_cells;
   return GR_OK;
@@ -2395,16 +1866,25 @@ extern "C" int gr_radius_fill(const float* q, const float* s, int64_t nq, int64_
   const bool same = h_info[2] != 0;
   const float4* sorted_q = same ? w.sorted_s : w.sorted_q;
   const float r2 = radius * radius;
-  if (h_info[1] == Q2_PLAN) {
-    GR_REQUIRE(q2_fits(width, width), "radius_fill: width %lld exceeds the counted width", (long long)width);
-    return launch_q2<Q2_FUSED>(w, sorted_q, nq, ns, (int)batch, w.start, r2, width, width, out, same, stream);
-  }
   return launch_fill<RT>(w, sorted_q, nq, ns, (int)batch, r2, width, width, h_info[1], out, stream);
 }
 
+namespace gr {
+namespace {
+// 0 = count, host, fill (default); 1 = the single-pass kernel.  Initialised from GR_RADIUS_SINGLE_PASS.
+std::atomic<int>& search_mode() {
+  static std::atomic<int> mode{[] {
+    const char* a = getenv("GR_RADIUS_SINGLE_PASS");
+    return (a && a[0] == '1') ? 1 : 0;
+  }()};
+  return mode;
+}
+}  // namespace
+}  // namespace gr
+
 extern "C" int gr_radius_search_mode(int mode) {
   const int old = search_mode().load();
-  if (mode >= 0 && mode <= 2) search_mode().store(mode);
+  if (mode >= 0 && mode <= 1) search_mode().store(mode);
   return old;
 }
 
@@ -2428,10 +1908,9 @@ extern "C" int gr_radius_search(const float* q, const float* s, const int64_t* h
   // GR_RADIUS_SINGLE_PASS=1 selects the single-pass kernel (fused_kernel above).  It is not the default: on 8 x 200 k points it
   // runs as long as count + fill together (both are bound by VALU issue: ~3 000 instructions per wave either way)
   const int mode = search_mode().load();
-  bool fused = (mode == 1 && fused_fits(limit)) || (mode == 2 && q2_fits(limit, limit));
+  bool fused = mode == 1 && fused_fits(limit);
   if (fused) {
-    rc = (mode == 2 && q2_fits(limit, limit)) ? launch_q2<Q2_FUSED>(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, limit, out, P.same, stream)
-                   : launch_fused(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, out, P.same, stream);
+    rc = launch_fused(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, out, P.same, stream);
     if (rc != GR_OK) return rc;
     GR_HIP(hipMemcpyAsync(h_pinned, w.hdr, sizeof(RadiusHdr), hipMemcpyDeviceToHost, stream));
     GR_HIP(hipStreamSynchronize(stream));

@@ -18,15 +18,6 @@ def _ext():
     return ext
 
 
-@pytest.fixture(params=[0, 2], ids=["count+fill", "half-wave-per-query"], autouse=True)
-def search_mode(request):
-    """radius_neighbors runs on the traverse_kernel pair (default) and on q2_kernel (COUNT + FILL launches, mode 2)."""
-    from gaussreg_amd import _lib
-    old = _lib.lib().gr_radius_search_mode(request.param)
-    yield request.param
-    _lib.lib().gr_radius_search_mode(old)
-
-
 def test_c1_radius_matches_reference_golden():
     g = load_golden("ext_c1.npz")
     pts = _t(c1_points())
@@ -200,7 +191,7 @@ def test_200k_properties():
     assert np.array_equal(sp.cpu().numpy().view(np.uint32), wp.view(np.uint32))
     # the radius_search(limit=40) wrapper, both search modes, against the truncated oracle rows
     from gaussreg_amd import _lib, ext as gext
-    for mode in (0, 1, 2):
+    for mode in (0, 1):
         old = _lib.lib().gr_radius_search_mode(mode)
         try:
             lim = gext.radius_neighbors_limited(d, d, lens, lens, r, 40)

@@ -1,15 +1,15 @@
 #!/bin/bash
-# Per-phase instruction counts of the single-pass radius kernels: one rocprofv3 --pmc pass per "stop after phase k" build
-# switch (GR_RADIUS_FUSED_STOP for fused_kernel, GR_RADIUS_Q2_STOP for q2_kernel); run on the GPU box via gpurun.
-#   tools/radius_phase_counters.sh fused|q2
-which=$1
+# Per-phase instruction counts of the single-pass radius kernel (fused_kernel): one rocprofv3 --pmc pass per "stop after
+# phase k" build switch (GR_RADIUS_FUSED_STOP); run on the GPU box via gpurun.
+#   tools/radius_phase_counters.sh
+which=fused
 out=$GRAFT_REPO_ROOT/gpurun_out/phase_$which
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-if [ "$which" = fused ]; then var=GR_RADIUS_FUSED_STOP; mode=1; stops="1 2 3 4 5 6 7 0"; else var=GR_RADIUS_Q2_STOP; mode=2; stops="1 2 3 5 0"; fi
+var=GR_RADIUS_FUSED_STOP; stops="1 2 3 4 5 6 7 0"
 for s in $stops; do
-  env $var=$s GR_RADIUS_MODE=$mode BRF_CHILD=1 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES \
-      --output-format csv -d $out/s$s -o p -- python $GRAFT_REPO_ROOT/tools/bench_radius_q2.py > $out/s$s.log 2>&1
+  env $var=$s GR_RADIUS_SINGLE_PASS=1 BRF_CHILD=1 BRF_MODE=1 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES \
+      --output-format csv -d $out/s$s -o p -- python $GRAFT_REPO_ROOT/tools/bench_radius_fused.py > $out/s$s.log 2>&1
 done
 python3 - "$out" "$which" <<'PY'
 import csv, glob, sys, collections
