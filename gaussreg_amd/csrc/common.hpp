@@ -87,7 +87,7 @@ int exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int rows, int
 // Pinned host scratch, one buffer per (host thread, slot), grown on demand and kept for the life of the process.  A copy
 // to or from pageable memory is staged and synchronised by the runtime; through these buffers the small uploads and
 // read-backs of the API calls are asynchronous for real.  Contract: the caller synchronises the stream before it returns
-// (slots 0-3: every entry point that uses them does) or guards the slot with an event it waits on before the next use
+// (slots 0-3 and 5-7: every entry point that uses them does) or guards the slot with an event it waits on before the next use
 // (slot 4, hash_order_device), so the next call on the thread finds the buffer free.
 void* pinned_scratch(int slot, size_t bytes);
 
@@ -139,8 +139,11 @@ void unordered_map_order(const uint64_t* keys, int64_t n, int32_t base, int32_t*
 // The same order for many clouds at once, evaluated on the device (hash_order_device.hip): keys on the device, clouds
 // contiguous (h_begins: batch + 1 host offsets); perm_out[begin_c + j] = global index of the j-th iterated key of cloud c.
 size_t hash_order_device_bytes(int64_t n, int64_t batch);
+// rows_out (optional): rows_out[begin_c + j] = rows_in[row_of[that key's index]], 3 floats per row -- the caller's gather
+// by the permutation done by the launch that knows the final positions; perm_out may then be null.
 int hash_order_device(const uint64_t* keys, const int64_t* h_begins, int64_t batch, int32_t* perm_out, void* ws,
-                      size_t ws_bytes, hipStream_t stream);
+                      size_t ws_bytes, hipStream_t stream, const float* rows_in = nullptr, const int32_t* row_of = nullptr,
+                      float* rows_out = nullptr);
 
 // lower_bound over a small ascending int32 offsets table: largest b with off[b] <= i (b < nb)
 // ---- wave64 scan / reduction on the DPP shift network (row_shr 1/2/4/8 inside 16-lane rows, row_bcast 15/31 across

@@ -100,9 +100,10 @@ __global__ __launch_bounds__(256) void keys_kernel(const float* __restrict__ pts
                                                    const int32_t* __restrict__ off, int nb,
                                                    const CloudGrid* __restrict__ grids,
                                                    int key_bits, uint64_t* __restrict__ keys,
-                                                   int32_t* __restrict__ vals) {
+                                                   int32_t* __restrict__ vals, int32_t* __restrict__ fo_flags) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (fo_flags) fo_flags[i] = 0;  // first-occurrence flags (reference order), set by cells_kernel
   const int b = find_batch(off, nb, i);
   const CloudGrid g = grids[b];
   const float x = pts[3 * (int64_t)i], y = pts[3 * (int64_t)i + 1], z = pts[3 * (int64_t)i + 2];
@@ -271,18 +272,40 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
     return GR_ERR_WORKSPACE;
   }
   const int nb = (int)batch;
-  std::vector<int32_t> off(batch + 1, 0);
-  for (int64_t b = 0; b < batch; ++b) off[b + 1] = off[b] + (int32_t)h_lengths[b];
-  GR_HIP(hipMemcpyAsync(w.off, off.data(), sizeof(int32_t) * (batch + 1), hipMemcpyHostToDevice, stream));
-  std::vector<int32_t> h_blk(batch + 1);
-  int rc = compute_bbox(points, off.data(), h_blk.data(), w.off, nb, w.bbox, w.blk_off, stream);
+  // Host staging is pinned (pageable copies block the host and leave the device idle meanwhile).  Its first part mirrors
+  // the first three arrays of the workspace -- point offsets, bounding boxes (their initial values), bbox workgroup
+  // offsets -- so ONE upload replaces two copies and the bbox-init launch.  Every upload below is followed by a stream
+  // synchronise before this function returns: the buffer is free again for the next call of this thread.
+  const size_t o_bbox = align_up(sizeof(int32_t) * (batch + 1), 256);
+  const size_t o_blk = o_bbox + align_up(sizeof(uint32_t) * 6 * batch, 256);
+  const size_t o_hb = o_blk + align_up(sizeof(int32_t) * (batch + 1), 256);
+  const size_t o_grids = o_hb + align_up(sizeof(uint32_t) * 6 * batch, 256);
+  const size_t o_mb = o_grids + align_up(sizeof(CloudGrid) * batch, 256);
+  char* pin = static_cast<char*>(pinned_scratch(7, o_mb + sizeof(int32_t) * (batch + 1)));
+  GR_REQUIRE(pin != nullptr, "grid_subsample: pinned staging buffer could not be allocated");
+  GR_REQUIRE(reinterpret_cast<char*>(w.bbox) == reinterpret_cast<char*>(w.off) + o_bbox &&
+                 reinterpret_cast<char*>(w.blk_off) == reinterpret_cast<char*>(w.off) + o_blk,
+             "grid_subsample: workspace layout");
+  int32_t* off = reinterpret_cast<int32_t*>(pin);
+  uint32_t* bb0 = reinterpret_cast<uint32_t*>(pin + o_bbox);
+  int32_t* h_blk = reinterpret_cast<int32_t*>(pin + o_blk);
+  const uint32_t* hb = reinterpret_cast<const uint32_t*>(pin + o_hb);
+  CloudGrid* hg = reinterpret_cast<CloudGrid*>(pin + o_grids);
+  const int32_t* h_mb = reinterpret_cast<const int32_t*>(pin + o_mb);
+  off[0] = 0;
+  for (int64_t b = 0; b < batch; ++b) {
+    off[b + 1] = off[b] + (int32_t)h_lengths[b];
+    for (int k = 0; k < 6; ++k) bb0[b * 6 + k] = k < 3 ? 0xffffffffu : 0u;
+  }
+  bbox_block_offsets(off, h_blk, nb);
+  GR_HIP(hipMemcpyAsync(w.off, pin, o_blk + sizeof(int32_t) * (batch + 1), hipMemcpyHostToDevice, stream));
+  int rc = compute_bbox(points, off, h_blk, w.off, nb, w.bbox, w.blk_off, stream, /*blk_off_on_device=*/true,
+                        /*init_bbox=*/false);
   if (rc != GR_OK) return rc;
-  std::vector<uint32_t> hb(batch * 6);
-  GR_HIP(hipMemcpyAsync(hb.data(), w.bbox, sizeof(uint32_t) * batch * 6, hipMemcpyDeviceToHost, stream));
+  GR_HIP(hipMemcpyAsync(pin + o_hb, w.bbox, sizeof(uint32_t) * batch * 6, hipMemcpyDeviceToHost, stream));
   GR_HIP(hipStreamSynchronize(stream));
 
   // ---- per-cloud grid, exactly the reference's fp32 expressions (this TU: -ffp-contract=off)
-  std::vector<CloudGrid> hg(batch);
   unsigned long long max_cells = 1;
   bool wrap = false;
   const float inv = static_cast<float>(1.0 / static_cast<double>(voxel));  // :11 `(1. / voxel_size)` -> float
@@ -307,15 +330,15 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
     }
     hg[b] = g;
   }
-  GR_HIP(hipMemcpyAsync(w.grids, hg.data(), sizeof(CloudGrid) * batch, hipMemcpyHostToDevice, stream));
+  GR_HIP(hipMemcpyAsync(w.grids, hg, sizeof(CloudGrid) * batch, hipMemcpyHostToDevice, stream));
   int key_bits = wrap ? 64 : bits_for(max_cells);
   const int b_bits = bits_for((unsigned long long)batch);
   const bool composite = key_bits + b_bits <= 64 && key_bits < 64;
   if (!composite) key_bits = 64;
 
-  if (order_mode != GR_ORDER_CELL) GR_HIP(hipMemsetAsync(w.flags, 0, sizeof(int32_t) * n, stream));  // first-occurrence flags
   const dim3 blk(256), grd((unsigned)((n + 255) / 256));
-  hipLaunchKernelGGL(keys_kernel, grd, blk, 0, stream, points, (int)n, w.off, nb, w.grids, key_bits, w.keys_a, w.vals_a);
+  hipLaunchKernelGGL(keys_kernel, grd, blk, 0, stream, points, (int)n, w.off, nb, w.grids, key_bits, w.keys_a, w.vals_a,
+                     order_mode != GR_ORDER_CELL ? w.flags : nullptr);
   GR_LAUNCH_CHECK();
   uint64_t* keys_sorted = w.keys_b;
   int32_t* vals_sorted = w.vals_b;
@@ -345,7 +368,7 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
                      composite ? 1 : 0, head);
   rc = exclusive_scan_i32(head, head_scan, n, 1, n, w.scan_ws, w.totals, stream);
   if (rc != GR_OK) return rc;
-  int32_t* fo_flags = order_mode == GR_ORDER_CELL ? nullptr : w.flags;  // zeroed above
+  int32_t* fo_flags = order_mode == GR_ORDER_CELL ? nullptr : w.flags;  // zeroed by keys_kernel
   // cell order: the barycentres ARE the output rows (cell = rank of the voxel key), written in place
   hipLaunchKernelGGL(cells_kernel, grd, blk, 0, stream, points, keys_sorted, vals_sorted, head, head_scan, (int)n,
                      w.off, nb, composite ? key_bits : 64, order_mode == GR_ORDER_CELL ? out_points : w.bary, w.first_idx,
@@ -353,9 +376,8 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
   hipLaunchKernelGGL(cloud_counts_kernel, dim3((nb + 255) / 256), blk, 0, stream, head_scan, w.totals, (int)n, w.off,
                      nb, w.m_b);
   GR_LAUNCH_CHECK();
-  std::vector<int32_t> h_mb(batch + 1);
   int32_t h_m = 0;
-  GR_HIP(hipMemcpyAsync(h_mb.data(), w.m_b, sizeof(int32_t) * (batch + 1), hipMemcpyDeviceToHost, stream));
+  GR_HIP(hipMemcpyAsync(pin + o_mb, w.m_b, sizeof(int32_t) * (batch + 1), hipMemcpyDeviceToHost, stream));
 
   if (order_mode == GR_ORDER_CELL) {
     GR_HIP(hipStreamSynchronize(stream));
@@ -379,7 +401,9 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
       std::vector<int64_t> r0(batch + 1, 0);
       for (int64_t b = 0; b < batch; ++b) r0[b + 1] = r0[b] + h_mb[b];
       if (!host_replay) {
-        rc = hash_order_device(w.keys_fo, r0.data(), batch, w.perm, w.ho_ws, w.ho_bytes, stream);
+        // the last launch of the evaluation moves the barycentres to their rows itself (no permutation, no gather launch)
+        rc = hash_order_device(w.keys_fo, r0.data(), batch, nullptr, w.ho_ws, w.ho_bytes, stream, w.bary, w.cell_of_rank,
+                               out_points);
         if (rc != GR_OK) return rc;
       } else {
       std::vector<uint64_t> hk(h_m);
@@ -402,9 +426,9 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
       }
       GR_HIP(hipMemcpyAsync(w.perm, perm.data(), sizeof(int32_t) * h_m, hipMemcpyHostToDevice, stream));
       GR_HIP(hipStreamSynchronize(stream));  // perm (host vector) must outlive the copy
-      }
       hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((h_m + 255) / 256)), blk, 0, stream, w.bary, w.cell_of_rank,
                          w.perm, h_m, out_points);
+      }
       GR_LAUNCH_CHECK();
     }
   }

@@ -32,9 +32,29 @@ struct HoCloud {    // per cloud, per stage
   int32_t m;        // elements taking part in this stage; for a cloud whose history has ended (n == 0): its size
   uint32_t n;       // bucket count of the table in force; 0 = the cloud is done, its positions are only carried along
   int32_t toff;     // where the cloud's bucket table starts
+  int32_t soff;     // where the cloud's slab totals start (one per HO_SLAB clock values; same array as the tables)
+  int32_t ebase;    // the cloud's slice of this stage's bucket ids / chain links starts at ebase + begin
 };
 
+// what the last stage does with the final list positions: the permutation, and / or rows moved straight to their place
+struct HoEmit {
+  int32_t* perm;           // perm[begin + pos] = element (may be null)
+  const float* rows_in;    // rows_out[begin + pos] = rows_in[row_of[element]] (3 floats; rows_out may be null)
+  const int32_t* row_of;
+  float* rows_out;
+};
+__device__ __forceinline__ void ho_emit(const HoEmit& em, int begin, int pos, int e) {
+  if (em.perm) em.perm[begin + pos] = e;  // j-th iterated element of the cloud = the element at list position j
+  if (em.rows_out) {
+    const int64_t r = em.row_of[e], o = (int64_t)begin + pos;
+    em.rows_out[3 * o] = em.rows_in[3 * r];
+    em.rows_out[3 * o + 1] = em.rows_in[3 * r + 1];
+    em.rows_out[3 * o + 2] = em.rows_in[3 * r + 2];
+  }
+}
+
 constexpr int HO_T = 256;
+constexpr int HO_SLAB = 1024;  // clock values per workgroup of the suffix sum
 
 __device__ __forceinline__ int ho_cloud_of(const int32_t* __restrict__ begins, int nb, int e) {
   int lo = 0, hi = nb;  // begins has nb + 1 entries
@@ -48,12 +68,12 @@ __device__ __forceinline__ int ho_cloud_of(const int32_t* __restrict__ begins, i
 
 __global__ __launch_bounds__(HO_T) void ho_init_kernel(int n, const int32_t* __restrict__ begins, int nb,
                                                        int32_t* __restrict__ Ta, int32_t* __restrict__ Tb,
-                                                       int32_t* __restrict__ cloud) {
+                                                       int32_t* __restrict__ head, int nhead) {
+  // every bucket of every stage's table starts empty (-1): cleared here rather than by a memset launch of its own
+  for (int i = blockIdx.x * HO_T + threadIdx.x; i < nhead; i += gridDim.x * HO_T) head[i] = -1;
   const int e = blockIdx.x * HO_T + threadIdx.x;
   if (e >= n) return;
-  const int c = ho_cloud_of(begins, nb, e);
-  cloud[e] = c;
-  Ta[e] = Tb[e] = e - begins[c];  // both ping-pong buffers: an element keeps T = insertion index until a stage covers it
+  Ta[e] = Tb[e] = e - begins[ho_cloud_of(begins, nb, e)];  // both ping-pong buffers: an element keeps T = insertion index until a stage covers it
 }
 
 // Stage kernels run on 2-D grids: blockIdx.y = cloud, blockIdx.x * HO_T + lane = local element; the grid's x extent is the
@@ -61,16 +81,17 @@ __global__ __launch_bounds__(HO_T) void ho_init_kernel(int n, const int32_t* __r
 // One device-scope atomic per element (returning global atomics are served behind the L2s and are what this step costs):
 // the exchange threads the element onto its bucket's chain; the bucket's size and oldest clock, which used to be an
 // atomicAdd and an atomicMin next to it, are read off the (short) chain by the two kernels that need them.
-__global__ __launch_bounds__(HO_T) void ho_bucket_kernel(const HoCloud* __restrict__ st,
+// ALL the big stages in one launch (blockIdx.z = stage): the buckets of a stage depend on the keys only, not on the clocks.
+__global__ __launch_bounds__(HO_T) void ho_bucket_kernel(const HoCloud* __restrict__ st_all, int batch,
                                                          const uint64_t* __restrict__ keys, int32_t* __restrict__ bkt,
                                                          int32_t* __restrict__ head, int32_t* __restrict__ nxt) {
-  const HoCloud s = st[blockIdx.y];
+  const HoCloud s = st_all[blockIdx.z * batch + blockIdx.y];
   const int le = blockIdx.x * HO_T + threadIdx.x;
   if (le >= s.m || s.n == 0) return;
   const int e = s.begin + le;
   const int b = s.toff + (int)(keys[e] % (uint64_t)s.n);  // std::hash<size_t> is the identity, not cached
-  bkt[e] = b;
-  nxt[e] = atomicExch(&head[b], e);  // chain order is irrelevant: the walks below only count and take minima
+  bkt[s.ebase + e] = b;
+  nxt[s.ebase + e] = atomicExch(&head[b], e);  // chain order is irrelevant: the walks below only count and take minima
 }
 
 __global__ __launch_bounds__(HO_T) void ho_group_kernel(const HoCloud* __restrict__ st, const int32_t* __restrict__ T,
@@ -82,33 +103,60 @@ __global__ __launch_bounds__(HO_T) void ho_group_kernel(const HoCloud* __restric
   const int e = s.begin + le;
   const int t = T[e];
   int first = t, cnt = 0;
-  for (int p = head[bkt[e]]; p >= 0; p = nxt[p]) {
+  for (int p = head[bkt[s.ebase + e]]; p >= 0; p = nxt[s.ebase + p]) {
     first = min(first, T[p]);
     ++cnt;
   }
   G[s.begin + t] = (t == first) ? cnt : 0;  // T is a permutation of 0 .. m-1: every slot written once
 }
 
-// per cloud: S[f] = sum of G over clock values > f (exclusive suffix sum), one workgroup per cloud
-__global__ __launch_bounds__(1024) void ho_suffix_kernel(const HoCloud* __restrict__ st, const int32_t* __restrict__ G,
-                                                         int32_t* __restrict__ S) {
+// The exclusive suffix sum S[f] = sum of G over clock values > f, in two parts.  Here, one workgroup per slab of HO_SLAB
+// clocks: the suffix sum INSIDE the slab (S) and the slab's total (slab[]); the totals of the slabs above are added by
+// the reader (ho_rank_kernel builds that table of m / HO_SLAB entries in LDS).  One workgroup per CLOUD walking all
+// slabs, as this was until round 4, took 69 us for the 150 k clocks of a 200 k-point cloud's last table -- a third of
+// the whole reference-order call; adding the group sizes into the slab totals with atomics in ho_group_kernel (tried)
+// took 219 us: ~600 device-scope atomics per address serialise.
+__global__ __launch_bounds__(HO_SLAB) void ho_suffix_kernel(const HoCloud* __restrict__ st, const int32_t* __restrict__ G,
+                                                            int32_t* __restrict__ slabs, int32_t* __restrict__ S) {
+  __shared__ int s_w[HO_SLAB / WAVE];
+  const HoCloud s = st[blockIdx.y];
+  const int slab = blockIdx.x;
+  if (s.n == 0 || slab * HO_SLAB >= s.m) return;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+  const int f = slab * HO_SLAB + HO_SLAB - 1 - tid;  // thread 0 takes the largest clock of the slab
+  const int g = f < s.m ? G[s.begin + f] : 0;
+  const int incl = wave_incl_scan_add_dpp(g);
+  if (lane == WAVE - 1) s_w[wv] = incl;
+  __syncthreads();
+  int base = 0, total = 0;
+  for (int i = 0; i < HO_SLAB / WAVE; ++i) {
+    base += i < wv ? s_w[i] : 0;
+    total += s_w[i];
+  }
+  if (f < s.m) S[s.begin + f] = base + incl - g;  // everything with a larger clock in this slab
+  if (tid == 0) slabs[s.soff + slab] = total;
+}
+
+// Clouds with more slabs than ho_rank_kernel keeps in LDS (HO_TAB: 4 M clocks): one workgroup per cloud turns the slab
+// totals into "total of the slabs above" in place, and the rank kernel reads that.
+__global__ __launch_bounds__(1024) void ho_slabscan_kernel(const HoCloud* __restrict__ st, int32_t* __restrict__ slabs) {
   __shared__ int s_w[1024 / WAVE];
   __shared__ int s_carry;
   const HoCloud s = st[blockIdx.x];
-  if (s.m == 0 || s.n == 0) return;
+  if (s.n == 0) return;
+  const int nslab = (s.m + HO_SLAB - 1) / HO_SLAB;
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   if (threadIdx.x == 0) s_carry = 0;
   __syncthreads();
-  // walk the clock from the top down in slabs of 1024
-  for (int hi = s.m; hi > 0; hi -= 1024) {
-    const int f = hi - 1 - (int)threadIdx.x;  // thread 0 takes the largest clock of the slab
-    const int g = f >= 0 ? G[s.begin + f] : 0;
+  for (int hi = nslab; hi > 0; hi -= 1024) {
+    const int j = hi - 1 - (int)threadIdx.x;  // thread 0 takes the highest slab
+    const int g = j >= 0 ? slabs[s.soff + j] : 0;
     const int incl = wave_incl_scan_add_dpp(g);
     if (lane == WAVE - 1) s_w[wv] = incl;
     __syncthreads();
     int base = s_carry;
     for (int i = 0; i < wv; ++i) base += s_w[i];
-    if (f >= 0) S[s.begin + f] = base + incl - g;  // everything with a larger clock
+    if (j >= 0) slabs[s.soff + j] = base + incl - g;
     __syncthreads();
     if (threadIdx.x == 1023) s_carry = base + incl;
     __syncthreads();
@@ -116,27 +164,59 @@ __global__ __launch_bounds__(1024) void ho_suffix_kernel(const HoCloud* __restri
 }
 
 // reads the clocks of the whole bucket chain from T, writes the new positions to the OTHER ping-pong buffer
+constexpr int HO_TAB = 4096;
+// LAST: the positions are final -- emitted (permutation and / or rows) instead of written back.
+template <bool PRESCANNED, bool LAST>
 __global__ __launch_bounds__(HO_T) void ho_rank_kernel(const HoCloud* __restrict__ st, const int32_t* __restrict__ T,
                                                        const int32_t* __restrict__ bkt,
                                                        const int32_t* __restrict__ head, const int32_t* __restrict__ nxt,
-                                                       const int32_t* __restrict__ S, int32_t* __restrict__ T_out) {
+                                                       const int32_t* __restrict__ S, const int32_t* __restrict__ slabs,
+                                                       int32_t* __restrict__ T_out, HoEmit em) {
+  __shared__ int s_above[PRESCANNED ? 1 : HO_TAB];
+  __shared__ int s_w[HO_T / WAVE];
   const HoCloud s = st[blockIdx.y];
   const int le = blockIdx.x * HO_T + threadIdx.x;
-  if (le >= s.m) return;
+  if (blockIdx.x * HO_T >= s.m) return;  // workgroup-uniform
   const int e = s.begin + le;
-  if (s.n == 0) {  // finished cloud: keep its final positions in the buffer the next stage (or the emit) reads
-    T_out[e] = T[e];
+  if (s.n == 0) {  // finished cloud: keep its final positions in the buffer the next stage reads
+    if (le < s.m) {
+      if (LAST) ho_emit(em, s.begin, T[e], e);
+      else T_out[e] = T[e];
+    }
     return;
   }
-  const int b = bkt[e];
+  if (!PRESCANNED) {  // s_above[j] = total of the slabs above slab j
+    const int nslab = (s.m + HO_SLAB - 1) / HO_SLAB;
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    int carry = 0;
+    for (int r0 = 0; r0 < nslab; r0 += HO_T) {
+      const int j = nslab - 1 - r0 - (int)threadIdx.x;  // thread 0 takes the highest slab
+      const int g = j >= 0 ? slabs[s.soff + j] : 0;
+      const int incl = wave_incl_scan_add_dpp(g);
+      if (lane == WAVE - 1) s_w[wv] = incl;
+      __syncthreads();
+      int base = carry;
+      for (int i = 0; i < HO_T / WAVE; ++i) {
+        base += i < wv ? s_w[i] : 0;
+        carry += s_w[i];
+      }
+      if (j >= 0) s_above[j] = base + incl - g;
+      __syncthreads();
+    }
+  }
+  if (le >= s.m) return;
+  const int b = bkt[s.ebase + e];
   const int t = T[e];
   int within = 0, first = t;
-  for (int p = head[b]; p >= 0; p = nxt[p]) {
+  for (int p = head[b]; p >= 0; p = nxt[s.ebase + p]) {
     const int tp = T[p];
     within += tp > t ? 1 : 0;
     first = min(first, tp);
   }
-  T_out[e] = S[s.begin + first] + within;
+  const int above = PRESCANNED ? slabs[s.soff + first / HO_SLAB] : s_above[first / HO_SLAB];
+  const int pos = S[s.begin + first] + above + within;
+  if (LAST) ho_emit(em, s.begin, pos, e);
+  else T_out[e] = pos;
 }
 
 // The first stages of every history are tiny (tables of 13, 29, 59 ... 2357 buckets): one workgroup per cloud runs them
@@ -144,7 +224,8 @@ __global__ __launch_bounds__(HO_T) void ho_rank_kernel(const HoCloud* __restrict
 constexpr int HO_SMALL = 2357;  // largest m (= bucket count) handled here
 __global__ __launch_bounds__(1024) void ho_small_stages_kernel(const HoCloud* __restrict__ st_all, int batch, int nsmall,
                                                                const uint64_t* __restrict__ keys,
-                                                               int32_t* __restrict__ T_out_a, int32_t* __restrict__ T_out_b) {
+                                                               int32_t* __restrict__ T_out_a, int32_t* __restrict__ T_out_b,
+                                                               int last, HoEmit em) {
   __shared__ int sT[HO_SMALL], sTn[HO_SMALL], sB[HO_SMALL], sNx[HO_SMALL], sG[HO_SMALL];
   __shared__ int sFirst[HO_SMALL], sCnt[HO_SMALL], sHead[HO_SMALL];
   __shared__ int s_w[1024 / WAVE];
@@ -201,15 +282,11 @@ __global__ __launch_bounds__(1024) void ho_small_stages_kernel(const HoCloud* __
     m_done = m;
     __syncthreads();
   }
+  if (last) {  // no cloud has a later stage: m_done is the whole cloud and the positions are final
+    for (int e = tid; e < m_done; e += 1024) ho_emit(em, begin, sT[e], begin + e);
+    return;
+  }
   for (int e = tid; e < m_done; e += 1024) T_out_a[begin + e] = T_out_b[begin + e] = sT[e];
-}
-
-__global__ __launch_bounds__(HO_T) void ho_emit_kernel(int n, const int32_t* __restrict__ begins,
-                                                       const int32_t* __restrict__ cloud, const int32_t* __restrict__ pos,
-                                                       int32_t* __restrict__ perm) {
-  const int e = blockIdx.x * HO_T + threadIdx.x;
-  if (e >= n) return;
-  perm[begins[cloud[e]] + pos[e]] = e;  // j-th iterated element of the cloud = the element at list position j
 }
 
 }  // namespace
@@ -234,15 +311,20 @@ static void rehash_schedule(int64_t m, std::vector<std::pair<int64_t, uint64_t>>
 
 size_t hash_order_device_bytes(int64_t n, int64_t batch) {
   // worst case bucket table: the policy at most doubles past the element count (+ the prime gap): 4 n + slack per cloud
-  const size_t buckets = (size_t)(4 * n + 64 * batch + 64);
-  return align_up((size_t)n * 4, 256) * 7 + align_up(2 * buckets * 4, 256) + align_up((size_t)(batch + 1) * 4, 256) * 2 +
+  const size_t buckets = (size_t)(4 * n + 64 * batch + 64) + (size_t)(n / 256 + 64 * batch + 64);  // tables + slab sums
+  // bucket ids and chain links per (stage, cloud): the stages' element counts at least halve going back from the last
+  // two (m, < m, < m / 2, ...): < 3 n in all
+  const size_t links = (size_t)(3 * n + 64 * batch + 64);
+  return align_up((size_t)n * 4, 256) * 4 + align_up(links * 4, 256) * 2 + align_up(2 * buckets * 4, 256) + align_up((size_t)(batch + 1) * 4, 256) * 2 +
          align_up((size_t)batch * sizeof(HoCloud), 256) * 64 + 4096;
 }
 
 // keys: device, n distinct-per-cloud keys in insertion order, clouds contiguous (h_begins: batch + 1 host offsets).
 // perm_out (device, n): perm_out[begin_c + j] = global index of the j-th element the container would iterate.
+// rows_out (optional, with rows_in / row_of): rows_out[begin_c + j] = rows_in[row_of[that element]] (3 floats per row) --
+// the caller's gather by the permutation, done by the launch that knows the final positions.  perm_out may then be null.
 int hash_order_device(const uint64_t* keys, const int64_t* h_begins, int64_t batch, int32_t* perm_out, void* ws,
-                      size_t ws_bytes, hipStream_t stream) {
+                      size_t ws_bytes, hipStream_t stream, const float* rows_in, const int32_t* row_of, float* rows_out) {
   const int64_t n = h_begins[batch];
   if (n == 0) return GR_OK;
   GR_REQUIRE(n < (1ll << 30) && batch >= 1, "hash_order_device: bad sizes");
@@ -264,27 +346,49 @@ int hash_order_device(const uint64_t* keys, const int64_t* h_begins, int64_t bat
   // every (stage, cloud) gets its own slice of the bucket tables (the bucket counts roughly double from stage to stage, so
   // all slices together are about twice the final tables): ONE clear up front instead of one per stage
   std::vector<HoCloud> hs(nstage * batch);
-  int64_t table_entries = 0;
+  int64_t table_entries = 0, link_entries = 0;
   for (size_t k = 0; k < nstage; ++k)
     for (int64_t c = 0; c < batch; ++c) {
-      HoCloud s{begins[c], (int32_t)(h_begins[c + 1] - h_begins[c]), 0u, 0};
+      HoCloud s{begins[c], (int32_t)(h_begins[c + 1] - h_begins[c]), 0u, 0, 0, 0};
       const auto& sc = sched[c];
       if (k < sc.size()) {
         s.n = (uint32_t)sc[k].second;
         s.m = (int32_t)(k + 1 < sc.size() ? sc[k + 1].first : h_begins[c + 1] - h_begins[c]);
         s.toff = (int32_t)table_entries;
         table_entries += s.n;
+        s.soff = (int32_t)table_entries;
+        table_entries += (s.m + HO_SLAB - 1) / HO_SLAB;
       }
       hs[k * batch + c] = s;
     }
-  GR_REQUIRE(table_entries < (1ll << 31), "hash_order_device: bucket tables out of range");
+  // stages whose largest m fits the LDS kernel (the rehash thresholds are the same prime sequence for every cloud)
+  size_t nsmall = 0;
+  while (nsmall < nstage) {
+    int64_t mm = 0, nn = 0;
+    for (int64_t c = 0; c < batch; ++c)
+      if (hs[nsmall * batch + c].n) {
+        mm = std::max<int64_t>(mm, hs[nsmall * batch + c].m);
+        nn = std::max<int64_t>(nn, hs[nsmall * batch + c].n);
+      }
+    if (mm > HO_SMALL || nn > HO_SMALL) break;
+    ++nsmall;
+  }
+  // the stages after those run one launch per step over all clouds; each (stage, cloud) has its own slice of bucket ids and
+  // chain links so that ONE launch can thread the chains of all of them
+  for (size_t k = nsmall; k < nstage; ++k)
+    for (int64_t c = 0; c < batch; ++c) {
+      HoCloud& s = hs[k * batch + c];
+      if (s.n == 0) continue;
+      s.ebase = (int32_t)(link_entries - begins[c]);
+      link_entries += s.m;
+    }
+  GR_REQUIRE(table_entries < (1ll << 31) && link_entries < (1ll << 31), "hash_order_device: bucket tables out of range");
   const size_t buckets = (size_t)table_entries;
   Carver cv(ws);
   int32_t* Ta = cv.take<int32_t>(n);
   int32_t* Tb = cv.take<int32_t>(n);
-  int32_t* cloud = cv.take<int32_t>(n);
-  int32_t* bkt = cv.take<int32_t>(n);
-  int32_t* nxt = cv.take<int32_t>(n);
+  int32_t* bkt = cv.take<int32_t>(link_entries);
+  int32_t* nxt = cv.take<int32_t>(link_entries);
   int32_t* G = cv.take<int32_t>(n);
   int32_t* S = cv.take<int32_t>(n);
   int32_t* head = cv.take<int32_t>(buckets);
@@ -301,47 +405,49 @@ int hash_order_device(const uint64_t* keys, const int64_t* h_begins, int64_t bat
   GR_REQUIRE(stage != nullptr, "hash_order_device: pinned staging buffer could not be allocated");
   memcpy(stage, begins.data(), begins_bytes);
   memcpy(stage + align_up(begins_bytes, 256), hs.data(), hs_bytes);
-  GR_HIP(hipMemcpyAsync(d_begins, stage, begins_bytes, hipMemcpyHostToDevice, stream));
-  GR_HIP(hipMemsetAsync(head, 0xff, sizeof(int32_t) * buckets, stream));    // -1
-  GR_HIP(hipMemcpyAsync(d_st, stage + align_up(begins_bytes, 256), hs_bytes, hipMemcpyHostToDevice, stream));
+  // d_begins and d_st are neighbours in the workspace with the staging buffer's layout: one copy
+  GR_REQUIRE(reinterpret_cast<char*>(d_st) == reinterpret_cast<char*>(d_begins) + align_up(begins_bytes, 256),
+             "hash_order_device: workspace layout");
+  GR_HIP(hipMemcpyAsync(d_begins, stage, align_up(begins_bytes, 256) + hs_bytes, hipMemcpyHostToDevice, stream));
   GR_HIP(hipEventRecord(staged, stream));
   const dim3 blk(HO_T), grd((unsigned)((n + HO_T - 1) / HO_T));
-  hipLaunchKernelGGL(ho_init_kernel, grd, blk, 0, stream, (int)n, d_begins, (int)batch, Ta, Tb, cloud);
+  hipLaunchKernelGGL(ho_init_kernel, grd, blk, 0, stream, (int)n, d_begins, (int)batch, Ta, Tb, head, (int)buckets);
   int32_t* Tin = Ta;
   int32_t* Tout = Tb;
-  // stages whose largest m fits the LDS kernel (the rehash thresholds are the same prime sequence for every cloud)
-  size_t nsmall = 0;
-  while (nsmall < nstage) {
-    int64_t mm = 0, nn = 0;
+  const HoEmit em{perm_out, rows_in, row_of, rows_out};
+  // stage 0 (13 buckets) is always small: with no big stage the LDS kernel emits
+  hipLaunchKernelGGL(ho_small_stages_kernel, dim3((unsigned)batch), dim3(1024), 0, stream, d_st, (int)batch, (int)nsmall, keys,
+                     Ta, Tb, nsmall == nstage ? 1 : 0, em);
+  const bool prescan_always = getenv("GR_HASH_ORDER_PRESCAN") != nullptr;  // test knob: the > 4 M-clock path
+  int64_t big_m = 0;
+  for (size_t k = nsmall; k < nstage; ++k)
     for (int64_t c = 0; c < batch; ++c)
-      if (hs[nsmall * batch + c].n) {
-        mm = std::max<int64_t>(mm, hs[nsmall * batch + c].m);
-        nn = std::max<int64_t>(nn, hs[nsmall * batch + c].n);
-      }
-    if (mm > HO_SMALL || nn > HO_SMALL) break;
-    ++nsmall;
-  }
-  if (nsmall > 0)
-    hipLaunchKernelGGL(ho_small_stages_kernel, dim3((unsigned)batch), dim3(1024), 0, stream, d_st, (int)batch, (int)nsmall, keys,
-                       Ta, Tb);
+      if (hs[k * batch + c].n) big_m = std::max<int64_t>(big_m, hs[k * batch + c].m);
+  if (nsmall < nstage && big_m > 0)
+    hipLaunchKernelGGL(ho_bucket_kernel, dim3((unsigned)((big_m + HO_T - 1) / HO_T), (unsigned)batch, (unsigned)(nstage - nsmall)),
+                       blk, 0, stream, d_st + nsmall * batch, (int)batch, keys, bkt, head, nxt);
   for (size_t k = nsmall; k < nstage; ++k) {
     const HoCloud* st = d_st + k * batch;
-    int64_t max_m = 0, max_n = 0;
-    for (int64_t c = 0; c < batch; ++c) {
-      const HoCloud& hc = hs[k * batch + c];
-      max_m = std::max<int64_t>(max_m, hc.m);
-      max_n = std::max<int64_t>(max_n, hc.n);
-    }
+    int64_t max_m = 0;  // every cloud takes part: finished ones have their positions carried along (or emitted)
+    for (int64_t c = 0; c < batch; ++c) max_m = std::max<int64_t>(max_m, hs[k * batch + c].m);
+    const bool last = k + 1 == nstage;
     if (max_m == 0) continue;
-    (void)max_n;
     const dim3 eg((unsigned)((max_m + HO_T - 1) / HO_T), (unsigned)batch);
-    hipLaunchKernelGGL(ho_bucket_kernel, eg, blk, 0, stream, st, keys, bkt, head, nxt);
     hipLaunchKernelGGL(ho_group_kernel, eg, blk, 0, stream, st, Tin, bkt, head, nxt, G);
-    hipLaunchKernelGGL(ho_suffix_kernel, dim3((unsigned)batch), dim3(1024), 0, stream, st, G, S);
-    hipLaunchKernelGGL(ho_rank_kernel, eg, blk, 0, stream, st, Tin, bkt, head, nxt, S, Tout);
+    const int64_t nslab = (max_m + HO_SLAB - 1) / HO_SLAB;
+    hipLaunchKernelGGL(ho_suffix_kernel, dim3((unsigned)nslab, (unsigned)batch), dim3(HO_SLAB), 0, stream, st, G, head, S);
+    const bool pre = nslab > HO_TAB || prescan_always;
+    if (pre) hipLaunchKernelGGL(ho_slabscan_kernel, dim3((unsigned)batch), dim3(1024), 0, stream, st, head);
+#define GR_HO_RANK(P, L) \
+  hipLaunchKernelGGL((ho_rank_kernel<P, L>), eg, blk, 0, stream, st, Tin, bkt, head, nxt, S, head, Tout, em)
+    if (pre) {
+      if (last) GR_HO_RANK(true, true); else GR_HO_RANK(true, false);
+    } else {
+      if (last) GR_HO_RANK(false, true); else GR_HO_RANK(false, false);
+    }
+#undef GR_HO_RANK
     std::swap(Tin, Tout);
   }
-  hipLaunchKernelGGL(ho_emit_kernel, grd, blk, 0, stream, (int)n, d_begins, cloud, Tin, perm_out);
   GR_LAUNCH_CHECK();
   return GR_OK;
 }
@@ -361,5 +467,6 @@ extern "C" int gr_hash_order_device(const uint64_t* d_keys, const int64_t* h_beg
   GR_REQUIRE(h_begins[0] == 0, "h_begins must start at 0");
   for (int64_t c = 0; c < batch; ++c) GR_REQUIRE(h_begins[c + 1] >= h_begins[c], "h_begins must be non-decreasing");
   GR_REQUIRE(h_begins[batch] == 0 || (d_keys && d_perm), "null argument");
-  return gr::hash_order_device(d_keys, h_begins, batch, d_perm, ws, ws_bytes, static_cast<hipStream_t>(stream));
+  return gr::hash_order_device(d_keys, h_begins, batch, d_perm, ws, ws_bytes, static_cast<hipStream_t>(stream), nullptr, nullptr,
+                               nullptr);
 }

@@ -60,9 +60,14 @@ def test_device_order_equals_host_replay_across_rehash_thresholds():
         assert np.array_equal(got, want), (i, len(c))
 
 
-def test_device_order_large_clouds():
+@pytest.mark.parametrize("prescan", [False, True])
+def test_device_order_large_clouds(prescan, monkeypatch):
+    """prescan: the path clouds of more than 4 M clocks take (slab totals scanned by a launch of their own)."""
+    if prescan:
+        monkeypatch.setenv("GR_HASH_ORDER_PRESCAN", "1")
     rng = np.random.default_rng(1)
-    clouds = [distinct(rng, n, kind) for n, kind in ((60000, "dense"), (49505, "random"), (100000, "dense"), (33333, "colliding"))]
+    clouds = [distinct(rng, n, kind) for n, kind in ((60000, "dense"), (49505, "random"), (100000, "dense"), (33333, "colliding"),
+                                                     (300000, "dense"))]
     perm, begins = device_order(clouds)
     for i, c in enumerate(clouds):
         assert np.array_equal(perm[begins[i]:begins[i + 1]], host_order(c) + begins[i]), i
