@@ -14,6 +14,7 @@ throughput path: per-Gaussian inputs are read once per batch).  Forward only: ou
 autograd graph (fine registration in GaussReg only renders).
 """
 import ctypes
+import os
 from typing import NamedTuple, Optional, Sequence
 
 import torch
@@ -94,6 +95,69 @@ def _dev_f32(t: Optional[torch.Tensor], dev, name):
     return t.detach().to(device=dev, dtype=torch.float32).contiguous()
 
 
+class _FramePipe:
+    """Two frames of ONE-camera calls in flight (per device).
+
+    A one-camera frame is a chain of ~15 dependent launches, most of them a few microseconds of work: alone on a stream the
+    chip idles through every hand-over.  Consecutive forward() calls therefore run on two internal streams in turn, so the
+    front of frame n+1 (preprocess, depth sort, tile counts) fills the gaps of frame n's scatter and blend.  For the caller
+    nothing changes: the outputs are joined into the caller's current stream before forward() returns.
+
+    Input readiness: a frame may only start when its input tensors are complete on the caller's stream.  In general that
+    is `side.wait_stream(current)` -- which, after the previous frame was joined into `current`, also waits for that
+    frame and serialises everything.  When the inputs are THE SAME tensors with the same version counters as in the
+    previous frame (a static scene rendered from moving cameras), they were already complete at the previous call, and
+    the frame waits only for the event recorded on the caller's stream then.  The previous frame's inputs are kept
+    referenced until the next call so that their addresses cannot be handed to other tensors in between (the stamp
+    compares storage address + version).  Writes that bypass the version counter (a foreign kernel writing through a raw
+    pointer) are not seen; GR_RASTER_PIPELINE=0 switches the pipe off."""
+
+    def __init__(self, dev):
+        self.streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        self.events = (torch.cuda.Event(), torch.cuda.Event())
+        self.turn = 0
+        self.stamp = None
+        self.keep = None
+        self.caller = None
+        self.ready = None
+
+    def begin(self, dev, inputs):
+        cur = torch.cuda.current_stream(dev)
+        side = self.streams[self.turn]
+        stamp = _lib.tensor_stamp(inputs)
+        if stamp is not None and stamp == self.stamp and self.caller == cur.cuda_stream and self.ready is not None:
+            side.wait_event(self.ready)
+        else:
+            side.wait_stream(cur)
+        self.stamp, self.keep, self.caller = stamp, inputs, cur.cuda_stream
+        return cur, side
+
+    def abort(self, cur, side):
+        self.stamp = self.keep = self.ready = None
+        cur.wait_stream(side)
+
+    def end(self, cur, side, outputs):
+        ev = self.events[self.turn]
+        ev.record(cur)  # the caller's stream up to here, BEFORE this frame is joined into it
+        self.ready = ev
+        self.turn ^= 1
+        cur.wait_stream(side)
+        for t in outputs:
+            t.record_stream(cur)
+
+
+_pipes = {}
+
+
+def _frame_pipe(dev, V):
+    if V != 1 or os.environ.get("GR_RASTER_PIPELINE", "1") == "0":
+        return None
+    p = _pipes.get(dev.index)
+    if p is None:
+        p = _pipes[dev.index] = _FramePipe(dev)
+    return p
+
+
 def rasterize_views(settings, means3D, opacities, shs=None,
                     colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, fast_exp=None):
     """Render the same Gaussians from len(settings) cameras (`settings`: a sequence of
@@ -105,10 +169,8 @@ def rasterize_views(settings, means3D, opacities, shs=None,
 
     `fast_exp=True`: the blend uses the hardware exponential (v_exp_f32) instead of the deterministic polynomial of the
     oracle -- the image is within 1e-5 relative of the bit-exact one (default False: bit-exact)."""
-    dev = _lib.require_gpu()
+    dev = means3D.device if means3D.is_cuda else _lib.require_gpu()
     L = _lib.lib()
-    if means3D.is_cuda:
-        dev = means3D.device
     n_pts = int(means3D.shape[0])
 
     def given(t):  # upstream passes empty tensors for "not provided"; with zero Gaussians everything is empty
@@ -133,11 +195,23 @@ def rasterize_views(settings, means3D, opacities, shs=None,
     rot = _dev_f32(rotations, dev, "rotations") if has_sr else None
     cov = _dev_f32(cov3D_precomp, dev, "cov3D_precomp") if has_cov else None
     M = 0 if sh is None else (sh.shape[1] if sh.dim() == 3 else sh.reshape(max(P, 1), -1, 3).shape[1])
-    color = torch.empty((V, 3, H, W), dtype=torch.float32, device=dev)
-    radii = torch.empty((V, P), dtype=torch.int32, device=dev)  # every entry is written by preprocess
     nr = (ctypes.c_int64 * (V + 1))()
-    with torch.cuda.device(dev):
-        st = _lib.stream_ptr(dev)
+    pipe = _frame_pipe(dev, V)
+    cur = side = None
+    # (explicit set_device / set_stream instead of the context managers: a one-camera frame is ~0.2 ms and every
+    # microsecond of Python between two library calls is on the critical path)
+    home = torch.cuda.current_device()
+    if home != dev.index:
+        torch.cuda.set_device(dev)
+    try:
+        if pipe is not None:
+            cur, side = pipe.begin(dev, tuple(t for t in (m, op, sh, cp, sc, rot, cov) if t is not None))
+            torch.cuda.set_stream(side)  # allocations below come from the side stream's pool
+            st = ctypes.c_void_p(side.cuda_stream)
+        else:
+            st = _lib.stream_ptr(dev)
+        color = torch.empty((V, 3, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((V, P), dtype=torch.int32, device=dev)  # every entry is written by preprocess
         geom = torch.empty(L.gr_raster_geom_bytes(P, V, W, H) + 256, dtype=torch.uint8, device=dev)
         flags = _flags(fast_exp)
         # the binning buffer is sized from the last call of this shape (+ 25 %): the library is entered once per frame, and
@@ -159,6 +233,17 @@ def rasterize_views(settings, means3D, opacities, shs=None,
         if len(_bin_hint) > 64:
             _bin_hint.clear()
         _bin_hint[key] = (need + need // 4 + 1024, int(nr[V]))
+        if pipe is not None:
+            torch.cuda.set_stream(cur)
+            pipe.end(cur, side, (color, radii))
+    except BaseException:
+        if pipe is not None and cur is not None:
+            torch.cuda.set_stream(cur)
+            pipe.abort(cur, side)
+        raise
+    finally:
+        if home != dev.index:
+            torch.cuda.set_device(home)
     return color, radii, [int(nr[v]) for v in range(V)]
 
 

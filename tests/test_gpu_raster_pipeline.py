@@ -1,0 +1,81 @@
+"""One-camera forward() calls run two frames in flight on internal streams (gaussreg_amd/rasterizer.py _FramePipe).  What
+must hold: every frame is bit-equal to the same call with the pipe switched off, an in-place update of a scene tensor
+between two calls is rendered, a scene replaced by new tensors is rendered, and a caller on its own stream gets its
+outputs ordered on that stream."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(P=60000, W=320, H=192, V=3, seed=11):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from helpers import raster_scene
+    g, cams = raster_scene(P, W, H, seed=seed, V=V)
+    t = {k: torch.from_numpy(v).cuda() for k, v in g.items()}
+    rast = [GaussianRasterizer(GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=c["tanfovx"], tanfovy=c["tanfovy"], bg=torch.tensor([0.1, 0.2, 0.3]).cuda(),
+        scale_modifier=1.0, viewmatrix=torch.from_numpy(c["viewmatrix"]).cuda(), projmatrix=torch.from_numpy(c["projmatrix"]).cuda(),
+        sh_degree=3, campos=torch.from_numpy(c["campos"]).cuda(), prefiltered=False, debug=False)) for c in cams]
+    return t, rast
+
+
+def _render(r, t):
+    return r(means3D=t["means3D"], means2D=None, opacities=t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+
+
+def _reference(rast, t, monkeypatch):
+    with monkeypatch.context() as mp:
+        mp.setenv("GR_RASTER_PIPELINE", "0")
+        out = [tuple(x.clone() for x in _render(r, t)) for r in rast]
+    torch.cuda.synchronize()
+    return out
+
+
+def test_frames_in_flight_equal_the_serial_frames(monkeypatch):
+    t, rast = _setup()
+    want = _reference(rast, t, monkeypatch)
+    assert not torch.equal(want[0][0], want[1][0])
+    # outputs are kept and checked at the end: nothing synchronises between the calls
+    got = [_render(rast[i % len(rast)], t) for i in range(12)]
+    for i, (img, radii) in enumerate(got):
+        assert torch.equal(img, want[i % len(rast)][0]) and torch.equal(radii, want[i % len(rast)][1]), i
+
+
+def test_in_place_update_and_replaced_scene_are_rendered(monkeypatch):
+    t, rast = _setup(seed=12)
+    a0 = _render(rast[0], t)[0]
+    a1 = _render(rast[1], t)[0]
+    # in place, on the caller's stream, right after two frames were queued
+    t["means3D"].add_(torch.tensor([0.05, -0.02, 0.03], device="cuda"))
+    t["opacities"].mul_(0.9)
+    b0 = _render(rast[0], t)[0]
+    b1 = _render(rast[1], t)[0]
+    # new tensors (new storage, version counters start again)
+    t2 = {k: (v * 1.0) for k, v in t.items()}
+    t2["shs"] = t2["shs"] * 0.5
+    c0 = _render(rast[0], t2)[0]
+    c2 = _render(rast[2], t2)[0]
+    t_now = {k: v.clone() for k, v in t.items()}
+    want_b = _reference(rast, t_now, monkeypatch)
+    want_c = _reference(rast, t2, monkeypatch)
+    assert torch.equal(b0, want_b[0][0]) and torch.equal(b1, want_b[1][0])
+    assert torch.equal(c0, want_c[0][0]) and torch.equal(c2, want_c[2][0])
+    assert not torch.equal(a0, b0) and not torch.equal(a1, b1) and not torch.equal(b0, c0)
+
+
+def test_caller_on_its_own_stream(monkeypatch):
+    t, rast = _setup(seed=13)
+    want = _reference(rast, t, monkeypatch)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    sums = []
+    with torch.cuda.stream(s):
+        scene = {k: v + 0.0 for k, v in t.items()}      # produced on s, consumed by the frames
+        for i in range(6):
+            img, radii = _render(rast[i % 3], scene)
+            sums.append((img.double().sum(), radii.long().sum()))  # consumers on s, straight after the call
+    s.synchronize()
+    for i, (a, b) in enumerate(sums):
+        assert float(a) == float(want[i % 3][0].double().sum()) and int(b) == int(want[i % 3][1].long().sum()), i
