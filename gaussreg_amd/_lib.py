@@ -59,6 +59,7 @@ SIGNATURES.update({
                                     c_void, c_int, c_void]),
     "gr_raster_forward": (c_int, [c_i64, c_int] + [c_void] * 7 + [ctypes.POINTER(RasterView), c_int, c_void, c_void, c_size,
                                   c_void, c_size, c_void, c_int, c_i64p, c_void]),
+    "gr_raster_forward_finish": (c_int, [c_i64p]),
     "gr_raster_lds_atomics_lane_ordered": (c_int, []),
     "gr_raster_mark_visible": (c_int, [c_i64, c_void, ctypes.POINTER(c_f32), c_void, c_void]),
 })
@@ -160,6 +161,8 @@ def lib():
     return _lib
 
 
+GR_PENDING = 2     # gr_raster_forward(GR_RASTER_SPLIT): enqueued, gr_raster_forward_finish collects the counts
+GR_RETRY_FULL = 3  # gr_raster_forward_finish: repeat the frame with an unsplit gr_raster_forward (depth >= 8192)
 GR_RETRY_BIN = 1   # include/gaussreg_hip.h: gr_raster_forward's "bin buffer too small, call gr_raster_render_ex" status
 
 

@@ -1686,6 +1686,35 @@ extern "C" int gr_raster_render_ex(int64_t P, const gr_raster_view* h_views, int
                      static_cast<hipStream_t>(stream_));
 }
 
+namespace gr {
+namespace {
+struct Pending {  // a gr_raster_forward(GR_RASTER_SPLIT) of this thread whose counts have not been collected yet
+  bool open;
+  int64_t P;
+  int num_views;
+  int64_t entries;
+  Deferred d;
+  hipStream_t stream;
+};
+thread_local Pending g_pending{false, 0, 0, 0, Deferred{nullptr, nullptr, 0, 0, false}, nullptr};
+}  // namespace
+}  // namespace gr
+
+extern "C" int gr_raster_forward_finish(int64_t* h_num_rendered) {
+  using namespace gr;
+  GR_REQUIRE(g_pending.open, "gr_raster_forward_finish: no split gr_raster_forward is open on this thread");
+  GR_REQUIRE(h_num_rendered != nullptr, "h_num_rendered is null");
+  Pending p = g_pending;
+  g_pending.open = false;
+  bool far_depth = false;
+  int rc = preprocess_collect(p.P, p.num_views, h_num_rendered, &far_depth, p.d, p.stream);
+  if (rc != GR_OK) return rc;
+  int64_t R = 0;
+  for (int v = 0; v < p.num_views; ++v) R += h_num_rendered[v];
+  if (far_depth) return GR_RETRY_FULL;
+  return R <= p.entries ? GR_OK : GR_RETRY_BIN;
+}
+
 extern "C" int gr_raster_forward(int64_t P, int M, const float* means3D, const float* shs, const float* colors_precomp,
                                  const float* opacities, const float* scales, const float* rotations,
                                  const float* cov3D_precomp, const gr_raster_view* h_views, int num_views, int32_t* radii,
@@ -1693,6 +1722,7 @@ extern "C" int gr_raster_forward(int64_t P, int M, const float* means3D, const f
                                  int64_t* h_num_rendered, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   GR_REQUIRE(h_num_rendered != nullptr, "h_num_rendered is null");
+  GR_REQUIRE(!g_pending.open, "gr_raster_forward: the previous split call of this thread was not finished");
   const int64_t stage_hint = h_num_rendered[num_views > 0 ? num_views : 0];  // in: last frame's largest chunk (0 = unknown)
   const int64_t entries = bin && bin_bytes > 512 ? (int64_t)((bin_bytes - 512) / sizeof(int32_t)) - 64 : -1;
   static const bool no_spec = getenv("GR_RASTER_NO_SPECULATION") && getenv("GR_RASTER_NO_SPECULATION")[0] == '1';
@@ -1729,6 +1759,10 @@ extern "C" int gr_raster_forward(int64_t P, int M, const float* means3D, const f
     h_num_rendered[num_views] = stage_hint;
     rc = render_impl(P, h_views, num_views, h_num_rendered, geom, geom_bytes, bin, bin_bytes, out_color, flags, entries, stream);
     if (rc != GR_OK) return rc;
+    if (flags & GR_RASTER_SPLIT) {  // the caller comes back with gr_raster_forward_finish (same thread)
+      g_pending = Pending{true, P, num_views, entries, d, stream};
+      return GR_PENDING;
+    }
     bool far_depth = false;
     rc = preprocess_collect(P, num_views, h_num_rendered, &far_depth, d, stream);
     if (rc != GR_OK) return rc;

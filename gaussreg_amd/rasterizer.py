@@ -38,6 +38,7 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 FAST_EXP = 1  # GR_RASTER_FAST_EXP (include/gaussreg_hip.h)
+SPLIT = 2     # GR_RASTER_SPLIT
 _ENV_FAST = None
 _bin_hint = {}  # (device, P, V, W, H) -> (bytes of the binning buffer, largest chunk) the last call of that shape needed
 
@@ -220,9 +221,27 @@ def rasterize_views(settings, means3D, opacities, shs=None,
         hint, chunk_hint = _bin_hint.get(key, (0, 0))
         binb = torch.empty(hint + 256, dtype=torch.uint8, device=dev) if hint else None
         nr[V] = chunk_hint  # in: sizes the scatter's staging block of the speculative launch; out: this call's figure
-        rc = L.gr_raster_forward(P, M, _lib.ptr(m), _lib.ptr(sh), _lib.ptr(cp), _lib.ptr(op), _lib.ptr(sc), _lib.ptr(rot),
-                                 _lib.ptr(cov), views, V, _lib.ptr(radii), _lib.ptr(geom), geom.numel(), _lib.ptr(binb),
-                                 binb.numel() if binb is not None else 0, _lib.ptr(color), flags, nr, st)
+
+        def forward(fl):
+            return L.gr_raster_forward(P, M, _lib.ptr(m), _lib.ptr(sh), _lib.ptr(cp), _lib.ptr(op), _lib.ptr(sc), _lib.ptr(rot),
+                                       _lib.ptr(cov), views, V, _lib.ptr(radii), _lib.ptr(geom), geom.numel(), _lib.ptr(binb),
+                                       binb.numel() if binb is not None else 0, _lib.ptr(color), fl, nr, st)
+        # with the pipe: the library returns as soon as the frame is enqueued, and the stream joins below run while the GPU
+        # works through the front of the frame; gr_raster_forward_finish then waits for the instance counts
+        rc = forward(flags | (SPLIT if pipe is not None else 0))
+        joined = False
+        if rc == _lib.GR_PENDING:
+            try:
+                torch.cuda.set_stream(cur)
+                pipe.end(cur, side, (color, radii))
+                joined = True
+            finally:
+                rc = L.gr_raster_forward_finish(nr)
+            if rc in (_lib.GR_RETRY_BIN, _lib.GR_RETRY_FULL):  # rare: more work for this frame on the side stream
+                torch.cuda.set_stream(side)
+                joined = False
+            if rc == _lib.GR_RETRY_FULL:
+                rc = forward(flags)
         _lib.check(rc, allow=(_lib.GR_RETRY_BIN,))
         total = sum(int(nr[v]) for v in range(V))
         need = L.gr_raster_bin_bytes(total, W, H, V)
@@ -233,7 +252,7 @@ def rasterize_views(settings, means3D, opacities, shs=None,
         if len(_bin_hint) > 64:
             _bin_hint.clear()
         _bin_hint[key] = (need + need // 4 + 1024, int(nr[V]))
-        if pipe is not None:
+        if pipe is not None and not joined:
             torch.cuda.set_stream(cur)
             pipe.end(cur, side, (color, radii))
     except BaseException:

@@ -196,6 +196,17 @@ int gr_raster_forward(int64_t P, int M, const float* means3D, const float* shs, 
                       const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
                       const gr_raster_view* h_views, int num_views, int32_t* radii, void* geom, size_t geom_bytes,
                       void* bin, size_t bin_bytes, float* out_color, int flags, int64_t* h_num_rendered, void* stream);
+/* Split form for callers with host work of their own per frame (the Python wrapper's stream joins and bookkeeping):
+ * with GR_RASTER_SPLIT in `flags`, gr_raster_forward returns GR_PENDING as soon as the frame is enqueued (speculatively,
+ * on `bin`) instead of waiting for the instance counts; gr_raster_forward_finish -- same host thread, before its next
+ * gr_raster_forward -- waits for them, fills h_num_rendered ([num_views] + the staging figure) and returns GR_OK (the frame
+ * is complete on the stream), GR_RETRY_BIN (as above), or GR_RETRY_FULL (a depth >= 8192 needs the full-width sort: the
+ * caller repeats the frame with an unsplit gr_raster_forward).  Without speculation (no `bin`, > 4 views, a verification
+ * frame) gr_raster_forward ignores the flag and returns its usual codes. */
+#define GR_RASTER_SPLIT 2
+#define GR_PENDING 2
+#define GR_RETRY_FULL 3
+int gr_raster_forward_finish(int64_t* h_num_rendered);
 /* Which ranking the tile-binning scatter uses on the current device: 1 = one LDS atomic per instance (the device was
  * probed and serves equal-address lanes of a ds_add_rtn in lane order), 0 = explicit ballot ranking (probe failed, or
  * GR_RASTER_BALLOT_RANKING=1), -1 = no render call has probed the device yet.  Both produce the same lists. */

@@ -17,6 +17,13 @@ acc = {"c": 0.0, "n": 0}
 class Wrap:
     def __getattr__(self, name):
         f = getattr(L, name)
+        if name == "gr_raster_forward_finish":
+            def timed_f(*a):
+                t0 = time.perf_counter()
+                r = f(*a)
+                acc["f"] = acc.get("f", 0.0) + time.perf_counter() - t0
+                return r
+            return timed_f
         if name != "gr_raster_forward":
             return f
         def timed(*a):
@@ -32,12 +39,14 @@ def loop(n):
         rast[i % 4](t["means3D"], None, t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
 loop(20)
 torch.cuda.synchronize()
-acc["c"] = 0.0; acc["n"] = 0
+acc["c"] = 0.0; acc["n"] = 0; acc["f"] = 0.0
 t0 = time.perf_counter()
 loop(400)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 400
-print("per call %.1f us; inside gr_raster_forward %.1f us; Python around it %.1f us" % (dt * 1e6, acc["c"] / acc["n"] * 1e6, (dt - acc["c"] / acc["n"]) * 1e6))
+c, f = acc["c"] / acc["n"] * 1e6, acc["f"] / acc["n"] * 1e6
+print("per call %.1f us; inside gr_raster_forward %.1f us (enqueue); inside gr_raster_forward_finish %.1f us (waiting for the counts); "
+      "Python around them %.1f us" % (dt * 1e6, c, f, dt * 1e6 - c - f))
 if "--profile" in sys.argv:
     import cProfile, pstats
     pr = cProfile.Profile(); pr.enable(); loop(400); pr.disable()
