@@ -229,7 +229,7 @@ def rasterize_views(settings, means3D, opacities, shs=None,
         # with the pipe: the library returns as soon as the frame is enqueued, and the stream joins below run while the GPU
         # works through the front of the frame; gr_raster_forward_finish then waits for the instance counts
         rc = forward(flags | (SPLIT if pipe is not None else 0))
-        joined = False
+        joined = rejoin = False
         if rc == _lib.GR_PENDING:
             try:
                 torch.cuda.set_stream(cur)
@@ -239,7 +239,7 @@ def rasterize_views(settings, means3D, opacities, shs=None,
                 rc = L.gr_raster_forward_finish(nr)
             if rc in (_lib.GR_RETRY_BIN, _lib.GR_RETRY_FULL):  # rare: more work for this frame on the side stream
                 torch.cuda.set_stream(side)
-                joined = False
+                rejoin = True
             if rc == _lib.GR_RETRY_FULL:
                 rc = forward(flags)
         _lib.check(rc, allow=(_lib.GR_RETRY_BIN,))
@@ -252,9 +252,12 @@ def rasterize_views(settings, means3D, opacities, shs=None,
         if len(_bin_hint) > 64:
             _bin_hint.clear()
         _bin_hint[key] = (need + need // 4 + 1024, int(nr[V]))
-        if pipe is not None and not joined:
+        if pipe is not None:
             torch.cuda.set_stream(cur)
-            pipe.end(cur, side, (color, radii))
+            if not joined:
+                pipe.end(cur, side, (color, radii))
+            elif rejoin:
+                cur.wait_stream(side)
     except BaseException:
         if pipe is not None and cur is not None:
             torch.cuda.set_stream(cur)

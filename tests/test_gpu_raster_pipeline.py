@@ -79,3 +79,25 @@ def test_caller_on_its_own_stream(monkeypatch):
     s.synchronize()
     for i, (a, b) in enumerate(sums):
         assert float(a) == float(want[i % 3][0].double().sum()) and int(b) == int(want[i % 3][1].long().sum()), i
+
+
+def test_frames_that_outgrow_the_speculative_list(monkeypatch):
+    """A narrow camera (few instances) followed by wide ones: the list sized from the previous frame is too small, the
+    split call reports GR_RETRY_BIN and the frame is drawn again inside the pipe."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from gaussreg_amd import synthetic
+    W, H, P = 320, 192, 60000
+    g = synthetic.gaussians_c2(P, 14, sh_degree=3)
+    t = {k: torch.from_numpy(v).cuda() for k, v in g.items()}
+    cams = [synthetic.camera(W, H, fovx_deg=4.0), synthetic.camera(W, H, fovx_deg=75.0),
+            synthetic.camera(W, H, fovx_deg=60.0, R_c2w=synthetic.rot_yx(0.2, -0.1), C=np.array([0.2, 0.1, -0.1]))]
+    rast = [GaussianRasterizer(GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=c["tanfovx"], tanfovy=c["tanfovy"], bg=torch.zeros(3).cuda(), scale_modifier=1.0,
+        viewmatrix=torch.from_numpy(c["viewmatrix"]).cuda(), projmatrix=torch.from_numpy(c["projmatrix"]).cuda(), sh_degree=3,
+        campos=torch.from_numpy(c["campos"]).cuda(), prefiltered=False, debug=False)) for c in cams]
+    want = _reference(rast, t, monkeypatch)
+    order = [0, 0, 1, 0, 2, 1, 0, 0, 2, 2, 1]
+    got = [_render(rast[i], t) for i in order]
+    for k, i in enumerate(order):
+        assert torch.equal(got[k][0], want[i][0]) and torch.equal(got[k][1], want[i][1]), (k, i)
+    assert int((want[0][1] > 0).sum()) * 4 < int((want[1][1] > 0).sum())  # the narrow view really sees far fewer Gaussians
