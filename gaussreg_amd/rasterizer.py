@@ -15,6 +15,7 @@ autograd graph (fine registration in GaussReg only renders).
 """
 import ctypes
 import os
+import threading
 from typing import NamedTuple, Optional, Sequence
 
 import torch
@@ -147,15 +148,18 @@ class _FramePipe:
             t.record_stream(cur)
 
 
-_pipes = {}
+_pipes = threading.local()  # per host thread (the library's split-call state is per thread too) and device
 
 
 def _frame_pipe(dev, V):
     if V != 1 or os.environ.get("GR_RASTER_PIPELINE", "1") == "0":
         return None
-    p = _pipes.get(dev.index)
+    table = getattr(_pipes, "table", None)
+    if table is None:
+        table = _pipes.table = {}
+    p = table.get(dev.index)
     if p is None:
-        p = _pipes[dev.index] = _FramePipe(dev)
+        p = table[dev.index] = _FramePipe(dev)
     return p
 
 

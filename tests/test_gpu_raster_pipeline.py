@@ -101,3 +101,29 @@ def test_frames_that_outgrow_the_speculative_list(monkeypatch):
     for k, i in enumerate(order):
         assert torch.equal(got[k][0], want[i][0]) and torch.equal(got[k][1], want[i][1]), (k, i)
     assert int((want[0][1] > 0).sum()) * 4 < int((want[1][1] > 0).sum())  # the narrow view really sees far fewer Gaussians
+
+
+def test_two_host_threads_render_side_by_side(monkeypatch):
+    """The frame pipe (and the library's split-call state) is per host thread: two threads rendering the same scene through
+    their own rasterizer objects get the serial frames."""
+    import threading
+    t, rast = _setup(seed=15)
+    want = _reference(rast, t, monkeypatch)
+    out, err = {}, []
+
+    def work(k):
+        try:
+            frames = [_render(rast[(i + k) % 3], t) for i in range(8)]
+            torch.cuda.synchronize()
+            out[k] = frames
+        except Exception as e:  # pragma: no cover
+            err.append(e)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not err, err
+    for k in range(2):
+        for i, (img, radii) in enumerate(out[k]):
+            assert torch.equal(img, want[(i + k) % 3][0]) and torch.equal(radii, want[(i + k) % 3][1]), (k, i)
