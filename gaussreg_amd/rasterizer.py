@@ -122,6 +122,7 @@ class _FramePipe:
         self.keep = None
         self.caller = None
         self.ready = None
+        self.ptrs = None   # the marshalled input pointers of the scene with this stamp (set by rasterize_views)
 
     def begin(self, dev, inputs):
         cur = torch.cuda.current_stream(dev)
@@ -131,11 +132,12 @@ class _FramePipe:
             side.wait_event(self.ready)
         else:
             side.wait_stream(cur)
+            self.ptrs = None
         self.stamp, self.keep, self.caller = stamp, inputs, cur.cuda_stream
         return cur, side
 
     def abort(self, cur, side):
-        self.stamp = self.keep = self.ready = None
+        self.stamp = self.keep = self.ready = self.ptrs = None
         cur.wait_stream(side)
 
     def end(self, cur, side, outputs):
@@ -163,8 +165,11 @@ def _frame_pipe(dev, V):
     return p
 
 
+_geom_bytes = {}
+
+
 def rasterize_views(settings, means3D, opacities, shs=None,
-                    colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, fast_exp=None):
+                    colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, fast_exp=None, _one=False):
     """Render the same Gaussians from len(settings) cameras (`settings`: a sequence of
     GaussianRasterizationSettings, or a prebuilt ViewBatch).
 
@@ -173,7 +178,8 @@ def rasterize_views(settings, means3D, opacities, shs=None,
     anywhere in the tile are dropped before the sort; the image is unaffected).
 
     `fast_exp=True`: the blend uses the hardware exponential (v_exp_f32) instead of the deterministic polynomial of the
-    oracle -- the image is within 1e-5 relative of the bit-exact one (default False: bit-exact)."""
+    oracle -- the image is within 1e-5 relative of the bit-exact one (default False: bit-exact).
+    (`_one`: internal, one camera -- the outputs come back as (3,H,W) and (P,), no view ops on the way out.)"""
     dev = means3D.device if means3D.is_cuda else _lib.require_gpu()
     L = _lib.lib()
     n_pts = int(means3D.shape[0])
@@ -215,9 +221,16 @@ def rasterize_views(settings, means3D, opacities, shs=None,
             st = ctypes.c_void_p(side.cuda_stream)
         else:
             st = _lib.stream_ptr(dev)
-        color = torch.empty((V, 3, H, W), dtype=torch.float32, device=dev)
-        radii = torch.empty((V, P), dtype=torch.int32, device=dev)  # every entry is written by preprocess
-        geom = torch.empty(L.gr_raster_geom_bytes(P, V, W, H) + 256, dtype=torch.uint8, device=dev)
+        one = _one and V == 1
+        color = torch.empty((3, H, W) if one else (V, 3, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((P,) if one else (V, P), dtype=torch.int32, device=dev)  # every entry is written by preprocess
+        gkey = (P, V, W, H)
+        gbytes = _geom_bytes.get(gkey)
+        if gbytes is None:
+            if len(_geom_bytes) > 64:
+                _geom_bytes.clear()
+            gbytes = _geom_bytes[gkey] = L.gr_raster_geom_bytes(P, V, W, H) + 256
+        geom = torch.empty(gbytes, dtype=torch.uint8, device=dev)
         flags = _flags(fast_exp)
         # the binning buffer is sized from the last call of this shape (+ 25 %): the library is entered once per frame, and
         # only a frame that needs more comes back for a larger buffer
@@ -226,10 +239,17 @@ def rasterize_views(settings, means3D, opacities, shs=None,
         binb = torch.empty(hint + 256, dtype=torch.uint8, device=dev) if hint else None
         nr[V] = chunk_hint  # in: sizes the scatter's staging block of the speculative launch; out: this call's figure
 
+        # (the inputs' pointers are marshalled once per scene: the pipe keeps them while the stamp stays the same)
+        if pipe is not None and pipe.ptrs is not None:
+            ptrs = pipe.ptrs
+        else:
+            ptrs = (_lib.ptr(m), _lib.ptr(sh), _lib.ptr(cp), _lib.ptr(op), _lib.ptr(sc), _lib.ptr(rot), _lib.ptr(cov))
+            if pipe is not None:
+                pipe.ptrs = ptrs
+
         def forward(fl):
-            return L.gr_raster_forward(P, M, _lib.ptr(m), _lib.ptr(sh), _lib.ptr(cp), _lib.ptr(op), _lib.ptr(sc), _lib.ptr(rot),
-                                       _lib.ptr(cov), views, V, _lib.ptr(radii), _lib.ptr(geom), geom.numel(), _lib.ptr(binb),
-                                       binb.numel() if binb is not None else 0, _lib.ptr(color), fl, nr, st)
+            return L.gr_raster_forward(P, M, *ptrs, views, V, _lib.ptr(radii), _lib.ptr(geom), gbytes, _lib.ptr(binb),
+                                       hint + 256 if binb is not None else 0, _lib.ptr(color), fl, nr, st)
         # with the pipe: the library returns as soon as the frame is enqueued, and the stream joins below run while the GPU
         # works through the front of the frame; gr_raster_forward_finish then waits for the instance counts
         rc = forward(flags | (SPLIT if pipe is not None else 0))
@@ -278,8 +298,8 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     """`raster_settings`: GaussianRasterizationSettings, or a one-camera ViewBatch built from it (marshalled once)."""
     vb = raster_settings if isinstance(raster_settings, ViewBatch) else [raster_settings]
     color, radii, _ = rasterize_views(vb, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp,
-                                      fast_exp=fast_exp)
-    return color[0], radii[0]
+                                      fast_exp=fast_exp, _one=True)
+    return color, radii
 
 
 class GaussianRasterizer(torch.nn.Module):
