@@ -66,6 +66,48 @@ void* pinned_scratch(int slot, size_t bytes) {
   return buf[slot];
 }
 
+// ------------------------------------------------------------------ host mailbox
+volatile int32_t* mailbox() {
+  static thread_local int32_t* page = nullptr;
+  static thread_local bool tried = false;
+  if (!tried) {
+    tried = true;
+    const char* off = getenv("GR_NO_MAILBOX");
+    void* mp = nullptr;
+    if (!(off && off[0] == '1') && hipHostMalloc(&mp, MAIL_WORDS * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+      memset(mp, 0, MAIL_WORDS * sizeof(int32_t));
+      page = static_cast<int32_t*>(mp);
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  return page;
+}
+
+int mailbox_next_stamp() {
+  static std::atomic<int> seq{0};
+  int s = seq.fetch_add(1) + 1;
+  if (s > 0x7ffffff0) {  // two billion calls: start over (a stale stamp of that age cannot be in flight)
+    seq.store(1);
+    s = 1;
+  }
+  return s;
+}
+
+int mailbox_wait(const volatile int32_t* stamp_word, int stamp, hipStream_t stream, const char* what) {
+  for (long spin = 0; spin < 400000000L; ++spin) {
+    if (__atomic_load_n(stamp_word, __ATOMIC_ACQUIRE) == stamp) return GR_OK;
+    if ((spin & 0xffff) == 0xffff && hipStreamQuery(stream) != hipErrorNotReady) {
+      // the stream has drained (or failed): the stamp must be there now
+      GR_HIP(hipStreamSynchronize(stream));
+      GR_REQUIRE(__atomic_load_n(stamp_word, __ATOMIC_ACQUIRE) == stamp, "%s: the kernel did not post its result", what);
+      return GR_OK;
+    }
+  }
+  set_error("%s: timed out waiting for the device", what);
+  return GR_ERR_HIP;
+}
+
 // ------------------------------------------------------------------ scan
 constexpr int SCAN_T = 256;
 constexpr int SCAN_ITEMS = 8;

@@ -91,6 +91,19 @@ int exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int rows, int
 // (slot 4, hash_order_device), so the next call on the thread finds the buffer free.
 void* pinned_scratch(int slot, size_t bytes);
 
+// Host-mapped, coherent pinned words (one 4 KB page per host thread) that a kernel writes and the host polls: a small
+// read-back without a copy in the stream and without a stream synchronise.  The kernel stores its payload, then the
+// call's stamp with a system-scope release store (mail_post); the host spins on the stamp (bounded; hipStreamQuery every
+// 65 536 polls so a failed stream is noticed).  mailbox() returns nullptr when the page cannot be mapped or
+// GR_NO_MAILBOX=1 is set -- callers then copy and synchronise as before.
+constexpr int MAIL_WORDS = 1024;
+volatile int32_t* mailbox();
+int mailbox_next_stamp();  // per process, never 0
+int mailbox_wait(const volatile int32_t* stamp_word, int stamp, hipStream_t stream, const char* what);
+__device__ __forceinline__ void mail_post(int32_t* stamp_word, int stamp) {
+  __hip_atomic_store(stamp_word, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Per-cloud bounding boxes of stacked points: bbox_dev[b*6 + {0,1,2}] = min xyz, +{3,4,5} = max xyz,
 // stored as order-preserving uints (decode with ord2f).  Empty clouds keep (0xffffffff, 0).
 // h_off: host copy of the nb+1 point offsets; h_blk: nb+1 ints of HOST scratch that must stay

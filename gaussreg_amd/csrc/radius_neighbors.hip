@@ -1525,8 +1525,9 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
 }
 
 // max / max over the per-block (max hits per query, hits per block) pairs -> hdr
+// mail (optional): the header also goes to the host's mailbox page, stamped (common.hpp) -- no copy, no stream synchronise
 __global__ __launch_bounds__(1024) void reduce_stats_kernel(const int32_t* __restrict__ blk_stats,
-                                                            int blocks, RadiusHdr* __restrict__ hdr) {
+                                                            int blocks, RadiusHdr* __restrict__ hdr, int32_t* mail, int stamp) {
   __shared__ int sh[2][1024 / WAVE];
   int mx = 0, ms = 0;
   for (int i = threadIdx.x; i < blocks; i += 1024) {
@@ -1550,6 +1551,13 @@ __global__ __launch_bounds__(1024) void reduce_stats_kernel(const int32_t* __res
     }
     hdr->max_count = (unsigned)mx;
     hdr->max_block_hits = (unsigned)ms;
+    if (mail) {
+      mail[0] = mx;
+      mail[1] = ms;
+      mail[2] = hdr->total_cells;
+      mail[3] = hdr->total_sup;
+      mail_post(mail + 4, stamp);
+    }
   }
 }
 
@@ -1558,9 +1566,35 @@ __global__ void pad_fill_kernel(int64_t* __restrict__ out, int64_t n, int64_t v)
   if (i < n) out[i] = v;
 }
 
+// Reduces the per-block statistics into the header and brings the header to the host: through the mailbox page (the
+// kernel posts it, the host polls -- no copy in the stream, no stream synchronise), else by a copy into pinned memory and a
+// synchronise.  Everything queued on `stream` before is complete when this returns.
+inline int reduce_and_read(const RadiusWs& w, int blocks, hipStream_t stream, RadiusHdr* h_out) {
+  volatile int32_t* mail = mailbox();
+  const int stamp = mail ? mailbox_next_stamp() : 0;
+  hipLaunchKernelGGL(reduce_stats_kernel, dim3(1), dim3(1024), 0, stream, w.blk_stats, blocks, w.hdr,
+                     const_cast<int32_t*>(mail), stamp);
+  GR_LAUNCH_CHECK();
+  if (mail) {
+    int rc = mailbox_wait(mail + 4, stamp, stream, "radius search");
+    if (rc != GR_OK) return rc;
+    h_out->max_count = (unsigned)mail[0];
+    h_out->max_block_hits = (unsigned)mail[1];
+    h_out->total_cells = mail[2];
+    h_out->total_sup = mail[3];
+    return GR_OK;
+  }
+  RadiusHdr* h_pinned = static_cast<RadiusHdr*>(pinned_scratch(3, sizeof(RadiusHdr)));
+  GR_REQUIRE(h_pinned != nullptr, "pinned read-back buffer could not be allocated");
+  GR_HIP(hipMemcpyAsync(h_pinned, w.hdr, sizeof(RadiusHdr), hipMemcpyDeviceToHost, stream));
+  GR_HIP(hipStreamSynchronize(stream));
+  *h_out = *h_pinned;
+  return GR_OK;
+}
+
 template <int RQ>
 int launch_count(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns, int nb, const int32_t* start_s,
-                 float r2, bool mono, hipStream_t stream) {
+                 float r2, bool mono, hipStream_t stream, RadiusHdr* h_out) {  // h_out: the header, on the host when this returns
   using L = TravLds<RQ>;
   const int blocks = (int)((nq + RQ - 1) / RQ);
   const int grid = (blocks + 7) / 8 * 8;
@@ -1568,9 +1602,7 @@ int launch_count(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t 
   hipLaunchKernelGGL((traverse_kernel<RQ, false, true>), dim3(grid), dim3(L::THREADS), L::count_bytes(nb <= L::TABLE_MAX ? nb : 0), stream, sorted_q,
                      (int)nq, w.q_off, nb, w.grids, start_s, w.sorted_s, r2, w.q_count, w.q_rng, w.q_mask, w.blk_stats,
                      0, 0, ns, (int64_t*)nullptr, 0, (unsigned long long*)nullptr, (unsigned char*)nullptr, mono ? 1 : 0);
-  hipLaunchKernelGGL(reduce_stats_kernel, dim3(1), dim3(1024), 0, stream, w.blk_stats, blocks, w.hdr);
-  GR_LAUNCH_CHECK();
-  return GR_OK;
+  return reduce_and_read(w, blocks, stream, h_out);
 }
 
 template <int RQ>
@@ -1626,7 +1658,7 @@ inline FusedCfg fused_cfg() {
 
 template <int RQ, bool ROWBUF>
 int launch_fused_t(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns, int nb, const int32_t* start_s,
-                   float r2, int64_t width, int per_q, int64_t* out, bool mono, hipStream_t stream) {
+                   float r2, int64_t width, int per_q, int64_t* out, bool mono, hipStream_t stream, RadiusHdr* h_out) {
   using L = FusedLds<RQ>;
   const int blocks = (int)((nq + RQ - 1) / RQ);
   const int grid = (blocks + 7) / 8 * 8;
@@ -1646,9 +1678,7 @@ int launch_fused_t(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_
     hipLaunchKernelGGL(kern, dim3(grid), dim3(L::THREADS), lds, stream, sorted_q, (int)nq, w.q_off, nb, w.grids, start_s,
                        w.sorted_s, (int)ns, r2, w.blk_stats, (int)width, ns, out, cap, (int)region, mono ? 1 : 0, fused_cfg().dbg_stop);
   }
-  hipLaunchKernelGGL(reduce_stats_kernel, dim3(1), dim3(1024), 0, stream, w.blk_stats, blocks, w.hdr);
-  GR_LAUNCH_CHECK();
-  return GR_OK;
+  return reduce_and_read(w, blocks, stream, h_out);
 }
 
 inline bool fused_fits(int64_t width) {
@@ -1657,15 +1687,15 @@ inline bool fused_fits(int64_t width) {
 }
 
 int launch_fused(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns, int nb, const int32_t* start_s,
-                 float r2, int64_t width, int64_t* out, bool mono, hipStream_t stream) {
+                 float r2, int64_t width, int64_t* out, bool mono, hipStream_t stream, RadiusHdr* h_out) {
   const FusedCfg c = fused_cfg();
   int rq = c.rq;
   if (rq == 128 && FusedLds<128>::total((int)width, (int)((2 * width + 2 + 15) / 16 * 16), 0) > 160 * 1024) rq = 64;
   if (rq == 128)
-    return c.rowbuf ? launch_fused_t<128, true>(w, sorted_q, nq, ns, nb, start_s, r2, width, c.per_q, out, mono, stream)
-                    : launch_fused_t<128, false>(w, sorted_q, nq, ns, nb, start_s, r2, width, c.per_q, out, mono, stream);
-  return c.rowbuf ? launch_fused_t<64, true>(w, sorted_q, nq, ns, nb, start_s, r2, width, c.per_q, out, mono, stream)
-                  : launch_fused_t<64, false>(w, sorted_q, nq, ns, nb, start_s, r2, width, c.per_q, out, mono, stream);
+    return c.rowbuf ? launch_fused_t<128, true>(w, sorted_q, nq, ns, nb, start_s, r2, width, c.per_q, out, mono, stream, h_out)
+                    : launch_fused_t<128, false>(w, sorted_q, nq, ns, nb, start_s, r2, width, c.per_q, out, mono, stream, h_out);
+  return c.rowbuf ? launch_fused_t<64, true>(w, sorted_q, nq, ns, nb, start_s, r2, width, c.per_q, out, mono, stream, h_out)
+                  : launch_fused_t<64, false>(w, sorted_q, nq, ns, nb, start_s, r2, width, c.per_q, out, mono, stream, h_out);
 }
 
 }  // namespace
@@ -1825,15 +1855,9 @@ extern "C" int gr_radius_count_cached(const float* q, const float* s, const int6
   if (P.empty) return GR_OK;  // width 0
   const RadiusWs& w = P.w;
   const bool same = P.same;
-  rc = launch_count<RT>(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, same, stream);
+  RadiusHdr h;
+  rc = launch_count<RT>(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, same, stream, &h);
   if (rc != GR_OK) return rc;
-  // the read-back lands in pinned memory (a copy into pageable memory is staged and synchronised by the runtime on top of
-  // the synchronise below)
-  RadiusHdr* h_pinned = static_cast<RadiusHdr*>(pinned_scratch(3, sizeof(RadiusHdr)));
-  GR_REQUIRE(h_pinned != nullptr, "pinned read-back buffer could not be allocated");
-  GR_HIP(hipMemcpyAsync(h_pinned, w.hdr, sizeof(RadiusHdr), hipMemcpyDeviceToHost, stream));
-  GR_HIP(hipStreamSynchronize(stream));
-  const RadiusHdr h = *h_pinned;
   h_info[0] = h.max_count;
   h_info[1] = h.max_block_hits;
   h_info[2] = same ? 1 : 0;
@@ -1903,21 +1927,18 @@ extern "C" int gr_radius_search(const float* q, const float* s, const int64_t* h
   if (rc != GR_OK) return rc;
   if (P.empty) return GR_OK;  // width 0
   const RadiusWs& w = P.w;
-  RadiusHdr* h_pinned = static_cast<RadiusHdr*>(pinned_scratch(3, sizeof(RadiusHdr)));
-  GR_REQUIRE(h_pinned != nullptr, "pinned read-back buffer could not be allocated");
   // GR_RADIUS_SINGLE_PASS=1 selects the single-pass kernel (fused_kernel above).  It is not the default: on 8 x 200 k points it
   // runs as long as count + fill together (both are bound by VALU issue: ~3 000 instructions per wave either way)
   const int mode = search_mode().load();
   bool fused = mode == 1 && fused_fits(limit);
   if (fused) {
-    rc = launch_fused(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, out, P.same, stream);
+    RadiusHdr hf;
+    rc = launch_fused(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, out, P.same, stream, &hf);
     if (rc != GR_OK) return rc;
-    GR_HIP(hipMemcpyAsync(h_pinned, w.hdr, sizeof(RadiusHdr), hipMemcpyDeviceToHost, stream));
-    GR_HIP(hipStreamSynchronize(stream));
-    h_info[0] = h_pinned->max_count;
+    h_info[0] = hf.max_count;
     h_info[2] = P.same ? 1 : 0;
-    h_info[3] = h_pinned->total_cells;
-    if (h_pinned->max_block_hits == 0) {  // no query overflowed its block's key area: `out` is complete
+    h_info[3] = hf.total_cells;
+    if (hf.max_block_hits == 0) {  // no query overflowed its block's key area: `out` is complete
       h_info[4] = 1;
       return GR_OK;
     }
@@ -1926,11 +1947,9 @@ extern "C" int gr_radius_search(const float* q, const float* s, const int64_t* h
   // fill behind the count with an LDS key area sized from the previous call of the same shape, to take the host out of the
   // middle -- 0.594 vs 0.579 ms per 8 x 200 k points: the host prepares the fill while the count runs; what is left of it
   // sits between calls, not between the kernels.)
-  rc = launch_count<RT>(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, P.same, stream);
+  RadiusHdr h;
+  rc = launch_count<RT>(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, P.same, stream, &h);
   if (rc != GR_OK) return rc;
-  GR_HIP(hipMemcpyAsync(h_pinned, w.hdr, sizeof(RadiusHdr), hipMemcpyDeviceToHost, stream));
-  GR_HIP(hipStreamSynchronize(stream));
-  const RadiusHdr h = *h_pinned;
   h_info[0] = h.max_count;
   h_info[1] = h.max_block_hits;
   h_info[2] = P.same ? 1 : 0;
