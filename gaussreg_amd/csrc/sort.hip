@@ -63,6 +63,41 @@ __global__ __launch_bounds__(RS_T) void rs_scan_kernel(uint32_t* __restrict__ hi
   if (lane == 0) totals[d] = carry;
 }
 
+// the same for long tables (millions of keys: thousands of chunks per digit): one workgroup per digit, 2048 chunks per step
+// as two int4 per thread, block scan, running carry -- a single wave walking 6 250 chunks 64 at a time took 37 us per pass
+__global__ __launch_bounds__(RS_T) void rs_scan_long_kernel(uint32_t* __restrict__ hist, int nchunk, uint32_t* __restrict__ totals) {
+  __shared__ unsigned int s_w[RS_NW];
+  const int d = blockIdx.x, lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  uint32_t* row = hist + (int64_t)d * nchunk;
+  unsigned int carry = 0u;
+  for (int c0 = 0; c0 < nchunk; c0 += RS_T * 8) {
+    const int base = c0 + (int)threadIdx.x * 8;
+    unsigned int v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = base + k < nchunk ? row[base + k] : 0u;
+    unsigned int sum = 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sum += v[k];
+    const unsigned int inc = (unsigned int)wave_incl_scan_add_dpp((int)sum);
+    if (lane == WAVE - 1) s_w[w] = inc;
+    __syncthreads();
+    unsigned int ex = carry + inc - sum, tot = 0u;
+#pragma unroll
+    for (int i = 0; i < RS_NW; ++i) {
+      ex += i < w ? s_w[i] : 0u;
+      tot += s_w[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (base + k < nchunk) row[base + k] = ex;
+      ex += v[k];
+    }
+    carry += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[d] = carry;
+}
+
 // STAGE: the chunk is first sorted inside LDS and leaves as per-digit runs (consecutive keys of a digit go to consecutive
 // addresses: with 8-bit digits a run is 8 keys = one 64-byte sector).  Without it every key is one scattered 8 + 4 byte
 // write -- fine for the launch-bound sizes (<= 500 k keys, 11-bit digits: a run would be one key anyway), 2-3x slower at
@@ -252,7 +287,10 @@ int radix_sort(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t*
     const bool iota = p == 0 && iota_period > 0;
     hipLaunchKernelGGL(rs_hist_kernel, dim3(pl.nchunk), dim3(RS_T), bins * sizeof(unsigned int), stream, kin, n, shift,
                        (unsigned)(bins - 1), bins, hist);
-    hipLaunchKernelGGL(rs_scan_kernel, dim3((bins + RS_NW - 1) / RS_NW), dim3(RS_T), 0, stream, hist, pl.nchunk, bins, totals);
+    if (pl.nchunk > 1024)
+      hipLaunchKernelGGL(rs_scan_long_kernel, dim3(bins), dim3(RS_T), 0, stream, hist, pl.nchunk, totals);
+    else
+      hipLaunchKernelGGL(rs_scan_kernel, dim3((bins + RS_NW - 1) / RS_NW), dim3(RS_T), 0, stream, hist, pl.nchunk, bins, totals);
     size_t lds = (size_t)(1 + RS_NW) * bins * sizeof(unsigned int);
     if (pl.stage) lds += (size_t)(bins + (bins & 1)) * sizeof(unsigned int) + (size_t)RS_CHUNK * 12;
 #define GR_RS_SCATTER(IO, ST)                                                                                              \

@@ -287,3 +287,17 @@ def test_large_clouds_take_the_staged_radix_sort():
         alone = farthest_point_sampling(t[o:o + n].contiguous(), [n], [2000], start_indices=[b])
         assert torch.equal(both[b], alone[0])
         o += n
+
+
+def test_millions_of_keys_take_the_long_chunk_scan():
+    """> 2 M keys = more than 1 024 chunks per digit: csrc/sort.hip scans the chunk table with one workgroup per digit
+    (rs_scan_long_kernel) and common.hip's scans run their three-launch form.  11 x 220 k points against the oracle, bit-exact
+    including the reference row order."""
+    from oracle import capi
+    rng = np.random.default_rng(23)
+    lens = np.array([220000] * 11, np.int64)
+    pts = (rng.random((int(lens.sum()), 3)) * [3, 2.5, 2]).astype(np.float32)
+    gp, gl = _ext().grid_subsampling(_t(pts), torch.from_numpy(lens), 0.05)
+    wp, wl = capi.grid_subsampling(pts, lens, 0.05)
+    assert np.array_equal(gl.numpy(), wl)
+    assert np.array_equal(gp.cpu().numpy().view(np.uint32), wp.view(np.uint32))
