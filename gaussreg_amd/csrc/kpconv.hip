@@ -267,7 +267,11 @@ constexpr int BT = 128, BK = 16, BLD = BK + 1;
 // BM = rows per workgroup: 128 (2 x 2 waves of 64 x 64) or 64 (2 x 2 waves of 32 x 64) -- the smaller tile doubles the
 // number of workgroups when M is only ~10^4 rows and the K loop (15 * Cin long, serial inside a workgroup) would
 // otherwise leave the matrix pipes of half the chip waiting on one wave per SIMD.
-template <int BM, int BN>
+// ALIGNED (Kd a multiple of the 16-wide slab, N a multiple of 4, both matrices 16-byte aligned): every fetch is one
+// unconditional float4 load on a clamped row / column -- rows and columns past the edge compute values nobody stores.  Behind
+// the bounds checks of the general path the compiler keeps each 4-byte load behind the previous one's use: sixteen memory
+// round trips per slab instead of one (the same step took the distance kernel from 56 to 92 TFLOP/s).
+template <int BM, int BN, bool ALIGNED = false>
 __global__ __launch_bounds__(256) void gemm_nn_big_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                           int M, int N, int Kd, const float* __restrict__ den,
                                                           const float* __restrict__ bias, float* __restrict__ out) {
@@ -288,7 +292,33 @@ __global__ __launch_bounds__(256) void gemm_nn_big_kernel(const float* __restric
   // staging: A tile BM rows x 16 k (coalesced along k: 16 threads per row), B tile 16 k x BN cols
   constexpr int NA = BM * BK / 256, NBv = BN * BK / 256;
   float ra[NA], rb[NBv];
+  // ALIGNED staging: A -- thread (row tid / 4 + 64 u, four consecutive k); B -- thread (k, four consecutive columns)
+  constexpr int VA = BM / 64, VB = BN / 64, BQ = BN / 4;  // float4 per thread and slab; float4 per B row of the tile
+  const float* arow[VA];
+  const float* bcol[VB];
+  if (ALIGNED) {
+#pragma unroll
+    for (int u = 0; u < VA; ++u) arow[u] = A + (int64_t)min(i0 + (tid >> 2) + 64 * u, M - 1) * Kd + (tid & 3) * 4;
+#pragma unroll
+    for (int u = 0; u < VB; ++u) {
+      const int e = tid + u * 256;
+      bcol[u] = B + (int64_t)(e / BQ) * N + min(j0 + (e % BQ) * 4, N - 4);
+    }
+  }
   auto load = [&](int k0) {
+    if (ALIGNED) {
+#pragma unroll
+      for (int u = 0; u < VA; ++u) {
+        const float4 t = *reinterpret_cast<const float4*>(arow[u] + k0);
+        ra[4 * u] = t.x, ra[4 * u + 1] = t.y, ra[4 * u + 2] = t.z, ra[4 * u + 3] = t.w;
+      }
+#pragma unroll
+      for (int u = 0; u < VB; ++u) {
+        const float4 t = *reinterpret_cast<const float4*>(bcol[u] + (int64_t)k0 * N);
+        rb[4 * u] = t.x, rb[4 * u + 1] = t.y, rb[4 * u + 2] = t.z, rb[4 * u + 3] = t.w;
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
       const int e = tid + u * 256;
@@ -305,6 +335,19 @@ __global__ __launch_bounds__(256) void gemm_nn_big_kernel(const float* __restric
     }
   };
   auto store = [&](int buf) {
+    if (ALIGNED) {
+#pragma unroll
+      for (int u = 0; u < VA; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sa[buf][(tid >> 2) + 64 * u][(tid & 3) * 4 + q] = ra[4 * u + q];
+#pragma unroll
+      for (int u = 0; u < VB; ++u) {
+        const int e = tid + u * 256;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sb[buf][(e % BQ) * 4 + q][e / BQ] = rb[4 * u + q];
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
       const int e = tid + u * 256;
@@ -476,22 +519,25 @@ extern "C" int gr_kpconv_forward(const float* s_feats, const float* q_points, co
     hipLaunchKernelGGL((kp_gather_kernel<256>), dim3((unsigned)m), dim3(256), kp_lds, stream, s_feats, q_points, s_points,
                        neighbor_indices, (int)n, (int)h, (int)cin, (int)k, kernel_points, sigma, inf, flag, WF, num);
   const int kd = (int)(k * cin);
+  static const bool no_aligned = getenv("GR_KPCONV_GEMM_GENERAL") != nullptr;
+  const bool aligned = !no_aligned && kd % BK == 0 && cout % 4 == 0 && cout >= 4 &&
+                       ((reinterpret_cast<uintptr_t>(WF) | reinterpret_cast<uintptr_t>(weights)) & 15) == 0;
   if (m >= BT && cout > 64) {
     const int64_t blocks128 = ((cout + BT - 1) / BT) * ((m + BT - 1) / BT);
     if (blocks128 >= 768) {  // three or more 128-row workgroups per CU: the big tile's operand reuse wins
       const dim3 grid((unsigned)((cout + BT - 1) / BT), (unsigned)((m + BT - 1) / BT));
-      hipLaunchKernelGGL((gemm_nn_big_kernel<128, 128>), grid, dim3(256), 0, stream, WF, weights, (int)m, (int)cout, kd, num,
-                         bias, out);
+      if (aligned) hipLaunchKernelGGL((gemm_nn_big_kernel<128, 128, true>), grid, dim3(256), 0, stream, WF, weights, (int)m, (int)cout, kd, num, bias, out);
+      else hipLaunchKernelGGL((gemm_nn_big_kernel<128, 128>), grid, dim3(256), 0, stream, WF, weights, (int)m, (int)cout, kd, num, bias, out);
     } else {
       const dim3 grid((unsigned)((cout + BT - 1) / BT), (unsigned)((m + 63) / 64));
-      hipLaunchKernelGGL((gemm_nn_big_kernel<64, 128>), grid, dim3(256), 0, stream, WF, weights, (int)m, (int)cout, kd, num,
-                         bias, out);
+      if (aligned) hipLaunchKernelGGL((gemm_nn_big_kernel<64, 128, true>), grid, dim3(256), 0, stream, WF, weights, (int)m, (int)cout, kd, num, bias, out);
+      else hipLaunchKernelGGL((gemm_nn_big_kernel<64, 128>), grid, dim3(256), 0, stream, WF, weights, (int)m, (int)cout, kd, num, bias, out);
     }
   } else if (m >= BT && cout > 16) {
     // narrow outputs (the 32- and 64-channel stages): 128 x 64 tiles, same double-buffered pipeline
     const dim3 grid((unsigned)((cout + 63) / 64), (unsigned)((m + BT - 1) / BT));
-    hipLaunchKernelGGL((gemm_nn_big_kernel<128, 64>), grid, dim3(256), 0, stream, WF, weights, (int)m, (int)cout, kd, num, bias,
-                       out);
+    if (aligned) hipLaunchKernelGGL((gemm_nn_big_kernel<128, 64, true>), grid, dim3(256), 0, stream, WF, weights, (int)m, (int)cout, kd, num, bias, out);
+    else hipLaunchKernelGGL((gemm_nn_big_kernel<128, 64>), grid, dim3(256), 0, stream, WF, weights, (int)m, (int)cout, kd, num, bias, out);
   } else {
     const dim3 grid((unsigned)((cout + GT - 1) / GT), (unsigned)((m + GT - 1) / GT));
     hipLaunchKernelGGL(gemm_nn_kernel, grid, dim3(256), 0, stream, WF, weights, (int)m, (int)cout, kd, num, bias, out);
