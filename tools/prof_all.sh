@@ -23,5 +23,5 @@ python tools/sq_summary.py gpurun_out/${R}_sq_counters.json sq1=gpurun_out/pmc_s
 cp gpurun_out/prof_bench/bench_kernel_stats.csv gpurun_out/${R}_bench_kernel_stats.csv
 cp gpurun_out/prof_sv/sv_kernel_stats.csv gpurun_out/${R}_single_view_kernel_stats.csv
 cp gpurun_out/prof_extras/extras_kernel_stats.csv gpurun_out/${R}_extras_kernel_stats.csv
-python tools/trace_gaps.py gpurun_out/prof_sv preprocess > gpurun_out/${R}_single_view_timeline.txt 2>&1
+python tools/trace_streams.py gpurun_out/prof_sv 64 > gpurun_out/${R}_single_view_timeline.txt 2>&1   # two frames in flight: queue, start -> end per kernel
 rm -f gpurun_out/pmc_*/*.csv gpurun_out/prof_*/*trace*.csv
