@@ -303,11 +303,19 @@ constexpr int BBOX_CHUNK = 1024;  // points per block (3072 floats = 256 threads
 // Block `blk` reduces one BBOX_CHUNK-point slice of ONE cloud (blk_off[b] = first block of cloud
 // b), reading it as a flat, fully coalesced float stream, and issues 6 atomics.
 // (Same-address global atomics cost ~11 ns each: one per wave was 200 us for 200 k points.)
+// post (optional): ticket = a zeroed counter, mail = the host's mailbox page -- the LAST workgroup to finish copies the 6 nb
+// words to mail[0 .. 6 nb) and stamps mail[6 nb] (common.hpp): the host gets the boxes without a copy in the stream.
+struct BboxPost {
+  int32_t* ticket;
+  int32_t* mail;
+  int stamp;
+};
 __global__ __launch_bounds__(256) void bbox_kernel(const float* __restrict__ pts,
                                                    const int32_t* __restrict__ off,
                                                    const int32_t* __restrict__ blk_off, int nb,
-                                                   uint32_t* __restrict__ bbox) {
+                                                   uint32_t* __restrict__ bbox, BboxPost post) {
   __shared__ uint32_t red[6][256 / WAVE];
+  __shared__ int s_last;
   const int b0 = find_batch(blk_off, nb, (int)blockIdx.x);
   const int p_first = off[b0] + ((int)blockIdx.x - blk_off[b0]) * BBOX_CHUNK;
   const int p_end = min(off[b0 + 1], p_first + BBOX_CHUNK);
@@ -368,6 +376,18 @@ __global__ __launch_bounds__(256) void bbox_kernel(const float* __restrict__ pts
     if (threadIdx.x < 3) atomicMin(&bbox[b0 * 6 + threadIdx.x], v);
     else atomicMax(&bbox[b0 * 6 + threadIdx.x], v);
   }
+  if (post.mail == nullptr) return;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_last = __hip_atomic_fetch_add(post.ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1 ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  for (int i = threadIdx.x; i < 6 * nb; i += 256)
+    post.mail[i] = (int32_t)__hip_atomic_load(&bbox[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) mail_post(post.mail + 6 * nb, post.stamp);
 }
 
 __global__ void bbox_init_kernel(uint32_t* __restrict__ bbox, int nb) {
@@ -382,7 +402,8 @@ void bbox_block_offsets(const int32_t* h_off, int32_t* blk, int nb) {
 }
 
 int compute_bbox(const float* pts, const int32_t* h_off, int32_t* blk, const int32_t* off_dev, int nb,
-                 uint32_t* bbox_dev, int32_t* blk_off_dev, hipStream_t stream, bool blk_off_on_device, bool init_bbox) {
+                 uint32_t* bbox_dev, int32_t* blk_off_dev, hipStream_t stream, bool blk_off_on_device, bool init_bbox,
+                 int32_t* zeroed_ticket, int32_t* mail, int stamp) {
   if (nb <= 0) return GR_OK;
   if (!blk_off_on_device) {
     bbox_block_offsets(h_off, blk, nb);
@@ -390,7 +411,8 @@ int compute_bbox(const float* pts, const int32_t* h_off, int32_t* blk, const int
   }
   if (init_bbox) hipLaunchKernelGGL(bbox_init_kernel, dim3((nb * 6 + 255) / 256), dim3(256), 0, stream, bbox_dev, nb);
   if (blk[nb] > 0)
-    hipLaunchKernelGGL(bbox_kernel, dim3(blk[nb]), dim3(256), 0, stream, pts, off_dev, blk_off_dev, nb, bbox_dev);
+    hipLaunchKernelGGL(bbox_kernel, dim3(blk[nb]), dim3(256), 0, stream, pts, off_dev, blk_off_dev, nb, bbox_dev,
+                       BboxPost{zeroed_ticket, zeroed_ticket ? mail : nullptr, stamp});
   GR_LAUNCH_CHECK();
   return GR_OK;
 }

@@ -113,7 +113,10 @@ __device__ __forceinline__ void mail_post(int32_t* stamp_word, int stamp) {
 void bbox_block_offsets(const int32_t* h_off, int32_t* h_blk, int nb);
 int compute_bbox(const float* pts, const int32_t* h_off, int32_t* h_blk, const int32_t* off_dev, int nb,
                  uint32_t* bbox_dev, int32_t* blk_off_dev, hipStream_t stream, bool blk_off_on_device = false,
-                 bool init_bbox = true);  // init_bbox = false: the caller has set bbox_dev to (0xffffffff x3, 0 x3) per cloud
+                 bool init_bbox = true,  // init_bbox = false: the caller has set bbox_dev to (0xffffffff x3, 0 x3) per cloud
+                 // zeroed_ticket + mail (the mailbox page, >= 6 nb + 1 words) + stamp: the last workgroup posts the boxes to
+                 // mail[0 .. 6 nb) and the stamp to mail[6 nb] -- nothing is posted when there are no points at all
+                 int32_t* zeroed_ticket = nullptr, int32_t* mail = nullptr, int stamp = 0);
 
 // Stable LSD radix sort of (u64 key, i32 value) pairs on bits [begin_bit, end_bit) (sort.hip: this library's own kernels).
 size_t sort_pairs_temp_bytes(int64_t n);

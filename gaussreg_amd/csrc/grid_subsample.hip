@@ -35,6 +35,7 @@ struct GridWs {
   int32_t* off;         // [B+1]
   uint32_t* bbox;       // [B*6]
   int32_t* blk_off;     // [B+1]
+  int32_t* ticket;      // [1] zeroed with the first upload: the last bbox workgroup posts the boxes to the host
   CloudGrid* grids;     // [B]
   uint64_t* keys_a;     // [N]
   uint64_t* keys_b;     // [N]
@@ -65,6 +66,7 @@ GridWs carve(void* ws, int64_t n, int64_t batch) {
   w.off = c.take<int32_t>(batch + 1);
   w.bbox = c.take<uint32_t>(batch * 6);
   w.blk_off = c.take<int32_t>(batch + 1);
+  w.ticket = c.take<int32_t>(1);
   w.grids = c.take<CloudGrid>(batch);
   w.keys_a = c.take<uint64_t>(n);
   w.keys_b = c.take<uint64_t>(n);
@@ -225,17 +227,28 @@ __global__ __launch_bounds__(256) void cells_kernel(
 
 // m_b = number of voxel runs of cloud b: sorted positions [off[b], off[b+1]) belong to cloud b,
 // and head_scan (exclusive) numbers the runs, so m_b is a difference of two scan values.
+// mail (single-workgroup launches only): the nb + 1 words also go to the host's mailbox page, stamped
 __global__ void cloud_counts_kernel(const int32_t* __restrict__ head_scan,
                                     const int32_t* __restrict__ total, int n,
                                     const int32_t* __restrict__ off, int nb,
-                                    int32_t* __restrict__ m_b) {
+                                    int32_t* __restrict__ m_b, int32_t* mail, int stamp) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b == 0) m_b[nb] = total[0];
-  if (b >= nb) return;
-  const int a = off[b], e = off[b + 1];
-  const int ca = a < n ? head_scan[a] : total[0];
-  const int ce = e < n ? head_scan[e] : total[0];
-  m_b[b] = ce - ca;
+  if (b == 0) {
+    m_b[nb] = total[0];
+    if (mail) mail[nb] = total[0];
+  }
+  if (b < nb) {
+    const int a = off[b], e = off[b + 1];
+    const int ca = a < n ? head_scan[a] : total[0];
+    const int ce = e < n ? head_scan[e] : total[0];
+    m_b[b] = ce - ca;
+    if (mail) mail[b] = ce - ca;
+  }
+  if (mail) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) mail_post(mail + nb + 1, stamp);
+  }
 }
 
 // rank cells by first occurrence: rank = (#cells whose first point index is smaller)
@@ -309,32 +322,49 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
   // synchronise before this function returns: the buffer is free again for the next call of this thread.
   const size_t o_bbox = align_up(sizeof(int32_t) * (batch + 1), 256);
   const size_t o_blk = o_bbox + align_up(sizeof(uint32_t) * 6 * batch, 256);
-  const size_t o_hb = o_blk + align_up(sizeof(int32_t) * (batch + 1), 256);
+  const size_t o_tick = o_blk + align_up(sizeof(int32_t) * (batch + 1), 256);
+  const size_t o_hb = o_tick + 256;
   const size_t o_grids = o_hb + align_up(sizeof(uint32_t) * 6 * batch, 256);
   const size_t o_mb = o_grids + align_up(sizeof(CloudGrid) * batch, 256);
   char* pin = static_cast<char*>(pinned_scratch(7, o_mb + sizeof(int32_t) * (batch + 1)));
   GR_REQUIRE(pin != nullptr, "grid_subsample: pinned staging buffer could not be allocated");
   GR_REQUIRE(reinterpret_cast<char*>(w.bbox) == reinterpret_cast<char*>(w.off) + o_bbox &&
-                 reinterpret_cast<char*>(w.blk_off) == reinterpret_cast<char*>(w.off) + o_blk,
+                 reinterpret_cast<char*>(w.blk_off) == reinterpret_cast<char*>(w.off) + o_blk &&
+                 reinterpret_cast<char*>(w.ticket) == reinterpret_cast<char*>(w.off) + o_tick,
              "grid_subsample: workspace layout");
   int32_t* off = reinterpret_cast<int32_t*>(pin);
   uint32_t* bb0 = reinterpret_cast<uint32_t*>(pin + o_bbox);
   int32_t* h_blk = reinterpret_cast<int32_t*>(pin + o_blk);
   const uint32_t* hb = reinterpret_cast<const uint32_t*>(pin + o_hb);
+  *reinterpret_cast<int32_t*>(pin + o_tick) = 0;
+  // small batches: the two read-backs (bounding boxes, cell counts) come through the mailbox page -- the kernels post
+  // them, the host polls: no copy in the stream, no stream synchronise (words [0, 6 B] boxes + stamp, [512, 512 + B + 1]
+  // counts + stamp)
+  volatile int32_t* mail = batch <= 80 ? mailbox() : nullptr;
+  const int stamp = mail ? mailbox_next_stamp() : 0;
   CloudGrid* hg = reinterpret_cast<CloudGrid*>(pin + o_grids);
-  const int32_t* h_mb = reinterpret_cast<const int32_t*>(pin + o_mb);
+  const int32_t* h_mb = reinterpret_cast<const int32_t*>(pin + o_mb);  // (or the mailbox page, below)
   off[0] = 0;
   for (int64_t b = 0; b < batch; ++b) {
     off[b + 1] = off[b] + (int32_t)h_lengths[b];
     for (int k = 0; k < 6; ++k) bb0[b * 6 + k] = k < 3 ? 0xffffffffu : 0u;
   }
   bbox_block_offsets(off, h_blk, nb);
-  GR_HIP(hipMemcpyAsync(w.off, pin, o_blk + sizeof(int32_t) * (batch + 1), hipMemcpyHostToDevice, stream));
+  GR_HIP(hipMemcpyAsync(w.off, pin, o_tick + sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  // (the ticket is one same-address atomic + a fence per workgroup: fine for a few hundred workgroups, 1.4 ms for the
+  // 12 500 of a 64 x 200 k call -- those copy and synchronise)
+  const bool bbox_by_mail = mail != nullptr && h_blk[nb] <= 512;
   int rc = compute_bbox(points, off, h_blk, w.off, nb, w.bbox, w.blk_off, stream, /*blk_off_on_device=*/true,
-                        /*init_bbox=*/false);
+                        /*init_bbox=*/false, bbox_by_mail ? w.ticket : nullptr, const_cast<int32_t*>(mail), stamp);
   if (rc != GR_OK) return rc;
-  GR_HIP(hipMemcpyAsync(pin + o_hb, w.bbox, sizeof(uint32_t) * batch * 6, hipMemcpyDeviceToHost, stream));
-  GR_HIP(hipStreamSynchronize(stream));
+  if (bbox_by_mail) {  // (n > 0 here: at least one bbox workgroup runs and posts)
+    rc = mailbox_wait(mail + 6 * batch, stamp, stream, "grid_subsample (bounding boxes)");
+    if (rc != GR_OK) return rc;
+    hb = const_cast<const uint32_t*>(reinterpret_cast<const volatile uint32_t*>(mail));
+  } else {
+    GR_HIP(hipMemcpyAsync(pin + o_hb, w.bbox, sizeof(uint32_t) * batch * 6, hipMemcpyDeviceToHost, stream));
+    GR_HIP(hipStreamSynchronize(stream));
+  }
 
   // ---- per-cloud grid, exactly the reference's fp32 expressions (this TU: -ffp-contract=off)
   unsigned long long max_cells = 1;
@@ -404,21 +434,33 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
   hipLaunchKernelGGL(cells_kernel, grd, blk, 0, stream, points, keys_sorted, vals_sorted, head, head_scan, (int)n,
                      w.off, nb, composite ? key_bits : 64, order_mode == GR_ORDER_CELL ? out_points : w.bary, w.first_idx,
                      w.cell_key, w.cell_batch, fo_flags);
+  int32_t* mail_counts = mail ? const_cast<int32_t*>(mail) + 512 : nullptr;  // (nb <= 80: one workgroup)
+  const int stamp2 = mail ? mailbox_next_stamp() : 0;
   hipLaunchKernelGGL(cloud_counts_kernel, dim3((nb + 255) / 256), blk, 0, stream, head_scan, w.totals, (int)n, w.off,
-                     nb, w.m_b);
+                     nb, w.m_b, mail_counts, stamp2);
   GR_LAUNCH_CHECK();
   int32_t h_m = 0;
-  GR_HIP(hipMemcpyAsync(pin + o_mb, w.m_b, sizeof(int32_t) * (batch + 1), hipMemcpyDeviceToHost, stream));
+  if (mail) h_mb = const_cast<const int32_t*>(reinterpret_cast<const volatile int32_t*>(mail + 512));
+  else GR_HIP(hipMemcpyAsync(pin + o_mb, w.m_b, sizeof(int32_t) * (batch + 1), hipMemcpyDeviceToHost, stream));
+  // (mailbox: the counts are on the host as soon as cloud_counts_kernel has run -- for the reference order that is while
+  // the first-occurrence scan below is still running)
+  auto wait_counts = [&]() -> int {
+    if (mail) return mailbox_wait(mail + 512 + batch + 1, stamp2, stream, "grid_subsample (cell counts)");
+    GR_HIP(hipStreamSynchronize(stream));
+    return GR_OK;
+  };
 
   if (order_mode == GR_ORDER_CELL) {
-    GR_HIP(hipStreamSynchronize(stream));
+    rc = wait_counts();
+    if (rc != GR_OK) return rc;
     h_m = h_mb[batch];
   } else {
     // first-occurrence rank of every cell, keys in that order -> host
     int32_t* fo_scan = w.scan;  // head flags no longer needed
     rc = exclusive_scan_i32(fo_flags, fo_scan, n, 1, n, w.scan_ws, w.totals + 1, stream);
     if (rc != GR_OK) return rc;
-    GR_HIP(hipStreamSynchronize(stream));
+    rc = wait_counts();
+    if (rc != GR_OK) return rc;
     h_m = h_mb[batch];
     if (h_m > 0) {
       hipLaunchKernelGGL(fo_rank_kernel, dim3((unsigned)((h_m + 255) / 256)), blk, 0, stream, w.first_idx, w.cell_key,
