@@ -95,17 +95,16 @@ int mailbox_next_stamp() {
 }
 
 int mailbox_wait(const volatile int32_t* stamp_word, int stamp, hipStream_t stream, const char* what) {
-  for (long spin = 0; spin < 400000000L; ++spin) {
+  // No time limit of its own: as long as the stream is still running the kernel may simply be long (or the device shared);
+  // a stream that has drained or failed without the stamp is an error.  (Exactly what hipStreamSynchronize would wait for.)
+  for (unsigned long spin = 1;; ++spin) {
     if (__atomic_load_n(stamp_word, __ATOMIC_ACQUIRE) == stamp) return GR_OK;
-    if ((spin & 0xffff) == 0xffff && hipStreamQuery(stream) != hipErrorNotReady) {
-      // the stream has drained (or failed): the stamp must be there now
+    if ((spin & 0xffff) == 0 && hipStreamQuery(stream) != hipErrorNotReady) {
       GR_HIP(hipStreamSynchronize(stream));
       GR_REQUIRE(__atomic_load_n(stamp_word, __ATOMIC_ACQUIRE) == stamp, "%s: the kernel did not post its result", what);
       return GR_OK;
     }
   }
-  set_error("%s: timed out waiting for the device", what);
-  return GR_ERR_HIP;
 }
 
 // ------------------------------------------------------------------ scan

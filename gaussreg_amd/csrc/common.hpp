@@ -93,7 +93,7 @@ void* pinned_scratch(int slot, size_t bytes);
 
 // Host-mapped, coherent pinned words (one 4 KB page per host thread) that a kernel writes and the host polls: a small
 // read-back without a copy in the stream and without a stream synchronise.  The kernel stores its payload, then the
-// call's stamp with a system-scope release store (mail_post); the host spins on the stamp (bounded; hipStreamQuery every
+// call's stamp with a system-scope release store (mail_post); the host spins on the stamp (hipStreamQuery every
 // 65 536 polls so a failed stream is noticed).  mailbox() returns nullptr when the page cannot be mapped or
 // GR_NO_MAILBOX=1 is set -- callers then copy and synchronise as before.
 constexpr int MAIL_WORDS = 1024;

@@ -1550,20 +1550,19 @@ static int preprocess_collect(int64_t P, int num_views, int64_t* h_num_rendered,
   const int nchunk = (int)((P + BIN_CHUNK - 1) / BIN_CHUNK);
   if (d.by_mail) {
     const volatile int32_t* m = d.mail;
-    // the GPU is still drawing while the host spins here; bounded: a device fault must not hang the caller
+    // the GPU is still drawing while the host spins here; no time limit of its own (a long or shared device is not an
+    // error), but a stream that has drained or failed without the stamps is
     bool ready = false;
-    for (long spin = 0; spin < 400000000L && !ready; ++spin) {
+    for (unsigned long spin = 1; !ready; ++spin) {
       ready = true;
       for (int v = 0; v < num_views; ++v) ready = ready && __atomic_load_n(&m[2 * num_views + 1 + v], __ATOMIC_ACQUIRE) == d.seq;
-      if (!ready && (spin & 0xffff) == 0xffff && hipStreamQuery(stream) != hipErrorNotReady) {
-        // the stream has drained (or failed): the stamps must be there now
+      if (!ready && (spin & 0xffff) == 0 && hipStreamQuery(stream) != hipErrorNotReady) {
         ready = true;
         for (int v = 0; v < num_views; ++v) ready = ready && __atomic_load_n(&m[2 * num_views + 1 + v], __ATOMIC_ACQUIRE) == d.seq;
         GR_HIP(hipStreamSynchronize(stream));
         GR_REQUIRE(ready, "rasterizer: the counting kernel did not report its totals");
       }
     }
-    GR_REQUIRE(ready, "rasterizer: timed out waiting for the counts of the frame");
     int32_t cm = m[num_views];
     for (int v = 1; v < num_views; ++v) {
       const int32_t mv = m[num_views + v];
