@@ -168,6 +168,15 @@ def _frame_pipe(dev, V):
 _geom_bytes = {}
 
 
+def reset_frame_pipe():
+    """Drop this thread's frame pipes: the references they keep to the last frame's input tensors (see _FramePipe) and the
+    readiness events.  The next one-camera call starts with a full wait on the caller's stream."""
+    table = getattr(_pipes, "table", None)
+    if table:
+        for p in table.values():
+            p.stamp = p.keep = p.ready = p.ptrs = None
+
+
 def rasterize_views(settings, means3D, opacities, shs=None,
                     colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, fast_exp=None, _one=False):
     """Render the same Gaussians from len(settings) cameras (`settings`: a sequence of

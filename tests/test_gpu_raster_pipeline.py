@@ -127,3 +127,21 @@ def test_two_host_threads_render_side_by_side(monkeypatch):
     for k in range(2):
         for i, (img, radii) in enumerate(out[k]):
             assert torch.equal(img, want[(i + k) % 3][0]) and torch.equal(radii, want[(i + k) % 3][1]), (k, i)
+
+
+def test_reset_frame_pipe_releases_the_inputs(monkeypatch):
+    import gc, weakref
+    from gaussreg_amd import rasterizer
+    t, rast = _setup(seed=16)
+    want = _reference(rast, t, monkeypatch)
+    scene = {k: v.clone() for k, v in t.items()}
+    ref = weakref.ref(scene["means3D"])
+    a = _render(rast[0], scene)[0]
+    del scene
+    gc.collect()
+    assert ref() is not None          # the pipe still holds the last frame's inputs
+    rasterizer.reset_frame_pipe()
+    gc.collect()
+    assert ref() is None
+    b = _render(rast[1], t)[0]
+    assert torch.equal(a, want[0][0]) and torch.equal(b, want[1][0])
