@@ -315,6 +315,15 @@ def run_gpu(h, args):
     blend_ms, blend_n = timing_read(L, "raster_blend")
     raster_kernels = per_step_ms(L, ["raster_preprocess", "raster_depth_sort", "raster_bin", "raster_sort", "raster_blend"],
                                  args.steps)
+    # Two calls are in flight (gaussreg_amd/rasterizer.py _FramePipe): in the timed region the blend shares the chip with the
+    # next step's preprocess / sort / binning, so its launch duration above is longer than the kernel's own.  The same steps
+    # once more with the pipe off, untimed for `value`, give the kernel alone.
+    os.environ["GR_RASTER_PIPELINE"] = "0"
+    h.timed(raster_step, args.steps, 1, after_warmup=L.gr_timing_reset)
+    os.environ.pop("GR_RASTER_PIPELINE", None)
+    alone_ms, alone_n = timing_read(L, "raster_blend")
+    alone_kernels = per_step_ms(L, ["raster_preprocess", "raster_depth_sort", "raster_bin", "raster_sort", "raster_blend"],
+                                args.steps)
     L.gr_timing_enable(0)
     L.gr_timing_reset()
     R_total = float(sum(last["nr"]))
@@ -332,6 +341,12 @@ def run_gpu(h, args):
          "roofline": hbm_roofline("raster_blend", blend_bytes, blend_ms, blend_n,
                                   pmc_traffic("raster_blend", (P, W, H) == (1_000_000, 640, 480), V),
                                   kernels_ms_per_step=raster_kernels,
+                                  one_step_at_a_time={"avg_launch_ms": round(alone_ms / max(alone_n, 1), 4),
+                                                      "frac": round(blend_bytes / (alone_ms / max(alone_n, 1) / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                      "kernels_ms_per_step": alone_kernels,
+                                                      "note": "GR_RASTER_PIPELINE=0: the blend alone on the chip; `achieved` / `frac` above "
+                                                              "are measured in the timed region, where two steps are in flight and the "
+                                                              "blend runs next to the following step's preprocess, sort and binning"},
                                   valu_busy=sq_valu_busy("blend_kernel<false", (P, W, H) == (1_000_000, 640, 480)),
                                   valu_busy_source="profiles/" + str(newest_profile("_sq_counters.json")))})
 

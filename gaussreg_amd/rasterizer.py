@@ -98,12 +98,14 @@ def _dev_f32(t: Optional[torch.Tensor], dev, name):
 
 
 class _FramePipe:
-    """Two frames of ONE-camera calls in flight (per device).
+    """Two rasterizer calls in flight (per device and host thread).
 
     A one-camera frame is a chain of ~15 dependent launches, most of them a few microseconds of work: alone on a stream the
-    chip idles through every hand-over.  Consecutive forward() calls therefore run on two internal streams in turn, so the
-    front of frame n+1 (preprocess, depth sort, tile counts) fills the gaps of frame n's scatter and blend.  For the caller
-    nothing changes: the outputs are joined into the caller's current stream before forward() returns.
+    chip idles through every hand-over.  Consecutive calls therefore run on two internal streams in turn, so the front of
+    frame n+1 (preprocess, depth sort, tile counts) fills the gaps of frame n's scatter and blend (+19 % views/s).  Batched
+    calls (32 views per call) gain too, for a different reason: the memory-bound sort and binning of call n+1 run next to
+    the instruction-bound blend of call n (+5.6 %).  For the caller nothing changes: the outputs are joined into the
+    caller's current stream before the call returns.
 
     Input readiness: a frame may only start when its input tensors are complete on the caller's stream.  In general that
     is `side.wait_stream(current)` -- which, after the previous frame was joined into `current`, also waits for that
@@ -154,7 +156,7 @@ _pipes = threading.local()  # per host thread (the library's split-call state is
 
 
 def _frame_pipe(dev, V):
-    if V != 1 or os.environ.get("GR_RASTER_PIPELINE", "1") == "0":
+    if os.environ.get("GR_RASTER_PIPELINE", "1") == "0":
         return None
     table = getattr(_pipes, "table", None)
     if table is None:

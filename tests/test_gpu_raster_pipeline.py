@@ -145,3 +145,23 @@ def test_reset_frame_pipe_releases_the_inputs(monkeypatch):
     assert ref() is None
     b = _render(rast[1], t)[0]
     assert torch.equal(a, want[0][0]) and torch.equal(b, want[1][0])
+
+
+def test_batched_calls_in_flight_equal_the_serial_calls(monkeypatch):
+    """rasterize_views with several cameras per call goes through the same pipe (and the library's count read-back in the
+    middle of every call)."""
+    from gaussreg_amd.rasterizer import rasterize_views
+    t, rast = _setup(seed=17, V=4)
+    sets = [r.raster_settings for r in rast]
+    groups = [sets[:3], sets[1:], sets[:2] + sets[3:]]
+
+    def render(g):
+        return rasterize_views(g, t["means3D"], t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+    with monkeypatch.context() as mp:
+        mp.setenv("GR_RASTER_PIPELINE", "0")
+        want = [tuple(x.clone() if torch.is_tensor(x) else x for x in render(g)) for g in groups]
+    torch.cuda.synchronize()
+    got = [render(groups[i % 3]) for i in range(9)]
+    for i, (img, radii, nr) in enumerate(got):
+        w = want[i % 3]
+        assert torch.equal(img, w[0]) and torch.equal(radii, w[1]) and nr == w[2], i
