@@ -111,19 +111,20 @@ class _FramePipe:
     is `side.wait_stream(current)` -- which, after the previous frame was joined into `current`, also waits for that
     frame and serialises everything.  When the inputs are THE SAME tensors with the same version counters as in the
     previous frame (a static scene rendered from moving cameras), they were already complete at the previous call, and
-    the frame waits only for the event recorded on the caller's stream then.  The previous frame's inputs are kept
-    referenced until the next call so that their addresses cannot be handed to other tensors in between (the stamp
-    compares storage address + version).  Writes that bypass the version counter (a foreign kernel writing through a raw
+    the frame waits only for the event recorded on the caller's stream at the FIRST call with these inputs.  The previous
+    frame's inputs are kept referenced until the next call so that their addresses cannot be handed to other tensors in
+    between (the stamp compares storage address + version).  An in-place update by the caller is ordered behind every frame
+    that read the old values: each call joins its frame into the caller's stream before it returns.  Writes that bypass the version counter (a foreign kernel writing through a raw
     pointer) are not seen; GR_RASTER_PIPELINE=0 switches the pipe off."""
 
     def __init__(self, dev):
-        self.streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
-        self.events = (torch.cuda.Event(), torch.cuda.Event())
+        depth = max(2, min(8, int(os.environ.get("GR_RASTER_PIPE_DEPTH", "2"))))
+        self.streams = tuple(torch.cuda.Stream(dev) for _ in range(depth))
         self.turn = 0
         self.stamp = None
         self.keep = None
         self.caller = None
-        self.ready = None
+        self.ready = None  # recorded on the caller's stream at the first call with this stamp: the inputs were complete there
         self.ptrs = None   # the marshalled input pointers of the scene with this stamp (set by rasterize_views)
 
     def begin(self, dev, inputs):
@@ -135,6 +136,10 @@ class _FramePipe:
         else:
             side.wait_stream(cur)
             self.ptrs = None
+            self.ready = None
+            if stamp is not None:
+                self.ready = torch.cuda.Event()
+                self.ready.record(cur)
         self.stamp, self.keep, self.caller = stamp, inputs, cur.cuda_stream
         return cur, side
 
@@ -143,10 +148,7 @@ class _FramePipe:
         cur.wait_stream(side)
 
     def end(self, cur, side, outputs):
-        ev = self.events[self.turn]
-        ev.record(cur)  # the caller's stream up to here, BEFORE this frame is joined into it
-        self.ready = ev
-        self.turn ^= 1
+        self.turn = (self.turn + 1) % len(self.streams)
         cur.wait_stream(side)
         for t in outputs:
             t.record_stream(cur)
