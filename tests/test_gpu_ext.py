@@ -301,3 +301,20 @@ def test_millions_of_keys_take_the_long_chunk_scan():
     wp, wl = capi.grid_subsampling(pts, lens, 0.05)
     assert np.array_equal(gl.numpy(), wl)
     assert np.array_equal(gp.cpu().numpy().view(np.uint32), wp.view(np.uint32))
+
+
+def test_many_small_clouds_per_call():
+    """100 clouds per call: past the 80-cloud limit of the mailbox read-backs (csrc/grid_subsample.hip copies and synchronises
+    instead), ragged sizes including empty clouds; grid_subsampling in the reference order and radius_neighbors against the oracle."""
+    from oracle import capi
+    rng = np.random.default_rng(31)
+    lens = rng.integers(0, 900, size=100).astype(np.int64)
+    lens[[3, 57, 99]] = 0
+    pts = (rng.random((int(lens.sum()), 3)) * [1.5, 1.0, 0.8]).astype(np.float32)
+    gp, gl = _ext().grid_subsampling(_t(pts), torch.from_numpy(lens), 0.08)
+    wp, wl = capi.grid_subsampling(pts, lens, 0.08)
+    assert np.array_equal(gl.numpy(), wl)
+    assert np.array_equal(gp.cpu().numpy().view(np.uint32), wp.view(np.uint32))
+    nb = _ext().radius_neighbors(gp, gp, gl, gl, 0.2)
+    want = capi.radius_neighbors(wp, wp, wl, wl, 0.2)
+    assert nb.shape == want.shape and np.array_equal(nb.cpu().numpy(), want)
