@@ -9,7 +9,11 @@ it refuses to run if the box has fewer than N GPUs -- it never reports fewer ran
 
 Headline metric (BASELINE.json): GS views/s at 1 M Gaussians, 640x480 (configs[1]) -- a "step" is one pass of the
 rasterizer forward over one batch of `--views` cameras of the same synthetic 1 M-Gaussian scene (inputs resident in HBM
-before the timed region; cameras are 200-byte host structs).  The same JSON line also carries, each timed the same way
+before the timed region; cameras are 200-byte host structs).  Consecutive rasterizer calls of an unchanged scene overlap: the
+wrapper keeps two calls in flight on internal streams and joins every call's outputs into the caller's stream before it
+returns (gaussreg_amd/rasterizer.py _FramePipe; all K steps are complete at the closing barrier + synchronize); `roofline`
+gives the blend's launch duration both inside that timed region and with one step at a time.
+The same JSON line also carries, each timed the same way
 (own warmup, barrier + synchronize on both sides, MAX over ranks):
     "single_view"       views/s through diff_gaussian_rasterization.GaussianRasterizer.forward, ONE camera per call
                         (the drop-in boundary number)
