@@ -1664,8 +1664,14 @@ static int render_impl(int64_t P, const gr_raster_view* h_views, int num_views, 
   static const bool stats = getenv("GR_BLEND_STATS") && getenv("GR_BLEND_STATS")[0] == '1';
   const bool fast = (flags & GR_RASTER_FAST_EXP) != 0;
   const int blend_chunks = (R > 0 || (spec && P > 0)) ? nchunk : 0;
+  // GR_RASTER_SHARE (a caller that keeps another one-camera frame in flight next to this one): the blend alone fills all 32
+  // wave slots of a CU (8 workgroups x 19 KB of LDS), and the next frame's front kernels -- the chain the host waits for --
+  // queue behind it.  14 KB of unused dynamic LDS cap it at 4 workgroups per CU: the blend takes longer, out of sight behind
+  // the other frame, and the front chain gets its slots (5 290 -> 5 450 views/s; GR_BLEND_SHARE_PAD to tune).
+  static const size_t share_pad = getenv("GR_BLEND_SHARE_PAD") ? (size_t)atoi(getenv("GR_BLEND_SHARE_PAD")) : 14000;
+  const size_t blend_pad = (spec && (flags & GR_RASTER_SHARE)) ? share_pad : 0;
 #define GR_BLEND(ST, FE)                                                                                                  \
-  hipLaunchKernelGGL((blend_kernel<ST, FE>), dim3(gx, gy, num_views), dim3(BLOCK), 0, stream, (int)P, W, H, blend_chunks, \
+  hipLaunchKernelGGL((blend_kernel<ST, FE>), dim3(gx, gy, num_views), dim3(BLOCK), blend_pad, stream, (int)P, W, H, blend_chunks, \
                      g.views, g.seg_off, point_list, g.rec, out_color, list_cap)
   if (stats) {
     if (fast) GR_BLEND(true, true); else GR_BLEND(true, false);

@@ -40,6 +40,7 @@ class GaussianRasterizationSettings(NamedTuple):
 
 FAST_EXP = 1  # GR_RASTER_FAST_EXP (include/gaussreg_hip.h)
 SPLIT = 2     # GR_RASTER_SPLIT
+SHARE = 4     # GR_RASTER_SHARE
 _ENV_FAST = None
 _bin_hint = {}  # (device, P, V, W, H) -> (bytes of the binning buffer, largest chunk) the last call of that shape needed
 
@@ -126,13 +127,16 @@ class _FramePipe:
         self.caller = None
         self.ready = None  # recorded on the caller's stream at the first call with this stamp: the inputs were complete there
         self.ptrs = None   # the marshalled input pointers of the scene with this stamp (set by rasterize_views)
+        self.overlapping = False
 
     def begin(self, dev, inputs):
         cur = torch.cuda.current_stream(dev)
         side = self.streams[self.turn]
         stamp = _lib.tensor_stamp(inputs)
+        self.overlapping = False
         if stamp is not None and stamp == self.stamp and self.caller == cur.cuda_stream and self.ready is not None:
             side.wait_event(self.ready)
+            self.overlapping = True   # this call runs next to the previous one
         else:
             side.wait_stream(cur)
             self.ptrs = None
@@ -265,7 +269,7 @@ def rasterize_views(settings, means3D, opacities, shs=None,
                                        hint + 256 if binb is not None else 0, _lib.ptr(color), fl, nr, st)
         # with the pipe: the library returns as soon as the frame is enqueued, and the stream joins below run while the GPU
         # works through the front of the frame; gr_raster_forward_finish then waits for the instance counts
-        rc = forward(flags | (SPLIT if pipe is not None else 0))
+        rc = forward(flags | ((SPLIT | (SHARE if pipe.overlapping and V == 1 else 0)) if pipe is not None else 0))
         joined = rejoin = False
         if rc == _lib.GR_PENDING:
             try:

@@ -204,6 +204,8 @@ int gr_raster_forward(int64_t P, int M, const float* means3D, const float* shs, 
  * caller repeats the frame with an unsplit gr_raster_forward).  Without speculation (no `bin`, > 4 views, a verification
  * frame) gr_raster_forward ignores the flag and returns its usual codes. */
 #define GR_RASTER_SPLIT 2
+#define GR_RASTER_SHARE 4 /* with GR_RASTER_SPLIT: another frame of the caller runs next to this one -- the blend is launched at
+                             half its usual occupancy so that the other frame's short kernels find wave slots */
 #define GR_PENDING 2
 #define GR_RETRY_FULL 3
 int gr_raster_forward_finish(int64_t* h_num_rendered);
