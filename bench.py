@@ -9,10 +9,12 @@ it refuses to run if the box has fewer than N GPUs -- it never reports fewer ran
 
 Headline metric (BASELINE.json): GS views/s at 1 M Gaussians, 640x480 (configs[1]) -- a "step" is one pass of the
 rasterizer forward over one batch of `--views` cameras of the same synthetic 1 M-Gaussian scene (inputs resident in HBM
-before the timed region; cameras are 200-byte host structs).  Consecutive rasterizer calls of an unchanged scene overlap: the
-wrapper keeps two calls in flight on internal streams and joins every call's outputs into the caller's stream before it
-returns (gaussreg_amd/rasterizer.py _FramePipe; all K steps are complete at the closing barrier + synchronize); `roofline`
-gives the blend's launch duration both inside that timed region and with one step at a time.
+before the timed region; cameras are 200-byte host structs), through the DEFAULT path of the wrapper: every call ordered on
+the caller's stream, like upstream's.  The opt-in `static_scene=True` mode (two calls in flight on internal streams,
+gaussreg_amd/rasterizer.py _FramePipe) is timed separately and reported as `config.static_scene_views_per_s`.
+The driver's record keeps the scalars of `config`, `roofline` and `cpu_baseline` and the tail of the line: the second half of
+the metric (radius_neighbors Mpts/s and its roofline fractions) and the one-camera figures are therefore ALSO scalars there
+(`roofline.radius_*`, `config.single_view_*`), and the line ends with a short `summary`.
 The same JSON line also carries, each timed the same way
 (own warmup, barrier + synchronize on both sides, MAX over ranks):
     "single_view"       views/s through diff_gaussian_rasterization.GaussianRasterizer.forward, ONE camera per call
@@ -62,6 +64,12 @@ def parse(argv=None):
     ap.add_argument("--no-radius-limited", action="store_true", help="skip the width-limited radius_search timing")
     ap.add_argument("--no-single-view", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--dry", action="store_true",
+                    help="first contact with a multi-GPU node: initialise the process group, run the collectives the bench uses "
+                         "(barrier, MAX / SUM all_reduce, sharding.gather_rows on a (3, 20) and on an empty device tensor), print "
+                         "one JSON line and exit -- no kernels, seconds per rank (tools/first_8gpu_run.md)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo exists for the CPU suite's test of --dry (same code path, CPU tensors)")
     return ap.parse_args(argv)
 
 
@@ -165,6 +173,40 @@ def self_spawn(args, argv):
     return subprocess.call(cmd, env=env)
 
 
+def dry_run(h, backend):
+    """`--dry`: every collective of the bench on tiny tensors, checked on every rank.  The only thing `backend` changes is
+    where the tensors live (Harness.from_env)."""
+    import torch
+    from gaussreg_amd import sharding
+    rank, world, dev = h.rank, h.world, h.device
+    t0 = time.perf_counter()
+    h.barrier()
+    checks = {}
+    checks["max_over_ranks"] = h.max_over_ranks(float(rank)) == float(world - 1)
+    checks["sum_over_ranks"] = h.sum_over_ranks(float(rank + 1)) == world * (world + 1) / 2.0
+    # the configs[4] gather: (3, 20) rows per rank, row value = 100 * rank + row
+    local = (torch.arange(3, dtype=torch.float32, device=dev).reshape(3, 1) + 100.0 * rank).expand(3, 20).contiguous()
+    rows = sharding.gather_rows(local, [3] * world)
+    want = torch.cat([torch.arange(3, dtype=torch.float32) + 100.0 * r for r in range(world)])
+    checks["gather_rows_3x20"] = tuple(rows.shape) == (3 * world, 20) and rows.device == local.device and \
+        torch.equal(rows[:, 0].cpu(), want) and torch.equal(rows[:, 19].cpu(), want)
+    # an idle rank (fewer pairs than GPUs): the odd ranks contribute nothing; counts learnt by the collective itself
+    part = local if rank % 2 == 0 else local[:0]
+    rows2 = sharding.gather_rows(part)
+    want2 = torch.cat([torch.arange(3, dtype=torch.float32) + 100.0 * r for r in range(0, world, 2)])
+    checks["gather_rows_ragged_with_empty"] = tuple(rows2.shape) == (3 * ((world + 1) // 2), 20) and torch.equal(rows2[:, 0].cpu(), want2)
+    empty = sharding.gather_rows(local[:0], [0] * world)
+    checks["gather_rows_all_empty"] = tuple(empty.shape) == (0, 20)
+    h.barrier()
+    ok = all(checks.values())
+    n_ok = h.sum_over_ranks(1.0 if ok else 0.0)
+    line = {"dry": True, "backend": backend, "n_gpus": world, "device": str(dev), "ok": bool(n_ok == world), "ranks_ok": int(n_ok),
+            "checks": checks, "seconds": round(time.perf_counter() - t0, 3)}
+    if not ok:
+        print(f"rank {rank}: --dry checks failed: {checks}", file=sys.stderr, flush=True)
+    return line
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 def newest_profile(suffix):
     try:
@@ -202,6 +244,19 @@ def sq_valu_busy(kernel_substr, ok):
         for k in doc["kernels"]:
             if kernel_substr in k["kernel"]:
                 return round(k["valu_issue_us_at_2p4GHz"] / k["profiled_duration_us_avg"], 3)
+    except Exception:
+        pass
+    return None
+
+
+def sq_insts(kernel_substr, counter):
+    """A raw per-launch SQ counter of a kernel from the newest committed SQ-counter summary (None if absent)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", newest_profile("_sq_counters.json"))) as fh:
+            doc = json.load(fh)
+        for k in doc["kernels"]:
+            if kernel_substr in k["kernel"]:
+                return float(k["per_launch"][counter])
     except Exception:
         pass
     return None
@@ -319,15 +374,18 @@ def run_gpu(h, args):
     blend_ms, blend_n = timing_read(L, "raster_blend")
     raster_kernels = per_step_ms(L, ["raster_preprocess", "raster_depth_sort", "raster_bin", "raster_sort", "raster_blend"],
                                  args.steps)
-    # Two calls are in flight (gaussreg_amd/rasterizer.py _FramePipe): in the timed region the blend shares the chip with the
-    # next step's preprocess / sort / binning, so its launch duration above is longer than the kernel's own.  The same steps
-    # once more with the pipe off, untimed for `value`, give the kernel alone.
-    os.environ["GR_RASTER_PIPELINE"] = "0"
-    h.timed(raster_step, args.steps, 1, after_warmup=L.gr_timing_reset)
-    os.environ.pop("GR_RASTER_PIPELINE", None)
-    alone_ms, alone_n = timing_read(L, "raster_blend")
-    alone_kernels = per_step_ms(L, ["raster_preprocess", "raster_depth_sort", "raster_bin", "raster_sort", "raster_blend"],
-                                args.steps)
+    # the opt-in static-scene mode: two calls in flight (gaussreg_amd/rasterizer.py _FramePipe); the blend then shares the chip
+    # with the next step's preprocess / sort / binning
+    def static_step():
+        img, radii, nr = rasterize_views(settings, t["means3D"], t["opacities"], shs=t["shs"], scales=t["scales"],
+                                         rotations=t["rotations"], static_scene=True)
+        last["img"] = img
+
+    static_step()
+    st_elapsed = h.timed(static_step, args.steps, args.warmup, after_warmup=L.gr_timing_reset)
+    st_ms, st_n = timing_read(L, "raster_blend")
+    st_kernels = per_step_ms(L, ["raster_preprocess", "raster_depth_sort", "raster_bin", "raster_sort", "raster_blend"],
+                             args.steps)
     L.gr_timing_enable(0)
     L.gr_timing_reset()
     R_total = float(sum(last["nr"]))
@@ -345,14 +403,13 @@ def run_gpu(h, args):
          "roofline": hbm_roofline("raster_blend", blend_bytes, blend_ms, blend_n,
                                   pmc_traffic("raster_blend", (P, W, H) == (1_000_000, 640, 480), V),
                                   kernels_ms_per_step=raster_kernels,
-                                  one_step_at_a_time={"avg_launch_ms": round(alone_ms / max(alone_n, 1), 4),
-                                                      "frac": round(blend_bytes / (alone_ms / max(alone_n, 1) / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
-                                                      "kernels_ms_per_step": alone_kernels,
-                                                      "note": "GR_RASTER_PIPELINE=0: the blend alone on the chip; `achieved` / `frac` above "
-                                                              "are measured in the timed region, where two steps are in flight and the "
-                                                              "blend runs next to the following step's preprocess, sort and binning"},
+                                  static_scene={"avg_launch_ms": round(st_ms / max(st_n, 1), 4), "kernels_ms_per_step": st_kernels,
+                                                "note": "static_scene=True: two steps in flight, the blend runs next to the following "
+                                                        "step's preprocess, sort and binning"},
                                   valu_busy=sq_valu_busy("blend_kernel<false", (P, W, H) == (1_000_000, 640, 480)),
                                   valu_busy_source="profiles/" + str(newest_profile("_sq_counters.json")))})
+    line["config"]["static_scene_views_per_s"] = round(world * V * args.steps / st_elapsed, 2)
+    line["config"]["static_scene_ms_per_step"] = round(st_elapsed / args.steps * 1e3, 4)
 
     # ------------------------------------------------------------------ the boundary: one camera per forward() call
     if not args.no_single_view:
@@ -365,10 +422,8 @@ def run_gpu(h, args):
             last["sv"] = r(t["means3D"], None, t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
 
         single_step()
-        # 200 frames at least: forward() keeps two one-camera frames in flight (gaussreg_amd/rasterizer.py _FramePipe); the
-        # drain at the closing synchronise is one un-overlapped blend, 3 % of a 20-frame measurement
         n_sv = max(args.steps, 200)
-        # throughput with the per-kernel event timers OFF (ten event records per frame are a measurable share of a 0.3 ms
+        # throughput with the per-kernel event timers OFF (ten event records per frame are a measurable share of a 0.2 ms
         # frame); the per-kernel figures come from a second, instrumented pass of the same loop
         L.gr_timing_enable(0)
         sv_elapsed = h.timed(single_step, n_sv, max(args.warmup, 3))
@@ -380,8 +435,23 @@ def run_gpu(h, args):
         L.gr_timing_reset()
         line["single_view"] = {"value": round(world * n_sv / sv_elapsed, 2), "unit": "views/s",
                                "ms_per_view": round(sv_elapsed / n_sv * 1e3, 4), "frames": n_sv,
-                               "api": "diff_gaussian_rasterization.GaussianRasterizer.forward, one camera per call, "
-                                      "same 1M-Gaussian scene", "kernels_ms_per_view": sv_kernels}
+                               "api": "diff_gaussian_rasterization.GaussianRasterizer.forward, one camera per call, one frame at a "
+                                      "time on the caller's stream (the default), same 1M-Gaussian scene",
+                               "kernels_ms_per_view": sv_kernels}
+        # opt-in: GaussianRasterizer(settings, static_scene=True) keeps two one-camera frames in flight; the drain at the closing
+        # synchronise is one un-overlapped blend (200 frames: < 1 %)
+        rast_s = [GaussianRasterizer(s, static_scene=True) for s in settings_list[: min(V, 8)]]
+
+        def single_static():
+            r = rast_s[k["i"] % len(rast_s)]
+            k["i"] += 1
+            last["sv"] = r(t["means3D"], None, t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+
+        single_static()
+        svs = h.timed(single_static, n_sv, max(args.warmup, 3))
+        line["single_view"]["static_scene"] = {"value": round(world * n_sv / svs, 2), "ms_per_view": round(svs / n_sv * 1e3, 4)}
+        line["config"]["single_view_views_per_s"] = line["single_view"]["value"]
+        line["config"]["single_view_static_scene_views_per_s"] = line["single_view"]["static_scene"]["value"]
         # the opt-in fast-exponential blend (1e-5 relative of the bit-exact image, tests/test_gpu_rasterizer_fast.py)
         rast_f = [GaussianRasterizer(s, fast_exp=True) for s in settings_list[: min(V, 8)]]
 
@@ -393,6 +463,7 @@ def run_gpu(h, args):
         single_fast()
         svf = h.timed(single_fast, n_sv, max(args.warmup, 3))
         line["single_view"]["fast_exp"] = {"value": round(world * n_sv / svf, 2), "ms_per_view": round(svf / n_sv * 1e3, 4)}
+        line["config"]["single_view_fast_exp_views_per_s"] = line["single_view"]["fast_exp"]["value"]
 
         def fast_step():
             img, radii, nr = rasterize_views(settings, t["means3D"], t["opacities"], shs=t["shs"], scales=t["scales"],
@@ -405,6 +476,7 @@ def run_gpu(h, args):
         fb_ms, fb_n = timing_read(L, "raster_blend")
         L.gr_timing_enable(0)
         L.gr_timing_reset()
+        line["config"]["fast_exp_views_per_s"] = round(world * V * args.steps / f_elapsed, 2)
         line["fast_exp"] = {"value": round(world * V * args.steps / f_elapsed, 2), "unit": "views/s",
                             "ms_per_step": round(f_elapsed / args.steps * 1e3, 4),
                             "blend_avg_launch_ms": round(fb_ms / max(fb_n, 1), 4),
@@ -442,6 +514,23 @@ def run_gpu(h, args):
                                            count_valu_busy=sq_valu_busy("traverse_kernel<128, false, true>", True),
                                            valu_busy_source="profiles/" + str(newest_profile("_sq_counters.json")),
                                            end_to_end_frac=round(fill_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4))}
+        # the second half of the metric as scalars the driver's flattened record keeps
+        rl = line["roofline"]
+        rl["radius_mpts_per_s"] = radius["value"]
+        rl["radius_ms_per_step"] = radius["ms_per_step"]
+        rl["radius_end_to_end_frac"] = radius["roofline"]["end_to_end_frac"]
+        rl["radius_fill_frac"] = radius["roofline"]["frac"]
+        rl["radius_fill_avg_launch_ms"] = radius["roofline"]["avg_launch_ms"]
+        # the bound that actually holds for this operator: VALU issue.  Wave-level VALU instructions per query of the search
+        # kernels (committed SQ-counter summary, same configuration) against the ~50 the tests + stores alone need
+        vc, vf = sq_insts("traverse_kernel<128, false, true>", "SQ_INSTS_VALU"), sq_insts("traverse_kernel<128, true, true>", "SQ_INSTS_VALU")
+        if vc and vf and B == 8:
+            per_q = (vc + vf) / float(nq)
+            radius["roofline_valu_issue"] = {"bound": "valu_issue", "achieved": round(per_q, 1), "floor": 50.0,
+                                             "unit": "wave-level VALU instructions per query (count + fill)", "frac": round(50.0 / per_q, 4),
+                                             "source": "profiles/" + str(newest_profile("_sq_counters.json")) + " (committed, not this run)"}
+            rl["radius_valu_per_query"] = round(per_q, 1)
+            rl["radius_valu_floor_per_query"] = 50.0
         # the width-limited path the data pyramid calls (radius_search with neighbor_limit, utils/data.py:35-67)
         if not args.no_radius_limited:
             lim = 40
@@ -458,6 +547,8 @@ def run_gpu(h, args):
                                  "ms_per_step": round(l_elapsed / args.steps * 1e3, 4), "neighbor_limit": lim, "width": lw,
                                  "end_to_end_frac": round(lbytes / (l_elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                                  "kernels_ms_per_step": lk, "mode": "count + fill (default)"}
+            rl["radius_limited_mpts_per_s"] = radius["limited"]["value"]
+            rl["radius_limited_end_to_end_frac"] = radius["limited"]["end_to_end_frac"]
             # the same call through the single-pass kernel (gr_radius_search mode 1)
             old_mode = L.gr_radius_search_mode(1)
             limited_step()
@@ -511,6 +602,7 @@ def run_gpu(h, args):
                                                       "geometric stages (matching ops, Sinkhorn, LGR, RANSAC) are wired correctly",
                          "median_rre_deg": round(float(rre.median()), 4), "median_rte_m": round(float(rte.median()), 5),
                          "kernel_ms_total_per_gpu": pk}
+        line["config"]["pairs_per_s"] = line["pairs"]["value"]
         # ---- where a pair's time goes: one more pass over the first block of pairs with a device synchronise around every stage
         #      (slower than the timed pass: nothing overlaps; the SHARES are what this is for).  `standin_descriptors` is harness
         #      work (random Fourier features in place of the learned features), everything else is the reference's pipeline.
@@ -550,6 +642,7 @@ def run_gpu(h, args):
                 "config": "same pairs; KPConvFPN (one pass per batch, GroupNorm per pair) + GeometricTransformer (padded batches of "
                           "16 pairs: embedding and self-attention per cloud, the rest over the batch) + backbone features in the "
                           "patch scores instead of the synthetic descriptors; 28 M seeded random parameters"}
+            line["config"]["pairs_with_network_per_s"] = line["pairs"]["with_network"]["value"]
             del regm
         except Exception as e:  # never takes the headline down with it
             line["pairs"]["with_network"] = {"error": repr(e)}
@@ -598,6 +691,10 @@ def run_gpu(h, args):
             ac["sample"] = (f"{ac.get('tasks')} searches of independent 200k-pt clouds, 8 per worker process, one process per core "
                             f"on {workers} cores, same {kind} core")
             radius["cpu_baseline"]["all_cores"] = ac
+            cpu_baseline["radius_1core_mpts_per_s"] = radius["cpu_baseline"]["value"]
+            cpu_baseline["radius_all_cores_mpts_per_s"] = ac.get("value")
+            cpu_baseline["radius_all_cores"] = ac.get("cores")
+            cpu_baseline["radius_kind"] = kind
         if "pairs" in line:
             # the reference's per-pair CPU work on this path: the collate pyramid (utils/data.py:13-77) on one core
             from gaussreg_amd import pair_pipeline
@@ -639,7 +736,47 @@ def run_gpu(h, args):
                     line["pairs"]["pyramid_only_gpu"] = {"extras_key": kname, **{kk: kval[kk] for kk in kval if kk in ("ms", "pairs", "pairs_per_s", "ms_per_pair")}}
                     break
     line["cpu_baseline"] = cpu_baseline
-    return line
+    return order_line(line)
+
+
+def order_line(line):
+    """Key order of the printed line: the contract's fields first, the long sections in the middle, and a short `summary` of
+    the figures that answer the metric LAST (the driver keeps the line's tail and the scalars of config / roofline / cpu_baseline)."""
+    head = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline"]
+    out = {k: line[k] for k in head if k in line}
+    for k in ("extras", "pairs", "fast_exp", "single_view", "radius_neighbors"):
+        if k in line:
+            out[k] = line[k]
+    for k in line:
+        if k not in out:
+            out[k] = line[k]
+    cfg, rl, cb = line.get("config") or {}, line.get("roofline") or {}, line.get("cpu_baseline") or {}
+    ex = line.get("extras") or {}
+
+    def frac(name):
+        v = ex.get(name)
+        return v.get("frac") if isinstance(v, dict) else None
+
+    def ms(name):
+        v = ex.get(name)
+        return v.get("ms") if isinstance(v, dict) else None
+    out["summary"] = {
+        "views_per_s": line.get("value"), "views_per_s_static_scene": cfg.get("static_scene_views_per_s"),
+        "blend_frac_of_hbm": rl.get("frac"),
+        "single_view_views_per_s": cfg.get("single_view_views_per_s"),
+        "single_view_static_scene_views_per_s": cfg.get("single_view_static_scene_views_per_s"),
+        "radius_mpts_per_s": rl.get("radius_mpts_per_s"), "radius_end_to_end_frac": rl.get("radius_end_to_end_frac"),
+        "radius_fill_frac": rl.get("radius_fill_frac"), "radius_limited_end_to_end_frac": rl.get("radius_limited_end_to_end_frac"),
+        "radius_valu_per_query": rl.get("radius_valu_per_query"),
+        "radius_cpu_1core_mpts_per_s": cb.get("radius_1core_mpts_per_s"), "radius_cpu_all_cores_mpts_per_s": cb.get("radius_all_cores_mpts_per_s"),
+        "pairs_per_s": cfg.get("pairs_per_s"), "pairs_with_network_per_s": cfg.get("pairs_with_network_per_s"),
+        "grid_subsample_64x200k_ms": [ms("grid_subsample_64x200k_reference_order"), ms("grid_subsample_64x200k_cell_order")],
+        "grid_subsample_200k_ms": ms("grid_subsample_200k_reference_order"),
+        "spm_batch_64x767_frac": frac("superpoint_matching_batch_64x767"), "spm_767_ms": ms("superpoint_matching_767"),
+        "kpconv_backbone_frac": frac("kpconv_backbone_11_layers"), "gs_fuse_frac": frac("gs_fuse_2x2p55M"),
+        "fps_2x200k_ms": ms("fps_2x200k_to_30k"), "n_gpus": line.get("n_gpus")}
+    return out
 
 
 def main(argv=None):
@@ -649,10 +786,20 @@ def main(argv=None):
         raise SystemExit("--gpus must be >= 1")
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
+        if args.backend != "nccl":
+            raise SystemExit("--backend gloo: launch the ranks yourself (torch.distributed.run); the self-spawn is for GPUs")
         return self_spawn(args, argv)
     if env_world is not None and int(env_world) != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={env_world}: they must agree")
-    h = Harness.from_env("nccl")
+    h = Harness.from_env(args.backend)
+    if args.dry:
+        line = dry_run(h, args.backend)
+        if h.rank == 0:
+            print(json.dumps(line), flush=True)
+        h.close()
+        return 0 if line["ok"] else 1
+    if args.backend != "nccl":
+        raise SystemExit("bench.py measures the HIP path on MI355X GPUs; --backend gloo exists for --dry only")
     line = run_gpu(h, args)
     if h.rank == 0:
         print(json.dumps(line), flush=True)

@@ -96,8 +96,14 @@ void* pinned_scratch(int slot, size_t bytes);
 // call's stamp with a system-scope release store (mail_post); the host spins on the stamp (hipStreamQuery every
 // 65 536 polls so a failed stream is noticed).  mailbox() returns nullptr when the page cannot be mapped or
 // GR_NO_MAILBOX=1 is set -- callers then copy and synchronise as before.
+// Every user owns a disjoint region of the page (a word that is payload for one operator is never the stamp word of
+// another) and clears its stamp word on the host before the launch that will post it (mailbox_arm).
 constexpr int MAIL_WORDS = 1024;
+constexpr int MAIL_GRID_BOXES = 0;     // grid_subsample: 6 B box words + stamp, B <= 80
+constexpr int MAIL_GRID_COUNTS = 512;  // grid_subsample: B + 1 counts + stamp
+constexpr int MAIL_RADIUS = 1008;      // radius search: 4 header words + stamp
 volatile int32_t* mailbox();
+inline void mailbox_arm(volatile int32_t* stamp_word) { __atomic_store_n(stamp_word, 0, __ATOMIC_RELEASE); }
 int mailbox_next_stamp();  // per process, never 0
 int mailbox_wait(const volatile int32_t* stamp_word, int stamp, hipStream_t stream, const char* what);
 __device__ __forceinline__ void mail_post(int32_t* stamp_word, int stamp) {

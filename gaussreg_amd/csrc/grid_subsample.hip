@@ -354,9 +354,13 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
   // (the ticket is one same-address atomic + a fence per workgroup: fine for a few hundred workgroups, 1.4 ms for the
   // 12 500 of a 64 x 200 k call -- those copy and synchronise)
   const bool bbox_by_mail = mail != nullptr && h_blk[nb] <= 512;
+  if (bbox_by_mail) mailbox_arm(mail + MAIL_GRID_BOXES + 6 * batch);
   int rc = compute_bbox(points, off, h_blk, w.off, nb, w.bbox, w.blk_off, stream, /*blk_off_on_device=*/true,
                         /*init_bbox=*/false, bbox_by_mail ? w.ticket : nullptr, const_cast<int32_t*>(mail), stamp);
-  if (rc != GR_OK) return rc;
+  if (rc != GR_OK) {
+    (void)hipStreamSynchronize(stream);  // nothing queued may post into the page after this call has returned
+    return rc;
+  }
   if (bbox_by_mail) {  // (n > 0 here: at least one bbox workgroup runs and posts)
     rc = mailbox_wait(mail + 6 * batch, stamp, stream, "grid_subsample (bounding boxes)");
     if (rc != GR_OK) return rc;
@@ -434,18 +438,19 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
   hipLaunchKernelGGL(cells_kernel, grd, blk, 0, stream, points, keys_sorted, vals_sorted, head, head_scan, (int)n,
                      w.off, nb, composite ? key_bits : 64, order_mode == GR_ORDER_CELL ? out_points : w.bary, w.first_idx,
                      w.cell_key, w.cell_batch, fo_flags);
-  int32_t* mail_counts = mail ? const_cast<int32_t*>(mail) + 512 : nullptr;  // (nb <= 80: one workgroup)
+  int32_t* mail_counts = mail ? const_cast<int32_t*>(mail) + MAIL_GRID_COUNTS : nullptr;  // (nb <= 80: one workgroup)
   const int stamp2 = mail ? mailbox_next_stamp() : 0;
+  if (mail) mailbox_arm(mail + MAIL_GRID_COUNTS + batch + 1);
   hipLaunchKernelGGL(cloud_counts_kernel, dim3((nb + 255) / 256), blk, 0, stream, head_scan, w.totals, (int)n, w.off,
                      nb, w.m_b, mail_counts, stamp2);
   GR_LAUNCH_CHECK();
   int32_t h_m = 0;
-  if (mail) h_mb = const_cast<const int32_t*>(reinterpret_cast<const volatile int32_t*>(mail + 512));
+  if (mail) h_mb = const_cast<const int32_t*>(reinterpret_cast<const volatile int32_t*>(mail + MAIL_GRID_COUNTS));
   else GR_HIP(hipMemcpyAsync(pin + o_mb, w.m_b, sizeof(int32_t) * (batch + 1), hipMemcpyDeviceToHost, stream));
   // (mailbox: the counts are on the host as soon as cloud_counts_kernel has run -- for the reference order that is while
   // the first-occurrence scan below is still running)
   auto wait_counts = [&]() -> int {
-    if (mail) return mailbox_wait(mail + 512 + batch + 1, stamp2, stream, "grid_subsample (cell counts)");
+    if (mail) return mailbox_wait(mail + MAIL_GRID_COUNTS + batch + 1, stamp2, stream, "grid_subsample (cell counts)");
     GR_HIP(hipStreamSynchronize(stream));
     return GR_OK;
   };

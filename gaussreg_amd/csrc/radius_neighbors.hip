@@ -1571,7 +1571,9 @@ __global__ void pad_fill_kernel(int64_t* __restrict__ out, int64_t n, int64_t v)
 // synchronise.  Everything queued on `stream` before is complete when this returns.
 inline int reduce_and_read(const RadiusWs& w, int blocks, hipStream_t stream, RadiusHdr* h_out) {
   volatile int32_t* mail = mailbox();
+  if (mail) mail += MAIL_RADIUS;
   const int stamp = mail ? mailbox_next_stamp() : 0;
+  if (mail) mailbox_arm(mail + 4);
   hipLaunchKernelGGL(reduce_stats_kernel, dim3(1), dim3(1024), 0, stream, w.blk_stats, blocks, w.hdr,
                      const_cast<int32_t*>(mail), stamp);
   GR_LAUNCH_CHECK();

@@ -1387,7 +1387,10 @@ static int preprocess_impl(int64_t P, int M, const float* means3D, const float* 
   const bool sh16 = shs != nullptr && M == 16 && (reinterpret_cast<uintptr_t>(shs) % 16 == 0);
   // one camera, deferred frame: the camera rides in the kernel arguments of the preprocess kernel and a far depth stores
   // this call's stamp into the flag word -- no upload, no clear in front of the frame
-  const bool cam_in_args = sh16 && num_views == 1 && defer_ev != nullptr && defer_ev->mail != nullptr;
+  // (only when the counts will leave through the mailbox, i.e. the chunk rows are short enough for the self-scanning count
+  // launch: the event path below reads the far flag as "non-zero", which needs the upload's clear)
+  const bool cam_in_args = sh16 && num_views == 1 && defer_ev != nullptr && defer_ev->mail != nullptr &&
+                           (P + BIN_CHUNK - 1) / BIN_CHUNK <= SCAN_SINGLE_ROW;
   DevView cam1;
   memset(&cam1, 0, sizeof(cam1));
   int far_seq = 1;

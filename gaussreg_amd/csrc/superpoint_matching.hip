@@ -717,14 +717,14 @@ SpmWs carve_spm(void* p, int64_t nr, int64_t ns) {
 
 using namespace gr;
 
-extern "C" size_t gr_pairwise_distance_workspace_bytes(int64_t n, int64_t m) {
-  if (n < 0 || m < 0) return 0;
-  return align_up((size_t)(n + m) * sizeof(float) + 512, 256);
-}
-
 extern "C" size_t gr_pairwise_distance_batch_workspace_bytes(int64_t batch, int64_t n, int64_t m) {
   if (n < 0 || m < 0 || batch < 0) return 0;
   return align_up((size_t)std::max<int64_t>(batch, 1) * (align_up((size_t)n, 64) + align_up((size_t)m, 64)) * sizeof(float) + 512, 256);
+}
+
+// gr_pairwise_distance forwards to the batch entry with batch = 1: one size rule for both
+extern "C" size_t gr_pairwise_distance_workspace_bytes(int64_t n, int64_t m) {
+  return gr_pairwise_distance_batch_workspace_bytes(1, n, m);
 }
 
 namespace gr {

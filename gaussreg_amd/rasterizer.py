@@ -115,8 +115,14 @@ class _FramePipe:
     the frame waits only for the event recorded on the caller's stream at the FIRST call with these inputs.  The previous
     frame's inputs are kept referenced until the next call so that their addresses cannot be handed to other tensors in
     between (the stamp compares storage address + version).  An in-place update by the caller is ordered behind every frame
-    that read the old values: each call joins its frame into the caller's stream before it returns.  Writes that bypass the version counter (a foreign kernel writing through a raw
-    pointer) are not seen; GR_RASTER_PIPELINE=0 switches the pipe off."""
+    that read the old values: each call joins its frame into the caller's stream before it returns.
+
+    OPT-IN (`static_scene=True` on rasterize_views / GaussianRasterizer, or GR_RASTER_PIPELINE=1): the stamp only sees
+    writes that bump a tensor's version counter.  `tensor.data.<op>_()` (`.data` carries its own counter), a custom
+    extension kernel or any other library writing through `data_ptr()` change the scene without changing the stamp; the
+    next frame would then start on the side stream next to that write and could render stale or torn values.  The
+    default therefore is no pipe: every call is ordered on the caller's stream like upstream's.  Callers that opt in and
+    do write behind the counter's back call reset_frame_pipe() after the write."""
 
     def __init__(self, dev):
         depth = max(2, min(8, int(os.environ.get("GR_RASTER_PIPE_DEPTH", "2"))))
@@ -161,8 +167,11 @@ class _FramePipe:
 _pipes = threading.local()  # per host thread (the library's split-call state is per thread too) and device
 
 
-def _frame_pipe(dev, V):
-    if os.environ.get("GR_RASTER_PIPELINE", "1") == "0":
+def _frame_pipe(dev, static_scene):
+    """The pipe is opt-in (see _FramePipe): `static_scene=True` per call, or GR_RASTER_PIPELINE=1 for the process
+    (GR_RASTER_PIPELINE=0 wins over the argument: the switch tests and benches use to get the serial path)."""
+    env = os.environ.get("GR_RASTER_PIPELINE")
+    if env == "0" or not (static_scene or env == "1"):
         return None
     table = getattr(_pipes, "table", None)
     if table is None:
@@ -186,7 +195,8 @@ def reset_frame_pipe():
 
 
 def rasterize_views(settings, means3D, opacities, shs=None,
-                    colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, fast_exp=None, _one=False):
+                    colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, fast_exp=None, _one=False,
+                    static_scene=False):
     """Render the same Gaussians from len(settings) cameras (`settings`: a sequence of
     GaussianRasterizationSettings, or a prebuilt ViewBatch).
 
@@ -196,6 +206,8 @@ def rasterize_views(settings, means3D, opacities, shs=None,
 
     `fast_exp=True`: the blend uses the hardware exponential (v_exp_f32) instead of the deterministic polynomial of the
     oracle -- the image is within 1e-5 relative of the bit-exact one (default False: bit-exact).
+    `static_scene=True` (extension): consecutive calls over the same, unmodified scene tensors overlap on two internal
+    streams (_FramePipe: read its contract first -- only writes that bump the tensors' version counters are seen).
     (`_one`: internal, one camera -- the outputs come back as (3,H,W) and (P,), no view ops on the way out.)"""
     dev = means3D.device if means3D.is_cuda else _lib.require_gpu()
     L = _lib.lib()
@@ -224,7 +236,7 @@ def rasterize_views(settings, means3D, opacities, shs=None,
     cov = _dev_f32(cov3D_precomp, dev, "cov3D_precomp") if has_cov else None
     M = 0 if sh is None else (sh.shape[1] if sh.dim() == 3 else sh.reshape(max(P, 1), -1, 3).shape[1])
     nr = (ctypes.c_int64 * (V + 1))()
-    pipe = _frame_pipe(dev, V)
+    pipe = _frame_pipe(dev, static_scene)
     cur = side = None
     # (explicit set_device / set_stream instead of the context managers: a one-camera frame is ~0.2 ms and every
     # microsecond of Python between two library calls is on the critical path)
@@ -311,20 +323,21 @@ def rasterize_views(settings, means3D, opacities, shs=None,
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, fast_exp=None):
+                        raster_settings, fast_exp=None, static_scene=False):
     """`raster_settings`: GaussianRasterizationSettings, or a one-camera ViewBatch built from it (marshalled once)."""
     vb = raster_settings if isinstance(raster_settings, ViewBatch) else [raster_settings]
     color, radii, _ = rasterize_views(vb, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp,
-                                      fast_exp=fast_exp, _one=True)
+                                      fast_exp=fast_exp, _one=True, static_scene=static_scene)
     return color, radii
 
 
 class GaussianRasterizer(torch.nn.Module):
-    def __init__(self, raster_settings: GaussianRasterizationSettings, fast_exp=None):
-        """`fast_exp` (extension, upstream has no such argument): see rasterize_views."""
+    def __init__(self, raster_settings: GaussianRasterizationSettings, fast_exp=None, static_scene=False):
+        """`fast_exp`, `static_scene` (extensions, upstream has no such arguments): see rasterize_views."""
         super().__init__()
         self.raster_settings = raster_settings
         self.fast_exp = fast_exp
+        self.static_scene = static_scene
         self._view_batch = None  # (settings object, tensor versions, ViewBatch): the C camera struct is built once
 
     @staticmethod
@@ -367,4 +380,4 @@ class GaussianRasterizer(torch.nn.Module):
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3D_precomp, self._views(), fast_exp=self.fast_exp)
+                                   cov3D_precomp, self._views(), fast_exp=self.fast_exp, static_scene=self.static_scene)

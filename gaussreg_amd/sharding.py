@@ -40,6 +40,8 @@ def gather_rows(local: torch.Tensor, counts: Sequence[int] = None) -> torch.Tens
         dist.all_gather(all_n, n_local)
         counts = [int(t.item()) for t in all_n]
     mx = max(counts) if counts else 0
+    if mx == 0:  # every rank knows it: no zero-byte collective (RCCL need not accept one)
+        return local[:0]
     pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     bufs = [torch.empty_like(pad) for _ in range(w)]

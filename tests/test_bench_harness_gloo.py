@@ -90,3 +90,39 @@ def test_single_rank_harness_is_plain_timing():
     assert el >= 0.006 and h.max_over_ranks(1.5) == 1.5
     line = bench.throughput_line(h, "m", "u/s", 4, 3, 1, el)
     assert line["n_gpus"] == 1 and abs(line["value"] - 12 / el) < 1e-2 * line["value"]
+
+
+def _dry_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import contextlib
+    import io
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        rc = bench.main(["--gpus", str(world), "--dry", "--backend", "gloo"])
+    with open(os.path.join(out_dir, f"dry{rank}.txt"), "w") as fh:
+        fh.write(f"{rc}\n{buf.getvalue()}")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_dry_mode_runs_every_collective_of_the_bench(tmp_path, world):
+    """`bench.py --gpus N --dry` (tools/first_8gpu_run.md): the code a first multi-GPU node runs in its first minute, here over
+    gloo -- the backend decides where the tensors live, nothing else."""
+    import json
+    last = None
+    for attempt in range(3):
+        try:
+            mp.spawn(_dry_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+            last = None
+            break
+        except Exception as e:  # noqa: BLE001
+            last = e
+    assert last is None, last
+    for r in range(world):
+        rc, _, out = open(os.path.join(str(tmp_path), f"dry{r}.txt")).read().partition("\n")
+        assert rc == "0"
+        if r == 0:
+            line = json.loads(out)
+            assert line["dry"] and line["ok"] and line["n_gpus"] == world and line["ranks_ok"] == world and line["backend"] == "gloo"
+            assert all(line["checks"].values()) and len(line["checks"]) == 5
+        else:
+            assert out.strip() == ""

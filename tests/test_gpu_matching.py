@@ -206,3 +206,25 @@ def test_superpoint_matching_more_ties_than_the_candidate_buffer():
     g, h = torch.nn.functional.normalize(g, dim=1), torch.nn.functional.normalize(h, dim=1)
     ri, si, sc = SuperPointMatching(64, False)(g, h)
     assert ri.shape == (64,) and bool((sc[:-1] >= sc[1:]).all())
+
+
+@pytest.mark.parametrize("n,m", [(65, 65), (1, 1), (767, 701), (64, 129)])
+def test_pairwise_distance_c_entry_with_the_header_workspace_rule(n, m):
+    """A C caller sizes the workspace with gr_pairwise_distance_workspace_bytes(n, m) (include/gaussreg_hip.h) and calls the
+    un-batched entry un-normalised: it must be accepted and equal the batched entry bit for bit."""
+    from gaussreg_amd import _lib, ops
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(n * 1000 + m)
+    x = torch.randn(n, 48, generator=g).cuda()
+    y = torch.randn(m, 48, generator=g).cuda()
+    nbytes = L.gr_pairwise_distance_workspace_bytes(n, m)
+    assert nbytes == L.gr_pairwise_distance_batch_workspace_bytes(1, n, m)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    out = torch.empty(n, m, device="cuda")
+    _lib.check(L.gr_pairwise_distance(_lib.ptr(x), _lib.ptr(y), n, m, 48, 0, _lib.ptr(out), _lib.ptr(ws), nbytes,
+                                      _lib.stream_ptr(x.device)))
+    assert torch.equal(out, ops.pairwise_distance(x, y))
+    # one byte less is refused, not overrun
+    rc = L.gr_pairwise_distance(_lib.ptr(x), _lib.ptr(y), n, m, 48, 0, _lib.ptr(out), _lib.ptr(ws), nbytes - 1,
+                                _lib.stream_ptr(x.device))
+    assert rc == -3  # GR_ERR_WORKSPACE (include/gaussreg_hip.h)

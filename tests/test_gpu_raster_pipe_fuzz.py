@@ -8,6 +8,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _pipe_on(monkeypatch):
+    # the pipe is opt-in (static_scene=True / GR_RASTER_PIPELINE=1); "0" inside a test selects the serial path
+    monkeypatch.setenv("GR_RASTER_PIPELINE", "1")
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_random_call_sequences(seed, monkeypatch):
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer

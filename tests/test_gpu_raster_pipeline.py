@@ -9,6 +9,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _pipe_on(monkeypatch):
+    # the pipe is opt-in (static_scene=True / GR_RASTER_PIPELINE=1); "0" inside a test selects the serial path
+    monkeypatch.setenv("GR_RASTER_PIPELINE", "1")
+
+
 def _setup(P=60000, W=320, H=192, V=3, seed=11):
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     from helpers import raster_scene

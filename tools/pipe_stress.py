@@ -17,7 +17,7 @@ want = [tuple(x.clone() for x in r(t["means3D"], None, t["opacities"], **kw)) fo
 wantb = rasterize_views(sets, t["means3D"], t["opacities"], **kw)
 wantb = (wantb[0].clone(), wantb[1].clone(), wantb[2])
 torch.cuda.synchronize()
-os.environ.pop("GR_RASTER_PIPELINE")
+os.environ["GR_RASTER_PIPELINE"] = "1"
 bad = 0
 outs = []
 for i in range(300):
