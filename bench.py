@@ -497,16 +497,19 @@ def run_gpu(h, args):
             out["nb"] = ext.radius_neighbors(dpts, dpts, lens, lens, 0.0625)
 
         radius_step()
+        # a step is 0.6 ms: at least 50 of them (and 10 to warm up -- the section follows the one-camera loops, which leave
+        # the chip mostly idle) so that the timed region is tens of milliseconds
+        n_r, w_r = max(args.steps, 50), max(args.warmup, 10)
         L.gr_timing_enable(1)
-        r_elapsed = h.timed(radius_step, args.steps, args.warmup, after_warmup=L.gr_timing_reset)
+        r_elapsed = h.timed(radius_step, n_r, w_r, after_warmup=L.gr_timing_reset)
         fill_ms, fill_n = timing_read(L, "radius_fill")
-        rk = per_step_ms(L, ["radius_bin", "radius_count", "radius_fill", "radius_fused"], args.steps)
+        rk = per_step_ms(L, ["radius_bin", "radius_count", "radius_fill", "radius_fused"], n_r)
         L.gr_timing_reset()
         nq = dpts.shape[0]
         width = out["nb"].shape[1]
         fill_bytes = 12.0 * nq + 12.0 * nq + 8.0 * nq * width      # 12 Nq + 12 Ns + 8 Nq W
-        step_s = r_elapsed / args.steps
-        radius = {"metric": "radius_neighbors throughput, 200k-pt clouds", "value": round(world * nq * args.steps / r_elapsed / 1e6, 2),
+        step_s = r_elapsed / n_r
+        radius = {"metric": "radius_neighbors throughput, 200k-pt clouds", "value": round(world * nq * n_r / r_elapsed / 1e6, 2), "steps": n_r,
                   "unit": "Mpts/s", "ms_per_step": round(step_s * 1e3, 4),
                   "config": {"workload": f"{B} x 200k-pt clouds per GPU per step, r=0.0625, self-search, width {width}"},
                   "roofline": hbm_roofline("radius_fill", fill_bytes, fill_ms, fill_n, pmc_traffic("radius_fill", True, B),
@@ -539,27 +542,27 @@ def run_gpu(h, args):
                 out["nbl"] = radius_search(dpts, dpts, lens, lens, 0.0625, lim)
 
             limited_step()
-            l_elapsed = h.timed(limited_step, args.steps, args.warmup, after_warmup=L.gr_timing_reset)
-            lk = per_step_ms(L, ["radius_bin", "radius_count", "radius_fill", "radius_fused"], args.steps)
+            l_elapsed = h.timed(limited_step, n_r, w_r, after_warmup=L.gr_timing_reset)
+            lk = per_step_ms(L, ["radius_bin", "radius_count", "radius_fill", "radius_fused"], n_r)
             lw = out["nbl"].shape[1]
             lbytes = 24.0 * nq + 8.0 * nq * lw
-            radius["limited"] = {"value": round(world * nq * args.steps / l_elapsed / 1e6, 2), "unit": "Mpts/s",
-                                 "ms_per_step": round(l_elapsed / args.steps * 1e3, 4), "neighbor_limit": lim, "width": lw,
-                                 "end_to_end_frac": round(lbytes / (l_elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            radius["limited"] = {"value": round(world * nq * n_r / l_elapsed / 1e6, 2), "unit": "Mpts/s",
+                                 "ms_per_step": round(l_elapsed / n_r * 1e3, 4), "neighbor_limit": lim, "width": lw,
+                                 "end_to_end_frac": round(lbytes / (l_elapsed / n_r) / 1e9 / HBM_PEAK_GBS, 4),
                                  "kernels_ms_per_step": lk, "mode": "count + fill (default)"}
             rl["radius_limited_mpts_per_s"] = radius["limited"]["value"]
             rl["radius_limited_end_to_end_frac"] = radius["limited"]["end_to_end_frac"]
             # the same call through the single-pass kernel (gr_radius_search mode 1)
             old_mode = L.gr_radius_search_mode(1)
             limited_step()
-            s_elapsed = h.timed(limited_step, args.steps, args.warmup, after_warmup=L.gr_timing_reset)
-            sk = per_step_ms(L, ["radius_bin", "radius_fused"], args.steps)
+            s_elapsed = h.timed(limited_step, n_r, w_r, after_warmup=L.gr_timing_reset)
+            sk = per_step_ms(L, ["radius_bin", "radius_fused"], n_r)
             L.gr_radius_search_mode(old_mode)
             fused_ms = sk.get("radius_fused", 0.0)
             radius["limited"]["single_pass"] = {
-                "value": round(world * nq * args.steps / s_elapsed / 1e6, 2), "ms_per_step": round(s_elapsed / args.steps * 1e3, 4),
-                "end_to_end_frac": round(lbytes / (s_elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4), "kernels_ms_per_step": sk,
-                "roofline": hbm_roofline("radius_fused", lbytes, fused_ms * args.steps, args.steps) if fused_ms else None}
+                "value": round(world * nq * n_r / s_elapsed / 1e6, 2), "ms_per_step": round(s_elapsed / n_r * 1e3, 4),
+                "end_to_end_frac": round(lbytes / (s_elapsed / n_r) / 1e9 / HBM_PEAK_GBS, 4), "kernels_ms_per_step": sk,
+                "roofline": hbm_roofline("radius_fused", lbytes, fused_ms * n_r, n_r) if fused_ms else None}
         L.gr_timing_enable(0)
         L.gr_timing_reset()
         del out, dpts

@@ -57,7 +57,7 @@ def main():
                          "fetch_kb_per_call": round(f.get(k, (0, 0))[0] / calls, 1), "write_kb_per_call": round(w.get(k, (0, 0))[0] / calls, 1)})
         skip = ()
         if op.startswith("kpconv"):  # the process also builds the pyramid once: only the KPConv kernels count
-            rows_op = [r for r in rows if "kpconv" in r["kernel"].lower() or "gather" in r["kernel"].lower()]
+            rows_op = [r for r in rows if any(t in r["kernel"] for t in ("kp_gather", "gemm_nn", "rowflag"))]
         else:
             rows_op = rows
         hbm = sum(2 * r["fetch_kb_per_call"] + r["write_kb_per_call"] for r in rows_op) * 1024.0
