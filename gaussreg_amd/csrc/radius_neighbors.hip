@@ -974,14 +974,9 @@ __global__ __launch_bounds__(NSUB* RQ) __attribute__((amdgpu_waves_per_eu(8, 8))
 //   decode           every thread walks its masks, one even and one odd hit per step, and leaves (query slot, staged
 //                    position) words in its part of the segment -- no arithmetic in the loop whose trip count diverges
 //   keys             one thread per hit (balanced): distance bits and support index from the staged planes
-//   keys             ... and the hit's distance bucket b = floor(64 d / r^2) (64 buckets per query, byte counters in LDS):
-//                    one ds_add_rtn per hit gives its arrival number inside the bucket
-//   prefix           one thread per query: exclusive prefix over the 64 byte counters (packed-byte arithmetic)
-//   scatter          one thread per hit: its slot in bucket order = prefix[b] + arrival -> a byte permutation of the segment
-//   ranking          one thread per hit: rank = prefix[b] + number of smaller (distance, index) keys INSIDE ITS BUCKET
-//                    (1.3 keys on average instead of the segment's 21: buckets are monotone in the distance, so no key of
-//                    another bucket can sit between two keys of one); the index goes to row[rank] in an LDS row buffer.
-//                    A workgroup with a query of more than 255 hits ranks by counting over the whole segment instead
+//   ranking          one thread per hit: rank = number of smaller distance words in the segment (32-bit compares, four keys
+//                    per ds_read_b128).  The index goes to row[rank] in an LDS row buffer with ds_min: equal distances
+//                    collide there, leave a hole behind them, and only such rows are ranked again on (distance, index)
 //   rows             whole rows leave as contiguous 16-byte pieces
 // Nothing per query goes through global memory in between (the two-pass path writes and re-reads 180 bytes of ranges /
 // masks / counts per query) and the host does not sit between two launches.
@@ -994,8 +989,9 @@ struct FusedLds {
   static constexpr int THREADS = NSUB * RQ;
   static constexpr int STAGE_CAP = 12 * RQ;
   static constexpr int TABLE_MAX = 256;
-  // ints: offs[RQ+1], orig[RQ], qtot[RQ], wsum[2 * THREADS/64], sub[3*RQ], band_lo[9], band_hi[9], band_base[10], misc[4]
-  static constexpr int N_INTS = (RQ + 1) + RQ + RQ + 2 * (THREADS / WAVE) + NSUB * RQ + 9 + 9 + 10 + 4;
+  // ints: offs[RQ+1], orig[RQ], qtot[RQ], wsum[2 * THREADS/64], sub[3*RQ], band_lo[9], band_hi[9], band_base[10], misc[4],
+  //       tie flags[RQ]
+  static constexpr int N_INTS = (RQ + 1) + RQ + RQ + 2 * (THREADS / WAVE) + NSUB * RQ + 9 + 9 + 10 + 4 + RQ;
   static constexpr size_t QBUF_OFF = (size_t)(N_INTS * 4 + 15) / 16 * 16;  // float4 per query slot
   static constexpr size_t STAGE_OFF = QBUF_OFF + (size_t)RQ * 16;
   static size_t region_bytes(int width) {  // candidate planes x, y, z, index (+ slack for the 4-wide tail reads); the row
@@ -1003,10 +999,7 @@ struct FusedLds {
     return st > rb ? st : rb;
   }
   static size_t tables_bytes(int tcap) { return tcap > 0 ? ((size_t)(tcap + 1) * 4 + 15) / 16 * 16 + (size_t)tcap * sizeof(BatchGrid) : 0; }
-  static constexpr int HIST_STRIDE = 20;  // words per query: 64 byte counters + 4 words of padding (a thread per query reads
-                                          // its 16 words as four ds_read_b128: 20-word rows spread the lanes over all banks)
-  // distance words, (slot, position) / index words, row bytes, arrival bytes, permutation bytes, bucket counters
-  static size_t hits_bytes(int cap) { return (size_t)(cap + 16) * 11 + (size_t)RQ * HIST_STRIDE * 4; }
+  static size_t hits_bytes(int cap) { return (size_t)(cap + 16) * 9; }  // distance words, (slot, position) / index words, row bytes
   static size_t total(int width, int cap, int tcap) {
     const size_t hits = hits_bytes(cap), tb = tables_bytes(tcap);
     return STAGE_OFF + region_bytes(width) + (hits > tb ? hits : tb);
@@ -1038,7 +1031,8 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
   int* band_lo = sub + NSUB * RQ;
   int* band_hi = band_lo + NBAND;
   int* band_base = band_hi + NBAND;
-  int* misc = band_base + NBAND + 1;  // [0] group search
+  int* misc = band_base + NBAND + 1;  // [0] group search, [1] number of rows with equal distances
+  int* tie_rows = misc + 4;
   float4* qbuf = reinterpret_cast<float4*>(smem + L::QBUF_OFF);
   float* sx = reinterpret_cast<float*>(smem + L::STAGE_OFF);
   float* sy = sx + L::STAGE_CAP;
@@ -1049,9 +1043,6 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
   unsigned int* hd = reinterpret_cast<unsigned int*>(hreg);      // distance bits per hit slot
   unsigned int* hm = hd + (cap + 16);                            // (slot << 16 | staged position), then the support index
   unsigned char* hrow = reinterpret_cast<unsigned char*>(hm + (cap + 16));
-  unsigned char* harr = hrow + (cap + 16);   // arrival number of a hit inside its distance bucket
-  unsigned char* perm = harr + (cap + 16);   // segment slot in bucket order -> hit slot (relative to the segment)
-  unsigned int* hist = reinterpret_cast<unsigned int*>(perm + (cap + 16));  // [RQ][HIST_STRIDE] byte counters, then prefixes
   const int dummy = cap + 8;  // a slot nobody reads: the target of the decode's "no hit" lanes
   // per-cloud tables for the set-up live where the keys go later
   const int tcap = nb <= L::TABLE_MAX ? nb : 0;
@@ -1072,6 +1063,8 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
     band_lo[tid] = 0x7fffffff;
     band_hi[tid] = 0;
   }
+  if (tid == 0) misc[1] = 0;
+  if (tid < RQ) tie_rows[tid] = 0;
   const bool tables_in_lds = tcap > 0;
   if (tables_in_lds) {
     for (int i = tid; i <= nb; i += L::THREADS) s_qoff[i] = q_off[i];
@@ -1278,7 +1271,6 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
   }
   GR_FUSED_STOP(3, n + (int)(lo >> 20) + (int)(hi >> 20))
   sub[tid] = n;
-  for (int i = tid; i < RQ * L::HIST_STRIDE; i += L::THREADS) hist[i] = 0u;  // (the per-cloud tables that lay here are dead)
   __syncthreads();
   // ---- block scan of the per-query totals; every slab group does it redundantly (no cross-group sync)
   int c[NSUB];
@@ -1308,14 +1300,7 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
   GR_FUSED_STOP(4, my_off + total4)
   int blk_flag = 0;
   const bool multi = total4 > cap;
-  int blk_max_tot = 0;
-#pragma unroll
-  for (int i = 0; i < RQ / WAVE; ++i) blk_max_tot = max(blk_max_tot, wsum[L::THREADS / WAVE + i]);
-  // bucket ranking + row buffer: byte counters and byte permutations hold a query of at most 255 hits
-  const bool use_rowbuf = ROWBUF && !multi && blk_max_tot <= 255;
-  const float bscale = 64.0f / r2;
-  auto bucket_of = [&](unsigned dbits) -> unsigned { return min((unsigned)(__uint_as_float(dbits) * bscale), 63u); };
-  auto prefix_of = [&](int r, unsigned b) -> int { return (int)((hist[r * L::HIST_STRIDE + (b >> 2)] >> ((b & 3u) << 3)) & 0xffu); };
+  const bool use_rowbuf = ROWBUF && !multi;
   const int rows_here = min(RQ, nq - blk * RQ);
   if (multi) __syncthreads();  // offs complete
   int glo = 0;
@@ -1419,99 +1404,43 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
       const float d = (dx * dx + dy * dy) + dz * dz;
       hd[e] = __float_as_uint(d);  // d >= 0: the bit pattern is monotone
       hm[e] = (unsigned)idx;
-      if (use_rowbuf) {
-        const unsigned b = bucket_of(__float_as_uint(d)), sh = (b & 3u) << 3;
-        const unsigned old = atomicAdd(&hist[r * L::HIST_STRIDE + (b >> 2)], 1u << sh);
-        harr[e] = (unsigned char)((old >> sh) & 0xffu);
-      }
     }
     __syncthreads();
     GR_FUSED_STOP(6, (int)hd[tid])
     if (use_rowbuf) {
-      // ---- prefix: one thread per query -- the 64 byte counters become exclusive prefixes (total <= 255: no byte carries)
-      if (tid < RQ) {
-        uint4* hq = reinterpret_cast<uint4*>(hist + tid * L::HIST_STRIDE);
-        uint4 w4[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) w4[u] = hq[u];
-        unsigned run = 0u;
-        auto step = [&](unsigned& x) {
-          const unsigned incl = x * 0x01010101u;          // byte k = x_0 + .. + x_k
-          x = (incl << 8) + run * 0x01010101u;            // exclusive, plus everything before this word
-          run += incl >> 24;
-        };
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          step(w4[u].x);
-          step(w4[u].y);
-          step(w4[u].z);
-          step(w4[u].w);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) hq[u] = w4[u];
-      }
+      // the planes are dead: their place becomes the row buffer, every entry "not written"
+      const int quads = (rows_here * width + 3) >> 2;
+      for (int i = tid; i < quads; i += L::THREADS) reinterpret_cast<uint4*>(rowbuf)[i] = make_uint4(PADMARK, PADMARK, PADMARK, PADMARK);
       __syncthreads();
-      // ---- scatter: slot of every hit in bucket order -> the segment's byte permutation
-      for (int e = tid; e < group_hits; e += L::THREADS) {
-        const int r = hrow[e];
-        if (r == 0xff) continue;
-        const int a = offs[r];
-        perm[a + prefix_of(r, bucket_of(hd[e])) + (int)harr[e]] = (unsigned char)(e - a);
-      }
-      __syncthreads();
-      // ---- ranking: one thread per hit, against the keys of its own bucket only
-      for (int e = tid; e < group_hits; e += L::THREADS) {
-        const int r = hrow[e];
-        if (r == 0xff) continue;
-        const int a = offs[r];
-        const unsigned d = hd[e], idx = hm[e], bk = bucket_of(d);
-        const int first = prefix_of(r, bk), last = bk == 63u ? qtot[r] : prefix_of(r, bk + 1u);
-        int rank = first;
-        for (int sl = first; sl < last; ++sl) {
-          const int e2 = a + (int)perm[a + sl];
-          const unsigned dk = hd[e2], ik = hm[e2];
-          rank += (dk < d || (dk == d && ik < idx)) ? 1 : 0;
+    }
+    // ---- ranking: one thread per hit
+    for (int e = tid; e < group_hits; e += L::THREADS) {
+      const int r = hrow[e];
+      if (r == 0xff) continue;
+      const int a = offs[r] - gbase, quads = (offs[r + 1] - offs[r]) >> 2;
+      const unsigned d = hd[e];
+      const unsigned idx = hm[e];
+      const uint4* seg = reinterpret_cast<const uint4*>(hd + a);
+      int rank = 0;
+      if (use_rowbuf) {
+        int jj = 0;
+        for (; jj + 4 <= quads; jj += 4) {
+          uint4 k4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) k4[u] = seg[jj + u];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            rank += (k4[u].x < d ? 1 : 0) + (k4[u].y < d ? 1 : 0) + (k4[u].z < d ? 1 : 0) + (k4[u].w < d ? 1 : 0);
         }
-        if (rank < width) rowbuf[r * width + rank] = idx;
-      }
-      __syncthreads();
-      GR_FUSED_STOP(7, (int)rowbuf[tid])
-      // ---- rows: consecutive lanes, consecutive 16-byte pieces (two columns) of a row; columns past the hit count are padding
-      {
-        const int npair = (width + 1) >> 1, total_pairs = rows_here * npair;
-        const unsigned magic = 0xffffffffu / (unsigned)npair + 1u;  // i / npair = mulhi(i, magic) for i < 2^16
-        const bool even = (width & 1) == 0;
-        for (int i = tid; i < total_pairs; i += L::THREADS) {
-          const int r = npair == 1 ? i : (int)__umulhi((unsigned)i, magic);
-          const int cc = (i - r * npair) * 2;
-          const int cnt = qtot[r];
-          const unsigned vx = rowbuf[r * width + cc];
-          const unsigned vy = rowbuf[r * width + min(cc + 1, width - 1)];
-          int64_t* dst = out + (int64_t)orig[r] * width + cc;
-          const long long ox = cc < cnt ? (long long)vx : (long long)pad_value;
-          const long long oy = cc + 1 < cnt ? (long long)vy : (long long)pad_value;
-          if (even) {
-            longlong2 o;
-            o.x = ox;
-            o.y = oy;
-            *reinterpret_cast<longlong2*>(dst) = o;  // width even: every pair is 16-byte aligned
-          } else {
-            dst[0] = ox;
-            if (cc + 1 < width) dst[1] = oy;
-          }
+        for (; jj < quads; ++jj) {
+          const uint4 k = seg[jj];
+          rank += (k.x < d ? 1 : 0) + (k.y < d ? 1 : 0) + (k.z < d ? 1 : 0) + (k.w < d ? 1 : 0);
         }
-      }
-    } else {
-      // ---- ranking by counting over the whole segment (a workgroup whose hits come in groups, or a query of more than 255
-      //      hits): exact (distance, index) order, one 8-byte store per hit
-      for (int e = tid; e < group_hits; e += L::THREADS) {
-        const int r = hrow[e];
-        if (r == 0xff) continue;
-        const int a = offs[r] - gbase, quads = (offs[r + 1] - offs[r]) >> 2;
-        const unsigned d = hd[e], idx = hm[e];
-        const uint4* seg = reinterpret_cast<const uint4*>(hd + a);
+        // equal distances meet in one entry (the smallest index stays) and leave the next one unwritten
+        if (rank < width) atomicMin(&rowbuf[r * width + rank], idx);
+      } else {
+        // direct stores: exact (distance, index) order in one go
         const uint4* segi = reinterpret_cast<const uint4*>(hm + a);
-        int rank = 0;
         for (int jj = 0; jj < quads; ++jj) {
           const uint4 k = seg[jj], ki = segi[jj];
           rank += (k.x < d || (k.x == d && ki.x < idx) ? 1 : 0) + (k.y < d || (k.y == d && ki.y < idx) ? 1 : 0) +
@@ -1519,6 +1448,63 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
         }
         if (rank < width) out[(int64_t)orig[r] * width + rank] = (int64_t)idx;
       }
+    }
+    if (use_rowbuf) {
+      __syncthreads();
+      GR_FUSED_STOP(7, (int)rowbuf[tid])
+      // whole rows leave as contiguous runs: consecutive lanes, consecutive 16-byte pieces of a row.  An unwritten entry
+      // below the row's hit count means two hits of that row have the same distance: the row is noted and redone below
+      if ((width & 1) == 0) {
+        const int w2 = width >> 1, total_pairs = rows_here * w2;
+        const float inv = 1.0f / (float)w2;
+        for (int i = tid; i < total_pairs; i += L::THREADS) {
+          int r = (int)((float)i * inv);
+          r = r * w2 > i ? r - 1 : ((r + 1) * w2 <= i ? r + 1 : r);
+          const int cc = (i - r * w2) * 2;
+          const int cnt = qtot[r];
+          const uint2 v = *reinterpret_cast<const uint2*>(rowbuf + r * width + cc);
+          if ((cc < cnt && v.x == PADMARK) || (cc + 1 < cnt && v.y == PADMARK)) {
+            tie_rows[r] = 1;
+            misc[1] = 1;
+          }
+          longlong2 o;
+          o.x = cc < cnt ? (long long)v.x : (long long)pad_value;
+          o.y = cc + 1 < cnt ? (long long)v.y : (long long)pad_value;
+          *reinterpret_cast<longlong2*>(out + (int64_t)orig[r] * width + cc) = o;
+        }
+      } else {
+        const int total_el = rows_here * width;
+        const float inv = 1.0f / (float)width;
+        for (int i = tid; i < total_el; i += L::THREADS) {
+          int r = (int)((float)i * inv);
+          r = r * width > i ? r - 1 : ((r + 1) * width <= i ? r + 1 : r);
+          const int cc = i - r * width;
+          const unsigned v = rowbuf[r * width + cc];
+          if (cc < qtot[r] && v == PADMARK) {
+            tie_rows[r] = 1;
+            misc[1] = 1;
+          }
+          out[(int64_t)orig[r] * width + cc] = cc < qtot[r] ? (long long)v : (long long)pad_value;
+        }
+      }
+      __syncthreads();
+      // rows with equal distances (rare): rank their hits again on (distance, index) and overwrite the row's entries
+      if (misc[1]) {
+        for (int r = 0; r < rows_here; ++r) {
+          if (!tie_rows[r]) continue;
+          const int a = offs[r], len = qtot[r];
+          for (int e = tid; e < len; e += L::THREADS) {
+            const unsigned d = hd[a + e], idx = hm[a + e];
+            int rank = 0;
+            for (int q2 = 0; q2 < len; ++q2) {
+              const unsigned dk = hd[a + q2], ik = hm[a + q2];
+              rank += (dk < d || (dk == d && ik < idx)) ? 1 : 0;
+            }
+            if (rank < width) out[(int64_t)orig[r] * width + rank] = (int64_t)idx;
+          }
+        }
+      }
+    } else {
       // ---- padding of the group's rows: half a wave per row
       for (int r = glo + tid / 32; r < min(ghi, rows_here); r += L::THREADS / 32) {
         int64_t* row = out + (int64_t)orig[r] * width;
