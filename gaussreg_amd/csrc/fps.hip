@@ -330,11 +330,9 @@ __device__ __forceinline__ int fps_resolve_conflicts_lds(int nq, unsigned long l
 // the candidates it published last round.  After the first few hundred samples that is almost every wave in almost
 // every round; results are exactly those of the unpruned algorithm (keys carry the ORIGINAL index).
 //
-// MW = keys a wave passes up, PT = points a thread offers.  The "wide" variant (M = 32, MW = 8, PT = 2; at most 16
-// workgroups per cloud, i.e. the batched calls) needs 219 rounds where M = 16 / MW = 4 / PT = 1 needs 476 for 200 k -> 30 k
-// with ten workgroups (tools/fps_round_model.py --g 10): with large M the bound B was set by some thread's SECOND point in
-// 79 % of the rounds, so a thread now offers its two best points and only its third bounds.
-template <int PPT, int M, int MW = FPS_MW, int PT = 1>
+// MW = keys a wave passes up.  (Measured and taken out: a "wide" variant -- 32 keys per workgroup, two points offered per
+// thread -- and a Morton curve order)
+template <int PPT, int M, int MW = FPS_MW>
 __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restrict__ pts, const float* __restrict__ spts,
                                                           const int32_t* __restrict__ perm,
                                                           const int32_t* __restrict__ off,
@@ -345,7 +343,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
   constexpr int KPL = FPS_KPL, LPS = M / KPL, NW = FPS_T / WAVE;  // LPS: polling lanes per slot
   constexpr int EC = M > 16 ? 512 : FPS_EC;                       // M = 32 runs with <= 16 workgroups: E never exceeds 512
   constexpr int NWK = NW * MW, KL = (NWK + WAVE - 1) / WAVE;      // wave-level candidates of the workgroup; per lane of wave 0
-  static_assert(M % KPL == 0 && FPS_SLOT_STRIDE > M && NWK % 2 == 0 && M < NWK && (PT == 1 || PT == 2), "layout");
+  static_assert(M % KPL == 0 && FPS_SLOT_STRIDE > M && NWK % 2 == 0 && M < NWK, "layout");
   constexpr bool ROWS = PPT >= 13;  // pays where a wave's run is long; the 20-point variant has no registers left for it (+11 spills: +1 %)
   constexpr int UN = PPT <= 10 ? 4 : 2;  // partners in flight in stages 4 and 6: the large slabs have no registers to spare
   extern __shared__ int s_perm[];  // [PPT][FPS_T] original (cloud-local) index of every point this workgroup holds
@@ -432,7 +430,6 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
   float wave_maxd = INFINITY;  // largest running distance among this wave's points (wave-uniform)
   bool owner = false;          // this lane's best point is one of the wave's published candidates ...
   int owner_bdi = 0;           // ... and had these distance bits when it was selected
-  int owner_sdi = 0;           // (PT = 2: the bits of its second point)
   const int start = start_idx ? min(max(start_idx[b], 0), n - 1) : 0;
   if (threadIdx.x == 0) {
     s_acc[0] = make_float4(P[3 * start], P[3 * start + 1], P[3 * start + 2], 0.f);
@@ -503,7 +500,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
         }
       }
     }
-    if (PT == 1 && touched) {  // wave-uniform; otherwise s_wtop / s_wbound still hold this wave's candidates of the last round
+    if (touched) {  // wave-uniform; otherwise s_wtop / s_wbound still hold this wave's candidates of the last round
       // the thread's best key and a bound for its runner-up.  Distances are >= 0 (empty slots hold -1), so their bit
       // patterns order like the values: the largest distance by integer maxima, then one pass that counts its occurrences,
       // keeps the largest OTHER distance and the slot -- five instructions per point, ONE index read from LDS (building
@@ -517,7 +514,7 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
       // samples of this round lowered points the wave never offered, and the selection below can be skipped.
       if (round > 2 && !__any(owner && bdi != owner_bdi)) touched = false;
     }
-    if (PT == 1 && touched) {
+    if (touched) {
       int bdi = __float_as_int(pd[0]);
 #pragma unroll
       for (int j = 1; j < PPT; ++j) bdi = max(bdi, __float_as_int(pd[j]));
@@ -568,72 +565,6 @@ __global__ __launch_bounds__(FPS_T) void fps_multi_kernel(const float* __restric
       {
         const unsigned long long wb = wave_max_u64(mine > second ? mine : second);
         if (ln == 0) s_wbound[wv] = wb;
-      }
-    }
-    if (PT == 2 && touched) {
-      // PT = 2: the thread offers its TWO best points, the third bounds.  m1 >= m2 >= m3: its largest distances as bit
-      // patterns, with multiplicity (distances are >= 0, empty slots hold -1: the patterns order like the values).
-      const int none = __float_as_int(-1.0f);
-      int m1 = none, m2 = none, m3 = none;
-#pragma unroll
-      for (int j = 0; j < PPT; ++j) {
-        int t = __float_as_int(pd[j]);
-        const int a = max(m1, t);
-        t = min(m1, t);
-        m1 = a;
-        const int b2 = max(m2, t);
-        t = min(m2, t);
-        m2 = b2;
-        m3 = max(m3, t);
-      }
-      // published keys belong to `owner` lanes; if neither of THEIR two best distances moved, the wave's top-MW keys are
-      // what they were and the old bound still bounds (distances only fall): skip the selection
-      if (round > 2 && !__any(owner && (m1 != owner_bdi || m2 != owner_sdi))) touched = false;
-      if (touched) {
-        int bj = 0, sj = 0;
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-          const int dv = __float_as_int(pd[j]);
-          bj = dv == m1 ? j : bj;
-          sj = dv == m2 ? j : sj;
-        }
-        unsigned long long k1 = 0ull, k2 = 0ull, k3 = 0ull;
-        if (m1 >= 0) k1 = ((unsigned long long)(unsigned)m1 << 32) | (0xffffffffu - (unsigned)s_perm[bj * FPS_T + tid]);
-        if (m2 >= 0) k2 = ((unsigned long long)(unsigned)m2 << 32) | (0xffffffffu - (unsigned)s_perm[sj * FPS_T + tid]);
-        if (m3 >= 0) k3 = ((unsigned long long)(unsigned)m3 << 32) | 0xffffffffull;  // bounds the key from above
-        if (m1 >= 0 && (m1 == m2 || (m2 >= 0 && m2 == m3))) {  // equal distances inside the thread: the exact keys decide
-          k1 = 0ull, k2 = 0ull, k3 = 0ull;
-#pragma unroll
-          for (int j = 0; j < PPT; ++j) {
-            if (__float_as_int(pd[j]) >= 0) {
-              unsigned long long kk = fps_key(pd[j], s_perm[j * FPS_T + tid]);
-              if (kk > k1) { const unsigned long long t = k1; k1 = kk; kk = t; }
-              if (kk > k2) { const unsigned long long t = k2; k2 = kk; kk = t; }
-              if (kk > k3) k3 = kk;
-            }
-          }
-        }
-        // ---- 2. top-MW of the wave's offers (unique keys: exactly one lane owns each maximum; a lane whose first key
-        // went up presents its second); what is left, and every third point, bounds B
-        unsigned long long mine = k1, nxt = k2;
-        owner = false;
-        owner_bdi = m1;
-        owner_sdi = m2;
-#pragma unroll
-        for (int r = 0; r < MW; ++r) {
-          const unsigned long long w = wave_max_u64(mine);
-          if (ln == 0) s_wtop[wv * MW + r] = w;
-          if (r == 0) wave_maxd = __uint_as_float((unsigned)(w >> 32));  // keys order by distance first
-          if (mine == w && w != 0ull) {
-            mine = nxt;
-            nxt = 0ull;
-            owner = true;
-          }
-        }
-        {
-          const unsigned long long wb = wave_max_u64(mine > k3 ? mine : k3);
-          if (ln == 0) s_wbound[wv] = wb;
-        }
       }
     }
     __syncthreads();
@@ -887,9 +818,9 @@ __device__ __forceinline__ unsigned hilbert3_code(unsigned x0, unsigned x1, unsi
   return (spread3(X[0] ^ t) << 2) | (spread3(X[1] ^ t) << 1) | spread3(X[2] ^ t);
 }
 
-// key = cloud << 32 | 30-bit Hilbert (or Morton) code of the point inside its cloud's bounding cube (1024 cells per axis)
+// key = cloud << 32 | 30-bit Hilbert code of the point inside its cloud's bounding cube (1024 cells per axis)
 __global__ __launch_bounds__(256) void fps_curve_kernel(const float* __restrict__ pts, const int32_t* __restrict__ off, int nb,
-                                                         const uint32_t* __restrict__ bbox, int n, int hilbert,
+                                                         const uint32_t* __restrict__ bbox, int n,
                                                          unsigned long long* __restrict__ keys) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -900,7 +831,7 @@ __global__ __launch_bounds__(256) void fps_curve_kernel(const float* __restrict_
   const unsigned cx = (unsigned)fminf(fmaxf((pts[3 * (int64_t)i] - mnx) * sc, 0.f), 1023.f);      // NaN -> 0
   const unsigned cy = (unsigned)fminf(fmaxf((pts[3 * (int64_t)i + 1] - mny) * sc, 0.f), 1023.f);
   const unsigned cz = (unsigned)fminf(fmaxf((pts[3 * (int64_t)i + 2] - mnz) * sc, 0.f), 1023.f);
-  const unsigned code = hilbert ? hilbert3_code(cx, cy, cz) : (spread3(cx) | (spread3(cy) << 1) | (spread3(cz) << 2));
+  const unsigned code = hilbert3_code(cx, cy, cz);
   keys[i] = ((unsigned long long)(unsigned)b << 32) | code;
 }
 
@@ -1013,9 +944,8 @@ extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64
       int rc = compute_bbox(points, off.data(), h_blk.data(), d_off, (int)batch, mbbox, mblk, stream);
       if (rc != GR_OK) return rc;
       const unsigned nblk = (unsigned)((n + 255) / 256);
-      static const bool morton = getenv("GR_FPS_ORDER") && !strcmp(getenv("GR_FPS_ORDER"), "morton");
       hipLaunchKernelGGL(fps_curve_kernel, dim3(nblk), dim3(256), 0, stream, points, d_off, (int)batch, mbbox, (int)n,
-                         morton ? 0 : 1, reinterpret_cast<unsigned long long*>(mkeys_a));
+                         reinterpret_cast<unsigned long long*>(mkeys_a));
       int cloud_bits = 1;
       while ((1ll << cloud_bits) < batch) ++cloud_bits;
       rc = sort_pairs_u64_iota(sort_tmp, sort_bytes, mkeys_a, mkeys_b, (int64_t)1 << 40, mvals, n, 0, 32 + cloud_bits, stream);
@@ -1038,16 +968,13 @@ extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64
       void** args = multi_args;
       size_t lds = 0;  // the workgroup's original indices: PPT * 1024 ints
       // sixteen keys per workgroup when few workgroups share a cloud (large slabs): more candidates per round
-      static const bool m16_off = getenv("GR_FPS_M16") && atoi(getenv("GR_FPS_M16")) == 0;
-      static const int wide_mode = getenv("GR_FPS_WIDE") ? atoi(getenv("GR_FPS_WIDE")) : 0;
-      const bool m16 = G <= 16 && per > 10 && !m16_off;
-      const bool wide = m16 && wide_mode == 1;  // 32 keys per workgroup, 8 per wave, two points per thread (opt-in: see DESIGN 3.5)
+      const bool m16 = G <= 16 && per > 10;
       if (per <= 4) fn = reinterpret_cast<const void*>(fps_multi_kernel<4, 8>), lds = 4;
       else if (per <= 7) fn = reinterpret_cast<const void*>(fps_multi_kernel<7, 8>), lds = 7;
       else if (per <= 10) fn = reinterpret_cast<const void*>(fps_multi_kernel<10, 8>), lds = 10;
-      else if (per <= 13) fn = wide ? reinterpret_cast<const void*>(fps_multi_kernel<13, 32, 8, 2>) : m16 ? reinterpret_cast<const void*>(fps_multi_kernel<13, 16>) : reinterpret_cast<const void*>(fps_multi_kernel<13, 8>), lds = 13;
-      else if (per <= 16) fn = wide ? reinterpret_cast<const void*>(fps_multi_kernel<16, 32, 8, 2>) : m16 ? reinterpret_cast<const void*>(fps_multi_kernel<16, 16>) : reinterpret_cast<const void*>(fps_multi_kernel<16, 8>), lds = 16;
-      else if (per <= 20) fn = wide ? reinterpret_cast<const void*>(fps_multi_kernel<20, 32, 8, 2>) : m16 ? reinterpret_cast<const void*>(fps_multi_kernel<20, 16>) : reinterpret_cast<const void*>(fps_multi_kernel<20, 8>), lds = 20;
+      else if (per <= 13) fn = m16 ? reinterpret_cast<const void*>(fps_multi_kernel<13, 16>) : reinterpret_cast<const void*>(fps_multi_kernel<13, 8>), lds = 13;
+      else if (per <= 16) fn = m16 ? reinterpret_cast<const void*>(fps_multi_kernel<16, 16>) : reinterpret_cast<const void*>(fps_multi_kernel<16, 8>), lds = 16;
+      else if (per <= 20) fn = m16 ? reinterpret_cast<const void*>(fps_multi_kernel<20, 16>) : reinterpret_cast<const void*>(fps_multi_kernel<20, 8>), lds = 20;
       lds *= (size_t)FPS_T * sizeof(int);
       if (lds > 48 * 1024) GR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       if (per > 20) {  // slab too large for registers: one sample per round, distances streamed from L2
@@ -1073,7 +1000,6 @@ extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64
     GR_HIP(hipStreamSynchronize(stream));  // also keeps the host staging vectors alive past the copies
     if (G > 1 && attempt == 0 && g_fps_force.load() == 2) h_err = 1;  // test switch: treat the co-operative run as timed out
     if (h_err == 0) return GR_OK;
-    if (getenv("GR_FPS_VERBOSE")) fprintf(stderr, "gr_fps: exchange timed out (G=%d, batch=%lld, per=%lld); retrying with one workgroup per cloud\n", G, (long long)batch, (long long)per);
     GR_REQUIRE(attempt == 0 && G > 1, "fps: exchange timed out with a single workgroup per cloud (internal error)");
   }
   set_error("fps: inter-workgroup exchange timed out and the single-workgroup retry was not possible");

@@ -18,8 +18,6 @@
 #include <vector>
 
 #include <algorithm>
-#include <atomic>
-#include <thread>
 
 #include "common.hpp"
 
@@ -264,18 +262,6 @@ __global__ __launch_bounds__(256) void fo_rank_kernel(const int32_t* __restrict_
   keys_fo[r] = cell_key[c];
 }
 
-__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ bary,
-                                                     const int32_t* __restrict__ cell_of_rank,
-                                                     const int32_t* __restrict__ perm, int m,
-                                                     float* __restrict__ out) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= m) return;
-  const int c = cell_of_rank[perm[j]];
-  out[3 * (int64_t)j] = bary[3 * (int64_t)c];
-  out[3 * (int64_t)j + 1] = bary[3 * (int64_t)c + 1];
-  out[3 * (int64_t)j + 2] = bary[3 * (int64_t)c + 2];
-}
-
 inline int bits_for(unsigned long long v) {  // bits needed to represent values in [0, v)
   int b = 0;
   while (b < 64 && (1ull << b) < v) ++b;
@@ -473,40 +459,14 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
       GR_LAUNCH_CHECK();
       // The reference inserts keys in first-occurrence order into an unordered_map and emits in its iteration order
       // (grid_subsampling_cpu.cpp:28-47).  Default: that order is evaluated on the device in closed form
-      // (hash_order_device.hip; the bucket counts come from the real libstdc++ rehash policy).  GR_HASH_ORDER_HOST=1
-      // selects the host replay of the container's linking rules instead (hash_order.hip; the checker of the former).
-      static const bool host_replay = getenv("GR_HASH_ORDER_HOST") && getenv("GR_HASH_ORDER_HOST")[0] == '1';
+      // (hash_order_device.hip; the bucket counts come from the real libstdc++ rehash policy).  The host replay of the
+      // container's linking rules (hash_order.hip, gr_host_unordered_map_order) is its checker: tests/test_gpu_hash_order.py.
       std::vector<int64_t> r0(batch + 1, 0);
       for (int64_t b = 0; b < batch; ++b) r0[b + 1] = r0[b] + h_mb[b];
-      if (!host_replay) {
-        // the last launch of the evaluation moves the barycentres to their rows itself (no permutation, no gather launch)
-        rc = hash_order_device(w.keys_fo, r0.data(), batch, nullptr, w.ho_ws, w.ho_bytes, stream, w.bary, w.cell_of_rank,
-                               out_points);
-        if (rc != GR_OK) return rc;
-      } else {
-      std::vector<uint64_t> hk(h_m);
-      GR_HIP(hipMemcpyAsync(hk.data(), w.keys_fo, sizeof(uint64_t) * h_m, hipMemcpyDeviceToHost, stream));
-      GR_HIP(hipStreamSynchronize(stream));
-      std::vector<int32_t> perm(h_m);
-      {
-        // clouds are independent: replay them on several host threads when there is enough work
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        const int64_t want = std::min<int64_t>({(int64_t)batch, (int64_t)hw, (int64_t)64, h_m / 40000 + 1});
-        std::atomic<int64_t> next_cloud{0};
-        auto worker = [&]() {
-          for (int64_t b = next_cloud.fetch_add(1); b < batch; b = next_cloud.fetch_add(1))
-            unordered_map_order(hk.data() + r0[b], h_mb[b], (int32_t)r0[b], perm.data() + r0[b]);  // hash_order.hip
-        };
-        std::vector<std::thread> pool;
-        for (int64_t t = 1; t < want; ++t) pool.emplace_back(worker);
-        worker();
-        for (auto& th : pool) th.join();
-      }
-      GR_HIP(hipMemcpyAsync(w.perm, perm.data(), sizeof(int32_t) * h_m, hipMemcpyHostToDevice, stream));
-      GR_HIP(hipStreamSynchronize(stream));  // perm (host vector) must outlive the copy
-      hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((h_m + 255) / 256)), blk, 0, stream, w.bary, w.cell_of_rank,
-                         w.perm, h_m, out_points);
-      }
+      // the last launch of the evaluation moves the barycentres to their rows itself (no permutation, no gather launch)
+      rc = hash_order_device(w.keys_fo, r0.data(), batch, nullptr, w.ho_ws, w.ho_bytes, stream, w.bary, w.cell_of_rank,
+                             out_points);
+      if (rc != GR_OK) return rc;
       GR_LAUNCH_CHECK();
     }
   }

@@ -19,6 +19,7 @@
 // a walk over the (short) bucket chain.  One such evaluation per rehash of the container's history (the bucket counts
 // come from the REAL _Prime_rehash_policy object of the libstdc++ this library is built against), plus one for the final
 // table; every evaluation is a handful of data-parallel passes over all clouds.
+#include <atomic>
 #include <unordered_map>  // std::__detail::_Prime_rehash_policy
 #include <vector>
 
@@ -26,6 +27,7 @@
 
 namespace gr {
 namespace {
+std::atomic<int> g_ho_force_prescan{0};  // test hook: take the slab-table pre-scan of the > 4 M-clock stages at any size
 
 struct HoCloud {    // per cloud, per stage
   int32_t begin;    // first element (global rank) of the cloud
@@ -418,7 +420,7 @@ int hash_order_device(const uint64_t* keys, const int64_t* h_begins, int64_t bat
   // stage 0 (13 buckets) is always small: with no big stage the LDS kernel emits
   hipLaunchKernelGGL(ho_small_stages_kernel, dim3((unsigned)batch), dim3(1024), 0, stream, d_st, (int)batch, (int)nsmall, keys,
                      Ta, Tb, nsmall == nstage ? 1 : 0, em);
-  const bool prescan_always = getenv("GR_HASH_ORDER_PRESCAN") != nullptr;  // test knob: the > 4 M-clock path
+  const bool prescan_always = g_ho_force_prescan.load() != 0;  // test hook (gr_hash_order_debug_force_prescan): the > 4 M-clock path
   int64_t big_m = 0;
   for (size_t k = nsmall; k < nstage; ++k)
     for (int64_t c = 0; c < batch; ++c)
@@ -469,4 +471,10 @@ extern "C" int gr_hash_order_device(const uint64_t* d_keys, const int64_t* h_beg
   GR_REQUIRE(h_begins[batch] == 0 || (d_keys && d_perm), "null argument");
   return gr::hash_order_device(d_keys, h_begins, batch, d_perm, ws, ws_bytes, static_cast<hipStream_t>(stream), nullptr, nullptr,
                                nullptr);
+}
+
+extern "C" int gr_hash_order_debug_force_prescan(int on) {
+  const int old = gr::g_ho_force_prescan.load();
+  if (on == 0 || on == 1) gr::g_ho_force_prescan.store(on);
+  return old;
 }

@@ -496,8 +496,7 @@ extern "C" int gr_kpconv_forward(const float* s_feats, const float* q_points, co
   if (n > 0)
     hipLaunchKernelGGL(rowflag_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, s_feats, (int)n, (int)cin, flag);
   const size_t kp_lds = (size_t)std::min<int64_t>(h, KP_HMAX) * (KP_MAX + 2) * sizeof(float);
-  static const bool mfma_off = getenv("GR_KPCONV_VALU_GATHER") && atoi(getenv("GR_KPCONV_VALU_GATHER")) != 0;
-  const bool mfma = !mfma_off && n > 0 && h <= 4 * KP_STEPS && (cin == 16 || cin == 32 || cin == 64 || cin == 128 || cin == 256);
+  const bool mfma = n > 0 && h <= 4 * KP_STEPS && (cin == 16 || cin == 32 || cin == 64 || cin == 128 || cin == 256);
   if (mfma) {
     const dim3 grid((unsigned)((m + 3) / 4)), blk(256);
 #define GR_KP_MFMA(NT)                                                                                                       \
@@ -519,8 +518,7 @@ extern "C" int gr_kpconv_forward(const float* s_feats, const float* q_points, co
     hipLaunchKernelGGL((kp_gather_kernel<256>), dim3((unsigned)m), dim3(256), kp_lds, stream, s_feats, q_points, s_points,
                        neighbor_indices, (int)n, (int)h, (int)cin, (int)k, kernel_points, sigma, inf, flag, WF, num);
   const int kd = (int)(k * cin);
-  static const bool no_aligned = getenv("GR_KPCONV_GEMM_GENERAL") != nullptr;
-  const bool aligned = !no_aligned && kd % BK == 0 && cout % 4 == 0 && cout >= 4 &&
+  const bool aligned = kd % BK == 0 && cout % 4 == 0 && cout >= 4 &&
                        ((reinterpret_cast<uintptr_t>(WF) | reinterpret_cast<uintptr_t>(weights)) & 15) == 0;
   if (m >= BT && cout > 64) {
     const int64_t blocks128 = ((cout + BT - 1) / BT) * ((m + BT - 1) / BT);

@@ -1006,19 +1006,12 @@ struct FusedLds {
   }
 };
 
-template <int RQ, bool ROWBUF>
+template <int RQ>
 __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
     const float4* __restrict__ sorted_q, int nq, const int32_t* __restrict__ q_off, int nb,
     const BatchGrid* __restrict__ grids, const int32_t* __restrict__ start_s, const float4* __restrict__ sorted_s, int ns_total,
     float r2, int32_t* __restrict__ blk_stats, int width, int64_t pad_value, int64_t* __restrict__ out, int cap,
-    int region_bytes, int mono, int dbg_stop) {
-  // dbg_stop (GR_RADIUS_FUSED_STOP, measurement only): leave after phase k -- 1 set-up, 2 staging, 3 tests, 4 scan,
-  // 5 decode, 6 keys, 7 ranking; 0 = the whole kernel
-#define GR_FUSED_STOP(K, VALUE)                                    \
-  if (dbg_stop == (K)) {                                           \
-    if ((VALUE) == 0x7fffffff) blk_stats[2 * blk] = tid;           \
-    return;                                                        \
-  }
+    int region_bytes, int mono) {
   using L = FusedLds<RQ>;
   static_assert(RQ % WAVE == 0 && RQ <= 256, "row ids are bytes; waves must not straddle slabs");
   constexpr unsigned PADMARK = 0xffffffffu;
@@ -1110,7 +1103,6 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
   } else if (j == 0) {
     orig[slot] = -1;
   }
-  GR_FUSED_STOP(1, p0[0] + p0[1] + p0[2] + p1[0] + p1[1] + p1[2])
   // ---- block-wide extent of every band (waves are slab-uniform: band index = 3*j + i)
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -1190,7 +1182,6 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
     }
     __syncthreads();
   }
-  GR_FUSED_STOP(2, (int)sx[tid])
   // ---- test every candidate, four per step.  Enumeration slot c = 4 * step + k (k = 0..3; a band's last step is padded);
   //      even slots are remembered in `lo`, odd slots in `hi`: two 32-bit SHIFT REGISTERS -- a hit is the sign bit of
   //      (distance bits - r2 bits) (both are non-negative floats: their bit patterns order like the values, NaN sorts above
@@ -1269,7 +1260,6 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
         n += d < r2 ? 1 : 0;
       }
   }
-  GR_FUSED_STOP(3, n + (int)(lo >> 20) + (int)(hi >> 20))
   sub[tid] = n;
   __syncthreads();
   // ---- block scan of the per-query totals; every slab group does it redundantly (no cross-group sync)
@@ -1297,10 +1287,9 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
     qtot[slot] = tot;
     if (slot == RQ - 1) offs[RQ] = q_start + tot4;
   }
-  GR_FUSED_STOP(4, my_off + total4)
   int blk_flag = 0;
   const bool multi = total4 > cap;
-  const bool use_rowbuf = ROWBUF && !multi;
+  const bool use_rowbuf = !multi;  // rows leave through an LDS row buffer as contiguous 16-byte pieces
   const int rows_here = min(RQ, nq - blk * RQ);
   if (multi) __syncthreads();  // offs complete
   int glo = 0;
@@ -1371,7 +1360,6 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
       }
     }
     __syncthreads();
-    GR_FUSED_STOP(5, (int)hm[tid])
     // ---- keys: one thread per hit slot -- distance bits and support index (balanced: no lane waits for a longer list)
     const int group_hits = skip ? 0 : offs[ghi] - gbase;
     for (int e = tid; e < group_hits; e += L::THREADS) {
@@ -1406,7 +1394,6 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
       hm[e] = (unsigned)idx;
     }
     __syncthreads();
-    GR_FUSED_STOP(6, (int)hd[tid])
     if (use_rowbuf) {
       // the planes are dead: their place becomes the row buffer, every entry "not written"
       const int quads = (rows_here * width + 3) >> 2;
@@ -1451,7 +1438,6 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
     }
     if (use_rowbuf) {
       __syncthreads();
-      GR_FUSED_STOP(7, (int)rowbuf[tid])
       // whole rows leave as contiguous runs: consecutive lanes, consecutive 16-byte pieces of a row.  An unwritten entry
       // below the row's hit count means two hits of that row have the same distance: the row is noted and redone below
       if ((width & 1) == 0) {
@@ -1521,7 +1507,6 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
     blk_stats[2 * blk] = mx;
     blk_stats[2 * blk + 1] = blk_flag;
   }
-#undef GR_FUSED_STOP
 }
 
 // max / max over the per-block (max hits per query, hits per block) pairs -> hdr
@@ -1640,64 +1625,37 @@ int launch_fill(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t n
   return GR_OK;
 }
 
-struct FusedCfg {
-  int rq;      // queries per block: 64 or 128
-  int rowbuf;  // rows leave through an LDS row buffer as contiguous 16-byte pieces (else: one 8-byte store per hit)
-  int per_q;   // key slots per query in a block's key area
-  int dbg_stop;
-};
-inline FusedCfg fused_cfg() {
-  static const FusedCfg cfg = [] {
-    FusedCfg c{64, 1, 28, 0};  // 64 queries per block: 30 KB of LDS, five blocks per CU (0.43 ms per 8 x 200 k; 128: 0.50 ms)
-    if (const char* e = getenv("GR_RADIUS_FUSED_STOP")) c.dbg_stop = atoi(e);
-    if (const char* e = getenv("GR_RADIUS_FUSED_RQ")) c.rq = atoi(e) == 128 ? 128 : 64;
-    if (const char* e = getenv("GR_RADIUS_FUSED_ROWBUF")) c.rowbuf = atoi(e) != 0;
-    if (const char* e = getenv("GR_RADIUS_FUSED_SLOTS")) c.per_q = max(8, min(512, atoi(e)));
-    return c;
-  }();
-  return cfg;
-}
+constexpr int FUSED_RQ = 64;     // queries per block: 30 KB of LDS, five blocks per CU (0.43 ms per 8 x 200 k; 128 queries: 0.50 ms)
+constexpr int FUSED_PER_Q = 28;  // key slots per query in a block's key area
 
-template <int RQ, bool ROWBUF>
-int launch_fused_t(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns, int nb, const int32_t* start_s,
-                   float r2, int64_t width, int per_q, int64_t* out, bool mono, hipStream_t stream, RadiusHdr* h_out) {
+int launch_fused(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns, int nb, const int32_t* start_s,
+                 float r2, int64_t width, int64_t* out, bool mono, hipStream_t stream, RadiusHdr* h_out) {
+  constexpr int RQ = FUSED_RQ;
   using L = FusedLds<RQ>;
   const int blocks = (int)((nq + RQ - 1) / RQ);
   const int grid = (blocks + 7) / 8 * 8;
   const int tcap = nb <= L::TABLE_MAX ? nb : 0;
-  // key area: `per_q` slots per query, never less than two full rows, within the 160 KB of a CU
-  int cap = max(per_q * RQ, (int)(2 * width + 2));
+  // key area: FUSED_PER_Q slots per query, never less than two full rows, within the 160 KB of a CU
+  int cap = max(FUSED_PER_Q * RQ, (int)(2 * width + 2));
   cap = (cap + 15) / 16 * 16;
   while (L::total((int)width, cap, tcap) > 160 * 1024 && cap > 64) cap -= 16;
   const size_t region = L::region_bytes((int)width);
   const size_t lds = L::total((int)width, cap, tcap);
   GR_REQUIRE(lds <= 160 * 1024, "radius_search: neighbor_limit %lld does not fit the single-pass kernel", (long long)width);
-  auto kern = fused_kernel<RQ, ROWBUF>;
+  auto kern = fused_kernel<RQ>;
   if (lds > 64 * 1024)
     GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   {
     KernelTimer timer("radius_fused", stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(L::THREADS), lds, stream, sorted_q, (int)nq, w.q_off, nb, w.grids, start_s,
-                       w.sorted_s, (int)ns, r2, w.blk_stats, (int)width, ns, out, cap, (int)region, mono ? 1 : 0, fused_cfg().dbg_stop);
+                       w.sorted_s, (int)ns, r2, w.blk_stats, (int)width, ns, out, cap, (int)region, mono ? 1 : 0);
   }
   return reduce_and_read(w, blocks, stream, h_out);
 }
 
 inline bool fused_fits(int64_t width) {
   // the row buffer / key area of the largest configuration must fit next to the candidate planes
-  return width >= 1 && FusedLds<64>::total((int)width, (int)((2 * width + 2 + 15) / 16 * 16), 0) <= 160 * 1024;
-}
-
-int launch_fused(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns, int nb, const int32_t* start_s,
-                 float r2, int64_t width, int64_t* out, bool mono, hipStream_t stream, RadiusHdr* h_out) {
-  const FusedCfg c = fused_cfg();
-  int rq = c.rq;
-  if (rq == 128 && FusedLds<128>::total((int)width, (int)((2 * width + 2 + 15) / 16 * 16), 0) > 160 * 1024) rq = 64;
-  if (rq == 128)
-    return c.rowbuf ? launch_fused_t<128, true>(w, sorted_q, nq, ns, nb, start_s, r2, width, c.per_q, out, mono, stream, h_out)
-                    : launch_fused_t<128, false>(w, sorted_q, nq, ns, nb, start_s, r2, width, c.per_q, out, mono, stream, h_out);
-  return c.rowbuf ? launch_fused_t<64, true>(w, sorted_q, nq, ns, nb, start_s, r2, width, c.per_q, out, mono, stream, h_out)
-                  : launch_fused_t<64, false>(w, sorted_q, nq, ns, nb, start_s, r2, width, c.per_q, out, mono, stream, h_out);
+  return width >= 1 && FusedLds<FUSED_RQ>::total((int)width, (int)((2 * width + 2 + 15) / 16 * 16), 0) <= 160 * 1024;
 }
 
 }  // namespace

@@ -867,11 +867,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int CELL = 4;
 constexpr int NCELL = (TILE / CELL) * (TILE / CELL);  // 16
 
-// development statistics (GR_BLEND_STATS=1): [0] tiles, [1] batches, [2] entries loaded, [3] cell-list entries,
-// [4] wave blend steps (two entries each), [5] entries a pixel actually blended, [6] sum over (wave, batch) of the largest
-// per-pixel blend count, [7] sum over lanes of the list lengths they set out to walk
-__device__ unsigned long long g_blend_stats[8];
-
 __device__ __forceinline__ float lds_f32(const float* plane, unsigned int byte_off) {
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane) + byte_off);
 }
@@ -892,7 +887,7 @@ __device__ __forceinline__ float min_f32_raw(float a, float b) {  // fminf, same
 // deterministic polynomial exp_det() -- 3 issue slots per pair of entries instead of 20.  The image is no longer bit-equal
 // to oracle/rasterizer_oracle.c but stays within 1e-5 relative of it (tests/test_gpu_rasterizer_fast.py); opt-in
 // (GR_RASTER_FAST_EXP flag of gr_raster_render_ex).
-template <bool STATS, bool FAST_EXP>
+template <bool FAST_EXP>
 __global__ __launch_bounds__(BLOCK) void blend_kernel(
     int P, int W, int H, int nchunk, const DevView* __restrict__ views, const uint32_t* __restrict__ seg_off,
     const int32_t* __restrict__ point_list, const float4* __restrict__ rec, float* __restrict__ out_color,
@@ -939,7 +934,6 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
   // lane = chunk, two 4-byte loads give segment start and end); the batches of 256 entries are cut out of that window.
   int c_next = 0, w_pos = 0, w_total = 0;  // block-uniform
   const uint32_t* seg_col = seg_off + (int64_t)v * nchunk * (tiles + 1) + tile;
-  if (STATS && tid == 0) atomicAdd(&g_blend_stats[0], 1ull);
   while (true) {
     // all 256 pixels saturated?  One ballot per wave, one flag per wave, one barrier (the later barriers of the batch
     // separate this read from the next write)
@@ -972,10 +966,6 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
     if (exhausted) break;
     // ---- load + cutoffs + cell mask
     const int e = w_pos + tid;
-    if (STATS && tid == 0) {
-      atomicAdd(&g_blend_stats[1], 1ull);
-      atomicAdd(&g_blend_stats[2], (unsigned long long)min(BLOCK, w_total - w_pos));
-    }
     w_pos += BLOCK;
     // reach[c]: the lanes of this wave whose entry can reach cell c -- 16 lane masks in scalar registers.  The rank of an
     // entry in a cell's list is a masked bit count of that mask and the list write runs under it as the exec mask
@@ -1060,16 +1050,10 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
     // ---- blend: each 16-lane group walks its own list
     const int len_cell = __shfl(tot_lane, (BLOCK / WAVE) * lw + lane / (CELL * CELL));  // cell = 4 lw + lane / 16
     const int n_cell = done ? 0 : len_cell;
-    if (STATS) {
-      if (pin == 0) atomicAdd(&g_blend_stats[3], (unsigned long long)len_cell);
-      const int mx = wave_max_i32_dpp(n_cell);
-      if (lane == 0) atomicAdd(&g_blend_stats[4], (unsigned long long)((mx + 1) / 2));
-    }
     // Two list entries per step: everything up to alpha is evaluated for both at once with packed fp32 math
     // (v_pk_fma/mul/add_f32 -- the same IEEE operations as the scalar sequence of the oracle, two per lane-slot);
     // only the order-dependent tail (transmittance test, colour accumulation) runs entry by entry.
     const unsigned short* lp = &s_list[cell][0];
-    int stat_hits = 0;
     for (int i = 0; i < n_cell && !done; i += 2) {
       const unsigned int o0 = lp[i], o1 = lp[i + 1];  // byte offsets of two list entries (an odd list ends with the pad entry)
       const f32x2 dx = f32x2{lds_f32(s_px, o0), lds_f32(s_px, o1)} - pfx, dy = f32x2{lds_f32(s_py, o0), lds_f32(s_py, o1)} - pfy;
@@ -1101,10 +1085,6 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
       const float alpha0 = min_f32_raw(al.x, 0.99f), alpha1 = min_f32_raw(al.y, 0.99f);
       const bool ok0 = !(power.x > 0.0f) && !(power.x < pc0) && !(alpha0 < 1.0f / 255.0f);
       const bool ok1 = !(power.y > 0.0f) && !(power.y < pc1) && !(alpha1 < 1.0f / 255.0f);
-      if (STATS) {
-        atomicAdd(&g_blend_stats[5], (unsigned long long)((ok0 ? 1 : 0) + (ok1 ? 1 : 0)));
-        stat_hits += (ok0 ? 1 : 0) + (ok1 ? 1 : 0);
-      }
       // A pixel that saturates leaves the walk through the loop condition, not through a `break`: the wave's control flow
       // stays one counted loop with two predicated regions.
       if (ok0) {
@@ -1129,11 +1109,6 @@ __global__ __launch_bounds__(BLOCK) void blend_kernel(
           T = test_T;
         }
       }
-    }
-    if (STATS) {  // [6] per wave: the largest number of blends any one pixel did in this batch; [7] lanes x list entries walked
-      const int mh = wave_max_i32_dpp(stat_hits);
-      if (lane == 0) atomicAdd(&g_blend_stats[6], (unsigned long long)mh);
-      atomicAdd(&g_blend_stats[7], (unsigned long long)n_cell);
     }
   }
   if (inside) {
@@ -1306,14 +1281,6 @@ using namespace gr;
 
 static int64_t tiles_of(int width, int height) {
   return (int64_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
-}
-
-extern "C" int gr_debug_blend_stats(unsigned long long* out8) {
-  GR_HIP(hipDeviceSynchronize());
-  GR_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_blend_stats), sizeof(unsigned long long) * 8));
-  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  GR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_blend_stats), z, sizeof(z)));
-  return GR_OK;
 }
 
 extern "C" int gr_raster_lds_atomics_lane_ordered(void) { return lds_atomics_lane_ordered_state(); }
@@ -1664,23 +1631,17 @@ static int render_impl(int64_t P, const gr_raster_view* h_views, int num_views, 
     }
   }
   KernelTimer timer("raster_blend", stream);
-  static const bool stats = getenv("GR_BLEND_STATS") && getenv("GR_BLEND_STATS")[0] == '1';
   const bool fast = (flags & GR_RASTER_FAST_EXP) != 0;
   const int blend_chunks = (R > 0 || (spec && P > 0)) ? nchunk : 0;
   // GR_RASTER_SHARE (a caller that keeps another one-camera frame in flight next to this one): the blend alone fills all 32
   // wave slots of a CU (8 workgroups x 19 KB of LDS), and the next frame's front kernels -- the chain the host waits for --
   // queue behind it.  14 KB of unused dynamic LDS cap it at 4 workgroups per CU: the blend takes longer, out of sight behind
-  // the other frame, and the front chain gets its slots (5 290 -> 5 450 views/s; GR_BLEND_SHARE_PAD to tune).
-  static const size_t share_pad = getenv("GR_BLEND_SHARE_PAD") ? (size_t)atoi(getenv("GR_BLEND_SHARE_PAD")) : 14000;
-  const size_t blend_pad = (spec && (flags & GR_RASTER_SHARE)) ? share_pad : 0;
-#define GR_BLEND(ST, FE)                                                                                                  \
-  hipLaunchKernelGGL((blend_kernel<ST, FE>), dim3(gx, gy, num_views), dim3(BLOCK), blend_pad, stream, (int)P, W, H, blend_chunks, \
+  // the other frame, and the front chain gets its slots (5 290 -> 5 450 views/s).
+  const size_t blend_pad = (spec && (flags & GR_RASTER_SHARE)) ? 14000 : 0;
+#define GR_BLEND(FE)                                                                                                  \
+  hipLaunchKernelGGL((blend_kernel<FE>), dim3(gx, gy, num_views), dim3(BLOCK), blend_pad, stream, (int)P, W, H, blend_chunks, \
                      g.views, g.seg_off, point_list, g.rec, out_color, list_cap)
-  if (stats) {
-    if (fast) GR_BLEND(true, true); else GR_BLEND(true, false);
-  } else {
-    if (fast) GR_BLEND(false, true); else GR_BLEND(false, false);
-  }
+  if (fast) GR_BLEND(true); else GR_BLEND(false);
 #undef GR_BLEND
   GR_LAUNCH_CHECK();
   frame_done();
@@ -1733,10 +1694,9 @@ extern "C" int gr_raster_forward(int64_t P, int M, const float* means3D, const f
   GR_REQUIRE(!g_pending.open, "gr_raster_forward: the previous split call of this thread was not finished");
   const int64_t stage_hint = h_num_rendered[num_views > 0 ? num_views : 0];  // in: last frame's largest chunk (0 = unknown)
   const int64_t entries = bin && bin_bytes > 512 ? (int64_t)((bin_bytes - 512) / sizeof(int32_t)) - 64 : -1;
-  static const bool no_spec = getenv("GR_RASTER_NO_SPECULATION") && getenv("GR_RASTER_NO_SPECULATION")[0] == '1';
   // (only for a few views per call: at 32 views the host's share of a 3 ms frame is nothing, and the scatter measured 16 %
   // slower when launched this way -- 0.474 vs 0.405 ms)
-  if (P > 0 && num_views <= 4 && entries > 0 && entries < (1ll << 31) - 1 && !no_spec && !verify_this_frame()) {
+  if (P > 0 && num_views <= 4 && entries > 0 && entries < (1ll << 31) - 1 && !verify_this_frame()) {
     // The host is not needed between the two halves of a frame: the counts are read back behind an event while the
     // binning scatter and the blend are launched right behind the counting kernels on a list sized by the caller
     // (last frame's count + 25 %).  The host then waits for the EVENT -- the GPU is still drawing -- and only a frame whose
@@ -1745,7 +1705,7 @@ extern "C" int gr_raster_forward(int64_t P, int M, const float* means3D, const f
     if (ev == nullptr) GR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     static thread_local int32_t* mail = nullptr;  // host-mapped, coherent: the counting kernel writes it, the host polls it
     if (mail == nullptr) {
-      static const bool no_mail = getenv("GR_RASTER_NO_MAILBOX") && getenv("GR_RASTER_NO_MAILBOX")[0] == '1';
+      static const bool no_mail = getenv("GR_NO_MAILBOX") && getenv("GR_NO_MAILBOX")[0] == '1';  // (common.hip: the same switch)
       void* mp = nullptr;
       if (!no_mail && hipHostMalloc(&mp, 4096, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
         memset(mp, 0, 4096);

@@ -580,11 +580,9 @@ extern "C" int gr_sinkhorn(const float* scores, int64_t batch, int64_t m, int64_
   if (lds > 64 * 1024)
     GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  // GR_SINKHORN_LOG_DOMAIN=1: every iteration as logsumexp (the fall-back of the scaling form, see the kernel)
-  static const int scaling_form = (getenv("GR_SINKHORN_LOG_DOMAIN") && atoi(getenv("GR_SINKHORN_LOG_DOMAIN")) != 0) ? 0 : 1;
-  // matrices with at most 63 valid rows and columns: one wave each (GR_SINKHORN_SMALL=0: everything through the 512-thread kernel)
-  static const int small_on = (getenv("GR_SINKHORN_SMALL") && atoi(getenv("GR_SINKHORN_SMALL")) == 0) ? 0 : 1;
-  const int small = small_on && scaling_form && num_iterations > 0 && (row_masks || col_masks || std::max(m, n) <= SS_MAX);
+  const int scaling_form = 1;  // (0: every iteration as logsumexp -- what the kernel itself falls back to, matrix by matrix)
+  // matrices with at most 63 valid rows and columns: one wave each
+  const int small = num_iterations > 0 && (row_masks || col_masks || std::max(m, n) <= SS_MAX);
   KernelTimer timer("sinkhorn", stream);
   if (small) {
     // [0] = number of matrices left for the 512-thread kernel, then their indices (caller's workspace: no allocation

@@ -731,9 +731,6 @@ namespace gr {
 namespace {
 // tile choice: 128 x 128 per workgroup once that still leaves every CU a workgroup or so; else 64 x 64
 inline bool pd_use_big(int64_t n, int64_t m, int64_t batch) {
-  static const int force = getenv("GR_PAIRWISE_TILE") ? atoi(getenv("GR_PAIRWISE_TILE")) : 0;  // 64 / 128: measurement only
-  if (force == 64) return false;
-  if (force == 128) return true;
   return ((n + PB_T - 1) / PB_T) * ((m + PB_T - 1) / PB_T) * batch >= 192;
 }
 }  // namespace

@@ -125,8 +125,7 @@ class _FramePipe:
     do write behind the counter's back call reset_frame_pipe() after the write."""
 
     def __init__(self, dev):
-        depth = max(2, min(8, int(os.environ.get("GR_RASTER_PIPE_DEPTH", "2"))))
-        self.streams = tuple(torch.cuda.Stream(dev) for _ in range(depth))
+        self.streams = tuple(torch.cuda.Stream(dev) for _ in range(2))
         self.turn = 0
         self.stamp = None
         self.keep = None

@@ -106,8 +106,8 @@ int gr_radius_search(const float* q, const float* s, const int64_t* h_q_lengths,
  * total.  Barycentres are bit-identical to the reference (sequential fp32 sums in input order,
  * times float(1.0/count)).  order_mode selects the ROW ORDER inside each cloud:
  *   GR_ORDER_REFERENCE  the reference's std::unordered_map iteration order, evaluated on the device in closed form
- *                       (csrc/hash_order_device.hip; GR_HASH_ORDER_HOST=1 selects the host replay of libstdc++'s
- *                       linking rules instead), bit-for-bit the tensor the reference returns;
+ *                       (csrc/hash_order_device.hip; checked against the host replay of libstdc++'s linking rules,
+ *                       gr_host_unordered_map_order), bit-for-bit the tensor the reference returns;
  *   GR_ORDER_CELL       ascending voxel key -- fully on device, same multiset of rows.
  * Synchronises `stream` (the output size is data dependent).
  */
@@ -124,6 +124,9 @@ int gr_host_unordered_map_order(const uint64_t* h_keys, int64_t n, int32_t* h_pe
 size_t gr_hash_order_device_workspace_bytes(int64_t n, int64_t batch);
 int gr_hash_order_device(const uint64_t* d_keys, const int64_t* h_begins, int64_t batch, int32_t* d_perm, void* ws,
                          size_t ws_bytes, void* stream);
+/* Test switch: 1 = the device evaluation takes the slab-table pre-scan of its > 4 M-clock stages at any size (same order).
+ * Returns the old value; another argument only queries. */
+int gr_hash_order_debug_force_prescan(int on);
 size_t gr_grid_subsample_workspace_bytes(int64_t n, int64_t batch);
 int gr_grid_subsample(const float* points, const int64_t* h_lengths, int64_t n, int64_t batch,
                       float voxel_size, int order_mode, float* out_points, int64_t* h_out_lengths,

@@ -63,12 +63,15 @@ def test_device_order_equals_host_replay_across_rehash_thresholds():
 @pytest.mark.parametrize("prescan", [False, True])
 def test_device_order_large_clouds(prescan, monkeypatch):
     """prescan: the path clouds of more than 4 M clocks take (slab totals scanned by a launch of their own)."""
-    if prescan:
-        monkeypatch.setenv("GR_HASH_ORDER_PRESCAN", "1")
+    from gaussreg_amd import _lib
     rng = np.random.default_rng(1)
     clouds = [distinct(rng, n, kind) for n, kind in ((60000, "dense"), (49505, "random"), (100000, "dense"), (33333, "colliding"),
                                                      (300000, "dense"))]
-    perm, begins = device_order(clouds)
+    old = _lib.lib().gr_hash_order_debug_force_prescan(1 if prescan else 0)
+    try:
+        perm, begins = device_order(clouds)
+    finally:
+        _lib.lib().gr_hash_order_debug_force_prescan(old)
     for i, c in enumerate(clouds):
         assert np.array_equal(perm[begins[i]:begins[i + 1]], host_order(c) + begins[i]), i
 

@@ -467,40 +467,25 @@ def test_fps_production_shape_to_the_end():
     assert np.array_equal(one, capi.farthest_point_sampling(clouds[1].cpu().numpy(), k, 11))
 
 
-@pytest.mark.parametrize("env", [{"GR_FPS_ORDER": "morton"}, {"GR_FPS_WIDE": "1"}, {"GR_FPS_WIDE": "1", "GR_FPS_ORDER": "morton"},
-                                 {"GR_FPS_M16": "0"}])
-def test_fps_alternative_variants_stay_exact(env):
-    """The switches are read once per process, so each combination runs in its own interpreter: Morton instead of Hilbert
-    order of the slabs (pruning only: the keys carry the original index), the wide variant (32 keys per workgroup, 8 per
-    wave, two points per thread; candidate sets of several hundred, chains over more than 64 candidates in conflict), and
-    eight keys per workgroup.  16 workgroups per cloud, 4 000 samples, clustered and room-like clouds, index-exact."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = """
-import numpy as np, torch, sys
-sys.path.insert(0, %r)
-from gaussreg_amd.registration import farthest_point_sampling
-from gaussreg_amd import pair_pipeline
-from oracle import matching_np as M
-n, batch, k = 200000, 16, 4000
-clouds = []
-for i in range(batch // 2):
-    r_, s_, _ = pair_pipeline.synthetic_room_pair(300 + i, n, torch.device("cuda:0"))
-    clouds += [r_, s_]
-rng = np.random.default_rng(5)
-centres = rng.random((300, 3)) * 50
-clustered = (centres[rng.integers(0, 300, n)] + rng.normal(0, 0.01, (n, 3))).astype(np.float32)
-clouds[3] = torch.from_numpy(clustered).cuda()
-got = farthest_point_sampling(torch.cat(clouds).contiguous(), [n] * batch, [k] * batch, start_indices=[3 * b for b in range(batch)])
-for b in (0, 3, batch - 1):
-    want = M.farthest_point_sampling(clouds[b].cpu().numpy(), k, 3 * b)
-    assert np.array_equal(got[b].cpu().numpy(), want), b
-print("ok")
-""" % root
-    res = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, cwd=root, timeout=600)
-    assert res.returncode == 0 and res.stdout.strip().endswith("ok"), res.stdout[-2000:] + res.stderr[-2000:]
+def test_fps_sixteen_clouds_per_call_stay_exact():
+    """16 clouds per call (16 workgroups per cloud: the sixteen-keys-per-workgroup variant), 4 000 samples, clustered and
+    room-like clouds, index-exact against the sequential definition."""
+    from gaussreg_amd.registration import farthest_point_sampling
+    from gaussreg_amd import pair_pipeline
+    from oracle import matching_np as M
+    n, batch, k = 200000, 16, 4000
+    clouds = []
+    for i in range(batch // 2):
+        r_, s_, _ = pair_pipeline.synthetic_room_pair(300 + i, n, torch.device("cuda:0"))
+        clouds += [r_, s_]
+    rng = np.random.default_rng(5)
+    centres = rng.random((300, 3)) * 50
+    clustered = (centres[rng.integers(0, 300, n)] + rng.normal(0, 0.01, (n, 3))).astype(np.float32)
+    clouds[3] = torch.from_numpy(clustered).cuda()
+    got = farthest_point_sampling(torch.cat(clouds).contiguous(), [n] * batch, [k] * batch, start_indices=[3 * b for b in range(batch)])
+    for b in (0, 3, batch - 1):
+        want = M.farthest_point_sampling(clouds[b].cpu().numpy(), k, 3 * b)
+        assert np.array_equal(got[b].cpu().numpy(), want), b
 
 
 def test_fps_clustered_cloud_many_candidates_in_conflict():

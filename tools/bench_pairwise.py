@@ -1,5 +1,5 @@
 """Dev tool: the dense distance kernel (pairwise_kernel 64 x 64 / pairwise_big_kernel 128 x 128 tiles, v_mfma_f32_32x32x2_f32)
-in TFLOP/s against the 157.3 TFLOP/s fp32 matrix peak, per tile size (GR_PAIRWISE_TILE is read once per process: one
+in TFLOP/s against the 157.3 TFLOP/s fp32 matrix peak, (tile size chosen by the library: one
 interpreter per configuration), plus the batched SuperPointMatching launch at the configs[4] shape (64 pairs x 767 superpoints).
 The two tile sizes must return the same bits; both are checked against torch in fp64."""
 import json
@@ -59,21 +59,14 @@ def child():
 
 
 def main():
-    outs = {}
-    for tile in ("64", "128", "0"):
-        env = dict(os.environ, BP_CHILD="1", GR_PAIRWISE_TILE=tile)
-        r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)
-        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
-        if not line:
-            print("tile", tile, "FAILED", r.stderr[-600:])
-            continue
-        outs[tile] = json.loads(line[0][7:])
-        print("tile", tile if tile != "0" else "auto")
-        for k, v in outs[tile].items():
-            print("   ", k, v)
-    if "64" in outs and "128" in outs:
-        same = all(outs["64"][k]["sha"] == outs["128"][k]["sha"] for k in outs["64"])
-        print("64 x 64 and 128 x 128 tiles bit-identical:", same)
+    env = dict(os.environ, BP_CHILD="1")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    if not line:
+        print("FAILED", r.stderr[-600:])
+        return
+    for k, v in json.loads(line[0][7:]).items():
+        print("   ", k, v)
 
 
 if __name__ == "__main__":

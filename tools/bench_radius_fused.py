@@ -1,6 +1,5 @@
-"""Dev tool: the single-pass radius_search (gr_radius_search) against the two-pass path, per configuration of the fused
-kernel (GR_RADIUS_FUSED_RQ / _ROWBUF / _SLOTS are read once per process, so every configuration runs in its own
-subprocess).  8 x 200 k-point clouds, r = 0.0625, neighbor_limit 40 -- the `limited` workload of bench.py."""
+"""Dev tool: the single-pass radius_search (gr_radius_search mode 1) against the two-pass path (mode 0), each in its own
+subprocess.  8 x 200 k-point clouds, r = 0.0625, neighbor_limit 40 -- the `limited` workload of bench.py."""
 import json
 import os
 import subprocess
@@ -46,23 +45,7 @@ def child():
 
 
 def main():
-    configs = [{"BRF_MODE": "0"}]
-    if "--ablate" in sys.argv:  # cumulative time of the fused kernel's phases (radius_fused timer; totals are meaningless)
-        configs = []
-        for rq, slots in (("64", "28"),):
-            for stop in ("1", "2", "3", "4", "5", "6", "7", "0"):
-                configs.append({"GR_RADIUS_FUSED_RQ": rq, "GR_RADIUS_FUSED_SLOTS": slots, "GR_RADIUS_FUSED_STOP": stop})
-        for c in configs:
-            env = dict(os.environ, BRF_CHILD="1", **c)
-            r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)
-            line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
-            print(json.dumps(c), line[0][7:] if line else ("FAILED " + r.stderr[-400:]), flush=True)
-        return
-    for rq in ("128", "64"):
-        for rb in ("1", "0"):
-            for slots in (("28", "40") if rq == "128" else ("28", "40", "56")):
-                configs.append({"GR_RADIUS_FUSED_RQ": rq, "GR_RADIUS_FUSED_ROWBUF": rb, "GR_RADIUS_FUSED_SLOTS": slots})
-    for c in configs:
+    for c in ({"BRF_MODE": "0"}, {"BRF_MODE": "1"}):
         env = dict(os.environ, BRF_CHILD="1", **c)
         r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
