@@ -47,9 +47,9 @@ KernelTimer::~KernelTimer() {
 
 // ------------------------------------------------------------------ pinned scratch
 void* pinned_scratch(int slot, size_t bytes) {
-  constexpr int SLOTS = 8;
-  static thread_local void* buf[SLOTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  static thread_local size_t cap[SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0};
+  constexpr int SLOTS = 10;
+  static thread_local void* buf[SLOTS] = {};
+  static thread_local size_t cap[SLOTS] = {};
   if (slot < 0 || slot >= SLOTS) return nullptr;
   if (cap[slot] < bytes) {
     if (buf[slot]) (void)hipHostFree(buf[slot]);

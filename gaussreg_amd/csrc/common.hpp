@@ -87,7 +87,7 @@ int exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int rows, int
 // Pinned host scratch, one buffer per (host thread, slot), grown on demand and kept for the life of the process.  A copy
 // to or from pageable memory is staged and synchronised by the runtime; through these buffers the small uploads and
 // read-backs of the API calls are asynchronous for real.  Contract: the caller synchronises the stream before it returns
-// (slots 0-3 and 5-7: every entry point that uses them does) or guards the slot with an event it waits on before the next use
+// (slots 0-3 and 5-8: every entry point that uses them does) or guards the slot with an event it waits on before the next use
 // (slot 4, hash_order_device), so the next call on the thread finds the buffer free.
 void* pinned_scratch(int slot, size_t bytes);
 

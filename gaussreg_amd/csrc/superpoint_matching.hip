@@ -303,7 +303,8 @@ struct SpmHdr {
   int32_t k_rem;        // how many still to take inside the selected bin
   int32_t k;            // min(num_correspondences, nr * ns)
   int32_t n_cand;       // candidates gathered (score >= threshold)
-  int32_t pad[2];
+  uint32_t tau_max;     // fast path: the largest slab threshold -- no score below it can be among the k best of the pair
+  int32_t overflow;     // fast path: a slab list, the candidate buffer or the sort buffer overflowed -> dense selection
 };
 
 // single block: order-preserving compaction of the true mask entries (torch.nonzero order)
@@ -360,21 +361,14 @@ __global__ __launch_bounds__(1024) void compact_masks_kernel(const uint8_t* __re
     hdr->prefix = 0;
     hdr->k_rem = hdr->k;
     hdr->n_cand = 0;
+    hdr->tau_max = 0u;
+    hdr->overflow = 0;
   }
 }
 
 // row sums: one wave per row, lanes stride the columns, fixed-shape tree reduce
-__global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ S, int ld,
-                                                     const SpmHdr* __restrict__ hdr,
-                                                     float* __restrict__ rs, const SpmStack* __restrict__ stack,
-                                                     size_t zstride) {
-  if (stack) {
-    ld = stack[blockIdx.z].ns;
-    const size_t zo = (size_t)blockIdx.z * zstride;
-    S = z_shift(S, zo), hdr = z_shift(hdr, zo), rs = z_shift(rs, zo);
-  }
-  const int nr = hdr->nr, ns = hdr->ns;
-  const int r = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
+__device__ __forceinline__ void rowsum_body(const float* __restrict__ S, int ld, int nr, int ns, float* __restrict__ rs, int block) {
+  const int r = block * (256 / WAVE) + threadIdx.x / WAVE;
   const int lane = threadIdx.x & (WAVE - 1);
   if (r >= nr) return;
   float s = 0.f;
@@ -386,19 +380,10 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ S
 
 // column sums: a block owns 64 columns; its four waves each sum a contiguous quarter of the rows
 // (coalesced across lanes), partials combined in fixed order -> reproducible
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ S, int ld,
-                                                     const SpmHdr* __restrict__ hdr,
-                                                     float* __restrict__ cs, const SpmStack* __restrict__ stack,
-                                                     size_t zstride) {
-  __shared__ float part[4][WAVE];
-  if (stack) {
-    ld = stack[blockIdx.z].ns;
-    const size_t zo = (size_t)blockIdx.z * zstride;
-    S = z_shift(S, zo), hdr = z_shift(hdr, zo), cs = z_shift(cs, zo);
-  }
-  const int nr = hdr->nr, ns = hdr->ns;
+__device__ __forceinline__ void colsum_body(const float* __restrict__ S, int ld, int nr, int ns, float* __restrict__ cs, int block,
+                                            float (*part)[WAVE]) {
   const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
-  const int c = blockIdx.x * WAVE + lane;
+  const int c = block * WAVE + lane;
   const int per = (nr + 3) / 4;
   const int r0 = w * per, r1 = min(nr, r0 + per);
   float s = 0.f;
@@ -416,6 +401,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ S
   part[w][lane] = s;
   __syncthreads();
   if (w == 0 && c < ns) cs[c] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+}
+
+// both in ONE launch: workgroups [0, row_blocks) sum rows (four each), the rest sum columns (64 each)
+__global__ __launch_bounds__(256) void sums_kernel(const float* __restrict__ S, int ld, const SpmHdr* __restrict__ hdr,
+                                                   float* __restrict__ rs, float* __restrict__ cs, int row_blocks,
+                                                   const SpmStack* __restrict__ stack, size_t zstride) {
+  __shared__ float part[4][WAVE];
+  if (stack) {
+    ld = stack[blockIdx.z].ns;
+    const size_t zo = (size_t)blockIdx.z * zstride;
+    S = z_shift(S, zo), hdr = z_shift(hdr, zo), rs = z_shift(rs, zo), cs = z_shift(cs, zo);
+  }
+  const int nr = hdr->nr, ns = hdr->ns;
+  if ((int)blockIdx.x < row_blocks) rowsum_body(S, ld, nr, ns, rs, (int)blockIdx.x);
+  else colsum_body(S, ld, nr, ns, cs, (int)blockIdx.x - row_blocks, part);
 }
 
 // scores, dense (nr x ns) row-major: superpoint_matching.py:38-41  (S / rowsum) * (S / colsum)
@@ -549,7 +549,8 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const float* __restric
     if (sh[i]) atomicAdd(&dst[i], sh[i]);
 }
 
-constexpr int CAND_CAP = 4096;
+constexpr int CAND_CAP = 4096;   // candidates the dense path gathers (= the sort buffer of select_emit_kernel)
+constexpr int CAND_BUF = 32768;  // keys a pair's candidate buffer holds (fast path: every slab appends its list)
 
 // gather every element with score >= threshold (bit pattern in hdr->prefix) as a sortable key
 __global__ __launch_bounds__(256) void select_gather_kernel(const float* __restrict__ score,
@@ -572,6 +573,7 @@ __global__ __launch_bounds__(256) void select_gather_kernel(const float* __restr
   const int ns = hdr->ns;
   const int64_t total = (int64_t)hdr->nr * ns;
   const uint32_t thr = hdr->k > 0 ? prefix : 0xffffffffu;  // exact bit pattern of the k-th largest score
+  if (blockIdx.x == 0 && threadIdx.x == 0) hdr->prefix = thr;  // (select_gather_ordered_kernel takes it from here)
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const uint32_t u = __float_as_uint(score[e]);
     if (u >= thr) {
@@ -637,25 +639,83 @@ __global__ __launch_bounds__(1024) void select_gather_ordered_kernel(const float
   if (threadIdx.x == 0) hdr->n_cand = k;
 }
 
-// single block: sort the candidates (descending), emit the first k
-__global__ __launch_bounds__(1024) void select_emit_kernel(const SpmHdr* __restrict__ hdr,
+// single block: sort the candidates (descending), emit the first k.  Candidates whose score lies below hdr->tau_max (fast
+// path: a bound every one of the pair's k best scores reaches) are dropped first; what is left must fit the sort buffer
+constexpr int EMIT_CAP = 4096;
+__global__ __launch_bounds__(1024) void select_emit_kernel(SpmHdr* __restrict__ hdr,
                                                            const unsigned long long* __restrict__ cand,
                                                            const int32_t* __restrict__ ridx,
                                                            const int32_t* __restrict__ sidx,
                                                            int64_t* __restrict__ out_ref,
                                                            int64_t* __restrict__ out_src,
-                                                           float* __restrict__ out_score, size_t zstride, int out_stride) {
-  __shared__ unsigned long long sk[CAND_CAP];
+                                                           float* __restrict__ out_score, size_t zstride, int out_stride,
+                                                           int cand_cap) {
+  __shared__ unsigned long long sk[EMIT_CAP];
+  __shared__ int s_n;
   {  // stack mode: workgroup = pair, its outputs are row blockIdx.x of the (pairs, num_correspondences) arrays
     const size_t zo = (size_t)blockIdx.x * zstride;
     hdr = z_shift(hdr, zo), cand = z_shift(cand, zo), ridx = z_shift(ridx, zo), sidx = z_shift(sidx, zo);
     out_ref += (int64_t)blockIdx.x * out_stride, out_src += (int64_t)blockIdx.x * out_stride;
     out_score += (int64_t)blockIdx.x * out_stride;
   }
-  const int n = min(hdr->n_cand, CAND_CAP);
+  if (hdr->overflow) return;  // (uniform) the caller repeats this pair on the dense path
+  const int n_all = min(hdr->n_cand, cand_cap);
+  const int k_sel = hdr->k;
+  // Two bounds below the pair's k-th best score: hdr->tau_max (the slabs' thresholds), and -- over the candidates that reach
+  // it -- the smallest of the 16 waves' ceil(k / 16)-th largest thread maxima (16 x ceil(k / 16) >= k candidates lie at or
+  // above it).  Only candidates at or above both are sorted.
+  constexpr int PER = CAND_BUF / 1024;  // candidates per thread, at most
+  __shared__ unsigned int s_off[1024 / WAVE];
+  unsigned int floor_u = hdr->tau_max;
+  unsigned int uu[PER];
+  unsigned int umax = 0u;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int i = threadIdx.x + j * 1024;
+    uu[j] = i < n_all ? (unsigned int)(cand[i] >> 32) : 0u;
+    if (i < n_all && uu[j] >= floor_u) umax = max(umax, uu[j]);
+  }
+  {
+    unsigned int x = umax;
+    const int lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+    for (int size = 2; size <= WAVE; size <<= 1) {
+#pragma unroll
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        const unsigned int y = (unsigned int)__shfl_xor((int)x, stride, WAVE);
+        const bool lower = (lane & stride) == 0, desc = (lane & size) == 0;
+        x = (lower == desc) ? max(x, y) : min(x, y);
+      }
+    }
+    const int want = (k_sel + 1024 / WAVE - 1) / (1024 / WAVE);
+    const unsigned int offer = want >= 1 && want <= WAVE ? (unsigned int)__shfl((int)x, want - 1, WAVE) : 0u;
+    if (lane == 0) s_off[threadIdx.x / WAVE] = offer;
+  }
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  {
+    unsigned int t2 = 0xffffffffu;
+#pragma unroll
+    for (int w = 0; w < 1024 / WAVE; ++w) t2 = min(t2, s_off[w]);
+    floor_u = max(floor_u, t2);
+  }
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int i = threadIdx.x + j * 1024;
+    if (i < n_all && uu[j] >= floor_u) {
+      const int pos = atomicAdd(&s_n, 1);
+      if (pos < EMIT_CAP) sk[pos] = cand[i];
+    }
+  }
+  __syncthreads();
+  const int n = s_n;
+  if (n > EMIT_CAP || n < min(k_sel, n_all)) {  // uniform.  (Fewer than k survivors cannot happen while the bounds hold: checked anyway)
+    if (threadIdx.x == 0) hdr->overflow = 1;
+    return;
+  }
   int np2 = 2;
   while (np2 < n) np2 <<= 1;
-  for (int i = threadIdx.x; i < np2; i += 1024) sk[i] = i < n ? cand[i] : 0ull;
+  for (int i = n + threadIdx.x; i < np2; i += 1024) sk[i] = 0ull;
   __syncthreads();
   // bitonic sort, descending, over the smallest power of two that holds the candidates
   for (int size = 2; size <= np2; size <<= 1) {
@@ -673,7 +733,7 @@ __global__ __launch_bounds__(1024) void select_emit_kernel(const SpmHdr* __restr
       __syncthreads();
     }
   }
-  const int k = hdr->k, ns = hdr->ns;
+  const int k = min(hdr->k, n), ns = hdr->ns;
   for (int i = threadIdx.x; i < k; i += 1024) {
     const unsigned long long key = sk[i];
     const uint32_t e = ~(uint32_t)(key & 0xffffffffull);
@@ -681,6 +741,129 @@ __global__ __launch_bounds__(1024) void select_emit_kernel(const SpmHdr* __restr
     out_src[i] = sidx[e % (uint32_t)ns];   // :45,48
     out_score[i] = __uint_as_float((uint32_t)(key >> 32));
   }
+}
+
+// ---------------------------------------------------------------- selection, fast path
+// One launch turns the (nr, ns) matrix of exp(-d) values into a short candidate list per pair -- instead of a dense score
+// matrix written, three histogram sweeps over it and a gather sweep (five launches, ~6 passes over the matrix).  One
+// workgroup of 1024 threads per SLAB of 48 matrix rows, thread = column: its 48 scores ((s / rowsum) * (s / colsum), the
+// expression of normalize_kernel: same bits) live in registers.
+//   1. tau: every wave that holds 64 valid columns sorts its 64 thread maxima (bitonic network over the lanes) and offers
+//      its ceil(k / full waves)-th largest; the smallest offer is a score that at least k scores of THIS SLAB reach, so it
+//      is a lower bound of the pair's k-th best score;
+//   2. every score >= tau goes to an LDS list as a key (score bits << 32 | ~flat index) -- a few hundred per slab -- and the
+//      list is appended to the pair's candidates; the largest tau of the pair's slabs is kept in the header;
+//   3. select_emit_kernel drops the candidates below that largest tau (each slab's tau bounds the pair's k-th best score
+//      from below, so does their maximum), sorts the few hundred that are left and emits the first k.
+// A slab list, candidate buffer or sort buffer that overflows (thousands of equal scores: degenerate inputs) raises
+// hdr->overflow: the caller then takes the dense path below, which handles ties at any multiplicity.
+constexpr int SS_T = 1024;       // threads per slab workgroup = columns it can hold
+constexpr int SS_ROWS = 48;      // rows per slab = scores per thread (registers: 1024 threads leave 128 VGPRs each)
+constexpr int SS_LIST = 2048;    // keys the slab's list holds
+
+__global__ __launch_bounds__(SS_T) void slab_select_kernel(const float* __restrict__ S, int ld, const float* __restrict__ rs,
+                                                           const float* __restrict__ cs, int dual, SpmHdr* __restrict__ hdr,
+                                                           unsigned long long* __restrict__ cand, int cand_cap,
+                                                           const SpmStack* __restrict__ stack, size_t zstride) {
+  __shared__ unsigned long long s_key[SS_LIST];
+  __shared__ unsigned int s_tau[SS_T / WAVE];
+  __shared__ int s_cnt, s_base;
+  if (stack) {
+    ld = stack[blockIdx.z].ns;
+    const size_t zo = (size_t)blockIdx.z * zstride;
+    S = z_shift(S, zo), rs = z_shift(rs, zo), cs = z_shift(cs, zo), hdr = z_shift(hdr, zo), cand = z_shift(cand, zo);
+  }
+  const int nr = hdr->nr, ns = hdr->ns, k = hdr->k;
+  const int r0 = (int)blockIdx.x * SS_ROWS;
+  if (r0 >= nr || k <= 0) return;  // (uniform: nobody waits at a barrier)
+  const int rows = min(SS_ROWS, nr - r0);
+  const int c = threadIdx.x;
+  const bool col_ok = c < ns;
+  const int cc = col_ok ? c : 0;
+  // 16 rows at a time: their loads first (unconditional, clamped), then the arithmetic; the scores stay as bit patterns
+  // (they are >= 0: the patterns order like the values; NaN above everything, as in the dense path)
+  const float csc = dual ? cs[cc] : 1.0f;
+  unsigned int u[SS_ROWS];
+  unsigned int umax = 0u;
+#pragma unroll
+  for (int g = 0; g < SS_ROWS; g += 16) {
+    float sv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sv[i] = S[(int64_t)(r0 + min(g + i, rows - 1)) * ld + cc];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float sc = dual ? (sv[i] / rs[r0 + min(g + i, rows - 1)]) * (sv[i] / csc) : sv[i];  // superpoint_matching.py:38-41
+      u[g + i] = __float_as_uint(sc);
+      if (col_ok && g + i < rows) umax = max(umax, u[g + i]);
+    }
+  }
+  if (threadIdx.x == 0) s_cnt = 0;
+  // ---- 1. a threshold that at least k scores of the slab reach: every wave sorts its 64 thread maxima (bitonic network over
+  //      the lanes, no barrier) and offers its ceil(k / 16)-th largest; the smallest offer of the 16 waves is the threshold
+  //      (16 waves x ceil(k / 16) maxima lie at or above it)
+  {
+    unsigned int x = col_ok ? umax : 0u;
+    const int lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+    for (int size = 2; size <= WAVE; size <<= 1) {
+#pragma unroll
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        const unsigned int y = (unsigned int)__shfl_xor((int)x, stride, WAVE);
+        const bool lower = (lane & stride) == 0, desc = (lane & size) == 0;
+        x = (lower == desc) ? max(x, y) : min(x, y);  // descending runs where (lane & size) == 0
+      }
+    }
+    // only waves whose 64 columns all exist take part (the others offer "no bound"); without a full wave, or when the
+    // full waves cannot supply k maxima, the threshold is 0: every score of the slab is a candidate
+    const int nfull = ns / WAVE;
+    const int want = nfull > 0 ? (k + nfull - 1) / nfull : WAVE + 1;
+    unsigned int offer = 0xffffffffu;
+    if (want <= WAVE) {
+      const unsigned int kth = (unsigned int)__shfl((int)x, want - 1, WAVE);
+      if ((int)(threadIdx.x / WAVE) < nfull) offer = kth;
+    } else {
+      offer = 0u;
+    }
+    if (lane == 0) s_tau[threadIdx.x / WAVE] = offer;
+  }
+  __syncthreads();
+  unsigned int tau = 0xffffffffu;
+#pragma unroll
+  for (int w = 0; w < SS_T / WAVE; ++w) tau = min(tau, s_tau[w]);
+  // ---- 2. everything >= tau is a candidate of the pair
+  if (col_ok) {
+#pragma unroll
+    for (int i = 0; i < SS_ROWS; ++i) {
+      if (i < rows && u[i] >= tau) {
+        const int pos = atomicAdd(&s_cnt, 1);
+        const unsigned int e = (unsigned int)(r0 + i) * (unsigned int)ns + (unsigned int)c;  // flat index in the (nr, ns) matrix
+        if (pos < SS_LIST) s_key[pos] = ((unsigned long long)u[i] << 32) | (unsigned int)(~e);
+      }
+    }
+  }
+  __syncthreads();
+  const int n = s_cnt;
+  if (threadIdx.x == 0) {
+    int base = 0;
+    if (n <= SS_LIST) base = atomicAdd(&hdr->n_cand, n);
+    if (n > SS_LIST || base + n > cand_cap) {
+      hdr->overflow = 1;
+      base = -1;
+    } else {
+      atomicMax(&hdr->tau_max, tau);
+    }
+    s_base = base;
+  }
+  __syncthreads();
+  const int base = s_base;
+  if (base < 0) return;
+  for (int i = threadIdx.x; i < n; i += SS_T) cand[base + i] = s_key[i];
+}
+
+// can the fast path take this shape?  (columns <= threads of a slab workgroup)
+inline bool spm_fast_ok(int64_t nr, int64_t ns, int k) {
+  (void)nr;
+  return ns <= SS_T && k <= SS_T;
 }
 
 struct SpmWs {
@@ -707,7 +890,7 @@ SpmWs carve_spm(void* p, int64_t nr, int64_t ns) {
   w.rs = c.take<float>(nr);
   w.cs = c.take<float>(ns);
   w.hist = c.take<uint32_t>(3 * 2048);
-  w.cand = c.take<unsigned long long>(CAND_CAP);
+  w.cand = c.take<unsigned long long>(CAND_BUF);
   w.bytes = c.used();
   return w;
 }
@@ -787,6 +970,23 @@ extern "C" size_t gr_superpoint_matching_workspace_bytes(int64_t nr, int64_t ns)
   return carve_spm(nullptr, nr, ns).bytes;
 }
 
+// the dense selection: normalised score matrix, 3-digit radix select of the k-th largest score, gather, sort.  Shapes the slab
+// kernel does not take, and pairs whose slabs overflowed (w.hist must be zero, w.rs / w.cs and hdr->k in place).
+static void spm_select_dense(int64_t nr, int64_t ns, int num_correspondences, int dual_normalization, int64_t* out_ref_idx,
+                             int64_t* out_src_idx, float* out_scores, const SpmWs& w, hipStream_t stream,
+                             const SpmStack* stack, size_t zstride, int npairs) {
+  const unsigned z = (unsigned)npairs;
+  hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((ns + 255) / 256), (unsigned)nr, z), dim3(256), 0, stream, w.S,
+                     (int)ns, w.rs, w.cs, dual_normalization, w.hdr, w.score, stack, zstride);
+  const int sel_blocks = (int)std::min<int64_t>(stack ? 64 : 512, (nr * ns + 1023) / 1024);
+  for (int pass = 0; pass < 3; ++pass)
+    hipLaunchKernelGGL(select_hist_kernel, dim3(sel_blocks, 1, z), dim3(256), 0, stream, w.score, w.hdr, pass, w.hist, zstride);
+  hipLaunchKernelGGL(select_gather_kernel, dim3(sel_blocks, 1, z), dim3(256), 0, stream, w.score, w.hdr, w.hist, w.cand,
+                     zstride);
+  hipLaunchKernelGGL(select_emit_kernel, dim3(z), dim3(1024), 0, stream, w.hdr, w.cand, w.ridx, w.sidx, out_ref_idx,
+                     out_src_idx, out_scores, zstride, num_correspondences, CAND_CAP);
+}
+
 // the launches of one pair -- or, with `stack`, of `npairs` pairs at once (nr / ns are then the largest counts, feats / masks
 // the stacked arrays, w the first pair's workspace and zstride the distance to the next) -- asynchronous; the header
 // (counts) stays in w.hdr
@@ -796,7 +996,7 @@ static int spm_launch(const float* ref_feats, const float* src_feats, int64_t nr
                       const SpmWs& w, hipStream_t stream, const SpmStack* stack = nullptr, size_t zstride = 0,
                       int npairs = 1) {
   const unsigned z = (unsigned)npairs;
-  if (!stack) GR_HIP(hipMemsetAsync(w.hist, 0, 3 * 2048 * sizeof(uint32_t), stream));
+  if (!stack && !spm_fast_ok(nr, ns, num_correspondences)) GR_HIP(hipMemsetAsync(w.hist, 0, 3 * 2048 * sizeof(uint32_t), stream));
   hipLaunchKernelGGL(compact_masks_kernel, dim3(z), dim3(1024), 0, stream, ref_masks, (int)nr, src_masks, (int)ns,
                      num_correspondences, w.ridx, w.sidx, w.hdr, w.hist, stack, zstride);
   // features are L2-normalised by the caller (model.py:143-144): d = 2 - 2 xy  (superpoint_matching.py:37)
@@ -818,20 +1018,20 @@ static int spm_launch(const float* ref_feats, const float* src_feats, int64_t nr
     }
   }
   if (dual_normalization) {
-    hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)((nr + 3) / 4), 1, z), dim3(256), 0, stream, w.S, (int)ns, w.hdr, w.rs,
-                       stack, zstride);
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((ns + WAVE - 1) / WAVE), 1, z), dim3(256), 0, stream, w.S, (int)ns,
-                       w.hdr, w.cs, stack, zstride);
+    const unsigned row_blocks = (unsigned)((nr + 3) / 4), col_blocks = (unsigned)((ns + WAVE - 1) / WAVE);
+    hipLaunchKernelGGL(sums_kernel, dim3(row_blocks + col_blocks, 1, z), dim3(256), 0, stream, w.S, (int)ns, w.hdr, w.rs, w.cs,
+                       (int)row_blocks, stack, zstride);
   }
-  hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((ns + 255) / 256), (unsigned)nr, z), dim3(256), 0, stream, w.S,
-                     (int)ns, w.rs, w.cs, dual_normalization, w.hdr, w.score, stack, zstride);
-  const int sel_blocks = (int)std::min<int64_t>(stack ? 64 : 512, (nr * ns + 1023) / 1024);
-  for (int pass = 0; pass < 3; ++pass)
-    hipLaunchKernelGGL(select_hist_kernel, dim3(sel_blocks, 1, z), dim3(256), 0, stream, w.score, w.hdr, pass, w.hist, zstride);
-  hipLaunchKernelGGL(select_gather_kernel, dim3(sel_blocks, 1, z), dim3(256), 0, stream, w.score, w.hdr, w.hist, w.cand,
-                     zstride);
-  hipLaunchKernelGGL(select_emit_kernel, dim3(z), dim3(1024), 0, stream, w.hdr, w.cand, w.ridx, w.sidx, out_ref_idx,
-                     out_src_idx, out_scores, zstride, num_correspondences);
+  if (spm_fast_ok(nr, ns, num_correspondences)) {
+    // the k best of every 64-row slab -> the pair's candidates (no dense score matrix, no histogram sweeps)
+    hipLaunchKernelGGL(slab_select_kernel, dim3((unsigned)((nr + SS_ROWS - 1) / SS_ROWS), 1, z), dim3(SS_T), 0, stream, w.S,
+                       (int)ns, w.rs, w.cs, dual_normalization, w.hdr, w.cand, CAND_BUF, stack, zstride);
+    hipLaunchKernelGGL(select_emit_kernel, dim3(z), dim3(1024), 0, stream, w.hdr, w.cand, w.ridx, w.sidx, out_ref_idx,
+                       out_src_idx, out_scores, zstride, num_correspondences, CAND_BUF);
+  } else {
+    spm_select_dense(nr, ns, num_correspondences, dual_normalization, out_ref_idx, out_src_idx, out_scores, w, stream, stack,
+                     zstride, npairs);
+  }
   GR_LAUNCH_CHECK();
   return GR_OK;
 }
@@ -863,14 +1063,29 @@ extern "C" int gr_superpoint_matching(const float* ref_feats, const float* src_f
   rc = spm_launch(ref_feats, src_feats, nr, ns, c, ref_masks, src_masks, num_correspondences, dual_normalization,
                   out_ref_idx, out_src_idx, out_scores, w, stream);
   if (rc != GR_OK) return rc;
-  SpmHdr h;
+  // (the header comes back through pinned memory: a copy into pageable memory is staged by the runtime, ~20 us of a 0.1 ms call)
+  SpmHdr* hp = static_cast<SpmHdr*>(pinned_scratch(8, sizeof(SpmHdr)));
+  GR_REQUIRE(hp != nullptr, "pinned read-back buffer could not be allocated");
+  SpmHdr& h = *hp;
   GR_HIP(hipMemcpyAsync(&h, w.hdr, sizeof(h), hipMemcpyDeviceToHost, stream));
   GR_HIP(hipStreamSynchronize(stream));
-  if (h.n_cand > CAND_CAP) {
+  bool dense = !spm_fast_ok(nr, ns, num_correspondences);
+  if (!dense && h.overflow) {
+    dense = true;
+    // fast path: a slab list, the candidate buffer or the sort buffer overflowed (thousands of scores at a threshold): the
+    // dense selection for this pair (counters and histograms cleared first)
+    GR_HIP(hipMemsetAsync(&w.hdr->n_cand, 0, 3 * sizeof(int32_t), stream));  // n_cand, tau_max, overflow
+    GR_HIP(hipMemsetAsync(w.hist, 0, 3 * 2048 * sizeof(uint32_t), stream));
+    spm_select_dense(nr, ns, num_correspondences, dual_normalization, out_ref_idx, out_src_idx, out_scores, w, stream, nullptr, 0, 1);
+    GR_LAUNCH_CHECK();
+    GR_HIP(hipMemcpyAsync(&h, w.hdr, sizeof(h), hipMemcpyDeviceToHost, stream));
+    GR_HIP(hipStreamSynchronize(stream));
+  }
+  if (dense && h.n_cand > CAND_CAP) {
     // more ties at the threshold than the candidate buffer holds: redo the gather in flat-index order (see above)
     hipLaunchKernelGGL(select_gather_ordered_kernel, dim3(1), dim3(1024), 0, stream, w.score, w.hdr, w.cand);
     hipLaunchKernelGGL(select_emit_kernel, dim3(1), dim3(1024), 0, stream, w.hdr, w.cand, w.ridx, w.sidx, out_ref_idx,
-                       out_src_idx, out_scores, (size_t)0, 0);
+                       out_src_idx, out_scores, (size_t)0, 0, CAND_CAP);
     GR_LAUNCH_CHECK();
     GR_HIP(hipStreamSynchronize(stream));
   }
@@ -881,7 +1096,7 @@ extern "C" int gr_superpoint_matching(const float* ref_feats, const float* src_f
 // Stack mode over `npairs` scene pairs (test.py:146-212 runs model.py:156-160 once per pair): the superpoint features of the
 // batch are stacked as [ref_0, src_0, ref_1, src_1, ...] with h_node_off (2 npairs + 1 offsets), masks likewise (null =
 // all true).  Pair b's matches go to row b of the (npairs, num_correspondences) outputs; h_num_out[b] = how many are valid.
-// ONE set of twelve launches for the whole batch (grid.z = pair; every pair owns an equally laid out slice of the
+// ONE set of five launches for the whole batch (grid.z = pair; every pair owns an equally laid out slice of the
 // workspace, sized for the largest pair), the pairs' headers read back ONCE.  (A pair with more ties at the selection
 // threshold than the candidate buffer holds is redone through the single-pair path afterwards.)
 static void spm_max_sizes(const int64_t* h_node_off, int64_t npairs, int64_t* max_nr, int64_t* max_ns) {
@@ -943,15 +1158,16 @@ extern "C" int gr_superpoint_matching_batch(const float* feats, const int64_t* h
   rc = spm_launch(feats, feats, mr, ms, c, masks, masks, num_correspondences, dual_normalization, out_ref_idx, out_src_idx,
                   out_scores, w, stream, d_stack, pair_bytes, (int)npairs);
   if (rc != GR_OK) return rc;
-  std::vector<SpmHdr> h(npairs);
-  GR_HIP(hipMemcpy2DAsync(h.data(), sizeof(SpmHdr), w.hdr, pair_bytes, sizeof(SpmHdr), (size_t)npairs, hipMemcpyDeviceToHost,
-                          stream));
+  SpmHdr* hb = static_cast<SpmHdr*>(pinned_scratch(8, sizeof(SpmHdr) * (size_t)npairs));
+  GR_REQUIRE(hb != nullptr, "pinned read-back buffer could not be allocated");
+  GR_HIP(hipMemcpy2DAsync(hb, sizeof(SpmHdr), w.hdr, pair_bytes, sizeof(SpmHdr), (size_t)npairs, hipMemcpyDeviceToHost, stream));
   GR_HIP(hipStreamSynchronize(stream));
+  const std::vector<SpmHdr> h(hb, hb + npairs);  // (a pair redone below goes through the single-pair entry, which reuses the slot)
   for (int64_t b = 0; b < npairs; ++b) {
     const int64_t r0 = h_node_off[2 * b], nr = h_node_off[2 * b + 1] - r0, s0 = h_node_off[2 * b + 1],
                   ns = h_node_off[2 * b + 2] - s0;
     if (nr == 0 || ns == 0) continue;  // (its header says k = 0 as well)
-    if (h[b].n_cand > CAND_CAP) {
+    if (spm_fast_ok(mr, ms, num_correspondences) ? h[b].overflow != 0 : h[b].n_cand > CAND_CAP) {
       rc = gr_superpoint_matching(feats + r0 * c, feats + s0 * c, nr, ns, c, masks ? masks + r0 : nullptr,
                                   masks ? masks + s0 : nullptr, num_correspondences, dual_normalization,
                                   out_ref_idx + b * num_correspondences, out_src_idx + b * num_correspondences,

@@ -206,6 +206,11 @@ def test_superpoint_matching_more_ties_than_the_candidate_buffer():
     g, h = torch.nn.functional.normalize(g, dim=1), torch.nn.functional.normalize(h, dim=1)
     ri, si, sc = SuperPointMatching(64, False)(g, h)
     assert ri.shape == (64,) and bool((sc[:-1] >= sc[1:]).all())
+    # exactly torch.topk's set under (score descending, flat index ascending): the tie value is shared by 89 x 89 entries
+    # (more than the candidate buffer holds: the flat-index-ordered gather), row / column 5 score differently
+    S = torch.exp(-(2.0 - 2.0 * g.double() @ h.double().T).clamp(min=0)).flatten()
+    order = sorted(range(S.numel()), key=lambda e: (-round(float(S[e]), 9), e))[:64]
+    assert (ri * 90 + si).tolist() == order
 
 
 @pytest.mark.parametrize("n,m", [(65, 65), (1, 1), (767, 701), (64, 129)])
