@@ -177,7 +177,13 @@ __global__ __launch_bounds__(256) void cells_kernel(
     int32_t* __restrict__ fo_flags) {
   __shared__ float s_x[256], s_y[256], s_z[256];
   __shared__ int s_head[256];
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  // XCD-aware block order (block b runs on XCD b % 8): every XCD gets one contiguous eighth of the sorted positions, i.e. its
+  // own clouds.  The gather below reads a cloud's points at random: in launch order all eight L2s fetched every cloud
+  // (measured: 1.2 GB of fetches for 154 MB of points at 64 x 200 k); now each cloud is fetched by one L2.
+  const int per_xcd = gridDim.x / 8;  // the grid is padded to a multiple of 8 blocks
+  const int blk = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8;
+  if ((int64_t)blk * 256 >= n) return;  // (block-uniform)
+  const int t = blk * 256 + threadIdx.x;
   const int tc = min(t, n - 1);
   const int64_t mine = vals[tc];
   const int h = t < n ? head[tc] : 1;  // positions past the end close the last run
@@ -216,9 +222,10 @@ __global__ __launch_bounds__(256) void cells_kernel(
   bary[3 * (int64_t)cell + 2] = sz * wgt;
   const int first = (int)mine;
   first_idx[cell] = first;
-  const int b = find_batch(off, nb, first);
-  cell_batch[cell] = b;
   const unsigned long long k = keys[t];
+  // composite keys carry the cloud in their high bits: no search through the offsets (six dependent loads per head thread)
+  const int b = key_bits < 64 ? (int)(k >> key_bits) : find_batch(off, nb, first);
+  cell_batch[cell] = b;
   cell_key[cell] = key_bits < 64 ? (k & ((1ull << key_bits) - 1ull)) : k;
   if (fo_flags) fo_flags[first] = 1;  // (reference order only)
 }
@@ -255,7 +262,9 @@ __global__ __launch_bounds__(256) void fo_rank_kernel(const int32_t* __restrict_
                                                       const int32_t* __restrict__ fo_scan, int m,
                                                       int32_t* __restrict__ cell_of_rank,
                                                       uint64_t* __restrict__ keys_fo) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  // (XCD-aware block order as in cells_kernel: the reads and writes below are random inside one cloud)
+  const int per_xcd = gridDim.x / 8;
+  const int c = (((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8) * 256 + threadIdx.x;
   if (c >= m) return;
   const int r = fo_scan[first_idx[c]];
   cell_of_rank[r] = c;
@@ -421,7 +430,7 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
   if (rc != GR_OK) return rc;
   int32_t* fo_flags = order_mode == GR_ORDER_CELL ? nullptr : w.flags;  // zeroed by keys_kernel
   // cell order: the barycentres ARE the output rows (cell = rank of the voxel key), written in place
-  hipLaunchKernelGGL(cells_kernel, grd, blk, 0, stream, points, keys_sorted, vals_sorted, head, head_scan, (int)n,
+  hipLaunchKernelGGL(cells_kernel, dim3((grd.x + 7) / 8 * 8), blk, 0, stream, points, keys_sorted, vals_sorted, head, head_scan, (int)n,
                      w.off, nb, composite ? key_bits : 64, order_mode == GR_ORDER_CELL ? out_points : w.bary, w.first_idx,
                      w.cell_key, w.cell_batch, fo_flags);
   int32_t* mail_counts = mail ? const_cast<int32_t*>(mail) + MAIL_GRID_COUNTS : nullptr;  // (nb <= 80: one workgroup)
@@ -454,7 +463,7 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
     if (rc != GR_OK) return rc;
     h_m = h_mb[batch];
     if (h_m > 0) {
-      hipLaunchKernelGGL(fo_rank_kernel, dim3((unsigned)((h_m + 255) / 256)), blk, 0, stream, w.first_idx, w.cell_key,
+      hipLaunchKernelGGL(fo_rank_kernel, dim3((unsigned)(((h_m + 255) / 256 + 7) / 8 * 8)), blk, 0, stream, w.first_idx, w.cell_key,
                          fo_scan, h_m, w.cell_of_rank, w.keys_fo);
       GR_LAUNCH_CHECK();
       // The reference inserts keys in first-occurrence order into an unordered_map and emits in its iteration order
