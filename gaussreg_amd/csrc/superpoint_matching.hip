@@ -746,8 +746,8 @@ __global__ __launch_bounds__(1024) void select_emit_kernel(SpmHdr* __restrict__ 
 // ---------------------------------------------------------------- selection, fast path
 // One launch turns the (nr, ns) matrix of exp(-d) values into a short candidate list per pair -- instead of a dense score
 // matrix written, three histogram sweeps over it and a gather sweep (five launches, ~6 passes over the matrix).  One
-// workgroup of 1024 threads per SLAB of 48 matrix rows, thread = column: its 48 scores ((s / rowsum) * (s / colsum), the
-// expression of normalize_kernel: same bits) live in registers.
+// workgroup of 1024 threads per SLAB of 48 matrix rows, thread = column: its 48 scores live in registers (priced with
+// reciprocals first; the exact (s / rowsum) * (s / colsum) of normalize_kernel -- same bits -- for the listed entries only).
 //   1. tau: every wave that holds 64 valid columns sorts its 64 thread maxima (bitonic network over the lanes) and offers
 //      its ceil(k / full waves)-th largest; the smallest offer is a score that at least k scores of THIS SLAB reach, so it
 //      is a lower bound of the pair's k-th best score;
@@ -760,14 +760,17 @@ __global__ __launch_bounds__(1024) void select_emit_kernel(SpmHdr* __restrict__ 
 constexpr int SS_T = 1024;       // threads per slab workgroup = columns it can hold
 constexpr int SS_ROWS = 48;      // rows per slab = scores per thread (registers: 1024 threads leave 128 VGPRs each)
 constexpr int SS_LIST = 2048;    // keys the slab's list holds
+constexpr int SS_CODES = 4096;   // entries whose exact score is computed (listed by their approximate score)
 
 __global__ __launch_bounds__(SS_T) void slab_select_kernel(const float* __restrict__ S, int ld, const float* __restrict__ rs,
                                                            const float* __restrict__ cs, int dual, SpmHdr* __restrict__ hdr,
                                                            unsigned long long* __restrict__ cand, int cand_cap,
                                                            const SpmStack* __restrict__ stack, size_t zstride) {
   __shared__ unsigned long long s_key[SS_LIST];
+  __shared__ unsigned short s_code[SS_CODES];
+  __shared__ float s_rr[SS_ROWS];
   __shared__ unsigned int s_tau[SS_T / WAVE];
-  __shared__ int s_cnt, s_base;
+  __shared__ int s_cnt, s_ncode, s_base;
   if (stack) {
     ld = stack[blockIdx.z].ns;
     const size_t zo = (size_t)blockIdx.z * zstride;
@@ -780,10 +783,18 @@ __global__ __launch_bounds__(SS_T) void slab_select_kernel(const float* __restri
   const int c = threadIdx.x;
   const bool col_ok = c < ns;
   const int cc = col_ok ? c : 0;
-  // 16 rows at a time: their loads first (unconditional, clamped), then the arithmetic; the scores stay as bit patterns
-  // (they are >= 0: the patterns order like the values; NaN above everything, as in the dense path)
-  const float csc = dual ? cs[cc] : 1.0f;
-  unsigned int u[SS_ROWS];
+  // The exact score (two IEEE divisions per entry: 22 instructions) is only needed for the few hundred entries that can be
+  // among the k best.  Everything is first priced with reciprocals: a = (s * rcp(rowsum)) * (s * rcp(colsum)), within
+  // EPS = 2e-6 relative of the exact value (v_rcp_f32 is good to 1 ulp, three roundings follow: < 5e-7 in all).  A bound
+  // tau_a that k approximate scores reach gives the exact bound tau = tau_a (1 - 2 EPS); entries whose approximate score
+  // reaches tau_a (1 - 4 EPS) -- a superset of the entries whose exact score reaches tau -- are listed, and the exact score
+  // is computed for the list only.  (An approximate score that is not a number lists its entry.)
+  constexpr float EPS = 2.0e-6f;
+  if (threadIdx.x < SS_ROWS) s_rr[threadIdx.x] = dual ? __builtin_amdgcn_rcpf(rs[r0 + min((int)threadIdx.x, rows - 1)]) : 1.0f;
+  if (threadIdx.x == 0) s_cnt = 0, s_ncode = 0;
+  const float rcs = dual ? __builtin_amdgcn_rcpf(cs[cc]) : 1.0f;
+  __syncthreads();
+  unsigned int u[SS_ROWS];  // approximate scores as bit patterns (>= 0: the patterns order like the values)
   unsigned int umax = 0u;
 #pragma unroll
   for (int g = 0; g < SS_ROWS; g += 16) {
@@ -792,15 +803,14 @@ __global__ __launch_bounds__(SS_T) void slab_select_kernel(const float* __restri
     for (int i = 0; i < 16; ++i) sv[i] = S[(int64_t)(r0 + min(g + i, rows - 1)) * ld + cc];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const float sc = dual ? (sv[i] / rs[r0 + min(g + i, rows - 1)]) * (sv[i] / csc) : sv[i];  // superpoint_matching.py:38-41
-      u[g + i] = __float_as_uint(sc);
-      if (col_ok && g + i < rows) umax = max(umax, u[g + i]);
+      const float ap = dual ? (sv[i] * s_rr[g + i]) * (sv[i] * rcs) : sv[i];
+      u[g + i] = __float_as_uint(ap);
+      if (col_ok && g + i < rows) umax = max(umax, u[g + i]);  // (a NaN pattern sorts above every number)
     }
   }
-  if (threadIdx.x == 0) s_cnt = 0;
-  // ---- 1. a threshold that at least k scores of the slab reach: every wave sorts its 64 thread maxima (bitonic network over
-  //      the lanes, no barrier) and offers its ceil(k / 16)-th largest; the smallest offer of the 16 waves is the threshold
-  //      (16 waves x ceil(k / 16) maxima lie at or above it)
+  // ---- 1. a threshold that at least k (approximate) scores of the slab reach: every wave sorts its 64 thread maxima
+  //      (bitonic network over the lanes, no barrier) and offers its ceil(k / full waves)-th largest; the smallest offer is
+  //      the threshold
   {
     unsigned int x = col_ok ? umax : 0u;
     const int lane = threadIdx.x & (WAVE - 1);
@@ -827,26 +837,45 @@ __global__ __launch_bounds__(SS_T) void slab_select_kernel(const float* __restri
     if (lane == 0) s_tau[threadIdx.x / WAVE] = offer;
   }
   __syncthreads();
-  unsigned int tau = 0xffffffffu;
+  unsigned int tau_a = 0xffffffffu;
 #pragma unroll
-  for (int w = 0; w < SS_T / WAVE; ++w) tau = min(tau, s_tau[w]);
-  // ---- 2. everything >= tau is a candidate of the pair
+  for (int w = 0; w < SS_T / WAVE; ++w) tau_a = min(tau_a, s_tau[w]);
+  // the bounds in the exact domain / for the listing (a threshold that is not a finite number bounds nothing)
+  const float taf = __uint_as_float(tau_a);
+  const bool tau_ok = taf == taf && taf < INFINITY;
+  const unsigned int tau = tau_ok ? __float_as_uint(taf * (1.0f - 2.0f * EPS)) : 0u;
+  const float list_from = tau_ok ? taf * (1.0f - 4.0f * EPS) : 0.0f;
+  // ---- 2a. list the entries that may reach tau: (row in slab, column) codes
   if (col_ok) {
 #pragma unroll
     for (int i = 0; i < SS_ROWS; ++i) {
-      if (i < rows && u[i] >= tau) {
-        const int pos = atomicAdd(&s_cnt, 1);
-        const unsigned int e = (unsigned int)(r0 + i) * (unsigned int)ns + (unsigned int)c;  // flat index in the (nr, ns) matrix
-        if (pos < SS_LIST) s_key[pos] = ((unsigned long long)u[i] << 32) | (unsigned int)(~e);
+      if (i < rows && !(__uint_as_float(u[i]) < list_from)) {
+        const int pos = atomicAdd(&s_ncode, 1);
+        if (pos < SS_CODES) s_code[pos] = (unsigned short)(i * SS_T + c);
       }
+    }
+  }
+  __syncthreads();
+  const int ncode = s_ncode;
+  // ---- 2b. the exact score of the listed entries (superpoint_matching.py:38-41: (s / rowsum) * (s / colsum)); those that reach
+  //      tau are candidates of the pair
+  for (int q = threadIdx.x; q < min(ncode, SS_CODES); q += SS_T) {
+    const int code = s_code[q], i = code / SS_T, cq = code % SS_T;
+    const float sq = S[(int64_t)(r0 + i) * ld + cq];
+    const float ex = dual ? (sq / rs[r0 + i]) * (sq / cs[cq]) : sq;
+    const unsigned int ue = __float_as_uint(ex);
+    if (ue >= tau) {
+      const int pos = atomicAdd(&s_cnt, 1);
+      const unsigned int e = (unsigned int)(r0 + i) * (unsigned int)ns + (unsigned int)cq;  // flat index in the (nr, ns) matrix
+      if (pos < SS_LIST) s_key[pos] = ((unsigned long long)ue << 32) | (unsigned int)(~e);
     }
   }
   __syncthreads();
   const int n = s_cnt;
   if (threadIdx.x == 0) {
     int base = 0;
-    if (n <= SS_LIST) base = atomicAdd(&hdr->n_cand, n);
-    if (n > SS_LIST || base + n > cand_cap) {
+    if (n <= SS_LIST && ncode <= SS_CODES) base = atomicAdd(&hdr->n_cand, n);
+    if (n > SS_LIST || ncode > SS_CODES || base + n > cand_cap) {
       hdr->overflow = 1;
       base = -1;
     } else {
