@@ -233,3 +233,27 @@ def test_pairwise_distance_c_entry_with_the_header_workspace_rule(n, m):
     rc = L.gr_pairwise_distance(_lib.ptr(x), _lib.ptr(y), n, m, 48, 0, _lib.ptr(out), _lib.ptr(ws), nbytes - 1,
                                 _lib.stream_ptr(x.device))
     assert rc == -3  # GR_ERR_WORKSPACE (include/gaussreg_hip.h)
+
+
+@pytest.mark.parametrize("nr,ns,k", [(300, 1024, 256), (300, 1025, 256), (2500, 700, 256), (130, 640, 1000), (97, 64, 40), (50, 63, 40)])
+def test_superpoint_matching_fast_and_dense_path_boundaries(nr, ns, k):
+    """The slab selection takes matrices of at most 1024 columns and k <= 1024 (one column per thread; the full waves must be
+    able to supply k thread maxima), everything else the dense radix select; 2 500 rows = 53 slabs appending to one candidate
+    buffer; 63 / 64 columns = no / one full wave; k = 1000 with 10 full waves = 100 maxima per wave asked of 64 (threshold 0,
+    every score listed -> overflow -> dense path).  Against a float64 evaluation of superpoint_matching.py:32-48."""
+    from gaussreg_amd.matching import SuperPointMatching
+    g = torch.Generator(device="cuda").manual_seed(nr * 7 + ns)
+    fr = torch.nn.functional.normalize(torch.randn(nr, 64, device="cuda", generator=g), dim=1)
+    fs = torch.nn.functional.normalize(torch.randn(ns, 64, device="cuda", generator=g), dim=1)
+    # a planted set of near-duplicates so that the best scores stand clear of the rest
+    nm = min(nr, ns, 300)
+    fs[:nm] = torch.nn.functional.normalize(fr[:nm] + 0.25 * torch.randn(nm, 64, device="cuda", generator=g), dim=1)
+    ri, si, sc = SuperPointMatching(k, True)(fr, fs)
+    S = torch.exp(-(2.0 - 2.0 * fr.double() @ fs.double().T).clamp(min=0))
+    score = (S / S.sum(1, keepdim=True)) * (S / S.sum(0, keepdim=True))
+    kk = min(k, nr * ns)
+    w = torch.topk(score.flatten(), kk)
+    assert ri.shape == (kk,) and bool((sc[:-1] >= sc[1:]).all())
+    np.testing.assert_allclose(sc.cpu().numpy(), w.values.cpu().numpy(), rtol=2e-5)
+    got, want = set((ri * ns + si).tolist()), set(w.indices.tolist())
+    assert len(got ^ want) <= 4  # the k-th boundary may flip inside the fp32 noise

@@ -171,3 +171,35 @@ def test_batched_calls_in_flight_equal_the_serial_calls(monkeypatch):
     for i, (img, radii, nr) in enumerate(got):
         w = want[i % 3]
         assert torch.equal(img, w[0]) and torch.equal(radii, w[1]) and nr == w[2], i
+
+
+def test_pipe_is_opt_in_per_call_and_default_calls_do_not_touch_it(monkeypatch):
+    """Without GR_RASTER_PIPELINE and without static_scene=True no internal stream is used and no input is kept alive; the
+    per-call argument (GaussianRasterizer(..., static_scene=True) / rasterize_views(static_scene=True)) switches it on and
+    GR_RASTER_PIPELINE=0 wins over the argument.  Every variant renders the same bits."""
+    import gc, weakref
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gaussreg_amd import rasterizer
+    monkeypatch.delenv("GR_RASTER_PIPELINE", raising=False)
+    rasterizer.reset_frame_pipe()
+    t, rast = _setup(seed=21)
+    want = [tuple(x.clone() for x in _render(r, t)) for r in rast]
+    torch.cuda.synchronize()
+    scene = {k: v.clone() for k, v in t.items()}
+    ref = weakref.ref(scene["means3D"])
+    a = _render(rast[0], scene)[0]
+    del scene
+    gc.collect()
+    assert ref() is None                      # default call: nothing kept
+    assert torch.equal(a, want[0][0])
+    piped = [GaussianRasterizer(r.raster_settings, static_scene=True) for r in rast]
+    got = [_render(piped[i % 3], t) for i in range(9)]
+    for i, (img, radii) in enumerate(got):
+        assert torch.equal(img, want[i % 3][0]) and torch.equal(radii, want[i % 3][1]), i
+    table = getattr(rasterizer._pipes, "table", None)
+    assert table and any(p.keep is not None for p in table.values())   # the opt-in calls did go through the pipe
+    rasterizer.reset_frame_pipe()
+    monkeypatch.setenv("GR_RASTER_PIPELINE", "0")
+    b = _render(piped[1], t)[0]
+    assert torch.equal(b, want[1][0])
+    assert all(p.keep is None for p in rasterizer._pipes.table.values())  # "0" wins: the pipe stayed untouched
