@@ -1509,449 +1509,6 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
   }
 }
 
-// ---------------------------------------------------------------- thread per query (round 5), gr_radius_search mode 2
-// Every design above splits a query over three threads for the tests and re-maps to one thread per HIT for the keys and the
-// ranking: decode, key and ranking phases are 60 % of their instructions.  Here ONE THREAD OWNS A QUERY from the first test
-// to its finished row, a workgroup is ONE WAVE of 64 neighbouring (cell-ordered) queries, and nothing is ranked:
-//   set-up, staging  as above (nine bands per thread instead of three; the band extents are wave reductions, no LDS)
-//   tests            the thread walks its nine candidate ranges out of the LDS planes, four candidates per step with packed
-//                    math; a hit appends its 16-bit plane position to the thread's list (slot-major in LDS: lane l, entry i
-//                    at [i][l] -- conflict-free)
-//   keys             the first 32 list entries -> 32 register pairs (distance bits << 32 | index), distances recomputed from
-//                    the planes with the same arithmetic (same bits)
-//   sort             Batcher's odd-even merge network on the 32 pairs (191 compare-exchanges in registers): every lane a
-//                    different query, no divergence, no LDS; the words' order IS the reference's (distance, then index)
-//   rows             sorted indices -> LDS row buffer (in the planes' place) -> contiguous 16-byte stores
-// A query with more than 32 hits (0.6 % at 20 expected neighbours) is finished by the whole wave afterwards: lanes = its
-// candidates, hits compacted by ballot, ranked by counting over a small key scratch.  More than TQ_BIG such queries in a
-// workgroup, more than TQ_BKEYS hits in one of them, or candidate ranges that do not fit the planes raise the block's flag:
-// the caller repeats the call on count + fill.
-constexpr int TQ_RQ = WAVE;       // queries per workgroup = one wave
-constexpr int TQ_NET = 32;        // hits the sorting network takes
-constexpr int TQ_NET_CE = 191;
-constexpr int TQ_BIG = 16;        // queries with more hits than the network a workgroup finishes itself
-constexpr int TQ_BKEYS = 256;     // hits of such a query
-constexpr int TQ_STAGE_CAP = 12 * TQ_RQ;
-static constexpr unsigned char TQ_PAIRS[TQ_NET_CE][2] = {
-    {0, 1}, {2, 3}, {0, 2}, {1, 3}, {1, 2}, {4, 5}, {6, 7}, {4, 6}, {5, 7}, {5, 6}, {0, 4}, {2, 6},
-    {2, 4}, {1, 5}, {3, 7}, {3, 5}, {1, 2}, {3, 4}, {5, 6}, {8, 9}, {10, 11}, {8, 10}, {9, 11}, {9, 10},
-    {12, 13}, {14, 15}, {12, 14}, {13, 15}, {13, 14}, {8, 12}, {10, 14}, {10, 12}, {9, 13}, {11, 15}, {11, 13}, {9, 10},
-    {11, 12}, {13, 14}, {0, 8}, {4, 12}, {4, 8}, {2, 10}, {6, 14}, {6, 10}, {2, 4}, {6, 8}, {10, 12}, {1, 9},
-    {5, 13}, {5, 9}, {3, 11}, {7, 15}, {7, 11}, {3, 5}, {7, 9}, {11, 13}, {1, 2}, {3, 4}, {5, 6}, {7, 8},
-    {9, 10}, {11, 12}, {13, 14}, {16, 17}, {18, 19}, {16, 18}, {17, 19}, {17, 18}, {20, 21}, {22, 23}, {20, 22}, {21, 23},
-    {21, 22}, {16, 20}, {18, 22}, {18, 20}, {17, 21}, {19, 23}, {19, 21}, {17, 18}, {19, 20}, {21, 22}, {24, 25}, {26, 27},
-    {24, 26}, {25, 27}, {25, 26}, {28, 29}, {30, 31}, {28, 30}, {29, 31}, {29, 30}, {24, 28}, {26, 30}, {26, 28}, {25, 29},
-    {27, 31}, {27, 29}, {25, 26}, {27, 28}, {29, 30}, {16, 24}, {20, 28}, {20, 24}, {18, 26}, {22, 30}, {22, 26}, {18, 20},
-    {22, 24}, {26, 28}, {17, 25}, {21, 29}, {21, 25}, {19, 27}, {23, 31}, {23, 27}, {19, 21}, {23, 25}, {27, 29}, {17, 18},
-    {19, 20}, {21, 22}, {23, 24}, {25, 26}, {27, 28}, {29, 30}, {0, 16}, {8, 24}, {8, 16}, {4, 20}, {12, 28}, {12, 20},
-    {4, 8}, {12, 16}, {20, 24}, {2, 18}, {10, 26}, {10, 18}, {6, 22}, {14, 30}, {14, 22}, {6, 10}, {14, 18}, {22, 26},
-    {2, 4}, {6, 8}, {10, 12}, {14, 16}, {18, 20}, {22, 24}, {26, 28}, {1, 17}, {9, 25}, {9, 17}, {5, 21}, {13, 29},
-    {13, 21}, {5, 9}, {13, 17}, {21, 25}, {3, 19}, {11, 27}, {11, 19}, {7, 23}, {15, 31}, {15, 23}, {7, 11}, {15, 19},
-    {23, 27}, {3, 5}, {7, 9}, {11, 13}, {15, 17}, {19, 21}, {23, 25}, {27, 29}, {1, 2}, {3, 4}, {5, 6}, {7, 8},
-    {9, 10}, {11, 12}, {13, 14}, {15, 16}, {17, 18}, {19, 20}, {21, 22}, {23, 24}, {25, 26}, {27, 28}, {29, 30}
-};
-
-struct TqLds {
-  static constexpr int TABLE_MAX = 256;
-  // ints: orig[64] qcnt[64] bigq[TQ_BIG] misc[4]
-  static constexpr size_t QBUF_OFF = (size_t)((2 * TQ_RQ + TQ_BIG + 4) * 4 + 15) / 16 * 16;
-  static constexpr size_t BRNG_OFF = QBUF_OFF + (size_t)TQ_RQ * 16;           // [TQ_BIG][18] staged ranges of the big queries
-  static constexpr size_t LIST_OFF = BRNG_OFF + (size_t)TQ_BIG * 18 * 4;      // [TQ_NET][64] u16 plane positions
-  static constexpr size_t TRNG_OFF = LIST_OFF + (size_t)(TQ_NET + 1) * TQ_RQ * 2;  // [18][64] u16 the thread's non-empty ranges
-  static constexpr size_t BKEY_OFF = TRNG_OFF + (size_t)18 * TQ_RQ * 2;       // [TQ_BKEYS] keys of the big query at hand
-  static constexpr size_t BROW_OFF = BKEY_OFF + (size_t)TQ_BKEYS * 8;         // [TQ_BIG][width] rows of the big queries
-  static size_t region_off(int width) { return (BROW_OFF + (size_t)TQ_BIG * width * 4 + 15) / 16 * 16; }
-  static size_t tables_bytes(int tcap) { return tcap > 0 ? ((size_t)(tcap + 1) * 4 + 15) / 16 * 16 + (size_t)tcap * sizeof(BatchGrid) : 0; }
-  static size_t region_bytes(int width, int tcap) {  // planes | row buffer | per-cloud tables of the set-up
-    size_t b = (size_t)TQ_STAGE_CAP * 16 + 16;
-    b = std::max(b, ((size_t)TQ_RQ * width * 4 + 15) / 16 * 16);
-    return std::max(b, tables_bytes(tcap));
-  }
-  static size_t total(int width, int tcap) { return region_off(width) + region_bytes(width, tcap); }
-};
-
-__global__ __launch_bounds__(TQ_RQ) void tq_kernel(
-    const float4* __restrict__ sorted_q, int nq, const int32_t* __restrict__ q_off, int nb,
-    const BatchGrid* __restrict__ grids, const int32_t* __restrict__ start_s, const float4* __restrict__ sorted_s, int ns_total,
-    float r2, int32_t* __restrict__ blk_stats, int width, int64_t pad_value, int64_t* __restrict__ out, int region_off, int mono, int stop) {
-#define TQ_STOP(K, V) if (stop == (K)) { if ((V) == 0x7fffffff) blk_stats[2 * blk] = lane; return; }
-  using L = TqLds;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int* orig = reinterpret_cast<int*>(smem);
-  int* qcnt = orig + TQ_RQ;
-  int* bigq = qcnt + TQ_RQ;
-  float4* qbuf = reinterpret_cast<float4*>(smem + L::QBUF_OFF);
-  int* brng = reinterpret_cast<int*>(smem + L::BRNG_OFF);
-  unsigned short* lists = reinterpret_cast<unsigned short*>(smem + L::LIST_OFF);
-  unsigned short* trng = reinterpret_cast<unsigned short*>(smem + L::TRNG_OFF);
-  unsigned long long* bkeys = reinterpret_cast<unsigned long long*>(smem + L::BKEY_OFF);
-  unsigned int* brow = reinterpret_cast<unsigned int*>(smem + L::BROW_OFF);
-  char* region = smem + region_off;
-  float* sx = reinterpret_cast<float*>(region);
-  float* sy = sx + TQ_STAGE_CAP;
-  float* sz = sy + TQ_STAGE_CAP;
-  int* si = reinterpret_cast<int*>(sz + TQ_STAGE_CAP);
-  unsigned int* rowbuf = reinterpret_cast<unsigned int*>(region);  // takes the planes' place once they are dead
-  const int tcap = nb <= L::TABLE_MAX ? nb : 0;
-  int* s_qoff = reinterpret_cast<int*>(region);
-  BatchGrid* s_grids = reinterpret_cast<BatchGrid*>(region + ((size_t)(tcap + 1) * 4 + 15) / 16 * 16);
-
-  const int lane = threadIdx.x;
-  const int nblk = (nq + TQ_RQ - 1) / TQ_RQ;
-  const int per_xcd = gridDim.x / 8;
-  const int blk = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;  // one contiguous eighth of the cell-ordered queries per XCD
-  if (blk >= nblk) return;
-  const int t = blk * TQ_RQ + lane;
-  const bool valid = t < nq;
-  if (tcap > 0) {
-    for (int i = lane; i <= nb; i += TQ_RQ) s_qoff[i] = q_off[i];
-    const int4* gsrc = reinterpret_cast<const int4*>(grids);
-    int4* gdst = reinterpret_cast<int4*>(s_grids);
-    for (int i = lane; i < nb * 4; i += TQ_RQ) gdst[i] = gsrc[i];
-  }
-  float4 qp = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (valid) qp = sorted_q[t];
-  __syncthreads();
-  // ---- set-up: the nine candidate ranges (global positions in the cell-sorted supports), band k = 3 * (dz + 1) + (dy + 1)
-  int p0[NBAND], p1[NBAND];
-#pragma unroll
-  for (int k = 0; k < NBAND; ++k) p0[k] = p1[k] = 0;
-  if (valid) {
-    int b;
-    BatchGrid g;
-    if (tcap > 0) {
-      b = find_batch(s_qoff, nb, __float_as_int(qp.w));
-      g = s_grids[b];
-    } else {
-      b = find_batch(q_off, nb, __float_as_int(qp.w));
-      g = grids[b];
-    }
-    const double ux = cell_coord(qp.x, g.org[0], g.inv_cell_x), kx = (double)g.xk;
-    const double uy = cell_coord(qp.y, g.org[1], g.inv_cell);
-    const double uz = cell_coord(qp.z, g.org[2], g.inv_cell);
-    const double tx = (double)(g.dim[0] - 1), ty = (double)(g.dim[1] - 1), tz = (double)(g.dim[2] - 1);
-    if ((ux + kx >= 0.0) && (ux - kx <= tx)) {  // NaN coordinates: no candidates
-      const int lx = (int)fmin(fmax(ux - kx, 0.0), tx);
-      const int hx = (int)fmin(fmax(ux + kx, 0.0), tx);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const double cz = uz + (double)(j - 1);
-        if (cz >= 0.0 && cz <= tz) {
-#pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            const double cy = uy + (double)(i - 1);
-            if (cy >= 0.0 && cy <= ty) {
-              const int base = g.cell_base + g.dim[0] * ((int)cy + g.dim[1] * (int)cz);
-              p0[3 * j + i] = start_s[base + lx];
-              p1[3 * j + i] = start_s[base + hx + 1];
-            }
-          }
-        }
-      }
-    }
-    orig[lane] = __float_as_int(qp.w);
-    qbuf[lane] = qp;
-  } else {
-    orig[lane] = -1;
-  }
-  TQ_STOP(1, p0[0] + p1[8] + p0[4])
-  // ---- wave-wide extent of every band -> where it lies in the planes (uniform values)
-  int blo[NBAND], bbase[NBAND + 1];
-  {
-    int acc = 0;
-#pragma unroll
-    for (int k = 0; k < NBAND; ++k) {
-      const bool has = p1[k] > p0[k];
-      int lo, hi;
-      if (mono) {  // self-search: ranges are non-decreasing along the wave
-        const unsigned long long m = __ballot(has);
-        lo = 0;
-        hi = 0;
-        if (m) {
-          lo = __builtin_amdgcn_readlane(p0[k], __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1));
-          hi = __builtin_amdgcn_readlane(p1[k], __builtin_amdgcn_readfirstlane(63 - __clzll((long long)m)));
-        }
-      } else {
-        lo = wave_min_i32_dpp(has ? p0[k] : 0x7fffffff);
-        hi = wave_max_i32_dpp(has ? p1[k] : 0);
-        lo = __builtin_amdgcn_readfirstlane(lo);
-        hi = __builtin_amdgcn_readfirstlane(hi);
-        if (hi <= lo) lo = hi = 0;
-      }
-      blo[k] = lo;
-      bbase[k] = acc;
-      acc += hi > lo ? hi - lo : 0;
-    }
-    bbase[NBAND] = acc;
-  }
-  const bool staged = bbase[NBAND] <= TQ_STAGE_CAP;
-  int blk_flag = 0;
-  int n = 0;
-  __syncthreads();  // the per-cloud tables (in the planes' place) are dead
-  if (staged) {
-    // ---- staging: the wave copies band after band, all loads of two 64-element pieces per band issued before the first LDS write
-#pragma unroll
-    for (int k = 0; k < NBAND; ++k) {
-      const int len = bbase[k + 1] - bbase[k];
-      float4 v[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) v[u] = sorted_s[min(blo[k] + u * WAVE + lane, ns_total - 1)];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int f = u * WAVE + lane;
-        if (f < len) {
-          sx[bbase[k] + f] = v[u].x;
-          sy[bbase[k] + f] = v[u].y;
-          sz[bbase[k] + f] = v[u].z;
-          si[bbase[k] + f] = __float_as_int(v[u].w);
-        }
-      }
-      for (int f = 2 * WAVE + lane; f < len; f += WAVE) {  // a band longer than 128 elements
-        const float4 t4 = sorted_s[blo[k] + f];
-        sx[bbase[k] + f] = t4.x;
-        sy[bbase[k] + f] = t4.y;
-        sz[bbase[k] + f] = t4.z;
-        si[bbase[k] + f] = __float_as_int(t4.w);
-      }
-    }
-    __syncthreads();
-    TQ_STOP(2, (int)sx[lane])
-    // ---- tests: four candidates per step; a hit (sign bit of distance bits - r2 bits: both are non-negative floats, NaN sorts
-    //      above everything) appends its plane position to the thread's list; the count runs on past the list's end
-    const unsigned r2b = r2 == r2 ? __float_as_uint(r2) : 0u;  // NaN radius: nothing is a neighbour
-    const f32x2 qx = {qp.x, qp.x}, qy = {qp.y, qp.y}, qz = {qp.z, qp.z};
-    unsigned short* my = lists + lane;
-    // The thread's non-empty ranges (staged positions) go to LDS as a little table so that ONE loop can walk them all: with a
-    // loop per band the wave runs every band as long as its longest lane (measured: 72 steps per wave for 40 of work).
-    int nrng = 0;
-#pragma unroll
-    for (int k = 0; k < NBAND; ++k) {
-      const int a0 = p0[k] + (bbase[k] - blo[k]), len = p1[k] - p0[k];
-      if (valid && len > 0) {
-        trng[(2 * nrng) * TQ_RQ + lane] = (unsigned short)a0;
-        trng[(2 * nrng + 1) * TQ_RQ + lane] = (unsigned short)(a0 + len);
-        ++nrng;
-      }
-    }
-    // (a wave's LDS operations are served in order: the reads below see these writes)
-    // Software pipeline: the planes of step i + 1 and the range after next are requested before step i is evaluated, so a
-    // step's LDS round trips hide behind the arithmetic of the step before (a wave has at most one partner on its SIMD here:
-    // nobody else would hide them).
-    int p = 0, e = 0, np = 0, ne = 0, kk = 2;
-    if (nrng > 0) p = trng[lane], e = trng[TQ_RQ + lane];
-    if (nrng > 1) np = trng[2 * TQ_RQ + lane], ne = trng[3 * TQ_RQ + lane];
-    bool live = p < e;
-    int pc = live ? p : 0;
-    f32x2 xa = {sx[pc], sx[pc + 1]}, xb = {sx[pc + 2], sx[pc + 3]};
-    f32x2 ya = {sy[pc], sy[pc + 1]}, yb = {sy[pc + 2], sy[pc + 3]};
-    f32x2 za = {sz[pc], sz[pc + 1]}, zb = {sz[pc + 2], sz[pc + 3]};
-    while (__any(live)) {
-      // where the next step reads
-      int p2 = p + 4, e2 = e;
-      if (p2 >= e2) {  // next range (empty = this thread is done)
-        p2 = np;
-        e2 = ne;
-        np = ne = 0;
-        if (kk < nrng) {
-          np = trng[(2 * kk) * TQ_RQ + lane];
-          ne = trng[(2 * kk + 1) * TQ_RQ + lane];
-        }
-        ++kk;
-      }
-      const bool live2 = p2 < e2;
-      const int pc2 = live2 ? p2 : 0;
-      const f32x2 nxa = {sx[pc2], sx[pc2 + 1]}, nxb = {sx[pc2 + 2], sx[pc2 + 3]};
-      const f32x2 nya = {sy[pc2], sy[pc2 + 1]}, nyb = {sy[pc2 + 2], sy[pc2 + 3]};
-      const f32x2 nza = {sz[pc2], sz[pc2 + 1]}, nzb = {sz[pc2 + 2], sz[pc2 + 3]};
-      // this step: four candidates (the reads past a range's end stay inside the planes); a candidate is a hit iff its
-      // distance bits lie below the radius' (both are non-negative floats; NaN sorts above everything).  The position is
-      // written to list slot n UNCONDITIONALLY and n moves on only for a hit: no branch per candidate; slot TQ_NET takes
-      // the writes of a full list
-      const int left = live ? e - p : 0;
-      // nanoflann.hpp:432-440: result += diff*diff for x, y, z starting from 0 (two candidates per op)
-      const f32x2 dxa = qx - xa, dya = qy - ya, dza = qz - za;
-      const f32x2 dxb = qx - xb, dyb = qy - yb, dzb = qz - zb;
-      const f32x2 da = (dxa * dxa + dya * dya) + dza * dza;
-      const f32x2 db = (dxb * dxb + dyb * dyb) + dzb * dzb;
-      const unsigned dbits[4] = {__float_as_uint(da.x), __float_as_uint(da.y), __float_as_uint(db.x), __float_as_uint(db.y)};
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool h = u < left && dbits[u] < r2b;
-        my[min(n, TQ_NET) * TQ_RQ] = (unsigned short)(pc + u);
-        n += h ? 1 : 0;
-      }
-      p = p2, e = e2, live = live2, pc = pc2;
-      xa = nxa, xb = nxb, ya = nya, yb = nyb, za = nza, zb = nzb;
-    }
-  } else {
-    blk_flag = 1;  // candidate ranges longer than the planes: the caller repeats the call on count + fill
-  }
-  TQ_STOP(3, n)
-  const int wmax = wave_max_i32_dpp(n);
-  const int wmax_u = __builtin_amdgcn_readfirstlane(wmax);
-  qcnt[lane] = n;
-  // ---- queries with more hits than the network takes: noted for the end (staged ranges, so nothing is recomputed)
-  const unsigned long long bigm = __ballot(n > TQ_NET);
-  const int nbig = __popcll(bigm);
-  if (nbig > TQ_BIG) blk_flag = 1;
-  if (n > TQ_NET && nbig <= TQ_BIG) {
-    const int bs = __popcll(bigm & ((1ull << lane) - 1ull));
-    bigq[bs] = lane;
-#pragma unroll
-    for (int k = 0; k < NBAND; ++k) {
-      brng[bs * 18 + 2 * k] = p0[k] + (bbase[k] - blo[k]);
-      brng[bs * 18 + 2 * k + 1] = p1[k] + (bbase[k] - blo[k]);
-    }
-  }
-  // ---- keys: list entries -> register pairs; slots past the hit count hold a word above every real one
-  unsigned long long key[TQ_NET];
-  if (staged && !blk_flag && wmax_u > 0) {
-    const int m = min(n, TQ_NET);
-#pragma unroll
-    for (int i8 = 0; i8 < TQ_NET; i8 += 8) {
-      if (i8 < wmax_u) {  // (uniform) eight entries at a time: their list reads, then their plane reads, then the arithmetic
-        int pp[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) pp[u] = i8 + u < m ? (int)lists[(i8 + u) * TQ_RQ + lane] : 0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const float dx = qp.x - sx[pp[u]], dy = qp.y - sy[pp[u]], dz = qp.z - sz[pp[u]];
-          const float d = (dx * dx + dy * dy) + dz * dz;  // same arithmetic as the test: same bits
-          key[i8 + u] = i8 + u < m ? ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)si[pp[u]] : ~0ull;
-        }
-      } else {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) key[i8 + u] = ~0ull;
-      }
-    }
-    TQ_STOP(4, (int)(key[0] >> 40) + (int)(key[31] >> 40) + (int)(key[17] >> 33))
-    if (wmax_u > 1) {
-#pragma unroll
-      for (int c = 0; c < TQ_NET_CE; ++c) {
-        const unsigned long long a = key[TQ_PAIRS[c][0]], b2 = key[TQ_PAIRS[c][1]];
-        const bool sw = b2 < a;
-        key[TQ_PAIRS[c][0]] = sw ? b2 : a;
-        key[TQ_PAIRS[c][1]] = sw ? a : b2;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < TQ_NET; ++i) key[i] = ~0ull;
-  }
-  TQ_STOP(5, (int)(key[0] >> 40) + (int)(key[31] >> 40) + (int)(key[9] >> 33))
-  __syncthreads();
-  // ---- the big queries, one after the other: lanes = candidates, hits compacted by ballot, ranked by counting
-  if (!blk_flag) {
-    for (int bi = 0; bi < nbig; ++bi) {
-      const int slot = bigq[bi];
-      const float4 q = qbuf[slot];
-      int s0[NBAND], len[NBAND];
-      int tot = 0;
-#pragma unroll
-      for (int k = 0; k < NBAND; ++k) {
-        s0[k] = brng[bi * 18 + 2 * k];
-        len[k] = brng[bi * 18 + 2 * k + 1] - s0[k];
-        tot += len[k];
-      }
-      const unsigned r2b = r2 == r2 ? __float_as_uint(r2) : 0u;
-      int h = 0;  // uniform
-      for (int c0 = 0; c0 < tot; c0 += WAVE) {
-        int c = c0 + lane;
-        const bool in = c < tot;
-        int p = 0;
-        {
-          int rem = in ? c : 0;
-          bool found = false;
-#pragma unroll
-          for (int k = 0; k < NBAND; ++k) {
-            if (!found && rem < len[k]) {
-              p = s0[k] + rem;
-              found = true;
-            }
-            rem -= found ? 0 : len[k];
-          }
-        }
-        const float dx = q.x - sx[p], dy = q.y - sy[p], dz = q.z - sz[p];
-        const float d = (dx * dx + dy * dy) + dz * dz;
-        const bool hit = in && (int)(__float_as_uint(d) - r2b) < 0;
-        const unsigned long long hm = __ballot(hit);
-        if (hit) {
-          const int pos = h + __popcll(hm & ((1ull << lane) - 1ull));
-          if (pos < TQ_BKEYS) bkeys[pos] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)si[p];
-        }
-        h += __popcll(hm);
-      }
-      if (h > TQ_BKEYS) {  // (uniform)
-        blk_flag = 1;
-        break;
-      }
-      __syncthreads();
-      for (int e = lane; e < h; e += WAVE) {
-        const unsigned long long ke = bkeys[e];
-        int rank = 0;
-        int j2 = 0;
-        for (; j2 + 8 <= h; j2 += 8) {  // eight independent (broadcast) reads in flight
-          unsigned long long kj[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) kj[u] = bkeys[j2 + u];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) rank += kj[u] < ke ? 1 : 0;
-        }
-        for (; j2 < h; ++j2) rank += bkeys[j2] < ke ? 1 : 0;
-        if (rank < width) brow[bi * width + rank] = (unsigned int)(ke & 0xffffffffull);
-      }
-      __syncthreads();
-    }
-  }
-  TQ_STOP(6, (int)brow[lane])
-  __syncthreads();
-  if (!blk_flag) {
-    // ---- rows: the planes are dead, their place is the row buffer
-    {
-      const int m = min(min(n, TQ_NET), width);
-      unsigned int* row = rowbuf + lane * width;
-      if (n <= TQ_NET) {
-#pragma unroll
-        for (int i = 0; i < TQ_NET; ++i)
-          if (i < m) row[i] = (unsigned int)(key[i] & 0xffffffffull);
-      }
-    }
-    __syncthreads();
-    for (int bi = 0; bi < nbig; ++bi) {
-      const int slot = bigq[bi], cnt = min(qcnt[slot], width);
-      for (int i = lane; i < cnt; i += WAVE) rowbuf[slot * width + i] = brow[bi * width + i];
-    }
-    __syncthreads();
-    const int rows_here = min(TQ_RQ, nq - blk * TQ_RQ);
-    const int npair = (width + 1) >> 1, total_pairs = rows_here * npair;
-    const unsigned magic = 0xffffffffu / (unsigned)npair + 1u;  // i / npair = mulhi(i, magic) for i < 2^16
-    const bool even = (width & 1) == 0;
-    for (int i = lane; i < total_pairs; i += WAVE) {
-      const int r = npair == 1 ? i : (int)__umulhi((unsigned)i, magic);
-      const int cc = (i - r * npair) * 2;
-      const int cnt = qcnt[r];
-      const unsigned vx = rowbuf[r * width + cc];
-      const unsigned vy = rowbuf[r * width + min(cc + 1, width - 1)];
-      int64_t* dst = out + (int64_t)orig[r] * width + cc;
-      const long long ox = cc < cnt ? (long long)vx : (long long)pad_value;
-      const long long oy = cc + 1 < cnt ? (long long)vy : (long long)pad_value;
-      if (even) {
-        longlong2 o;
-        o.x = ox;
-        o.y = oy;
-        *reinterpret_cast<longlong2*>(dst) = o;  // width even: every pair is 16-byte aligned
-      } else {
-        dst[0] = ox;
-        if (cc + 1 < width) dst[1] = oy;
-      }
-    }
-  }
-  if (lane == 0) {
-    blk_stats[2 * blk] = wmax_u;
-    blk_stats[2 * blk + 1] = blk_flag;
-  }
-}
-
 // max / max over the per-block (max hits per query, hits per block) pairs -> hdr
 // mail (optional): the header also goes to the host's mailbox page, stamped (common.hpp) -- no copy, no stream synchronise
 __global__ __launch_bounds__(1024) void reduce_stats_kernel(const int32_t* __restrict__ blk_stats,
@@ -2092,31 +1649,6 @@ int launch_fused(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t 
     KernelTimer timer("radius_fused", stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(L::THREADS), lds, stream, sorted_q, (int)nq, w.q_off, nb, w.grids, start_s,
                        w.sorted_s, (int)ns, r2, w.blk_stats, (int)width, ns, out, cap, (int)region, mono ? 1 : 0);
-  }
-  return reduce_and_read(w, blocks, stream, h_out);
-}
-
-inline bool tq_fits(int64_t width, int nb) {
-  return width >= 1 && TqLds::total((int)width, nb <= TqLds::TABLE_MAX ? nb : 0) <= 160 * 1024;
-}
-
-// gr_radius_search mode 2: one thread per query.  h_out->max_block_hits != 0 = a workgroup could not finish (see the kernel):
-// the caller repeats the call on count + fill.
-int launch_tq(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns, int nb, const int32_t* start_s, float r2,
-              int64_t width, int64_t* out, bool mono, hipStream_t stream, RadiusHdr* h_out) {
-  using L = TqLds;
-  const int blocks = (int)((nq + TQ_RQ - 1) / TQ_RQ);
-  const int grid = (blocks + 7) / 8 * 8;
-  const int tcap = nb <= L::TABLE_MAX ? nb : 0;
-  const size_t lds = L::total((int)width, tcap);
-  GR_REQUIRE(lds <= 160 * 1024, "radius_search: neighbor_limit %lld does not fit the thread-per-query kernel", (long long)width);
-  if (lds > 64 * 1024)
-    GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  {
-    KernelTimer timer("radius_tq", stream);
-    hipLaunchKernelGGL(tq_kernel, dim3(grid), dim3(TQ_RQ), lds, stream, sorted_q, (int)nq, w.q_off, nb, w.grids, start_s, w.sorted_s,
-                       (int)ns, r2, w.blk_stats, (int)width, ns, out, (int)L::region_off((int)width), mono ? 1 : 0,
-                       getenv("TQ_STOP") ? atoi(getenv("TQ_STOP")) : 0);
   }
   return reduce_and_read(w, blocks, stream, h_out);
 }
@@ -2327,7 +1859,7 @@ namespace {
 std::atomic<int>& search_mode() {
   static std::atomic<int> mode{[] {
     const char* a = getenv("GR_RADIUS_SINGLE_PASS");
-    return (a && a[0] == '1') ? 1 : ((a && a[0] == '2') ? 2 : 0);
+    return (a && a[0] == '1') ? 1 : 0;
   }()};
   return mode;
 }
@@ -2336,7 +1868,7 @@ std::atomic<int>& search_mode() {
 
 extern "C" int gr_radius_search_mode(int mode) {
   const int old = search_mode().load();
-  if (mode >= 0 && mode <= 2) search_mode().store(mode);
+  if (mode >= 0 && mode <= 1) search_mode().store(mode);
   return old;
 }
 
@@ -2358,11 +1890,10 @@ extern "C" int gr_radius_search(const float* q, const float* s, const int64_t* h
   // GR_RADIUS_SINGLE_PASS=1 selects the single-pass kernel (fused_kernel above).  It is not the default: on 8 x 200 k points it
   // runs as long as count + fill together (both are bound by VALU issue: ~3 000 instructions per wave either way)
   const int mode = search_mode().load();
-  const bool fused = (mode == 1 && fused_fits(limit)) || (mode == 2 && tq_fits(limit, P.nb));
+  bool fused = mode == 1 && fused_fits(limit);
   if (fused) {
     RadiusHdr hf;
-    rc = mode == 2 ? launch_tq(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, out, P.same, stream, &hf)
-                   : launch_fused(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, out, P.same, stream, &hf);
+    rc = launch_fused(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, out, P.same, stream, &hf);
     if (rc != GR_OK) return rc;
     h_info[0] = hf.max_count;
     h_info[2] = P.same ? 1 : 0;

@@ -34,7 +34,7 @@ def child():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     res = {"ms": round(dt * 1e3, 4), "width": out.shape[1]}
-    for name in ("radius_bin", "radius_count", "radius_fill", "radius_fused", "radius_tq"):
+    for name in ("radius_bin", "radius_count", "radius_fill", "radius_fused"):
         tot, cnt = ctypes.c_double(0), ctypes.c_int64(0)
         L.gr_timing_read(name.encode(), ctypes.byref(tot), ctypes.byref(cnt))
         if cnt.value:
