@@ -40,6 +40,57 @@ __device__ __forceinline__ T* z_shift(T* p, size_t bytes) {  // (pointer arithme
   return p ? reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(p)) + bytes) : p;
 }
 
+// SuperPointMatching's normalisation needs the row and column sums of the exp(-d) matrix: the distance kernels leave
+// PARTIAL sums of their output tile -- rs_part[tile column][row] = the row's sum over the tile's columns, cs_part[tile row]
+// [column] = the column's sum over the tile's rows -- and sums_finish_kernel adds a row's / column's partials in tile order:
+// fixed summation order, no float atomics, and nobody reads the matrix again for it (the two-kernel form read it twice).
+// v[a][b][r]: the wave's values in MFMA C/D layout (col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) inside the
+// 32 x 32 block (a, b)), zero outside the matrix.  WR x WC waves per workgroup; wr / wc = this wave's position; s_red: LDS
+// scratch of (WR + WC) * T floats (T = 32 * max(A * WR, B * WC) = the tile edge), free when this is called.
+template <int A, int B, int WR, int WC>
+__device__ __forceinline__ void tile_partial_sums(const float (&v)[A][B][16], int wr, int wc, int lane, int tid, float* s_red,
+                                                  int i0, int j0, int n, int m, float* __restrict__ rs_row,
+                                                  float* __restrict__ cs_row) {
+  constexpr int T = 32 * A * WR;
+  static_assert(A * WR == B * WC, "square workgroup tiles");
+  float* s_rows = s_red;            // [WC][T]
+  float* s_cols = s_red + WC * T;   // [WR][T]
+  // rows: over b, then a butterfly over the 32 lanes of the half-wave (every lane ends with the sum)
+#pragma unroll
+  for (int a = 0; a < A; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float t = v[a][0][r];
+#pragma unroll
+      for (int b = 1; b < B; ++b) t += v[a][b][r];
+#pragma unroll
+      for (int d = 16; d > 0; d >>= 1) t += __shfl_xor(t, d, WAVE);
+      if ((lane & 31) == 0) s_rows[wc * T + wr * 32 * A + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = t;
+    }
+  // columns: the lane's 16 A values, then the other half-wave's
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    float t = 0.f;
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += v[a][b][r];
+    t += __shfl_xor(t, 32, WAVE);
+    if (lane < 32) s_cols[wr * T + wc * 32 * B + 32 * b + lane] = t;
+  }
+  __syncthreads();
+  if (tid < T) {
+    float t = s_rows[tid];
+#pragma unroll
+    for (int w = 1; w < WC; ++w) t += s_rows[w * T + tid];
+    if (i0 + tid < n) rs_row[i0 + tid] = t;
+    float u = s_cols[tid];
+#pragma unroll
+    for (int w = 1; w < WR; ++w) u += s_cols[w * T + tid];
+    if (j0 + tid < m) cs_row[j0 + tid] = u;
+  }
+}
+
 // out[i][j] = epilogue(dist(x[xi[i]], y[yi[j]]));  xi / yi optional gather tables (nullptr = identity).
 // n_dev / m_dev (optional) hold the row / column counts on the device (after a compaction).
 template <int EPI>
@@ -47,7 +98,8 @@ __global__ __launch_bounds__(256) void pairwise_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const int32_t* __restrict__ xi,
     const int32_t* __restrict__ yi, int n, int m, const int32_t* __restrict__ nm_dev, int C,
     int normalized, const float* __restrict__ x2, const float* __restrict__ y2,
-    float* __restrict__ out, int ld_out, const SpmStack* __restrict__ stack, size_t zstride, PdBatch bs) {
+    float* __restrict__ out, int ld_out, const SpmStack* __restrict__ stack, size_t zstride, PdBatch bs,
+    float* __restrict__ rs_part, float* __restrict__ cs_part, int ld_rs, int ld_cs) {
   __shared__ float sx[PD_T][PD_LD];
   __shared__ float sy[PD_T][PD_LD];
   if (stack) {  // x = y = the stacked features; the gather tables, counts and the output belong to pair blockIdx.z
@@ -59,6 +111,7 @@ __global__ __launch_bounds__(256) void pairwise_kernel(
     ld_out = P.ns;
     const size_t zo = (size_t)blockIdx.z * zstride;
     xi = z_shift(xi, zo), yi = z_shift(yi, zo), nm_dev = z_shift(nm_dev, zo), out = z_shift(out, zo);
+    rs_part = z_shift(rs_part, zo), cs_part = z_shift(cs_part, zo);
   }
   if (!stack && gridDim.z > 1) {  // plain batch: matrix blockIdx.z
     const int64_t z = blockIdx.z;
@@ -98,10 +151,12 @@ __global__ __launch_bounds__(256) void pairwise_kernel(
     __syncthreads();
   }
   // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  float vals[1][1][16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int gi = i0 + wi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     const int gj = j0 + wj + (lane & 31);
+    vals[0][0][r] = 0.f;
     if (gi < n && gj < m) {
       const float xy = acc[r];
       float d;
@@ -110,8 +165,12 @@ __global__ __launch_bounds__(256) void pairwise_kernel(
       d = fmaxf(d, 0.0f);                                       // :31 clamp(min=0)
       if (EPI == EPI_EXPNEG) d = expf(-d);                      // superpoint_matching.py:37
       out[(int64_t)gi * ld_out + gj] = d;
+      vals[0][0][r] = d;
     }
   }
+  if (EPI == EPI_EXPNEG && rs_part != nullptr)  // (the k loop ended with a barrier: the staging slabs are free)
+    tile_partial_sums<1, 1, 2, 2>(vals, w >> 1, w & 1, lane, tid, &sx[0][0], i0, j0, n, m, rs_part + (int64_t)blockIdx.x * ld_rs,
+                                  cs_part + (int64_t)blockIdx.y * ld_cs);
 }
 
 // The same contraction for LARGE outputs (and for the batched SuperPointMatching launch): 128 x 128 per workgroup, 64 x 64 per
@@ -132,7 +191,8 @@ __global__ __launch_bounds__(256, 2) void pairwise_big_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const int32_t* __restrict__ xi,
     const int32_t* __restrict__ yi, int n, int m, const int32_t* __restrict__ nm_dev, int C,
     int normalized, const float* __restrict__ x2, const float* __restrict__ y2,
-    float* __restrict__ out, int ld_out, const SpmStack* __restrict__ stack, size_t zstride, PdBatch bs) {
+    float* __restrict__ out, int ld_out, const SpmStack* __restrict__ stack, size_t zstride, PdBatch bs,
+    float* __restrict__ rs_part, float* __restrict__ cs_part, int ld_rs, int ld_cs) {
   __shared__ float sx[2][PB_T][PB_LD];
   __shared__ float sy[2][PB_T][PB_LD];
   if (stack) {
@@ -144,6 +204,7 @@ __global__ __launch_bounds__(256, 2) void pairwise_big_kernel(
     ld_out = P.ns;
     const size_t zo = (size_t)blockIdx.z * zstride;
     xi = z_shift(xi, zo), yi = z_shift(yi, zo), nm_dev = z_shift(nm_dev, zo), out = z_shift(out, zo);
+    rs_part = z_shift(rs_part, zo), cs_part = z_shift(cs_part, zo);
   }
   if (!stack && gridDim.z > 1) {  // plain batch: matrix blockIdx.z
     const int64_t z = blockIdx.z;
@@ -260,6 +321,7 @@ __global__ __launch_bounds__(256, 2) void pairwise_big_kernel(
     }
 #pragma unroll
   for (int b = 0; b < 2; ++b) yy[b] = normalized ? 0.f : y2[min(j0 + wj + 32 * b + (lane & 31), m - 1)];
+  float vals[2][2][16];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -274,9 +336,14 @@ __global__ __launch_bounds__(256, 2) void pairwise_big_kernel(
         else d = (xx[a][r] - 2.0f * xy) + yy[b];   // pairwise_distance.py:30
         d = fmaxf(d, 0.0f);                        // :31 clamp(min=0)
         if (EPI == EPI_EXPNEG) d = expf(-d);       // superpoint_matching.py:37
-        if (gi < n && gj < m) out[(int64_t)gi * ld_out + gj] = d;
+        const bool in = gi < n && gj < m;
+        if (in) out[(int64_t)gi * ld_out + gj] = d;
+        vals[a][b][r] = in ? d : 0.f;
       }
     }
+  if (EPI == EPI_EXPNEG && rs_part != nullptr)  // (the k loop ended with a barrier: the staging slabs are free)
+    tile_partial_sums<2, 2, 2, 2>(vals, w >> 1, w & 1, lane, tid, &sx[0][0][0], i0, j0, n, m, rs_part + (int64_t)blockIdx.x * ld_rs,
+                                  cs_part + (int64_t)blockIdx.y * ld_cs);
 }
 
 // squared norms of the rows: one wave per row, lanes stride the channels (coalesced; a thread per row read its 1 KB row on
@@ -366,56 +433,29 @@ __global__ __launch_bounds__(1024) void compact_masks_kernel(const uint8_t* __re
   }
 }
 
-// row sums: one wave per row, lanes stride the columns, fixed-shape tree reduce
-__device__ __forceinline__ void rowsum_body(const float* __restrict__ S, int ld, int nr, int ns, float* __restrict__ rs, int block) {
-  const int r = block * (256 / WAVE) + threadIdx.x / WAVE;
-  const int lane = threadIdx.x & (WAVE - 1);
-  if (r >= nr) return;
-  float s = 0.f;
-  for (int c = lane; c < ns; c += WAVE) s += S[(int64_t)r * ld + c];
-#pragma unroll
-  for (int d = WAVE / 2; d > 0; d >>= 1) s += __shfl_xor(s, d, WAVE);
-  if (lane == 0) rs[r] = s;
-}
-
-// column sums: a block owns 64 columns; its four waves each sum a contiguous quarter of the rows
-// (coalesced across lanes), partials combined in fixed order -> reproducible
-__device__ __forceinline__ void colsum_body(const float* __restrict__ S, int ld, int nr, int ns, float* __restrict__ cs, int block,
-                                            float (*part)[WAVE]) {
-  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
-  const int c = block * WAVE + lane;
-  const int per = (nr + 3) / 4;
-  const int r0 = w * per, r1 = min(nr, r0 + per);
-  float s = 0.f;
-  if (c < ns) {
-    int r = r0;
-    for (; r + 8 <= r1; r += 8) {  // eight independent loads in flight, summed in row order
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = S[(int64_t)(r + u) * ld + c];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
-    }
-    for (; r < r1; ++r) s += S[(int64_t)r * ld + c];
-  }
-  part[w][lane] = s;
-  __syncthreads();
-  if (w == 0 && c < ns) cs[c] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
-}
-
-// both in ONE launch: workgroups [0, row_blocks) sum rows (four each), the rest sum columns (64 each)
-__global__ __launch_bounds__(256) void sums_kernel(const float* __restrict__ S, int ld, const SpmHdr* __restrict__ hdr,
-                                                   float* __restrict__ rs, float* __restrict__ cs, int row_blocks,
-                                                   const SpmStack* __restrict__ stack, size_t zstride) {
-  __shared__ float part[4][WAVE];
+// row / column sums of the exp(-d) matrix from the partial sums the distance kernel left (tile_partial_sums): a row's partials
+// in tile-column order, a column's in tile-row order -- fixed summation order
+__global__ __launch_bounds__(256) void sums_finish_kernel(const SpmHdr* __restrict__ hdr, const float* __restrict__ rs_part,
+                                                          const float* __restrict__ cs_part, int ld_rs, int ld_cs, int tile,
+                                                          float* __restrict__ rs, float* __restrict__ cs,
+                                                          const SpmStack* __restrict__ stack, size_t zstride) {
   if (stack) {
-    ld = stack[blockIdx.z].ns;
     const size_t zo = (size_t)blockIdx.z * zstride;
-    S = z_shift(S, zo), hdr = z_shift(hdr, zo), rs = z_shift(rs, zo), cs = z_shift(cs, zo);
+    hdr = z_shift(hdr, zo), rs_part = z_shift(rs_part, zo), cs_part = z_shift(cs_part, zo), rs = z_shift(rs, zo), cs = z_shift(cs, zo);
   }
   const int nr = hdr->nr, ns = hdr->ns;
-  if ((int)blockIdx.x < row_blocks) rowsum_body(S, ld, nr, ns, rs, (int)blockIdx.x);
-  else colsum_body(S, ld, nr, ns, cs, (int)blockIdx.x - row_blocks, part);
+  const int ntc = (ns + tile - 1) / tile, ntr = (nr + tile - 1) / tile;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < nr) {
+    float t = 0.f;
+    for (int c = 0; c < ntc; ++c) t += rs_part[(int64_t)c * ld_rs + i];
+    rs[i] = t;
+  }
+  if (i < ns) {
+    float t = 0.f;
+    for (int r = 0; r < ntr; ++r) t += cs_part[(int64_t)r * ld_cs + i];
+    cs[i] = t;
+  }
 }
 
 // scores, dense (nr x ns) row-major: superpoint_matching.py:38-41  (S / rowsum) * (S / colsum)
@@ -903,6 +943,8 @@ struct SpmWs {
   float* score;
   float* rs;
   float* cs;
+  float* rs_part;  // [ceil(ns / 64)][nr] partial row sums per tile column (distance kernel epilogue)
+  float* cs_part;  // [ceil(nr / 64)][ns]
   uint32_t* hist;
   unsigned long long* cand;
   size_t bytes;
@@ -918,6 +960,8 @@ SpmWs carve_spm(void* p, int64_t nr, int64_t ns) {
   w.score = c.take<float>(nr * ns);
   w.rs = c.take<float>(nr);
   w.cs = c.take<float>(ns);
+  w.rs_part = c.take<float>(((ns + PD_T - 1) / PD_T) * nr);
+  w.cs_part = c.take<float>(((nr + PD_T - 1) / PD_T) * ns);
   w.hist = c.take<uint32_t>(3 * 2048);
   w.cand = c.take<unsigned long long>(CAND_BUF);
   w.bytes = c.used();
@@ -978,12 +1022,12 @@ extern "C" int gr_pairwise_distance_batch(const float* x, const float* y, int64_
     auto kern = aligned ? pairwise_big_kernel<EPI_DIST, true> : pairwise_big_kernel<EPI_DIST, false>;
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream, x, y, (const int32_t*)nullptr,
                        (const int32_t*)nullptr, (int)n, (int)m, (const int32_t*)nullptr, (int)c, normalized, x2, y2, out,
-                       (int)m, (const SpmStack*)nullptr, (size_t)0, bs);
+                       (int)m, (const SpmStack*)nullptr, (size_t)0, bs, (float*)nullptr, (float*)nullptr, 0, 0);
   } else {
     const dim3 grid((unsigned)((m + PD_T - 1) / PD_T), (unsigned)((n + PD_T - 1) / PD_T), (unsigned)batch);
     hipLaunchKernelGGL((pairwise_kernel<EPI_DIST>), grid, dim3(256), 0, stream, x, y, (const int32_t*)nullptr,
                        (const int32_t*)nullptr, (int)n, (int)m, (const int32_t*)nullptr, (int)c, normalized, x2, y2, out,
-                       (int)m, (const SpmStack*)nullptr, (size_t)0, bs);
+                       (int)m, (const SpmStack*)nullptr, (size_t)0, bs, (float*)nullptr, (float*)nullptr, 0, 0);
   }
   GR_LAUNCH_CHECK();
   return GR_OK;
@@ -1038,18 +1082,20 @@ static int spm_launch(const float* ref_feats, const float* src_feats, int64_t nr
       auto kern = aligned ? pairwise_big_kernel<EPI_EXPNEG, true> : pairwise_big_kernel<EPI_EXPNEG, false>;
       hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream, ref_feats, src_feats, w.ridx, w.sidx,
                          (int)nr, (int)ns, reinterpret_cast<const int32_t*>(w.hdr), (int)c, 1, (const float*)nullptr,
-                         (const float*)nullptr, w.S, (int)ns, stack, zstride, none);
+                         (const float*)nullptr, w.S, (int)ns, stack, zstride, none, dual_normalization ? w.rs_part : nullptr,
+                         dual_normalization ? w.cs_part : nullptr, (int)nr, (int)ns);
     } else {
       const dim3 grid((unsigned)((ns + PD_T - 1) / PD_T), (unsigned)((nr + PD_T - 1) / PD_T), z);
       hipLaunchKernelGGL((pairwise_kernel<EPI_EXPNEG>), grid, dim3(256), 0, stream, ref_feats, src_feats, w.ridx, w.sidx,
                          (int)nr, (int)ns, reinterpret_cast<const int32_t*>(w.hdr), (int)c, 1, (const float*)nullptr,
-                         (const float*)nullptr, w.S, (int)ns, stack, zstride, none);
+                         (const float*)nullptr, w.S, (int)ns, stack, zstride, none, dual_normalization ? w.rs_part : nullptr,
+                         dual_normalization ? w.cs_part : nullptr, (int)nr, (int)ns);
     }
   }
   if (dual_normalization) {
-    const unsigned row_blocks = (unsigned)((nr + 3) / 4), col_blocks = (unsigned)((ns + WAVE - 1) / WAVE);
-    hipLaunchKernelGGL(sums_kernel, dim3(row_blocks + col_blocks, 1, z), dim3(256), 0, stream, w.S, (int)ns, w.hdr, w.rs, w.cs,
-                       (int)row_blocks, stack, zstride);
+    const int tile = pd_use_big(nr, ns, npairs) ? PB_T : PD_T;  // (the kernel that ran above)
+    hipLaunchKernelGGL(sums_finish_kernel, dim3((unsigned)((std::max(nr, ns) + 255) / 256), 1, z), dim3(256), 0, stream, w.hdr,
+                       w.rs_part, w.cs_part, (int)nr, (int)ns, tile, w.rs, w.cs, stack, zstride);
   }
   if (spm_fast_ok(nr, ns, num_correspondences)) {
     // the k best of every 64-row slab -> the pair's candidates (no dense score matrix, no histogram sweeps)
