@@ -686,8 +686,11 @@ __global__ __launch_bounds__(256) void seg_scan_kernel(int V, int tiles, int nch
   if (threadIdx.x == 0) dst[tiles] = (uint32_t)s_carry;
 }
 
-template <bool LANE_ORDERED>
-__global__ __launch_bounds__(BIN_T) void tile_scatter_kernel(int P, int V, int gx, int gy, int nchunk, int tile_bits,
+// TT = threads per workgroup: 256 (four waves, each a quarter of the chunk) for many views per call; 1024 for a few views,
+// where the launch has fewer workgroups than the chip has CUs and a workgroup's walk through its chunk IS the kernel's
+// duration (16 waves, an eighth of the steps each: 33 -> 12 us per one-camera frame)
+template <bool LANE_ORDERED, int TT>
+__global__ __launch_bounds__(TT) void tile_scatter_kernel(int P, int V, int gx, int gy, int nchunk, int tile_bits,
                                                              int stage_cap, const int32_t* __restrict__ nvis,
                                                              const uint32_t* __restrict__ rects,
                                                              const int32_t* __restrict__ ids,
@@ -697,7 +700,7 @@ __global__ __launch_bounds__(BIN_T) void tile_scatter_kernel(int P, int V, int g
   // list_cap: entries the point list holds.  A speculative launch (gr_raster_forward) sizes the list before the instance
   // count is known: a chunk that would end past it writes nothing (the host then repeats the render with a larger list)
   extern __shared__ unsigned int s_cur[];  // [waves][tiles] counts -> cursors, then [stage_cap] staged chunk-local indices
-  constexpr int NW = BIN_T / WAVE, CW = BIN_CHUNK / NW;
+  constexpr int NW = TT / WAVE, CW = BIN_CHUNK / NW;
   int v, c;
   if (!bin_block(V, nchunk, v, c)) return;
   const int tiles = gx * gy;
@@ -710,7 +713,7 @@ __global__ __launch_bounds__(BIN_T) void tile_scatter_kernel(int P, int V, int g
   unsigned int* my = s_cur + wv * tiles;
   // staged entries are 16-bit positions inside the chunk (BIN_CHUNK <= 65536); the ids are looked up on the way out
   unsigned short* stage = reinterpret_cast<unsigned short*>(s_cur + NW * tiles);
-  for (int T = threadIdx.x; T < NW * tiles; T += BIN_T) s_cur[T] = 0u;
+  for (int T = threadIdx.x; T < NW * tiles; T += TT) s_cur[T] = 0u;
   __syncthreads();
   const int64_t vbase = (int64_t)v * P;
   const int w_begin = c * BIN_CHUNK + wv * CW, w_end = min(nvis[v], w_begin + CW);
@@ -735,7 +738,7 @@ __global__ __launch_bounds__(BIN_T) void tile_scatter_kernel(int P, int V, int g
   }
   __syncthreads();
   // ---- phase B: counts -> cursors (chunk-local when staged, global otherwise)
-  for (int T = threadIdx.x; T < tiles; T += BIN_T) {
+  for (int T = threadIdx.x; T < tiles; T += TT) {
     unsigned int run = seg[T] - (staged ? chunk_begin : 0u);
 #pragma unroll
     for (int w2 = 0; w2 < NW; ++w2) {
@@ -848,7 +851,7 @@ __global__ __launch_bounds__(BIN_T) void tile_scatter_kernel(int P, int V, int g
   __syncthreads();
   // ---- phase D: the chunk's block leaves as full coalesced lines
   const int32_t* cid = ids + vbase + (int64_t)c * BIN_CHUNK;
-  for (int i = threadIdx.x; i < total; i += BIN_T) point_list[chunk_begin + i] = cid[stage[i]];
+  for (int i = threadIdx.x; i < total; i += TT) point_list[chunk_begin + i] = cid[stage[i]];
 }
 
 // ------------------------------------------------------------------------------------ blend
@@ -1590,8 +1593,12 @@ static int render_impl(int64_t P, const gr_raster_view* h_views, int num_views, 
   if (R > 0 || (spec && P > 0)) {
     // LDS: per-wave tile cursors + a staging block that holds a whole chunk's instances (chunks that do not fit write
     // straight to global memory); sized for the largest chunk of this call, capped so that two workgroups share a CU
-    const size_t cur_bytes = (size_t)(BIN_T / WAVE) * tiles * sizeof(unsigned int);
-    const int64_t cap_max = ((int64_t)78 * 1024 - (int64_t)cur_bytes) / 2;
+    // few views: 1024 threads per workgroup (see the kernel) -- as long as their sixteen cursor rows leave room for the staging block
+    constexpr int WIDE_T = 1024;
+    const bool wide = num_views <= 4 && (size_t)(WIDE_T / WAVE) * tiles * sizeof(unsigned int) <= 100 * 1024;
+    const int scatter_threads = wide ? WIDE_T : BIN_T;
+    const size_t cur_bytes = (size_t)(scatter_threads / WAVE) * tiles * sizeof(unsigned int);
+    const int64_t cap_max = ((int64_t)(wide ? 156 : 78) * 1024 - (int64_t)cur_bytes) / 2;
     int64_t want = std::max<int64_t>(h_num_rendered[num_views], 0);
     if (spec) want = want > 0 ? want + 64 : cap_max;  // the hint is last frame's figure; a chunk that outgrows it writes straight
                                                       // to memory (a 25 % margin here cost a resident workgroup per CU: + 16 % scatter time)
@@ -1600,14 +1607,15 @@ static int render_impl(int64_t P, const gr_raster_view* h_views, int num_views, 
     bool ordered = false;
     rc = lds_atomics_lane_ordered(stream, &ordered);
     if (rc != GR_OK) return rc;
-    auto kern = ordered ? tile_scatter_kernel<true> : tile_scatter_kernel<false>;
+    auto kern = wide ? (ordered ? tile_scatter_kernel<true, WIDE_T> : tile_scatter_kernel<false, WIDE_T>)
+                     : (ordered ? tile_scatter_kernel<true, BIN_T> : tile_scatter_kernel<false, BIN_T>);
     int tile_bits = 0;
     while ((1 << tile_bits) < tiles) ++tile_bits;
     if (lds > 64 * 1024)
       GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     {
       KernelTimer timer("raster_bin", stream);
-      hipLaunchKernelGGL(kern, dim3((unsigned)bin_grid(num_views, nchunk)), dim3(BIN_T), lds, stream, (int)P, num_views, gx, gy,
+      hipLaunchKernelGGL(kern, dim3((unsigned)bin_grid(num_views, nchunk)), dim3(scatter_threads), lds, stream, (int)P, num_views, gx, gy,
                          nchunk, tile_bits, stage_cap, g.nvis, g.rects, g.order_b, g.rec, g.seg_off, b.point_list, list_cap);
       GR_LAUNCH_CHECK();
     }
@@ -1621,7 +1629,10 @@ static int render_impl(int64_t P, const gr_raster_view* h_views, int num_views, 
       if (rc != GR_OK) return rc;
       if (h_bad != 0 && ordered) {
         lds_order_demote();
-        hipLaunchKernelGGL(tile_scatter_kernel<false>, dim3((unsigned)bin_grid(num_views, nchunk)), dim3(BIN_T), lds, stream, (int)P,
+        auto kern_b = wide ? tile_scatter_kernel<false, WIDE_T> : tile_scatter_kernel<false, BIN_T>;
+        if (lds > 64 * 1024)
+          GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_b), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(kern_b, dim3((unsigned)bin_grid(num_views, nchunk)), dim3(scatter_threads), lds, stream, (int)P,
                            num_views, gx, gy, nchunk, tile_bits, stage_cap, g.nvis, g.rects, g.order_b, g.rec, g.seg_off,
                            b.point_list, list_cap);
         GR_LAUNCH_CHECK();
