@@ -127,20 +127,42 @@ __global__ __launch_bounds__(256) void pairwise_kernel(
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wi = (w >> 1) * 32, wj = (w & 1) * 32;  // wave's 32x32 sub-tile
   f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // staging: element e of a 64 x 32 slab = (row e / 32, k e % 32); a thread owns eight of them, the same (row, k) pair of
+  // every slab, so its row addresses are fixed for the whole k loop.  The loads of slab s + 1 are issued before the MFMAs of
+  // slab s (registers) and land while they run: one global round trip per slab used to sit between two barriers with nothing
+  // to cover it (144 workgroups of a 767 x 767 call: 34 us for 0.3 GFLOP)
+  constexpr int PER = PD_T * PD_K / 256;  // 8
+  const float* xrow[PER];
+  const float* yrow[PER];
+  bool xok[PER], yok[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int e = tid + u * 256, r = e / PD_K;
+    const int gi = i0 + r, gj = j0 + r;
+    xok[u] = gi < n;
+    yok[u] = gj < m;
+    xrow[u] = x + (int64_t)(xok[u] ? (xi ? xi[gi] : gi) : 0) * C + (e % PD_K);
+    yrow[u] = y + (int64_t)(yok[u] ? (yi ? yi[gj] : gj) : 0) * C + (e % PD_K);
+  }
+  float rx[PER], ry[PER];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const bool kin = k0 + ((tid + u * 256) % PD_K) < C;
+      rx[u] = (xok[u] && kin) ? xrow[u][k0] : 0.f;   // out-of-range -> 0
+      ry[u] = (yok[u] && kin) ? yrow[u][k0] : 0.f;
+    }
+  };
+  fetch(0);
   for (int k0 = 0; k0 < C; k0 += PD_K) {
-    // stage 64 x 32 slabs of x and y (coalesced along k); out-of-range -> 0
-    for (int e = tid; e < PD_T * PD_K; e += 256) {
-      const int r = e / PD_K, k = e % PD_K;
-      const int gi = i0 + r, gj = j0 + r, gk = k0 + k;
-      float vx = 0.f, vy = 0.f;
-      if (gk < C) {
-        if (gi < n) vx = x[(int64_t)(xi ? xi[gi] : gi) * C + gk];
-        if (gj < m) vy = y[(int64_t)(yi ? yi[gj] : gj) * C + gk];
-      }
-      sx[r][k] = vx;
-      sy[r][k] = vy;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e = tid + u * 256;
+      sx[e / PD_K][e % PD_K] = rx[u];
+      sy[e / PD_K][e % PD_K] = ry[u];
     }
     __syncthreads();
+    if (k0 + PD_K < C) fetch(k0 + PD_K);
 #pragma unroll
     for (int k = 0; k < PD_K; k += 2) {
       // A[i = lane & 31][k = lane >> 5],  B[k = lane >> 5][j = lane & 31]
