@@ -711,7 +711,7 @@ __global__ __launch_bounds__(1024) void select_emit_kernel(SpmHdr* __restrict__ 
                                                            int64_t* __restrict__ out_ref,
                                                            int64_t* __restrict__ out_src,
                                                            float* __restrict__ out_score, size_t zstride, int out_stride,
-                                                           int cand_cap) {
+                                                           int cand_cap, int4* __restrict__ summary) {
   __shared__ unsigned long long sk[EMIT_CAP];
   __shared__ int s_n;
   {  // stack mode: workgroup = pair, its outputs are row blockIdx.x of the (pairs, num_correspondences) arrays
@@ -720,7 +720,15 @@ __global__ __launch_bounds__(1024) void select_emit_kernel(SpmHdr* __restrict__ 
     out_ref += (int64_t)blockIdx.x * out_stride, out_src += (int64_t)blockIdx.x * out_stride;
     out_score += (int64_t)blockIdx.x * out_stride;
   }
-  if (hdr->overflow) return;  // (uniform) the caller repeats this pair on the dense path
+  // what the host needs of every pair's header, in ONE contiguous row per pair (the headers themselves lie a workspace slice
+  // apart: a strided read-back)
+  auto report = [&](int overflow) {
+    if (summary != nullptr && threadIdx.x == 0) summary[blockIdx.x] = make_int4(hdr->k, overflow, hdr->n_cand, 0);
+  };
+  if (hdr->overflow) {  // (uniform) the caller repeats this pair on the dense path
+    report(1);
+    return;
+  }
   const int n_all = min(hdr->n_cand, cand_cap);
   const int k_sel = hdr->k;
   // Two bounds below the pair's k-th best score: hdr->tau_max (the slabs' thresholds), and -- over the candidates that reach
@@ -773,12 +781,42 @@ __global__ __launch_bounds__(1024) void select_emit_kernel(SpmHdr* __restrict__ 
   const int n = s_n;
   if (n > EMIT_CAP || n < min(k_sel, n_all)) {  // uniform.  (Fewer than k survivors cannot happen while the bounds hold: checked anyway)
     if (threadIdx.x == 0) hdr->overflow = 1;
+    report(1);
     return;
   }
+  report(0);
   int np2 = 2;
   while (np2 < n) np2 <<= 1;
   for (int i = n + threadIdx.x; i < np2; i += 1024) sk[i] = 0ull;
   __syncthreads();
+  if (np2 <= 1024) {
+    // one key per thread, in a register: exchanges with a partner less than 64 positions away are lane shuffles (no LDS, no
+    // barrier); only the few steps with a stride of 64 or more go through LDS -- 10 barrier pairs for 1 024 keys instead of
+    // the 55 of the all-LDS network below (14 of this kernel's 18 us at a few hundred candidates)
+    const int t = threadIdx.x;
+    unsigned long long x = t < np2 ? sk[t] : 0ull;
+    for (int size = 2; size <= np2; size <<= 1) {
+      const bool desc = (t & size) == 0;
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        unsigned long long y;
+        if (stride >= WAVE) {
+          __syncthreads();
+          sk[t] = x;
+          __syncthreads();
+          y = sk[t ^ stride];
+        } else {
+          const unsigned int lo32 = (unsigned int)__shfl_xor((int)(unsigned int)x, stride, WAVE);
+          const unsigned int hi32 = (unsigned int)__shfl_xor((int)(unsigned int)(x >> 32), stride, WAVE);
+          y = ((unsigned long long)hi32 << 32) | lo32;
+        }
+        const bool lower = (t & stride) == 0;
+        x = (lower == desc) ? (x > y ? x : y) : (x < y ? x : y);
+      }
+    }
+    __syncthreads();
+    sk[t] = x;
+    __syncthreads();
+  } else
   // bitonic sort, descending, over the smallest power of two that holds the candidates
   for (int size = 2; size <= np2; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -1069,7 +1107,7 @@ extern "C" size_t gr_superpoint_matching_workspace_bytes(int64_t nr, int64_t ns)
 // kernel does not take, and pairs whose slabs overflowed (w.hist must be zero, w.rs / w.cs and hdr->k in place).
 static void spm_select_dense(int64_t nr, int64_t ns, int num_correspondences, int dual_normalization, int64_t* out_ref_idx,
                              int64_t* out_src_idx, float* out_scores, const SpmWs& w, hipStream_t stream,
-                             const SpmStack* stack, size_t zstride, int npairs) {
+                             const SpmStack* stack, size_t zstride, int npairs, int4* summary = nullptr) {
   const unsigned z = (unsigned)npairs;
   hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((ns + 255) / 256), (unsigned)nr, z), dim3(256), 0, stream, w.S,
                      (int)ns, w.rs, w.cs, dual_normalization, w.hdr, w.score, stack, zstride);
@@ -1079,7 +1117,7 @@ static void spm_select_dense(int64_t nr, int64_t ns, int num_correspondences, in
   hipLaunchKernelGGL(select_gather_kernel, dim3(sel_blocks, 1, z), dim3(256), 0, stream, w.score, w.hdr, w.hist, w.cand,
                      zstride);
   hipLaunchKernelGGL(select_emit_kernel, dim3(z), dim3(1024), 0, stream, w.hdr, w.cand, w.ridx, w.sidx, out_ref_idx,
-                     out_src_idx, out_scores, zstride, num_correspondences, CAND_CAP);
+                     out_src_idx, out_scores, zstride, num_correspondences, CAND_CAP, summary);
 }
 
 // the launches of one pair -- or, with `stack`, of `npairs` pairs at once (nr / ns are then the largest counts, feats / masks
@@ -1089,7 +1127,7 @@ static int spm_launch(const float* ref_feats, const float* src_feats, int64_t nr
                       const uint8_t* ref_masks, const uint8_t* src_masks, int num_correspondences,
                       int dual_normalization, int64_t* out_ref_idx, int64_t* out_src_idx, float* out_scores,
                       const SpmWs& w, hipStream_t stream, const SpmStack* stack = nullptr, size_t zstride = 0,
-                      int npairs = 1) {
+                      int npairs = 1, int4* summary = nullptr) {
   const unsigned z = (unsigned)npairs;
   if (!stack && !spm_fast_ok(nr, ns, num_correspondences)) GR_HIP(hipMemsetAsync(w.hist, 0, 3 * 2048 * sizeof(uint32_t), stream));
   hipLaunchKernelGGL(compact_masks_kernel, dim3(z), dim3(1024), 0, stream, ref_masks, (int)nr, src_masks, (int)ns,
@@ -1124,10 +1162,10 @@ static int spm_launch(const float* ref_feats, const float* src_feats, int64_t nr
     hipLaunchKernelGGL(slab_select_kernel, dim3((unsigned)((nr + SS_ROWS - 1) / SS_ROWS), 1, z), dim3(SS_T), 0, stream, w.S,
                        (int)ns, w.rs, w.cs, dual_normalization, w.hdr, w.cand, CAND_BUF, stack, zstride);
     hipLaunchKernelGGL(select_emit_kernel, dim3(z), dim3(1024), 0, stream, w.hdr, w.cand, w.ridx, w.sidx, out_ref_idx,
-                       out_src_idx, out_scores, zstride, num_correspondences, CAND_BUF);
+                       out_src_idx, out_scores, zstride, num_correspondences, CAND_BUF, summary);
   } else {
     spm_select_dense(nr, ns, num_correspondences, dual_normalization, out_ref_idx, out_src_idx, out_scores, w, stream, stack,
-                     zstride, npairs);
+                     zstride, npairs, summary);
   }
   GR_LAUNCH_CHECK();
   return GR_OK;
@@ -1182,7 +1220,7 @@ extern "C" int gr_superpoint_matching(const float* ref_feats, const float* src_f
     // more ties at the threshold than the candidate buffer holds: redo the gather in flat-index order (see above)
     hipLaunchKernelGGL(select_gather_ordered_kernel, dim3(1), dim3(1024), 0, stream, w.score, w.hdr, w.cand);
     hipLaunchKernelGGL(select_emit_kernel, dim3(1), dim3(1024), 0, stream, w.hdr, w.cand, w.ridx, w.sidx, out_ref_idx,
-                       out_src_idx, out_scores, (size_t)0, 0, CAND_CAP);
+                       out_src_idx, out_scores, (size_t)0, 0, CAND_CAP, (int4*)nullptr);
     GR_LAUNCH_CHECK();
     GR_HIP(hipStreamSynchronize(stream));
   }
@@ -1209,7 +1247,8 @@ extern "C" size_t gr_superpoint_matching_batch_workspace_bytes(const int64_t* h_
   int64_t mr, ms;
   spm_max_sizes(h_node_off, npairs, &mr, &ms);
   return (size_t)std::max<int64_t>(npairs, 1) * align_up(carve_spm(nullptr, mr, ms).bytes, 256) +
-         align_up((size_t)std::max<int64_t>(npairs, 1) * sizeof(SpmStack), 256);
+         align_up((size_t)std::max<int64_t>(npairs, 1) * sizeof(SpmStack), 256) +
+         align_up((size_t)std::max<int64_t>(npairs, 1) * sizeof(int4), 256);
 }
 
 extern "C" int gr_superpoint_matching_batch(const float* feats, const int64_t* h_node_off, int64_t npairs, int64_t c,
@@ -1252,26 +1291,27 @@ extern "C" int gr_superpoint_matching_batch(const float* feats, const int64_t* h
   GR_HIP(hipMemcpyAsync(d_stack, h_stack, sizeof(SpmStack) * (size_t)npairs, hipMemcpyHostToDevice, stream));
   GR_HIP(hipEventRecord(staged, stream));
   SpmWs w = carve_spm(ws, mr, ms);  // pair 0's slice; pair z's is zstride = pair_bytes further
+  int4* d_sum = reinterpret_cast<int4*>(reinterpret_cast<char*>(d_stack) + align_up((size_t)npairs * sizeof(SpmStack), 256));
   rc = spm_launch(feats, feats, mr, ms, c, masks, masks, num_correspondences, dual_normalization, out_ref_idx, out_src_idx,
-                  out_scores, w, stream, d_stack, pair_bytes, (int)npairs);
+                  out_scores, w, stream, d_stack, pair_bytes, (int)npairs, d_sum);
   if (rc != GR_OK) return rc;
-  SpmHdr* hb = static_cast<SpmHdr*>(pinned_scratch(8, sizeof(SpmHdr) * (size_t)npairs));
+  int4* hb = static_cast<int4*>(pinned_scratch(8, sizeof(int4) * (size_t)npairs));
   GR_REQUIRE(hb != nullptr, "pinned read-back buffer could not be allocated");
-  GR_HIP(hipMemcpy2DAsync(hb, sizeof(SpmHdr), w.hdr, pair_bytes, sizeof(SpmHdr), (size_t)npairs, hipMemcpyDeviceToHost, stream));
+  GR_HIP(hipMemcpyAsync(hb, d_sum, sizeof(int4) * (size_t)npairs, hipMemcpyDeviceToHost, stream));  // (k, overflow, n_cand) per pair
   GR_HIP(hipStreamSynchronize(stream));
-  const std::vector<SpmHdr> h(hb, hb + npairs);  // (a pair redone below goes through the single-pair entry, which reuses the slot)
+  const std::vector<int4> h(hb, hb + npairs);  // (a pair redone below goes through the single-pair entry, which reuses the slot)
   for (int64_t b = 0; b < npairs; ++b) {
     const int64_t r0 = h_node_off[2 * b], nr = h_node_off[2 * b + 1] - r0, s0 = h_node_off[2 * b + 1],
                   ns = h_node_off[2 * b + 2] - s0;
     if (nr == 0 || ns == 0) continue;  // (its header says k = 0 as well)
-    if (spm_fast_ok(mr, ms, num_correspondences) ? h[b].overflow != 0 : h[b].n_cand > CAND_CAP) {
+    if (spm_fast_ok(mr, ms, num_correspondences) ? h[b].y != 0 : h[b].z > CAND_CAP) {
       rc = gr_superpoint_matching(feats + r0 * c, feats + s0 * c, nr, ns, c, masks ? masks + r0 : nullptr,
                                   masks ? masks + s0 : nullptr, num_correspondences, dual_normalization,
                                   out_ref_idx + b * num_correspondences, out_src_idx + b * num_correspondences,
                                   out_scores + b * num_correspondences, h_num_out + b, ws, pair_bytes, stream_);
       if (rc != GR_OK) return rc;
     } else {
-      h_num_out[b] = h[b].k;
+      h_num_out[b] = h[b].x;
     }
   }
   return GR_OK;
