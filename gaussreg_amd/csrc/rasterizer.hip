@@ -696,7 +696,7 @@ __global__ __launch_bounds__(TT) void tile_scatter_kernel(int P, int V, int gx, 
                                                              const int32_t* __restrict__ ids,
                                                              const float4* __restrict__ rec,
                                                              const uint32_t* __restrict__ seg_off,
-                                                             int32_t* __restrict__ point_list, unsigned int list_cap) {
+                                                             int32_t* __restrict__ point_list, unsigned int list_cap, int elist_cap) {
   // list_cap: entries the point list holds.  A speculative launch (gr_raster_forward) sizes the list before the instance
   // count is known: a chunk that would end past it writes nothing (the host then repeats the render with a larger list)
   extern __shared__ unsigned int s_cur[];  // [waves][tiles] counts -> cursors, then [stage_cap] staged chunk-local indices
@@ -713,6 +713,8 @@ __global__ __launch_bounds__(TT) void tile_scatter_kernel(int P, int V, int gx, 
   unsigned int* my = s_cur + wv * tiles;
   // staged entries are 16-bit positions inside the chunk (BIN_CHUNK <= 65536); the ids are looked up on the way out
   unsigned short* stage = reinterpret_cast<unsigned short*>(s_cur + NW * tiles);
+  // (elist_cap > 0) per wave: the (owner lane, tile) words of one 64-Gaussian step, behind the staging block
+  unsigned int* elist = s_cur + NW * tiles + (stage_cap + 1) / 2 + wv * elist_cap;
   for (int T = threadIdx.x; T < NW * tiles; T += TT) s_cur[T] = 0u;
   __syncthreads();
   const int64_t vbase = (int64_t)v * P;
@@ -818,9 +820,57 @@ __global__ __launch_bounds__(TT) void tile_scatter_kernel(int P, int V, int gx, 
           }
         }
       };
+      // Rectangles of 5 .. 8 tiles a side (large images): the 8 x 8 residue walk issues 64 rounds with a seventh of the lanes
+      // active.  Instead every lane lists its own tiles (owner lane << 16 | tile) at its offset in a per-wave LDS list, and the
+      // wave then works through the list with all lanes busy: lane i of a round holds instance i -- instances are in (owner,
+      // tile) order, so the lanes of one atomic still arrive at a tile's cursor in depth order.
+      int n_inst = 0, inc_inst = 0, t_inst = 0x7fffffff;
+      if (maxd > 4 && elist_cap > 0) {
+        n_inst = w * h;
+        inc_inst = wave_incl_scan_add_dpp(n_inst);
+        t_inst = __builtin_amdgcn_readlane(inc_inst, WAVE - 1);
+      }
       if (maxd <= 2) walk(std::integral_constant<int, 2>{});
       else if (maxd <= 4) walk(std::integral_constant<int, 4>{});
-      else walk(std::integral_constant<int, 8>{});
+      else if (t_inst > elist_cap) walk(std::integral_constant<int, 8>{});
+      else {
+        {
+          unsigned int* dst = elist + (inc_inst - n_inst);
+          const unsigned int tag = (unsigned int)lane << 16;
+          for (int dy = 0; dy < h; ++dy)
+            for (int dx = 0; dx < w; ++dx) *dst++ = tag | (unsigned int)((y0 + dy) * gx + x0 + dx);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int i0 = 0; i0 < t_inst; i0 += WAVE) {
+          const int i = i0 + lane;
+          const bool act = i < t_inst;
+          const unsigned int e = act ? elist[i] : 0u;
+          const int owner = (int)(e >> 16);
+          const unsigned int tile = e & 0xffffu;
+          const int oid = __shfl(id, owner, WAVE);
+          const int olocal = t0 + owner - c * BIN_CHUNK;
+          if (LANE_ORDERED) {
+            if (act) put(atomicAdd(&my[tile], 1u), olocal, oid);
+          } else {
+            unsigned long long peers = __ballot(act);
+            for (int bit = 0; bit < tile_bits; ++bit) {
+              const bool one = (tile >> bit) & 1u;
+              const unsigned long long bal = __ballot(one);
+              peers &= one ? bal : ~bal;
+            }
+            if (act) {
+              const unsigned int base = my[tile];
+              put(base + (unsigned int)__popcll(peers & lt), olocal, oid);
+              if ((peers >> lane) == 1ull) my[tile] = base + (unsigned int)__popcll(peers);  // last lane of the group
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+      }
     } else {
       const uint32_t pr = (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)w << 16) | ((uint32_t)h << 24);  // gx, gy <= 255
       while (live) {
@@ -1603,7 +1653,12 @@ static int render_impl(int64_t P, const gr_raster_view* h_views, int num_views, 
     if (spec) want = want > 0 ? want + 64 : cap_max;  // the hint is last frame's figure; a chunk that outgrows it writes straight
                                                       // to memory (a 25 % margin here cost a resident workgroup per CU: + 16 % scatter time)
     int stage_cap = (int)std::min<int64_t>(std::max<int64_t>(cap_max, 0), (want + 63) / 64 * 64);
-    const size_t lds = cur_bytes + (size_t)stage_cap * sizeof(unsigned short);
+    // + per wave the instance list of a step with rectangles of 5 .. 8 tiles a side (see the kernel), when it still fits
+    constexpr int ELIST = 1024;
+    const size_t base_lds = cur_bytes + ((size_t)stage_cap * sizeof(unsigned short) + 3) / 4 * 4;
+    // (only for images whose rectangles are that large: at 640 x 480 the 16 KB would cost a resident workgroup per CU)
+    const int elist_cap = tiles >= 4096 && base_lds + (size_t)(scatter_threads / WAVE) * ELIST * 4 <= 156 * 1024 ? ELIST : 0;
+    const size_t lds = base_lds + (size_t)(scatter_threads / WAVE) * elist_cap * 4;
     bool ordered = false;
     rc = lds_atomics_lane_ordered(stream, &ordered);
     if (rc != GR_OK) return rc;
@@ -1616,7 +1671,7 @@ static int render_impl(int64_t P, const gr_raster_view* h_views, int num_views, 
     {
       KernelTimer timer("raster_bin", stream);
       hipLaunchKernelGGL(kern, dim3((unsigned)bin_grid(num_views, nchunk)), dim3(scatter_threads), lds, stream, (int)P, num_views, gx, gy,
-                         nchunk, tile_bits, stage_cap, g.nvis, g.rects, g.order_b, g.rec, g.seg_off, b.point_list, list_cap);
+                         nchunk, tile_bits, stage_cap, g.nvis, g.rects, g.order_b, g.rec, g.seg_off, b.point_list, list_cap, elist_cap);
       GR_LAUNCH_CHECK();
     }
     if (!spec && verify_this_frame()) {  // first frames: every (chunk, tile) segment in depth order?
@@ -1634,7 +1689,7 @@ static int render_impl(int64_t P, const gr_raster_view* h_views, int num_views, 
           GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_b), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         hipLaunchKernelGGL(kern_b, dim3((unsigned)bin_grid(num_views, nchunk)), dim3(scatter_threads), lds, stream, (int)P,
                            num_views, gx, gy, nchunk, tile_bits, stage_cap, g.nvis, g.rects, g.order_b, g.rec, g.seg_off,
-                           b.point_list, list_cap);
+                           b.point_list, list_cap, elist_cap);
         GR_LAUNCH_CHECK();
       } else {
         GR_REQUIRE(h_bad == 0, "tile binning produced an unsorted list (internal error)");
