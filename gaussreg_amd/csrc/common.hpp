@@ -143,7 +143,12 @@ void lds_order_demote();                // a sort that relied on the property ca
 size_t depth_sort_table_bytes(int64_t P, int V);
 int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* keys_a, uint64_t* keys_b, int32_t* ids_out,
                      uint32_t* rect_out, int32_t* nvalid_out, int64_t P, int V, int key_bits, void* table, size_t table_bytes,
-                     hipStream_t stream);
+                     hipStream_t stream, const int2* key_mm = nullptr, int nb_mm = 0, int32_t* overflow_flag = nullptr,
+                     int overflow_value = 0);
+// key_mm != null: the four-launch path for a few views per call (top-digit pass + in-LDS bucket sort): key_mm = [V][nb_mm]
+// {smallest, largest} non-zero field of a block of Gaussians (0x7fffffff / 0 for a block without one); a bucket that does
+// not fit stores overflow_value into *overflow_flag and the order is then NOT valid -- repeat with key_mm = null.
+bool depth_sort_msd_possible(int64_t P, int V, int key_bits);
 
 // Optional per-kernel HIP-event timing (off by default; bench.py turns it on to measure the
 // dominant kernel's average launch duration on the stream it is launched on).

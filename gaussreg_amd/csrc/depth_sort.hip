@@ -25,6 +25,15 @@
 //   * with >= 8 views all chunks of a view run on one XCD (block b sits on XCD b % 8): the 512 write frontiers of a view
 //     stay in that XCD's L2.
 // Per pass: count (per-chunk digit histogram) -> scan (prefix over the chunks of a view, digit bases) -> scatter.
+//
+// Few views per call (one camera: the launch chain IS the frame time, nine launches of 5-9 us): ONE such pass on the TOP
+// bits, then one launch that finishes every bucket inside LDS ("MSD" below, four launches).  The top digit is taken
+// relative to the view's own key range -- bucket = (key - kmin) >> s with s = bits(kmax - kmin) - 9, from the per-block
+// minima / maxima the preprocess kernel leaves -- so the 512 buckets cover exactly the depths that occur; what is left of
+// a key is s <= 18 bits.  A bucket (a contiguous run of <= MSD_CAP words, already in id order) becomes 32-bit items
+// [rest (s bits) | position in the bucket (14 bits)] -- all distinct, so plain integer order of the items IS (key, id)
+// order -- sorted by one or two stable 9-bit passes between two LDS buffers, then the words are fetched in that order.
+// A bucket above MSD_CAP raises a flag: the caller repeats the frame with the three-pass sort.
 #include <type_traits>
 
 #include "common.hpp"
@@ -53,15 +62,53 @@ __device__ __forceinline__ bool ds_block(int V, int nchunk, int& v, int& c) {
 }
 inline int ds_grid(int V, int nchunk) { return V >= 8 ? 8 * ((V + 7) / 8) * nchunk : V * nchunk; }
 
+constexpr int MSD_T = 512;         // threads of a bucket workgroup
+constexpr int MSD_NW = MSD_T / WAVE;
+constexpr int MSD_IDX_BITS = 14;
+constexpr int MSD_CAP = 7936;      // items per bucket: 2 x 31 KB of items + 16 KB of counters -> two workgroups per CU
+constexpr int MSD_STEPS = (MSD_CAP + MSD_T - 1) / MSD_T;  // 64-item steps of a wave (its share of the bucket)
+static_assert(MSD_CAP <= (1 << MSD_IDX_BITS), "bucket positions must fit the item's index field");
+static_assert(MSD_T == DS_BINS, "the bucket kernel scans the digits with one thread each");
+
 // FIRST: the source is the raw key array (all P entries of the view, culled ones have a zero depth field)
-template <bool FIRST>
+// MSD (with FIRST): the digit is the top of the key relative to the view's range; every block derives the range from the
+// per-block minima / maxima of the preprocess kernel (key_mm: [V][nb_mm] {min, max}, 0x7fffffff / 0 for an empty block)
+// and the first one of a view leaves {kmin, s} in range[v] for the launches behind this one.
+template <bool FIRST, bool MSD>
 __global__ __launch_bounds__(DS_T) void ds_count_kernel(int P, int V, int nchunk, const int32_t* __restrict__ nvalid,
                                                         const uint32_t* __restrict__ field, const uint64_t* __restrict__ keys,
-                                                        int word_shift, uint32_t dmask, uint16_t* __restrict__ hist) {
+                                                        int word_shift, uint32_t dmask, uint16_t* __restrict__ hist,
+                                                        const int2* __restrict__ key_mm, int nb_mm,
+                                                        uint32_t* __restrict__ range) {
   __shared__ unsigned int s_h[DS_BINS];
+  __shared__ int s_mm[2][DS_NW];
   int v, c;
   if (!ds_block(V, nchunk, v, c)) return;
   for (int d = threadIdx.x; d < DS_BINS; d += DS_T) s_h[d] = 0u;
+  uint32_t kmin = 0u;
+  int sh = 0;
+  if (MSD) {
+    int mn = 0x7fffffff, mx = 0;
+    const int2* row = key_mm + (int64_t)v * nb_mm;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < nb_mm; i += DS_T) {
+      const int2 m = row[i];
+      mn = min(mn, m.x);
+      mx = max(mx, m.y);
+    }
+    mn = wave_min_i32_dpp(mn);
+    mx = wave_max_i32_dpp(mx);
+    if ((threadIdx.x & (WAVE - 1)) == 0) s_mm[0][threadIdx.x / WAVE] = mn, s_mm[1][threadIdx.x / WAVE] = mx;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < DS_NW; ++w) mn = min(mn, s_mm[0][w]), mx = max(mx, s_mm[1][w]);
+    if (mx == 0) mn = 0;  // nothing visible
+    kmin = (uint32_t)mn;
+    const uint32_t span = (uint32_t)(mx - mn);
+    sh = max(0, 32 - __clz((int)span) - DS_BITS);  // span < 2^(sh + 9)
+    if (span == 0u) sh = 0;
+    if (c == 0 && threadIdx.x == 0) range[2 * v] = kmin, range[2 * v + 1] = (uint32_t)sh;
+  }
   __syncthreads();
   const int n = FIRST ? P : nvalid[v];
   const int64_t vbase = (int64_t)v * P;
@@ -76,7 +123,7 @@ __global__ __launch_bounds__(DS_T) void ds_count_kernel(int P, int V, int nchunk
     if (FIRST) {
       const uint32_t f = field[vbase + tc];
       have[it] = t < n && f != 0u;
-      dg[it] = f & dmask;
+      dg[it] = MSD ? ((f - kmin) >> sh) & dmask : f & dmask;  // (the mask only matters for culled entries: never counted)
     } else {
       have[it] = t < n;
       dg[it] = (uint32_t)(keys[vbase + tc] >> word_shift) & dmask;
@@ -145,7 +192,8 @@ __global__ __launch_bounds__(DS_SCAN_NW* WAVE) void ds_scan_kernel(int nchunk, c
 // FIRST: raw 4-byte fields (compaction, word assembly).  LAST: writes the id and the rectangle.
 // id_bits > 0: packed words [field >> 9 | id (id_bits) | rectangle (26)]; id_bits == 0: (field << 32 | id) words.
 // word_shift: where this pass's digit sits in the word (passes after the first).
-template <bool FIRST, bool LAST, bool LANE_ORDERED>
+// MSD (FIRST, not LAST): digit = (field - kmin) >> s, the word keeps the s bits below it (range[v] = {kmin, s}).
+template <bool FIRST, bool LAST, bool LANE_ORDERED, bool MSD = false>
 __global__ __launch_bounds__(DS_T) void ds_scatter_kernel(int P, int V, int nchunk, const int32_t* __restrict__ nvalid,
                                                           const uint32_t* __restrict__ field,
                                                           const uint64_t* __restrict__ keys_in, int word_shift, int id_bits,
@@ -154,7 +202,9 @@ __global__ __launch_bounds__(DS_T) void ds_scatter_kernel(int P, int V, int nchu
                                                           const int32_t* __restrict__ digit_total,
                                                           uint64_t* __restrict__ keys_out, const uint32_t* __restrict__ rect_raw,
                                                           uint32_t* __restrict__ rect_out, int32_t* __restrict__ ids_out,
-                                                          int32_t* __restrict__ nvalid_out) {
+                                                          int32_t* __restrict__ nvalid_out,
+                                                          const uint32_t* __restrict__ range) {
+  static_assert(!MSD || (FIRST && !LAST), "the top-digit pass is a first pass with another launch behind it");
   __shared__ unsigned int s_cnt[DS_NW][DS_BINS];  // per-wave digit counters -> per-wave bases
   __shared__ int s_delta[DS_BINS];                // global position of a digit's run minus its chunk-local start
   __shared__ int s_w[DS_T / WAVE];
@@ -166,6 +216,8 @@ __global__ __launch_bounds__(DS_T) void ds_scatter_kernel(int P, int V, int nchu
   const int n = FIRST ? P : nvalid[v];
   if (c * DS_CHUNK >= n) return;
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  const uint32_t kmin = MSD ? range[2 * v] : 0u;
+  const int sh = MSD ? (int)range[2 * v + 1] : 0;
   for (int i = threadIdx.x; i < DS_NW * DS_BINS; i += DS_T) (&s_cnt[0][0])[i] = 0u;
   __syncthreads();
   // ---- phase 1: wave w takes positions [w * 512, (w + 1) * 512) of the chunk, 64 at a time in order
@@ -194,9 +246,15 @@ __global__ __launch_bounds__(DS_T) void ds_scatter_kernel(int P, int V, int nchu
       const uint32_t f = fv[j];
       const uint32_t rct = rv[j];
       present[j] = t < n && f != 0u;
-      digit[j] = (unsigned short)(f & dmask);
-      key[j] = id_bits > 0 ? ((uint64_t)(f >> DS_BITS) << (id_bits + 26)) | ((uint64_t)(uint32_t)t << 26) | rct
-                           : ((uint64_t)f << 32) | (uint32_t)t;
+      if (MSD) {
+        const uint32_t rel = f - kmin;
+        digit[j] = (unsigned short)((rel >> sh) & dmask);
+        key[j] = ((uint64_t)(rel & ((1u << sh) - 1u)) << (id_bits + 26)) | ((uint64_t)(uint32_t)t << 26) | rct;
+      } else {
+        digit[j] = (unsigned short)(f & dmask);
+        key[j] = id_bits > 0 ? ((uint64_t)(f >> DS_BITS) << (id_bits + 26)) | ((uint64_t)(uint32_t)t << 26) | rct
+                             : ((uint64_t)f << 32) | (uint32_t)t;
+      }
     } else {
       key[j] = keys_in[vbase + tc];
       present[j] = t < n;
@@ -301,20 +359,145 @@ __global__ __launch_bounds__(DS_T) void ds_scatter_kernel(int P, int V, int nchu
   }
 }
 
+// One workgroup per (view, bucket of the top-digit pass): the bucket's words -- a contiguous run of keys[], in id order --
+// leave in (rest of the key, id) order as ids + rectangles.
+template <bool LANE_ORDERED>
+__global__ __launch_bounds__(MSD_T) void ds_bucket_sort_kernel(int P, const int32_t* __restrict__ digit_total,
+                                                               const uint32_t* __restrict__ range,
+                                                               const uint64_t* __restrict__ keys, int id_bits,
+                                                               int32_t* __restrict__ ids_out, uint32_t* __restrict__ rect_out,
+                                                               int32_t* __restrict__ flag, int flag_value) {
+  __shared__ unsigned int s_cnt[MSD_NW][DS_BINS];
+  __shared__ uint32_t s_item[2][MSD_CAP];
+  __shared__ int s_w[MSD_NW];
+  const int v = blockIdx.y, d = blockIdx.x;
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  const int32_t* trow = digit_total + v * DS_BINS;
+  const int n = trow[d];
+  if (n == 0) return;
+  // where the bucket starts: the totals of the digits below (512 threads, one digit each)
+  {
+    const int mine = (int)threadIdx.x < d ? trow[threadIdx.x] : 0;
+    const int ws = wave_sum_i32_dpp(mine);
+    if (lane == 0) s_w[wv] = ws;
+  }
+  __syncthreads();
+  int start = 0;
+#pragma unroll
+  for (int w = 0; w < MSD_NW; ++w) start += s_w[w];
+  const int sh = (int)range[2 * v + 1];
+  const int64_t base = (int64_t)v * P + start;
+  const uint32_t idmask = (1u << id_bits) - 1u;
+  if (sh == 0 || n == 1) {  // equal keys: id order is the order
+    for (int i = threadIdx.x; i < n; i += MSD_T) {
+      const uint64_t k = keys[base + i];
+      ids_out[base + i] = (int32_t)((uint32_t)(k >> 26) & idmask);
+      rect_out[base + i] = (uint32_t)k & 0x3ffffffu;
+    }
+    return;
+  }
+  if (n > MSD_CAP) {
+    if (threadIdx.x == 0) *flag = flag_value;
+    return;
+  }
+  for (int i = threadIdx.x; i < n; i += MSD_T)
+    s_item[0][i] = ((uint32_t)(keys[base + i] >> (id_bits + 26)) << MSD_IDX_BITS) | (uint32_t)i;
+  // a wave's share of the bucket: whole 64-item steps
+  const int seg = ((n + MSD_NW - 1) / MSD_NW + WAVE - 1) / WAVE * WAVE;
+  const int w0 = wv * seg, w1 = min(n, w0 + seg);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int cur = 0;
+  for (int shift = MSD_IDX_BITS; shift < MSD_IDX_BITS + sh; shift += DS_BITS) {
+    const uint32_t dmask = (1u << min(DS_BITS, MSD_IDX_BITS + sh - shift)) - 1u;
+    for (int i = threadIdx.x; i < MSD_NW * DS_BINS; i += MSD_T) (&s_cnt[0][0])[i] = 0u;
+    __syncthreads();  // (also: the items of the previous round are in place)
+    const uint32_t* src = s_item[cur];
+    uint32_t* dst = s_item[cur ^ 1];
+    int rank[MSD_STEPS];
+#pragma unroll
+    for (int j = 0; j < MSD_STEPS; ++j) {
+      rank[j] = -1;
+      if (w0 + j * WAVE >= w1) continue;  // wave-uniform
+      const int i = w0 + j * WAVE + lane;
+      const bool have = i < w1;
+      const uint32_t dg = have ? (src[i] >> shift) & dmask : 0u;
+      if (LANE_ORDERED) {
+        if (have) rank[j] = (int)atomicAdd(&s_cnt[wv][dg], 1u);
+      } else {
+        unsigned long long peers = __ballot(have);
+#pragma unroll
+        for (int bit = 0; bit < DS_BITS; ++bit) {
+          const bool one = (dg >> bit) & 1u;
+          const unsigned long long bal = __ballot(one);
+          peers &= one ? bal : ~bal;
+        }
+        if (have) {
+          const unsigned int b0 = s_cnt[wv][dg];
+          rank[j] = (int)(b0 + (unsigned int)__popcll(peers & lt));
+          if ((peers >> lane) == 1ull) s_cnt[wv][dg] = b0 + (unsigned int)__popcll(peers);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+    __syncthreads();
+    // digit starts (thread = digit) and the waves' bases inside a digit's run
+    {
+      unsigned int cw[MSD_NW];
+      int tot = 0;
+#pragma unroll
+      for (int w = 0; w < MSD_NW; ++w) {
+        cw[w] = s_cnt[w][threadIdx.x];
+        tot += (int)cw[w];
+      }
+      const int incl = wave_incl_scan_add_dpp(tot);
+      if (lane == WAVE - 1) s_w[wv] = incl;
+      __syncthreads();
+      int run = incl - tot;
+      for (int w = 0; w < wv; ++w) run += s_w[w];
+#pragma unroll
+      for (int w = 0; w < MSD_NW; ++w) {
+        s_cnt[w][threadIdx.x] = (unsigned int)run;
+        run += (int)cw[w];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MSD_STEPS; ++j)
+      if (rank[j] >= 0) {
+        const uint32_t it = src[w0 + j * WAVE + lane];
+        dst[s_cnt[wv][(it >> shift) & dmask] + (unsigned int)rank[j]] = it;
+      }
+    cur ^= 1;
+    __syncthreads();  // the bases are read to the end before the next round clears them; the items are in place
+  }
+  for (int j = threadIdx.x; j < n; j += MSD_T) {
+    const uint64_t k = keys[base + (s_item[cur][j] & ((1u << MSD_IDX_BITS) - 1u))];
+    ids_out[base + j] = (int32_t)((uint32_t)(k >> 26) & idmask);
+    rect_out[base + j] = (uint32_t)k & 0x3ffffffu;
+  }
+}
+
 }  // namespace
 
 size_t depth_sort_table_bytes(int64_t P, int V) {
   const int64_t nchunk = (P + DS_CHUNK - 1) / DS_CHUNK;
   return align_up((size_t)V * nchunk * DS_BINS * sizeof(uint16_t), 256) +
          align_up((size_t)V * nchunk * DS_BINS * sizeof(uint32_t), 256) + align_up((size_t)V * DS_BINS * sizeof(int32_t), 256) +
-         256;
+         align_up((size_t)V * 2 * sizeof(uint32_t), 256) + 256;
+}
+
+bool depth_sort_msd_possible(int64_t P, int V, int key_bits) {
+  // the word holds [<= 18 rest bits | id | 26 rectangle bits]; few views only (with many the launches are not the cost)
+  return V <= 4 && P <= (1ll << 20) && key_bits <= 2 * DS_BITS + DS_BITS;
 }
 
 // field, rect_raw: [V*P] per (view, Gaussian), left untouched.  keys_a, keys_b: [V*P] scratch.  Out: ids_out / rect_out
 // [V*P] (the first nvalid_out[v] entries of every view's stride-P segment), nvalid_out [V] on the device.
 int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* keys_a, uint64_t* keys_b, int32_t* ids_out,
                      uint32_t* rect_out, int32_t* nvalid_out, int64_t P, int V, int key_bits, void* table, size_t table_bytes,
-                     hipStream_t stream) {
+                     hipStream_t stream, const int2* key_mm, int nb_mm, int32_t* overflow_flag, int overflow_value) {
   if (P <= 0 || V <= 0) return GR_OK;
   GR_REQUIRE(key_bits >= 1 && key_bits <= 32, "depth_sort: key_bits %d out of range", key_bits);
   GR_REQUIRE(table && table_bytes >= depth_sort_table_bytes(P, V), "depth_sort: table too small");
@@ -323,6 +506,7 @@ int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* 
   uint16_t* hist = cv.take<uint16_t>((size_t)V * nchunk * DS_BINS);
   uint32_t* offs = cv.take<uint32_t>((size_t)V * nchunk * DS_BINS);
   int32_t* dbase = cv.take<int32_t>((size_t)V * DS_BINS);
+  uint32_t* range = cv.take<uint32_t>((size_t)V * 2);
   bool ordered = false;
   int rc = lds_atomics_lane_ordered(stream, &ordered);
   if (rc != GR_OK) return rc;
@@ -330,6 +514,31 @@ int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* 
   const dim3 grid((unsigned)ds_grid(V, nchunk)), blk(DS_T);
   int id_bits = 1;
   while (id_bits < 32 && (1ll << id_bits) < P) ++id_bits;
+  if (key_mm != nullptr) {  // top-digit pass + one launch over the buckets (see the head of this file)
+    GR_REQUIRE(depth_sort_msd_possible(P, V, key_bits) && overflow_flag != nullptr && nb_mm > 0, "depth_sort: bucket path misused");
+    const uint32_t dmask = DS_BINS - 1;
+    hipLaunchKernelGGL((ds_count_kernel<true, true>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field,
+                       (const uint64_t*)nullptr, 0, dmask, hist, key_mm, nb_mm, range);
+    hipLaunchKernelGGL(ds_scan_kernel, dim3((unsigned)(V * (DS_BINS / WAVE))), dim3(DS_SCAN_NW * WAVE), 0, stream, nchunk, hist,
+                       offs, dbase);
+    if (ordered)
+      hipLaunchKernelGGL((ds_scatter_kernel<true, false, true, true>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field,
+                         (const uint64_t*)nullptr, 0, id_bits, dmask, offs, dbase, keys_a, rect_raw, rect_out, ids_out, nvalid_out,
+                         range);
+    else
+      hipLaunchKernelGGL((ds_scatter_kernel<true, false, false, true>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field,
+                         (const uint64_t*)nullptr, 0, id_bits, dmask, offs, dbase, keys_a, rect_raw, rect_out, ids_out, nvalid_out,
+                         range);
+    const dim3 bgrid(DS_BINS, (unsigned)V);
+    if (ordered)
+      hipLaunchKernelGGL(ds_bucket_sort_kernel<true>, bgrid, dim3(MSD_T), 0, stream, (int)P, dbase, range, keys_a, id_bits, ids_out,
+                         rect_out, overflow_flag, overflow_value);
+    else
+      hipLaunchKernelGGL(ds_bucket_sort_kernel<false>, bgrid, dim3(MSD_T), 0, stream, (int)P, dbase, range, keys_a, id_bits, ids_out,
+                         rect_out, overflow_flag, overflow_value);
+    GR_LAUNCH_CHECK();
+    return GR_OK;
+  }
   const int rest_bits = std::max(0, key_bits - DS_BITS);  // field bits still to be sorted after the first pass
   const bool packed = rest_bits + id_bits + 26 <= 64;
   if (!packed) id_bits = 0;
@@ -343,16 +552,17 @@ int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* 
     const uint64_t* kin = first ? nullptr : kbuf[(p + 1) % 2];
     uint64_t* kout = kbuf[p % 2];
     if (first)
-      hipLaunchKernelGGL(ds_count_kernel<true>, grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field, kin, word_shift,
-                         dmask, hist);
+      hipLaunchKernelGGL((ds_count_kernel<true, false>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field, kin,
+                         word_shift, dmask, hist, (const int2*)nullptr, 0, (uint32_t*)nullptr);
     else
-      hipLaunchKernelGGL(ds_count_kernel<false>, grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field, kin, word_shift,
-                         dmask, hist);
+      hipLaunchKernelGGL((ds_count_kernel<false, false>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field, kin,
+                         word_shift, dmask, hist, (const int2*)nullptr, 0, (uint32_t*)nullptr);
     hipLaunchKernelGGL(ds_scan_kernel, dim3((unsigned)(V * (DS_BINS / WAVE))), dim3(DS_SCAN_NW * WAVE), 0, stream, nchunk, hist,
                        offs, dbase);
 #define GR_DS_SCATTER(F, L, O)                                                                                            \
   hipLaunchKernelGGL((ds_scatter_kernel<F, L, O>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field, kin, \
-                     word_shift, id_bits, dmask, offs, dbase, kout, rect_raw, rect_out, ids_out, first ? nvalid_out : nullptr)
+                     word_shift, id_bits, dmask, offs, dbase, kout, rect_raw, rect_out, ids_out, first ? nvalid_out : nullptr, \
+                     (const uint32_t*)nullptr)
     if (ordered) {
       if (first && last) GR_DS_SCATTER(true, true, true);
       else if (first) GR_DS_SCATTER(true, false, true);

@@ -198,6 +198,7 @@ struct Geom {
   int32_t* chunk_max;    // [1] largest chunk total
   void* ds_table;        // depth-sort histograms / offsets
   size_t ds_table_bytes;
+  int2* key_mm;          // [V][ceil(P / 256)] smallest / largest depth field of a preprocess block (few views per call only)
   int32_t* nvis;         // [V] visible (depth-ordered) Gaussians per view
   int32_t* totals;       // [V] instances per view, [V] largest chunk total of every view, [1] depth-overflow flag, [3] pad --
   DevView* views;        // -- immediately followed by the [MAX_VIEWS] camera table: ONE upload clears the flag and sets the cameras
@@ -226,6 +227,7 @@ Geom carve_geom(void* p, int64_t P, int V, int64_t tiles) {
   g.chunk_max = c.take<int32_t>(1);
   g.ds_table_bytes = depth_sort_table_bytes(P, V);
   g.ds_table = c.take<char>(g.ds_table_bytes);
+  g.key_mm = c.take<int2>((V <= 4 ? V : 0) * ((P + 255) / 256));
   g.nvis = c.take<int32_t>(V);
   g.totals = c.take<int32_t>(2 * V + 4 + MAX_VIEWS * (sizeof(DevView) / sizeof(int32_t)));
   g.views = reinterpret_cast<DevView*>(g.totals ? g.totals + 2 * V + 4 : nullptr);
@@ -280,7 +282,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const float* __restrict__ opacities, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, int W, int H,
     int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ dfield,
-    uint32_t* __restrict__ rect_raw, int32_t* __restrict__ far_flag, DevView cam1, int far_seq) {
+    uint32_t* __restrict__ rect_raw, int32_t* __restrict__ far_flag, DevView cam1, int far_seq,
+    int2* __restrict__ key_mm) {
   // LATE (one camera per call): the camera arrives in the kernel arguments `cam1` (no upload in front of the frame); the first
   // block leaves it in `views` for the kernels behind this one.  far_seq: the value a far depth stores into *far_flag
   // (a per-call stamp when nobody cleared the flag, else 1).
@@ -288,6 +291,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     reinterpret_cast<float*>(const_cast<DevView*>(views))[threadIdx.x] = reinterpret_cast<const float*>(&cam1)[threadIdx.x];
   __shared__ float4 s_sh[(SH16 && !LATE) ? WAVE * SH_ROW : 1];
   __shared__ float4 s_rec[256 / WAVE][4 * REC_PLANE];
+  __shared__ int s_mm[2][2][256 / WAVE];  // [view parity][min, max][wave]
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   float shr[SH16 ? 48 : 1];
   if (SH16 && !LATE) {
@@ -453,6 +457,18 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
       radii[o] = out_radius;
       dfield[o] = out_field;
       rect_raw[o] = out_rect;
+    }
+    if (key_mm != nullptr) {  // the block's key range of this view, for the bucket sort (depth_sort.hip)
+      const uint32_t fld = valid ? out_field : 0u;
+      const int mn = wave_min_i32_dpp(fld != 0u ? (int)fld : 0x7fffffff), mx = wave_max_i32_dpp((int)fld);
+      if (lane == 0) s_mm[v & 1][0][threadIdx.x / WAVE] = mn, s_mm[v & 1][1][threadIdx.x / WAVE] = mx;
+      __syncthreads();  // (one barrier per view: the other half of s_mm is the one the next view writes)
+      if (threadIdx.x == 0) {
+        int bmn = 0x7fffffff, bmx = 0;
+#pragma unroll
+        for (int w = 0; w < 256 / WAVE; ++w) bmn = min(bmn, s_mm[v & 1][0][w]), bmx = max(bmx, s_mm[v & 1][1][w]);
+        key_mm[(int64_t)v * gridDim.x + blockIdx.x] = make_int2(bmn, bmx);
+      }
     }
     // The wave's 64 records (4 KB, contiguous) leave through LDS: lane l stores piece l % 4 of record 16 k + l / 4 in
     // store k, so every store instruction covers whole lines.  (Each lane writing its own record piece by piece costs four
@@ -1343,6 +1359,17 @@ extern "C" size_t gr_raster_geom_bytes(int64_t P, int num_views, int width, int 
   return carve_geom(nullptr, P, num_views, tiles_of(width, height)).bytes;
 }
 
+extern "C" int gr_raster_debug_geom_layout(int64_t P, int num_views, int width, int height, int64_t* h_offsets) {
+  GR_REQUIRE(P >= 0 && num_views >= 1 && width > 0 && height > 0 && h_offsets != nullptr, "bad argument");
+  char* const origin = reinterpret_cast<char*>(uintptr_t(1) << 32);  // never dereferenced: the carver only adds to it
+  const Geom g = carve_geom(origin, P, num_views, tiles_of(width, height));
+  h_offsets[0] = reinterpret_cast<char*>(g.dfield) - origin;
+  h_offsets[1] = reinterpret_cast<char*>(g.order_b) - origin;
+  h_offsets[2] = reinterpret_cast<char*>(g.rects) - origin;
+  h_offsets[3] = reinterpret_cast<char*>(g.nvis) - origin;
+  return 4;
+}
+
 extern "C" size_t gr_raster_bin_bytes(int64_t total_rendered, int width, int height, int num_views) {
   if (total_rendered < 0 || width <= 0 || height <= 0 || num_views < 1) return 0;
   return carve_bin(nullptr, total_rendered, tiles_of(width, height) * num_views).bytes;
@@ -1356,8 +1383,10 @@ struct Deferred {
   hipEvent_t ev;
   volatile int32_t* mail;  // [V] totals, [V] chunk maxima, [1] far word, [V] stamps
   int seq;                 // this frame's stamp (never 0)
-  int far_seq;             // the far word equals this value iff a depth overflowed the compact keys
+  int far_seq;             // the far word equals this value iff a depth overflowed the compact keys (and its negative iff a
+                           // bucket of the four-launch depth sort did not fit: the order is then not valid either)
   bool by_mail;            // out: which of the two ways this frame took
+  bool bucket_sort;        // in: take the four-launch depth sort
 };
 
 // defer_ev != nullptr: everything is enqueued, the read-back of the counts is followed by this event instead of a stream
@@ -1422,15 +1451,21 @@ static int preprocess_impl(int64_t P, int M, const float* means3D, const float* 
     if (rc != GR_OK) return rc;
   }
   if (defer_ev != nullptr) defer_ev->far_seq = far_seq;
+  // a deferred frame of a few views: the four-launch depth sort (a bucket that outgrows LDS raises the far word with the
+  // sign flipped; the caller then takes the plain path, which always sorts in three passes)
+  const bool msd = defer_ev != nullptr && defer_ev->bucket_sort && depth_sort_msd_possible(P, num_views, KEY_DEPTH_BITS);
+  int2* const mm_out = msd ? g.key_mm : nullptr;
 #define GR_PRE(SH, COV, S16)                                                                       \
   if (S16 && num_views == 1)                                                                       \
     hipLaunchKernelGGL((preprocess_kernel<SH, COV, S16, S16>), grd, blk, 0, stream, (int)P, D, M, num_views, \
                        g.views, means3D, shs, colors_precomp, opacities, scales, rotations,        \
-                       cov3D_precomp, W, H, radii, g.rec, g.dfield, g.rect_raw, g.totals + 2 * num_views, cam1, far_seq); \
+                       cov3D_precomp, W, H, radii, g.rec, g.dfield, g.rect_raw, g.totals + 2 * num_views, cam1, far_seq, \
+                       mm_out);                                                                    \
   else                                                                                             \
   hipLaunchKernelGGL((preprocess_kernel<SH, COV, S16, false>), grd, blk, 0, stream, (int)P, D, M, num_views, \
                      g.views, means3D, shs, colors_precomp, opacities, scales, rotations,          \
-                     cov3D_precomp, W, H, radii, g.rec, g.dfield, g.rect_raw, g.totals + 2 * num_views, cam1, far_seq)
+                     cov3D_precomp, W, H, radii, g.rec, g.dfield, g.rect_raw, g.totals + 2 * num_views, cam1, far_seq, \
+                     mm_out)
   auto run_preprocess = [&]() {
     KernelTimer timer("raster_preprocess", stream);
     if (shs && cov3D_precomp) { if (sh16) GR_PRE(true, true, true); else GR_PRE(true, true, false); }
@@ -1449,7 +1484,8 @@ static int preprocess_impl(int64_t P, int M, const float* means3D, const float* 
       KernelTimer timer("raster_depth_sort", stream);
       // visible Gaussians of every view in depth order (ties: Gaussian id): ids -> order_b, rectangles -> rects
       int rcs = depth_sort_views(g.dfield, g.rect_raw, g.keys_a, g.keys_b, g.order_b, g.rects, g.nvis, P, num_views, key_bits,
-                                 g.ds_table, g.ds_table_bytes, stream);
+                                 g.ds_table, g.ds_table_bytes, stream, msd && key_bits == KEY_DEPTH_BITS ? g.key_mm : nullptr,
+                                 (int)((P + 255) / 256), g.totals + 2 * num_views, -far_seq);
       if (rcs != GR_OK) return rcs;
     }
     {
@@ -1569,7 +1605,10 @@ extern "C" int gr_raster_preprocess(int64_t P, int M, const float* means3D, cons
 
 // waits for the counts of a deferred preprocess_impl (mailbox stamps or the event): counts -> h_num_rendered;
 // *far_depth = the depth-overflow flag
-static int preprocess_collect(int64_t P, int num_views, int64_t* h_num_rendered, bool* far_depth, Deferred& d, hipStream_t stream) {
+// (also set when a bucket of the four-launch depth sort overflowed -- either way the frame has to be redone on the plain
+// path; *bucket_overflow tells the two apart)
+static int preprocess_collect(int64_t P, int num_views, int64_t* h_num_rendered, bool* far_depth, Deferred& d, hipStream_t stream,
+                              bool* bucket_overflow = nullptr) {
   const int nchunk = (int)((P + BIN_CHUNK - 1) / BIN_CHUNK);
   if (d.by_mail) {
     const volatile int32_t* m = d.mail;
@@ -1593,7 +1632,8 @@ static int preprocess_collect(int64_t P, int num_views, int64_t* h_num_rendered,
     }
     for (int v = 0; v < num_views; ++v) h_num_rendered[v] = m[v];
     h_num_rendered[num_views] = cm;
-    *far_depth = m[2 * num_views] == d.far_seq;
+    *far_depth = m[2 * num_views] == d.far_seq || m[2 * num_views] == -d.far_seq;
+    if (bucket_overflow) *bucket_overflow = m[2 * num_views] == -d.far_seq;
     return GR_OK;
   }
   GR_HIP(hipEventSynchronize(d.ev));
@@ -1606,6 +1646,7 @@ static int preprocess_collect(int64_t P, int num_views, int64_t* h_num_rendered,
   for (int v = 0; v < num_views; ++v) h_num_rendered[v] = tot[v];
   h_num_rendered[num_views] = cm;
   *far_depth = tot[2 * num_views] != 0;
+  if (bucket_overflow) *bucket_overflow = tot[2 * num_views] < 0;
   return GR_OK;
 }
 
@@ -1731,7 +1772,11 @@ struct Pending {  // a gr_raster_forward(GR_RASTER_SPLIT) of this thread whose c
   Deferred d;
   hipStream_t stream;
 };
-thread_local Pending g_pending{false, 0, 0, 0, Deferred{nullptr, nullptr, 0, 0, false}, nullptr};
+thread_local Pending g_pending{false, 0, 0, 0, Deferred{nullptr, nullptr, 0, 0, false, false}, nullptr};
+// frames left before the four-launch depth sort is tried again after one of its buckets overflowed (a scene whose depths
+// crowd into a sliver of the key range: every frame would be drawn twice)
+thread_local int g_bucket_cooldown = 0;
+constexpr int BUCKET_COOLDOWN_FRAMES = 256;
 }  // namespace
 }  // namespace gr
 
@@ -1741,9 +1786,10 @@ extern "C" int gr_raster_forward_finish(int64_t* h_num_rendered) {
   GR_REQUIRE(h_num_rendered != nullptr, "h_num_rendered is null");
   Pending p = g_pending;
   g_pending.open = false;
-  bool far_depth = false;
-  int rc = preprocess_collect(p.P, p.num_views, h_num_rendered, &far_depth, p.d, p.stream);
+  bool far_depth = false, bucket_overflow = false;
+  int rc = preprocess_collect(p.P, p.num_views, h_num_rendered, &far_depth, p.d, p.stream, &bucket_overflow);
   if (rc != GR_OK) return rc;
+  if (bucket_overflow) g_bucket_cooldown = BUCKET_COOLDOWN_FRAMES;
   int64_t R = 0;
   for (int v = 0; v < p.num_views; ++v) R += h_num_rendered[v];
   if (far_depth) return GR_RETRY_FULL;
@@ -1786,7 +1832,8 @@ extern "C" int gr_raster_forward(int64_t P, int M, const float* means3D, const f
       frame_seq.store(1);
       seq = 1;
     }
-    Deferred d{ev, mail, seq, 1, false};
+    if (g_bucket_cooldown > 0) --g_bucket_cooldown;
+    Deferred d{ev, mail, seq, 1, false, g_bucket_cooldown == 0};
     int rc = preprocess_impl(P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, h_views,
                              num_views, radii, geom, geom_bytes, h_num_rendered, stream, &d);
     if (rc != GR_OK) return rc;
@@ -1797,9 +1844,10 @@ extern "C" int gr_raster_forward(int64_t P, int M, const float* means3D, const f
       g_pending = Pending{true, P, num_views, entries, d, stream};
       return GR_PENDING;
     }
-    bool far_depth = false;
-    rc = preprocess_collect(P, num_views, h_num_rendered, &far_depth, d, stream);
+    bool far_depth = false, bucket_overflow = false;
+    rc = preprocess_collect(P, num_views, h_num_rendered, &far_depth, d, stream, &bucket_overflow);
     if (rc != GR_OK) return rc;
+    if (bucket_overflow) g_bucket_cooldown = BUCKET_COOLDOWN_FRAMES;
     int64_t R = 0;
     for (int v = 0; v < num_views; ++v) R += h_num_rendered[v];
     if (!far_depth) return R <= entries ? GR_OK : GR_RETRY_BIN;

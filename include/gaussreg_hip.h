@@ -173,6 +173,10 @@ typedef struct gr_raster_view {
 } gr_raster_view;
 
 size_t gr_raster_geom_bytes(int64_t P, int num_views, int width, int height);
+/* Test hook: byte offsets inside a geometry buffer of, in this order, the per-(view, Gaussian) depth fields (uint32,
+ * 0 = culled), the depth-ordered Gaussian ids (int32, stride P per view), their packed rectangles (uint32) and the
+ * per-view visible counts (int32) -- what the depth sort of the last frame left there.  Returns 4. */
+int gr_raster_debug_geom_layout(int64_t P, int num_views, int width, int height, int64_t* h_offsets);
 size_t gr_raster_bin_bytes(int64_t total_rendered, int width, int height, int num_views);
 int gr_raster_preprocess(int64_t P, int sh_coeffs, const float* means3D, const float* shs,
                          const float* colors_precomp, const float* opacities, const float* scales,
