@@ -52,6 +52,7 @@ SIGNATURES.update({
     "gr_raster_geom_bytes": (c_size, [c_i64, c_int, c_int, c_int]),
     "gr_raster_bin_bytes": (c_size, [c_i64, c_int, c_int, c_int]),
     "gr_raster_debug_geom_layout": (c_int, [c_i64, c_int, c_int, c_int, c_void]),
+    "gr_raster_debug_bucket_cooldown": (c_int, [c_int]),
     "gr_raster_preprocess": (c_int, [c_i64, c_int] + [c_void] * 7 + [ctypes.POINTER(RasterView), c_int, c_void,
                                                                      c_void, c_size, c_i64p, c_void]),
     "gr_raster_render": (c_int, [c_i64, ctypes.POINTER(RasterView), c_int, c_i64p, c_void, c_size, c_void, c_size,

@@ -139,12 +139,51 @@ int lds_atomics_lane_ordered(hipStream_t stream, bool* ordered);
 int lds_atomics_lane_ordered_state();  // 1 yes, 0 no, -1 not probed yet
 void lds_order_demote();                // a sort that relied on the property came out unsorted: use ballot ranking from now on
 
+// ---- the rasterizer's packed tile rectangles (26 bits: x:7 | y:7 | w:6 | h:6; shared by rasterizer.hip and depth_sort.hip)
+constexpr int RASTER_TILE = 16;
+constexpr uint32_t RECT_MARKER26 = 127u | (127u << 7);  // w = h = 0: "did not fit, rebuild from the record"
+#ifdef __HIPCC__
+__device__ __forceinline__ void get_rect(float px, float py, int radius, int gx, int gy, int* rmin, int* rmax) {
+  const float r = (float)radius;
+  rmin[0] = min(gx, max(0, (int)((px - r) / (float)RASTER_TILE)));
+  rmin[1] = min(gy, max(0, (int)((py - r) / (float)RASTER_TILE)));
+  rmax[0] = min(gx, max(0, (int)((px + r + (float)(RASTER_TILE - 1)) / (float)RASTER_TILE)));
+  rmax[1] = min(gy, max(0, (int)((py + r + (float)(RASTER_TILE - 1)) / (float)RASTER_TILE)));
+}
+// rec: the per-(view, Gaussian) records ([.][4] float4: [0] = {px, py, ..}, [3].x = radius as int bits)
+__device__ __forceinline__ bool rect_decode(uint32_t r, int id, int64_t vbase, const float4* __restrict__ rec, int gx,
+                                            int gy, int& x0, int& y0, int& w, int& h) {
+  x0 = (int)(r & 127u);
+  y0 = (int)((r >> 7) & 127u);
+  w = (int)((r >> 14) & 63u);
+  h = (int)((r >> 20) & 63u);
+  if (r == RECT_MARKER26) {  // wide rectangle: rebuild the reference square from the record
+    const float4 r0 = rec[4 * (vbase + id)];
+    int rmin[2], rmax[2];
+    get_rect(r0.x, r0.y, __float_as_int(rec[4 * (vbase + id) + 3].x), gx, gy, rmin, rmax);
+    x0 = rmin[0];
+    y0 = rmin[1];
+    w = rmax[0] - rmin[0];
+    h = rmax[1] - rmin[1];
+  }
+  return w * h != 0;
+}
+#endif
+
 // Segmented stable LSD radix sort of the rasterizer's (view, Gaussian) depth keys (depth_sort.hip).
+// (bucket path only) the sort also adds up the tile instances of every `chunk` consecutive depth-ordered Gaussians of a
+// view -- what the binning needs first -- into chunk_total[v * nchunk + c], which it clears itself
+struct DepthSortTotals {
+  int32_t* chunk_total;
+  int chunk, nchunk;
+  const float4* rec;  // records, for rectangles that do not fit the packing
+  int gx, gy;
+};
 size_t depth_sort_table_bytes(int64_t P, int V);
 int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* keys_a, uint64_t* keys_b, int32_t* ids_out,
                      uint32_t* rect_out, int32_t* nvalid_out, int64_t P, int V, int key_bits, void* table, size_t table_bytes,
                      hipStream_t stream, const int2* key_mm = nullptr, int nb_mm = 0, int32_t* overflow_flag = nullptr,
-                     int overflow_value = 0);
+                     int overflow_value = 0, const DepthSortTotals* chunk_totals = nullptr);
 // key_mm != null: the four-launch path for a few views per call (top-digit pass + in-LDS bucket sort): key_mm = [V][nb_mm]
 // {smallest, largest} non-zero field of a block of Gaussians (0x7fffffff / 0 for a block without one); a bucket that does
 // not fit stores overflow_value into *overflow_flag and the order is then NOT valid -- repeat with key_mm = null.

@@ -142,8 +142,12 @@ __global__ __launch_bounds__(DS_T) void ds_count_kernel(int P, int V, int nchunk
 constexpr int DS_SCAN_NW = 16;  // waves per scan workgroup
 __global__ __launch_bounds__(DS_SCAN_NW* WAVE) void ds_scan_kernel(int nchunk, const uint16_t* __restrict__ hist,
                                                                    uint32_t* __restrict__ offs,
-                                                                   int32_t* __restrict__ digit_total) {
+                                                                   int32_t* __restrict__ digit_total,
+                                                                   int32_t* __restrict__ clear, int n_clear) {
   __shared__ unsigned int s_part[DS_SCAN_NW][WAVE];
+  // (bucket path: the chunk totals the bucket launch adds into)
+  if (clear != nullptr && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < n_clear; i += DS_SCAN_NW * WAVE) clear[i] = 0;
   const int v = blockIdx.x / (DS_BINS / WAVE), dg = blockIdx.x % (DS_BINS / WAVE);
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   const int d = dg * WAVE + lane;
@@ -366,10 +370,11 @@ __global__ __launch_bounds__(MSD_T) void ds_bucket_sort_kernel(int P, const int3
                                                                const uint32_t* __restrict__ range,
                                                                const uint64_t* __restrict__ keys, int id_bits,
                                                                int32_t* __restrict__ ids_out, uint32_t* __restrict__ rect_out,
-                                                               int32_t* __restrict__ flag, int flag_value) {
+                                                               int32_t* __restrict__ flag, int flag_value, DepthSortTotals ct) {
   __shared__ unsigned int s_cnt[MSD_NW][DS_BINS];
   __shared__ uint32_t s_item[2][MSD_CAP];
   __shared__ int s_w[MSD_NW];
+  __shared__ int s_ct[MSD_CAP / 64 + 2];  // tile instances per chunk the bucket touches (chunk >= 64 entries)
   const int v = blockIdx.y, d = blockIdx.x;
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   const int32_t* trow = digit_total + v * DS_BINS;
@@ -388,16 +393,60 @@ __global__ __launch_bounds__(MSD_T) void ds_bucket_sort_kernel(int P, const int3
   const int sh = (int)range[2 * v + 1];
   const int64_t base = (int64_t)v * P + start;
   const uint32_t idmask = (1u << id_bits) - 1u;
-  if (sh == 0 || n == 1) {  // equal keys: id order is the order
+  if (n > MSD_CAP && sh != 0) {
+    // the frame will be repeated; until then the launches behind this one must find nothing to bin here
+    // (empty rectangles, no chunk totals) rather than whatever the buffers held
+    if (threadIdx.x == 0) *flag = flag_value;
     for (int i = threadIdx.x; i < n; i += MSD_T) {
-      const uint64_t k = keys[base + i];
-      ids_out[base + i] = (int32_t)((uint32_t)(k >> 26) & idmask);
-      rect_out[base + i] = (uint32_t)k & 0x3ffffffu;
+      ids_out[base + i] = 0;
+      rect_out[base + i] = 0u;
     }
     return;
   }
-  if (n > MSD_CAP) {
-    if (threadIdx.x == 0) *flag = flag_value;
+  // one entry leaves: id, rectangle, and its tile instances into the total of the chunk its position falls into.  64
+  // consecutive positions touch at most two chunks: two wave sums, then one LDS add each.
+  const int chunk0 = ct.chunk_total != nullptr ? start / ct.chunk : 0;
+  const bool few_chunks = ct.chunk_total != nullptr && (start + n - 1) / ct.chunk - chunk0 < (int)(sizeof(s_ct) / sizeof(int));
+  if (ct.chunk_total != nullptr && few_chunks)
+    for (int i = threadIdx.x; i < (int)(sizeof(s_ct) / sizeof(int)); i += MSD_T) s_ct[i] = 0;
+  auto emit = [&](int j, bool have, uint64_t k) {  // wave-uniform call; j = position in the bucket
+    const uint32_t id = (uint32_t)(k >> 26) & idmask, r = (uint32_t)k & 0x3ffffffu;
+    if (have) {
+      ids_out[base + j] = (int32_t)id;
+      rect_out[base + j] = r;
+    }
+    if (ct.chunk_total != nullptr) {
+      int x0, y0, w = 0, h = 0;
+      if (have && r != 0u) rect_decode(r, (int)id, (int64_t)v * P, ct.rec, ct.gx, ct.gy, x0, y0, w, h);
+      const int nt = have ? w * h : 0;
+      const int ck = (start + j) / ct.chunk;
+      const int ck_first = __builtin_amdgcn_readfirstlane(ck);
+      const int a = wave_sum_i32_dpp(ck == ck_first ? nt : 0), b = wave_sum_i32_dpp(ck == ck_first ? 0 : nt);
+      if (lane == 0) {
+        if (few_chunks) {
+          if (a) atomicAdd(&s_ct[ck_first - chunk0], a);
+          if (b) atomicAdd(&s_ct[ck_first + 1 - chunk0], b);
+        } else {  // (a bucket of equal keys longer than the table covers: straight to memory)
+          if (a) atomicAdd(&ct.chunk_total[v * ct.nchunk + ck_first], a);
+          if (b) atomicAdd(&ct.chunk_total[v * ct.nchunk + ck_first + 1], b);
+        }
+      }
+    }
+  };
+  auto flush_totals = [&]() {
+    if (ct.chunk_total == nullptr || !few_chunks) return;
+    __syncthreads();
+    for (int i = threadIdx.x; i < (int)(sizeof(s_ct) / sizeof(int)); i += MSD_T)
+      if (s_ct[i] != 0) atomicAdd(&ct.chunk_total[v * ct.nchunk + chunk0 + i], s_ct[i]);
+  };
+  if (sh == 0 || n == 1) {  // equal keys: id order is the order
+    __syncthreads();  // (s_ct cleared)
+    for (int i0 = 0; i0 < n; i0 += MSD_T) {
+      const int i = i0 + (int)threadIdx.x;
+      if (i0 + wv * WAVE >= n) break;  // wave-uniform
+      emit(i, i < n, i < n ? keys[base + i] : 0ull);
+    }
+    flush_totals();
     return;
   }
   for (int i = threadIdx.x; i < n; i += MSD_T)
@@ -472,11 +521,12 @@ __global__ __launch_bounds__(MSD_T) void ds_bucket_sort_kernel(int P, const int3
     cur ^= 1;
     __syncthreads();  // the bases are read to the end before the next round clears them; the items are in place
   }
-  for (int j = threadIdx.x; j < n; j += MSD_T) {
-    const uint64_t k = keys[base + (s_item[cur][j] & ((1u << MSD_IDX_BITS) - 1u))];
-    ids_out[base + j] = (int32_t)((uint32_t)(k >> 26) & idmask);
-    rect_out[base + j] = (uint32_t)k & 0x3ffffffu;
+  for (int j0 = 0; j0 < n; j0 += MSD_T) {
+    const int j = j0 + (int)threadIdx.x;
+    if (j0 + wv * WAVE >= n) break;  // wave-uniform
+    emit(j, j < n, j < n ? keys[base + (s_item[cur][j] & ((1u << MSD_IDX_BITS) - 1u))] : 0ull);
   }
+  flush_totals();
 }
 
 }  // namespace
@@ -497,7 +547,8 @@ bool depth_sort_msd_possible(int64_t P, int V, int key_bits) {
 // [V*P] (the first nvalid_out[v] entries of every view's stride-P segment), nvalid_out [V] on the device.
 int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* keys_a, uint64_t* keys_b, int32_t* ids_out,
                      uint32_t* rect_out, int32_t* nvalid_out, int64_t P, int V, int key_bits, void* table, size_t table_bytes,
-                     hipStream_t stream, const int2* key_mm, int nb_mm, int32_t* overflow_flag, int overflow_value) {
+                     hipStream_t stream, const int2* key_mm, int nb_mm, int32_t* overflow_flag, int overflow_value,
+                     const DepthSortTotals* chunk_totals) {
   if (P <= 0 || V <= 0) return GR_OK;
   GR_REQUIRE(key_bits >= 1 && key_bits <= 32, "depth_sort: key_bits %d out of range", key_bits);
   GR_REQUIRE(table && table_bytes >= depth_sort_table_bytes(P, V), "depth_sort: table too small");
@@ -519,8 +570,10 @@ int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* 
     const uint32_t dmask = DS_BINS - 1;
     hipLaunchKernelGGL((ds_count_kernel<true, true>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field,
                        (const uint64_t*)nullptr, 0, dmask, hist, key_mm, nb_mm, range);
+    DepthSortTotals ct{nullptr, 1, 0, nullptr, 0, 0};
+    if (chunk_totals != nullptr) ct = *chunk_totals;
     hipLaunchKernelGGL(ds_scan_kernel, dim3((unsigned)(V * (DS_BINS / WAVE))), dim3(DS_SCAN_NW * WAVE), 0, stream, nchunk, hist,
-                       offs, dbase);
+                       offs, dbase, ct.chunk_total, V * ct.nchunk);
     if (ordered)
       hipLaunchKernelGGL((ds_scatter_kernel<true, false, true, true>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field,
                          (const uint64_t*)nullptr, 0, id_bits, dmask, offs, dbase, keys_a, rect_raw, rect_out, ids_out, nvalid_out,
@@ -532,10 +585,10 @@ int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* 
     const dim3 bgrid(DS_BINS, (unsigned)V);
     if (ordered)
       hipLaunchKernelGGL(ds_bucket_sort_kernel<true>, bgrid, dim3(MSD_T), 0, stream, (int)P, dbase, range, keys_a, id_bits, ids_out,
-                         rect_out, overflow_flag, overflow_value);
+                         rect_out, overflow_flag, overflow_value, ct);
     else
       hipLaunchKernelGGL(ds_bucket_sort_kernel<false>, bgrid, dim3(MSD_T), 0, stream, (int)P, dbase, range, keys_a, id_bits, ids_out,
-                         rect_out, overflow_flag, overflow_value);
+                         rect_out, overflow_flag, overflow_value, ct);
     GR_LAUNCH_CHECK();
     return GR_OK;
   }
@@ -558,7 +611,7 @@ int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* 
       hipLaunchKernelGGL((ds_count_kernel<false, false>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field, kin,
                          word_shift, dmask, hist, (const int2*)nullptr, 0, (uint32_t*)nullptr);
     hipLaunchKernelGGL(ds_scan_kernel, dim3((unsigned)(V * (DS_BINS / WAVE))), dim3(DS_SCAN_NW * WAVE), 0, stream, nchunk, hist,
-                       offs, dbase);
+                       offs, dbase, (int32_t*)nullptr, 0);
 #define GR_DS_SCATTER(F, L, O)                                                                                            \
   hipLaunchKernelGGL((ds_scatter_kernel<F, L, O>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field, kin, \
                      word_shift, id_bits, dmask, offs, dbase, kout, rect_raw, rect_out, ids_out, first ? nvalid_out : nullptr, \

@@ -170,14 +170,7 @@ __device__ __forceinline__ void sh_to_rgb(int deg, const float* pos, const float
   }
 }
 
-__device__ __forceinline__ void get_rect(float px, float py, int radius, int gx, int gy, int* rmin,
-                                         int* rmax) {
-  const float r = (float)radius;
-  rmin[0] = min(gx, max(0, (int)((px - r) / (float)TILE)));
-  rmin[1] = min(gy, max(0, (int)((py - r) / (float)TILE)));
-  rmax[0] = min(gx, max(0, (int)((px + r + (float)(TILE - 1)) / (float)TILE)));
-  rmax[1] = min(gy, max(0, (int)((py + r + (float)(TILE - 1)) / (float)TILE)));
-}
+static_assert(TILE == RASTER_TILE, "get_rect / rect_decode (common.hpp) are written for this tile size");
 
 // geometry state: one 64-byte record per (view, Gaussian) so that the blend's per-instance gather
 // (ids arrive in depth order, i.e. random in memory) touches ONE 64-B sector instead of three lines:
@@ -260,7 +253,6 @@ Bin carve_bin(void* p, int64_t R, int64_t vtiles) {
 // full 32 depth bits (slow path, never taken by sane scenes).
 constexpr int KEY_DEPTH_BITS = 27;
 constexpr uint32_t KEY_DEPTH_BASE = 0x3E000000u;  // bits of 0.125f
-constexpr uint32_t RECT_MARKER26 = 127u | (127u << 7);  // w = h = 0
 
 __device__ __forceinline__ uint32_t pack_rect(const int* rmin, const int* rmax) {
   const int w = rmax[0] - rmin[0], h = rmax[1] - rmin[1];
@@ -529,24 +521,6 @@ __global__ __launch_bounds__(256) void full_keys_kernel(int64_t n, const float4*
 //            (chunks whose instances do not fit the staging block write straight to their final global position).
 // With >= 8 views the workgroups of one view all run on the same XCD (block b sits on XCD b % 8).
 
-__device__ __forceinline__ bool rect_decode(uint32_t r, int id, int64_t vbase, const float4* __restrict__ rec, int gx,
-                                            int gy, int& x0, int& y0, int& w, int& h) {
-  x0 = (int)(r & 127u);
-  y0 = (int)((r >> 7) & 127u);
-  w = (int)((r >> 14) & 63u);
-  h = (int)((r >> 20) & 63u);
-  if (r == RECT_MARKER26) {  // wide rectangle: rebuild the reference square from the record
-    const float4 r0 = rec[4 * (vbase + id)];
-    int rmin[2], rmax[2];
-    get_rect(r0.x, r0.y, __float_as_int(rec[4 * (vbase + id) + 3].x), gx, gy, rmin, rmax);
-    x0 = rmin[0];
-    y0 = rmin[1];
-    w = rmax[0] - rmin[0];
-    h = rmax[1] - rmin[1];
-  }
-  return w * h != 0;
-}
-
 // block -> (view, chunk); XCD-affine when there are at least 8 views
 __device__ __forceinline__ bool bin_block(int V, int nchunk, int& v, int& c) {
   const int b = blockIdx.x;
@@ -705,14 +679,25 @@ __global__ __launch_bounds__(256) void seg_scan_kernel(int V, int tiles, int nch
 // TT = threads per workgroup: 256 (four waves, each a quarter of the chunk) for many views per call; 1024 for a few views,
 // where the launch has fewer workgroups than the chip has CUs and a workgroup's walk through its chunk IS the kernel's
 // duration (16 waves, an eighth of the steps each: 33 -> 12 us per one-camera frame)
-template <bool LANE_ORDERED, int TT>
+// SELF_SEG (a few views per call, behind the bucket depth sort): no count / scan launch ran before this one.  The chunk
+// totals came out of the sort (chunk_total: raw, per (view, chunk)); every workgroup sums the ones in front of its own,
+// scans the tile counts it has to build anyway and WRITES its row of seg_off for the blend; the first chunk of a view
+// reports the view's total and largest chunk to the host (see seg_scan_kernel<true>, whose job this is otherwise).
+struct SelfSeg {
+  const int32_t* chunk_total;
+  int32_t* totals;
+  int32_t* mail;
+  int mail_seq;
+};
+template <bool LANE_ORDERED, int TT, bool SELF_SEG = false>
 __global__ __launch_bounds__(TT) void tile_scatter_kernel(int P, int V, int gx, int gy, int nchunk, int tile_bits,
                                                              int stage_cap, const int32_t* __restrict__ nvis,
                                                              const uint32_t* __restrict__ rects,
                                                              const int32_t* __restrict__ ids,
                                                              const float4* __restrict__ rec,
-                                                             const uint32_t* __restrict__ seg_off,
-                                                             int32_t* __restrict__ point_list, unsigned int list_cap, int elist_cap) {
+                                                             uint32_t* __restrict__ seg_off,
+                                                             int32_t* __restrict__ point_list, unsigned int list_cap, int elist_cap,
+                                                             SelfSeg self) {
   // list_cap: entries the point list holds.  A speculative launch (gr_raster_forward) sizes the list before the instance
   // count is known: a chunk that would end past it writes nothing (the host then repeats the render with a larger list)
   extern __shared__ unsigned int s_cur[];  // [waves][tiles] counts -> cursors, then [stage_cap] staged chunk-local indices
@@ -720,12 +705,61 @@ __global__ __launch_bounds__(TT) void tile_scatter_kernel(int P, int V, int gx, 
   int v, c;
   if (!bin_block(V, nchunk, v, c)) return;
   const int tiles = gx * gy;
-  const uint32_t* seg = seg_off + ((int64_t)v * nchunk + c) * (tiles + 1);
-  const unsigned int chunk_begin = seg[0];
-  const int total = (int)(seg[tiles] - chunk_begin);
-  if (total == 0 || seg[tiles] > list_cap) return;  // block-uniform
-  const bool staged = total <= stage_cap;
+  uint32_t* seg = seg_off + ((int64_t)v * nchunk + c) * (tiles + 1);
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  __shared__ int s_red[2][TT / WAVE];
+  __shared__ unsigned int s_carry;
+  unsigned int chunk_begin;
+  int total;
+  if (SELF_SEG) {
+    const int me = v * nchunk + c;  // everything in front belongs to earlier views / chunks
+    int part = 0;
+    for (int i = threadIdx.x; i < me; i += TT) part += self.chunk_total[i];
+    part = wave_sum_i32_dpp(part);
+    if (lane == 0) s_red[0][wv] = part;
+    __syncthreads();
+    int front = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < TT / WAVE; ++w2) front += s_red[0][w2];
+    chunk_begin = (unsigned int)front;
+    total = self.chunk_total[me];
+    if (c == 0) {  // block-uniform: the view's figures for the host
+      __syncthreads();
+      int sum = 0, mx = 0;
+      for (int i = threadIdx.x; i < nchunk; i += TT) {
+        const int t = self.chunk_total[v * nchunk + i];
+        sum += t;
+        mx = max(mx, t);
+      }
+      sum = wave_sum_i32_dpp(sum);
+      mx = wave_max_i32_dpp(mx);
+      if (lane == 0) s_red[0][wv] = sum, s_red[1][wv] = mx;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int tv = 0, mv = 0;
+        for (int w2 = 0; w2 < TT / WAVE; ++w2) tv += s_red[0][w2], mv = max(mv, s_red[1][w2]);
+        self.totals[v] = tv;
+        self.totals[V + v] = mv;
+        if (self.mail != nullptr) {
+          __hip_atomic_store(&self.mail[v], tv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&self.mail[V + v], mv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (v == 0) __hip_atomic_store(&self.mail[2 * V], self.totals[2 * V], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&self.mail[2 * V + 1 + v], self.mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
+    if (total == 0) {  // an empty row for the blend
+      for (int T = threadIdx.x; T <= tiles; T += TT) seg[T] = chunk_begin;
+      return;
+    }
+    // (a chunk that would end past the list still counts and scans: the render that repeats this frame with a larger list
+    // finds every row of seg_off in place; it stops before it writes any entry)
+  } else {
+    chunk_begin = seg[0];
+    total = (int)(seg[tiles] - chunk_begin);
+    if (total == 0 || seg[tiles] > list_cap) return;  // block-uniform
+  }
+  const bool staged = total <= stage_cap;
   unsigned int* my = s_cur + wv * tiles;
   // staged entries are 16-bit positions inside the chunk (BIN_CHUNK <= 65536); the ids are looked up on the way out
   unsigned short* stage = reinterpret_cast<unsigned short*>(s_cur + NW * tiles);
@@ -756,13 +790,48 @@ __global__ __launch_bounds__(TT) void tile_scatter_kernel(int P, int V, int gx, 
   }
   __syncthreads();
   // ---- phase B: counts -> cursors (chunk-local when staged, global otherwise)
-  for (int T = threadIdx.x; T < tiles; T += TT) {
-    unsigned int run = seg[T] - (staged ? chunk_begin : 0u);
+  if (SELF_SEG) {
+    // the segment starts are this workgroup's own exclusive scan over the tiles of the counts it just made
+    if (threadIdx.x == 0) s_carry = 0u;
+    __syncthreads();
+    for (int T0 = 0; T0 < tiles; T0 += TT) {
+      const int T = T0 + (int)threadIdx.x;
+      unsigned int cw[NW];
+      int n_all = 0;
 #pragma unroll
-    for (int w2 = 0; w2 < NW; ++w2) {
-      const unsigned int n = s_cur[w2 * tiles + T];
-      s_cur[w2 * tiles + T] = run;
-      run += n;
+      for (int w2 = 0; w2 < NW; ++w2) {
+        cw[w2] = T < tiles ? s_cur[w2 * tiles + T] : 0u;
+        n_all += (int)cw[w2];
+      }
+      const int incl = wave_incl_scan_add_dpp(n_all);
+      if (lane == WAVE - 1) s_red[0][wv] = incl;
+      __syncthreads();
+      unsigned int before = s_carry + (unsigned int)(incl - n_all);
+      for (int w2 = 0; w2 < wv; ++w2) before += (unsigned int)s_red[0][w2];
+      if (T < tiles) {
+        seg[T] = chunk_begin + before;
+        unsigned int run = before + (staged ? 0u : chunk_begin);
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) {
+          s_cur[w2 * tiles + T] = run;
+          run += cw[w2];
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == TT - 1) s_carry = before + (unsigned int)n_all;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) seg[tiles] = chunk_begin + (unsigned int)total;
+    if (chunk_begin + (unsigned int)total > list_cap) return;  // block-uniform
+  } else {
+    for (int T = threadIdx.x; T < tiles; T += TT) {
+      unsigned int run = seg[T] - (staged ? chunk_begin : 0u);
+#pragma unroll
+      for (int w2 = 0; w2 < NW; ++w2) {
+        const unsigned int n = s_cur[w2 * tiles + T];
+        s_cur[w2 * tiles + T] = run;
+        run += n;
+      }
     }
   }
   __syncthreads();
@@ -1387,6 +1456,8 @@ struct Deferred {
                            // bucket of the four-launch depth sort did not fit: the order is then not valid either)
   bool by_mail;            // out: which of the two ways this frame took
   bool bucket_sort;        // in: take the four-launch depth sort
+  bool self_seg;           // out: the depth sort left the chunk totals and nothing else was launched -- the scatter of this
+                           // frame scans its own segments and mails the counts (tile_scatter_kernel SELF_SEG)
 };
 
 // defer_ev != nullptr: everything is enqueued, the read-back of the counts is followed by this event instead of a stream
@@ -1483,10 +1554,19 @@ static int preprocess_impl(int64_t P, int M, const float* means3D, const float* 
     {
       KernelTimer timer("raster_depth_sort", stream);
       // visible Gaussians of every view in depth order (ties: Gaussian id): ids -> order_b, rectangles -> rects
+      const bool msd_now = msd && key_bits == KEY_DEPTH_BITS;
+      // ... and with the mailbox: no count / scan launch either, the scatter does both (its SELF_SEG variant)
+      const bool self_seg = msd_now && defer_ev->mail != nullptr && nchunk <= SCAN_SINGLE_ROW;
+      const DepthSortTotals ct{g.chunk_total, BIN_CHUNK, nchunk, g.rec, gx, gy};
       int rcs = depth_sort_views(g.dfield, g.rect_raw, g.keys_a, g.keys_b, g.order_b, g.rects, g.nvis, P, num_views, key_bits,
-                                 g.ds_table, g.ds_table_bytes, stream, msd && key_bits == KEY_DEPTH_BITS ? g.key_mm : nullptr,
-                                 (int)((P + 255) / 256), g.totals + 2 * num_views, -far_seq);
+                                 g.ds_table, g.ds_table_bytes, stream, msd_now ? g.key_mm : nullptr,
+                                 (int)((P + 255) / 256), g.totals + 2 * num_views, -far_seq, self_seg ? &ct : nullptr);
       if (rcs != GR_OK) return rcs;
+      if (self_seg) {
+        defer_ev->by_mail = true;
+        defer_ev->self_seg = true;
+        return GR_OK;
+      }
     }
     {
       KernelTimer timer("raster_bin", stream);
@@ -1656,7 +1736,7 @@ static int preprocess_collect(int64_t P, int num_views, int64_t* h_num_rendered,
 // refuse to run past the list (tile_scatter_kernel / blend_kernel list_cap).
 static int render_impl(int64_t P, const gr_raster_view* h_views, int num_views, const int64_t* h_num_rendered,
                        const void* geom, size_t geom_bytes, void* bin, size_t bin_bytes, float* out_color, int flags,
-                       int64_t spec_entries, hipStream_t stream) {
+                       int64_t spec_entries, hipStream_t stream, const Deferred* defer = nullptr) {
   int rc = check_views(h_views, num_views);
   if (rc != GR_OK) return rc;
   GR_REQUIRE(out_color != nullptr && h_num_rendered != nullptr, "null argument");
@@ -1703,16 +1783,22 @@ static int render_impl(int64_t P, const gr_raster_view* h_views, int num_views, 
     bool ordered = false;
     rc = lds_atomics_lane_ordered(stream, &ordered);
     if (rc != GR_OK) return rc;
-    auto kern = wide ? (ordered ? tile_scatter_kernel<true, WIDE_T> : tile_scatter_kernel<false, WIDE_T>)
-                     : (ordered ? tile_scatter_kernel<true, BIN_T> : tile_scatter_kernel<false, BIN_T>);
+    const bool self_seg = spec && defer != nullptr && defer->self_seg;
+    const SelfSeg self{g.chunk_total, g.totals, self_seg ? const_cast<int32_t*>(defer->mail) : nullptr, self_seg ? defer->seq : 0};
+    auto kern = self_seg ? (wide ? (ordered ? tile_scatter_kernel<true, WIDE_T, true> : tile_scatter_kernel<false, WIDE_T, true>)
+                                 : (ordered ? tile_scatter_kernel<true, BIN_T, true> : tile_scatter_kernel<false, BIN_T, true>))
+                : wide   ? (ordered ? tile_scatter_kernel<true, WIDE_T> : tile_scatter_kernel<false, WIDE_T>)
+                         : (ordered ? tile_scatter_kernel<true, BIN_T> : tile_scatter_kernel<false, BIN_T>);
     int tile_bits = 0;
     while ((1 << tile_bits) < tiles) ++tile_bits;
     if (lds > 64 * 1024)
-      GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 160 * 1024 - 512));  // (the SELF_SEG variants hold a few static words as well)
     {
       KernelTimer timer("raster_bin", stream);
       hipLaunchKernelGGL(kern, dim3((unsigned)bin_grid(num_views, nchunk)), dim3(scatter_threads), lds, stream, (int)P, num_views, gx, gy,
-                         nchunk, tile_bits, stage_cap, g.nvis, g.rects, g.order_b, g.rec, g.seg_off, b.point_list, list_cap, elist_cap);
+                         nchunk, tile_bits, stage_cap, g.nvis, g.rects, g.order_b, g.rec, g.seg_off, b.point_list, list_cap, elist_cap,
+                         self);
       GR_LAUNCH_CHECK();
     }
     if (!spec && verify_this_frame()) {  // first frames: every (chunk, tile) segment in depth order?
@@ -1727,10 +1813,11 @@ static int render_impl(int64_t P, const gr_raster_view* h_views, int num_views, 
         lds_order_demote();
         auto kern_b = wide ? tile_scatter_kernel<false, WIDE_T> : tile_scatter_kernel<false, BIN_T>;
         if (lds > 64 * 1024)
-          GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_b), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_b), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024 - 512));
         hipLaunchKernelGGL(kern_b, dim3((unsigned)bin_grid(num_views, nchunk)), dim3(scatter_threads), lds, stream, (int)P,
                            num_views, gx, gy, nchunk, tile_bits, stage_cap, g.nvis, g.rects, g.order_b, g.rec, g.seg_off,
-                           b.point_list, list_cap, elist_cap);
+                           b.point_list, list_cap, elist_cap, self);
         GR_LAUNCH_CHECK();
       } else {
         GR_REQUIRE(h_bad == 0, "tile binning produced an unsorted list (internal error)");
@@ -1772,13 +1859,19 @@ struct Pending {  // a gr_raster_forward(GR_RASTER_SPLIT) of this thread whose c
   Deferred d;
   hipStream_t stream;
 };
-thread_local Pending g_pending{false, 0, 0, 0, Deferred{nullptr, nullptr, 0, 0, false, false}, nullptr};
+thread_local Pending g_pending{false, 0, 0, 0, Deferred{nullptr, nullptr, 0, 0, false, false, false}, nullptr};
 // frames left before the four-launch depth sort is tried again after one of its buckets overflowed (a scene whose depths
 // crowd into a sliver of the key range: every frame would be drawn twice)
 thread_local int g_bucket_cooldown = 0;
 constexpr int BUCKET_COOLDOWN_FRAMES = 256;
 }  // namespace
 }  // namespace gr
+
+extern "C" int gr_raster_debug_bucket_cooldown(int reset) {
+  const int left = gr::g_bucket_cooldown;
+  if (reset) gr::g_bucket_cooldown = 0;
+  return left;
+}
 
 extern "C" int gr_raster_forward_finish(int64_t* h_num_rendered) {
   using namespace gr;
@@ -1833,12 +1926,13 @@ extern "C" int gr_raster_forward(int64_t P, int M, const float* means3D, const f
       seq = 1;
     }
     if (g_bucket_cooldown > 0) --g_bucket_cooldown;
-    Deferred d{ev, mail, seq, 1, false, g_bucket_cooldown == 0};
+    Deferred d{ev, mail, seq, 1, false, g_bucket_cooldown == 0, false};
     int rc = preprocess_impl(P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, h_views,
                              num_views, radii, geom, geom_bytes, h_num_rendered, stream, &d);
     if (rc != GR_OK) return rc;
     h_num_rendered[num_views] = stage_hint;
-    rc = render_impl(P, h_views, num_views, h_num_rendered, geom, geom_bytes, bin, bin_bytes, out_color, flags, entries, stream);
+    rc = render_impl(P, h_views, num_views, h_num_rendered, geom, geom_bytes, bin, bin_bytes, out_color, flags, entries, stream,
+                     &d);
     if (rc != GR_OK) return rc;
     if (flags & GR_RASTER_SPLIT) {  // the caller comes back with gr_raster_forward_finish (same thread)
       g_pending = Pending{true, P, num_views, entries, d, stream};

@@ -1,0 +1,125 @@
+"""GPU: the four-launch depth sort of a few views per call (depth_sort.hip: top-digit pass relative to the view's key range +
+in-LDS bucket sort) and the scatter that scans its own segments behind it (tile_scatter_kernel SELF_SEG).
+
+White box: the order a deferred gr_raster_forward leaves in the geometry buffer (gr_raster_debug_geom_layout) must be the
+stable argsort of the depth fields of the same frame -- bit-exact integer work, every visible Gaussian of every view.
+Black box: the images of such frames equal the ones of the plain path (many cameras per call: three-pass sort, separate count /
+scan launches), bit for bit -- including a scene that overflows a bucket and falls back."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("P,W,H,V,frames", [(3000, 64, 48, 1, 8), (50000, 320, 240, 2, 6), (300000, 640, 480, 4, 5),
+                                            (1000000, 640, 480, 1, 6), (7, 64, 48, 3, 5)])
+def test_deferred_frames_leave_the_stable_depth_order(P, W, H, V, frames):
+    import depth_order_check
+    assert depth_order_check.run(P, W, H, V, frames, verbose=False) == 0
+
+
+def _settings(cam, bg=(0.0, 0.0, 0.0)):
+    from gaussreg_amd.rasterizer import GaussianRasterizationSettings
+    return GaussianRasterizationSettings(
+        image_height=cam["image_height"], image_width=cam["image_width"], tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],
+        bg=torch.tensor(bg, dtype=torch.float32, device="cuda"), scale_modifier=1.0,
+        viewmatrix=torch.from_numpy(cam["viewmatrix"]).cuda(), projmatrix=torch.from_numpy(cam["projmatrix"]).cuda(),
+        sh_degree=3, campos=torch.from_numpy(cam["campos"]).cuda(), prefiltered=False, debug=False)
+
+
+def _render_each(sets, t, n_frames):
+    from gaussreg_amd.rasterizer import GaussianRasterizer
+    out = []
+    for f in range(n_frames):
+        r = GaussianRasterizer(sets[f % len(sets)])
+        img, radii = r(means3D=t["means3D"], means2D=None, opacities=t["opacities"], shs=t["shs"], scales=t["scales"],
+                       rotations=t["rotations"])
+        out.append((img.cpu().numpy(), radii.cpu().numpy()))
+    return out
+
+
+def _plain_reference(sets, t):
+    """More than four cameras in one call: the plain path (three-pass sort, count and scan launches of their own)."""
+    from gaussreg_amd.rasterizer import rasterize_views
+    many = list(sets) + [sets[0]] * max(0, 5 - len(sets))
+    color, radii, _ = rasterize_views(many, t["means3D"], t["opacities"], shs=t["shs"], scales=t["scales"],
+                                      rotations=t["rotations"])
+    return color.cpu().numpy(), radii.cpu().numpy()
+
+
+def test_one_camera_frames_equal_the_plain_path_bit_for_bit():
+    from gaussreg_amd import _lib, synthetic
+    L = _lib.lib()
+    L.gr_raster_debug_bucket_cooldown(1)
+    P, W, H = 200000, 320, 240
+    g = synthetic.gaussians_c2(P, seed=5, sh_degree=3)
+    t = {k: torch.from_numpy(v).cuda() for k, v in g.items()}
+    sets = [_settings(c) for c in synthetic.camera_ring(4, W, H, seed=1)]
+    want_c, want_r = _plain_reference(sets, t)
+    for f, (img, radii) in enumerate(_render_each(sets, t, 12)):
+        assert np.array_equal(img.view(np.uint32), want_c[f % 4].view(np.uint32)), f"frame {f}"
+        assert np.array_equal(radii, want_r[f % 4])
+    assert L.gr_raster_debug_bucket_cooldown(0) == 0  # no bucket of this scene overflowed: the frames took the bucket sort
+
+
+def test_a_crowded_bucket_falls_back_and_the_frame_is_still_exact():
+    """40 000 Gaussians inside 4 mm of depth plus one very near and one very far: the key range is wide, so all of them land
+    in ONE bucket of the top-digit pass (> 7 936 entries) -- the bucket launch raises the flag, the call repeats the frame with
+    the three-pass sort and stays with it for a while."""
+    from gaussreg_amd import _lib, synthetic
+    L = _lib.lib()
+    L.gr_raster_debug_bucket_cooldown(1)
+    P, W, H = 40002, 256, 192
+    rng = np.random.default_rng(11)
+    g = synthetic.gaussians_c2(P, seed=2, sh_degree=3)
+    g["means3D"][:, 0] = (rng.random(P) - 0.5) * 3.0
+    g["means3D"][:, 1] = (rng.random(P) - 0.5) * 2.0
+    g["means3D"][:, 2] = 3.0 + rng.random(P) * 0.004
+    g["means3D"][0] = (0.0, 0.0, 0.3)
+    g["means3D"][1] = (0.5, 0.5, 60.0)
+    g["means3D"] = g["means3D"].astype(np.float32)
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in g.items()}
+    sets = [_settings(synthetic.camera(W, H), bg=(0.2, 0.1, 0.0))]
+    want_c, want_r = _plain_reference(sets, t)
+    frames = _render_each(sets, t, 6)
+    for f, (img, radii) in enumerate(frames):
+        assert np.array_equal(img.view(np.uint32), want_c[0].view(np.uint32)), f"frame {f}"
+        assert np.array_equal(radii, want_r[0])
+    assert (want_r[0] > 0).sum() > 30000
+    left = L.gr_raster_debug_bucket_cooldown(1)
+    assert 0 < left <= 256, left  # the overflow was seen and the thread is in its three-pass period
+    # ... and a scene that fits takes the bucket sort again once the period is cleared
+    g2 = synthetic.gaussians_c2(20000, seed=3, sh_degree=3)
+    t2 = {k: torch.from_numpy(v).cuda() for k, v in g2.items()}
+    want2_c, _ = _plain_reference(sets, t2)
+    for img, _ in _render_each(sets, t2, 3):
+        assert np.array_equal(img.view(np.uint32), want2_c[0].view(np.uint32))
+    assert L.gr_raster_debug_bucket_cooldown(0) == 0
+
+
+def test_equal_depths_take_the_copy_branch():
+    """Every Gaussian at exactly the same camera depth: the key range is empty, one bucket holds everything and is already in
+    id order (no LDS sort, no overflow however many there are)."""
+    from gaussreg_amd import _lib, synthetic
+    L = _lib.lib()
+    L.gr_raster_debug_bucket_cooldown(1)
+    P, W, H = 30000, 192, 144
+    rng = np.random.default_rng(4)
+    g = synthetic.gaussians_c2(P, seed=8, sh_degree=3)
+    g["means3D"][:, 0] = (rng.random(P) - 0.5) * 3.0
+    g["means3D"][:, 1] = (rng.random(P) - 0.5) * 2.0
+    g["means3D"][:, 2] = 2.5
+    g["means3D"] = g["means3D"].astype(np.float32)
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in g.items()}
+    sets = [_settings(synthetic.camera(W, H))]
+    want_c, want_r = _plain_reference(sets, t)
+    for img, radii in _render_each(sets, t, 4):
+        assert np.array_equal(img.view(np.uint32), want_c[0].view(np.uint32))
+        assert np.array_equal(radii, want_r[0])
+    assert L.gr_raster_debug_bucket_cooldown(0) == 0
