@@ -707,6 +707,20 @@ __global__ __launch_bounds__(TT) void tile_scatter_kernel(int P, int V, int gx, 
   const int tiles = gx * gy;
   uint32_t* seg = seg_off + ((int64_t)v * nchunk + c) * (tiles + 1);
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  // the wave's rectangles and ids, requested up front and before anything else is waited for (on clamped positions; what
+  // lies past the view's visible count is dropped once that count has arrived): both walks below run out of registers, and
+  // the trip to memory overlaps the ones of the prologue instead of following them
+  const int64_t vbase = (int64_t)v * P;
+  const int w_begin = c * BIN_CHUNK + wv * (BIN_CHUNK / (TT / WAVE));
+  uint32_t rr[BIN_CHUNK / TT];
+  int32_t ii[BIN_CHUNK / TT];
+#pragma unroll
+  for (int j = 0; j < BIN_CHUNK / TT; ++j) {
+    const int64_t o = vbase + min(w_begin + j * WAVE + lane, P - 1);
+    rr[j] = rects[o];
+    ii[j] = ids[o];
+  }
+  const int nv = nvis[v];
   __shared__ int s_red[2][TT / WAVE];
   __shared__ unsigned int s_carry;
   unsigned int chunk_begin;
@@ -767,17 +781,12 @@ __global__ __launch_bounds__(TT) void tile_scatter_kernel(int P, int V, int gx, 
   unsigned int* elist = s_cur + NW * tiles + (stage_cap + 1) / 2 + wv * elist_cap;
   for (int T = threadIdx.x; T < NW * tiles; T += TT) s_cur[T] = 0u;
   __syncthreads();
-  const int64_t vbase = (int64_t)v * P;
-  const int w_begin = c * BIN_CHUNK + wv * CW, w_end = min(nvis[v], w_begin + CW);
-  // the wave's rectangles and ids, requested up front: both walks below run out of registers (one memory round trip
-  // instead of one per 64-Gaussian step and walk)
-  uint32_t rr[CW / WAVE];
-  int32_t ii[CW / WAVE];
+  const int w_end = min(nv, w_begin + CW);
 #pragma unroll
   for (int j = 0; j < CW / WAVE; ++j) {
     const int t = w_begin + j * WAVE + lane;
-    rr[j] = t < w_end ? rects[vbase + t] : 0u;
-    ii[j] = t < w_end ? ids[vbase + t] : 0;
+    rr[j] = t < w_end ? rr[j] : 0u;  // (past the view's visible count the arrays hold leftovers)
+    ii[j] = t < w_end ? ii[j] : 0;
   }
   // ---- phase A: this wave's tile counts
 #pragma unroll
