@@ -186,7 +186,8 @@ int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* 
                      int overflow_value = 0, const DepthSortTotals* chunk_totals = nullptr);
 // key_mm != null: the four-launch path for a few views per call (top-digit pass + in-LDS bucket sort): key_mm = [V][nb_mm]
 // {smallest, largest} non-zero field of a block of Gaussians (0x7fffffff / 0 for a block without one); a bucket that does
-// not fit stores overflow_value into *overflow_flag and the order is then NOT valid -- repeat with key_mm = null.
+// not fit stores overflow_value into *overflow_flag (a negative value; a positive one is OR-ed in) and the order is then NOT
+// valid -- repeat with key_mm = null.
 bool depth_sort_msd_possible(int64_t P, int V, int key_bits);
 
 // Optional per-kernel HIP-event timing (off by default; bench.py turns it on to measure the

@@ -191,7 +191,7 @@ struct Geom {
   int32_t* chunk_max;    // [1] largest chunk total
   void* ds_table;        // depth-sort histograms / offsets
   size_t ds_table_bytes;
-  int2* key_mm;          // [V][ceil(P / 256)] smallest / largest depth field of a preprocess block (few views per call only)
+  int2* key_mm;          // [V][ceil(P / 256)] smallest / largest depth field of a preprocess block (a few views per call only)
   int32_t* nvis;         // [V] visible (depth-ordered) Gaussians per view
   int32_t* totals;       // [V] instances per view, [V] largest chunk total of every view, [1] depth-overflow flag, [3] pad --
   DevView* views;        // -- immediately followed by the [MAX_VIEWS] camera table: ONE upload clears the flag and sets the cameras
@@ -220,7 +220,7 @@ Geom carve_geom(void* p, int64_t P, int V, int64_t tiles) {
   g.chunk_max = c.take<int32_t>(1);
   g.ds_table_bytes = depth_sort_table_bytes(P, V);
   g.ds_table = c.take<char>(g.ds_table_bytes);
-  g.key_mm = c.take<int2>((V <= 4 ? V : 0) * ((P + 255) / 256));
+  g.key_mm = c.take<int2>((V <= 4 ? V : 0) * ((P + 255) / 256));  // (depth_sort_msd_possible)
   g.nvis = c.take<int32_t>(V);
   g.totals = c.take<int32_t>(2 * V + 4 + MAX_VIEWS * (sizeof(DevView) / sizeof(int32_t)));
   g.views = reinterpret_cast<DevView*>(g.totals ? g.totals + 2 * V + 4 : nullptr);
@@ -1353,6 +1353,17 @@ bool verify_this_frame() {
   return always || f < 3 || (f & 255) == 0;
 }
 
+// calls left before the bucket depth sort (depth_sort.hip) is tried again after one of its buckets overflowed (a scene whose
+// depths crowd into a sliver of the key range: every frame would be ordered twice); per host thread
+thread_local int g_bucket_cooldown = 0;
+constexpr int BUCKET_COOLDOWN_FRAMES = 256;
+bool bucket_sort_allowed() {  // one call of the waiting period
+  if (g_bucket_cooldown == 0) return true;
+  --g_bucket_cooldown;
+  return false;
+}
+void bucket_sort_overflowed() { g_bucket_cooldown = BUCKET_COOLDOWN_FRAMES; }
+
 void frame_done() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
@@ -1533,7 +1544,9 @@ static int preprocess_impl(int64_t P, int M, const float* means3D, const float* 
   if (defer_ev != nullptr) defer_ev->far_seq = far_seq;
   // a deferred frame of a few views: the four-launch depth sort (a bucket that outgrows LDS raises the far word with the
   // sign flipped; the caller then takes the plain path, which always sorts in three passes)
-  const bool msd = defer_ev != nullptr && defer_ev->bucket_sort && depth_sort_msd_possible(P, num_views, KEY_DEPTH_BITS);
+  // (a plain call reads the counts itself: bit 1 of the far word says "overflow" there and the ordering is redone in place)
+  const bool msd = (defer_ev != nullptr ? defer_ev->bucket_sort : bucket_sort_allowed()) &&
+                   depth_sort_msd_possible(P, num_views, KEY_DEPTH_BITS);
   int2* const mm_out = msd ? g.key_mm : nullptr;
 #define GR_PRE(SH, COV, S16)                                                                       \
   if (S16 && num_views == 1)                                                                       \
@@ -1559,17 +1572,19 @@ static int preprocess_impl(int64_t P, int M, const float* means3D, const float* 
   GR_REQUIRE(tot != nullptr, "pinned read-back buffer could not be allocated");
   const int nchunk = (int)((P + BIN_CHUNK - 1) / BIN_CHUNK);
   int32_t h_chunk_max = 0;
-  auto sort_and_count = [&](int key_bits) -> int {
+  auto sort_and_count = [&](int key_bits, bool buckets = true) -> int {
     {
       KernelTimer timer("raster_depth_sort", stream);
       // visible Gaussians of every view in depth order (ties: Gaussian id): ids -> order_b, rectangles -> rects
-      const bool msd_now = msd && key_bits == KEY_DEPTH_BITS;
+      const bool msd_now = msd && buckets && key_bits == KEY_DEPTH_BITS;
       // ... and with the mailbox: no count / scan launch either, the scatter does both (its SELF_SEG variant)
-      const bool self_seg = msd_now && defer_ev->mail != nullptr && nchunk <= SCAN_SINGLE_ROW;
+      const bool self_seg = msd_now && defer_ev != nullptr && defer_ev->mail != nullptr && nchunk <= SCAN_SINGLE_ROW &&
+                            num_views <= 4;
       const DepthSortTotals ct{g.chunk_total, BIN_CHUNK, nchunk, g.rec, gx, gy};
       int rcs = depth_sort_views(g.dfield, g.rect_raw, g.keys_a, g.keys_b, g.order_b, g.rects, g.nvis, P, num_views, key_bits,
                                  g.ds_table, g.ds_table_bytes, stream, msd_now ? g.key_mm : nullptr,
-                                 (int)((P + 255) / 256), g.totals + 2 * num_views, -far_seq, self_seg ? &ct : nullptr);
+                                 (int)((P + 255) / 256), g.totals + 2 * num_views, defer_ev != nullptr ? -far_seq : 2,
+                                 self_seg ? &ct : nullptr);
       if (rcs != GR_OK) return rcs;
       if (self_seg) {
         defer_ev->by_mail = true;
@@ -1653,6 +1668,12 @@ static int preprocess_impl(int64_t P, int M, const float* means3D, const float* 
     GR_REQUIRE(h_bad == 0, "depth sort produced an unsorted order (internal error)");
     return GR_OK;
   };
+  if (tot[2 * num_views] & 2) {  // a bucket of the four-launch sort overflowed: three passes, now and for a while
+    bucket_sort_overflowed();
+    GR_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(g.totals + 2 * num_views), tot[2 * num_views] & 1, 1, stream));
+    rc = sort_and_count(KEY_DEPTH_BITS, false);
+    if (rc != GR_OK) return rc;
+  }
   if (tot[2 * num_views] != 0) {  // some depth >= 8192: redo the ordering with full-width keys
     hipLaunchKernelGGL(full_keys_kernel, dim3((unsigned)((P * num_views + 255) / 256)), blk, 0, stream, P * num_views,
                        g.rec, radii, g.dfield);
@@ -1662,7 +1683,7 @@ static int preprocess_impl(int64_t P, int M, const float* means3D, const float* 
   }
   rc = check_depth_order();
   if (rc == 1) {
-    rc = sort_and_count(tot[2 * num_views] != 0 ? 32 : KEY_DEPTH_BITS);
+    rc = sort_and_count(tot[2 * num_views] != 0 ? 32 : KEY_DEPTH_BITS, false);
     if (rc != GR_OK) return rc;
     rc = check_depth_order();
     if (rc == 1) rc = GR_OK;
@@ -1869,16 +1890,12 @@ struct Pending {  // a gr_raster_forward(GR_RASTER_SPLIT) of this thread whose c
   hipStream_t stream;
 };
 thread_local Pending g_pending{false, 0, 0, 0, Deferred{nullptr, nullptr, 0, 0, false, false, false}, nullptr};
-// frames left before the four-launch depth sort is tried again after one of its buckets overflowed (a scene whose depths
-// crowd into a sliver of the key range: every frame would be drawn twice)
-thread_local int g_bucket_cooldown = 0;
-constexpr int BUCKET_COOLDOWN_FRAMES = 256;
 }  // namespace
 }  // namespace gr
 
-extern "C" int gr_raster_debug_bucket_cooldown(int reset) {
+extern "C" int gr_raster_debug_bucket_cooldown(int set) {
   const int left = gr::g_bucket_cooldown;
-  if (reset) gr::g_bucket_cooldown = 0;
+  if (set >= 0) gr::g_bucket_cooldown = set;
   return left;
 }
 
@@ -1891,7 +1908,7 @@ extern "C" int gr_raster_forward_finish(int64_t* h_num_rendered) {
   bool far_depth = false, bucket_overflow = false;
   int rc = preprocess_collect(p.P, p.num_views, h_num_rendered, &far_depth, p.d, p.stream, &bucket_overflow);
   if (rc != GR_OK) return rc;
-  if (bucket_overflow) g_bucket_cooldown = BUCKET_COOLDOWN_FRAMES;
+  if (bucket_overflow) bucket_sort_overflowed();
   int64_t R = 0;
   for (int v = 0; v < p.num_views; ++v) R += h_num_rendered[v];
   if (far_depth) return GR_RETRY_FULL;
@@ -1934,8 +1951,7 @@ extern "C" int gr_raster_forward(int64_t P, int M, const float* means3D, const f
       frame_seq.store(1);
       seq = 1;
     }
-    if (g_bucket_cooldown > 0) --g_bucket_cooldown;
-    Deferred d{ev, mail, seq, 1, false, g_bucket_cooldown == 0, false};
+    Deferred d{ev, mail, seq, 1, false, bucket_sort_allowed(), false};
     int rc = preprocess_impl(P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, h_views,
                              num_views, radii, geom, geom_bytes, h_num_rendered, stream, &d);
     if (rc != GR_OK) return rc;
@@ -1950,7 +1966,7 @@ extern "C" int gr_raster_forward(int64_t P, int M, const float* means3D, const f
     bool far_depth = false, bucket_overflow = false;
     rc = preprocess_collect(P, num_views, h_num_rendered, &far_depth, d, stream, &bucket_overflow);
     if (rc != GR_OK) return rc;
-    if (bucket_overflow) g_bucket_cooldown = BUCKET_COOLDOWN_FRAMES;
+    if (bucket_overflow) bucket_sort_overflowed();
     int64_t R = 0;
     for (int v = 0; v < num_views; ++v) R += h_num_rendered[v];
     if (!far_depth) return R <= entries ? GR_OK : GR_RETRY_BIN;

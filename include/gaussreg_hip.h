@@ -177,9 +177,10 @@ size_t gr_raster_geom_bytes(int64_t P, int num_views, int width, int height);
  * 0 = culled), the depth-ordered Gaussian ids (int32, stride P per view), their packed rectangles (uint32) and the
  * per-view visible counts (int32) -- what the depth sort of the last frame left there.  Returns 4. */
 int gr_raster_debug_geom_layout(int64_t P, int num_views, int width, int height, int64_t* h_offsets);
-/* Test hook: frames of this host thread for which gr_raster_forward stays with the three-pass depth sort because a bucket of
- * the four-launch one overflowed (0 = the four-launch sort is tried); reset != 0 clears the count. */
-int gr_raster_debug_bucket_cooldown(int reset);
+/* Test hook: rasterizer calls of this host thread that stay with the three-pass depth sort because a bucket of the
+ * four-launch one overflowed (0 = the four-launch sort is tried).  Returns the count; set >= 0 replaces it (a large value
+ * pins the three-pass sort, 0 ends the period), set < 0 only queries. */
+int gr_raster_debug_bucket_cooldown(int set);
 size_t gr_raster_bin_bytes(int64_t total_rendered, int width, int height, int num_views);
 int gr_raster_preprocess(int64_t P, int sh_coeffs, const float* means3D, const float* shs,
                          const float* colors_precomp, const float* opacities, const float* scales,

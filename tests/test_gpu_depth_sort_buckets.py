@@ -3,8 +3,9 @@ in-LDS bucket sort) and the scatter that scans its own segments behind it (tile_
 
 White box: the order a deferred gr_raster_forward leaves in the geometry buffer (gr_raster_debug_geom_layout) must be the
 stable argsort of the depth fields of the same frame -- bit-exact integer work, every visible Gaussian of every view.
-Black box: the images of such frames equal the ones of the plain path (many cameras per call: three-pass sort, separate count /
-scan launches), bit for bit -- including a scene that overflows a bucket and falls back."""
+Black box: the images of such frames equal the ones of the three-pass sort with its separate count / scan launches (pinned
+through gr_raster_debug_bucket_cooldown), bit for bit -- one camera and many per call, including a scene that overflows a
+bucket and falls back."""
 import os
 import sys
 
@@ -45,18 +46,44 @@ def _render_each(sets, t, n_frames):
 
 
 def _plain_reference(sets, t):
-    """More than four cameras in one call: the plain path (three-pass sort, count and scan launches of their own)."""
+    """More than four cameras in one call (the host reads the counts between the two halves, count and scan launches of their
+    own) with the three-pass sort pinned; the thread's waiting period is cleared afterwards."""
+    from gaussreg_amd import _lib
     from gaussreg_amd.rasterizer import rasterize_views
+    L = _lib.lib()
     many = list(sets) + [sets[0]] * max(0, 5 - len(sets))
-    color, radii, _ = rasterize_views(many, t["means3D"], t["opacities"], shs=t["shs"], scales=t["scales"],
-                                      rotations=t["rotations"])
+    L.gr_raster_debug_bucket_cooldown(1 << 20)
+    try:
+        color, radii, _ = rasterize_views(many, t["means3D"], t["opacities"], shs=t["shs"], scales=t["scales"],
+                                          rotations=t["rotations"])
+    finally:
+        L.gr_raster_debug_bucket_cooldown(0)
     return color.cpu().numpy(), radii.cpu().numpy()
+
+
+def test_three_cameras_per_call_plain_and_deferred_equal_the_three_pass_sort():
+    """The first call of a shape has no list-size hint and takes the plain path (the host reads the counts between the two
+    halves; the bucket sort is used there too), the later ones are deferred."""
+    from gaussreg_amd import _lib, synthetic
+    from gaussreg_amd.rasterizer import rasterize_views
+    L = _lib.lib()
+    P, W, H, V = 300017, 320, 240, 3
+    g = synthetic.gaussians_c2(P, seed=6, sh_degree=3)
+    t = {k: torch.from_numpy(v).cuda() for k, v in g.items()}
+    sets = [_settings(c) for c in synthetic.camera_ring(V, W, H, seed=2)]
+    want_c, want_r = _plain_reference(sets, t)
+    for _ in range(5):  # (the first frames of a process are the self-checked ones: both kinds pass through here)
+        color, radii, _ = rasterize_views(sets, t["means3D"], t["opacities"], shs=t["shs"], scales=t["scales"],
+                                          rotations=t["rotations"])
+        assert np.array_equal(color.cpu().numpy().view(np.uint32), want_c[:V].view(np.uint32))
+        assert np.array_equal(radii.cpu().numpy(), want_r[:V])
+    assert L.gr_raster_debug_bucket_cooldown(-1) == 0
 
 
 def test_one_camera_frames_equal_the_plain_path_bit_for_bit():
     from gaussreg_amd import _lib, synthetic
     L = _lib.lib()
-    L.gr_raster_debug_bucket_cooldown(1)
+    L.gr_raster_debug_bucket_cooldown(0)
     P, W, H = 200000, 320, 240
     g = synthetic.gaussians_c2(P, seed=5, sh_degree=3)
     t = {k: torch.from_numpy(v).cuda() for k, v in g.items()}
@@ -65,7 +92,7 @@ def test_one_camera_frames_equal_the_plain_path_bit_for_bit():
     for f, (img, radii) in enumerate(_render_each(sets, t, 12)):
         assert np.array_equal(img.view(np.uint32), want_c[f % 4].view(np.uint32)), f"frame {f}"
         assert np.array_equal(radii, want_r[f % 4])
-    assert L.gr_raster_debug_bucket_cooldown(0) == 0  # no bucket of this scene overflowed: the frames took the bucket sort
+    assert L.gr_raster_debug_bucket_cooldown(-1) == 0  # no bucket of this scene overflowed: the frames took the bucket sort
 
 
 def test_a_crowded_bucket_falls_back_and_the_frame_is_still_exact():
@@ -74,7 +101,7 @@ def test_a_crowded_bucket_falls_back_and_the_frame_is_still_exact():
     the three-pass sort and stays with it for a while."""
     from gaussreg_amd import _lib, synthetic
     L = _lib.lib()
-    L.gr_raster_debug_bucket_cooldown(1)
+    L.gr_raster_debug_bucket_cooldown(0)
     P, W, H = 40002, 256, 192
     rng = np.random.default_rng(11)
     g = synthetic.gaussians_c2(P, seed=2, sh_degree=3)
@@ -92,15 +119,24 @@ def test_a_crowded_bucket_falls_back_and_the_frame_is_still_exact():
         assert np.array_equal(img.view(np.uint32), want_c[0].view(np.uint32)), f"frame {f}"
         assert np.array_equal(radii, want_r[0])
     assert (want_r[0] > 0).sum() > 30000
-    left = L.gr_raster_debug_bucket_cooldown(1)
+    left = L.gr_raster_debug_bucket_cooldown(0)
     assert 0 < left <= 256, left  # the overflow was seen and the thread is in its three-pass period
+    # the same through the plain path (first call of a three-camera shape: the host reads the flag next to the counts and
+    # orders the views again in place)
+    from gaussreg_amd.rasterizer import rasterize_views
+    color, radii5, _ = rasterize_views(sets * 3, t["means3D"], t["opacities"], shs=t["shs"], scales=t["scales"],
+                                       rotations=t["rotations"])
+    for v in range(3):
+        assert np.array_equal(color[v].cpu().numpy().view(np.uint32), want_c[0].view(np.uint32)), f"view {v}"
+        assert np.array_equal(radii5[v].cpu().numpy(), want_r[0])
+    assert L.gr_raster_debug_bucket_cooldown(0) == 256
     # ... and a scene that fits takes the bucket sort again once the period is cleared
     g2 = synthetic.gaussians_c2(20000, seed=3, sh_degree=3)
     t2 = {k: torch.from_numpy(v).cuda() for k, v in g2.items()}
     want2_c, _ = _plain_reference(sets, t2)
     for img, _ in _render_each(sets, t2, 3):
         assert np.array_equal(img.view(np.uint32), want2_c[0].view(np.uint32))
-    assert L.gr_raster_debug_bucket_cooldown(0) == 0
+    assert L.gr_raster_debug_bucket_cooldown(-1) == 0
 
 
 def test_equal_depths_take_the_copy_branch():
@@ -108,7 +144,7 @@ def test_equal_depths_take_the_copy_branch():
     id order (no LDS sort, no overflow however many there are)."""
     from gaussreg_amd import _lib, synthetic
     L = _lib.lib()
-    L.gr_raster_debug_bucket_cooldown(1)
+    L.gr_raster_debug_bucket_cooldown(0)
     P, W, H = 30000, 192, 144
     rng = np.random.default_rng(4)
     g = synthetic.gaussians_c2(P, seed=8, sh_degree=3)
@@ -122,4 +158,4 @@ def test_equal_depths_take_the_copy_branch():
     for img, radii in _render_each(sets, t, 4):
         assert np.array_equal(img.view(np.uint32), want_c[0].view(np.uint32))
         assert np.array_equal(radii, want_r[0])
-    assert L.gr_raster_debug_bucket_cooldown(0) == 0
+    assert L.gr_raster_debug_bucket_cooldown(-1) == 0
