@@ -100,7 +100,7 @@ void* pinned_scratch(int slot, size_t bytes);
 // another) and clears its stamp word on the host before the launch that will post it (mailbox_arm).
 constexpr int MAIL_WORDS = 1024;
 constexpr int MAIL_GRID_BOXES = 0;     // grid_subsample: 6 B box words + stamp, B <= 80
-constexpr int MAIL_GRID_COUNTS = 512;  // grid_subsample: B + 1 counts + stamp
+constexpr int MAIL_GRID_COUNTS = 512;  // grid_subsample: B + 1 counts, the bucket-overflow flag, the stamp
 constexpr int MAIL_RADIUS = 1008;      // radius search: 4 header words + stamp
 volatile int32_t* mailbox();
 inline void mailbox_arm(volatile int32_t* stamp_word) { __atomic_store_n(stamp_word, 0, __ATOMIC_RELEASE); }
@@ -179,11 +179,22 @@ struct DepthSortTotals {
   const float4* rec;  // records, for rectangles that do not fit the packing
   int gx, gy;
 };
+// (bucket path only) ragged segments instead of V equal strides: segment v is [seg_off[v], seg_off[v + 1]) of every array
+// (P = the longest one), its key range is known to the caller (range_in[2 v] = smallest field, [2 v + 1] = the shift s with
+// (largest - smallest) >> s < 512), ids leave as positions in the whole array, and the 26-bit payload can leave widened
+// to 64-bit (segment << key64_shift | payload) words instead of rect_out -- grid_subsample's (cloud, voxel) sort.
+struct DepthSortSegments {
+  const int32_t* seg_off;
+  const uint32_t* range_in;
+  uint64_t* key64_out;
+  int key64_shift;
+};
 size_t depth_sort_table_bytes(int64_t P, int V);
 int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* keys_a, uint64_t* keys_b, int32_t* ids_out,
                      uint32_t* rect_out, int32_t* nvalid_out, int64_t P, int V, int key_bits, void* table, size_t table_bytes,
                      hipStream_t stream, const int2* key_mm = nullptr, int nb_mm = 0, int32_t* overflow_flag = nullptr,
-                     int overflow_value = 0, const DepthSortTotals* chunk_totals = nullptr);
+                     int overflow_value = 0, const DepthSortTotals* chunk_totals = nullptr,
+                     const DepthSortSegments* segments = nullptr);
 // key_mm != null: the four-launch path for a few views per call (top-digit pass + in-LDS bucket sort): key_mm = [V][nb_mm]
 // {smallest, largest} non-zero field of a block of Gaussians (0x7fffffff / 0 for a block without one); a bucket that does
 // not fit stores overflow_value into *overflow_flag (a negative value; a positive one is OR-ed in) and the order is then NOT

@@ -63,12 +63,9 @@ __device__ __forceinline__ bool ds_block(int V, int nchunk, int& v, int& c) {
 inline int ds_grid(int V, int nchunk) { return V >= 8 ? 8 * ((V + 7) / 8) * nchunk : V * nchunk; }
 
 constexpr int MSD_T = 512;         // threads of a bucket workgroup
-constexpr int MSD_NW = MSD_T / WAVE;
 constexpr int MSD_IDX_BITS = 14;
 constexpr int MSD_CAP = 7936;      // items per bucket: 2 x 31 KB of items + 16 KB of counters -> two workgroups per CU
-constexpr int MSD_STEPS = (MSD_CAP + MSD_T - 1) / MSD_T;  // 64-item steps of a wave (its share of the bucket)
 static_assert(MSD_CAP <= (1 << MSD_IDX_BITS), "bucket positions must fit the item's index field");
-static_assert(MSD_T == DS_BINS, "the bucket kernel scans the digits with one thread each");
 
 // FIRST: the source is the raw key array (all P entries of the view, culled ones have a zero depth field)
 // MSD (with FIRST): the digit is the top of the key relative to the view's range; every block derives the range from the
@@ -79,7 +76,7 @@ __global__ __launch_bounds__(DS_T) void ds_count_kernel(int P, int V, int nchunk
                                                         const uint32_t* __restrict__ field, const uint64_t* __restrict__ keys,
                                                         int word_shift, uint32_t dmask, uint16_t* __restrict__ hist,
                                                         const int2* __restrict__ key_mm, int nb_mm,
-                                                        uint32_t* __restrict__ range) {
+                                                        uint32_t* __restrict__ range, DepthSortSegments sg) {
   __shared__ unsigned int s_h[DS_BINS];
   __shared__ int s_mm[2][DS_NW];
   int v, c;
@@ -87,7 +84,10 @@ __global__ __launch_bounds__(DS_T) void ds_count_kernel(int P, int V, int nchunk
   for (int d = threadIdx.x; d < DS_BINS; d += DS_T) s_h[d] = 0u;
   uint32_t kmin = 0u;
   int sh = 0;
-  if (MSD) {
+  if (MSD && key_mm == nullptr) {  // the caller knows the key range of every segment (sg.range_in, also read by the launches behind)
+    kmin = sg.range_in[2 * v];
+    sh = (int)sg.range_in[2 * v + 1];
+  } else if (MSD) {
     int mn = 0x7fffffff, mx = 0;
     const int2* row = key_mm + (int64_t)v * nb_mm;
 #pragma unroll 4
@@ -110,8 +110,13 @@ __global__ __launch_bounds__(DS_T) void ds_count_kernel(int P, int V, int nchunk
     if (c == 0 && threadIdx.x == 0) range[2 * v] = kmin, range[2 * v + 1] = (uint32_t)sh;
   }
   __syncthreads();
-  const int n = FIRST ? P : nvalid[v];
-  const int64_t vbase = (int64_t)v * P;
+  const int64_t vbase = sg.seg_off ? (int64_t)sg.seg_off[v] : (int64_t)v * P;
+  const int n = !FIRST ? nvalid[v] : sg.seg_off ? sg.seg_off[v + 1] - sg.seg_off[v] : P;
+  if (c * DS_CHUNK >= n) {  // (a short or empty segment: nothing of it in this chunk -- and nothing to read)
+    uint16_t* dst0 = hist + ((int64_t)v * nchunk + c) * DS_BINS;
+    for (int d = threadIdx.x; d < DS_BINS; d += DS_T) dst0[d] = 0;
+    return;
+  }
   // all loads first, on clamped indices and without branches (the compiler keeps a conditional load behind the LDS atomic
   // of the previous step: eight memory round trips per workgroup instead of one), then the histogram
   uint32_t dg[DS_STEPS];
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(DS_T) void ds_scatter_kernel(int P, int V, int nchu
                                                           uint64_t* __restrict__ keys_out, const uint32_t* __restrict__ rect_raw,
                                                           uint32_t* __restrict__ rect_out, int32_t* __restrict__ ids_out,
                                                           int32_t* __restrict__ nvalid_out,
-                                                          const uint32_t* __restrict__ range) {
+                                                          const uint32_t* __restrict__ range, DepthSortSegments sg) {
   static_assert(!MSD || (FIRST && !LAST), "the top-digit pass is a first pass with another launch behind it");
   __shared__ unsigned int s_cnt[DS_NW][DS_BINS];  // per-wave digit counters -> per-wave bases
   __shared__ int s_delta[DS_BINS];                // global position of a digit's run minus its chunk-local start
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(DS_T) void ds_scatter_kernel(int P, int V, int nchu
   __shared__ unsigned short s_dig[FIRST ? DS_CHUNK : 1];
   int v, c;
   if (!ds_block(V, nchunk, v, c)) return;
-  const int n = FIRST ? P : nvalid[v];
+  const int n = !FIRST ? nvalid[v] : sg.seg_off ? sg.seg_off[v + 1] - sg.seg_off[v] : P;
   if (c * DS_CHUNK >= n) return;
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   const uint32_t kmin = MSD ? range[2 * v] : 0u;
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(DS_T) void ds_scatter_kernel(int P, int V, int nchu
   for (int i = threadIdx.x; i < DS_NW * DS_BINS; i += DS_T) (&s_cnt[0][0])[i] = 0u;
   __syncthreads();
   // ---- phase 1: wave w takes positions [w * 512, (w + 1) * 512) of the chunk, 64 at a time in order
-  const int64_t vbase = (int64_t)v * P;
+  const int64_t vbase = sg.seg_off ? (int64_t)sg.seg_off[v] : (int64_t)v * P;
   const int wbase = c * DS_CHUNK + wv * (DS_CHUNK / DS_NW);
   uint64_t key[DS_STEPS];
   unsigned short digit[DS_STEPS];
@@ -365,44 +370,54 @@ __global__ __launch_bounds__(DS_T) void ds_scatter_kernel(int P, int V, int nchu
 
 // One workgroup per (view, bucket of the top-digit pass): the bucket's words -- a contiguous run of keys[], in id order --
 // leave in (rest of the key, id) order as ids + rectangles.
-template <bool LANE_ORDERED>
-__global__ __launch_bounds__(MSD_T) void ds_bucket_sort_kernel(int P, const int32_t* __restrict__ digit_total,
+// BT threads and room for BCAP items: the launch for the usual buckets, and one with small workgroups for callers with
+// tens of thousands of small buckets (grid_subsample: ~400 points each -- 512 threads and 80 KB of LDS per bucket made the
+// launch 190 us, all of it per-workgroup overhead); a workgroup only takes buckets of n_lo < n <= n_hi entries.
+template <bool LANE_ORDERED, int BT, int BCAP>
+__global__ __launch_bounds__(BT) void ds_bucket_sort_kernel(int P, int n_lo, int n_hi, const int32_t* __restrict__ digit_total,
                                                                const uint32_t* __restrict__ range,
                                                                const uint64_t* __restrict__ keys, int id_bits,
                                                                int32_t* __restrict__ ids_out, uint32_t* __restrict__ rect_out,
-                                                               int32_t* __restrict__ flag, int flag_value, DepthSortTotals ct) {
-  __shared__ unsigned int s_cnt[MSD_NW][DS_BINS];
-  __shared__ uint32_t s_item[2][MSD_CAP];
-  __shared__ int s_w[MSD_NW];
-  __shared__ int s_ct[MSD_CAP / 64 + 2];  // tile instances per chunk the bucket touches (chunk >= 64 entries)
+                                                               int32_t* __restrict__ flag, int flag_value, DepthSortTotals ct,
+                                                               DepthSortSegments sg) {
+  constexpr int BNW = BT / WAVE, BSTEPS = (BCAP + BT - 1) / BT, DPT = DS_BINS / BT;  // digits per thread in the scan
+  static_assert(DS_BINS % BT == 0 && BCAP <= (1 << MSD_IDX_BITS), "bucket workgroup shape");
+  __shared__ unsigned int s_cnt[BNW][DS_BINS];
+  __shared__ uint32_t s_item[2][BCAP];
+  __shared__ int s_w[BNW];
+  __shared__ int s_ct[BCAP / 64 + 2];  // tile instances per chunk the bucket touches (chunk >= 64 entries)
   const int v = blockIdx.y, d = blockIdx.x;
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   const int32_t* trow = digit_total + v * DS_BINS;
   const int n = trow[d];
-  if (n == 0) return;
-  // where the bucket starts: the totals of the digits below (512 threads, one digit each)
+  if (n <= n_lo || n > n_hi) return;  // (n_lo >= 0: empty buckets leave here)
+  // where the bucket starts: the totals of the digits below
   {
-    const int mine = (int)threadIdx.x < d ? trow[threadIdx.x] : 0;
+    int mine = 0;
+    for (int i = threadIdx.x; i < d; i += BT) mine += trow[i];
     const int ws = wave_sum_i32_dpp(mine);
     if (lane == 0) s_w[wv] = ws;
   }
   __syncthreads();
   int start = 0;
 #pragma unroll
-  for (int w = 0; w < MSD_NW; ++w) start += s_w[w];
+  for (int w = 0; w < BNW; ++w) start += s_w[w];
   const int sh = (int)range[2 * v + 1];
-  const int64_t base = (int64_t)v * P + start;
+  const int64_t vbase = sg.seg_off ? (int64_t)sg.seg_off[v] : (int64_t)v * P;
+  const int64_t base = vbase + start;
+  const int32_t id_add = sg.seg_off ? sg.seg_off[v] : 0;  // segments with offsets: ids leave as positions in the whole array
   const uint32_t idmask = (1u << id_bits) - 1u;
-  if (n > MSD_CAP && sh != 0) {
+  if (n > BCAP && sh != 0) {
     // the frame will be repeated; until then the launches behind this one must find nothing to bin here
     // (empty rectangles, no chunk totals) rather than whatever the buffers held
     if (threadIdx.x == 0) {
       if (flag_value > 0) atomicOr(flag, flag_value);  // a bit next to others
       else *flag = flag_value;                         // a per-call stamp
     }
-    for (int i = threadIdx.x; i < n; i += MSD_T) {
-      ids_out[base + i] = 0;
-      rect_out[base + i] = 0u;
+    for (int i = threadIdx.x; i < n; i += BT) {
+      ids_out[base + i] = id_add;
+      if (sg.key64_out != nullptr) sg.key64_out[base + i] = (uint64_t)v << sg.key64_shift;
+      else rect_out[base + i] = 0u;
     }
     return;
   }
@@ -411,16 +426,17 @@ __global__ __launch_bounds__(MSD_T) void ds_bucket_sort_kernel(int P, const int3
   const int chunk0 = ct.chunk_total != nullptr ? start / ct.chunk : 0;
   const bool few_chunks = ct.chunk_total != nullptr && (start + n - 1) / ct.chunk - chunk0 < (int)(sizeof(s_ct) / sizeof(int));
   if (ct.chunk_total != nullptr && few_chunks)
-    for (int i = threadIdx.x; i < (int)(sizeof(s_ct) / sizeof(int)); i += MSD_T) s_ct[i] = 0;
+    for (int i = threadIdx.x; i < (int)(sizeof(s_ct) / sizeof(int)); i += BT) s_ct[i] = 0;
   auto emit = [&](int j, bool have, uint64_t k) {  // wave-uniform call; j = position in the bucket
     const uint32_t id = (uint32_t)(k >> 26) & idmask, r = (uint32_t)k & 0x3ffffffu;
     if (have) {
-      ids_out[base + j] = (int32_t)id;
-      rect_out[base + j] = r;
+      ids_out[base + j] = (int32_t)id + id_add;
+      if (sg.key64_out != nullptr) sg.key64_out[base + j] = ((uint64_t)v << sg.key64_shift) | r;  // (segment, payload) words
+      else rect_out[base + j] = r;
     }
     if (ct.chunk_total != nullptr) {
       int x0, y0, w = 0, h = 0;
-      if (have && r != 0u) rect_decode(r, (int)id, (int64_t)v * P, ct.rec, ct.gx, ct.gy, x0, y0, w, h);
+      if (have && r != 0u) rect_decode(r, (int)id, vbase, ct.rec, ct.gx, ct.gy, x0, y0, w, h);
       const int nt = have ? w * h : 0;
       const int ck = (start + j) / ct.chunk;
       const int ck_first = __builtin_amdgcn_readfirstlane(ck);
@@ -439,12 +455,12 @@ __global__ __launch_bounds__(MSD_T) void ds_bucket_sort_kernel(int P, const int3
   auto flush_totals = [&]() {
     if (ct.chunk_total == nullptr || !few_chunks) return;
     __syncthreads();
-    for (int i = threadIdx.x; i < (int)(sizeof(s_ct) / sizeof(int)); i += MSD_T)
+    for (int i = threadIdx.x; i < (int)(sizeof(s_ct) / sizeof(int)); i += BT)
       if (s_ct[i] != 0) atomicAdd(&ct.chunk_total[v * ct.nchunk + chunk0 + i], s_ct[i]);
   };
   if (sh == 0 || n == 1) {  // equal keys: id order is the order
     __syncthreads();  // (s_ct cleared)
-    for (int i0 = 0; i0 < n; i0 += MSD_T) {
+    for (int i0 = 0; i0 < n; i0 += BT) {
       const int i = i0 + (int)threadIdx.x;
       if (i0 + wv * WAVE >= n) break;  // wave-uniform
       emit(i, i < n, i < n ? keys[base + i] : 0ull);
@@ -452,22 +468,22 @@ __global__ __launch_bounds__(MSD_T) void ds_bucket_sort_kernel(int P, const int3
     flush_totals();
     return;
   }
-  for (int i = threadIdx.x; i < n; i += MSD_T)
+  for (int i = threadIdx.x; i < n; i += BT)
     s_item[0][i] = ((uint32_t)(keys[base + i] >> (id_bits + 26)) << MSD_IDX_BITS) | (uint32_t)i;
   // a wave's share of the bucket: whole 64-item steps
-  const int seg = ((n + MSD_NW - 1) / MSD_NW + WAVE - 1) / WAVE * WAVE;
+  const int seg = ((n + BNW - 1) / BNW + WAVE - 1) / WAVE * WAVE;
   const int w0 = wv * seg, w1 = min(n, w0 + seg);
   const unsigned long long lt = (1ull << lane) - 1ull;
   int cur = 0;
   for (int shift = MSD_IDX_BITS; shift < MSD_IDX_BITS + sh; shift += DS_BITS) {
     const uint32_t dmask = (1u << min(DS_BITS, MSD_IDX_BITS + sh - shift)) - 1u;
-    for (int i = threadIdx.x; i < MSD_NW * DS_BINS; i += MSD_T) (&s_cnt[0][0])[i] = 0u;
+    for (int i = threadIdx.x; i < BNW * DS_BINS; i += BT) (&s_cnt[0][0])[i] = 0u;
     __syncthreads();  // (also: the items of the previous round are in place)
     const uint32_t* src = s_item[cur];
     uint32_t* dst = s_item[cur ^ 1];
-    int rank[MSD_STEPS];
+    int rank[BSTEPS];
 #pragma unroll
-    for (int j = 0; j < MSD_STEPS; ++j) {
+    for (int j = 0; j < BSTEPS; ++j) {
       rank[j] = -1;
       if (w0 + j * WAVE >= w1) continue;  // wave-uniform
       const int i = w0 + j * WAVE + lane;
@@ -494,29 +510,33 @@ __global__ __launch_bounds__(MSD_T) void ds_bucket_sort_kernel(int P, const int3
       }
     }
     __syncthreads();
-    // digit starts (thread = digit) and the waves' bases inside a digit's run
+    // digit starts (a thread takes DPT adjacent digits) and the waves' bases inside a digit's run
     {
-      unsigned int cw[MSD_NW];
+      unsigned int cw[DPT][BNW];
       int tot = 0;
 #pragma unroll
-      for (int w = 0; w < MSD_NW; ++w) {
-        cw[w] = s_cnt[w][threadIdx.x];
-        tot += (int)cw[w];
-      }
+      for (int u = 0; u < DPT; ++u)
+#pragma unroll
+        for (int w = 0; w < BNW; ++w) {
+          cw[u][w] = s_cnt[w][threadIdx.x * DPT + u];
+          tot += (int)cw[u][w];
+        }
       const int incl = wave_incl_scan_add_dpp(tot);
       if (lane == WAVE - 1) s_w[wv] = incl;
       __syncthreads();
       int run = incl - tot;
       for (int w = 0; w < wv; ++w) run += s_w[w];
 #pragma unroll
-      for (int w = 0; w < MSD_NW; ++w) {
-        s_cnt[w][threadIdx.x] = (unsigned int)run;
-        run += (int)cw[w];
-      }
+      for (int u = 0; u < DPT; ++u)
+#pragma unroll
+        for (int w = 0; w < BNW; ++w) {
+          s_cnt[w][threadIdx.x * DPT + u] = (unsigned int)run;
+          run += (int)cw[u][w];
+        }
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < MSD_STEPS; ++j)
+    for (int j = 0; j < BSTEPS; ++j)
       if (rank[j] >= 0) {
         const uint32_t it = src[w0 + j * WAVE + lane];
         dst[s_cnt[wv][(it >> shift) & dmask] + (unsigned int)rank[j]] = it;
@@ -524,7 +544,7 @@ __global__ __launch_bounds__(MSD_T) void ds_bucket_sort_kernel(int P, const int3
     cur ^= 1;
     __syncthreads();  // the bases are read to the end before the next round clears them; the items are in place
   }
-  for (int j0 = 0; j0 < n; j0 += MSD_T) {
+  for (int j0 = 0; j0 < n; j0 += BT) {
     const int j = j0 + (int)threadIdx.x;
     if (j0 + wv * WAVE >= n) break;  // wave-uniform
     emit(j, j < n, j < n ? keys[base + (s_item[cur][j] & ((1u << MSD_IDX_BITS) - 1u))] : 0ull);
@@ -553,7 +573,7 @@ bool depth_sort_msd_possible(int64_t P, int V, int key_bits) {
 int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* keys_a, uint64_t* keys_b, int32_t* ids_out,
                      uint32_t* rect_out, int32_t* nvalid_out, int64_t P, int V, int key_bits, void* table, size_t table_bytes,
                      hipStream_t stream, const int2* key_mm, int nb_mm, int32_t* overflow_flag, int overflow_value,
-                     const DepthSortTotals* chunk_totals) {
+                     const DepthSortTotals* chunk_totals, const DepthSortSegments* segments) {
   if (P <= 0 || V <= 0) return GR_OK;
   GR_REQUIRE(key_bits >= 1 && key_bits <= 32, "depth_sort: key_bits %d out of range", key_bits);
   GR_REQUIRE(table && table_bytes >= depth_sort_table_bytes(P, V), "depth_sort: table too small");
@@ -570,11 +590,17 @@ int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* 
   const dim3 grid((unsigned)ds_grid(V, nchunk)), blk(DS_T);
   int id_bits = 1;
   while (id_bits < 32 && (1ll << id_bits) < P) ++id_bits;
-  if (key_mm != nullptr) {  // top-digit pass + one launch over the buckets (see the head of this file)
-    GR_REQUIRE(depth_sort_msd_possible(P, V, key_bits) && overflow_flag != nullptr && nb_mm > 0, "depth_sort: bucket path misused");
+  DepthSortSegments sg{nullptr, nullptr, nullptr, 0};
+  if (segments != nullptr) sg = *segments;
+  if (key_mm != nullptr || segments != nullptr) {  // top-digit pass + one launch over the buckets (see the head of this file)
+    GR_REQUIRE(overflow_flag != nullptr && P <= (1ll << 20) && key_bits <= 3 * DS_BITS &&
+                   (segments != nullptr ? (key_mm == nullptr && sg.range_in != nullptr)
+                                        : (depth_sort_msd_possible(P, V, key_bits) && nb_mm > 0)),
+               "depth_sort: bucket path misused");
     const uint32_t dmask = DS_BINS - 1;
+    if (segments != nullptr) range = const_cast<uint32_t*>(sg.range_in);
     hipLaunchKernelGGL((ds_count_kernel<true, true>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field,
-                       (const uint64_t*)nullptr, 0, dmask, hist, key_mm, nb_mm, range);
+                       (const uint64_t*)nullptr, 0, dmask, hist, key_mm, nb_mm, range, sg);
     DepthSortTotals ct{nullptr, 1, 0, nullptr, 0, 0};
     if (chunk_totals != nullptr) ct = *chunk_totals;
     hipLaunchKernelGGL(ds_scan_kernel, dim3((unsigned)(V * (DS_BINS / WAVE))), dim3(DS_SCAN_NW * WAVE), 0, stream, nchunk, hist,
@@ -582,18 +608,30 @@ int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* 
     if (ordered)
       hipLaunchKernelGGL((ds_scatter_kernel<true, false, true, true>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field,
                          (const uint64_t*)nullptr, 0, id_bits, dmask, offs, dbase, keys_a, rect_raw, rect_out, ids_out, nvalid_out,
-                         range);
+                         range, sg);
     else
       hipLaunchKernelGGL((ds_scatter_kernel<true, false, false, true>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field,
                          (const uint64_t*)nullptr, 0, id_bits, dmask, offs, dbase, keys_a, rect_raw, rect_out, ids_out, nvalid_out,
-                         range);
+                         range, sg);
     const dim3 bgrid(DS_BINS, (unsigned)V);
+    // many small buckets (segments: tens of thousands of a few hundred entries): those first, on small workgroups
+    constexpr int SMALL_T = 128, SMALL_CAP = 1024;
+    const bool two_sizes = segments != nullptr;
+    const int split = two_sizes ? SMALL_CAP : 0;
+    if (two_sizes) {
+      if (ordered)
+        hipLaunchKernelGGL((ds_bucket_sort_kernel<true, SMALL_T, SMALL_CAP>), bgrid, dim3(SMALL_T), 0, stream, (int)P, 0, split, dbase,
+                           range, keys_a, id_bits, ids_out, rect_out, overflow_flag, overflow_value, ct, sg);
+      else
+        hipLaunchKernelGGL((ds_bucket_sort_kernel<false, SMALL_T, SMALL_CAP>), bgrid, dim3(SMALL_T), 0, stream, (int)P, 0, split, dbase,
+                           range, keys_a, id_bits, ids_out, rect_out, overflow_flag, overflow_value, ct, sg);
+    }
     if (ordered)
-      hipLaunchKernelGGL(ds_bucket_sort_kernel<true>, bgrid, dim3(MSD_T), 0, stream, (int)P, dbase, range, keys_a, id_bits, ids_out,
-                         rect_out, overflow_flag, overflow_value, ct);
+      hipLaunchKernelGGL((ds_bucket_sort_kernel<true, MSD_T, MSD_CAP>), bgrid, dim3(MSD_T), 0, stream, (int)P, split, 0x7fffffff, dbase,
+                         range, keys_a, id_bits, ids_out, rect_out, overflow_flag, overflow_value, ct, sg);
     else
-      hipLaunchKernelGGL(ds_bucket_sort_kernel<false>, bgrid, dim3(MSD_T), 0, stream, (int)P, dbase, range, keys_a, id_bits, ids_out,
-                         rect_out, overflow_flag, overflow_value, ct);
+      hipLaunchKernelGGL((ds_bucket_sort_kernel<false, MSD_T, MSD_CAP>), bgrid, dim3(MSD_T), 0, stream, (int)P, split, 0x7fffffff, dbase,
+                         range, keys_a, id_bits, ids_out, rect_out, overflow_flag, overflow_value, ct, sg);
     GR_LAUNCH_CHECK();
     return GR_OK;
   }
@@ -611,16 +649,16 @@ int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* 
     uint64_t* kout = kbuf[p % 2];
     if (first)
       hipLaunchKernelGGL((ds_count_kernel<true, false>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field, kin,
-                         word_shift, dmask, hist, (const int2*)nullptr, 0, (uint32_t*)nullptr);
+                         word_shift, dmask, hist, (const int2*)nullptr, 0, (uint32_t*)nullptr, sg);
     else
       hipLaunchKernelGGL((ds_count_kernel<false, false>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field, kin,
-                         word_shift, dmask, hist, (const int2*)nullptr, 0, (uint32_t*)nullptr);
+                         word_shift, dmask, hist, (const int2*)nullptr, 0, (uint32_t*)nullptr, sg);
     hipLaunchKernelGGL(ds_scan_kernel, dim3((unsigned)(V * (DS_BINS / WAVE))), dim3(DS_SCAN_NW * WAVE), 0, stream, nchunk, hist,
                        offs, dbase, (int32_t*)nullptr, 0);
 #define GR_DS_SCATTER(F, L, O)                                                                                            \
   hipLaunchKernelGGL((ds_scatter_kernel<F, L, O>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field, kin, \
                      word_shift, id_bits, dmask, offs, dbase, kout, rect_raw, rect_out, ids_out, first ? nvalid_out : nullptr, \
-                     (const uint32_t*)nullptr)
+                     (const uint32_t*)nullptr, sg)
     if (ordered) {
       if (first && last) GR_DS_SCATTER(true, true, true);
       else if (first) GR_DS_SCATTER(true, false, true);

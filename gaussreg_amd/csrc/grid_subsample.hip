@@ -18,6 +18,7 @@
 #include <vector>
 
 #include <algorithm>
+#include <atomic>
 
 #include "common.hpp"
 
@@ -27,6 +28,7 @@ namespace {
 struct CloudGrid {
   float ox, oy, oz, v;
   unsigned long long nx, nxny;
+  int sh, pad;  // bucket sort: (cells - 1) >> sh < 512
 };
 
 struct GridWs {
@@ -55,8 +57,18 @@ struct GridWs {
   size_t sort_temp_bytes;
   void* ho_ws;          // device evaluation of the unordered_map iteration order (hash_order_device.hip)
   size_t ho_bytes;
+  void* ds_table;       // bucket sort (depth_sort.hip): histograms / offsets, sized for rows <= ds_rows (cloud, chunk) pairs
+  size_t ds_bytes;
+  int64_t ds_rows;
+  uint32_t* ds_range;   // [2 B] {smallest field, shift} per cloud
+  int32_t* ds_nvalid;   // [B]
+  int32_t* ds_ovf;      // [1] a bucket did not fit
   size_t bytes;
 };
+
+// rows of the bucket sort's tables the workspace holds: (cloud, 2048-point chunk of the LONGEST cloud) pairs -- up to twice
+// what the points need, so a batch of clouds of similar length fits and a very ragged one takes the general sort
+inline int64_t ds_rows_cap(int64_t n, int64_t batch) { return 2 * ((n + 2047) / 2048) + 2 * batch; }
 
 GridWs carve(void* ws, int64_t n, int64_t batch) {
   GridWs w;
@@ -78,7 +90,7 @@ GridWs carve(void* ws, int64_t n, int64_t batch) {
   w.first_idx = c.take<int32_t>(n);
   w.cell_key = c.take<uint64_t>(n);
   w.cell_batch = c.take<int32_t>(n);
-  w.m_b = c.take<int32_t>(batch + 1);  // [batch] = the total (one read-back for counts and total)
+  w.m_b = c.take<int32_t>(batch + 2);  // [batch] = the total, [batch + 1] = bucket-overflow flag (one read-back for all)
   w.cell_of_rank = c.take<int32_t>(n);
   w.keys_fo = c.take<uint64_t>(n);
   w.perm = c.take<int32_t>(n);
@@ -86,6 +98,13 @@ GridWs carve(void* ws, int64_t n, int64_t batch) {
   w.sort_temp = c.take<char>(w.sort_temp_bytes);
   w.ho_bytes = hash_order_device_bytes(n, batch);
   w.ho_ws = c.take<char>(w.ho_bytes);
+  w.ds_rows = ds_rows_cap(n, batch);
+  w.ds_bytes = align_up((size_t)w.ds_rows * 512 * sizeof(uint16_t), 256) + align_up((size_t)w.ds_rows * 512 * sizeof(uint32_t), 256) +
+               align_up((size_t)batch * 512 * sizeof(int32_t), 256) + align_up((size_t)batch * 2 * sizeof(uint32_t), 256) + 512;
+  w.ds_table = c.take<char>(w.ds_bytes);
+  w.ds_range = c.take<uint32_t>(2 * batch);
+  w.ds_nvalid = c.take<int32_t>(batch);
+  w.ds_ovf = c.take<int32_t>(1);
   w.bytes = c.used();
   return w;
 }
@@ -122,6 +141,36 @@ __global__ __launch_bounds__(256) void keys_kernel(const float* __restrict__ pts
   if (key_bits < 64) key |= (unsigned long long)b << key_bits;  // composite (cloud, key)
   keys[i] = key;
   vals[i] = i;
+}
+
+// Bucket-sort front (a batch whose keys fit 26 bits): field = voxel key + 1 (never 0 = "culled" for depth_sort.hip), payload =
+// the voxel key; the first workgroup leaves every cloud's {smallest field, shift} and clears the overflow flag.
+__global__ __launch_bounds__(256) void keys32_kernel(const float* __restrict__ pts, int n, const int32_t* __restrict__ off, int nb,
+                                                     const CloudGrid* __restrict__ grids, uint32_t* __restrict__ field,
+                                                     uint32_t* __restrict__ payload, int32_t* __restrict__ fo_flags,
+                                                     uint32_t* __restrict__ range, int32_t* __restrict__ ovf) {
+  __shared__ int32_t s_off[256];
+  const bool in_lds = nb + 1 <= 256;
+  if (in_lds) {
+    if ((int)threadIdx.x <= nb) s_off[threadIdx.x] = off[threadIdx.x];
+    __syncthreads();
+  }
+  if (blockIdx.x == 0) {
+    for (int b = threadIdx.x; b < nb; b += 256) range[2 * b] = 1u, range[2 * b + 1] = (uint32_t)grids[b].sh;
+    if (threadIdx.x == 0) *ovf = 0;
+  }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (fo_flags) fo_flags[i] = 0;
+  const int b = in_lds ? find_batch(s_off, nb, i) : find_batch(off, nb, i);
+  const CloudGrid g = grids[b];
+  const float x = pts[3 * (int64_t)i], y = pts[3 * (int64_t)i + 1], z = pts[3 * (int64_t)i + 2];
+  const unsigned long long ix = to_size_t(floor((double)((x - g.ox) / g.v)));
+  const unsigned long long iy = to_size_t(floor((double)((y - g.oy) / g.v)));
+  const unsigned long long iz = to_size_t(floor((double)((z - g.oz) / g.v)));
+  const uint32_t key = (uint32_t)(ix + g.nx * iy + g.nxny * iz);  // < 2^26 (checked on the host: no negative cell, no wrap)
+  field[i] = key + 1u;
+  payload[i] = key;
 }
 
 // keys (without the cloud id) for points listed in `vals` order
@@ -236,11 +285,13 @@ __global__ __launch_bounds__(256) void cells_kernel(
 __global__ void cloud_counts_kernel(const int32_t* __restrict__ head_scan,
                                     const int32_t* __restrict__ total, int n,
                                     const int32_t* __restrict__ off, int nb,
-                                    int32_t* __restrict__ m_b, int32_t* mail, int stamp) {
+                                    int32_t* __restrict__ m_b, int32_t* mail, int stamp,
+                                    const int32_t* __restrict__ ovf) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b == 0) {
     m_b[nb] = total[0];
-    if (mail) mail[nb] = total[0];
+    m_b[nb + 1] = ovf ? *ovf : 0;
+    if (mail) mail[nb] = total[0], mail[nb + 1] = m_b[nb + 1];
   }
   if (b < nb) {
     const int a = off[b], e = off[b + 1];
@@ -252,7 +303,7 @@ __global__ void cloud_counts_kernel(const int32_t* __restrict__ head_scan,
   if (mail) {
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) mail_post(mail + nb + 1, stamp);
+    if (threadIdx.x == 0) mail_post(mail + nb + 2, stamp);
   }
 }
 
@@ -271,6 +322,10 @@ __global__ __launch_bounds__(256) void fo_rank_kernel(const int32_t* __restrict_
   keys_fo[r] = cell_key[c];
 }
 
+// Test switch (gr_grid_subsample_debug_bucket_sort): 0 = every call takes the general radix sort
+std::atomic<int> g_grid_bucket_sort{1};
+std::atomic<int> g_grid_bucket_fallbacks{0};  // calls that started over because a bucket overflowed (test hook)
+
 inline int bits_for(unsigned long long v) {  // bits needed to represent values in [0, v)
   int b = 0;
   while (b < 64 && (1ull << b) < v) ++b;
@@ -287,10 +342,10 @@ extern "C" size_t gr_grid_subsample_workspace_bytes(int64_t n, int64_t batch) {
   return carve(nullptr, n, batch).bytes;
 }
 
-extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, int64_t n,
-                                 int64_t batch, float voxel, int order_mode, float* out_points,
-                                 int64_t* h_out_lengths, int64_t* h_total_m, void* ws,
-                                 size_t ws_bytes, void* stream_) {
+static int grid_subsample_impl(const float* points, const int64_t* h_lengths, int64_t n,
+                               int64_t batch, float voxel, int order_mode, float* out_points,
+                               int64_t* h_out_lengths, int64_t* h_total_m, void* ws,
+                               size_t ws_bytes, void* stream_, bool allow_bucket_sort) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   GR_REQUIRE(h_total_m && (batch == 0 || (h_lengths && h_out_lengths)), "null host pointer");
   *h_total_m = 0;
@@ -321,7 +376,7 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
   const size_t o_hb = o_tick + 256;
   const size_t o_grids = o_hb + align_up(sizeof(uint32_t) * 6 * batch, 256);
   const size_t o_mb = o_grids + align_up(sizeof(CloudGrid) * batch, 256);
-  char* pin = static_cast<char*>(pinned_scratch(7, o_mb + sizeof(int32_t) * (batch + 1)));
+  char* pin = static_cast<char*>(pinned_scratch(7, o_mb + sizeof(int32_t) * (batch + 2)));
   GR_REQUIRE(pin != nullptr, "grid_subsample: pinned staging buffer could not be allocated");
   GR_REQUIRE(reinterpret_cast<char*>(w.bbox) == reinterpret_cast<char*>(w.off) + o_bbox &&
                  reinterpret_cast<char*>(w.blk_off) == reinterpret_cast<char*>(w.off) + o_blk &&
@@ -370,7 +425,7 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
   bool wrap = false;
   const float inv = static_cast<float>(1.0 / static_cast<double>(voxel));  // :11 `(1. / voxel_size)` -> float
   for (int64_t b = 0; b < batch; ++b) {
-    CloudGrid g{0.f, 0.f, 0.f, voxel, 1ull, 1ull};
+    CloudGrid g{0.f, 0.f, 0.f, voxel, 1ull, 1ull, 0, 0};
     if (h_lengths[b] > 0) {
       const float mnx = ord2f(hb[b * 6 + 0]), mny = ord2f(hb[b * 6 + 1]), mnz = ord2f(hb[b * 6 + 2]);
       const float mxx = ord2f(hb[b * 6 + 3]), mxy = ord2f(hb[b * 6 + 4]), mxz = ord2f(hb[b * 6 + 5]);
@@ -386,7 +441,10 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
       if ((mnx - g.ox) / voxel < 0.f || (mny - g.oy) / voxel < 0.f || (mnz - g.oz) / voxel < 0.f) wrap = true;
       const long double cells = (long double)NX * (long double)NY * (long double)NZ;
       if (cells >= 18446744073709551615.0L || !std::isfinite((double)cells)) wrap = true;
-      else if ((unsigned long long)cells > max_cells) max_cells = (unsigned long long)cells;
+      else {
+        if ((unsigned long long)cells > max_cells) max_cells = (unsigned long long)cells;
+        g.sh = std::max(0, bits_for((unsigned long long)cells) - 9);  // fields 1 .. cells: (cells - 1) >> sh < 512
+      }
     }
     hg[b] = g;
   }
@@ -397,11 +455,32 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
   if (!composite) key_bits = 64;
 
   const dim3 blk(256), grd((unsigned)((n + 255) / 256));
+  uint64_t* keys_sorted = w.keys_b;
+  int32_t* vals_sorted = w.vals_b;
+  // Bucket sort (depth_sort.hip: ONE pass over the top nine bits of every cloud's own key range, then every bucket -- a few
+  // hundred points, whole voxels -- is finished inside LDS): two trips through memory instead of three radix passes with
+  // three launches each.  For voxel keys of <= 26 bits, clouds of <= 2^20 points and a batch that is not too ragged (the
+  // tables are laid out for the longest cloud); a bucket that outgrows LDS (a cloud crowded into a few voxel slabs) raises
+  // a flag that comes back with the cell counts, and the call starts over with the general sort.
+  int64_t max_len = 0;
+  for (int64_t b = 0; b < batch; ++b) max_len = std::max<int64_t>(max_len, h_lengths[b]);
+  const bool bucket = allow_bucket_sort && composite && !wrap && key_bits <= 26 && max_len <= (1ll << 20) &&
+                      batch * ((max_len + 2047) / 2048) <= w.ds_rows && depth_sort_table_bytes(max_len, nb) <= w.ds_bytes;
+  if (bucket) {
+    uint32_t* field = reinterpret_cast<uint32_t*>(w.keys_a);
+    uint32_t* payload = field + n;
+    hipLaunchKernelGGL(keys32_kernel, grd, blk, 0, stream, points, (int)n, w.off, nb, w.grids, field, payload,
+                       order_mode != GR_ORDER_CELL ? w.flags : nullptr, w.ds_range, w.ds_ovf);
+    GR_LAUNCH_CHECK();
+    const DepthSortSegments sg{w.off, w.ds_range, w.keys_fo, key_bits};
+    rc = depth_sort_views(field, payload, w.keys_b, w.keys_b, w.vals_b, reinterpret_cast<uint32_t*>(w.scan), w.ds_nvalid, max_len, nb,
+                          27, w.ds_table, w.ds_bytes, stream, nullptr, 0, w.ds_ovf, 1, nullptr, &sg);
+    if (rc != GR_OK) return rc;
+    keys_sorted = w.keys_fo;  // (cloud << key_bits | voxel key) words, as the general sort leaves them
+  } else {
   hipLaunchKernelGGL(keys_kernel, grd, blk, 0, stream, points, (int)n, w.off, nb, w.grids, key_bits, w.keys_a, w.vals_a,
                      order_mode != GR_ORDER_CELL ? w.flags : nullptr);
   GR_LAUNCH_CHECK();
-  uint64_t* keys_sorted = w.keys_b;
-  int32_t* vals_sorted = w.vals_b;
   if (composite || batch == 1) {
     rc = sort_pairs_u64_i32(w.sort_temp, w.sort_temp_bytes, w.keys_a, w.keys_b, w.vals_a, w.vals_b, n, 0,
                             composite ? key_bits + b_bits : 64, stream);
@@ -419,6 +498,7 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
     keys_sorted = w.keys_b;  // overwritten by regather_keys
     hipLaunchKernelGGL(regather_keys_kernel, grd, blk, 0, stream, points, vals_sorted, (int)n, w.off, nb, w.grids, keys_sorted);
   }
+  }
   GR_LAUNCH_CHECK();
 
   // ---- runs -> cells
@@ -435,17 +515,24 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
                      w.cell_key, w.cell_batch, fo_flags);
   int32_t* mail_counts = mail ? const_cast<int32_t*>(mail) + MAIL_GRID_COUNTS : nullptr;  // (nb <= 80: one workgroup)
   const int stamp2 = mail ? mailbox_next_stamp() : 0;
-  if (mail) mailbox_arm(mail + MAIL_GRID_COUNTS + batch + 1);
+  if (mail) mailbox_arm(mail + MAIL_GRID_COUNTS + batch + 2);
   hipLaunchKernelGGL(cloud_counts_kernel, dim3((nb + 255) / 256), blk, 0, stream, head_scan, w.totals, (int)n, w.off,
-                     nb, w.m_b, mail_counts, stamp2);
+                     nb, w.m_b, mail_counts, stamp2, bucket ? w.ds_ovf : nullptr);
   GR_LAUNCH_CHECK();
   int32_t h_m = 0;
+  // (bucket sort) a bucket overflowed: nothing behind the sort is valid -- the whole call again, general sort
+  auto start_over = [&]() -> int {
+    GR_HIP(hipStreamSynchronize(stream));  // nothing of this attempt may still post into the mailbox page
+    g_grid_bucket_fallbacks.fetch_add(1);
+    return grid_subsample_impl(points, h_lengths, n, batch, voxel, order_mode, out_points, h_out_lengths, h_total_m, ws,
+                               ws_bytes, stream_, false);
+  };
   if (mail) h_mb = const_cast<const int32_t*>(reinterpret_cast<const volatile int32_t*>(mail + MAIL_GRID_COUNTS));
-  else GR_HIP(hipMemcpyAsync(pin + o_mb, w.m_b, sizeof(int32_t) * (batch + 1), hipMemcpyDeviceToHost, stream));
+  else GR_HIP(hipMemcpyAsync(pin + o_mb, w.m_b, sizeof(int32_t) * (batch + 2), hipMemcpyDeviceToHost, stream));
   // (mailbox: the counts are on the host as soon as cloud_counts_kernel has run -- for the reference order that is while
   // the first-occurrence scan below is still running)
   auto wait_counts = [&]() -> int {
-    if (mail) return mailbox_wait(mail + MAIL_GRID_COUNTS + batch + 1, stamp2, stream, "grid_subsample (cell counts)");
+    if (mail) return mailbox_wait(mail + MAIL_GRID_COUNTS + batch + 2, stamp2, stream, "grid_subsample (cell counts)");
     GR_HIP(hipStreamSynchronize(stream));
     return GR_OK;
   };
@@ -453,6 +540,7 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
   if (order_mode == GR_ORDER_CELL) {
     rc = wait_counts();
     if (rc != GR_OK) return rc;
+    if (bucket && h_mb[batch + 1] != 0) return start_over();
     h_m = h_mb[batch];
   } else {
     // first-occurrence rank of every cell, keys in that order -> host
@@ -461,6 +549,7 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
     if (rc != GR_OK) return rc;
     rc = wait_counts();
     if (rc != GR_OK) return rc;
+    if (bucket && h_mb[batch + 1] != 0) return start_over();
     h_m = h_mb[batch];
     if (h_m > 0) {
       hipLaunchKernelGGL(fo_rank_kernel, dim3((unsigned)(((h_m + 255) / 256 + 7) / 8 * 8)), blk, 0, stream, w.first_idx, w.cell_key,
@@ -482,4 +571,19 @@ extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, 
   for (int64_t b = 0; b < batch; ++b) h_out_lengths[b] = h_mb[b];
   *h_total_m = h_m;
   return GR_OK;
+}
+
+extern "C" int gr_grid_subsample(const float* points, const int64_t* h_lengths, int64_t n,
+                                 int64_t batch, float voxel, int order_mode, float* out_points,
+                                 int64_t* h_out_lengths, int64_t* h_total_m, void* ws,
+                                 size_t ws_bytes, void* stream_) {
+  return grid_subsample_impl(points, h_lengths, n, batch, voxel, order_mode, out_points, h_out_lengths, h_total_m, ws, ws_bytes,
+                             stream_, gr::g_grid_bucket_sort.load() != 0);
+}
+
+extern "C" int gr_grid_subsample_debug_bucket_sort(int on) {
+  if (on == 2) return gr::g_grid_bucket_fallbacks.load();
+  const int old = gr::g_grid_bucket_sort.load();
+  if (on == 0 || on == 1) gr::g_grid_bucket_sort.store(on);
+  return old;
 }

@@ -127,6 +127,10 @@ int gr_hash_order_device(const uint64_t* d_keys, const int64_t* h_begins, int64_
 /* Test switch: 1 = the device evaluation takes the slab-table pre-scan of its > 4 M-clock stages at any size (same order).
  * Returns the old value; another argument only queries. */
 int gr_hash_order_debug_force_prescan(int on);
+/* Test switch: 0 = gr_grid_subsample always sorts with the general three-pass radix sort, 1 (default) = batches that qualify take
+ * the bucket sort (same rows, bit for bit).  Returns the old value; 2 returns instead how many calls of this process started over
+ * with the general sort because a bucket overflowed; another argument only queries the switch. */
+int gr_grid_subsample_debug_bucket_sort(int on);
 size_t gr_grid_subsample_workspace_bytes(int64_t n, int64_t batch);
 int gr_grid_subsample(const float* points, const int64_t* h_lengths, int64_t n, int64_t batch,
                       float voxel_size, int order_mode, float* out_points, int64_t* h_out_lengths,
