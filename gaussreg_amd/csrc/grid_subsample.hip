@@ -37,6 +37,7 @@ struct GridWs {
   int32_t* blk_off;     // [B+1]
   int32_t* ticket;      // [1] zeroed with the first upload: the last bbox workgroup posts the boxes to the host
   CloudGrid* grids;     // [B]
+  int32_t* cblk;        // [B+1] first 256-position workgroup of every cloud (workgroups do not straddle clouds); uploaded with grids
   uint64_t* keys_a;     // [N]
   uint64_t* keys_b;     // [N]
   int32_t* vals_a;      // [N]
@@ -78,6 +79,7 @@ GridWs carve(void* ws, int64_t n, int64_t batch) {
   w.blk_off = c.take<int32_t>(batch + 1);
   w.ticket = c.take<int32_t>(1);
   w.grids = c.take<CloudGrid>(batch);
+  w.cblk = c.take<int32_t>(batch + 1);
   w.keys_a = c.take<uint64_t>(n);
   w.keys_b = c.take<uint64_t>(n);
   w.vals_a = c.take<int32_t>(n);
@@ -197,19 +199,38 @@ __global__ __launch_bounds__(256) void batch_keys_kernel(const int32_t* __restri
   if (t < n) bkeys[t] = (uint64_t)find_batch(off, nb, vals[t]);
 }
 
-// head[t] = 1 where a new (cloud, voxel) run starts in sorted order
-__global__ __launch_bounds__(256) void heads_kernel(const uint64_t* __restrict__ keys,
-                                                    const int32_t* __restrict__ vals, int n,
-                                                    const int32_t* __restrict__ off, int nb,
-                                                    int composite, int32_t* __restrict__ head) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  int h = 1;
-  if (t > 0) {
-    h = keys[t] != keys[t - 1];
-    if (!h && !composite) h = find_batch(off, nb, vals[t]) != find_batch(off, nb, vals[t - 1]);
-  }
-  head[t] = h;
+// does a new (cloud, voxel) run start at sorted position t?
+__device__ __forceinline__ int is_head(const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals,
+                                       const int32_t* __restrict__ off, int nb, int composite, int t) {
+  if (t == 0) return 1;
+  int h = keys[t] != keys[t - 1];
+  if (!h && !composite) h = find_batch(off, nb, vals[t]) != find_batch(off, nb, vals[t - 1]);
+  return h;
+}
+
+// run heads per workgroup of 256 sorted positions.  The cell index of a run = (heads in the workgroups in front: a scan over
+// n / 256 values) + (heads in front of it inside its own workgroup: cells_kernel counts those itself) -- the head flags and
+// their scan over all n positions (three launches, 100 MB written and read back at 64 x 200 k) are never materialised.
+// (Workgroups do not straddle clouds -- cblk[b] = first workgroup of cloud b -- so a cloud's run count is a difference of two
+// scan values and nobody has to count inside a workgroup for it.)
+__device__ __forceinline__ int wg_first_position(const int32_t* __restrict__ cblk, const int32_t* __restrict__ off, int nb, int wg,
+                                                 int& end) {
+  const int b = find_batch(cblk, nb, wg);
+  end = off[b + 1];
+  return off[b] + (wg - cblk[b]) * 256;
+}
+
+__global__ __launch_bounds__(256) void head_count_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals, int n,
+                                                         const int32_t* __restrict__ off, int nb, int composite,
+                                                         const int32_t* __restrict__ cblk, int32_t* __restrict__ blk_cnt) {
+  __shared__ int s_w[256 / WAVE];
+  int end;
+  const int t = wg_first_position(cblk, off, nb, (int)blockIdx.x, end) + (int)threadIdx.x;
+  const int h = t < end ? is_head(keys, vals, off, nb, composite, t) : 0;
+  const int c = __popcll(__ballot(h != 0));
+  if ((threadIdx.x & (WAVE - 1)) == 0) s_w[threadIdx.x / WAVE] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
 // Barycentres: sequential fp32 sums in input order (stable sort => ascending index), one thread per run head -- but the
@@ -219,30 +240,37 @@ __global__ __launch_bounds__(256) void heads_kernel(const uint64_t* __restrict__
 // a 64 x 200 k call.)  A run that continues past the workgroup's 256 positions is finished from global memory.
 __global__ __launch_bounds__(256) void cells_kernel(
     const float* __restrict__ pts, const uint64_t* __restrict__ keys,
-    const int32_t* __restrict__ vals, const int32_t* __restrict__ head,
-    const int32_t* __restrict__ head_scan, int n, const int32_t* __restrict__ off, int nb,
+    const int32_t* __restrict__ vals, const int32_t* __restrict__ blk_base, int composite,
+    const int32_t* __restrict__ cblk, int n_wg, int n, const int32_t* __restrict__ off, int nb,
     int key_bits, float* __restrict__ bary, int32_t* __restrict__ first_idx,
     uint64_t* __restrict__ cell_key, int32_t* __restrict__ cell_batch,
     int32_t* __restrict__ fo_flags) {
   __shared__ float s_x[256], s_y[256], s_z[256];
   __shared__ int s_head[256];
+  __shared__ int s_wc[256 / WAVE];
   // XCD-aware block order (block b runs on XCD b % 8): every XCD gets one contiguous eighth of the sorted positions, i.e. its
   // own clouds.  The gather below reads a cloud's points at random: in launch order all eight L2s fetched every cloud
   // (measured: 1.2 GB of fetches for 154 MB of points at 64 x 200 k); now each cloud is fetched by one L2.
   const int per_xcd = gridDim.x / 8;  // the grid is padded to a multiple of 8 blocks
   const int blk = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8;
-  if ((int64_t)blk * 256 >= n) return;  // (block-uniform)
-  const int t = blk * 256 + threadIdx.x;
-  const int tc = min(t, n - 1);
+  if (blk >= n_wg) return;  // (block-uniform)
+  int end;
+  const int t = wg_first_position(cblk, off, nb, blk, end) + (int)threadIdx.x;
+  const int tc = min(t, end - 1);
   const int64_t mine = vals[tc];
-  const int h = t < n ? head[tc] : 1;  // positions past the end close the last run
+  const int h = t < end ? is_head(keys, vals, off, nb, composite, tc) : 1;  // positions past the cloud's end close its last run
+  // heads in front of this position inside the workgroup (blk_base: heads in the workgroups in front, see head_count_kernel)
+  const unsigned long long hb = __ballot(h != 0 && t < end);
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  if (lane == 0) s_wc[wv] = __popcll(hb);
   s_x[threadIdx.x] = pts[3 * mine];
   s_y[threadIdx.x] = pts[3 * mine + 1];
   s_z[threadIdx.x] = pts[3 * mine + 2];
   s_head[threadIdx.x] = h;
   __syncthreads();
-  if (t >= n || !h) return;
-  const int cell = head_scan[t];  // exclusive scan of head == index of this run
+  if (t >= end || !h) return;
+  int cell = blk_base[blk] + __popcll(hb & ((1ull << lane) - 1ull));
+  for (int w2 = 0; w2 < wv; ++w2) cell += s_wc[w2];
   float sx = 0.f, sy = 0.f, sz = 0.f;
   int count = 0;
   int l = threadIdx.x;
@@ -255,7 +283,7 @@ __global__ __launch_bounds__(256) void cells_kernel(
   } while (l < 256 && !s_head[l]);
   if (l == 256) {  // the run may go on in the next workgroup's positions
     int u = t + count;
-    while (u < n && !head[u]) {
+    while (u < n && !is_head(keys, vals, off, nb, composite, u)) {
       const int64_t i = vals[u];
       sx += pts[3 * i];
       sy += pts[3 * i + 1];
@@ -279,10 +307,9 @@ __global__ __launch_bounds__(256) void cells_kernel(
   if (fo_flags) fo_flags[first] = 1;  // (reference order only)
 }
 
-// m_b = number of voxel runs of cloud b: sorted positions [off[b], off[b+1]) belong to cloud b,
-// and head_scan (exclusive) numbers the runs, so m_b is a difference of two scan values.
+// m_b = number of voxel runs of cloud b = runs in front of its successor's first workgroup - runs in front of its own.
 // mail (single-workgroup launches only): the nb + 1 words also go to the host's mailbox page, stamped
-__global__ void cloud_counts_kernel(const int32_t* __restrict__ head_scan,
+__global__ void cloud_counts_kernel(const int32_t* __restrict__ cblk, int n_wg, const int32_t* __restrict__ blk_base,
                                     const int32_t* __restrict__ total, int n,
                                     const int32_t* __restrict__ off, int nb,
                                     int32_t* __restrict__ m_b, int32_t* mail, int stamp,
@@ -294,9 +321,8 @@ __global__ void cloud_counts_kernel(const int32_t* __restrict__ head_scan,
     if (mail) mail[nb] = total[0], mail[nb + 1] = m_b[nb + 1];
   }
   if (b < nb) {
-    const int a = off[b], e = off[b + 1];
-    const int ca = a < n ? head_scan[a] : total[0];
-    const int ce = e < n ? head_scan[e] : total[0];
+    const int wa = cblk[b], we = cblk[b + 1];  // the cloud's workgroups
+    const int ca = wa < n_wg ? blk_base[wa] : total[0], ce = we < n_wg ? blk_base[we] : total[0];
     m_b[b] = ce - ca;
     if (mail) mail[b] = ce - ca;
   }
@@ -375,7 +401,8 @@ static int grid_subsample_impl(const float* points, const int64_t* h_lengths, in
   const size_t o_tick = o_blk + align_up(sizeof(int32_t) * (batch + 1), 256);
   const size_t o_hb = o_tick + 256;
   const size_t o_grids = o_hb + align_up(sizeof(uint32_t) * 6 * batch, 256);
-  const size_t o_mb = o_grids + align_up(sizeof(CloudGrid) * batch, 256);
+  const size_t o_cblk = o_grids + align_up(sizeof(CloudGrid) * batch, 256);  // (the carver's alignment: one upload for both)
+  const size_t o_mb = o_cblk + align_up(sizeof(int32_t) * (batch + 1), 256);
   char* pin = static_cast<char*>(pinned_scratch(7, o_mb + sizeof(int32_t) * (batch + 2)));
   GR_REQUIRE(pin != nullptr, "grid_subsample: pinned staging buffer could not be allocated");
   GR_REQUIRE(reinterpret_cast<char*>(w.bbox) == reinterpret_cast<char*>(w.off) + o_bbox &&
@@ -448,7 +475,11 @@ static int grid_subsample_impl(const float* points, const int64_t* h_lengths, in
     }
     hg[b] = g;
   }
-  GR_HIP(hipMemcpyAsync(w.grids, hg, sizeof(CloudGrid) * batch, hipMemcpyHostToDevice, stream));
+  int32_t* h_cblk = reinterpret_cast<int32_t*>(pin + o_cblk);
+  h_cblk[0] = 0;
+  for (int64_t b = 0; b < batch; ++b) h_cblk[b + 1] = h_cblk[b] + (int32_t)((h_lengths[b] + 255) / 256);
+  GR_REQUIRE(reinterpret_cast<char*>(w.cblk) == reinterpret_cast<char*>(w.grids) + (o_cblk - o_grids), "grid_subsample: workspace layout");
+  GR_HIP(hipMemcpyAsync(w.grids, hg, (o_cblk - o_grids) + sizeof(int32_t) * (batch + 1), hipMemcpyHostToDevice, stream));
   int key_bits = wrap ? 64 : bits_for(max_cells);
   const int b_bits = bits_for((unsigned long long)batch);
   const bool composite = key_bits + b_bits <= 64 && key_bits < 64;
@@ -502,21 +533,23 @@ static int grid_subsample_impl(const float* points, const int64_t* h_lengths, in
   GR_LAUNCH_CHECK();
 
   // ---- runs -> cells
-  int32_t* head = w.scan;        // head flags
-  int32_t* head_scan = w.perm;   // exclusive scan of head (perm is free until the very end)
-  hipLaunchKernelGGL(heads_kernel, grd, blk, 0, stream, keys_sorted, vals_sorted, (int)n, w.off, nb,
-                     composite ? 1 : 0, head);
-  rc = exclusive_scan_i32(head, head_scan, n, 1, n, w.scan_ws, w.totals, stream);
+  int32_t* blk_cnt = w.scan;    // run heads per workgroup of 256 sorted positions
+  int32_t* blk_base = w.perm;   // ... and their exclusive scan (perm is free until the very end)
+  const int64_t nblk = h_cblk[nb];  // (>= 1: n > 0)
+  hipLaunchKernelGGL(head_count_kernel, dim3((unsigned)nblk), blk, 0, stream, keys_sorted, vals_sorted, (int)n, w.off, nb,
+                     composite ? 1 : 0, w.cblk, blk_cnt);
+  rc = exclusive_scan_i32(blk_cnt, blk_base, nblk, 1, nblk, w.scan_ws, w.totals, stream);
   if (rc != GR_OK) return rc;
   int32_t* fo_flags = order_mode == GR_ORDER_CELL ? nullptr : w.flags;  // zeroed by keys_kernel
   // cell order: the barycentres ARE the output rows (cell = rank of the voxel key), written in place
-  hipLaunchKernelGGL(cells_kernel, dim3((grd.x + 7) / 8 * 8), blk, 0, stream, points, keys_sorted, vals_sorted, head, head_scan, (int)n,
+  hipLaunchKernelGGL(cells_kernel, dim3((unsigned)((nblk + 7) / 8 * 8)), blk, 0, stream, points, keys_sorted, vals_sorted, blk_base,
+                     composite ? 1 : 0, w.cblk, (int)nblk, (int)n,
                      w.off, nb, composite ? key_bits : 64, order_mode == GR_ORDER_CELL ? out_points : w.bary, w.first_idx,
                      w.cell_key, w.cell_batch, fo_flags);
   int32_t* mail_counts = mail ? const_cast<int32_t*>(mail) + MAIL_GRID_COUNTS : nullptr;  // (nb <= 80: one workgroup)
   const int stamp2 = mail ? mailbox_next_stamp() : 0;
   if (mail) mailbox_arm(mail + MAIL_GRID_COUNTS + batch + 2);
-  hipLaunchKernelGGL(cloud_counts_kernel, dim3((nb + 255) / 256), blk, 0, stream, head_scan, w.totals, (int)n, w.off,
+  hipLaunchKernelGGL(cloud_counts_kernel, dim3((nb + 255) / 256), blk, 0, stream, w.cblk, (int)nblk, blk_base, w.totals, (int)n, w.off,
                      nb, w.m_b, mail_counts, stamp2, bucket ? w.ds_ovf : nullptr);
   GR_LAUNCH_CHECK();
   int32_t h_m = 0;
