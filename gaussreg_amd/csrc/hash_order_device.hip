@@ -96,6 +96,48 @@ __global__ __launch_bounds__(HO_T) void ho_bucket_kernel(const HoCloud* __restri
   nxt[s.ebase + e] = atomicExch(&head[b], e);  // chain order is irrelevant: the walks below only count and take minima
 }
 
+// The same chains without a single global atomic, for tables of up to HO_SLABS_MAX x HO_BSLAB buckets: a workgroup owns a
+// slab of HO_BSLAB consecutive buckets of one (stage, cloud) table with their heads in LDS, streams through ALL the keys of
+// the cloud (coalesced, L2-resident: a cloud's keys are a few hundred KB) and threads the ones that hash into its slab --
+// (slabs) x the key reads and modulo operations, in exchange for LDS exchanges instead of device-scope ones (64 x 75 k cells:
+// 9.6 M returning global atomics were 450 us, most of the reference-order evaluation).
+// (the bucket ids come from a launch of their own, ho_bucket_id_kernel: one modulo per element and stage, not one per slab)
+constexpr int HO_BSLAB = 16384;   // 64 KB of heads
+constexpr int HO_SLABS_MAX = 16;
+constexpr int HO_BT = 1024;
+__global__ __launch_bounds__(HO_T) void ho_bucket_id_kernel(const HoCloud* __restrict__ st_all, int batch,
+                                                            const uint64_t* __restrict__ keys, int32_t* __restrict__ bkt) {
+  const HoCloud s = st_all[blockIdx.z * batch + blockIdx.y];
+  const int le = blockIdx.x * HO_T + threadIdx.x;
+  if (le >= s.m || s.n == 0) return;
+  const int e = s.begin + le;
+  const uint64_t k = keys[e];
+  // std::hash<size_t> is the identity; voxel keys fit 32 bits unless the grid wrapped
+  const uint32_t b = (k >> 32) == 0ull ? (uint32_t)k % s.n : (uint32_t)(k % (uint64_t)s.n);
+  bkt[s.ebase + e] = s.toff + (int)b;
+}
+__global__ __launch_bounds__(HO_BT) void ho_bucket_slab_kernel(const HoCloud* __restrict__ st_all, int batch,
+                                                               const int32_t* __restrict__ bkt,
+                                                               int32_t* __restrict__ head, int32_t* __restrict__ nxt) {
+  __shared__ int32_t s_head[HO_BSLAB];
+  const HoCloud s = st_all[blockIdx.z * batch + blockIdx.y];
+  const uint32_t lo = blockIdx.x * (uint32_t)HO_BSLAB;
+  if (s.n == 0 || s.m <= 0 || lo >= s.n) return;
+  const uint32_t width = min((uint32_t)HO_BSLAB, s.n - lo);
+  for (uint32_t i = threadIdx.x; i < width; i += HO_BT) s_head[i] = -1;
+  __syncthreads();
+  const int32_t* row = bkt + s.ebase + s.begin;
+  int32_t* link = nxt + s.ebase + s.begin;
+  const uint32_t first = (uint32_t)s.toff + lo;
+#pragma unroll 4
+  for (int le = threadIdx.x; le < s.m; le += HO_BT) {
+    const uint32_t r = (uint32_t)row[le] - first;
+    if (r < width) link[le] = atomicExch(&s_head[r], s.begin + le);  // (LDS) chain order is irrelevant, see ho_bucket_kernel
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < width; i += HO_BT) head[s.toff + lo + i] = s_head[i];
+}
+
 __global__ __launch_bounds__(HO_T) void ho_group_kernel(const HoCloud* __restrict__ st, const int32_t* __restrict__ T,
                                                         const int32_t* __restrict__ bkt, const int32_t* __restrict__ head,
                                                         const int32_t* __restrict__ nxt, int32_t* __restrict__ G) {
@@ -425,9 +467,22 @@ int hash_order_device(const uint64_t* keys, const int64_t* h_begins, int64_t bat
   for (size_t k = nsmall; k < nstage; ++k)
     for (int64_t c = 0; c < batch; ++c)
       if (hs[k * batch + c].n) big_m = std::max<int64_t>(big_m, hs[k * batch + c].m);
-  if (nsmall < nstage && big_m > 0)
-    hipLaunchKernelGGL(ho_bucket_kernel, dim3((unsigned)((big_m + HO_T - 1) / HO_T), (unsigned)batch, (unsigned)(nstage - nsmall)),
-                       blk, 0, stream, d_st + nsmall * batch, (int)batch, keys, bkt, head, nxt);
+  if (nsmall < nstage && big_m > 0) {
+    uint64_t big_n = 0;
+    for (size_t k = nsmall; k < nstage; ++k)
+      for (int64_t c = 0; c < batch; ++c) big_n = std::max<uint64_t>(big_n, hs[k * batch + c].n);
+    const unsigned slabs = (unsigned)((big_n + HO_BSLAB - 1) / HO_BSLAB);
+    // (a few clouds: a few hundred thousand atomics are over before the slab workgroups have streamed through their clouds --
+    // one 200 k cloud measured 0.20 ms with the atomics, 0.25 ms with the slabs)
+    if (slabs <= (unsigned)HO_SLABS_MAX && link_entries >= (1 << 20)) {
+      hipLaunchKernelGGL(ho_bucket_id_kernel, dim3((unsigned)((big_m + HO_T - 1) / HO_T), (unsigned)batch, (unsigned)(nstage - nsmall)),
+                         blk, 0, stream, d_st + nsmall * batch, (int)batch, keys, bkt);
+      hipLaunchKernelGGL(ho_bucket_slab_kernel, dim3(slabs, (unsigned)batch, (unsigned)(nstage - nsmall)), dim3(HO_BT), 0, stream,
+                         d_st + nsmall * batch, (int)batch, bkt, head, nxt);
+    } else  // (very large clouds: every slab would stream through all the bucket ids)
+      hipLaunchKernelGGL(ho_bucket_kernel, dim3((unsigned)((big_m + HO_T - 1) / HO_T), (unsigned)batch, (unsigned)(nstage - nsmall)),
+                         blk, 0, stream, d_st + nsmall * batch, (int)batch, keys, bkt, head, nxt);
+  }
   for (size_t k = nsmall; k < nstage; ++k) {
     const HoCloud* st = d_st + k * batch;
     int64_t max_m = 0;  // every cloud takes part: finished ones have their positions carried along (or emitted)

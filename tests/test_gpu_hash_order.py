@@ -76,6 +76,20 @@ def test_device_order_large_clouds(prescan, monkeypatch):
         assert np.array_equal(perm[begins[i]:begins[i + 1]], host_order(c) + begins[i]), i
 
 
+def test_device_order_medium_clouds_take_the_slab_chains():
+    """Tables of at most 16 x 16 384 buckets: the chains are threaded per bucket slab in LDS (ho_bucket_slab_kernel) -- 32-bit
+    and 64-bit keys, heavy collisions, sizes on both sides of a slab boundary; the call above with a 300 000-key cloud keeps
+    the device-scope atomics of ho_bucket_kernel covered."""
+    rng = np.random.default_rng(2)
+    clouds = [distinct(rng, n, kind) for n, kind in ((60000, "dense"), (49505, "random"), (100000, "dense"), (33333, "colliding"),
+                                                     (130000, "dense"), (16384, "dense"), (16385, "colliding"), (5, "random"),
+                                                     (120000, "random"), (90000, "colliding"))]
+    assert sum(len(c) for c in clouds) > 600000  # (the slabs are for calls with many elements; fewer take the atomics)
+    perm, begins = device_order(clouds)
+    for i, c in enumerate(clouds):
+        assert np.array_equal(perm[begins[i]:begins[i + 1]], host_order(c) + begins[i]), i
+
+
 def test_grid_subsample_same_rows_with_either_order_engine(monkeypatch):
     """ext.grid_subsampling(order="reference") through the device evaluation equals the golden (reference C++) rows."""
     from helpers import c1_points, load_golden
