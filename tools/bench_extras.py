@@ -71,8 +71,9 @@ def run(dev):
             sp, _ = ext.grid_subsampling(dp64, lens64, 0.05, order=order)
             ms = _ms(lambda: ext.grid_subsampling(dp64, lens64, 0.05, order=order), 5, 1)
             out[f"grid_subsample_64x200k_{order}_order"] = _hbm(ms, 12 * dp64.shape[0] + 12 * sp.shape[0], Mpts_per_s=round(12.8 / ms * 1e3, 1),
-                                                                note="algorithmic bytes 12 N + 12 M; the implementation is a stable radix sort of (cloud, voxel key, index) "
-                                                                     "+ run passes: ~12 x the algorithmic traffic by construction")
+                                                                note="algorithmic bytes 12 N + 12 M; the implementation is a bucket sort of every cloud's voxel keys (one pass over "
+                                                                     "the top nine bits + every bucket finished in LDS), run heads counted per workgroup, one gather of "
+                                                                     "the points; the measured traffic ratio is in profiles/*_pmc_ops.json")
         del pts64, dp64, sp
         # ---- the data pyramid, 64 pairs of 2 x 30 000 points per call
         Bp = 64
