@@ -386,11 +386,15 @@ __global__ __launch_bounds__(BT) void ds_bucket_sort_kernel(int P, int n_lo, int
   __shared__ uint32_t s_item[2][BCAP];
   __shared__ int s_w[BNW];
   __shared__ int s_ct[BCAP / 64 + 2];  // tile instances per chunk the bucket touches (chunk >= 64 entries)
-  const int v = blockIdx.y, d = blockIdx.x;
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  auto one_bucket = [&](const int v, const int d) {
   const int32_t* trow = digit_total + v * DS_BINS;
   const int n = trow[d];
-  if (n <= n_lo || n > n_hi) return;  // (n_lo >= 0: empty buckets leave here)
+  if (n <= n_lo || n > n_hi) {  // (n_lo >= 0: empty buckets leave here)
+    // two size classes: the launch of the small class lists the buckets of the large one (usually none)
+    if (n > n_hi && sg.big_list != nullptr && threadIdx.x == 0) sg.big_list[atomicAdd(sg.big_cnt, 1)] = v * DS_BINS + d;
+    return;
+  }
   // where the bucket starts: the totals of the digits below
   {
     int mine = 0;
@@ -550,6 +554,18 @@ __global__ __launch_bounds__(BT) void ds_bucket_sort_kernel(int P, int n_lo, int
     emit(j, j < n, j < n ? keys[base + (s_item[cur][j] & ((1u << MSD_IDX_BITS) - 1u))] : 0ull);
   }
   flush_totals();
+  };  // one_bucket
+  if (n_lo > 0 && sg.big_list != nullptr) {
+    // the large class of a two-class call: a fixed grid walks the list the small launch left
+    const int listed = *sg.big_cnt;
+    for (int i = blockIdx.y * gridDim.x + blockIdx.x; i < listed; i += gridDim.x * gridDim.y) {
+      const int code = sg.big_list[i];
+      one_bucket(code / DS_BINS, code % DS_BINS);
+      __syncthreads();  // (the LDS arrays are the next bucket's)
+    }
+    return;
+  }
+  one_bucket((int)blockIdx.y, (int)blockIdx.x);
 }
 
 }  // namespace
@@ -558,7 +574,7 @@ size_t depth_sort_table_bytes(int64_t P, int V) {
   const int64_t nchunk = (P + DS_CHUNK - 1) / DS_CHUNK;
   return align_up((size_t)V * nchunk * DS_BINS * sizeof(uint16_t), 256) +
          align_up((size_t)V * nchunk * DS_BINS * sizeof(uint32_t), 256) + align_up((size_t)V * DS_BINS * sizeof(int32_t), 256) +
-         align_up((size_t)V * 2 * sizeof(uint32_t), 256) + 256;
+         align_up((size_t)V * 2 * sizeof(uint32_t), 256) + align_up(((size_t)V * DS_BINS + 1) * sizeof(int32_t), 256) + 256;
 }
 
 bool depth_sort_msd_possible(int64_t P, int V, int key_bits) {
@@ -583,6 +599,7 @@ int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* 
   uint32_t* offs = cv.take<uint32_t>((size_t)V * nchunk * DS_BINS);
   int32_t* dbase = cv.take<int32_t>((size_t)V * DS_BINS);
   uint32_t* range = cv.take<uint32_t>((size_t)V * 2);
+  int32_t* big = cv.take<int32_t>((size_t)V * DS_BINS + 1);  // [0] count, then the listed (view, bucket) codes
   bool ordered = false;
   int rc = lds_atomics_lane_ordered(stream, &ordered);
   if (rc != GR_OK) return rc;
@@ -590,7 +607,7 @@ int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* 
   const dim3 grid((unsigned)ds_grid(V, nchunk)), blk(DS_T);
   int id_bits = 1;
   while (id_bits < 32 && (1ll << id_bits) < P) ++id_bits;
-  DepthSortSegments sg{nullptr, nullptr, nullptr, 0};
+  DepthSortSegments sg{nullptr, nullptr, nullptr, 0, nullptr, nullptr};
   if (segments != nullptr) sg = *segments;
   if (key_mm != nullptr || segments != nullptr) {  // top-digit pass + one launch over the buckets (see the head of this file)
     GR_REQUIRE(overflow_flag != nullptr && P <= (1ll << 20) && key_bits <= 3 * DS_BITS &&
@@ -603,8 +620,15 @@ int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* 
                        (const uint64_t*)nullptr, 0, dmask, hist, key_mm, nb_mm, range, sg);
     DepthSortTotals ct{nullptr, 1, 0, nullptr, 0, 0};
     if (chunk_totals != nullptr) ct = *chunk_totals;
+    // many small buckets (segments: tens of thousands of a few hundred entries): those first, on small workgroups, which
+    // also list the few large ones for a launch of a fixed grid (a workgroup per bucket that only finds out that the
+    // bucket is not its size cost 22 us at 32 768 buckets)
+    constexpr int SMALL_T = 128, SMALL_CAP = 1024;
+    const bool two_sizes = segments != nullptr;
+    GR_REQUIRE(!(two_sizes && chunk_totals != nullptr), "depth_sort: chunk totals and segments together");
+    if (two_sizes) sg.big_cnt = big, sg.big_list = big + 1;
     hipLaunchKernelGGL(ds_scan_kernel, dim3((unsigned)(V * (DS_BINS / WAVE))), dim3(DS_SCAN_NW * WAVE), 0, stream, nchunk, hist,
-                       offs, dbase, ct.chunk_total, V * ct.nchunk);
+                       offs, dbase, two_sizes ? big : ct.chunk_total, two_sizes ? 1 : V * ct.nchunk);
     if (ordered)
       hipLaunchKernelGGL((ds_scatter_kernel<true, false, true, true>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field,
                          (const uint64_t*)nullptr, 0, id_bits, dmask, offs, dbase, keys_a, rect_raw, rect_out, ids_out, nvalid_out,
@@ -614,10 +638,8 @@ int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* 
                          (const uint64_t*)nullptr, 0, id_bits, dmask, offs, dbase, keys_a, rect_raw, rect_out, ids_out, nvalid_out,
                          range, sg);
     const dim3 bgrid(DS_BINS, (unsigned)V);
-    // many small buckets (segments: tens of thousands of a few hundred entries): those first, on small workgroups
-    constexpr int SMALL_T = 128, SMALL_CAP = 1024;
-    const bool two_sizes = segments != nullptr;
     const int split = two_sizes ? SMALL_CAP : 0;
+    const dim3 biggrid = two_sizes ? dim3(std::min<unsigned>(1024u, (unsigned)V * DS_BINS), 1) : bgrid;
     if (two_sizes) {
       if (ordered)
         hipLaunchKernelGGL((ds_bucket_sort_kernel<true, SMALL_T, SMALL_CAP>), bgrid, dim3(SMALL_T), 0, stream, (int)P, 0, split, dbase,
@@ -627,10 +649,10 @@ int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* 
                            range, keys_a, id_bits, ids_out, rect_out, overflow_flag, overflow_value, ct, sg);
     }
     if (ordered)
-      hipLaunchKernelGGL((ds_bucket_sort_kernel<true, MSD_T, MSD_CAP>), bgrid, dim3(MSD_T), 0, stream, (int)P, split, 0x7fffffff, dbase,
+      hipLaunchKernelGGL((ds_bucket_sort_kernel<true, MSD_T, MSD_CAP>), biggrid, dim3(MSD_T), 0, stream, (int)P, split, 0x7fffffff, dbase,
                          range, keys_a, id_bits, ids_out, rect_out, overflow_flag, overflow_value, ct, sg);
     else
-      hipLaunchKernelGGL((ds_bucket_sort_kernel<false, MSD_T, MSD_CAP>), bgrid, dim3(MSD_T), 0, stream, (int)P, split, 0x7fffffff, dbase,
+      hipLaunchKernelGGL((ds_bucket_sort_kernel<false, MSD_T, MSD_CAP>), biggrid, dim3(MSD_T), 0, stream, (int)P, split, 0x7fffffff, dbase,
                          range, keys_a, id_bits, ids_out, rect_out, overflow_flag, overflow_value, ct, sg);
     GR_LAUNCH_CHECK();
     return GR_OK;

@@ -102,7 +102,8 @@ GridWs carve(void* ws, int64_t n, int64_t batch) {
   w.ho_ws = c.take<char>(w.ho_bytes);
   w.ds_rows = ds_rows_cap(n, batch);
   w.ds_bytes = align_up((size_t)w.ds_rows * 512 * sizeof(uint16_t), 256) + align_up((size_t)w.ds_rows * 512 * sizeof(uint32_t), 256) +
-               align_up((size_t)batch * 512 * sizeof(int32_t), 256) + align_up((size_t)batch * 2 * sizeof(uint32_t), 256) + 512;
+               align_up((size_t)batch * 512 * sizeof(int32_t), 256) + align_up((size_t)batch * 2 * sizeof(uint32_t), 256) +
+               align_up(((size_t)batch * 512 + 1) * sizeof(int32_t), 256) + 512;  // (depth_sort_table_bytes with rows for nchunk * batch)
   w.ds_table = c.take<char>(w.ds_bytes);
   w.ds_range = c.take<uint32_t>(2 * batch);
   w.ds_nvalid = c.take<int32_t>(batch);
@@ -213,19 +214,26 @@ __device__ __forceinline__ int is_head(const uint64_t* __restrict__ keys, const 
 // their scan over all n positions (three launches, 100 MB written and read back at 64 x 200 k) are never materialised.
 // (Workgroups do not straddle clouds -- cblk[b] = first workgroup of cloud b -- so a cloud's run count is a difference of two
 // scan values and nobody has to count inside a workgroup for it.)
+// (one thread searches -- seven dependent loads -- and hands the answer to the others through LDS; contains a barrier)
 __device__ __forceinline__ int wg_first_position(const int32_t* __restrict__ cblk, const int32_t* __restrict__ off, int nb, int wg,
-                                                 int& end) {
-  const int b = find_batch(cblk, nb, wg);
-  end = off[b + 1];
-  return off[b] + (wg - cblk[b]) * 256;
+                                                 int& end, int* s_pair) {
+  if (threadIdx.x == 0) {
+    const int b = find_batch(cblk, nb, wg);
+    s_pair[0] = off[b] + (wg - cblk[b]) * 256;
+    s_pair[1] = off[b + 1];
+  }
+  __syncthreads();
+  end = s_pair[1];
+  return s_pair[0];
 }
 
 __global__ __launch_bounds__(256) void head_count_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals, int n,
                                                          const int32_t* __restrict__ off, int nb, int composite,
                                                          const int32_t* __restrict__ cblk, int32_t* __restrict__ blk_cnt) {
   __shared__ int s_w[256 / WAVE];
+  __shared__ int s_pair[2];
   int end;
-  const int t = wg_first_position(cblk, off, nb, (int)blockIdx.x, end) + (int)threadIdx.x;
+  const int t = wg_first_position(cblk, off, nb, (int)blockIdx.x, end, s_pair) + (int)threadIdx.x;
   const int h = t < end ? is_head(keys, vals, off, nb, composite, t) : 0;
   const int c = __popcll(__ballot(h != 0));
   if ((threadIdx.x & (WAVE - 1)) == 0) s_w[threadIdx.x / WAVE] = c;
@@ -254,8 +262,9 @@ __global__ __launch_bounds__(256) void cells_kernel(
   const int per_xcd = gridDim.x / 8;  // the grid is padded to a multiple of 8 blocks
   const int blk = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8;
   if (blk >= n_wg) return;  // (block-uniform)
+  __shared__ int s_pair[2];
   int end;
-  const int t = wg_first_position(cblk, off, nb, blk, end) + (int)threadIdx.x;
+  const int t = wg_first_position(cblk, off, nb, blk, end, s_pair) + (int)threadIdx.x;
   const int tc = min(t, end - 1);
   const int64_t mine = vals[tc];
   const int h = t < end ? is_head(keys, vals, off, nb, composite, tc) : 1;  // positions past the cloud's end close its last run
@@ -503,7 +512,7 @@ static int grid_subsample_impl(const float* points, const int64_t* h_lengths, in
     hipLaunchKernelGGL(keys32_kernel, grd, blk, 0, stream, points, (int)n, w.off, nb, w.grids, field, payload,
                        order_mode != GR_ORDER_CELL ? w.flags : nullptr, w.ds_range, w.ds_ovf);
     GR_LAUNCH_CHECK();
-    const DepthSortSegments sg{w.off, w.ds_range, w.keys_fo, key_bits};
+    const DepthSortSegments sg{w.off, w.ds_range, w.keys_fo, key_bits, nullptr, nullptr};
     rc = depth_sort_views(field, payload, w.keys_b, w.keys_b, w.vals_b, reinterpret_cast<uint32_t*>(w.scan), w.ds_nvalid, max_len, nb,
                           27, w.ds_table, w.ds_bytes, stream, nullptr, 0, w.ds_ovf, 1, nullptr, &sg);
     if (rc != GR_OK) return rc;
