@@ -159,3 +159,35 @@ def test_equal_depths_take_the_copy_branch():
         assert np.array_equal(img.view(np.uint32), want_c[0].view(np.uint32))
         assert np.array_equal(radii, want_r[0])
     assert L.gr_raster_debug_bucket_cooldown(-1) == 0
+
+
+def test_fuzz_small_odd_shapes_plain_and_deferred_frames():
+    """Random small scenes and image sizes, 1 - 4 cameras per call, three calls each (the first takes the plain path, the others
+    are deferred: bucket sort + the scatter that scans its own segments), against the three-pass sort with its own count / scan
+    launches -- images and radii bit for bit."""
+    from gaussreg_amd import _lib, synthetic
+    from gaussreg_amd.rasterizer import rasterize_views
+    L = _lib.lib()
+    rng = np.random.default_rng(2024)
+    for case in range(14):
+        P = int(rng.integers(1, 6000))
+        W, H = int(rng.integers(17, 300)), int(rng.integers(9, 200))
+        V = int(rng.integers(1, 5))
+        g = synthetic.gaussians_c2(P, seed=100 + case, sh_degree=3)
+        if case % 3 == 0:  # bigger splats: rectangles of many tiles, the marker path
+            g["scales"] = (g["scales"] + np.float32(1.5)).astype(np.float32)
+        t = {k: torch.from_numpy(v).cuda() for k, v in g.items()}
+        sets = [_settings(c, bg=(0.1, 0.2, 0.3)) for c in synthetic.camera_ring(V, W, H, seed=case)]
+        L.gr_raster_debug_bucket_cooldown(1 << 20)
+        try:
+            want_c, want_r, _ = rasterize_views(sets, t["means3D"], t["opacities"], shs=t["shs"], scales=t["scales"],
+                                                rotations=t["rotations"])
+            want_c, want_r = want_c.cpu().numpy(), want_r.cpu().numpy()
+        finally:
+            L.gr_raster_debug_bucket_cooldown(0)
+        for call in range(3):
+            c, r, _ = rasterize_views(sets, t["means3D"], t["opacities"], shs=t["shs"], scales=t["scales"],
+                                      rotations=t["rotations"])
+            assert np.array_equal(c.cpu().numpy().view(np.uint32), want_c.view(np.uint32)), (case, call, P, W, H, V)
+            assert np.array_equal(r.cpu().numpy(), want_r), (case, call)
+        assert L.gr_raster_debug_bucket_cooldown(-1) == 0, case
