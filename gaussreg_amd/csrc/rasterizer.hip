@@ -995,7 +995,16 @@ __global__ __launch_bounds__(TT) void tile_scatter_kernel(int P, int V, int gx, 
   __syncthreads();
   // ---- phase D: the chunk's block leaves as full coalesced lines
   const int32_t* cid = ids + vbase + (int64_t)c * BIN_CHUNK;
-  for (int i = threadIdx.x; i < total; i += TT) point_list[chunk_begin + i] = cid[stage[i]];
+  // (four independent LDS -> gather -> store chains in flight per thread: a rolled loop runs them one after the other)
+  int i = threadIdx.x;
+  for (; i + 3 * TT < total; i += 4 * TT) {
+    const int a0 = cid[stage[i]], a1 = cid[stage[i + TT]], a2 = cid[stage[i + 2 * TT]], a3 = cid[stage[i + 3 * TT]];
+    point_list[chunk_begin + i] = a0;
+    point_list[chunk_begin + i + TT] = a1;
+    point_list[chunk_begin + i + 2 * TT] = a2;
+    point_list[chunk_begin + i + 3 * TT] = a3;
+  }
+  for (; i < total; i += TT) point_list[chunk_begin + i] = cid[stage[i]];
 }
 
 // ------------------------------------------------------------------------------------ blend
