@@ -191,3 +191,27 @@ def test_fuzz_small_odd_shapes_plain_and_deferred_frames():
             assert np.array_equal(c.cpu().numpy().view(np.uint32), want_c.view(np.uint32)), (case, call, P, W, H, V)
             assert np.array_equal(r.cpu().numpy(), want_r), (case, call)
         assert L.gr_raster_debug_bucket_cooldown(-1) == 0, case
+
+
+def test_large_image_few_cameras_deferred():
+    """1920 x 1080 (8 160 tiles: the scatter keeps four waves per chunk and, with rectangles of 5 - 8 tiles a side, expands
+    them through its per-wave instance list), two cameras per call, deferred frames with the self-scanning scatter."""
+    from gaussreg_amd import _lib, synthetic
+    from gaussreg_amd.rasterizer import rasterize_views
+    L = _lib.lib()
+    P, W, H, V = 60000, 1920, 1080, 2
+    g = synthetic.gaussians_c2(P, seed=21, sh_degree=3)
+    g["scales"] = (g["scales"] * np.float32(2.5)).astype(np.float32)  # splats of a few tiles a side
+    t = {k: torch.from_numpy(v).cuda() for k, v in g.items()}
+    sets = [_settings(c) for c in synthetic.camera_ring(V, W, H, seed=4)]
+    L.gr_raster_debug_bucket_cooldown(1 << 20)
+    try:
+        want_c, want_r, _ = rasterize_views(sets, t["means3D"], t["opacities"], shs=t["shs"], scales=t["scales"],
+                                            rotations=t["rotations"])
+        want_c, want_r = want_c.cpu().numpy(), want_r.cpu().numpy()
+    finally:
+        L.gr_raster_debug_bucket_cooldown(0)
+    for call in range(3):
+        c, r, _ = rasterize_views(sets, t["means3D"], t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+        assert np.array_equal(c.cpu().numpy().view(np.uint32), want_c.view(np.uint32)), call
+        assert np.array_equal(r.cpu().numpy(), want_r), call
