@@ -297,7 +297,11 @@ __global__ __launch_bounds__(SCAN_T) void scan_add_self_kernel(int32_t* __restri
 }
 
 // ------------------------------------------------------------------ per-cloud bounding boxes
-constexpr int BBOX_CHUNK = 1024;  // points per block (3072 floats = 256 threads x 12: four batches of three independent loads)
+constexpr int BBOX_SLICE = 1024;  // points per step of a block (3072 floats = 256 threads x 12 loads, all in flight together)
+constexpr int BBOX_CHUNK = 4 * BBOX_SLICE;  // points per block: its six atomics land on the few cache lines that hold ALL the
+                                            // boxes of the call and are served one at a time (~10 ns) -- with 1 024 points per
+                                            // block the 75 000 atomics of a 64 x 200 k call WERE the launch (60 us); four steps
+                                            // per block: a quarter of them
 
 // Block `blk` reduces one BBOX_CHUNK-point slice of ONE cloud (blk_off[b] = first block of cloud
 // b), reading it as a flat, fully coalesced float stream, and issues 6 atomics.
@@ -315,48 +319,80 @@ __global__ __launch_bounds__(256) void bbox_kernel(const float* __restrict__ pts
                                                    uint32_t* __restrict__ bbox, BboxPost post) {
   __shared__ uint32_t red[6][256 / WAVE];
   __shared__ int s_last;
-  const int b0 = find_batch(blk_off, nb, (int)blockIdx.x);
-  const int p_first = off[b0] + ((int)blockIdx.x - blk_off[b0]) * BBOX_CHUNK;
-  const int p_end = min(off[b0 + 1], p_first + BBOX_CHUNK);
-  const int64_t f0 = (int64_t)p_first * 3, f1 = (int64_t)p_end * 3;
+  __shared__ int s_where[3];
+  __shared__ int32_t s_tab[256];
+  // which cloud: a search through blk_off -- seven DEPENDENT loads in front of the data loads of every workgroup (3 - 4 us of a
+  // 5 us workgroup).  Small batches: the table comes into LDS with one load and is searched there.
+  if (nb + 1 <= 256) {
+    if ((int)threadIdx.x <= nb) s_tab[threadIdx.x] = blk_off[threadIdx.x];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int bb = nb + 1 <= 256 ? find_batch(s_tab, nb, (int)blockIdx.x) : find_batch(blk_off, nb, (int)blockIdx.x);
+    s_where[0] = bb;
+    s_where[1] = off[bb] + ((int)blockIdx.x - (nb + 1 <= 256 ? s_tab[bb] : blk_off[bb])) * BBOX_CHUNK;
+    s_where[2] = off[bb + 1];
+  }
+  __syncthreads();
+  const int b0 = s_where[0];
+  const int p_first = s_where[1];
+  const int p_end = min(s_where[2], p_first + BBOX_CHUNK);
   uint32_t lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
+  for (int ps = p_first; ps < p_end; ps += BBOX_SLICE) {  // (block-uniform trip count)
+  const int64_t f0 = (int64_t)ps * 3, f1 = (int64_t)min(p_end, ps + BBOX_SLICE) * 3;
   // the axis of element f is f % 3 and the stride is 256 = 1 (mod 3): a thread's elements cycle through the axes, so
   // three consecutive loads (issued together) feed lo/hi[ax], [ax+1], [ax+2] -- no modulo, no dependent load chain
   const int ax0 = (int)((f0 + threadIdx.x) % 3);
   const float* src = pts + f0;
   const int count = (int)(f1 - f0);
   uint32_t l3[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, h3[3] = {0u, 0u, 0u};  // indexed by (axis - ax0) mod 3
-  // all twelve loads of the thread first, on clamped indices and without branches: ONE memory round trip per workgroup
+  // all twelve loads of the thread first, on clamped indices and without branches: ONE memory round trip per step
   // (four batches of three, each behind the previous one's use, were four: 94 us for 64 x 200 k points)
-  constexpr int PER = 3 * BBOX_CHUNK / 256;
+  constexpr int PER = 3 * BBOX_SLICE / 256;
   static_assert(PER % 3 == 0, "a thread's elements must cycle through the axes");
-  float raw[PER];
+  static_assert(PER == 12, "the aligned path reads a thread's share as three float4");
+  const bool wide = count == 3 * BBOX_SLICE && (reinterpret_cast<uintptr_t>(src) & 15u) == 0;  // block-uniform
+  if (wide) {
+    // a full, 16-byte aligned slice: thread t owns four whole points (floats 12 t .. 12 t + 11) as three 16-byte loads
+    const float4* s4 = reinterpret_cast<const float4*>(src) + 3 * threadIdx.x;
+    const float4 a = s4[0], bq = s4[1], cq = s4[2];  // x y z x | y z x y | z x y z
+    const float ex[4] = {a.x, a.w, bq.z, cq.y}, ey[4] = {a.y, bq.x, bq.w, cq.z}, ez[4] = {a.z, bq.y, cq.x, cq.w};
 #pragma unroll
-  for (int u = 0; u < PER; ++u) raw[u] = src[min((int)threadIdx.x + u * 256, max(count - 1, 0))];
-#pragma unroll
-  for (int u = 0; u < PER; ++u)
-    if ((int)threadIdx.x + u * 256 < count) {
-      const uint32_t v = f2ord(raw[u]);
-      l3[u % 3] = min(l3[u % 3], v);
-      h3[u % 3] = max(h3[u % 3], v);
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t vx = f2ord(ex[u]), vy = f2ord(ey[u]), vz = f2ord(ez[u]);
+      lo[0] = min(lo[0], vx), hi[0] = max(hi[0], vx);
+      lo[1] = min(lo[1], vy), hi[1] = max(hi[1], vy);
+      lo[2] = min(lo[2], vz), hi[2] = max(hi[2], vz);
     }
+  } else {
+    float raw[PER];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {  // slot k holds axis (ax0 + k) % 3
-    const int ax = ax0 + k >= 3 ? ax0 + k - 3 : ax0 + k;
-    lo[0] = ax == 0 ? l3[k] : lo[0];
-    lo[1] = ax == 1 ? l3[k] : lo[1];
-    lo[2] = ax == 2 ? l3[k] : lo[2];
-    hi[0] = ax == 0 ? h3[k] : hi[0];
-    hi[1] = ax == 1 ? h3[k] : hi[1];
-    hi[2] = ax == 2 ? h3[k] : hi[2];
+    for (int u = 0; u < PER; ++u) raw[u] = src[min((int)threadIdx.x + u * 256, max(count - 1, 0))];
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+      if ((int)threadIdx.x + u * 256 < count) {
+        const uint32_t v = f2ord(raw[u]);
+        l3[u % 3] = min(l3[u % 3], v);
+        h3[u % 3] = max(h3[u % 3], v);
+      }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {  // slot k holds axis (ax0 + k) % 3
+      const int ax = ax0 + k >= 3 ? ax0 + k - 3 : ax0 + k;
+      lo[0] = ax == 0 ? min(lo[0], l3[k]) : lo[0];
+      lo[1] = ax == 1 ? min(lo[1], l3[k]) : lo[1];
+      lo[2] = ax == 2 ? min(lo[2], l3[k]) : lo[2];
+      hi[0] = ax == 0 ? max(hi[0], h3[k]) : hi[0];
+      hi[1] = ax == 1 ? max(hi[1], h3[k]) : hi[1];
+      hi[2] = ax == 2 ? max(hi[2], h3[k]) : hi[2];
+    }
   }
+  }
+  // wave-wide on the DPP network (the ordered words, biased into int range): six VALU steps per value instead of six
+  // ds_bpermute round trips
 #pragma unroll
-  for (int d = WAVE / 2; d > 0; d >>= 1) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      lo[k] = min(lo[k], (uint32_t)__shfl_xor((int)lo[k], d, WAVE));
-      hi[k] = max(hi[k], (uint32_t)__shfl_xor((int)hi[k], d, WAVE));
-    }
+  for (int k = 0; k < 3; ++k) {
+    lo[k] = (uint32_t)wave_min_i32_dpp((int)(lo[k] ^ 0x80000000u)) ^ 0x80000000u;
+    hi[k] = (uint32_t)wave_max_i32_dpp((int)(hi[k] ^ 0x80000000u)) ^ 0x80000000u;
   }
   const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
   if (lane == 0) {
