@@ -34,6 +34,13 @@
 // [rest (s bits) | position in the bucket (14 bits)] -- all distinct, so plain integer order of the items IS (key, id)
 // order -- sorted by one or two stable 9-bit passes between two LDS buffers, then the words are fetched in that order.
 // A bucket above MSD_CAP raises a flag: the caller repeats the frame with the three-pass sort.
+// The same launch can add up the tile instances of every chunk of sorted positions (DepthSortTotals: what the binning needs
+// first, so that no count launch follows the sort).
+//
+// A second user, grid_subsample.hip (DepthSortSegments): ragged segments (clouds) instead of equal strides, key range known
+// to the caller, the 26-bit payload = the voxel key, ids leaving as global point indices -- the (cloud, voxel key, index)
+// sort of a batch of clouds in two trips through memory.  Its buckets are small (a few hundred points) and many (512 per
+// cloud): they run on 128-thread workgroups, which list the few larger ones for a fixed grid of the big ones.
 #include <type_traits>
 
 #include "common.hpp"
