@@ -278,20 +278,39 @@ __global__ __launch_bounds__(1024) void ho_small_stages_kernel(const HoCloud* __
   const int lane = tid & (WAVE - 1), wv = tid / WAVE;
   const int begin = st_all[c].begin;
   int m_done = 0;
+  // everything the stages read from memory, requested ONCE up front (a stage is a dozen barriers of LDS work; a dependent
+  // trip to memory for its descriptor and another for its keys were most of its 3.4 us): the descriptors of all small
+  // stages (<= HO_SMALL_STAGES) and the first HO_SMALL keys, three per thread in registers
+  constexpr int HO_SMALL_STAGES = 16, KPT = (HO_SMALL + 1023) / 1024;
+  __shared__ int s_m[HO_SMALL_STAGES], s_n[HO_SMALL_STAGES];
+  if (tid < HO_SMALL_STAGES) {
+    const bool have = tid < nsmall;
+    const HoCloud sd = st_all[(have ? tid : 0) * batch + c];
+    s_m[tid] = have ? sd.m : 0;
+    s_n[tid] = have ? (int)sd.n : 0;
+  }
+  // (the last small stage's m -- or, for a cloud whose history ended earlier, its size -- bounds every index the stages use)
+  const int m_all = nsmall > 0 ? st_all[(nsmall - 1) * batch + c].m : 0;
+  uint64_t kreg[KPT];
+#pragma unroll
+  for (int u = 0; u < KPT; ++u) kreg[u] = m_all > 0 ? keys[begin + min(tid + u * 1024, m_all - 1)] : 0ull;
   for (int i = tid; i < HO_SMALL; i += 1024) sT[i] = i;
   __syncthreads();
   for (int k = 0; k < nsmall; ++k) {
-    const HoCloud s = st_all[k * batch + c];
-    if (s.n == 0) break;  // block-uniform: this cloud's history has ended
-    const int m = s.m, n = (int)s.n;
+    if (s_n[k] == 0) break;  // block-uniform: this cloud's history has ended
+    const int m = s_m[k], n = s_n[k];
     for (int i = tid; i < n; i += 1024) {
       sFirst[i] = 0x7fffffff;
       sCnt[i] = 0;
       sHead[i] = -1;
     }
     __syncthreads();
-    for (int e = tid; e < m; e += 1024) {
-      const int b = (int)(keys[begin + e] % (uint64_t)n);
+#pragma unroll
+    for (int u = 0; u < KPT; ++u) {
+      const int e = tid + u * 1024;
+      if (e >= m) break;
+      const uint64_t kk = kreg[u];
+      const int b = (kk >> 32) == 0ull ? (int)((uint32_t)kk % (uint32_t)n) : (int)(kk % (uint64_t)n);
       sB[e] = b;
       atomicMin(&sFirst[b], sT[e]);
       atomicAdd(&sCnt[b], 1);
@@ -460,6 +479,7 @@ int hash_order_device(const uint64_t* keys, const int64_t* h_begins, int64_t bat
   int32_t* Tout = Tb;
   const HoEmit em{perm_out, rows_in, row_of, rows_out};
   // stage 0 (13 buckets) is always small: with no big stage the LDS kernel emits
+  GR_REQUIRE(nsmall <= 16, "hash_order_device: more small stages than the LDS kernel keeps descriptors for");
   hipLaunchKernelGGL(ho_small_stages_kernel, dim3((unsigned)batch), dim3(1024), 0, stream, d_st, (int)batch, (int)nsmall, keys,
                      Ta, Tb, nsmall == nstage ? 1 : 0, em);
   const bool prescan_always = g_ho_force_prescan.load() != 0;  // test hook (gr_hash_order_debug_force_prescan): the > 4 M-clock path
