@@ -140,18 +140,24 @@ __global__ __launch_bounds__(HO_BT) void ho_bucket_slab_kernel(const HoCloud* __
 
 __global__ __launch_bounds__(HO_T) void ho_group_kernel(const HoCloud* __restrict__ st, const int32_t* __restrict__ T,
                                                         const int32_t* __restrict__ bkt, const int32_t* __restrict__ head,
-                                                        const int32_t* __restrict__ nxt, int32_t* __restrict__ G) {
+                                                        const int32_t* __restrict__ nxt, int32_t* __restrict__ G,
+                                                        int2* __restrict__ FW) {
   const HoCloud s = st[blockIdx.y];
   const int le = blockIdx.x * HO_T + threadIdx.x;
   if (le >= s.m || s.n == 0) return;
   const int e = s.begin + le;
   const int t = T[e];
-  int first = t, cnt = 0;
+  int first = t, cnt = 0, within = 0;
   for (int p = head[bkt[s.ebase + e]]; p >= 0; p = nxt[s.ebase + p]) {
-    first = min(first, T[p]);
+    const int tp = T[p];
+    first = min(first, tp);
+    within += tp > t ? 1 : 0;
     ++cnt;
   }
   G[s.begin + t] = (t == first) ? cnt : 0;  // T is a permutation of 0 .. m-1: every slot written once
+  // what ho_rank_kernel needs of the chain -- its oldest clock and how many of its elements are younger than this one -- so
+  // that the chain (three or four dependent random reads per element) is walked ONCE per stage, not twice
+  FW[e] = make_int2(first, within);
 }
 
 // The exclusive suffix sum S[f] = sum of G over clock values > f, in two parts.  Here, one workgroup per slab of HO_SLAB
@@ -212,8 +218,7 @@ constexpr int HO_TAB = 4096;
 // LAST: the positions are final -- emitted (permutation and / or rows) instead of written back.
 template <bool PRESCANNED, bool LAST>
 __global__ __launch_bounds__(HO_T) void ho_rank_kernel(const HoCloud* __restrict__ st, const int32_t* __restrict__ T,
-                                                       const int32_t* __restrict__ bkt,
-                                                       const int32_t* __restrict__ head, const int32_t* __restrict__ nxt,
+                                                       const int2* __restrict__ FW,
                                                        const int32_t* __restrict__ S, const int32_t* __restrict__ slabs,
                                                        int32_t* __restrict__ T_out, HoEmit em) {
   __shared__ int s_above[PRESCANNED ? 1 : HO_TAB];
@@ -249,14 +254,8 @@ __global__ __launch_bounds__(HO_T) void ho_rank_kernel(const HoCloud* __restrict
     }
   }
   if (le >= s.m) return;
-  const int b = bkt[s.ebase + e];
-  const int t = T[e];
-  int within = 0, first = t;
-  for (int p = head[b]; p >= 0; p = nxt[s.ebase + p]) {
-    const int tp = T[p];
-    within += tp > t ? 1 : 0;
-    first = min(first, tp);
-  }
+  const int2 fw = FW[e];  // (ho_group_kernel walked the chain)
+  const int first = fw.x, within = fw.y;
   const int above = PRESCANNED ? slabs[s.soff + first / HO_SLAB] : s_above[first / HO_SLAB];
   const int pos = S[s.begin + first] + above + within;
   if (LAST) ho_emit(em, s.begin, pos, e);
@@ -378,7 +377,7 @@ size_t hash_order_device_bytes(int64_t n, int64_t batch) {
   // bucket ids and chain links per (stage, cloud): the stages' element counts at least halve going back from the last
   // two (m, < m, < m / 2, ...): < 3 n in all
   const size_t links = (size_t)(3 * n + 64 * batch + 64);
-  return align_up((size_t)n * 4, 256) * 4 + align_up(links * 4, 256) * 2 + align_up(2 * buckets * 4, 256) + align_up((size_t)(batch + 1) * 4, 256) * 2 +
+  return align_up((size_t)n * 4, 256) * 4 + align_up((size_t)n * 8, 256) + align_up(links * 4, 256) * 2 + align_up(2 * buckets * 4, 256) + align_up((size_t)(batch + 1) * 4, 256) * 2 +
          align_up((size_t)batch * sizeof(HoCloud), 256) * 64 + 4096;
 }
 
@@ -453,6 +452,7 @@ int hash_order_device(const uint64_t* keys, const int64_t* h_begins, int64_t bat
   int32_t* bkt = cv.take<int32_t>(link_entries);
   int32_t* nxt = cv.take<int32_t>(link_entries);
   int32_t* G = cv.take<int32_t>(n);
+  int2* FW = cv.take<int2>(n);
   int32_t* S = cv.take<int32_t>(n);
   int32_t* head = cv.take<int32_t>(buckets);
   int32_t* d_begins = cv.take<int32_t>(batch + 1);
@@ -510,13 +510,13 @@ int hash_order_device(const uint64_t* keys, const int64_t* h_begins, int64_t bat
     const bool last = k + 1 == nstage;
     if (max_m == 0) continue;
     const dim3 eg((unsigned)((max_m + HO_T - 1) / HO_T), (unsigned)batch);
-    hipLaunchKernelGGL(ho_group_kernel, eg, blk, 0, stream, st, Tin, bkt, head, nxt, G);
+    hipLaunchKernelGGL(ho_group_kernel, eg, blk, 0, stream, st, Tin, bkt, head, nxt, G, FW);
     const int64_t nslab = (max_m + HO_SLAB - 1) / HO_SLAB;
     hipLaunchKernelGGL(ho_suffix_kernel, dim3((unsigned)nslab, (unsigned)batch), dim3(HO_SLAB), 0, stream, st, G, head, S);
     const bool pre = nslab > HO_TAB || prescan_always;
     if (pre) hipLaunchKernelGGL(ho_slabscan_kernel, dim3((unsigned)batch), dim3(1024), 0, stream, st, head);
 #define GR_HO_RANK(P, L) \
-  hipLaunchKernelGGL((ho_rank_kernel<P, L>), eg, blk, 0, stream, st, Tin, bkt, head, nxt, S, head, Tout, em)
+  hipLaunchKernelGGL((ho_rank_kernel<P, L>), eg, blk, 0, stream, st, Tin, FW, S, head, Tout, em)
     if (pre) {
       if (last) GR_HO_RANK(true, true); else GR_HO_RANK(true, false);
     } else {
