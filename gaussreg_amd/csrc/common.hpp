@@ -190,6 +190,7 @@ struct DepthSortSegments {
   int key64_shift;
   int32_t* big_cnt;   // (set by depth_sort_views: the list the small-bucket launch leaves for the large-bucket one)
   int32_t* big_list;
+  const uint64_t* gather64;  // non-null: key64_out[position] = gather64[the entry's index in the whole array] instead
 };
 size_t depth_sort_table_bytes(int64_t P, int V);
 int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* keys_a, uint64_t* keys_b, int32_t* ids_out,

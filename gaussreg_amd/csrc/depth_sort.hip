@@ -442,7 +442,8 @@ __global__ __launch_bounds__(BT) void ds_bucket_sort_kernel(int P, int n_lo, int
     const uint32_t id = (uint32_t)(k >> 26) & idmask, r = (uint32_t)k & 0x3ffffffu;
     if (have) {
       ids_out[base + j] = (int32_t)id + id_add;
-      if (sg.key64_out != nullptr) sg.key64_out[base + j] = ((uint64_t)v << sg.key64_shift) | r;  // (segment, payload) words
+      if (sg.gather64 != nullptr) sg.key64_out[base + j] = sg.gather64[(int64_t)id + id_add];  // a 64-bit value by index
+      else if (sg.key64_out != nullptr) sg.key64_out[base + j] = ((uint64_t)v << sg.key64_shift) | r;  // (segment, payload) words
       else rect_out[base + j] = r;
     }
     if (ct.chunk_total != nullptr) {
@@ -614,7 +615,7 @@ int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* 
   const dim3 grid((unsigned)ds_grid(V, nchunk)), blk(DS_T);
   int id_bits = 1;
   while (id_bits < 32 && (1ll << id_bits) < P) ++id_bits;
-  DepthSortSegments sg{nullptr, nullptr, nullptr, 0, nullptr, nullptr};
+  DepthSortSegments sg{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
   if (segments != nullptr) sg = *segments;
   if (key_mm != nullptr || segments != nullptr) {  // top-digit pass + one launch over the buckets (see the head of this file)
     GR_REQUIRE(overflow_flag != nullptr && P <= (1ll << 20) && key_bits <= 3 * DS_BITS &&

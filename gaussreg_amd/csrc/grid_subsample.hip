@@ -28,7 +28,7 @@ namespace {
 struct CloudGrid {
   float ox, oy, oz, v;
   unsigned long long nx, nxny;
-  int sh, pad;  // bucket sort: (cells - 1) >> sh < 512
+  int sh, sh_fo;  // bucket sorts: (cells - 1) >> sh < 512 (voxel keys), (points - 1) >> sh_fo < 512 (first occurrences)
 };
 
 struct GridWs {
@@ -62,6 +62,8 @@ struct GridWs {
   size_t ds_bytes;
   int64_t ds_rows;
   uint32_t* ds_range;   // [2 B] {smallest field, shift} per cloud
+  uint32_t* ds_range_fo;  // [2 B] the same for the first-occurrence sort
+  int32_t* cell_off;    // [B + 1] first cell (run) of every cloud, on the device (cloud_counts_kernel)
   int32_t* ds_nvalid;   // [B]
   int32_t* ds_ovf;      // [1] a bucket did not fit
   size_t bytes;
@@ -106,6 +108,8 @@ GridWs carve(void* ws, int64_t n, int64_t batch) {
                align_up(((size_t)batch * 512 + 1) * sizeof(int32_t), 256) + 512;  // (depth_sort_table_bytes with rows for nchunk * batch)
   w.ds_table = c.take<char>(w.ds_bytes);
   w.ds_range = c.take<uint32_t>(2 * batch);
+  w.ds_range_fo = c.take<uint32_t>(2 * batch);
+  w.cell_off = c.take<int32_t>(batch + 1);
   w.ds_nvalid = c.take<int32_t>(batch);
   w.ds_ovf = c.take<int32_t>(1);
   w.bytes = c.used();
@@ -151,7 +155,8 @@ __global__ __launch_bounds__(256) void keys_kernel(const float* __restrict__ pts
 __global__ __launch_bounds__(256) void keys32_kernel(const float* __restrict__ pts, int n, const int32_t* __restrict__ off, int nb,
                                                      const CloudGrid* __restrict__ grids, uint32_t* __restrict__ field,
                                                      uint32_t* __restrict__ payload, int32_t* __restrict__ fo_flags,
-                                                     uint32_t* __restrict__ range, int32_t* __restrict__ ovf) {
+                                                     uint32_t* __restrict__ range, int32_t* __restrict__ ovf,
+                                                     uint32_t* __restrict__ range_fo) {
   __shared__ int32_t s_off[256];
   const bool in_lds = nb + 1 <= 256;
   if (in_lds) {
@@ -159,7 +164,10 @@ __global__ __launch_bounds__(256) void keys32_kernel(const float* __restrict__ p
     __syncthreads();
   }
   if (blockIdx.x == 0) {
-    for (int b = threadIdx.x; b < nb; b += 256) range[2 * b] = 1u, range[2 * b + 1] = (uint32_t)grids[b].sh;
+    for (int b = threadIdx.x; b < nb; b += 256) {
+      range[2 * b] = 1u, range[2 * b + 1] = (uint32_t)grids[b].sh;
+      range_fo[2 * b] = 1u, range_fo[2 * b + 1] = (uint32_t)grids[b].sh_fo;
+    }
     if (threadIdx.x == 0) *ovf = 0;
   }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -252,7 +260,9 @@ __global__ __launch_bounds__(256) void cells_kernel(
     const int32_t* __restrict__ cblk, int n_wg, int n, const int32_t* __restrict__ off, int nb,
     int key_bits, float* __restrict__ bary, int32_t* __restrict__ first_idx,
     uint64_t* __restrict__ cell_key, int32_t* __restrict__ cell_batch,
-    int32_t* __restrict__ fo_flags) {
+    int32_t* __restrict__ fo_flags, int fo_local) {
+  // fo_local: first_idx[cell] = the first point's index INSIDE its cloud, + 1 -- the field of the first-occurrence sort
+  // (depth_sort.hip; no flags over the points then)
   __shared__ float s_x[256], s_y[256], s_z[256];
   __shared__ int s_head[256];
   __shared__ int s_wc[256 / WAVE];
@@ -307,10 +317,10 @@ __global__ __launch_bounds__(256) void cells_kernel(
   bary[3 * (int64_t)cell + 1] = sy * wgt;
   bary[3 * (int64_t)cell + 2] = sz * wgt;
   const int first = (int)mine;
-  first_idx[cell] = first;
   const unsigned long long k = keys[t];
   // composite keys carry the cloud in their high bits: no search through the offsets (six dependent loads per head thread)
   const int b = key_bits < 64 ? (int)(k >> key_bits) : find_batch(off, nb, first);
+  first_idx[cell] = fo_local ? first - off[b] + 1 : first;
   cell_batch[cell] = b;
   cell_key[cell] = key_bits < 64 ? (k & ((1ull << key_bits) - 1ull)) : k;
   if (fo_flags) fo_flags[first] = 1;  // (reference order only)
@@ -322,7 +332,7 @@ __global__ void cloud_counts_kernel(const int32_t* __restrict__ cblk, int n_wg, 
                                     const int32_t* __restrict__ total, int n,
                                     const int32_t* __restrict__ off, int nb,
                                     int32_t* __restrict__ m_b, int32_t* mail, int stamp,
-                                    const int32_t* __restrict__ ovf) {
+                                    const int32_t* __restrict__ ovf, int32_t* __restrict__ cell_off) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b == 0) {
     m_b[nb] = total[0];
@@ -333,6 +343,8 @@ __global__ void cloud_counts_kernel(const int32_t* __restrict__ cblk, int n_wg, 
     const int wa = cblk[b], we = cblk[b + 1];  // the cloud's workgroups
     const int ca = wa < n_wg ? blk_base[wa] : total[0], ce = we < n_wg ? blk_base[we] : total[0];
     m_b[b] = ce - ca;
+    cell_off[b] = ca;
+    if (b == nb - 1) cell_off[nb] = ce;
     if (mail) mail[b] = ce - ca;
   }
   if (mail) {
@@ -480,6 +492,7 @@ static int grid_subsample_impl(const float* points, const int64_t* h_lengths, in
       else {
         if ((unsigned long long)cells > max_cells) max_cells = (unsigned long long)cells;
         g.sh = std::max(0, bits_for((unsigned long long)cells) - 9);  // fields 1 .. cells: (cells - 1) >> sh < 512
+        g.sh_fo = std::max(0, bits_for((unsigned long long)h_lengths[b]) - 9);
       }
     }
     hg[b] = g;
@@ -506,13 +519,17 @@ static int grid_subsample_impl(const float* points, const int64_t* h_lengths, in
   for (int64_t b = 0; b < batch; ++b) max_len = std::max<int64_t>(max_len, h_lengths[b]);
   const bool bucket = allow_bucket_sort && composite && !wrap && key_bits <= 26 && max_len <= (1ll << 20) &&
                       batch * ((max_len + 2047) / 2048) <= w.ds_rows && depth_sort_table_bytes(max_len, nb) <= w.ds_bytes;
+  // (reference order) rank the cells by their first point with a second bucket sort instead of flags + a scan over all points:
+  // five launches against four, so only where launches are not the cost (one 200 k cloud: 0.194 ms with the flags, 0.207 with
+  // the sort; 64 of them: 1.26 -> 1.17 ms)
+  const bool fo_by_sort = bucket && order_mode != GR_ORDER_CELL && n >= (1ll << 21);
   if (bucket) {
     uint32_t* field = reinterpret_cast<uint32_t*>(w.keys_a);
     uint32_t* payload = field + n;
     hipLaunchKernelGGL(keys32_kernel, grd, blk, 0, stream, points, (int)n, w.off, nb, w.grids, field, payload,
-                       order_mode != GR_ORDER_CELL ? w.flags : nullptr, w.ds_range, w.ds_ovf);
+                       order_mode != GR_ORDER_CELL && !fo_by_sort ? w.flags : nullptr, w.ds_range, w.ds_ovf, w.ds_range_fo);
     GR_LAUNCH_CHECK();
-    const DepthSortSegments sg{w.off, w.ds_range, w.keys_fo, key_bits, nullptr, nullptr};
+    const DepthSortSegments sg{w.off, w.ds_range, w.keys_fo, key_bits, nullptr, nullptr, nullptr};
     rc = depth_sort_views(field, payload, w.keys_b, w.keys_b, w.vals_b, reinterpret_cast<uint32_t*>(w.scan), w.ds_nvalid, max_len, nb,
                           27, w.ds_table, w.ds_bytes, stream, nullptr, 0, w.ds_ovf, 1, nullptr, &sg);
     if (rc != GR_OK) return rc;
@@ -549,18 +566,32 @@ static int grid_subsample_impl(const float* points, const int64_t* h_lengths, in
                      composite ? 1 : 0, w.cblk, blk_cnt);
   rc = exclusive_scan_i32(blk_cnt, blk_base, nblk, 1, nblk, w.scan_ws, w.totals, stream);
   if (rc != GR_OK) return rc;
-  int32_t* fo_flags = order_mode == GR_ORDER_CELL ? nullptr : w.flags;  // zeroed by keys_kernel
+  // reference order: the cells are ranked by their first point.  General path: a flag per point (zeroed by keys_kernel, set by
+  // cells_kernel), a scan over all points, a launch that reads every cell's rank off it.  Bucket path: cells_kernel leaves
+  // (first point inside its cloud) + 1 per cell and the bucket sort orders the cells of every cloud by it -- sorted position =
+  // rank, so the ids it writes ARE cell_of_rank and its 64-bit output gathers the cells' keys in that order.
+  const bool fo_sort = fo_by_sort;
+  int32_t* fo_flags = order_mode == GR_ORDER_CELL || fo_sort ? nullptr : w.flags;  // zeroed by keys_kernel
   // cell order: the barycentres ARE the output rows (cell = rank of the voxel key), written in place
   hipLaunchKernelGGL(cells_kernel, dim3((unsigned)((nblk + 7) / 8 * 8)), blk, 0, stream, points, keys_sorted, vals_sorted, blk_base,
                      composite ? 1 : 0, w.cblk, (int)nblk, (int)n,
                      w.off, nb, composite ? key_bits : 64, order_mode == GR_ORDER_CELL ? out_points : w.bary, w.first_idx,
-                     w.cell_key, w.cell_batch, fo_flags);
+                     w.cell_key, w.cell_batch, fo_flags, fo_sort ? 1 : 0);
   int32_t* mail_counts = mail ? const_cast<int32_t*>(mail) + MAIL_GRID_COUNTS : nullptr;  // (nb <= 80: one workgroup)
   const int stamp2 = mail ? mailbox_next_stamp() : 0;
   if (mail) mailbox_arm(mail + MAIL_GRID_COUNTS + batch + 2);
   hipLaunchKernelGGL(cloud_counts_kernel, dim3((nb + 255) / 256), blk, 0, stream, w.cblk, (int)nblk, blk_base, w.totals, (int)n, w.off,
-                     nb, w.m_b, mail_counts, stamp2, bucket ? w.ds_ovf : nullptr);
+                     nb, w.m_b, mail_counts, stamp2, bucket ? w.ds_ovf : nullptr, w.cell_off);
   GR_LAUNCH_CHECK();
+  if (fo_sort) {
+    // (no bucket of this sort can overflow: its digit is the top nine bits of a point index, so a bucket holds the cells whose
+    // first point lies in a span of <= len / 512 <= 2 048 points)
+    uint32_t* fo_field = reinterpret_cast<uint32_t*>(w.first_idx);  // also the (unused, < 2^26) payload
+    const DepthSortSegments sg2{w.cell_off, w.ds_range_fo, w.keys_fo, 0, nullptr, nullptr, w.cell_key};
+    rc = depth_sort_views(fo_field, fo_field, w.keys_b, w.keys_b, w.cell_of_rank, reinterpret_cast<uint32_t*>(w.scan), w.ds_nvalid,
+                          max_len, nb, 27, w.ds_table, w.ds_bytes, stream, nullptr, 0, w.ds_ovf, 1, nullptr, &sg2);
+    if (rc != GR_OK) return rc;
+  }
   int32_t h_m = 0;
   // (bucket sort) a bucket overflowed: nothing behind the sort is valid -- the whole call again, general sort
   auto start_over = [&]() -> int {
@@ -587,13 +618,16 @@ static int grid_subsample_impl(const float* points, const int64_t* h_lengths, in
   } else {
     // first-occurrence rank of every cell, keys in that order -> host
     int32_t* fo_scan = w.scan;  // head flags no longer needed
-    rc = exclusive_scan_i32(fo_flags, fo_scan, n, 1, n, w.scan_ws, w.totals + 1, stream);
-    if (rc != GR_OK) return rc;
+    if (!fo_sort) {
+      rc = exclusive_scan_i32(fo_flags, fo_scan, n, 1, n, w.scan_ws, w.totals + 1, stream);
+      if (rc != GR_OK) return rc;
+    }
     rc = wait_counts();
     if (rc != GR_OK) return rc;
     if (bucket && h_mb[batch + 1] != 0) return start_over();
     h_m = h_mb[batch];
     if (h_m > 0) {
+      if (!fo_sort)
       hipLaunchKernelGGL(fo_rank_kernel, dim3((unsigned)(((h_m + 255) / 256 + 7) / 8 * 8)), blk, 0, stream, w.first_idx, w.cell_key,
                          fo_scan, h_m, w.cell_of_rank, w.keys_fo);
       GR_LAUNCH_CHECK();

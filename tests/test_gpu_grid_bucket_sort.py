@@ -39,6 +39,7 @@ def _same(points, lengths, voxel):
     (2, [5000, 0, 70000, 1, 12345, 2048, 2049, 0], 0.04),       # ragged, empty clouds, chunk edges
     (3, [100] * 40, 0.1),                                         # many small clouds
     (4, [150000, 900], 0.02),                                     # too ragged for the tables?  either way the same rows
+    (5, [800000, 0, 800000, 5, 700000], 0.03),                    # > 2 M points: the cells are ranked by a second bucket sort
 ])
 def test_bucket_sort_rows_equal_the_general_sort(seed, lengths, voxel):
     rng = np.random.default_rng(seed)
