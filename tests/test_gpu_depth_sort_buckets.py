@@ -178,16 +178,21 @@ def test_fuzz_small_odd_shapes_plain_and_deferred_frames():
             g["scales"] = (g["scales"] + np.float32(1.5)).astype(np.float32)
         t = {k: torch.from_numpy(v).cuda() for k, v in g.items()}
         sets = [_settings(c, bg=(0.1, 0.2, 0.3)) for c in synthetic.camera_ring(V, W, H, seed=case)]
+        kw = dict(shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+        if case % 4 == 1:  # the other preprocess variants: colours given, no SH
+            kw = dict(colors_precomp=torch.rand(P, 3, generator=torch.Generator().manual_seed(case)).cuda(), scales=t["scales"],
+                      rotations=t["rotations"])
+        elif case % 4 == 2:  # ... 4 SH coefficients (degree 1): not the 16-coefficient fast path
+            sets = [s._replace(sh_degree=1) for s in sets]
+            kw = dict(shs=t["shs"][:, :4].contiguous(), scales=t["scales"], rotations=t["rotations"])
         L.gr_raster_debug_bucket_cooldown(1 << 20)
         try:
-            want_c, want_r, _ = rasterize_views(sets, t["means3D"], t["opacities"], shs=t["shs"], scales=t["scales"],
-                                                rotations=t["rotations"])
+            want_c, want_r, _ = rasterize_views(sets, t["means3D"], t["opacities"], **kw)
             want_c, want_r = want_c.cpu().numpy(), want_r.cpu().numpy()
         finally:
             L.gr_raster_debug_bucket_cooldown(0)
         for call in range(3):
-            c, r, _ = rasterize_views(sets, t["means3D"], t["opacities"], shs=t["shs"], scales=t["scales"],
-                                      rotations=t["rotations"])
+            c, r, _ = rasterize_views(sets, t["means3D"], t["opacities"], **kw)
             assert np.array_equal(c.cpu().numpy().view(np.uint32), want_c.view(np.uint32)), (case, call, P, W, H, V)
             assert np.array_equal(r.cpu().numpy(), want_r), (case, call)
         assert L.gr_raster_debug_bucket_cooldown(-1) == 0, case
