@@ -63,6 +63,9 @@ def parse(argv=None):
     ap.add_argument("--no-radius", action="store_true")
     ap.add_argument("--no-radius-limited", action="store_true", help="skip the width-limited radius_search timing")
     ap.add_argument("--no-single-view", action="store_true")
+    ap.add_argument("--no-static-scene", action="store_true",
+                    help="skip the second, static_scene=True pass over the headline workload (tools/prof_all.sh: the rocprofv3 "
+                         "averages of that command are then those of the default path alone)")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--dry", action="store_true",
                     help="first contact with a multi-GPU node: initialise the process group, run the collectives the bench uses "
@@ -381,11 +384,13 @@ def run_gpu(h, args):
                                          rotations=t["rotations"], static_scene=True)
         last["img"] = img
 
-    static_step()
-    st_elapsed = h.timed(static_step, args.steps, args.warmup, after_warmup=L.gr_timing_reset)
-    st_ms, st_n = timing_read(L, "raster_blend")
-    st_kernels = per_step_ms(L, ["raster_preprocess", "raster_depth_sort", "raster_bin", "raster_sort", "raster_blend"],
-                             args.steps)
+    st_elapsed, st_ms, st_n, st_kernels = None, 0.0, 0, None
+    if not args.no_static_scene:
+        static_step()
+        st_elapsed = h.timed(static_step, args.steps, args.warmup, after_warmup=L.gr_timing_reset)
+        st_ms, st_n = timing_read(L, "raster_blend")
+        st_kernels = per_step_ms(L, ["raster_preprocess", "raster_depth_sort", "raster_bin", "raster_sort", "raster_blend"],
+                                 args.steps)
     L.gr_timing_enable(0)
     L.gr_timing_reset()
     R_total = float(sum(last["nr"]))
@@ -408,8 +413,8 @@ def run_gpu(h, args):
                                                         "step's preprocess, sort and binning"},
                                   valu_busy=sq_valu_busy("blend_kernel<false", (P, W, H) == (1_000_000, 640, 480)),
                                   valu_busy_source="profiles/" + str(newest_profile("_sq_counters.json")))})
-    line["config"]["static_scene_views_per_s"] = round(world * V * args.steps / st_elapsed, 2)
-    line["config"]["static_scene_ms_per_step"] = round(st_elapsed / args.steps * 1e3, 4)
+    line["config"]["static_scene_views_per_s"] = round(world * V * args.steps / st_elapsed, 2) if st_elapsed else None
+    line["config"]["static_scene_ms_per_step"] = round(st_elapsed / args.steps * 1e3, 4) if st_elapsed else None
 
     # ------------------------------------------------------------------ the boundary: one camera per forward() call
     if not args.no_single_view:

@@ -1,14 +1,15 @@
 # Collects everything under profiles/ for one round (GPU box, via gpurun):  bash tools/prof_all.sh r03
 # bench.py with its extras or pairs section dies in rocprofv3's exit handler (after the JSON line is out), so the kernel
 # stats come in parts:
-#   <R>_bench_kernel_stats.csv   raster (32 views per launch, NO one-camera section: every rasterizer row is a V = 32 row)
+#   <R>_bench_kernel_stats.csv   raster (32 views per launch on the default path -- no one-camera section, no static-scene pass:
+#                                every rasterizer row is a V = 32 row of one call at a time)
 #                                + radius (bare, limited in both modes) from bench.py
 #   <R>_single_view_kernel_stats.csv   the one-camera loop alone (tools/single_view_loop.py): V = 1 rows
 #   <R>_extras_kernel_stats.csv  everything else through tools/bench_extras.py
 # The counter passes use the same command as the first CSV.
 R=${1:-r03}
 cd $GRAFT_REPO_ROOT
-B="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --pairs 0 --no-single-view"
+B="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --pairs 0 --no-single-view --no-static-scene"
 bash tools/prof.sh bench $GRAFT_REPO_ROOT/$B > /dev/null 2>&1
 bash tools/prof.sh sv $GRAFT_REPO_ROOT/tools/single_view_loop.py > /dev/null 2>&1
 bash tools/prof.sh extras $GRAFT_REPO_ROOT/tools/bench_extras.py > /dev/null 2>&1
