@@ -92,6 +92,11 @@ struct RadiusWs {
   int2* q_rng;         // [3 dy][3 slab][nq] candidate range (p0, p1) per band
   unsigned long long* q_mask;  // [3 slab][nq] hit bits in candidate enumeration order
   int32_t* blk_stats;  // [blocks][2]
+  float* plane_x;      // [ns + 8] cell-ordered coordinate planes of the supports + their original indices (tq_kernel)
+  float* plane_y;
+  float* plane_z;
+  int32_t* plane_i;
+  uint32_t* tiles;     // [nq rounded up to 64][TQ_ROW_CAP] sorted neighbour indices per query, cell order (tq_kernel, compact mode)
   int64_t ccap;
   int64_t nsup;  // upper bound of the number of super-cells
   size_t bytes;
@@ -117,6 +122,10 @@ RadiusWs carve(void* ws, int64_t nq, int64_t ns, int64_t batch) {
   w.pairs_s = c.take<int2>(ns);
   w.start = c.take<int32_t>(2 * (w.ccap + 1));
   w.sorted_s = c.take<float4>(ns);
+  w.plane_x = c.take<float>(ns + 8);
+  w.plane_y = c.take<float>(ns + 8);
+  w.plane_z = c.take<float>(ns + 8);
+  w.plane_i = c.take<int32_t>(ns + 8);
   // query side
   w.q_cell = c.take<int32_t>(nq);
   w.pairs_q = c.take<int2>(nq);
@@ -125,6 +134,7 @@ RadiusWs carve(void* ws, int64_t nq, int64_t ns, int64_t batch) {
   w.q_rng = c.take<int2>(9 * nq);
   w.q_mask = c.take<unsigned long long>(3 * nq);
   w.blk_stats = c.take<int32_t>(2 * ((nq + 63) / 64 + 8));  // fused_kernel runs 64 queries per workgroup
+  w.tiles = c.take<uint32_t>((size_t)((nq + 63) / 64) * 64 * 64);
   w.bytes = c.used();
   return w;
 }
@@ -354,6 +364,10 @@ struct BinSide {
   int32_t* sup_start;     // [nsup+1]
   float4* sorted;         // [n] {x, y, z, original index} in cell order
   int32_t* cell_start;    // [cells+1] or null (queries need no cell table)
+  float* plane_x;         // [n + 8] or null: the same order as coordinate planes + original indices (supports only)
+  float* plane_y;
+  float* plane_z;
+  int32_t* plane_i;
 };
 
 __global__ void bin_init_kernel(uint32_t* __restrict__ bbox, int nb, int32_t* __restrict__ zero, int nzero) {
@@ -545,6 +559,12 @@ __global__ __launch_bounds__(256) void fine_kernel(BinSide A, BinSide B, int blo
         if (a + k * 256 + tid < e) {
           const int slot = atomicAdd(&hist[pr[k].y - first], 1);
           S.sorted[a + slot] = make_float4(cx[k], cy[k], cz[k], __int_as_float(pr[k].x));
+          if (S.plane_x) {
+            S.plane_x[a + slot] = cx[k];
+            S.plane_y[a + slot] = cy[k];
+            S.plane_z[a + slot] = cz[k];
+            S.plane_i[a + slot] = pr[k].x;
+          }
         }
     } else {
       for (int p = a + tid; p < e; p += 256) {
@@ -552,6 +572,12 @@ __global__ __launch_bounds__(256) void fine_kernel(BinSide A, BinSide B, int blo
         const int slot = atomicAdd(&hist[q.y - first], 1);
         const float* src = S.pts + 3 * (int64_t)q.x;
         S.sorted[a + slot] = make_float4(src[0], src[1], src[2], __int_as_float(q.x));
+        if (S.plane_x) {
+          S.plane_x[a + slot] = src[0];
+          S.plane_y[a + slot] = src[1];
+          S.plane_z[a + slot] = src[2];
+          S.plane_i[a + slot] = q.x;
+        }
       }
     }
     __syncthreads();  // hist is cleared by the next super-cell of this workgroup
@@ -1509,6 +1535,8 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
   }
 }
 
+#include "radius_tq.hpp"
+
 // max / max over the per-block (max hits per query, hits per block) pairs -> hdr
 // mail (optional): the header also goes to the host's mailbox page, stamped (common.hpp) -- no copy, no stream synchronise
 __global__ __launch_bounds__(1024) void reduce_stats_kernel(const int32_t* __restrict__ blk_stats,
@@ -1653,6 +1681,35 @@ int launch_fused(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t 
   return reduce_and_read(w, blocks, stream, h_out);
 }
 
+// gr_radius_search mode 2 / the bare search: one thread per query (radius_tq.hpp).  out != null: rows of `width` columns are
+// written by the kernel; out == null: tiles + counts for launch_tq_expand.  h_out->max_block_hits != 0 = a workgroup could not
+// finish: the caller repeats the call on count + fill.
+int launch_tq(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns, int nb, const int32_t* start_s, float r2,
+              int64_t width, int64_t* out, bool mono, hipStream_t stream, RadiusHdr* h_out) {
+  const int blocks = (int)((nq + WAVE - 1) / WAVE);
+  const int grid = (blocks + 7) / 8 * 8;
+  {
+    KernelTimer timer("radius_tq", stream);
+    if (out)
+      hipLaunchKernelGGL((tq_kernel<32, true>), dim3(grid), dim3(WAVE), 0, stream, sorted_q, (int)nq, w.q_off, nb, w.grids, start_s,
+                         w.sorted_s, w.plane_x, w.plane_y, w.plane_z, w.plane_i, (int)ns, r2, w.blk_stats, (int)width, ns, out,
+                         (uint32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (size_t)0, mono ? 1 : 0, getenv("TQ_STOP") ? atoi(getenv("TQ_STOP")) : 0);
+    else
+      hipLaunchKernelGGL((tq_kernel<32, false>), dim3(grid), dim3(WAVE), 0, stream, sorted_q, (int)nq, w.q_off, nb, w.grids, start_s,
+                         w.sorted_s, w.plane_x, w.plane_y, w.plane_z, w.plane_i, (int)ns, r2, w.blk_stats, 0, ns, (int64_t*)nullptr,
+                         w.tiles, w.q_count, w.q_count + nq, (size_t)((nq + 63) / 64) * 64 * 32, mono ? 1 : 0, 0);
+  }
+  return reduce_and_read(w, blocks, stream, h_out);
+}
+
+int launch_tq_expand(const RadiusWs& w, int64_t nq, int64_t ns, int64_t width, int64_t* out, hipStream_t stream) {
+  KernelTimer timer("radius_expand", stream);
+  hipLaunchKernelGGL(tq_expand_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(256), 0, stream, w.tiles, w.q_count, w.q_count + nq,
+                     (size_t)((nq + 63) / 64) * 64 * 32, (int)nq, (int)width, ns, out);
+  GR_LAUNCH_CHECK();
+  return GR_OK;
+}
+
 inline bool fused_fits(int64_t width) {
   // the row buffer / key area of the largest configuration must fit next to the candidate planes
   return width >= 1 && FusedLds<FUSED_RQ>::total((int)width, (int)((2 * width + 2 + 15) / 16 * 16), 0) <= 160 * 1024;
@@ -1753,8 +1810,10 @@ int radius_prepare(const float* q, const float* s, const int64_t* h_q_lengths, c
   int32_t* start_s = w.start;
   KernelTimer bin_timer("radius_bin", stream);  // bbox .. cell order (nothing is launched when the grid is reused in a self-search)
   const int64_t su = w.nsup + 1;
-  BinSide A{s, (int)ns, w.s_off, w.s_cell, w.pairs_s, w.sup_zero, w.sup_zero + 2 * su, w.sup_start, w.sorted_s, start_s};
-  BinSide B{q, (int)nq, w.q_off, w.q_cell, w.pairs_q, w.sup_zero + su, w.sup_zero + 3 * su, w.sup_start + su, w.sorted_q, nullptr};
+  BinSide A{s, (int)ns, w.s_off, w.s_cell, w.pairs_s, w.sup_zero, w.sup_zero + 2 * su, w.sup_start, w.sorted_s, start_s,
+            w.plane_x, w.plane_y, w.plane_z, w.plane_i};
+  BinSide B{q, (int)nq, w.q_off, w.q_cell, w.pairs_q, w.sup_zero + su, w.sup_zero + 3 * su, w.sup_start + su, w.sorted_q, nullptr,
+            nullptr, nullptr, nullptr, nullptr};
   const int blocks_s = (int)((ns + COARSE_PTS - 1) / COARSE_PTS), blocks_q = (int)((nq + COARSE_PTS - 1) / COARSE_PTS);
   if (!reuse) {
     // ---- supports (and, in the same launches, the queries): bbox, grid, two-level counting sort
@@ -1801,6 +1860,20 @@ int radius_prepare(const float* q, const float* s, const int64_t* h_q_lengths, c
 }  // namespace
 }  // namespace gr
 
+namespace gr {
+namespace {
+// 0 = count, host, fill; 1 = the single-pass kernel (three threads per query); 2 = one thread per query (radius_tq.hpp).
+// Initialised from GR_RADIUS_SINGLE_PASS.
+std::atomic<int>& search_mode() {
+  static std::atomic<int> mode{[] {
+    const char* a = getenv("GR_RADIUS_SINGLE_PASS");
+    return (a && a[0] == '1') ? 1 : ((a && a[0] == '2') ? 2 : 0);
+  }()};
+  return mode;
+}
+}  // namespace
+}  // namespace gr
+
 extern "C" int gr_radius_count_cached(const float* q, const float* s, const int64_t* h_q_lengths,
                                       const int64_t* h_s_lengths, int64_t nq, int64_t ns, int64_t batch,
                                       float radius, void* ws, size_t ws_bytes, int64_t* h_info,
@@ -1816,6 +1889,18 @@ extern "C" int gr_radius_count_cached(const float* q, const float* s, const int6
   const RadiusWs& w = P.w;
   const bool same = P.same;
   RadiusHdr h;
+  if (search_mode().load() == 2) {
+    // one thread per query: the whole search now (sorted rows as u32 tiles), gr_radius_fill only widens them
+    rc = launch_tq(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, 0, nullptr, same, stream, &h);
+    if (rc != GR_OK) return rc;
+    if (h.max_block_hits == 0 && h.max_count <= (unsigned)TQ_ROW_CAP) {
+      h_info[0] = h.max_count;
+      h_info[1] = -1;  // the tiles are in the workspace
+      h_info[2] = same ? 1 : 0;
+      h_info[3] = h.total_cells;
+      return GR_OK;
+    }
+  }
   rc = launch_count<RT>(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, same, stream, &h);
   if (rc != GR_OK) return rc;
   h_info[0] = h.max_count;
@@ -1850,25 +1935,13 @@ extern "C" int gr_radius_fill(const float* q, const float* s, int64_t nq, int64_
   const bool same = h_info[2] != 0;
   const float4* sorted_q = same ? w.sorted_s : w.sorted_q;
   const float r2 = radius * radius;
+  if (h_info[1] == -1) return launch_tq_expand(w, nq, ns, width, out, stream);
   return launch_fill<RT>(w, sorted_q, nq, ns, (int)batch, r2, width, width, h_info[1], out, stream);
 }
 
-namespace gr {
-namespace {
-// 0 = count, host, fill (default); 1 = the single-pass kernel.  Initialised from GR_RADIUS_SINGLE_PASS.
-std::atomic<int>& search_mode() {
-  static std::atomic<int> mode{[] {
-    const char* a = getenv("GR_RADIUS_SINGLE_PASS");
-    return (a && a[0] == '1') ? 1 : 0;
-  }()};
-  return mode;
-}
-}  // namespace
-}  // namespace gr
-
 extern "C" int gr_radius_search_mode(int mode) {
   const int old = search_mode().load();
-  if (mode >= 0 && mode <= 1) search_mode().store(mode);
+  if (mode >= 0 && mode <= 2) search_mode().store(mode);
   return old;
 }
 
@@ -1890,10 +1963,11 @@ extern "C" int gr_radius_search(const float* q, const float* s, const int64_t* h
   // GR_RADIUS_SINGLE_PASS=1 selects the single-pass kernel (fused_kernel above).  It is not the default: on 8 x 200 k points it
   // runs as long as count + fill together (both are bound by VALU issue: ~3 000 instructions per wave either way)
   const int mode = search_mode().load();
-  bool fused = mode == 1 && fused_fits(limit);
+  const bool fused = (mode == 1 && fused_fits(limit)) || mode == 2;
   if (fused) {
     RadiusHdr hf;
-    rc = launch_fused(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, out, P.same, stream, &hf);
+    rc = mode == 2 ? launch_tq(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, out, P.same, stream, &hf)
+                   : launch_fused(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, out, P.same, stream, &hf);
     if (rc != GR_OK) return rc;
     h_info[0] = hf.max_count;
     h_info[2] = P.same ? 1 : 0;

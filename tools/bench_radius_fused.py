@@ -17,11 +17,14 @@ def child():
     L = _lib.lib()
     B = int(os.environ.get("BRF_CLOUDS", "8"))
     lim = int(os.environ.get("BRF_LIMIT", "40"))
-    two = False
+    two = os.environ.get("BRF_BARE", "0") == "1"
     L.gr_radius_search_mode(int(os.environ.get("BRF_MODE", "1")))
     pts, lens = synthetic.cloud_200k(B, seed=0)
     d = pts.cuda()
-    fn = lambda: ext.radius_neighbors_limited(d, d, lens, lens, 0.0625, lim, two_pass=two)  # noqa: E731
+    if two:
+        fn = lambda: ext.radius_neighbors(d, d, lens, lens, 0.0625)  # noqa: E731
+    else:
+        fn = lambda: ext.radius_neighbors_limited(d, d, lens, lens, 0.0625, lim)  # noqa: E731
     for _ in range(3):
         out = fn()
     torch.cuda.synchronize()
@@ -34,7 +37,7 @@ def child():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     res = {"ms": round(dt * 1e3, 4), "width": out.shape[1]}
-    for name in ("radius_bin", "radius_count", "radius_fill", "radius_fused"):
+    for name in ("radius_bin", "radius_count", "radius_fill", "radius_fused", "radius_tq", "radius_expand"):
         tot, cnt = ctypes.c_double(0), ctypes.c_int64(0)
         L.gr_timing_read(name.encode(), ctypes.byref(tot), ctypes.byref(cnt))
         if cnt.value:
@@ -45,7 +48,10 @@ def child():
 
 
 def main():
-    for c in ({"BRF_MODE": "0"}, {"BRF_MODE": "1"}):
+    cases = ({"BRF_MODE": "0"}, {"BRF_MODE": "1"}, {"BRF_MODE": "2"}, {"BRF_MODE": "0", "BRF_BARE": "1"}, {"BRF_MODE": "2", "BRF_BARE": "1"})
+    if os.environ.get("BRF_ABLATE"):  # cumulative time of the thread-per-query kernel stopped after each phase
+        cases = tuple({"BRF_MODE": "2", "TQ_STOP": str(k)} for k in (1, 2, 3, 4, 5, 0))
+    for c in cases:
         env = dict(os.environ, BRF_CHILD="1", **c)
         r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
