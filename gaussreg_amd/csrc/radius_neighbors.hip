@@ -25,6 +25,7 @@
 // support side (the data pyramid searches every level's supports three times).
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "common.hpp"
@@ -1862,14 +1863,69 @@ int radius_prepare(const float* q, const float* s, const int64_t* h_q_lengths, c
 
 namespace gr {
 namespace {
-// 0 = count, host, fill; 1 = the single-pass kernel (three threads per query); 2 = one thread per query (radius_tq.hpp).
+// 0 = count, host, fill; 1 = the single-pass kernel (three threads per query); 2 = one thread per query (radius_tq.hpp),
+// always tried first; 3 (default) = one thread per query where it has not given up lately (tq_wanted), else count + fill.
 // Initialised from GR_RADIUS_SINGLE_PASS.
 std::atomic<int>& search_mode() {
   static std::atomic<int> mode{[] {
     const char* a = getenv("GR_RADIUS_SINGLE_PASS");
-    return (a && a[0] == '1') ? 1 : ((a && a[0] == '2') ? 2 : 0);
+    return (a && a[0] >= '0' && a[0] <= '3') ? a[0] - '0' : 3;
   }()};
   return mode;
+}
+}  // namespace
+}  // namespace gr
+
+namespace gr {
+namespace {
+// Which searches the thread-per-query kernel is tried on.  It is built for neighbourhoods of up to ~32 hits (the big levels
+// of the data pyramid: 4 - 14 on average); on denser ones most queries need its exact wave-finished path, the kernel gives
+// up after its tests and the call is repeated on count + fill.  A caller repeats the same (radius, limit) call site over
+// and over (13 per pair in the pyramid), so a give-up is remembered per (radius bits, limit) and that site goes to
+// count + fill directly for the next TQ_RETRY_AFTER calls.
+constexpr int TQ_MEMO = 64, TQ_RETRY_AFTER = 256;
+struct TqMemo {
+  uint32_t rbits;
+  int64_t limit;
+  int skip;  // calls left before the kernel is tried again
+  bool used;
+};
+TqMemo g_tq_memo[TQ_MEMO];
+std::mutex g_tq_memo_mu;
+
+bool tq_wanted(float radius, int64_t limit) {
+  uint32_t rb;
+  memcpy(&rb, &radius, 4);
+  std::lock_guard<std::mutex> lk(g_tq_memo_mu);
+  for (TqMemo& e : g_tq_memo)
+    if (e.used && e.rbits == rb && e.limit == limit) {
+      if (e.skip > 0) {
+        --e.skip;
+        return false;
+      }
+      return true;
+    }
+  return true;
+}
+
+void tq_report(float radius, int64_t limit, bool gave_up) {
+  uint32_t rb;
+  memcpy(&rb, &radius, 4);
+  std::lock_guard<std::mutex> lk(g_tq_memo_mu);
+  TqMemo* slot = nullptr;
+  for (TqMemo& e : g_tq_memo)
+    if (e.used && e.rbits == rb && e.limit == limit) slot = &e;
+  if (!slot && !gave_up) return;
+  if (!slot) {
+    static int next = 0;
+    for (TqMemo& e : g_tq_memo)
+      if (!e.used && !slot) slot = &e;
+    if (!slot) slot = &g_tq_memo[next++ % TQ_MEMO];
+    slot->used = true;
+    slot->rbits = rb;
+    slot->limit = limit;
+  }
+  slot->skip = gave_up ? TQ_RETRY_AFTER : 0;
 }
 }  // namespace
 }  // namespace gr
@@ -1889,11 +1945,14 @@ extern "C" int gr_radius_count_cached(const float* q, const float* s, const int6
   const RadiusWs& w = P.w;
   const bool same = P.same;
   RadiusHdr h;
-  if (search_mode().load() == 2) {
-    // one thread per query: the whole search now (sorted rows as u32 tiles), gr_radius_fill only widens them
+  const int mode = search_mode().load();
+  if ((mode == 2 || mode == 3) && ns < (1ll << 29) && (mode == 2 || tq_wanted(radius, -1))) {
+    // one thread per query: the whole search now (sorted compact rows), gr_radius_fill only widens them
     rc = launch_tq(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, 0, nullptr, same, stream, &h);
     if (rc != GR_OK) return rc;
-    if (h.max_block_hits == 0 && h.max_count <= (unsigned)TQ_ROW_CAP) {
+    const bool done = h.max_block_hits == 0 && h.max_count <= (unsigned)TQ_ROW_CAP;
+    tq_report(radius, -1, !done);
+    if (done) {
       h_info[0] = h.max_count;
       h_info[1] = -1;  // the tiles are in the workspace
       h_info[2] = same ? 1 : 0;
@@ -1941,7 +2000,7 @@ extern "C" int gr_radius_fill(const float* q, const float* s, int64_t nq, int64_
 
 extern "C" int gr_radius_search_mode(int mode) {
   const int old = search_mode().load();
-  if (mode >= 0 && mode <= 2) search_mode().store(mode);
+  if (mode >= 0 && mode <= 3) search_mode().store(mode);
   return old;
 }
 
@@ -1963,12 +2022,14 @@ extern "C" int gr_radius_search(const float* q, const float* s, const int64_t* h
   // GR_RADIUS_SINGLE_PASS=1 selects the single-pass kernel (fused_kernel above).  It is not the default: on 8 x 200 k points it
   // runs as long as count + fill together (both are bound by VALU issue: ~3 000 instructions per wave either way)
   const int mode = search_mode().load();
-  const bool fused = (mode == 1 && fused_fits(limit)) || mode == 2;
+  const bool tq = (mode == 2 || mode == 3) && ns < (1ll << 29) && (mode == 2 || tq_wanted(radius, limit));
+  const bool fused = (mode == 1 && fused_fits(limit)) || tq;
   if (fused) {
     RadiusHdr hf;
-    rc = mode == 2 ? launch_tq(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, out, P.same, stream, &hf)
-                   : launch_fused(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, out, P.same, stream, &hf);
+    rc = tq ? launch_tq(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, out, P.same, stream, &hf)
+            : launch_fused(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, out, P.same, stream, &hf);
     if (rc != GR_OK) return rc;
+    if (tq) tq_report(radius, limit, hf.max_block_hits != 0);
     h_info[0] = hf.max_count;
     h_info[2] = P.same ? 1 : 0;
     h_info[3] = hf.total_cells;

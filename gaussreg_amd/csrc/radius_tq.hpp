@@ -72,7 +72,8 @@ struct TqLds {
   struct Search {
     unsigned short lists[LIST_ROWS * WAVE];
     unsigned short trng[2 * (NBAND + 1) * WAVE];  // the threads' non-empty ranges (start code, end code) + an empty one
-  };
+    char idx_room[NET * WAVE * 4 > (LIST_ROWS + 2 * (NBAND + 1)) * WAVE * 2 ? NET * WAVE * 4 - (LIST_ROWS + 2 * (NBAND + 1)) * WAVE * 2 : 1];
+  };  // (after the tests the same bytes hold idx32[NET][64]: the support index of every list slot)
   struct Rows {  // once the sorted indices are in registers the lists are dead: rows are transposed here
     unsigned int rowbuf[WAVE * RS];
     int2 qinfo[WAVE];  // (original index, count or -1 = finished by the wave)
@@ -268,14 +269,21 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
   }
   TQ_STOP(2, n)
   const bool big = n > NET;
+  // a wave most of whose queries need the exact way is not what this kernel is for: give up before the sort (the caller
+  // repeats the call on count + fill and remembers the shape)
+  if (__popcll(__ballot(big)) > TQ_BIG_MAX) blk_flag = 1;
   const int m = min(n, NET);
   const int wmax_u = __builtin_amdgcn_readfirstlane(wave_max_i32_dpp(m));
   // ---- keys: list entries -> one word per hit; slots past the hit count hold pad words (distinct distance fields above
   //      every real one, so pads never look like ties)
   unsigned key[NET];
   const float scale = (float)(1u << FB) / r2;
+  // The support index of slot s goes to LDS as idx32[s][lane], IN PLACE over the lists: row s of the u16 lists is bytes
+  // [128 s, 128 s + 128), idx32 row s is bytes [256 s, 256 s + 256) -- walking the slots downwards, a group's idx rows only
+  // cover list rows that this or an earlier group has already read.
+  unsigned int* idx32 = reinterpret_cast<unsigned int*>(&lds.s);
 #pragma unroll
-  for (int s8 = 0; s8 < NET; s8 += 8) {
+  for (int s8 = NET - 8; s8 >= 0; s8 -= 8) {
     if (s8 < wmax_u) {  // (uniform) eight hits at a time: one 16-byte gather each from the cell-sorted records
       float4 sp[8];
 #pragma unroll
@@ -283,18 +291,21 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
         const int c = (int)lists[(s8 + u) * WAVE + lane];
         sp[u] = sorted_s[s8 + u < m ? tbl[c >> 12] + c : 0];
       }
+      __syncthreads();  // (the list reads above are done before the rows are overwritten)
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const float dx = qp.x - sp[u].x, dy = qp.y - sp[u].y, dz = qp.z - sp[u].z;
         const float d = (dx * dx + dy * dy) + dz * dz;  // same arithmetic as the test: same bits
         const unsigned fix = min(__float2uint_rz(d * scale), FIX_MAX);
         key[s8 + u] = s8 + u < m ? (fix << SB) | (unsigned)(s8 + u) : ((((1u << FB) - (unsigned)NET + (unsigned)(s8 + u)) << SB) | (unsigned)(s8 + u));
+        idx32[(s8 + u) * WAVE + lane] = __float_as_uint(sp[u].w);
       }
     } else {
 #pragma unroll
       for (int u = 0; u < 8; ++u) key[s8 + u] = (((1u << FB) - (unsigned)NET + (unsigned)(s8 + u)) << SB) | (unsigned)(s8 + u);
     }
   }
+  __syncthreads();
   TQ_STOP(3, (int)(key[0] ^ key[13] ^ key[31]))
   bool tie = false;
   if (wmax_u > 1) {
@@ -314,16 +325,12 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
   const bool slow = valid && !blk_flag && (big || tie);
   int hmax = 0;
   if (!blk_flag) {
-    // sorted list slots -> support indices (in the key registers); then the lists are dead and the rows are transposed
+    // sorted list slots -> support indices (in the key registers); then idx32 is dead and the rows are transposed
     // through LDS in blocks of 16 columns (a thread storing its own row is 64 rows per store instruction: measured
     // 0.17 ms for 8 x 200 k x 40)
 #pragma unroll
-    for (int i = 0; i < NET; ++i) {
-      if (i < wmax_u) {  // (uniform)
-        const int c = (int)lists[(int)(key[i] & (unsigned)(NET - 1)) * WAVE + lane];
-        key[i] = (unsigned)pidx[i < m ? tbl[c >> 12] + c : 0];
-      }
-    }
+    for (int i = 0; i < NET; ++i)
+      if (i < wmax_u) key[i] = idx32[(int)(key[i] & (unsigned)(NET - 1)) * WAVE + lane];  // (uniform guard)
     TQ_STOP(5, (int)(key[0] ^ key[13] ^ key[31]))
     __syncthreads();
     lds.r.qinfo[lane] = make_int2(orig, (valid && !slow) ? m : -1);

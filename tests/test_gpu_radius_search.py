@@ -14,7 +14,7 @@ def _t(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["count+fill", "single-pass", "thread-per-query"], autouse=True)
+@pytest.fixture(params=[0, 1, 2, 3], ids=["count+fill", "single-pass", "thread-per-query", "adaptive"], autouse=True)
 def search_mode(request):
     """Every test of this file runs in both modes of gr_radius_search (include/gaussreg_hip.h)."""
     from gaussreg_amd import _lib
@@ -87,7 +87,7 @@ def test_dense_blocks_work_in_groups_and_giant_queries_fall_back(search_mode):
         want = capi.radius_neighbors(q, s, ql, sl, radius)
         info, out = _info(tq, ts, ql.tolist(), sl.tolist(), radius, limit)
         assert info[0] == want.shape[1]
-        if search_mode != 2:  # (mode 2 hands dense calls like these back to count + fill)
+        if search_mode < 2:  # (modes 2 and 3 hand dense calls like these back to count + fill)
             assert (info[4] == 1) == (single and search_mode == 1), (radius, limit, info)
         w = min(limit, want.shape[1])
         assert np.array_equal(out[:, :w].cpu().numpy(), want[:, :w])
