@@ -93,10 +93,9 @@ struct RadiusWs {
   int2* q_rng;         // [3 dy][3 slab][nq] candidate range (p0, p1) per band
   unsigned long long* q_mask;  // [3 slab][nq] hit bits in candidate enumeration order
   int32_t* blk_stats;  // [blocks][2]
-  float* plane_x;      // [ns + 8] cell-ordered coordinate planes of the supports + their original indices (tq_kernel)
+  float* plane_x;      // [ns + 8] cell-ordered coordinate planes of the supports (tq_kernel)
   float* plane_y;
   float* plane_z;
-  int32_t* plane_i;
   uint32_t* tiles;     // [nq rounded up to 64][TQ_ROW_CAP] sorted neighbour indices per query, cell order (tq_kernel, compact mode)
   int64_t ccap;
   int64_t nsup;  // upper bound of the number of super-cells
@@ -126,7 +125,6 @@ RadiusWs carve(void* ws, int64_t nq, int64_t ns, int64_t batch) {
   w.plane_x = c.take<float>(ns + 8);
   w.plane_y = c.take<float>(ns + 8);
   w.plane_z = c.take<float>(ns + 8);
-  w.plane_i = c.take<int32_t>(ns + 8);
   // query side
   w.q_cell = c.take<int32_t>(nq);
   w.pairs_q = c.take<int2>(nq);
@@ -365,10 +363,9 @@ struct BinSide {
   int32_t* sup_start;     // [nsup+1]
   float4* sorted;         // [n] {x, y, z, original index} in cell order
   int32_t* cell_start;    // [cells+1] or null (queries need no cell table)
-  float* plane_x;         // [n + 8] or null: the same order as coordinate planes + original indices (supports only)
+  float* plane_x;         // [n + 8] or null: the same order as coordinate planes (supports only)
   float* plane_y;
   float* plane_z;
-  int32_t* plane_i;
 };
 
 __global__ void bin_init_kernel(uint32_t* __restrict__ bbox, int nb, int32_t* __restrict__ zero, int nzero) {
@@ -499,6 +496,7 @@ __global__ __launch_bounds__(256) void fine_kernel(BinSide A, BinSide B, int blo
                                                    const RadiusHdr* __restrict__ hdr) {
   __shared__ int hist[SUP_CELLS];
   __shared__ int wsum[256 / WAVE];
+  __shared__ float4 stage[256 * FINE_PER];  // the super-cell in cell order: leaves as coalesced copies (records + planes)
   const bool second = (int)blockIdx.x >= blocks_a;
   const BinSide& S = second ? B : A;
   const int stride = second ? (int)gridDim.x - blocks_a : blocks_a;
@@ -559,14 +557,19 @@ __global__ __launch_bounds__(256) void fine_kernel(BinSide A, BinSide B, int blo
       for (int k = 0; k < FINE_PER; ++k)
         if (a + k * 256 + tid < e) {
           const int slot = atomicAdd(&hist[pr[k].y - first], 1);
-          S.sorted[a + slot] = make_float4(cx[k], cy[k], cz[k], __int_as_float(pr[k].x));
-          if (S.plane_x) {
-            S.plane_x[a + slot] = cx[k];
-            S.plane_y[a + slot] = cy[k];
-            S.plane_z[a + slot] = cz[k];
-            S.plane_i[a + slot] = pr[k].x;
-          }
+          stage[slot] = make_float4(cx[k], cy[k], cz[k], __int_as_float(pr[k].x));
         }
+      __syncthreads();
+      // (scattering 16 + 3 x 4 bytes per point straight to global memory took 49 us of the 8 x 200 k binning; staged: 29)
+      for (int p = tid; p < e - a; p += 256) {
+        const float4 v = stage[p];
+        S.sorted[a + p] = v;
+        if (S.plane_x) {
+          S.plane_x[a + p] = v.x;
+          S.plane_y[a + p] = v.y;
+          S.plane_z[a + p] = v.z;
+        }
+      }
     } else {
       for (int p = a + tid; p < e; p += 256) {
         const int2 q = S.pairs[p];
@@ -577,7 +580,6 @@ __global__ __launch_bounds__(256) void fine_kernel(BinSide A, BinSide B, int blo
           S.plane_x[a + slot] = src[0];
           S.plane_y[a + slot] = src[1];
           S.plane_z[a + slot] = src[2];
-          S.plane_i[a + slot] = q.x;
         }
       }
     }
@@ -1693,11 +1695,11 @@ int launch_tq(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns,
     KernelTimer timer("radius_tq", stream);
     if (out)
       hipLaunchKernelGGL((tq_kernel<32, true>), dim3(grid), dim3(WAVE), 0, stream, sorted_q, (int)nq, w.q_off, nb, w.grids, start_s,
-                         w.sorted_s, w.plane_x, w.plane_y, w.plane_z, w.plane_i, (int)ns, r2, w.blk_stats, (int)width, ns, out,
+                         w.sorted_s, w.plane_x, w.plane_y, w.plane_z, (int)ns, r2, w.blk_stats, (int)width, ns, out,
                          (uint32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (size_t)0, mono ? 1 : 0, getenv("TQ_STOP") ? atoi(getenv("TQ_STOP")) : 0);
     else
       hipLaunchKernelGGL((tq_kernel<32, false>), dim3(grid), dim3(WAVE), 0, stream, sorted_q, (int)nq, w.q_off, nb, w.grids, start_s,
-                         w.sorted_s, w.plane_x, w.plane_y, w.plane_z, w.plane_i, (int)ns, r2, w.blk_stats, 0, ns, (int64_t*)nullptr,
+                         w.sorted_s, w.plane_x, w.plane_y, w.plane_z, (int)ns, r2, w.blk_stats, 0, ns, (int64_t*)nullptr,
                          w.tiles, w.q_count, w.q_count + nq, (size_t)((nq + 63) / 64) * 64 * 32, mono ? 1 : 0, 0);
   }
   return reduce_and_read(w, blocks, stream, h_out);
@@ -1812,9 +1814,9 @@ int radius_prepare(const float* q, const float* s, const int64_t* h_q_lengths, c
   KernelTimer bin_timer("radius_bin", stream);  // bbox .. cell order (nothing is launched when the grid is reused in a self-search)
   const int64_t su = w.nsup + 1;
   BinSide A{s, (int)ns, w.s_off, w.s_cell, w.pairs_s, w.sup_zero, w.sup_zero + 2 * su, w.sup_start, w.sorted_s, start_s,
-            w.plane_x, w.plane_y, w.plane_z, w.plane_i};
+            w.plane_x, w.plane_y, w.plane_z};
   BinSide B{q, (int)nq, w.q_off, w.q_cell, w.pairs_q, w.sup_zero + su, w.sup_zero + 3 * su, w.sup_start + su, w.sorted_q, nullptr,
-            nullptr, nullptr, nullptr, nullptr};
+            nullptr, nullptr, nullptr};
   const int blocks_s = (int)((ns + COARSE_PTS - 1) / COARSE_PTS), blocks_q = (int)((nq + COARSE_PTS - 1) / COARSE_PTS);
   if (!reuse) {
     // ---- supports (and, in the same launches, the queries): bbox, grid, two-level counting sort

@@ -92,7 +92,7 @@ template <int NET, bool DIRECT>
 __global__ __launch_bounds__(WAVE) void tq_kernel(
     const float4* __restrict__ sorted_q, int nq, const int32_t* __restrict__ q_off, int nb,
     const BatchGrid* __restrict__ grids, const int32_t* __restrict__ start_s, const float4* __restrict__ sorted_s,
-    const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz, const int32_t* __restrict__ pidx, int ns_total, float r2,
+    const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz, int ns_total, float r2,
     int32_t* __restrict__ blk_stats, int width, int64_t pad_value, int64_t* __restrict__ out, uint32_t* __restrict__ rows32,
     int32_t* __restrict__ q_cnt, int32_t* __restrict__ q_pos, size_t rows_hi, int mono, int stop) {
 #define TQ_STOP(K, V) if (stop == (K)) { if ((V) == 0x7fffffff) blk_stats[0] = 1; return; }
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
         const unsigned long long hm = __ballot(hit);
         if (hit) {
           const int pos = h + __popcll(hm & ((1ull << lane) - 1ull));
-          if (pos < TQ_BKEYS) lds.bkeys[pos] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)pidx[p];
+          if (pos < TQ_BKEYS) lds.bkeys[pos] = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(sorted_s[p].w);
         }
         h += __popcll(hm);
       }
