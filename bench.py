@@ -505,21 +505,31 @@ def run_gpu(h, args):
         # a step is 0.6 ms: at least 50 of them (and 10 to warm up -- the section follows the one-camera loops, which leave
         # the chip mostly idle) so that the timed region is tens of milliseconds
         n_r, w_r = max(args.steps, 50), max(args.warmup, 10)
+        RT = ["radius_bin", "radius_tq", "radius_expand", "radius_count", "radius_fill", "radius_fused"]
         L.gr_timing_enable(1)
         r_elapsed = h.timed(radius_step, n_r, w_r, after_warmup=L.gr_timing_reset)
+        tq_ms, tq_n = timing_read(L, "radius_tq")
+        ex_ms, _ = timing_read(L, "radius_expand")
         fill_ms, fill_n = timing_read(L, "radius_fill")
-        rk = per_step_ms(L, ["radius_bin", "radius_count", "radius_fill", "radius_fused"], n_r)
+        rk = per_step_ms(L, RT, n_r)
         L.gr_timing_reset()
         nq = dpts.shape[0]
         width = out["nb"].shape[1]
         fill_bytes = 12.0 * nq + 12.0 * nq + 8.0 * nq * width      # 12 Nq + 12 Ns + 8 Nq W
         step_s = r_elapsed / n_r
+        # the search proper (everything behind the binning): one thread per query (radius_tq.hpp) leaves compact rows, the
+        # expand kernel widens them once the host knows the width; count + fill where that kernel gave up (dense clouds)
+        if tq_n:
+            s_name, s_ms, s_n = "radius_tq + radius_expand", tq_ms + ex_ms, tq_n
+            s_kernels = ("tq_kernel<32, false>", "tq_expand_kernel")
+        else:
+            s_name, s_ms, s_n = "radius_fill", fill_ms, fill_n
+            s_kernels = ("traverse_kernel<128, false, true>", "traverse_kernel<128, true, true>")
         radius = {"metric": "radius_neighbors throughput, 200k-pt clouds", "value": round(world * nq * n_r / r_elapsed / 1e6, 2), "steps": n_r,
                   "unit": "Mpts/s", "ms_per_step": round(step_s * 1e3, 4),
                   "config": {"workload": f"{B} x 200k-pt clouds per GPU per step, r=0.0625, self-search, width {width}"},
-                  "roofline": hbm_roofline("radius_fill", fill_bytes, fill_ms, fill_n, pmc_traffic("radius_fill", True, B),
-                                           kernels_ms_per_step=rk, valu_busy=sq_valu_busy("traverse_kernel<128, true, true>", True),
-                                           count_valu_busy=sq_valu_busy("traverse_kernel<128, false, true>", True),
+                  "roofline": hbm_roofline(s_name, fill_bytes, s_ms, s_n, pmc_traffic("radius_search", True, B),
+                                           kernels_ms_per_step=rk, valu_busy=sq_valu_busy(s_kernels[0], True),
                                            valu_busy_source="profiles/" + str(newest_profile("_sq_counters.json")),
                                            end_to_end_frac=round(fill_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4))}
         # the second half of the metric as scalars the driver's flattened record keeps
@@ -527,18 +537,18 @@ def run_gpu(h, args):
         rl["radius_mpts_per_s"] = radius["value"]
         rl["radius_ms_per_step"] = radius["ms_per_step"]
         rl["radius_end_to_end_frac"] = radius["roofline"]["end_to_end_frac"]
-        rl["radius_fill_frac"] = radius["roofline"]["frac"]
-        rl["radius_fill_avg_launch_ms"] = radius["roofline"]["avg_launch_ms"]
-        # the bound that actually holds for this operator: VALU issue.  Wave-level VALU instructions per query of the search
-        # kernels (committed SQ-counter summary, same configuration) against the ~50 the tests + stores alone need
-        vc, vf = sq_insts("traverse_kernel<128, false, true>", "SQ_INSTS_VALU"), sq_insts("traverse_kernel<128, true, true>", "SQ_INSTS_VALU")
-        if vc and vf and B == 8:
-            per_q = (vc + vf) / float(nq)
-            radius["roofline_valu_issue"] = {"bound": "valu_issue", "achieved": round(per_q, 1), "floor": 50.0,
-                                             "unit": "wave-level VALU instructions per query (count + fill)", "frac": round(50.0 / per_q, 4),
-                                             "source": "profiles/" + str(newest_profile("_sq_counters.json")) + " (committed, not this run)"}
-            rl["radius_valu_per_query"] = round(per_q, 1)
-            rl["radius_valu_floor_per_query"] = 50.0
+        rl["radius_search_frac"] = radius["roofline"]["frac"]
+        rl["radius_search_avg_launch_ms"] = radius["roofline"]["avg_launch_ms"]
+        for k, v in rk.items():
+            rl["radius_ms_" + k[7:]] = v
+        # the same call on count + fill (gr_radius_search_mode 0: the default of rounds 1 - 5)
+        old_mode = L.gr_radius_search_mode(0)
+        radius_step()
+        c_elapsed = h.timed(radius_step, n_r, w_r, after_warmup=L.gr_timing_reset)
+        radius["count_fill"] = {"ms_per_step": round(c_elapsed / n_r * 1e3, 4), "kernels_ms_per_step": per_step_ms(L, RT, n_r),
+                                "end_to_end_frac": round(fill_bytes / (c_elapsed / n_r) / 1e9 / HBM_PEAK_GBS, 4)}
+        rl["radius_count_fill_end_to_end_frac"] = radius["count_fill"]["end_to_end_frac"]
+        L.gr_radius_search_mode(old_mode)
         # the width-limited path the data pyramid calls (radius_search with neighbor_limit, utils/data.py:35-67)
         if not args.no_radius_limited:
             lim = 40
@@ -548,26 +558,44 @@ def run_gpu(h, args):
 
             limited_step()
             l_elapsed = h.timed(limited_step, n_r, w_r, after_warmup=L.gr_timing_reset)
-            lk = per_step_ms(L, ["radius_bin", "radius_count", "radius_fill", "radius_fused"], n_r)
+            lk = per_step_ms(L, RT, n_r)
+            ltq_ms, ltq_n = timing_read(L, "radius_tq")
             lw = out["nbl"].shape[1]
             lbytes = 24.0 * nq + 8.0 * nq * lw
             radius["limited"] = {"value": round(world * nq * n_r / l_elapsed / 1e6, 2), "unit": "Mpts/s",
                                  "ms_per_step": round(l_elapsed / n_r * 1e3, 4), "neighbor_limit": lim, "width": lw,
                                  "end_to_end_frac": round(lbytes / (l_elapsed / n_r) / 1e9 / HBM_PEAK_GBS, 4),
-                                 "kernels_ms_per_step": lk, "mode": "count + fill (default)"}
+                                 "kernels_ms_per_step": lk,
+                                 "mode": "one thread per query, one kernel (default)" if ltq_n else "count + fill",
+                                 "roofline": hbm_roofline("radius_tq", lbytes, ltq_ms, ltq_n) if ltq_n else None}
             rl["radius_limited_mpts_per_s"] = radius["limited"]["value"]
+            rl["radius_limited_ms_per_step"] = radius["limited"]["ms_per_step"]
             rl["radius_limited_end_to_end_frac"] = radius["limited"]["end_to_end_frac"]
-            # the same call through the single-pass kernel (gr_radius_search mode 1)
-            old_mode = L.gr_radius_search_mode(1)
-            limited_step()
-            s_elapsed = h.timed(limited_step, n_r, w_r, after_warmup=L.gr_timing_reset)
-            sk = per_step_ms(L, ["radius_bin", "radius_fused"], n_r)
-            L.gr_radius_search_mode(old_mode)
-            fused_ms = sk.get("radius_fused", 0.0)
-            radius["limited"]["single_pass"] = {
-                "value": round(world * nq * n_r / s_elapsed / 1e6, 2), "ms_per_step": round(s_elapsed / n_r * 1e3, 4),
-                "end_to_end_frac": round(lbytes / (s_elapsed / n_r) / 1e9 / HBM_PEAK_GBS, 4), "kernels_ms_per_step": sk,
-                "roofline": hbm_roofline("radius_fused", lbytes, fused_ms * n_r, n_r) if fused_ms else None}
+            if ltq_n:
+                rl["radius_limited_search_frac"] = radius["limited"]["roofline"]["frac"]
+                rl["radius_limited_ms_tq"] = lk.get("radius_tq")
+                rl["radius_limited_ms_bin"] = lk.get("radius_bin")
+            # what bounds the search kernel: VALU issue.  Wave-level VALU instructions per query (committed SQ-counter
+            # summary, same configuration) against the ~50 the tests + stores alone need
+            vq = sq_insts("tq_kernel<32, true>", "SQ_INSTS_VALU")
+            if vq and B == 8:
+                per_q = vq / float(nq)
+                radius["roofline_valu_issue"] = {"bound": "valu_issue", "achieved": round(per_q, 1), "floor": 50.0,
+                                                 "unit": "wave-level VALU instructions per query (tq_kernel, limit 40)", "frac": round(50.0 / per_q, 4),
+                                                 "valu_busy": sq_valu_busy("tq_kernel<32, true>", True),
+                                                 "source": "profiles/" + str(newest_profile("_sq_counters.json")) + " (committed, not this run)"}
+                rl["radius_valu_per_query"] = round(per_q, 1)
+                rl["radius_valu_floor_per_query"] = 50.0
+            # the same call on count + fill and through the three-threads-per-query single-pass kernel (modes 0 and 1)
+            for mode, key in ((0, "count_fill"), (1, "single_pass")):
+                old_mode = L.gr_radius_search_mode(mode)
+                limited_step()
+                s_elapsed = h.timed(limited_step, n_r, w_r, after_warmup=L.gr_timing_reset)
+                L.gr_radius_search_mode(old_mode)
+                radius["limited"][key] = {
+                    "value": round(world * nq * n_r / s_elapsed / 1e6, 2), "ms_per_step": round(s_elapsed / n_r * 1e3, 4),
+                    "end_to_end_frac": round(lbytes / (s_elapsed / n_r) / 1e9 / HBM_PEAK_GBS, 4), "kernels_ms_per_step": per_step_ms(L, RT, n_r)}
+            rl["radius_limited_count_fill_end_to_end_frac"] = radius["limited"]["count_fill"]["end_to_end_frac"]
         L.gr_timing_enable(0)
         L.gr_timing_reset()
         del out, dpts
@@ -590,7 +618,7 @@ def run_gpu(h, args):
 
         L.gr_timing_enable(1)
         p_elapsed = h.timed(pairs_pass, 1, 0, after_warmup=L.gr_timing_reset)
-        pk = per_step_ms(L, ["fps", "radius_bin", "radius_count", "radius_fill", "radius_fused", "sinkhorn", "lgr", "ransac"], 1)
+        pk = per_step_ms(L, ["fps", "radius_bin", "radius_tq", "radius_expand", "radius_count", "radius_fill", "radius_fused", "sinkhorn", "lgr", "ransac"], 1)
         L.gr_timing_enable(0)
         L.gr_timing_reset()
         local = torch.cat(rows, 0)
@@ -775,7 +803,7 @@ def order_line(line):
         "single_view_views_per_s": cfg.get("single_view_views_per_s"),
         "single_view_static_scene_views_per_s": cfg.get("single_view_static_scene_views_per_s"),
         "radius_mpts_per_s": rl.get("radius_mpts_per_s"), "radius_end_to_end_frac": rl.get("radius_end_to_end_frac"),
-        "radius_fill_frac": rl.get("radius_fill_frac"), "radius_limited_end_to_end_frac": rl.get("radius_limited_end_to_end_frac"),
+        "radius_search_frac": rl.get("radius_search_frac"), "radius_limited_end_to_end_frac": rl.get("radius_limited_end_to_end_frac"),
         "radius_valu_per_query": rl.get("radius_valu_per_query"),
         "radius_cpu_1core_mpts_per_s": cb.get("radius_1core_mpts_per_s"), "radius_cpu_all_cores_mpts_per_s": cb.get("radius_all_cores_mpts_per_s"),
         "pairs_per_s": cfg.get("pairs_per_s"), "pairs_with_network_per_s": cfg.get("pairs_with_network_per_s"),
