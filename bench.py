@@ -144,6 +144,13 @@ class Harness:
         self.barrier()
         return self.max_over_ranks(time.perf_counter() - t0)
 
+    def timed3(self, fn, steps, warmup, after_warmup=None, repeats=3):
+        """`timed` three times over (sections whose timed region is under ~100 ms): (median, {min, max, spread}) -- spread =
+        (max - min) / median of the elapsed times, so a line read once is not one unlucky sample."""
+        ts = sorted(self.timed(fn, steps, warmup if i == 0 else 1, after_warmup=after_warmup) for i in range(repeats))
+        med = ts[len(ts) // 2]
+        return med, {"min_s": ts[0], "max_s": ts[-1], "spread": round((ts[-1] - ts[0]) / med, 4) if med > 0 else None}
+
     def close(self):
         if self.world > 1:
             import torch.distributed as dist
@@ -369,6 +376,7 @@ def run_gpu(h, args):
                                          rotations=t["rotations"])
         last["nr"] = nr
         last["img"] = img
+        last["radii"] = radii
 
     raster_step()  # allocate / page in before anything is timed
     L.gr_timing_reset()
@@ -413,8 +421,23 @@ def run_gpu(h, args):
                                                         "step's preprocess, sort and binning"},
                                   valu_busy=sq_valu_busy("blend_kernel<false", (P, W, H) == (1_000_000, 640, 480)),
                                   valu_busy_source="profiles/" + str(newest_profile("_sq_counters.json")))})
+    # share of the (Gaussian, view) pairs that survive the culling: the others cost 12 bytes of preprocess output (radius,
+    # depth field, rectangle -- their 64-byte record is never written) and are dropped by the depth sort's first pass
+    line["config"]["visible_fraction"] = round(float((last["radii"] > 0).float().mean().item()), 4)
+    for kname, kms in raster_kernels.items():  # scalars: the driver's flattened record drops nested objects
+        line["roofline"]["ms_" + kname[7:]] = kms
     line["config"]["static_scene_views_per_s"] = round(world * V * args.steps / st_elapsed, 2) if st_elapsed else None
     line["config"]["static_scene_ms_per_step"] = round(st_elapsed / args.steps * 1e3, 4) if st_elapsed else None
+
+    # the architecturally guaranteed ordering (explicit ballot ranking in the depth sort and the tile scatter instead of the
+    # probed lane order of ds_add_rtn): same images, its cost in the record
+    old_rank = L.gr_raster_ballot_ranking(1)
+    raster_step()
+    b_elapsed = h.timed(raster_step, args.steps, args.warmup)
+    L.gr_raster_ballot_ranking(old_rank)
+    line["config"]["ballot_ranking_views_per_s"] = round(world * V * args.steps / b_elapsed, 2)
+    line["config"]["ballot_ranking_cost"] = round(b_elapsed / elapsed - 1.0, 4)
+    line["config"]["lds_atomics_lane_ordered"] = int(L.gr_raster_lds_atomics_lane_ordered())
 
     # ------------------------------------------------------------------ the boundary: one camera per forward() call
     if not args.no_single_view:
@@ -431,7 +454,7 @@ def run_gpu(h, args):
         # throughput with the per-kernel event timers OFF (ten event records per frame are a measurable share of a 0.2 ms
         # frame); the per-kernel figures come from a second, instrumented pass of the same loop
         L.gr_timing_enable(0)
-        sv_elapsed = h.timed(single_step, n_sv, max(args.warmup, 3))
+        sv_elapsed, sv_spread = h.timed3(single_step, n_sv, max(args.warmup, 3))
         L.gr_timing_enable(1)
         L.gr_timing_reset()
         h.timed(single_step, n_sv, 1, after_warmup=L.gr_timing_reset)
@@ -453,10 +476,22 @@ def run_gpu(h, args):
             last["sv"] = r(t["means3D"], None, t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
 
         single_static()
-        svs = h.timed(single_static, n_sv, max(args.warmup, 3))
-        line["single_view"]["static_scene"] = {"value": round(world * n_sv / svs, 2), "ms_per_view": round(svs / n_sv * 1e3, 4)}
+        svs, svs_spread = h.timed3(single_static, n_sv, max(args.warmup, 3))
+        line["single_view"]["static_scene"] = {"value": round(world * n_sv / svs, 2), "ms_per_view": round(svs / n_sv * 1e3, 4),
+                                               "spread": svs_spread["spread"]}
+        line["single_view"]["spread"] = sv_spread["spread"]
         line["config"]["single_view_views_per_s"] = line["single_view"]["value"]
+        line["config"]["single_view_spread"] = sv_spread["spread"]
         line["config"]["single_view_static_scene_views_per_s"] = line["single_view"]["static_scene"]["value"]
+        line["config"]["single_view_static_scene_spread"] = svs_spread["spread"]
+        line["config"]["single_view_static_scene_min_views_per_s"] = round(world * n_sv / svs_spread["max_s"], 2)
+        # one camera per call with the guaranteed ordering
+        old_rank = L.gr_raster_ballot_ranking(1)
+        single_step()
+        svb, svb_spread = h.timed3(single_step, n_sv, max(args.warmup, 3))
+        L.gr_raster_ballot_ranking(old_rank)
+        line["config"]["single_view_ballot_ranking_views_per_s"] = round(world * n_sv / svb, 2)
+        line["config"]["single_view_ballot_ranking_cost"] = round(svb / sv_elapsed - 1.0, 4)
         # the opt-in fast-exponential blend (1e-5 relative of the bit-exact image, tests/test_gpu_rasterizer_fast.py)
         rast_f = [GaussianRasterizer(s, fast_exp=True) for s in settings_list[: min(V, 8)]]
 
@@ -466,7 +501,7 @@ def run_gpu(h, args):
             last["sv"] = r(t["means3D"], None, t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
 
         single_fast()
-        svf = h.timed(single_fast, n_sv, max(args.warmup, 3))
+        svf, _ = h.timed3(single_fast, n_sv, max(args.warmup, 3))
         line["single_view"]["fast_exp"] = {"value": round(world * n_sv / svf, 2), "ms_per_view": round(svf / n_sv * 1e3, 4)}
         line["config"]["single_view_fast_exp_views_per_s"] = line["single_view"]["fast_exp"]["value"]
 
@@ -507,7 +542,8 @@ def run_gpu(h, args):
         n_r, w_r = max(args.steps, 50), max(args.warmup, 10)
         RT = ["radius_bin", "radius_tq", "radius_expand", "radius_count", "radius_fill", "radius_fused"]
         L.gr_timing_enable(1)
-        r_elapsed = h.timed(radius_step, n_r, w_r, after_warmup=L.gr_timing_reset)
+        r_elapsed, r_spread = h.timed3(radius_step, n_r, w_r)   # median of three timed regions (each ~30 ms)
+        h.timed(radius_step, n_r, 1, after_warmup=L.gr_timing_reset)  # a fourth, instrumented pass for the per-kernel figures
         tq_ms, tq_n = timing_read(L, "radius_tq")
         ex_ms, _ = timing_read(L, "radius_expand")
         fill_ms, fill_n = timing_read(L, "radius_fill")
@@ -536,6 +572,7 @@ def run_gpu(h, args):
         rl = line["roofline"]
         rl["radius_mpts_per_s"] = radius["value"]
         rl["radius_ms_per_step"] = radius["ms_per_step"]
+        rl["radius_spread"] = r_spread["spread"]
         rl["radius_end_to_end_frac"] = radius["roofline"]["end_to_end_frac"]
         rl["radius_search_frac"] = radius["roofline"]["frac"]
         rl["radius_search_avg_launch_ms"] = radius["roofline"]["avg_launch_ms"]
@@ -557,7 +594,8 @@ def run_gpu(h, args):
                 out["nbl"] = radius_search(dpts, dpts, lens, lens, 0.0625, lim)
 
             limited_step()
-            l_elapsed = h.timed(limited_step, n_r, w_r, after_warmup=L.gr_timing_reset)
+            l_elapsed, l_spread = h.timed3(limited_step, n_r, w_r)
+            h.timed(limited_step, n_r, 1, after_warmup=L.gr_timing_reset)
             lk = per_step_ms(L, RT, n_r)
             ltq_ms, ltq_n = timing_read(L, "radius_tq")
             lw = out["nbl"].shape[1]
@@ -570,6 +608,7 @@ def run_gpu(h, args):
                                  "roofline": hbm_roofline("radius_tq", lbytes, ltq_ms, ltq_n) if ltq_n else None}
             rl["radius_limited_mpts_per_s"] = radius["limited"]["value"]
             rl["radius_limited_ms_per_step"] = radius["limited"]["ms_per_step"]
+            rl["radius_limited_spread"] = l_spread["spread"]
             rl["radius_limited_end_to_end_frac"] = radius["limited"]["end_to_end_frac"]
             if ltq_n:
                 rl["radius_limited_search_frac"] = radius["limited"]["roofline"]["frac"]

@@ -63,6 +63,7 @@ SIGNATURES.update({
                                   c_void, c_size, c_void, c_int, c_i64p, c_void]),
     "gr_raster_forward_finish": (c_int, [c_i64p]),
     "gr_raster_lds_atomics_lane_ordered": (c_int, []),
+    "gr_raster_ballot_ranking": (c_int, [c_int]),
     "gr_raster_mark_visible": (c_int, [c_i64, c_void, ctypes.POINTER(c_f32), c_void, c_void]),
 })
 

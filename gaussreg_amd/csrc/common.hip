@@ -532,6 +532,15 @@ static void lds_order_init() {
   for (auto& v : g_lds_order) v.store(-1);
 }
 
+// 1 = explicit ballot ranking whatever the probe says (GR_RASTER_BALLOT_RANKING=1 or gr_raster_ballot_ranking(1))
+static std::atomic<int>& lds_force_ballot() {
+  static std::atomic<int> v{[] {
+    const char* force = getenv("GR_RASTER_BALLOT_RANKING");
+    return (force && force[0] == '1') ? 1 : 0;
+  }()};
+  return v;
+}
+
 static int lds_device_slot() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return -1;
@@ -542,8 +551,7 @@ int lds_atomics_lane_ordered(hipStream_t stream, bool* ordered) {
   std::call_once(g_lds_once, lds_order_init);
   const int dev = lds_device_slot();
   GR_REQUIRE(dev >= 0, "hipGetDevice failed");
-  const char* force = getenv("GR_RASTER_BALLOT_RANKING");
-  if (force && force[0] == '1') {
+  if (lds_force_ballot().load() == 1) {
     *ordered = false;
     return GR_OK;
   }
@@ -566,7 +574,14 @@ int lds_atomics_lane_ordered(hipStream_t stream, bool* ordered) {
 int lds_atomics_lane_ordered_state() {
   std::call_once(g_lds_once, lds_order_init);
   const int dev = lds_device_slot();
+  if (dev >= 0 && lds_force_ballot().load() == 1) return 0;
   return dev < 0 ? -1 : g_lds_order[dev].load();
+}
+
+int lds_ballot_ranking_force(int on) {
+  const int old = lds_force_ballot().load();
+  if (on == 0 || on == 1) lds_force_ballot().store(on);
+  return old;
 }
 
 void lds_order_demote() {

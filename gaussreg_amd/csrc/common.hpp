@@ -137,6 +137,7 @@ int sort_pairs_u64_iota(void* temp, size_t temp_bytes, const uint64_t* keys_in, 
 // this device?  Probed once per process and device (common.hip); GR_RASTER_BALLOT_RANKING=1 forces "no".
 int lds_atomics_lane_ordered(hipStream_t stream, bool* ordered);
 int lds_atomics_lane_ordered_state();  // 1 yes, 0 no, -1 not probed yet
+int lds_ballot_ranking_force(int on);   // 1 = ballot ranking whatever the probe says, 0 = as probed; returns the previous setting
 void lds_order_demote();                // a sort that relied on the property came out unsorted: use ballot ranking from now on
 
 // ---- the rasterizer's packed tile rectangles (26 bits: x:7 | y:7 | w:6 | h:6; shared by rasterizer.hip and depth_sort.hip)

@@ -1451,6 +1451,7 @@ static int64_t tiles_of(int width, int height) {
 }
 
 extern "C" int gr_raster_lds_atomics_lane_ordered(void) { return lds_atomics_lane_ordered_state(); }
+extern "C" int gr_raster_ballot_ranking(int on) { return lds_ballot_ranking_force(on); }
 
 extern "C" size_t gr_raster_geom_bytes(int64_t P, int num_views, int width, int height) {
   if (P < 0 || num_views < 1 || width <= 0 || height <= 0) return 0;

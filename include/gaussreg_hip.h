@@ -228,6 +228,11 @@ int gr_raster_forward_finish(int64_t* h_num_rendered);
  * probed and serves equal-address lanes of a ds_add_rtn in lane order), 0 = explicit ballot ranking (probe failed, or
  * GR_RASTER_BALLOT_RANKING=1), -1 = no render call has probed the device yet.  Both produce the same lists. */
 int gr_raster_lds_atomics_lane_ordered(void);
+/* on = 1: the depth sort and the tile scatter take their stable ranks from explicit ballot ranking (architecturally
+ * guaranteed) whatever the probe of the lane order of ds_add_rtn said; on = 0: as probed (default; GR_RASTER_BALLOT_RANKING=1
+ * starts the process with 1); any other value only queries.  Process-wide; returns the previous setting.  Same images
+ * either way (tests/test_gpu_rasterizer.py); bench.py reports both (config.ballot_ranking_views_per_s). */
+int gr_raster_ballot_ranking(int on);
 /* present[i] = 1 iff Gaussian i passes the near-plane test of `viewmatrix` (markVisible). */
 int gr_raster_mark_visible(int64_t P, const float* means3D, const float* h_viewmatrix,
                            uint8_t* present, void* stream);
