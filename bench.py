@@ -42,6 +42,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+try:
+    _INITIAL_AFFINITY = sorted(os.sched_getaffinity(0))  # before any rank binding: the CPU-baseline workers get this mask back
+except AttributeError:
+    _INITIAL_AFFINITY = None
+
 HBM_PEAK_GBS = 8000.0   # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s peak, ~6.3 TB/s achievable)
 FP32_MFMA_PEAK_TF = 157.3
 
@@ -79,9 +84,10 @@ def parse(argv=None):
 # ----------------------------------------------------------------------------------------------------------------------
 # process group / timing harness (device-agnostic: the CPU test drives it over gloo with stub workloads)
 class Harness:
-    def __init__(self, rank, world, device, sync=None):
+    def __init__(self, rank, world, device, sync=None, affinity=None):
         self.rank, self.world, self.device = rank, world, device
         self._sync = sync if sync is not None else (lambda: None)
+        self.affinity = affinity  # where this rank's host thread was pinned (gaussreg_amd/affinity.py), None = not bound
 
     @staticmethod
     def from_env(backend="nccl"):
@@ -90,6 +96,13 @@ class Harness:
         world = int(os.environ.get("WORLD_SIZE", "1"))
         rank = int(os.environ.get("RANK", "0"))
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # one process per GPU: pin this one to the CPUs of its GPU's NUMA node BEFORE the library maps its pinned pages (the
+        # mailbox page a rank spin-polls, the staging buffers) so that first touch puts them there.  Single-rank runs keep the
+        # whole machine (the CPU-baseline leg uses every core).
+        aff = None
+        if world > 1:
+            from gaussreg_amd import affinity
+            aff = affinity.bind_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
         if backend == "nccl":
             if not torch.cuda.is_available():
                 raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
@@ -104,7 +117,7 @@ class Harness:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             dist.init_process_group(backend=backend, rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
-        return Harness(rank, world, device, sync)
+        return Harness(rank, world, device, sync, aff)
 
     def barrier(self):
         import torch.distributed as dist
@@ -210,8 +223,14 @@ def dry_run(h, backend):
     h.barrier()
     ok = all(checks.values())
     n_ok = h.sum_over_ranks(1.0 if ok else 0.0)
+    # where every rank's host thread sits (numa node of its GPU, the CPUs it was pinned to)
+    placement = [h.affinity]
+    if world > 1:
+        import torch.distributed as dist
+        placement = [None] * world
+        dist.all_gather_object(placement, h.affinity)
     line = {"dry": True, "backend": backend, "n_gpus": world, "device": str(dev), "ok": bool(n_ok == world), "ranks_ok": int(n_ok),
-            "checks": checks, "seconds": round(time.perf_counter() - t0, 3)}
+            "checks": checks, "placement": placement, "seconds": round(time.perf_counter() - t0, 3)}
     if not ok:
         print(f"rank {rank}: --dry checks failed: {checks}", file=sys.stderr, flush=True)
     return line
@@ -304,6 +323,7 @@ def all_cores(task, units_per_task, unit, workers, tasks_per_worker=1, lead_s=12
     start = time.time() + lead_s   # the workers import numpy / torch first and then wait for this instant
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "cpu_worker.py"), task, str(tasks_per_worker),
                                repr(start), str(i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                              preexec_fn=(lambda: os.sched_setaffinity(0, _INITIAL_AFFINITY)) if _INITIAL_AFFINITY else None,
                               env=dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
              for i in range(workers)]
     t_first, t_last, ok = None, None, 0

@@ -99,6 +99,7 @@ int mailbox_wait(const volatile int32_t* stamp_word, int stamp, hipStream_t stre
   // a stream that has drained or failed without the stamp is an error.  (Exactly what hipStreamSynchronize would wait for.)
   for (unsigned long spin = 1;; ++spin) {
     if (__atomic_load_n(stamp_word, __ATOMIC_ACQUIRE) == stamp) return GR_OK;
+    __builtin_ia32_pause();  // (eight ranks spin like this on one host: leave the core's other thread its issue slots)
     if ((spin & 0xffff) == 0 && hipStreamQuery(stream) != hipErrorNotReady) {
       GR_HIP(hipStreamSynchronize(stream));
       GR_REQUIRE(__atomic_load_n(stamp_word, __ATOMIC_ACQUIRE) == stamp, "%s: the kernel did not post its result", what);
