@@ -1688,19 +1688,25 @@ int launch_fused(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t 
 // written by the kernel; out == null: tiles + counts for launch_tq_expand.  h_out->max_block_hits != 0 = a workgroup could not
 // finish: the caller repeats the call on count + fill.
 int launch_tq(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns, int nb, const int32_t* start_s, float r2,
-              int64_t width, int64_t* out, bool mono, hipStream_t stream, RadiusHdr* h_out) {
+              int64_t width, int64_t* out, bool mono, hipStream_t stream, RadiusHdr* h_out, int net = 32) {
   const int blocks = (int)((nq + WAVE - 1) / WAVE);
   const int grid = (blocks + 7) / 8 * 8;
   {
     KernelTimer timer("radius_tq", stream);
-    if (out)
-      hipLaunchKernelGGL((tq_kernel<32, true>), dim3(grid), dim3(WAVE), 0, stream, sorted_q, (int)nq, w.q_off, nb, w.grids, start_s,
-                         w.sorted_s, w.plane_x, w.plane_y, w.plane_z, (int)ns, r2, w.blk_stats, (int)width, ns, out,
-                         (uint32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (size_t)0, mono ? 1 : 0, getenv("TQ_STOP") ? atoi(getenv("TQ_STOP")) : 0);
-    else
-      hipLaunchKernelGGL((tq_kernel<32, false>), dim3(grid), dim3(WAVE), 0, stream, sorted_q, (int)nq, w.q_off, nb, w.grids, start_s,
-                         w.sorted_s, w.plane_x, w.plane_y, w.plane_z, (int)ns, r2, w.blk_stats, 0, ns, (int64_t*)nullptr,
-                         w.tiles, w.q_count, w.q_count + nq, (size_t)((nq + 63) / 64) * 64 * 32, mono ? 1 : 0, 0);
+    const int stop = getenv("TQ_STOP") ? atoi(getenv("TQ_STOP")) : 0;
+    const size_t rows_hi = (size_t)((nq + 63) / 64) * 64 * 32;
+#define TQ_GO(NET)                                                                                                          \
+  if (out)                                                                                                                  \
+    hipLaunchKernelGGL((tq_kernel<NET, true>), dim3(grid), dim3(WAVE), 0, stream, sorted_q, (int)nq, w.q_off, nb, w.grids,   \
+                       start_s, w.sorted_s, w.plane_x, w.plane_y, w.plane_z, (int)ns, r2, w.blk_stats, (int)width, ns, out, \
+                       (uint32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (size_t)0, mono ? 1 : 0, stop);            \
+  else                                                                                                                      \
+    hipLaunchKernelGGL((tq_kernel<NET, false>), dim3(grid), dim3(WAVE), 0, stream, sorted_q, (int)nq, w.q_off, nb, w.grids,  \
+                       start_s, w.sorted_s, w.plane_x, w.plane_y, w.plane_z, (int)ns, r2, w.blk_stats, 0, ns,               \
+                       (int64_t*)nullptr, w.tiles, w.q_count, w.q_count + nq, rows_hi, mono ? 1 : 0, 0)
+    if (net == 64) TQ_GO(64);
+    else TQ_GO(32);
+#undef TQ_GO
   }
   return reduce_and_read(w, blocks, stream, h_out);
 }
@@ -1866,12 +1872,13 @@ int radius_prepare(const float* q, const float* s, const int64_t* h_q_lengths, c
 namespace gr {
 namespace {
 // 0 = count, host, fill; 1 = the single-pass kernel (three threads per query); 2 = one thread per query (radius_tq.hpp),
-// always tried first; 3 (default) = one thread per query where it has not given up lately (tq_wanted), else count + fill.
+// always tried first (32-hit network); 3 (default) = the kernel tq_choice picks for the call site (32-hit network, 64-hit network
+// or count + fill); 4 = the 64-hit network always tried first.
 // Initialised from GR_RADIUS_SINGLE_PASS.
 std::atomic<int>& search_mode() {
   static std::atomic<int> mode{[] {
     const char* a = getenv("GR_RADIUS_SINGLE_PASS");
-    return (a && a[0] >= '0' && a[0] <= '3') ? a[0] - '0' : 3;
+    return (a && a[0] >= '0' && a[0] <= '4') ? a[0] - '0' : 3;
   }()};
   return mode;
 }
@@ -1880,54 +1887,60 @@ std::atomic<int>& search_mode() {
 
 namespace gr {
 namespace {
-// Which searches the thread-per-query kernel is tried on.  It is built for neighbourhoods of up to ~32 hits (the big levels
-// of the data pyramid: 4 - 14 on average); on denser ones most queries need its exact wave-finished path, the kernel gives
-// up after its tests and the call is repeated on count + fill.  A caller repeats the same (radius, limit) call site over
-// and over (13 per pair in the pyramid), so a give-up is remembered per (radius bits, limit) and that site goes to
-// count + fill directly for the next TQ_RETRY_AFTER calls.
+// Which search kernel a call site gets.  The thread-per-query kernel sorts up to NET hits per query in registers (NET = 32:
+// the big levels of the data pyramid, 4 - 14 hits on average; NET = 64: its middle levels, ~30); where most queries of a
+// wave have more, the kernel gives up after its tests and the call is repeated on count + fill.  A caller repeats the same
+// (radius, limit) call site over and over (13 per pair in the pyramid), so a give-up is remembered per (radius bits,
+// limit): the site moves 32 -> 64 -> count + fill, and steps back down one level every TQ_RETRY_AFTER calls.
 constexpr int TQ_MEMO = 64, TQ_RETRY_AFTER = 256;
 struct TqMemo {
   uint32_t rbits;
   int64_t limit;
-  int skip;  // calls left before the kernel is tried again
+  int level;  // 0: the 32-hit network, 1: the 64-hit network, 2: count + fill
+  int calls;  // calls at this level since it last changed (a site at level > 0 steps back down every TQ_RETRY_AFTER calls)
   bool used;
 };
 TqMemo g_tq_memo[TQ_MEMO];
 std::mutex g_tq_memo_mu;
 
-bool tq_wanted(float radius, int64_t limit) {
-  uint32_t rb;
-  memcpy(&rb, &radius, 4);
-  std::lock_guard<std::mutex> lk(g_tq_memo_mu);
+TqMemo* tq_find(uint32_t rb, int64_t limit) {
   for (TqMemo& e : g_tq_memo)
-    if (e.used && e.rbits == rb && e.limit == limit) {
-      if (e.skip > 0) {
-        --e.skip;
-        return false;
-      }
-      return true;
-    }
-  return true;
+    if (e.used && e.rbits == rb && e.limit == limit) return &e;
+  return nullptr;
 }
 
-void tq_report(float radius, int64_t limit, bool gave_up) {
+// which kernel this call site gets: 32 / 64 = the thread-per-query kernel with that network, 0 = count + fill
+int tq_choice(float radius, int64_t limit) {
   uint32_t rb;
   memcpy(&rb, &radius, 4);
   std::lock_guard<std::mutex> lk(g_tq_memo_mu);
-  TqMemo* slot = nullptr;
-  for (TqMemo& e : g_tq_memo)
-    if (e.used && e.rbits == rb && e.limit == limit) slot = &e;
-  if (!slot && !gave_up) return;
-  if (!slot) {
-    static int next = 0;
-    for (TqMemo& e : g_tq_memo)
-      if (!e.used && !slot) slot = &e;
-    if (!slot) slot = &g_tq_memo[next++ % TQ_MEMO];
-    slot->used = true;
-    slot->rbits = rb;
-    slot->limit = limit;
+  TqMemo* e = tq_find(rb, limit);
+  if (!e) return 32;
+  if (e->level > 0 && ++e->calls > TQ_RETRY_AFTER) {
+    e->level -= 1;
+    e->calls = 0;
   }
-  slot->skip = gave_up ? TQ_RETRY_AFTER : 0;
+  return e->level == 0 ? 32 : (e->level == 1 ? 64 : 0);
+}
+
+void tq_report(float radius, int64_t limit, int net, bool gave_up) {
+  if (!gave_up) return;
+  uint32_t rb;
+  memcpy(&rb, &radius, 4);
+  std::lock_guard<std::mutex> lk(g_tq_memo_mu);
+  TqMemo* e = tq_find(rb, limit);
+  if (!e) {
+    static int next = 0;
+    for (TqMemo& c : g_tq_memo)
+      if (!c.used && !e) e = &c;
+    if (!e) e = &g_tq_memo[next++ % TQ_MEMO];
+    e->used = true;
+    e->rbits = rb;
+    e->limit = limit;
+    e->level = 0;
+  }
+  e->level = net == 32 ? 1 : 2;
+  e->calls = 0;
 }
 }  // namespace
 }  // namespace gr
@@ -1948,12 +1961,13 @@ extern "C" int gr_radius_count_cached(const float* q, const float* s, const int6
   const bool same = P.same;
   RadiusHdr h;
   const int mode = search_mode().load();
-  if ((mode == 2 || mode == 3) && ns < (1ll << 29) && (mode == 2 || tq_wanted(radius, -1))) {
+  const int net = mode == 2 ? 32 : (mode == 4 ? 64 : (mode == 3 && ns < (1ll << 29) ? tq_choice(radius, -1) : 0));
+  if (net != 0 && ns < (1ll << 29)) {
     // one thread per query: the whole search now (sorted compact rows), gr_radius_fill only widens them
-    rc = launch_tq(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, 0, nullptr, same, stream, &h);
+    rc = launch_tq(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, 0, nullptr, same, stream, &h, net);
     if (rc != GR_OK) return rc;
     const bool done = h.max_block_hits == 0 && h.max_count <= (unsigned)TQ_ROW_CAP;
-    tq_report(radius, -1, !done);
+    if (mode == 3) tq_report(radius, -1, net, !done);
     if (done) {
       h_info[0] = h.max_count;
       h_info[1] = -1;  // the tiles are in the workspace
@@ -2002,7 +2016,7 @@ extern "C" int gr_radius_fill(const float* q, const float* s, int64_t nq, int64_
 
 extern "C" int gr_radius_search_mode(int mode) {
   const int old = search_mode().load();
-  if (mode >= 0 && mode <= 3) search_mode().store(mode);
+  if (mode >= 0 && mode <= 4) search_mode().store(mode);
   return old;
 }
 
@@ -2024,14 +2038,15 @@ extern "C" int gr_radius_search(const float* q, const float* s, const int64_t* h
   // GR_RADIUS_SINGLE_PASS=1 selects the single-pass kernel (fused_kernel above).  It is not the default: on 8 x 200 k points it
   // runs as long as count + fill together (both are bound by VALU issue: ~3 000 instructions per wave either way)
   const int mode = search_mode().load();
-  const bool tq = (mode == 2 || mode == 3) && ns < (1ll << 29) && (mode == 2 || tq_wanted(radius, limit));
+  const int net = ns >= (1ll << 29) ? 0 : (mode == 2 ? 32 : (mode == 4 ? 64 : (mode == 3 ? tq_choice(radius, limit) : 0)));
+  const bool tq = net != 0;
   const bool fused = (mode == 1 && fused_fits(limit)) || tq;
   if (fused) {
     RadiusHdr hf;
-    rc = tq ? launch_tq(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, out, P.same, stream, &hf)
+    rc = tq ? launch_tq(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, out, P.same, stream, &hf, net)
             : launch_fused(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, out, P.same, stream, &hf);
     if (rc != GR_OK) return rc;
-    if (tq) tq_report(radius, limit, hf.max_block_hits != 0);
+    if (tq && mode == 3) tq_report(radius, limit, net, hf.max_block_hits != 0);
     h_info[0] = hf.max_count;
     h_info[2] = P.same ? 1 : 0;
     h_info[3] = hf.total_cells;

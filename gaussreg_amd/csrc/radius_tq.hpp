@@ -86,7 +86,7 @@ struct TqLds {
   };
   int tbl[16];
 };
-static_assert(sizeof(TqLds<32, true>) <= 9 * 1024 + 64, "tq kernel: LDS per wave");
+static_assert(sizeof(TqLds<32, true>) <= 9 * 1024 + 64 && sizeof(TqLds<64, true>) <= 17 * 1024, "tq kernel: LDS per wave");
 
 template <int NET, bool DIRECT>
 __global__ __launch_bounds__(WAVE) void tq_kernel(
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
       // ORIGINAL order and fetches each row from here.  Four lanes write the 64 bytes a row has in the block.
       if (valid && !slow) q_cnt[t] = n;  // (a wave-finished query's count is written below)
       if (valid) q_pos[orig] = t;
-      static_assert(NET <= TQ_ROW_HALF, "the network's rows fit the first halves");
+      static_assert(NET <= TQ_ROW_CAP, "the network's rows fit the two halves");
       uint32_t* base = rows32 + (size_t)blk * (WAVE * TQ_ROW_HALF);
 #pragma unroll
       for (int cb = 0; cb < NET; cb += L::RB) {
@@ -419,7 +419,8 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
             v.y = lds.r.rowbuf[r * L::RS + ci + 1];
             v.z = lds.r.rowbuf[r * L::RS + ci + 2];
             v.w = lds.r.rowbuf[r * L::RS + ci + 3];
-            if (lds.r.qinfo[r].y >= 0) *reinterpret_cast<uint4*>(base + r * TQ_ROW_HALF + cb + ci) = v;
+            if (lds.r.qinfo[r].y >= 0)
+              *reinterpret_cast<uint4*>(base + (cb < TQ_ROW_HALF ? (size_t)0 : rows_hi) + r * TQ_ROW_HALF + (cb & (TQ_ROW_HALF - 1)) + ci) = v;
           }
           __syncthreads();
         }

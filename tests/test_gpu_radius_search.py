@@ -14,7 +14,7 @@ def _t(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.fixture(params=[0, 1, 2, 3], ids=["count+fill", "single-pass", "thread-per-query", "adaptive"], autouse=True)
+@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["count+fill", "single-pass", "thread-per-query", "adaptive", "thread-per-query-64"], autouse=True)
 def search_mode(request):
     """Every test of this file runs in both modes of gr_radius_search (include/gaussreg_hip.h)."""
     from gaussreg_amd import _lib
