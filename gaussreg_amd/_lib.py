@@ -73,7 +73,6 @@ SIGNATURES.update({
     "gr_sinkhorn": (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_void, c_void, c_int, c_f32, c_int, c_void, c_void, c_size,
                             c_void]),
     "gr_kpconv_workspace_bytes": (c_size, [c_i64, c_i64, c_i64, c_i64]),
-    "gr_kpconv_debug_fused": (c_int, [c_int]),
     "gr_kpconv_forward": (c_int, [c_void] * 4 + [c_i64] * 5 + [c_void, c_i64, c_void, c_void, c_f32, c_f32, c_void,
                                                             c_void, c_size, c_void]),
     "gr_gather_rows": (c_int, [c_void, c_i64, c_i64, c_void, c_i64, c_void, c_void, c_void]),

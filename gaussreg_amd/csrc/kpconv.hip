@@ -9,7 +9,6 @@
 //             over the neighbours with coalesced feature-row reads            -> WF (M, K*Cin)
 //   gemm      out = WF (M x K*Cin) . W (K*Cin x Cout) on fp32 MFMA 32x32x2, epilogue / neighbor_num + bias
 #include <algorithm>
-#include <atomic>
 
 #include "common.hpp"
 
@@ -215,239 +214,6 @@ __global__ __launch_bounds__(256) void kp_gather_mfma_kernel(
     }
   cnt = wave_sum_i32_dpp(cnt);
   if (lane == 0) inv_num[m] = (float)max(cnt, 1);                         // :114 max(neighbor_num, 1)
-}
-
-// ---------------------------------------------------------------- gather + product in ONE launch (round 6)
-// The two launches above hand WF (M x K Cin fp32: 11.6 GB at 1.5 M points x 128 channels) through HBM, exactly like the
-// reference's weighted_feats (kpconv.py:103-108).  Here it never leaves the CU: a workgroup of eight waves owns SIXTEEN
-// queries and walks the input channels in chunks of CCH = min(Cin, 64):
-//   gather   wave w computes WF[q][k][chunk] for its two queries with the per-query MFMA formulation above (A = kernel-point
-//            influences, B = the neighbours' 256-byte row pieces), the gathers of FPS_PD steps in flight (two workgroups =
-//            sixteen waves per CU is fewer than the stand-alone gather kernel keeps, so the depth has to come from the wave),
-//            and leaves the D registers in an LDS tile A2[16 queries][K CCH (+4)] -- 61 KB, two workgroups per CU;
-//   product  out[16 x Cout] += A2 (16 x K CCH) . W[chunk rows] (K CCH x Cout) on v_mfma_f32_16x16x4f32: the A operand is one
-//            ds_read_b128 per four steps (lane group g of the MFMA walks its own contiguous quarter of the reduction, so a
-//            lane's consecutive steps are consecutive floats), the B operand streams from the L2 (W is 245 KB - 1 MB per
-//            layer, shared by every workgroup) two or three blocks ahead; the waves split the output columns (TW 16-column
-//            tiles each) and, for narrow outputs, the reduction (KS parts, added through LDS at the end);
-//   epilogue / neighbor_num + bias as before (kpconv.py:112-119).
-// The reduction order differs from the two-launch path (chunk by chunk, four interleaved quarters): same 1e-5 bar.
-constexpr int KPF_NW = 8;   // waves per workgroup
-constexpr int KPF_PD = 4;   // feature-row pieces in flight per wave in the gather
-template <int CIN, int TW, int KS>
-__global__ __launch_bounds__(KPF_NW* WAVE) void kpconv_fused_kernel(
-    const float* __restrict__ s_feats, const float* __restrict__ q_points, const float* __restrict__ s_points,
-    const int64_t* __restrict__ nbr, int N, int M, int H, int K, const float* __restrict__ kpts, float sigma, float inf,
-    const uint8_t* __restrict__ flag, const float* __restrict__ Wt, const float* __restrict__ bias, int COUT,
-    float* __restrict__ out) {
-  constexpr int CCH = CIN < 64 ? CIN : 64;  // channels per chunk
-  constexpr int NCH = CIN / CCH;
-  constexpr int NT = CCH / 16;              // 16-channel tiles of the gather
-  constexpr int VEC = NT < 4 ? NT : 4;
-  static_assert(NT == VEC, "a chunk is one vector load per lane");
-  typedef float vec_t __attribute__((ext_vector_type(VEC)));
-  constexpr int VB = TW < 4 ? TW : 4;       // output columns per B load
-  constexpr int NGB = TW / VB;
-  constexpr int PB = TW <= 2 ? 3 : 2;       // blocks of four reduction steps in flight in the product
-  constexpr int WCOL = KPF_NW / KS;         // waves along the output columns
-  typedef float vb_t __attribute__((ext_vector_type(VB)));
-  extern __shared__ __attribute__((aligned(16))) float fz_smem[];
-  const int KC = K * CCH, LD = KC + 4, R = KC / 4;
-  float* A2 = fz_smem;              // [16][LD]
-  float* s_num = A2 + 16 * LD;      // [16]
-  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
-  const int kk = lane & 15, hq = lane >> 4;
-  const int m0 = blockIdx.x * 16;
-  const bool kreal = kk < K;
-  const float kx = kreal ? kpts[3 * kk] : 0.f, ky = kreal ? kpts[3 * kk + 1] : 0.f, kz = kreal ? kpts[3 * kk + 2] : 0.f;
-  const int nsteps = (H + 3) / 4;
-  // product: this wave's column tiles and its part of the reduction
-  const int wt = w % WCOL, kh = w / WCOL;
-  const int wcol0 = wt * TW * 16;
-  f32x4 oacc[TW];
-#pragma unroll
-  for (int t = 0; t < TW; ++t) oacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // the neighbour rows of this wave's two queries and their kernel-point influences (the same for every chunk): every
-  // lane owns one (neighbour of the step, kernel point) pair per step; all support points are requested before the first
-  // one is used -- one memory round trip for the row's geometry
-  int idxs[2][KP_STEPS];
-  float infl[2][KP_STEPS];
-#pragma unroll
-  for (int qi = 0; qi < 2; ++qi) {
-    const int ql = w + KPF_NW * qi, m = m0 + ql;
-    const int64_t* row = nbr + (int64_t)min(m, M - 1) * H;
-#pragma unroll
-    for (int sidx = 0; sidx < KP_STEPS; ++sidx) {
-      const int h = 4 * sidx + hq;
-      const int64_t v = (h < H && m < M) ? row[h] : -1;
-      idxs[qi][sidx] = (v >= N || v < 0) ? -1 : (int)v;
-    }
-    const int64_t mq = min(m, M - 1);
-    const float qx = q_points[3 * mq], qy = q_points[3 * mq + 1], qz = q_points[3 * mq + 2];
-    int cnt = 0;
-#pragma unroll
-    for (int s8 = 0; s8 < KP_STEPS; s8 += 8) {  // eight steps' support points in flight at a time (registers)
-      float sx[8], sy[8], sz[8];
-      int sf[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (s8 + u < nsteps) {  // wave-uniform
-          const int64_t si = idxs[qi][s8 + u] < 0 ? 0 : idxs[qi][s8 + u];
-          sx[u] = s_points[3 * si], sy[u] = s_points[3 * si + 1], sz[u] = s_points[3 * si + 2];
-          sf[u] = flag[si];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        infl[qi][s8 + u] = 0.f;
-        if (s8 + u < nsteps) {
-          const bool pad = idxs[qi][s8 + u] < 0;
-          // kpconv.py:90-98: shadow support at +inf, neighbours centred on the query, influence max(1 - |.|/sigma, 0)
-          const float nx = (pad ? inf : sx[u]) - qx, ny = (pad ? inf : sy[u]) - qy, nz = (pad ? inf : sz[u]) - qz;
-          const float dx = nx - kx, dy = ny - ky, dz = nz - kz;
-          const float sq = (dx * dx + dy * dy) + dz * dz;
-          infl[qi][s8 + u] = (kreal && !pad) ? fmaxf(1.0f - sqrtf(sq) / sigma, 0.0f) : 0.0f;
-          cnt += (kk == 0 && !pad && sf[u]) ? 1 : 0;  // :112-113, one lane per neighbour
-        }
-      }
-    }
-    cnt = wave_sum_i32_dpp(cnt);
-    if (lane == 0) s_num[ql] = (float)max(cnt, 1);  // :114 max(neighbor_num, 1)
-  }
-#pragma unroll 1
-  for (int ch = 0; ch < NCH; ++ch) {
-    const int c0 = ch * CCH;
-    // ---- gather: two queries per wave, KPF_PD feature-row pieces in flight
-#pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
-      const int ql = w + KPF_NW * qi, m = m0 + ql;
-      if (m >= M) {  // (wave-uniform) rows past the end: zeros, so the product stays finite
-        for (int e = lane; e < KC; e += WAVE) A2[ql * LD + e] = 0.f;
-        continue;
-      }
-      f32x4 acc[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      vec_t rb[KPF_PD];
-#define KPF_FETCH(S)                                                                                                   \
-  {                                                                                                                    \
-    int id = idxs[qi][S];                                                                                              \
-    asm volatile("" : "+v"(id)); /* (keeps the 64-bit row addresses of all 32 steps from being hoisted out of the chunk loop) */ \
-    const int64_t si = id < 0 ? 0 : id;                                                                                \
-    rb[(S) % KPF_PD] = *(reinterpret_cast<const vec_t*>(s_feats + si * CIN + c0) + kk); /* zeros selected below (:103) */ \
-  }
-#pragma unroll
-      for (int p = 0; p < KPF_PD - 1; ++p)
-        if (p < nsteps) KPF_FETCH(p)
-#pragma unroll
-      for (int sidx = 0; sidx < KP_STEPS; ++sidx) {
-        if (sidx < nsteps) {  // wave-uniform
-          if (sidx + KPF_PD - 1 < KP_STEPS && sidx + KPF_PD - 1 < nsteps) KPF_FETCH(sidx + KPF_PD - 1)
-          const bool pad = idxs[qi][sidx] < 0;
-          const vec_t b = rb[sidx % KPF_PD];
-          const float a = infl[qi][sidx];
-#pragma unroll
-          for (int c = 0; c < VEC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, pad ? 0.0f : b[c], acc[c], 0, 0, 0);
-        }
-      }
-#undef KPF_FETCH
-      // D[i][j]: lane l holds rows i = 4 (l / 16) + r, column j = l % 16  ->  A2[q][i CCH + VEC j + c]
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 4 * hq + r;
-        vec_t o;
-#pragma unroll
-        for (int c = 0; c < VEC; ++c) o[c] = acc[c][r];
-        if (i < K) *reinterpret_cast<vec_t*>(A2 + ql * LD + i * CCH + VEC * kk) = o;
-      }
-    }
-    __syncthreads();
-    // ---- product: lane group g = hq walks reduction indices g R + [4 b_lo, 4 b_hi), four steps per block, PB blocks ahead
-    {
-      const int nblk = R / 4;
-      const int b_lo = kh * nblk / KS, b_hi = (kh + 1) * nblk / KS;
-      const float* arow = A2 + kk * LD + hq * R;
-      f32x4 av[PB];
-      vb_t bv[PB][4][NGB];
-#define KPF_LOAD(SLOT, BLK)                                                                                           \
-  {                                                                                                                   \
-    const int s_ = 4 * (BLK);                                                                                         \
-    av[SLOT] = *reinterpret_cast<const f32x4*>(arow + s_);                                                            \
-    const int r2 = hq * R + s_; /* (four consecutive reduction indices never straddle a kernel point: CCH % 4 == 0) */ \
-    const float* wp = Wt + ((int64_t)(r2 / CCH) * CIN + c0 + (r2 % CCH)) * COUT + wcol0 + VB * kk;                    \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                                     \
-        _Pragma("unroll") for (int g = 0; g < NGB; ++g)                                                               \
-            bv[SLOT][u][g] = *reinterpret_cast<const vb_t*>(wp + (int64_t)u * COUT + g * 16 * VB);                    \
-  }
-#pragma unroll
-      for (int p = 0; p < PB; ++p)
-        if (b_lo + p < b_hi) KPF_LOAD(p, b_lo + p)
-      for (int blk0 = b_lo; blk0 < b_hi; blk0 += PB) {
-#pragma unroll
-        for (int p = 0; p < PB; ++p) {
-          if (blk0 + p < b_hi) {  // wave-uniform
-            const f32x4 a = av[p];
-            vb_t b[4][NGB];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-              for (int g = 0; g < NGB; ++g) b[u][g] = bv[p][u][g];
-            if (blk0 + p + PB < b_hi) KPF_LOAD(p, blk0 + p + PB)  // in flight during the MFMAs of the next PB blocks
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-              for (int g = 0; g < NGB; ++g)
-#pragma unroll
-                for (int c = 0; c < VB; ++c)
-                  oacc[g * VB + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u][g][c], oacc[g * VB + c], 0, 0, 0);
-          }
-        }
-      }
-#undef KPF_LOAD
-    }
-    __syncthreads();  // the tile is rewritten by the next chunk
-  }
-  // ---- narrow outputs: add the KS parts of the reduction through LDS (the tile's place)
-  if (KS > 1) {
-    float* red = A2;  // [KS - 1][WCOL][TW][4][64]
-    if (kh > 0) {
-#pragma unroll
-      for (int t = 0; t < TW; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[((((kh - 1) * WCOL + wt) * TW + t) * 4 + r) * WAVE + lane] = oacc[t][r];
-    }
-    __syncthreads();
-    if (kh == 0) {
-#pragma unroll
-      for (int h2 = 1; h2 < KS; ++h2)
-#pragma unroll
-        for (int t = 0; t < TW; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) oacc[t][r] += red[((((h2 - 1) * WCOL + wt) * TW + t) * 4 + r) * WAVE + lane];
-    }
-  }
-  // ---- epilogue: D[q = 4 hq + r][n = kk] of tile t = g VB + c is column wcol0 + 16 VB g + VB kk + c
-  if (kh == 0) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ql = 4 * hq + r, m = m0 + ql;
-      if (m < M) {
-        const float den = s_num[ql];
-#pragma unroll
-        for (int g = 0; g < NGB; ++g) {
-          const int col = wcol0 + g * 16 * VB + VB * kk;
-          vb_t o;
-#pragma unroll
-          for (int c = 0; c < VB; ++c) {
-            float v = oacc[g * VB + c][r] / den;                    // kpconv.py:115
-            if (bias) v = v + bias[col + c];                        // :118-119
-            o[c] = v;
-          }
-          *reinterpret_cast<vb_t*>(out + (int64_t)m * COUT + col) = o;
-        }
-      }
-    }
-  }
 }
 
 constexpr int GT = 64, GK = 32, GLD = GK + 1;
@@ -699,18 +465,6 @@ __global__ __launch_bounds__(256) void pool4_kernel(const float4* __restrict__ x
 
 using namespace gr;
 
-namespace gr {
-namespace {
-std::atomic<int> g_kpconv_fused{1};  // test hook (gr_kpconv_debug_fused): 0 = always the two-launch path
-}
-}  // namespace gr
-
-extern "C" int gr_kpconv_debug_fused(int on) {
-  const int old = gr::g_kpconv_fused.load();
-  if (on == 0 || on == 1) gr::g_kpconv_fused.store(on);
-  return old;
-}
-
 extern "C" size_t gr_kpconv_workspace_bytes(int64_t n, int64_t m, int64_t k, int64_t cin) {
   if (n < 0 || m < 0 || k < 0 || cin < 0) return 0;
   return align_up((size_t)m * k * cin * sizeof(float), 256) + align_up((size_t)m * sizeof(float), 256) +
@@ -741,38 +495,6 @@ extern "C" int gr_kpconv_forward(const float* s_feats, const float* q_points, co
   KernelTimer timer("kpconv", stream);
   if (n > 0)
     hipLaunchKernelGGL(rowflag_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, s_feats, (int)n, (int)cin, flag);
-  // one launch (kpconv_fused_kernel) where its tiling applies: Cin in {32, 64, 128, 256}, Cout in {32, 64, 128, 256, 512}
-  if (g_kpconv_fused.load() && n > 0 && h <= 4 * KP_STEPS && (cin == 32 || cin == 64 || cin == 128 || cin == 256) &&
-      (cout == 32 || cout == 64 || cout == 128 || cout == 256 || cout == 512) && (k * std::min<int64_t>(cin, 64)) % 16 == 0 &&
-      ((reinterpret_cast<uintptr_t>(weights) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(s_feats)) & 15) == 0) {
-    const int cch = (int)std::min<int64_t>(cin, 64);
-    const size_t lds = ((size_t)16 * (k * cch + 4) + 16) * sizeof(float);
-    const dim3 grid((unsigned)((m + 15) / 16)), blk(KPF_NW * WAVE);
-#define GR_KP_FUSED(CIN, TW, KS)                                                                                              \
-  do {                                                                                                                        \
-    auto kern = kpconv_fused_kernel<CIN, TW, KS>;                                                                             \
-    if (lds > 64 * 1024)                                                                                                      \
-      GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-    hipLaunchKernelGGL(kern, grid, blk, lds, stream, s_feats, q_points, s_points, neighbor_indices, (int)n, (int)m, (int)h,  \
-                       (int)k, kernel_points, sigma, inf, flag, weights, bias, (int)cout, out);                               \
-  } while (0)
-#define GR_KP_FUSED_COUT(CIN)                                 \
-  do {                                                        \
-    if (cout == 32) GR_KP_FUSED(CIN, 1, 4);                   \
-    else if (cout == 64) GR_KP_FUSED(CIN, 1, 2);              \
-    else if (cout == 128) GR_KP_FUSED(CIN, 1, 1);             \
-    else if (cout == 256) GR_KP_FUSED(CIN, 2, 1);             \
-    else GR_KP_FUSED(CIN, 4, 1);                              \
-  } while (0)
-    if (cin == 32) GR_KP_FUSED_COUT(32);
-    else if (cin == 64) GR_KP_FUSED_COUT(64);
-    else if (cin == 128) GR_KP_FUSED_COUT(128);
-    else GR_KP_FUSED_COUT(256);
-#undef GR_KP_FUSED_COUT
-#undef GR_KP_FUSED
-    GR_LAUNCH_CHECK();
-    return GR_OK;
-  }
   const size_t kp_lds = (size_t)std::min<int64_t>(h, KP_HMAX) * (KP_MAX + 2) * sizeof(float);
   const bool mfma = n > 0 && h <= 4 * KP_STEPS && (cin == 16 || cin == 32 || cin == 64 || cin == 128 || cin == 256);
   if (mfma) {

@@ -272,9 +272,6 @@ int gr_sinkhorn(const float* scores, int64_t batch, int64_t m, int64_t n, const 
  * with n, kernel_points (k,3), weights (k,cin,cout), bias (cout) or null -> out (m,cout).
  * gr_neighbor_pool: kpconv/functional.py maxpool (mode 0, :54-67) / nearest_upsample (mode 1, :6-22). */
 size_t gr_kpconv_workspace_bytes(int64_t n, int64_t m, int64_t k, int64_t cin);
-/* test hook: 0 = always the two-launch path (gather -> WF in the workspace -> product), 1 = the one-launch kernel where its
- * tiling applies (default); any other value only queries.  Returns the previous setting. */
-int gr_kpconv_debug_fused(int on);
 int gr_kpconv_forward(const float* s_feats, const float* q_points, const float* s_points,
                       const int64_t* neighbor_indices, int64_t n, int64_t m, int64_t h, int64_t cin, int64_t cout,
                       const float* kernel_points, int64_t k, const float* weights, const float* bias, float sigma,

@@ -135,43 +135,6 @@ def test_kpconv_shapes_vs_oracle(Cin, Cout, H):
     assert_rel_scale(y, want, 1e-5, "KPConv vs oracle")
 
 
-@pytest.mark.parametrize("Cin,Cout,H,Mq", [(32, 32, 18, 2500), (64, 64, 30, 2501), (128, 128, 43, 1999), (256, 256, 49, 900),
-                                            (64, 128, 16, 777), (32, 64, 7, 33), (128, 256, 64, 1200), (256, 512, 20, 500),
-                                            (128, 32, 5, 640), (64, 512, 1, 100)])
-def test_kpconv_one_launch_vs_two_launches_and_oracle(Cin, Cout, H, Mq):
-    """The one-launch kernel (gather -> 16-query WF tile in LDS -> product, channel chunks of 64) against the two-launch path
-    (WF through the workspace) and the NumPy oracle: every Cin / Cout tiling it has, query counts that are not multiples
-    of 16, shadow neighbours, all-zero feature rows, a bias."""
-    from gaussreg_amd import _lib
-    from gaussreg_amd.kpconv import KPConv
-    from oracle import matching_np as M
-    rng = np.random.default_rng(Cin * 1000 + Cout + H)
-    N, K = 3000, 15
-    sp = rng.random((N, 3)).astype(np.float32) * 0.6
-    qp = sp[rng.permutation(N)[:Mq]] + rng.normal(0, 0.004, (Mq, 3)).astype(np.float32)
-    d = ((qp[:, None, :] - sp[None]) ** 2).sum(-1)
-    idx = np.argsort(d, axis=1)[:, :H]
-    idx = np.where(np.take_along_axis(d, idx, 1) > 0.07 ** 2, N, idx).astype(np.int64)
-    f = np.maximum(rng.normal(size=(N, Cin)), 0).astype(np.float32)
-    f[::11] = 0
-    kp = (rng.normal(size=(K, 3)) * 0.035).astype(np.float32)
-    conv = KPConv(Cin, Cout, K, 0.0625, 0.045, bias=True, kernel_points=kp).cuda()
-    with torch.no_grad():
-        conv.bias.copy_(torch.from_numpy(rng.normal(size=(Cout,)).astype(np.float32)))
-    args = (_c(f), _c(qp), _c(sp), _c(idx))
-    L = _lib.lib()
-    old = L.gr_kpconv_debug_fused(1)
-    try:
-        one = conv(*args).cpu().numpy()
-        L.gr_kpconv_debug_fused(0)
-        two = conv(*args).cpu().numpy()
-    finally:
-        L.gr_kpconv_debug_fused(old)
-    want = M.kpconv(f, qp, sp, idx, kp, conv.weights.detach().cpu().numpy(), 0.045) + conv.bias.detach().cpu().numpy()[None]
-    assert_rel_scale(one, two, 1e-5, "KPConv one launch vs two launches")
-    assert_rel_scale(one, want, 1e-5, "KPConv one launch vs oracle")
-
-
 def test_gs_fusion_vs_reference_golden(tmp_path):
     from gaussreg_amd.gs_io import gaussian_fuse, gaussian_fuse_records, read_gs_ply, write_gs_ply
     g = load_golden("gs_fusion.npz")

@@ -7,8 +7,6 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests", "golde
 from gen_golden_ext import room_pair
 from gaussreg_amd.data import precompute_data_stack_mode
 from gaussreg_amd.kpconv import KPConv
-from gaussreg_amd import _lib as _glib
-_glib.lib().gr_kpconv_debug_fused(int(os.environ.get('KP_FUSED', '1')))  # 0 = the two-launch path
 
 
 def timeit(fn, n=10, warm=2):

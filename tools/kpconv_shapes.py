@@ -3,8 +3,6 @@
 import os, sys, time, collections, torch
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 from gaussreg_amd import pair_pipeline, kpconv
-from gaussreg_amd import _lib as _glib
-_glib.lib().gr_kpconv_debug_fused(int(os.environ.get('KP_FUSED', '1')))  # 0 = the two-launch path
 dev = torch.device("cuda", 0)
 pairs = [pair_pipeline.synthetic_room_pair(i, 200000, dev) for i in range(32)]
 reg = pair_pipeline.PairRegistrar(dev, features="model")
