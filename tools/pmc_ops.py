@@ -3,7 +3,7 @@ HBM roofline (tools/pmc_ops.sh runs it under rocprofv3 --pmc, tools/pmc_ops_summ
 process and divides by the number of operator calls printed here).
 
     python tools/pmc_ops.py <op> [calls]
-    ops: grid_ref_64x200k grid_cell_64x200k grid_ref_1x200k kpconv_2_2_x32 gs_fuse_2x2p55M fps_2x200k radius_8x200k
+    ops: grid_ref_64x200k grid_cell_64x200k grid_ref_1x200k kpconv_2_2_x32 gs_fuse_2x2p55M fps_2x200k radius_8x200k radius_limited_8x200k
 
 Prints one JSON line: {"op", "calls", "algorithmic_bytes_per_call", ...}.  Every call of the process is counted (no separate
 warm-up: the first call's traffic is the same traffic)."""
@@ -40,6 +40,14 @@ def main():
             dp = pts.to(dev)
             for _ in range(calls):
                 nb = ext.radius_neighbors(dp, dp, lens, lens, 0.0625)
+            info["algorithmic_bytes_per_call"] = 24 * dp.shape[0] + 8 * dp.shape[0] * nb.shape[1]
+            info["width"] = int(nb.shape[1])
+        elif op == "radius_limited_8x200k":
+            from gaussreg_amd.ops import radius_search
+            pts, lens = synthetic.cloud_200k(8, seed=0)
+            dp = pts.to(dev)
+            for _ in range(calls):
+                nb = radius_search(dp, dp, lens, lens, 0.0625, 40)
             info["algorithmic_bytes_per_call"] = 24 * dp.shape[0] + 8 * dp.shape[0] * nb.shape[1]
             info["width"] = int(nb.shape[1])
         elif op == "kpconv_2_2_x32":

@@ -3,7 +3,7 @@
 # FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes (no tracing flags), one process per operator and counter;
 # tools/pmc_ops_summary.py turns them into gpurun_out/<R>_pmc_ops.json (copy to profiles/).
 R=${1:-r05}; shift
-OPS=${@:-grid_ref_64x200k grid_cell_64x200k grid_ref_1x200k radius_8x200k kpconv_2_2_x32 gs_fuse_2x2p55M fps_2x200k}
+OPS=${@:-grid_ref_64x200k grid_cell_64x200k grid_ref_1x200k radius_8x200k radius_limited_8x200k kpconv_2_2_x32 gs_fuse_2x2p55M fps_2x200k}
 cd /tmp && export TMPDIR=/tmp
 for op in $OPS; do
   for ctr in FETCH_SIZE WRITE_SIZE; do

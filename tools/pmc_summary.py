@@ -8,7 +8,7 @@ import sys
 
 KEEP = ("blend_kernel", "preprocess_kernel", "traverse_kernel", "ds_scatter_kernel", "ds_count_kernel", "ds_scan_kernel",
         "tile_scatter_kernel", "tile_count_kernel", "seg_scan_kernel", "coarse_kernel", "fine_kernel", "bbox_partial_kernel",
-        "fused_kernel", "rpe_attention_kernel", "geo_embedding", "fps_multi_kernel", "kpconv")
+        "fused_kernel", "rpe_attention_kernel", "geo_embedding", "fps_multi_kernel", "kpconv", "tq_kernel", "tq_expand_kernel")
 
 
 def short(name):
@@ -46,10 +46,16 @@ def main():
                    "--steps 3 --warmup 1 --no-cpu-baseline --pairs 0 --no-extras --no-single-view; values in KB per launch as reported. Per MI355X_MICROARCH.md (HBM "
                    "section) FETCH_SIZE on gfx950 counts wide coalesced reads at 1/2 -> hbm_bytes ~= (2*FETCH_SIZE + WRITE_SIZE)*1024.",
            "config": {"raster": f"1M Gaussians, 640x480, {views} views/launch", "radius": f"{clouds} x 200k-pt clouds/launch, r=0.0625"},
-           "units_per_launch": {"raster_blend": views, "radius_fill": clouds, "radius_count": clouds, "radius_fused": clouds},
+           "units_per_launch": {"raster_blend": views, "radius_fill": clouds, "radius_count": clouds, "radius_fused": clouds,
+                                "radius_search": clouds, "radius_tq_limited": clouds},
            "kernels": kernels, "traffic_bytes_per_launch": {}}
-    for k in kernels:  # the two kernels bench.py prices against the HBM roofline
+    tr = doc["traffic_bytes_per_launch"]
+    for k in kernels:  # the kernels bench.py prices against the HBM roofline
         hbm = int((2 * k["fetch_size_kb_avg"] + k["write_size_kb_avg"]) * 1024)
+        if k["kernel"].startswith("tq_kernel<32, false>") or k["kernel"].startswith("tq_expand_kernel"):
+            tr["radius_search"] = tr.get("radius_search", 0) + hbm   # the bare search: compact rows + their expansion
+        if k["kernel"].startswith("tq_kernel<32, true>"):
+            tr["radius_tq_limited"] = hbm
         if k["kernel"].startswith("blend_kernel"):
             doc["traffic_bytes_per_launch"]["raster_blend"] = hbm
         if k["kernel"].startswith("traverse_kernel<128, true"):

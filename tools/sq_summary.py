@@ -5,7 +5,7 @@ import csv
 import json
 import sys
 
-KEEP = tuple(__import__("os").environ.get("GR_SQ_KEEP", "blend_kernel,preprocess_kernel,traverse_kernel,fused_kernel,coarse_kernel,fine_kernel,tile_scatter_kernel,tile_count_kernel,ds_scatter_kernel,ds_count_kernel,rpe_attention_kernel,fps_multi_kernel").split(","))
+KEEP = tuple(__import__("os").environ.get("GR_SQ_KEEP", "blend_kernel,preprocess_kernel,traverse_kernel,fused_kernel,tq_kernel,tq_expand_kernel,coarse_kernel,fine_kernel,tile_scatter_kernel,tile_count_kernel,ds_scatter_kernel,ds_count_kernel,rpe_attention_kernel,fps_multi_kernel").split(","))
 SIMDS, GHZ = 1024, 2.4
 
 
