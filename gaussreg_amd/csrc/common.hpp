@@ -12,6 +12,12 @@
 namespace gr {
 
 constexpr int WAVE = 64;
+// gfx950 only: several kernels of this library allocate 64 - 93 KB of static LDS per workgroup (the in-LDS bucket sorts of
+// depth_sort.hip, the slab chains of hash_order_device.hip, the tile scatter), which needs the 160 KB a CDNA4 CU has;
+// on any other --offload-arch this fails here with a reason instead of a bare "local memory limit exceeded".
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libgaussreg_hip is written for gfx950 (MI355X, 160 KB of LDS per CU): build with --offload-arch=gfx950"
+#endif
 
 void set_error(const char* fmt, ...);
 

@@ -1366,7 +1366,10 @@ bool verify_this_frame() {
 // depths crowd into a sliver of the key range: every frame would be ordered twice); per host thread
 thread_local int g_bucket_cooldown = 0;
 constexpr int BUCKET_COOLDOWN_FRAMES = 256;
-bool bucket_sort_allowed() {  // one call of the waiting period
+// One call of the waiting period.  The unit is library calls that COULD have used the bucket sort (`possible`): calls of
+// many views, which never take it, do not run the period down.
+bool bucket_sort_allowed(bool possible) {
+  if (!possible) return false;
   if (g_bucket_cooldown == 0) return true;
   --g_bucket_cooldown;
   return false;
@@ -1555,8 +1558,8 @@ static int preprocess_impl(int64_t P, int M, const float* means3D, const float* 
   // a deferred frame of a few views: the four-launch depth sort (a bucket that outgrows LDS raises the far word with the
   // sign flipped; the caller then takes the plain path, which always sorts in three passes)
   // (a plain call reads the counts itself: bit 1 of the far word says "overflow" there and the ordering is redone in place)
-  const bool msd = (defer_ev != nullptr ? defer_ev->bucket_sort : bucket_sort_allowed()) &&
-                   depth_sort_msd_possible(P, num_views, KEY_DEPTH_BITS);
+  const bool msd_possible = depth_sort_msd_possible(P, num_views, KEY_DEPTH_BITS);
+  const bool msd = msd_possible && (defer_ev != nullptr ? defer_ev->bucket_sort : bucket_sort_allowed(true));
   int2* const mm_out = msd ? g.key_mm : nullptr;
 #define GR_PRE(SH, COV, S16)                                                                       \
   if (S16 && num_views == 1)                                                                       \
@@ -1961,7 +1964,7 @@ extern "C" int gr_raster_forward(int64_t P, int M, const float* means3D, const f
       frame_seq.store(1);
       seq = 1;
     }
-    Deferred d{ev, mail, seq, 1, false, bucket_sort_allowed(), false};
+    Deferred d{ev, mail, seq, 1, false, bucket_sort_allowed(depth_sort_msd_possible(P, num_views, KEY_DEPTH_BITS)), false};
     int rc = preprocess_impl(P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, h_views,
                              num_views, radii, geom, geom_bytes, h_num_rendered, stream, &d);
     if (rc != GR_OK) return rc;

@@ -186,9 +186,9 @@ def grid_subsampling(points, lengths, voxel_size, order="reference"):
         _lib.check(L.gr_grid_subsample(_lib.ptr(p), hl, n, nb, float(voxel_size), _ORDER[order], _lib.ptr(out),
                                        out_l, ctypes.byref(total), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)))
     s_points = out[: total.value]
-    if total.value * 4 < n:
-        s_points = s_points.clone()  # do not pin the (n,3) allocation behind a SMALL view (a view of a quarter or more of it
-                                     # is returned as it is: the copy costs 20 - 40 us per call, stream time included)
+    if total.value * 4 < 3 * n:
+        s_points = s_points.clone()  # do not pin the (n, 3) allocation behind a view of less than three quarters of it: the
+                                     # pyramid keeps every level's output (the copy costs 20 - 40 us per call)
     s_lengths = torch.tensor([out_l[b] for b in range(nb)], dtype=torch.int64, device=lengths.device)
     if out_device.type != "cuda":
         s_points = s_points.to(out_device)

@@ -257,3 +257,46 @@ def test_superpoint_matching_fast_and_dense_path_boundaries(nr, ns, k):
     np.testing.assert_allclose(sc.cpu().numpy(), w.values.cpu().numpy(), rtol=2e-5)
     got, want = set((ri * ns + si).tolist()), set(w.indices.tolist())
     assert len(got ^ want) <= 4  # the k-th boundary may flip inside the fp32 noise
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_superpoint_matching_slab_selection_under_extreme_row_and_column_sums(seed):
+    """The slab selection filters with reciprocal-priced approximate scores and a fixed 2e-6 relative margin.  Fuzz it where
+    that margin is thinnest: un-normalised features (superpoint_matching.py:33 always uses the `2 - 2 xy` form, so d spans
+    0 ... 20 and exp(-d) 1 ... 2e-9: row and column sums between ~1e-8 and a few hundred), clusters of near-identical points
+    (hundreds of nearly tied scores around the k-th) and rows / columns that are far from everything.  Every emitted score
+    must be the float64 score of its (row, column), the emitted set must be the float64 top-k up to entries tied within
+    fp32 noise, and the dense path (k > 1024 takes the radix select) must emit the same leading entries."""
+    from gaussreg_amd.matching import SuperPointMatching
+    g = torch.Generator(device="cuda").manual_seed(1000 + seed)
+    nr, ns, k, c = 700, 900, 256, 32
+    centres = torch.randn(12, c, device="cuda", generator=g) * 0.5
+    which_r = torch.randint(0, 12, (nr,), device="cuda", generator=g)
+    which_s = torch.randint(0, 12, (ns,), device="cuda", generator=g)
+    fr = centres[which_r] + torch.randn(nr, c, device="cuda", generator=g) * 0.02
+    fs = centres[which_s] + torch.randn(ns, c, device="cuda", generator=g) * 0.02
+    fr[::7] *= -1.0                                  # rows opposite to every cluster: tiny row sums
+    fs[::5] *= -0.5                                  # columns likewise: tiny column sums
+    fr[1::50] = fs[1:nr:50][: fr[1::50].shape[0]]    # exact duplicates across the two sets
+
+    xy = fr.double() @ fs.double().T
+    S = torch.exp(-(2.0 - 2.0 * xy).clamp(min=0))
+    score = (S / S.sum(1, keepdim=True)) * (S / S.sum(0, keepdim=True))
+    ri, si, sc = SuperPointMatching(k, True)(fr, fs)
+    assert ri.shape == (k,) and bool((sc[:-1] >= sc[1:]).all())
+    mine = score[ri, si]
+    np.testing.assert_allclose(sc.cpu().numpy(), mine.cpu().numpy(), rtol=1e-4, atol=1e-37)
+    kth = torch.topk(score.flatten(), k).values[-1]
+    assert bool((mine >= kth * (1 - 1e-3)).all()), "an emitted entry lies clearly below the float64 k-th best"
+    missing = (score >= kth * (1 + 1e-3))
+    missing[ri, si] = False
+    assert int(missing.sum()) == 0, "an entry clearly above the float64 k-th best was dropped by the filter"
+    # the dense path (k > 1024): its leading k entries are the slab path's
+    ri2, si2, sc2 = SuperPointMatching(1100, True)(fr, fs)
+    np.testing.assert_allclose(sc2[:k].cpu().numpy(), sc.cpu().numpy(), rtol=1e-6, atol=1e-37)
+    distinct = sc[:-1] > sc[1:] * (1 + 1e-6)     # where neighbours are not tied, the order of the entries is pinned too
+    same = (ri2[:k] == ri) & (si2[:k] == si)
+    strict = torch.ones(k, dtype=torch.bool, device=sc.device)
+    strict[1:] &= distinct
+    strict[:-1] &= distinct
+    assert bool(same[strict].all())
