@@ -13,8 +13,9 @@
  * of IEEE-754 binary32 operations, so the HIP image is compared BIT-EXACT with this file):
  *   - every `a*b+c` that is fused is written as fmaf(); everything else is separate mul/add
  *     (build with -ffp-contract=off);  sqrtf, '/', ceilf, rintf are correctly rounded;
- *   - exp() in the blend is exp_det() below (Cephes-style range reduction + degree-6 polynomial,
- *     all fmaf) -- within 1 ulp of expf, and reproducible on any IEEE machine, CPU or GPU;
+ *   - exp() in the blend is exp_det() below (base-2 range reduction through the float's own bits + a degree-5
+ *     polynomial, all fmaf: thirteen operations) -- within 2.4e-7 relative of exp where alpha can reach 1/255, and
+ *     reproducible on any IEEE machine, CPU or GPU;
  *   - per-tile depth order = ascending (depth bits, Gaussian index) == a stable radix sort of
  *     (tile << 32 | depth_bits) keys emitted in Gaussian order (upstream's cub SortPairs).
  */
@@ -33,20 +34,36 @@ static const float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570
                                0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
                                -0.5900435899266435f};
 
-/* Deterministic expf for x <= 0 (clamped at -100).  Cephes expf coefficients. */
+/* Deterministic expf for x <= 0 (clamped at -86: exp(-86) = 4.5e-38 is still a normal number).  Base-2 form, thirteen
+ * basic operations (round 6; rounds 1 - 5 used the Cephes form, twenty):
+ *   t  = x * log2(e)
+ *   tm = t + 1.5 * 2^23                 the add rounds t to the nearest integer n (ties to even); n sits in tm's low bits
+ *   nf = tm - 1.5 * 2^23                n as a float (exact)
+ *   f  = fma(x, log2(e), -nf)           the reduced argument from the EXACT product: |f| <= 0.5 (+ 1 ulp of t)
+ *   p  = 2^f, degree-5 polynomial with p(0) = 1, Horner in fmaf (minimax fit on [-0.5, 0.5]: 7e-8)
+ *   result = bits(p) + (bits(tm) << 23) the integer add puts n into p's exponent field (n << 23 mod 2^32; -125 <= n <= 0)
+ * Within 2.4e-7 relative of exp on [-6, 0] (where alpha can reach 1/255), 4.3e-7 on [-20, 0]; exp_det(0) == 1 exactly;
+ * every operation is a correctly rounded IEEE-754 binary32 operation or integer arithmetic: the same bits on any machine. */
 float oracle_exp_det(float x) {
-  x = fmaxf(x, -100.0f);
-  const float n = rintf(x * 1.44269504088896341f);
-  float r = fmaf(n, -0.693359375f, x);
-  r = fmaf(n, 2.12194440e-4f, r);
-  float p = 1.9875691500e-4f;
-  p = fmaf(p, r, 1.3981999507e-3f);
-  p = fmaf(p, r, 8.3334519073e-3f);
-  p = fmaf(p, r, 4.1665795894e-2f);
-  p = fmaf(p, r, 1.6666665459e-1f);
-  p = fmaf(p, r, 5.0000001201e-1f);
-  const float y = fmaf(p, r * r, r) + 1.0f;
-  return ldexpf(y, (int)n);
+  x = fmaxf(x, -86.0f);
+  const float L2E = 1.44269504088896341f, MAGIC = 12582912.0f;
+  const float t = x * L2E;
+  const float tm = t + MAGIC;
+  const float nf = tm - MAGIC;
+  const float f = fmaf(x, L2E, -nf);
+  float p = 1.3264815788716078e-3f;
+  p = fmaf(p, f, 9.671512059867382e-3f);
+  p = fmaf(p, f, 5.550733581185341e-2f);
+  p = fmaf(p, f, 2.4022242426872253e-1f);
+  p = fmaf(p, f, 6.931470036506653e-1f);
+  p = fmaf(p, f, 1.0f);
+  uint32_t pb, tb;
+  memcpy(&pb, &p, 4);
+  memcpy(&tb, &tm, 4);
+  pb += tb << 23;
+  float r;
+  memcpy(&r, &pb, 4);
+  return r;
 }
 
 static inline void xform4x3(const float* M, const float* p, float* o) {
