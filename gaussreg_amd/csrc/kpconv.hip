@@ -210,7 +210,10 @@ __global__ __launch_bounds__(256) void kp_gather_mfma_kernel(
       vec_t o;
 #pragma unroll
       for (int c = 0; c < VEC; ++c) o[c] = acc[g * VEC + c][r];
-      if (i < K) dst[(int64_t)i * (Cin / VEC) + 16 * g] = o;
+      // streaming store: WF is read back once, by the product launch, long after it has left the caches; kept out of them
+      // the neighbours' feature rows (re-gathered ~H times) stay (14 KPConv calls of a 32-pair batch 81.2 -> 79.4 ms;
+      // streaming LOADS of WF in the product measured slower: 84 ms)
+      if (i < K) __builtin_nontemporal_store(o, dst + (int64_t)i * (Cin / VEC) + 16 * g);
     }
   cnt = wave_sum_i32_dpp(cnt);
   if (lane == 0) inv_num[m] = (float)max(cnt, 1);                         // :114 max(neighbor_num, 1)
