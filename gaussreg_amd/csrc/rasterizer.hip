@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
       }
     }
     if (valid) {
-      radii[o] = out_radius;
+      __builtin_nontemporal_store(out_radius, radii + o);  // (an output nobody in the pipeline reads)
       dfield[o] = out_field;
       rect_raw[o] = out_rect;
     }
@@ -481,7 +481,13 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     for (int k = 0; k < 4; ++k) {
       const int rl = 16 * k + lane / 4;
       const float4 piece = wrec[(lane & 3) * REC_PLANE + rl];
-      if ((vis >> rl) & 1ull) wout[4 * rl + (lane & 3)] = piece;
+      // streaming stores (whole 64-byte records, 1 KB per instruction): the records are next read by the blend, three
+      // stages later and in another order -- kept out of the caches they no longer evict the depth fields and rectangles the
+      // sort is about to read (32 views: preprocess 0.61 -> 0.56 ms, depth sort 0.46 -> 0.41 ms)
+      if ((vis >> rl) & 1ull) {
+        typedef float pre_f4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(pre_f4{piece.x, piece.y, piece.z, piece.w}, reinterpret_cast<pre_f4*>(wout + 4 * rl + (lane & 3)));
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
