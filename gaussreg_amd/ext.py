@@ -110,6 +110,9 @@ def _radius(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, gr
     return out if out_device.type == "cuda" else out.to(out_device)
 
 
+_WIDTH_HINT = {}  # (radius, neighbor_limit) -> largest neighbour count of the last search of that call site
+
+
 def _radius_limited(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, grid):
     """radius_search with neighbor_limit > 0: the (nq, limit) rows are allocated before anything is counted and ONE
     kernel searches, ranks and writes them (gr_radius_search); the read-back of max_count only decides whether the
@@ -128,7 +131,6 @@ def _radius_limited(q_points, s_points, q_lengths, s_lengths, radius, neighbor_l
     with torch.cuda.device(dev):
         info = (ctypes.c_int64 * 6)()
         st = _lib.stream_ptr(dev)
-        out = torch.empty((nq, limit), dtype=torch.int64, device=dev)
         if grid is None:
             ws = _lib.workspace(dev, L.gr_radius_workspace_bytes(nq, ns, nb))
             sig, reuse = None, 0
@@ -137,13 +139,31 @@ def _radius_limited(q_points, s_points, q_lengths, s_lengths, radius, neighbor_l
             key = (s.data_ptr(), ns, nb, float(radius), tuple(sl))
             reuse = 1 if (grid.key == key and ns > 0 and nq > 0) else 0
             sig = grid.sig
-        _lib.check(L.gr_radius_search(_lib.ptr(q), _lib.ptr(s), hq, hs, nq, ns, nb, float(radius), limit, _lib.ptr(out),
-                                      _lib.ptr(ws), ws.numel(), info, sig, reuse, st))
-        if grid is not None:
-            grid.key = key if (ns > 0 and nq > 0 and nb > 0) else None
-            grid._keep = s
+        # Row stride of the search.  The reference's limit is an upper bound chosen by calibration and can be far above
+        # what a level ever returns (the demo pyramid: limit 89, largest count 18): rows of `limit` columns would be 5 x the
+        # bytes, written by the kernel and read again by the truncating copy.  A call site (radius, limit) therefore
+        # remembers the largest count it has seen and searches with rows of that width + a margin (a multiple of 8: whole
+        # 64-byte sectors per row piece, streaming stores); a call whose largest count does not fit is repeated at the full
+        # limit -- the result is the same tensor either way.
+        hint = _WIDTH_HINT.get((float(radius), limit))
+        stride = limit if hint is None else min(limit, max(8, (hint + max(2, hint // 4) + 7) // 8 * 8))
+        while True:
+            out = torch.empty((nq, stride), dtype=torch.int64, device=dev)
+            _lib.check(L.gr_radius_search(_lib.ptr(q), _lib.ptr(s), hq, hs, nq, ns, nb, float(radius), stride, _lib.ptr(out),
+                                          _lib.ptr(ws), ws.numel(), info, sig, reuse, st))
+            if grid is not None:
+                grid.key = key if (ns > 0 and nq > 0 and nb > 0) else None
+                grid._keep = s
+                reuse = 1 if grid.key is not None else 0  # (a repeat finds the supports binned)
+            if int(info[0]) <= stride or stride == limit:
+                break
+            stride = limit
+        if nq > 0 and ns > 0 and nb > 0:
+            _WIDTH_HINT[(float(radius), limit)] = int(info[0])
+            if len(_WIDTH_HINT) > 4096:
+                _WIDTH_HINT.clear()
         width = min(int(info[0]), limit)
-        if width < limit:
+        if width < stride:
             out = out[:, :width].contiguous()
     return out if out_device.type == "cuda" else out.to(out_device)
 

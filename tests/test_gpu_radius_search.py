@@ -169,3 +169,24 @@ def test_equal_distances_follow_the_index_order(limit):
         want = capi.radius_neighbors(q, s, ql, sl, radius)[:, :limit]
         got = ext.radius_neighbors_limited(_t(q), ts, torch.from_numpy(ql), tsl, radius, limit)
         assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_call_site_width_hint_narrow_rows_and_the_repeat_at_full_limit():
+    """`radius_search` remembers the largest count of a (radius, limit) call site and searches the next call with narrower
+    rows (ext._WIDTH_HINT).  Sparse cloud first (hint 8-ish against a limit of 60), then a cloud ten times as dense at the
+    same call site: its counts do not fit the hinted rows, the call repeats itself at the full limit.  Same tensor as the
+    oracle's every time, contiguous, and the same as a process that has no hint."""
+    from gaussreg_amd import ext
+    from oracle import capi
+    rng = np.random.default_rng(5)
+    radius, limit = 0.0731, 60
+    ext._WIDTH_HINT.pop((float(radius), limit), None)
+    for n, want_hint_before in ((4000, False), (4000, True), (40000, True), (40000, True), (4000, True)):
+        pts = rng.random((n, 3)).astype(np.float32)
+        lens = np.array([n // 2, n - n // 2], np.int64)
+        want = capi.radius_neighbors(pts, pts, lens, lens, radius)[:, :limit]
+        assert ((float(radius), limit) in ext._WIDTH_HINT) == want_hint_before
+        t = _t(pts)
+        got = ext.radius_neighbors_limited(t, t, torch.from_numpy(lens), torch.from_numpy(lens), radius, limit)
+        assert got.is_contiguous() and got.shape == want.shape and np.array_equal(got.cpu().numpy(), want)
+        assert ext._WIDTH_HINT[(float(radius), limit)] == capi.radius_neighbors(pts, pts, lens, lens, radius).shape[1]
