@@ -10,7 +10,7 @@
 //     thread pulls four consecutive candidates per plane with one 16-byte load (dword aligned) and tests them two at a time
 //     with packed fp32 math.  Round 5's version of this mapping staged 12 KB of planes per wave and was left with 6 waves per
 //     CU; here LDS holds only the hit lists (u16 codes: band << 12 | offset from the wave's first candidate of that band),
-//     the threads' range tables and a small key scratch: 8.7 KB per wave;
+//     the threads' range tables and band bases and a small key scratch: 10.5 KB per wave;
 //   * sorting: the first NET hits -> one 32-bit word per hit, (fixed-point distance << log2 NET) | list slot, sorted by
 //     Batcher's odd-even merge network with v_min_u32 / v_max_u32 (2 instructions per comparator; the 64-bit (distance,
 //     index) words of round 5 cost 6).  The fixed-point distance is a monotone map of the fp32 distance (d * 2^FB / r^2,
@@ -21,8 +21,8 @@
 //   * rows: transposed through LDS in blocks of 16 columns and written as 128-byte pieces.  DIRECT: int64 rows of the
 //     caller's width in the caller's order; otherwise compact u32 rows in cell order, which tq_expand_kernel turns into
 //     int64 rows once the host knows the width (the bare radius_neighbors, whose width is the largest count).
-// A workgroup that cannot finish (band extents beyond 12 bits, too many wave-finished queries, a query with more hits than
-// the key scratch) raises its flag and the caller repeats the call on count + fill.
+// A workgroup that cannot finish raises its flag (2: a single range beyond 12 bits, 3 / 4: too many wave-finished queries,
+// 5: a query with more hits than the key scratch) and the caller repeats the call on count + fill.
 #pragma once
 #include <type_traits>
 
@@ -84,9 +84,9 @@ struct TqLds {
     unsigned long long bkeys[TQ_BKEYS];  // wave-finished queries (after the rows have left)
     char tables[(TABLE_MAX + 1) * 4 + 16 + TABLE_MAX * 64];
   };
-  int tbl[16];
+  int lbase[NBAND * WAVE];  // per thread and band: first candidate - (band << 12)
 };
-static_assert(sizeof(TqLds<32, true>) <= 9 * 1024 + 64 && sizeof(TqLds<64, true>) <= 17 * 1024, "tq kernel: LDS per wave");
+static_assert(sizeof(TqLds<32, true>) <= 11 * 1024 && sizeof(TqLds<64, true>) <= 19 * 1024, "tq kernel: LDS per wave");
 
 template <int NET, bool DIRECT>
 __global__ __launch_bounds__(WAVE) void tq_kernel(
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
   __shared__ __attribute__((aligned(16))) L lds;
   unsigned short* lists = lds.s.lists;
   unsigned short* trng = lds.s.trng;
-  int* tbl = lds.tbl;
+  int* lbase = lds.lbase;
   const int tcap = nb <= L::TABLE_MAX ? nb : 0;
   int* s_qoff = reinterpret_cast<int*>(lds.tables);
   BatchGrid* s_grids = reinterpret_cast<BatchGrid*>(lds.tables + ((size_t)(tcap + 1) * 4 + 15) / 16 * 16);
@@ -165,38 +165,24 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
   }
   TQ_STOP(1, p0[0] + p1[8] + p0[4])
   __syncthreads();  // the per-cloud tables (in the lists' place) are dead
-  // ---- the wave's first candidate of every band (uniform) -> 12-bit offsets; tbl[k] + code = position in the planes
+  // ---- the thread's non-empty ranges as 16-bit codes (band << 12 | offset from the thread's OWN first candidate of the
+  //      band); lbase[k][lane] + code = position in the planes.  (Offsets from the WAVE's first candidate of a band -- a
+  //      uniform base table -- overflowed 12 bits on real scans: 64 consecutive queries of a sparse slab (walls) can span
+  //      thirty rows of cells, and the band one slab below (the floor) then covers thirty full rows of a dense one.)
   int blk_flag = 0;
   int nrng = 0;
 #pragma unroll
   for (int k = 0; k < NBAND; ++k) {
     const bool has = p1[k] > p0[k];
-    int lo, hi;
-    if (mono) {  // self-search: ranges are non-decreasing along the wave
-      const unsigned long long m = __ballot(has);
-      lo = 0;
-      hi = 0;
-      if (m) {
-        lo = __builtin_amdgcn_readlane(p0[k], __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1));
-        hi = __builtin_amdgcn_readlane(p1[k], __builtin_amdgcn_readfirstlane(63 - __clzll((long long)m)));
-      }
-    } else {
-      lo = wave_min_i32_dpp(has ? p0[k] : 0x7fffffff);
-      hi = wave_max_i32_dpp(has ? p1[k] : 0);
-      lo = __builtin_amdgcn_readfirstlane(lo);
-      hi = __builtin_amdgcn_readfirstlane(hi);
-      if (hi <= lo) lo = hi = 0;
-    }
-    if (hi - lo > TQ_EXT_MAX) blk_flag = 1;
-    if (lane == k) tbl[k] = lo - (k << 12);
+    if (__any(has && p1[k] - p0[k] > TQ_EXT_MAX)) blk_flag = 2;  // a single range beyond 12 bits (thousands of points per cell)
+    lbase[k * WAVE + lane] = p0[k] - (k << 12);
     if (has) {
-      const int code = (k << 12) | (p0[k] - lo);
+      const int code = k << 12;
       trng[(2 * nrng) * WAVE + lane] = (unsigned short)code;
       trng[(2 * nrng + 1) * WAVE + lane] = (unsigned short)(code + (p1[k] - p0[k]));
       ++nrng;
     }
   }
-  if (lane >= NBAND && lane < 16) tbl[lane] = 0;
   trng[(2 * nrng) * WAVE + lane] = 0;  // the empty range a finished thread stays in
   trng[(2 * nrng + 1) * WAVE + lane] = 0;
   // (a wave's LDS operations are served in order: the reads below see these writes)
@@ -208,9 +194,9 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
     //      [i][l]); the code is written to slot n UNCONDITIONALLY and n moves on only for a hit -- no branch per candidate
     const f32x2 qx = {qp.x, qp.x}, qy = {qp.y, qp.y}, qz = {qp.z, qp.z};
     unsigned short* my = lists + lane;
-    int code = trng[lane], ecode = trng[WAVE + lane], badj = tbl[code >> 12];
+    int code = trng[lane], ecode = trng[WAVE + lane], badj = lbase[(code >> 12) * WAVE + lane];
     int kk = min(1, nrng);
-    int ncode = trng[(2 * kk) * WAVE + lane], necode = trng[(2 * kk + 1) * WAVE + lane], nbadj = tbl[ncode >> 12];
+    int ncode = trng[(2 * kk) * WAVE + lane], necode = trng[(2 * kk + 1) * WAVE + lane], nbadj = lbase[(ncode >> 12) * WAVE + lane];
     kk = min(2, nrng);
     // (32-bit byte offsets from uniform plane bases: the loads take the "saddr + voffset" form, no 64-bit address arithmetic)
     const char* const bx_ = reinterpret_cast<const char*>(px);
@@ -230,7 +216,7 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
     const int c2 = sw ? ncode : c4, e2 = sw ? necode : ecode, b2 = sw ? nbadj : badj;                                    \
     {                                                                                                                    \
       const int rc = trng[(2 * kk) * WAVE + lane], re = trng[(2 * kk + 1) * WAVE + lane];                                \
-      const int rb = tbl[rc >> 12];                                                                                      \
+      const int rb = lbase[(rc >> 12) * WAVE + lane];                                                                    \
       ncode = sw ? rc : ncode;                                                                                           \
       necode = sw ? re : necode;                                                                                         \
       nbadj = sw ? rb : nbadj;                                                                                           \
@@ -271,7 +257,7 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
   const bool big = n > NET;
   // a wave most of whose queries need the exact way is not what this kernel is for: give up before the sort (the caller
   // repeats the call on count + fill and remembers the shape)
-  if (__popcll(__ballot(big)) > TQ_BIG_MAX) blk_flag = 1;
+  if (__popcll(__ballot(big)) > TQ_BIG_MAX) blk_flag = 3;
   const int m = min(n, NET);
   const int wmax_u = __builtin_amdgcn_readfirstlane(wave_max_i32_dpp(m));
   // ---- keys: list entries -> one word per hit; slots past the hit count hold pad words (distinct distance fields above
@@ -289,7 +275,7 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int c = (int)lists[(s8 + u) * WAVE + lane];
-        sp[u] = sorted_s[s8 + u < m ? tbl[c >> 12] + c : 0];
+        sp[u] = sorted_s[s8 + u < m ? lbase[min(c >> 12, NBAND - 1) * WAVE + lane] + c : 0];
       }
       __syncthreads();  // (the list reads above are done before the rows are overwritten)
 #pragma unroll
@@ -429,7 +415,7 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
     // ---- wave-finished queries, one after the other: lanes = candidates, hits compacted by ballot, ranked by counting
     unsigned long long slowm = __ballot(slow);
     if (__popcll(slowm) > TQ_BIG_MAX) {
-      blk_flag = 1;
+      blk_flag = 4;
       slowm = 0ull;
     }
     while (slowm) {
@@ -475,7 +461,7 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
         h += __popcll(hm);
       }
       if (h > TQ_BKEYS) {  // (uniform)
-        blk_flag = 1;
+        blk_flag = 5;
         break;
       }
       hmax = max(hmax, h);
