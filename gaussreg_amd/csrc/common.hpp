@@ -107,7 +107,7 @@ void* pinned_scratch(int slot, size_t bytes);
 constexpr int MAIL_WORDS = 1024;
 constexpr int MAIL_GRID_BOXES = 0;     // grid_subsample: 6 B box words + stamp, B <= 80
 constexpr int MAIL_GRID_COUNTS = 512;  // grid_subsample: B + 1 counts, the bucket-overflow flag, the stamp
-constexpr int MAIL_RADIUS = 1008;      // radius search: 4 header words + stamp
+constexpr int MAIL_RADIUS = 1008;      // radius search: 5 header words + stamp
 volatile int32_t* mailbox();
 inline void mailbox_arm(volatile int32_t* stamp_word) { __atomic_store_n(stamp_word, 0, __ATOMIC_RELEASE); }
 int mailbox_next_stamp();  // per process, never 0

@@ -61,6 +61,7 @@ struct RadiusHdr {
   unsigned int max_block_hits;
   int total_cells;
   int total_sup;  // super-cells of all clouds
+  int slow_sum;   // (thread-per-query kernel) queries the network could not finish: finished exactly by their wave
 };
 
 constexpr int RT = 128;
@@ -1543,36 +1544,46 @@ __global__ __launch_bounds__(NSUB* RQ) void fused_kernel(
 // max / max over the per-block (max hits per query, hits per block) pairs -> hdr
 // mail (optional): the header also goes to the host's mailbox page, stamped (common.hpp) -- no copy, no stream synchronise
 __global__ __launch_bounds__(1024) void reduce_stats_kernel(const int32_t* __restrict__ blk_stats,
-                                                            int blocks, RadiusHdr* __restrict__ hdr, int32_t* mail, int stamp) {
-  __shared__ int sh[2][1024 / WAVE];
-  int mx = 0, ms = 0;
+                                                            int blocks, RadiusHdr* __restrict__ hdr, int32_t* mail, int stamp,
+                                                            int tq) {
+  // tq: the second word of a block is (give-up code | wave-finished queries << 8): max of the codes, sum of the counts
+  __shared__ int sh[3][1024 / WAVE];
+  int mx = 0, ms = 0, sum = 0;
   for (int i = threadIdx.x; i < blocks; i += 1024) {
     mx = max(mx, blk_stats[2 * i]);
-    ms = max(ms, blk_stats[2 * i + 1]);
+    const int v = blk_stats[2 * i + 1];
+    ms = max(ms, tq ? (v & 255) : v);
+    sum += tq ? (v >> 8) : 0;
   }
 #pragma unroll
   for (int d = WAVE / 2; d > 0; d >>= 1) {
     mx = max(mx, __shfl_xor(mx, d, WAVE));
     ms = max(ms, __shfl_xor(ms, d, WAVE));
+    sum += __shfl_xor(sum, d, WAVE);
   }
   if ((threadIdx.x & (WAVE - 1)) == 0) {
     sh[0][threadIdx.x / WAVE] = mx;
     sh[1][threadIdx.x / WAVE] = ms;
+    sh[2][threadIdx.x / WAVE] = sum;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
+    mx = 0, ms = 0, sum = 0;
     for (int i = 0; i < 1024 / WAVE; ++i) {
       mx = max(mx, sh[0][i]);
       ms = max(ms, sh[1][i]);
+      sum += sh[2][i];
     }
     hdr->max_count = (unsigned)mx;
     hdr->max_block_hits = (unsigned)ms;
+    hdr->slow_sum = sum;
     if (mail) {
       mail[0] = mx;
       mail[1] = ms;
       mail[2] = hdr->total_cells;
       mail[3] = hdr->total_sup;
-      mail_post(mail + 4, stamp);
+      mail[4] = sum;
+      mail_post(mail + 5, stamp);
     }
   }
 }
@@ -1585,21 +1596,22 @@ __global__ void pad_fill_kernel(int64_t* __restrict__ out, int64_t n, int64_t v)
 // Reduces the per-block statistics into the header and brings the header to the host: through the mailbox page (the
 // kernel posts it, the host polls -- no copy in the stream, no stream synchronise), else by a copy into pinned memory and a
 // synchronise.  Everything queued on `stream` before is complete when this returns.
-inline int reduce_and_read(const RadiusWs& w, int blocks, hipStream_t stream, RadiusHdr* h_out) {
+inline int reduce_and_read(const RadiusWs& w, int blocks, hipStream_t stream, RadiusHdr* h_out, bool tq = false) {
   volatile int32_t* mail = mailbox();
   if (mail) mail += MAIL_RADIUS;
   const int stamp = mail ? mailbox_next_stamp() : 0;
-  if (mail) mailbox_arm(mail + 4);
+  if (mail) mailbox_arm(mail + 5);
   hipLaunchKernelGGL(reduce_stats_kernel, dim3(1), dim3(1024), 0, stream, w.blk_stats, blocks, w.hdr,
-                     const_cast<int32_t*>(mail), stamp);
+                     const_cast<int32_t*>(mail), stamp, tq ? 1 : 0);
   GR_LAUNCH_CHECK();
   if (mail) {
-    int rc = mailbox_wait(mail + 4, stamp, stream, "radius search");
+    int rc = mailbox_wait(mail + 5, stamp, stream, "radius search");
     if (rc != GR_OK) return rc;
     h_out->max_count = (unsigned)mail[0];
     h_out->max_block_hits = (unsigned)mail[1];
     h_out->total_cells = mail[2];
     h_out->total_sup = mail[3];
+    h_out->slow_sum = mail[4];
     return GR_OK;
   }
   RadiusHdr* h_pinned = static_cast<RadiusHdr*>(pinned_scratch(3, sizeof(RadiusHdr)));
@@ -1708,7 +1720,7 @@ int launch_tq(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns,
     else TQ_GO(32);
 #undef TQ_GO
   }
-  return reduce_and_read(w, blocks, stream, h_out);
+  return reduce_and_read(w, blocks, stream, h_out, true);
 }
 
 int launch_tq_expand(const RadiusWs& w, int64_t nq, int64_t ns, int64_t width, int64_t* out, hipStream_t stream) {
@@ -1967,7 +1979,8 @@ extern "C" int gr_radius_count_cached(const float* q, const float* s, const int6
     rc = launch_tq(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, 0, nullptr, same, stream, &h, net);
     if (rc != GR_OK) return rc;
     const bool done = h.max_block_hits == 0 && h.max_count <= (unsigned)TQ_ROW_CAP;
-    if (mode == 3) tq_report(radius, -1, net, !done);
+    // (a finished call most of whose waves needed the exact path is reported too: the next call of the site starts higher)
+    if (mode == 3) tq_report(radius, -1, net, !done || (int64_t)h.slow_sum * 8 > nq);
     if (done) {
       h_info[0] = h.max_count;
       h_info[1] = -1;  // the tiles are in the workspace
@@ -2046,7 +2059,7 @@ extern "C" int gr_radius_search(const float* q, const float* s, const int64_t* h
     rc = tq ? launch_tq(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, out, P.same, stream, &hf, net)
             : launch_fused(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, limit, out, P.same, stream, &hf);
     if (rc != GR_OK) return rc;
-    if (tq && mode == 3) tq_report(radius, limit, net, hf.max_block_hits != 0);
+    if (tq && mode == 3) tq_report(radius, limit, net, hf.max_block_hits != 0 || (int64_t)hf.slow_sum * 8 > nq);
     h_info[0] = hf.max_count;
     h_info[2] = P.same ? 1 : 0;
     h_info[3] = hf.total_cells;

@@ -21,8 +21,9 @@
 //   * rows: transposed through LDS in blocks of 16 columns and written as 128-byte pieces.  DIRECT: int64 rows of the
 //     caller's width in the caller's order; otherwise compact u32 rows in cell order, which tq_expand_kernel turns into
 //     int64 rows once the host knows the width (the bare radius_neighbors, whose width is the largest count).
-// A workgroup that cannot finish raises its flag (2: a single range beyond 12 bits, 3 / 4: too many wave-finished queries,
-// 5: a query with more hits than the key scratch) and the caller repeats the call on count + fill.
+// A workgroup that cannot finish raises its flag (2: a single range beyond 12 bits, 5: a query with more hits than the key
+// scratch) and the caller repeats the call on count + fill.  The number of wave-finished queries is reported: a call in
+// which they are more than an eighth of all queries is complete, but its call site starts on the next kernel next time.
 #pragma once
 #include <type_traits>
 
@@ -30,7 +31,6 @@ constexpr int TQ_ROW_CAP = 64;    // the widest row the expand kernel can delive
 constexpr int TQ_ROW_HALF = 32;   // (first halves dense in one array -- 128 bytes per query; second halves, only written for
                                   // wave-finished queries, in another)
 constexpr int TQ_BKEYS = 192;     // hits of a wave-finished query
-constexpr int TQ_BIG_MAX = 20;    // wave-finished queries per workgroup before it gives up
 constexpr int TQ_EXT_MAX = 4095;  // band extent of a wave (offsets are 12 bits)
 
 template <int N>
@@ -255,9 +255,6 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
   }
   TQ_STOP(2, n)
   const bool big = n > NET;
-  // a wave most of whose queries need the exact way is not what this kernel is for: give up before the sort (the caller
-  // repeats the call on count + fill and remembers the shape)
-  if (__popcll(__ballot(big)) > TQ_BIG_MAX) blk_flag = 3;
   const int m = min(n, NET);
   const int wmax_u = __builtin_amdgcn_readfirstlane(wave_max_i32_dpp(m));
   // ---- keys: list entries -> one word per hit; slots past the hit count hold pad words (distinct distance fields above
@@ -309,7 +306,7 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
   TQ_STOP(4, (int)(key[0] ^ key[13] ^ key[31]) + (tie ? 1 : 0))
   // ---- rows of the queries the network finished
   const bool slow = valid && !blk_flag && (big || tie);
-  int hmax = 0;
+  int hmax = 0, nslow = 0;
   if (!blk_flag) {
     // sorted list slots -> support indices (in the key registers); then idx32 is dead and the rows are transposed
     // through LDS in blocks of 16 columns (a thread storing its own row is 64 rows per store instruction: measured
@@ -414,10 +411,7 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
     }
     // ---- wave-finished queries, one after the other: lanes = candidates, hits compacted by ballot, ranked by counting
     unsigned long long slowm = __ballot(slow);
-    if (__popcll(slowm) > TQ_BIG_MAX) {
-      blk_flag = 4;
-      slowm = 0ull;
-    }
+    nslow = __popcll(slowm);  // (reported: a call with many of these tells the caller to start the site on another kernel)
     while (slowm) {
       const int sl = __ffsll((long long)slowm) - 1;
       slowm &= slowm - 1ull;
@@ -497,7 +491,7 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
   const int nmax = __builtin_amdgcn_readfirstlane(wave_max_i32_dpp(slow ? 0 : n));
   if (lane == 0) {
     blk_stats[2 * blk] = max(nmax, hmax);
-    blk_stats[2 * blk + 1] = blk_flag;
+    blk_stats[2 * blk + 1] = blk_flag | (nslow << 8);
   }
 }
 

@@ -86,12 +86,12 @@ int gr_radius_fill(const float* q, const float* s, int64_t nq, int64_t ns, int64
  *   h_info[4] = 1 if ONE kernel produced `out` (modes 1 - 4 below), 0 if count + fill did.
  * Modes (gr_radius_search_mode; returns the previous mode; a negative argument only queries; GR_RADIUS_SINGLE_PASS=<mode>
  * sets the process default).  Every mode returns the same rows; gr_radius_count / gr_radius_fill follow the mode too:
- *   3  (default) per (radius, limit) call site the library picks one of the kernels below and remembers a give-up: the
- *      thread-per-query kernel with its 32-hit network -> the same with its 64-hit network -> count + fill, stepping back
- *      one level every 256 calls;
+ *   3  (default) per (radius, limit) call site the library picks one of the kernels below and remembers a give-up, or a
+ *      call in which more than an eighth of the queries went beyond the network: the thread-per-query kernel with its
+ *      32-hit network -> the same with its 64-hit network -> count + fill, stepping back one level every 256 calls;
  *   2 / 4  always try the thread-per-query kernel first, 32- / 64-hit network (csrc/radius_tq.hpp: one wave = 64
- *      cell-ordered queries, candidates through the vector L1, hits sorted in registers, rows through LDS); a wave with more
- *      than 20 queries beyond the network, or any query with more than 192 hits, hands the call back to count + fill;
+ *      cell-ordered queries, candidates through the vector L1, hits sorted in registers, rows through LDS); queries beyond
+ *      the network are finished exactly by their wave; a query with more than 192 hits hands the call back to count + fill;
  *   0  count, host, fill -- three threads per query, the rows allocated up front;
  *   1  the three-threads-per-query single pass (tests, LDS ranking, whole-row stores); falls back to count + fill when one
  *      query has more hits than a workgroup's key area or the limit is too wide for LDS.
