@@ -21,8 +21,8 @@
 //   * rows: transposed through LDS in blocks of 16 columns and written as 128-byte pieces.  DIRECT: int64 rows of the
 //     caller's width in the caller's order; otherwise compact u32 rows in cell order, which tq_expand_kernel turns into
 //     int64 rows once the host knows the width (the bare radius_neighbors, whose width is the largest count).
-// A workgroup that cannot finish raises its flag (2: a single range beyond 12 bits, 5: a query with more hits than the key
-// scratch) and the caller repeats the call on count + fill.  The number of wave-finished queries is reported: a call in
+// A workgroup that cannot finish raises its flag (2: a single range beyond 12 bits, 3: more than 40 of its 64 queries beyond
+// the network, 5: a query with more hits than the key scratch) and the caller repeats the call on count + fill.  The number of wave-finished queries is reported: a call in
 // which they are more than an eighth of all queries is complete, but its call site starts on the next kernel next time.
 #pragma once
 #include <type_traits>
@@ -31,6 +31,7 @@ constexpr int TQ_ROW_CAP = 64;    // the widest row the expand kernel can delive
 constexpr int TQ_ROW_HALF = 32;   // (first halves dense in one array -- 128 bytes per query; second halves, only written for
                                   // wave-finished queries, in another)
 constexpr int TQ_BKEYS = 192;     // hits of a wave-finished query
+constexpr int TQ_HOPELESS = 40;   // queries beyond the network in one wave at which the workgroup gives up instead
 constexpr int TQ_EXT_MAX = 4095;  // band extent of a wave (offsets are 12 bits)
 
 template <int N>
@@ -255,6 +256,9 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
   }
   TQ_STOP(2, n)
   const bool big = n > NET;
+  // a wave nearly all of whose queries are beyond the network is not what this kernel is for: give up before the sort (the
+  // caller repeats the call on the next kernel and remembers the site).  Fewer are finished here, one after the other.
+  if (__popcll(__ballot(big)) > TQ_HOPELESS) blk_flag = 3;
   const int m = min(n, NET);
   const int wmax_u = __builtin_amdgcn_readfirstlane(wave_max_i32_dpp(m));
   // ---- keys: list entries -> one word per hit; slots past the hit count hold pad words (distinct distance fields above
