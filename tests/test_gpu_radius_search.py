@@ -190,3 +190,26 @@ def test_call_site_width_hint_narrow_rows_and_the_repeat_at_full_limit():
         got = ext.radius_neighbors_limited(t, t, torch.from_numpy(lens), torch.from_numpy(lens), radius, limit)
         assert got.is_contiguous() and got.shape == want.shape and np.array_equal(got.cpu().numpy(), want)
         assert ext._WIDTH_HINT[(float(radius), limit)] == capi.radius_neighbors(pts, pts, lens, lens, radius).shape[1]
+
+
+def test_a_cell_with_more_points_than_a_12_bit_range_and_nan_queries():
+    """5 000 supports inside one cell: a thread's candidate range there is longer than the 12-bit offsets of the
+    thread-per-query kernel's hit codes (give-up code 2: the call repeats itself on count + fill), every cluster query has
+    thousands of neighbours; queries with NaN / infinite coordinates have none.  Same rows as the oracle in every mode."""
+    from gaussreg_amd import ext
+    from oracle import capi
+    rng = np.random.default_rng(17)
+    cluster = (0.5 + rng.random((5000, 3)) * 1e-3).astype(np.float32)
+    spread = rng.random((3000, 3)).astype(np.float32)
+    s = np.concatenate([cluster, spread])[rng.permutation(8000)]
+    q = np.concatenate([cluster[:40], spread[:300], rng.random((200, 3)).astype(np.float32)])
+    q[5] = np.nan
+    q[50, 1] = np.inf
+    q[400, 2] = -np.inf
+    ql, sl = np.array([q.shape[0]], np.int64), np.array([8000], np.int64)
+    want = capi.radius_neighbors(q, s, ql, sl, 0.05)
+    assert want.shape[1] >= 5000
+    for limit in (16, 70):
+        got = ext.radius_neighbors_limited(_t(q), _t(s), torch.from_numpy(ql), torch.from_numpy(sl), 0.05, limit)
+        assert np.array_equal(got.cpu().numpy(), want[:, :limit])
+        assert bool((got[5] == 8000).all()) and bool((got[50] == 8000).all()) and bool((got[400] == 8000).all())
