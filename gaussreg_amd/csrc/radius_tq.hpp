@@ -73,7 +73,8 @@ struct TqLds {
   struct Search {
     unsigned short lists[LIST_ROWS * WAVE];
     unsigned short trng[2 * (NBAND + 1) * WAVE];  // the threads' non-empty ranges (start code, end code) + an empty one
-    char idx_room[NET * WAVE * 4 > (LIST_ROWS + 2 * (NBAND + 1)) * WAVE * 2 ? NET * WAVE * 4 - (LIST_ROWS + 2 * (NBAND + 1)) * WAVE * 2 : 1];
+    // (NET = 64 keeps no idx32: 16 KB per wave would leave 8 waves per CU; its indices are gathered again after the sort)
+    char idx_room[(NET <= 32 && NET * WAVE * 4 > (LIST_ROWS + 2 * (NBAND + 1)) * WAVE * 2) ? NET * WAVE * 4 - (LIST_ROWS + 2 * (NBAND + 1)) * WAVE * 2 : 1];
   };  // (after the tests the same bytes hold idx32[NET][64]: the support index of every list slot)
   struct Rows {  // once the sorted indices are in registers the lists are dead: rows are transposed here
     unsigned int rowbuf[WAVE * RS];
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
         const float d = (dx * dx + dy * dy) + dz * dz;  // same arithmetic as the test: same bits
         const unsigned fix = min(__float2uint_rz(d * scale), FIX_MAX);
         key[s8 + u] = s8 + u < m ? (fix << SB) | (unsigned)(s8 + u) : ((((1u << FB) - (unsigned)NET + (unsigned)(s8 + u)) << SB) | (unsigned)(s8 + u));
-        idx32[(s8 + u) * WAVE + lane] = __float_as_uint(sp[u].w);
+        if (NET <= 32) idx32[(s8 + u) * WAVE + lane] = __float_as_uint(sp[u].w);
       }
     } else {
 #pragma unroll
@@ -317,7 +318,14 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
     // 0.17 ms for 8 x 200 k x 40)
 #pragma unroll
     for (int i = 0; i < NET; ++i)
-      if (i < wmax_u) key[i] = idx32[(int)(key[i] & (unsigned)(NET - 1)) * WAVE + lane];  // (uniform guard)
+      if (i < wmax_u) {  // (uniform guard)
+        if (NET <= 32) {
+          key[i] = idx32[(int)(key[i] & (unsigned)(NET - 1)) * WAVE + lane];
+        } else {
+          const int c = (int)lists[(int)(key[i] & (unsigned)(NET - 1)) * WAVE + lane];
+          key[i] = __float_as_uint(sorted_s[i < m ? lbase[min(c >> 12, NBAND - 1) * WAVE + lane] + c : 0].w);
+        }
+      }
     TQ_STOP(5, (int)(key[0] ^ key[13] ^ key[31]))
     __syncthreads();
     lds.r.qinfo[lane] = make_int2(orig, (valid && !slow) ? m : -1);
