@@ -1711,11 +1711,11 @@ int launch_tq(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns,
   if (out)                                                                                                                  \
     hipLaunchKernelGGL((tq_kernel<NET, true>), dim3(grid), dim3(WAVE), 0, stream, sorted_q, (int)nq, w.q_off, nb, w.grids,   \
                        start_s, w.sorted_s, w.plane_x, w.plane_y, w.plane_z, (int)ns, r2, w.blk_stats, (int)width, ns, out, \
-                       (uint32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (size_t)0, mono ? 1 : 0, stop);            \
+                       (uint32_t*)nullptr, (int32_t*)nullptr, (size_t)0, mono ? 1 : 0, stop);            \
   else                                                                                                                      \
     hipLaunchKernelGGL((tq_kernel<NET, false>), dim3(grid), dim3(WAVE), 0, stream, sorted_q, (int)nq, w.q_off, nb, w.grids,  \
                        start_s, w.sorted_s, w.plane_x, w.plane_y, w.plane_z, (int)ns, r2, w.blk_stats, 0, ns,               \
-                       (int64_t*)nullptr, w.tiles, w.q_count, w.q_count + nq, rows_hi, mono ? 1 : 0, 0)
+                       (int64_t*)nullptr, w.tiles, w.q_count, rows_hi, mono ? 1 : 0, 0)
     if (net == 64) TQ_GO(64);
     else TQ_GO(32);
 #undef TQ_GO
@@ -1725,7 +1725,7 @@ int launch_tq(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns,
 
 int launch_tq_expand(const RadiusWs& w, int64_t nq, int64_t ns, int64_t width, int64_t* out, hipStream_t stream) {
   KernelTimer timer("radius_expand", stream);
-  hipLaunchKernelGGL(tq_expand_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(256), 0, stream, w.tiles, w.q_count, w.q_count + nq,
+  hipLaunchKernelGGL(tq_expand_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(256), 0, stream, w.tiles, w.q_count,
                      (size_t)((nq + 63) / 64) * 64 * 32, (int)nq, (int)width, ns, out);
   GR_LAUNCH_CHECK();
   return GR_OK;

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
     const BatchGrid* __restrict__ grids, const int32_t* __restrict__ start_s, const float4* __restrict__ sorted_s,
     const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz, int ns_total, float r2,
     int32_t* __restrict__ blk_stats, int width, int64_t pad_value, int64_t* __restrict__ out, uint32_t* __restrict__ rows32,
-    int32_t* __restrict__ q_cnt, int32_t* __restrict__ q_pos, size_t rows_hi, int mono, int stop) {
+    int32_t* __restrict__ q_cnt, size_t rows_hi, int mono, int stop) {
 #define TQ_STOP(K, V) if (stop == (K)) { if ((V) == 0x7fffffff) blk_stats[0] = 1; return; }
   using L = TqLds<NET, DIRECT>;
   constexpr int SB = NET == 64 ? 6 : (NET == 32 ? 5 : 4);        // slot bits of a sort word
@@ -393,13 +393,11 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
       }
       __syncthreads();
     } else {
-      // compact rows: u32, TQ_ROW_CAP per query, in CELL order (this wave's 64 rows are one contiguous 16 KB piece: plain
-      // sequential traffic); the count and the query's place in that order go with them -- tq_expand_kernel walks the
-      // ORIGINAL order and fetches each row from here.  Four lanes write the 64 bytes a row has in the block.
-      if (valid && !slow) q_cnt[t] = n;  // (a wave-finished query's count is written below)
-      if (valid) q_pos[orig] = t;
+      // compact rows: u32, two halves of TQ_ROW_HALF per query, in the caller's (ORIGINAL) order -- the scatter happens here,
+      // as whole 64-byte sectors (four lanes write the 64 bytes a row has in the block), so that tq_expand_kernel is two
+      // sequential streams; the counts go with them.
+      if (valid && !slow) q_cnt[orig] = n;  // (a wave-finished query's count is written below)
       static_assert(NET <= TQ_ROW_CAP, "the network's rows fit the two halves");
-      uint32_t* base = rows32 + (size_t)blk * (WAVE * TQ_ROW_HALF);
 #pragma unroll
       for (int cb = 0; cb < NET; cb += L::RB) {
         if (cb < wmax_u) {  // (uniform) entries past a query's own count are never read
@@ -414,8 +412,10 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
             v.y = lds.r.rowbuf[r * L::RS + ci + 1];
             v.z = lds.r.rowbuf[r * L::RS + ci + 2];
             v.w = lds.r.rowbuf[r * L::RS + ci + 3];
-            if (lds.r.qinfo[r].y >= 0)
-              *reinterpret_cast<uint4*>(base + (cb < TQ_ROW_HALF ? (size_t)0 : rows_hi) + r * TQ_ROW_HALF + (cb & (TQ_ROW_HALF - 1)) + ci) = v;
+            const int2 qi = lds.r.qinfo[r];
+            if (qi.y >= 0)
+              *reinterpret_cast<uint4*>(rows32 + (cb < TQ_ROW_HALF ? (size_t)0 : rows_hi) + (size_t)qi.x * TQ_ROW_HALF +
+                                        (cb & (TQ_ROW_HALF - 1)) + ci) = v;
           }
           __syncthreads();
         }
@@ -488,14 +488,14 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
           if (rank < width) out[(int64_t)borig * width + rank] = (int64_t)(unsigned int)(ke & 0xffffffffull);
         } else {
           if (rank < TQ_ROW_CAP)
-            rows32[(rank < TQ_ROW_HALF ? (size_t)0 : rows_hi) + ((size_t)blk * WAVE + sl) * TQ_ROW_HALF + (rank & (TQ_ROW_HALF - 1))] =
+            rows32[(rank < TQ_ROW_HALF ? (size_t)0 : rows_hi) + (size_t)borig * TQ_ROW_HALF + (rank & (TQ_ROW_HALF - 1))] =
                 (uint32_t)(ke & 0xffffffffull);
         }
       }
       if (DIRECT) {
         for (int c = h + lane; c < width; c += WAVE) out[(int64_t)borig * width + c] = pad_value;
       } else if (lane == 0) {
-        q_cnt[blk * WAVE + sl] = h;
+        q_cnt[borig] = h;
       }
       __syncthreads();
     }
@@ -508,23 +508,23 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
 }
 
 // Compact rows -> int64 rows of the final width (the bare radius_neighbors: the width is the largest count, known to the
-// host between the two launches).  A plain gather-copy in the ORIGINAL row order: thread = (row, group of four columns);
-// the writes are one sequential stream (every 64-byte sector whole, whatever the width -- scattering finished rows from the
-// cell order instead measured 0.27 - 0.45 ms for 589 MB), the reads are 16-byte pieces of 256-byte compact rows.
+// host between the two launches).  Both sides are in the caller's row order (tq_kernel scatters its compact rows there as
+// whole sectors), so this is a widening copy of two sequential streams: thread = (row, group of four columns).
+// (Compact rows in cell order + a gather here measured 0.22 ms for 205 + 589 MB, this form 0.18 - 0.20 ms.)
 __global__ __launch_bounds__(256) void tq_expand_kernel(const uint32_t* __restrict__ rows32, const int32_t* __restrict__ q_cnt,
-                                                        const int32_t* __restrict__ q_pos, size_t rows_hi, int nq, int width,
+                                                        size_t rows_hi, int nq, int width,
                                                         int64_t pad_value, int64_t* __restrict__ out) {
   const int groups = (width + 3) >> 2;
   const unsigned magic = 0xffffffffu / (unsigned)groups + 1u;  // (e / groups for e < 2^16 only: rows are split per block)
   // a block owns 256 / groups whole rows... keep it simple: 64 rows per block, threads loop over (row, group)
   const int row0 = blockIdx.x * 64;
-  __shared__ int2 info[64];  // (place in the cell order, count)
+  __shared__ int2 info[64];  // (row, count)
   if (threadIdx.x < 64) {
     const int o = row0 + threadIdx.x;
     int2 v = make_int2(0, 0);
     if (o < nq) {
-      v.x = q_pos[o];
-      v.y = min(q_cnt[v.x], width);
+      v.x = o;
+      v.y = min(q_cnt[o], width);
     }
     info[threadIdx.x] = v;
   }
