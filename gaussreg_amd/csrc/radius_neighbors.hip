@@ -1716,7 +1716,11 @@ int launch_tq(const RadiusWs& w, const float4* sorted_q, int64_t nq, int64_t ns,
     hipLaunchKernelGGL((tq_kernel<NET, false>), dim3(grid), dim3(WAVE), 0, stream, sorted_q, (int)nq, w.q_off, nb, w.grids,  \
                        start_s, w.sorted_s, w.plane_x, w.plane_y, w.plane_z, (int)ns, r2, w.blk_stats, 0, ns,               \
                        (int64_t*)nullptr, w.tiles, w.q_count, rows_hi, mono ? 1 : 0, 0)
-    if (net == 64) TQ_GO(64);
+    if (net == 65 && out)  // the 64-hit network behind a pre-selection of the `width` nearest hits (radius_tq.hpp, PRESEL)
+      hipLaunchKernelGGL((tq_kernel<64, true, true>), dim3(grid), dim3(WAVE), 0, stream, sorted_q, (int)nq, w.q_off, nb, w.grids,
+                         start_s, w.sorted_s, w.plane_x, w.plane_y, w.plane_z, (int)ns, r2, w.blk_stats, (int)width, ns, out,
+                         (uint32_t*)nullptr, (int32_t*)nullptr, (size_t)0, mono ? 1 : 0, stop);
+    else if (net >= 64) TQ_GO(64);
     else TQ_GO(32);
 #undef TQ_GO
   }
@@ -1884,13 +1888,14 @@ int radius_prepare(const float* q, const float* s, const int64_t* h_q_lengths, c
 namespace gr {
 namespace {
 // 0 = count, host, fill; 1 = the single-pass kernel (three threads per query); 2 = one thread per query (radius_tq.hpp),
-// always tried first (32-hit network); 3 (default) = the kernel tq_choice picks for the call site (32-hit network, 64-hit network
-// or count + fill); 4 = the 64-hit network always tried first.
+// always tried first (32-hit network); 3 (default) = the kernel tq_choice picks for the call site (32-hit network, 64-hit network,
+// 64-hit network behind the pre-selection, or count + fill); 4 = the 64-hit network always tried first; 5 = the same behind
+// the pre-selection (limited searches; the bare search has no width to select for and takes the plain 64-hit network).
 // Initialised from GR_RADIUS_SINGLE_PASS.
 std::atomic<int>& search_mode() {
   static std::atomic<int> mode{[] {
     const char* a = getenv("GR_RADIUS_SINGLE_PASS");
-    return (a && a[0] >= '0' && a[0] <= '4') ? a[0] - '0' : 3;
+    return (a && a[0] >= '0' && a[0] <= '5') ? a[0] - '0' : 3;
   }()};
   return mode;
 }
@@ -1903,12 +1908,14 @@ namespace {
 // the big levels of the data pyramid, 4 - 14 hits on average; NET = 64: its middle levels, ~30); where most queries of a
 // wave have more, the kernel gives up after its tests and the call is repeated on count + fill.  A caller repeats the same
 // (radius, limit) call site over and over (13 per pair in the pyramid), so a give-up is remembered per (radius bits,
-// limit): the site moves 32 -> 64 -> count + fill, and steps back down one level every TQ_RETRY_AFTER calls.
+// limit): the site moves 32 -> 64 -> 64 behind the pre-selection (rows of a known width <= TQ_PRESEL_MAX: the coarsest levels,
+// where a query has ~150 hits and keeps 49) -> count + fill, and steps back down one level every TQ_RETRY_AFTER calls.
 constexpr int TQ_MEMO = 64, TQ_RETRY_AFTER = 256;
+constexpr int64_t TQ_PRESEL_MAX = 56;  // the selection needs a bin boundary between `width` and 64 hits
 struct TqMemo {
   uint32_t rbits;
   int64_t limit;
-  int level;  // 0: the 32-hit network, 1: the 64-hit network, 2: count + fill
+  int level;  // 0: the 32-hit network, 1: the 64-hit network, 2: the 64-hit network behind the pre-selection, 3: count + fill
   int calls;  // calls at this level since it last changed (a site at level > 0 steps back down every TQ_RETRY_AFTER calls)
   bool used;
 };
@@ -1921,7 +1928,10 @@ TqMemo* tq_find(uint32_t rb, int64_t limit) {
   return nullptr;
 }
 
-// which kernel this call site gets: 32 / 64 = the thread-per-query kernel with that network, 0 = count + fill
+inline bool tq_presel_ok(int64_t limit) { return limit >= 1 && limit <= TQ_PRESEL_MAX; }
+
+// which kernel this call site gets: 32 / 64 = the thread-per-query kernel with that network, 65 = the 64-hit network behind the
+// pre-selection, 0 = count + fill
 int tq_choice(float radius, int64_t limit) {
   uint32_t rb;
   memcpy(&rb, &radius, 4);
@@ -1929,10 +1939,10 @@ int tq_choice(float radius, int64_t limit) {
   TqMemo* e = tq_find(rb, limit);
   if (!e) return 32;
   if (e->level > 0 && ++e->calls > TQ_RETRY_AFTER) {
-    e->level -= 1;
+    e->level -= (e->level == 3 && !tq_presel_ok(limit)) ? 2 : 1;
     e->calls = 0;
   }
-  return e->level == 0 ? 32 : (e->level == 1 ? 64 : 0);
+  return e->level == 0 ? 32 : (e->level == 1 ? 64 : (e->level == 2 ? 65 : 0));
 }
 
 void tq_report(float radius, int64_t limit, int net, bool gave_up) {
@@ -1951,7 +1961,7 @@ void tq_report(float radius, int64_t limit, int net, bool gave_up) {
     e->limit = limit;
     e->level = 0;
   }
-  e->level = net == 32 ? 1 : 2;
+  e->level = net == 32 ? 1 : (net == 64 && tq_presel_ok(limit) ? 2 : 3);
   e->calls = 0;
 }
 }  // namespace
@@ -1973,7 +1983,7 @@ extern "C" int gr_radius_count_cached(const float* q, const float* s, const int6
   const bool same = P.same;
   RadiusHdr h;
   const int mode = search_mode().load();
-  const int net = mode == 2 ? 32 : (mode == 4 ? 64 : (mode == 3 && ns < (1ll << 29) ? tq_choice(radius, -1) : 0));
+  const int net = mode == 2 ? 32 : (mode == 4 || mode == 5 ? 64 : (mode == 3 && ns < (1ll << 29) ? tq_choice(radius, -1) : 0));
   if (net != 0 && ns < (1ll << 29)) {
     // one thread per query: the whole search now (sorted compact rows), gr_radius_fill only widens them
     rc = launch_tq(w, P.sorted_q, nq, ns, P.nb, P.start_s, P.r2, 0, nullptr, same, stream, &h, net);
@@ -2029,7 +2039,7 @@ extern "C" int gr_radius_fill(const float* q, const float* s, int64_t nq, int64_
 
 extern "C" int gr_radius_search_mode(int mode) {
   const int old = search_mode().load();
-  if (mode >= 0 && mode <= 4) search_mode().store(mode);
+  if (mode >= 0 && mode <= 5) search_mode().store(mode);
   return old;
 }
 
@@ -2051,7 +2061,7 @@ extern "C" int gr_radius_search(const float* q, const float* s, const int64_t* h
   // GR_RADIUS_SINGLE_PASS=1 selects the single-pass kernel (fused_kernel above).  It is not the default: on 8 x 200 k points it
   // runs as long as count + fill together (both are bound by VALU issue: ~3 000 instructions per wave either way)
   const int mode = search_mode().load();
-  const int net = ns >= (1ll << 29) ? 0 : (mode == 2 ? 32 : (mode == 4 ? 64 : (mode == 3 ? tq_choice(radius, limit) : 0)));
+  const int net = ns >= (1ll << 29) ? 0 : (mode == 2 ? 32 : (mode == 4 ? 64 : (mode == 5 ? 65 : (mode == 3 ? tq_choice(radius, limit) : 0))));
   const bool tq = net != 0;
   const bool fused = (mode == 1 && fused_fits(limit)) || tq;
   if (fused) {

@@ -90,7 +90,7 @@ struct TqLds {
 };
 static_assert(sizeof(TqLds<32, true>) <= 11 * 1024 && sizeof(TqLds<64, true>) <= 19 * 1024, "tq kernel: LDS per wave");
 
-template <int NET, bool DIRECT>
+template <int NET, bool DIRECT, bool PRESEL = false>
 __global__ __launch_bounds__(WAVE) void tq_kernel(
     const float4* __restrict__ sorted_q, int nq, const int32_t* __restrict__ q_off, int nb,
     const BatchGrid* __restrict__ grids, const int32_t* __restrict__ start_s, const float4* __restrict__ sorted_s,
@@ -102,6 +102,7 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
   constexpr int SB = NET == 64 ? 6 : (NET == 32 ? 5 : 4);        // slot bits of a sort word
   constexpr int FB = 32 - SB;                                     // distance field
   constexpr unsigned FIX_MAX = (1u << FB) - 1u - (unsigned)NET;   // real hits stay below the pad words
+  static_assert(!PRESEL || (DIRECT && NET == 64), "the pre-selection is built for rows of a known width on the 64-hit network");
   __shared__ __attribute__((aligned(16))) L lds;
   unsigned short* lists = lds.s.lists;
   unsigned short* trng = lds.s.trng;
@@ -190,7 +191,21 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
   // (a wave's LDS operations are served in order: the reads below see these writes)
   const unsigned r2b = r2 == r2 ? __float_as_uint(r2) : 0u;  // NaN radius: nothing is a neighbour
   int n = 0;
+  const float scale = (float)(1u << FB) / r2;  // distance -> fixed point (the sort words; PRESEL: the histogram bins)
+  // PRESEL (rows truncated to `width` <= 56 where most queries have MORE than NET hits: the coarsest pyramid levels, ~150 hits
+  // of ~770 candidates): the tests run twice.  Pass 1 counts the hits and drops each into a 64-bin histogram of its
+  // fixed-point distance (one fire-and-forget ds_add_u32 per candidate on the thread's own column, two 16-bit bins per
+  // word, in the lists' place); the thread then walks its bins to the first one at which the running count reaches `width`
+  // and pass 2 lists only the hits up to and including that bin -- at least `width`, nearly always at most NET of them, and
+  // every hit left out is farther than every hit kept (the bins are a monotone function of the fp32 distance, equal
+  // distances share a bin).  From there on the query is an ordinary one; a crowded last bin (more than NET kept) or an equal
+  // pair sends it to the wave's exact path, restricted to the same bins.
+  int ntrue = 0;          // PRESEL: all hits of the query (what the reference would count)
+  float fcut = INFINITY;  // PRESEL: a hit is listed iff d * scale < fcut
   if (!blk_flag) {
+  auto scan = [&](auto pass_tag) {
+    constexpr int PASS = decltype(pass_tag)::value;  // 0: list every hit; 1: count + histogram; 2: list the hits below fcut
+    unsigned int* hist = reinterpret_cast<unsigned int*>(lists);
     // ---- tests: one flattened loop over the thread's ranges, four candidates per step, the planes of step i + 1 requested
     //      before step i is evaluated.  A hit appends its code to the thread's list (slot-major: entry i of lane l at
     //      [i][l]); the code is written to slot n UNCONDITIONALLY and n moves on only for a hit -- no branch per candidate
@@ -235,10 +250,19 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
     const f32x2 da = (dxa * dxa + dya * dya) + dza * dza;                                                                \
     const f32x2 db = (dxb * dxb + dyb * dyb) + dzb * dzb;                                                                \
     const unsigned dbits[4] = {__float_as_uint(da.x), __float_as_uint(da.y), __float_as_uint(db.x), __float_as_uint(db.y)}; \
-    n = min(n, NET + 1);                                                                                                 \
+    const f32x2 fa = da * scale, fb = db * scale;                                                                        \
+    const float fd[4] = {fa.x, fa.y, fb.x, fb.y};                                                                        \
+    if (PASS != 1) n = min(n, NET + 1);                                                                                  \
     _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                      \
-      const bool h = u < left && dbits[u] < r2b; /* both are non-negative floats; NaN sorts above everything */         \
-      my[n * WAVE] = (unsigned short)(code + u);                                                                         \
+      bool h = u < left && dbits[u] < r2b; /* both are non-negative floats; NaN sorts above everything */               \
+      if (PASS == 2) h = h && fd[u] < fcut;                                                                              \
+      if (PASS == 1) {                                                                                                   \
+        const unsigned fx = min(__float2uint_rz(fd[u]), FIX_MAX);                                                        \
+        __hip_atomic_fetch_add(&hist[(fx >> (FB - 5)) * WAVE + lane], h ? 1u << ((fx >> (FB - 10)) & 16u) : 0u,          \
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);                                          \
+      } else {                                                                                                           \
+        my[n * WAVE] = (unsigned short)(code + u);                                                                       \
+      }                                                                                                                  \
       n += h ? 1 : 0;                                                                                                    \
     }                                                                                                                    \
     code = c2, ecode = e2, badj = b2;                                                                                    \
@@ -254,6 +278,33 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
     }
 #undef TQ_STEP
 #undef TQ_LOAD
+  };
+    if (PRESEL) {
+      unsigned int* hist = reinterpret_cast<unsigned int*>(lists);
+#pragma unroll
+      for (int i = 0; i < 32; ++i) hist[i * WAVE + lane] = 0u;
+      scan(std::integral_constant<int, 1>{});
+      ntrue = n;
+      // first bin at which the running count reaches the row width (lanes with <= NET hits list everything)
+      const int need = min(width, NET);
+      int cum = 0, bsel = 64;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        const unsigned v = hist[i * WAVE + lane];
+        cum += (int)(v & 0xffffu);
+        bsel = (bsel == 64 && cum >= need) ? 2 * i : bsel;
+        cum += (int)(v >> 16);
+        bsel = (bsel == 64 && cum >= need) ? 2 * i + 1 : bsel;
+      }
+      // (bin 63 holds the clamped fixed-point values: keeping it means keeping everything; rows wider than the network
+      // keep everything too -- such a query is finished by the wave as in the plain kernel)
+      fcut = (ntrue > NET && width <= NET && bsel < 63) ? (float)((unsigned)(bsel + 1) << (FB - 6)) : INFINITY;
+      n = 0;
+      scan(std::integral_constant<int, 2>{});
+    } else {
+      scan(std::integral_constant<int, 0>{});
+      ntrue = n;
+    }
   }
   TQ_STOP(2, n)
   const bool big = n > NET;
@@ -265,7 +316,6 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
   // ---- keys: list entries -> one word per hit; slots past the hit count hold pad words (distinct distance fields above
   //      every real one, so pads never look like ties)
   unsigned key[NET];
-  const float scale = (float)(1u << FB) / r2;
   // The support index of slot s goes to LDS as idx32[s][lane], IN PLACE over the lists: row s of the u16 lists is bytes
   // [128 s, 128 s + 128), idx32 row s is bytes [256 s, 256 s + 256) -- walking the slots downwards, a group's idx rows only
   // cover list rows that this or an earlier group has already read.
@@ -431,6 +481,8 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
       const float by = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qp.y), sl));
       const float bz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qp.z), sl));
       const int borig = __builtin_amdgcn_readlane(orig, sl);
+      const float bcut = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fcut), sl));  // (PRESEL; else +inf)
+      const int btrue = __builtin_amdgcn_readlane(ntrue, sl);
       int s0[NBAND], len[NBAND];
       int tot = 0;
 #pragma unroll
@@ -458,7 +510,7 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
         }
         const float dx = bx - px[p], dy = by - py[p], dz = bz - pz[p];
         const float d = (dx * dx + dy * dy) + dz * dz;
-        const bool hit = in && __float_as_uint(d) < r2b;
+        const bool hit = in && __float_as_uint(d) < r2b && (!PRESEL || d * scale < bcut);
         const unsigned long long hm = __ballot(hit);
         if (hit) {
           const int pos = h + __popcll(hm & ((1ull << lane) - 1ull));
@@ -470,7 +522,7 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
         blk_flag = 5;
         break;
       }
-      hmax = max(hmax, h);
+      hmax = max(hmax, PRESEL ? btrue : h);
       __syncthreads();
       for (int e = lane; e < h; e += WAVE) {
         const unsigned long long ke = lds.bkeys[e];
@@ -500,7 +552,7 @@ __global__ __launch_bounds__(WAVE) void tq_kernel(
       __syncthreads();
     }
   }
-  const int nmax = __builtin_amdgcn_readfirstlane(wave_max_i32_dpp(slow ? 0 : n));
+  const int nmax = __builtin_amdgcn_readfirstlane(wave_max_i32_dpp(slow ? 0 : ntrue));
   if (lane == 0) {
     blk_stats[2 * blk] = max(nmax, hmax);
     blk_stats[2 * blk + 1] = blk_flag | (nslow << 8);

@@ -191,7 +191,7 @@ def test_200k_properties():
     assert np.array_equal(sp.cpu().numpy().view(np.uint32), wp.view(np.uint32))
     # the radius_search(limit=40) wrapper, both search modes, against the truncated oracle rows
     from gaussreg_amd import _lib, ext as gext
-    for mode in (0, 1, 2, 3, 4):
+    for mode in (0, 1, 2, 3, 4, 5):
         old = _lib.lib().gr_radius_search_mode(mode)
         try:
             lim = gext.radius_neighbors_limited(d, d, lens, lens, r, 40)

@@ -14,7 +14,9 @@ def _t(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["count+fill", "single-pass", "thread-per-query", "adaptive", "thread-per-query-64"], autouse=True)
+@pytest.fixture(params=[0, 1, 2, 3, 4, 5],
+                ids=["count+fill", "single-pass", "thread-per-query", "adaptive", "thread-per-query-64", "thread-per-query-64-preselect"],
+                autouse=True)
 def search_mode(request):
     """Every test of this file runs in both modes of gr_radius_search (include/gaussreg_hip.h)."""
     from gaussreg_amd import _lib
@@ -159,7 +161,7 @@ def test_equal_distances_follow_the_index_order(limit):
     lattice = (np.stack(np.meshgrid(*[np.arange(9)] * 3, indexing="ij"), -1).reshape(-1, 3) * 0.125).astype(np.float32)
     s = np.concatenate([dup[rng.permutation(dup.shape[0])], lattice[rng.permutation(lattice.shape[0])]])
     sl = np.array([dup.shape[0], lattice.shape[0]], np.int64)
-    for radius in (0.13, 0.26):
+    for radius in (0.13, 0.26, 0.4):  # (0.4: ~120 hits at a dozen distinct distances -- whole bins of the pre-selection tie)
         want = capi.radius_neighbors(s, s, sl, sl, radius)[:, :limit]
         ts, tsl = _t(s), torch.from_numpy(sl)
         got = ext.radius_neighbors_limited(ts, ts, tsl, tsl, radius, limit)
@@ -213,3 +215,36 @@ def test_a_cell_with_more_points_than_a_12_bit_range_and_nan_queries():
         got = ext.radius_neighbors_limited(_t(q), _t(s), torch.from_numpy(ql), torch.from_numpy(sl), 0.05, limit)
         assert np.array_equal(got.cpu().numpy(), want[:, :limit])
         assert bool((got[5] == 8000).all()) and bool((got[50] == 8000).all()) and bool((got[400] == 8000).all())
+
+
+@pytest.mark.parametrize("limit", [1, 20, 49, 56, 60])
+def test_coarsest_level_shape_many_more_hits_than_the_row_keeps(search_mode, limit):
+    """The last level of the data pyramid: clouds of ~770 points, a radius that reaches a fifth of the cloud (~150 hits), rows
+    of 49.  The default mode moves such a call site to the pre-selecting kernel (mode 5 starts there): same rows as the
+    truncated oracle, the reported width is the true largest count, and the site memory ends up on a kernel that finishes."""
+    from gaussreg_amd import ext
+    from oracle import capi
+    rng = np.random.default_rng(17)
+    nb = 6
+    clouds, queries = [], []
+    for b in range(nb):  # points on the walls and the floor of a room: surfaces, as in a scan
+        n = 767 + 5 * b
+        u = rng.random((n, 3)).astype(np.float32) * np.array([2.6, 2.2, 1.8], np.float32)
+        face = rng.integers(0, 3, n)
+        u[np.arange(n), face] = 0.0
+        clouds.append(u + np.float32(b))
+        queries.append((clouds[-1][rng.integers(0, n, 3000)] + rng.normal(0, 0.05, (3000, 3))).astype(np.float32))
+    s, q = np.concatenate(clouds), np.concatenate(queries)
+    sl, ql = np.array([c.shape[0] for c in clouds], np.int64), np.array([3000] * nb, np.int64)
+    full = capi.radius_neighbors(q, s, ql, sl, 1.0)
+    counts = (full < s.shape[0]).sum(1)
+    assert counts.mean() > 100 and full.shape[1] > 200
+    tq, ts, tql, tsl = _t(q), _t(s), torch.from_numpy(ql), torch.from_numpy(sl)
+    for _ in range(3):  # (mode 3: the first calls walk the site up its kernels)
+        info, out = _info(tq, ts, ql.tolist(), sl.tolist(), 1.0, limit)
+        assert info[0] == full.shape[1]
+        assert np.array_equal(out.cpu().numpy(), full[:, :limit])
+    if search_mode == 5 and limit <= 56:
+        assert info[4] == 1  # finished by the thread-per-query kernel itself
+    got = ext.radius_neighbors_limited(ts, ts, tsl, tsl, 1.0, limit)
+    assert np.array_equal(got.cpu().numpy(), capi.radius_neighbors(s, s, sl, sl, 1.0)[:, :limit])
