@@ -83,19 +83,23 @@ int gr_radius_fill(const float* q, const float* s, int64_t nq, int64_t ns, int64
  * anything is counted (row stride = limit; columns past a query's hit count hold the padding value ns) and the host is
  * not needed between the kernels.  SYNCHRONISES `stream` once, at the end, to return
  *   h_info[0] = max_count (the reference's untruncated width): the result is out[:, :min(max_count, limit)];
- *   h_info[4] = 1 if ONE kernel produced `out` (modes 1 - 4 below), 0 if count + fill did.
+ *   h_info[4] = 1 if ONE kernel produced `out` (modes 1 - 5 below), 0 if count + fill did.
  * Modes (gr_radius_search_mode; returns the previous mode; a negative argument only queries; GR_RADIUS_SINGLE_PASS=<mode>
  * sets the process default).  Every mode returns the same rows; gr_radius_count / gr_radius_fill follow the mode too:
  *   3  (default) per (radius, limit) call site the library picks one of the kernels below and remembers a give-up, or a
  *      call in which more than an eighth of the queries went beyond the network: the thread-per-query kernel with its
- *      32-hit network -> the same with its 64-hit network -> count + fill, stepping back one level every 256 calls;
+ *      32-hit network -> the same with its 64-hit network -> the 64-hit network behind a pre-selection of the `limit`
+ *      nearest hits (limit <= 56: rows truncated far below the hit count, the coarsest pyramid levels) -> count + fill,
+ *      stepping back one level every 256 calls;
+ *   5  always try the pre-selecting kernel first (gr_radius_search only; gr_radius_count has no width to select for and
+ *      takes the plain 64-hit network);
  *   2 / 4  always try the thread-per-query kernel first, 32- / 64-hit network (csrc/radius_tq.hpp: one wave = 64
  *      cell-ordered queries, candidates through the vector L1, hits sorted in registers, rows through LDS); queries beyond
  *      the network are finished exactly by their wave; a query with more than 192 hits hands the call back to count + fill;
  *   0  count, host, fill -- three threads per query, the rows allocated up front;
  *   1  the three-threads-per-query single pass (tests, LDS ranking, whole-row stores); falls back to count + fill when one
  *      query has more hits than a workgroup's key area or the limit is too wide for LDS.
- * With modes 2 - 4 gr_radius_count does the whole search (compact u32 rows in the workspace, h_info[1] = -1) and
+ * With modes 2 - 5 gr_radius_count does the whole search (compact u32 rows in the workspace, h_info[1] = -1) and
  * gr_radius_fill only widens them to int64 rows of the final width.
  * h_support_sig / reuse_support as in gr_radius_count_cached (may be NULL / 0).  `ws`: gr_radius_workspace_bytes. */
 int gr_radius_search_mode(int mode);
