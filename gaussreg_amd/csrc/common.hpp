@@ -106,7 +106,7 @@ void* pinned_scratch(int slot, size_t bytes);
 // another) and clears its stamp word on the host before the launch that will post it (mailbox_arm).
 constexpr int MAIL_WORDS = 1024;
 constexpr int MAIL_GRID_BOXES = 0;     // grid_subsample: 6 B box words + stamp, B <= 80
-constexpr int MAIL_GRID_COUNTS = 512;  // grid_subsample: B + 1 counts, the bucket-overflow flag, the stamp
+constexpr int MAIL_GRID_COUNTS = 512;  // grid_subsample: B + 1 counts, the bucket-overflow flag, the stamp, B <= 256
 constexpr int MAIL_RADIUS = 1008;      // radius search: 5 header words + stamp
 volatile int32_t* mailbox();
 inline void mailbox_arm(volatile int32_t* stamp_word) { __atomic_store_n(stamp_word, 0, __ATOMIC_RELEASE); }
@@ -198,6 +198,8 @@ struct DepthSortSegments {
   int32_t* big_cnt;   // (set by depth_sort_views: the list the small-bucket launch leaves for the large-bucket one)
   int32_t* big_list;
   const uint64_t* gather64;  // non-null: key64_out[position] = gather64[the entry's index in the whole array] instead
+  int bins_used = 0;         // > 0: no segment's top digit reaches this value (small segments sorted on fewer than nine bits:
+                             // the scan and the bucket launch skip the digits above)
 };
 size_t depth_sort_table_bytes(int64_t P, int V);
 int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* keys_a, uint64_t* keys_b, int32_t* ids_out,

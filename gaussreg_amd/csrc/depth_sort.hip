@@ -155,7 +155,7 @@ constexpr int DS_SCAN_NW = 16;  // waves per scan workgroup
 __global__ __launch_bounds__(DS_SCAN_NW* WAVE) void ds_scan_kernel(int nchunk, const uint16_t* __restrict__ hist,
                                                                    uint32_t* __restrict__ offs,
                                                                    int32_t* __restrict__ digit_total,
-                                                                   int32_t* __restrict__ clear, int n_clear) {
+                                                                   int32_t* __restrict__ clear, int n_clear, int bins) {
   __shared__ unsigned int s_part[DS_SCAN_NW][WAVE];
   // (bucket path: the chunk totals the bucket launch adds into)
   if (clear != nullptr && blockIdx.x == 0)
@@ -163,6 +163,10 @@ __global__ __launch_bounds__(DS_SCAN_NW* WAVE) void ds_scan_kernel(int nchunk, c
   const int v = blockIdx.x / (DS_BINS / WAVE), dg = blockIdx.x % (DS_BINS / WAVE);
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   const int d = dg * WAVE + lane;
+  if (dg * WAVE >= bins) {  // (segments sorted on fewer bits: no key carries these digits; only their zero totals are read)
+    if (wv == 0) digit_total[v * DS_BINS + d] = 0;
+    return;
+  }
   const int per = (nchunk + DS_SCAN_NW - 1) / DS_SCAN_NW;
   const int c0 = wv * per, c1 = min(nchunk, c0 + per);
   const uint16_t* col = hist + (int64_t)v * nchunk * DS_BINS + d;
@@ -633,10 +637,11 @@ int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* 
     // bucket is not its size cost 22 us at 32 768 buckets)
     constexpr int SMALL_T = 128, SMALL_CAP = 1024;
     const bool two_sizes = segments != nullptr;
+    const int bins_used = (two_sizes && sg.bins_used > 0 && sg.bins_used < DS_BINS) ? sg.bins_used : DS_BINS;
     GR_REQUIRE(!(two_sizes && chunk_totals != nullptr), "depth_sort: chunk totals and segments together");
     if (two_sizes) sg.big_cnt = big, sg.big_list = big + 1;
     hipLaunchKernelGGL(ds_scan_kernel, dim3((unsigned)(V * (DS_BINS / WAVE))), dim3(DS_SCAN_NW * WAVE), 0, stream, nchunk, hist,
-                       offs, dbase, two_sizes ? big : ct.chunk_total, two_sizes ? 1 : V * ct.nchunk);
+                       offs, dbase, two_sizes ? big : ct.chunk_total, two_sizes ? 1 : V * ct.nchunk, bins_used);
     if (ordered)
       hipLaunchKernelGGL((ds_scatter_kernel<true, false, true, true>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field,
                          (const uint64_t*)nullptr, 0, id_bits, dmask, offs, dbase, keys_a, rect_raw, rect_out, ids_out, nvalid_out,
@@ -645,7 +650,7 @@ int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* 
       hipLaunchKernelGGL((ds_scatter_kernel<true, false, false, true>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field,
                          (const uint64_t*)nullptr, 0, id_bits, dmask, offs, dbase, keys_a, rect_raw, rect_out, ids_out, nvalid_out,
                          range, sg);
-    const dim3 bgrid(DS_BINS, (unsigned)V);
+    const dim3 bgrid((unsigned)bins_used, (unsigned)V);
     const int split = two_sizes ? SMALL_CAP : 0;
     const dim3 biggrid = two_sizes ? dim3(std::min<unsigned>(1024u, (unsigned)V * DS_BINS), 1) : bgrid;
     if (two_sizes) {
@@ -684,7 +689,7 @@ int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* 
       hipLaunchKernelGGL((ds_count_kernel<false, false>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field, kin,
                          word_shift, dmask, hist, (const int2*)nullptr, 0, (uint32_t*)nullptr, sg);
     hipLaunchKernelGGL(ds_scan_kernel, dim3((unsigned)(V * (DS_BINS / WAVE))), dim3(DS_SCAN_NW * WAVE), 0, stream, nchunk, hist,
-                       offs, dbase, (int32_t*)nullptr, 0);
+                       offs, dbase, (int32_t*)nullptr, 0, DS_BINS);
 #define GR_DS_SCATTER(F, L, O)                                                                                            \
   hipLaunchKernelGGL((ds_scatter_kernel<F, L, O>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field, kin, \
                      word_shift, id_bits, dmask, offs, dbase, kout, rect_raw, rect_out, ids_out, first ? nvalid_out : nullptr, \

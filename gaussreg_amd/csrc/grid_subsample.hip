@@ -438,7 +438,9 @@ static int grid_subsample_impl(const float* points, const int64_t* h_lengths, in
   // small batches: the two read-backs (bounding boxes, cell counts) come through the mailbox page -- the kernels post
   // them, the host polls: no copy in the stream, no stream synchronise (words [0, 6 B] boxes + stamp, [512, 512 + B + 1]
   // counts + stamp)
-  volatile int32_t* mail = batch <= 80 ? mailbox() : nullptr;
+  // (the boxes of up to 80 clouds fit their half of the page; the counts of up to 256 -- cloud_counts_kernel posts from a
+  // single workgroup -- fit theirs: a 64-pair pyramid level, 128 clouds, waits for its counts without a copy + synchronise)
+  volatile int32_t* mail = batch <= 256 ? mailbox() : nullptr;
   const int stamp = mail ? mailbox_next_stamp() : 0;
   CloudGrid* hg = reinterpret_cast<CloudGrid*>(pin + o_grids);
   const int32_t* h_mb = reinterpret_cast<const int32_t*>(pin + o_mb);  // (or the mailbox page, below)
@@ -451,7 +453,7 @@ static int grid_subsample_impl(const float* points, const int64_t* h_lengths, in
   GR_HIP(hipMemcpyAsync(w.off, pin, o_tick + sizeof(int32_t), hipMemcpyHostToDevice, stream));
   // (the ticket is one same-address atomic + a fence per workgroup: fine for a few hundred workgroups, 1.4 ms for the
   // 12 500 of a 64 x 200 k call -- those copy and synchronise)
-  const bool bbox_by_mail = mail != nullptr && h_blk[nb] <= 512;
+  const bool bbox_by_mail = mail != nullptr && batch <= 80 && h_blk[nb] <= 512;
   if (bbox_by_mail) mailbox_arm(mail + MAIL_GRID_BOXES + 6 * batch);
   int rc = compute_bbox(points, off, h_blk, w.off, nb, w.bbox, w.blk_off, stream, /*blk_off_on_device=*/true,
                         /*init_bbox=*/false, bbox_by_mail ? w.ticket : nullptr, const_cast<int32_t*>(mail), stamp);
@@ -471,6 +473,8 @@ static int grid_subsample_impl(const float* points, const int64_t* h_lengths, in
   // ---- per-cloud grid, exactly the reference's fp32 expressions (this TU: -ffp-contract=off)
   unsigned long long max_cells = 1;
   bool wrap = false;
+  int max_dig = 3, max_dig_fo = 3;
+  constexpr int64_t MIN_BUCKETS = 8192;  // (64 pairs of 30 000-point clouds: 6 bits 0.247 ms per call, 7: 0.256, 8: 0.272, 9: 0.288)
   const float inv = static_cast<float>(1.0 / static_cast<double>(voxel));  // :11 `(1. / voxel_size)` -> float
   for (int64_t b = 0; b < batch; ++b) {
     CloudGrid g{0.f, 0.f, 0.f, voxel, 1ull, 1ull, 0, 0};
@@ -491,8 +495,20 @@ static int grid_subsample_impl(const float* points, const int64_t* h_lengths, in
       if (cells >= 18446744073709551615.0L || !std::isfinite((double)cells)) wrap = true;
       else {
         if ((unsigned long long)cells > max_cells) max_cells = (unsigned long long)cells;
-        g.sh = std::max(0, bits_for((unsigned long long)cells) - 9);  // fields 1 .. cells: (cells - 1) >> sh < 512
-        g.sh_fo = std::max(0, bits_for((unsigned long long)h_lengths[b]) - 9);
+        // top digit of the bucket sorts: nine bits for a large cloud; a small one takes fewer, so that a bucket still holds a
+        // few hundred points (30 000 points over 512 buckets were 58 per 128-thread workgroup: 65 000 workgroups of fixed
+        // costs per 64-pair level, 77 us of a 0.29 ms call).  What is left of a key has to fit the 18 bits of an LDS item.
+        const int len_bits = bits_for((unsigned long long)h_lengths[b]), cell_bits = bits_for((unsigned long long)cells);
+        // (only where the batch still fills the device with the fewer, larger buckets: two 30 000-point clouds on 2 x 64
+        // buckets measured 0.092 ms against 0.081 on 2 x 512)
+        int dig_small = std::min(std::max(len_bits - 9, 3), 9);
+        while (dig_small < 9 && (batch << dig_small) < MIN_BUCKETS) ++dig_small;
+        const int dig = std::max(dig_small, cell_bits - 18);
+        const int dig_fo = dig_small;
+        g.sh = std::max(0, cell_bits - dig);    // fields 1 .. cells: (cells - 1) >> sh < 2^dig
+        g.sh_fo = std::max(0, len_bits - dig_fo);
+        max_dig = std::max(max_dig, std::min(dig, 9));
+        max_dig_fo = std::max(max_dig_fo, dig_fo);
       }
     }
     hg[b] = g;
@@ -529,7 +545,7 @@ static int grid_subsample_impl(const float* points, const int64_t* h_lengths, in
     hipLaunchKernelGGL(keys32_kernel, grd, blk, 0, stream, points, (int)n, w.off, nb, w.grids, field, payload,
                        order_mode != GR_ORDER_CELL && !fo_by_sort ? w.flags : nullptr, w.ds_range, w.ds_ovf, w.ds_range_fo);
     GR_LAUNCH_CHECK();
-    const DepthSortSegments sg{w.off, w.ds_range, w.keys_fo, key_bits, nullptr, nullptr, nullptr};
+    const DepthSortSegments sg{w.off, w.ds_range, w.keys_fo, key_bits, nullptr, nullptr, nullptr, 1 << max_dig};
     rc = depth_sort_views(field, payload, w.keys_b, w.keys_b, w.vals_b, reinterpret_cast<uint32_t*>(w.scan), w.ds_nvalid, max_len, nb,
                           27, w.ds_table, w.ds_bytes, stream, nullptr, 0, w.ds_ovf, 1, nullptr, &sg);
     if (rc != GR_OK) return rc;
@@ -587,7 +603,7 @@ static int grid_subsample_impl(const float* points, const int64_t* h_lengths, in
     // (no bucket of this sort can overflow: its digit is the top nine bits of a point index, so a bucket holds the cells whose
     // first point lies in a span of <= len / 512 <= 2 048 points)
     uint32_t* fo_field = reinterpret_cast<uint32_t*>(w.first_idx);  // also the (unused, < 2^26) payload
-    const DepthSortSegments sg2{w.cell_off, w.ds_range_fo, w.keys_fo, 0, nullptr, nullptr, w.cell_key};
+    const DepthSortSegments sg2{w.cell_off, w.ds_range_fo, w.keys_fo, 0, nullptr, nullptr, w.cell_key, 1 << max_dig_fo};
     rc = depth_sort_views(fo_field, fo_field, w.keys_b, w.keys_b, w.cell_of_rank, reinterpret_cast<uint32_t*>(w.scan), w.ds_nvalid,
                           max_len, nb, 27, w.ds_table, w.ds_bytes, stream, nullptr, 0, w.ds_ovf, 1, nullptr, &sg2);
     if (rc != GR_OK) return rc;

@@ -138,12 +138,32 @@ __global__ __launch_bounds__(HO_BT) void ho_bucket_slab_kernel(const HoCloud* __
   for (uint32_t i = threadIdx.x; i < width; i += HO_BT) head[s.toff + lo + i] = s_head[i];
 }
 
+// Which (cloud, block of the cloud) a workgroup of a 1-D stage grid takes.  xcd != 0 (many clouds per call): workgroup b runs
+// on XCD b % 8, and all workgroups of a cloud are dealt to ONE XCD -- the chain walks and the final row moves are random
+// accesses inside the cloud's own few hundred KB (tables, clocks, rows), which then stay in that XCD's L2 instead of being
+// spread over eight of them (a cloud's rows written from eight L2s leave as partial sectors).  Grid: 8 * ceil(batch / 8) *
+// nbx workgroups.  xcd == 0: cloud-major, as a 2-D grid would be.
+__device__ __forceinline__ bool ho_block(int nbx, int batch, int xcd, int& bx, int& cloud) {
+  const int id = blockIdx.x;
+  if (xcd) {
+    const int slot = id >> 3, g = slot / nbx;
+    cloud = g * 8 + (id & 7);
+    bx = slot - g * nbx;
+  } else {
+    cloud = id / nbx;
+    bx = id - cloud * nbx;
+  }
+  return cloud < batch;
+}
+
 __global__ __launch_bounds__(HO_T) void ho_group_kernel(const HoCloud* __restrict__ st, const int32_t* __restrict__ T,
                                                         const int32_t* __restrict__ bkt, const int32_t* __restrict__ head,
                                                         const int32_t* __restrict__ nxt, int32_t* __restrict__ G,
-                                                        int2* __restrict__ FW) {
-  const HoCloud s = st[blockIdx.y];
-  const int le = blockIdx.x * HO_T + threadIdx.x;
+                                                        int2* __restrict__ FW, int nbx, int batch, int xcd) {
+  int bx, cloud;
+  if (!ho_block(nbx, batch, xcd, bx, cloud)) return;
+  const HoCloud s = st[cloud];
+  const int le = bx * HO_T + threadIdx.x;
   if (le >= s.m || s.n == 0) return;
   const int e = s.begin + le;
   const int t = T[e];
@@ -220,12 +240,14 @@ template <bool PRESCANNED, bool LAST>
 __global__ __launch_bounds__(HO_T) void ho_rank_kernel(const HoCloud* __restrict__ st, const int32_t* __restrict__ T,
                                                        const int2* __restrict__ FW,
                                                        const int32_t* __restrict__ S, const int32_t* __restrict__ slabs,
-                                                       int32_t* __restrict__ T_out, HoEmit em) {
+                                                       int32_t* __restrict__ T_out, HoEmit em, int nbx, int batch, int xcd) {
   __shared__ int s_above[PRESCANNED ? 1 : HO_TAB];
   __shared__ int s_w[HO_T / WAVE];
-  const HoCloud s = st[blockIdx.y];
-  const int le = blockIdx.x * HO_T + threadIdx.x;
-  if (blockIdx.x * HO_T >= s.m) return;  // workgroup-uniform
+  int bx, cloud;
+  if (!ho_block(nbx, batch, xcd, bx, cloud)) return;
+  const HoCloud s = st[cloud];
+  const int le = bx * HO_T + threadIdx.x;
+  if (bx * HO_T >= s.m) return;  // workgroup-uniform
   const int e = s.begin + le;
   if (s.n == 0) {  // finished cloud: keep its final positions in the buffer the next stage reads
     if (le < s.m) {
@@ -509,14 +531,16 @@ int hash_order_device(const uint64_t* keys, const int64_t* h_begins, int64_t bat
     for (int64_t c = 0; c < batch; ++c) max_m = std::max<int64_t>(max_m, hs[k * batch + c].m);
     const bool last = k + 1 == nstage;
     if (max_m == 0) continue;
-    const dim3 eg((unsigned)((max_m + HO_T - 1) / HO_T), (unsigned)batch);
-    hipLaunchKernelGGL(ho_group_kernel, eg, blk, 0, stream, st, Tin, bkt, head, nxt, G, FW);
+    const int nbx = (int)((max_m + HO_T - 1) / HO_T);
+    const int xcd = batch >= 32 ? 1 : 0;  // (few clouds: a cloud per XCD would leave XCDs idle)
+    const dim3 eg((unsigned)(nbx * (xcd ? (batch + 7) / 8 * 8 : batch)));
+    hipLaunchKernelGGL(ho_group_kernel, eg, blk, 0, stream, st, Tin, bkt, head, nxt, G, FW, nbx, (int)batch, xcd);
     const int64_t nslab = (max_m + HO_SLAB - 1) / HO_SLAB;
     hipLaunchKernelGGL(ho_suffix_kernel, dim3((unsigned)nslab, (unsigned)batch), dim3(HO_SLAB), 0, stream, st, G, head, S);
     const bool pre = nslab > HO_TAB || prescan_always;
     if (pre) hipLaunchKernelGGL(ho_slabscan_kernel, dim3((unsigned)batch), dim3(1024), 0, stream, st, head);
 #define GR_HO_RANK(P, L) \
-  hipLaunchKernelGGL((ho_rank_kernel<P, L>), eg, blk, 0, stream, st, Tin, FW, S, head, Tout, em)
+  hipLaunchKernelGGL((ho_rank_kernel<P, L>), eg, blk, 0, stream, st, Tin, FW, S, head, Tout, em, nbx, (int)batch, xcd)
     if (pre) {
       if (last) GR_HO_RANK(true, true); else GR_HO_RANK(true, false);
     } else {
