@@ -200,6 +200,8 @@ struct DepthSortSegments {
   const uint64_t* gather64;  // non-null: key64_out[position] = gather64[the entry's index in the whole array] instead
   int bins_used = 0;         // > 0: no segment's top digit reaches this value (small segments sorted on fewer than nine bits:
                              // the scan and the bucket launch skip the digits above)
+  int xcd_segments = 0;      // (set by depth_sort_views) > 0: the small-bucket launch is a 1-D grid that deals all buckets of a
+                             // segment to ONE XCD (workgroup b runs on XCD b % 8); the value is the number of segments
 };
 size_t depth_sort_table_bytes(int64_t P, int V);
 int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* keys_a, uint64_t* keys_b, int32_t* ids_out,

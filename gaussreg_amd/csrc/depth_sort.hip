@@ -577,6 +577,14 @@ __global__ __launch_bounds__(BT) void ds_bucket_sort_kernel(int P, int n_lo, int
     }
     return;
   }
+  if (sg.xcd_segments > 0) {
+    // many segments: all buckets of a segment on one XCD -- what a bucket's entries look up by index (gather64: a value per
+    // entry at a random place of the segment's own array) is then fetched by one L2, not by eight
+    const int id = (int)blockIdx.x, slot = id >> 3, bins = sg.bins_used, g = slot / bins;
+    const int v = g * 8 + (id & 7);
+    if (v < sg.xcd_segments) one_bucket(v, slot - g * bins);
+    return;
+  }
   one_bucket((int)blockIdx.y, (int)blockIdx.x);
 }
 
@@ -650,7 +658,12 @@ int depth_sort_views(const uint32_t* field, const uint32_t* rect_raw, uint64_t* 
       hipLaunchKernelGGL((ds_scatter_kernel<true, false, false, true>), grid, blk, 0, stream, (int)P, V, nchunk, nvalid_out, field,
                          (const uint64_t*)nullptr, 0, id_bits, dmask, offs, dbase, keys_a, rect_raw, rect_out, ids_out, nvalid_out,
                          range, sg);
-    const dim3 bgrid((unsigned)bins_used, (unsigned)V);
+    dim3 bgrid((unsigned)bins_used, (unsigned)V);
+    if (two_sizes && V >= 32) {
+      sg.bins_used = bins_used;
+      sg.xcd_segments = V;
+      bgrid = dim3((unsigned)(bins_used * ((V + 7) / 8 * 8)), 1);
+    }
     const int split = two_sizes ? SMALL_CAP : 0;
     const dim3 biggrid = two_sizes ? dim3(std::min<unsigned>(1024u, (unsigned)V * DS_BINS), 1) : bgrid;
     if (two_sizes) {
