@@ -577,7 +577,7 @@ def run_gpu(h, args):
         # expand kernel widens them once the host knows the width; count + fill where that kernel gave up (dense clouds)
         if tq_n:
             s_name, s_ms, s_n = "radius_tq + radius_expand", tq_ms + ex_ms, tq_n
-            s_kernels = ("tq_kernel<32, false>", "tq_expand_kernel")
+            s_kernels = ("tq_kernel<32, false", "tq_expand_kernel")
         else:
             s_name, s_ms, s_n = "radius_fill", fill_ms, fill_n
             s_kernels = ("traverse_kernel<128, false, true>", "traverse_kernel<128, true, true>")
@@ -636,12 +636,12 @@ def run_gpu(h, args):
                 rl["radius_limited_ms_bin"] = lk.get("radius_bin")
             # what bounds the search kernel: VALU issue.  Wave-level VALU instructions per query (committed SQ-counter
             # summary, same configuration) against the ~50 the tests + stores alone need
-            vq = sq_insts("tq_kernel<32, true>", "SQ_INSTS_VALU")
+            vq = sq_insts("tq_kernel<32, true", "SQ_INSTS_VALU")
             if vq and B == 8:
                 per_q = vq / float(nq)
                 radius["roofline_valu_issue"] = {"bound": "valu_issue", "achieved": round(per_q, 1), "floor": 50.0,
                                                  "unit": "wave-level VALU instructions per query (tq_kernel, limit 40)", "frac": round(50.0 / per_q, 4),
-                                                 "valu_busy": sq_valu_busy("tq_kernel<32, true>", True),
+                                                 "valu_busy": sq_valu_busy("tq_kernel<32, true", True),
                                                  "source": "profiles/" + str(newest_profile("_sq_counters.json")) + " (committed, not this run)"}
                 rl["radius_valu_per_query"] = round(per_q, 1)
                 rl["radius_valu_floor_per_query"] = 50.0

@@ -52,9 +52,9 @@ def main():
     tr = doc["traffic_bytes_per_launch"]
     for k in kernels:  # the kernels bench.py prices against the HBM roofline
         hbm = int((2 * k["fetch_size_kb_avg"] + k["write_size_kb_avg"]) * 1024)
-        if k["kernel"].startswith("tq_kernel<32, false>") or k["kernel"].startswith("tq_expand_kernel"):
+        if k["kernel"].startswith("tq_kernel<32, false") or k["kernel"].startswith("tq_expand_kernel"):
             tr["radius_search"] = tr.get("radius_search", 0) + hbm   # the bare search: compact rows + their expansion
-        if k["kernel"].startswith("tq_kernel<32, true>"):
+        if k["kernel"].startswith("tq_kernel<32, true"):
             tr["radius_tq_limited"] = hbm
         if k["kernel"].startswith("blend_kernel"):
             doc["traffic_bytes_per_launch"]["raster_blend"] = hbm
