@@ -40,6 +40,10 @@ def _same(points, lengths, voxel):
     (3, [100] * 40, 0.1),                                         # many small clouds
     (4, [150000, 900], 0.02),                                     # too ragged for the tables?  either way the same rows
     (5, [800000, 0, 800000, 5, 700000], 0.03),                    # > 2 M points: the cells are ranked by a second bucket sort
+    (6, [30000] * 67 + [0, 7], 0.05),                             # a pyramid level of many pairs: six-bit digits, clouds dealt to
+                                                                  # XCDs (69 is no multiple of 8), > 2 M points
+    (7, [4500] * 130 + [60000, 3, 0] + [700] * 140, 0.2),         # 273 clouds (past the mailbox's 256), sizes of three digit widths
+    (8, [25000] * 40, 0.05),                                      # 40 clouds: XCD mapping, counts through the mailbox
 ])
 def test_bucket_sort_rows_equal_the_general_sort(seed, lengths, voxel):
     rng = np.random.default_rng(seed)
@@ -90,3 +94,19 @@ def test_sixty_four_clouds_of_200k_cell_order_full_size():
     g = torch.Generator().manual_seed(0)
     pts = (torch.rand(200000 * 64, 3, generator=g) * 10 ** (1 / 3)).float().numpy()
     _same(pts, [200000] * 64, 0.05)
+
+
+def test_many_clouds_of_mixed_sizes_match_the_oracle():
+    """The digit width of the bucket sorts follows the cloud sizes, the hash-order stages deal clouds to XCDs from 32 clouds
+    on: 45 clouds between 0 and 9 000 points against the reference's own code, both steps of its row order included."""
+    from oracle import capi
+    rng = np.random.default_rng(19)
+    lengths = [int(x) for x in rng.integers(0, 9000, size=45)]
+    lengths[5] = 0
+    lengths[44] = 1
+    pts = (rng.random((sum(lengths), 3)) * np.array([3.0, 2.0, 1.2])).astype(np.float32)
+    want_p, want_l = capi.grid_subsampling(pts, np.array(lengths, np.int64), 0.06)
+    a, al, b, bl = _both(pts, lengths, 0.06, "reference")
+    assert al == list(want_l) and bl == list(want_l)
+    assert np.array_equal(a.view(np.uint32), np.asarray(want_p, np.float32).view(np.uint32))
+    assert np.array_equal(b.view(np.uint32), np.asarray(want_p, np.float32).view(np.uint32))
