@@ -248,3 +248,29 @@ def test_coarsest_level_shape_many_more_hits_than_the_row_keeps(search_mode, lim
         assert info[4] == 1  # finished by the thread-per-query kernel itself
     got = ext.radius_neighbors_limited(ts, ts, tsl, tsl, 1.0, limit)
     assert np.array_equal(got.cpu().numpy(), capi.radius_neighbors(s, s, sl, sl, 1.0)[:, :limit])
+
+
+def test_preselection_with_a_last_bin_of_hundreds_of_equal_distances(search_mode):
+    """240 copies of one support (equal distances, one histogram bin) behind 30 nearer ones, rows of 40: the bin that holds the
+    row's end cannot be cut, the wave's exact path gets 270 keys -- more than its key area -- and the call repeats itself on
+    count + fill.  A second cloud with 100 copies stays inside the key area.  Rows = the oracle's (ties by ascending index)."""
+    from oracle import capi
+    rng = np.random.default_rng(23)
+
+    def cloud(copies):
+        near = (rng.random((30, 3)) * 0.2).astype(np.float32)
+        far = np.tile(np.array([[0.45, 0.1, 0.05]], np.float32), (copies, 1))
+        rest = (rng.random((400, 3)) * 0.9).astype(np.float32)
+        pts = np.concatenate([near, far, rest])
+        return pts[rng.permutation(pts.shape[0])]
+
+    s = np.concatenate([cloud(240), cloud(100) + np.float32(3.0)])
+    sl = np.array([670, 530], np.int64)
+    q = np.concatenate([(rng.random((200, 3)) * 0.1).astype(np.float32), (rng.random((200, 3)) * 0.1).astype(np.float32) + np.float32(3.0)])
+    ql = np.array([200, 200], np.int64)
+    want = capi.radius_neighbors(q, s, ql, sl, 0.6)
+    assert want.shape[1] > 270
+    for limit in (40, 56):
+        info, out = _info(_t(q), _t(s), ql.tolist(), sl.tolist(), 0.6, limit)
+        assert info[0] == want.shape[1]
+        assert np.array_equal(out.cpu().numpy(), want[:, :limit])
