@@ -12,14 +12,16 @@ from .ops import grid_subsample, radius_search
 
 
 def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, neighbor_limits, order="reference",
-                               pipeline=None):
+                               pipeline=None, contiguous_neighbors=True):
     """utils/data.py:13-77: 4 grid_subsample + 13 radius_search calls, same order of results, same parameters.
 
     `pipeline=True`: the subsampling chain runs on a second host thread and a second HIP stream while this thread runs
     the radius searches of the levels that already exist.  That paid while every grid_subsample call ended in a host-side
     replay of libstdc++'s unordered_map iteration order (the GPU idled meanwhile); with the order evaluated on the device
     it is worth 4 % at 64 pairs per call on a quiet host and costs 3x when the two host threads fight for cores, so it is
-    off by default.  Results are identical either way."""
+    off by default.  Results are identical either way.
+    `contiguous_neighbors=False`: index tensors may be column slices of wider rows (the reference's own truncated results
+    are): no dense copy of a level's rows for a caller that does not need one."""
     assert num_stages == len(neighbor_limits)
     on_gpu = points.is_cuda
     if pipeline is None:
@@ -91,14 +93,14 @@ def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, 
         for i in range(num_stages):
             cur_points, cur_lengths = points_list[i], lengths_list[i]
             neighbors_list.append(radius_search(cur_points, cur_points, cur_lengths, cur_lengths, radius,
-                                                neighbor_limits[i], grid=grid_of(i)))
+                                                neighbor_limits[i], grid=grid_of(i), contiguous=contiguous_neighbors))
             if i < num_stages - 1:
                 next_level()
                 sub_points, sub_lengths = points_list[i + 1], lengths_list[i + 1]
                 subsampling_list.append(radius_search(sub_points, cur_points, sub_lengths, cur_lengths, radius,
-                                                      neighbor_limits[i], grid=grid_of(i)))
+                                                      neighbor_limits[i], grid=grid_of(i), contiguous=contiguous_neighbors))
                 upsampling_list.append(radius_search(cur_points, sub_points, cur_lengths, sub_lengths, radius * 2,
-                                                     neighbor_limits[i + 1], grid=grid_of(i + 1)))
+                                                     neighbor_limits[i + 1], grid=grid_of(i + 1), contiguous=contiguous_neighbors))
             radius *= 2
     finally:
         if th is not None:

@@ -113,7 +113,7 @@ def _radius(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, gr
 _WIDTH_HINT = {}  # (radius, neighbor_limit) -> largest neighbour count of the last search of that call site
 
 
-def _radius_limited(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, grid):
+def _radius_limited(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, grid, contiguous=True):
     """radius_search with neighbor_limit > 0: the (nq, limit) rows are allocated before anything is counted and ONE
     kernel searches, ranks and writes them (gr_radius_search); the read-back of max_count only decides whether the
     reference would have returned fewer columns (radius_search.py:25-26 keeps min(max_count, limit))."""
@@ -164,7 +164,9 @@ def _radius_limited(q_points, s_points, q_lengths, s_lengths, radius, neighbor_l
                 _WIDTH_HINT.clear()
         width = min(int(info[0]), limit)
         if width < stride:
-            out = out[:, :width].contiguous()
+            # (contiguous=False: the column slice of the searched rows, row stride `stride` -- what the reference itself returns
+            # when it truncates, radius_search.py:26; saves a copy of the whole result where nobody needs it dense)
+            out = out[:, :width].contiguous() if contiguous else out[:, :width]
     return out if out_device.type == "cuda" else out.to(out_device)
 
 
@@ -173,12 +175,13 @@ def radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius, grid=None
     return _radius(q_points, s_points, q_lengths, s_lengths, radius, None, grid, True)
 
 
-def radius_neighbors_limited(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, grid=None, two_pass=False):
+def radius_neighbors_limited(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, grid=None, two_pass=False,
+                             contiguous=True):
     """radius_neighbors + the column truncation of modules/ops/radius_search.py:25-26 done inside the
     kernel: only min(max_count, neighbor_limit) columns are ever written (contiguous result).  With a positive limit the
     search is ONE pass (gr_radius_search); `two_pass=True` forces the count + fill pair the bare radius_neighbors uses."""
     if neighbor_limit is not None and neighbor_limit > 0 and not two_pass:
-        return _radius_limited(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, grid)
+        return _radius_limited(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, grid, contiguous)
     return _radius(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, grid, False)
 
 

@@ -11,14 +11,16 @@ def grid_subsample(points, lengths, voxel_size, order="reference"):
     return s_points, s_lengths
 
 
-def radius_search(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, grid=None):
+def radius_search(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, grid=None, contiguous=True):
     """Radius search in stack mode -> (N, min(max_count, neighbor_limit)) int64, padded with M.
 
     radius_search.py:7-27.  The reference materialises the full width and returns a NON-contiguous
     column slice (radius_search.py:26); here the truncation happens inside the fill kernel, so only
     the kept columns are ever written and the result is contiguous (what KPConv's index_select
     needs once the CPU->GPU copy that used to re-densify it is gone -- SURVEY.md section 8b).
-    `grid` (optional ext.SupportGrid): reuse the support binning across searches over the same supports and radius."""
+    `grid` (optional ext.SupportGrid): reuse the support binning across searches over the same supports and radius.
+    `contiguous=False`: where the rows were searched wider than the result, return the column slice (as the reference does)
+    instead of a dense copy."""
     for t, n in ((q_points, "q_points"), (s_points, "s_points")):
         ext._check_points(t, n)
         ext._check_float(t, n)
@@ -26,7 +28,8 @@ def radius_search(q_points, s_points, q_lengths, s_lengths, radius, neighbor_lim
     for t, n in ((q_lengths, "q_lengths"), (s_lengths, "s_lengths")):
         ext._check_long(t, n)
         ext._check_contig(t, n)
-    return ext.radius_neighbors_limited(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, grid=grid)
+    return ext.radius_neighbors_limited(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, grid=grid,
+                                        contiguous=contiguous)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -272,8 +272,10 @@ class PairRegistrar:
             lengths = torch.tensor([c.shape[0] for c in sampled], dtype=torch.int64)
             if self.order == "cell":
                 points = spatial_sort(points, lengths, 2 * INIT_VOXEL)
+            # (the index tensors of the searches are consumed by the network only: with stand-in descriptors nobody needs the
+            # level-0 rows -- limit 89, ~23 columns found, searched at 32 -- as a dense copy)
             pyr = precompute_data_stack_mode(points, lengths, NUM_STAGES, INIT_VOXEL, INIT_RADIUS, NEIGHBOR_LIMITS,
-                                             order=self.order)
+                                             order=self.order, contiguous_neighbors=self.features == "model")
             len_c, len_f = pyr["lengths"][-1].tolist(), pyr["lengths"][1].tolist()
         off_c = [0]
         off_f = [0]

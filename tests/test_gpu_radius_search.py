@@ -274,3 +274,24 @@ def test_preselection_with_a_last_bin_of_hundreds_of_equal_distances(search_mode
         info, out = _info(_t(q), _t(s), ql.tolist(), sl.tolist(), 0.6, limit)
         assert info[0] == want.shape[1]
         assert np.array_equal(out.cpu().numpy(), want[:, :limit])
+
+
+def test_column_slice_on_request_instead_of_a_dense_copy():
+    """contiguous=False hands back the column slice of the searched rows where the result is narrower than the rows the
+    kernel wrote (the reference's own truncated result is such a slice, radius_search.py:26): same values and shape, no copy;
+    the default stays dense."""
+    from gaussreg_amd import ext, ops
+    from oracle import capi
+    rng = np.random.default_rng(29)
+    s = rng.random((4000, 3)).astype(np.float32)
+    lens = np.array([4000], np.int64)
+    want = capi.radius_neighbors(s, s, lens, lens, 0.07)
+    assert want.shape[1] < 60
+    ts, tl = _t(s), torch.from_numpy(lens)
+    ext._WIDTH_HINT.pop((0.07, 89), None)
+    for call in range(2):  # (first call: rows of the full limit; second: rows of the remembered width + margin)
+        dense = ops.radius_search(ts, ts, tl, tl, 0.07, 89)
+        sliced = ops.radius_search(ts, ts, tl, tl, 0.07, 89, contiguous=False)
+        assert dense.is_contiguous() and dense.shape == want.shape and np.array_equal(dense.cpu().numpy(), want)
+        assert sliced.shape == want.shape and not sliced.is_contiguous() and sliced.stride(1) == 1
+        assert torch.equal(sliced, dense)
