@@ -22,6 +22,7 @@ constexpr int RS_MAXN = 8;
 constexpr int RS_LPH = 16;    // lanes per hypothesis in the scoring kernel
 constexpr int RS_ST = 256;    // scoring kernel threads (16 hypotheses per workgroup)
 constexpr int RS_CHUNK = 1024;  // correspondences staged per round
+constexpr int64_t RS_WIDE_MIN = 256 * 256 * 2;  // hypotheses per call from which one thread each fills the device
 
 __host__ __device__ inline uint32_t rs_hash(uint32_t seed, uint32_t h, uint32_t k, uint32_t attempt) {
   uint32_t x = seed ^ (h * 0x9E3779B9u) ^ (k * 0x85EBCA6Bu) ^ (attempt * 0xC2B2AE35u);
@@ -201,6 +202,92 @@ __global__ __launch_bounds__(RS_ST) void ransac_score_kernel(const float* __rest
   }
 }
 
+// The same scores, bit for bit, for calls with enough hypotheses to fill the device with one THREAD per hypothesis (the
+// stack-mode call: 64 pairs x 10 000): the transform stays in registers, every lane of a wave reads the SAME correspondence --
+// LDS broadcasts of coordinate planes, two correspondences per 8-byte read and per packed fp32 instruction -- instead of sixteen
+// lanes of a hypothesis walking sixteen different LDS rows (six 4-byte reads per 18 arithmetic instructions: the LDS pipe
+// was the bound, 3.6 ms per 64-pair batch).  The order of the error sums is the sixteen-lane kernel's: sixteen partial
+// sums over i = r, r + 16, ... in ascending order, then the pairwise tree of its lane butterfly -- ties between hypotheses
+// are broken by these sums, and a batch must pick what the single calls pick.
+typedef float rs_f2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(RS_ST) void ransac_score_wide_kernel(const float* __restrict__ src, const float* __restrict__ ref, int C,
+                                                                 int num_hyp, float thr, const float* __restrict__ transforms,
+                                                                 int32_t* __restrict__ inliers, float* __restrict__ sqerr,
+                                                                 const int32_t* __restrict__ seg_row_off) {
+  __shared__ __attribute__((aligned(16))) float s_c[6][RS_CHUNK];  // planes: src x, y, z, ref x, y, z
+  static_assert(RS_CHUNK % RS_LPH == 0 && RS_LPH == 16, "a chunk holds whole groups of sixteen: index mod 16 = position mod 16");
+  if (seg_row_off) {
+    const int a = seg_row_off[blockIdx.y];
+    C = seg_row_off[blockIdx.y + 1] - a;
+    src += 3 * (int64_t)a;
+    ref += 3 * (int64_t)a;
+    transforms += (int64_t)blockIdx.y * num_hyp * 12;
+    inliers += (int64_t)blockIdx.y * num_hyp;
+    sqerr += (int64_t)blockIdx.y * num_hyp;
+  }
+  const int h = blockIdx.x * RS_ST + threadIdx.x;
+  const bool ok = h < num_hyp && inliers[h] >= 0;
+  rs_f2 T[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    const float t = ok ? transforms[h * 12 + k] : 0.f;
+    T[k] = rs_f2{t, t};
+  }
+  int cnt = 0;
+  rs_f2 acc[RS_LPH / 2];  // acc[m] = the partial sums of positions 2 m and 2 m + 1 (mod 16)
+#pragma unroll
+  for (int m = 0; m < RS_LPH / 2; ++m) acc[m] = rs_f2{0.f, 0.f};
+  const float thr2 = thr * thr;
+  for (int c0 = 0; c0 < C; c0 += RS_CHUNK) {
+    const int nn = min(RS_CHUNK, C - c0);
+    const int np = (nn + RS_LPH - 1) / RS_LPH * RS_LPH;
+    __syncthreads();
+    for (int e = threadIdx.x; e < nn * 3; e += RS_ST) {
+      const int i = e / 3, a = e - 3 * i;
+      s_c[a][i] = src[3 * (int64_t)c0 + e];
+      s_c[3 + a][i] = ref[3 * (int64_t)c0 + e];
+    }
+    // the tail of the last group: entries that are inliers of nothing (reference at infinity)
+    for (int i = nn + threadIdx.x; i < np; i += RS_ST) {
+      s_c[0][i] = s_c[1][i] = s_c[2][i] = 0.f;
+      s_c[3][i] = s_c[4][i] = s_c[5][i] = INFINITY;
+    }
+    __syncthreads();
+    if (ok) {
+      for (int i0 = 0; i0 < np; i0 += RS_LPH) {
+#pragma unroll
+        for (int m = 0; m < RS_LPH / 2; ++m) {
+          const int i = i0 + 2 * m;
+          const rs_f2 x = *reinterpret_cast<const rs_f2*>(&s_c[0][i]), y = *reinterpret_cast<const rs_f2*>(&s_c[1][i]);
+          const rs_f2 z = *reinterpret_cast<const rs_f2*>(&s_c[2][i]);
+          const rs_f2 rx = *reinterpret_cast<const rs_f2*>(&s_c[3][i]), ry = *reinterpret_cast<const rs_f2*>(&s_c[4][i]);
+          const rs_f2 rz = *reinterpret_cast<const rs_f2*>(&s_c[5][i]);
+          // (the sixteen-lane kernel's expressions, two correspondences per instruction)
+          const rs_f2 dx = rx - __builtin_elementwise_fma(T[0], x, __builtin_elementwise_fma(T[1], y, __builtin_elementwise_fma(T[2], z, T[3])));
+          const rs_f2 dy = ry - __builtin_elementwise_fma(T[4], x, __builtin_elementwise_fma(T[5], y, __builtin_elementwise_fma(T[6], z, T[7])));
+          const rs_f2 dz = rz - __builtin_elementwise_fma(T[8], x, __builtin_elementwise_fma(T[9], y, __builtin_elementwise_fma(T[10], z, T[11])));
+          const rs_f2 d2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
+          const bool in0 = d2.x < thr2, in1 = d2.y < thr2;
+          cnt += (in0 ? 1 : 0) + (in1 ? 1 : 0);
+          acc[m] += rs_f2{in0 ? d2.x : 0.f, in1 ? d2.y : 0.f};  // (+ 0 leaves a sum as it is: same bits as not adding)
+        }
+      }
+    }
+  }
+  if (ok) {
+    // the lane butterfly of the sixteen-lane kernel: partner distance 8, 4, 2, 1
+    float a[RS_LPH];
+#pragma unroll
+    for (int m = 0; m < RS_LPH / 2; ++m) a[2 * m] = acc[m].x, a[2 * m + 1] = acc[m].y;
+#pragma unroll
+    for (int d = RS_LPH / 2; d > 0; d >>= 1)
+#pragma unroll
+      for (int j = 0; j < d; ++j) a[j] = a[j] + a[j + d];
+    inliers[h] = cnt;
+    sqerr[h] = a[0];
+  }
+}
+
 // best hypothesis (most inliers, then lowest squared error, then lowest index) + optional refit on its inliers
 __global__ __launch_bounds__(1024) void ransac_best_kernel(const float* __restrict__ src, const float* __restrict__ ref, int C,
                                                            int num_hyp, const float* __restrict__ transforms,
@@ -340,6 +427,11 @@ extern "C" int gr_ransac_similarity(const float* src_points, const float* ref_po
                      src_points, ref_points, (int)num_corr, ransac_n, (int)num_hypotheses, seed, distance_threshold,
                      with_scaling, transforms, inl, err, (const int32_t*)nullptr);
   constexpr int HPB = RS_ST / RS_LPH;
+  if (num_hypotheses >= RS_WIDE_MIN)
+    hipLaunchKernelGGL(ransac_score_wide_kernel, dim3((unsigned)((num_hypotheses + RS_ST - 1) / RS_ST)), dim3(RS_ST), 0, stream, src_points,
+                       ref_points, (int)num_corr, (int)num_hypotheses, distance_threshold, transforms, inl, err,
+                       (const int32_t*)nullptr);
+  else
   hipLaunchKernelGGL(ransac_score_kernel, dim3((unsigned)((num_hypotheses + HPB - 1) / HPB)), dim3(RS_ST), 0, stream, src_points,
                      ref_points, (int)num_corr, (int)num_hypotheses, distance_threshold, transforms, inl, err,
                      (const int32_t*)nullptr);
@@ -383,6 +475,12 @@ extern "C" int gr_ransac_similarity_seg(const float* src_points, const float* re
                      0, stream, src_points, ref_points, 0, ransac_n, (int)num_hypotheses, seed, distance_threshold,
                      with_scaling, transforms, inl, err, seg_row_off);
   constexpr int HPB = RS_ST / RS_LPH;
+  // enough hypotheses for one thread each to fill the device: the thread-per-hypothesis kernel (same scores, bit for bit)
+  if (nseg * num_hypotheses >= RS_WIDE_MIN)
+    hipLaunchKernelGGL(ransac_score_wide_kernel, dim3((unsigned)((num_hypotheses + RS_ST - 1) / RS_ST), (unsigned)nseg), dim3(RS_ST), 0,
+                       stream, src_points, ref_points, 0, (int)num_hypotheses, distance_threshold, transforms, inl, err,
+                       seg_row_off);
+  else
   hipLaunchKernelGGL(ransac_score_kernel, dim3((unsigned)((num_hypotheses + HPB - 1) / HPB), (unsigned)nseg), dim3(RS_ST), 0,
                      stream, src_points, ref_points, 0, (int)num_hypotheses, distance_threshold, transforms, inl, err,
                      seg_row_off);

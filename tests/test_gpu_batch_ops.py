@@ -136,3 +136,33 @@ def test_transformer_padded_batch_equals_pairs_alone():
             assert float((got_r[b, :rl[b]] - want_r[0]).abs().max()) <= 2e-5 * scale, b
             assert float((got_s[b, :sl[b]] - want_s[0]).abs().max()) <= 2e-5 * scale, b
         assert torch.isfinite(got_r).all() and torch.isfinite(got_s).all()
+
+
+def test_ransac_thread_per_hypothesis_scores_equal_the_sixteen_lane_kernel():
+    """A stack-mode call with >= 131 072 hypotheses scores them one thread each (ransac_score_wide_kernel), a single call with
+    fewer takes sixteen lanes per hypothesis: the two must agree to the bit -- the error sums break the ties between
+    hypotheses of equal inlier count, and with few correspondences (40 - 1 100 here, not multiples of 16, one of them past a
+    1 024-row chunk) nearly every pair is decided by such a tie.  refine=False: the winning hypothesis' own transform."""
+    from gaussreg_amd.registration import registration_with_ransac_batch, registration_with_ransac_from_correspondences
+    rng = np.random.default_rng(41)
+    counts = [40, 57, 333, 1100, 64, 16, 5, 250]
+    H = 20000                                                    # 8 x 20 000 = 160 000 hypotheses in the batch call
+    srcs, refs = [], []
+    for b, c in enumerate(counts):
+        R = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        if np.linalg.det(R) < 0:
+            R[:, 0] = -R[:, 0]
+        src = rng.random((c, 3)) * 2.0
+        ref = 1.3 * src @ R.T + rng.normal(0, 0.5, 3) + rng.normal(0, 0.02, (c, 3))
+        bad = rng.random(c) < 0.4
+        ref[bad] = rng.random((int(bad.sum()), 3)) * 4.0
+        srcs.append(src.astype(np.float32)); refs.append(ref.astype(np.float32))
+    rows = torch.tensor(np.cumsum([0] + counts), dtype=torch.int32).cuda()
+    s, r = _c(np.concatenate(srcs)), _c(np.concatenate(refs))
+    for refine in (False, True):
+        Tb, stb = registration_with_ransac_batch(s, r, rows, None, 0.05, 5, H, refine=refine, seed=3, return_stats=True)
+        for b, c in enumerate(counts):
+            want, wst = registration_with_ransac_from_correspondences(_c(srcs[b]), _c(refs[b]), None, 0.05, 5, H, refine=refine,
+                                                                      seed=3 + b, return_stats=True)
+            assert torch.equal(stb[b], wst), (b, c, stb[b], wst)
+            assert torch.equal(Tb[b], want), (b, c)
