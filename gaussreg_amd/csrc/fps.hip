@@ -820,7 +820,7 @@ __device__ __forceinline__ unsigned hilbert3_code(unsigned x0, unsigned x1, unsi
 
 // key = cloud << 32 | 30-bit Hilbert code of the point inside its cloud's bounding cube (1024 cells per axis)
 __global__ __launch_bounds__(256) void fps_curve_kernel(const float* __restrict__ pts, const int32_t* __restrict__ off, int nb,
-                                                         const uint32_t* __restrict__ bbox, int n,
+                                                         const uint32_t* __restrict__ bbox, int n, int drop,
                                                          unsigned long long* __restrict__ keys) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(256) void fps_curve_kernel(const float* __restrict_
   const unsigned cy = (unsigned)fminf(fmaxf((pts[3 * (int64_t)i + 1] - mny) * sc, 0.f), 1023.f);
   const unsigned cz = (unsigned)fminf(fmaxf((pts[3 * (int64_t)i + 2] - mnz) * sc, 0.f), 1023.f);
   const unsigned code = hilbert3_code(cx, cy, cz);
-  keys[i] = ((unsigned long long)(unsigned)b << 32) | code;
+  keys[i] = (((unsigned long long)(unsigned)b << 32) | code) >> drop;  // (a prefix of a Hilbert code is the coarser curve)
 }
 
 // sorted position j holds global point vals[j]: copy its coordinates, keep its cloud-local index
@@ -944,11 +944,15 @@ extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64
       int rc = compute_bbox(points, off.data(), h_blk.data(), d_off, (int)batch, mbbox, mblk, stream);
       if (rc != GR_OK) return rc;
       const unsigned nblk = (unsigned)((n + 255) / 256);
-      hipLaunchKernelGGL(fps_curve_kernel, dim3(nblk), dim3(256), 0, stream, points, d_off, (int)batch, mbbox, (int)n,
+      // The order only serves the pruning (results do not depend on it), and a wave's run is ~1 300 consecutive points: the top
+      // 18 bits of the code (64 cells per axis) order the runs as well as all 30 do, and the sort below is three radix passes
+      // instead of five (24 clouds: sort 275 -> 189 us, sampling kernel 4 805 -> 4 827 us).
+      constexpr int drop = 12;
+      hipLaunchKernelGGL(fps_curve_kernel, dim3(nblk), dim3(256), 0, stream, points, d_off, (int)batch, mbbox, (int)n, drop,
                          reinterpret_cast<unsigned long long*>(mkeys_a));
       int cloud_bits = 1;
       while ((1ll << cloud_bits) < batch) ++cloud_bits;
-      rc = sort_pairs_u64_iota(sort_tmp, sort_bytes, mkeys_a, mkeys_b, (int64_t)1 << 40, mvals, n, 0, 32 + cloud_bits, stream);
+      rc = sort_pairs_u64_iota(sort_tmp, sort_bytes, mkeys_a, mkeys_b, (int64_t)1 << 40, mvals, n, 0, 32 + cloud_bits - drop, stream);
       if (rc != GR_OK) return rc;
       hipLaunchKernelGGL(fps_gather_kernel, dim3(nblk), dim3(256), 0, stream, points, d_off, (int)batch, mvals, (int)n, spts, mperm);
       GR_LAUNCH_CHECK();
