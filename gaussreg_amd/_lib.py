@@ -91,6 +91,7 @@ SIGNATURES.update({
     "gr_pairwise_distance_workspace_bytes": (c_size, [c_i64, c_i64]),
     "gr_pairwise_distance": (c_int, [c_void, c_void, c_i64, c_i64, c_i64, c_int, c_void, c_void, c_size, c_void]),
     "gr_fps_debug_force_fallback": (c_int, [c_int]),
+    "gr_fps_debug_bucket_sort": (c_int, [c_int]),
     "gr_hash_order_debug_force_prescan": (c_int, [c_int]),
     "gr_grid_subsample_debug_bucket_sort": (c_int, [c_int]),
     "gr_standin_descriptors": (c_int, [c_void, c_i64, c_void, c_void, c_void, c_void, c_void, c_i64, c_f32, c_int, c_void, c_void]),

@@ -821,7 +821,7 @@ __device__ __forceinline__ unsigned hilbert3_code(unsigned x0, unsigned x1, unsi
 // key = cloud << 32 | 30-bit Hilbert code of the point inside its cloud's bounding cube (1024 cells per axis)
 __global__ __launch_bounds__(256) void fps_curve_kernel(const float* __restrict__ pts, const int32_t* __restrict__ off, int nb,
                                                          const uint32_t* __restrict__ bbox, int n, int drop,
-                                                         unsigned long long* __restrict__ keys) {
+                                                         unsigned long long* __restrict__ keys, uint32_t* __restrict__ field) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int b = find_batch(off, nb, i);
@@ -832,7 +832,9 @@ __global__ __launch_bounds__(256) void fps_curve_kernel(const float* __restrict_
   const unsigned cy = (unsigned)fminf(fmaxf((pts[3 * (int64_t)i + 1] - mny) * sc, 0.f), 1023.f);
   const unsigned cz = (unsigned)fminf(fmaxf((pts[3 * (int64_t)i + 2] - mnz) * sc, 0.f), 1023.f);
   const unsigned code = hilbert3_code(cx, cy, cz);
-  keys[i] = (((unsigned long long)(unsigned)b << 32) | code) >> drop;  // (a prefix of a Hilbert code is the coarser curve)
+  // (a prefix of a Hilbert code is the coarser curve)
+  if (field) field[i] = (code >> drop) + 1u;  // the bucket sort's field (0 = "absent" there); the cloud is the segment
+  else keys[i] = (((unsigned long long)(unsigned)b << 32) | code) >> drop;
 }
 
 // sorted position j holds global point vals[j]: copy its coordinates, keep its cloud-local index
@@ -858,9 +860,37 @@ void g_fps_force_set(int m) { g_fps_force.store(m); }
 
 using namespace gr;
 
+namespace gr {
+namespace {
+// Test switch (gr_fps_debug_bucket_sort): 0 = the curve pre-pass always takes the radix sort
+std::atomic<int> g_fps_bucket_sort{1};
+// the bucket sort of the curve pre-pass (depth_sort.hip, ragged segments = clouds): tables for up to this many (cloud, 2048-point
+// chunk of the LONGEST cloud) rows -- a batch more ragged than that takes the radix sort
+inline int64_t fps_ds_rows(int64_t n, int64_t batch) { return 2 * ((n + 2047) / 2048) + 2 * batch; }
+inline size_t fps_ds_bytes(int64_t n, int64_t batch) {
+  const size_t rows = (size_t)fps_ds_rows(n, batch);
+  return align_up(rows * 512 * sizeof(uint16_t), 256) + align_up(rows * 512 * sizeof(uint32_t), 256) +
+         align_up((size_t)batch * 512 * sizeof(int32_t), 256) + align_up((size_t)batch * 2 * sizeof(uint32_t), 256) +
+         align_up(((size_t)batch * 512 + 1) * sizeof(int32_t), 256) + 512;
+}
+inline int fps_bits_for(unsigned long long v) {  // bits needed to represent values in [0, v)
+  int b = 0;
+  while (b < 64 && (1ull << b) < v) ++b;
+  return b;
+}
+}  // namespace
+}  // namespace gr
+
+extern "C" int gr_fps_debug_bucket_sort(int on) {
+  const int old = gr::g_fps_bucket_sort.load();
+  if (on == 0 || on == 1) gr::g_fps_bucket_sort.store(on);
+  return old;
+}
+
 extern "C" size_t gr_fps_workspace_bytes(int64_t n, int64_t batch) {
   if (n < 0 || batch < 0) return 0;
-  return align_up((size_t)n * 4, 256) + 3 * align_up((size_t)(batch + 1) * 4, 256) +
+  return align_up(gr::fps_ds_bytes(n, batch), 256) + align_up((size_t)batch * 2 * 4, 256) + 2 * align_up((size_t)(batch + 1) * 4, 256) +
+         align_up((size_t)n * 4, 256) + 3 * align_up((size_t)(batch + 1) * 4, 256) +
          align_up((size_t)batch * 2 * FPS_GMAX * sizeof(FpsCand), 256) + align_up((size_t)(batch + 1) * 4, 256) +
          align_up((size_t)batch * 2 * FPS_GMAX * FPS_SLOT_STRIDE * 8, 256) +
          // curve pre-pass: keys in/out, values out, sorted points, permutation, bounding boxes, sort scratch
@@ -918,6 +948,11 @@ extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64
   int32_t* mblk = c.take<int32_t>(batch + 1);
   const size_t sort_bytes = sort_pairs_temp_bytes(n);
   void* sort_tmp = c.take<char>(sort_bytes);
+  const size_t ds_bytes = fps_ds_bytes(n, batch);
+  void* ds_table = c.take<char>(ds_bytes);
+  uint32_t* ds_range = c.take<uint32_t>(2 * batch);
+  int32_t* ds_nvalid = c.take<int32_t>(batch + 1);
+  int32_t* ds_ovf = c.take<int32_t>(batch + 1);  // [0]: a bucket did not fit
   bool curve_done = false;
   GR_HIP(hipMemcpyAsync(d_off, off.data(), sizeof(int32_t) * (batch + 1), hipMemcpyHostToDevice, stream));
   GR_HIP(hipMemcpyAsync(d_soff, soff.data(), sizeof(int32_t) * (batch + 1), hipMemcpyHostToDevice, stream));
@@ -939,24 +974,58 @@ extern "C" int gr_fps(const float* points, const int64_t* h_lengths, const int64
     GR_HIP(hipMemsetAsync(mslots, 0, sizeof(unsigned long long) * (size_t)batch * 2 * FPS_GMAX * FPS_SLOT_STRIDE, stream));
     bool launched = true;
     if (per <= 20 && !curve_done) {
-      // curve order for the bucket pruning: boxes, keys, one radix sort over (cloud, code), gather
+      // curve order for the bucket pruning: boxes, codes, a sort over (cloud, code), gather
       std::vector<int32_t> h_blk(batch + 1);
       int rc = compute_bbox(points, off.data(), h_blk.data(), d_off, (int)batch, mbbox, mblk, stream);
       if (rc != GR_OK) return rc;
       const unsigned nblk = (unsigned)((n + 255) / 256);
       // The order only serves the pruning (results do not depend on it), and a wave's run is ~1 300 consecutive points: the top
-      // 18 bits of the code (64 cells per axis) order the runs as well as all 30 do, and the sort below is three radix passes
-      // instead of five (24 clouds: sort 275 -> 189 us, sampling kernel 4 805 -> 4 827 us).
-      constexpr int drop = 12;
-      hipLaunchKernelGGL(fps_curve_kernel, dim3(nblk), dim3(256), 0, stream, points, d_off, (int)batch, mbbox, (int)n, drop,
-                         reinterpret_cast<unsigned long long*>(mkeys_a));
-      int cloud_bits = 1;
-      while ((1ll << cloud_bits) < batch) ++cloud_bits;
-      rc = sort_pairs_u64_iota(sort_tmp, sort_bytes, mkeys_a, mkeys_b, (int64_t)1 << 40, mvals, n, 0, 32 + cloud_bits - drop, stream);
-      if (rc != GR_OK) return rc;
-      hipLaunchKernelGGL(fps_gather_kernel, dim3(nblk), dim3(256), 0, stream, points, d_off, (int)batch, mvals, (int)n, spts, mperm);
+      // 18 bits of the code (64 cells per axis) order the runs as well as all 30 do.
+      constexpr int drop = 12, code_bits = 30 - drop;
+      // Sort of (cloud, code, index).  Bucket sort (depth_sort.hip, the one grid_subsample uses: one pass over the top bits of
+      // the code, every bucket finished in LDS -- 24 x 200 k points: 60 us) where the batch is not too ragged for its tables;
+      // a cloud crowded into a few cells overflows a bucket and the call repeats the order with three radix passes (189 us).
+      bool sorted = false;
+      if (g_fps_bucket_sort.load() && nmax <= (1ll << 20) && batch * ((nmax + 2047) / 2048) <= fps_ds_rows(n, batch) &&
+          depth_sort_table_bytes(nmax, (int)batch) <= ds_bytes) {
+        std::vector<uint32_t> h_range(2 * batch);
+        int max_dig = 3;
+        for (int64_t b2 = 0; b2 < batch; ++b2) {
+          // fewer top bits for small clouds (a bucket should hold a few hundred points), as long as the batch fills the device
+          int dig = std::min(std::max(fps_bits_for((unsigned long long)h_lengths[b2]) - 9, 3), 9);
+          while (dig < 9 && (batch << dig) < 8192) ++dig;
+          h_range[2 * b2] = 1u;
+          h_range[2 * b2 + 1] = (uint32_t)(code_bits - dig);
+          max_dig = std::max(max_dig, dig);
+        }
+        GR_HIP(hipMemcpyAsync(ds_range, h_range.data(), sizeof(uint32_t) * 2 * batch, hipMemcpyHostToDevice, stream));
+        GR_HIP(hipMemsetAsync(ds_ovf, 0, sizeof(int32_t), stream));
+        uint32_t* field = reinterpret_cast<uint32_t*>(mkeys_a);  // [n]; the second half of the array: the sort's unused payload output
+        hipLaunchKernelGGL(fps_curve_kernel, dim3(nblk), dim3(256), 0, stream, points, d_off, (int)batch, mbbox, (int)n, drop,
+                           (unsigned long long*)nullptr, field);
+        const DepthSortSegments sg{d_off, ds_range, nullptr, 0, nullptr, nullptr, nullptr, 1 << max_dig};
+        rc = depth_sort_views(field, field, mkeys_b, mkeys_b, mvals, field + n, ds_nvalid, nmax, (int)batch, code_bits + 1, ds_table,
+                              ds_bytes, stream, nullptr, 0, ds_ovf, 1, nullptr, &sg);
+        if (rc != GR_OK) return rc;
+        // (the gather is launched behind the sort at once; the overflow flag comes back with the synchronise that follows it)
+        hipLaunchKernelGGL(fps_gather_kernel, dim3(nblk), dim3(256), 0, stream, points, d_off, (int)batch, mvals, (int)n, spts, mperm);
+        int h_ovf = 0;
+        GR_HIP(hipMemcpyAsync(&h_ovf, ds_ovf, sizeof(int), hipMemcpyDeviceToHost, stream));
+        GR_HIP(hipStreamSynchronize(stream));  // (also: h_range and h_blk live on this stack frame)
+        sorted = h_ovf == 0;
+      }
+      if (!sorted) {
+        hipLaunchKernelGGL(fps_curve_kernel, dim3(nblk), dim3(256), 0, stream, points, d_off, (int)batch, mbbox, (int)n, drop,
+                           reinterpret_cast<unsigned long long*>(mkeys_a), (uint32_t*)nullptr);
+        int cloud_bits = 1;
+        while ((1ll << cloud_bits) < batch) ++cloud_bits;
+        rc = sort_pairs_u64_iota(sort_tmp, sort_bytes, mkeys_a, mkeys_b, (int64_t)1 << 40, mvals, n, 0, 32 + cloud_bits - drop, stream);
+        if (rc != GR_OK) return rc;
+        hipLaunchKernelGGL(fps_gather_kernel, dim3(nblk), dim3(256), 0, stream, points, d_off, (int)batch, mvals, (int)n, spts, mperm);
+        GR_LAUNCH_CHECK();
+        GR_HIP(hipStreamSynchronize(stream));  // h_blk lives on this stack frame
+      }
       GR_LAUNCH_CHECK();
-      GR_HIP(hipStreamSynchronize(stream));  // h_blk lives on this stack frame
       curve_done = true;
     }
     {

@@ -475,6 +475,10 @@ int gr_point_to_node_partition_batch(const float* points, const int64_t* h_point
  * inter-workgroup exchange had timed out.  Both force the one-workgroup-per-cloud retry (same indices).  Returns the old mode;
  * a negative argument only queries. */
 int gr_fps_debug_force_fallback(int mode);
+/* Test switch: 0 = the curve pre-pass of gr_fps always takes the radix sort (default 1: the bucket sort of depth_sort.hip where
+ * the batch allows it; a bucket that does not fit repeats the order on the radix sort).  Returns the previous value; the
+ * sample sets do not depend on it. */
+int gr_fps_debug_bucket_sort(int on);
 
 /* ------------------------------------------------------------------------------------------------
  * Harness support, NOT a reference interface: stand-in position descriptors of the configs[4] pair pipeline

@@ -608,3 +608,30 @@ def test_group_norm_unsupported_width_takes_the_torch_path():
         got = m(x, 0.1)
         ref = torch.nn.functional.leaky_relu(m.norm(x.t().unsqueeze(0)).squeeze(0).t(), 0.1)
     assert torch.allclose(got, ref, atol=1e-6)
+
+
+def test_fps_curve_prepass_bucket_sort_and_its_radix_fallback():
+    """The order of the curve pre-pass only serves the pruning: the same sample sets with the bucket sort (default), with the
+    radix sort pinned, and for a cloud crowded into one cell of the curve (a bucket that cannot fit: the call repeats the order
+    on the radix sort).  Against the sequential definition."""
+    from gaussreg_amd import _lib
+    from gaussreg_amd.registration import farthest_point_sampling
+    from oracle import matching_np as M
+    rng = np.random.default_rng(77)
+    a = (rng.random((60000, 3)) * [5, 4, 3]).astype(np.float32)
+    crowd = np.concatenate([(0.5 + rng.random((30000, 3)) * 1e-3), rng.random((2000, 3)) * 4.0]).astype(np.float32)  # one curve cell
+    tiny = rng.random((700, 3)).astype(np.float32)
+    pts, lens, ks = np.concatenate([a, crowd, tiny]), [60000, 32000, 700], [900, 400, 50]
+    L = _lib.lib()
+    got = {}
+    for on in (1, 0):
+        old = L.gr_fps_debug_bucket_sort(on)
+        try:
+            got[on] = [g.cpu().numpy() for g in farthest_point_sampling(_c(pts), lens, ks, start_indices=[3, 0, 9])]
+        finally:
+            L.gr_fps_debug_bucket_sort(old)
+    o = 0
+    for b, (n, k, st) in enumerate(zip(lens, ks, [3, 0, 9])):
+        want = M.farthest_point_sampling(pts[o:o + n], k, st)
+        assert np.array_equal(got[1][b], want) and np.array_equal(got[0][b], want), b
+        o += n
