@@ -200,6 +200,88 @@ __global__ __launch_bounds__(LG_T) void lgr_verify_kernel(const float* __restric
   }
 }
 
+// The same counts in stack mode, one THREAD per hypothesis: a workgroup takes one slice of one scene pair's correspondences
+// (staged in LDS as coordinate planes, read as broadcasts, two per packed fp32 instruction) and runs all the pair's patch
+// hypotheses over it -- 256 at a time, transforms in registers -- instead of one workgroup per hypothesis streaming all of
+// the pair's correspondences from L2 (64 pairs x 256 hypotheses x 12 000 correspondences: 16 384 workgroups x 288 KB =
+// 4.7 GB of L2 reads, 0.52 ms).  Same arithmetic as inlier() above; `sqrtf(d2) < radius` is evaluated as `d2 < x0` with x0 the
+// smallest float whose sqrtf reaches the radius (found once per workgroup with the same sqrtf: it is monotone).
+// inliers[] must be zero on entry; the slices add their counts (integers: any order), slice 0 marks the invalid patches.
+constexpr int LGV_CHUNK = 1024, LGV_SLICES = 16;
+typedef float lg_f2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(LG_T) void lgr_verify_wide_kernel(const float* __restrict__ src, const float* __restrict__ ref,
+                                                               const float* __restrict__ transforms,
+                                                               const int32_t* __restrict__ valid, float radius,
+                                                               int32_t* __restrict__ inliers,
+                                                               const int32_t* __restrict__ seg_patch_off,
+                                                               const int32_t* __restrict__ row_off) {
+  __shared__ __attribute__((aligned(16))) float s_c[6][LGV_CHUNK];  // planes: src x, y, z, ref x, y, z
+  __shared__ float s_x0;
+  const int pa = seg_patch_off[blockIdx.y], pe = seg_patch_off[blockIdx.y + 1];
+  const int a = row_off[pa], C = row_off[pe] - a;
+  src += 3 * (int64_t)a;
+  ref += 3 * (int64_t)a;
+  // this workgroup's slice of the pair's correspondences: whole pairs of rows
+  const int per = ((C + LGV_SLICES - 1) / LGV_SLICES + 1) & ~1;
+  const int c_lo = min((int)blockIdx.x * per, C), c_hi = min(c_lo + per, C);
+  if (threadIdx.x == 0) {
+    unsigned lo = 0u, hi = 0x7f800000u;  // smallest bit pattern b in [lo, hi] with sqrtf(float(b)) >= radius (hi: sqrtf(inf) = inf)
+    if (!(radius == radius)) lo = hi = 0u;  // NaN radius: nothing is an inlier (d2 < 0 never holds)
+    else if (!(sqrtf(__uint_as_float(hi)) >= radius)) lo = hi;
+    while (lo < hi) {
+      const unsigned mid = lo + (hi - lo) / 2u;
+      if (sqrtf(__uint_as_float(mid)) >= radius) hi = mid;
+      else lo = mid + 1u;
+    }
+    s_x0 = __uint_as_float(lo);
+  }
+  if (blockIdx.x == 0)
+    for (int p = pa + (int)threadIdx.x; p < pe; p += LG_T)
+      if (!valid[p]) inliers[p] = -1;
+  __syncthreads();
+  const float x0 = s_x0;
+  for (int pb = pa; pb < pe; pb += LG_T) {
+    const int p = pb + (int)threadIdx.x;
+    const bool ok = p < pe && valid[p] != 0;
+    lg_f2 T[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const float t = ok ? transforms[(int64_t)p * 12 + k] : 0.f;
+      T[k] = lg_f2{t, t};
+    }
+    int cnt = 0;
+    for (int c0 = c_lo; c0 < c_hi; c0 += LGV_CHUNK) {
+      const int nn = min(LGV_CHUNK, c_hi - c0), np = (nn + 1) & ~1;
+      __syncthreads();
+      for (int e = threadIdx.x; e < nn * 3; e += LG_T) {
+        const int i = e / 3, q = e - 3 * i;
+        s_c[q][i] = src[3 * (int64_t)c0 + e];
+        s_c[3 + q][i] = ref[3 * (int64_t)c0 + e];
+      }
+      if (threadIdx.x == 0 && np > nn) {  // the odd row's partner: an inlier of nothing
+        s_c[0][nn] = s_c[1][nn] = s_c[2][nn] = 0.f;
+        s_c[3][nn] = s_c[4][nn] = s_c[5][nn] = INFINITY;
+      }
+      __syncthreads();
+      if (ok) {
+#pragma unroll 4
+        for (int i = 0; i < np; i += 2) {
+          const lg_f2 sx = *reinterpret_cast<const lg_f2*>(&s_c[0][i]), sy = *reinterpret_cast<const lg_f2*>(&s_c[1][i]);
+          const lg_f2 sz = *reinterpret_cast<const lg_f2*>(&s_c[2][i]);
+          const lg_f2 ax = (sx * T[0] + sy * T[1] + sz * T[2]) + T[9];
+          const lg_f2 ay = (sx * T[3] + sy * T[4] + sz * T[5]) + T[10];
+          const lg_f2 az = (sx * T[6] + sy * T[7] + sz * T[8]) + T[11];
+          const lg_f2 dx = *reinterpret_cast<const lg_f2*>(&s_c[3][i]) - ax, dy = *reinterpret_cast<const lg_f2*>(&s_c[4][i]) - ay;
+          const lg_f2 dz = *reinterpret_cast<const lg_f2*>(&s_c[5][i]) - az;
+          const lg_f2 d2 = (dx * dx + dy * dy) + dz * dz;
+          cnt += (d2.x < x0 ? 1 : 0) + (d2.y < x0 ? 1 : 0);
+        }
+      }
+    }
+    if (ok && cnt) atomicAdd(&inliers[p], cnt);
+  }
+}
+
 // best hypothesis + global refinement (local_global_registration.py:171-192): one workgroup, so a wide one (the two passes
 // of every refinement step stream all correspondences)
 constexpr int LG_RT = 1024;
@@ -373,6 +455,12 @@ extern "C" int gr_lgr_register_seg(const float* ref_corr_points, const float* sr
   if (batch > 0) {
     hipLaunchKernelGGL(lgr_local_kernel, dim3((unsigned)batch), dim3(LG_T), 0, stream, src_corr_points, ref_corr_points,
                        corr_scores, counts, offsets, correspondence_threshold, transforms, valid);
+    // many hypotheses in the call: one thread each over slices of the correspondences (same counts)
+    if (batch >= 2048) {
+      GR_HIP(hipMemsetAsync(inl, 0, sizeof(int32_t) * batch, stream));
+      hipLaunchKernelGGL(lgr_verify_wide_kernel, dim3(LGV_SLICES, (unsigned)nseg), dim3(LG_T), 0, stream, src_corr_points,
+                         ref_corr_points, transforms, valid, acceptance_radius, inl, seg_patch_off, offsets);
+    } else
     hipLaunchKernelGGL(lgr_verify_kernel, dim3((unsigned)batch), dim3(LG_T), 0, stream, src_corr_points, ref_corr_points,
                        0, transforms, valid, acceptance_radius, inl, seg_patch_off, (int)nseg, offsets);
   }

@@ -166,3 +166,28 @@ def test_ransac_thread_per_hypothesis_scores_equal_the_sixteen_lane_kernel():
                                                                       seed=3 + b, return_stats=True)
             assert torch.equal(stb[b], wst), (b, c, stb[b], wst)
             assert torch.equal(Tb[b], want), (b, c)
+
+
+def test_lgr_stack_mode_with_thousands_of_patches_equals_single_calls():
+    """>= 2 048 patches in one stack-mode call: the hypotheses are verified one thread each over slices of the pair's
+    correspondences (lgr_verify_wide_kernel: `d2 < x0` instead of `sqrtf(d2) < radius`, integer adds across the slices);
+    single calls take the workgroup-per-hypothesis kernel.  Same correspondences, same estimates, bit for bit."""
+    from gaussreg_amd.matching import LocalGlobalRegistration
+    rng = np.random.default_rng(53)
+    K = 128
+    per_pair = [256, 256, 200, 256, 256, 1, 256, 256, 256, 256, 77]
+    shifts = [0.4, -0.7, 1.1, 0.2, -0.3, 0.1, 0.9, -1.2, 0.6, -0.5, 0.3]
+    parts = [_patches(rng, n, K, sft, bad=(0,) if n == 1 else ()) for n, sft in zip(per_pair, shifts)]
+    ref, src, rm, sm, ls = (np.concatenate([p[i] for p in parts]) for i in range(5))
+    assert ref.shape[0] >= 2048
+    lgr = LocalGlobalRegistration(3, 0.1)
+    rc, sc, cs, T, rows = lgr.forward_batch(_c(ref), _c(src), _c(rm), _c(sm), _c(ls), None, per_pair)
+    rows_h = rows.cpu().numpy()
+    poff = np.cumsum([0] + per_pair)
+    for b in range(len(per_pair)):
+        a, e = poff[b], poff[b + 1]
+        w = lgr(_c(ref[a:e]), _c(src[a:e]), _c(rm[a:e]), _c(sm[a:e]), _c(ls[a:e]), None)
+        r0, r1 = rows_h[b], rows_h[b + 1]
+        assert r1 - r0 == w[0].shape[0], f"pair {b}"
+        assert torch.equal(rc[r0:r1], w[0]) and torch.equal(sc[r0:r1], w[1]) and torch.equal(cs[r0:r1], w[2]), f"pair {b}"
+        assert torch.equal(T[b], w[3]), f"pair {b}: transform\n{T[b]}\n{w[3]}"
