@@ -19,8 +19,11 @@
 //   * a query with more than NET hits, or with an equal pair of distance fields, is finished by the whole wave: lanes =
 //     its candidates, hits compacted by ballot into (distance bits << 32 | index) words, ranked by counting;
 //   * rows: transposed through LDS in blocks of 16 columns and written as 128-byte pieces.  DIRECT: int64 rows of the
-//     caller's width in the caller's order; otherwise compact u32 rows in cell order, which tq_expand_kernel turns into
-//     int64 rows once the host knows the width (the bare radius_neighbors, whose width is the largest count).
+//     caller's width in the caller's order; otherwise compact u32 rows, scattered into the caller's order as whole sectors,
+//     which tq_expand_kernel widens to int64 rows once the host knows the width (the bare radius_neighbors, whose width is the
+//     largest count);
+//   * PRESEL (rows of a known width far below the hit counts): a histogram pre-selection in front of the network, see the
+//     comment at the tests.
 // A workgroup that cannot finish raises its flag (2: a single range beyond 12 bits, 3: more than 40 of its 64 queries beyond
 // the network, 5: a query with more hits than the key scratch) and the caller repeats the call on count + fill.  The number of wave-finished queries is reported: a call in
 // which they are more than an eighth of all queries is complete, but its call site starts on the next kernel next time.
