@@ -143,13 +143,26 @@ RadiusWs carve(void* ws, int64_t nq, int64_t ns, int64_t batch) {
 // Per-cloud bounding boxes without atomics: a block reduces one BBOX_PTS-point slice of ONE cloud into six words of
 // `partial` (same-address global atomics cost ~60 ns each across XCDs: the shared bbox_kernel of common.hip, six atomics
 // per 1024 points, took 32 us of the 8 x 200 k binning); grid_setup_kernel folds the partials.
-__global__ __launch_bounds__(256) void bbox_partial_kernel(const float* __restrict__ pts, const int32_t* __restrict__ off,
-                                                           const int32_t* __restrict__ blk_off, int nb,
+// Offsets of a call with few clouds travel in the kernel arguments of the FIRST launch (q offsets | s offsets | bbox block
+// offsets, nb + 1 entries each): no host -> device copy in front of the binning (a copy-engine operation and the hand-over to
+// the first kernel: ~8 us of a 0.36 ms search); block 0 leaves them in the workspace for the launches behind.
+constexpr int KARG_CLOUDS = 64;
+struct OffsetArgs {
+  int32_t v[3 * (KARG_CLOUDS + 1)];
+};
+
+template <bool KARG>
+__global__ __launch_bounds__(256) void bbox_partial_kernel(const float* __restrict__ pts, const int32_t* __restrict__ off_dev,
+                                                           const int32_t* __restrict__ blk_off_dev, int nb,
                                                            uint32_t* __restrict__ partial, int32_t* __restrict__ zero,
-                                                           int nzero) {
+                                                           int nzero, const OffsetArgs ka, int32_t* __restrict__ q_off_out) {
   __shared__ uint32_t red[6][256 / WAVE];
   // (the super-cell counters of the counting sort are cleared here, by the way: one launch less in front of every search)
   for (int k = blockIdx.x * 256 + threadIdx.x; k < nzero; k += gridDim.x * 256) zero[k] = 0;
+  const int32_t* off = KARG ? ka.v + (nb + 1) : off_dev;           // (the supports' offsets)
+  const int32_t* blk_off = KARG ? ka.v + 2 * (nb + 1) : blk_off_dev;
+  if (KARG && blockIdx.x == 0)
+    for (int k = threadIdx.x; k < 3 * (nb + 1); k += 256) q_off_out[k] = ka.v[k];  // q_off | s_off | blk_off are neighbours
   const int b0 = find_batch(blk_off, nb, (int)blockIdx.x);
   const int p_first = off[b0] + ((int)blockIdx.x - blk_off[b0]) * BBOX_PTS;
   const int p_end = min(off[b0 + 1], p_first + BBOX_PTS);
@@ -1829,7 +1842,9 @@ int radius_prepare(const float* q, const float* s, const int64_t* h_q_lengths, c
       blk[0] = 0;
       for (int64_t b = 0; b < batch; ++b) blk[b + 1] = blk[b] + (int32_t)((h_s_lengths[b] + BBOX_PTS - 1) / BBOX_PTS);
     }
-    GR_HIP(hipMemcpyAsync(w.q_off, tmp, sizeof(int32_t) * (reuse ? 1 : 3) * (batch + 1), hipMemcpyHostToDevice, stream));
+    // (few clouds, full binning: the offsets ride in the first launch's arguments instead -- see OffsetArgs)
+    if (reuse || batch > KARG_CLOUDS)
+      GR_HIP(hipMemcpyAsync(w.q_off, tmp, sizeof(int32_t) * (reuse ? 1 : 3) * (batch + 1), hipMemcpyHostToDevice, stream));
   }
   const int nb = (int)batch;
   int32_t* start_s = w.start;
@@ -1845,8 +1860,16 @@ int radius_prepare(const float* q, const float* s, const int64_t* h_q_lengths, c
     {
       const int nzero = (int)(4 * su);
       const int bbox_blocks = h_offsets[2 * (batch + 1) + batch];
-      hipLaunchKernelGGL(bbox_partial_kernel, dim3(bbox_blocks), dim3(256), 0, stream, s, w.s_off, w.blk_off, nb, w.bbox_partial,
-                         w.sup_zero, nzero);
+      OffsetArgs ka;
+      if (batch <= KARG_CLOUDS) {
+        GR_REQUIRE(w.s_off == w.q_off + (batch + 1) && w.blk_off == w.q_off + 2 * (batch + 1), "radius workspace layout");
+        memcpy(ka.v, h_offsets, sizeof(int32_t) * 3 * (batch + 1));
+        hipLaunchKernelGGL((bbox_partial_kernel<true>), dim3(bbox_blocks), dim3(256), 0, stream, s, w.s_off, w.blk_off, nb,
+                           w.bbox_partial, w.sup_zero, nzero, ka, w.q_off);
+      } else {
+        hipLaunchKernelGGL((bbox_partial_kernel<false>), dim3(bbox_blocks), dim3(256), 0, stream, s, w.s_off, w.blk_off, nb,
+                           w.bbox_partial, w.sup_zero, nzero, ka, w.q_off);
+      }
     }
     // x sub-cells per cell: 2 measured best end to end (count pass 0.166 -> 0.157 ms; 8 gives 0.150 ms but the scan and the
     // scatter over an 8x larger cell table take the difference back)
